@@ -1,0 +1,916 @@
+/*
+ * fpx_oracle.c -- CPU oracle (TEST INFRASTRUCTURE, see fpx_oracle.h).
+ *
+ * Plain-C restatement of the reference CPU search path of acoustid/acoustid-index:
+ *   src/streamvbyte.zig  (StreamVByte 0124 / 1234 codec)
+ *   src/block.zig        (BlockEncoder / BlockReader)
+ *   src/filefmt.zig:94-138 (writeBlocks: block fill + block index + terminator)
+ *   src/FileSegment.zig:83-89,135-180 (search with the 4-block / 1000-doc caps)
+ *   src/MemorySegment.zig:44-54,81-148
+ *   src/common.zig:61-71,121-171 (SearchResults.incr / finish)
+ *   src/Index.zig:133-149,170-177,489-499 (hasNewerCommit, IndexReader.search, dedupSorted)
+ *   src/MultiIndex.zig:302-306 (SearchOptions derivation)
+ * Each function names the lines it follows.  Pinned by tests/test_oracle_kat.py.
+ */
+#include "fpx_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+/* ======================================================================= */
+/* StreamVByte                                                              */
+/* ======================================================================= */
+
+static uint8_t g_len_0124[256], g_len_1234[256];
+static uint8_t g_shuf_0124[256][16] __attribute__((aligned(16)));
+static uint8_t g_shuf_1234[256][16] __attribute__((aligned(16)));
+static int g_tables_ready = 0;
+static int g_simd = 0;
+
+/* src/streamvbyte.zig:100-211 -- shuffle masks (0x80 = emit zero byte) and byte lengths */
+static void init_tables(void)
+{
+    static const uint8_t bytes_0124[4] = {0, 1, 2, 4};
+    static const uint8_t bytes_1234[4] = {1, 2, 3, 4};
+    for (int control = 0; control < 256; control++) {
+        uint8_t off0 = 0, off1 = 0;
+        memset(g_shuf_0124[control], 0x80, 16);
+        memset(g_shuf_1234[control], 0x80, 16);
+        for (int i = 0; i < 4; i++) {
+            int code = (control >> (2 * i)) & 3;
+            for (int b = 0; b < bytes_0124[code]; b++) g_shuf_0124[control][i * 4 + b] = (uint8_t)(off0 + b);
+            off0 += bytes_0124[code];
+            for (int b = 0; b < bytes_1234[code]; b++) g_shuf_1234[control][i * 4 + b] = (uint8_t)(off1 + b);
+            off1 += bytes_1234[code];
+        }
+        g_len_0124[control] = off0;
+        g_len_1234[control] = off1;
+    }
+#if defined(__x86_64__)
+    g_simd = __builtin_cpu_supports("ssse3") ? 1 : 0;
+#endif
+    g_tables_ready = 1;
+}
+
+__attribute__((constructor)) static void orc_ctor(void) { init_tables(); }
+
+void orc_set_simd(int on)
+{
+#if defined(__x86_64__)
+    g_simd = (on && __builtin_cpu_supports("ssse3")) ? 1 : 0;
+#else
+    (void)on; g_simd = 0;
+#endif
+}
+int orc_get_simd(void) { return g_simd; }
+
+uint8_t orc_svb_length(int variant, uint8_t control)
+{
+    return variant == ORC_V1234 ? g_len_1234[control] : g_len_0124[control];
+}
+
+/* scalar form of svbDecodeQuadBase (:216-247): the pshufb table picks, for value i, its
+ * little-endian bytes from the packed stream and zero-fills the rest */
+static inline size_t decode_quad_scalar(int variant, uint8_t control, const uint8_t *in, uint32_t out[4])
+{
+    const uint8_t *p = in;
+    for (int i = 0; i < 4; i++) {
+        int code = (control >> (2 * i)) & 3;
+        uint32_t v = 0;
+        int nb = (variant == ORC_V1234) ? code + 1 : (code == 3 ? 4 : code);
+        for (int b = 0; b < nb; b++) v |= (uint32_t)p[b] << (8 * b);
+        p += nb;
+        out[i] = v + (variant == ORC_V0124_MINUS1 ? 1u : 0u);
+    }
+    return (size_t)(p - in);
+}
+
+#if defined(__x86_64__)
+__attribute__((target("ssse3")))
+static inline size_t decode_quad_ssse3(int variant, uint8_t control, const uint8_t *in, uint32_t out[4])
+{
+    __m128i data = _mm_loadu_si128((const __m128i *)in);
+    const uint8_t *mask = (variant == ORC_V1234) ? g_shuf_1234[control] : g_shuf_0124[control];
+    __m128i r = _mm_shuffle_epi8(data, _mm_load_si128((const __m128i *)mask));
+    if (variant == ORC_V0124_MINUS1) r = _mm_add_epi32(r, _mm_set1_epi32(1));
+    _mm_storeu_si128((__m128i *)out, r);
+    return (variant == ORC_V1234) ? g_len_1234[control] : g_len_0124[control];
+}
+#endif
+
+size_t orc_svb_decode_quad(int variant, uint8_t control, const uint8_t *in, uint32_t out[4])
+{
+#if defined(__x86_64__)
+    if (g_simd) return decode_quad_ssse3(variant, control, in, out);
+#endif
+    return decode_quad_scalar(variant, control, in, out);
+}
+
+/* svbDecodeQuadWithDelta (:264-283): in-quad inclusive prefix sum, then + carry (wrapping u32) */
+size_t orc_svb_decode_quad_delta(int variant, uint8_t control, const uint8_t *in, uint32_t out[4], uint32_t carry)
+{
+    uint32_t v[4];
+    size_t consumed = orc_svb_decode_quad(variant, control, in, v);
+    v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+    out[0] = v[0] + carry; out[1] = v[1] + carry; out[2] = v[2] + carry; out[3] = v[3] + carry;
+    return consumed;
+}
+
+/* svbDeltaDecodeInPlace (:287-339): data[0] += first; data[i] += data[i-1] */
+void orc_svb_delta_decode_in_place(uint32_t *data, size_t n, uint32_t first)
+{
+    if (n == 0) return;
+    data[0] += first;
+    for (size_t i = 1; i < n; i++) data[i] += data[i - 1];
+}
+
+/* decodeValues (:341-412) */
+void orc_svb_decode_values(size_t total_items, size_t start_item, size_t end_item,
+                           const uint8_t *in, uint32_t *out, int variant, int delta, uint32_t first_value)
+{
+    const uint8_t *len = (variant == ORC_V1234) ? g_len_1234 : g_len_0124;
+    size_t start_quad = start_item / 4;
+    size_t end_quad = (end_item + 3) / 4;
+    size_t total_quads = (total_items + 3) / 4;
+
+    size_t data_offset = total_quads;                       /* :361 */
+    for (size_t q = 0; q < start_quad; q++) data_offset += len[in[q]];
+    const uint8_t *ctrl = in + start_quad;
+    const uint8_t *data = in + data_offset;
+    uint32_t *o = out + start_quad * 4;
+    size_t remaining = end_quad - start_quad;
+
+    if (delta) {
+        uint32_t carry = first_value;                       /* :376 */
+        while (remaining > 0) {
+            size_t c = orc_svb_decode_quad_delta(variant, *ctrl, data, o, carry);
+            carry = o[3];
+            ctrl++; data += c; o += 4; remaining--;
+        }
+    } else {
+        while (remaining > 0) {                             /* :392-411 (the 8x unroll is an optimisation) */
+            size_t c = orc_svb_decode_quad(variant, *ctrl, data, o);
+            ctrl++; data += c; o += 4; remaining--;
+        }
+    }
+}
+
+/* svbEncodeValue0124 / svbEncodeQuad0124 (:418-469) */
+size_t orc_svb_encode_quad_0124(const uint32_t in[4], uint8_t *out_data, uint8_t *out_control)
+{
+    uint8_t *p = out_data;
+    uint8_t control = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t v = in[i];
+        if (v == 0) {
+            /* code 0, no bytes */
+        } else if (v < (1u << 8)) {
+            p[0] = (uint8_t)v; p += 1; control |= (uint8_t)(1u << (2 * i));
+        } else if (v < (1u << 16)) {
+            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p += 2; control |= (uint8_t)(2u << (2 * i));
+        } else {
+            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+            p += 4; control |= (uint8_t)(3u << (2 * i));
+        }
+    }
+    *out_control = control;
+    return (size_t)(p - out_data);
+}
+
+/* svbEncodeValue1234 / svbEncodeQuad1234 (:441-480) */
+size_t orc_svb_encode_quad_1234(const uint32_t in[4], uint8_t *out_data, uint8_t *out_control)
+{
+    uint8_t *p = out_data;
+    uint8_t control = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t v = in[i];
+        int code = (v < (1u << 8)) ? 0 : (v < (1u << 16)) ? 1 : (v < (1u << 24)) ? 2 : 3;
+        for (int b = 0; b <= code; b++) p[b] = (uint8_t)(v >> (8 * b));
+        p += code + 1;
+        control |= (uint8_t)(code << (2 * i));
+    }
+    *out_control = control;
+    return (size_t)(p - out_data);
+}
+
+size_t orc_svb_encode_quad_size_0124(const uint32_t in[4])   /* :483-499 */
+{
+    size_t s = 0;
+    for (int i = 0; i < 4; i++) s += in[i] == 0 ? 0 : in[i] < (1u << 8) ? 1 : in[i] < (1u << 16) ? 2 : 4;
+    return s;
+}
+
+size_t orc_svb_encode_quad_size_1234(const uint32_t in[4])   /* :501-516 */
+{
+    size_t s = 0;
+    for (int i = 0; i < 4; i++) s += in[i] < (1u << 8) ? 1 : in[i] < (1u << 16) ? 2 : in[i] < (1u << 24) ? 3 : 4;
+    return s;
+}
+
+/* ======================================================================= */
+/* Block codec                                                              */
+/* ======================================================================= */
+
+static inline uint32_t item_hash(uint64_t it) { return (uint32_t)(it >> 32); }  /* src/segment.zig:87-89 */
+static inline uint32_t item_id(uint64_t it) { return (uint32_t)it; }
+
+void orc_block_header_decode(const uint8_t *d, orc_block_header *h)   /* src/block.zig:46-56 (LE) */
+{
+    h->min_hash = (uint32_t)d[0] | (uint32_t)d[1] << 8 | (uint32_t)d[2] << 16 | (uint32_t)d[3] << 24;
+    h->num_items = (uint16_t)(d[4] | d[5] << 8);
+    h->docids_offset = (uint16_t)(d[6] | d[7] << 8);
+}
+
+static void block_header_encode(const orc_block_header *h, uint8_t *d)
+{
+    d[0] = (uint8_t)h->min_hash; d[1] = (uint8_t)(h->min_hash >> 8);
+    d[2] = (uint8_t)(h->min_hash >> 16); d[3] = (uint8_t)(h->min_hash >> 24);
+    d[4] = (uint8_t)h->num_items; d[5] = (uint8_t)(h->num_items >> 8);
+    d[6] = (uint8_t)h->docids_offset; d[7] = (uint8_t)(h->docids_offset >> 8);
+}
+
+/* BlockEncoder state (src/block.zig:420-436) */
+typedef struct {
+    uint16_t num_items;
+    uint32_t last_hash, last_docid;
+    uint8_t hashes[ORC_MAX_BLOCK_SIZE + 16], hashes_ctrl[ORC_MAX_BLOCK_SIZE + 16];
+    uint8_t docids[ORC_MAX_BLOCK_SIZE + 16], docids_ctrl[ORC_MAX_BLOCK_SIZE + 16];
+    size_t hashes_len, hashes_ctrl_len, docids_len, docids_ctrl_len;
+} block_encoder;
+
+/* encodeChunk (:438-499): returns 0 on success, 1 on BlockFull */
+static int encode_chunk(block_encoder *e, const uint64_t *items, size_t n, uint32_t min_doc_id, size_t block_size)
+{
+    uint32_t ch[4] = {0, 0, 0, 0}, cd[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        uint32_t h = item_hash(items[i]), d = item_id(items[i]);
+        ch[i] = h - e->last_hash;
+        cd[i] = (h != e->last_hash) ? d - min_doc_id : d - e->last_docid;   /* :453-460 */
+        e->last_hash = h;
+        e->last_docid = d;
+    }
+    size_t hs = orc_svb_encode_quad_0124(ch, e->hashes + e->hashes_len, &e->hashes_ctrl[e->hashes_ctrl_len]);
+    size_t ds = orc_svb_encode_quad_1234(cd, e->docids + e->docids_len, &e->docids_ctrl[e->docids_ctrl_len]);
+    size_t new_size = ORC_BLOCK_HEADER_SIZE + e->hashes_len + hs + e->hashes_ctrl_len + 1 +
+                      e->docids_len + ds + e->docids_ctrl_len + 1;              /* :480-482 */
+    if (new_size > block_size) return 1;
+    e->hashes_len += hs; e->hashes_ctrl_len += 1;
+    e->docids_len += ds; e->docids_ctrl_len += 1;
+    e->num_items = (uint16_t)(e->num_items + n);
+    return 0;
+}
+
+/* encodeBlock (:501-567) */
+static size_t encode_block(block_encoder *e, const uint64_t *items, size_t n, uint32_t min_doc_id,
+                           uint8_t *out, size_t block_size)
+{
+    if (n == 0) { memset(out, 0, block_size); return 0; }
+    e->num_items = 0;
+    e->hashes_len = e->hashes_ctrl_len = e->docids_len = e->docids_ctrl_len = 0;
+    e->last_hash = item_hash(items[0]);
+    e->last_docid = min_doc_id;
+
+    const uint64_t *p = items;
+    size_t left = n;
+    while (left >= 4) {
+        if (encode_chunk(e, p, 4, min_doc_id, block_size)) { left = 0; break; }   /* :524-533 */
+        p += 4; left -= 4;
+    }
+    if (left > 0) (void)encode_chunk(e, p, left, min_doc_id, block_size);        /* :536-542 */
+
+    orc_block_header h;
+    h.min_hash = item_hash(items[0]);
+    h.num_items = e->num_items;
+    h.docids_offset = (uint16_t)(e->hashes_len + e->hashes_ctrl_len);
+    block_header_encode(&h, out);
+    size_t w = ORC_BLOCK_HEADER_SIZE;
+    memcpy(out + w, e->hashes_ctrl, e->hashes_ctrl_len); w += e->hashes_ctrl_len;
+    memcpy(out + w, e->hashes, e->hashes_len); w += e->hashes_len;
+    memcpy(out + w, e->docids_ctrl, e->docids_ctrl_len); w += e->docids_ctrl_len;
+    memcpy(out + w, e->docids, e->docids_len); w += e->docids_len;
+    memset(out + w, 0, block_size - w);
+    return e->num_items;
+}
+
+size_t orc_block_encode(const uint64_t *items, size_t n, uint32_t min_doc_id, uint8_t *out, size_t block_size)
+{
+    block_encoder *e = (block_encoder *)malloc(sizeof *e);
+    if (!e) return 0;
+    size_t r = encode_block(e, items, n, min_doc_id, out, block_size);
+    free(e);
+    return r;
+}
+
+/* BlockReader (src/block.zig:66-312).  block_data may be shorter than 16 bytes past the
+ * last value; the reference guarantees 16 readable bytes (FileSegment.loadBlockData :83-89),
+ * here a padded private copy is used when the caller's slice is not long enough. */
+typedef struct {
+    uint32_t min_doc_id;
+    const uint8_t *block;
+    size_t block_len;
+    uint32_t hashes[ORC_MAX_ITEMS_PER_BLOCK + 4];
+    uint32_t docids[ORC_MAX_ITEMS_PER_BLOCK + 4];
+    int hashes_loaded;
+    orc_block_header h;
+} block_reader;
+
+static void reader_load(block_reader *r, const uint8_t *block, size_t len)   /* :104-117 (lazy) */
+{
+    r->block = block; r->block_len = len; r->hashes_loaded = 0;
+    orc_block_header_decode(block, &r->h);
+}
+
+static void reader_ensure_hashes(block_reader *r)   /* :137-158 */
+{
+    if (r->hashes_loaded) return;
+    if (r->h.num_items != 0)
+        orc_svb_decode_values(r->h.num_items, 0, r->h.num_items, r->block + ORC_BLOCK_HEADER_SIZE,
+                              r->hashes, ORC_V0124, 1, r->h.min_hash);
+    r->hashes_loaded = 1;
+}
+
+/* std.sort.equalRange over hashes[0..n) (:217-231) */
+static void reader_find_hash(block_reader *r, uint32_t hash, uint32_t *start, uint32_t *end)
+{
+    if (r->h.num_items == 0) { *start = 0; *end = 0; return; }
+    reader_ensure_hashes(r);
+    uint32_t n = r->h.num_items, lo = 0, hi = n;
+    while (lo < hi) { uint32_t m = lo + (hi - lo) / 2; if (r->hashes[m] < hash) lo = m + 1; else hi = m; }
+    *start = lo;
+    hi = n;
+    while (lo < hi) { uint32_t m = lo + (hi - lo) / 2; if (r->hashes[m] <= hash) lo = m + 1; else hi = m; }
+    *end = lo;
+}
+
+/* getDocidsForRange (:235-265): returns pointer into r->docids, *n = count */
+static const uint32_t *reader_docids_for_range(block_reader *r, uint32_t start, uint32_t end, size_t *n)
+{
+    if (start >= end) { *n = 0; return r->docids; }
+    orc_svb_decode_values(r->h.num_items, start, end,
+                          r->block + ORC_BLOCK_HEADER_SIZE + r->h.docids_offset,
+                          r->docids, ORC_V1234, 0, 0);
+    orc_svb_delta_decode_in_place(r->docids + start, end - start, r->min_doc_id);
+    *n = end - start;
+    return r->docids + start;
+}
+
+/* pad helper for the public single-block entry points */
+static uint8_t *padded_copy(const uint8_t *block, size_t len)
+{
+    uint8_t *c = (uint8_t *)calloc(len + 32, 1);
+    if (c) memcpy(c, block, len);
+    return c;
+}
+
+void orc_block_find_hash(const uint8_t *block, size_t block_len, uint32_t hash, uint32_t *start, uint32_t *end)
+{
+    uint8_t *c = padded_copy(block, block_len);
+    block_reader *r = (block_reader *)malloc(sizeof *r);
+    r->min_doc_id = 0;
+    reader_load(r, c, block_len + 32);
+    reader_find_hash(r, hash, start, end);
+    free(r); free(c);
+}
+
+size_t orc_block_search_hash(const uint8_t *block, size_t block_len, uint32_t min_doc_id, uint32_t hash, uint32_t *out)
+{
+    uint8_t *c = padded_copy(block, block_len);
+    block_reader *r = (block_reader *)malloc(sizeof *r);
+    r->min_doc_id = min_doc_id;
+    reader_load(r, c, block_len + 32);
+    uint32_t s, e; size_t n;
+    reader_find_hash(r, hash, &s, &e);
+    const uint32_t *d = reader_docids_for_range(r, s, e, &n);
+    memcpy(out, d, n * sizeof(uint32_t));
+    free(r); free(c);
+    return n;
+}
+
+/* ensureDocidsLoaded + getItems (:159-203, :282-305): docid delta base resets to min_doc_id
+ * at every hash change */
+size_t orc_block_decode_items(const uint8_t *block, size_t block_len, uint32_t min_doc_id,
+                              uint32_t *hashes, uint32_t *docids)
+{
+    uint8_t *c = padded_copy(block, block_len);
+    orc_block_header h;
+    orc_block_header_decode(c, &h);
+    size_t n = h.num_items;
+    if (n) {
+        uint32_t *th = (uint32_t *)malloc((n + 4) * sizeof(uint32_t));
+        uint32_t *td = (uint32_t *)malloc((n + 4) * sizeof(uint32_t));
+        orc_svb_decode_values(n, 0, n, c + ORC_BLOCK_HEADER_SIZE, th, ORC_V0124, 1, h.min_hash);
+        orc_svb_decode_values(n, 0, n, c + ORC_BLOCK_HEADER_SIZE + h.docids_offset, td, ORC_V1234, 0, 0);
+        uint32_t last_docid = min_doc_id, last_hash = th[0];
+        for (size_t i = 0; i < n; i++) {
+            if (th[i] != last_hash) { last_docid = min_doc_id; last_hash = th[i]; }
+            td[i] += last_docid;
+            last_docid = td[i];
+        }
+        memcpy(hashes, th, n * sizeof(uint32_t));
+        memcpy(docids, td, n * sizeof(uint32_t));
+        free(th); free(td);
+    }
+    free(c);
+    return n;
+}
+
+/* ======================================================================= */
+/* Segment build: filefmt.writeBlocks (src/filefmt.zig:94-138)             */
+/* ======================================================================= */
+
+void orc_free(void *p) { free(p); }
+
+int orc_build_blocks(const uint64_t *items, size_t n, uint32_t min_doc_id, uint32_t block_size,
+                     uint8_t **blocks_out, size_t *blocks_len, uint32_t **index_out, uint32_t *num_blocks_out)
+{
+    if (block_size < ORC_MIN_BLOCK_SIZE || block_size > ORC_MAX_BLOCK_SIZE) return -1;
+    block_encoder *e = (block_encoder *)malloc(sizeof *e);
+    size_t cap_blocks = n / 8 + 16;                /* grows below if needed */
+    uint8_t *blocks = (uint8_t *)malloc(cap_blocks * (size_t)block_size);
+    uint32_t *index = (uint32_t *)malloc(cap_blocks * sizeof(uint32_t));
+    if (!e || !blocks || !index) { free(e); free(blocks); free(index); return -1; }
+    size_t nb = 0, pos = 0;
+    for (;;) {
+        if (nb + 2 > cap_blocks) {
+            cap_blocks *= 2;
+            blocks = (uint8_t *)realloc(blocks, cap_blocks * (size_t)block_size);
+            index = (uint32_t *)realloc(index, cap_blocks * sizeof(uint32_t));
+            if (!blocks || !index) { free(e); return -1; }
+        }
+        /* the writer refills a MAX_ITEMS_PER_BLOCK window before every block (:108-113) */
+        size_t window = n - pos;
+        if (window > ORC_MAX_ITEMS_PER_BLOCK) window = ORC_MAX_ITEMS_PER_BLOCK;
+        size_t consumed = encode_block(e, items + pos, window, min_doc_id, blocks + nb * (size_t)block_size, block_size);
+        if (consumed == 0) {
+            if (window != 0) { free(e); free(blocks); free(index); return -2; } /* block too small for a chunk */
+            break;                                   /* empty terminator block written (:117) */
+        }
+        index[nb] = item_hash(items[pos + consumed - 1]);    /* :119 */
+        nb++;
+        pos += consumed;
+    }
+    free(e);
+    *blocks_out = blocks;
+    *blocks_len = (nb + 1) * (size_t)block_size;
+    *index_out = index;
+    *num_blocks_out = (uint32_t)nb;
+    return 0;
+}
+
+/* ======================================================================= */
+/* Segments                                                                 */
+/* ======================================================================= */
+
+struct orc_segment {
+    int is_file;
+    int owns_blocks;
+    /* file */
+    const uint8_t *blocks; size_t blocks_len; uint32_t block_size;
+    const uint32_t *block_index; uint32_t num_blocks;
+    /* memory */
+    uint64_t *items; size_t num_items;
+    /* common */
+    uint32_t min_doc_id, max_doc_id; uint64_t commit_id;
+    uint32_t *doc_ids; uint8_t *doc_alive; uint32_t num_docs;   /* sorted by id */
+};
+
+static int cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+static int set_docs(orc_segment *s, const uint32_t *ids, const uint8_t *alive, uint32_t n)
+{
+    s->num_docs = n;
+    s->doc_ids = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    s->doc_alive = (uint8_t *)malloc(n ? n : 1);
+    if (!s->doc_ids || !s->doc_alive) return -1;
+    /* sort (id, alive) by id */
+    uint64_t *tmp = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    if (!tmp) return -1;
+    for (uint32_t i = 0; i < n; i++) tmp[i] = (uint64_t)ids[i] << 8 | (alive ? (alive[i] ? 1u : 0u) : 1u);
+    orc_sort_u64(tmp, n);
+    for (uint32_t i = 0; i < n; i++) { s->doc_ids[i] = (uint32_t)(tmp[i] >> 8); s->doc_alive[i] = (uint8_t)(tmp[i] & 1); }
+    free(tmp);
+    return 0;
+}
+
+static orc_segment *create_file(const uint8_t *blocks, size_t blocks_len, uint32_t block_size,
+                                const uint32_t *block_index, uint32_t num_blocks,
+                                uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs, int copy)
+{
+    orc_segment *s = (orc_segment *)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    s->is_file = 1; s->owns_blocks = copy;
+    if (copy) {
+        uint8_t *b = (uint8_t *)malloc(blocks_len + 16);
+        uint32_t *ix = (uint32_t *)malloc((num_blocks ? num_blocks : 1) * sizeof(uint32_t));
+        if (!b || !ix) { free(b); free(ix); free(s); return NULL; }
+        memcpy(b, blocks, blocks_len); memset(b + blocks_len, 0, 16);
+        memcpy(ix, block_index, (size_t)num_blocks * sizeof(uint32_t));
+        s->blocks = b; s->block_index = ix;
+    } else {
+        s->blocks = blocks; s->block_index = block_index;
+    }
+    s->blocks_len = blocks_len; s->block_size = block_size; s->num_blocks = num_blocks;
+    s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id; s->commit_id = commit_id;
+    if (set_docs(s, doc_ids, doc_alive, num_docs)) { orc_segment_free(s); return NULL; }
+    return s;
+}
+
+orc_segment *orc_segment_create_file(const uint8_t *blocks, size_t blocks_len, uint32_t block_size,
+                                     const uint32_t *block_index, uint32_t num_blocks,
+                                     uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                     const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs)
+{
+    return create_file(blocks, blocks_len, block_size, block_index, num_blocks, min_doc_id, max_doc_id,
+                       commit_id, doc_ids, doc_alive, num_docs, 1);
+}
+
+orc_segment *orc_segment_create_file_borrowed(const uint8_t *blocks, size_t blocks_len, uint32_t block_size,
+                                     const uint32_t *block_index, uint32_t num_blocks,
+                                     uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                     const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs)
+{
+    return create_file(blocks, blocks_len, block_size, block_index, num_blocks, min_doc_id, max_doc_id,
+                       commit_id, doc_ids, doc_alive, num_docs, 0);
+}
+
+orc_segment *orc_segment_create_memory(const uint64_t *items, size_t n,
+                                       uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                       const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs)
+{
+    orc_segment *s = (orc_segment *)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    s->items = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    if (!s->items) { free(s); return NULL; }
+    memcpy(s->items, items, n * sizeof(uint64_t));
+    s->num_items = n;
+    s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id; s->commit_id = commit_id;
+    if (set_docs(s, doc_ids, doc_alive, num_docs)) { orc_segment_free(s); return NULL; }
+    return s;
+}
+
+/* MemorySegment.build (src/MemorySegment.zig:81-148): reverse scan, first occurrence of an
+ * id wins (so the LAST change for an id in the batch is the one kept); items sorted as u64 */
+orc_segment *orc_segment_build_memory(const uint8_t *kind, const uint32_t *ids,
+                                      const uint32_t *hashes, const uint64_t *hash_off,
+                                      size_t num_changes, uint64_t commit_id)
+{
+    orc_segment *s = (orc_segment *)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    size_t total = 0;
+    for (size_t i = 0; i < num_changes; i++) if (kind[i] == 0) total += (size_t)(hash_off[i + 1] - hash_off[i]);
+    s->items = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+    uint32_t *dids = (uint32_t *)malloc((num_changes ? num_changes : 1) * sizeof(uint32_t));
+    uint8_t *dalive = (uint8_t *)malloc(num_changes ? num_changes : 1);
+    uint32_t nd = 0; size_t ni = 0;
+    s->commit_id = commit_id;
+    for (size_t i = num_changes; i-- > 0;) {
+        uint32_t id = ids[i];
+        int seen = 0;
+        for (uint32_t k = 0; k < nd; k++) if (dids[k] == id) { seen = 1; break; }   /* docs.getOrPut */
+        if (seen) continue;
+        dids[nd] = id; dalive[nd] = (kind[i] == 0); nd++;
+        if (kind[i] == 0)
+            for (uint64_t j = hash_off[i]; j < hash_off[i + 1]; j++) s->items[ni++] = (uint64_t)hashes[j] << 32 | id;
+        if (s->min_doc_id == 0 || id < s->min_doc_id) s->min_doc_id = id;
+        if (s->max_doc_id == 0 || id > s->max_doc_id) s->max_doc_id = id;
+    }
+    s->num_items = ni;
+    orc_sort_u64(s->items, ni);
+    int rc = set_docs(s, dids, dalive, nd);
+    free(dids); free(dalive);
+    if (rc) { orc_segment_free(s); return NULL; }
+    return s;
+}
+
+void orc_segment_free(orc_segment *s)
+{
+    if (!s) return;
+    if (s->is_file && s->owns_blocks) { free((void *)s->blocks); free((void *)s->block_index); }
+    free(s->items); free(s->doc_ids); free(s->doc_alive);
+    free(s);
+}
+
+size_t orc_segment_num_items(const orc_segment *s) { return s->num_items; }
+const uint64_t *orc_segment_items(const orc_segment *s) { return s->items; }
+uint32_t orc_segment_min_doc_id(const orc_segment *s) { return s->min_doc_id; }
+uint32_t orc_segment_max_doc_id(const orc_segment *s) { return s->max_doc_id; }
+uint32_t orc_segment_num_docs(const orc_segment *s) { return s->num_docs; }
+const uint32_t *orc_segment_doc_ids(const orc_segment *s) { return s->doc_ids; }
+const uint8_t *orc_segment_doc_alive(const orc_segment *s) { return s->doc_alive; }
+
+static int docs_contains(const orc_segment *s, uint32_t id)
+{
+    uint32_t lo = 0, hi = s->num_docs;
+    while (lo < hi) { uint32_t m = lo + (hi - lo) / 2; if (s->doc_ids[m] < id) lo = m + 1; else hi = m; }
+    return lo < s->num_docs && s->doc_ids[lo] == id;
+}
+
+struct orc_snapshot {
+    orc_segment **file; uint32_t n_file;
+    orc_segment **memory; uint32_t n_memory;
+};
+
+orc_snapshot *orc_snapshot_create(orc_segment *const *file, uint32_t n_file,
+                                  orc_segment *const *memory, uint32_t n_memory)
+{
+    orc_snapshot *s = (orc_snapshot *)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    s->file = (orc_segment **)malloc((n_file ? n_file : 1) * sizeof(void *));
+    s->memory = (orc_segment **)malloc((n_memory ? n_memory : 1) * sizeof(void *));
+    if (n_file) memcpy(s->file, file, n_file * sizeof(void *));
+    if (n_memory) memcpy(s->memory, memory, n_memory * sizeof(void *));
+    s->n_file = n_file; s->n_memory = n_memory;
+    return s;
+}
+
+void orc_snapshot_free(orc_snapshot *s) { if (s) { free(s->file); free(s->memory); free(s); } }
+
+/* Segments.hasNewerCommit (src/Index.zig:133-149) */
+int orc_snapshot_has_newer_commit(const orc_snapshot *s, uint32_t id, uint64_t commit_id)
+{
+    for (uint32_t i = s->n_memory; i-- > 0;) {
+        const orc_segment *g = s->memory[i];
+        if (g->commit_id <= commit_id) return 0;
+        if (id >= g->min_doc_id && id <= g->max_doc_id && docs_contains(g, id)) return 1;
+    }
+    for (uint32_t j = s->n_file; j-- > 0;) {
+        const orc_segment *g = s->file[j];
+        if (g->commit_id <= commit_id) return 0;
+        if (id >= g->min_doc_id && id <= g->max_doc_id && docs_contains(g, id)) return 1;
+    }
+    return 0;
+}
+
+/* ======================================================================= */
+/* SearchResults (src/common.zig:73-176)                                    */
+/* ======================================================================= */
+
+typedef struct { uint32_t id; uint32_t score; uint64_t commit_id; } hit_slot;   /* id==0 -> empty */
+
+typedef struct {
+    hit_slot *slots; size_t cap; size_t count;    /* cap is a power of two */
+    int has_zero; hit_slot zero;                 /* id 0 is illegal upstream but keep the map total */
+    int oom;
+} hit_map;
+
+static inline uint64_t hit_hash(uint32_t key)     /* HitContext.hash (:61-68) */
+{
+    uint64_t x = key;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+
+static int map_init(hit_map *m, size_t cap)
+{
+    m->slots = (hit_slot *)calloc(cap, sizeof(hit_slot));
+    m->cap = cap; m->count = 0; m->has_zero = 0; m->oom = 0;
+    return m->slots ? 0 : -1;
+}
+
+static hit_slot *map_slot(hit_map *m, uint32_t id, int *found)
+{
+    if (id == 0) { *found = m->has_zero; m->has_zero = 1; return &m->zero; }
+    size_t mask = m->cap - 1, i = (size_t)hit_hash(id) & mask;
+    for (;;) {
+        hit_slot *s = &m->slots[i];
+        if (s->id == id) { *found = 1; return s; }
+        if (s->id == 0) { *found = 0; return s; }
+        i = (i + 1) & mask;
+    }
+}
+
+static int map_grow(hit_map *m)
+{
+    hit_map n;
+    if (map_init(&n, m->cap * 2)) return -1;
+    for (size_t i = 0; i < m->cap; i++) if (m->slots[i].id) {
+        int f; hit_slot *s = map_slot(&n, m->slots[i].id, &f);
+        *s = m->slots[i]; n.count++;
+    }
+    n.has_zero = m->has_zero; n.zero = m->zero;
+    free(m->slots);
+    *m = n;
+    return 0;
+}
+
+/* SearchResults.incr (:121-129) */
+static void results_incr(hit_map *m, uint32_t id, uint64_t commit_id)
+{
+    if (m->oom) return;
+    if ((m->count + 1) * 5 > m->cap * 4) { if (map_grow(m)) { m->oom = 1; return; } }
+    int found; hit_slot *s = map_slot(m, id, &found);
+    if (!found || s->commit_id < commit_id) {
+        if (!found) { s->id = id; if (id) m->count++; }
+        s->score = 1; s->commit_id = commit_id;
+    } else if (s->commit_id == commit_id) {
+        s->score += 1;
+    }
+}
+
+/* ======================================================================= */
+/* FileSegment.search (src/FileSegment.zig:135-180)                         */
+/* ======================================================================= */
+
+#define MAX_BLOCKS_PER_HASH 4      /* :25 */
+#define MAX_DOCS_PER_HASH 1000     /* :26 */
+
+typedef struct { size_t block_no; block_reader reader; } cache_entry;
+
+static int file_segment_search(const orc_segment *seg, const uint32_t *sorted_hashes, size_t n,
+                               hit_map *results, orc_stats *st)
+{
+    cache_entry *cache = (cache_entry *)malloc(sizeof(cache_entry) * MAX_BLOCKS_PER_HASH);
+    if (!cache) return -1;
+    for (int i = 0; i < MAX_BLOCKS_PER_HASH; i++) { cache[i].block_no = (size_t)-1; cache[i].reader.min_doc_id = seg->min_doc_id; }
+
+    size_t prev = 0;
+    for (size_t qi = 0; qi < n; qi++) {
+        uint32_t hash = sorted_hashes[qi];
+        /* lowerBound over block_index[prev..] (:145-151) */
+        size_t lo = prev, hi = seg->num_blocks;
+        while (lo < hi) { size_t m = lo + (hi - lo) / 2; if (seg->block_index[m] < hash) lo = m + 1; else hi = m; }
+        size_t block_no = lo;
+        prev = block_no;
+
+        size_t num_docs = 0; uint64_t num_blocks = 0;
+        for (; block_no < seg->num_blocks; block_no++) {
+            cache_entry *ce = &cache[block_no % MAX_BLOCKS_PER_HASH];
+            if (ce->block_no != block_no) {
+                ce->block_no = block_no;
+                size_t start = block_no * (size_t)seg->block_size;
+                size_t end = start + seg->block_size + 16;                 /* loadBlockData :83-89 */
+                if (end > seg->blocks_len) end = seg->blocks_len;
+                reader_load(&ce->reader, seg->blocks + start, end - start);
+            }
+            block_reader *r = &ce->reader;
+            if (r->h.min_hash > hash) break;                                /* :164 */
+            uint32_t s, e; size_t cnt;
+            reader_find_hash(r, hash, &s, &e);
+            const uint32_t *d = reader_docids_for_range(r, s, e, &cnt);
+            for (size_t k = 0; k < cnt; k++) results_incr(results, d[k], seg->commit_id);
+            num_blocks += 1;
+            num_docs += cnt;
+            if (num_blocks >= MAX_BLOCKS_PER_HASH) break;                   /* :173 */
+            if (num_docs > MAX_DOCS_PER_HASH) break;                        /* :174 */
+        }
+        if (st) { st->scanned_blocks += num_blocks; st->scanned_docs += num_docs; st->probes += 1; }
+    }
+    free(cache);
+    return results->oom ? -1 : 0;
+}
+
+/* MemorySegment.search (src/MemorySegment.zig:44-54): equalRange by hash over the shrinking tail */
+static int memory_segment_search(const orc_segment *seg, const uint32_t *sorted_hashes, size_t n, hit_map *results)
+{
+    const uint64_t *items = seg->items;
+    size_t len = seg->num_items;
+    for (size_t qi = 0; qi < n; qi++) {
+        uint32_t hash = sorted_hashes[qi];
+        size_t lo = 0, hi = len;
+        while (lo < hi) { size_t m = lo + (hi - lo) / 2; if ((uint32_t)(items[m] >> 32) < hash) lo = m + 1; else hi = m; }
+        size_t first = lo;
+        hi = len;
+        while (lo < hi) { size_t m = lo + (hi - lo) / 2; if ((uint32_t)(items[m] >> 32) <= hash) lo = m + 1; else hi = m; }
+        for (size_t i = first; i < lo; i++) results_incr(results, (uint32_t)items[i], seg->commit_id);
+        items += lo; len -= lo;
+    }
+    return results->oom ? -1 : 0;
+}
+
+uint32_t orc_default_min_score(uint32_t raw_query_len) { return (uint32_t)(((uint64_t)raw_query_len + 19) / 20); } /* MultiIndex.zig:304 */
+
+/* sort + dedupSorted (src/Index.zig:171-172, :489-499) then the segment scans (:173-175) */
+static int run_scans(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n, hit_map *m, orc_stats *st)
+{
+    uint32_t *q = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!q) return -1;
+    memcpy(q, hashes, (size_t)n * sizeof(uint32_t));
+    qsort(q, n, sizeof(uint32_t), cmp_u32);
+    uint32_t w = 0;
+    if (n) { w = 1; for (uint32_t i = 1; i < n; i++) if (q[i] != q[w - 1]) q[w++] = q[i]; }
+    int rc = 0;
+    for (uint32_t i = 0; i < snap->n_file && !rc; i++) rc = file_segment_search(snap->file[i], q, w, m, st);
+    for (uint32_t i = 0; i < snap->n_memory && !rc; i++) rc = memory_segment_search(snap->memory[i], q, w, m);
+    free(q);
+    return rc;
+}
+
+static int cmp_result(const void *a, const void *b)     /* compareResults (src/common.zig:169-171) */
+{
+    const orc_result *x = (const orc_result *)a, *y = (const orc_result *)b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    return x->id < y->id ? -1 : x->id > y->id;
+}
+
+int orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
+               uint32_t max_results, uint32_t min_score_opt, uint32_t min_score_pct,
+               orc_result *out, uint32_t out_cap, orc_stats *stats)
+{
+    hit_map m;
+    if (map_init(&m, 1024)) return -1;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (run_scans(snap, hashes, n, &m, stats)) { free(m.slots); return -1; }
+    if (stats) stats->hits_unique = m.count + (size_t)m.has_zero;
+
+    /* finish (src/common.zig:131-167) */
+    uint32_t min_score = min_score_opt;
+    size_t nc = 0;
+    orc_result *cand = (orc_result *)malloc((m.count + 2) * sizeof(orc_result));
+    if (!cand) { free(m.slots); return -1; }
+    for (size_t i = 0; i < m.cap; i++)
+        if (m.slots[i].id && m.slots[i].score >= min_score) { cand[nc].id = m.slots[i].id; cand[nc].score = m.slots[i].score; nc++; }
+    if (m.has_zero && m.zero.score >= min_score) { cand[nc].id = 0; cand[nc].score = m.zero.score; nc++; }
+    qsort(cand, nc, sizeof(orc_result), cmp_result);
+
+    uint32_t outn = 0;
+    for (size_t i = 0; i < nc; i++) {
+        if (outn == max_results) break;
+        int f; hit_slot *h = map_slot(&m, cand[i].id, &f);
+        if (orc_snapshot_has_newer_commit(snap, cand[i].id, h->commit_id)) continue;
+        if (cand[i].score < min_score) break;
+        if (outn == 0) {
+            uint32_t rel = (uint32_t)((uint64_t)cand[i].score * min_score_pct / 100);   /* :162 (no u32 overflow for pct<=100) */
+            if (rel > min_score) min_score = rel;
+        }
+        if (outn < out_cap) out[outn] = cand[i];
+        outn++;
+    }
+    free(cand); free(m.slots);
+    return (int)(outn < out_cap ? outn : out_cap);
+}
+
+int orc_search_hits(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
+                    uint32_t *ids, uint64_t *commit_ids, uint32_t *scores, uint32_t cap)
+{
+    hit_map m;
+    if (map_init(&m, 1024)) return -1;
+    if (run_scans(snap, hashes, n, &m, NULL)) { free(m.slots); return -1; }
+    uint32_t k = 0;
+    for (size_t i = 0; i < m.cap; i++) if (m.slots[i].id) {
+        if (k < cap) { ids[k] = m.slots[i].id; commit_ids[k] = m.slots[i].commit_id; scores[k] = m.slots[i].score; }
+        k++;
+    }
+    free(m.slots);
+    return (int)k;
+}
+
+/* ======================================================================= */
+/* Seeded synthetic fingerprints (definition shared with the GPU builder)   */
+/* ======================================================================= */
+
+uint64_t orc_mix64(uint64_t x)      /* splitmix64 finalizer */
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+uint32_t orc_synth_hash(uint64_t seed, uint32_t doc, uint32_t j, int dist)
+{
+    uint64_t a = orc_mix64(seed + (uint64_t)doc * 0xD1B54A32D192ED03ULL);
+    uint64_t r = orc_mix64(a ^ (uint64_t)j);
+    if (dist == 1 && (r & 0xFFFF) < 1311) {                /* ~2 % from a 4095-value hot pool, log-uniform rank */
+        uint32_t e = (uint32_t)((r >> 16) & 0xFF) % 12;
+        uint32_t k = (1u << e) + ((uint32_t)(r >> 24) & ((1u << e) - 1)) - 1;
+        return (uint32_t)(orc_mix64(seed ^ 0x5bd1e9955bd1e995ULL ^ ((uint64_t)k << 32)) >> 32);
+    }
+    return (uint32_t)(r >> 32);
+}
+
+void orc_sort_u64(uint64_t *v, size_t n)     /* LSD radix sort, 8 x 8 bits */
+{
+    if (n < 2) return;
+    uint64_t *tmp = (uint64_t *)malloc(n * sizeof(uint64_t));
+    if (!tmp) return;
+    uint64_t *src = v, *dst = tmp;
+    for (int pass = 0; pass < 8; pass++) {
+        size_t cnt[256] = {0};
+        int shift = pass * 8;
+        for (size_t i = 0; i < n; i++) cnt[(src[i] >> shift) & 0xFF]++;
+        if (cnt[(src[0] >> shift) & 0xFF] == n) continue;     /* all equal in this digit */
+        size_t sum = 0;
+        for (int b = 0; b < 256; b++) { size_t c = cnt[b]; cnt[b] = sum; sum += c; }
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 0xFF]++] = src[i];
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != v) memcpy(v, src, n * sizeof(uint64_t));
+    free(tmp);
+}
+
+void orc_synth_items(uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist, uint64_t *items)
+{
+    for (uint32_t d = 0; d < num_docs; d++)
+        for (uint32_t j = 0; j < H; j++)
+            items[(size_t)d * H + j] = (uint64_t)orc_synth_hash(seed, first_doc + d, j, dist) << 32 | (first_doc + d);
+    orc_sort_u64(items, (size_t)num_docs * H);
+}

@@ -1,0 +1,9 @@
+"""fpx -- MI355X-native search path for the AcoustID fingerprint inverted index.
+
+Only the /_search hot path of acoustid/acoustid-index lives here:
+csrc/ holds the HIP kernels and the C ABI (include/fpx.h), this package is the host-side
+mirror of the reference's search interface."""
+from ._lib import FpxError, SearchTimeout, Stats, lib, LIB_PATH  # noqa: F401
+from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegment, SearchOptions,  # noqa: F401
+                    SearchResults, Segments, http_options)
+from . import synth  # noqa: F401

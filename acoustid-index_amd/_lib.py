@@ -1,0 +1,96 @@
+"""ctypes binding of libfpx.so (include/fpx.h).  There is no CPU fallback: if the HIP
+library is missing or no gfx950 device is visible, every entry point fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfpx.so")
+
+FPX_OK, FPX_E_NOMEM, FPX_E_TIMEOUT, FPX_E_DEVICE, FPX_E_INVAL, FPX_E_NODEVICE = 0, -1, -2, -3, -4, -5
+
+
+class FpxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libfpx error {status}: {message}")
+        self.status = status
+
+
+class SearchTimeout(FpxError):
+    """error.SearchTimeout (src/MultiIndex.zig:319-322)"""
+
+
+class Result(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("score", C.c_uint32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("max_results", C.c_uint32), ("min_score", C.c_uint32),
+                ("has_min_score", C.c_uint32), ("min_score_pct", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("probes", C.c_uint64), ("scanned_blocks", C.c_uint64), ("scanned_docs", C.c_uint64),
+                ("hits", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("candidates", C.c_uint64),
+                ("probe_kernel_ms", C.c_float), ("total_gpu_ms", C.c_float),
+                ("probe_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/fpx.h declares: name -> (restype, argtypes)
+_vp, _u32, _u64, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+SIGNATURES = {
+    "fpx_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "fpx_ctx_destroy": (None, [_vp]),
+    "fpx_strerror": (C.c_char_p, [C.c_int]),
+    "fpx_last_error": (C.c_char_p, []),
+    "fpx_version": (C.c_int, []),
+    "fpx_segment_create_file": (C.c_int, [_vp, _vp, _sz, _u32, _vp, _u32, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
+    "fpx_segment_create_memory": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
+    "fpx_segment_create_remote": (C.c_int, [_vp, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
+    "fpx_segment_retain": (None, [_vp]),
+    "fpx_segment_release": (None, [_vp]),
+    "fpx_segment_num_items": (_u64, [_vp]),
+    "fpx_segment_num_blocks": (_u32, [_vp]),
+    "fpx_segment_block_size": (_u32, [_vp]),
+    "fpx_segment_device_bytes": (_u64, [_vp]),
+    "fpx_segment_download": (C.c_int, [_vp, _vp, _sz, _vp, _u32]),
+    "fpx_snapshot_create": (C.c_int, [_vp, _vp, _u32, C.POINTER(_vp)]),
+    "fpx_snapshot_retain": (None, [_vp]),
+    "fpx_snapshot_release": (None, [_vp]),
+    "fpx_search": (C.c_int, [_vp, _vp, _u32, C.POINTER(Opts), _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(Stats)]),
+    "fpx_search_batch": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
+    "fpx_search_batch_partial": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
+    "fpx_merge_partials": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
+    "fpx_synth_segment": (C.c_int, [_vp, _u64, _u32, _u32, _u32, C.c_int, _u32, _u64, C.POINTER(_vp)]),
+    "fpx_measure_bandwidth": (C.c_int, [_vp, _sz, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libfpx.so (built by acoustid-index_amd/build.sh / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FpxError(FPX_E_NODEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() -- there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)      # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status == FPX_OK:
+        return
+    msg = lib().fpx_last_error().decode(errors="replace") or lib().fpx_strerror(status).decode()
+    if status == FPX_E_TIMEOUT:
+        raise SearchTimeout(status, msg or "search timeout")
+    if status == FPX_E_NOMEM:
+        raise MemoryError(f"libfpx: {msg}")
+    raise FpxError(status, msg)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libfpx.so (HIP, gfx950 only) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")/csrc"
+OUT=../libfpx.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+mkdir -p ../build
+pids=()
+for f in fpx_sort fpx_search fpx_api fpx_build; do
+  if [ ! -f ../build/$f.o ] || [ $f.hip -nt ../build/$f.o ] || [ fpx_internal.h -nt ../build/$f.o ] || [ ../../include/fpx.h -nt ../build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o ../build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../build/fpx_sort.o ../build/fpx_search.o ../build/fpx_api.o ../build/fpx_build.o
+echo "built $(realpath $OUT)"

@@ -1,0 +1,457 @@
+// fpx_api.hip -- C ABI of libfpx (include/fpx.h): context, resident segments, snapshots with their
+// supersession tables, workspace pool, and the search entry points.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <new>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return e == hipErrorOutOfMemory ? FPX_E_NOMEM : FPX_E_DEVICE;
+}
+
+// ---------------------------------------------------------------- workspace pool
+Workspace* ws_acquire(Ctx* ctx)
+{
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        if (!ctx->free_ws.empty()) {
+            Workspace* w = ctx->free_ws.back();
+            ctx->free_ws.pop_back();
+            return w;
+        }
+    }
+    Workspace* w = new (std::nothrow) Workspace();
+    if (!w) { set_error("out of host memory"); return nullptr; }
+    bool ok = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&w->ev_begin) == hipSuccess && hipEventCreate(&w->ev_probe0) == hipSuccess &&
+              hipEventCreate(&w->ev_probe1) == hipSuccess && hipEventCreate(&w->ev_end) == hipSuccess &&
+              hipMalloc(&w->d_counters, CTR_COUNT * sizeof(unsigned long long)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&w->h_counters), CTR_COUNT * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) { set_error("workspace creation failed: %s", hipGetErrorString(hipGetLastError())); ws_destroy(w); return nullptr; }
+    ctx->live_ws++;
+    return w;
+}
+
+void ws_release(Ctx* ctx, Workspace* ws)
+{
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->free_ws.push_back(ws);
+}
+
+void ws_destroy(Workspace* w)
+{
+    if (!w) return;
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    void* bufs[] = {w->d_hashes, w->d_offsets, w->d_opts, w->d_keys[0], w->d_keys[1], w->d_hits[0], w->d_hits[1],
+                    w->d_cands[0], w->d_cands[1], w->d_temp, w->d_counters, w->d_out, w->d_out_n};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (w->h_counters) (void)hipHostFree(w->h_counters);
+    if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
+    if (w->ev_probe0) (void)hipEventDestroy(w->ev_probe0);
+    if (w->ev_probe1) (void)hipEventDestroy(w->ev_probe1);
+    if (w->ev_end) (void)hipEventDestroy(w->ev_end);
+    if (w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+}
+
+// ---------------------------------------------------------------- segments
+static void set_docs(Segment* s, const uint32_t* ids, uint32_t n)
+{
+    s->doc_ids.assign(ids, ids + n);
+    if (!std::is_sorted(s->doc_ids.begin(), s->doc_ids.end())) std::sort(s->doc_ids.begin(), s->doc_ids.end());
+    s->doc_ids.erase(std::unique(s->doc_ids.begin(), s->doc_ids.end()), s->doc_ids.end());
+}
+
+static void segment_free(Segment* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_blocks) (void)hipFree(s->d_blocks);
+    if (s->d_block_index) (void)hipFree(s->d_block_index);
+    if (s->d_bucket) (void)hipFree(s->d_bucket);
+    if (s->d_items) (void)hipFree(s->d_items);
+    delete s;
+}
+
+__global__ void k_count_items(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
+                              unsigned long long* total)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n = 0;
+    if (b < num_blocks) {
+        const uint8_t* p = blocks + (size_t)b * block_size;
+        n = (unsigned long long)p[4] | ((unsigned long long)p[5] << 8);     // num_items, src/block.zig:46-50
+    }
+    for (int d = 32; d > 0; d >>= 1) n += __shfl_down(n, d);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
+}
+
+// finish a file segment whose blocks and block index are already in HBM (upload or GPU build)
+int finish_file_segment(Segment* s)
+{
+    if (s->num_blocks == 0) { s->num_buckets = 1; s->bucket_shift = 32; }
+    int rc = build_bucket_table(s, 0);
+    if (rc) return rc;
+    unsigned long long* d_total = nullptr;
+    FPX_HIP(hipMalloc(&d_total, 8));
+    FPX_HIP(hipMemset(d_total, 0, 8));
+    if (s->num_blocks)
+        hipLaunchKernelGGL(k_count_items, dim3((s->num_blocks + 255) / 256), dim3(256), 0, 0,
+                           s->d_blocks, s->block_size, s->num_blocks, d_total);
+    unsigned long long total = 0;
+    FPX_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_total);
+    s->num_items = total;
+    return FPX_OK;
+}
+
+}  // namespace fpx
+
+using namespace fpx;
+
+extern "C" {
+
+int fpx_version(void) { return 1; }
+
+const char* fpx_last_error(void) { return g_err; }
+
+const char* fpx_strerror(int status)
+{
+    switch (status) {
+        case FPX_OK: return "ok";
+        case FPX_E_NOMEM: return "out of memory";
+        case FPX_E_TIMEOUT: return "search timeout";
+        case FPX_E_DEVICE: return "device error";
+        case FPX_E_INVAL: return "invalid argument";
+        case FPX_E_NODEVICE: return "no HIP device";
+        default: return "unknown";
+    }
+}
+
+int fpx_ctx_create(int device, fpx_ctx** out)
+{
+    if (!out) { set_error("null out"); return FPX_E_INVAL; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (%s): libfpx has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return FPX_E_NODEVICE;
+    }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= n) { set_error("device %d out of range (%d visible)", device, n); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FPX_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libfpx is built for gfx950 only", device, prop.gcnArchName);
+        return FPX_E_NODEVICE;
+    }
+    Ctx* c = new (std::nothrow) Ctx();
+    if (!c) return FPX_E_NOMEM;
+    c->device = device;
+    *out = reinterpret_cast<fpx_ctx*>(c);
+    return FPX_OK;
+}
+
+void fpx_ctx_destroy(fpx_ctx* ctx_)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx_);
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (Workspace* w : c->free_ws) ws_destroy(w);
+    delete c;
+}
+
+int fpx_segment_create_file(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_len, uint32_t block_size,
+                            const uint32_t* block_index, uint32_t num_blocks,
+                            uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                            const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs,
+                            fpx_segment** out)
+{
+    (void)doc_alive;   // a tombstone supersedes older segments exactly like a live doc (src/Index.zig:133-149)
+    Ctx* c = reinterpret_cast<Ctx*>(ctx_);
+    if (!c || !out || (!blocks && blocks_len) || (!block_index && num_blocks) || (!doc_ids && num_docs)) {
+        set_error("null argument"); return FPX_E_INVAL;
+    }
+    *out = nullptr;
+    if (block_size < 64 || block_size > 4096) { set_error("block_size %u outside [64,4096] (src/filefmt.zig:236)", block_size); return FPX_E_INVAL; }
+    if (blocks_len < (size_t)num_blocks * block_size) { set_error("blocks_len shorter than num_blocks * block_size"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(c->device));
+    Segment* s = new (std::nothrow) Segment();
+    if (!s) return FPX_E_NOMEM;
+    s->ctx = c; s->kind = 0; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
+    s->block_size = block_size; s->num_blocks = num_blocks;
+    set_docs(s, doc_ids, num_docs);
+    // resident copy: real blocks + one zero terminator block + 16 B (the over-read slack of
+    // src/streamvbyte.zig:5 / src/FileSegment.zig:87 made explicit)
+    s->blocks_len = ((size_t)num_blocks + 1) * block_size;
+    const size_t alloc = s->blocks_len + 16;
+    hipError_t e = hipMalloc(&s->d_blocks, alloc);
+    if (e == hipSuccess) e = hipMalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t));
+    if (e != hipSuccess) { segment_free(s); return hip_fail(e, "hipMalloc(segment)"); }
+    s->device_bytes = alloc + ((size_t)num_blocks + 1) * sizeof(uint32_t);
+    const size_t copy = (size_t)num_blocks * block_size;
+    if ((e = hipMemset(s->d_blocks + copy, 0, alloc - copy)) != hipSuccess ||
+        (copy && (e = hipMemcpy(s->d_blocks, blocks, copy, hipMemcpyHostToDevice)) != hipSuccess) ||
+        (num_blocks && (e = hipMemcpy(s->d_block_index, block_index, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess)) {
+        segment_free(s); return hip_fail(e, "segment upload");
+    }
+    int rc = finish_file_segment(s);
+    if (rc) { segment_free(s); return rc; }
+    FPX_HIP(hipDeviceSynchronize());
+    *out = reinterpret_cast<fpx_segment*>(s);
+    return FPX_OK;
+}
+
+int fpx_segment_create_memory(fpx_ctx* ctx_, const uint64_t* items, size_t num_items,
+                              uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                              const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs, fpx_segment** out)
+{
+    (void)doc_alive;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx_);
+    if (!c || !out || (!items && num_items) || (!doc_ids && num_docs)) { set_error("null argument"); return FPX_E_INVAL; }
+    *out = nullptr;
+    for (size_t i = 1; i < num_items; ++i)
+        if (items[i] < items[i - 1]) { set_error("memory segment items must be sorted (src/MemorySegment.zig:139)"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(c->device));
+    Segment* s = new (std::nothrow) Segment();
+    if (!s) return FPX_E_NOMEM;
+    s->ctx = c; s->kind = 1; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
+    s->num_items = num_items;
+    set_docs(s, doc_ids, num_docs);
+    hipError_t e = hipMalloc(&s->d_items, (num_items + 1) * sizeof(uint64_t));
+    if (e == hipSuccess && num_items) e = hipMemcpy(s->d_items, items, num_items * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { segment_free(s); return hip_fail(e, "memory segment upload"); }
+    s->device_bytes = (num_items + 1) * sizeof(uint64_t);
+    *out = reinterpret_cast<fpx_segment*>(s);
+    return FPX_OK;
+}
+
+int fpx_segment_create_remote(fpx_ctx* ctx_, uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                              const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs, fpx_segment** out)
+{
+    (void)doc_alive;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx_);
+    if (!c || !out || (!doc_ids && num_docs)) { set_error("null argument"); return FPX_E_INVAL; }
+    Segment* s = new (std::nothrow) Segment();
+    if (!s) return FPX_E_NOMEM;
+    s->ctx = c; s->kind = 2; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
+    set_docs(s, doc_ids, num_docs);
+    *out = reinterpret_cast<fpx_segment*>(s);
+    return FPX_OK;
+}
+
+void fpx_segment_retain(fpx_segment* seg) { if (seg) reinterpret_cast<Segment*>(seg)->refs.fetch_add(1); }
+
+void fpx_segment_release(fpx_segment* seg)
+{
+    Segment* s = reinterpret_cast<Segment*>(seg);
+    if (s && s->refs.fetch_sub(1) == 1) segment_free(s);
+}
+
+uint64_t fpx_segment_num_items(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->num_items : 0; }
+uint32_t fpx_segment_num_blocks(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->num_blocks : 0; }
+uint32_t fpx_segment_block_size(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->block_size : 0; }
+uint64_t fpx_segment_device_bytes(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->device_bytes : 0; }
+
+int fpx_segment_download(const fpx_segment* seg, uint8_t* blocks, size_t blocks_cap, uint32_t* block_index, uint32_t index_cap)
+{
+    const Segment* s = reinterpret_cast<const Segment*>(seg);
+    if (!s || s->kind != 0) { set_error("not a resident file segment"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(s->ctx->device));
+    if (blocks) {
+        if (blocks_cap < s->blocks_len) { set_error("blocks buffer too small"); return FPX_E_INVAL; }
+        FPX_HIP(hipMemcpy(blocks, s->d_blocks, s->blocks_len, hipMemcpyDeviceToHost));
+    }
+    if (block_index) {
+        if (index_cap < s->num_blocks) { set_error("index buffer too small"); return FPX_E_INVAL; }
+        if (s->num_blocks) FPX_HIP(hipMemcpy(block_index, s->d_block_index, (size_t)s->num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return FPX_OK;
+}
+
+// ---------------------------------------------------------------- snapshot
+// dead(s) = { d in docs(s) : some newer segment s' has min(s') <= d <= max(s') and d in docs(s') }
+// i.e. exactly the postings SearchResults.finish drops through Segments.hasNewerCommit
+// (src/common.zig:158, src/Index.zig:133-149), resolved once per snapshot instead of once per candidate.
+static void compute_dead(const std::vector<Segment*>& segs, size_t si, std::vector<uint32_t>& dead)
+{
+    dead.clear();
+    const Segment* s = segs[si];
+    if (s->kind == 2 || s->doc_ids.empty()) return;
+    const uint32_t lo_s = s->doc_ids.front(), hi_s = s->doc_ids.back();
+    for (size_t j = si + 1; j < segs.size(); ++j) {
+        const Segment* t = segs[j];
+        if (t->doc_ids.empty()) continue;
+        const uint32_t lo = std::max(std::max(lo_s, t->min_doc_id), t->doc_ids.front());
+        const uint32_t hi = std::min(std::min(hi_s, t->max_doc_id), t->doc_ids.back());
+        if (lo > hi) continue;
+        auto a0 = std::lower_bound(s->doc_ids.begin(), s->doc_ids.end(), lo);
+        auto a1 = std::upper_bound(s->doc_ids.begin(), s->doc_ids.end(), hi);
+        auto b0 = std::lower_bound(t->doc_ids.begin(), t->doc_ids.end(), lo);
+        auto b1 = std::upper_bound(t->doc_ids.begin(), t->doc_ids.end(), hi);
+        std::set_intersection(a0, a1, b0, b1, std::back_inserter(dead));
+    }
+    std::sort(dead.begin(), dead.end());
+    dead.erase(std::unique(dead.begin(), dead.end()), dead.end());
+}
+
+static void snapshot_free(Snapshot* sn)
+{
+    if (!sn) return;
+    (void)hipSetDevice(sn->ctx->device);
+    for (uint32_t* d : sn->d_dead) if (d) (void)hipFree(d);
+    if (sn->d_file) (void)hipFree(sn->d_file);
+    if (sn->d_mem) (void)hipFree(sn->d_mem);
+    for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
+    delete sn;
+}
+
+int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_segs, fpx_snapshot** out)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx_);
+    if (!c || !out || (!segs && num_segs)) { set_error("null argument"); return FPX_E_INVAL; }
+    *out = nullptr;
+    bool seen_memory = false;
+    for (uint32_t i = 0; i < num_segs; ++i) {
+        const Segment* s = reinterpret_cast<const Segment*>(segs[i]);
+        if (!s) { set_error("null segment"); return FPX_E_INVAL; }
+        if (i && s->commit_id <= reinterpret_cast<const Segment*>(segs[i - 1])->commit_id) {
+            set_error("segments must be ordered oldest -> newest by strictly ascending commit_id (src/Index.zig:36-41)");
+            return FPX_E_INVAL;
+        }
+        if (s->kind == 1) seen_memory = true;
+        else if (s->kind == 0 && seen_memory) { set_error("file segments must precede memory segments (src/Index.zig:38-39)"); return FPX_E_INVAL; }
+    }
+    FPX_HIP(hipSetDevice(c->device));
+    Snapshot* sn = new (std::nothrow) Snapshot();
+    if (!sn) return FPX_E_NOMEM;
+    sn->ctx = c;
+    for (uint32_t i = 0; i < num_segs; ++i) {
+        Segment* s = reinterpret_cast<Segment*>(segs[i]);
+        s->refs.fetch_add(1);
+        sn->segs.push_back(s);
+    }
+    std::vector<uint32_t> dead;
+    for (size_t i = 0; i < sn->segs.size(); ++i) {
+        Segment* s = sn->segs[i];
+        if (s->kind == 2) continue;
+        compute_dead(sn->segs, i, dead);
+        uint32_t* d_dead = nullptr;
+        if (!dead.empty()) {
+            hipError_t e = hipMalloc(&d_dead, dead.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(d_dead, dead.data(), dead.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "dead list upload"); }
+            sn->d_dead.push_back(d_dead);
+        }
+        const uint32_t slo = dead.empty() ? 1u : dead.front(), shi = dead.empty() ? 0u : dead.back();
+        if (s->kind == 0) {
+            SegDesc d{};
+            d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead;
+            d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
+            d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
+            sn->h_file.push_back(d);
+            sn->max_block_size = std::max(sn->max_block_size, s->block_size);
+        } else {
+            MemDesc d{};
+            d.items = s->d_items; d.dead = d_dead; d.num_items = s->num_items;
+            d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
+            sn->h_mem.push_back(d);
+        }
+    }
+    sn->n_file = (uint32_t)sn->h_file.size();
+    sn->n_mem = (uint32_t)sn->h_mem.size();
+    if (sn->max_block_size == 0) sn->max_block_size = 512;
+    hipError_t e = hipSuccess;
+    if (sn->n_file) {
+        e = hipMalloc(&sn->d_file, sn->n_file * sizeof(SegDesc));
+        if (e == hipSuccess) e = hipMemcpy(sn->d_file, sn->h_file.data(), sn->n_file * sizeof(SegDesc), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && sn->n_mem) {
+        e = hipMalloc(&sn->d_mem, sn->n_mem * sizeof(MemDesc));
+        if (e == hipSuccess) e = hipMemcpy(sn->d_mem, sn->h_mem.data(), sn->n_mem * sizeof(MemDesc), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "snapshot upload"); }
+    *out = reinterpret_cast<fpx_snapshot*>(sn);
+    return FPX_OK;
+}
+
+void fpx_snapshot_retain(fpx_snapshot* snap) { if (snap) reinterpret_cast<Snapshot*>(snap)->refs.fetch_add(1); }
+
+void fpx_snapshot_release(fpx_snapshot* snap)
+{
+    Snapshot* sn = reinterpret_cast<Snapshot*>(snap);
+    if (sn && sn->refs.fetch_sub(1) == 1) snapshot_free(sn);
+}
+
+// ---------------------------------------------------------------- search
+int fpx_search_batch(fpx_snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t num_queries,
+                     const fpx_opts* opts, uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n,
+                     fpx_stats* stats)
+{
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), hashes, offsets, num_queries, opts, timeout_ms,
+                             false, out, out_cap, out_n, stats);
+}
+
+int fpx_search(fpx_snapshot* snap, const uint32_t* hashes, uint32_t num_hashes, const fpx_opts* opts, uint32_t timeout_ms,
+               fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+{
+    const uint64_t offsets[2] = {0, num_hashes};
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), hashes, offsets, 1, opts, timeout_ms,
+                             false, out, out_cap, out_n, stats);
+}
+
+int fpx_search_batch_partial(fpx_snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t num_queries,
+                             const fpx_opts* opts, uint32_t timeout_ms, void* d_out, uint32_t out_cap, void* d_out_n,
+                             fpx_stats* stats)
+{
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), hashes, offsets, num_queries, opts, timeout_ms,
+                             true, reinterpret_cast<fpx_result*>(d_out), out_cap, reinterpret_cast<uint32_t*>(d_out_n), stats);
+}
+
+int fpx_merge_partials(fpx_ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world, uint32_t num_queries,
+                       uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
+                       fpx_result* out, uint32_t out_cap, uint32_t* out_n)
+{
+    return merge_partials_impl(reinterpret_cast<Ctx*>(ctx), d_parts, d_counts, world, num_queries, part_cap, opts, offsets,
+                               out, out_cap, out_n);
+}
+
+int fpx_synth_segment(fpx_ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t hashes_per_doc,
+                      int dist, uint32_t block_size, uint64_t commit_id, fpx_segment** out)
+{
+    if (!ctx || !out) { set_error("null argument"); return FPX_E_INVAL; }
+    Segment* s = nullptr;
+    int rc = synth_segment_impl(reinterpret_cast<Ctx*>(ctx), seed, first_doc, num_docs, hashes_per_doc, dist, block_size,
+                                commit_id, &s);
+    *out = reinterpret_cast<fpx_segment*>(s);
+    return rc;
+}
+
+int fpx_measure_bandwidth(fpx_ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs)
+{
+    if (!ctx) { set_error("null ctx"); return FPX_E_INVAL; }
+    return measure_bandwidth_impl(reinterpret_cast<Ctx*>(ctx), bytes, block_size, stream_gbs, random_gbs);
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// fpx_internal.h -- declarations shared by the libfpx translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fpx.h"
+
+namespace fpx {
+
+// ---------------------------------------------------------------- device-visible layout
+// One resident file segment as the kernels see it (mirrors the fields FileSegment.search reads,
+// src/FileSegment.zig:33-48, plus two derived acceleration tables).
+struct SegDesc {
+    const uint8_t*  blocks;        // (num_blocks + 1) * block_size bytes, 512-B aligned
+    const uint32_t* block_index;   // max hash per block (src/filefmt.zig:119)
+    const uint32_t* bucket;        // [nbuckets + 1]: lower_bound(block_index, k << bucket_shift)
+    const uint32_t* dead;          // sorted ids of this segment's docs that a newer segment mentions
+    uint32_t num_blocks;
+    uint32_t block_size;
+    uint32_t bucket_shift;         // bucket of hash h = h >> bucket_shift (32 -> one bucket)
+    uint32_t min_doc_id;
+    uint32_t num_dead;
+    uint32_t shadow_lo, shadow_hi; // id range covered by `dead`
+    uint32_t pad;
+};
+
+// One resident memory segment (src/MemorySegment.zig:27-28).
+struct MemDesc {
+    const uint64_t* items;         // hash << 32 | id, sorted
+    const uint32_t* dead;
+    uint64_t num_items;
+    uint32_t num_dead;
+    uint32_t shadow_lo, shadow_hi;
+    uint32_t pad;
+};
+
+// per-batch counters living in device memory (one 64-bit word each)
+enum Counter : int {
+    CTR_HITS = 0,        // hit records appended (may exceed capacity -> rerun with a larger buffer)
+    CTR_CANDS = 1,       // candidate records appended
+    CTR_BLOCKS = 2,      // visited blocks
+    CTR_DOCS = 3,        // matched docs before supersession filtering
+    CTR_BYTES = 4,       // algorithmic bytes
+    CTR_PROBES = 5,      // valid (unique hash, file segment) probes
+    CTR_COUNT = 8
+};
+
+// ---------------------------------------------------------------- host objects
+struct Ctx;
+
+struct Segment {
+    std::atomic<int> refs{1};
+    Ctx* ctx = nullptr;
+    int kind = 0;                  // 0 file, 1 memory, 2 remote (docs only)
+    uint64_t commit_id = 0;
+    uint32_t min_doc_id = 0, max_doc_id = 0;
+    std::vector<uint32_t> doc_ids; // sorted ascending (alive flag irrelevant to search: tombstones supersede too)
+    // file
+    uint8_t* d_blocks = nullptr; size_t blocks_len = 0; uint32_t block_size = 0;
+    uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
+    uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
+    uint64_t num_items = 0;
+    // memory
+    uint64_t* d_items = nullptr;
+    uint64_t device_bytes = 0;
+};
+
+struct Snapshot {
+    std::atomic<int> refs{1};
+    Ctx* ctx = nullptr;
+    std::vector<Segment*> segs;          // retained
+    std::vector<SegDesc> h_file;         // host copies of the descriptors
+    std::vector<MemDesc> h_mem;
+    SegDesc* d_file = nullptr; uint32_t n_file = 0;
+    MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
+    std::vector<uint32_t*> d_dead;       // owned dead lists
+    uint32_t max_block_size = 0;
+};
+
+// Pooled per-call device workspace (analogue of SearchResultsPool, src/common.zig:186-300).
+struct Workspace {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr, ev_end = nullptr;
+    // device buffers (capacity in elements)
+    uint32_t* d_hashes = nullptr; size_t cap_hashes = 0;     // raw concatenated query hashes
+    uint64_t* d_offsets = nullptr; size_t cap_queries = 0;   // [B+1]
+    uint32_t* d_opts = nullptr;                               // [B][4]: max_results, min_score, pct, raw_len
+    uint64_t* d_keys[2] = {nullptr, nullptr}; size_t cap_keys = 0;    // (hash, q) pairs
+    uint64_t* d_hits[2] = {nullptr, nullptr}; size_t cap_hits = 0;    // (q, doc) records
+    uint64_t* d_cands[2] = {nullptr, nullptr}; size_t cap_cands = 0;  // candidate keys
+    void* d_temp = nullptr; size_t cap_temp = 0;              // radix sort temp
+    unsigned long long* d_counters = nullptr;                 // [CTR_COUNT]
+    fpx_result* d_out = nullptr; uint32_t* d_out_n = nullptr; size_t cap_out = 0; // [B*cap], [B]
+    // pinned host staging
+    unsigned long long* h_counters = nullptr;
+};
+
+struct Ctx {
+    int device = 0;
+    std::mutex mu;
+    std::vector<Workspace*> free_ws;
+    std::atomic<int> live_ws{0};
+};
+
+void set_error(const char* fmt, ...);
+int  hip_fail(hipError_t e, const char* what);
+#define FPX_HIP(expr)                                              \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return ::fpx::hip_fail(_e, #expr);   \
+    } while (0)
+
+Workspace* ws_acquire(Ctx* ctx);
+void ws_release(Ctx* ctx, Workspace* ws);
+void ws_destroy(Workspace* ws);
+
+// fpx_sort.hip
+size_t sort_u64_temp_bytes(size_t n, unsigned begin_bit, unsigned end_bit);
+hipError_t sort_u64(void* temp, size_t temp_bytes, uint64_t* buf0, uint64_t* buf1, size_t n,
+                    unsigned begin_bit, unsigned end_bit, hipStream_t stream, int* result_in);
+
+// fpx_search.hip
+int build_bucket_table(Segment* seg, hipStream_t stream);
+int search_batch_impl(Snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
+                      fpx_result* out, uint32_t out_cap, uint32_t* out_n,   // host (final) or device (partial)
+                      fpx_stats* stats);
+int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
+                        uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
+                        fpx_result* out, uint32_t out_cap, uint32_t* out_n);
+int measure_bandwidth_impl(Ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs);
+
+// fpx_api.hip
+int finish_file_segment(Segment* seg);   // bucket table + item count for blocks already in HBM
+
+// fpx_build.hip
+int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist,
+                       uint32_t block_size, uint64_t commit_id, Segment** out);
+
+}  // namespace fpx

@@ -1,0 +1,929 @@
+// fpx_search.hip -- the /_search hot path on MI355X (gfx950, wave64).
+//
+// Reference path being replaced (all CPU, per query, per segment, per hash):
+//   IndexReader.search      src/Index.zig:170-177      sort + dedup, drive segments, finish
+//   FileSegment.search      src/FileSegment.zig:135-180 block_index lower_bound, <=4 blocks / >1000 docs caps
+//   BlockReader.searchHash  src/block.zig:137-158,217-271 StreamVByte 0124 hash decode, equalRange, 1234 docid decode
+//   MemorySegment.search    src/MemorySegment.zig:44-54
+//   SearchResults.incr/finish src/common.zig:121-171  + Segments.hasNewerCommit src/Index.zig:133-149
+//
+// GPU formulation (batch of B queries at once):
+//   1. k_make_keys      (hash, q) pair per query hash, packed hash << QB | q
+//   2. radix sort       all pairs of the batch by (hash, q): duplicates become adjacent (dedup) and
+//                       consecutive probes walk block_index / bucket tables sequentially
+//   3. k_probe          per (pair, file segment): bucket-table + block_index lower_bound, 512-B block ->
+//                       LDS, lane-per-quad StreamVByte decode with half-wave prefix sums, equal-range match,
+//                       ranged docid decode, supersession filter, hits (q, doc) staged in LDS and appended
+//   4. k_probe_mem      per (pair, memory segment): equal_range over sorted items
+//   5. radix sort       hit records by (q, doc); k_rle turns runs into scores, keeps score >= min_score
+//   6. radix sort       candidates by (q, score desc, doc asc); k_finish applies the relative cut-off + top-k
+// Integer gather/scan work: HBM-bound, no MFMA.
+#include <cstring>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+constexpr int WG = 256;            // 4 waves
+constexpr int WAVES = WG / 64;
+constexpr int STAGE_CAP = 2048;    // LDS hit staging per workgroup (records)
+constexpr int STAGE_FLUSH = 1024;
+constexpr int MAX_BLOCKS_PER_HASH = 4;     // src/FileSegment.zig:25
+constexpr int MAX_DOCS_PER_HASH = 1000;    // src/FileSegment.zig:26
+constexpr int MAX_ITEMS_PER_BLOCK = 2048;  // src/block.zig:43
+
+// byte length of the 4 values of one control byte; value i lives in bits 2i..2i+1
+// (src/streamvbyte.zig:178-211).  0124: code c -> c + (c == 3);  1234: code c -> c + 1.
+__device__ __forceinline__ uint32_t len0124(uint32_t c)
+{
+    uint32_t lo = c & 0x55u, hi = (c >> 1) & 0x55u;
+    return __popc(lo) + 2u * __popc(hi) + __popc(lo & hi);
+}
+__device__ __forceinline__ uint32_t len1234(uint32_t c)
+{
+    uint32_t lo = c & 0x55u, hi = (c >> 1) & 0x55u;
+    return 4u + __popc(lo) + 2u * __popc(hi);
+}
+
+// unaligned little-endian u32 from an LDS byte buffer whose base is 4-byte aligned
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t* blk, uint32_t p)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blk) + (p >> 2);
+    uint32_t a = w[0], b = w[1];
+    return __builtin_amdgcn_alignbyte(b, a, p & 3u);
+}
+
+__device__ __forceinline__ uint32_t keep_bytes(uint32_t raw, uint32_t nb)
+{
+    return nb >= 4u ? raw : (raw & ((1u << (8u * nb)) - 1u));
+}
+
+// inclusive prefix sum inside each 32-lane half of the wave
+__device__ __forceinline__ uint32_t scan32(uint32_t v, uint32_t sl)
+{
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 32);
+        if (sl >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32_t lo_id, uint32_t hi_id, uint32_t d)
+{
+    if (n == 0 || d < lo_id || d > hi_id) return false;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t m = (lo + hi) >> 1;
+        if (dead[m] < d) lo = m + 1; else hi = m;
+    }
+    return lo < n && dead[lo] == d;
+}
+
+// first block whose max hash >= h (src/FileSegment.zig:145-151); the reference restricts the search
+// to block_index[prev..], which returns the same block because the query hashes ascend.
+__device__ __forceinline__ uint32_t lookup_block(const SegDesc& s, uint32_t h)
+{
+    uint32_t k = s.bucket_shift >= 32u ? 0u : (h >> s.bucket_shift);
+    uint32_t lo = s.bucket[k], hi = s.bucket[k + 1];
+    while (lo < hi) {
+        uint32_t m = (lo + hi) >> 1;
+        if (s.block_index[m] < h) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. keys
+// ------------------------------------------------------------------------------------------------
+__global__ void k_make_keys(const uint32_t* __restrict__ hashes, const uint64_t* __restrict__ offsets,
+                            uint32_t B, uint32_t qb, uint64_t* __restrict__ keys)
+{
+    // one workgroup per query
+    uint32_t q = blockIdx.x;
+    if (q >= B) return;
+    uint64_t lo = offsets[q], hi = offsets[q + 1];
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+        keys[i] = ((uint64_t)hashes[i] << qb) | q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. file-segment probe kernel (the dominant kernel)
+// ------------------------------------------------------------------------------------------------
+struct ProbeArgs {
+    const SegDesc* segs;
+    const uint64_t* pairs;     // sorted (hash << qb | q)
+    uint64_t P;
+    uint32_t qb;
+    uint32_t ppw;              // pairs per wave per round (even, <= 64)
+    uint32_t rounds;
+    uint32_t bsp;              // LDS bytes reserved per staged block (max block_size + 16)
+    uint64_t* hits;            // (q << 32 | doc)
+    uint64_t hit_cap;
+    unsigned long long* counters;
+};
+
+__global__ __launch_bounds__(WG) void k_probe(ProbeArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);                  // STAGE_CAP records
+    uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t);                // WAVES * 2 * bsp bytes
+    __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_bytes;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, half = lane >> 5, sl = lane & 31u;
+    const SegDesc seg = a.segs[blockIdx.y];
+    uint8_t* blk = blkmem + (size_t)(wave * 2u + half) * a.bsp;
+    const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
+
+    if (tid == 0) {
+        stage_count = 0; stage_valid = STAGE_CAP;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_bytes = 0;
+    }
+    __syncthreads();
+
+    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
+
+    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(WAVES * a.ppw) * a.rounds;
+    for (uint32_t round = 0; round < a.rounds; ++round) {
+        // ---- phase 1: one lane per pair: dedup + block lookup
+        uint64_t p = wg_base + (uint64_t)round * (WAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
+        bool valid = lane < a.ppw && p < a.P;
+        uint64_t key = valid ? a.pairs[p] : 0ull;
+        if (valid && p > 0 && a.pairs[p - 1] == key) valid = false;      // dedupSorted, src/Index.zig:489-499
+        uint32_t h = (uint32_t)(key >> a.qb);
+        uint32_t q = (uint32_t)key & qmask;
+        uint32_t b0 = seg.num_blocks;
+        if (valid) {
+            my_probes += 1;
+            b0 = lookup_block(seg, h);
+        }
+        if (b0 >= seg.num_blocks) valid = false;
+
+        // ---- phase 2: two probes per iteration, one per 32-lane half
+        const uint32_t iters = (a.ppw + 1u) >> 1;
+        for (uint32_t it = 0; it < iters; ++it) {
+            const int src = (int)(it * 2u + half);
+            const uint32_t ph = __shfl(h, src);
+            const uint32_t pq = __shfl(q, src);
+            uint32_t pb = __shfl(b0, src);
+            bool pact = __shfl((int)valid, src) != 0;
+            uint32_t nbv = 0, ndv = 0;
+
+            while (__any(pact)) {
+                uint32_t kf = 0;                 // bit k: value k of my quad is a kept match
+                uint32_t dd[4] = {0, 0, 0, 0};
+                bool cont = false;
+                if (pact) {
+                    // -- stage the block in LDS (coalesced 16-B loads: the half-wave reads 512 contiguous bytes)
+                    const uint8_t* src_blk = seg.blocks + (size_t)pb * seg.block_size;
+                    if ((seg.block_size & 15u) == 0u) {
+                        for (uint32_t o = sl * 16u; o < seg.block_size; o += 512u)
+                            *reinterpret_cast<uint4*>(blk + o) = *reinterpret_cast<const uint4*>(src_blk + o);
+                    } else {
+                        for (uint32_t o = sl; o < seg.block_size; o += 32u) blk[o] = src_blk[o];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // -- header (src/block.zig:46-50)
+                    const uint32_t* hw = reinterpret_cast<const uint32_t*>(blk);
+                    const uint32_t min_hash = hw[0];
+                    uint32_t n_items = hw[1] & 0xFFFFu;
+                    const uint32_t doff = hw[1] >> 16;
+                    if (n_items > (uint32_t)MAX_ITEMS_PER_BLOCK) n_items = MAX_ITEMS_PER_BLOCK;
+                    if (min_hash > ph) {
+                        // src/FileSegment.zig:164 -- the hash falls in the gap before this block: not visited
+                    } else {
+                        const uint32_t nq = (n_items + 3u) >> 2;
+                        const uint32_t hdata = 8u + nq;                 // hash data starts after nq control bytes
+                        const uint32_t dctrl = 8u + doff;               // docid control bytes
+                        const uint32_t ddata = dctrl + nq;
+                        const uint32_t limit = a.bsp - 8u;              // keep corrupt offsets inside the staging slot
+                        uint32_t hoff_carry = 0, hval_carry = 0, xcarry = 0, cnt = 0;
+                        for (uint32_t c0 = 0; c0 < nq; c0 += 32u) {
+                            const uint32_t qi = c0 + sl;
+                            const bool act = qi < nq;
+                            // ---- hashes: 0124 + delta (src/block.zig:137-158, src/streamvbyte.zig:264-283)
+                            const uint32_t hc = act ? blk[8u + qi] : 0u;
+                            const uint32_t hl = len0124(hc);
+                            const uint32_t hincl = scan32(hl, sl);
+                            uint32_t pp = min(hdata + hoff_carry + hincl - hl, limit);
+                            hoff_carry += __shfl(hincl, 31, 32);
+                            uint32_t v[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const uint32_t code = (hc >> (2 * k)) & 3u;
+                                const uint32_t nb = code + (code == 3u ? 1u : 0u);
+                                v[k] = keep_bytes(lds_u32(blk, pp), nb);
+                                pp = min(pp + nb, limit);
+                            }
+                            v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+                            const uint32_t vincl = scan32(v[3], sl);
+                            const uint32_t base = min_hash + hval_carry + vincl - v[3];
+                            hval_carry += __shfl(vincl, 31, 32);
+                            // ---- equalRange (src/block.zig:217-231): matches form one contiguous run
+                            uint32_t e = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (qi * 4u + (uint32_t)k < n_items && base + v[k] == ph) e |= 1u << k;
+                            const bool any_e = __any((int)(e != 0u)) != 0;   // wave-level; halves checked below
+                            if (any_e) {
+                                // ---- docids of the run: 1234, no delta, then prefix sum seeded with min_doc_id
+                                //      (src/block.zig:235-265, src/streamvbyte.zig:287-339)
+                                uint32_t dbase = 0;
+                                if (c0 != 0u) {
+                                    // data bytes of all earlier quads of this block
+                                    uint32_t s = 0;
+                                    for (uint32_t j = sl; j < c0; j += 32u) s += len1234(blk[dctrl + j]);
+                                    s = scan32(s, sl);
+                                    dbase = __shfl(s, 31, 32);
+                                }
+                                const uint32_t dc = act ? blk[min(dctrl + qi, limit)] : 0u;
+                                const uint32_t dl = act ? len1234(dc) : 0u;
+                                const uint32_t dincl = scan32(dl, sl);
+                                uint32_t dp = min(ddata + dbase + dincl - dl, limit);
+                                uint32_t x[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const uint32_t nb = ((dc >> (2 * k)) & 3u) + 1u;
+                                    const uint32_t raw = keep_bytes(lds_u32(blk, dp), nb);
+                                    x[k] = ((e >> k) & 1u) ? raw : 0u;
+                                    dp = min(dp + nb, limit);
+                                }
+                                x[1] += x[0]; x[2] += x[1]; x[3] += x[2];
+                                const uint32_t xincl = scan32(x[3], sl);
+                                const uint32_t xb = seg.min_doc_id + xcarry + xincl - x[3];
+                                xcarry += __shfl(xincl, 31, 32);
+                                uint32_t ecount = scan32(__popc(e), sl);
+                                cnt += __shfl(ecount, 31, 32);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    if ((e >> k) & 1u) {
+                                        const uint32_t d = xb + x[k];
+                                        // supersession (src/common.zig:158 + src/Index.zig:133-149), applied per posting
+                                        if (!is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, d)) {
+                                            kf |= 1u << k;
+                                            dd[k] = d;
+                                        }
+                                    }
+                                }
+                            }
+                            // blocks with more than 128 items (rare at 512 B): every chunk but the last hands its
+                            // matches to the staging buffer lane by lane, the last one uses the ballot path below
+                            if (c0 + 32u < nq && kf != 0u) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    if ((kf >> k) & 1u) {
+                                        const uint64_t rec = ((uint64_t)pq << 32) | dd[k];
+                                        const uint32_t pos = atomicAdd(&stage_count, 1u);
+                                        if (pos < (uint32_t)STAGE_CAP) {
+                                            stage[pos] = rec;
+                                        } else {
+                                            atomicMin(&stage_valid, pos);
+                                            unsigned long long g = atomicAdd(&a.counters[CTR_HITS], 1ull);
+                                            if (g < a.hit_cap) a.hits[g] = rec;
+                                        }
+                                    }
+                                }
+                                kf = 0;
+                            }
+                        }
+                        // ---- caps (src/FileSegment.zig:171-174)
+                        nbv += 1;
+                        ndv += cnt;
+                        const bool more = nbv < (uint32_t)MAX_BLOCKS_PER_HASH && ndv <= (uint32_t)MAX_DOCS_PER_HASH &&
+                                          pb + 1u < seg.num_blocks;
+                        // the next block can only start with ph if this block ends with ph
+                        if (more && seg.block_index[pb] == ph) cont = true;
+                        if (sl == 0) { my_blocks += 1; my_docs += cnt; }
+                    }
+                }
+                pact = cont;
+                pb += 1;
+
+                // ---- emission of this iteration's kept matches (wave-uniform control flow)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long m = __ballot((int)((kf >> k) & 1u));
+                    if (m == 0ull) continue;
+                    const uint32_t total = __popcll(m);
+                    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+                    uint32_t pos = 0;
+                    if (lane == 0) pos = atomicAdd(&stage_count, total);
+                    pos = __shfl(pos, 0);
+                    if (pos + total <= (uint32_t)STAGE_CAP) {
+                        if ((kf >> k) & 1u) stage[pos + rank] = ((uint64_t)pq << 32) | dd[k];
+                    } else {
+                        // staging full: remember where the valid prefix ends and append directly
+                        if (lane == 0) atomicMin(&stage_valid, pos);
+                        unsigned long long g = 0;
+                        if (lane == 0) g = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+                        g = __shfl(g, 0);
+                        if (((kf >> k) & 1u) && g + rank < a.hit_cap) a.hits[g + rank] = ((uint64_t)pq << 32) | dd[k];
+                    }
+                }
+            }
+        }
+
+        // ---- flush the LDS staging buffer at round boundaries
+        __syncthreads();
+        const uint32_t sc = stage_count;
+        const bool last = (round + 1u == a.rounds);
+        if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
+            const uint32_t n = min(sc, stage_valid);
+            if (tid == 0) {
+                unsigned long long g = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
+                flush_base_lo = (uint32_t)g; flush_base_hi = (uint32_t)(g >> 32);
+            }
+            __syncthreads();
+            const unsigned long long g = ((unsigned long long)flush_base_hi << 32) | flush_base_lo;
+            for (uint32_t i = tid; i < n; i += WG)
+                if (g + i < a.hit_cap) a.hits[g + i] = stage[i];
+            __syncthreads();
+            if (tid == 0) { stage_count = 0; stage_valid = STAGE_CAP; }
+        }
+        __syncthreads();
+    }
+
+    // ---- per-workgroup statistics (fpindex_scanned_blocks_per_hash / _docs_per_hash totals)
+    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
+    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
+    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    __syncthreads();
+    if (tid == 0) {
+        if (wg_blocks) {
+            atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks);
+            atomicAdd(&a.counters[CTR_BYTES], wg_blocks * (unsigned long long)seg.block_size);
+        }
+        if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
+        if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. memory segments (src/MemorySegment.zig:44-54): equal_range on hash over sorted u64 items, no caps
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uint64_t* __restrict__ pairs, uint64_t P,
+                                                   uint32_t qb, uint64_t* hits, uint64_t hit_cap,
+                                                   unsigned long long* counters)
+{
+    const MemDesc ms = mems[blockIdx.y];
+    const uint64_t p = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
+    if (p >= P) return;
+    const uint64_t key = pairs[p];
+    if (p > 0 && pairs[p - 1] == key) return;
+    const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
+    uint64_t lo = 0, hi = ms.num_items;
+    while (lo < hi) {
+        uint64_t m = (lo + hi) >> 1;
+        if ((uint32_t)(ms.items[m] >> 32) < h) lo = m + 1; else hi = m;
+    }
+    for (uint64_t i = lo; i < ms.num_items; ++i) {
+        const uint64_t it = ms.items[i];
+        if ((uint32_t)(it >> 32) != h) break;
+        const uint32_t d = (uint32_t)it;
+        if (is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, d)) continue;
+        unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+        if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5. run-length scoring: sorted (q, doc) records -> candidates with score >= min_score[q]
+//    (SearchResults.incr + the min_score filter of finish, src/common.zig:121-145)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_rle(const uint64_t* __restrict__ hits, uint64_t H, const uint32_t* __restrict__ opts,
+                                             uint32_t sb, uint64_t* cands, uint64_t cand_cap, unsigned long long* counters)
+{
+    __shared__ uint32_t wg_n;
+    __shared__ unsigned long long wg_base;
+    if (threadIdx.x == 0) wg_n = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t ckey = 0;
+    bool is_cand = false;
+    if (i < H) {
+        const uint64_t rec = hits[i];
+        if (i == 0 || hits[i - 1] != rec) {
+            uint64_t len = 1;
+            while (i + len < H && hits[i + len] == rec) ++len;
+            const uint32_t q = (uint32_t)(rec >> 32), d = (uint32_t)rec;
+            const uint32_t min_score = opts[q * 4u + 1u];
+            if (len >= (uint64_t)min_score) {
+                const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
+                const uint64_t sc = len > smax ? smax : len;
+                ckey = ((uint64_t)q << (32u + sb)) | ((smax - sc) << 32) | d;
+                is_cand = true;
+            }
+        }
+    }
+    uint32_t slot = 0;
+    if (is_cand) slot = atomicAdd(&wg_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_n) wg_base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)wg_n);
+    __syncthreads();
+    if (is_cand && wg_base + slot < cand_cap) cands[wg_base + slot] = ckey;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 6. finish: per query, candidates sorted by (score desc, id asc); relative cut-off anchored on the
+//    best score; truncate to max_results (src/common.zig:147-167)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const uint32_t* __restrict__ opts, uint32_t B,
+                         uint32_t sb, int partial, fpx_result* out, uint32_t out_cap, uint32_t* out_n)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B) return;
+    const uint32_t max_results = opts[q * 4u + 0u];
+    uint32_t min_score = opts[q * 4u + 1u];
+    const uint32_t pct = opts[q * 4u + 2u];
+    const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
+    const uint64_t qkey = (uint64_t)q << (32u + sb);
+    uint64_t lo = 0, hi = C;
+    while (lo < hi) {
+        uint64_t m = (lo + hi) >> 1;
+        if (cands[m] < qkey) lo = m + 1; else hi = m;
+    }
+    uint32_t n = 0;
+    for (uint64_t i = lo; i < C; ++i) {
+        const uint64_t k = cands[i];
+        if ((k >> (32u + sb)) != (uint64_t)q) break;
+        if (n == max_results) break;
+        const uint32_t score = (uint32_t)(smax - ((k >> 32) & smax));
+        if (score < min_score) break;
+        if (n == 0 && !partial) {
+            const uint32_t rel = (uint32_t)((uint64_t)score * pct / 100ull);
+            if (rel > min_score) min_score = rel;
+        }
+        if (n < out_cap) { out[(size_t)q * out_cap + n].id = (uint32_t)k; out[(size_t)q * out_cap + n].score = score; }
+        ++n;
+    }
+    out_n[q] = n < out_cap ? n : out_cap;
+}
+
+// merge `world` per-rank tables (each sorted by score desc, id asc, disjoint doc ownership)
+__global__ void k_merge(const fpx_result* __restrict__ parts, const uint32_t* __restrict__ counts, uint32_t world,
+                        uint32_t B, uint32_t part_cap, const uint32_t* __restrict__ opts,
+                        fpx_result* out, uint32_t out_cap, uint32_t* out_n)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B) return;
+    const uint32_t max_results = opts[q * 4u + 0u];
+    uint32_t min_score = opts[q * 4u + 1u];
+    const uint32_t pct = opts[q * 4u + 2u];
+    uint32_t n = 0;
+    // k-way merge with per-rank cursors kept implicitly: pick the best head > last emitted
+    uint64_t last = ~0ull;   // key of the last emitted entry: (score << 32 | ~id), descending order
+    bool first = true;
+    for (;;) {
+        if (n == max_results) break;
+        uint64_t best = 0; bool have = false;
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint32_t cnt = counts[(size_t)r * B + q];
+            const fpx_result* t = parts + ((size_t)r * B + q) * part_cap;
+            // lists are short (<= max_results): linear scan for the first entry ordered after `last`
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t k = ((uint64_t)t[i].score << 32) | (uint32_t)(~t[i].id);
+                if (first || k < last) {
+                    if (!have || k > best) { best = k; have = true; }
+                    break;   // list is sorted descending by k: the first qualifying entry is the best of this rank
+                }
+            }
+        }
+        if (!have) break;
+        const uint32_t score = (uint32_t)(best >> 32), id = ~(uint32_t)best;
+        if (score < min_score) break;
+        if (n == 0) {
+            const uint32_t rel = (uint32_t)((uint64_t)score * pct / 100ull);
+            if (rel > min_score) min_score = rel;
+        }
+        if (n < out_cap) { out[(size_t)q * out_cap + n].id = id; out[(size_t)q * out_cap + n].score = score; }
+        ++n;
+        last = best; first = false;
+    }
+    out_n[q] = n < out_cap ? n : out_cap;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bucket table: bucket[k] = lower_bound(block_index, k << shift), bucket[nb] = num_blocks
+// ------------------------------------------------------------------------------------------------
+__global__ void k_build_buckets(const uint32_t* __restrict__ block_index, uint32_t num_blocks, uint32_t shift,
+                                uint32_t nbuckets, uint32_t* __restrict__ bucket)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nbuckets) return;
+    if (k == nbuckets) { bucket[k] = num_blocks; return; }
+    const uint32_t h = shift >= 32u ? 0u : (k << shift);
+    uint32_t lo = 0, hi = num_blocks;
+    while (lo < hi) {
+        uint32_t m = (lo + hi) >> 1;
+        if (block_index[m] < h) lo = m + 1; else hi = m;
+    }
+    bucket[k] = lo;
+}
+
+int build_bucket_table(Segment* seg, hipStream_t stream)
+{
+    // ~8 blocks per bucket; at least one bucket
+    uint32_t bits = 0;
+    while (bits < 24u && (1ull << (bits + 3)) < (uint64_t)seg->num_blocks) ++bits;
+    seg->num_buckets = 1u << bits;
+    seg->bucket_shift = 32u - bits;
+    FPX_HIP(hipMalloc(&seg->d_bucket, ((size_t)seg->num_buckets + 1) * sizeof(uint32_t)));
+    seg->device_bytes += ((size_t)seg->num_buckets + 1) * sizeof(uint32_t);
+    const uint32_t n = seg->num_buckets + 1;
+    hipLaunchKernelGGL(k_build_buckets, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       seg->d_block_index, seg->num_blocks, seg->bucket_shift, seg->num_buckets, seg->d_bucket);
+    FPX_HIP(hipGetLastError());
+    return FPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+template <class T>
+static int grow(T** p, size_t* cap, size_t need, size_t slack_num = 5, size_t slack_den = 4)
+{
+    if (need <= *cap) return FPX_OK;
+    size_t ncap = need * slack_num / slack_den + 64;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), ncap * sizeof(T));
+    if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", ncap * sizeof(T), hipGetErrorString(e)); return FPX_E_NOMEM; }
+    *cap = ncap;
+    return FPX_OK;
+}
+
+static int grow_pair(uint64_t* p[2], size_t* cap, size_t need)
+{
+    if (need <= *cap) return FPX_OK;
+    size_t c0 = *cap, c1 = *cap;
+    int rc = grow(&p[0], &c0, need);
+    if (rc) return rc;
+    rc = grow(&p[1], &c1, need);
+    if (rc) return rc;
+    *cap = std::min(c0, c1);
+    return FPX_OK;
+}
+
+static unsigned bits_for(uint64_t n)   // number of bits needed to represent values in [0, n)
+{
+    unsigned b = 0;
+    while (b < 64 && (1ull << b) < n) ++b;
+    return b;
+}
+
+// per-query arrays (offsets, options, result counts) share one capacity
+static int ensure_queries(Workspace* ws, size_t B)
+{
+    if (B + 1 <= ws->cap_queries && ws->d_offsets && ws->d_opts && ws->d_out_n) return FPX_OK;
+    const size_t cap = (B + 1) * 5 / 4 + 64;
+    if (ws->d_offsets) (void)hipFree(ws->d_offsets);
+    if (ws->d_opts) (void)hipFree(ws->d_opts);
+    if (ws->d_out_n) (void)hipFree(ws->d_out_n);
+    ws->d_offsets = nullptr; ws->d_opts = nullptr; ws->d_out_n = nullptr; ws->cap_queries = 0;
+    if (hipMalloc(&ws->d_offsets, cap * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc(&ws->d_opts, cap * 4 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&ws->d_out_n, cap * sizeof(uint32_t)) != hipSuccess) {
+        set_error("hipMalloc(query arrays) failed");
+        return FPX_E_NOMEM;
+    }
+    ws->cap_queries = cap;
+    return FPX_OK;
+}
+
+static void fill_opts(std::vector<uint32_t>& h_opts, const fpx_opts* opts, const uint64_t* offsets, uint32_t B)
+{
+    h_opts.resize((size_t)B * 4);
+    for (uint32_t q = 0; q < B; ++q) {
+        const uint64_t raw_len = offsets[q + 1] - offsets[q];
+        h_opts[q * 4 + 0] = opts[q].max_results;
+        // src/MultiIndex.zig:304: the default floor uses the RAW query length (before dedup)
+        h_opts[q * 4 + 1] = opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20);
+        h_opts[q * 4 + 2] = opts[q].min_score_pct;
+        h_opts[q * 4 + 3] = (uint32_t)raw_len;
+    }
+}
+
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch driver
+// ------------------------------------------------------------------------------------------------
+static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                     const fpx_opts* opts, uint32_t timeout_ms, bool partial,
+                     fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+{
+    const double t_start = now_ms();
+    hipStream_t st = ws->stream;
+    const uint64_t P = offsets[B];
+    uint64_t max_len = 1;
+    for (uint32_t q = 0; q < B; ++q) max_len = std::max<uint64_t>(max_len, offsets[q + 1] - offsets[q]);
+    const unsigned qb = bits_for(B);            // q in [0, B)
+    const unsigned sb = bits_for(max_len + 1);  // score in [0, max_len]
+    if (qb + sb > 32) { set_error("batch too large for one pass (qb=%u sb=%u)", qb, sb); return FPX_E_INVAL; }
+
+    // ---- upload the batch
+    int rc;
+    if ((rc = grow(&ws->d_hashes, &ws->cap_hashes, (size_t)P + 1))) return rc;
+    if ((rc = ensure_queries(ws, B))) return rc;
+    if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
+    if (!partial && (rc = grow(&ws->d_out, &ws->cap_out, (size_t)B * out_cap + 1))) return rc;
+    static_assert(sizeof(fpx_result) == 8, "fpx_result layout");
+    for (uint32_t q = 0; q < B; ++q)
+        if (opts[q].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
+    std::vector<uint32_t> h_opts;
+    fill_opts(h_opts, opts, offsets, B);
+    FPX_HIP(hipEventRecord(ws->ev_begin, st));
+    if (P) FPX_HIP(hipMemcpyAsync(ws->d_hashes, hashes, P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    FPX_HIP(hipMemcpyAsync(ws->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    FPX_HIP(hipMemcpyAsync(ws->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+
+    // ---- 1+2: keys, sort by (hash, q)
+    int kcur = 0;
+    if (P) {
+        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, ws->d_hashes, ws->d_offsets, B, qb, ws->d_keys[0]);
+        const size_t tb = sort_u64_temp_bytes(P, 0, 32 + qb);
+        if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
+        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, 0, 32 + qb, st, &kcur));
+    }
+    const uint64_t* d_pairs = ws->d_keys[kcur];
+
+    // ---- 3+4: probes (rerun with a larger hit buffer on overflow)
+    uint64_t H = 0;
+    float probe_ms = 0.f;
+    uint32_t probe_launches = 0;
+    if (ws->cap_hits == 0) {
+        size_t want = std::max<size_t>(1u << 20, (size_t)P * std::max<uint32_t>(1u, snap->n_file + snap->n_mem));
+        if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, want))) return rc;
+    }
+    for (int attempt = 0;; ++attempt) {
+        FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+        if (P && snap->n_file) {
+            ProbeArgs a;
+            a.segs = snap->d_file; a.pairs = d_pairs; a.P = P; a.qb = qb;
+            // enough workgroups to fill 256 CUs; long per-wave runs amortise the index walk for big batches
+            const uint64_t total = P * snap->n_file;
+            a.ppw = total >= (1ull << 22) ? 64u : total >= (1ull << 18) ? 16u : 4u;
+            a.rounds = total >= (1ull << 24) ? 4u : 1u;
+            a.bsp = ((snap->max_block_size + 15u) & ~15u) + 16u;
+            a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
+            const uint64_t per_wg = (uint64_t)WAVES * a.ppw * a.rounds;
+            const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
+            const size_t lds = STAGE_CAP * sizeof(uint64_t) + (size_t)WAVES * 2 * a.bsp;
+            FPX_HIP(hipEventRecord(ws->ev_probe0, st));
+            hipLaunchKernelGGL(k_probe, dim3(gx, snap->n_file), dim3(WG), lds, st, a);
+            FPX_HIP(hipEventRecord(ws->ev_probe1, st));
+            FPX_HIP(hipGetLastError());
+            probe_launches += 1;
+        }
+        if (P && snap->n_mem) {
+            hipLaunchKernelGGL(k_probe_mem, dim3((uint32_t)((P + WG - 1) / WG), snap->n_mem), dim3(WG), 0, st,
+                               snap->d_mem, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
+            FPX_HIP(hipGetLastError());
+        }
+        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (P && snap->n_file) {
+            float ms = 0.f;
+            FPX_HIP(hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1));
+            probe_ms += ms;
+        }
+        H = ws->h_counters[CTR_HITS];
+        if (H <= ws->cap_hits) break;
+        if (attempt >= 2) { set_error("hit buffer overflow persists (%llu records)", (unsigned long long)H); return FPX_E_DEVICE; }
+        if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
+    }
+    if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
+    const unsigned long long c_blocks = ws->h_counters[CTR_BLOCKS], c_docs = ws->h_counters[CTR_DOCS],
+                             c_bytes = ws->h_counters[CTR_BYTES], c_probes = ws->h_counters[CTR_PROBES];
+
+    // ---- 5: sort hits by (q, doc), run-length score, keep score >= min_score
+    uint64_t C = 0;
+    int ccur = 0;
+    if (H) {
+        int hcur = 0;
+        const size_t tb = sort_u64_temp_bytes(H, 0, 32 + qb);
+        if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
+        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_hits[0], ws->d_hits[1], H, 0, 32 + qb, st, &hcur));
+        if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);   // keep the convention: d_hits[0] holds the data
+        if (ws->cap_cands == 0) {
+            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, std::max<size_t>(1u << 16, (size_t)B * 64)))) return rc;
+        }
+        for (int attempt = 0;; ++attempt) {
+            FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_rle, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st,
+                               ws->d_hits[0], H, ws->d_opts, sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_CANDS], &ws->d_counters[CTR_CANDS], sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipStreamSynchronize(st));
+            C = ws->h_counters[CTR_CANDS];
+            if (C <= ws->cap_cands) break;
+            if (attempt >= 2) { set_error("candidate buffer overflow persists"); return FPX_E_DEVICE; }
+            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, (size_t)C + 1024))) return rc;
+        }
+        // ---- 6: sort candidates by (q, score desc, id asc)
+        if (C) {
+            const size_t tb2 = sort_u64_temp_bytes(C, 0, 32 + sb + qb);
+            if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb2 + 256))) return rc;
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_cands[0], ws->d_cands[1], C, 0, 32 + sb + qb, st, &ccur));
+        }
+    }
+    if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
+
+    // ---- finish
+    fpx_result* d_res = partial ? out : ws->d_out;
+    uint32_t* d_res_n = partial ? out_n : ws->d_out_n;
+    hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
+                       (const uint64_t*)ws->d_cands[ccur], C, ws->d_opts, B, sb, partial ? 1 : 0, d_res, out_cap, d_res_n);
+    FPX_HIP(hipGetLastError());
+    if (!partial) {
+        FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+    }
+    FPX_HIP(hipEventRecord(ws->ev_end, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
+
+    if (stats) {
+        float total_ms = 0.f;
+        (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
+        stats->probes += c_probes;
+        stats->scanned_blocks += c_blocks;
+        stats->scanned_docs += c_docs;
+        stats->hits += H;
+        stats->algorithmic_bytes += c_bytes;
+        stats->candidates += C;
+        stats->probe_kernel_ms += probe_ms;
+        stats->total_gpu_ms += total_ms;
+        stats->probe_launches += probe_launches;
+    }
+    return FPX_OK;
+}
+
+int search_batch_impl(Snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
+                      fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+{
+    if (!snap || !offsets || !opts || !out_n || (!out && out_cap) || (B && offsets[B] && !hashes)) {
+        set_error("null argument"); return FPX_E_INVAL;
+    }
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (B == 0) return FPX_OK;
+    for (uint32_t q = 0; q < B; ++q)
+        if (offsets[q + 1] < offsets[q]) { set_error("offsets must be non-decreasing"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(snap->ctx->device));
+
+    // split batches whose (query index, score) bits do not fit one 64-bit candidate key
+    uint64_t max_len = 1;
+    for (uint32_t q = 0; q < B; ++q) max_len = std::max<uint64_t>(max_len, offsets[q + 1] - offsets[q]);
+    if (max_len >= (1ull << 32)) { set_error("query longer than 2^32-1 hashes"); return FPX_E_INVAL; }
+    if (bits_for(B) + bits_for(max_len + 1) > 32 && B > 1) {
+        const uint32_t half = B / 2;
+        std::vector<uint64_t> off2(B - half + 1);
+        for (uint32_t q = half; q <= B; ++q) off2[q - half] = offsets[q] - offsets[half];
+        fpx_stats s1{}, s2{};
+        int rc = search_batch_impl(snap, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, &s1);
+        if (rc) return rc;
+        fpx_result* out2 = out ? out + (size_t)half * out_cap : out;
+        rc = search_batch_impl(snap, hashes + offsets[half], off2.data(), B - half, opts + half, timeout_ms, partial,
+                               out2, out_cap, out_n + half, &s2);
+        if (rc) return rc;
+        if (stats) {
+            stats->probes = s1.probes + s2.probes; stats->scanned_blocks = s1.scanned_blocks + s2.scanned_blocks;
+            stats->scanned_docs = s1.scanned_docs + s2.scanned_docs; stats->hits = s1.hits + s2.hits;
+            stats->algorithmic_bytes = s1.algorithmic_bytes + s2.algorithmic_bytes;
+            stats->candidates = s1.candidates + s2.candidates;
+            stats->probe_kernel_ms = s1.probe_kernel_ms + s2.probe_kernel_ms;
+            stats->total_gpu_ms = s1.total_gpu_ms + s2.total_gpu_ms;
+            stats->probe_launches = s1.probe_launches + s2.probe_launches;
+        }
+        return FPX_OK;
+    }
+
+    Workspace* ws = ws_acquire(snap->ctx);
+    if (!ws) return FPX_E_NOMEM;
+    int rc = run_batch(snap, ws, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    ws_release(snap->ctx, ws);
+    return rc;
+}
+
+int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
+                        uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
+                        fpx_result* out, uint32_t out_cap, uint32_t* out_n)
+{
+    if (!ctx || !d_parts || !d_counts || !opts || !offsets || !out_n) { set_error("null argument"); return FPX_E_INVAL; }
+    if (B == 0) return FPX_OK;
+    FPX_HIP(hipSetDevice(ctx->device));
+    Workspace* ws = ws_acquire(ctx);
+    if (!ws) return FPX_E_NOMEM;
+    int rc = FPX_OK;
+    auto body = [&]() -> int {
+        int r;
+        if ((r = ensure_queries(ws, B))) return r;
+        if ((r = grow(&ws->d_out, &ws->cap_out, (size_t)B * out_cap + 1))) return r;
+        std::vector<uint32_t> h_opts;
+        fill_opts(h_opts, opts, offsets, B);
+        hipStream_t st = ws->stream;
+        FPX_HIP(hipMemcpyAsync(ws->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_merge, dim3((B + 127) / 128), dim3(128), 0, st,
+                           (const fpx_result*)d_parts, (const uint32_t*)d_counts, world, B, part_cap, ws->d_opts,
+                           ws->d_out, out_cap, ws->d_out_n);
+        FPX_HIP(hipGetLastError());
+        FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (out_cap) FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        return FPX_OK;
+    };
+    rc = body();
+    ws_release(ctx, ws);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bandwidth probes (denominators for the roofline report)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bw_stream(const uint4* __restrict__ src, size_t n16, unsigned long long* sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);
+}
+
+// every half-wave reads one random block_size-byte block per step (the access pattern of k_probe)
+__global__ __launch_bounds__(256) void k_bw_random(const uint8_t* __restrict__ src, uint64_t nblocks, uint32_t block_size,
+                                                   uint32_t steps, unsigned long long* sink)
+{
+    const uint32_t lane = threadIdx.x & 31u;
+    const uint64_t hw = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    uint32_t acc = 0;
+    uint64_t x = hw * 0x9E3779B97F4A7C15ull + 12345;
+    for (uint32_t s = 0; s < steps; ++s) {
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        const uint64_t b = x % nblocks;
+        for (uint32_t o = lane * 16u; o < block_size; o += 512u) {
+            uint4 v = *reinterpret_cast<const uint4*>(src + b * block_size + o);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);
+}
+
+int measure_bandwidth_impl(Ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs)
+{
+    FPX_HIP(hipSetDevice(ctx->device));
+    if (block_size < 64 || (block_size & 15u)) { set_error("block_size must be a multiple of 16"); return FPX_E_INVAL; }
+    bytes = bytes / 4096 * 4096;
+    if (bytes < (1u << 20)) { set_error("buffer too small"); return FPX_E_INVAL; }
+    uint8_t* buf = nullptr; unsigned long long* sink = nullptr;
+    FPX_HIP(hipMalloc(&buf, bytes));
+    FPX_HIP(hipMalloc(&sink, 8));
+    FPX_HIP(hipMemset(buf, 0x5a, bytes));
+    FPX_HIP(hipMemset(sink, 0, 8));
+    hipEvent_t e0, e1;
+    FPX_HIP(hipEventCreate(&e0)); FPX_HIP(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {      // first pass warms up
+        FPX_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bw_stream, dim3(256 * 8), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);
+        FPX_HIP(hipEventRecord(e1, 0));
+        FPX_HIP(hipEventSynchronize(e1));
+        FPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    }
+    if (stream_gbs) *stream_gbs = (double)bytes / (ms * 1e-3) / 1e9;
+    const uint64_t nblocks = bytes / block_size;
+    const uint32_t steps = 64;
+    const uint32_t grid = 256 * 16;
+    const double rbytes = (double)grid * (256 / 32) * steps * block_size;
+    for (int rep = 0; rep < 2; ++rep) {
+        FPX_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_bw_random, dim3(grid), dim3(256), 0, 0, (const uint8_t*)buf, nblocks, block_size, steps, sink);
+        FPX_HIP(hipEventRecord(e1, 0));
+        FPX_HIP(hipEventSynchronize(e1));
+        FPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    }
+    if (random_gbs) *random_gbs = rbytes / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(buf); (void)hipFree(sink);
+    return FPX_OK;
+}
+
+}  // namespace fpx

@@ -1,0 +1,31 @@
+// fpx_sort.hip -- device radix sort of 64-bit keys used by the batch pipeline
+// (query (hash,q) pairs, (q,doc) hit records, candidate keys).  Thin wrapper over
+// rocPRIM's device radix sort so the slow-to-compile header stays in its own TU.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "fpx_internal.h"
+
+namespace fpx {
+
+size_t sort_u64_temp_bytes(size_t n, unsigned begin_bit, unsigned end_bit)
+{
+    size_t bytes = 0;
+    rocprim::double_buffer<uint64_t> db(nullptr, nullptr);
+    (void)rocprim::radix_sort_keys(nullptr, bytes, db, n, begin_bit, end_bit, (hipStream_t)0);
+    return bytes;
+}
+
+// Sorts n keys held in bufs[0]; returns the index (0/1) of the buffer that holds the result.
+hipError_t sort_u64(void* temp, size_t temp_bytes, uint64_t* buf0, uint64_t* buf1, size_t n,
+                    unsigned begin_bit, unsigned end_bit, hipStream_t stream, int* result_in)
+{
+    if (n == 0) { *result_in = 0; return hipSuccess; }
+    if (end_bit <= begin_bit) { *result_in = 0; return hipSuccess; }
+    rocprim::double_buffer<uint64_t> db(buf0, buf1);
+    hipError_t e = rocprim::radix_sort_keys(temp, temp_bytes, db, n, begin_bit, end_bit, stream);
+    *result_in = (db.current() == buf0) ? 0 : 1;
+    return e;
+}
+
+}  // namespace fpx

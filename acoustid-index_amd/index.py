@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's search interface on top of the libfpx C ABI.
+
+Names and argument meaning follow the reference so the parity tests read like its own tests:
+  SearchOptions / SearchResult / SearchResults   src/common.zig:45-176
+  FileSegment / MemorySegment                    src/FileSegment.zig:33-48, src/MemorySegment.zig:21-28
+  Segments (snapshot) / IndexReader.search       src/Index.zig:36-177
+  MultiIndex.search option derivation            src/MultiIndex.zig:302-306
+All arithmetic happens in the HIP library; nothing here computes a score."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import Opts, Result, Stats, check, lib
+
+
+@dataclass
+class SearchOptions:            # src/common.zig:50-54
+    max_results: int = 10
+    min_score: Optional[int] = 1      # None -> (len(raw query) + 19) // 20, src/MultiIndex.zig:304
+    min_score_pct: int = 10
+
+    def to_c(self):
+        return Opts(self.max_results, 0 if self.min_score is None else self.min_score,
+                    0 if self.min_score is None else 1, self.min_score_pct)
+
+
+def http_options(limit=40, min_score=None, score_pct=10):
+    """SearchRequest defaults + the HTTP clamp (src/api.zig:7-22, src/server.zig:192-193)."""
+    return SearchOptions(max(1, min(int(limit), 100)), min_score, score_pct)
+
+
+class Context:
+    """One per GPU / process."""
+
+    def __init__(self, device=-1):
+        h = C.c_void_p()
+        check(lib().fpx_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fpx_ctx_destroy(self.h)
+            self.h = None
+
+    def measure_bandwidth(self, nbytes=1 << 30, block_size=512):
+        s, r = C.c_double(), C.c_double()
+        check(lib().fpx_measure_bandwidth(self.h, nbytes, block_size, C.byref(s), C.byref(r)))
+        return s.value, r.value
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _Segment:
+    kind = "?"
+
+    def __init__(self, ctx, handle, commit_id, min_doc_id, max_doc_id, doc_ids, doc_alive):
+        self.ctx, self.h = ctx, handle
+        self.commit_id, self.min_doc_id, self.max_doc_id = commit_id, min_doc_id, max_doc_id
+        self.doc_ids, self.doc_alive = doc_ids, doc_alive
+
+    def release(self):
+        if getattr(self, "h", None):
+            lib().fpx_segment_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def getSize(self):
+        return lib().fpx_segment_num_items(self.h)
+
+    @property
+    def device_bytes(self):
+        return lib().fpx_segment_device_bytes(self.h)
+
+
+def _docs_args(doc_ids, doc_alive):
+    ids = _u32(doc_ids)
+    alive = (np.ones(len(ids), np.uint8) if doc_alive is None else np.ascontiguousarray(doc_alive, dtype=np.uint8))
+    return ids, alive
+
+
+class FileSegment(_Segment):
+    """Immutable segment resident in HBM (reference: resident in RAM, src/FileSegment.zig:1-4)."""
+    kind = "file"
+
+    def __init__(self, ctx, blocks, block_size, block_index, min_doc_id, max_doc_id, commit_id, doc_ids, doc_alive=None):
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+        block_index = _u32(block_index)
+        ids, alive = _docs_args(doc_ids, doc_alive)
+        h = C.c_void_p()
+        check(lib().fpx_segment_create_file(ctx.h, _p(blocks), blocks.size, block_size, _p(block_index), len(block_index),
+                                            min_doc_id, max_doc_id, commit_id, _p(ids), _p(alive), len(ids), C.byref(h)))
+        super().__init__(ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
+
+    @classmethod
+    def synth(cls, ctx, seed, first_doc, num_docs, hashes_per_doc, dist=0, block_size=512, commit_id=1):
+        """Seeded synthetic segment built on the GPU (fpx_synth_segment)."""
+        h = C.c_void_p()
+        check(lib().fpx_synth_segment(ctx.h, seed, first_doc, num_docs, hashes_per_doc, dist, block_size, commit_id, C.byref(h)))
+        self = cls.__new__(cls)
+        ids = None   # contiguous id range: kept implicit on the host side
+        _Segment.__init__(self, ctx, h, commit_id, first_doc, first_doc + num_docs - 1, ids, None)
+        self.first_doc, self.num_docs = first_doc, num_docs
+        return self
+
+    @property
+    def num_blocks(self):
+        return lib().fpx_segment_num_blocks(self.h)
+
+    @property
+    def block_size(self):
+        return lib().fpx_segment_block_size(self.h)
+
+    def download(self):
+        nb, bs = self.num_blocks, self.block_size
+        blocks = np.empty((nb + 1) * bs, np.uint8)
+        index = np.empty(max(nb, 1), np.uint32)
+        check(lib().fpx_segment_download(self.h, _p(blocks), blocks.size, _p(index), len(index)))
+        return blocks, index[:nb]
+
+
+class MemorySegment(_Segment):
+    kind = "memory"
+
+    def __init__(self, ctx, items, min_doc_id, max_doc_id, commit_id, doc_ids, doc_alive=None):
+        items = np.ascontiguousarray(items, dtype=np.uint64)
+        ids, alive = _docs_args(doc_ids, doc_alive)
+        h = C.c_void_p()
+        check(lib().fpx_segment_create_memory(ctx.h, _p(items), len(items), min_doc_id, max_doc_id, commit_id,
+                                              _p(ids), _p(alive), len(ids), C.byref(h)))
+        super().__init__(ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
+
+
+class RemoteSegment(_Segment):
+    """A segment whose postings live on another GPU: identity + docs map only (supersession)."""
+    kind = "remote"
+
+    def __init__(self, ctx, min_doc_id, max_doc_id, commit_id, doc_ids, doc_alive=None):
+        ids, alive = _docs_args(doc_ids, doc_alive)
+        h = C.c_void_p()
+        check(lib().fpx_segment_create_remote(ctx.h, min_doc_id, max_doc_id, commit_id, _p(ids), _p(alive), len(ids), C.byref(h)))
+        super().__init__(ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
+
+
+class Segments:
+    """Immutable snapshot: file[] then memory[], oldest -> newest (src/Index.zig:36-41)."""
+
+    def __init__(self, ctx, segments):
+        self.ctx = ctx
+        self.segments = list(segments)
+        arr = (C.c_void_p * max(1, len(self.segments)))(*[s.h for s in self.segments])
+        h = C.c_void_p()
+        check(lib().fpx_snapshot_create(ctx.h, arr, len(self.segments), C.byref(h)))
+        self.h = h
+
+    def release(self):
+        if getattr(self, "h", None):
+            lib().fpx_snapshot_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class SearchResults:
+    """Collector handed to IndexReader.search (src/common.zig:73-176)."""
+
+    def __init__(self, options: SearchOptions = None):
+        self.options = options or SearchOptions()
+        self.results = []
+        self.stats = None
+
+    def getResults(self):
+        return self.results
+
+
+def _flatten(queries):
+    lens = np.fromiter((len(q) for q in queries), dtype=np.uint64, count=len(queries))
+    offsets = np.zeros(len(queries) + 1, np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    if offsets[-1]:
+        flat = np.concatenate([np.asarray(q, dtype=np.uint64) & np.uint64(0xFFFFFFFF) for q in queries if len(q)]).astype(np.uint32)
+    else:
+        flat = np.zeros(1, np.uint32)
+    return np.ascontiguousarray(flat), offsets
+
+
+class IndexReader:
+    """A held snapshot (src/Index.zig:152-206)."""
+
+    def __init__(self, snapshot: Segments):
+        self.snapshot = snapshot
+
+    def search(self, hashes, results: SearchResults, timeout_ms=0):
+        """IndexReader.search(hashes, results) (src/Index.zig:170-177): raw hashes in, ranked results out."""
+        q = _u32(np.asarray(hashes, dtype=np.uint64) & np.uint64(0xFFFFFFFF)) if len(hashes) else np.zeros(1, np.uint32)
+        n = len(hashes)
+        cap = max(1, results.options.max_results)
+        out = (Result * cap)()
+        out_n = C.c_uint32()
+        st = Stats()
+        opts = results.options.to_c()
+        check(lib().fpx_search(self.snapshot.h, _p(q), n, C.byref(opts), timeout_ms, out, cap, C.byref(out_n), C.byref(st)))
+        results.results = [(out[i].id, out[i].score) for i in range(out_n.value)]
+        results.stats = st
+        return results.results
+
+    def search_batch(self, queries, options, timeout_ms=0, flat=None):
+        """Batched form (fpx_search_batch).  `options`: one SearchOptions for all queries or a list.
+        Returns (list of per-query [(id, score)], Stats)."""
+        B = len(queries) if flat is None else len(flat[1]) - 1
+        flat_h, offsets = _flatten(queries) if flat is None else flat
+        if isinstance(options, SearchOptions):
+            options = [options] * B
+        copts = (Opts * max(1, B))(*[o.to_c() for o in options])
+        cap = max([1] + [o.max_results for o in options])
+        out = np.zeros((max(1, B), cap, 2), np.uint32)
+        out_n = np.zeros(max(1, B), np.uint32)
+        st = Stats()
+        check(lib().fpx_search_batch(self.snapshot.h, _p(flat_h), _p(offsets), B, copts, timeout_ms,
+                                     _p(out), cap, _p(out_n), C.byref(st)))
+        res = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(out_n[q])] for q in range(B)]
+        return res, st
+
+    def search_batch_raw(self, flat_h, offsets, copts, cap, timeout_ms=0):
+        """Same call with pre-built numpy/ctypes buffers (used by bench.py's timed loop)."""
+        B = len(offsets) - 1
+        out = np.zeros((max(1, B), cap, 2), np.uint32)
+        out_n = np.zeros(max(1, B), np.uint32)
+        st = Stats()
+        check(lib().fpx_search_batch(self.snapshot.h, _p(flat_h), _p(offsets), B, copts, timeout_ms,
+                                     _p(out), cap, _p(out_n), C.byref(st)))
+        return out, out_n, st

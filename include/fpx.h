@@ -1,0 +1,181 @@
+/*
+ * fpx.h -- C ABI of libfpx, the MI355X-native search path for the AcoustID
+ * fingerprint inverted index ("fpindex", acoustid/acoustid-index).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * The reference has no FFI for this path today (it is ordinary Zig method calls),
+ * so each entry point cites the reference call site it replaces; the Zig-side
+ * `extern fn` declarations a maintainer would add are in INTEGRATION.md.
+ *
+ * Threading: every function is re-entrant.  Searches may be issued concurrently
+ * from many OS threads on one snapshot (the reference runs one search per zio
+ * executor thread on an immutable snapshot, src/main.zig:272-276, src/Index.zig:1-6);
+ * each call takes a pooled device workspace + HIP stream (the analogue of
+ * SearchResultsPool, src/common.zig:186-300) and holds no lock while the GPU works.
+ *
+ * Ownership: inputs are borrowed for the duration of the call and copied to HBM;
+ * outputs are written to caller-provided memory; handles are reference counted and
+ * a segment stays resident while any snapshot references it (src/Index.zig:53-63,
+ * src/FileSegment.zig:62-73, src/shared_ptr.zig:68-78).
+ *
+ * Errors: int status, 0 = success.  No exceptions or longjmp cross this boundary.
+ */
+#ifndef FPX_H
+#define FPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPX_OK          0
+#define FPX_E_NOMEM    -1   /* error.OutOfMemory (host or HBM) */
+#define FPX_E_TIMEOUT  -2   /* error.SearchTimeout (src/MultiIndex.zig:319-322): no partial results */
+#define FPX_E_DEVICE   -3   /* HIP runtime / kernel failure */
+#define FPX_E_INVAL    -4   /* malformed argument */
+#define FPX_E_NODEVICE -5   /* no gfx950 device visible: the HIP path is the only path */
+
+typedef struct fpx_ctx fpx_ctx;
+typedef struct fpx_segment fpx_segment;
+typedef struct fpx_snapshot fpx_snapshot;
+
+/* SearchResult (src/common.zig:45-48, src/api.zig:57-60) */
+typedef struct { uint32_t id; uint32_t score; } fpx_result;
+
+/* Per-query SearchOptions (src/common.zig:50-54) as derived by MultiIndex.search
+ * (src/MultiIndex.zig:302-306): has_min_score == 0 means "null" -> (raw query length + 19) / 20.
+ * max_results is used as given (the HTTP front end clamps to [1,100], src/server.zig:192;
+ * the legacy front end passes 500, src/legacy.zig:194).  min_score_pct must be <= 100. */
+typedef struct {
+    uint32_t max_results;
+    uint32_t min_score;
+    uint32_t has_min_score;
+    uint32_t min_score_pct;
+} fpx_opts;
+
+/* Totals the reference exports as fpindex_scanned_blocks_per_hash / _docs_per_hash
+ * (src/FileSegment.zig:177-178, src/metrics.zig:93-101) plus device timing. */
+typedef struct {
+    uint64_t probes;            /* (unique query hash, file segment) pairs */
+    uint64_t scanned_blocks;    /* sum of the reference's num_blocks counter (src/FileSegment.zig:154,171) */
+    uint64_t scanned_docs;      /* sum of num_docs (:153,172), before supersession filtering */
+    uint64_t hits;              /* postings accumulated after supersession filtering */
+    uint64_t algorithmic_bytes; /* sum over visited blocks of that segment's block_size */
+    uint64_t candidates;        /* (query, doc) pairs with score >= min_score */
+    float    probe_kernel_ms;   /* HIP-event time of the posting decode + match kernel launches */
+    float    total_gpu_ms;      /* first launch -> last kernel of this call, on the call's stream */
+    uint32_t probe_launches;
+    uint32_t reserved;
+} fpx_stats;
+
+/* ---- context ----------------------------------------------------------- */
+/* One context per GPU / process.  device = HIP ordinal, -1 = current device. */
+int  fpx_ctx_create(int device, fpx_ctx **out);
+void fpx_ctx_destroy(fpx_ctx *ctx);
+const char *fpx_strerror(int status);
+/* last error text of the calling thread (valid until its next fpx call) */
+const char *fpx_last_error(void);
+int  fpx_version(void);
+
+/* ---- segments ---------------------------------------------------------- */
+/* Replaces: end of filefmt.readSegment (src/filefmt.zig:270-284) and
+ * Index.mergeToFileSegment (src/Index.zig:961-983) -- "segment becomes resident".
+ * blocks: num_blocks fixed-size blocks + the empty terminator block (src/filefmt.zig:9-10),
+ * blocks_len = (num_blocks + 1) * block_size; block_index: max hash per block, LE u32.
+ * doc_ids/doc_alive: the segment's `docs` map (alive or tombstone), any order.
+ * Every id that occurs in the blocks must be listed in doc_ids (reference invariant). */
+int fpx_segment_create_file(fpx_ctx *ctx,
+                            const uint8_t *blocks, size_t blocks_len, uint32_t block_size,
+                            const uint32_t *block_index, uint32_t num_blocks,
+                            uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                            const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs,
+                            fpx_segment **out);
+
+/* Replaces: MemorySegment.build's result (src/MemorySegment.zig:81-148, src/Index.zig:531-534).
+ * items: u64 = hash << 32 | id (src/segment.zig:87-89), sorted ascending, duplicates kept. */
+int fpx_segment_create_memory(fpx_ctx *ctx, const uint64_t *items, size_t num_items,
+                              uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                              const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs,
+                              fpx_segment **out);
+
+/* A segment whose postings live on ANOTHER GPU (segment sharding, one process per GPU):
+ * only its identity and `docs` map are needed here, for supersession (hasNewerCommit,
+ * src/Index.zig:133-149).  It contributes no hits on this device. */
+int fpx_segment_create_remote(fpx_ctx *ctx, uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                              const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs,
+                              fpx_segment **out);
+
+/* SharedPtr.acquire / release (src/shared_ptr.zig:38-85): HBM is freed on the last release. */
+void fpx_segment_retain(fpx_segment *seg);
+void fpx_segment_release(fpx_segment *seg);
+
+/* introspection */
+uint64_t fpx_segment_num_items(const fpx_segment *seg);     /* FileSegment/MemorySegment.getSize */
+uint32_t fpx_segment_num_blocks(const fpx_segment *seg);
+uint32_t fpx_segment_block_size(const fpx_segment *seg);
+uint64_t fpx_segment_device_bytes(const fpx_segment *seg);
+/* copy a resident file segment's blocks (+terminator) and block index back to the host */
+int fpx_segment_download(const fpx_segment *seg, uint8_t *blocks, size_t blocks_cap,
+                         uint32_t *block_index, uint32_t index_cap);
+
+/* ---- snapshot ---------------------------------------------------------- */
+/* Replaces: Index.createSnapshot + swapSnapshot (src/Index.zig:450-485).  `segs` is the
+ * Segments snapshot order: file[] then memory[], oldest -> newest, commit_id strictly
+ * ascending (src/Index.zig:36-41).  Builds the supersession tables.  Retains the segments. */
+int  fpx_snapshot_create(fpx_ctx *ctx, fpx_segment *const *segs, uint32_t num_segs, fpx_snapshot **out);
+/* acquireReader / IndexReader.deinit (src/Index.zig:430-434, :157-163) */
+void fpx_snapshot_retain(fpx_snapshot *snap);
+void fpx_snapshot_release(fpx_snapshot *snap);
+
+/* ---- search ------------------------------------------------------------ */
+/* Replaces: IndexReader.search(hashes, results) + results.getResults()
+ * (src/Index.zig:170-177, src/common.zig:131-173) as called by MultiIndex.search
+ * (src/MultiIndex.zig:287-330).  `hashes` is the raw query: unsorted, duplicates allowed,
+ * not modified.  timeout_ms == 0 means unbounded (src/MultiIndex.zig:286,315).
+ * Writes min(*out_n, out_cap) results ordered by (score desc, id asc). */
+int fpx_search(fpx_snapshot *snap, const uint32_t *hashes, uint32_t num_hashes,
+               const fpx_opts *opts, uint32_t timeout_ms,
+               fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
+
+/* Batched form (what a host-side request coalescer drives; BASELINE configs use B = 1024 / 8192).
+ * Query q is hashes[offsets[q] .. offsets[q+1]); opts[q] its options; results of query q are
+ * written to out[q * out_cap ..] and their count to out_n[q]. */
+int fpx_search_batch(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets,
+                     uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
+                     fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
+
+/* Segment-sharded multi-GPU: stage 1 on every rank.  Same as fpx_search_batch but the
+ * per-query tables stay in HBM (d_out: num_queries * out_cap fpx_result, d_out_n: num_queries u32,
+ * both DEVICE pointers) and only the absolute min_score floor is applied, so the tables of all
+ * ranks can be exchanged with an RCCL all-gather and merged by fpx_merge_partials. */
+int fpx_search_batch_partial(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets,
+                             uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
+                             void *d_out, uint32_t out_cap, void *d_out_n, fpx_stats *stats);
+
+/* Stage 2: merge `world` gathered partial tables (DEVICE pointers, rank-major:
+ * d_parts[r][q][out_cap], d_counts[r][q]) into the final per-query top-k on the host
+ * (relative min_score_pct cut-off anchored on the global best score, src/common.zig:162). */
+int fpx_merge_partials(fpx_ctx *ctx, const void *d_parts, const void *d_counts, uint32_t world,
+                       uint32_t num_queries, uint32_t part_cap, const fpx_opts *opts,
+                       const uint64_t *offsets,
+                       fpx_result *out, uint32_t out_cap, uint32_t *out_n);
+
+/* ---- synthetic index builder (benchmarks / tests; not part of the reference surface) --- */
+/* Builds, entirely on the GPU, the file segment holding documents
+ * [first_doc, first_doc + num_docs) x hashes_per_doc seeded hashes (definition in DESIGN.md,
+ * identical to oracle/fpx_oracle.c:orc_synth_hash), sorted and block-encoded with the
+ * reference's fill rule (src/block.zig:501-567, src/filefmt.zig:94-138). dist: 0 uniform, 1 hot-pool. */
+int fpx_synth_segment(fpx_ctx *ctx, uint64_t seed, uint32_t first_doc, uint32_t num_docs,
+                      uint32_t hashes_per_doc, int dist, uint32_t block_size, uint64_t commit_id,
+                      fpx_segment **out);
+
+/* HBM streaming-read and random-block-read bandwidth of this device (GB/s), measured by trivial
+ * kernels: the second denominator SURVEY 8(d) asks for next to the 8 TB/s spec peak. */
+int fpx_measure_bandwidth(fpx_ctx *ctx, size_t bytes, uint32_t block_size, double *stream_gbs, double *random_gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPX_H */

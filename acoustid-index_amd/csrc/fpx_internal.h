@@ -48,6 +48,7 @@ enum Counter : int {
     CTR_DOCS = 3,        // matched docs before supersession filtering
     CTR_BYTES = 4,       // algorithmic bytes
     CTR_PROBES = 5,      // valid (unique hash, file segment) probes
+    CTR_MAXSCORE = 6,    // largest score of any candidate (sizes the score field of the candidate key)
     CTR_COUNT = 8
 };
 

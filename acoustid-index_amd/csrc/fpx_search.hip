@@ -266,14 +266,18 @@ __global__ __launch_bounds__(WG) void k_probe(ProbeArgs a)
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     if ((e >> k) & 1u) {
-                                        const uint32_t d = xb + x[k];
-                                        // supersession (src/common.zig:158 + src/Index.zig:133-149), applied per posting
-                                        if (!is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, d)) {
-                                            kf |= 1u << k;
-                                            dd[k] = d;
-                                        }
+                                        kf |= 1u << k;
+                                        dd[k] = xb + x[k];
                                     }
                                 }
+                            }
+                            // supersession (src/common.zig:158 + src/Index.zig:133-149), applied per posting: a doc
+                            // that a newer segment mentions contributes nothing from this segment
+                            if (seg.num_dead != 0u && kf != 0u) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (((kf >> k) & 1u) && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, dd[k]))
+                                        kf &= ~(1u << k);
                             }
                             // blocks with more than 128 items (rare at 512 B): every chunk but the last hands its
                             // matches to the staging buffer lane by lane, the last one uses the ballot path below
@@ -400,20 +404,25 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
 // 5. run-length scoring: sorted (q, doc) records -> candidates with score >= min_score[q]
 //    (SearchResults.incr + the min_score filter of finish, src/common.zig:121-145)
 // ------------------------------------------------------------------------------------------------
+// pass 0 (write == 0): count the candidates and find the largest score; pass 1: write the keys
+//   key = q << (32 + sb) | (smax - score) << 32 | doc   -> ascending key order = (q, score desc, doc asc)
+// A doc that holds the same hash several times scores once per posting (duplicates are kept in segments,
+// src/MemorySegment.zig:139), so the score is bounded by the number of hits, not by the query length.
 __global__ __launch_bounds__(WG) void k_rle(const uint64_t* __restrict__ hits, uint64_t H, const uint32_t* __restrict__ opts,
-                                             uint32_t sb, uint64_t* cands, uint64_t cand_cap, unsigned long long* counters)
+                                             uint32_t sb, int write, uint64_t* cands, uint64_t cand_cap,
+                                             unsigned long long* counters)
 {
     __shared__ uint32_t wg_n;
-    __shared__ unsigned long long wg_base;
-    if (threadIdx.x == 0) wg_n = 0;
+    __shared__ unsigned long long wg_base, wg_max;
+    if (threadIdx.x == 0) { wg_n = 0; wg_max = 0; }
     __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    uint64_t ckey = 0;
+    uint64_t ckey = 0, len = 0;
     bool is_cand = false;
     if (i < H) {
         const uint64_t rec = hits[i];
         if (i == 0 || hits[i - 1] != rec) {
-            uint64_t len = 1;
+            len = 1;
             while (i + len < H && hits[i + len] == rec) ++len;
             const uint32_t q = (uint32_t)(rec >> 32), d = (uint32_t)rec;
             const uint32_t min_score = opts[q * 4u + 1u];
@@ -426,11 +435,17 @@ __global__ __launch_bounds__(WG) void k_rle(const uint64_t* __restrict__ hits, u
         }
     }
     uint32_t slot = 0;
-    if (is_cand) slot = atomicAdd(&wg_n, 1u);
+    if (is_cand) {
+        slot = atomicAdd(&wg_n, 1u);
+        if (!write) atomicMax(&wg_max, (unsigned long long)len);
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && wg_n) wg_base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)wg_n);
+    if (threadIdx.x == 0 && wg_n) {
+        wg_base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)wg_n);
+        if (!write) atomicMax(&counters[CTR_MAXSCORE], wg_max);
+    }
     __syncthreads();
-    if (is_cand && wg_base + slot < cand_cap) cands[wg_base + slot] = ckey;
+    if (write && is_cand && wg_base + slot < cand_cap) cands[wg_base + slot] = ckey;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,6 +589,8 @@ static int grow_pair(uint64_t* p[2], size_t* cap, size_t need)
     return FPX_OK;
 }
 
+constexpr int FPX_SPLIT = 1;   // internal: candidate key does not fit 64 bits, split the batch
+
 static unsigned bits_for(uint64_t n)   // number of bits needed to represent values in [0, n)
 {
     unsigned b = 0;
@@ -629,11 +646,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, cons
     const double t_start = now_ms();
     hipStream_t st = ws->stream;
     const uint64_t P = offsets[B];
-    uint64_t max_len = 1;
-    for (uint32_t q = 0; q < B; ++q) max_len = std::max<uint64_t>(max_len, offsets[q + 1] - offsets[q]);
     const unsigned qb = bits_for(B);            // q in [0, B)
-    const unsigned sb = bits_for(max_len + 1);  // score in [0, max_len]
-    if (qb + sb > 32) { set_error("batch too large for one pass (qb=%u sb=%u)", qb, sb); return FPX_E_INVAL; }
+    unsigned sb = 1;                            // bits of the score field; sized after scoring
 
     // ---- upload the batch
     int rc;
@@ -720,21 +734,25 @@ static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, cons
         if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
         FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_hits[0], ws->d_hits[1], H, 0, 32 + qb, st, &hcur));
         if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);   // keep the convention: d_hits[0] holds the data
-        if (ws->cap_cands == 0) {
-            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, std::max<size_t>(1u << 16, (size_t)B * 64)))) return rc;
-        }
-        for (int attempt = 0;; ++attempt) {
+        // pass 0: number of candidates and the largest score; pass 1: write the candidate keys
+        FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
+        FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_rle, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st,
+                           ws->d_hits[0], H, ws->d_opts, 32u, 0, (uint64_t*)nullptr, (uint64_t)0, ws->d_counters);
+        FPX_HIP(hipGetLastError());
+        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        C = ws->h_counters[CTR_CANDS];
+        const unsigned long long max_score = ws->h_counters[CTR_MAXSCORE];
+        if (max_score > 0xFFFFFFFFull) { set_error("score overflows u32"); return FPX_E_INVAL; }
+        sb = std::max(1u, bits_for(max_score + 1));
+        if (qb + sb > 32) return FPX_SPLIT;     // the caller retries with smaller batches
+        if (C) {
+            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, (size_t)C + 64))) return rc;
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_rle, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st,
-                               ws->d_hits[0], H, ws->d_opts, sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
+                               ws->d_hits[0], H, ws->d_opts, sb, 1, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
             FPX_HIP(hipGetLastError());
-            FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_CANDS], &ws->d_counters[CTR_CANDS], sizeof(unsigned long long),
-                                   hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipStreamSynchronize(st));
-            C = ws->h_counters[CTR_CANDS];
-            if (C <= ws->cap_cands) break;
-            if (attempt >= 2) { set_error("candidate buffer overflow persists"); return FPX_E_DEVICE; }
-            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, (size_t)C + 1024))) return rc;
         }
         // ---- 6: sort candidates by (q, score desc, id asc)
         if (C) {
@@ -775,6 +793,37 @@ static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, cons
     return FPX_OK;
 }
 
+static void add_stats(fpx_stats* dst, const fpx_stats& s)
+{
+    dst->probes += s.probes; dst->scanned_blocks += s.scanned_blocks; dst->scanned_docs += s.scanned_docs;
+    dst->hits += s.hits; dst->algorithmic_bytes += s.algorithmic_bytes; dst->candidates += s.candidates;
+    dst->probe_kernel_ms += s.probe_kernel_ms; dst->total_gpu_ms += s.total_gpu_ms; dst->probe_launches += s.probe_launches;
+}
+
+// one pass, or -- when (query index, score) do not fit the 64-bit candidate key -- two half batches
+static int search_split(Snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                        const fpx_opts* opts, uint32_t timeout_ms, bool partial,
+                        fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+{
+    Workspace* ws = ws_acquire(snap->ctx);
+    if (!ws) return FPX_E_NOMEM;
+    fpx_stats local{};
+    int rc = run_batch(snap, ws, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local);
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    ws_release(snap->ctx, ws);
+    if (rc == FPX_OK) { if (stats) add_stats(stats, local); return FPX_OK; }
+    if (rc != FPX_SPLIT) return rc;
+    if (B <= 1) { set_error("internal: single query cannot be split"); return FPX_E_DEVICE; }
+    const uint32_t half = B / 2;
+    std::vector<uint64_t> off2(B - half + 1);
+    for (uint32_t q = half; q <= B; ++q) off2[q - half] = offsets[q] - offsets[half];
+    rc = search_split(snap, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+    if (rc) return rc;
+    fpx_result* out2 = out ? out + (size_t)half * out_cap : out;
+    return search_split(snap, hashes + offsets[half], off2.data(), B - half, opts + half, timeout_ms, partial,
+                        out2, out_cap, out_n + half, stats);
+}
+
 int search_batch_impl(Snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                       const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                       fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
@@ -784,43 +833,12 @@ int search_batch_impl(Snapshot* snap, const uint32_t* hashes, const uint64_t* of
     }
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (B == 0) return FPX_OK;
-    for (uint32_t q = 0; q < B; ++q)
+    for (uint32_t q = 0; q < B; ++q) {
         if (offsets[q + 1] < offsets[q]) { set_error("offsets must be non-decreasing"); return FPX_E_INVAL; }
-    FPX_HIP(hipSetDevice(snap->ctx->device));
-
-    // split batches whose (query index, score) bits do not fit one 64-bit candidate key
-    uint64_t max_len = 1;
-    for (uint32_t q = 0; q < B; ++q) max_len = std::max<uint64_t>(max_len, offsets[q + 1] - offsets[q]);
-    if (max_len >= (1ull << 32)) { set_error("query longer than 2^32-1 hashes"); return FPX_E_INVAL; }
-    if (bits_for(B) + bits_for(max_len + 1) > 32 && B > 1) {
-        const uint32_t half = B / 2;
-        std::vector<uint64_t> off2(B - half + 1);
-        for (uint32_t q = half; q <= B; ++q) off2[q - half] = offsets[q] - offsets[half];
-        fpx_stats s1{}, s2{};
-        int rc = search_batch_impl(snap, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, &s1);
-        if (rc) return rc;
-        fpx_result* out2 = out ? out + (size_t)half * out_cap : out;
-        rc = search_batch_impl(snap, hashes + offsets[half], off2.data(), B - half, opts + half, timeout_ms, partial,
-                               out2, out_cap, out_n + half, &s2);
-        if (rc) return rc;
-        if (stats) {
-            stats->probes = s1.probes + s2.probes; stats->scanned_blocks = s1.scanned_blocks + s2.scanned_blocks;
-            stats->scanned_docs = s1.scanned_docs + s2.scanned_docs; stats->hits = s1.hits + s2.hits;
-            stats->algorithmic_bytes = s1.algorithmic_bytes + s2.algorithmic_bytes;
-            stats->candidates = s1.candidates + s2.candidates;
-            stats->probe_kernel_ms = s1.probe_kernel_ms + s2.probe_kernel_ms;
-            stats->total_gpu_ms = s1.total_gpu_ms + s2.total_gpu_ms;
-            stats->probe_launches = s1.probe_launches + s2.probe_launches;
-        }
-        return FPX_OK;
+        if (offsets[q + 1] - offsets[q] >= (1ull << 32)) { set_error("query longer than 2^32-1 hashes"); return FPX_E_INVAL; }
     }
-
-    Workspace* ws = ws_acquire(snap->ctx);
-    if (!ws) return FPX_E_NOMEM;
-    int rc = run_batch(snap, ws, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats);
-    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
-    ws_release(snap->ctx, ws);
-    return rc;
+    FPX_HIP(hipSetDevice(snap->ctx->device));
+    return search_split(snap, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats);
 }
 
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,

@@ -50,3 +50,140 @@ def test_golden_api_vectors(env):
     p.finish()
     got, _ = p.check([[101, 201, 301, 102, 202, 302]], fpx.http_options())
     assert got == [[]]
+
+
+def test_zipf_caps_multi_segment(env):
+    """Hot hashes spanning > 4 blocks and > 1000 docs exercise MAX_BLOCKS_PER_HASH / MAX_DOCS_PER_HASH
+    (src/FileSegment.zig:25-26,171-174); 3 segments, contiguous id ranges."""
+    fpx, oracle, Pair, ctx = env
+    seed, H, per = 5, 96, 30000
+    p = Pair(ctx)
+    for s in range(3):
+        lo = s * per + 1
+        p.add_file(fpx.synth.synth_items(seed, lo, per, H, dist=1), lo, lo + per - 1, s + 1, np.arange(lo, lo + per))
+    p.finish()
+    qs, _ = _queries(fpx, seed, 96, 3 * per, H, 300, dist=1)
+    got, st = p.check(qs, fpx.http_options())
+    # the hottest pool value alone: every segment stops at the 4-block cap / after > 1000 docs
+    hot0 = int(fpx.synth.mix64(np.uint64(seed) ^ np.uint64(0x5bd1e9955bd1e995)) >> np.uint64(32))
+    _, st1 = p.check([[hot0]], fpx.SearchOptions(10, 1, 10))
+    assert st1.probes == 3 and st1.scanned_blocks > 3 and st1.scanned_docs > 1000
+    # legacy options (src/legacy.zig:192-198): limit 500, min_score 1 -> thousands of candidates per query
+    p.check(qs[:24], fpx.SearchOptions(500, 1, 10))
+    p.check(qs[:8], fpx.SearchOptions(100000, 1, 0))
+
+
+@pytest.mark.parametrize("block_size", [64, 100, 128, 256, 1024, 4096])
+def test_block_sizes(env, block_size):
+    """block_size comes from the segment header, 64..4096 (src/filefmt.zig:236); small id ranges make
+    blocks with > 128 items (multi-chunk decode), 4096-B blocks hold ~1000 items."""
+    fpx, oracle, Pair, ctx = env
+    seed, ndocs, H = 21 + block_size, 3000, 48
+    p = Pair(ctx)
+    p.add_file(fpx.synth.synth_items(seed, 1, ndocs, H, dist=1), 1, ndocs, 1, np.arange(1, ndocs + 1), block_size=block_size)
+    p.finish()
+    qs, _ = _queries(fpx, seed, 32, ndocs, H, 120, dist=1)
+    p.check(qs, fpx.http_options())
+    p.check(qs[:8], fpx.SearchOptions(500, 1, 10))
+
+
+def test_supersession_and_tombstones(env):
+    """Re-inserted docs and tombstones in newer file/memory segments hide older postings
+    (src/common.zig:121-129,158; src/Index.zig:133-149), combined with top-k truncation."""
+    fpx, oracle, Pair, ctx = env
+    seed, H, n = 77, 32, 6000
+    rng = np.random.default_rng(3)
+    p = Pair(ctx)
+    p.add_file(fpx.synth.synth_items(seed, 1, n, H), 1, n, 1, np.arange(1, n + 1))
+    # segment 2: 300 docs of segment 1 re-inserted with fresh hashes + 150 tombstones + 1000 new docs
+    re_ids = np.sort(rng.choice(np.arange(1, n + 1), 300, replace=False)).astype(np.uint64)
+    tomb = np.sort(rng.choice(np.setdiff1d(np.arange(1, n + 1), re_ids), 150, replace=False)).astype(np.uint64)
+    new_ids = np.arange(n + 1, n + 1001, dtype=np.uint64)
+    ids2 = np.concatenate([re_ids, new_ids])
+    h2 = fpx.synth.synth_hashes(seed + 1, ids2, H).astype(np.uint64)
+    items2 = np.sort(((h2 << np.uint64(32)) | ids2[:, None]).ravel())
+    docs2 = np.concatenate([ids2, tomb]).astype(np.uint32)
+    alive2 = np.concatenate([np.ones(len(ids2), np.uint8), np.zeros(len(tomb), np.uint8)])
+    p.add_file(items2, int(docs2.min()), int(docs2.max()), 2, docs2, alive2)
+    # memory segments: an overwrite of a doc from segment 2 and a delete of a doc from segment 1
+    victim = int(re_ids[0])
+    p.add_memory_changes([("insert", victim, fpx.synth.synth_hashes(seed + 2, [victim], H)[0].tolist())], 3)
+    p.add_memory_changes([("delete", int(np.setdiff1d(np.arange(1, n + 1), np.concatenate([re_ids, tomb]))[0]))], 4)
+    p.finish()
+    # queries: old hashes of re-inserted docs (must NOT be found), their new hashes (found), tombstoned docs, plain docs
+    def q_of(seed_, doc):
+        return fpx.synth.synth_hashes(seed_, [doc], H)[0]
+    qs = [q_of(seed, int(d)) for d in re_ids[:10]] + [q_of(seed + 1, int(d)) for d in re_ids[:10]]
+    qs += [q_of(seed, int(d)) for d in tomb[:10]] + [q_of(seed, d) for d in range(1, 11)]
+    qs += [q_of(seed + 2, victim), q_of(seed + 1, victim)]
+    got, _ = p.check(qs, fpx.SearchOptions(10, 1, 10))
+    assert all(not g or g[0][0] != int(d) for g, d in zip(got[:10], re_ids[:10]))   # old versions are hidden
+    assert got[10] == [] and got[11][0] == (int(re_ids[1]), H)                      # victim overwritten again
+    assert all(not g or g[0][0] != int(d) for g, d in zip(got[20:30], tomb[:10]))   # tombstones hide
+    assert got[-2][0] == (victim, H)
+
+
+def test_query_edge_cases(env):
+    """empty query, duplicate hashes (src/Index.zig:1056-1096), hash 0 / 0xFFFFFFFF, hashes beyond every
+    block, min_score defaults from the RAW length (src/MultiIndex.zig:304), ties broken by id."""
+    fpx, oracle, Pair, ctx = env
+    p = Pair(ctx)
+    items = oracle.pack_items([(0, 5), (0, 6), (7, 5), (0xFFFFFFFF, 5), (0xFFFFFFFF, 9), (100, 9), (100, 5), (100, 6)])
+    items = np.sort(items)
+    p.add_file(items, 5, 9, 1, [5, 6, 9])
+    p.finish()
+    qs = [[], [100, 100, 100], [0, 0xFFFFFFFF, 7, 100], [0xFFFFFFFF], [1, 2, 3], [100] * 45, [0xFFFFFFFE, 5, 8]]
+    got, _ = p.check(qs, fpx.http_options())
+    assert got[0] == [] and got[1] == [(5, 1), (6, 1), (9, 1)] and got[2][0] == (5, 4)
+    assert got[5] == []     # 45 raw hashes -> min_score 3 even though only one unique hash
+    p.check(qs, fpx.SearchOptions(2, 1, 100))
+    p.check(qs, fpx.SearchOptions(1, 2, 50))
+
+
+def test_single_search_entry_point(env):
+    """fpx_search (one query, IndexReader.search signature) agrees with the batched entry point."""
+    fpx, oracle, Pair, ctx = env
+    seed, ndocs, H = 3, 5000, 40
+    p = Pair(ctx)
+    p.add_file(fpx.synth.synth_items(seed, 1, ndocs, H), 1, ndocs, 1, np.arange(1, ndocs + 1))
+    p.finish()
+    qs, targets = _queries(fpx, seed, 4, ndocs, H, 80)
+    for q, t in zip(qs, targets):
+        r = fpx.SearchResults(fpx.http_options())
+        p.reader.search(q, r)
+        assert r.getResults() == p.osnap.search(q) and r.getResults()[0][0] == int(t)
+
+
+def test_insert_many_50k_golden(env):
+    """tests/test_fingerprint_api.py:67-99 / test_parallel_loading.py:11-67 on the GPU: exactly [(100, 100)]."""
+    import random
+    fpx, oracle, Pair, ctx = env
+    n, max_hash, nseg = 50000, 2 ** 18, 3
+    per = (n + nseg - 1) // nseg
+    p = Pair(ctx)
+    for s in range(nseg):
+        lo, hi = s * per + 1, min(n, (s + 1) * per)
+        hs = np.empty((hi - lo + 1, 100), np.uint64)
+        for i in range(lo, hi + 1):
+            rng = random.Random(i)
+            hs[i - lo] = [rng.randint(0, max_hash) for _ in range(100)]
+        ids = np.arange(lo, hi + 1, dtype=np.uint64)
+        p.add_file(np.sort(((hs << np.uint64(32)) | ids[:, None]).ravel()), lo, hi, s + 1, ids.astype(np.uint32))
+    p.finish()
+    rng = random.Random(100)
+    q = [rng.randint(0, max_hash) for _ in range(100)]
+    got, _ = p.check([q], fpx.http_options())
+    assert got == [[(100, 100)]]
+
+
+def test_duplicate_postings_score_above_query_length(env):
+    """A doc that holds the same hash several times scores once per posting, so a score can exceed the
+    number of query hashes (segments keep duplicate items, src/MemorySegment.zig:139)."""
+    fpx, oracle, Pair, ctx = env
+    p = Pair(ctx)
+    items = np.sort(oracle.pack_items([(50, 7)] * 9 + [(50, 8)] * 2 + [(60, 7)]))
+    p.add_file(items, 7, 8, 1, [7, 8])
+    p.add_memory(np.sort(oracle.pack_items([(50, 9)] * 5)), 9, 9, 2, [9])
+    p.finish()
+    got, _ = p.check([[50], [50, 60], [60]] * 40, fpx.SearchOptions(10, 1, 10))
+    assert got[0] == [(7, 9), (9, 5), (8, 2)] and got[1][0] == (7, 10)

@@ -5,5 +5,6 @@ csrc/ holds the HIP kernels and the C ABI (include/fpx.h), this package is the h
 mirror of the reference's search interface."""
 from ._lib import FpxError, SearchTimeout, Stats, lib, LIB_PATH  # noqa: F401
 from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegment, SearchOptions,  # noqa: F401
-                    SearchResults, Segments, http_options)
+                    SearchResults, Segments, http_options, QueryBatch, search_resident, search_resident_partial,
+                    merge_partials, results_to_lists)
 from . import synth  # noqa: F401

@@ -62,6 +62,10 @@ SIGNATURES = {
     "fpx_search": (C.c_int, [_vp, _vp, _u32, C.POINTER(Opts), _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(Stats)]),
     "fpx_search_batch": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_search_batch_partial": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
+    "fpx_query_batch_create": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(_vp)]),
+    "fpx_query_batch_release": (None, [_vp]),
+    "fpx_search_resident": (C.c_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
+    "fpx_search_resident_partial": (C.c_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_merge_partials": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "fpx_synth_segment": (C.c_int, [_vp, _u64, _u32, _u32, _u32, C.c_int, _u32, _u64, C.POINTER(_vp)]),
     "fpx_measure_bandwidth": (C.c_int, [_vp, _sz, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

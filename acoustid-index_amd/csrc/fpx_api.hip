@@ -409,7 +409,7 @@ int fpx_search_batch(fpx_snapshot* snap, const uint32_t* hashes, const uint64_t*
                      const fpx_opts* opts, uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n,
                      fpx_stats* stats)
 {
-    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), hashes, offsets, num_queries, opts, timeout_ms,
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), nullptr, hashes, offsets, num_queries, opts, timeout_ms,
                              false, out, out_cap, out_n, stats);
 }
 
@@ -417,7 +417,7 @@ int fpx_search(fpx_snapshot* snap, const uint32_t* hashes, uint32_t num_hashes, 
                fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
 {
     const uint64_t offsets[2] = {0, num_hashes};
-    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), hashes, offsets, 1, opts, timeout_ms,
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), nullptr, hashes, offsets, 1, opts, timeout_ms,
                              false, out, out_cap, out_n, stats);
 }
 
@@ -425,8 +425,37 @@ int fpx_search_batch_partial(fpx_snapshot* snap, const uint32_t* hashes, const u
                              const fpx_opts* opts, uint32_t timeout_ms, void* d_out, uint32_t out_cap, void* d_out_n,
                              fpx_stats* stats)
 {
-    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), hashes, offsets, num_queries, opts, timeout_ms,
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), nullptr, hashes, offsets, num_queries, opts, timeout_ms,
                              true, reinterpret_cast<fpx_result*>(d_out), out_cap, reinterpret_cast<uint32_t*>(d_out_n), stats);
+}
+
+int fpx_query_batch_create(fpx_ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t num_queries,
+                           const fpx_opts* opts, fpx_query_batch** out)
+{
+    if (!out) { set_error("null out"); return FPX_E_INVAL; }
+    QueryBatch* qb = nullptr;
+    int rc = query_batch_create_impl(reinterpret_cast<Ctx*>(ctx), hashes, offsets, num_queries, opts, &qb);
+    *out = reinterpret_cast<fpx_query_batch*>(qb);
+    return rc;
+}
+
+void fpx_query_batch_release(fpx_query_batch* qb) { query_batch_free(reinterpret_cast<QueryBatch*>(qb)); }
+
+int fpx_search_resident(fpx_snapshot* snap, const fpx_query_batch* qb, uint32_t timeout_ms,
+                        fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+{
+    if (!qb) { set_error("null query batch"); return FPX_E_INVAL; }
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), reinterpret_cast<const QueryBatch*>(qb), nullptr, nullptr, 0,
+                             nullptr, timeout_ms, false, out, out_cap, out_n, stats);
+}
+
+int fpx_search_resident_partial(fpx_snapshot* snap, const fpx_query_batch* qb, uint32_t timeout_ms,
+                                void* d_out, uint32_t out_cap, void* d_out_n, fpx_stats* stats)
+{
+    if (!qb) { set_error("null query batch"); return FPX_E_INVAL; }
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), reinterpret_cast<const QueryBatch*>(qb), nullptr, nullptr, 0,
+                             nullptr, timeout_ms, true, reinterpret_cast<fpx_result*>(d_out), out_cap,
+                             reinterpret_cast<uint32_t*>(d_out_n), stats);
 }
 
 int fpx_merge_partials(fpx_ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world, uint32_t num_queries,

@@ -1,15 +1,383 @@
 // fpx_build.hip -- GPU builder of seeded synthetic file segments (benchmarks / tests).
+//
+// Produces, entirely in HBM, the same bytes the reference writer would produce for the same sorted items:
+//   BlockEncoder.encodeChunk / encodeBlock   src/block.zig:438-567   (greedy fill in chunks of 4 items)
+//   filefmt.writeBlocks                      src/filefmt.zig:94-138  (2048-item window, index = last hash,
+//                                                                     one all-zero terminator block)
+// The fill rule is sequential (where a block ends decides where the next starts).  It is parallelised
+// exactly: the item stream is cut into chunks of CQ quads; every chunk walks the greedy rule from an entry
+// quad; entry[c+1] = exit[c] is iterated to its fixpoint (chains started at different quads merge after a
+// few blocks, so this takes 2-3 rounds on real data and at most #chunks rounds on degenerate data).
 #include <cstring>
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <numeric>
+
 #include "fpx_internal.h"
 
 namespace fpx {
 
-int synth_segment_impl(Ctx*, uint64_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint64_t, Segment** out)
+// ---- seeded fingerprints: identical to oracle/fpx_oracle.c:orc_synth_hash and synth.py -------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint32_t synth_hash(uint64_t seed, uint32_t doc, uint32_t j, int dist)
+{
+    const uint64_t a = mix64(seed + (uint64_t)doc * 0xD1B54A32D192ED03ull);
+    const uint64_t r = mix64(a ^ (uint64_t)j);
+    if (dist == 1 && (r & 0xFFFFull) < 1311ull) {
+        const uint32_t e = (uint32_t)((r >> 16) & 0xFFull) % 12u;
+        const uint32_t k = (1u << e) + ((uint32_t)(r >> 24) & ((1u << e) - 1u)) - 1u;
+        return (uint32_t)(mix64(seed ^ 0x5bd1e9955bd1e995ull ^ ((uint64_t)k << 32)) >> 32);
+    }
+    return (uint32_t)(r >> 32);
+}
+
+__global__ __launch_bounds__(256) void k_gen_items(uint64_t seed, uint32_t first_doc, uint64_t n, uint32_t H, int dist,
+                                                   uint64_t* __restrict__ items)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = first_doc + (uint32_t)(i / H), j = (uint32_t)(i % H);
+        items[i] = ((uint64_t)synth_hash(seed, d, j, dist) << 32) | d;
+    }
+}
+
+// ---- encoded sizes -----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t size0124(uint32_t v) { return v == 0 ? 0u : v < 256u ? 1u : v < 65536u ? 2u : 4u; }
+__device__ __forceinline__ uint32_t size1234(uint32_t v) { return v < 256u ? 1u : v < 65536u ? 2u : v < (1u << 24) ? 3u : 4u; }
+
+// deltas of item i when it is NOT the first item of its block (src/block.zig:449-460)
+__device__ __forceinline__ void mid_deltas(const uint64_t* items, uint64_t i, uint32_t min_doc, uint32_t& hd, uint32_t& dd)
+{
+    const uint64_t cur = items[i], prev = items[i - 1];
+    const uint32_t h = (uint32_t)(cur >> 32), ph = (uint32_t)(prev >> 32);
+    hd = h - ph;
+    dd = (h != ph) ? (uint32_t)cur - min_doc : (uint32_t)cur - (uint32_t)prev;
+}
+
+// per quad: bytes it adds to a block as a middle quad / as the first quad of a block (2 control bytes included)
+__global__ __launch_bounds__(256) void k_quad_costs(const uint64_t* __restrict__ items, uint64_t n, uint32_t min_doc,
+                                                    uint8_t* __restrict__ cost_mid, uint8_t* __restrict__ cost_first)
+{
+    const uint64_t nq = (n + 3) / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t mid = 2, first = 2;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint64_t i = q * 4 + k;
+            if (i >= n) { mid += 1; first += 1; continue; }      // padding: hash delta 0 -> 0 B, docid 0 -> 1 B (:443-444)
+            uint32_t hd = 0, dd = (uint32_t)items[i] - min_doc;
+            const uint32_t f = (k == 0) ? size1234(dd) : 0u;     // first item of a block: hash delta 0, id - min_doc
+            if (i > 0) mid_deltas(items, i, min_doc, hd, dd);
+            const uint32_t m = size0124(hd) + size1234(dd);
+            mid += m;
+            first += (k == 0) ? f : m;
+        }
+        cost_mid[q] = (uint8_t)mid;
+        cost_first[q] = (uint8_t)first;
+    }
+}
+
+// ---- greedy fill, one thread per chunk of CQ quads -----------------------------------------------------
+struct WalkArgs {
+    const uint8_t* cost_mid; const uint8_t* cost_first;
+    uint64_t nq;                 // total quads
+    uint32_t block_size;
+    uint32_t cq;                 // quads per chunk
+    uint64_t nchunks;
+    const uint64_t* entry;       // [nchunks] first block start at or after the chunk's first quad (or >= chunk end)
+    uint64_t* exit;              // [nchunks] first block start >= chunk end
+    uint32_t* count;             // [nchunks] block starts inside the chunk
+    const uint64_t* boff;        // [nchunks] exclusive prefix of count (write pass)
+    uint64_t* bstart;            // block start quads (write pass)
+    int* error;
+};
+
+__global__ __launch_bounds__(256) void k_walk(WalkArgs a, int write)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nchunks) return;
+    const uint64_t chunk_end = std::min<uint64_t>((c + 1) * a.cq, a.nq);
+    uint64_t s = a.entry[c];
+    uint32_t cnt = 0;
+    uint64_t out = write ? a.boff[c] : 0;
+    while (s < chunk_end) {
+        if (write) a.bstart[out++] = s;
+        ++cnt;
+        uint32_t size = 8u + a.cost_first[s];
+        if (size > a.block_size) { *a.error = 1; s = chunk_end; break; }    // block too small for one chunk
+        uint64_t q = s + 1;
+        uint32_t quads = 1;
+        // src/block.zig:480-486 (BlockFull) and the 2048-item window of src/filefmt.zig:108-113
+        while (q < a.nq && quads < 512u) {
+            const uint32_t ns = size + a.cost_mid[q];
+            if (ns > a.block_size) break;
+            size = ns; ++q; ++quads;
+        }
+        s = q;
+    }
+    if (!write) { a.exit[c] = s; a.count[c] = cnt; }
+}
+
+__global__ void k_next_entries(const uint64_t* exit, uint64_t* entry, uint64_t nchunks, int* changed)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c + 1 >= nchunks) return;
+    const uint64_t e = exit[c];
+    if (entry[c + 1] != e) { entry[c + 1] = e; *changed = 1; }
+}
+
+__global__ void k_init_entries(uint64_t* entry, uint64_t nchunks, uint32_t cq)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchunks) entry[c] = c * cq;
+}
+
+// single-workgroup exclusive scan of the per-chunk block counts
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* count, uint64_t nchunks, uint64_t* boff, uint64_t* total)
+{
+    __shared__ uint64_t part[1024];
+    const uint64_t per = (nchunks + 1023) / 1024;
+    const uint64_t lo = threadIdx.x * per, hi = std::min<uint64_t>(lo + per, nchunks);
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += count[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint64_t i = lo; i < hi; ++i) { boff[i] = run; run += count[i]; }
+}
+
+// ---- block encoder: one wave per block, one lane per quad --------------------------------------------
+__device__ __forceinline__ uint32_t scan64(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_encode_blocks(const uint64_t* __restrict__ items, uint64_t n, uint32_t min_doc,
+                                                       const uint64_t* __restrict__ bstart, uint64_t num_blocks, uint64_t nq_total,
+                                                       uint32_t block_size, uint8_t* __restrict__ blocks,
+                                                       uint32_t* __restrict__ block_index)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint8_t* blk = smem + (size_t)wave * block_size;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + wave;
+    if (b >= num_blocks) return;
+    const uint64_t s = bstart[b], e = (b + 1 < num_blocks) ? bstart[b + 1] : nq_total;
+    const uint32_t nq = (uint32_t)(e - s);
+    const uint64_t i_first = s * 4, i_end = std::min<uint64_t>(e * 4, n);
+    const uint32_t n_items = (uint32_t)(i_end - i_first);
+
+    for (uint32_t o = lane * 4u; o < block_size; o += 256u) *reinterpret_cast<uint32_t*>(blk + o) = 0u;   // block_size % 4 == 0 checked by host
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // pass A: hashes (0124, delta; src/streamvbyte.zig:418-469)
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < nq; c0 += 64u) {
+        const uint32_t qi = c0 + lane;
+        uint32_t ctrl = 0, len = 0, vals[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+        if (qi < nq) {
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint64_t i = (s + qi) * 4 + k;
+                uint32_t hd = 0, dd = 0;
+                if (i < n && i > i_first) mid_deltas(items, i, min_doc, hd, dd);
+                const uint32_t sz = size0124(hd);
+                vals[k] = hd; nb[k] = sz;
+                ctrl |= (sz == 4u ? 3u : sz) << (2 * k);
+                len += sz;
+            }
+            blk[8u + qi] = (uint8_t)ctrl;
+        }
+        const uint32_t incl = scan64(len, lane);
+        uint32_t p = 8u + nq + carry + incl - len;
+        carry += __shfl(incl, 63);
+        if (qi < nq)
+            for (uint32_t k = 0; k < 4; ++k)
+                for (uint32_t j = 0; j < nb[k]; ++j) blk[p++] = (uint8_t)(vals[k] >> (8 * j));
+    }
+    const uint32_t doff = nq + carry;         // docids_offset (src/block.zig:547)
+    // pass B: docids (1234; delta base resets to min_doc at every hash change and at block start)
+    carry = 0;
+    for (uint32_t c0 = 0; c0 < nq; c0 += 64u) {
+        const uint32_t qi = c0 + lane;
+        uint32_t ctrl = 0, len = 0, vals[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+        if (qi < nq) {
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint64_t i = (s + qi) * 4 + k;
+                uint32_t hd = 0, dd = 0;
+                if (i < n) {
+                    if (i > i_first) mid_deltas(items, i, min_doc, hd, dd);
+                    else dd = (uint32_t)items[i] - min_doc;
+                }
+                const uint32_t sz = size1234(dd);
+                vals[k] = dd; nb[k] = sz;
+                ctrl |= (sz - 1u) << (2 * k);
+                len += sz;
+            }
+            blk[8u + doff + qi] = (uint8_t)ctrl;
+        }
+        const uint32_t incl = scan64(len, lane);
+        uint32_t p = 8u + doff + nq + carry + incl - len;
+        carry += __shfl(incl, 63);
+        if (qi < nq)
+            for (uint32_t k = 0; k < 4; ++k)
+                for (uint32_t j = 0; j < nb[k]; ++j) blk[p++] = (uint8_t)(vals[k] >> (8 * j));
+    }
+    if (lane == 0) {
+        const uint32_t min_hash = (uint32_t)(items[i_first] >> 32);
+        *reinterpret_cast<uint32_t*>(blk) = min_hash;                                 // src/block.zig:46-50
+        *reinterpret_cast<uint32_t*>(blk + 4) = (n_items & 0xFFFFu) | (doff << 16);
+        block_index[b] = (uint32_t)(items[i_end - 1] >> 32);                          // src/filefmt.zig:119
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint8_t* dst = blocks + b * (uint64_t)block_size;
+    for (uint32_t o = lane * 4u; o < block_size; o += 256u)
+        *reinterpret_cast<uint32_t*>(dst + o) = *reinterpret_cast<const uint32_t*>(blk + o);
+}
+
+// ---- driver ----------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return FPX_E_NOMEM; }
+        return FPX_OK;
+    }
+};
+
+int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist,
+                       uint32_t block_size, uint64_t commit_id, Segment** out)
 {
     *out = nullptr;
-    set_error("fpx_synth_segment: not built yet");
-    return FPX_E_INVAL;
+    if (num_docs == 0 || H == 0 || first_doc == 0) { set_error("num_docs, hashes_per_doc and first_doc must be non-zero"); return FPX_E_INVAL; }
+    if (block_size < 64 || block_size > 4096 || (block_size & 3u)) { set_error("block_size must be in [64,4096] and a multiple of 4"); return FPX_E_INVAL; }
+    if ((uint64_t)first_doc + num_docs - 1 > 0xFFFFFFFFull) { set_error("doc ids overflow u32"); return FPX_E_INVAL; }
+    const uint64_t n = (uint64_t)num_docs * H;
+    if (n > 0xFFFFFFFFull) { set_error("segment holds more than 2^32-1 items (num_items is u32, src/filefmt.zig:80)"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = 0;
+    int rc;
+
+    // 1. items, sorted as u64 (src/segment.zig:90-94)
+    DevBuf items0, items1, temp;
+    if ((rc = items0.alloc(n * 8)) || (rc = items1.alloc(n * 8))) return rc;
+    hipLaunchKernelGGL(k_gen_items, dim3(256 * 16), dim3(256), 0, st, seed, first_doc, n, H, dist, items0.as<uint64_t>());
+    FPX_HIP(hipGetLastError());
+    const unsigned id_bits = 32;   // ids occupy the low word; all 64 bits take part in the order
+    (void)id_bits;
+    const size_t tb = sort_u64_temp_bytes(n, 0, 64);
+    if ((rc = temp.alloc(tb + 256))) return rc;
+    int cur = 0;
+    FPX_HIP(sort_u64(temp.p, tb + 256, items0.as<uint64_t>(), items1.as<uint64_t>(), n, 0, 64, st, &cur));
+    FPX_HIP(hipStreamSynchronize(st));
+    const uint64_t* items = cur == 0 ? items0.as<uint64_t>() : items1.as<uint64_t>();
+    // the other buffer is no longer needed
+    if (cur == 0) { (void)hipFree(items1.p); items1.p = nullptr; } else { (void)hipFree(items0.p); items0.p = nullptr; }
+    (void)hipFree(temp.p); temp.p = nullptr;
+
+    // 2. per-quad costs
+    const uint64_t nq = (n + 3) / 4;
+    DevBuf cmid, cfirst;
+    if ((rc = cmid.alloc(nq)) || (rc = cfirst.alloc(nq))) return rc;
+    hipLaunchKernelGGL(k_quad_costs, dim3(256 * 16), dim3(256), 0, st, items, n, first_doc, cmid.as<uint8_t>(), cfirst.as<uint8_t>());
+    FPX_HIP(hipGetLastError());
+
+    // 3. fixpoint of the greedy fill over chunks
+    const uint32_t cq = 4096;
+    const uint64_t nchunks = (nq + cq - 1) / cq;
+    DevBuf entry, exitb, count, boff, flags;
+    if ((rc = entry.alloc(nchunks * 8)) || (rc = exitb.alloc(nchunks * 8)) || (rc = count.alloc(nchunks * 4)) ||
+        (rc = boff.alloc(nchunks * 8)) || (rc = flags.alloc(64)))
+        return rc;
+    int* d_changed = flags.as<int>();
+    int* d_error = flags.as<int>() + 1;
+    uint64_t* d_total = reinterpret_cast<uint64_t*>(flags.as<int>() + 2);
+    FPX_HIP(hipMemsetAsync(flags.p, 0, 64, st));
+    const uint32_t gch = (uint32_t)((nchunks + 255) / 256);
+    hipLaunchKernelGGL(k_init_entries, dim3(gch), dim3(256), 0, st, entry.as<uint64_t>(), nchunks, cq);
+    WalkArgs wa{};
+    wa.cost_mid = cmid.as<uint8_t>(); wa.cost_first = cfirst.as<uint8_t>(); wa.nq = nq; wa.block_size = block_size;
+    wa.cq = cq; wa.nchunks = nchunks; wa.entry = entry.as<uint64_t>(); wa.exit = exitb.as<uint64_t>();
+    wa.count = count.as<uint32_t>(); wa.boff = boff.as<uint64_t>(); wa.bstart = nullptr; wa.error = d_error;
+    for (uint64_t round = 0; round <= nchunks + 1; ++round) {
+        FPX_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 0);
+        hipLaunchKernelGGL(k_next_entries, dim3(gch), dim3(256), 0, st, exitb.as<uint64_t>(), entry.as<uint64_t>(), nchunks, d_changed);
+        FPX_HIP(hipGetLastError());
+        int h_flags[2] = {0, 0};
+        FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (h_flags[1]) { set_error("block_size %u cannot hold one chunk of 4 items", block_size); return FPX_E_INVAL; }
+        if (!h_flags[0]) break;
+    }
+    // counts are those of the last walk, which ran on the final entries only if nothing changed afterwards
+    hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 0);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, count.as<uint32_t>(), nchunks, boff.as<uint64_t>(), d_total);
+    FPX_HIP(hipGetLastError());
+    uint64_t num_blocks64 = 0;
+    FPX_HIP(hipMemcpyAsync(&num_blocks64, d_total, 8, hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    if (num_blocks64 >= 0xFFFFFFFFull) { set_error("too many blocks"); return FPX_E_INVAL; }
+    const uint32_t num_blocks = (uint32_t)num_blocks64;
+    DevBuf bstart;
+    if ((rc = bstart.alloc(((size_t)num_blocks + 1) * 8))) return rc;
+    wa.bstart = bstart.as<uint64_t>();
+    hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 1);
+    FPX_HIP(hipGetLastError());
+
+    // 4. encode
+    Segment* s = new (std::nothrow) Segment();
+    if (!s) return FPX_E_NOMEM;
+    s->ctx = ctx; s->kind = 0; s->commit_id = commit_id; s->min_doc_id = first_doc; s->max_doc_id = first_doc + num_docs - 1;
+    s->block_size = block_size; s->num_blocks = num_blocks;
+    s->blocks_len = ((size_t)num_blocks + 1) * block_size;
+    s->doc_ids.resize(num_docs);
+    std::iota(s->doc_ids.begin(), s->doc_ids.end(), first_doc);
+    auto fail = [&](int code) { if (s->d_blocks) (void)hipFree(s->d_blocks); if (s->d_block_index) (void)hipFree(s->d_block_index);
+                                if (s->d_bucket) (void)hipFree(s->d_bucket); delete s; return code; };
+    hipError_t e = hipMalloc(&s->d_blocks, s->blocks_len + 16);
+    if (e == hipSuccess) e = hipMalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t));
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc(segment)"));
+    s->device_bytes = s->blocks_len + 16 + ((size_t)num_blocks + 1) * sizeof(uint32_t);
+    e = hipMemsetAsync(s->d_blocks + (size_t)num_blocks * block_size, 0, block_size + 16, st);   // terminator + slack
+    if (e != hipSuccess) return fail(hip_fail(e, "memset"));
+    if (num_blocks) {
+        hipLaunchKernelGGL(k_encode_blocks, dim3((num_blocks + 3) / 4), dim3(256), 4 * block_size, st,
+                           items, n, first_doc, bstart.as<uint64_t>(), (uint64_t)num_blocks, nq, block_size,
+                           s->d_blocks, s->d_block_index);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(hip_fail(e, "k_encode_blocks"));
+    }
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(hip_fail(e, "encode sync"));
+    rc = finish_file_segment(s);
+    if (rc) return fail(rc);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(hip_fail(e, "finish sync"));
+    if (s->num_items != n) { set_error("internal: built %llu items, expected %llu", (unsigned long long)s->num_items, (unsigned long long)n); return fail(FPX_E_DEVICE); }
+    *out = s;
+    return FPX_OK;
 }
 
 }  // namespace fpx

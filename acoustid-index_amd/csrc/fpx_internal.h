@@ -102,6 +102,18 @@ struct Workspace {
     unsigned long long* h_counters = nullptr;
 };
 
+// A query batch already uploaded to HBM (fpx_query_batch_create): the timed region of a resident
+// search starts with the inputs in device memory.
+struct QueryBatch {
+    Ctx* ctx = nullptr;
+    uint32_t B = 0;
+    uint32_t* d_hashes = nullptr;
+    uint64_t* d_offsets = nullptr;       // [B+1], absolute
+    uint32_t* d_opts = nullptr;          // [B][4]
+    std::vector<uint64_t> offsets;       // host copy
+    std::vector<fpx_opts> opts;
+};
+
 struct Ctx {
     int device = 0;
     std::mutex mu;
@@ -128,7 +140,10 @@ hipError_t sort_u64(void* temp, size_t temp_bytes, uint64_t* buf0, uint64_t* buf
 
 // fpx_search.hip
 int build_bucket_table(Segment* seg, hipStream_t stream);
-int search_batch_impl(Snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                            const fpx_opts* opts, QueryBatch** out);
+void query_batch_free(QueryBatch* qb);
+int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                       const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                       fpx_result* out, uint32_t out_cap, uint32_t* out_n,   // host (final) or device (partial)
                       fpx_stats* stats);

@@ -103,15 +103,16 @@ __device__ __forceinline__ uint32_t lookup_block(const SegDesc& s, uint32_t h)
 // ------------------------------------------------------------------------------------------------
 // 1. keys
 // ------------------------------------------------------------------------------------------------
-__global__ void k_make_keys(const uint32_t* __restrict__ hashes, const uint64_t* __restrict__ offsets,
-                            uint32_t B, uint32_t qb, uint64_t* __restrict__ keys)
+// hashes_base[i] is the hash at ABSOLUTE position i of the batch; the view starts at absolute position `base`
+__global__ void k_make_keys(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
+                            uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys)
 {
     // one workgroup per query
     uint32_t q = blockIdx.x;
     if (q >= B) return;
     uint64_t lo = offsets[q], hi = offsets[q + 1];
     for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-        keys[i] = ((uint64_t)hashes[i] << qb) | q;
+        keys[i - base] = ((uint64_t)hashes_base[i] << qb) | q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -639,37 +640,54 @@ static double now_ms()
 // ------------------------------------------------------------------------------------------------
 // batch driver
 // ------------------------------------------------------------------------------------------------
-static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+// `offsets` are absolute positions into the batch the view [q0, q0+B) belongs to; `hashes` (host) points at
+// absolute position 0 and is only read when the batch is not resident.
+static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, uint32_t q0,
+                     const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                      fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
 {
     const double t_start = now_ms();
     hipStream_t st = ws->stream;
-    const uint64_t P = offsets[B];
+    const uint64_t base = offsets[0];
+    const uint64_t P = offsets[B] - base;
     const unsigned qb = bits_for(B);            // q in [0, B)
     unsigned sb = 1;                            // bits of the score field; sized after scoring
 
-    // ---- upload the batch
+    // ---- the batch: resident in HBM already, or uploaded from the caller's host buffers
     int rc;
-    if ((rc = grow(&ws->d_hashes, &ws->cap_hashes, (size_t)P + 1))) return rc;
-    if ((rc = ensure_queries(ws, B))) return rc;
+    if ((rc = ensure_queries(ws, B))) return rc;       // d_out_n (+ staging for non-resident batches)
     if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
     if (!partial && (rc = grow(&ws->d_out, &ws->cap_out, (size_t)B * out_cap + 1))) return rc;
     static_assert(sizeof(fpx_result) == 8, "fpx_result layout");
-    for (uint32_t q = 0; q < B; ++q)
-        if (opts[q].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
-    std::vector<uint32_t> h_opts;
-    fill_opts(h_opts, opts, offsets, B);
+    const uint32_t* d_hashes_base;
+    const uint64_t* d_offsets;
+    const uint32_t* d_opts;
     FPX_HIP(hipEventRecord(ws->ev_begin, st));
-    if (P) FPX_HIP(hipMemcpyAsync(ws->d_hashes, hashes, P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    FPX_HIP(hipMemcpyAsync(ws->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    FPX_HIP(hipMemcpyAsync(ws->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (resident) {
+        d_hashes_base = resident->d_hashes;
+        d_offsets = resident->d_offsets + q0;
+        d_opts = resident->d_opts + (size_t)q0 * 4;
+    } else {
+        for (uint32_t q = 0; q < B; ++q)
+            if (opts[q].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
+        if ((rc = grow(&ws->d_hashes, &ws->cap_hashes, (size_t)P + 1))) return rc;
+        std::vector<uint32_t> h_opts;
+        fill_opts(h_opts, opts, offsets, B);
+        if (P) FPX_HIP(hipMemcpyAsync(ws->d_hashes, hashes + base, P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        FPX_HIP(hipMemcpyAsync(ws->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        FPX_HIP(hipMemcpyAsync(ws->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        FPX_HIP(hipStreamSynchronize(st));             // h_opts is a local
+        d_hashes_base = ws->d_hashes - base;
+        d_offsets = ws->d_offsets;
+        d_opts = ws->d_opts;
+    }
     FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
     if (P) {
-        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, ws->d_hashes, ws->d_offsets, B, qb, ws->d_keys[0]);
+        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, base, ws->d_keys[0]);
         const size_t tb = sort_u64_temp_bytes(P, 0, 32 + qb);
         if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
         FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, 0, 32 + qb, st, &kcur));
@@ -738,7 +756,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, cons
         FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
         FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_rle, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st,
-                           ws->d_hits[0], H, ws->d_opts, 32u, 0, (uint64_t*)nullptr, (uint64_t)0, ws->d_counters);
+                           ws->d_hits[0], H, d_opts, 32u, 0, (uint64_t*)nullptr, (uint64_t)0, ws->d_counters);
         FPX_HIP(hipGetLastError());
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipStreamSynchronize(st));
@@ -751,7 +769,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, cons
             if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, (size_t)C + 64))) return rc;
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_rle, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st,
-                               ws->d_hits[0], H, ws->d_opts, sb, 1, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
+                               ws->d_hits[0], H, d_opts, sb, 1, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
             FPX_HIP(hipGetLastError());
         }
         // ---- 6: sort candidates by (q, score desc, id asc)
@@ -767,7 +785,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const uint32_t* hashes, cons
     fpx_result* d_res = partial ? out : ws->d_out;
     uint32_t* d_res_n = partial ? out_n : ws->d_out_n;
     hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
-                       (const uint64_t*)ws->d_cands[ccur], C, ws->d_opts, B, sb, partial ? 1 : 0, d_res, out_cap, d_res_n);
+                       (const uint64_t*)ws->d_cands[ccur], C, d_opts, B, sb, partial ? 1 : 0, d_res, out_cap, d_res_n);
     FPX_HIP(hipGetLastError());
     if (!partial) {
         FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -801,36 +819,37 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
 }
 
 // one pass, or -- when (query index, score) do not fit the 64-bit candidate key -- two half batches
-static int search_split(Snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
+                        const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                         const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
 {
     Workspace* ws = ws_acquire(snap->ctx);
     if (!ws) return FPX_E_NOMEM;
     fpx_stats local{};
-    int rc = run_batch(snap, ws, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local);
+    int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local);
     if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
     ws_release(snap->ctx, ws);
     if (rc == FPX_OK) { if (stats) add_stats(stats, local); return FPX_OK; }
     if (rc != FPX_SPLIT) return rc;
     if (B <= 1) { set_error("internal: single query cannot be split"); return FPX_E_DEVICE; }
     const uint32_t half = B / 2;
-    std::vector<uint64_t> off2(B - half + 1);
-    for (uint32_t q = half; q <= B; ++q) off2[q - half] = offsets[q] - offsets[half];
-    rc = search_split(snap, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+    rc = search_split(snap, resident, q0, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, stats);
     if (rc) return rc;
     fpx_result* out2 = out ? out + (size_t)half * out_cap : out;
-    return search_split(snap, hashes + offsets[half], off2.data(), B - half, opts + half, timeout_ms, partial,
+    return search_split(snap, resident, q0 + half, hashes, offsets + half, B - half, opts + half, timeout_ms, partial,
                         out2, out_cap, out_n + half, stats);
 }
 
-int search_batch_impl(Snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                       const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                       fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
 {
-    if (!snap || !offsets || !opts || !out_n || (!out && out_cap) || (B && offsets[B] && !hashes)) {
+    if (resident) { offsets = resident->offsets.data(); opts = resident->opts.data(); B = resident->B; hashes = nullptr; }
+    if (!snap || !offsets || !opts || !out_n || (!out && out_cap) || (!resident && B && offsets[B] && !hashes)) {
         set_error("null argument"); return FPX_E_INVAL;
     }
+    if (resident && resident->ctx != snap->ctx) { set_error("query batch and snapshot belong to different contexts"); return FPX_E_INVAL; }
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (B == 0) return FPX_OK;
     for (uint32_t q = 0; q < B; ++q) {
@@ -838,7 +857,47 @@ int search_batch_impl(Snapshot* snap, const uint32_t* hashes, const uint64_t* of
         if (offsets[q + 1] - offsets[q] >= (1ull << 32)) { set_error("query longer than 2^32-1 hashes"); return FPX_E_INVAL; }
     }
     FPX_HIP(hipSetDevice(snap->ctx->device));
-    return search_split(snap, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+    return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+}
+
+void query_batch_free(QueryBatch* qb)
+{
+    if (!qb) return;
+    (void)hipSetDevice(qb->ctx->device);
+    if (qb->d_hashes) (void)hipFree(qb->d_hashes);
+    if (qb->d_offsets) (void)hipFree(qb->d_offsets);
+    if (qb->d_opts) (void)hipFree(qb->d_opts);
+    delete qb;
+}
+
+int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                            const fpx_opts* opts, QueryBatch** out)
+{
+    *out = nullptr;
+    if (!ctx || !offsets || !opts || (B && offsets[B] && !hashes)) { set_error("null argument"); return FPX_E_INVAL; }
+    if (offsets[0] != 0) { set_error("offsets[0] must be 0"); return FPX_E_INVAL; }
+    for (uint32_t q = 0; q < B; ++q) {
+        if (offsets[q + 1] < offsets[q]) { set_error("offsets must be non-decreasing"); return FPX_E_INVAL; }
+        if (opts[q].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
+    }
+    FPX_HIP(hipSetDevice(ctx->device));
+    QueryBatch* qb = new (std::nothrow) QueryBatch();
+    if (!qb) return FPX_E_NOMEM;
+    qb->ctx = ctx; qb->B = B;
+    qb->offsets.assign(offsets, offsets + B + 1);
+    qb->opts.assign(opts, opts + B);
+    std::vector<uint32_t> h_opts;
+    fill_opts(h_opts, opts, offsets, B);
+    const uint64_t P = offsets[B];
+    hipError_t e = hipMalloc(&qb->d_hashes, (P + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&qb->d_offsets, ((size_t)B + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&qb->d_opts, ((size_t)B * 4 + 4) * sizeof(uint32_t));
+    if (e == hipSuccess && P) e = hipMemcpy(qb->d_hashes, hashes, P * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(qb->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && B) e = hipMemcpy(qb->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { query_batch_free(qb); return hip_fail(e, "query batch upload"); }
+    *out = qb;
+    return FPX_OK;
 }
 
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,

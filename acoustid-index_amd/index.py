@@ -247,3 +247,64 @@ class IndexReader:
         check(lib().fpx_search_batch(self.snapshot.h, _p(flat_h), _p(offsets), B, copts, timeout_ms,
                                      _p(out), cap, _p(out_n), C.byref(st)))
         return out, out_n, st
+
+
+class QueryBatch:
+    """A batch of queries resident in HBM (fpx_query_batch_create)."""
+
+    def __init__(self, ctx, queries=None, options=None, flat=None):
+        flat_h, offsets = _flatten(queries) if flat is None else flat
+        self.B = len(offsets) - 1
+        if isinstance(options, SearchOptions):
+            options = [options] * self.B
+        self.options = options
+        self.flat, self.offsets = flat_h, np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.copts = (Opts * max(1, self.B))(*[o.to_c() for o in options])
+        self.cap = max([1] + [o.max_results for o in options])
+        h = C.c_void_p()
+        check(lib().fpx_query_batch_create(ctx.h, _p(self.flat), _p(self.offsets), self.B, self.copts, C.byref(h)))
+        self.h = h
+        self.ctx = ctx
+
+    def release(self):
+        if getattr(self, "h", None):
+            lib().fpx_query_batch_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def search_resident(reader, qb, timeout_ms=0, out=None, out_n=None):
+    """fpx_search_resident: results to host numpy arrays [B, cap, 2] / [B]."""
+    if out is None:
+        out = np.zeros((max(1, qb.B), qb.cap, 2), np.uint32)
+        out_n = np.zeros(max(1, qb.B), np.uint32)
+    st = Stats()
+    check(lib().fpx_search_resident(reader.snapshot.h, qb.h, timeout_ms, _p(out), qb.cap, _p(out_n), C.byref(st)))
+    return out, out_n, st
+
+
+def search_resident_partial(reader, qb, d_out_ptr, d_out_n_ptr, timeout_ms=0):
+    """fpx_search_resident_partial: per-rank tables stay in HBM at the given device pointers."""
+    st = Stats()
+    check(lib().fpx_search_resident_partial(reader.snapshot.h, qb.h, timeout_ms, C.c_void_p(d_out_ptr), qb.cap,
+                                            C.c_void_p(d_out_n_ptr), C.byref(st)))
+    return st
+
+
+def merge_partials(ctx, qb, d_parts_ptr, d_counts_ptr, world, out=None, out_n=None):
+    """fpx_merge_partials: gathered [world][B][cap] tables -> final host results."""
+    if out is None:
+        out = np.zeros((max(1, qb.B), qb.cap, 2), np.uint32)
+        out_n = np.zeros(max(1, qb.B), np.uint32)
+    check(lib().fpx_merge_partials(ctx.h, C.c_void_p(d_parts_ptr), C.c_void_p(d_counts_ptr), world, qb.B, qb.cap,
+                                   qb.copts, _p(qb.offsets), _p(out), qb.cap, _p(out_n)))
+    return out, out_n
+
+
+def results_to_lists(out, out_n):
+    return [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(int(out_n[q]))] for q in range(len(out_n))]

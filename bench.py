@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the fpindex /_search hot path on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic queries (default: 1024 queries x 1000 hashes)
+against a seeded synthetic index resident in HBM (default: BASELINE.json configs[2], 100 M fingerprints x 256
+hashes in 16 FileSegments).  With --gpus N > 1 the SAME index is sharded by segment over the ranks
+(segment s lives on rank s % N), every rank probes its own segments for the whole batch, the per-rank top-k
+tables are exchanged with one RCCL all-gather and merged (strong scaling: total work fixed).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=int(os.environ.get("FPX_BENCH_DOCS", 100_000_000)))
+    ap.add_argument("--segments", type=int, default=int(os.environ.get("FPX_BENCH_SEGMENTS", 16)))
+    ap.add_argument("--hashes", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FPX_BENCH_BATCH", 1024)))
+    ap.add_argument("--query-len", type=int, default=1000)
+    ap.add_argument("--limit", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("FPX_BENCH_CPU_QUERIES", 256)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--measure-bw", action="store_true", help="also report the measured streaming / random-block read bandwidth")
+    return ap.parse_args()
+
+
+def cpu_baseline(fpx, oracle, ctx, seg, first_doc, ndocs, flat, offsets, nq, nseg_total, gpu_single, block_size=512):
+    """The oracle (C restatement of the reference CPU path) on this box's host cores, on a bounded sample:
+    `nq` queries of the SAME batch against ONE of the index's segments (downloaded from HBM), one query per
+    thread on all cores (the reference runs one search per executor thread, src/main.zig:272-276).  A whole
+    query costs `nseg_total` such segment scans, so qps = nq / seconds / nseg_total."""
+    blocks, index = seg.download()
+    ids = np.arange(first_doc, first_doc + ndocs, dtype=np.uint32)
+    oseg = oracle.file_segment(blocks, block_size, index, first_doc, first_doc + ndocs - 1, 1, ids, borrow=True)
+    osnap = oracle.Snapshot([oseg], [])
+    cores = os.cpu_count() or 1
+    queries = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(nq)]
+    results = [None] * nq
+
+    def work(tid):
+        for i in range(tid, nq, cores):
+            results[i] = osnap.search(queries[i], 40, None, 10)
+
+    # warm the page cache / tables with a few queries
+    for i in range(min(4, nq)):
+        osnap.search(queries[i], 40, None, 10)
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    # parity at full size on the sample: the GPU path restricted to the same segment must agree bit-exactly
+    mism = sum(1 for i in range(nq) if results[i] != gpu_single[i])
+    qps = nq / dt / nseg_total
+    return {"value": qps, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{nq} queries of the batch x 1 of {nseg_total} segments, {dt:.2f} s wall on {cores} threads; "
+                      f"qps = {nq}/{dt:.2f}/{nseg_total}; GPU-vs-oracle mismatches on the sample: {mism}",
+            "parity_mismatches": mism}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})", file=sys.stderr)
+        sys.exit(2)
+
+    import torch                                   # first: one HIP runtime for torch and libfpx
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    fpx = load_package()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libfpx has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctx = fpx.Context(local_rank)
+
+    # ---- index: S contiguous id ranges, commit_id = s + 1; shrink if HBM is too small
+    S, H, B = args.segments, args.hashes, args.batch
+    docs = args.docs
+    free_b, total_b = torch.cuda.mem_get_info()
+    local_segs = [s for s in range(S) if s % world == rank]
+    est_seg_bytes = (docs // S) * H * 5.4                  # ~4.5-5.3 B/item in blocks
+    need = est_seg_bytes * len(local_segs) + (docs // S) * H * 8 * 2.3 + (4 << 30)   # + build scratch of one segment
+    while need > free_b * 0.92 and docs > 1_000_000:
+        docs //= 2
+        est_seg_bytes = (docs // S) * H * 5.4
+        need = est_seg_bytes * len(local_segs) + (docs // S) * H * 8 * 2.3 + (4 << 30)
+    per = docs // S
+    docs = per * S
+    t_build0 = time.perf_counter()
+    segs = []
+    for s in range(S):
+        lo = s * per + 1
+        if s in local_segs:
+            segs.append(fpx.FileSegment.synth(ctx, args.seed, lo, per, H, 0, 512, s + 1))
+        else:
+            segs.append(fpx.RemoteSegment(ctx, lo, lo + per - 1, s + 1, np.arange(lo, lo + per, dtype=np.uint32)))
+    snapshot = fpx.Segments(ctx, segs)
+    reader = fpx.IndexReader(snapshot)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build0
+    index_bytes = sum(s.device_bytes for s in segs if s.kind == "file")
+    index_blocks = sum(s.num_blocks for s in segs if s.kind == "file")
+
+    # ---- queries (identical on every rank), resident in HBM before the timed region
+    flat, offsets, targets = fpx.synth.make_queries(args.seed, 4242, B, docs, H, query_len=args.query_len)
+    opts = fpx.http_options(limit=args.limit)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    cap = qb.cap
+    out = np.zeros((B, cap, 2), np.uint32)
+    out_n = np.zeros(B, np.uint32)
+    if world > 1:
+        d_part = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
+        d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        d_parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
+        d_cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+
+    agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0}
+
+    def step(record):
+        if world == 1:
+            _, _, st = fpx.search_resident(reader, qb, 0, out, out_n)
+        else:
+            st = fpx.search_resident_partial(reader, qb, d_part.data_ptr(), d_cnt.data_ptr())
+            dist.all_gather_into_tensor(d_parts, d_part)           # RCCL over xGMI: [world][B][cap]{id,score}
+            dist.all_gather_into_tensor(d_cnts, d_cnt)
+            torch.cuda.synchronize()
+            fpx.merge_partials(ctx, qb, d_parts.data_ptr(), d_cnts.data_ptr(), world, out, out_n)
+        if record:
+            agg["bytes"] += st.algorithmic_bytes
+            agg["probe_ms"] += st.probe_kernel_ms
+            agg["launches"] += st.probe_launches
+            agg["blocks"] += st.scanned_blocks
+            agg["gpu_ms"] += st.total_gpu_ms
+            agg["hits"] += st.hits
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # roofline numerator / denominator of the slowest rank is this rank's own; report rank 0's kernel
+    qps = B * args.steps / dt
+
+    # ---- size-independent correctness property at full size: the target doc ranks first
+    found = sum(1 for q in range(B) if out_n[q] > 0 and out[q, 0, 0] == targets[q])
+    top_scores = [int(out[q, 0, 1]) for q in range(B) if out_n[q] > 0]
+
+    result = None
+    if rank == 0:
+        launches = max(1, agg["launches"])
+        avg_ms = agg["probe_ms"] / launches
+        bytes_per_launch = agg["bytes"] / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        result = {
+            "metric": "queries/sec + p50 /_search latency, 100M-fp index, 1k-hash queries",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{docs} fingerprints x {H} u32 hashes in {S} FileSegments (512-B blocks), "
+                                   f"segments sharded over {world} GPU(s); batch of {B} queries x {args.query_len} hashes, "
+                                   f"limit {args.limit}, min_score (n+19)/20, score_pct 10; queries resident in HBM",
+                       "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "query_len": args.query_len,
+                       "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
+                       "index_build_seconds": round(build_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                         "visited_blocks_per_launch": agg["blocks"] / launches},
+            "p50_batch_latency_ms": dt / args.steps * 1e3,
+            "gpu_ms_per_step": agg["gpu_ms"] / max(1, args.steps),
+            "hits_per_step": agg["hits"] / max(1, args.steps),
+            "targets_found": found, "targets_total": B, "median_top_score": int(np.median(top_scores)) if top_scores else 0,
+        }
+        if args.measure_bw:
+            s_gbs, r_gbs = ctx.measure_bandwidth(8 << 30, 512)
+            result["measured_bandwidth"] = {"stream_read_GBs": s_gbs, "random_512B_read_GBs": r_gbs}
+
+    # ---- p50 latency of a single /_search (batch of 1), rank-local index share only when sharded
+    if rank == 0 and world == 1:
+        lat = []
+        one = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(32)]
+        r1 = fpx.SearchResults(opts)
+        for i in range(32):
+            t1 = time.perf_counter()
+            reader.search(one[i], r1)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        result["p50_single_search_ms"] = float(np.median(lat[4:]))
+
+    # ---- CPU baseline on rank 0 at N = 1
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        nq = min(args.cpu_queries, B)
+        seg0 = segs[0]
+        single = fpx.IndexReader(fpx.Segments(ctx, [seg0]))
+        sub = fpx.QueryBatch(ctx, options=opts, flat=(np.ascontiguousarray(flat[:int(offsets[nq])]), offsets[:nq + 1]))
+        o1, n1, _ = fpx.search_resident(single, sub)
+        gpu_single = fpx.results_to_lists(o1, n1)
+        result["cpu_baseline"] = cpu_baseline(fpx, oracle, ctx, seg0, 1, per, flat, offsets, nq, S, gpu_single)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

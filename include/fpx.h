@@ -146,6 +146,18 @@ int fpx_search_batch(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t 
                      uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
                      fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
 
+/* Query batch already resident in HBM: what a host-side coalescer that keeps its staging buffers on the
+ * device would hand over, and what bench.py times ("inputs resident in HBM when the timed region starts").
+ * fpx_search_resident(snap, qb, ...) == fpx_search_batch(snap, <the arrays qb was created from>, ...). */
+typedef struct fpx_query_batch fpx_query_batch;
+int  fpx_query_batch_create(fpx_ctx *ctx, const uint32_t *hashes, const uint64_t *offsets, uint32_t num_queries,
+                            const fpx_opts *opts, fpx_query_batch **out);
+void fpx_query_batch_release(fpx_query_batch *qb);
+int  fpx_search_resident(fpx_snapshot *snap, const fpx_query_batch *qb, uint32_t timeout_ms,
+                         fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
+int  fpx_search_resident_partial(fpx_snapshot *snap, const fpx_query_batch *qb, uint32_t timeout_ms,
+                                 void *d_out, uint32_t out_cap, void *d_out_n, fpx_stats *stats);
+
 /* Segment-sharded multi-GPU: stage 1 on every rank.  Same as fpx_search_batch but the
  * per-query tables stay in HBM (d_out: num_queries * out_cap fpx_result, d_out_n: num_queries u32,
  * both DEVICE pointers) and only the absolute min_score floor is applied, so the tables of all

@@ -372,6 +372,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
             sn->h_file.push_back(d);
             sn->max_block_size = std::max(sn->max_block_size, s->block_size);
+            if (s->block_size != 512) sn->all_512 = false;
         } else {
             MemDesc d{};
             d.items = s->d_items; d.dead = d_dead; d.num_items = s->num_items;

@@ -82,6 +82,7 @@ struct Snapshot {
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
     std::vector<uint32_t*> d_dead;       // owned dead lists
     uint32_t max_block_size = 0;
+    bool all_512 = true;                 // every file segment uses 512-B blocks (the only size the reference writes)
 };
 
 // Pooled per-call device workspace (analogue of SearchResultsPool, src/common.zig:186-300).

@@ -33,11 +33,25 @@ namespace fpx {
 // ------------------------------------------------------------------------------------------------
 constexpr int WG = 256;            // 4 waves
 constexpr int WAVES = WG / 64;
-constexpr int STAGE_CAP = 2048;    // LDS hit staging per workgroup (records)
-constexpr int STAGE_FLUSH = 1024;
+constexpr int STAGE_CAP = 1024;    // LDS hit staging per workgroup (records)
+constexpr int STAGE_FLUSH = 512;
 constexpr int MAX_BLOCKS_PER_HASH = 4;     // src/FileSegment.zig:25
 constexpr int MAX_DOCS_PER_HASH = 1000;    // src/FileSegment.zig:26
 constexpr int MAX_ITEMS_PER_BLOCK = 2048;  // src/block.zig:43
+
+// Pointers read out of a descriptor in memory have no known address space, so plain dereferences compile to
+// FLAT loads, which tick both vmcnt and lgkmcnt and serialise against every LDS access.  These helpers pin
+// the global address space (global_load_*), which keeps LDS traffic and the block prefetch independent.
+#define FPX_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ uint32_t gload_u32(const uint32_t* p) { return *(const FPX_GLOBAL uint32_t*)p; }
+__device__ __forceinline__ uint64_t gload_u64(const uint64_t* p) { return *(const FPX_GLOBAL uint64_t*)p; }
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gload_u4(const uint8_t* p)
+{
+    const u32x4_t v = *(const FPX_GLOBAL u32x4_t*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint8_t gload_u8(const uint8_t* p) { return *(const FPX_GLOBAL uint8_t*)p; }
 
 // byte length of the 4 values of one control byte; value i lives in bits 2i..2i+1
 // (src/streamvbyte.zig:178-211).  0124: code c -> c + (c == 3);  1234: code c -> c + 1.
@@ -82,9 +96,9 @@ __device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         uint32_t m = (lo + hi) >> 1;
-        if (dead[m] < d) lo = m + 1; else hi = m;
+        if (gload_u32(dead + m) < d) lo = m + 1; else hi = m;
     }
-    return lo < n && dead[lo] == d;
+    return lo < n && gload_u32(dead + lo) == d;
 }
 
 // first block whose max hash >= h (src/FileSegment.zig:145-151); the reference restricts the search
@@ -92,10 +106,10 @@ __device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32
 __device__ __forceinline__ uint32_t lookup_block(const SegDesc& s, uint32_t h)
 {
     uint32_t k = s.bucket_shift >= 32u ? 0u : (h >> s.bucket_shift);
-    uint32_t lo = s.bucket[k], hi = s.bucket[k + 1];
+    uint32_t lo = gload_u32(s.bucket + k), hi = gload_u32(s.bucket + k + 1);
     while (lo < hi) {
         uint32_t m = (lo + hi) >> 1;
-        if (s.block_index[m] < h) lo = m + 1; else hi = m;
+        if (gload_u32(s.block_index + m) < h) lo = m + 1; else hi = m;
     }
     return lo;
 }
@@ -131,65 +145,176 @@ struct ProbeArgs {
     unsigned long long* counters;
 };
 
-__global__ __launch_bounds__(WG) void k_probe(ProbeArgs a)
+// ---- decode tables (the GPU form of the reference's 256-entry shuffle/length tables, src/streamvbyte.zig:76-211)
+// lutA[v][c]: byte offsets of values 1..3 of control byte c (one byte each) | total length << 24
+// lutB[v][c]: four v_perm_b32 selectors that keep the low nb bytes of an unaligned dword and zero the rest
+struct DecodeLut {
+    uint32_t a[2][256];
+    uint4 b[2][256];
+};
+
+__device__ __forceinline__ uint32_t perm_sel(uint32_t nb)
+{
+    // selector byte 0x0c yields 0x00; 0..3 pick that byte of the source dword
+    return nb == 0u ? 0x0C0C0C0Cu : nb == 1u ? 0x0C0C0C00u : nb == 2u ? 0x0C0C0100u : nb == 3u ? 0x0C020100u : 0x03020100u;
+}
+
+__device__ __forceinline__ void init_lut(DecodeLut* lut, uint32_t c)
+{
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        uint32_t off = 0, packed = 0, sel[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t code = (c >> (2 * k)) & 3u;
+            const uint32_t nb = v == 0 ? code + (code == 3u ? 1u : 0u) : code + 1u;
+            if (k > 0) packed |= off << (8 * (k - 1));
+            sel[k] = perm_sel(nb);
+            off += nb;
+        }
+        lut->a[v][c] = packed | (off << 24);
+        lut->b[v][c] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+    }
+}
+
+// little-endian dword at byte offset `off` of the workgroup's dynamic LDS: one aligned dword-pair read
+// (ds_read2_b32) + v_alignbyte.  gfx950 also executes unaligned ds_read_b32, but measured ~20x slower.
+__device__ __forceinline__ uint32_t lds_u32u(const uint8_t* sm, uint32_t off)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(sm + (off & ~3u));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], off);
+}
+
+// the four values of the control byte c whose data starts at byte offset `off` of the dynamic LDS
+template <int V>
+__device__ __forceinline__ void decode_quad(const DecodeLut* lut, const uint8_t* sm, uint32_t off, uint32_t c, uint32_t v[4])
+{
+    const uint32_t a = lut->a[V][c];
+    const uint4 sel = lut->b[V][c];
+    const uint32_t r0 = lds_u32u(sm, off), r1 = lds_u32u(sm, off + (a & 0xFFu)), r2 = lds_u32u(sm, off + ((a >> 8) & 0xFFu)),
+                   r3 = lds_u32u(sm, off + ((a >> 16) & 0xFFu));
+    v[0] = __builtin_amdgcn_perm(r0, r0, sel.x);
+    v[1] = __builtin_amdgcn_perm(r1, r1, sel.y);
+    v[2] = __builtin_amdgcn_perm(r2, r2, sel.z);
+    v[3] = __builtin_amdgcn_perm(r3, r3, sel.w);
+}
+
+// inclusive prefix sum inside each 16-lane row of the wave on the DPP crossbar (no LDS traffic)
+__device__ __forceinline__ uint32_t scan16(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    return v;
+}
+
+// value held by lane 15 of the own 16-lane row (ds_swizzle bit mode: lane' = (lane & 0x10) | 0x0f)
+__device__ __forceinline__ uint32_t row_last(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (0x0F << 5));
+}
+
+// ---- the probe kernel ---------------------------------------------------------------------------
+// One wave works on FOUR probes at a time, one per 16-lane row; lane r of a row owns quads 2r and 2r+1
+// of every 32-quad chunk of the block (a 512-B block holds ~29 quads).  Blocks are prefetched one
+// iteration ahead into registers (FAST512) so that ~40 random 512-B reads per SIMD are in flight.
+constexpr int PWG = 512;           // probe workgroup: 8 waves share the decode tables and the hit staging
+constexpr int PWAVES = PWG / 64;
+
+template <bool FAST512>
+__global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint64_t* stage = reinterpret_cast<uint64_t*>(smem);                  // STAGE_CAP records
-    uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t);                // WAVES * 2 * bsp bytes
+    DecodeLut* lut = reinterpret_cast<DecodeLut*>(smem + STAGE_CAP * sizeof(uint64_t));
+    uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut);   // PWAVES * 4 * bsp bytes
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
-    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_bytes;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, half = lane >> 5, sl = lane & 31u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 4, gl = lane & 15u;
     const SegDesc seg = a.segs[blockIdx.y];
-    uint8_t* blk = blkmem + (size_t)(wave * 2u + half) * a.bsp;
+    uint8_t* blk = blkmem + (size_t)(wave * 4u + g) * a.bsp;
+    const uint32_t blko = (uint32_t)(blk - smem);          // my row's staging slot as an offset into the dynamic LDS
     const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
+    const uint32_t bs = FAST512 ? 512u : seg.block_size;
 
+    if (tid < 256u) init_lut(lut, tid);
     if (tid == 0) {
         stage_count = 0; stage_valid = STAGE_CAP;
-        wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_bytes = 0;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0;
     }
     __syncthreads();
 
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
 
-    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(WAVES * a.ppw) * a.rounds;
+    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
     for (uint32_t round = 0; round < a.rounds; ++round) {
         // ---- phase 1: one lane per pair: dedup + block lookup
-        uint64_t p = wg_base + (uint64_t)round * (WAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
+        uint64_t p = wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
         bool valid = lane < a.ppw && p < a.P;
-        uint64_t key = valid ? a.pairs[p] : 0ull;
-        if (valid && p > 0 && a.pairs[p - 1] == key) valid = false;      // dedupSorted, src/Index.zig:489-499
-        uint32_t h = (uint32_t)(key >> a.qb);
-        uint32_t q = (uint32_t)key & qmask;
+        uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
+        if (valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;      // dedupSorted, src/Index.zig:489-499
+        const uint32_t h = (uint32_t)(key >> a.qb);
+        const uint32_t q = (uint32_t)key & qmask;
         uint32_t b0 = seg.num_blocks;
         if (valid) {
             my_probes += 1;
             b0 = lookup_block(seg, h);
         }
         if (b0 >= seg.num_blocks) valid = false;
+        // bit 31 of the block number carries `valid` through the row broadcast below
+        const uint32_t b0v = (b0 & 0x7FFFFFFFu) | (valid ? 0x80000000u : 0u);
 
-        // ---- phase 2: two probes per iteration, one per 32-lane half
-        const uint32_t iters = (a.ppw + 1u) >> 1;
+        // ---- phase 2: four probes per iteration, one per 16-lane row
+        const uint32_t iters = (a.ppw + 3u) >> 2;
+        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+        if (FAST512) {
+            const uint32_t nb = __shfl(b0v, (int)g);
+            if (nb >> 31) {
+                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                pre0 = gload_u4(sb);
+                pre1 = gload_u4(sb + 256);
+            }
+        }
         for (uint32_t it = 0; it < iters; ++it) {
-            const int src = (int)(it * 2u + half);
+            const int src = (int)(it * 4u + g);
             const uint32_t ph = __shfl(h, src);
             const uint32_t pq = __shfl(q, src);
-            uint32_t pb = __shfl(b0, src);
-            bool pact = __shfl((int)valid, src) != 0;
+            const uint32_t pbv = __shfl(b0v, src);
+            uint32_t pb = pbv & 0x7FFFFFFFu;
+            bool pact = (pbv >> 31) != 0u;
             uint32_t nbv = 0, ndv = 0;
+            bool first = true;
+
+            uint4 cur0 = pre0, cur1 = pre1;
+            if (FAST512 && it + 1u < iters) {
+                // prefetch the blocks of the next iteration while this one is decoded
+                const uint32_t nb = __shfl(b0v, src + 4);
+                if (nb >> 31) {
+                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                    pre0 = gload_u4(sb);
+                    pre1 = gload_u4(sb + 256);
+                }
+            }
 
             while (__any(pact)) {
-                uint32_t kf = 0;                 // bit k: value k of my quad is a kept match
-                uint32_t dd[4] = {0, 0, 0, 0};
+                uint32_t kf = 0;                 // bit k: value k of my two quads is a kept match
+                uint32_t dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 bool cont = false;
                 if (pact) {
-                    // -- stage the block in LDS (coalesced 16-B loads: the half-wave reads 512 contiguous bytes)
-                    const uint8_t* src_blk = seg.blocks + (size_t)pb * seg.block_size;
-                    if ((seg.block_size & 15u) == 0u) {
-                        for (uint32_t o = sl * 16u; o < seg.block_size; o += 512u)
-                            *reinterpret_cast<uint4*>(blk + o) = *reinterpret_cast<const uint4*>(src_blk + o);
+                    // -- stage the block in LDS (each 16-lane row moves one contiguous block)
+                    if (FAST512 && first) {
+                        *reinterpret_cast<uint4*>(blk + gl * 16u) = cur0;
+                        *reinterpret_cast<uint4*>(blk + 256u + gl * 16u) = cur1;
                     } else {
-                        for (uint32_t o = sl; o < seg.block_size; o += 32u) blk[o] = src_blk[o];
+                        const uint8_t* src_blk = seg.blocks + (size_t)pb * bs;
+                        if ((bs & 15u) == 0u) {
+                            for (uint32_t o = gl * 16u; o < bs; o += 256u)
+                                *reinterpret_cast<uint4*>(blk + o) = gload_u4(src_blk + o);
+                        } else {
+                            for (uint32_t o = gl; o < bs; o += 16u) blk[o] = gload_u8(src_blk + o);
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -206,85 +331,91 @@ __global__ __launch_bounds__(WG) void k_probe(ProbeArgs a)
                         const uint32_t hdata = 8u + nq;                 // hash data starts after nq control bytes
                         const uint32_t dctrl = 8u + doff;               // docid control bytes
                         const uint32_t ddata = dctrl + nq;
-                        const uint32_t limit = a.bsp - 8u;              // keep corrupt offsets inside the staging slot
+                        const uint32_t limit = a.bsp - 24u;             // keeps corrupt offsets inside the staging slot
                         uint32_t hoff_carry = 0, hval_carry = 0, xcarry = 0, cnt = 0;
+                        bool ends_with_ph = false;                      // the block's last item carries hash ph
                         for (uint32_t c0 = 0; c0 < nq; c0 += 32u) {
-                            const uint32_t qi = c0 + sl;
-                            const bool act = qi < nq;
+                            const uint32_t qa = c0 + 2u * gl;             // my quads: qa, qa + 1
+                            const bool more_chunks = c0 + 32u < nq;
                             // ---- hashes: 0124 + delta (src/block.zig:137-158, src/streamvbyte.zig:264-283)
-                            const uint32_t hc = act ? blk[8u + qi] : 0u;
-                            const uint32_t hl = len0124(hc);
-                            const uint32_t hincl = scan32(hl, sl);
-                            uint32_t pp = min(hdata + hoff_carry + hincl - hl, limit);
-                            hoff_carry += __shfl(hincl, 31, 32);
-                            uint32_t v[4];
+                            uint32_t cc = *reinterpret_cast<const uint16_t*>(blk + min(8u + qa, limit));   // 2 control bytes
+                            cc = qa + 1u < nq ? cc : (qa < nq ? (cc & 0xFFu) : 0u);   // control 0 decodes to four zeros
+                            const uint32_t ca = cc & 0xFFu, cb = cc >> 8;
+                            const uint32_t la = lut->a[0][ca]   >> 24, lb = lut->a[0][cb]   >> 24;
+                            const uint32_t hincl = scan16(la + lb);
+                            const uint32_t pa = min(hdata + hoff_carry + hincl - la - lb, limit);
+                            uint32_t v[8];
+                            decode_quad<0>(lut, smem, blko + pa, ca, v);
+                            decode_quad<0>(lut, smem, blko + min(pa + la, limit), cb, v + 4);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const uint32_t code = (hc >> (2 * k)) & 3u;
-                                const uint32_t nb = code + (code == 3u ? 1u : 0u);
-                                v[k] = keep_bytes(lds_u32(blk, pp), nb);
-                                pp = min(pp + nb, limit);
-                            }
-                            v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
-                            const uint32_t vincl = scan32(v[3], sl);
-                            const uint32_t base = min_hash + hval_carry + vincl - v[3];
-                            hval_carry += __shfl(vincl, 31, 32);
+                            for (int k = 1; k < 8; ++k) v[k] += v[k - 1];
+                            const uint32_t vincl = scan16(v[7]);
+                            // target relative to my first value's base: a match is v[k] == t
+                            const uint32_t t = ph - (min_hash + hval_carry + vincl - v[7]);
+                            if (more_chunks) { hoff_carry += row_last(hincl); hval_carry += row_last(vincl); }
                             // ---- equalRange (src/block.zig:217-231): matches form one contiguous run
                             uint32_t e = 0;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (qi * 4u + (uint32_t)k < n_items && base + v[k] == ph) e |= 1u << k;
-                            const bool any_e = __any((int)(e != 0u)) != 0;   // wave-level; halves checked below
-                            if (any_e) {
+                            for (int k = 7; k >= 0; --k) e = e + e + (v[k] == t ? 1u : 0u);     // v_cmp + v_addc per value
+                            // quads past nq were decoded from control byte 0 and repeat the previous value
+                            e &= qa + 1u < nq ? 0xFFu : (qa < nq ? 0x0Fu : 0u);
+                            if (__any((int)(n_items & 3u))) {
+                                // only the last block of a segment holds a partial quad: its padding items repeat too
+                                const uint32_t first_item = qa * 4u;
+                                const uint32_t nvalid = n_items > first_item ? min(n_items - first_item, 8u) : 0u;
+                                e &= (1u << nvalid) - 1u;
+                            }
+                            {
+                                // does the block's last item carry ph?  (then the next block may continue the run)
+                                const uint32_t last = n_items - 1u - qa * 4u;        // index of the last item among my 8
+                                ends_with_ph = last < 8u && ((e >> last) & 1u);
+                            }
+                            if (__any((int)(e != 0u))) {
                                 // ---- docids of the run: 1234, no delta, then prefix sum seeded with min_doc_id
                                 //      (src/block.zig:235-265, src/streamvbyte.zig:287-339)
                                 uint32_t dbase = 0;
                                 if (c0 != 0u) {
                                     // data bytes of all earlier quads of this block
                                     uint32_t s = 0;
-                                    for (uint32_t j = sl; j < c0; j += 32u) s += len1234(blk[dctrl + j]);
-                                    s = scan32(s, sl);
-                                    dbase = __shfl(s, 31, 32);
+                                    for (uint32_t j = gl; j < c0; j += 16u) s += lut->a[1][blk[min(dctrl + j, limit)]]   >> 24;
+                                    dbase = row_last(scan16(s));
                                 }
-                                const uint32_t dc = act ? blk[min(dctrl + qi, limit)] : 0u;
-                                const uint32_t dl = act ? len1234(dc) : 0u;
-                                const uint32_t dincl = scan32(dl, sl);
-                                uint32_t dp = min(ddata + dbase + dincl - dl, limit);
-                                uint32_t x[4];
+                                const uint32_t dcc = lds_u32u(smem, blko + min(dctrl + qa, limit));
+                                const uint32_t da = dcc & 0xFFu, db = (dcc >> 8) & 0xFFu;
+                                const uint32_t dla = qa < nq ? (lut->a[1][da]   >> 24) : 0u;
+                                const uint32_t dlb = qa + 1u < nq ? (lut->a[1][db]   >> 24) : 0u;
+                                const uint32_t dincl = scan16(dla + dlb);
+                                uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                                if (e != 0u) {
+                                    const uint32_t dpa = min(ddata + dbase + dincl - dla - dlb, limit);
+                                    if (e & 0x0Fu) decode_quad<1>(lut, smem, blko + dpa, da, x);
+                                    if (e & 0xF0u) decode_quad<1>(lut, smem, blko + min(dpa + dla, limit), db, x + 4);
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    const uint32_t nb = ((dc >> (2 * k)) & 3u) + 1u;
-                                    const uint32_t raw = keep_bytes(lds_u32(blk, dp), nb);
-                                    x[k] = ((e >> k) & 1u) ? raw : 0u;
-                                    dp = min(dp + nb, limit);
-                                }
-                                x[1] += x[0]; x[2] += x[1]; x[3] += x[2];
-                                const uint32_t xincl = scan32(x[3], sl);
-                                const uint32_t xb = seg.min_doc_id + xcarry + xincl - x[3];
-                                xcarry += __shfl(xincl, 31, 32);
-                                uint32_t ecount = scan32(__popc(e), sl);
-                                cnt += __shfl(ecount, 31, 32);
+                                    for (int k = 0; k < 8; ++k) x[k] = ((e >> k) & 1u) ? x[k] : 0u;
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    if ((e >> k) & 1u) {
-                                        kf |= 1u << k;
-                                        dd[k] = xb + x[k];
-                                    }
+                                    for (int k = 1; k < 8; ++k) x[k] += x[k - 1];
                                 }
+                                const uint32_t xincl = scan16(x[7]);
+                                const uint32_t xb = seg.min_doc_id + xcarry + xincl - x[7];
+                                if (more_chunks) xcarry += row_last(xincl);
+                                cnt += row_last(scan16(__popc(e)));
+                                kf = e;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) dd[k] = xb + x[k];
                             }
                             // supersession (src/common.zig:158 + src/Index.zig:133-149), applied per posting: a doc
                             // that a newer segment mentions contributes nothing from this segment
                             if (seg.num_dead != 0u && kf != 0u) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k)
+                                for (int k = 0; k < 8; ++k)
                                     if (((kf >> k) & 1u) && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, dd[k]))
                                         kf &= ~(1u << k);
                             }
                             // blocks with more than 128 items (rare at 512 B): every chunk but the last hands its
                             // matches to the staging buffer lane by lane, the last one uses the ballot path below
-                            if (c0 + 32u < nq && kf != 0u) {
+                            if (more_chunks && kf != 0u) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
+                                for (int k = 0; k < 8; ++k) {
                                     if ((kf >> k) & 1u) {
                                         const uint64_t rec = ((uint64_t)pq << 32) | dd[k];
                                         const uint32_t pos = atomicAdd(&stage_count, 1u);
@@ -292,8 +423,8 @@ __global__ __launch_bounds__(WG) void k_probe(ProbeArgs a)
                                             stage[pos] = rec;
                                         } else {
                                             atomicMin(&stage_valid, pos);
-                                            unsigned long long g = atomicAdd(&a.counters[CTR_HITS], 1ull);
-                                            if (g < a.hit_cap) a.hits[g] = rec;
+                                            unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
+                                            if (gg < a.hit_cap) a.hits[gg] = rec;
                                         }
                                     }
                                 }
@@ -305,33 +436,38 @@ __global__ __launch_bounds__(WG) void k_probe(ProbeArgs a)
                         ndv += cnt;
                         const bool more = nbv < (uint32_t)MAX_BLOCKS_PER_HASH && ndv <= (uint32_t)MAX_DOCS_PER_HASH &&
                                           pb + 1u < seg.num_blocks;
-                        // the next block can only start with ph if this block ends with ph
-                        if (more && seg.block_index[pb] == ph) cont = true;
-                        if (sl == 0) { my_blocks += 1; my_docs += cnt; }
+                        // the next block can only start with ph if this block ends with ph (block_index[pb] == ph,
+                        // read off the decoded items instead of global memory so that nothing queues behind the prefetch)
+                        const uint32_t ends_row = (uint32_t)(__ballot((int)ends_with_ph) >> (g * 16u)) & 0xFFFFu;
+                        if (more && ends_row != 0u) cont = true;
+                        if (gl == 0) { my_blocks += 1; my_docs += cnt; }
                     }
                 }
                 pact = cont;
                 pb += 1;
+                first = false;
 
                 // ---- emission of this iteration's kept matches (wave-uniform control flow)
+                if (__any((int)(kf != 0u))) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned long long m = __ballot((int)((kf >> k) & 1u));
-                    if (m == 0ull) continue;
-                    const uint32_t total = __popcll(m);
-                    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-                    uint32_t pos = 0;
-                    if (lane == 0) pos = atomicAdd(&stage_count, total);
-                    pos = __shfl(pos, 0);
-                    if (pos + total <= (uint32_t)STAGE_CAP) {
-                        if ((kf >> k) & 1u) stage[pos + rank] = ((uint64_t)pq << 32) | dd[k];
-                    } else {
-                        // staging full: remember where the valid prefix ends and append directly
-                        if (lane == 0) atomicMin(&stage_valid, pos);
-                        unsigned long long g = 0;
-                        if (lane == 0) g = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
-                        g = __shfl(g, 0);
-                        if (((kf >> k) & 1u) && g + rank < a.hit_cap) a.hits[g + rank] = ((uint64_t)pq << 32) | dd[k];
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned long long m = __ballot((int)((kf >> k) & 1u));
+                        if (m == 0ull) continue;
+                        const uint32_t total = __popcll(m);
+                        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+                        uint32_t pos = 0;
+                        if (lane == 0) pos = atomicAdd(&stage_count, total);
+                        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                        if (pos + total <= (uint32_t)STAGE_CAP) {
+                            if ((kf >> k) & 1u) stage[pos + rank] = ((uint64_t)pq << 32) | dd[k];
+                        } else {
+                            // staging full: remember where the valid prefix ends and append directly
+                            if (lane == 0) atomicMin(&stage_valid, pos);
+                            unsigned long long gg = 0;
+                            if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+                            gg = __shfl(gg, 0);
+                            if (((kf >> k) & 1u) && gg + rank < a.hit_cap) a.hits[gg + rank] = ((uint64_t)pq << 32) | dd[k];
+                        }
                     }
                 }
             }
@@ -344,13 +480,13 @@ __global__ __launch_bounds__(WG) void k_probe(ProbeArgs a)
         if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
             const uint32_t n = min(sc, stage_valid);
             if (tid == 0) {
-                unsigned long long g = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
-                flush_base_lo = (uint32_t)g; flush_base_hi = (uint32_t)(g >> 32);
+                unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
+                flush_base_lo = (uint32_t)gg; flush_base_hi = (uint32_t)(gg >> 32);
             }
             __syncthreads();
-            const unsigned long long g = ((unsigned long long)flush_base_hi << 32) | flush_base_lo;
-            for (uint32_t i = tid; i < n; i += WG)
-                if (g + i < a.hit_cap) a.hits[g + i] = stage[i];
+            const unsigned long long gg = ((unsigned long long)flush_base_hi << 32) | flush_base_lo;
+            for (uint32_t i = tid; i < n; i += PWG)
+                if (gg + i < a.hit_cap) a.hits[gg + i] = stage[i];
             __syncthreads();
             if (tid == 0) { stage_count = 0; stage_valid = STAGE_CAP; }
         }
@@ -710,14 +846,17 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             // enough workgroups to fill 256 CUs; long per-wave runs amortise the index walk for big batches
             const uint64_t total = P * snap->n_file;
             a.ppw = total >= (1ull << 22) ? 64u : total >= (1ull << 18) ? 16u : 4u;
-            a.rounds = total >= (1ull << 24) ? 4u : 1u;
-            a.bsp = ((snap->max_block_size + 15u) & ~15u) + 16u;
+            a.rounds = total >= (1ull << 25) ? 2u : 1u;
+            a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
-            const uint64_t per_wg = (uint64_t)WAVES * a.ppw * a.rounds;
+            const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
-            const size_t lds = STAGE_CAP * sizeof(uint64_t) + (size_t)WAVES * 2 * a.bsp;
+            const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
             FPX_HIP(hipEventRecord(ws->ev_probe0, st));
-            hipLaunchKernelGGL(k_probe, dim3(gx, snap->n_file), dim3(WG), lds, st, a);
+            if (snap->all_512)
+                hipLaunchKernelGGL(k_probe<true>, dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+            else
+                hipLaunchKernelGGL(k_probe<false>, dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             FPX_HIP(hipGetLastError());
             probe_launches += 1;

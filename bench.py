@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("FPX_BENCH_CPU_QUERIES", 256)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency probe (profiling runs)")
     ap.add_argument("--measure-bw", action="store_true", help="also report the measured streaming / random-block read bandwidth")
     return ap.parse_args()
 
@@ -215,7 +216,7 @@ def main():
             result["measured_bandwidth"] = {"stream_read_GBs": s_gbs, "random_512B_read_GBs": r_gbs}
 
     # ---- p50 latency of a single /_search (batch of 1), rank-local index share only when sharded
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_latency:
         lat = []
         one = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(32)]
         r1 = fpx.SearchResults(opts)

@@ -8,3 +8,4 @@ from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegm
                     SearchResults, Segments, http_options, QueryBatch, search_resident, search_resident_partial,
                     merge_partials, results_to_lists)
 from . import synth  # noqa: F401
+from . import sharding  # noqa: F401

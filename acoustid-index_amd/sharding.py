@@ -1,0 +1,58 @@
+"""Segment sharding across the GPUs of one node (one process per GPU, torch.distributed over RCCL/xGMI).
+
+Segments are the natural shard unit: FileSegment.search reads only its own blocks and the per-hash caps are per
+(hash, segment) (src/FileSegment.zig:153-174); with supersession resolved per posting every document's score comes
+from exactly one segment, hence from exactly one rank.  Per batch every rank
+  1. probes ITS segments for the whole query batch -> per-query table of (id, score) with score >= min_score,
+     already ordered (score desc, id asc) and truncated to `limit` (fpx_search_resident_partial),
+  2. all-gathers the fixed-shape tables [B][limit]{u32 id, u32 score} + [B] counts (RCCL, ~0.3 MB per rank),
+  3. merges them: k-way merge, relative cut-off anchored on the GLOBAL best score, truncate (fpx_merge_partials).
+No dense per-doc table ever crosses a link."""
+import numpy as np
+
+
+def assign_segments(weights, world):
+    """Greedy balance of segments over ranks by weight (blocks or bytes).  Returns rank per segment.
+    Equal weights degrade to round-robin (segment s -> rank s % world)."""
+    load = [0] * world
+    owner = [0] * len(weights)
+    for s in sorted(range(len(weights)), key=lambda i: (-weights[i], i)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[s] = r
+        load[r] += weights[s]
+    return owner
+
+
+def gather_tables(dist, table, counts, world, group=None):
+    """all-gather of the per-rank tables.  `table`: [B, cap, 2] int32 tensor, `counts`: [B] int32 tensor, on the
+    device the process group works on (cuda for nccl/RCCL, cpu for gloo).  Returns ([world,B,cap,2], [world,B])."""
+    import torch
+    # concatenation along dim 0 is the layout every backend (RCCL and gloo) accepts; viewed rank-major afterwards
+    tables = torch.empty((world * table.shape[0],) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+    cnts = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(tables, table.contiguous(), group=group)
+    dist.all_gather_into_tensor(cnts, counts.contiguous(), group=group)
+    tables = tables.view((world,) + tuple(table.shape))
+    cnts = cnts.view((world,) + tuple(counts.shape))
+    return tables, cnts
+
+
+class ShardedReader:
+    """IndexReader over a snapshot whose file segments are split across the ranks of a process group."""
+
+    def __init__(self, fpx, ctx, reader, dist, world):
+        self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
+        self._bufs = {}
+
+    def search_resident(self, qb, out=None, out_n=None):
+        import torch
+        key = (qb.B, qb.cap)
+        if key not in self._bufs:
+            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device="cuda"),
+                               torch.zeros((qb.B,), dtype=torch.int32, device="cuda"))
+        d_part, d_cnt = self._bufs[key]
+        st = self.fpx.search_resident_partial(self.reader, qb, d_part.data_ptr(), d_cnt.data_ptr())
+        tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
+        torch.cuda.synchronize()
+        out, out_n = self.fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
+        return out, out_n, st

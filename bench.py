@@ -136,11 +136,7 @@ def main():
     cap = qb.cap
     out = np.zeros((B, cap, 2), np.uint32)
     out_n = np.zeros(B, np.uint32)
-    if world > 1:
-        d_part = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
-        d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
-        d_parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
-        d_cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+    sharded = fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world) if world > 1 else None
 
     agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0}
 
@@ -148,11 +144,7 @@ def main():
         if world == 1:
             _, _, st = fpx.search_resident(reader, qb, 0, out, out_n)
         else:
-            st = fpx.search_resident_partial(reader, qb, d_part.data_ptr(), d_cnt.data_ptr())
-            dist.all_gather_into_tensor(d_parts, d_part)           # RCCL over xGMI: [world][B][cap]{id,score}
-            dist.all_gather_into_tensor(d_cnts, d_cnt)
-            torch.cuda.synchronize()
-            fpx.merge_partials(ctx, qb, d_parts.data_ptr(), d_cnts.data_ptr(), world, out, out_n)
+            _, _, st = sharded.search_resident(qb, out, out_n)     # partial tables -> RCCL all-gather -> merge
         if record:
             agg["bytes"] += st.algorithmic_bytes
             agg["probe_ms"] += st.probe_kernel_ms

@@ -1,0 +1,108 @@
+"""world_size-2 test of the segment-sharded search protocol on CPU (gloo).
+
+What is exercised: per-rank partial tables (only the absolute min_score floor, ordered, truncated to `limit`,
+supersession resolved against ALL segments of the snapshot), one all-gather of the fixed-shape tables through
+acoustid_index_amd.sharding.gather_tables, and the merge rule (k-way merge, relative cut-off anchored on the
+global best score).  Per-rank tables are produced by the CPU oracle here (there is no GPU); on a GPU box the
+same protocol runs through fpx_search_resident_partial / fpx_merge_partials (tests/test_gpu_sharded.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def merge_tables(tables, counts, limit, min_score, pct):
+    """numpy restatement of fpx_merge_partials for one query: tables [world, cap, 2], counts [world]."""
+    ent = [(int(tables[r, i, 1]), int(tables[r, i, 0])) for r in range(tables.shape[0]) for i in range(int(counts[r]))]
+    ent.sort(key=lambda e: (-e[0], e[1]))
+    out = []
+    for score, doc in ent:
+        if len(out) == limit or score < min_score:
+            break
+        if not out:
+            min_score = max(min_score, score * pct // 100)
+        out.append((doc, score))
+    return out
+
+
+def _build(oracle, fpx, rank, world):
+    """3 file segments + 1 memory segment; rank r holds the postings of segment s iff s % world == r, and an empty
+    stand-in (docs only) for the others -- the CPU analogue of fpx_segment_create_remote."""
+    seed, H, per = 31, 48, 4000
+    rng = np.random.default_rng(11)
+    segs, mems, full_segs, full_mems = [], [], [], []
+    for s in range(3):
+        lo = s * per + 1
+        ids = np.arange(lo, lo + per, dtype=np.uint64)
+        extra = np.sort(rng.choice(np.arange(1, lo), 200, replace=False)).astype(np.uint64) if s else np.zeros(0, np.uint64)
+        all_ids = np.concatenate([extra, ids])                        # re-insertions of older docs supersede them
+        h = fpx.synth.synth_hashes(seed + s, all_ids, H, 1).astype(np.uint64)
+        items = np.sort(((h << np.uint64(32)) | all_ids[:, None]).ravel())
+        blocks, index = oracle.build_blocks(items, int(all_ids.min()), 512)
+        mk = lambda b, i: oracle.file_segment(b, 512, i, int(all_ids.min()), int(all_ids.max()), s + 1, all_ids.astype(np.uint32))
+        full_segs.append(mk(blocks, index))
+        empty = np.zeros(512, np.uint8)
+        segs.append(mk(blocks, index) if s % world == rank else mk(empty, np.zeros(0, np.uint32)))
+    changes = [("insert", 77, fpx.synth.synth_hashes(99, [77], H)[0].tolist()), ("delete", 78)]
+    full_mems.append(oracle.memory_segment_from_changes(changes, 4))
+    if 3 % world == rank:
+        mems.append(oracle.memory_segment_from_changes(changes, 4))
+    else:
+        m = full_mems[0]
+        ids, alive = m.docs()
+        mems.append(oracle.memory_segment(np.zeros(0, np.uint64), m.min_doc_id, m.max_doc_id, 4, ids, alive))
+    return oracle.Snapshot(segs, mems), oracle.Snapshot(full_segs, full_mems), (seed, H, per)
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fpx_testlib import fpx, oracle
+        local, full, (seed, H, per) = _build(oracle, fpx, rank, world)
+        limit, pct = 10, 10
+        qdocs = [5, 77, 78, 4001, 9000, 100, 200]
+        queries = [fpx.synth.synth_hashes(seed + (0 if d <= per else (d - 1) // per), [d], H, 1)[0] for d in qdocs]
+        queries.append(fpx.synth.synth_hashes(99, [77], H)[0])
+        B = len(queries)
+        table = torch.zeros((B, limit, 2), dtype=torch.int32)
+        counts = torch.zeros((B,), dtype=torch.int32)
+        floors = []
+        for q, hashes in enumerate(queries):
+            floor = (len(hashes) + 19) // 20
+            floors.append(floor)
+            part = local.search(hashes, max_results=limit, min_score=floor, min_score_pct=0)   # stage 1: floor only
+            counts[q] = len(part)
+            for i, (doc, score) in enumerate(part):
+                table[q, i, 0], table[q, i, 1] = doc, score
+        tables, cnts = fpx.sharding.gather_tables(dist, table, counts, world)                  # stage 2: one all-gather
+        assert tuple(tables.shape) == (world, B, limit, 2)
+        ok = True
+        for q, hashes in enumerate(queries):
+            got = merge_tables(tables[:, q].numpy(), cnts[:, q].numpy(), limit, floors[q], pct)  # stage 3
+            want = full.search(hashes, max_results=limit, min_score=None, min_score_pct=pct)
+            ok = ok and got == want
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_protocol_world_size_2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

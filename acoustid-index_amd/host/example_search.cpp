@@ -1,0 +1,36 @@
+// example_search.cpp -- the reference's "segment round-trip: write, read, search" test (src/filefmt.zig:293-338)
+// and "duplicate query hashes" test (src/Index.zig:1056-1096) written against the C++ host mirror.
+// Needs an MI355X:  ./example_search   (exit code 0 = both expectations hold)
+#include <algorithm>
+#include <cstdio>
+
+#include "fpx.hpp"
+
+int main()
+{
+    try {
+        fpx::Context ctx(0);
+        // MemorySegment.build of: insert{1,[100,200,300]}, insert{2,[100,200]}
+        std::vector<uint64_t> items;
+        auto item = [](uint32_t hash, uint32_t id) { return (uint64_t)hash << 32 | id; };
+        for (uint32_t h : {100u, 200u, 300u}) items.push_back(item(h, 1));
+        for (uint32_t h : {100u, 200u}) items.push_back(item(h, 2));
+        std::sort(items.begin(), items.end());
+        fpx::MemorySegment mem(ctx, items, 1, 2, 1, fpx::Docs{{1, 2}, {}});
+        fpx::IndexReader reader(fpx::Segments(ctx, {mem}));
+
+        fpx::SearchResults r(fpx::SearchOptions{10, 1, 10});
+        reader.search({100, 200, 300}, r);
+        const auto& out = r.getResults();
+        bool ok = out.size() == 2 && out[0].id == 1 && out[0].score == 3 && out[1].id == 2 && out[1].score == 2;
+
+        fpx::SearchResults dup(fpx::SearchOptions{10, 1, 10});
+        reader.search({100, 100}, dup);                       // the query is a set: a repeated hash scores once
+        ok = ok && dup.getResults().size() == 2 && dup.getResults()[0].score == 1;
+        std::printf("%s\n", ok ? "ok" : "MISMATCH");
+        return ok ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 2;
+    }
+}

@@ -48,7 +48,8 @@ enum Counter : int {
     CTR_DOCS = 3,        // matched docs before supersession filtering
     CTR_BYTES = 4,       // algorithmic bytes
     CTR_PROBES = 5,      // valid (unique hash, file segment) probes
-    CTR_MAXSCORE = 6,    // largest score of any candidate (sizes the score field of the candidate key)
+    CTR_MAXSCORE = 6,
+    CTR_GENERIC = 7,     // wave iterations of k_probe that took the generic (per-value) decode path    // largest score of any candidate (sizes the score field of the candidate key)
     CTR_COUNT = 8
 };
 
@@ -98,6 +99,8 @@ struct Workspace {
     uint64_t* d_cands[2] = {nullptr, nullptr}; size_t cap_cands = 0;  // candidate keys
     void* d_temp = nullptr; size_t cap_temp = 0;              // radix sort temp
     unsigned long long* d_counters = nullptr;                 // [CTR_COUNT]
+    uint32_t* d_def_list = nullptr; size_t cap_def = 0;       // deferred probes of the lean kernel [n_file][def_cap]
+    unsigned int* d_def_count = nullptr; unsigned int* h_def_count = nullptr; size_t cap_def_segs = 0;
     fpx_result* d_out = nullptr; uint32_t* d_out_n = nullptr; size_t cap_out = 0; // [B*cap], [B]
     // pinned host staging
     unsigned long long* h_counters = nullptr;

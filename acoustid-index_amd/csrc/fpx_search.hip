@@ -143,6 +143,10 @@ struct ProbeArgs {
     uint64_t* hits;            // (q << 32 | doc)
     uint64_t hit_cap;
     unsigned long long* counters;
+    // probes the lean kernel could not finish (generic decode, continuation blocks): pair indices per segment
+    uint32_t* def_list;        // [n_file][def_cap]
+    unsigned int* def_count;   // [n_file]
+    uint32_t def_cap;
 };
 
 // ---- decode tables (the GPU form of the reference's 256-entry shuffle/length tables, src/streamvbyte.zig:76-211)
@@ -151,6 +155,7 @@ struct ProbeArgs {
 struct DecodeLut {
     uint32_t a[2][256];
     uint4 b[2][256];
+    uint2 f[256];          // 0124 only: {a[0][c], selector that keeps the quad's `len` data bytes}: quad sums via v_sad_u8
 };
 
 __device__ __forceinline__ uint32_t perm_sel(uint32_t nb)
@@ -174,6 +179,7 @@ __device__ __forceinline__ void init_lut(DecodeLut* lut, uint32_t c)
         }
         lut->a[v][c] = packed | (off << 24);
         lut->b[v][c] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+        if (v == 0) lut->f[c] = make_uint2(packed | (off << 24), perm_sel(off > 4u ? 4u : off));
     }
 }
 
@@ -215,6 +221,41 @@ __device__ __forceinline__ uint32_t row_last(uint32_t v)
     return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (0x0F << 5));
 }
 
+// dd[k] for a loop counter k (keeps the array in registers: a select chain instead of scratch indexing)
+__device__ __forceinline__ uint32_t dd_at(const uint32_t dd[8], int k)
+{
+    uint32_t r = dd[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r = (k == j) ? dd[j] : r;
+    return r;
+}
+
+// the 16 bits of a wave ballot that belong to row g (g = lane >> 4)
+__device__ __forceinline__ uint32_t row_bits(unsigned long long m, uint32_t g)
+{
+    const uint32_t w = (g & 2u) ? (uint32_t)(m >> 32) : (uint32_t)m;
+    return (w >> ((g & 1u) * 16u)) & 0xFFFFu;
+}
+
+// inclusive prefix sum over lanes 0..3 of each row (lanes >= 4 of the row receive meaningless sums)
+__device__ __forceinline__ uint32_t scan4(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    return v;
+}
+
+// value k (= lane & 3) of the quad with control byte c whose data starts at LDS offset `off`; V = 0: 0124, 1: 1234
+template <int V>
+__device__ __forceinline__ uint32_t decode_one(const DecodeLut* lut, const uint8_t* sm, uint32_t off, uint32_t c, uint32_t k)
+{
+    const uint32_t a = lut->a[V][c];
+    const uint32_t sel = reinterpret_cast<const uint32_t*>(&lut->b[V][c])[k];
+    const uint32_t ok = ((a << 8) >> (8u * k)) & 0xFFu;            // byte offset of value k (0 for k = 0)
+    const uint32_t raw = lds_u32u(sm, off + ok);
+    return __builtin_amdgcn_perm(raw, raw, sel);
+}
+
 // ---- the probe kernel ---------------------------------------------------------------------------
 // One wave works on FOUR probes at a time, one per 16-lane row; lane r of a row owns quads 2r and 2r+1
 // of every 32-quad chunk of the block (a 512-B block holds ~29 quads).  Blocks are prefetched one
@@ -222,7 +263,7 @@ __device__ __forceinline__ uint32_t row_last(uint32_t v)
 constexpr int PWG = 512;           // probe workgroup: 8 waves share the decode tables and the hit staging
 constexpr int PWAVES = PWG / 64;
 
-template <bool FAST512>
+template <bool FAST512, bool DEFERRED>
 __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -238,6 +279,11 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     const uint32_t blko = (uint32_t)(blk - smem);          // my row's staging slot as an offset into the dynamic LDS
     const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
     const uint32_t bs = FAST512 ? 512u : seg.block_size;
+    if (DEFERRED) {
+        // most workgroups of the deferred pass find nothing to do
+        const uint64_t first = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
+        if (first >= (uint64_t)min(a.def_count[blockIdx.y], a.def_cap)) return;
+    }
 
     if (tid < 256u) init_lut(lut, tid);
     if (tid == 0) {
@@ -246,20 +292,28 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     }
     __syncthreads();
 
-    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
+    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_generic = 0;
 
     const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
     for (uint32_t round = 0; round < a.rounds; ++round) {
         // ---- phase 1: one lane per pair: dedup + block lookup
         uint64_t p = wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
-        bool valid = lane < a.ppw && p < a.P;
+        bool valid;
+        if (DEFERRED) {
+            // p indexes this segment's list of deferred probes (already deduplicated and counted by k_probe_lean)
+            const uint32_t n = min(a.def_count[blockIdx.y], a.def_cap);
+            valid = lane < a.ppw && p < (uint64_t)n;
+            if (valid) p = gload_u32(a.def_list + (size_t)blockIdx.y * a.def_cap + p);
+        } else {
+            valid = lane < a.ppw && p < a.P;
+        }
         uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
-        if (valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;      // dedupSorted, src/Index.zig:489-499
+        if (!DEFERRED && valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;  // dedupSorted, src/Index.zig:489-499
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint32_t q = (uint32_t)key & qmask;
         uint32_t b0 = seg.num_blocks;
         if (valid) {
-            my_probes += 1;
+            if (!DEFERRED) my_probes += 1;
             b0 = lookup_block(seg, h);
         }
         if (b0 >= seg.num_blocks) valid = false;
@@ -300,7 +354,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
 
             while (__any(pact)) {
                 uint32_t kf = 0;                 // bit k: value k of my two quads is a kept match
-                uint32_t dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t dd[8];                  // dd[k] is defined wherever bit k of kf is set
                 bool cont = false;
                 if (pact) {
                     // -- stage the block in LDS (each 16-lane row moves one contiguous block)
@@ -334,6 +388,68 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                         const uint32_t limit = a.bsp - 24u;             // keeps corrupt offsets inside the staging slot
                         uint32_t hoff_carry = 0, hval_carry = 0, xcarry = 0, cnt = 0;
                         bool ends_with_ph = false;                      // the block's last item carries hash ph
+                        bool generic = true;
+                        // ---- two-level fast path (the common case): every hash delta of the block fits one byte and at
+                        //      most ONE quad of the block can hold the target.  Level 1 needs only the SUM of each quad
+                        //      (v_sad_u8 over its <= 4 data bytes); level 2 decodes the single candidate quad with
+                        //      lanes 0..3 of the row.  Anything else (wide deltas, > 32 quads, a partial last quad, a
+                        //      run that may cross quads) takes the generic per-value path below; both are exact.
+                        if (!__any((int)(nq > 32u || (n_items & 3u) != 0u))) {
+                            const uint32_t qa = 2u * gl;
+                            uint32_t cc = *reinterpret_cast<const uint16_t*>(blk + 8u + qa);
+                            cc = qa + 1u < nq ? cc : (qa < nq ? (cc & 0xFFu) : 0u);
+                            const uint32_t ca = cc & 0xFFu, cb = cc >> 8;
+                            const uint2 fa = lut->f[ca], fb = lut->f[cb];
+                            const uint32_t la = fa.x >> 24, lb = fb.x >> 24;
+                            const uint32_t hincl = scan16(la + lb);
+                            const uint32_t pa = min(hdata + hincl - la - lb, limit), pb2 = min(pa + la, limit);
+                            const uint32_t ra = lds_u32u(smem, blko + pa), rb = lds_u32u(smem, blko + pb2);
+                            const uint32_t sa = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(ra, ra, fa.y), 0u, 0u);
+                            const uint32_t sb = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(rb, rb, fb.y), 0u, 0u);
+                            const uint32_t vincl = scan16(sa + sb);
+                            const uint32_t ua = ph - min_hash - (vincl - sa - sb);      // target relative to quad A's base
+                            const uint32_t ub = ua - sa;                                //                  quad B's base
+                            // a quad can hold the target iff base < T <= base + sum, or T == base and its first delta is 0
+                            const bool canda = qa < nq && (ua - 1u < sa || (ua == 0u && (ca & 3u) == 0u));
+                            const bool candb = qa + 1u < nq && (ub - 1u < sb || (ub == 0u && (cb & 3u) == 0u));
+                            const uint32_t rab = row_bits(__ballot((int)canda), g) | (row_bits(__ballot((int)candb), g) << 16);
+                            if (!__any((int)((cc & 0xAAAAu) != 0u || __popc(rab) > 1))) {
+                                generic = false;
+                                const bool hasc = rab != 0u;
+                                const uint32_t idx = hasc ? (uint32_t)__builtin_ctz(rab) : 0u;   // < 16: quad A of lane idx, else quad B
+                                const int owner = (int)((lane & 48u) | (idx & 15u));
+                                // the owner lane publishes {data offset | control byte << 16} and the relative target
+                                const uint32_t mypack = canda ? (pa | (ca << 16)) : (pb2 | (cb << 16));
+                                const uint32_t pk = __shfl(mypack, owner);
+                                const uint32_t ut = __shfl(canda ? ua : ub, owner);
+                                const uint32_t k = gl & 3u;
+                                const uint32_t val = decode_one<0>(lut, smem, blko + (pk & 0xFFFFu), pk >> 16, k);
+                                const bool ek = hasc && gl < 4u && scan4(val) == ut;            // item k of the candidate quad matches
+                                const unsigned long long me = __ballot((int)ek);
+                                if (me != 0ull) {
+                                    // ---- docids of the run (all inside the candidate quad)
+                                    const uint32_t dcc = lds_u32u(smem, blko + min(dctrl + qa, limit));
+                                    const uint32_t da = dcc & 0xFFu, db = (dcc >> 8) & 0xFFu;
+                                    const uint32_t dla = qa < nq ? (lut->a[1][da] >> 24) : 0u;
+                                    const uint32_t dlb = qa + 1u < nq ? (lut->a[1][db] >> 24) : 0u;
+                                    const uint32_t dincl = scan16(dla + dlb);
+                                    const uint32_t dpa = min(ddata + dincl - dla - dlb, limit), dpb = min(dpa + dla, limit);
+                                    const uint32_t dpk = __shfl(canda ? (dpa | (da << 16)) : (dpb | (db << 16)), owner);
+                                    const uint32_t dv = decode_one<1>(lut, smem, blko + (dpk & 0xFFFFu), dpk >> 16, k);
+                                    const uint32_t doc = seg.min_doc_id + scan4(ek ? dv : 0u);
+                                    const uint32_t erow = row_bits(me, g);
+                                    cnt = __popc(erow);
+                                    bool keep = ek;
+                                    if (seg.num_dead != 0u && keep && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc)) keep = false;
+                                    if (keep) { kf = 1u; dd[0] = doc; }
+                                    // the block ends with ph iff the last item of the last quad matched
+                                    const uint32_t qstar = 2u * (idx & 15u) + (idx >> 4);
+                                    ends_with_ph = qstar + 1u == nq && ((erow >> 3) & 1u) != 0u;
+                                }
+                            }
+                        }
+                        if (generic && gl == 0u) my_generic += 1;
+                        if (generic)
                         for (uint32_t c0 = 0; c0 < nq; c0 += 32u) {
                             const uint32_t qa = c0 + 2u * gl;             // my quads: qa, qa + 1
                             const bool more_chunks = c0 + 32u < nq;
@@ -449,8 +565,8 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
 
                 // ---- emission of this iteration's kept matches (wave-uniform control flow)
                 if (__any((int)(kf != 0u))) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    const int kmax = __any((int)((kf & ~1u) != 0u)) ? 8 : 1;    // the fast path only ever sets bit 0
+                    for (int k = 0; k < kmax; ++k) {
                         const unsigned long long m = __ballot((int)((kf >> k) & 1u));
                         if (m == 0ull) continue;
                         const uint32_t total = __popcll(m);
@@ -459,14 +575,14 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                         if (lane == 0) pos = atomicAdd(&stage_count, total);
                         pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
                         if (pos + total <= (uint32_t)STAGE_CAP) {
-                            if ((kf >> k) & 1u) stage[pos + rank] = ((uint64_t)pq << 32) | dd[k];
+                            if ((kf >> k) & 1u) stage[pos + rank] = ((uint64_t)pq << 32) | dd_at(dd, k);
                         } else {
                             // staging full: remember where the valid prefix ends and append directly
                             if (lane == 0) atomicMin(&stage_valid, pos);
                             unsigned long long gg = 0;
                             if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
                             gg = __shfl(gg, 0);
-                            if (((kf >> k) & 1u) && gg + rank < a.hit_cap) a.hits[gg + rank] = ((uint64_t)pq << 32) | dd[k];
+                            if (((kf >> k) & 1u) && gg + rank < a.hit_cap) a.hits[gg + rank] = ((uint64_t)pq << 32) | dd_at(dd, k);
                         }
                     }
                 }
@@ -497,11 +613,214 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
     if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
     if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    if (my_generic) atomicAdd(&a.counters[CTR_GENERIC], (unsigned long long)my_generic);
     __syncthreads();
     if (tid == 0) {
         if (wg_blocks) {
             atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks);
             atomicAdd(&a.counters[CTR_BYTES], wg_blocks * (unsigned long long)seg.block_size);
+        }
+        if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
+        if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
+    }
+}
+
+// ---- the lean probe kernel (snapshots whose file segments all use 512-B blocks) ---------------------
+// Straight-line version of the common case: the probe's first block, every hash delta one byte, at most one
+// candidate quad, no continuation into the next block.  Rows that need anything else write their pair index to
+// the segment's deferred list and are finished by k_probe<.., DEFERRED>; the lean loop carries no rare-case state.
+__global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);                  // STAGE_CAP records
+    DecodeLut* lut = reinterpret_cast<DecodeLut*>(smem + STAGE_CAP * sizeof(uint64_t));
+    uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut);   // PWAVES * 4 * 544 bytes
+    __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+
+    constexpr uint32_t SLOT = 544u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 4, gl = lane & 15u;
+    const SegDesc seg = a.segs[blockIdx.y];
+    uint8_t* blk = blkmem + (size_t)(wave * 4u + g) * SLOT;
+    const uint32_t blko = (uint32_t)(blk - smem);
+    const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
+
+    if (tid < 256u) init_lut(lut, tid);
+    if (tid == 0) {
+        stage_count = 0; stage_valid = STAGE_CAP;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0;
+    }
+    __syncthreads();
+
+    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
+    const uint32_t k = gl & 3u;
+    const uint32_t qa = 2u * gl;
+
+    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
+    for (uint32_t round = 0; round < a.rounds; ++round) {
+        // ---- phase 1: one lane per pair: dedup + block lookup
+        const uint64_t p = wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
+        bool valid = lane < a.ppw && p < a.P;
+        const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
+        if (valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;      // dedupSorted, src/Index.zig:489-499
+        const uint32_t h = (uint32_t)(key >> a.qb);
+        const uint32_t q = (uint32_t)key & qmask;
+        uint32_t b0 = seg.num_blocks;
+        if (valid) {
+            my_probes += 1;
+            b0 = lookup_block(seg, h);
+        }
+        if (b0 >= seg.num_blocks) valid = false;
+        const uint32_t b0v = (b0 & 0x7FFFFFFFu) | (valid ? 0x80000000u : 0u);
+        const uint32_t wave_pair0 = (uint32_t)(p - lane);                   // pair index of lane 0 (P < 2^32)
+
+        // ---- phase 2: four probes per iteration, one per 16-lane row, blocks prefetched one iteration ahead
+        const uint32_t iters = (a.ppw + 3u) >> 2;
+        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+        {
+            const uint32_t nb = __shfl(b0v, (int)g);
+            if (nb >> 31) {
+                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                pre0 = gload_u4(sb);
+                pre1 = gload_u4(sb + 256);
+            }
+        }
+        for (uint32_t it = 0; it < iters; ++it) {
+            const int src = (int)(it * 4u + g);
+            const uint32_t ph = __shfl(h, src);
+            const uint32_t pq = __shfl(q, src);
+            const uint32_t pbv = __shfl(b0v, src);
+            const bool pact = (pbv >> 31) != 0u;
+            *reinterpret_cast<uint4*>(blk + gl * 16u) = pre0;
+            *reinterpret_cast<uint4*>(blk + 256u + gl * 16u) = pre1;
+            if (it + 1u < iters) {
+                const uint32_t nb = __shfl(b0v, src + 4);
+                if (nb >> 31) {
+                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                    pre0 = gload_u4(sb);
+                    pre1 = gload_u4(sb + 256);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // -- header (src/block.zig:46-50); rows without a probe decode stale bytes and are masked at the end
+            const uint32_t* hw = reinterpret_cast<const uint32_t*>(blk);
+            const uint32_t min_hash = hw[0];
+            const uint32_t n_items = hw[1] & 0xFFFFu;
+            const uint32_t doff = min(hw[1] >> 16, 504u);
+            const uint32_t nq = (n_items + 3u) >> 2;
+            const bool visited = pact && min_hash <= ph;                       // src/FileSegment.zig:164
+            bool defer = nq > 32u || (n_items & 3u) != 0u;                     // multi-chunk block / partial last quad
+
+            // -- level 1: quad sums (see k_probe for the scheme)
+            uint32_t cc = *reinterpret_cast<const uint16_t*>(blk + 8u + qa);
+            cc = qa + 1u < nq ? cc : (qa < nq ? (cc & 0xFFu) : 0u);
+            const uint32_t ca = cc & 0xFFu, cb = cc >> 8;
+            const uint2 fa = lut->f[ca], fb = lut->f[cb];
+            const uint32_t la = fa.x >> 24, lb = fb.x >> 24;
+            const uint32_t hincl = scan16(la + lb);
+            const uint32_t pa = (8u + nq + hincl - la - lb) & 1023u, pb2 = pa + la;
+            const uint32_t ra = lds_u32u(smem, blko + pa), rb = lds_u32u(smem, blko + pb2);
+            const uint32_t sa = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(ra, ra, fa.y), 0u, 0u);
+            const uint32_t sb = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(rb, rb, fb.y), 0u, 0u);
+            const uint32_t vincl = scan16(sa + sb);
+            const uint32_t ua = ph - min_hash - (vincl - sa - sb);
+            const uint32_t ub = ua - sa;
+            const bool canda = qa < nq && (ua - 1u < sa || (ua == 0u && (ca & 3u) == 0u));
+            const bool candb = qa + 1u < nq && (ub - 1u < sb || (ub == 0u && (cb & 3u) == 0u));
+            const uint32_t rab = row_bits(__ballot((int)canda), g) | (row_bits(__ballot((int)candb), g) << 16);
+            defer = defer || row_bits(__ballot((int)((cc & 0xAAAAu) != 0u)), g) != 0u || __popc(rab) > 1;
+
+            // -- level 2: lanes 0..3 of the row decode the single candidate quad
+            const bool hasc = rab != 0u;
+            const uint32_t idx = hasc ? (uint32_t)__builtin_ctz(rab) : 0u;
+            const int owner = (int)((lane & 48u) | (idx & 15u));
+            const uint32_t pk = __shfl(canda ? (pa | (ca << 16)) : (pb2 | (cb << 16)), owner);
+            const uint32_t ut = __shfl(canda ? ua : ub, owner);
+            const uint32_t val = decode_one<0>(lut, smem, blko + (pk & 0xFFFFu), pk >> 16, k);
+            const bool ek = visited && !defer && hasc && gl < 4u && scan4(val) == ut;
+            const unsigned long long me = __ballot((int)ek);
+            uint32_t cnt = 0;
+            bool keep = false;
+            uint32_t doc = 0;
+            if (me != 0ull) {
+                // -- docids of the run (all inside the candidate quad)
+                const uint32_t dcc = lds_u32u(smem, blko + 8u + doff + qa);
+                const uint32_t da = dcc & 0xFFu, db = (dcc >> 8) & 0xFFu;
+                const uint32_t dla = qa < nq ? (lut->a[1][da] >> 24) : 0u;
+                const uint32_t dlb = qa + 1u < nq ? (lut->a[1][db] >> 24) : 0u;
+                const uint32_t dincl = scan16(dla + dlb);
+                const uint32_t dpa = (8u + doff + nq + dincl - dla - dlb) & 1023u, dpb = dpa + dla;
+                const uint32_t dpk = __shfl(canda ? (dpa | (da << 16)) : (dpb | (db << 16)), owner);
+                const uint32_t dv = decode_one<1>(lut, smem, blko + (dpk & 0xFFFFu), dpk >> 16, k);
+                doc = seg.min_doc_id + scan4(ek ? dv : 0u);
+                const uint32_t erow = row_bits(me, g);
+                cnt = __popc(erow);
+                // a run that reaches the block's last item may continue in the next block: let k_probe finish it
+                const uint32_t qstar = 2u * (idx & 15u) + (idx >> 4);
+                if (qstar + 1u == nq && ((erow >> 3) & 1u) != 0u && (pbv & 0x7FFFFFFFu) + 1u < seg.num_blocks) defer = true;
+                keep = ek && !defer;
+                if (seg.num_dead != 0u && keep && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc)) keep = false;
+            }
+            // -- bookkeeping per row
+            if (gl == 0u && visited) {
+                if (defer) {
+                    const unsigned int slot = atomicAdd(&a.def_count[blockIdx.y], 1u);
+                    if (slot < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + slot] = wave_pair0 + it * 4u + g;
+                } else {
+                    my_blocks += 1; my_docs += cnt;
+                }
+            }
+            // -- emission (wave-uniform control flow)
+            const unsigned long long m = __ballot((int)keep);
+            if (m != 0ull) {
+                const uint32_t total = __popcll(m);
+                const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+                uint32_t pos = 0;
+                if (lane == 0) pos = atomicAdd(&stage_count, total);
+                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                const uint64_t rec = ((uint64_t)pq << 32) | doc;
+                if (pos + total <= (uint32_t)STAGE_CAP) {
+                    if (keep) stage[pos + rank] = rec;
+                } else {
+                    if (lane == 0) atomicMin(&stage_valid, pos);
+                    unsigned long long gg = 0;
+                    if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+                    gg = __shfl(gg, 0);
+                    if (keep && gg + rank < a.hit_cap) a.hits[gg + rank] = rec;
+                }
+            }
+        }
+
+        // ---- flush the LDS staging buffer at round boundaries
+        __syncthreads();
+        const uint32_t sc = stage_count;
+        const bool last = (round + 1u == a.rounds);
+        if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
+            const uint32_t n = min(sc, stage_valid);
+            if (tid == 0) {
+                unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
+                flush_base_lo = (uint32_t)gg; flush_base_hi = (uint32_t)(gg >> 32);
+            }
+            __syncthreads();
+            const unsigned long long gg = ((unsigned long long)flush_base_hi << 32) | flush_base_lo;
+            for (uint32_t i = tid; i < n; i += PWG)
+                if (gg + i < a.hit_cap) a.hits[gg + i] = stage[i];
+            __syncthreads();
+            if (tid == 0) { stage_count = 0; stage_valid = STAGE_CAP; }
+        }
+        __syncthreads();
+    }
+
+    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
+    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
+    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    __syncthreads();
+    if (tid == 0) {
+        if (wg_blocks) {
+            atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks);
+            atomicAdd(&a.counters[CTR_BYTES], wg_blocks * 512ull);
         }
         if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
         if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
@@ -838,7 +1157,23 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         size_t want = std::max<size_t>(1u << 20, (size_t)P * std::max<uint32_t>(1u, snap->n_file + snap->n_mem));
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, want))) return rc;
     }
+    // deferred-probe lists of the lean kernel: room for 1/8 of the pairs per segment (typically < 2 % are deferred)
+    const size_t def_cap = std::max<size_t>(4096, (size_t)(P / 8));
+    if (snap->n_file) {
+        const size_t need = def_cap * snap->n_file;
+        if ((rc = grow(&ws->d_def_list, &ws->cap_def, need))) return rc;
+        if (snap->n_file > ws->cap_def_segs) {
+            if (ws->d_def_count) (void)hipFree(ws->d_def_count);
+            if (ws->h_def_count) (void)hipHostFree(ws->h_def_count);
+            ws->d_def_count = nullptr; ws->h_def_count = nullptr; ws->cap_def_segs = 0;
+            FPX_HIP(hipMalloc(&ws->d_def_count, snap->n_file * sizeof(unsigned int)));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), snap->n_file * sizeof(unsigned int)));
+            ws->cap_def_segs = snap->n_file;
+        }
+    }
+    bool force_generic = false, used_lean = false;
     for (int attempt = 0;; ++attempt) {
+        used_lean = false;
         FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
         if (P && snap->n_file) {
             ProbeArgs a;
@@ -849,17 +1184,35 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.rounds = total >= (1ull << 25) ? 2u : 1u;
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
+            a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
+            const bool lean = snap->all_512 && !force_generic && P < 0xFFFFFFFFull;
             FPX_HIP(hipEventRecord(ws->ev_probe0, st));
-            if (snap->all_512)
-                hipLaunchKernelGGL(k_probe<true>, dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
-            else
-                hipLaunchKernelGGL(k_probe<false>, dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+            if (lean) {
+                // lean kernel for the common case, then the generic kernel on the (few) deferred probes
+                FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_file * sizeof(unsigned int), st));
+                const size_t lds_lean = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * 544;
+                hipLaunchKernelGGL(k_probe_lean, dim3(gx, snap->n_file), dim3(PWG), lds_lean, st, a);
+                ProbeArgs d = a;
+                d.ppw = 16u; d.rounds = 1u;
+                const uint64_t per_wg_d = (uint64_t)PWAVES * d.ppw;
+                const uint32_t gxd = (uint32_t)((def_cap + per_wg_d - 1) / per_wg_d);
+                hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_file), dim3(PWG), lds, st, d);
+                probe_launches += 1;
+            } else if (snap->all_512) {
+                hipLaunchKernelGGL((k_probe<true, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+            } else {
+                hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+            }
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             FPX_HIP(hipGetLastError());
             probe_launches += 1;
+            if (lean) {
+                FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, snap->n_file * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                used_lean = true;
+            }
         }
         if (P && snap->n_mem) {
             hipLaunchKernelGGL(k_probe_mem, dim3((uint32_t)((P + WG - 1) / WG), snap->n_mem), dim3(WG), 0, st,
@@ -874,13 +1227,23 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             probe_ms += ms;
         }
         H = ws->h_counters[CTR_HITS];
+        if (used_lean) {
+            bool overflow = false;
+            for (uint32_t i = 0; i < snap->n_file; ++i) overflow = overflow || ws->h_def_count[i] > def_cap;
+            if (overflow) {                 // pathological data: nearly every probe needs the generic path
+                if (attempt >= 3) { set_error("deferred list overflow persists"); return FPX_E_DEVICE; }
+                force_generic = true;
+                continue;
+            }
+        }
         if (H <= ws->cap_hits) break;
-        if (attempt >= 2) { set_error("hit buffer overflow persists (%llu records)", (unsigned long long)H); return FPX_E_DEVICE; }
+        if (attempt >= 4) { set_error("hit buffer overflow persists (%llu records)", (unsigned long long)H); return FPX_E_DEVICE; }
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
     }
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
     const unsigned long long c_blocks = ws->h_counters[CTR_BLOCKS], c_docs = ws->h_counters[CTR_DOCS],
-                             c_bytes = ws->h_counters[CTR_BYTES], c_probes = ws->h_counters[CTR_PROBES];
+                             c_bytes = ws->h_counters[CTR_BYTES], c_probes = ws->h_counters[CTR_PROBES],
+                             c_generic = ws->h_counters[CTR_GENERIC];
 
     // ---- 5: sort hits by (q, doc), run-length score, keep score >= min_score
     uint64_t C = 0;
@@ -946,6 +1309,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         stats->probe_kernel_ms += probe_ms;
         stats->total_gpu_ms += total_ms;
         stats->probe_launches += probe_launches;
+        stats->generic_iters += (uint32_t)c_generic;
     }
     return FPX_OK;
 }
@@ -954,7 +1318,7 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
 {
     dst->probes += s.probes; dst->scanned_blocks += s.scanned_blocks; dst->scanned_docs += s.scanned_docs;
     dst->hits += s.hits; dst->algorithmic_bytes += s.algorithmic_bytes; dst->candidates += s.candidates;
-    dst->probe_kernel_ms += s.probe_kernel_ms; dst->total_gpu_ms += s.total_gpu_ms; dst->probe_launches += s.probe_launches;
+    dst->probe_kernel_ms += s.probe_kernel_ms; dst->total_gpu_ms += s.total_gpu_ms; dst->probe_launches += s.probe_launches; dst->generic_iters += s.generic_iters;
 }
 
 // one pass, or -- when (query index, score) do not fit the 64-bit candidate key -- two half batches

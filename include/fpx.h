@@ -67,7 +67,7 @@ typedef struct {
     float    probe_kernel_ms;   /* HIP-event time of the posting decode + match kernel launches */
     float    total_gpu_ms;      /* first launch -> last kernel of this call, on the call's stream */
     uint32_t probe_launches;
-    uint32_t reserved;
+    uint32_t generic_iters;     /* wave iterations of the probe kernel that needed the generic per-value decode path */
 } fpx_stats;
 
 /* ---- context ----------------------------------------------------------- */

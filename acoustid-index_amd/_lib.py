@@ -32,10 +32,11 @@ class Stats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("scanned_blocks", C.c_uint64), ("scanned_docs", C.c_uint64),
                 ("hits", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("candidates", C.c_uint64),
                 ("probe_kernel_ms", C.c_float), ("total_gpu_ms", C.c_float),
-                ("probe_launches", C.c_uint32), ("generic_iters", C.c_uint32)]
+                ("probe_launches", C.c_uint32), ("generic_iters", C.c_uint32),
+                ("probe_kernel_bytes", C.c_uint64), ("probe_aux_ms", C.c_float), ("reserved", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if True}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
 # every symbol include/fpx.h declares: name -> (restype, argtypes)

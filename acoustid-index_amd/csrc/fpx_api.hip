@@ -43,7 +43,8 @@ Workspace* ws_acquire(Ctx* ctx)
     if (!w) { set_error("out of host memory"); return nullptr; }
     bool ok = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&w->ev_begin) == hipSuccess && hipEventCreate(&w->ev_probe0) == hipSuccess &&
-              hipEventCreate(&w->ev_probe1) == hipSuccess && hipEventCreate(&w->ev_end) == hipSuccess &&
+              hipEventCreate(&w->ev_probe1) == hipSuccess && hipEventCreate(&w->ev_probe2) == hipSuccess &&
+              hipEventCreate(&w->ev_end) == hipSuccess &&
               hipMalloc(&w->d_counters, CTR_COUNT * sizeof(unsigned long long)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&w->h_counters), CTR_COUNT * sizeof(unsigned long long)) == hipSuccess;
     if (!ok) { set_error("workspace creation failed: %s", hipGetErrorString(hipGetLastError())); ws_destroy(w); return nullptr; }
@@ -69,6 +70,7 @@ void ws_destroy(Workspace* w)
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_probe0) (void)hipEventDestroy(w->ev_probe0);
     if (w->ev_probe1) (void)hipEventDestroy(w->ev_probe1);
+    if (w->ev_probe2) (void)hipEventDestroy(w->ev_probe2);
     if (w->ev_end) (void)hipEventDestroy(w->ev_end);
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
@@ -323,6 +325,8 @@ static void snapshot_free(Snapshot* sn)
     (void)hipSetDevice(sn->ctx->device);
     for (uint32_t* d : sn->d_dead) if (d) (void)hipFree(d);
     if (sn->d_file) (void)hipFree(sn->d_file);
+    if (sn->d_lean) (void)hipFree(sn->d_lean);
+    if (sn->d_gen) (void)hipFree(sn->d_gen);
     if (sn->d_mem) (void)hipFree(sn->d_mem);
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;
@@ -388,6 +392,26 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     if (sn->n_file) {
         e = hipMalloc(&sn->d_file, sn->n_file * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_file, sn->h_file.data(), sn->n_file * sizeof(SegDesc), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && sn->n_file) {
+        // k_probe_lean pays off on 512-B segments dense enough that hash deltas fit two bytes (>= 2^20 items)
+        std::vector<SegDesc> lean, gen;
+        size_t fi = 0;
+        for (Segment* sg : sn->segs) {
+            if (sg->kind != 0) continue;
+            const SegDesc& d = sn->h_file[fi++];
+            if (d.block_size == 512 && sg->num_items >= (1ull << 20)) lean.push_back(d);
+            else { gen.push_back(d); if (d.block_size != 512) sn->gen_all_512 = false; }
+        }
+        sn->n_lean = (uint32_t)lean.size(); sn->n_gen = (uint32_t)gen.size();
+        if (sn->n_lean) {
+            e = hipMalloc(&sn->d_lean, lean.size() * sizeof(SegDesc));
+            if (e == hipSuccess) e = hipMemcpy(sn->d_lean, lean.data(), lean.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess && sn->n_gen) {
+            e = hipMalloc(&sn->d_gen, gen.size() * sizeof(SegDesc));
+            if (e == hipSuccess) e = hipMemcpy(sn->d_gen, gen.data(), gen.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
+        }
     }
     if (e == hipSuccess && sn->n_mem) {
         e = hipMalloc(&sn->d_mem, sn->n_mem * sizeof(MemDesc));

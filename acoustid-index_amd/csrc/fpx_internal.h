@@ -50,7 +50,7 @@ enum Counter : int {
     CTR_PROBES = 5,      // valid (unique hash, file segment) probes
     CTR_MAXSCORE = 6,
     CTR_GENERIC = 7,     // wave iterations of k_probe that took the generic (per-value) decode path    // largest score of any candidate (sizes the score field of the candidate key)
-    CTR_COUNT = 8
+    CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean (ctr_off = 8)
 };
 
 // ---------------------------------------------------------------- host objects
@@ -80,6 +80,9 @@ struct Snapshot {
     std::vector<SegDesc> h_file;         // host copies of the descriptors
     std::vector<MemDesc> h_mem;
     SegDesc* d_file = nullptr; uint32_t n_file = 0;
+    // file segments split by the kernel that suits them: dense 512-B segments (lean) and the rest (generic)
+    SegDesc* d_lean = nullptr; uint32_t n_lean = 0;
+    SegDesc* d_gen = nullptr; uint32_t n_gen = 0; bool gen_all_512 = true;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
     std::vector<uint32_t*> d_dead;       // owned dead lists
     uint32_t max_block_size = 0;
@@ -89,7 +92,7 @@ struct Snapshot {
 // Pooled per-call device workspace (analogue of SearchResultsPool, src/common.zig:186-300).
 struct Workspace {
     hipStream_t stream = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr, ev_end = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr, ev_probe2 = nullptr, ev_end = nullptr;
     // device buffers (capacity in elements)
     uint32_t* d_hashes = nullptr; size_t cap_hashes = 0;     // raw concatenated query hashes
     uint64_t* d_offsets = nullptr; size_t cap_queries = 0;   // [B+1]

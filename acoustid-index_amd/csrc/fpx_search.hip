@@ -147,6 +147,7 @@ struct ProbeArgs {
     uint32_t* def_list;        // [n_file][def_cap]
     unsigned int* def_count;   // [n_file]
     uint32_t def_cap;
+    uint32_t ctr_off;          // 0, or 8 for k_probe_lean: which statistics slots of `counters` to use
 };
 
 // ---- decode tables (the GPU form of the reference's 256-entry shuffle/length tables, src/streamvbyte.zig:76-211)
@@ -155,7 +156,9 @@ struct ProbeArgs {
 struct DecodeLut {
     uint32_t a[2][256];
     uint4 b[2][256];
-    uint2 f[256];          // 0124 only: {a[0][c], selector that keeps the quad's `len` data bytes}: quad sums via v_sad_u8
+    uint2 f[256];          // 0124, codes <= 2 only: {a[0][c], v_perm selector gathering the LOW byte of each value}
+    uint32_t fh[256];      //                        v_perm selector gathering the HIGH byte of each 2-byte value
+                           // quad sum = v_sad_u8(low bytes) + 256 * v_sad_u8(high bytes) over the quad's <= 8 data bytes
 };
 
 __device__ __forceinline__ uint32_t perm_sel(uint32_t nb)
@@ -179,7 +182,18 @@ __device__ __forceinline__ void init_lut(DecodeLut* lut, uint32_t c)
         }
         lut->a[v][c] = packed | (off << 24);
         lut->b[v][c] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
-        if (v == 0) lut->f[c] = make_uint2(packed | (off << 24), perm_sel(off > 4u ? 4u : off));
+        if (v == 0) {
+            uint32_t sl = 0, sh = 0, o = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t code = (c >> (2 * k)) & 3u;
+                const uint32_t nb = code + (code == 3u ? 1u : 0u);
+                sl |= ((nb >= 1u && o < 8u) ? o : 0x0Cu) << (8 * k);
+                sh |= ((nb == 2u && o + 1u < 8u) ? o + 1u : 0x0Cu) << (8 * k);
+                o += nb;
+            }
+            lut->f[c] = make_uint2(packed | (off << 24), sl);
+            lut->fh[c] = sh;
+        }
     }
 }
 
@@ -230,6 +244,19 @@ __device__ __forceinline__ uint32_t dd_at(const uint32_t dd[8], int k)
     return r;
 }
 
+// sum of the four hash deltas of a quad whose codes are all <= 1 byte (w0 = its first data dword)
+__device__ __forceinline__ uint32_t quad_sum1(uint32_t w0, uint32_t sel_lo)
+{
+    return __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(w0, w0, sel_lo), 0u, 0u);
+}
+// same for codes <= 2 bytes: the quad's data is at most 8 bytes {w1:w0}
+__device__ __forceinline__ uint32_t quad_sum2(uint32_t w0, uint32_t w1, uint32_t sel_lo, uint32_t sel_hi)
+{
+    const uint32_t lo = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(w1, w0, sel_lo), 0u, 0u);
+    const uint32_t hi = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(w1, w0, sel_hi), 0u, 0u);
+    return lo + (hi << 8);
+}
+
 // the 16 bits of a wave ballot that belong to row g (g = lane >> 4)
 __device__ __forceinline__ uint32_t row_bits(unsigned long long m, uint32_t g)
 {
@@ -260,6 +287,8 @@ __device__ __forceinline__ uint32_t decode_one(const DecodeLut* lut, const uint8
 // One wave works on FOUR probes at a time, one per 16-lane row; lane r of a row owns quads 2r and 2r+1
 // of every 32-quad chunk of the block (a 512-B block holds ~29 quads).  Blocks are prefetched one
 // iteration ahead into registers (FAST512) so that ~40 random 512-B reads per SIMD are in flight.
+constexpr int LEAN_KPL = 4;        // keys per lane per round in k_probe_lean (256 pairs per wave per round)
+constexpr int DEF_STAGE_CAP = 512; // LDS staging of deferred pair indices per workgroup
 constexpr int PWG = 512;           // probe workgroup: 8 waves share the decode tables and the hit staging
 constexpr int PWAVES = PWG / 64;
 
@@ -404,8 +433,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                             const uint32_t hincl = scan16(la + lb);
                             const uint32_t pa = min(hdata + hincl - la - lb, limit), pb2 = min(pa + la, limit);
                             const uint32_t ra = lds_u32u(smem, blko + pa), rb = lds_u32u(smem, blko + pb2);
-                            const uint32_t sa = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(ra, ra, fa.y), 0u, 0u);
-                            const uint32_t sb = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(rb, rb, fb.y), 0u, 0u);
+                            const uint32_t sa = quad_sum1(ra, fa.y), sb = quad_sum1(rb, fb.y);
                             const uint32_t vincl = scan16(sa + sb);
                             const uint32_t ua = ph - min_hash - (vincl - sa - sb);      // target relative to quad A's base
                             const uint32_t ub = ua - sa;                                //                  quad B's base
@@ -636,6 +664,8 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
     DecodeLut* lut = reinterpret_cast<DecodeLut*>(smem + STAGE_CAP * sizeof(uint64_t));
     uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut);   // PWAVES * 4 * 544 bytes
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
+    __shared__ uint32_t def_stage[DEF_STAGE_CAP];
+    __shared__ uint32_t def_n, def_base;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
 
     constexpr uint32_t SLOT = 544u;
@@ -647,7 +677,7 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
 
     if (tid < 256u) init_lut(lut, tid);
     if (tid == 0) {
-        stage_count = 0; stage_valid = STAGE_CAP;
+        stage_count = 0; stage_valid = STAGE_CAP; def_n = 0;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0;
     }
     __syncthreads();
@@ -656,45 +686,84 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
     const uint32_t k = gl & 3u;
     const uint32_t qa = 2u * gl;
 
-    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
+    // One round = LEAN_KPL * 64 pairs per wave.  Phase 1 walks the LEAN_KPL lookups of a lane in lockstep so that
+    // their dependent loads (bucket table, block_index binary search) overlap: the walk costs one latency chain
+    // per round, and a longer round amortises it over more probes.
+    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * 64u * LEAN_KPL) * a.rounds;
     for (uint32_t round = 0; round < a.rounds; ++round) {
-        // ---- phase 1: one lane per pair: dedup + block lookup
-        const uint64_t p = wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
-        bool valid = lane < a.ppw && p < a.P;
-        const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
-        if (valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;      // dedupSorted, src/Index.zig:489-499
-        const uint32_t h = (uint32_t)(key >> a.qb);
-        const uint32_t q = (uint32_t)key & qmask;
-        uint32_t b0 = seg.num_blocks;
-        if (valid) {
-            my_probes += 1;
-            b0 = lookup_block(seg, h);
+        // ---- phase 1: LEAN_KPL pairs per lane: dedup + block lookup
+        const uint64_t wave_base = wg_base + (uint64_t)round * (PWAVES * 64u * LEAN_KPL) + (uint64_t)wave * (64u * LEAN_KPL);
+        const uint32_t wave_pair0 = (uint32_t)wave_base;                    // pair index of lane 0, key 0 (P < 2^32)
+        uint32_t h[LEAN_KPL], q[LEAN_KPL], b0v[LEAN_KPL], lo[LEAN_KPL], hi[LEAN_KPL];
+        bool any_open = false;
+#pragma unroll
+        for (int j = 0; j < LEAN_KPL; ++j) {
+            const uint64_t p = wave_base + (uint64_t)j * 64u + lane;
+            bool valid = p < a.P;
+            const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
+            if (valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;      // dedupSorted, src/Index.zig:489-499
+            h[j] = (uint32_t)(key >> a.qb);
+            q[j] = (uint32_t)key & qmask;
+            lo[j] = 0; hi[j] = 0;
+            if (valid) {
+                my_probes += 1;
+                const uint32_t kb = seg.bucket_shift >= 32u ? 0u : (h[j] >> seg.bucket_shift);
+                lo[j] = gload_u32(seg.bucket + kb);
+                hi[j] = gload_u32(seg.bucket + kb + 1);
+            }
+            b0v[j] = valid ? 1u : 0u;                                          // provisional: validity flag
+            any_open = any_open || lo[j] < hi[j];
         }
-        if (b0 >= seg.num_blocks) valid = false;
-        const uint32_t b0v = (b0 & 0x7FFFFFFFu) | (valid ? 0x80000000u : 0u);
-        const uint32_t wave_pair0 = (uint32_t)(p - lane);                   // pair index of lane 0 (P < 2^32)
+        while (__any((int)any_open)) {                                         // lockstep binary search (src/FileSegment.zig:145-151)
+            any_open = false;
+            uint32_t mid[LEAN_KPL], mv[LEAN_KPL];
+#pragma unroll
+            for (int j = 0; j < LEAN_KPL; ++j) {
+                mid[j] = (lo[j] + hi[j]) >> 1;
+                mv[j] = lo[j] < hi[j] ? gload_u32(seg.block_index + mid[j]) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < LEAN_KPL; ++j) {
+                if (lo[j] < hi[j]) { if (mv[j] < h[j]) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
+                any_open = any_open || lo[j] < hi[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LEAN_KPL; ++j) {
+            const bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
+            b0v[j] = (lo[j] & 0x7FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
+        }
 
         // ---- phase 2: four probes per iteration, one per 16-lane row, blocks prefetched one iteration ahead
-        const uint32_t iters = (a.ppw + 3u) >> 2;
+        constexpr uint32_t iters = 16u * LEAN_KPL;
         uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
         {
-            const uint32_t nb = __shfl(b0v, (int)g);
+            const uint32_t nb = __shfl(b0v[0], (int)g);
             if (nb >> 31) {
                 const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
                 pre0 = gload_u4(sb);
                 pre1 = gload_u4(sb + 256);
             }
         }
+#pragma unroll 1
         for (uint32_t it = 0; it < iters; ++it) {
-            const int src = (int)(it * 4u + g);
-            const uint32_t ph = __shfl(h, src);
-            const uint32_t pq = __shfl(q, src);
-            const uint32_t pbv = __shfl(b0v, src);
+            const uint32_t j = it >> 4;                                       // which of the lane's keys (wave-uniform)
+            const int src = (int)((it & 15u) * 4u + g);
+            uint32_t hj = h[0], qj = q[0], bj = b0v[0];
+#pragma unroll
+            for (int jj = 1; jj < LEAN_KPL; ++jj) { if (j == (uint32_t)jj) { hj = h[jj]; qj = q[jj]; bj = b0v[jj]; } }
+            const uint32_t ph = __shfl(hj, src);
+            const uint32_t pq = __shfl(qj, src);
+            const uint32_t pbv = __shfl(bj, src);
             const bool pact = (pbv >> 31) != 0u;
             *reinterpret_cast<uint4*>(blk + gl * 16u) = pre0;
             *reinterpret_cast<uint4*>(blk + 256u + gl * 16u) = pre1;
             if (it + 1u < iters) {
-                const uint32_t nb = __shfl(b0v, src + 4);
+                const uint32_t jn = (it + 1u) >> 4;
+                uint32_t bn = b0v[0];
+#pragma unroll
+                for (int jj = 1; jj < LEAN_KPL; ++jj) { if (jn == (uint32_t)jj) bn = b0v[jj]; }
+                const uint32_t nb = __shfl(bn, (int)(((it + 1u) & 15u) * 4u + g));
                 if (nb >> 31) {
                     const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
                     pre0 = gload_u4(sb);
@@ -722,15 +791,24 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             const uint32_t hincl = scan16(la + lb);
             const uint32_t pa = (8u + nq + hincl - la - lb) & 1023u, pb2 = pa + la;
             const uint32_t ra = lds_u32u(smem, blko + pa), rb = lds_u32u(smem, blko + pb2);
-            const uint32_t sa = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(ra, ra, fa.y), 0u, 0u);
-            const uint32_t sb = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(rb, rb, fb.y), 0u, 0u);
+            uint32_t sa, sb;
+            if (__any((int)((cc & 0xAAAAu) != 0u))) {
+                // some delta of this wave's blocks needs two bytes (sparser segments): 8-byte data windows
+                const uint32_t ra1 = lds_u32u(smem, blko + pa + 4u), rb1 = lds_u32u(smem, blko + pb2 + 4u);
+                sa = quad_sum2(ra, ra1, fa.y, lut->fh[ca]);
+                sb = quad_sum2(rb, rb1, fb.y, lut->fh[cb]);
+            } else {
+                sa = quad_sum1(ra, fa.y);
+                sb = quad_sum1(rb, fb.y);
+            }
             const uint32_t vincl = scan16(sa + sb);
             const uint32_t ua = ph - min_hash - (vincl - sa - sb);
             const uint32_t ub = ua - sa;
             const bool canda = qa < nq && (ua - 1u < sa || (ua == 0u && (ca & 3u) == 0u));
             const bool candb = qa + 1u < nq && (ub - 1u < sb || (ub == 0u && (cb & 3u) == 0u));
             const uint32_t rab = row_bits(__ballot((int)canda), g) | (row_bits(__ballot((int)candb), g) << 16);
-            defer = defer || row_bits(__ballot((int)((cc & 0xAAAAu) != 0u)), g) != 0u || __popc(rab) > 1;
+            // a 4-byte delta (code 3) anywhere in the block, or two candidate quads: the generic pass decides
+            defer = defer || row_bits(__ballot((int)((cc & (cc >> 1) & 0x5555u) != 0u)), g) != 0u || __popc(rab) > 1;
 
             // -- level 2: lanes 0..3 of the row decode the single candidate quad
             const bool hasc = rab != 0u;
@@ -766,8 +844,14 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             // -- bookkeeping per row
             if (gl == 0u && visited) {
                 if (defer) {
-                    const unsigned int slot = atomicAdd(&a.def_count[blockIdx.y], 1u);
-                    if (slot < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + slot] = wave_pair0 + it * 4u + g;
+                    const uint32_t pair = wave_pair0 + j * 64u + (it & 15u) * 4u + g;
+                    const uint32_t slot = atomicAdd(&def_n, 1u);
+                    if (slot < (uint32_t)DEF_STAGE_CAP) {
+                        def_stage[slot] = pair;
+                    } else {                                   // staging full: append directly
+                        const unsigned int gs = atomicAdd(&a.def_count[blockIdx.y], 1u);
+                        if (gs < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + gs] = pair;
+                    }
                 } else {
                     my_blocks += 1; my_docs += cnt;
                 }
@@ -811,6 +895,19 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             if (tid == 0) { stage_count = 0; stage_valid = STAGE_CAP; }
         }
         __syncthreads();
+        // ---- flush the deferred-probe staging (one global atomic per round)
+        {
+            const uint32_t dn = min(def_n, (uint32_t)DEF_STAGE_CAP);
+            if (dn != 0u) {
+                if (tid == 0) def_base = atomicAdd(&a.def_count[blockIdx.y], dn);
+                __syncthreads();
+                for (uint32_t i = tid; i < dn; i += PWG)
+                    if (def_base + i < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + def_base + i] = def_stage[i];
+                __syncthreads();
+                if (tid == 0) def_n = 0;
+                __syncthreads();
+            }
+        }
     }
 
     if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
@@ -819,11 +916,11 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
     __syncthreads();
     if (tid == 0) {
         if (wg_blocks) {
-            atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks);
-            atomicAdd(&a.counters[CTR_BYTES], wg_blocks * 512ull);
+            atomicAdd(&a.counters[a.ctr_off + CTR_BLOCKS], wg_blocks);
+            atomicAdd(&a.counters[a.ctr_off + CTR_BYTES], wg_blocks * 512ull);
         }
-        if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
-        if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
+        if (wg_docs) atomicAdd(&a.counters[a.ctr_off + CTR_DOCS], wg_docs);
+        if (wg_probes) atomicAdd(&a.counters[a.ctr_off + CTR_PROBES], wg_probes);
     }
 }
 
@@ -1151,7 +1248,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
 
     // ---- 3+4: probes (rerun with a larger hit buffer on overflow)
     uint64_t H = 0;
-    float probe_ms = 0.f;
+    float probe_ms = 0.f, aux_ms = 0.f;
     uint32_t probe_launches = 0;
     if (ws->cap_hits == 0) {
         size_t want = std::max<size_t>(1u << 20, (size_t)P * std::max<uint32_t>(1u, snap->n_file + snap->n_mem));
@@ -1159,16 +1256,16 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     }
     // deferred-probe lists of the lean kernel: room for 1/8 of the pairs per segment (typically < 2 % are deferred)
     const size_t def_cap = std::max<size_t>(4096, (size_t)(P / 8));
-    if (snap->n_file) {
-        const size_t need = def_cap * snap->n_file;
+    if (snap->n_lean) {
+        const size_t need = def_cap * snap->n_lean;
         if ((rc = grow(&ws->d_def_list, &ws->cap_def, need))) return rc;
-        if (snap->n_file > ws->cap_def_segs) {
+        if (snap->n_lean > ws->cap_def_segs) {
             if (ws->d_def_count) (void)hipFree(ws->d_def_count);
             if (ws->h_def_count) (void)hipHostFree(ws->h_def_count);
             ws->d_def_count = nullptr; ws->h_def_count = nullptr; ws->cap_def_segs = 0;
-            FPX_HIP(hipMalloc(&ws->d_def_count, snap->n_file * sizeof(unsigned int)));
-            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), snap->n_file * sizeof(unsigned int)));
-            ws->cap_def_segs = snap->n_file;
+            FPX_HIP(hipMalloc(&ws->d_def_count, snap->n_lean * sizeof(unsigned int)));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), snap->n_lean * sizeof(unsigned int)));
+            ws->cap_def_segs = snap->n_lean;
         }
     }
     bool force_generic = false, used_lean = false;
@@ -1177,42 +1274,52 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
         if (P && snap->n_file) {
             ProbeArgs a;
-            a.segs = snap->d_file; a.pairs = d_pairs; a.P = P; a.qb = qb;
+            a.pairs = d_pairs; a.P = P; a.qb = qb;
             // enough workgroups to fill 256 CUs; long per-wave runs amortise the index walk for big batches
             const uint64_t total = P * snap->n_file;
             a.ppw = total >= (1ull << 22) ? 64u : total >= (1ull << 18) ? 16u : 4u;
             a.rounds = total >= (1ull << 25) ? 2u : 1u;
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
-            a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap;
+            a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
-            const bool lean = snap->all_512 && !force_generic && P < 0xFFFFFFFFull;
+            const bool lean = snap->n_lean != 0 && !force_generic && P < 0xFFFFFFFFull && total >= (1ull << 20);
             FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (lean) {
-                // lean kernel for the common case, then the generic kernel on the (few) deferred probes
-                FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_file * sizeof(unsigned int), st));
+                // main kernel: k_probe_lean over the dense 512-B segments
+                FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));
                 const size_t lds_lean = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * 544;
-                hipLaunchKernelGGL(k_probe_lean, dim3(gx, snap->n_file), dim3(PWG), lds_lean, st, a);
+                ProbeArgs l = a;
+                l.segs = snap->d_lean; l.rounds = 1u; l.ctr_off = 8u;
+                const uint64_t per_wg_l = (uint64_t)PWAVES * 64u * LEAN_KPL * l.rounds;
+                const uint32_t gxl = (uint32_t)((P + per_wg_l - 1) / per_wg_l);
+                hipLaunchKernelGGL(k_probe_lean, dim3(gxl, snap->n_lean), dim3(PWG), lds_lean, st, l);
+                FPX_HIP(hipEventRecord(ws->ev_probe1, st));
+                // auxiliary passes: the rows the lean kernel deferred, and the segments it does not suit
                 ProbeArgs d = a;
-                d.ppw = 16u; d.rounds = 1u;
+                d.segs = snap->d_lean; d.ppw = 16u; d.rounds = 1u;
                 const uint64_t per_wg_d = (uint64_t)PWAVES * d.ppw;
                 const uint32_t gxd = (uint32_t)((def_cap + per_wg_d - 1) / per_wg_d);
-                hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_file), dim3(PWG), lds, st, d);
-                probe_launches += 1;
-            } else if (snap->all_512) {
-                hipLaunchKernelGGL((k_probe<true, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+                hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
+                if (snap->n_gen) {
+                    ProbeArgs ge = a;
+                    ge.segs = snap->d_gen;
+                    if (snap->gen_all_512) hipLaunchKernelGGL((k_probe<true, false>), dim3(gx, snap->n_gen), dim3(PWG), lds, st, ge);
+                    else hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_gen), dim3(PWG), lds, st, ge);
+                }
+                FPX_HIP(hipEventRecord(ws->ev_probe2, st));
+                FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, snap->n_lean * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                used_lean = true;
             } else {
-                hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+                a.segs = snap->d_file;
+                if (snap->all_512) hipLaunchKernelGGL((k_probe<true, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+                else hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+                FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             }
-            FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             FPX_HIP(hipGetLastError());
             probe_launches += 1;
-            if (lean) {
-                FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, snap->n_file * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-                used_lean = true;
-            }
         }
         if (P && snap->n_mem) {
             hipLaunchKernelGGL(k_probe_mem, dim3((uint32_t)((P + WG - 1) / WG), snap->n_mem), dim3(WG), 0, st,
@@ -1224,12 +1331,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (P && snap->n_file) {
             float ms = 0.f;
             FPX_HIP(hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1));
-            probe_ms += ms;
+            probe_ms = ms;
+            aux_ms = 0.f;
+            if (used_lean) FPX_HIP(hipEventElapsedTime(&aux_ms, ws->ev_probe1, ws->ev_probe2));
         }
         H = ws->h_counters[CTR_HITS];
         if (used_lean) {
             bool overflow = false;
-            for (uint32_t i = 0; i < snap->n_file; ++i) overflow = overflow || ws->h_def_count[i] > def_cap;
+            for (uint32_t i = 0; i < snap->n_lean; ++i) overflow = overflow || ws->h_def_count[i] > def_cap;
             if (overflow) {                 // pathological data: nearly every probe needs the generic path
                 if (attempt >= 3) { set_error("deferred list overflow persists"); return FPX_E_DEVICE; }
                 force_generic = true;
@@ -1241,9 +1350,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
     }
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
-    const unsigned long long c_blocks = ws->h_counters[CTR_BLOCKS], c_docs = ws->h_counters[CTR_DOCS],
-                             c_bytes = ws->h_counters[CTR_BYTES], c_probes = ws->h_counters[CTR_PROBES],
-                             c_generic = ws->h_counters[CTR_GENERIC];
+    // statistics: slots 0..7 are written by k_probe (generic / deferred / memory), 8..15 by k_probe_lean
+    const unsigned long long c_blocks = ws->h_counters[CTR_BLOCKS] + ws->h_counters[8 + CTR_BLOCKS],
+                             c_docs = ws->h_counters[CTR_DOCS] + ws->h_counters[8 + CTR_DOCS],
+                             c_bytes = ws->h_counters[CTR_BYTES] + ws->h_counters[8 + CTR_BYTES],
+                             c_probes = ws->h_counters[CTR_PROBES] + ws->h_counters[8 + CTR_PROBES],
+                             c_generic = ws->h_counters[CTR_GENERIC],
+                             c_main_bytes = used_lean ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES];
 
     // ---- 5: sort hits by (q, doc), run-length score, keep score >= min_score
     uint64_t C = 0;
@@ -1310,6 +1423,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         stats->total_gpu_ms += total_ms;
         stats->probe_launches += probe_launches;
         stats->generic_iters += (uint32_t)c_generic;
+        stats->probe_kernel_bytes += c_main_bytes;
+        stats->probe_aux_ms += aux_ms;
     }
     return FPX_OK;
 }
@@ -1319,6 +1434,7 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
     dst->probes += s.probes; dst->scanned_blocks += s.scanned_blocks; dst->scanned_docs += s.scanned_docs;
     dst->hits += s.hits; dst->algorithmic_bytes += s.algorithmic_bytes; dst->candidates += s.candidates;
     dst->probe_kernel_ms += s.probe_kernel_ms; dst->total_gpu_ms += s.total_gpu_ms; dst->probe_launches += s.probe_launches; dst->generic_iters += s.generic_iters;
+    dst->probe_kernel_bytes += s.probe_kernel_bytes; dst->probe_aux_ms += s.probe_aux_ms;
 }
 
 // one pass, or -- when (query index, score) do not fit the 64-bit candidate key -- two half batches

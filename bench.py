@@ -146,7 +146,8 @@ def main():
     out_n = np.zeros(B, np.uint32)
     sharded = fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world) if world > 1 else None
 
-    agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0}
+    agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0, "main_bytes": 0, "aux_ms": 0.0,
+           "generic": 0}
 
     def step(record):
         if world == 1:
@@ -160,6 +161,9 @@ def main():
             agg["blocks"] += st.scanned_blocks
             agg["gpu_ms"] += st.total_gpu_ms
             agg["hits"] += st.hits
+            agg["main_bytes"] += st.probe_kernel_bytes
+            agg["aux_ms"] += st.probe_aux_ms
+            agg["generic"] += st.generic_iters
 
     def barrier():
         if world > 1:
@@ -189,7 +193,7 @@ def main():
     if rank == 0:
         launches = max(1, agg["launches"])
         avg_ms = agg["probe_ms"] / launches
-        bytes_per_launch = agg["bytes"] / launches
+        bytes_per_launch = agg["main_bytes"] / launches       # blocks the main kernel visited itself
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         result = {
             "metric": "queries/sec + p50 /_search latency, 100M-fp index, 1k-hash queries",
@@ -202,10 +206,13 @@ def main():
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "index_build_seconds": round(build_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                         "visited_blocks_per_launch": agg["blocks"] / launches},
+                         "all_probe_passes": {"algorithmic_bytes_per_step": agg["bytes"] / max(1, args.steps),
+                                              "ms_per_step": (agg["probe_ms"] + agg["aux_ms"]) / max(1, args.steps),
+                                              "visited_blocks_per_step": agg["blocks"] / max(1, args.steps),
+                                              "blocks_finished_by_generic_pass_per_step": agg["generic"] / max(1, args.steps)}},
             "p50_batch_latency_ms": dt / args.steps * 1e3,
             "gpu_ms_per_step": agg["gpu_ms"] / max(1, args.steps),
             "hits_per_step": agg["hits"] / max(1, args.steps),

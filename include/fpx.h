@@ -64,10 +64,14 @@ typedef struct {
     uint64_t hits;              /* postings accumulated after supersession filtering */
     uint64_t algorithmic_bytes; /* sum over visited blocks of that segment's block_size */
     uint64_t candidates;        /* (query, doc) pairs with score >= min_score */
-    float    probe_kernel_ms;   /* HIP-event time of the posting decode + match kernel launches */
+    float    probe_kernel_ms;   /* HIP-event time of the MAIN posting decode + match kernel (k_probe_lean when the
+                                   batch is large and segments are dense 512-B ones, else k_probe) */
     float    total_gpu_ms;      /* first launch -> last kernel of this call, on the call's stream */
-    uint32_t probe_launches;
-    uint32_t generic_iters;     /* wave iterations of the probe kernel that needed the generic per-value decode path */
+    uint32_t probe_launches;    /* launches of the main probe kernel */
+    uint32_t generic_iters;     /* block visits that needed the generic per-value decode path */
+    uint64_t probe_kernel_bytes;/* algorithmic bytes of the blocks the main probe kernel visited itself */
+    float    probe_aux_ms;      /* deferred / generic auxiliary probe passes (their blocks are in algorithmic_bytes) */
+    uint32_t reserved;
 } fpx_stats;
 
 /* ---- context ----------------------------------------------------------- */

@@ -198,3 +198,26 @@ def test_cpp_host_mirror_example(env):
     subprocess.check_call(["bash", os.path.join(host, "build_host.sh")], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(host, "example_search")], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+def test_lean_kernel_and_deferred_pass(env, dist):
+    """Batches with >= 2^20 probes on 512-B segments run k_probe_lean (two-level match) and finish the rows it
+    cannot handle (wide deltas, runs crossing quads/blocks, > 32 quads) with the deferred generic pass.
+    dist = 1 (hot pool) makes a large share of the probes take the deferred pass."""
+    fpx, oracle, Pair, ctx = env
+    seed, H, per, S = 91 + dist, 128, 9000, 3          # 1.15 M items per segment: 2-byte hash deltas, lean-eligible
+    p = Pair(ctx)
+    for s in range(S):
+        lo = s * per + 1 + (70000 if s else 0)          # ids >= 65536 give 3-byte docids (<= 32 quads per block)
+        p.add_file(fpx.synth.synth_items(seed, lo, per, H, dist=dist), lo, lo + per - 1, s + 1, np.arange(lo, lo + per))
+    p.finish()
+    nq = 360
+    flat, off, targets = fpx.synth.make_queries(seed, 77, nq, per, H, query_len=1000, dist=dist, first_doc=1)
+    qs = [flat[int(off[i]):int(off[i + 1])] for i in range(nq)]
+    got, st = p.check(qs, fpx.http_options())
+    assert st.probes >= (1 << 20) - 4096
+    assert st.probe_kernel_bytes > 0 and st.probe_kernel_bytes < st.algorithmic_bytes   # lean + deferred both worked
+    if dist == 0:
+        assert st.generic_iters < st.probes // 8        # the lean path carried the bulk
+    assert all(g and g[0][0] == int(t) for g, t in zip(got, targets))

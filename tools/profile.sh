@@ -5,7 +5,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o $tag -- \
   python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-latency "$@" > $GRAFT_REPO_ROOT/gpurun_out/${tag}.log 2>&1
-tail -1 $GRAFT_REPO_ROOT/gpurun_out/${tag}.log | grep '^{' > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench.json
+grep '^{"metric' $GRAFT_REPO_ROOT/gpurun_out/${tag}.log | tail -1 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench.json
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$GRAFT_REPO_ROOT/gpurun_out/$tag/${tag}_kernel_stats.csv")))

@@ -101,6 +101,7 @@ struct Workspace {
     uint64_t* d_hits[2] = {nullptr, nullptr}; size_t cap_hits = 0;    // (q, doc) records
     uint64_t* d_cands[2] = {nullptr, nullptr}; size_t cap_cands = 0;  // candidate keys
     void* d_temp = nullptr; size_t cap_temp = 0;              // radix sort temp
+    uint64_t* d_qrange = nullptr; size_t cap_qrange = 0;      // [B][2] begin/end of each query's hit records
     unsigned long long* d_counters = nullptr;                 // [CTR_COUNT]
     uint32_t* d_def_list = nullptr; size_t cap_def = 0;       // deferred probes of the lean kernel [n_file][def_cap]
     unsigned int* d_def_count = nullptr; unsigned int* h_def_count = nullptr; size_t cap_def_segs = 0;

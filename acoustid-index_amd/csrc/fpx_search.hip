@@ -32,7 +32,6 @@ namespace fpx {
 // small device helpers
 // ------------------------------------------------------------------------------------------------
 constexpr int WG = 256;            // 4 waves
-constexpr int WAVES = WG / 64;
 constexpr int STAGE_CAP = 1024;    // LDS hit staging per workgroup (records)
 constexpr int STAGE_FLUSH = 512;
 constexpr int MAX_BLOCKS_PER_HASH = 4;     // src/FileSegment.zig:25
@@ -954,51 +953,99 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// 5. run-length scoring: sorted (q, doc) records -> candidates with score >= min_score[q]
+// 5. scoring: hit records partitioned by query -> per-query hash-table count in LDS -> candidates
 //    (SearchResults.incr + the min_score filter of finish, src/common.zig:121-145)
 // ------------------------------------------------------------------------------------------------
-// pass 0 (write == 0): count the candidates and find the largest score; pass 1: write the keys
-//   key = q << (32 + sb) | (smax - score) << 32 | doc   -> ascending key order = (q, score desc, doc asc)
-// A doc that holds the same hash several times scores once per posting (duplicates are kept in segments,
-// src/MemorySegment.zig:139), so the score is bounded by the number of hits, not by the query length.
-__global__ __launch_bounds__(WG) void k_rle(const uint64_t* __restrict__ hits, uint64_t H, const uint32_t* __restrict__ opts,
-                                             uint32_t sb, int write, uint64_t* cands, uint64_t cand_cap,
-                                             unsigned long long* counters)
+// hits are sorted by q (stable partition); qrange[2q], qrange[2q+1] = [begin, end) of query q
+__global__ __launch_bounds__(WG) void k_bounds(const uint64_t* __restrict__ hits, uint64_t H, uint64_t* __restrict__ qrange)
 {
-    __shared__ uint32_t wg_n;
-    __shared__ unsigned long long wg_base, wg_max;
-    if (threadIdx.x == 0) { wg_n = 0; wg_max = 0; }
-    __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    uint64_t ckey = 0, len = 0;
-    bool is_cand = false;
-    if (i < H) {
-        const uint64_t rec = hits[i];
-        if (i == 0 || hits[i - 1] != rec) {
-            len = 1;
-            while (i + len < H && hits[i + len] == rec) ++len;
-            const uint32_t q = (uint32_t)(rec >> 32), d = (uint32_t)rec;
-            const uint32_t min_score = opts[q * 4u + 1u];
-            if (len >= (uint64_t)min_score) {
-                const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
-                const uint64_t sc = len > smax ? smax : len;
-                ckey = ((uint64_t)q << (32u + sb)) | ((smax - sc) << 32) | d;
-                is_cand = true;
+    if (i >= H) return;
+    const uint32_t q = (uint32_t)(hits[i] >> 32);
+    if (i == 0 || (uint32_t)(hits[i - 1] >> 32) != q) qrange[2ull * q] = i;
+    if (i + 1 == H || (uint32_t)(hits[i + 1] >> 32) != q) qrange[2ull * q + 1] = i + 1;
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// One workgroup per query.  Open-addressing table of (doc << 32 | count) slots in LDS, built with 64-bit LDS
+// atomics -- the GPU form of the reference's per-search hit map (src/common.zig:83-129).  A query with more hits
+// than the table holds is processed in several passes over disjoint doc classes (mix32(doc) % passes).
+// Candidate key = q << (32 + sb) | (smax - score) << 32 | doc   (ascending = score desc, doc asc within a query).
+__global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ qrange,
+                                               const uint32_t* __restrict__ opts, uint32_t log2t, uint32_t sb,
+                                               uint64_t* cands, uint64_t cand_cap, unsigned long long* counters)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ uint32_t wg_n;
+    __shared__ unsigned long long wg_base;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint64_t lo = qrange[2ull * q], hi = qrange[2ull * q + 1];
+    if (hi <= lo) return;
+    const uint64_t n = hi - lo;
+    const uint32_t T = 1u << log2t, mask = T - 1u;
+    const uint32_t min_score = opts[q * 4u + 1u];
+    if (n < (uint64_t)min_score) return;                          // no doc can reach the floor
+    const uint64_t fill = (uint64_t)T * 3u / 4u;
+    const uint32_t passes = (uint32_t)((n + fill - 1) / fill);
+    const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        for (uint32_t s = tid; s < T; s += WG) table[s] = 0ull;
+        if (tid == 0) wg_n = 0;
+        __syncthreads();
+        for (uint64_t i = tid; i < n; i += WG) {
+            const uint32_t d = (uint32_t)hits[lo + i];
+            const uint32_t hsh = mix32(d);
+            if (passes > 1u && (hsh % passes) != pass) continue;
+            uint32_t s = (hsh >> 7) & mask;
+            for (;;) {
+                unsigned long long cur = table[s];
+                if ((uint32_t)cur == 0u) {                                     // empty: try to claim it with count 1
+                    const unsigned long long want = ((unsigned long long)d << 32) | 1ull;
+                    const unsigned long long prev = atomicCAS(&table[s], 0ull, want);
+                    if (prev == 0ull) break;
+                    cur = prev;
+                }
+                if ((uint32_t)(cur >> 32) == d) { atomicAdd(&table[s], 1ull); break; }
+                s = (s + 1u) & mask;
             }
         }
+        __syncthreads();
+        // candidates of this pass
+        for (uint32_t s0 = 0; s0 < T; s0 += WG) {
+            const unsigned long long e = table[s0 + tid];
+            const uint32_t count = (uint32_t)e;
+            const bool is_cand = count != 0u && count >= min_score;
+            if (is_cand && (uint64_t)count > smax) atomicMax(&counters[CTR_MAXSCORE], (unsigned long long)count);
+            const unsigned long long m = __ballot((int)is_cand);
+            if (m == 0ull) continue;
+            if ((tid & 63u) == 0u) atomicAdd(&wg_n, (uint32_t)__popcll(m));          // count first, then reserve once
+        }
+        __syncthreads();
+        const uint32_t total = wg_n;
+        if (total != 0u) {
+            if (tid == 0) wg_base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)total);
+            __syncthreads();
+            if (tid == 0) wg_n = 0;
+            __syncthreads();
+            for (uint32_t s0 = 0; s0 < T; s0 += WG) {
+                const unsigned long long e = table[s0 + tid];
+                const uint32_t count = (uint32_t)e;
+                if (count != 0u && count >= min_score) {
+                    const uint32_t slot = atomicAdd(&wg_n, 1u);
+                    const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
+                    const uint64_t qpart = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
+                    if (wg_base + slot < cand_cap) cands[wg_base + slot] = qpart | ((smax - sc) << 32) | (e >> 32);
+                }
+            }
+        }
+        __syncthreads();
     }
-    uint32_t slot = 0;
-    if (is_cand) {
-        slot = atomicAdd(&wg_n, 1u);
-        if (!write) atomicMax(&wg_max, (unsigned long long)len);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && wg_n) {
-        wg_base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)wg_n);
-        if (!write) atomicMax(&counters[CTR_MAXSCORE], wg_max);
-    }
-    __syncthreads();
-    if (write && is_cand && wg_base + slot < cand_cap) cands[wg_base + slot] = ckey;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1014,7 +1061,7 @@ __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const u
     uint32_t min_score = opts[q * 4u + 1u];
     const uint32_t pct = opts[q * 4u + 2u];
     const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
-    const uint64_t qkey = (uint64_t)q << (32u + sb);
+    const uint64_t qkey = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
     uint64_t lo = 0, hi = C;
     while (lo < hi) {
         uint64_t m = (lo + hi) >> 1;
@@ -1023,7 +1070,7 @@ __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const u
     uint32_t n = 0;
     for (uint64_t i = lo; i < C; ++i) {
         const uint64_t k = cands[i];
-        if ((k >> (32u + sb)) != (uint64_t)q) break;
+        if (sb < 32u && (k >> (32u + sb)) != (uint64_t)q) break;
         if (n == max_results) break;
         const uint32_t score = (uint32_t)(smax - ((k >> 32) & smax));
         if (score < min_score) break;
@@ -1358,40 +1405,51 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_generic = ws->h_counters[CTR_GENERIC],
                              c_main_bytes = used_lean ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES];
 
-    // ---- 5: sort hits by (q, doc), run-length score, keep score >= min_score
+    // ---- 5: partition the hit records by query, count per (query, doc) in LDS, keep score >= min_score
     uint64_t C = 0;
     int ccur = 0;
+    sb = 32u - qb;                              // score field of the candidate key; larger scores -> split the batch
     if (H) {
-        int hcur = 0;
-        const size_t tb = sort_u64_temp_bytes(H, 0, 32 + qb);
-        if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
-        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_hits[0], ws->d_hits[1], H, 0, 32 + qb, st, &hcur));
-        if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);   // keep the convention: d_hits[0] holds the data
-        // pass 0: number of candidates and the largest score; pass 1: write the candidate keys
-        FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
-        FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_rle, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st,
-                           ws->d_hits[0], H, d_opts, 32u, 0, (uint64_t*)nullptr, (uint64_t)0, ws->d_counters);
-        FPX_HIP(hipGetLastError());
-        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipStreamSynchronize(st));
-        C = ws->h_counters[CTR_CANDS];
-        const unsigned long long max_score = ws->h_counters[CTR_MAXSCORE];
-        if (max_score > 0xFFFFFFFFull) { set_error("score overflows u32"); return FPX_E_INVAL; }
-        sb = std::max(1u, bits_for(max_score + 1));
-        if (qb + sb > 32) return FPX_SPLIT;     // the caller retries with smaller batches
-        if (C) {
-            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, (size_t)C + 64))) return rc;
+        if (qb) {
+            int hcur = 0;
+            const size_t tb = sort_u64_temp_bytes(H, 32, 32 + qb);
+            if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_hits[0], ws->d_hits[1], H, 32, 32 + qb, st, &hcur));
+            if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);   // keep the convention: d_hits[0] holds the data
+        }
+        if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;
+        FPX_HIP(hipMemsetAsync(ws->d_qrange, 0, (size_t)B * 2 * sizeof(uint64_t), st));
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st, ws->d_hits[0], H, ws->d_qrange);
+        // table sized for ~4x the average number of hits per query, 16 KB .. 128 KB of LDS
+        uint32_t log2t = 11;
+        while (log2t < 14 && (1ull << log2t) < 4 * (H / B + 1)) ++log2t;
+        const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
+        if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
+        static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)lds_attr;
+        for (int attempt = 0;; ++attempt) {
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_rle, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st,
-                               ws->d_hits[0], H, d_opts, sb, 1, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
+            FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_score, dim3(B), dim3(WG), (size_t)8 << log2t, st, (const uint64_t*)ws->d_hits[0],
+                               (const uint64_t*)ws->d_qrange, d_opts, log2t, sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
             FPX_HIP(hipGetLastError());
+            FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipStreamSynchronize(st));
+            C = ws->h_counters[CTR_CANDS];
+            if (ws->h_counters[CTR_MAXSCORE] != 0) {              // a score does not fit the key's score field
+                if (B <= 1) { set_error("score overflows u32"); return FPX_E_INVAL; }
+                return FPX_SPLIT;                                  // the caller retries with smaller batches
+            }
+            if (C <= ws->cap_cands) break;
+            if (attempt >= 2) { set_error("candidate buffer overflow persists"); return FPX_E_DEVICE; }
+            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, (size_t)C + 1024))) return rc;
         }
         // ---- 6: sort candidates by (q, score desc, id asc)
         if (C) {
-            const size_t tb2 = sort_u64_temp_bytes(C, 0, 32 + sb + qb);
+            const size_t tb2 = sort_u64_temp_bytes(C, 0, 64);
             if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb2 + 256))) return rc;
-            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_cands[0], ws->d_cands[1], C, 0, 32 + sb + qb, st, &ccur));
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_cands[0], ws->d_cands[1], C, 0, 64, st, &ccur));
         }
     }
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;

@@ -806,39 +806,76 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             const bool canda = qa < nq && (ua - 1u < sa || (ua == 0u && (ca & 3u) == 0u));
             const bool candb = qa + 1u < nq && (ub - 1u < sb || (ub == 0u && (cb & 3u) == 0u));
             const uint32_t rab = row_bits(__ballot((int)canda), g) | (row_bits(__ballot((int)candb), g) << 16);
-            // a 4-byte delta (code 3) anywhere in the block, or two candidate quads: the generic pass decides
-            defer = defer || row_bits(__ballot((int)((cc & (cc >> 1) & 0x5555u) != 0u)), g) != 0u || __popc(rab) > 1;
+            // a 4-byte delta (code 3) anywhere in the block: the generic pass decides
+            defer = defer || row_bits(__ballot((int)((cc & (cc >> 1) & 0x5555u) != 0u)), g) != 0u;
+            // One candidate quad is the rule.  Two ADJACENT candidates mean a run of equal hashes crosses a quad
+            // boundary: the upper one then starts exactly at the target (relative target 0) and holds the run's
+            // zero-delta tail.  Anything else (three candidates = a run longer than a quad, ...) is deferred.
+            const uint32_t ncand = __popc(rab);
+            const uint32_t rab2 = rab & (rab - 1u);
+            const uint32_t b1 = ncand ? (uint32_t)__builtin_ctz(rab) : 0u, b2 = rab2 ? (uint32_t)__builtin_ctz(rab2) : 0u;
+            const uint32_t q1 = 2u * (b1 & 15u) + (b1 >> 4), q2 = 2u * (b2 & 15u) + (b2 >> 4);
+            const bool two = ncand == 2u && (q1 + 1u == q2 || q2 + 1u == q1);
+            const bool swap12 = ncand == 2u && q2 < q1;
+            const uint32_t blo = swap12 ? b2 : b1, bhi = swap12 ? b1 : b2;
+            defer = defer || ncand > 2u || (ncand == 2u && !two);
 
-            // -- level 2: lanes 0..3 of the row decode the single candidate quad
-            const bool hasc = rab != 0u;
-            const uint32_t idx = hasc ? (uint32_t)__builtin_ctz(rab) : 0u;
-            const int owner = (int)((lane & 48u) | (idx & 15u));
-            const uint32_t pk = __shfl(canda ? (pa | (ca << 16)) : (pb2 | (cb << 16)), owner);
-            const uint32_t ut = __shfl(canda ? ua : ub, owner);
-            const uint32_t val = decode_one<0>(lut, smem, blko + (pk & 0xFFFFu), pk >> 16, k);
-            const bool ek = visited && !defer && hasc && gl < 4u && scan4(val) == ut;
-            const unsigned long long me = __ballot((int)ek);
-            uint32_t cnt = 0;
-            bool keep = false;
-            uint32_t doc = 0;
-            if (me != 0ull) {
-                // -- docids of the run (all inside the candidate quad)
+            // -- level 2: lanes 0..3 of the row decode the candidate quad(s)
+            const uint32_t packab = pa | (ca << 10) | (cb << 18) | (la << 26);
+            const int owner0 = (int)((lane & 48u) | (blo & 15u));
+            const uint32_t x0 = __shfl(packab, owner0);
+            const uint32_t ut0 = __shfl((blo >> 4) ? ub : ua, owner0);
+            const bool useb0 = (blo >> 4) != 0u;
+            const uint32_t val0 = decode_one<0>(lut, smem, blko + (x0 & 1023u) + (useb0 ? (x0 >> 26) : 0u),
+                                                useb0 ? ((x0 >> 18) & 0xFFu) : ((x0 >> 10) & 0xFFu), k);
+            const bool live = visited && !defer && gl < 4u;
+            const bool ek0 = live && ncand != 0u && scan4(val0) == ut0;
+            bool ek1 = false;
+            const int owner1 = (int)((lane & 48u) | (bhi & 15u));
+            if (__any((int)(two && live))) {
+                const uint32_t x1 = __shfl(packab, owner1);
+                const bool useb1 = (bhi >> 4) != 0u;
+                const uint32_t val1 = decode_one<0>(lut, smem, blko + (x1 & 1023u) + (useb1 ? (x1 >> 26) : 0u),
+                                                    useb1 ? ((x1 >> 18) & 0xFFu) : ((x1 >> 10) & 0xFFu), k);
+                ek1 = live && two && scan4(val1) == 0u;            // the leading zero deltas of the upper quad
+            }
+            const unsigned long long me0 = __ballot((int)ek0), me1 = __ballot((int)ek1);
+            uint32_t cnt = 0, doc0 = 0, doc1 = 0;
+            if ((me0 | me1) != 0ull) {
+                // -- docids of the run
                 const uint32_t dcc = lds_u32u(smem, blko + 8u + doff + qa);
                 const uint32_t da = dcc & 0xFFu, db = (dcc >> 8) & 0xFFu;
                 const uint32_t dla = qa < nq ? (lut->a[1][da] >> 24) : 0u;
                 const uint32_t dlb = qa + 1u < nq ? (lut->a[1][db] >> 24) : 0u;
                 const uint32_t dincl = scan16(dla + dlb);
-                const uint32_t dpa = (8u + doff + nq + dincl - dla - dlb) & 1023u, dpb = dpa + dla;
-                const uint32_t dpk = __shfl(canda ? (dpa | (da << 16)) : (dpb | (db << 16)), owner);
-                const uint32_t dv = decode_one<1>(lut, smem, blko + (dpk & 0xFFFFu), dpk >> 16, k);
-                doc = seg.min_doc_id + scan4(ek ? dv : 0u);
-                const uint32_t erow = row_bits(me, g);
-                cnt = __popc(erow);
+                const uint32_t dpa = (8u + doff + nq + dincl - dla - dlb) & 1023u;
+                const uint32_t dpackab = dpa | (da << 10) | (db << 18) | (dla << 26);
+                const uint32_t y0 = __shfl(dpackab, owner0);
+                const uint32_t dv0 = decode_one<1>(lut, smem, blko + (y0 & 1023u) + (useb0 ? (y0 >> 26) : 0u),
+                                                   useb0 ? ((y0 >> 18) & 0xFFu) : ((y0 >> 10) & 0xFFu), k);
+                doc0 = seg.min_doc_id + scan4(ek0 ? dv0 : 0u);
+                const uint32_t erow0 = row_bits(me0, g);
+                cnt = __popc(erow0);
+                uint32_t elast = erow0, qlast = swap12 ? q2 : q1;              // the quad that ends the run
+                if (me1 != 0ull) {
+                    const uint32_t y1 = __shfl(dpackab, owner1);
+                    const bool useb1 = (bhi >> 4) != 0u;
+                    const uint32_t dv1 = decode_one<1>(lut, smem, blko + (y1 & 1023u) + (useb1 ? (y1 >> 26) : 0u),
+                                                       useb1 ? ((y1 >> 18) & 0xFFu) : ((y1 >> 10) & 0xFFu), k);
+                    // the run continues from the lower quad's last item (lane 3 of the row)
+                    const uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)doc0, 0xFF, 0xF, 0xF, false);
+                    doc1 = carry + scan4(ek1 ? dv1 : 0u);
+                    const uint32_t erow1 = row_bits(me1, g);
+                    cnt += __popc(erow1);
+                    if (two) { elast = erow1; qlast = swap12 ? q1 : q2; }
+                }
                 // a run that reaches the block's last item may continue in the next block: let k_probe finish it
-                const uint32_t qstar = 2u * (idx & 15u) + (idx >> 4);
-                if (qstar + 1u == nq && ((erow >> 3) & 1u) != 0u && (pbv & 0x7FFFFFFFu) + 1u < seg.num_blocks) defer = true;
-                keep = ek && !defer;
-                if (seg.num_dead != 0u && keep && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc)) keep = false;
+                if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && (pbv & 0x7FFFFFFFu) + 1u < seg.num_blocks) defer = true;
+            }
+            bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
+            if (seg.num_dead != 0u) {
+                if (keep0 && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc0)) keep0 = false;
+                if (keep1 && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc1)) keep1 = false;
             }
             // -- bookkeeping per row
             if (gl == 0u && visited) {
@@ -856,14 +893,17 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
                 }
             }
             // -- emission (wave-uniform control flow)
-            const unsigned long long m = __ballot((int)keep);
-            if (m != 0ull) {
+            const int nsets = me1 != 0ull ? 2 : 1;
+            for (int e = 0; e < nsets; ++e) {
+                const bool keep = e ? keep1 : keep0;
+                const unsigned long long m = __ballot((int)keep);
+                if (m == 0ull) continue;
                 const uint32_t total = __popcll(m);
                 const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
                 uint32_t pos = 0;
                 if (lane == 0) pos = atomicAdd(&stage_count, total);
                 pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                const uint64_t rec = ((uint64_t)pq << 32) | doc;
+                const uint64_t rec = ((uint64_t)pq << 32) | (e ? doc1 : doc0);
                 if (pos + total <= (uint32_t)STAGE_CAP) {
                     if (keep) stage[pos + rank] = rec;
                 } else {
@@ -982,8 +1022,6 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
 {
     extern __shared__ __align__(16) uint8_t smem[];
     unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);
-    __shared__ uint32_t wg_n;
-    __shared__ unsigned long long wg_base;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint64_t lo = qrange[2ull * q], hi = qrange[2ull * q + 1];
     if (hi <= lo) return;
@@ -991,12 +1029,11 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
     const uint32_t T = 1u << log2t, mask = T - 1u;
     const uint32_t min_score = opts[q * 4u + 1u];
     if (n < (uint64_t)min_score) return;                          // no doc can reach the floor
-    const uint64_t fill = (uint64_t)T * 3u / 4u;
+    const uint64_t fill = (uint64_t)T * 7u / 8u;
     const uint32_t passes = (uint32_t)((n + fill - 1) / fill);
     const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
     for (uint32_t pass = 0; pass < passes; ++pass) {
         for (uint32_t s = tid; s < T; s += WG) table[s] = 0ull;
-        if (tid == 0) wg_n = 0;
         __syncthreads();
         for (uint64_t i = tid; i < n; i += WG) {
             const uint32_t d = (uint32_t)hits[lo + i];
@@ -1016,32 +1053,22 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
             }
         }
         __syncthreads();
-        // candidates of this pass
+        // candidates of this pass (rare: a handful per query): one global reservation per wave that has any
         for (uint32_t s0 = 0; s0 < T; s0 += WG) {
             const unsigned long long e = table[s0 + tid];
             const uint32_t count = (uint32_t)e;
             const bool is_cand = count != 0u && count >= min_score;
-            if (is_cand && (uint64_t)count > smax) atomicMax(&counters[CTR_MAXSCORE], (unsigned long long)count);
             const unsigned long long m = __ballot((int)is_cand);
             if (m == 0ull) continue;
-            if ((tid & 63u) == 0u) atomicAdd(&wg_n, (uint32_t)__popcll(m));          // count first, then reserve once
-        }
-        __syncthreads();
-        const uint32_t total = wg_n;
-        if (total != 0u) {
-            if (tid == 0) wg_base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)total);
-            __syncthreads();
-            if (tid == 0) wg_n = 0;
-            __syncthreads();
-            for (uint32_t s0 = 0; s0 < T; s0 += WG) {
-                const unsigned long long e = table[s0 + tid];
-                const uint32_t count = (uint32_t)e;
-                if (count != 0u && count >= min_score) {
-                    const uint32_t slot = atomicAdd(&wg_n, 1u);
-                    const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
-                    const uint64_t qpart = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
-                    if (wg_base + slot < cand_cap) cands[wg_base + slot] = qpart | ((smax - sc) << 32) | (e >> 32);
-                }
+            if (is_cand && (uint64_t)count > smax) atomicMax(&counters[CTR_MAXSCORE], (unsigned long long)count);
+            unsigned long long base = 0;
+            if ((tid & 63u) == 0u) base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)__popcll(m));
+            base = __shfl(base, 0);
+            if (is_cand) {
+                const uint64_t slot = base + __popcll(m & ((1ull << (tid & 63u)) - 1ull));
+                const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
+                const uint64_t qpart = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
+                if (slot < cand_cap) cands[slot] = qpart | ((smax - sc) << 32) | (e >> 32);
             }
         }
         __syncthreads();
@@ -1420,9 +1447,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;
         FPX_HIP(hipMemsetAsync(ws->d_qrange, 0, (size_t)B * 2 * sizeof(uint64_t), st));
         hipLaunchKernelGGL(k_bounds, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st, ws->d_hits[0], H, ws->d_qrange);
-        // table sized for ~4x the average number of hits per query, 16 KB .. 128 KB of LDS
+        // table sized for ~1.3x the average number of hits per query (a fuller query takes a second pass), 16 .. 128 KB of LDS
         uint32_t log2t = 11;
-        while (log2t < 14 && (1ull << log2t) < 4 * (H / B + 1)) ++log2t;
+        while (log2t < 14 && (1ull << log2t) * 3 < 4 * (H / B + 1)) ++log2t;
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
         static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     const uint32_t bs = FAST512 ? 512u : seg.block_size;
     if (DEFERRED) {
         // most workgroups of the deferred pass find nothing to do
-        const uint64_t first = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
+        const uint64_t first = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw);
         if (first >= (uint64_t)min(a.def_count[blockIdx.y], a.def_cap)) return;
     }
 
@@ -322,10 +322,14 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
 
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_generic = 0;
 
-    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
-    for (uint32_t round = 0; round < a.rounds; ++round) {
+    // DEFERRED: a small persistent grid strides over the segment's (usually tiny) list of deferred probes
+    const uint32_t def_n = DEFERRED ? min(a.def_count[blockIdx.y], a.def_cap) : 0u;
+    const uint32_t nrounds = DEFERRED ? (def_n + gridDim.x * PWAVES * a.ppw - 1u) / (gridDim.x * PWAVES * a.ppw) : a.rounds;
+    const uint64_t wg_base = DEFERRED ? 0ull : (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
+    for (uint32_t round = 0; round < nrounds; ++round) {
         // ---- phase 1: one lane per pair: dedup + block lookup
-        uint64_t p = wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
+        uint64_t p = DEFERRED ? ((uint64_t)round * gridDim.x + blockIdx.x) * (uint64_t)(PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane
+                              : wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
         bool valid;
         if (DEFERRED) {
             // p indexes this segment's list of deferred probes (already deduplicated and counted by k_probe_lean)
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         // ---- flush the LDS staging buffer at round boundaries
         __syncthreads();
         const uint32_t sc = stage_count;
-        const bool last = (round + 1u == a.rounds);
+        const bool last = (round + 1u == nrounds);
         if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
             const uint32_t n = min(sc, stage_valid);
             if (tid == 0) {
@@ -996,7 +1000,7 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
 // 5. scoring: hit records partitioned by query -> per-query hash-table count in LDS -> candidates
 //    (SearchResults.incr + the min_score filter of finish, src/common.zig:121-145)
 // ------------------------------------------------------------------------------------------------
-// hits are sorted by q (stable partition); qrange[2q], qrange[2q+1] = [begin, end) of query q
+// hit records sorted by q (stable radix partition on the query bits): [begin, end) of each query's records
 __global__ __launch_bounds__(WG) void k_bounds(const uint64_t* __restrict__ hits, uint64_t H, uint64_t* __restrict__ qrange)
 {
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
@@ -1035,8 +1039,19 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
     for (uint32_t pass = 0; pass < passes; ++pass) {
         for (uint32_t s = tid; s < T; s += WG) table[s] = 0ull;
         __syncthreads();
-        for (uint64_t i = tid; i < n; i += WG) {
-            const uint32_t d = (uint32_t)hits[lo + i];
+        constexpr int LB = 8;                                     // records loaded per thread before inserting them
+        for (uint64_t i0 = 0; i0 < n; i0 += (uint64_t)WG * LB) {
+            uint32_t dbuf[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const uint64_t i = i0 + (uint64_t)u * WG + tid;
+                dbuf[u] = i < n ? (uint32_t)hits[lo + i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * WG + tid;
+            if (i >= n) continue;
+            const uint32_t d = dbuf[u];
             const uint32_t hsh = mix32(d);
             if (passes > 1u && (hsh % passes) != pass) continue;
             uint32_t s = (hsh >> 7) & mask;
@@ -1050,6 +1065,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
                 }
                 if ((uint32_t)(cur >> 32) == d) { atomicAdd(&table[s], 1ull); break; }
                 s = (s + 1u) & mask;
+            }
             }
         }
         __syncthreads();
@@ -1375,7 +1391,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 ProbeArgs d = a;
                 d.segs = snap->d_lean; d.ppw = 16u; d.rounds = 1u;
                 const uint64_t per_wg_d = (uint64_t)PWAVES * d.ppw;
-                const uint32_t gxd = (uint32_t)((def_cap + per_wg_d - 1) / per_wg_d);
+                const uint32_t gxd = (uint32_t)std::min<uint64_t>((def_cap + per_wg_d - 1) / per_wg_d, 64);
                 hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
                 if (snap->n_gen) {
                     ProbeArgs ge = a;
@@ -1437,16 +1453,17 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     int ccur = 0;
     sb = 32u - qb;                              // score field of the candidate key; larger scores -> split the batch
     if (H) {
+        // partition of the records by query (order inside a query is irrelevant to the hash-table count)
+        if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;
         if (qb) {
             int hcur = 0;
             const size_t tb = sort_u64_temp_bytes(H, 32, 32 + qb);
             if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
             FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_hits[0], ws->d_hits[1], H, 32, 32 + qb, st, &hcur));
-            if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);   // keep the convention: d_hits[0] holds the data
+            if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);   // convention: d_hits[0] holds the data
         }
-        if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;
         FPX_HIP(hipMemsetAsync(ws->d_qrange, 0, (size_t)B * 2 * sizeof(uint64_t), st));
-        hipLaunchKernelGGL(k_bounds, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st, ws->d_hits[0], H, ws->d_qrange);
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)ws->d_hits[0], H, ws->d_qrange);
         // table sized for ~1.3x the average number of hits per query (a fuller query takes a second pass), 16 .. 128 KB of LDS
         uint32_t log2t = 11;
         while (log2t < 14 && (1ull << log2t) * 3 < 4 * (H / B + 1)) ++log2t;

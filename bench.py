@@ -195,6 +195,16 @@ def main():
         avg_ms = agg["probe_ms"] / launches
         bytes_per_launch = agg["main_bytes"] / launches       # blocks the main kernel visited itself
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc FETCH_SIZE pass (tools/pmc_traffic.sh),
+        # stored with its calibration under profiles/; it is reported only for the configuration it was measured on
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            c = tr["config"]
+            if world == 1 and (c["docs"], c["segments"], c["hashes_per_doc"], c["batch"], c["query_len"]) == (docs, S, H, B, args.query_len):
+                traffic = tr["k_probe_lean"]["hbm_read_bytes_per_launch_corrected"]
+        except (OSError, KeyError, ValueError):
+            pass
         result = {
             "metric": "queries/sec + p50 /_search latency, 100M-fp index, 1k-hash queries",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,7 +217,7 @@ def main():
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "index_build_seconds": round(build_s, 2)},
             "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                          "all_probe_passes": {"algorithmic_bytes_per_step": agg["bytes"] / max(1, args.steps),
                                               "ms_per_step": (agg["probe_ms"] + agg["aux_ms"]) / max(1, args.steps),

@@ -221,3 +221,22 @@ def test_lean_kernel_and_deferred_pass(env, dist):
     if dist == 0:
         assert st.generic_iters < st.probes // 8        # the lean path carried the bulk
     assert all(g and g[0][0] == int(t) for g, t in zip(got, targets))
+
+
+def test_score_table_multi_pass_and_many_candidates(env):
+    """k_score sizes its LDS table for the AVERAGE hits per query; a query far above the average is counted in
+    several passes over disjoint doc classes.  One heavy query (hot hashes, min_score 1, limit 500) rides in a
+    batch of light ones."""
+    fpx, oracle, Pair, ctx = env
+    seed, H, per = 401, 96, 40000
+    p = Pair(ctx)
+    p.add_file(fpx.synth.synth_items(seed, 1, per, H, dist=1), 1, per, 1, np.arange(1, per + 1))
+    p.add_file(fpx.synth.synth_items(seed, per + 1, per, H, dist=1), per + 1, 2 * per, 2, np.arange(per + 1, 2 * per + 1))
+    p.finish()
+    hot = [int(fpx.synth.mix64(np.uint64(seed) ^ np.uint64(0x5bd1e9955bd1e995) ^ (np.uint64(k) << np.uint64(32))) >> np.uint64(32))
+           for k in range(64)]
+    heavy = np.array(hot, dtype=np.uint32)                     # 64 hot values x up to ~2000 docs each
+    light = [fpx.synth.synth_hashes(seed, [d], H, 1)[0][:8] for d in range(1, 120)]
+    opts = [fpx.SearchOptions(500, 1, 0)] + [fpx.SearchOptions(5, 1, 10)] * len(light)
+    got, st = p.check([heavy] + light, opts)
+    assert len(got[0]) == 500 and st.hits > 20000 and st.candidates > 10000

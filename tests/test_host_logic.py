@@ -58,3 +58,19 @@ def test_assign_segments_balances():
     own = fpx.sharding.assign_segments([100, 1, 1, 1, 1, 1, 1, 1], 2)
     load = [sum(w for w, o in zip([100, 1, 1, 1, 1, 1, 1, 1], own) if o == r) for r in range(2)]
     assert max(load) == 100 and min(load) == 7
+
+
+def test_baseline_config_1_cpu_plumbing():
+    """BASELINE.json configs[0]: 10 k fingerprints x 256 u32 hashes, one /_search query on the CPU path
+    (here: the oracle, HTTP default options).  The target ranks first with nearly all of its hashes."""
+    seed, ndocs, H = 2026, 10000, 256
+    items = oracle.synth_items(seed, 1, ndocs, H)
+    blocks, index = oracle.build_blocks(items, 1, 512)
+    seg = oracle.file_segment(blocks, 512, index, 1, ndocs, 1, np.arange(1, ndocs + 1, dtype=np.uint32))
+    snap = oracle.Snapshot([seg], [])
+    flat, off, targets = fpx.synth.make_queries(seed, 1, 4, ndocs, H, query_len=1000)
+    for q in range(4):
+        res, st = snap.search(flat[int(off[q]):int(off[q + 1])], 40, None, 10, with_stats=True)
+        assert res and res[0][0] == int(targets[q]) and res[0][1] >= 200
+        assert all(s >= 50 for _, s in res)                  # min_score = (1000 + 19) // 20
+        assert st.probes >= 990 and st.scanned_blocks <= st.probes + 8

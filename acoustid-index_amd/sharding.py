@@ -40,19 +40,34 @@ def gather_tables(dist, table, counts, world, group=None):
 class ShardedReader:
     """IndexReader over a snapshot whose file segments are split across the ranks of a process group."""
 
-    def __init__(self, fpx, ctx, reader, dist, world):
+    def __init__(self, fpx, ctx, reader, dist, world, host_staged=False):
         self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
+        self.host_staged = host_staged      # debugging aid: exchange through host memory with a CPU backend (gloo)
         self._bufs = {}
 
-    def search_resident(self, qb, out=None, out_n=None):
+    def partial(self, qb):
+        """stage 1: probe the local segments; the per-query tables stay in HBM"""
         import torch
         key = (qb.B, qb.cap)
         if key not in self._bufs:
             self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device="cuda"),
                                torch.zeros((qb.B,), dtype=torch.int32, device="cuda"))
         d_part, d_cnt = self._bufs[key]
-        st = self.fpx.search_resident_partial(self.reader, qb, d_part.data_ptr(), d_cnt.data_ptr())
-        tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
+        return self.fpx.search_resident_partial(self.reader, qb, d_part.data_ptr(), d_cnt.data_ptr())
+
+    def gather_merge(self, qb, out=None, out_n=None):
+        """stages 2 + 3: all-gather of the tables, merge.  Every rank must call this in the same order."""
+        import torch
+        d_part, d_cnt = self._bufs[(qb.B, qb.cap)]
+        if self.host_staged:
+            tables, cnts = gather_tables(self.dist, d_part.cpu(), d_cnt.cpu(), self.world)
+            tables, cnts = tables.cuda(), cnts.cuda()
+        else:
+            tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)      # RCCL all-gather over xGMI
         torch.cuda.synchronize()
-        out, out_n = self.fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
+        return self.fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
+
+    def search_resident(self, qb, out=None, out_n=None):
+        st = self.partial(qb)
+        out, out_n = self.gather_merge(qb, out, out_n)
         return out, out_n, st

@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("FPX_BENCH_CPU_QUERIES", 1024)))
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FPX_BENCH_CPU_SECONDS", 10.0)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("FPX_BENCH_INFLIGHT", 0)),
+                    help="batches kept in flight by that many host threads (each call owns a pooled workspace + HIP stream); "
+                         "0 = auto: 1 on one GPU (clean per-kernel timing), 2 when sharded (hides the all-gather/merge latency)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency probe (profiling runs)")
     ap.add_argument("--measure-bw", action="store_true", help="also report the measured streaming / random-block read bandwidth")
     return ap.parse_args()
@@ -103,11 +106,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libfpx has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # FPX_BENCH_BACKEND=gloo + FPX_BENCH_DEVICE=0 let several ranks share ONE GPU (debugging the multi-process
+    # flow on a single-GPU box): the tables then travel through host memory instead of RCCL.
+    backend = os.environ.get("FPX_BENCH_BACKEND", "nccl")
+    device = int(os.environ.get("FPX_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    ctx = fpx.Context(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    ctx = fpx.Context(device)
 
     # ---- index: S contiguous id ranges, commit_id = s + 1; shrink if HBM is too small
     S, H, B = args.segments, args.hashes, args.batch
@@ -144,17 +154,18 @@ def main():
     cap = qb.cap
     out = np.zeros((B, cap, 2), np.uint32)
     out_n = np.zeros(B, np.uint32)
-    sharded = fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world) if world > 1 else None
 
     agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0, "main_bytes": 0, "aux_ms": 0.0,
            "generic": 0}
 
-    def step(record):
-        if world == 1:
-            _, _, st = fpx.search_resident(reader, qb, 0, out, out_n)
-        else:
-            _, _, st = sharded.search_resident(qb, out, out_n)     # partial tables -> RCCL all-gather -> merge
-        if record:
+    import concurrent.futures as cf
+    lock = threading.Lock()
+    nfl = args.inflight if args.inflight > 0 else (1 if world == 1 else 2)
+    outs = [(np.zeros((B, cap, 2), np.uint32), np.zeros(B, np.uint32)) for _ in range(nfl)]
+    shardeds = [fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world, host_staged=(backend != "nccl")) for _ in range(nfl)] if world > 1 else None
+
+    def record_stats(st):
+        with lock:
             agg["bytes"] += st.algorithmic_bytes
             agg["probe_ms"] += st.probe_kernel_ms
             agg["launches"] += st.probe_launches
@@ -165,21 +176,53 @@ def main():
             agg["aux_ms"] += st.probe_aux_ms
             agg["generic"] += st.generic_iters
 
+    def run_steps(nsteps, record):
+        """nsteps batches, `nfl` of them in flight.  world == 1: every thread runs whole searches.  world > 1: threads
+        run stage 1 (local partial search); the all-gather + merge of step s is issued by this thread in step order so
+        that every rank enters the collectives in the same sequence."""
+        if world == 1:
+            def one(i):
+                o, n = outs[i % nfl]
+                _, _, st = fpx.search_resident(reader, qb, 0, o, n)
+                if record:
+                    record_stats(st)
+            if nfl == 1:
+                for i in range(nsteps):
+                    one(i)
+            else:
+                with cf.ThreadPoolExecutor(nfl) as ex:
+                    list(ex.map(one, range(nsteps)))
+            return
+        def stage1(i):
+            sh = shardeds[i % nfl]
+            return sh.partial(qb)
+        with cf.ThreadPoolExecutor(nfl) as ex:
+            pending = []
+            nxt = 0
+            for i in range(nsteps):
+                while nxt < nsteps and len(pending) < nfl:
+                    pending.append(ex.submit(stage1, nxt))
+                    nxt += 1
+                st = pending.pop(0).result()
+                o, n = outs[i % nfl]
+                shardeds[i % nfl].gather_merge(qb, o, n)
+                if record:
+                    record_stats(st)
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    run_steps(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_steps(args.steps, True)
     barrier()
+    out, out_n = outs[(args.steps - 1) % nfl]
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # roofline numerator / denominator of the slowest rank is this rank's own; report rank 0's kernel
@@ -223,7 +266,7 @@ def main():
                                               "ms_per_step": (agg["probe_ms"] + agg["aux_ms"]) / max(1, args.steps),
                                               "visited_blocks_per_step": agg["blocks"] / max(1, args.steps),
                                               "blocks_finished_by_generic_pass_per_step": agg["generic"] / max(1, args.steps)}},
-            "p50_batch_latency_ms": dt / args.steps * 1e3,
+            "inflight": nfl,
             "gpu_ms_per_step": agg["gpu_ms"] / max(1, args.steps),
             "hits_per_step": agg["hits"] / max(1, args.steps),
             "targets_found": found, "targets_total": B, "median_top_score": int(np.median(top_scores)) if top_scores else 0,

@@ -815,14 +815,20 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             // One candidate quad is the rule.  Two ADJACENT candidates mean a run of equal hashes crosses a quad
             // boundary: the upper one then starts exactly at the target (relative target 0) and holds the run's
             // zero-delta tail.  Anything else (three candidates = a run longer than a quad, ...) is deferred.
-            const uint32_t ncand = __popc(rab);
-            const uint32_t rab2 = rab & (rab - 1u);
-            const uint32_t b1 = ncand ? (uint32_t)__builtin_ctz(rab) : 0u, b2 = rab2 ? (uint32_t)__builtin_ctz(rab2) : 0u;
-            const uint32_t q1 = 2u * (b1 & 15u) + (b1 >> 4), q2 = 2u * (b2 & 15u) + (b2 >> 4);
-            const bool two = ncand == 2u && (q1 + 1u == q2 || q2 + 1u == q1);
-            const bool swap12 = ncand == 2u && q2 < q1;
+            const uint32_t rab2 = rab & (rab - 1u);                         // != 0: more than one candidate
+            const uint32_t b1 = rab ? (uint32_t)__builtin_ctz(rab) : 0u;
+            const uint32_t q1 = 2u * (b1 & 15u) + (b1 >> 4);
+            const uint32_t ncand = rab == 0u ? 0u : (rab2 == 0u ? 1u : 2u);  // 2 stands for "two or more"
+            uint32_t b2 = 0, q2 = 0;
+            bool two = false, swap12 = false;
+            if (__any((int)(rab2 != 0u))) {                                 // rare (a run crossing a quad boundary)
+                b2 = rab2 ? (uint32_t)__builtin_ctz(rab2) : 0u;
+                q2 = 2u * (b2 & 15u) + (b2 >> 4);
+                two = rab2 != 0u && (rab2 & (rab2 - 1u)) == 0u && (q1 + 1u == q2 || q2 + 1u == q1);
+                swap12 = two && q2 < q1;
+                defer = defer || (rab2 != 0u && !two);
+            }
             const uint32_t blo = swap12 ? b2 : b1, bhi = swap12 ? b1 : b2;
-            defer = defer || ncand > 2u || (ncand == 2u && !two);
 
             // -- level 2: lanes 0..3 of the row decode the candidate quad(s)
             const uint32_t packab = pa | (ca << 10) | (cb << 18) | (la << 26);

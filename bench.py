@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the fpindex /_search hot path on MI355X.
 
-One step = one pass of the hot path over one batch of synthetic queries (default: 1024 queries x 1000 hashes)
+One step = one pass of the hot path over one batch of synthetic queries (default: 8192 queries x 1000 hashes -- the
+batch size BASELINE.json names for its largest config; `--batch 1024` is configs[1]'s batch)
 against a seeded synthetic index resident in HBM (default: BASELINE.json configs[2], 100 M fingerprints x 256
 hashes in 16 FileSegments).  With --gpus N > 1 the SAME index is sharded by segment over the ranks
 (segment s lives on rank s % N), every rank probes its own segments for the whole batch, the per-rank top-k
@@ -32,7 +33,7 @@ def parse_args():
     ap.add_argument("--docs", type=int, default=int(os.environ.get("FPX_BENCH_DOCS", 100_000_000)))
     ap.add_argument("--segments", type=int, default=int(os.environ.get("FPX_BENCH_SEGMENTS", 16)))
     ap.add_argument("--hashes", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("FPX_BENCH_BATCH", 1024)))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FPX_BENCH_BATCH", 8192)))
     ap.add_argument("--query-len", type=int, default=1000)
     ap.add_argument("--limit", type=int, default=40)
     ap.add_argument("--seed", type=int, default=20260928)

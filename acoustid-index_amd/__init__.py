@@ -9,3 +9,4 @@ from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegm
                     merge_partials, results_to_lists)
 from . import synth  # noqa: F401
 from . import sharding  # noqa: F401
+from . import segfile  # noqa: F401

@@ -69,6 +69,7 @@ SIGNATURES = {
     "fpx_search_resident_partial": (C.c_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_merge_partials": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "fpx_synth_segment": (C.c_int, [_vp, _u64, _u32, _u32, _u32, C.c_int, _u32, _u64, C.POINTER(_vp)]),
+    "fpx_crc64_xz": (_u64, [_u64, _vp, _sz]),
     "fpx_measure_bandwidth": (C.c_int, [_vp, _sz, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

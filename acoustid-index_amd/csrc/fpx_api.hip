@@ -503,6 +503,34 @@ int fpx_synth_segment(fpx_ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t 
     return rc;
 }
 
+// CRC-64/XZ (ECMA-182 polynomial, reflected, init/xorout all ones), slicing-by-8
+uint64_t fpx_crc64_xz(uint64_t crc, const uint8_t* data, size_t len)
+{
+    static uint64_t T[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (int i = 0; i < 256; ++i) {
+            uint64_t c = (uint64_t)i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0xC96C5795D7870F42ull : c >> 1;
+            T[0][i] = c;
+        }
+        for (int i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    uint64_t c = ~crc;
+    while (len >= 8) {
+        uint64_t w;
+        std::memcpy(&w, data, 8);
+        c ^= w;
+        c = T[7][c & 0xFF] ^ T[6][(c >> 8) & 0xFF] ^ T[5][(c >> 16) & 0xFF] ^ T[4][(c >> 24) & 0xFF] ^
+            T[3][(c >> 32) & 0xFF] ^ T[2][(c >> 40) & 0xFF] ^ T[1][(c >> 48) & 0xFF] ^ T[0][c >> 56];
+        data += 8; len -= 8;
+    }
+    while (len--) c = T[0][(c ^ *data++) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+
 int fpx_measure_bandwidth(fpx_ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs)
 {
     if (!ctx) { set_error("null ctx"); return FPX_E_INVAL; }

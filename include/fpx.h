@@ -187,6 +187,10 @@ int fpx_synth_segment(fpx_ctx *ctx, uint64_t seed, uint32_t first_doc, uint32_t 
                       uint32_t hashes_per_doc, int dist, uint32_t block_size, uint64_t commit_id,
                       fpx_segment **out);
 
+/* CRC-64/XZ over `len` bytes continuing from `crc` (start with 0): the checksum the reference stores in the
+ * segment file footer over the data blocks (std.hash.crc.Crc64Xz, src/filefmt.zig:101,119,261-284).  Host code. */
+uint64_t fpx_crc64_xz(uint64_t crc, const uint8_t *data, size_t len);
+
 /* HBM streaming-read and random-block-read bandwidth of this device (GB/s), measured by trivial
  * kernels: the second denominator SURVEY 8(d) asks for next to the 8 TB/s spec peak. */
 int fpx_measure_bandwidth(fpx_ctx *ctx, size_t bytes, uint32_t block_size, double *stream_gbs, double *random_gbs);

@@ -1,0 +1,112 @@
+"""C-ABI behaviour on the GPU: error codes, ownership/lifetime, re-entrancy, resident batches, timeout."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fpx_testlib import fpx, oracle, Pair
+    ctx = fpx.Context(0)
+    seed, ndocs, H = 13, 30000, 64
+    p = Pair(ctx)
+    p.add_file(fpx.synth.synth_items(seed, 1, ndocs, H), 1, ndocs, 1, np.arange(1, ndocs + 1))
+    p.add_memory_changes([("insert", 5, [1, 2, 3])], 2)
+    p.finish()
+    flat, off, targets = fpx.synth.make_queries(seed, 3, 96, ndocs, H, query_len=300)
+    qs = [flat[int(off[i]):int(off[i + 1])] for i in range(96)]
+    return fpx, oracle, ctx, p, qs, (flat, off), targets
+
+
+def test_invalid_arguments_are_rejected(env):
+    fpx, oracle, ctx, p, qs, flat, targets = env
+    with pytest.raises(fpx.FpxError) as e:
+        p.reader.search_batch(qs[:2], fpx.SearchOptions(10, 1, 101))          # score_pct > 100
+    assert e.value.status == -4
+    # snapshot order: commit ids must ascend, file segments before memory segments (src/Index.zig:36-41)
+    a = fpx.MemorySegment(ctx, np.array([(7 << 32) | 1], np.uint64), 1, 1, 5, [1])
+    b = fpx.MemorySegment(ctx, np.array([(7 << 32) | 2], np.uint64), 2, 2, 4, [2])
+    with pytest.raises(fpx.FpxError):
+        fpx.Segments(ctx, [a, b])
+    with pytest.raises(fpx.FpxError):
+        fpx.Segments(ctx, [a, p.gpu_segs[0]])
+    with pytest.raises(fpx.FpxError):                                          # items must be sorted
+        fpx.MemorySegment(ctx, np.array([(9 << 32) | 1, (7 << 32) | 1], np.uint64), 1, 1, 9, [1])
+    with pytest.raises(fpx.FpxError):                                          # block_size outside [64, 4096]
+        fpx.FileSegment(ctx, np.zeros(64, np.uint8), 32, np.zeros(0, np.uint32), 1, 1, 1, [1])
+
+
+def test_segments_outlive_their_python_handles(env):
+    """A snapshot retains its segments (SharedPtr semantics, src/shared_ptr.zig): releasing the caller's
+    references must not free HBM that an in-flight reader still uses."""
+    fpx, oracle, ctx, p, qs, flat, targets = env
+    items = fpx.synth.synth_items(99, 1, 2000, 32)
+    blocks, index = oracle.build_blocks(items, 1, 512)
+    seg = fpx.FileSegment(ctx, blocks, 512, index, 1, 2000, 1, np.arange(1, 2001))
+    reader = fpx.IndexReader(fpx.Segments(ctx, [seg]))
+    seg.release()
+    del seg
+    q = fpx.synth.synth_hashes(99, [77], 32)[0]
+    r = fpx.SearchResults(fpx.SearchOptions(5, 1, 10))
+    assert reader.search(q, r)[0] == (77, 32)
+
+
+def test_concurrent_searches_from_many_threads(env):
+    """The reference runs one search per executor thread on a shared immutable snapshot (src/main.zig:272-276);
+    fpx_search* is re-entrant: every call takes its own pooled workspace + stream."""
+    fpx, oracle, ctx, p, qs, flat, targets = env
+    want = [p.osnap.search(q) for q in qs]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                if tid % 2:
+                    got, _ = p.reader.search_batch(qs, fpx.http_options())
+                    assert got == want
+                else:
+                    for i in range(tid, len(qs), 8):
+                        r = fpx.SearchResults(fpx.http_options())
+                        assert p.reader.search(qs[i], r) == want[i]
+        except Exception as ex:          # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_resident_batch_equals_host_batch(env):
+    fpx, oracle, ctx, p, qs, flat, targets = env
+    opts = [fpx.http_options(limit=1 + (i % 50)) for i in range(len(qs))]
+    qb = fpx.QueryBatch(ctx, options=opts, flat=flat)
+    out, out_n, st = fpx.search_resident(p.reader, qb)
+    got = fpx.results_to_lists(out, out_n)
+    host, _ = p.reader.search_batch(qs, opts)
+    assert got == host
+    assert all(g[0][0] == int(t) for g, t in zip(got, targets))
+    # per-query limits are honoured inside one batch
+    assert all(len(g) <= o.max_results for g, o in zip(got, opts))
+
+
+def test_timeout_reports_search_timeout_and_no_results(env):
+    """error.SearchTimeout (src/MultiIndex.zig:319-322): a search that overruns its deadline returns no partial
+    results.  A 1 ms deadline cannot be met by a cold 2^20-probe batch."""
+    fpx, oracle, ctx, p, qs, flat, targets = env
+    big = qs * 12
+    try:
+        res, _ = p.reader.search_batch(big, fpx.http_options(), timeout_ms=1)
+    except fpx.SearchTimeout as e:
+        assert e.status == -2
+    else:
+        # fast enough to beat 1 ms: then the results must be complete and correct
+        assert res[0] == p.osnap.search(big[0])
+    # timeout 0 = unbounded (src/MultiIndex.zig:286,315)
+    res, _ = p.reader.search_batch(qs[:4], fpx.http_options(), timeout_ms=0)
+    assert res[0] == p.osnap.search(qs[0])

@@ -1022,56 +1022,100 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     return x;
 }
 
-// One workgroup per query.  Open-addressing table of (doc << 32 | count) slots in LDS, built with 64-bit LDS
-// atomics -- the GPU form of the reference's per-search hit map (src/common.zig:83-129).  A query with more hits
-// than the table holds is processed in several passes over disjoint doc classes (mix32(doc) % passes).
+// One workgroup per query, two stages in LDS:
+//   A. counting filter: filter[mix(doc) & (F-1)] += 1 for every record -- one LDS atomic per record, no probing.
+//      A doc can only reach min_score if its filter cell did, so for the usual floor (min_score = n/20) almost
+//      every noise record (a doc hit once or twice) is discarded here.
+//   B. exact count of the surviving records in an open-addressing table of (doc << 32 | count) slots built with
+//      64-bit LDS atomics -- the GPU form of the reference's per-search hit map (src/common.zig:83-129).  If more
+//      records survive than the table holds they are counted in passes over disjoint doc classes.
 // Candidate key = q << (32 + sb) | (smax - score) << 32 | doc   (ascending = score desc, doc asc within a query).
+constexpr uint32_t SCORE_TABLE_LOG2 = 11;       // exact table: 2048 slots = 16 KB
+
 __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ qrange,
-                                               const uint32_t* __restrict__ opts, uint32_t log2t, uint32_t sb,
+                                               const uint32_t* __restrict__ opts, uint32_t log2f, uint32_t sb,
                                                uint64_t* cands, uint64_t cand_cap, unsigned long long* counters)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);                 // 2^SCORE_TABLE_LOG2 slots
+    unsigned int* filter = reinterpret_cast<unsigned int*>(smem + (8u << SCORE_TABLE_LOG2)); // 2^log2f cells
+    __shared__ uint32_t survivors;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint64_t lo = qrange[2ull * q], hi = qrange[2ull * q + 1];
     if (hi <= lo) return;
     const uint64_t n = hi - lo;
-    const uint32_t T = 1u << log2t, mask = T - 1u;
     const uint32_t min_score = opts[q * 4u + 1u];
     if (n < (uint64_t)min_score) return;                          // no doc can reach the floor
-    const uint64_t fill = (uint64_t)T * 7u / 8u;
-    const uint32_t passes = (uint32_t)((n + fill - 1) / fill);
+    const uint32_t F = 1u << log2f, fmask = F - 1u;
+    const uint32_t T = 1u << SCORE_TABLE_LOG2, tmask = T - 1u;
     const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
+
+    // The records are read in tiles of WG * RPT: every thread first issues all its loads (RPT of them in flight), then
+    // works on registers.  A query that fits one tile (the normal case) is read from memory exactly once.
+    constexpr int RPT = 32;
+    constexpr uint64_t TILE = (uint64_t)WG * RPT;
+    uint32_t rec[RPT];
+    const bool one_tile = n <= TILE;
+    auto load_tile = [&](uint64_t t0) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const uint64_t i = t0 + (uint64_t)u * WG + tid;
+            rec[u] = i < n ? (uint32_t)hits[lo + i] : 0u;
+        }
+    };
+
+    // ---- stage A
+    for (uint32_t s = tid; s < F; s += WG) filter[s] = 0u;
+    if (tid == 0) survivors = 0u;
+    __syncthreads();
+    for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
+        load_tile(t0);
+#pragma unroll
+        for (int u = 0; u < RPT; ++u)
+            if (t0 + (uint64_t)u * WG + tid < n) atomicAdd(&filter[mix32(rec[u]) & fmask], 1u);
+    }
+    __syncthreads();
+    {
+        uint32_t mine = 0;
+        for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
+            if (!one_tile) load_tile(t0);
+#pragma unroll
+            for (int u = 0; u < RPT; ++u)
+                if (t0 + (uint64_t)u * WG + tid < n) mine += filter[mix32(rec[u]) & fmask] >= min_score ? 1u : 0u;
+        }
+        if (mine) atomicAdd(&survivors, mine);
+    }
+    __syncthreads();
+    const uint32_t nsurv = survivors;
+    if (nsurv < min_score) return;
+    const uint32_t fill = T * 3u / 4u;
+    const uint32_t passes = (nsurv + fill - 1u) / fill;
+
+    // ---- stage B
     for (uint32_t pass = 0; pass < passes; ++pass) {
         for (uint32_t s = tid; s < T; s += WG) table[s] = 0ull;
         __syncthreads();
-        constexpr int LB = 8;                                     // records loaded per thread before inserting them
-        for (uint64_t i0 = 0; i0 < n; i0 += (uint64_t)WG * LB) {
-            uint32_t dbuf[LB];
+        for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
+            if (!one_tile) load_tile(t0);
 #pragma unroll
-            for (int u = 0; u < LB; ++u) {
-                const uint64_t i = i0 + (uint64_t)u * WG + tid;
-                dbuf[u] = i < n ? (uint32_t)hits[lo + i] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < LB; ++u) {
-            const uint64_t i = i0 + (uint64_t)u * WG + tid;
-            if (i >= n) continue;
-            const uint32_t d = dbuf[u];
-            const uint32_t hsh = mix32(d);
-            if (passes > 1u && (hsh % passes) != pass) continue;
-            uint32_t s = (hsh >> 7) & mask;
-            for (;;) {
-                unsigned long long cur = table[s];
-                if ((uint32_t)cur == 0u) {                                     // empty: try to claim it with count 1
-                    const unsigned long long want = ((unsigned long long)d << 32) | 1ull;
-                    const unsigned long long prev = atomicCAS(&table[s], 0ull, want);
-                    if (prev == 0ull) break;
-                    cur = prev;
+            for (int u = 0; u < RPT; ++u) {
+                if (t0 + (uint64_t)u * WG + tid >= n) continue;
+                const uint32_t d = rec[u];
+                const uint32_t hsh = mix32(d);
+                if (filter[hsh & fmask] < min_score) continue;
+                if (passes > 1u && ((hsh >> 16) % passes) != pass) continue;
+                uint32_t s = (hsh >> 9) & tmask;
+                for (;;) {
+                    unsigned long long cur = table[s];
+                    if ((uint32_t)cur == 0u) {                                     // empty: try to claim it with count 1
+                        const unsigned long long want = ((unsigned long long)d << 32) | 1ull;
+                        const unsigned long long prev = atomicCAS(&table[s], 0ull, want);
+                        if (prev == 0ull) break;
+                        cur = prev;
+                    }
+                    if ((uint32_t)(cur >> 32) == d) { atomicAdd(&table[s], 1ull); break; }
+                    s = (s + 1u) & tmask;
                 }
-                if ((uint32_t)(cur >> 32) == d) { atomicAdd(&table[s], 1ull); break; }
-                s = (s + 1u) & mask;
-            }
             }
         }
         __syncthreads();
@@ -1470,9 +1514,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         FPX_HIP(hipMemsetAsync(ws->d_qrange, 0, (size_t)B * 2 * sizeof(uint64_t), st));
         hipLaunchKernelGGL(k_bounds, dim3((uint32_t)((H + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)ws->d_hits[0], H, ws->d_qrange);
-        // table sized for ~1.3x the average number of hits per query (a fuller query takes a second pass), 16 .. 128 KB of LDS
-        uint32_t log2t = 11;
-        while (log2t < 14 && (1ull << log2t) * 3 < 4 * (H / B + 1)) ++log2t;
+        // counting filter sized for ~2x the average number of records per query (8 KB .. 64 KB of LDS) + 16 KB exact table
+        uint32_t log2f = 11;
+        while (log2f < 14 && (1ull << log2f) < 2 * (H / B + 1)) ++log2f;
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
         static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),
@@ -1481,8 +1525,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         for (int attempt = 0;; ++attempt) {
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_score, dim3(B), dim3(WG), (size_t)8 << log2t, st, (const uint64_t*)ws->d_hits[0],
-                               (const uint64_t*)ws->d_qrange, d_opts, log2t, sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
+            hipLaunchKernelGGL(k_score, dim3(B), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
+                               (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f, sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
             FPX_HIP(hipGetLastError());
             FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipStreamSynchronize(st));

@@ -282,6 +282,74 @@ __device__ __forceinline__ uint32_t decode_one(const DecodeLut* lut, const uint8
     return __builtin_amdgcn_perm(raw, raw, sel);
 }
 
+// ---- hit staging shared by the probe kernels ------------------------------------------------------
+// Hits are collected in an LDS buffer per workgroup and appended to the global record buffer with ONE global
+// atomic per flush (same-address global atomics serialise: one per wave costs milliseconds per batch).
+// A wave reserves `total` slots with one LDS atomic; if the buffer is full it appends directly and marks where
+// the valid prefix of the buffer ends.
+struct HitStage {
+    uint64_t* buf;               // STAGE_CAP records of LDS
+    uint32_t* count;             // reserved slots (may run past STAGE_CAP)
+    uint32_t* valid;             // end of the valid prefix once a reservation did not fit
+    uint32_t* base_lo;           // flush broadcast
+    uint32_t* base_hi;
+};
+
+// wave-uniform control flow: lanes with `keep` append `rec`
+__device__ __forceinline__ void stage_emit(const HitStage& st, const ProbeArgs& a, bool keep, uint64_t rec, uint32_t lane)
+{
+    const unsigned long long m = __ballot((int)keep);
+    if (m == 0ull) return;
+    const uint32_t total = __popcll(m);
+    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+    uint32_t pos = 0;
+    if (lane == 0) pos = atomicAdd(st.count, total);
+    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+    if (pos + total <= (uint32_t)STAGE_CAP) {
+        if (keep) st.buf[pos + rank] = rec;
+    } else {
+        if (lane == 0) atomicMin(st.valid, pos);
+        unsigned long long gg = 0;
+        if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+        gg = __shfl(gg, 0);
+        if (keep && gg + rank < a.hit_cap) a.hits[gg + rank] = rec;
+    }
+}
+
+// single lane, any control flow (rare paths)
+__device__ __forceinline__ void stage_emit_one(const HitStage& st, const ProbeArgs& a, uint64_t rec)
+{
+    const uint32_t pos = atomicAdd(st.count, 1u);
+    if (pos < (uint32_t)STAGE_CAP) {
+        st.buf[pos] = rec;
+    } else {
+        atomicMin(st.valid, pos);
+        const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
+        if (gg < a.hit_cap) a.hits[gg] = rec;
+    }
+}
+
+// whole workgroup, at a round boundary: flush when half full or at the end
+__device__ __forceinline__ void stage_flush(const HitStage& st, const ProbeArgs& a, bool last, uint32_t tid, uint32_t nthreads)
+{
+    __syncthreads();
+    const uint32_t sc = *st.count;
+    if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
+        const uint32_t n = min(sc, *st.valid);
+        if (tid == 0) {
+            const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
+            *st.base_lo = (uint32_t)gg; *st.base_hi = (uint32_t)(gg >> 32);
+        }
+        __syncthreads();
+        const unsigned long long gg = ((unsigned long long)*st.base_hi << 32) | *st.base_lo;
+        for (uint32_t i = tid; i < n; i += nthreads)
+            if (gg + i < a.hit_cap) a.hits[gg + i] = st.buf[i];
+        __syncthreads();
+        if (tid == 0) { *st.count = 0; *st.valid = STAGE_CAP; }
+    }
+    __syncthreads();
+}
+
 // ---- the probe kernel ---------------------------------------------------------------------------
 // One wave works on FOUR probes at a time, one per 16-lane row; lane r of a row owns quads 2r and 2r+1
 // of every 32-quad chunk of the block (a 512-B block holds ~29 quads).  Blocks are prefetched one
@@ -300,6 +368,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut);   // PWAVES * 4 * bsp bytes
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 4, gl = lane & 15u;
     const SegDesc seg = a.segs[blockIdx.y];
@@ -563,17 +632,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                             if (more_chunks && kf != 0u) {
 #pragma unroll
                                 for (int k = 0; k < 8; ++k) {
-                                    if ((kf >> k) & 1u) {
-                                        const uint64_t rec = ((uint64_t)pq << 32) | dd[k];
-                                        const uint32_t pos = atomicAdd(&stage_count, 1u);
-                                        if (pos < (uint32_t)STAGE_CAP) {
-                                            stage[pos] = rec;
-                                        } else {
-                                            atomicMin(&stage_valid, pos);
-                                            unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
-                                            if (gg < a.hit_cap) a.hits[gg] = rec;
-                                        }
-                                    }
+                                    if ((kf >> k) & 1u) stage_emit_one(hs, a, ((uint64_t)pq << 32) | dd[k]);
                                 }
                                 kf = 0;
                             }
@@ -598,46 +657,14 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                 if (__any((int)(kf != 0u))) {
                     const int kmax = __any((int)((kf & ~1u) != 0u)) ? 8 : 1;    // the fast path only ever sets bit 0
                     for (int k = 0; k < kmax; ++k) {
-                        const unsigned long long m = __ballot((int)((kf >> k) & 1u));
-                        if (m == 0ull) continue;
-                        const uint32_t total = __popcll(m);
-                        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-                        uint32_t pos = 0;
-                        if (lane == 0) pos = atomicAdd(&stage_count, total);
-                        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                        if (pos + total <= (uint32_t)STAGE_CAP) {
-                            if ((kf >> k) & 1u) stage[pos + rank] = ((uint64_t)pq << 32) | dd_at(dd, k);
-                        } else {
-                            // staging full: remember where the valid prefix ends and append directly
-                            if (lane == 0) atomicMin(&stage_valid, pos);
-                            unsigned long long gg = 0;
-                            if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
-                            gg = __shfl(gg, 0);
-                            if (((kf >> k) & 1u) && gg + rank < a.hit_cap) a.hits[gg + rank] = ((uint64_t)pq << 32) | dd_at(dd, k);
-                        }
+                        stage_emit(hs, a, ((kf >> k) & 1u) != 0u, ((uint64_t)pq << 32) | dd_at(dd, k), lane);
                     }
                 }
             }
         }
 
         // ---- flush the LDS staging buffer at round boundaries
-        __syncthreads();
-        const uint32_t sc = stage_count;
-        const bool last = (round + 1u == nrounds);
-        if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
-            const uint32_t n = min(sc, stage_valid);
-            if (tid == 0) {
-                unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
-                flush_base_lo = (uint32_t)gg; flush_base_hi = (uint32_t)(gg >> 32);
-            }
-            __syncthreads();
-            const unsigned long long gg = ((unsigned long long)flush_base_hi << 32) | flush_base_lo;
-            for (uint32_t i = tid; i < n; i += PWG)
-                if (gg + i < a.hit_cap) a.hits[gg + i] = stage[i];
-            __syncthreads();
-            if (tid == 0) { stage_count = 0; stage_valid = STAGE_CAP; }
-        }
-        __syncthreads();
+        stage_flush(hs, a, round + 1u == nrounds, tid, PWG);
     }
 
     // ---- per-workgroup statistics (fpindex_scanned_blocks_per_hash / _docs_per_hash totals)
@@ -670,6 +697,7 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
     __shared__ uint32_t def_stage[DEF_STAGE_CAP];
     __shared__ uint32_t def_n, def_base;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
 
     constexpr uint32_t SLOT = 544u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 4, gl = lane & 15u;
@@ -905,45 +933,12 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             // -- emission (wave-uniform control flow)
             const int nsets = me1 != 0ull ? 2 : 1;
             for (int e = 0; e < nsets; ++e) {
-                const bool keep = e ? keep1 : keep0;
-                const unsigned long long m = __ballot((int)keep);
-                if (m == 0ull) continue;
-                const uint32_t total = __popcll(m);
-                const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-                uint32_t pos = 0;
-                if (lane == 0) pos = atomicAdd(&stage_count, total);
-                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                const uint64_t rec = ((uint64_t)pq << 32) | (e ? doc1 : doc0);
-                if (pos + total <= (uint32_t)STAGE_CAP) {
-                    if (keep) stage[pos + rank] = rec;
-                } else {
-                    if (lane == 0) atomicMin(&stage_valid, pos);
-                    unsigned long long gg = 0;
-                    if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
-                    gg = __shfl(gg, 0);
-                    if (keep && gg + rank < a.hit_cap) a.hits[gg + rank] = rec;
-                }
+                stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane);
             }
         }
 
         // ---- flush the LDS staging buffer at round boundaries
-        __syncthreads();
-        const uint32_t sc = stage_count;
-        const bool last = (round + 1u == a.rounds);
-        if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
-            const uint32_t n = min(sc, stage_valid);
-            if (tid == 0) {
-                unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
-                flush_base_lo = (uint32_t)gg; flush_base_hi = (uint32_t)(gg >> 32);
-            }
-            __syncthreads();
-            const unsigned long long gg = ((unsigned long long)flush_base_hi << 32) | flush_base_lo;
-            for (uint32_t i = tid; i < n; i += PWG)
-                if (gg + i < a.hit_cap) a.hits[gg + i] = stage[i];
-            __syncthreads();
-            if (tid == 0) { stage_count = 0; stage_valid = STAGE_CAP; }
-        }
-        __syncthreads();
+        stage_flush(hs, a, round + 1u == a.rounds, tid, PWG);
         // ---- flush the deferred-probe staging (one global atomic per round)
         {
             const uint32_t dn = min(def_n, (uint32_t)DEF_STAGE_CAP);

@@ -240,3 +240,38 @@ def test_score_table_multi_pass_and_many_candidates(env):
     opts = [fpx.SearchOptions(500, 1, 0)] + [fpx.SearchOptions(5, 1, 10)] * len(light)
     got, st = p.check([heavy] + light, opts)
     assert len(got[0]) == 500 and st.hits > 20000 and st.candidates > 10000
+
+
+@pytest.mark.parametrize("name,ndocs,H,S,batch,qlen,limit", [
+    ("configs[1] / 1000: one segment, batch 1024", 10000, 256, 1, 1024, 1000, 40),
+    ("configs[2] / 1000: 16 segments", 100000, 256, 16, 256, 1000, 40),
+    ("configs[4] / 1000: 120 hashes, limit 100", 128000, 120, 8, 512, 1000, 100),
+])
+def test_baseline_config_mini_twins(env, name, ndocs, H, S, batch, qlen, limit):
+    """The /1000 twins of the BASELINE configs: same code paths, sizes the oracle finishes in seconds."""
+    fpx, oracle, Pair, ctx = env
+    seed, per = 20260928, ndocs // S
+    p = Pair(ctx)
+    for s in range(S):
+        lo = s * per + 1
+        g = fpx.FileSegment.synth(ctx, seed, lo, per, H, 0, 512, s + 1)           # built on the GPU ...
+        blocks, index = g.download()
+        p.gpu_segs.append(g)
+        p.orc_file.append(oracle.file_segment(blocks, 512, index, lo, lo + per - 1, s + 1, np.arange(lo, lo + per)))
+    p.finish()
+    flat, off, targets = fpx.synth.make_queries(seed, 4242, batch, per * S, H, query_len=qlen)
+    qs = [flat[int(off[i]):int(off[i + 1])] for i in range(batch)]
+    got, st = p.check(qs, fpx.http_options(limit=limit))
+    assert all(g and g[0][0] == int(t) for g, t in zip(got, targets))
+    assert st.probes >= batch * 900 * S
+
+
+def test_cpp_request_coalescer(env):
+    """acoustid-index_amd/host/fpx_coalescer.hpp: 64 threads of single searches served as device batches."""
+    import os
+    import subprocess
+    from fpx_testlib import ROOT
+    host = os.path.join(ROOT, "acoustid-index_amd", "host")
+    subprocess.check_call(["bash", os.path.join(host, "build_host.sh")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(host, "test_coalescer")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr

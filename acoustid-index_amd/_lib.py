@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfpx.so")
+LIB_PATH = os.environ.get("FPX_LIB", os.path.join(_HERE, "libfpx.so"))      # FPX_LIB: A/B a second build
 
 FPX_OK, FPX_E_NOMEM, FPX_E_TIMEOUT, FPX_E_DEVICE, FPX_E_INVAL, FPX_E_NODEVICE = 0, -1, -2, -3, -4, -5
 

@@ -810,8 +810,8 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             const uint32_t n_items = hw[1] & 0xFFFFu;
             const uint32_t doff = min(hw[1] >> 16, 504u);
             const uint32_t nq = (n_items + 3u) >> 2;
-            const bool visited = pact && min_hash <= ph;                       // src/FileSegment.zig:164
-            bool defer = nq > 32u || (n_items & 3u) != 0u;                     // multi-chunk block / partial last quad
+            const bool visited = pact & (min_hash <= ph);                      // src/FileSegment.zig:164
+            bool defer = (nq > 32u) | ((n_items & 3u) != 0u);                  // multi-chunk block / partial last quad
 
             // -- level 1: quad sums (see k_probe for the scheme)
             uint32_t cc = *reinterpret_cast<const uint16_t*>(blk + 8u + qa);
@@ -835,11 +835,12 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             const uint32_t vincl = scan16(sa + sb);
             const uint32_t ua = ph - min_hash - (vincl - sa - sb);
             const uint32_t ub = ua - sa;
-            const bool canda = qa < nq && (ua - 1u < sa || (ua == 0u && (ca & 3u) == 0u));
-            const bool candb = qa + 1u < nq && (ub - 1u < sb || (ub == 0u && (cb & 3u) == 0u));
+            // (bitwise, not short-circuit: the conditions are cheap and branches cost exec-mask traffic)
+            const bool canda = (qa < nq) & ((ua - 1u < sa) | ((ua == 0u) & ((ca & 3u) == 0u)));
+            const bool candb = (qa + 1u < nq) & ((ub - 1u < sb) | ((ub == 0u) & ((cb & 3u) == 0u)));
             const uint32_t rab = row_bits(__ballot((int)canda), g) | (row_bits(__ballot((int)candb), g) << 16);
             // a 4-byte delta (code 3) anywhere in the block: the generic pass decides
-            defer = defer || row_bits(__ballot((int)((cc & (cc >> 1) & 0x5555u) != 0u)), g) != 0u;
+            defer = defer | (row_bits(__ballot((int)((cc & (cc >> 1) & 0x5555u) != 0u)), g) != 0u);
             // One candidate quad is the rule.  Two ADJACENT candidates mean a run of equal hashes crosses a quad
             // boundary: the upper one then starts exactly at the target (relative target 0) and holds the run's
             // zero-delta tail.  Anything else (three candidates = a run longer than a quad, ...) is deferred.
@@ -866,8 +867,8 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
             const bool useb0 = (blo >> 4) != 0u;
             const uint32_t val0 = decode_one<0>(lut, smem, blko + (x0 & 1023u) + (useb0 ? (x0 >> 26) : 0u),
                                                 useb0 ? ((x0 >> 18) & 0xFFu) : ((x0 >> 10) & 0xFFu), k);
-            const bool live = visited && !defer && gl < 4u;
-            const bool ek0 = live && ncand != 0u && scan4(val0) == ut0;
+            const bool live = visited & !defer & (gl < 4u);
+            const bool ek0 = live & (ncand != 0u) & (scan4(val0) == ut0);
             bool ek1 = false;
             const int owner1 = (int)((lane & 48u) | (bhi & 15u));
             if (__any((int)(two && live))) {

@@ -1376,9 +1376,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     int kcur = 0;
     if (P) {
         hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, base, ws->d_keys[0]);
-        const size_t tb = sort_u64_temp_bytes(P, 0, 32 + qb);
+        // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
+        // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
+        const size_t tb = sort_u64_temp_bytes(P, qb, 32 + qb);
         if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
-        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, 0, 32 + qb, st, &kcur));
+        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb, 32 + qb, st, &kcur));
     }
     const uint64_t* d_pairs = ws->d_keys[kcur];
 
@@ -1437,7 +1439,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 ProbeArgs d = a;
                 d.segs = snap->d_lean; d.ppw = 16u; d.rounds = 1u;
                 const uint64_t per_wg_d = (uint64_t)PWAVES * d.ppw;
-                const uint32_t gxd = (uint32_t)std::min<uint64_t>((def_cap + per_wg_d - 1) / per_wg_d, 64);
+                // persistent workgroups striding over the device-side list: about 1024 of them over all segments
+                const uint64_t gxd_cap = std::max<uint64_t>(64, (1024 + snap->n_lean - 1) / snap->n_lean);
+                const uint32_t gxd = (uint32_t)std::min<uint64_t>((def_cap + per_wg_d - 1) / per_wg_d, gxd_cap);
                 hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
                 if (snap->n_gen) {
                     ProbeArgs ge = a;

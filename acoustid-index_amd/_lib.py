@@ -69,6 +69,13 @@ SIGNATURES = {
     "fpx_search_resident_partial": (C.c_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_merge_partials": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "fpx_synth_segment": (C.c_int, [_vp, _u64, _u32, _u32, _u32, C.c_int, _u32, _u64, C.POINTER(_vp)]),
+    "fpx_segment_build": (C.c_int, [_vp, _vp, _sz, C.c_int, _u32, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
+    "fpx_segment_merge": (C.c_int, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
+    "fpx_segment_commit_id": (_u64, [_vp]),
+    "fpx_segment_min_doc_id": (_u32, [_vp]),
+    "fpx_segment_max_doc_id": (_u32, [_vp]),
+    "fpx_segment_num_docs": (_u32, [_vp]),
+    "fpx_segment_docs": (C.c_int, [_vp, _vp, _vp, _u32]),
     "fpx_crc64_xz": (_u64, [_u64, _vp, _sz]),
     "fpx_measure_bandwidth": (C.c_int, [_vp, _sz, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -77,11 +77,19 @@ void ws_destroy(Workspace* w)
 }
 
 // ---------------------------------------------------------------- segments
-static void set_docs(Segment* s, const uint32_t* ids, uint32_t n)
+static void set_docs(Segment* s, const uint32_t* ids, const uint8_t* alive, uint32_t n)
 {
-    s->doc_ids.assign(ids, ids + n);
-    if (!std::is_sorted(s->doc_ids.begin(), s->doc_ids.end())) std::sort(s->doc_ids.begin(), s->doc_ids.end());
-    s->doc_ids.erase(std::unique(s->doc_ids.begin(), s->doc_ids.end()), s->doc_ids.end());
+    // sorted by id; of several entries for one id the last one given wins (a map put)
+    std::vector<uint64_t> v(n);
+    for (uint32_t i = 0; i < n; ++i) v[i] = ((uint64_t)ids[i] << 32) | ((uint64_t)i << 1) | (alive ? (alive[i] ? 1u : 0u) : 1u);
+    std::sort(v.begin(), v.end());
+    s->doc_ids.clear(); s->doc_alive.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t id = (uint32_t)(v[i] >> 32);
+        if (i + 1 < n && (uint32_t)(v[i + 1] >> 32) == id) continue;
+        s->doc_ids.push_back(id);
+        s->doc_alive.push_back((uint8_t)(v[i] & 1u));
+    }
 }
 
 static void segment_free(Segment* s)
@@ -191,7 +199,6 @@ int fpx_segment_create_file(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_
                             const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs,
                             fpx_segment** out)
 {
-    (void)doc_alive;   // a tombstone supersedes older segments exactly like a live doc (src/Index.zig:133-149)
     Ctx* c = reinterpret_cast<Ctx*>(ctx_);
     if (!c || !out || (!blocks && blocks_len) || (!block_index && num_blocks) || (!doc_ids && num_docs)) {
         set_error("null argument"); return FPX_E_INVAL;
@@ -204,7 +211,7 @@ int fpx_segment_create_file(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_
     if (!s) return FPX_E_NOMEM;
     s->ctx = c; s->kind = 0; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
     s->block_size = block_size; s->num_blocks = num_blocks;
-    set_docs(s, doc_ids, num_docs);
+    set_docs(s, doc_ids, doc_alive, num_docs);
     // resident copy: real blocks + one zero terminator block + 16 B (the over-read slack of
     // src/streamvbyte.zig:5 / src/FileSegment.zig:87 made explicit)
     s->blocks_len = ((size_t)num_blocks + 1) * block_size;
@@ -230,7 +237,6 @@ int fpx_segment_create_memory(fpx_ctx* ctx_, const uint64_t* items, size_t num_i
                               uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
                               const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs, fpx_segment** out)
 {
-    (void)doc_alive;
     Ctx* c = reinterpret_cast<Ctx*>(ctx_);
     if (!c || !out || (!items && num_items) || (!doc_ids && num_docs)) { set_error("null argument"); return FPX_E_INVAL; }
     *out = nullptr;
@@ -241,7 +247,7 @@ int fpx_segment_create_memory(fpx_ctx* ctx_, const uint64_t* items, size_t num_i
     if (!s) return FPX_E_NOMEM;
     s->ctx = c; s->kind = 1; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
     s->num_items = num_items;
-    set_docs(s, doc_ids, num_docs);
+    set_docs(s, doc_ids, doc_alive, num_docs);
     hipError_t e = hipMalloc(&s->d_items, (num_items + 1) * sizeof(uint64_t));
     if (e == hipSuccess && num_items) e = hipMemcpy(s->d_items, items, num_items * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) { segment_free(s); return hip_fail(e, "memory segment upload"); }
@@ -253,13 +259,12 @@ int fpx_segment_create_memory(fpx_ctx* ctx_, const uint64_t* items, size_t num_i
 int fpx_segment_create_remote(fpx_ctx* ctx_, uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
                               const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs, fpx_segment** out)
 {
-    (void)doc_alive;
     Ctx* c = reinterpret_cast<Ctx*>(ctx_);
     if (!c || !out || (!doc_ids && num_docs)) { set_error("null argument"); return FPX_E_INVAL; }
     Segment* s = new (std::nothrow) Segment();
     if (!s) return FPX_E_NOMEM;
     s->ctx = c; s->kind = 2; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
-    set_docs(s, doc_ids, num_docs);
+    set_docs(s, doc_ids, doc_alive, num_docs);
     *out = reinterpret_cast<fpx_segment*>(s);
     return FPX_OK;
 }
@@ -501,6 +506,81 @@ int fpx_synth_segment(fpx_ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t 
                                 commit_id, &s);
     *out = reinterpret_cast<fpx_segment*>(s);
     return rc;
+}
+
+// ---------------------------------------------------------------- device-side segment build / merge
+int fpx_segment_build(fpx_ctx* ctx_, const uint64_t* items, size_t num_items, int sorted, uint32_t block_size,
+                      uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                      const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs, fpx_segment** out)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx_);
+    if (!c || !out || (!items && num_items) || (!doc_ids && num_docs)) { set_error("null argument"); return FPX_E_INVAL; }
+    *out = nullptr;
+    Segment* s = new (std::nothrow) Segment();
+    if (!s) return FPX_E_NOMEM;
+    set_docs(s, doc_ids, doc_alive, num_docs);
+    int rc = segment_build_impl(c, items, num_items, sorted != 0, block_size, min_doc_id, max_doc_id, commit_id, s);
+    if (rc) { s->ctx = c; segment_free(s); return rc; }
+    *out = reinterpret_cast<fpx_segment*>(s);
+    return FPX_OK;
+}
+
+int fpx_segment_merge(fpx_snapshot* collection, fpx_segment* const* sources, uint32_t num_sources, uint32_t block_size,
+                      fpx_segment** out)
+{
+    Snapshot* sn = reinterpret_cast<Snapshot*>(collection);
+    if (!sn || !out || (!sources && num_sources)) { set_error("null argument"); return FPX_E_INVAL; }
+    *out = nullptr;
+    if (num_sources == 0) { set_error("no sources (error.NoSources, src/segment_merger.zig:88)"); return FPX_E_INVAL; }
+    // prepare() (src/segment_merger.zig:85-131): merged docs map, skip lists, id range, merged commit id
+    std::vector<MergeSource> srcs(num_sources);
+    std::vector<uint64_t> docs;                       // id << 1 | alive
+    uint64_t commit = 0;
+    for (uint32_t i = 0; i < num_sources; ++i) {
+        const Segment* g = reinterpret_cast<const Segment*>(sources[i]);
+        size_t si = 0;
+        while (si < sn->segs.size() && sn->segs[si] != g) ++si;
+        if (!g || si == sn->segs.size()) { set_error("source %u is not a segment of the collection", i); return FPX_E_INVAL; }
+        if (i > 0 && g->commit_id <= reinterpret_cast<const Segment*>(sources[i - 1])->commit_id) {
+            set_error("sources must be ordered oldest to newest"); return FPX_E_INVAL;
+        }
+        srcs[i].seg = g;
+        compute_dead(sn->segs, si, srcs[i].dead);
+        commit = i == 0 ? g->commit_id : std::min(commit, g->commit_id);          // SegmentInfo.merge, src/segment.zig:38-51
+        size_t k = 0;
+        for (size_t d = 0; d < g->doc_ids.size(); ++d) {
+            while (k < srcs[i].dead.size() && srcs[i].dead[k] < g->doc_ids[d]) ++k;
+            if (k < srcs[i].dead.size() && srcs[i].dead[k] == g->doc_ids[d]) continue;   // hasNewerCommit: skipped
+            docs.push_back(((uint64_t)g->doc_ids[d] << 1) | (g->doc_alive[d] ? 1u : 0u));
+        }
+    }
+    std::sort(docs.begin(), docs.end());
+    Segment* s = new (std::nothrow) Segment();
+    if (!s) return FPX_E_NOMEM;
+    s->ctx = sn->ctx; s->kind = 0; s->commit_id = commit;
+    s->doc_ids.reserve(docs.size()); s->doc_alive.reserve(docs.size());
+    for (uint64_t v : docs) { s->doc_ids.push_back((uint32_t)(v >> 1)); s->doc_alive.push_back((uint8_t)(v & 1u)); }
+    s->min_doc_id = docs.empty() ? 0u : s->doc_ids.front();
+    s->max_doc_id = docs.empty() ? 0u : s->doc_ids.back();
+    int rc = segment_merge_device(sn->ctx, srcs, block_size, s->min_doc_id, s);
+    if (rc) { segment_free(s); return rc; }
+    *out = reinterpret_cast<fpx_segment*>(s);
+    return FPX_OK;
+}
+
+uint64_t fpx_segment_commit_id(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->commit_id : 0; }
+uint32_t fpx_segment_min_doc_id(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->min_doc_id : 0; }
+uint32_t fpx_segment_max_doc_id(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->max_doc_id : 0; }
+uint32_t fpx_segment_num_docs(const fpx_segment* seg) { return seg ? (uint32_t)reinterpret_cast<const Segment*>(seg)->doc_ids.size() : 0; }
+
+int fpx_segment_docs(const fpx_segment* seg, uint32_t* doc_ids, uint8_t* doc_alive, uint32_t cap)
+{
+    const Segment* s = reinterpret_cast<const Segment*>(seg);
+    if (!s) { set_error("null segment"); return FPX_E_INVAL; }
+    if (cap < s->doc_ids.size()) { set_error("docs buffer too small"); return FPX_E_INVAL; }
+    if (doc_ids) std::copy(s->doc_ids.begin(), s->doc_ids.end(), doc_ids);
+    if (doc_alive) std::copy(s->doc_alive.begin(), s->doc_alive.end(), doc_alive);
+    return FPX_OK;
 }
 
 // CRC-64/XZ (ECMA-182 polynomial, reflected, init/xorout all ones), slicing-by-8

@@ -271,118 +271,378 @@ struct DevBuf {
     }
 };
 
+// Encode `n` sorted items (device memory) into the blocks + block index of `s` (filefmt.writeBlocks,
+// src/filefmt.zig:94-138).  `s->block_size` is taken from the argument; on failure the caller frees `s`.
+static int encode_sorted_items(const uint64_t* items, uint64_t n, uint32_t min_doc, uint32_t block_size, Segment* s, hipStream_t st)
+{
+    int rc;
+    s->block_size = block_size;
+    uint32_t num_blocks = 0;
+    DevBuf cmid, cfirst, entry, exitb, count, boff, flags, bstart;
+    const uint64_t nq = (n + 3) / 4;
+    if (n) {
+        // per-quad costs
+        if ((rc = cmid.alloc(nq + 16)) || (rc = cfirst.alloc(nq + 16))) return rc;      // +16: the walk reads 8-byte words
+        hipLaunchKernelGGL(k_quad_costs, dim3(256 * 16), dim3(256), 0, st, items, n, min_doc, cmid.as<uint8_t>(), cfirst.as<uint8_t>());
+        FPX_HIP(hipGetLastError());
+
+        // fixpoint of the greedy fill over chunks
+        const uint32_t cq = 4096;
+        const uint64_t nchunks = (nq + cq - 1) / cq;
+        if ((rc = entry.alloc(nchunks * 8)) || (rc = exitb.alloc(nchunks * 8)) || (rc = count.alloc(nchunks * 4)) ||
+            (rc = boff.alloc(nchunks * 8)) || (rc = flags.alloc(64)))
+            return rc;
+        int* d_changed = flags.as<int>();
+        int* d_error = flags.as<int>() + 1;
+        uint64_t* d_total = reinterpret_cast<uint64_t*>(flags.as<int>() + 2);
+        FPX_HIP(hipMemsetAsync(flags.p, 0, 64, st));
+        const uint32_t gch = (uint32_t)((nchunks + 255) / 256);
+        hipLaunchKernelGGL(k_init_entries, dim3(gch), dim3(256), 0, st, entry.as<uint64_t>(), nchunks, cq);
+        WalkArgs wa{};
+        wa.cost_mid = cmid.as<uint8_t>(); wa.cost_first = cfirst.as<uint8_t>(); wa.nq = nq; wa.block_size = block_size;
+        wa.cq = cq; wa.nchunks = nchunks; wa.entry = entry.as<uint64_t>(); wa.exit = exitb.as<uint64_t>();
+        wa.count = count.as<uint32_t>(); wa.boff = boff.as<uint64_t>(); wa.bstart = nullptr; wa.error = d_error;
+        for (uint64_t round = 0; round <= nchunks + 1; ++round) {
+            FPX_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 0);
+            hipLaunchKernelGGL(k_next_entries, dim3(gch), dim3(256), 0, st, exitb.as<uint64_t>(), entry.as<uint64_t>(), nchunks, d_changed);
+            FPX_HIP(hipGetLastError());
+            int h_flags[2] = {0, 0};
+            FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipStreamSynchronize(st));
+            if (h_flags[1]) { set_error("block_size %u cannot hold one chunk of 4 items", block_size); return FPX_E_INVAL; }
+            if (!h_flags[0]) break;
+        }
+        // counts are those of the last walk, which ran on the final entries only if nothing changed afterwards
+        hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 0);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, count.as<uint32_t>(), nchunks, boff.as<uint64_t>(), d_total);
+        FPX_HIP(hipGetLastError());
+        uint64_t num_blocks64 = 0;
+        FPX_HIP(hipMemcpyAsync(&num_blocks64, d_total, 8, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (num_blocks64 >= 0xFFFFFFFFull) { set_error("too many blocks"); return FPX_E_INVAL; }
+        num_blocks = (uint32_t)num_blocks64;
+        if ((rc = bstart.alloc(((size_t)num_blocks + 1) * 8))) return rc;
+        wa.bstart = bstart.as<uint64_t>();
+        hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 1);
+        FPX_HIP(hipGetLastError());
+    }
+
+    // encode
+    s->num_blocks = num_blocks;
+    s->blocks_len = ((size_t)num_blocks + 1) * block_size;
+    FPX_HIP(hipMalloc(&s->d_blocks, s->blocks_len + 16));
+    FPX_HIP(hipMalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t)));
+    s->device_bytes = s->blocks_len + 16 + ((size_t)num_blocks + 1) * sizeof(uint32_t);
+    FPX_HIP(hipMemsetAsync(s->d_blocks + (size_t)num_blocks * block_size, 0, block_size + 16, st));   // terminator + slack
+    if (num_blocks) {
+        hipLaunchKernelGGL(k_encode_blocks, dim3((num_blocks + 3) / 4), dim3(256), 4 * block_size, st,
+                           items, n, min_doc, bstart.as<uint64_t>(), (uint64_t)num_blocks, nq, block_size,
+                           s->d_blocks, s->d_block_index);
+        FPX_HIP(hipGetLastError());
+    }
+    FPX_HIP(hipStreamSynchronize(st));
+    rc = finish_file_segment(s);
+    if (rc) return rc;
+    FPX_HIP(hipDeviceSynchronize());
+    if (s->num_items != n) {
+        set_error("internal: built %llu items, expected %llu", (unsigned long long)s->num_items, (unsigned long long)n);
+        return FPX_E_DEVICE;
+    }
+    return FPX_OK;
+}
+
+static void free_partial_segment(Segment* s)
+{
+    if (!s) return;
+    if (s->d_blocks) (void)hipFree(s->d_blocks);
+    if (s->d_block_index) (void)hipFree(s->d_block_index);
+    if (s->d_bucket) (void)hipFree(s->d_bucket);
+    delete s;
+}
+
+static int check_block_size(uint32_t block_size)
+{
+    if (block_size < 64 || block_size > 4096 || (block_size & 3u)) { set_error("block_size must be in [64,4096] and a multiple of 4"); return FPX_E_INVAL; }
+    return FPX_OK;
+}
+
+// sort `n` items held in buf0 (buf1 = scratch of the same size); returns the buffer holding the result
+static int sort_items(DevBuf& buf0, DevBuf& buf1, uint64_t n, hipStream_t st, const uint64_t** sorted)
+{
+    int rc;
+    DevBuf temp;
+    const size_t tb = sort_u64_temp_bytes(n, 0, 64);
+    if ((rc = temp.alloc(tb + 256))) return rc;
+    int cur = 0;
+    FPX_HIP(sort_u64(temp.p, tb + 256, buf0.as<uint64_t>(), buf1.as<uint64_t>(), n, 0, 64, st, &cur));   // Item order, src/segment.zig:90-94
+    FPX_HIP(hipStreamSynchronize(st));
+    // the other buffer is no longer needed
+    if (cur == 0) { (void)hipFree(buf1.p); buf1.p = nullptr; *sorted = buf0.as<uint64_t>(); }
+    else { (void)hipFree(buf0.p); buf0.p = nullptr; *sorted = buf1.as<uint64_t>(); }
+    return FPX_OK;
+}
+
 int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist,
                        uint32_t block_size, uint64_t commit_id, Segment** out)
 {
     *out = nullptr;
     if (num_docs == 0 || H == 0 || first_doc == 0) { set_error("num_docs, hashes_per_doc and first_doc must be non-zero"); return FPX_E_INVAL; }
-    if (block_size < 64 || block_size > 4096 || (block_size & 3u)) { set_error("block_size must be in [64,4096] and a multiple of 4"); return FPX_E_INVAL; }
+    int rc;
+    if ((rc = check_block_size(block_size))) return rc;
     if ((uint64_t)first_doc + num_docs - 1 > 0xFFFFFFFFull) { set_error("doc ids overflow u32"); return FPX_E_INVAL; }
     const uint64_t n = (uint64_t)num_docs * H;
     if (n > 0xFFFFFFFFull) { set_error("segment holds more than 2^32-1 items (num_items is u32, src/filefmt.zig:80)"); return FPX_E_INVAL; }
     FPX_HIP(hipSetDevice(ctx->device));
     hipStream_t st = 0;
-    int rc;
 
-    // 1. items, sorted as u64 (src/segment.zig:90-94)
-    DevBuf items0, items1, temp;
+    DevBuf items0, items1;
     if ((rc = items0.alloc(n * 8)) || (rc = items1.alloc(n * 8))) return rc;
     hipLaunchKernelGGL(k_gen_items, dim3(256 * 16), dim3(256), 0, st, seed, first_doc, n, H, dist, items0.as<uint64_t>());
     FPX_HIP(hipGetLastError());
-    const unsigned id_bits = 32;   // ids occupy the low word; all 64 bits take part in the order
-    (void)id_bits;
-    const size_t tb = sort_u64_temp_bytes(n, 0, 64);
-    if ((rc = temp.alloc(tb + 256))) return rc;
-    int cur = 0;
-    FPX_HIP(sort_u64(temp.p, tb + 256, items0.as<uint64_t>(), items1.as<uint64_t>(), n, 0, 64, st, &cur));
-    FPX_HIP(hipStreamSynchronize(st));
-    const uint64_t* items = cur == 0 ? items0.as<uint64_t>() : items1.as<uint64_t>();
-    // the other buffer is no longer needed
-    if (cur == 0) { (void)hipFree(items1.p); items1.p = nullptr; } else { (void)hipFree(items0.p); items0.p = nullptr; }
-    (void)hipFree(temp.p); temp.p = nullptr;
+    const uint64_t* items = nullptr;
+    if ((rc = sort_items(items0, items1, n, st, &items))) return rc;
 
-    // 2. per-quad costs
-    const uint64_t nq = (n + 3) / 4;
-    DevBuf cmid, cfirst;
-    if ((rc = cmid.alloc(nq + 16)) || (rc = cfirst.alloc(nq + 16))) return rc;      // +16: the walk reads 8-byte words
-    hipLaunchKernelGGL(k_quad_costs, dim3(256 * 16), dim3(256), 0, st, items, n, first_doc, cmid.as<uint8_t>(), cfirst.as<uint8_t>());
-    FPX_HIP(hipGetLastError());
-
-    // 3. fixpoint of the greedy fill over chunks
-    const uint32_t cq = 4096;
-    const uint64_t nchunks = (nq + cq - 1) / cq;
-    DevBuf entry, exitb, count, boff, flags;
-    if ((rc = entry.alloc(nchunks * 8)) || (rc = exitb.alloc(nchunks * 8)) || (rc = count.alloc(nchunks * 4)) ||
-        (rc = boff.alloc(nchunks * 8)) || (rc = flags.alloc(64)))
-        return rc;
-    int* d_changed = flags.as<int>();
-    int* d_error = flags.as<int>() + 1;
-    uint64_t* d_total = reinterpret_cast<uint64_t*>(flags.as<int>() + 2);
-    FPX_HIP(hipMemsetAsync(flags.p, 0, 64, st));
-    const uint32_t gch = (uint32_t)((nchunks + 255) / 256);
-    hipLaunchKernelGGL(k_init_entries, dim3(gch), dim3(256), 0, st, entry.as<uint64_t>(), nchunks, cq);
-    WalkArgs wa{};
-    wa.cost_mid = cmid.as<uint8_t>(); wa.cost_first = cfirst.as<uint8_t>(); wa.nq = nq; wa.block_size = block_size;
-    wa.cq = cq; wa.nchunks = nchunks; wa.entry = entry.as<uint64_t>(); wa.exit = exitb.as<uint64_t>();
-    wa.count = count.as<uint32_t>(); wa.boff = boff.as<uint64_t>(); wa.bstart = nullptr; wa.error = d_error;
-    for (uint64_t round = 0; round <= nchunks + 1; ++round) {
-        FPX_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 0);
-        hipLaunchKernelGGL(k_next_entries, dim3(gch), dim3(256), 0, st, exitb.as<uint64_t>(), entry.as<uint64_t>(), nchunks, d_changed);
-        FPX_HIP(hipGetLastError());
-        int h_flags[2] = {0, 0};
-        FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipStreamSynchronize(st));
-        if (h_flags[1]) { set_error("block_size %u cannot hold one chunk of 4 items", block_size); return FPX_E_INVAL; }
-        if (!h_flags[0]) break;
-    }
-    // counts are those of the last walk, which ran on the final entries only if nothing changed afterwards
-    hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 0);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, count.as<uint32_t>(), nchunks, boff.as<uint64_t>(), d_total);
-    FPX_HIP(hipGetLastError());
-    uint64_t num_blocks64 = 0;
-    FPX_HIP(hipMemcpyAsync(&num_blocks64, d_total, 8, hipMemcpyDeviceToHost, st));
-    FPX_HIP(hipStreamSynchronize(st));
-    if (num_blocks64 >= 0xFFFFFFFFull) { set_error("too many blocks"); return FPX_E_INVAL; }
-    const uint32_t num_blocks = (uint32_t)num_blocks64;
-    DevBuf bstart;
-    if ((rc = bstart.alloc(((size_t)num_blocks + 1) * 8))) return rc;
-    wa.bstart = bstart.as<uint64_t>();
-    hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 1);
-    FPX_HIP(hipGetLastError());
-
-    // 4. encode
     Segment* s = new (std::nothrow) Segment();
     if (!s) return FPX_E_NOMEM;
     s->ctx = ctx; s->kind = 0; s->commit_id = commit_id; s->min_doc_id = first_doc; s->max_doc_id = first_doc + num_docs - 1;
-    s->block_size = block_size; s->num_blocks = num_blocks;
-    s->blocks_len = ((size_t)num_blocks + 1) * block_size;
     s->doc_ids.resize(num_docs);
     std::iota(s->doc_ids.begin(), s->doc_ids.end(), first_doc);
-    auto fail = [&](int code) { if (s->d_blocks) (void)hipFree(s->d_blocks); if (s->d_block_index) (void)hipFree(s->d_block_index);
-                                if (s->d_bucket) (void)hipFree(s->d_bucket); delete s; return code; };
-    hipError_t e = hipMalloc(&s->d_blocks, s->blocks_len + 16);
-    if (e == hipSuccess) e = hipMalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t));
-    if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc(segment)"));
-    s->device_bytes = s->blocks_len + 16 + ((size_t)num_blocks + 1) * sizeof(uint32_t);
-    e = hipMemsetAsync(s->d_blocks + (size_t)num_blocks * block_size, 0, block_size + 16, st);   // terminator + slack
-    if (e != hipSuccess) return fail(hip_fail(e, "memset"));
-    if (num_blocks) {
-        hipLaunchKernelGGL(k_encode_blocks, dim3((num_blocks + 3) / 4), dim3(256), 4 * block_size, st,
-                           items, n, first_doc, bstart.as<uint64_t>(), (uint64_t)num_blocks, nq, block_size,
-                           s->d_blocks, s->d_block_index);
-        e = hipGetLastError();
-        if (e != hipSuccess) return fail(hip_fail(e, "k_encode_blocks"));
-    }
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return fail(hip_fail(e, "encode sync"));
-    rc = finish_file_segment(s);
-    if (rc) return fail(rc);
-    e = hipDeviceSynchronize();
-    if (e != hipSuccess) return fail(hip_fail(e, "finish sync"));
-    if (s->num_items != n) { set_error("internal: built %llu items, expected %llu", (unsigned long long)s->num_items, (unsigned long long)n); return fail(FPX_E_DEVICE); }
+    s->doc_alive.assign(num_docs, 1);
+    rc = encode_sorted_items(items, n, first_doc, block_size, s, st);
+    if (rc) { free_partial_segment(s); return rc; }
     *out = s;
     return FPX_OK;
+}
+
+// ---- generic builder: what Index.checkpoint / mergeToFileSegment hand to filefmt.writeSegment -----------------
+__global__ __launch_bounds__(256) void k_check_items(const uint64_t* __restrict__ items, uint64_t n, uint32_t min_doc, uint32_t max_doc,
+                                                     int* flags)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t id = (uint32_t)items[i];
+        if (id < min_doc || id > max_doc) flags[0] = 1;
+        if (i > 0 && items[i - 1] > items[i]) flags[1] = 1;
+    }
+}
+
+int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool sorted, uint32_t block_size,
+                       uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, Segment* s)
+{
+    int rc;
+    if ((rc = check_block_size(block_size))) return rc;
+    if (n > 0xFFFFFFFFull) { set_error("segment holds more than 2^32-1 items (num_items is u32, src/filefmt.zig:80)"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = 0;
+    DevBuf items0, items1, flags;
+    if ((rc = items0.alloc(n * 8)) || (rc = flags.alloc(16))) return rc;
+    if (n) FPX_HIP(hipMemcpyAsync(items0.p, items_host, n * 8, hipMemcpyHostToDevice, st));
+    const uint64_t* items = items0.as<uint64_t>();
+    if (!sorted && n > 1) {
+        if ((rc = items1.alloc(n * 8))) return rc;
+        if ((rc = sort_items(items0, items1, n, st, &items))) return rc;
+    }
+    FPX_HIP(hipMemsetAsync(flags.p, 0, 16, st));
+    if (n) hipLaunchKernelGGL(k_check_items, dim3(256 * 4), dim3(256), 0, st, items, n, min_doc_id, max_doc_id, flags.as<int>());
+    int h_flags[2] = {0, 0};
+    FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    if (h_flags[0]) { set_error("an item's doc id lies outside [min_doc_id, max_doc_id]"); return FPX_E_INVAL; }
+    if (h_flags[1]) { set_error("items are not sorted (pass sorted = 0 to sort them on the device)"); return FPX_E_INVAL; }
+    s->ctx = ctx; s->kind = 0; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
+    return encode_sorted_items(items, n, min_doc_id, block_size, s, st);
+}
+
+// ---- merge: decode the sources' items on the device, drop superseded docs, sort, encode ----------------------
+__device__ __forceinline__ bool merge_is_dead(const uint32_t* dead, uint32_t n, uint32_t d)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t m = (lo + hi) >> 1;
+        if (dead[m] < d) lo = m + 1; else hi = m;
+    }
+    return lo < n && dead[lo] == d;
+}
+
+__global__ void k_block_item_counts(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks, uint32_t* counts)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < num_blocks) counts[b] = *reinterpret_cast<const uint16_t*>(blocks + (size_t)b * block_size + 4);   // src/block.zig:46-50
+}
+
+// One wave per block, one lane per quad, 64 quads per pass (the inverse of k_encode_blocks):
+// BlockReader full decode, src/block.zig:137-203 + src/streamvbyte.zig:264-339.
+__global__ __launch_bounds__(256) void k_decode_items(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
+                                                      uint32_t min_doc, const uint64_t* __restrict__ boff,
+                                                      const uint32_t* __restrict__ dead, uint32_t num_dead,
+                                                      uint64_t* __restrict__ items, uint8_t* __restrict__ live)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= num_blocks) return;
+    const uint8_t* blk = blocks + b * (uint64_t)block_size;
+    const uint32_t min_hash = *reinterpret_cast<const uint32_t*>(blk);
+    const uint32_t n_items = *reinterpret_cast<const uint16_t*>(blk + 4);
+    const uint32_t doff = *reinterpret_cast<const uint16_t*>(blk + 6);
+    const uint32_t nq = (n_items + 3u) >> 2;
+    const uint64_t out0 = boff[b];
+    uint32_t hcarry = 0, dcarry = 0;         // bytes of hash / docid data consumed by earlier passes
+    uint32_t hbase = min_hash;               // hash of the last item of the previous pass
+    uint32_t pdoc = 0;                       // (doc - min_doc) of the last item of the previous pass
+    for (uint32_t c0 = 0; c0 < nq; c0 += 64u) {
+        const uint32_t qi = c0 + lane;
+        const bool act = qi < nq;
+        // hashes: 0124, delta
+        const uint32_t hc = act ? blk[8u + qi] : 0u;
+        uint32_t hlen = 0;
+        for (uint32_t k = 0; k < 4; ++k) hlen += (1u << ((hc >> (2 * k)) & 3u)) >> 1;
+        const uint32_t hincl = scan64(hlen, lane);
+        uint32_t hp = 8u + nq + hcarry + hincl - hlen;
+        hcarry += __shfl(hincl, 63);
+        uint32_t h[4], qs = 0;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t nb = (1u << ((hc >> (2 * k)) & 3u)) >> 1;
+            uint32_t v = 0;
+            for (uint32_t j = 0; j < nb; ++j) v |= (uint32_t)blk[min(hp + j, block_size - 1u)] << (8 * j);
+            hp += nb;
+            qs += v;
+            h[k] = qs;
+        }
+        const uint32_t qincl = scan64(qs, lane);
+        const uint32_t hprev_pass = hbase;                               // hash of the item just before this pass
+        const uint32_t base = hbase + qincl - qs;
+        hbase += __shfl(qincl, 63);
+        for (uint32_t k = 0; k < 4; ++k) h[k] += base;
+        // docids: 1234; the delta base resets to min_doc at every hash change and at block start
+        const uint32_t dc = act ? blk[min(8u + doff + qi, block_size - 1u)] : 0u;
+        uint32_t dlen = 0;
+        for (uint32_t k = 0; k < 4; ++k) dlen += ((dc >> (2 * k)) & 3u) + 1u;
+        if (!act) dlen = 0;
+        const uint32_t dincl = scan64(dlen, lane);
+        uint32_t dp = 8u + doff + nq + dcarry + dincl - dlen;
+        dcarry += __shfl(dincl, 63);
+        const uint32_t h_up = __shfl_up(h[3], 1, 64);
+        const uint32_t h_before = lane == 0 ? hprev_pass : h_up;          // hash of the item just before this quad
+        uint32_t s[4];            // sum of deltas since the last reset inside the quad (or since the quad start)
+        bool f[4];                // a reset happened inside the quad at or before item k
+        uint32_t S = 0; bool F = false;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t nb = ((dc >> (2 * k)) & 3u) + 1u;
+            uint32_t v = 0;
+            if (act) for (uint32_t j = 0; j < nb; ++j) v |= (uint32_t)blk[min(dp + j, block_size - 1u)] << (8 * j);
+            dp += nb;
+            const uint32_t prevh = k ? h[k - 1] : h_before;
+            const bool reset = (qi == 0u && k == 0u) || h[k] != prevh;
+            if (reset) { S = v; F = true; } else S += v;
+            s[k] = S; f[k] = F;
+        }
+        // segmented inclusive scan of (F, S) across lanes
+        uint32_t SS = S; bool FF = F;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ts = __shfl_up(SS, d, 64);
+            const int tf = __shfl_up((int)FF, d, 64);
+            if (lane >= (uint32_t)d) { if (!FF) SS += ts; FF = FF || (tf != 0); }
+        }
+        uint32_t Se = __shfl_up(SS, 1, 64);
+        int Fe = __shfl_up((int)FF, 1, 64);
+        if (lane == 0) { Se = 0; Fe = 0; }
+        // exclusive prefix combined with the carry of the previous pass (absolute value pdoc)
+        const uint32_t excl = Fe ? Se : pdoc + Se;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = qi * 4u + k;
+            if (act && i < n_items) {
+                const uint32_t D = f[k] ? s[k] : excl + s[k];
+                const uint32_t doc = min_doc + D;
+                items[out0 + i] = ((uint64_t)h[k] << 32) | doc;
+                live[out0 + i] = (num_dead != 0u && merge_is_dead(dead, num_dead, doc)) ? 0 : 1;
+            }
+        }
+        // carry the last item's relative doc id to the next pass
+        const uint32_t lastS = __shfl(SS, 63);
+        const int lastF = __shfl((int)FF, 63);
+        pdoc = lastF ? lastS : pdoc + lastS;
+    }
+}
+
+// memory-segment source: copy the items and flag the ones whose doc is superseded
+__global__ __launch_bounds__(256) void k_flag_items(const uint64_t* __restrict__ src, uint64_t n, const uint32_t* __restrict__ dead,
+                                                    uint32_t num_dead, uint64_t* __restrict__ items, uint8_t* __restrict__ live)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t it = src[i];
+        items[i] = it;
+        live[i] = (num_dead != 0u && merge_is_dead(dead, num_dead, (uint32_t)it)) ? 0 : 1;
+    }
+}
+
+// SegmentMerger.read()/advance() for all sources at once (src/segment_merger.zig:133-155): the k-way merge of sorted
+// sources equals one sort of their concatenation, which is how a GPU merges.
+int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_t block_size, uint32_t min_doc_id, Segment* s)
+{
+    int rc;
+    if ((rc = check_block_size(block_size))) return rc;
+    FPX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = 0;
+    uint64_t total = 0;
+    bool any_dead = false;
+    for (const MergeSource& m : srcs) {
+        if (m.seg->kind == 2) { set_error("a remote segment holds no items to merge"); return FPX_E_INVAL; }
+        total += m.seg->num_items;
+        any_dead = any_dead || !m.dead.empty();
+    }
+    if (total > 0xFFFFFFFFull) { set_error("merged segment would hold more than 2^32-1 items (src/filefmt.zig:80)"); return FPX_E_INVAL; }
+    DevBuf all, other, live;
+    if ((rc = all.alloc(total * 8)) || (rc = other.alloc(total * 8)) || (rc = live.alloc(total + 16))) return rc;
+    uint64_t off = 0;
+    for (const MergeSource& m : srcs) {
+        const Segment* g = m.seg;
+        DevBuf dead;
+        const uint32_t nd = (uint32_t)m.dead.size();
+        if (nd) {
+            if ((rc = dead.alloc((size_t)nd * 4))) return rc;
+            FPX_HIP(hipMemcpyAsync(dead.p, m.dead.data(), (size_t)nd * 4, hipMemcpyHostToDevice, st));
+        }
+        if (g->kind == 0 && g->num_blocks) {
+            DevBuf counts, boff, tot;
+            if ((rc = counts.alloc((size_t)g->num_blocks * 4)) || (rc = boff.alloc((size_t)g->num_blocks * 8)) || (rc = tot.alloc(8))) return rc;
+            hipLaunchKernelGGL(k_block_item_counts, dim3((g->num_blocks + 255) / 256), dim3(256), 0, st,
+                               g->d_blocks, g->block_size, g->num_blocks, counts.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)g->num_blocks,
+                               boff.as<uint64_t>(), tot.as<uint64_t>());
+            hipLaunchKernelGGL(k_decode_items, dim3((g->num_blocks + 3) / 4), dim3(256), 0, st,
+                               g->d_blocks, g->block_size, g->num_blocks, g->min_doc_id, boff.as<uint64_t>(),
+                               dead.as<uint32_t>(), nd, all.as<uint64_t>() + off, live.as<uint8_t>() + off);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipStreamSynchronize(st));          // the temporaries die with this scope
+        } else if (g->kind == 1 && g->num_items) {
+            hipLaunchKernelGGL(k_flag_items, dim3(256 * 4), dim3(256), 0, st, g->d_items, g->num_items,
+                               dead.as<uint32_t>(), nd, all.as<uint64_t>() + off, live.as<uint8_t>() + off);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipStreamSynchronize(st));
+        }
+        off += g->num_items;
+    }
+    uint64_t n_live = total;
+    if (any_dead && total) {                               // Source.read() drops the items of skipped docs (:44-53)
+        DevBuf temp, cnt;
+        const size_t tb = select_u64_temp_bytes(total);
+        if ((rc = temp.alloc(tb + 256)) || (rc = cnt.alloc(8))) return rc;
+        FPX_HIP(select_u64(temp.p, tb + 256, all.as<uint64_t>(), live.as<uint8_t>(), other.as<uint64_t>(),
+                           cnt.as<unsigned long long>(), total, st));
+        unsigned long long h_cnt = 0;
+        FPX_HIP(hipMemcpyAsync(&h_cnt, cnt.p, 8, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        n_live = h_cnt;
+        std::swap(all.p, other.p);
+    }
+    (void)hipFree(live.p); live.p = nullptr;
+    const uint64_t* items = all.as<uint64_t>();
+    if (srcs.size() > 1 && n_live > 1) {
+        if ((rc = sort_items(all, other, n_live, st, &items))) return rc;
+    } else {
+        (void)hipFree(other.p); other.p = nullptr;
+    }
+    return encode_sorted_items(items, n_live, min_doc_id, block_size, s, st);
 }
 
 }  // namespace fpx

@@ -63,6 +63,7 @@ struct Segment {
     uint64_t commit_id = 0;
     uint32_t min_doc_id = 0, max_doc_id = 0;
     std::vector<uint32_t> doc_ids; // sorted ascending (alive flag irrelevant to search: tombstones supersede too)
+    std::vector<uint8_t> doc_alive; // parallel to doc_ids; carried for merges (src/segment_merger.zig:112-118)
     // file
     uint8_t* d_blocks = nullptr; size_t blocks_len = 0; uint32_t block_size = 0;
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
@@ -146,6 +147,10 @@ size_t sort_u64_temp_bytes(size_t n, unsigned begin_bit, unsigned end_bit);
 hipError_t sort_u64(void* temp, size_t temp_bytes, uint64_t* buf0, uint64_t* buf1, size_t n,
                     unsigned begin_bit, unsigned end_bit, hipStream_t stream, int* result_in);
 
+size_t select_u64_temp_bytes(size_t n);
+hipError_t select_u64(void* temp, size_t temp_bytes, const uint64_t* in, const uint8_t* flags, uint64_t* out,
+                      unsigned long long* d_count, size_t n, hipStream_t stream);
+
 // fpx_search.hip
 int build_bucket_table(Segment* seg, hipStream_t stream);
 int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
@@ -166,5 +171,10 @@ int finish_file_segment(Segment* seg);   // bucket table + item count for blocks
 // fpx_build.hip
 int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist,
                        uint32_t block_size, uint64_t commit_id, Segment** out);
+// `s` arrives with its docs set; on failure the caller frees it
+int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool sorted, uint32_t block_size,
+                       uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, Segment* s);
+struct MergeSource { const Segment* seg; std::vector<uint32_t> dead; };   // dead = skip_docs, sorted
+int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_t block_size, uint32_t min_doc_id, Segment* s);
 
 }  // namespace fpx

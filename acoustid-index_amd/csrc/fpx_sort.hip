@@ -28,4 +28,19 @@ hipError_t sort_u64(void* temp, size_t temp_bytes, uint64_t* buf0, uint64_t* buf
     return e;
 }
 
+// stream compaction of 64-bit items by a byte flag (segment merges drop the items of superseded docs)
+size_t select_u64_temp_bytes(size_t n)
+{
+    size_t bytes = 0;
+    (void)rocprim::select(nullptr, bytes, (const uint64_t*)nullptr, (const uint8_t*)nullptr, (uint64_t*)nullptr,
+                          (unsigned long long*)nullptr, n, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t select_u64(void* temp, size_t temp_bytes, const uint64_t* in, const uint8_t* flags, uint64_t* out,
+                      unsigned long long* d_count, size_t n, hipStream_t stream)
+{
+    return rocprim::select(temp, temp_bytes, in, flags, out, d_count, n, stream);
+}
+
 }  // namespace fpx

@@ -81,6 +81,22 @@ class _Segment:
     def getSize(self):
         return lib().fpx_segment_num_items(self.h)
 
+    def docs(self):
+        """(doc_ids ascending, doc_alive) as the C side holds them"""
+        n = lib().fpx_segment_num_docs(self.h)
+        ids, alive = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint8)
+        check(lib().fpx_segment_docs(self.h, _p(ids), _p(alive), len(ids)))
+        return ids[:n], alive[:n]
+
+    @classmethod
+    def _adopt(cls, ctx, h):
+        """wrap a handle produced by the C side (build / merge): ids and docs are read back from it"""
+        self = cls.__new__(cls)
+        _Segment.__init__(self, ctx, h, lib().fpx_segment_commit_id(h), lib().fpx_segment_min_doc_id(h),
+                          lib().fpx_segment_max_doc_id(h), None, None)
+        self.doc_ids, self.doc_alive = self.docs()
+        return self
+
     @property
     def device_bytes(self):
         return lib().fpx_segment_device_bytes(self.h)
@@ -116,6 +132,17 @@ class FileSegment(_Segment):
         self.first_doc, self.num_docs = first_doc, num_docs
         return self
 
+    @classmethod
+    def build(cls, ctx, items, block_size, min_doc_id, max_doc_id, commit_id, doc_ids, doc_alive=None, sorted=False):
+        """Encode items (hash << 32 | id) into a resident FileSegment on the GPU (fpx_segment_build):
+        filefmt.writeBlocks + BlockEncoder, src/filefmt.zig:94-138, src/block.zig:438-567."""
+        items = np.ascontiguousarray(items, dtype=np.uint64)
+        ids, alive = _docs_args(doc_ids, doc_alive)
+        h = C.c_void_p()
+        check(lib().fpx_segment_build(ctx.h, _p(items), len(items), 1 if sorted else 0, block_size, min_doc_id, max_doc_id,
+                                      commit_id, _p(ids), _p(alive), len(ids), C.byref(h)))
+        return cls._adopt(ctx, h)
+
     @property
     def num_blocks(self):
         return lib().fpx_segment_num_blocks(self.h)
@@ -144,6 +171,31 @@ class MemorySegment(_Segment):
         super().__init__(ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
 
 
+def build_memory_segment(ctx, changes, commit_id):
+    """MemorySegment.build (src/MemorySegment.zig:81-148): `changes` is a list of ("insert", id, hashes) /
+    ("delete", id); walking it BACKWARDS, the first occurrence of an id wins; a delete leaves a tombstone in the docs
+    map; min/max_doc_id cover inserts and deletes; items are sorted as u64 (hash << 32 | id)."""
+    docs = {}
+    parts = []
+    mn = mx = 0
+    for ch in reversed(list(changes)):
+        op, doc_id = ch[0], int(ch[1])
+        if op not in ("insert", "delete"):
+            continue                                  # set_metadata does not touch the search path
+        if doc_id in docs:
+            continue
+        docs[doc_id] = op == "insert"
+        if op == "insert":
+            h = np.asarray(ch[2], dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+            parts.append((h << np.uint64(32)) | np.uint64(doc_id))
+        mn = doc_id if mn == 0 or doc_id < mn else mn
+        mx = doc_id if mx == 0 or doc_id > mx else mx
+    items = np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+    ids = np.array(sorted(docs), np.uint32)
+    alive = np.array([docs[int(i)] for i in ids], np.uint8)
+    return MemorySegment(ctx, items, mn, mx, commit_id, ids, alive)
+
+
 class RemoteSegment(_Segment):
     """A segment whose postings live on another GPU: identity + docs map only (supersession)."""
     kind = "remote"
@@ -165,6 +217,14 @@ class Segments:
         h = C.c_void_p()
         check(lib().fpx_snapshot_create(ctx.h, arr, len(self.segments), C.byref(h)))
         self.h = h
+
+    def merge(self, sources, block_size=512):
+        """Index.mergeToFileSegment on the GPU (fpx_segment_merge): SegmentMerger over `sources` (segments of this
+        snapshot, oldest first) encoded into a new resident FileSegment; src/segment_merger.zig:85-155."""
+        arr = (C.c_void_p * max(1, len(sources)))(*[s.h for s in sources])
+        h = C.c_void_p()
+        check(lib().fpx_segment_merge(self.h, arr, len(sources), block_size, C.byref(h)))
+        return FileSegment._adopt(self.ctx, h)
 
     def release(self):
         if getattr(self, "h", None):

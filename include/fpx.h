@@ -187,6 +187,30 @@ int fpx_synth_segment(fpx_ctx *ctx, uint64_t seed, uint32_t first_doc, uint32_t 
                       uint32_t hashes_per_doc, int dist, uint32_t block_size, uint64_t commit_id,
                       fpx_segment **out);
 
+/* ---- device-side segment build and merge -------------------------------------------------------
+ * fpx_segment_build: filefmt.writeBlocks + BlockEncoder (src/filefmt.zig:94-138, src/block.zig:438-567) run on the GPU
+ * over caller-provided items (hash << 32 | id); the result is a resident FileSegment whose bytes equal what the
+ * reference writer produces for the same sorted items.  sorted = 0: the items are sorted on the device first
+ * (Item order, src/segment.zig:90-94).  Every item's id must lie in [min_doc_id, max_doc_id]. */
+int fpx_segment_build(fpx_ctx *ctx, const uint64_t *items, size_t num_items, int sorted, uint32_t block_size,
+                      uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                      const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs, fpx_segment **out);
+
+/* fpx_segment_merge: SegmentMerger.prepare + read/advance feeding writeSegment, i.e. Index.mergeToFileSegment
+ * (src/segment_merger.zig:85-155, src/Index.zig:961-983) for checkpoints (memory sources) and merges (file sources).
+ * `sources` are segments of `collection`, oldest first.  Docs with a newer commit in the collection are dropped with
+ * their items; the others keep their alive/tombstone status; min/max_doc_id cover the kept docs; commit_id is the
+ * smallest of the sources (SegmentInfo.merge, src/segment.zig:38-51; the caller tracks `merges`). */
+int fpx_segment_merge(fpx_snapshot *collection, fpx_segment *const *sources, uint32_t num_sources, uint32_t block_size,
+                      fpx_segment **out);
+
+/* the docs map and id range of a segment (after a merge the caller needs them for the manifest / segment file) */
+uint64_t fpx_segment_commit_id(const fpx_segment *seg);
+uint32_t fpx_segment_min_doc_id(const fpx_segment *seg);
+uint32_t fpx_segment_max_doc_id(const fpx_segment *seg);
+uint32_t fpx_segment_num_docs(const fpx_segment *seg);
+int fpx_segment_docs(const fpx_segment *seg, uint32_t *doc_ids, uint8_t *doc_alive, uint32_t cap);   /* ids ascending */
+
 /* CRC-64/XZ over `len` bytes continuing from `crc` (start with 0): the checksum the reference stores in the
  * segment file footer over the data blocks (std.hash.crc.Crc64Xz, src/filefmt.zig:101,119,261-284).  Host code. */
 uint64_t fpx_crc64_xz(uint64_t crc, const uint8_t *data, size_t len);

@@ -650,6 +650,126 @@ int orc_snapshot_has_newer_commit(const orc_snapshot *s, uint32_t id, uint64_t c
 }
 
 /* ======================================================================= */
+/* SegmentMerger (src/segment_merger.zig)                                   */
+/* ======================================================================= */
+
+/* all items of a segment in Item order: what Segment.Reader.read()/advance() yields one by one
+ * (FileSegment: block after block, src/FileSegment.zig reader; MemorySegment: the items array) */
+static uint64_t *segment_all_items(const orc_segment *s, size_t *n_out)
+{
+    if (!s->is_file) {
+        uint64_t *v = (uint64_t *)malloc((s->num_items ? s->num_items : 1) * sizeof(uint64_t));
+        if (!v) return NULL;
+        memcpy(v, s->items, s->num_items * sizeof(uint64_t));
+        *n_out = s->num_items;
+        return v;
+    }
+    size_t total = 0;
+    for (uint32_t b = 0; b < s->num_blocks; b++) {
+        orc_block_header h;
+        orc_block_header_decode(s->blocks + (size_t)b * s->block_size, &h);
+        total += h.num_items;
+    }
+    uint64_t *v = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+    uint32_t *th = (uint32_t *)malloc(ORC_MAX_ITEMS_PER_BLOCK * sizeof(uint32_t));
+    uint32_t *td = (uint32_t *)malloc(ORC_MAX_ITEMS_PER_BLOCK * sizeof(uint32_t));
+    if (!v || !th || !td) { free(v); free(th); free(td); return NULL; }
+    size_t k = 0;
+    for (uint32_t b = 0; b < s->num_blocks; b++) {
+        size_t n = orc_block_decode_items(s->blocks + (size_t)b * s->block_size, s->block_size, s->min_doc_id, th, td);
+        for (size_t i = 0; i < n; i++) v[k++] = (uint64_t)th[i] << 32 | td[i];
+    }
+    free(th); free(td);
+    *n_out = k;
+    return v;
+}
+
+int orc_merge_segments(const orc_snapshot *collection, orc_segment *const *sources, uint32_t n_sources,
+                       uint64_t **items_out, size_t *num_items_out,
+                       uint32_t **doc_ids_out, uint8_t **doc_alive_out, uint32_t *num_docs_out,
+                       uint32_t *min_doc_id_out, uint32_t *max_doc_id_out, uint64_t *commit_id_out)
+{
+    if (n_sources == 0) return -2;                                           /* :88 error.NoSources */
+    int rc = -1;
+    uint64_t **src_items = (uint64_t **)calloc(n_sources, sizeof(*src_items));
+    size_t *src_n = (size_t *)calloc(n_sources, sizeof(*src_n));
+    size_t *cursor = (size_t *)calloc(n_sources, sizeof(*cursor));
+    uint8_t **skip = (uint8_t **)calloc(n_sources, sizeof(*skip));           /* skip_docs, indexed like doc_ids */
+    uint64_t *docs = NULL, *out = NULL;
+    if (!src_items || !src_n || !cursor || !skip) goto done;
+
+    /* prepare(): merged info, docs map, skip_docs (:90-131) */
+    uint64_t commit = sources[0]->commit_id;
+    size_t total_docs = 0, total_items = 0;
+    for (uint32_t i = 0; i < n_sources; i++) {
+        if (sources[i]->commit_id < commit) commit = sources[i]->commit_id;
+        total_docs += sources[i]->num_docs;
+    }
+    docs = (uint64_t *)malloc((total_docs ? total_docs : 1) * sizeof(uint64_t));   /* id<<8 | alive */
+    if (!docs) goto done;
+    size_t nd = 0;
+    uint32_t mn = 0, mx = 0;
+    for (uint32_t i = 0; i < n_sources; i++) {
+        const orc_segment *g = sources[i];
+        skip[i] = (uint8_t *)calloc(g->num_docs ? g->num_docs : 1, 1);
+        if (!skip[i]) goto done;
+        for (uint32_t d = 0; d < g->num_docs; d++) {
+            const uint32_t id = g->doc_ids[d];
+            if (!orc_snapshot_has_newer_commit(collection, id, g->commit_id)) {
+                docs[nd++] = (uint64_t)id << 8 | g->doc_alive[d];
+                if (mn == 0 || id < mn) mn = id;
+                if (mx == 0 || id > mx) mx = id;
+            } else {
+                skip[i][d] = 1;
+            }
+        }
+        src_items[i] = segment_all_items(g, &src_n[i]);
+        if (!src_items[i]) goto done;
+        total_items += src_n[i];
+    }
+    orc_sort_u64(docs, nd);                     /* ids are unique here: an older copy of a doc is always skipped */
+
+    /* read()/advance() (:133-155): smallest head item wins, the first source on ties */
+    out = (uint64_t *)malloc((total_items ? total_items : 1) * sizeof(uint64_t));
+    if (!out) goto done;
+    size_t k = 0;
+    for (;;) {
+        int best = -1;
+        uint64_t best_item = 0;
+        for (uint32_t i = 0; i < n_sources; i++) {
+            const orc_segment *g = sources[i];
+            while (cursor[i] < src_n[i]) {                                   /* Source.read(): drop skipped docs (:44-53) */
+                const uint32_t id = (uint32_t)src_items[i][cursor[i]];
+                uint32_t lo = 0, hi = g->num_docs;
+                while (lo < hi) { uint32_t m = lo + (hi - lo) / 2; if (g->doc_ids[m] < id) lo = m + 1; else hi = m; }
+                if (lo < g->num_docs && g->doc_ids[lo] == id && skip[i][lo]) cursor[i]++; else break;
+            }
+            if (cursor[i] < src_n[i] && (best < 0 || src_items[i][cursor[i]] < best_item)) {
+                best = (int)i; best_item = src_items[i][cursor[i]];
+            }
+        }
+        if (best < 0) break;
+        cursor[best]++;
+        out[k++] = best_item;
+    }
+
+    *doc_ids_out = (uint32_t *)malloc((nd ? nd : 1) * sizeof(uint32_t));
+    *doc_alive_out = (uint8_t *)malloc(nd ? nd : 1);
+    if (!*doc_ids_out || !*doc_alive_out) { free(*doc_ids_out); free(*doc_alive_out); goto done; }
+    for (size_t i = 0; i < nd; i++) { (*doc_ids_out)[i] = (uint32_t)(docs[i] >> 8); (*doc_alive_out)[i] = (uint8_t)(docs[i] & 1); }
+    *items_out = out; out = NULL;
+    *num_items_out = k;
+    *num_docs_out = (uint32_t)nd;
+    *min_doc_id_out = mn; *max_doc_id_out = mx; *commit_id_out = commit;
+    rc = 0;
+done:
+    if (src_items) for (uint32_t i = 0; i < n_sources; i++) free(src_items[i]);
+    if (skip) for (uint32_t i = 0; i < n_sources; i++) free(skip[i]);
+    free(src_items); free(src_n); free(cursor); free(skip); free(docs); free(out);
+    return rc;
+}
+
+/* ======================================================================= */
 /* SearchResults (src/common.zig:73-176)                                    */
 /* ======================================================================= */
 

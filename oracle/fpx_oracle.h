@@ -138,6 +138,17 @@ int  orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
 int  orc_search_hits(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
                      uint32_t *ids, uint64_t *commit_ids, uint32_t *scores, uint32_t cap);
 
+/* ---- SegmentMerger (src/segment_merger.zig:85-151): prepare() + the read()/advance() k-way merge ----
+ * `collection` answers hasNewerCommit; `sources` are segments of it, oldest to newest.  A doc of a source that has a
+ * newer commit in the collection is skipped (its items too); the others keep their alive/tombstone status in the merged
+ * docs map.  min/max_doc_id cover the kept docs (0/0 when none); commit_id is the smallest of the sources
+ * (SegmentInfo.merge, src/segment.zig:38-51).  Outputs are malloc'd (orc_free); doc ids ascending. Returns 0, -1 on OOM,
+ * -2 when there are no sources (error.NoSources). */
+int orc_merge_segments(const orc_snapshot *collection, orc_segment *const *sources, uint32_t n_sources,
+                       uint64_t **items, size_t *num_items,
+                       uint32_t **doc_ids, uint8_t **doc_alive, uint32_t *num_docs,
+                       uint32_t *min_doc_id, uint32_t *max_doc_id, uint64_t *commit_id);
+
 /* ---- seeded synthetic fingerprints (shared definition with the GPU builder) -- */
 uint64_t orc_mix64(uint64_t x);
 /* hash j of document `doc` under `seed`; dist 0 = uniform u32, 1 = 2 % hot pool */

@@ -83,6 +83,7 @@ def lib():
         "orc_snapshot_create": (vp, [vp, C.c_uint32, vp, C.c_uint32]),
         "orc_snapshot_free": (None, [vp]),
         "orc_snapshot_has_newer_commit": (C.c_int, [vp, C.c_uint32, C.c_uint64]),
+        "orc_merge_segments": (C.c_int, [vp, vp, C.c_uint32] + [vp] * 8),
         "orc_default_min_score": (C.c_uint32, [C.c_uint32]),
         "orc_search": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32,
                                  C.POINTER(Stats)]),
@@ -301,6 +302,29 @@ class Snapshot:
 
     def has_newer_commit(self, doc_id, commit_id):
         return bool(lib().orc_snapshot_has_newer_commit(self.h, doc_id, commit_id))
+
+    def merge(self, sources):
+        """SegmentMerger over `sources` (segments of this snapshot, oldest first), src/segment_merger.zig:85-151.
+        Returns dict(items, doc_ids, doc_alive, min_doc_id, max_doc_id, commit_id)."""
+        arr = (C.c_void_p * max(1, len(sources)))(*[s.h for s in sources])
+        ip, dp, ap = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, nd, mn, mx, cid = C.c_size_t(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        rc = lib().orc_merge_segments(self.h, arr, len(sources), C.byref(ip), C.byref(n), C.byref(dp), C.byref(ap),
+                                      C.byref(nd), C.byref(mn), C.byref(mx), C.byref(cid))
+        if rc == -2:
+            raise ValueError("NoSources")
+        if rc != 0:
+            raise MemoryError("orc_merge_segments")
+        items = (np.ctypeslib.as_array(C.cast(ip, C.POINTER(C.c_uint64)), shape=(n.value,)).copy()
+                 if n.value else np.zeros(0, np.uint64))
+        ids = (np.ctypeslib.as_array(C.cast(dp, C.POINTER(C.c_uint32)), shape=(nd.value,)).copy()
+               if nd.value else np.zeros(0, np.uint32))
+        alive = (np.ctypeslib.as_array(C.cast(ap, C.POINTER(C.c_uint8)), shape=(nd.value,)).copy()
+                 if nd.value else np.zeros(0, np.uint8))
+        for q in (ip, dp, ap):
+            lib().orc_free(q)
+        return dict(items=items, doc_ids=ids, doc_alive=alive, min_doc_id=mn.value, max_doc_id=mx.value,
+                    commit_id=cid.value)
 
     def search(self, hashes, max_results=40, min_score=None, min_score_pct=10, with_stats=False):
         q = _u32(np.asarray(hashes, dtype=np.uint64) & 0xFFFFFFFF) if len(hashes) else np.zeros(0, np.uint32)

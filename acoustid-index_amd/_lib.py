@@ -18,6 +18,12 @@ class FpxError(RuntimeError):
 class SearchTimeout(FpxError):
     """error.SearchTimeout (src/MultiIndex.zig:319-322)"""
 
+    def __init__(self, status_or_message, message=None):
+        if message is None:                    # raised by host code (coalescer): message only
+            super().__init__(FPX_E_TIMEOUT, str(status_or_message))
+        else:
+            super().__init__(status_or_message, message)
+
 
 class Result(C.Structure):
     _fields_ = [("id", C.c_uint32), ("score", C.c_uint32)]

@@ -99,6 +99,7 @@ static void segment_free(Segment* s)
     if (s->d_blocks) (void)hipFree(s->d_blocks);
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
+    if (s->d_cont) (void)hipFree(s->d_cont);
     if (s->d_items) (void)hipFree(s->d_items);
     delete s;
 }
@@ -116,12 +117,37 @@ __global__ void k_count_items(const uint8_t* __restrict__ blocks, uint32_t block
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
 }
 
+// cont bit of block b: block b+1 exists and its min_hash equals block b's max hash, i.e. FileSegment.search would
+// also visit block b+1 for that hash (src/FileSegment.zig:153-164).  One word per 32 blocks.
+__global__ void k_build_cont(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
+                             const uint32_t* __restrict__ block_index, uint32_t* __restrict__ cont)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bit = false;
+    if (b + 1u < num_blocks)
+        bit = *reinterpret_cast<const uint32_t*>(blocks + (size_t)(b + 1u) * block_size) == block_index[b];
+    const unsigned long long m = __ballot((int)bit);
+    if ((threadIdx.x & 63u) == 0u && b < num_blocks + 64u) {
+        cont[(b >> 5)] = (uint32_t)m;
+        cont[(b >> 5) + 1u] = (uint32_t)(m >> 32);
+    }
+}
+
 // finish a file segment whose blocks and block index are already in HBM (upload or GPU build)
 int finish_file_segment(Segment* s)
 {
     if (s->num_blocks == 0) { s->num_buckets = 1; s->bucket_shift = 32; }
     int rc = build_bucket_table(s, 0);
     if (rc) return rc;
+    {
+        const size_t words = ((size_t)s->num_blocks + 63) / 64 * 2 + 2;
+        FPX_HIP(hipMalloc(&s->d_cont, words * sizeof(uint32_t)));
+        FPX_HIP(hipMemset(s->d_cont, 0, words * sizeof(uint32_t)));
+        s->device_bytes += words * sizeof(uint32_t);
+        if (s->num_blocks)
+            hipLaunchKernelGGL(k_build_cont, dim3((s->num_blocks + 255) / 256), dim3(256), 0, 0,
+                               s->d_blocks, s->block_size, s->num_blocks, s->d_block_index, s->d_cont);
+    }
     unsigned long long* d_total = nullptr;
     FPX_HIP(hipMalloc(&d_total, 8));
     FPX_HIP(hipMemset(d_total, 0, 8));
@@ -377,7 +403,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         const uint32_t slo = dead.empty() ? 1u : dead.front(), shi = dead.empty() ? 0u : dead.back();
         if (s->kind == 0) {
             SegDesc d{};
-            d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead;
+            d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
             sn->h_file.push_back(d);
@@ -405,7 +431,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         for (Segment* sg : sn->segs) {
             if (sg->kind != 0) continue;
             const SegDesc& d = sn->h_file[fi++];
-            if (d.block_size == 512 && sg->num_items >= (1ull << 20)) lean.push_back(d);
+            if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30)) lean.push_back(d);
             else { gen.push_back(d); if (d.block_size != 512) sn->gen_all_512 = false; }
         }
         sn->n_lean = (uint32_t)lean.size(); sn->n_gen = (uint32_t)gen.size();

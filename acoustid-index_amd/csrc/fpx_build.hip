@@ -358,6 +358,7 @@ static void free_partial_segment(Segment* s)
     if (s->d_blocks) (void)hipFree(s->d_blocks);
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
+    if (s->d_cont) (void)hipFree(s->d_cont);
     delete s;
 }
 

@@ -21,6 +21,7 @@ struct SegDesc {
     const uint32_t* block_index;   // max hash per block (src/filefmt.zig:119)
     const uint32_t* bucket;        // [nbuckets + 1]: lower_bound(block_index, k << bucket_shift)
     const uint32_t* dead;          // sorted ids of this segment's docs that a newer segment mentions
+    const uint32_t* cont;          // bit b: block b+1 starts with block b's last hash (a run may continue there)
     uint32_t num_blocks;
     uint32_t block_size;
     uint32_t bucket_shift;         // bucket of hash h = h >> bucket_shift (32 -> one bucket)
@@ -28,6 +29,7 @@ struct SegDesc {
     uint32_t num_dead;
     uint32_t shadow_lo, shadow_hi; // id range covered by `dead`
     uint32_t pad;
+    uint32_t pad2[2];
 };
 
 // One resident memory segment (src/MemorySegment.zig:27-28).
@@ -68,6 +70,7 @@ struct Segment {
     uint8_t* d_blocks = nullptr; size_t blocks_len = 0; uint32_t block_size = 0;
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
+    uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
     uint64_t num_items = 0;
     // memory
     uint64_t* d_items = nullptr;

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         if (FAST512) {
             const uint32_t nb = __shfl(b0v, (int)g);
             if (nb >> 31) {
-                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + gl * 16u;
                 pre0 = gload_u4(sb);
                 pre1 = gload_u4(sb + 256);
             }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                 // prefetch the blocks of the next iteration while this one is decoded
                 const uint32_t nb = __shfl(b0v, src + 4);
                 if (nb >> 31) {
-                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + gl * 16u;
                     pre0 = gload_u4(sb);
                     pre1 = gload_u4(sb + 256);
                 }
@@ -760,11 +760,15 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
                 any_open = any_open || lo[j] < hi[j];
             }
         }
+        uint32_t cw[LEAN_KPL];
 #pragma unroll
         for (int j = 0; j < LEAN_KPL; ++j) {
             const bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
-            b0v[j] = (lo[j] & 0x7FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
+            cw[j] = valid ? gload_u32(seg.cont + (lo[j] >> 5)) : 0u;           // may the hash's run continue in block lo + 1?
+            b0v[j] = (lo[j] & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
         }
+#pragma unroll
+        for (int j = 0; j < LEAN_KPL; ++j) b0v[j] |= ((cw[j] >> (lo[j] & 31u)) & 1u) << 30;   // bit 30: continuation possible
 
         // ---- phase 2: four probes per iteration, one per 16-lane row, blocks prefetched one iteration ahead
         constexpr uint32_t iters = 16u * LEAN_KPL;
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
         {
             const uint32_t nb = __shfl(b0v[0], (int)g);
             if (nb >> 31) {
-                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + gl * 16u;
                 pre0 = gload_u4(sb);
                 pre1 = gload_u4(sb + 256);
             }
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
                 for (int jj = 1; jj < LEAN_KPL; ++jj) { if (jn == (uint32_t)jj) bn = b0v[jj]; }
                 const uint32_t nb = __shfl(bn, (int)(((it + 1u) & 15u) * 4u + g));
                 if (nb >> 31) {
-                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + gl * 16u;
+                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + gl * 16u;
                     pre0 = gload_u4(sb);
                     pre1 = gload_u4(sb + 256);
                 }
@@ -909,8 +913,9 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
                     cnt += __popc(erow1);
                     if (two) { elast = erow1; qlast = swap12 ? q1 : q2; }
                 }
-                // a run that reaches the block's last item may continue in the next block: let k_probe finish it
-                if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && (pbv & 0x7FFFFFFFu) + 1u < seg.num_blocks) defer = true;
+                // a run that reaches the block's last item continues in the next block when that one starts with the same hash
+                // (the segment's continuation bitmap): let k_probe finish it
+                if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && ((pbv >> 30) & 1u) != 0u) defer = true;
             }
             bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
             if (seg.num_dead != 0u) {
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
 // ------------------------------------------------------------------------------------------------
 constexpr int L8_WG = 256;                 // 4 waves: LDS per workgroup stays near 30 KB (5 workgroups per CU)
 constexpr int L8_WAVES = L8_WG / 64;
-constexpr int L8_SLOT = 544;               // LDS bytes per staged block
+constexpr int L8_SLOT = 528;               // LDS bytes per staged block: 132 dwords, so the 8 groups of a wave start 4 banks apart
 
 struct LeanLut {
     uint32_t a[2][256];    // as DecodeLut::a
@@ -1141,11 +1146,15 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                 any_open = any_open || lo[j] < hi[j];
             }
         }
+        uint32_t cw[LEAN_KPL];
 #pragma unroll
         for (int j = 0; j < LEAN_KPL; ++j) {
             const bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
-            b0v[j] = (lo[j] & 0x7FFFFFFFu) | (valid ? 0x80000000u : 0u);
+            cw[j] = valid ? gload_u32(seg.cont + (lo[j] >> 5)) : 0u;           // may the hash's run continue in block lo + 1?
+            b0v[j] = (lo[j] & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
         }
+#pragma unroll
+        for (int j = 0; j < LEAN_KPL; ++j) b0v[j] |= ((cw[j] >> (lo[j] & 31u)) & 1u) << 30;   // bit 30: continuation possible
 
         // ---- phase 2: eight probes per iteration, one per 8-lane group, blocks prefetched one iteration ahead
         constexpr uint32_t iters = 8u * LEAN_KPL;
@@ -1153,7 +1162,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
         {
             const uint32_t nb = __shfl(b0v[0], (int)g);
             if (nb >> 31) {
-                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + l * 16u;
+                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + l * 16u;
                 pre0 = gload_u4(sb); pre1 = gload_u4(sb + 128); pre2 = gload_u4(sb + 256); pre3 = gload_u4(sb + 384);
             }
         }
@@ -1179,7 +1188,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                 for (int jj = 1; jj < LEAN_KPL; ++jj) { if (jn == (uint32_t)jj) bn = b0v[jj]; }
                 const uint32_t nb = __shfl(bn, (int)(((it + 1u) & 7u) * 8u + g));
                 if (nb >> 31) {
-                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x7FFFFFFFu) * 512u + l * 16u;
+                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + l * 16u;
                     pre0 = gload_u4(sb); pre1 = gload_u4(sb + 128); pre2 = gload_u4(sb + 256); pre3 = gload_u4(sb + 384);
                 }
             }
@@ -1295,8 +1304,9 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                     cnt += __popc(erow1);
                     if (two) { elast = erow1; qlast = qc1 + 1u; }
                 }
-                // a run that reaches the block's last item may continue in the next block: let k_probe finish it
-                if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && (pbv & 0x7FFFFFFFu) + 1u < seg.num_blocks) defer = true;
+                // a run that reaches the block's last item continues in the next block when that one starts with the same hash
+                // (the segment's continuation bitmap): let k_probe finish it
+                if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && ((pbv >> 30) & 1u) != 0u) defer = true;
             }
             bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
             if (seg.num_dead != 0u) {

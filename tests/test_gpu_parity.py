@@ -217,7 +217,9 @@ def test_lean_kernel_and_deferred_pass(env, dist):
     qs = [flat[int(off[i]):int(off[i + 1])] for i in range(nq)]
     got, st = p.check(qs, fpx.http_options())
     assert st.probes >= (1 << 20) - 4096
-    assert st.probe_kernel_bytes > 0 and st.probe_kernel_bytes < st.algorithmic_bytes   # lean + deferred both worked
+    assert 0 < st.probe_kernel_bytes <= st.algorithmic_bytes                            # the lean kernel worked ...
+    if dist == 1:
+        assert st.probe_kernel_bytes < st.algorithmic_bytes                             # ... and so did the deferred pass
     if dist == 0:
         assert st.generic_iters < st.probes // 8        # the lean path carried the bulk
     assert all(g and g[0][0] == int(t) for g, t in zip(got, targets))

@@ -425,7 +425,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         if (e == hipSuccess) e = hipMemcpy(sn->d_file, sn->h_file.data(), sn->n_file * sizeof(SegDesc), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && sn->n_file) {
-        // k_probe_lean pays off on 512-B segments dense enough that hash deltas fit two bytes (>= 2^20 items)
+        // k_probe_lean8 pays off on 512-B segments dense enough that hash deltas fit two bytes (>= 2^20 items)
         std::vector<SegDesc> lean, gen;
         size_t fi = 0;
         for (Segment* sg : sn->segs) {

@@ -52,7 +52,7 @@ enum Counter : int {
     CTR_PROBES = 5,      // valid (unique hash, file segment) probes
     CTR_MAXSCORE = 6,
     CTR_GENERIC = 7,     // wave iterations of k_probe that took the generic (per-value) decode path    // largest score of any candidate (sizes the score field of the candidate key)
-    CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean (ctr_off = 8)
+    CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
 };
 
 // ---------------------------------------------------------------- host objects

@@ -23,7 +23,6 @@
 
 #include <algorithm>
 #include <chrono>
-#include <cstdlib>
 
 #include "fpx_internal.h"
 
@@ -147,7 +146,7 @@ struct ProbeArgs {
     uint32_t* def_list;        // [n_file][def_cap]
     unsigned int* def_count;   // [n_file]
     uint32_t def_cap;
-    uint32_t ctr_off;          // 0, or 8 for k_probe_lean: which statistics slots of `counters` to use
+    uint32_t ctr_off;          // 0, or 8 for k_probe_lean8: which statistics slots of `counters` to use
 };
 
 // ---- decode tables (the GPU form of the reference's 256-entry shuffle/length tables, src/streamvbyte.zig:76-211)
@@ -355,7 +354,7 @@ __device__ __forceinline__ void stage_flush(const HitStage& st, const ProbeArgs&
 // One wave works on FOUR probes at a time, one per 16-lane row; lane r of a row owns quads 2r and 2r+1
 // of every 32-quad chunk of the block (a 512-B block holds ~29 quads).  Blocks are prefetched one
 // iteration ahead into registers (FAST512) so that ~40 random 512-B reads per SIMD are in flight.
-constexpr int LEAN_KPL = 4;        // keys per lane per round in k_probe_lean (256 pairs per wave per round)
+constexpr int LEAN_KPL = 4;        // keys per lane per round in k_probe_lean8 (256 pairs per wave per round)
 constexpr int DEF_STAGE_CAP = 512; // LDS staging of deferred pair indices per workgroup
 constexpr int PWG = 512;           // probe workgroup: 8 waves share the decode tables and the hit staging
 constexpr int PWAVES = PWG / 64;
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                               : wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
         bool valid;
         if (DEFERRED) {
-            // p indexes this segment's list of deferred probes (already deduplicated and counted by k_probe_lean)
+            // p indexes this segment's list of deferred probes (already deduplicated and counted by k_probe_lean8)
             const uint32_t n = min(a.def_count[blockIdx.y], a.def_cap);
             valid = lane < a.ppw && p < (uint64_t)n;
             if (valid) p = gload_u32(a.def_list + (size_t)blockIdx.y * a.def_cap + p);
@@ -684,302 +683,16 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     }
 }
 
-// ---- the lean probe kernel (snapshots whose file segments all use 512-B blocks) ---------------------
-// Straight-line version of the common case: the probe's first block, every hash delta one byte, at most one
-// candidate quad, no continuation into the next block.  Rows that need anything else write their pair index to
-// the segment's deferred list and are finished by k_probe<.., DEFERRED>; the lean loop carries no rare-case state.
-__global__ __launch_bounds__(PWG) void k_probe_lean(ProbeArgs a)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);                  // STAGE_CAP records
-    DecodeLut* lut = reinterpret_cast<DecodeLut*>(smem + STAGE_CAP * sizeof(uint64_t));
-    uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut);   // PWAVES * 4 * 544 bytes
-    __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
-    __shared__ uint32_t def_stage[DEF_STAGE_CAP];
-    __shared__ uint32_t def_n, def_base;
-    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
-    const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
-
-    constexpr uint32_t SLOT = 544u;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 4, gl = lane & 15u;
-    const SegDesc seg = a.segs[blockIdx.y];
-    uint8_t* blk = blkmem + (size_t)(wave * 4u + g) * SLOT;
-    const uint32_t blko = (uint32_t)(blk - smem);
-    const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
-
-    if (tid < 256u) init_lut(lut, tid);
-    if (tid == 0) {
-        stage_count = 0; stage_valid = STAGE_CAP; def_n = 0;
-        wg_blocks = 0; wg_docs = 0; wg_probes = 0;
-    }
-    __syncthreads();
-
-    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
-    const uint32_t k = gl & 3u;
-    const uint32_t qa = 2u * gl;
-
-    // One round = LEAN_KPL * 64 pairs per wave.  Phase 1 walks the LEAN_KPL lookups of a lane in lockstep so that
-    // their dependent loads (bucket table, block_index binary search) overlap: the walk costs one latency chain
-    // per round, and a longer round amortises it over more probes.
-    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * 64u * LEAN_KPL) * a.rounds;
-    for (uint32_t round = 0; round < a.rounds; ++round) {
-        // ---- phase 1: LEAN_KPL pairs per lane: dedup + block lookup
-        const uint64_t wave_base = wg_base + (uint64_t)round * (PWAVES * 64u * LEAN_KPL) + (uint64_t)wave * (64u * LEAN_KPL);
-        const uint32_t wave_pair0 = (uint32_t)wave_base;                    // pair index of lane 0, key 0 (P < 2^32)
-        uint32_t h[LEAN_KPL], q[LEAN_KPL], b0v[LEAN_KPL], lo[LEAN_KPL], hi[LEAN_KPL];
-        bool any_open = false;
-#pragma unroll
-        for (int j = 0; j < LEAN_KPL; ++j) {
-            const uint64_t p = wave_base + (uint64_t)j * 64u + lane;
-            bool valid = p < a.P;
-            const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
-            if (valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;      // dedupSorted, src/Index.zig:489-499
-            h[j] = (uint32_t)(key >> a.qb);
-            q[j] = (uint32_t)key & qmask;
-            lo[j] = 0; hi[j] = 0;
-            if (valid) {
-                my_probes += 1;
-                const uint32_t kb = seg.bucket_shift >= 32u ? 0u : (h[j] >> seg.bucket_shift);
-                lo[j] = gload_u32(seg.bucket + kb);
-                hi[j] = gload_u32(seg.bucket + kb + 1);
-            }
-            b0v[j] = valid ? 1u : 0u;                                          // provisional: validity flag
-            any_open = any_open || lo[j] < hi[j];
-        }
-        while (__any((int)any_open)) {                                         // lockstep binary search (src/FileSegment.zig:145-151)
-            any_open = false;
-            uint32_t mid[LEAN_KPL], mv[LEAN_KPL];
-#pragma unroll
-            for (int j = 0; j < LEAN_KPL; ++j) {
-                mid[j] = (lo[j] + hi[j]) >> 1;
-                mv[j] = lo[j] < hi[j] ? gload_u32(seg.block_index + mid[j]) : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < LEAN_KPL; ++j) {
-                if (lo[j] < hi[j]) { if (mv[j] < h[j]) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
-                any_open = any_open || lo[j] < hi[j];
-            }
-        }
-        uint32_t cw[LEAN_KPL];
-#pragma unroll
-        for (int j = 0; j < LEAN_KPL; ++j) {
-            const bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
-            cw[j] = valid ? gload_u32(seg.cont + (lo[j] >> 5)) : 0u;           // may the hash's run continue in block lo + 1?
-            b0v[j] = (lo[j] & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
-        }
-#pragma unroll
-        for (int j = 0; j < LEAN_KPL; ++j) b0v[j] |= ((cw[j] >> (lo[j] & 31u)) & 1u) << 30;   // bit 30: continuation possible
-
-        // ---- phase 2: four probes per iteration, one per 16-lane row, blocks prefetched one iteration ahead
-        constexpr uint32_t iters = 16u * LEAN_KPL;
-        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
-        {
-            const uint32_t nb = __shfl(b0v[0], (int)g);
-            if (nb >> 31) {
-                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + gl * 16u;
-                pre0 = gload_u4(sb);
-                pre1 = gload_u4(sb + 256);
-            }
-        }
-#pragma unroll 1
-        for (uint32_t it = 0; it < iters; ++it) {
-            const uint32_t j = it >> 4;                                       // which of the lane's keys (wave-uniform)
-            const int src = (int)((it & 15u) * 4u + g);
-            uint32_t hj = h[0], qj = q[0], bj = b0v[0];
-#pragma unroll
-            for (int jj = 1; jj < LEAN_KPL; ++jj) { if (j == (uint32_t)jj) { hj = h[jj]; qj = q[jj]; bj = b0v[jj]; } }
-            const uint32_t ph = __shfl(hj, src);
-            const uint32_t pq = __shfl(qj, src);
-            const uint32_t pbv = __shfl(bj, src);
-            const bool pact = (pbv >> 31) != 0u;
-            *reinterpret_cast<uint4*>(blk + gl * 16u) = pre0;
-            *reinterpret_cast<uint4*>(blk + 256u + gl * 16u) = pre1;
-            if (it + 1u < iters) {
-                const uint32_t jn = (it + 1u) >> 4;
-                uint32_t bn = b0v[0];
-#pragma unroll
-                for (int jj = 1; jj < LEAN_KPL; ++jj) { if (jn == (uint32_t)jj) bn = b0v[jj]; }
-                const uint32_t nb = __shfl(bn, (int)(((it + 1u) & 15u) * 4u + g));
-                if (nb >> 31) {
-                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + gl * 16u;
-                    pre0 = gload_u4(sb);
-                    pre1 = gload_u4(sb + 256);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-
-            // -- header (src/block.zig:46-50); rows without a probe decode stale bytes and are masked at the end
-            const uint32_t* hw = reinterpret_cast<const uint32_t*>(blk);
-            const uint32_t min_hash = hw[0];
-            const uint32_t n_items = hw[1] & 0xFFFFu;
-            const uint32_t doff = min(hw[1] >> 16, 504u);
-            const uint32_t nq = (n_items + 3u) >> 2;
-            const bool visited = pact & (min_hash <= ph);                      // src/FileSegment.zig:164
-            bool defer = (nq > 32u) | ((n_items & 3u) != 0u);                  // multi-chunk block / partial last quad
-
-            // -- level 1: quad sums (see k_probe for the scheme)
-            uint32_t cc = *reinterpret_cast<const uint16_t*>(blk + 8u + qa);
-            cc = qa + 1u < nq ? cc : (qa < nq ? (cc & 0xFFu) : 0u);
-            const uint32_t ca = cc & 0xFFu, cb = cc >> 8;
-            const uint2 fa = lut->f[ca], fb = lut->f[cb];
-            const uint32_t la = fa.x >> 24, lb = fb.x >> 24;
-            const uint32_t hincl = scan16(la + lb);
-            const uint32_t pa = (8u + nq + hincl - la - lb) & 1023u, pb2 = pa + la;
-            const uint32_t ra = lds_u32u(smem, blko + pa), rb = lds_u32u(smem, blko + pb2);
-            uint32_t sa, sb;
-            if (__any((int)((cc & 0xAAAAu) != 0u))) {
-                // some delta of this wave's blocks needs two bytes (sparser segments): 8-byte data windows
-                const uint32_t ra1 = lds_u32u(smem, blko + pa + 4u), rb1 = lds_u32u(smem, blko + pb2 + 4u);
-                sa = quad_sum2(ra, ra1, fa.y, lut->fh[ca]);
-                sb = quad_sum2(rb, rb1, fb.y, lut->fh[cb]);
-            } else {
-                sa = quad_sum1(ra, fa.y);
-                sb = quad_sum1(rb, fb.y);
-            }
-            const uint32_t vincl = scan16(sa + sb);
-            const uint32_t ua = ph - min_hash - (vincl - sa - sb);
-            const uint32_t ub = ua - sa;
-            // (bitwise, not short-circuit: the conditions are cheap and branches cost exec-mask traffic)
-            const bool canda = (qa < nq) & ((ua - 1u < sa) | ((ua == 0u) & ((ca & 3u) == 0u)));
-            const bool candb = (qa + 1u < nq) & ((ub - 1u < sb) | ((ub == 0u) & ((cb & 3u) == 0u)));
-            const uint32_t rab = row_bits(__ballot((int)canda), g) | (row_bits(__ballot((int)candb), g) << 16);
-            // a 4-byte delta (code 3) anywhere in the block: the generic pass decides
-            defer = defer | (row_bits(__ballot((int)((cc & (cc >> 1) & 0x5555u) != 0u)), g) != 0u);
-            // One candidate quad is the rule.  Two ADJACENT candidates mean a run of equal hashes crosses a quad
-            // boundary: the upper one then starts exactly at the target (relative target 0) and holds the run's
-            // zero-delta tail.  Anything else (three candidates = a run longer than a quad, ...) is deferred.
-            const uint32_t rab2 = rab & (rab - 1u);                         // != 0: more than one candidate
-            const uint32_t b1 = rab ? (uint32_t)__builtin_ctz(rab) : 0u;
-            const uint32_t q1 = 2u * (b1 & 15u) + (b1 >> 4);
-            const uint32_t ncand = rab == 0u ? 0u : (rab2 == 0u ? 1u : 2u);  // 2 stands for "two or more"
-            uint32_t b2 = 0, q2 = 0;
-            bool two = false, swap12 = false;
-            if (__any((int)(rab2 != 0u))) {                                 // rare (a run crossing a quad boundary)
-                b2 = rab2 ? (uint32_t)__builtin_ctz(rab2) : 0u;
-                q2 = 2u * (b2 & 15u) + (b2 >> 4);
-                two = rab2 != 0u && (rab2 & (rab2 - 1u)) == 0u && (q1 + 1u == q2 || q2 + 1u == q1);
-                swap12 = two && q2 < q1;
-                defer = defer || (rab2 != 0u && !two);
-            }
-            const uint32_t blo = swap12 ? b2 : b1, bhi = swap12 ? b1 : b2;
-
-            // -- level 2: lanes 0..3 of the row decode the candidate quad(s)
-            const uint32_t packab = pa | (ca << 10) | (cb << 18) | (la << 26);
-            const int owner0 = (int)((lane & 48u) | (blo & 15u));
-            const uint32_t x0 = __shfl(packab, owner0);
-            const uint32_t ut0 = __shfl((blo >> 4) ? ub : ua, owner0);
-            const bool useb0 = (blo >> 4) != 0u;
-            const uint32_t val0 = decode_one<0>(lut, smem, blko + (x0 & 1023u) + (useb0 ? (x0 >> 26) : 0u),
-                                                useb0 ? ((x0 >> 18) & 0xFFu) : ((x0 >> 10) & 0xFFu), k);
-            const bool live = visited & !defer & (gl < 4u);
-            const bool ek0 = live & (ncand != 0u) & (scan4(val0) == ut0);
-            bool ek1 = false;
-            const int owner1 = (int)((lane & 48u) | (bhi & 15u));
-            if (__any((int)(two && live))) {
-                const uint32_t x1 = __shfl(packab, owner1);
-                const bool useb1 = (bhi >> 4) != 0u;
-                const uint32_t val1 = decode_one<0>(lut, smem, blko + (x1 & 1023u) + (useb1 ? (x1 >> 26) : 0u),
-                                                    useb1 ? ((x1 >> 18) & 0xFFu) : ((x1 >> 10) & 0xFFu), k);
-                ek1 = live && two && scan4(val1) == 0u;            // the leading zero deltas of the upper quad
-            }
-            const unsigned long long me0 = __ballot((int)ek0), me1 = __ballot((int)ek1);
-            uint32_t cnt = 0, doc0 = 0, doc1 = 0;
-            if ((me0 | me1) != 0ull) {
-                // -- docids of the run
-                const uint32_t dcc = lds_u32u(smem, blko + 8u + doff + qa);
-                const uint32_t da = dcc & 0xFFu, db = (dcc >> 8) & 0xFFu;
-                const uint32_t dla = qa < nq ? (lut->a[1][da] >> 24) : 0u;
-                const uint32_t dlb = qa + 1u < nq ? (lut->a[1][db] >> 24) : 0u;
-                const uint32_t dincl = scan16(dla + dlb);
-                const uint32_t dpa = (8u + doff + nq + dincl - dla - dlb) & 1023u;
-                const uint32_t dpackab = dpa | (da << 10) | (db << 18) | (dla << 26);
-                const uint32_t y0 = __shfl(dpackab, owner0);
-                const uint32_t dv0 = decode_one<1>(lut, smem, blko + (y0 & 1023u) + (useb0 ? (y0 >> 26) : 0u),
-                                                   useb0 ? ((y0 >> 18) & 0xFFu) : ((y0 >> 10) & 0xFFu), k);
-                doc0 = seg.min_doc_id + scan4(ek0 ? dv0 : 0u);
-                const uint32_t erow0 = row_bits(me0, g);
-                cnt = __popc(erow0);
-                uint32_t elast = erow0, qlast = swap12 ? q2 : q1;              // the quad that ends the run
-                if (me1 != 0ull) {
-                    const uint32_t y1 = __shfl(dpackab, owner1);
-                    const bool useb1 = (bhi >> 4) != 0u;
-                    const uint32_t dv1 = decode_one<1>(lut, smem, blko + (y1 & 1023u) + (useb1 ? (y1 >> 26) : 0u),
-                                                       useb1 ? ((y1 >> 18) & 0xFFu) : ((y1 >> 10) & 0xFFu), k);
-                    // the run continues from the lower quad's last item (lane 3 of the row)
-                    const uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)doc0, 0xFF, 0xF, 0xF, false);
-                    doc1 = carry + scan4(ek1 ? dv1 : 0u);
-                    const uint32_t erow1 = row_bits(me1, g);
-                    cnt += __popc(erow1);
-                    if (two) { elast = erow1; qlast = swap12 ? q1 : q2; }
-                }
-                // a run that reaches the block's last item continues in the next block when that one starts with the same hash
-                // (the segment's continuation bitmap): let k_probe finish it
-                if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && ((pbv >> 30) & 1u) != 0u) defer = true;
-            }
-            bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
-            if (seg.num_dead != 0u) {
-                if (keep0 && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc0)) keep0 = false;
-                if (keep1 && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc1)) keep1 = false;
-            }
-            // -- bookkeeping per row
-            if (gl == 0u && visited) {
-                if (defer) {
-                    const uint32_t pair = wave_pair0 + j * 64u + (it & 15u) * 4u + g;
-                    const uint32_t slot = atomicAdd(&def_n, 1u);
-                    if (slot < (uint32_t)DEF_STAGE_CAP) {
-                        def_stage[slot] = pair;
-                    } else {                                   // staging full: append directly
-                        const unsigned int gs = atomicAdd(&a.def_count[blockIdx.y], 1u);
-                        if (gs < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + gs] = pair;
-                    }
-                } else {
-                    my_blocks += 1; my_docs += cnt;
-                }
-            }
-            // -- emission (wave-uniform control flow)
-            const int nsets = me1 != 0ull ? 2 : 1;
-            for (int e = 0; e < nsets; ++e) {
-                stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane);
-            }
-        }
-
-        // ---- flush the LDS staging buffer at round boundaries
-        stage_flush(hs, a, round + 1u == a.rounds, tid, PWG);
-        // ---- flush the deferred-probe staging (one global atomic per round)
-        {
-            const uint32_t dn = min(def_n, (uint32_t)DEF_STAGE_CAP);
-            if (dn != 0u) {
-                if (tid == 0) def_base = atomicAdd(&a.def_count[blockIdx.y], dn);
-                __syncthreads();
-                for (uint32_t i = tid; i < dn; i += PWG)
-                    if (def_base + i < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + def_base + i] = def_stage[i];
-                __syncthreads();
-                if (tid == 0) def_n = 0;
-                __syncthreads();
-            }
-        }
-    }
-
-    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
-    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
-    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
-    __syncthreads();
-    if (tid == 0) {
-        if (wg_blocks) {
-            atomicAdd(&a.counters[a.ctr_off + CTR_BLOCKS], wg_blocks);
-            atomicAdd(&a.counters[a.ctr_off + CTR_BYTES], wg_blocks * 512ull);
-        }
-        if (wg_docs) atomicAdd(&a.counters[a.ctr_off + CTR_DOCS], wg_docs);
-        if (wg_probes) atomicAdd(&a.counters[a.ctr_off + CTR_PROBES], wg_probes);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// 3b. k_probe_lean8: the lean kernel with EIGHT probes per wave (8 lanes per probe, lane l owns quads 4l..4l+3).
-// k_probe_lean is VALU-issue bound and most of its per-iteration work (key broadcast, prefetch addressing, header,
-// candidate resolution, the 4-lane quad decode, docid stage, emission) does not depend on how many probes share
-// the wave; halving the lanes per probe halves that part per probe.  Same results, same deferral rules.
+// 3b. k_probe_lean8: the lean probe kernel (dense 512-B segments, big batches) -- the dominant kernel.
+// Straight-line version of the common case: the probe's first block, every hash delta at most two bytes, at most two
+// adjacent candidate quads, no continuation into the next block.  Rows that need anything else write their pair
+// index to the segment's deferred list and are finished by k_probe<.., DEFERRED>; the loop carries no rare-case state.
+//
+// EIGHT probes per wave: 8 lanes per probe, lane l owns quads 4l..4l+3 of the block (a 512-B block holds ~29 quads).
+// The kernel is VALU-issue bound, and most of its per-iteration work (key broadcast, prefetch addressing, header,
+// candidate resolution, the 4-lane quad decode, docid stage, emission) does not depend on how many probes share the
+// wave: the 16-lanes-per-probe predecessor spent 48 VALU instructions per probe, this one 33.
 // ------------------------------------------------------------------------------------------------
 constexpr int L8_WG = 256;                 // 4 waves: LDS per workgroup stays near 30 KB (5 workgroups per CU)
 constexpr int L8_WAVES = L8_WG / 64;
@@ -1109,7 +822,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
 
     const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(L8_WAVES * 64u * LEAN_KPL) * a.rounds;
     for (uint32_t round = 0; round < a.rounds; ++round) {
-        // ---- phase 1 (as k_probe_lean): LEAN_KPL pairs per lane, dedup + block lookup in lockstep
+        // ---- phase 1: LEAN_KPL pairs per lane, dedup + block lookup in lockstep
         const uint64_t wave_base = wg_base + (uint64_t)round * (L8_WAVES * 64u * LEAN_KPL) + (uint64_t)wave * (64u * LEAN_KPL);
         const uint32_t wave_pair0 = (uint32_t)wave_base;
         uint32_t h[LEAN_KPL], q[LEAN_KPL], b0v[LEAN_KPL], lo[LEAN_KPL], hi[LEAN_KPL];
@@ -1823,22 +1536,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const bool lean = snap->n_lean != 0 && !force_generic && P < 0xFFFFFFFFull && total >= (1ull << 20);
             FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (lean) {
-                // main kernel: k_probe_lean over the dense 512-B segments
+                // main kernel: k_probe_lean8 over the dense 512-B segments
                 FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));
-                const size_t lds_lean = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * 544;
                 ProbeArgs l = a;
                 l.segs = snap->d_lean; l.rounds = 1u; l.ctr_off = 8u;
-                static const bool use_lean8 = [] { const char* e = getenv("FPX_LEAN8"); return !e || atoi(e) != 0; }();
-                if (use_lean8) {
-                    const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
-                    const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;
-                    const uint32_t gx8 = (uint32_t)((P + per_wg_8 - 1) / per_wg_8);
-                    hipLaunchKernelGGL(k_probe_lean8, dim3(gx8, snap->n_lean), dim3(L8_WG), lds8, st, l);
-                } else {
-                    const uint64_t per_wg_l = (uint64_t)PWAVES * 64u * LEAN_KPL * l.rounds;
-                    const uint32_t gxl = (uint32_t)((P + per_wg_l - 1) / per_wg_l);
-                    hipLaunchKernelGGL(k_probe_lean, dim3(gxl, snap->n_lean), dim3(PWG), lds_lean, st, l);
-                }
+                const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
+                const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;
+                const uint32_t gx8 = (uint32_t)((P + per_wg_8 - 1) / per_wg_8);
+                hipLaunchKernelGGL(k_probe_lean8, dim3(gx8, snap->n_lean), dim3(L8_WG), lds8, st, l);
                 FPX_HIP(hipEventRecord(ws->ev_probe1, st));
                 // auxiliary passes: the rows the lean kernel deferred, and the segments it does not suit
                 ProbeArgs d = a;
@@ -1895,7 +1600,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
     }
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
-    // statistics: slots 0..7 are written by k_probe (generic / deferred / memory), 8..15 by k_probe_lean
+    // statistics: slots 0..7 are written by k_probe (generic / deferred / memory), 8..15 by k_probe_lean8
     const unsigned long long c_blocks = ws->h_counters[CTR_BLOCKS] + ws->h_counters[8 + CTR_BLOCKS],
                              c_docs = ws->h_counters[CTR_DOCS] + ws->h_counters[8 + CTR_DOCS],
                              c_bytes = ws->h_counters[CTR_BYTES] + ws->h_counters[8 + CTR_BYTES],

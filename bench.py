@@ -246,7 +246,7 @@ def main():
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             c = tr["config"]
             if world == 1 and (c["docs"], c["segments"], c["hashes_per_doc"], c["batch"], c["query_len"]) == (docs, S, H, B, args.query_len):
-                traffic = tr["k_probe_lean"]["hbm_read_bytes_per_launch_corrected"]
+                traffic = tr["k_probe_lean8"]["hbm_read_bytes_per_launch_corrected"]
         except (OSError, KeyError, ValueError):
             pass
         result = {
@@ -260,7 +260,7 @@ def main():
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "index_build_seconds": round(build_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean8", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                          "all_probe_passes": {"algorithmic_bytes_per_step": agg["bytes"] / max(1, args.steps),

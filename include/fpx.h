@@ -64,7 +64,7 @@ typedef struct {
     uint64_t hits;              /* postings accumulated after supersession filtering */
     uint64_t algorithmic_bytes; /* sum over visited blocks of that segment's block_size */
     uint64_t candidates;        /* (query, doc) pairs with score >= min_score */
-    float    probe_kernel_ms;   /* HIP-event time of the MAIN posting decode + match kernel (k_probe_lean when the
+    float    probe_kernel_ms;   /* HIP-event time of the MAIN posting decode + match kernel (k_probe_lean8 when the
                                    batch is large and segments are dense 512-B ones, else k_probe) */
     float    total_gpu_ms;      /* first launch -> last kernel of this call, on the call's stream */
     uint32_t probe_launches;    /* launches of the main probe kernel */

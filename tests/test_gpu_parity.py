@@ -202,7 +202,7 @@ def test_cpp_host_mirror_example(env):
 
 @pytest.mark.parametrize("dist", [0, 1])
 def test_lean_kernel_and_deferred_pass(env, dist):
-    """Batches with >= 2^20 probes on 512-B segments run k_probe_lean (two-level match) and finish the rows it
+    """Batches with >= 2^20 probes on 512-B segments run k_probe_lean8 (two-level match) and finish the rows it
     cannot handle (wide deltas, runs crossing quads/blocks, > 32 quads) with the deferred generic pass.
     dist = 1 (hot pool) makes a large share of the probes take the deferred pass."""
     fpx, oracle, Pair, ctx = env

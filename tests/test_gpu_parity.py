@@ -277,3 +277,46 @@ def test_cpp_request_coalescer(env):
     subprocess.check_call(["bash", os.path.join(host, "build_host.sh")], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(host, "test_coalescer")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env):
+    """The lean path on segments whose docs are partly superseded (per-posting `dead` filter), with a segment of sparse
+    ids (docid deltas of 3 and 4 bytes, ids above 2^24), tombstones and inserts in memory segments on top."""
+    fpx, oracle, Pair, ctx = env
+    seed, H, per = 733, 128, 9000                      # 1.15 M items per file segment: lean-eligible
+    p = Pair(ctx)
+    a = fpx.synth.synth_items(seed, 1, per, H)
+    p.add_file(a, 1, per, 1, np.arange(1, per + 1))
+    # segment B re-inserts ids 5001..9000 with fresh hashes (A's copies become dead) and adds 9001..14000
+    b = fpx.synth.synth_items(seed + 1, 5001, per, H)
+    p.add_file(b, 5001, 5000 + per, 2, np.arange(5001, 5001 + per))
+    # segment C: sparse ids 20000 + 3001 * i (up to 27 M: 4-byte docid values, 2- and 3-byte deltas inside runs)
+    c = fpx.synth.synth_items(seed + 2, 1, per, H)
+    ids_c = (20000 + 3001 * np.arange(per)).astype(np.uint64)
+    c = np.sort((c & ~np.uint64(0xFFFFFFFF)) | ids_c[(c & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1])
+    p.add_file(c, int(ids_c[0]), int(ids_c[-1]), 3, ids_c.astype(np.uint32))
+    # memory segments: tombstones over all three, one overwrite, one fresh doc
+    h_a = ((a[(a & np.uint64(0xFFFFFFFF)) == 77][:5]) >> np.uint64(32)).astype(np.uint32).tolist()
+    p.add_memory_changes([("delete", 10), ("delete", 6000), ("delete", int(ids_c[5])), ("insert", 77, h_a + [1, 2, 3])], 4)
+    p.add_memory_changes([("insert", 30000000, [9, 8, 7]), ("delete", 12000)], 5)
+    p.finish()
+    rng = np.random.default_rng(3)
+    nq = 360
+    qs = []
+    for i in range(nq):
+        src = (a, b, c)[i % 3]
+        doc = np.uint64(src[rng.integers(0, len(src))] & np.uint64(0xFFFFFFFF))
+        hs = (src[(src & np.uint64(0xFFFFFFFF)) == doc] >> np.uint64(32)).astype(np.uint32)
+        noise = rng.integers(0, 1 << 32, 1000 - len(hs), dtype=np.uint64).astype(np.uint32)
+        qs.append(np.concatenate([hs, noise]))
+    # some queries aimed at the superseded / deleted docs and at the memory segments
+    for doc, src in ((10, a), (6000, a), (6000, b), (12000, b), (77, a), (int(ids_c[5]), c)):
+        hs = (src[(src & np.uint64(0xFFFFFFFF)) == np.uint64(doc)] >> np.uint64(32)).astype(np.uint32)
+        qs.append(np.concatenate([hs, np.array([1, 2, 3, 9, 8, 7], np.uint32), rng.integers(0, 1 << 32, 1000 - len(hs) - 6, dtype=np.uint64).astype(np.uint32)]))
+    got, st = p.check(qs, fpx.SearchOptions(max_results=20, min_score=1, min_score_pct=0))
+    assert st.probes >= (1 << 20)
+    assert 0 < st.probe_kernel_bytes                                                   # the lean kernel ran
+    top = {i: (g[0] if g else None) for i, g in enumerate(got)}
+    assert top[nq + 0] is None or top[nq + 0][0] != 10                                # deleted
+    assert all(r[0] != 6000 for r in got[nq + 1])                                     # A's copy of 6000 is superseded, B's deleted
+    assert got[nq + 4][0][0] == 77 and got[nq + 4][0][1] >= 8                         # overwritten in a memory segment

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 
 #include "fpx_internal.h"
 
@@ -1533,7 +1534,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
-            const bool lean = snap->n_lean != 0 && !force_generic && P < 0xFFFFFFFFull && total >= (1ull << 20);
+            static const uint64_t lean_min = [] { const char* e = getenv("FPX_LEAN_MIN"); return e ? strtoull(e, nullptr, 0) : (1ull << 16); }();
+            const bool lean = snap->n_lean != 0 && !force_generic && P < 0xFFFFFFFFull && total >= lean_min;
             FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (lean) {
                 // main kernel: k_probe_lean8 over the dense 512-B segments

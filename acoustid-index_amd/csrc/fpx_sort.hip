@@ -8,11 +8,16 @@
 
 namespace fpx {
 
+// rocPRIM switches to a merge sort (dozens of small launches) below 2^20 keys by default; the batch pipeline sorts
+// 10^5..10^6 keys per stage at small batch sizes, where the Onesweep radix sort (one histogram + one launch per 8 bits)
+// is several times faster.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
+
 size_t sort_u64_temp_bytes(size_t n, unsigned begin_bit, unsigned end_bit)
 {
     size_t bytes = 0;
     rocprim::double_buffer<uint64_t> db(nullptr, nullptr);
-    (void)rocprim::radix_sort_keys(nullptr, bytes, db, n, begin_bit, end_bit, (hipStream_t)0);
+    (void)rocprim::radix_sort_keys<SortConfig>(nullptr, bytes, db, n, begin_bit, end_bit, (hipStream_t)0);
     return bytes;
 }
 
@@ -23,7 +28,7 @@ hipError_t sort_u64(void* temp, size_t temp_bytes, uint64_t* buf0, uint64_t* buf
     if (n == 0) { *result_in = 0; return hipSuccess; }
     if (end_bit <= begin_bit) { *result_in = 0; return hipSuccess; }
     rocprim::double_buffer<uint64_t> db(buf0, buf1);
-    hipError_t e = rocprim::radix_sort_keys(temp, temp_bytes, db, n, begin_bit, end_bit, stream);
+    hipError_t e = rocprim::radix_sort_keys<SortConfig>(temp, temp_bytes, db, n, begin_bit, end_bit, stream);
     *result_in = (db.current() == buf0) ? 0 : 1;
     return e;
 }

@@ -64,7 +64,9 @@ class ShardedReader:
             tables, cnts = tables.cuda(), cnts.cuda()
         else:
             tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)      # RCCL all-gather over xGMI
-        torch.cuda.synchronize()
+        # The collective is ordered on torch's current stream; wait for THAT stream only -- a device-wide synchronize would
+        # also wait for the next batch's probe kernels, which run on libfpx's own streams from another host thread.
+        torch.cuda.current_stream().synchronize()
         return self.fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
 
     def search_resident(self, qb, out=None, out_n=None):

@@ -53,43 +53,6 @@ __device__ __forceinline__ uint4 gload_u4(const uint8_t* p)
 }
 __device__ __forceinline__ uint8_t gload_u8(const uint8_t* p) { return *(const FPX_GLOBAL uint8_t*)p; }
 
-// byte length of the 4 values of one control byte; value i lives in bits 2i..2i+1
-// (src/streamvbyte.zig:178-211).  0124: code c -> c + (c == 3);  1234: code c -> c + 1.
-__device__ __forceinline__ uint32_t len0124(uint32_t c)
-{
-    uint32_t lo = c & 0x55u, hi = (c >> 1) & 0x55u;
-    return __popc(lo) + 2u * __popc(hi) + __popc(lo & hi);
-}
-__device__ __forceinline__ uint32_t len1234(uint32_t c)
-{
-    uint32_t lo = c & 0x55u, hi = (c >> 1) & 0x55u;
-    return 4u + __popc(lo) + 2u * __popc(hi);
-}
-
-// unaligned little-endian u32 from an LDS byte buffer whose base is 4-byte aligned
-__device__ __forceinline__ uint32_t lds_u32(const uint8_t* blk, uint32_t p)
-{
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(blk) + (p >> 2);
-    uint32_t a = w[0], b = w[1];
-    return __builtin_amdgcn_alignbyte(b, a, p & 3u);
-}
-
-__device__ __forceinline__ uint32_t keep_bytes(uint32_t raw, uint32_t nb)
-{
-    return nb >= 4u ? raw : (raw & ((1u << (8u * nb)) - 1u));
-}
-
-// inclusive prefix sum inside each 32-lane half of the wave
-__device__ __forceinline__ uint32_t scan32(uint32_t v, uint32_t sl)
-{
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 32);
-        if (sl >= (uint32_t)d) v += t;
-    }
-    return v;
-}
-
 __device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32_t lo_id, uint32_t hi_id, uint32_t d)
 {
     if (n == 0 || d < lo_id || d > hi_id) return false;

@@ -44,7 +44,8 @@ def parse_args():
                     help="batches kept in flight by that many host threads (each call owns a pooled workspace + HIP stream); "
                          "0 = auto: 1 on one GPU (clean per-kernel timing), 2 when sharded (hides the all-gather/merge latency)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency probe (profiling runs)")
-    ap.add_argument("--measure-bw", action="store_true", help="also report the measured streaming / random-block read bandwidth")
+    ap.add_argument("--no-measure-bw", action="store_true",
+                    help="skip the measured streaming / random-512-B read bandwidth (the second roofline denominator)")
     return ap.parse_args()
 
 
@@ -65,9 +66,15 @@ def cpu_baseline(fpx, oracle, ctx, seg, first_doc, ndocs, flat, offsets, nq, nse
         for i in range(tid, nq, cores):
             results[i] = osnap.search(queries[i], 40, None, 10)
 
-    # warm the page cache / tables with a few queries
+    # warm the page cache / tables with a few queries, then time single-threaded scans of one segment: a whole query
+    # on the reference costs `nseg_total` of them back to back (src/Index.zig:170-177 walks the segments serially)
     for i in range(min(4, nq)):
         osnap.search(queries[i], 40, None, 10)
+    lat1 = []
+    for i in range(min(16, nq)):
+        t1 = time.perf_counter()
+        osnap.search(queries[i], 40, None, 10)
+        lat1.append((time.perf_counter() - t1) * 1e3 * nseg_total)
     # repeat passes over the sample until ~target_s seconds of wall time have been spent (bounded CPU work)
     t0 = time.perf_counter()
     passes = 0
@@ -88,7 +95,8 @@ def cpu_baseline(fpx, oracle, ctx, seg, first_doc, ndocs, flat, offsets, nq, nse
             "sample": f"{nq} queries of the batch x 1 of {nseg_total} segments, {passes} passes, {dt:.2f} s wall on {cores} threads "
                       f"(one query per thread, SSSE3 decode); qps = {nq}*{passes}/{dt:.2f}/{nseg_total}; "
                       f"GPU-vs-oracle mismatches on the sample: {mism}",
-            "parity_mismatches": mism}
+            "parity_mismatches": mism,
+            "single_thread_query_ms_p50": float(np.median(lat1)), "single_thread_query_ms_max": float(np.max(lat1))}
 
 
 def main():
@@ -272,9 +280,13 @@ def main():
             "hits_per_step": agg["hits"] / max(1, args.steps),
             "targets_found": found, "targets_total": B, "median_top_score": int(np.median(top_scores)) if top_scores else 0,
         }
-        if args.measure_bw:
+        if not args.no_measure_bw:
             s_gbs, r_gbs = ctx.measure_bandwidth(8 << 30, 512)
             result["measured_bandwidth"] = {"stream_read_GBs": s_gbs, "random_512B_read_GBs": r_gbs}
+            # second denominator: what this box sustains for the kernel's own access pattern
+            result["roofline"]["peak_measured_random_512B"] = r_gbs
+            if traffic:
+                result["roofline"]["hbm_read_frac_of_measured"] = traffic / (agg["probe_ms"] / max(1, agg["launches"]) * 1e-3) / 1e9 / r_gbs
 
     # ---- p50 latency of a single /_search (batch of 1), rank-local index share only when sharded
     if rank == 0 and world == 1 and not args.no_latency:

@@ -28,7 +28,7 @@ for k, kb in known.items():
     cal[k] = {"known_bytes": kb, "FETCH_SIZE_KB": v, "reported_over_known": v * 1024 / kb}
 kbl = sum(by["k_probe_lean8"][-2:]) / len(by["k_probe_lean8"][-2:])
 t = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --measure-bw  (tools/pmc_traffic.sh)",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency  (tools/pmc_traffic.sh)",
     "config": {k: b["config"][k] for k in ("docs", "segments", "hashes_per_doc", "batch", "query_len")},
     "calibration": {**cal, "correction": "x2 (gfx950 FETCH_SIZE reports half of a wide coalesced read; MI355X_MICROARCH.md HBM section; "
                                          "confirmed by both calibration kernels)"},

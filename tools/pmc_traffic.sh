@@ -2,7 +2,7 @@
 # tools/pmc_traffic.sh <tag> -- FETCH_SIZE of the probe kernels and of the calibration kernels (known byte counts)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --measure-bw "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag.log 2>&1
 python3 - <<PY
 import csv, collections
 rows=list(csv.DictReader(open("$GRAFT_REPO_ROOT/gpurun_out/$tag/${tag}_counter_collection.csv")))

@@ -54,6 +54,10 @@ SIGNATURES = {
     "fpx_last_error": (C.c_char_p, []),
     "fpx_version": (C.c_int, []),
     "fpx_segment_create_file": (C.c_int, [_vp, _vp, _sz, _u32, _vp, _u32, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
+    "fpx_segment_create_file_slice": (C.c_int, [_vp, _vp, _sz, _u32, _vp, _u32, C.c_int, _u32, C.c_int, _u32, _u32, _u32, _u64, _vp, _vp, _u32,
+                                                C.POINTER(_vp)]),
+    "fpx_probe_resident": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, C.POINTER(Stats)]),
+    "fpx_score_partial": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _vp]),
     "fpx_segment_create_memory": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
     "fpx_segment_create_remote": (C.c_int, [_vp, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
     "fpx_segment_retain": (None, [_vp]),

@@ -219,8 +219,9 @@ void fpx_ctx_destroy(fpx_ctx* ctx_)
     delete c;
 }
 
-int fpx_segment_create_file(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_len, uint32_t block_size,
+static int create_file_impl(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_len, uint32_t block_size,
                             const uint32_t* block_index, uint32_t num_blocks,
+                            uint32_t own_flags, uint32_t own_lo, uint32_t own_hi,
                             uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
                             const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs,
                             fpx_segment** out)
@@ -237,6 +238,7 @@ int fpx_segment_create_file(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_
     if (!s) return FPX_E_NOMEM;
     s->ctx = c; s->kind = 0; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
     s->block_size = block_size; s->num_blocks = num_blocks;
+    s->own_flags = own_flags; s->own_lo = own_lo; s->own_hi = own_hi;
     set_docs(s, doc_ids, doc_alive, num_docs);
     // resident copy: real blocks + one zero terminator block + 16 B (the over-read slack of
     // src/streamvbyte.zig:5 / src/FileSegment.zig:87 made explicit)
@@ -257,6 +259,29 @@ int fpx_segment_create_file(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_
     FPX_HIP(hipDeviceSynchronize());
     *out = reinterpret_cast<fpx_segment*>(s);
     return FPX_OK;
+}
+
+int fpx_segment_create_file(fpx_ctx* ctx, const uint8_t* blocks, size_t blocks_len, uint32_t block_size,
+                            const uint32_t* block_index, uint32_t num_blocks,
+                            uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                            const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs,
+                            fpx_segment** out)
+{
+    return create_file_impl(ctx, blocks, blocks_len, block_size, block_index, num_blocks, 0, 0, 0, min_doc_id, max_doc_id,
+                            commit_id, doc_ids, doc_alive, num_docs, out);
+}
+
+int fpx_segment_create_file_slice(fpx_ctx* ctx, const uint8_t* blocks, size_t blocks_len, uint32_t block_size,
+                                  const uint32_t* block_index, uint32_t num_blocks,
+                                  int has_lo, uint32_t lo_excl, int has_hi, uint32_t hi_incl,
+                                  uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                  const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs,
+                                  fpx_segment** out)
+{
+    if (has_lo && has_hi && hi_incl < lo_excl) { set_error("empty hash window"); return FPX_E_INVAL; }
+    return create_file_impl(ctx, blocks, blocks_len, block_size, block_index, num_blocks,
+                            (has_lo ? 1u : 0u) | (has_hi ? 2u : 0u), lo_excl, hi_incl, min_doc_id, max_doc_id,
+                            commit_id, doc_ids, doc_alive, num_docs, out);
 }
 
 int fpx_segment_create_memory(fpx_ctx* ctx_, const uint64_t* items, size_t num_items,
@@ -336,7 +361,7 @@ static void compute_dead(const std::vector<Segment*>& segs, size_t si, std::vect
     const uint32_t lo_s = s->doc_ids.front(), hi_s = s->doc_ids.back();
     for (size_t j = si + 1; j < segs.size(); ++j) {
         const Segment* t = segs[j];
-        if (t->doc_ids.empty()) continue;
+        if (t->doc_ids.empty() || t->commit_id <= s->commit_id) continue;    // hasNewerCommit compares commit ids
         const uint32_t lo = std::max(std::max(lo_s, t->min_doc_id), t->doc_ids.front());
         const uint32_t hi = std::min(std::min(hi_s, t->max_doc_id), t->doc_ids.back());
         if (lo > hi) continue;
@@ -404,6 +429,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         if (s->kind == 0) {
             SegDesc d{};
             d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
+            d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
             sn->h_file.push_back(d);
@@ -513,6 +539,24 @@ int fpx_search_resident_partial(fpx_snapshot* snap, const fpx_query_batch* qb, u
     return search_batch_impl(reinterpret_cast<Snapshot*>(snap), reinterpret_cast<const QueryBatch*>(qb), nullptr, nullptr, 0,
                              nullptr, timeout_ms, true, reinterpret_cast<fpx_result*>(d_out), out_cap,
                              reinterpret_cast<uint32_t*>(d_out_n), stats);
+}
+
+int fpx_probe_resident(fpx_snapshot* snap, const fpx_query_batch* qb, uint32_t world, uint32_t timeout_ms,
+                       void* d_records, uint64_t records_cap, uint64_t* counts, fpx_stats* stats)
+{
+    if (!snap || !qb || !counts || (!d_records && records_cap)) { set_error("null argument"); return FPX_E_INVAL; }
+    if (world == 0 || (world & (world - 1)) != 0 || world > 256) { set_error("world must be a power of two <= 256"); return FPX_E_INVAL; }
+    return probe_records_impl(reinterpret_cast<Snapshot*>(snap), reinterpret_cast<const QueryBatch*>(qb), world, timeout_ms,
+                              reinterpret_cast<uint64_t*>(d_records), records_cap, counts, stats);
+}
+
+int fpx_score_partial(fpx_ctx* ctx, const fpx_query_batch* qb, const void* d_records, uint64_t num_records, uint32_t timeout_ms,
+                      void* d_out, uint32_t out_cap, void* d_out_n)
+{
+    if (!ctx || !qb || !d_out_n || (!d_out && out_cap) || (!d_records && num_records)) { set_error("null argument"); return FPX_E_INVAL; }
+    return score_records_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb),
+                              reinterpret_cast<const uint64_t*>(d_records), num_records, timeout_ms,
+                              reinterpret_cast<fpx_result*>(d_out), out_cap, reinterpret_cast<uint32_t*>(d_out_n));
 }
 
 int fpx_merge_partials(fpx_ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world, uint32_t num_queries,

@@ -28,8 +28,9 @@ struct SegDesc {
     uint32_t min_doc_id;
     uint32_t num_dead;
     uint32_t shadow_lo, shadow_hi; // id range covered by `dead`
-    uint32_t pad;
-    uint32_t pad2[2];
+    // hash-range slice of a segment (second mode): only hashes in (own_lo, own_hi] are probed here
+    uint32_t own_flags;            // bit 0: own_lo is set, bit 1: own_hi is set
+    uint32_t own_lo, own_hi;
 };
 
 // One resident memory segment (src/MemorySegment.zig:27-28).
@@ -71,6 +72,7 @@ struct Segment {
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
+    uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     uint64_t num_items = 0;
     // memory
     uint64_t* d_items = nullptr;
@@ -163,6 +165,11 @@ int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t
                       const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                       fpx_result* out, uint32_t out_cap, uint32_t* out_n,   // host (final) or device (partial)
                       fpx_stats* stats);
+// the two halves of a partial search, for exchanging hit records between them (hash-range sharding)
+int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
+                       uint64_t* d_records, uint64_t records_cap, uint64_t* counts, fpx_stats* stats);
+int score_records_impl(Ctx* ctx, const QueryBatch* qb, const uint64_t* d_records, uint64_t num_records, uint32_t timeout_ms,
+                       fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n);
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
                         uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n);

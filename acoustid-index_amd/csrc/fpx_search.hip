@@ -64,6 +64,12 @@ __device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32
     return lo < n && gload_u32(dead + lo) == d;
 }
 
+// hash-range slices (one segment split across GPUs): is hash h probed in this slice?
+__device__ __forceinline__ bool owned_hash(const SegDesc& s, uint32_t h)
+{
+    return ((s.own_flags & 1u) == 0u || h > s.own_lo) && ((s.own_flags & 2u) == 0u || h <= s.own_hi);
+}
+
 // first block whose max hash >= h (src/FileSegment.zig:145-151); the reference restricts the search
 // to block_index[prev..], which returns the same block because the query hashes ascend.
 __device__ __forceinline__ uint32_t lookup_block(const SegDesc& s, uint32_t h)
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint32_t q = (uint32_t)key & qmask;
         uint32_t b0 = seg.num_blocks;
+        if (seg.own_flags != 0u && !owned_hash(seg, h)) valid = false;          // another slice of the segment probes h
         if (valid) {
             if (!DEFERRED) my_probes += 1;
             b0 = lookup_block(seg, h);
@@ -800,6 +807,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             h[j] = (uint32_t)(key >> a.qb);
             q[j] = (uint32_t)key & qmask;
             lo[j] = 0; hi[j] = 0;
+            if (seg.own_flags != 0u && !owned_hash(seg, h[j])) valid = false;      // another slice of the segment probes h
             if (valid) {
                 my_probes += 1;
                 const uint32_t kb = seg.bucket_shift >= 32u ? 0u : (h[j] >> seg.bucket_shift);
@@ -1415,11 +1423,35 @@ static double now_ms()
 // ------------------------------------------------------------------------------------------------
 // `offsets` are absolute positions into the batch the view [q0, q0+B) belongs to; `hashes` (host) points at
 // absolute position 0 and is only read when the batch is not resident.
+// Hash-range sharding of one segment (second mode) cuts the pipeline at the hit records: a doc's
+// postings may come from several GPUs, so the records travel (grouped by doc & (world - 1)) before they are counted.
+struct Exchange {
+    int mode = 0;                 // 1: probe only, records out;  2: score only, records in
+    uint32_t world = 1;           // mode 1: number of destination ranks (power of two)
+    uint64_t* d_records = nullptr; uint64_t cap = 0;   // mode 1: destination buffer;  mode 2: source
+    uint64_t n = 0;               // mode 2: number of records
+    uint64_t* counts = nullptr;   // mode 1: records per destination rank [world]
+};
+
+// records sorted by (rec & mask): first index whose destination is >= d, for d = 0 .. world
+__global__ void k_dest_bounds(const uint64_t* __restrict__ recs, uint64_t n, uint32_t mask, uint32_t world, uint64_t* __restrict__ bounds)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > world) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t m = (lo + hi) >> 1;
+        if (((uint32_t)recs[m] & mask) < d) lo = m + 1; else hi = m;
+    }
+    bounds[d] = lo;
+}
+
 static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, uint32_t q0,
                      const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
-                     fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+                     fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, const Exchange* ex = nullptr)
 {
+    const bool probe_only = ex && ex->mode == 1, score_only = ex && ex->mode == 2;
     const double t_start = now_ms();
     hipStream_t st = ws->stream;
     const uint64_t base = offsets[0];
@@ -1459,7 +1491,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
-    if (P) {
+    if (P && !score_only) {
         hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, base, ws->d_keys[0]);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
@@ -1575,6 +1607,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (attempt >= 4) { set_error("hit buffer overflow persists (%llu records)", (unsigned long long)H); return FPX_E_DEVICE; }
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
     }
+    if (score_only) {                           // the records come from the exchange instead of the probes above
+        H = ex->n;
+        if (H > ws->cap_hits && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
+        if (H) FPX_HIP(hipMemcpyAsync(ws->d_hits[0], ex->d_records, H * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    }
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
     // statistics: slots 0..7 are written by k_probe (generic / deferred / memory), 8..15 by k_probe_lean8
     const unsigned long long c_blocks = ws->h_counters[CTR_BLOCKS] + ws->h_counters[8 + CTR_BLOCKS],
@@ -1584,8 +1621,53 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_generic = ws->h_counters[CTR_GENERIC],
                              c_main_bytes = used_lean ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES];
 
-    // ---- 5: partition the hit records by query, count per (query, doc) in LDS, keep score >= min_score
     uint64_t C = 0;
+    auto fill_stats = [&]() {
+        if (!stats) return;
+        float total_ms = 0.f;
+        (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
+        stats->probes += c_probes;
+        stats->scanned_blocks += c_blocks;
+        stats->scanned_docs += c_docs;
+        stats->hits += H;
+        stats->algorithmic_bytes += c_bytes;
+        stats->candidates += C;
+        stats->probe_kernel_ms += probe_ms;
+        stats->total_gpu_ms += total_ms;
+        stats->probe_launches += probe_launches;
+        stats->generic_iters += (uint32_t)c_generic;
+        stats->probe_kernel_bytes += c_main_bytes;
+        stats->probe_aux_ms += aux_ms;
+    };
+
+    if (probe_only) {
+        // group the records by destination rank (doc & (world - 1)) and hand them to the caller
+        const uint32_t world = ex->world, mask = world - 1u;
+        if (world > 1 && H) {
+            int hcur = 0;
+            const unsigned wb = bits_for(world);
+            const size_t tb = sort_u64_temp_bytes(H, 0, wb);
+            if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_hits[0], ws->d_hits[1], H, 0, wb, st, &hcur));
+            if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);
+        }
+        if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)world + 2))) return rc;
+        hipLaunchKernelGGL(k_dest_bounds, dim3((world + 1 + 63) / 64), dim3(64), 0, st,
+                           (const uint64_t*)ws->d_hits[0], H, mask, world, ws->d_qrange);
+        FPX_HIP(hipGetLastError());
+        std::vector<uint64_t> hb(world + 1);
+        FPX_HIP(hipMemcpyAsync(hb.data(), ws->d_qrange, ((size_t)world + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        const bool fits = H <= ex->cap;
+        if (fits && H) FPX_HIP(hipMemcpyAsync(ex->d_records, ws->d_hits[0], H * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        FPX_HIP(hipEventRecord(ws->ev_end, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        for (uint32_t d = 0; d < world; ++d) ex->counts[d] = hb[d + 1] - hb[d];
+        if (!fits) { set_error("records buffer too small: %llu records (counts are filled in; retry with room for them)", (unsigned long long)H); return FPX_E_INVAL; }
+        fill_stats();
+        return FPX_OK;
+    }
+
+    // ---- 5: partition the hit records by query, count per (query, doc) in LDS, keep score >= min_score
     int ccur = 0;
     sb = 32u - qb;                              // score field of the candidate key; larger scores -> split the batch
     if (H) {
@@ -1618,6 +1700,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             C = ws->h_counters[CTR_CANDS];
             if (ws->h_counters[CTR_MAXSCORE] != 0) {              // a score does not fit the key's score field
                 if (B <= 1) { set_error("score overflows u32"); return FPX_E_INVAL; }
+                if (score_only) { set_error("a score does not fit the candidate key: use smaller query batches"); return FPX_E_INVAL; }
                 return FPX_SPLIT;                                  // the caller retries with smaller batches
             }
             if (C <= ws->cap_cands) break;
@@ -1647,22 +1730,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     FPX_HIP(hipStreamSynchronize(st));
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
 
-    if (stats) {
-        float total_ms = 0.f;
-        (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
-        stats->probes += c_probes;
-        stats->scanned_blocks += c_blocks;
-        stats->scanned_docs += c_docs;
-        stats->hits += H;
-        stats->algorithmic_bytes += c_bytes;
-        stats->candidates += C;
-        stats->probe_kernel_ms += probe_ms;
-        stats->total_gpu_ms += total_ms;
-        stats->probe_launches += probe_launches;
-        stats->generic_iters += (uint32_t)c_generic;
-        stats->probe_kernel_bytes += c_main_bytes;
-        stats->probe_aux_ms += aux_ms;
-    }
+    fill_stats();
     return FPX_OK;
 }
 
@@ -1714,6 +1782,44 @@ int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t
     }
     FPX_HIP(hipSetDevice(snap->ctx->device));
     return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+}
+
+int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
+                       uint64_t* d_records, uint64_t records_cap, uint64_t* counts, fpx_stats* stats)
+{
+    if (qb->ctx != snap->ctx) { set_error("query batch and snapshot belong to different contexts"); return FPX_E_INVAL; }
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    for (uint32_t d = 0; d < world; ++d) counts[d] = 0;
+    if (qb->B == 0) return FPX_OK;
+    FPX_HIP(hipSetDevice(snap->ctx->device));
+    Workspace* ws = ws_acquire(snap->ctx);
+    if (!ws) return FPX_E_NOMEM;
+    Exchange ex;
+    ex.mode = 1; ex.world = world; ex.d_records = d_records; ex.cap = records_cap; ex.counts = counts;
+    int rc = run_batch(snap, ws, qb, 0, nullptr, qb->offsets.data(), qb->B, qb->opts.data(), timeout_ms, true,
+                       nullptr, 0, nullptr, stats, &ex);
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    ws_release(snap->ctx, ws);
+    return rc;
+}
+
+int score_records_impl(Ctx* ctx, const QueryBatch* qb, const uint64_t* d_records, uint64_t num_records, uint32_t timeout_ms,
+                       fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n)
+{
+    if (qb->ctx != ctx) { set_error("query batch belongs to a different context"); return FPX_E_INVAL; }
+    if (qb->B == 0) return FPX_OK;
+    FPX_HIP(hipSetDevice(ctx->device));
+    Workspace* ws = ws_acquire(ctx);
+    if (!ws) return FPX_E_NOMEM;
+    Snapshot none;                                  // no segments: the probe stage finds nothing to do
+    none.ctx = ctx;
+    Exchange ex;
+    ex.mode = 2; ex.d_records = const_cast<uint64_t*>(d_records); ex.n = num_records;
+    int rc = run_batch(&none, ws, qb, 0, nullptr, qb->offsets.data(), qb->B, qb->opts.data(), timeout_ms, true,
+                       d_out, out_cap, d_out_n, nullptr, &ex);
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    ws_release(ctx, ws);
+    return rc;
 }
 
 void query_batch_free(QueryBatch* qb)

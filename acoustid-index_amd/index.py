@@ -122,6 +122,23 @@ class FileSegment(_Segment):
         super().__init__(ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
 
     @classmethod
+    def slice(cls, ctx, blocks, block_size, block_index, lo_excl, hi_incl, min_doc_id, max_doc_id, commit_id, doc_ids,
+              doc_alive=None):
+        """One hash-range slice of a segment (fpx_segment_create_file_slice): `blocks` / `block_index` hold the owned
+        blocks plus the halo; only hashes in (lo_excl, hi_incl] are probed here (None = unbounded)."""
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+        block_index = _u32(block_index)
+        ids, alive = _docs_args(doc_ids, doc_alive)
+        h = C.c_void_p()
+        check(lib().fpx_segment_create_file_slice(ctx.h, _p(blocks), blocks.size, block_size, _p(block_index), len(block_index),
+                                                  0 if lo_excl is None else 1, 0 if lo_excl is None else int(lo_excl),
+                                                  0 if hi_incl is None else 1, 0 if hi_incl is None else int(hi_incl),
+                                                  min_doc_id, max_doc_id, commit_id, _p(ids), _p(alive), len(ids), C.byref(h)))
+        self = cls.__new__(cls)
+        _Segment.__init__(self, ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
+        return self
+
+    @classmethod
     def synth(cls, ctx, seed, first_doc, num_docs, hashes_per_doc, dist=0, block_size=512, commit_id=1):
         """Seeded synthetic segment built on the GPU (fpx_synth_segment)."""
         h = C.c_void_p()
@@ -354,6 +371,19 @@ def search_resident_partial(reader, qb, d_out_ptr, d_out_n_ptr, timeout_ms=0):
     check(lib().fpx_search_resident_partial(reader.snapshot.h, qb.h, timeout_ms, C.c_void_p(d_out_ptr), qb.cap,
                                             C.c_void_p(d_out_n_ptr), C.byref(st)))
     return st
+
+
+def probe_resident(reader, qb, world, d_records_ptr, records_cap, timeout_ms=0):
+    """stage 1 of hash-range sharding (fpx_probe_resident): hit records grouped by doc & (world - 1) -> counts per rank"""
+    counts = np.zeros(world, np.uint64)
+    st = Stats()
+    check(lib().fpx_probe_resident(reader.snapshot.h, qb.h, world, timeout_ms, d_records_ptr, records_cap, _p(counts), C.byref(st)))
+    return counts, st
+
+
+def score_partial(ctx, qb, d_records_ptr, num_records, d_out_ptr, d_out_n_ptr, timeout_ms=0):
+    """stage 2 of hash-range sharding (fpx_score_partial): received records -> per-query partial tables in HBM"""
+    check(lib().fpx_score_partial(ctx.h, qb.h, d_records_ptr, int(num_records), timeout_ms, d_out_ptr, qb.cap, d_out_n_ptr))
 
 
 def merge_partials(ctx, qb, d_parts_ptr, d_counts_ptr, world, out=None, out_n=None):

@@ -73,3 +73,81 @@ class ShardedReader:
         st = self.partial(qb)
         out, out_n = self.gather_merge(qb, out, out_n)
         return out, out_n, st
+
+
+# ---- hash-range sharding of single segments (second mode) -------------------------------------------------
+HALO_BLOCKS = 3        # MAX_BLOCKS_PER_HASH - 1 (src/FileSegment.zig:25): a run starting in the last owned block stays local
+
+
+def split_by_hash(blocks, block_size, block_index, parts):
+    """Cut one segment into `parts` hash-range slices at block boundaries.  Returns a list of
+    (blocks_slice, index_slice, lo_excl, hi_incl): the owned blocks plus the halo, and the hash window (None = open)
+    that fpx_segment_create_file_slice takes."""
+    blocks = np.asarray(blocks, dtype=np.uint8)
+    block_index = np.asarray(block_index, dtype=np.uint32)
+    nb = len(block_index)
+    cuts = [nb * i // parts for i in range(parts + 1)]
+    out = []
+    for i in range(parts):
+        b0, b1 = cuts[i], cuts[i + 1]
+        e = min(nb, b1 + HALO_BLOCKS)
+        lo = None if b0 == 0 else int(block_index[b0 - 1])
+        hi = None if b1 == nb else (int(block_index[b1 - 1]) if b1 > 0 else 0)
+        if b1 == b0:                     # more parts than blocks: an empty window
+            lo, hi = (0, 0) if lo is None else (lo, lo)
+        out.append((blocks[b0 * block_size:e * block_size], block_index[b0:e], lo, hi))
+    return out
+
+
+def exchange_records(dist, records, counts, world, group=None):
+    """all-to-all of the hit records: `records` is an int64 tensor grouped by destination rank, counts[r] records for
+    rank r (as fpx_probe_resident returns them).  Returns the records this rank received.  Works on cuda tensors over
+    RCCL and on cpu tensors over gloo."""
+    import torch
+    send = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=records.device)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)                     # how much will arrive from every rank
+    in_splits = [int(c) for c in counts]
+    out_splits = [int(c) for c in recv.cpu().tolist()]
+    got = torch.empty((sum(out_splits),) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
+    dist.all_to_all_single(got, records[:sum(in_splits)].contiguous(), out_splits, in_splits, group=group)
+    return got
+
+
+class HashShardedReader:
+    """IndexReader over a snapshot of hash-range SLICES (this rank's slice of every segment): probe -> all-to-all of
+    the hit records by doc & (world - 1) -> score -> all-gather of the tables -> merge."""
+
+    def __init__(self, fpx, ctx, reader, dist, world):
+        if world & (world - 1):
+            raise ValueError("hash-range sharding needs a power-of-two world size")
+        self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
+        self._rec = None
+        self._bufs = {}
+
+    def search_resident(self, qb, out=None, out_n=None):
+        import torch
+        fpx = self.fpx
+        if self._rec is None:
+            self._rec = torch.empty((1 << 20,), dtype=torch.int64, device="cuda")
+        while True:
+            try:
+                counts, st = fpx.probe_resident(self.reader, qb, self.world, self._rec.data_ptr(), self._rec.numel())
+                break
+            except fpx.FpxError:
+                need = 0 if self._rec.numel() >= (1 << 34) else self._rec.numel() * 4
+                if not need:
+                    raise
+                self._rec = torch.empty((need,), dtype=torch.int64, device="cuda")
+        got = exchange_records(self.dist, self._rec, counts, self.world)
+        torch.cuda.current_stream().synchronize()
+        key = (qb.B, qb.cap)
+        if key not in self._bufs:
+            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device="cuda"),
+                               torch.zeros((qb.B,), dtype=torch.int32, device="cuda"))
+        d_part, d_cnt = self._bufs[key]
+        fpx.score_partial(self.ctx, qb, got.data_ptr(), got.numel(), d_part.data_ptr(), d_cnt.data_ptr())
+        tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
+        torch.cuda.current_stream().synchronize()
+        out, out_n = fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
+        return out, out_n, st

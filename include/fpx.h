@@ -187,6 +187,35 @@ int fpx_synth_segment(fpx_ctx *ctx, uint64_t seed, uint32_t first_doc, uint32_t 
                       uint32_t hashes_per_doc, int dist, uint32_t block_size, uint64_t commit_id,
                       fpx_segment **out);
 
+/* ---- hash-range sharding of ONE segment across GPUs (second mode) ------------------------------------
+ * When a single segment must be split (more GPUs than segments, or a segment larger than one GPU's HBM), it is cut by
+ * hash range at block boundaries.  A slice holds the blocks it owns plus the MAX_BLOCKS_PER_HASH - 1 = 3 following halo
+ * blocks, so that a hash's run of <= 4 blocks (src/FileSegment.zig:25,153-174) stays with the slice that owns its first
+ * block; `block_index` is the matching sub-array.  Only hashes in (lo_excl, hi_incl] are probed in the slice:
+ * lo_excl = max hash of the block before the slice's first block (has_lo = 0 for the first slice),
+ * hi_incl = max hash of the slice's last OWNED block (has_hi = 0 for the last slice).  Every slice carries the whole
+ * docs map of its segment. */
+int fpx_segment_create_file_slice(fpx_ctx *ctx, const uint8_t *blocks, size_t blocks_len, uint32_t block_size,
+                                  const uint32_t *block_index, uint32_t num_blocks,
+                                  int has_lo, uint32_t lo_excl, int has_hi, uint32_t hi_incl,
+                                  uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                  const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs,
+                                  fpx_segment **out);
+
+/* With slices a document's postings come from several GPUs, so its score is a true sum across ranks: the pipeline is
+ * cut at the hit records.  Stage 1 (fpx_probe_resident) runs the probes of the local snapshot only and writes the
+ * records (q << 32 | doc) to `d_records` (device memory, room for `records_cap`), grouped by destination rank
+ * doc & (world - 1) (`world` a power of two); counts[r] = records for rank r.  If the buffer is too small the call fails
+ * with FPX_E_INVAL after filling `counts`, so the caller can retry with room for their sum.  The caller exchanges the
+ * groups (all-to-all over RCCL) and every rank feeds what it received to stage 2 (fpx_score_partial), which counts per
+ * (query, doc), applies the absolute floor and emits the per-query tables fpx_search_resident_partial would -- exact,
+ * because all records of a document land on one rank.  fpx_merge_partials then finishes as in segment sharding. */
+int fpx_probe_resident(fpx_snapshot *snap, const fpx_query_batch *qb, uint32_t world, uint32_t timeout_ms,
+                       void *d_records, uint64_t records_cap, uint64_t *counts /* [world] */, fpx_stats *stats);
+int fpx_score_partial(fpx_ctx *ctx, const fpx_query_batch *qb, const void *d_records, uint64_t num_records,
+                      uint32_t timeout_ms, void *d_out /* [B][out_cap] fpx_result */, uint32_t out_cap,
+                      void *d_out_n /* [B] uint32 */);
+
 /* ---- device-side segment build and merge -------------------------------------------------------
  * fpx_segment_build: filefmt.writeBlocks + BlockEncoder (src/filefmt.zig:94-138, src/block.zig:438-567) run on the GPU
  * over caller-provided items (hash << 32 | id); the result is a resident FileSegment whose bytes equal what the

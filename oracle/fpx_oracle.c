@@ -475,6 +475,8 @@ struct orc_segment {
     /* common */
     uint32_t min_doc_id, max_doc_id; uint64_t commit_id;
     uint32_t *doc_ids; uint8_t *doc_alive; uint32_t num_docs;   /* sorted by id */
+    /* test aid for hash-range sharding: only hashes in (win_lo, win_hi] are scanned in this (slice of a) segment */
+    int win_has_lo, win_has_hi; uint32_t win_lo, win_hi;
 };
 
 static int cmp_u32(const void *a, const void *b)
@@ -588,6 +590,11 @@ orc_segment *orc_segment_build_memory(const uint8_t *kind, const uint32_t *ids,
     free(dids); free(dalive);
     if (rc) { orc_segment_free(s); return NULL; }
     return s;
+}
+
+void orc_segment_set_window(orc_segment *s, int has_lo, uint32_t lo_excl, int has_hi, uint32_t hi_incl)
+{
+    s->win_has_lo = has_lo; s->win_lo = lo_excl; s->win_has_hi = has_hi; s->win_hi = hi_incl;
 }
 
 void orc_segment_free(orc_segment *s)
@@ -855,6 +862,7 @@ static int file_segment_search(const orc_segment *seg, const uint32_t *sorted_ha
     size_t prev = 0;
     for (size_t qi = 0; qi < n; qi++) {
         uint32_t hash = sorted_hashes[qi];
+        if ((seg->win_has_lo && hash <= seg->win_lo) || (seg->win_has_hi && hash > seg->win_hi)) continue;   /* another slice's */
         /* lowerBound over block_index[prev..] (:145-151) */
         size_t lo = prev, hi = seg->num_blocks;
         while (lo < hi) { size_t m = lo + (hi - lo) / 2; if (seg->block_index[m] < hash) lo = m + 1; else hi = m; }

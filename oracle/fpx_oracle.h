@@ -107,6 +107,9 @@ orc_segment *orc_segment_create_memory(const uint64_t *items, size_t n,
 orc_segment *orc_segment_build_memory(const uint8_t *kind, const uint32_t *ids,
                                       const uint32_t *hashes, const uint64_t *hash_off,
                                       size_t num_changes, uint64_t commit_id);
+/* test aid for hash-range sharding (include/fpx.h: fpx_segment_create_file_slice): scan only hashes in
+ * (lo_excl, hi_incl] in this segment -- the segment then stands for one slice */
+void orc_segment_set_window(orc_segment *s, int has_lo, uint32_t lo_excl, int has_hi, uint32_t hi_incl);
 void orc_segment_free(orc_segment *s);
 /* introspection for tests */
 size_t orc_segment_num_items(const orc_segment *s);

@@ -83,6 +83,7 @@ def lib():
         "orc_snapshot_create": (vp, [vp, C.c_uint32, vp, C.c_uint32]),
         "orc_snapshot_free": (None, [vp]),
         "orc_snapshot_has_newer_commit": (C.c_int, [vp, C.c_uint32, C.c_uint64]),
+        "orc_segment_set_window": (None, [vp, C.c_int, C.c_uint32, C.c_int, C.c_uint32]),
         "orc_merge_segments": (C.c_int, [vp, vp, C.c_uint32] + [vp] * 8),
         "orc_default_min_score": (C.c_uint32, [C.c_uint32]),
         "orc_search": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32,
@@ -221,6 +222,12 @@ class Segment:
         if getattr(self, "h", None):
             lib().orc_segment_free(self.h)
             self.h = None
+
+    def set_window(self, lo_excl, hi_incl):
+        """scan only hashes in (lo_excl, hi_incl] (None = open): the segment stands for one hash-range slice"""
+        lib().orc_segment_set_window(self.h, 0 if lo_excl is None else 1, 0 if lo_excl is None else int(lo_excl),
+                                     0 if hi_incl is None else 1, 0 if hi_incl is None else int(hi_incl))
+        return self
 
     @property
     def num_items(self):

@@ -106,3 +106,77 @@ def test_sharded_protocol_world_size_2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---- hash-range sharding of single segments (second mode): world_size 2 over gloo ------------------------
+def _hash_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fpx_testlib import fpx, oracle
+        seed, H, per = 57, 48, 4000
+        rng = np.random.default_rng(13)
+        slices, full_segs = [], []
+        for s in range(2):
+            lo = s * per + 1
+            ids = np.arange(lo, lo + per, dtype=np.uint64)
+            extra = np.sort(rng.choice(np.arange(1, lo), 200, replace=False)).astype(np.uint64) if s else np.zeros(0, np.uint64)
+            all_ids = np.concatenate([extra, ids])
+            h = fpx.synth.synth_hashes(seed + s, all_ids, H, 1).astype(np.uint64)
+            items = np.sort(((h << np.uint64(32)) | all_ids[:, None]).ravel())
+            blocks, index = oracle.build_blocks(items, int(all_ids.min()), 512)
+            mk = lambda b, i: oracle.file_segment(b, 512, i, int(all_ids.min()), int(all_ids.max()), s + 1, all_ids.astype(np.uint32))
+            full_segs.append(mk(blocks, index))
+            b, ix, wlo, whi = fpx.sharding.split_by_hash(blocks, 512, index, world)[rank]
+            slices.append(mk(np.concatenate([b, np.zeros(512, np.uint8)]), ix).set_window(wlo, whi))    # + terminator block
+        local, full = oracle.Snapshot(slices, []), oracle.Snapshot(full_segs, [])
+        limit, pct = 10, 10
+        qdocs = [5, 77, 4001, 7000, 100, 200, 3999]
+        queries = [fpx.synth.synth_hashes(seed + (0 if d <= per else 1), [d], H, 1)[0] for d in qdocs]
+        B = len(queries)
+        # stage 1: the local slices' postings per (query, doc): (q, doc, commit, count) tuples, grouped by doc % world
+        tuples = []
+        for q, hashes in enumerate(queries):
+            for doc, (commit, score) in local.hits(hashes).items():
+                tuples.append((doc % world, q, doc, commit, score))
+        tuples.sort()
+        counts = [sum(1 for t in tuples if t[0] == d) for d in range(world)]
+        rec = torch.tensor([t[1:] for t in tuples], dtype=torch.int64).reshape(-1, 4)
+        got = fpx.sharding.exchange_records(dist, rec, counts, world)                  # stage 2: all-to-all
+        assert all(int(r[1]) % world == rank for r in got)
+        # stage 3: a doc's score = the postings of its newest commit, summed over the ranks that sent some
+        acc = {}
+        for q, doc, commit, score in got.tolist():
+            c, s_ = acc.get((q, doc), (0, 0))
+            if commit > c:
+                c, s_ = commit, 0
+            if commit == c:
+                s_ += score
+            acc[(q, doc)] = (c, s_)
+        table = torch.zeros((B, limit, 2), dtype=torch.int32)
+        cnt = torch.zeros((B,), dtype=torch.int32)
+        floors = [(len(h) + 19) // 20 for h in queries]
+        for q in range(B):
+            ent = [(s_, doc) for (qq, doc), (c, s_) in acc.items()
+                   if qq == q and s_ >= floors[q] and not full.has_newer_commit(doc, c)]
+            ent.sort(key=lambda e: (-e[0], e[1]))
+            cnt[q] = min(len(ent), limit)
+            for i, (s_, doc) in enumerate(ent[:limit]):
+                table[q, i, 0], table[q, i, 1] = doc, s_
+        tables, cnts = fpx.sharding.gather_tables(dist, table, cnt, world)             # stage 4 + 5: as segment sharding
+        ok = True
+        for q, hashes in enumerate(queries):
+            res = merge_tables(tables[:, q].numpy(), cnts[:, q].numpy(), limit, floors[q], pct)
+            ok = ok and res == full.search(hashes, max_results=limit, min_score=None, min_score_pct=pct)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hash_range_protocol_world_size_2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hash_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -1547,7 +1547,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 // main kernel: k_probe_lean8 over the dense 512-B segments
                 FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));
                 ProbeArgs l = a;
-                l.segs = snap->d_lean; l.rounds = 1u; l.ctr_off = 8u;
+                static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 2u; }();
+                l.segs = snap->d_lean; l.rounds = (P >= (1ull << 22)) ? lean_rounds : 1u; l.ctr_off = 8u;
                 const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
                 const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;
                 const uint32_t gx8 = (uint32_t)((P + per_wg_8 - 1) / per_wg_8);

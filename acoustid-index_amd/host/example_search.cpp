@@ -27,6 +27,17 @@ int main()
         fpx::SearchResults dup(fpx::SearchOptions{10, 1, 10});
         reader.search({100, 100}, dup);                       // the query is a set: a repeated hash scores once
         ok = ok && dup.getResults().size() == 2 && dup.getResults()[0].score == 1;
+
+        // the same through a FILE segment: checkpoint the memory segment on the GPU (src/filefmt.zig:293-338 writes and
+        // re-reads the segment; here SegmentMerger + the block encoder run on the device) and search it
+        fpx::Segments snap(ctx, {mem});
+        fpx::FileSegment file = snap.merge({mem});
+        ok = ok && file.numItems() == 5 && file.numBlocks() == 1 && file.docs().ids.size() == 2 && file.commitId() == 1;
+        fpx::IndexReader freader(fpx::Segments(ctx, {file}));
+        fpx::SearchResults fr(fpx::SearchOptions{10, 1, 10});
+        freader.search({100, 200, 300}, fr);
+        const auto& fo = fr.getResults();
+        ok = ok && fo.size() == 2 && fo[0].id == 1 && fo[0].score == 3 && fo[1].id == 2 && fo[1].score == 2;
         std::printf("%s\n", ok ? "ok" : "MISMATCH");
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

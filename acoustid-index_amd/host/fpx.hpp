@@ -104,7 +104,33 @@ public:
         *static_cast<Segment*>(&s) = Segment(h);
         return s;
     }
+    // filefmt.writeBlocks on the device over caller items (hash << 32 | id), src/filefmt.zig:94-138
+    static FileSegment build(const Context& ctx, const std::vector<uint64_t>& items, bool sorted, uint32_t block_size,
+                             uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, const Docs& docs)
+    {
+        fpx_segment* h = nullptr;
+        check(fpx_segment_build(ctx.handle(), items.data(), items.size(), sorted ? 1 : 0, block_size, min_doc_id, max_doc_id,
+                                commit_id, docs.ids.data(), docs.alive.empty() ? nullptr : docs.alive.data(),
+                                (uint32_t)docs.ids.size(), &h));
+        return adopt(h);
+    }
+    static FileSegment adopt(fpx_segment* h)
+    {
+        FileSegment s;
+        *static_cast<Segment*>(&s) = Segment(h);
+        return s;
+    }
     uint32_t numBlocks() const { return fpx_segment_num_blocks(handle()); }
+    uint64_t numItems() const { return fpx_segment_num_items(handle()); }
+    uint64_t commitId() const { return fpx_segment_commit_id(handle()); }
+    Docs docs() const
+    {
+        Docs d;
+        const uint32_t n = fpx_segment_num_docs(handle());
+        d.ids.resize(n); d.alive.resize(n);
+        check(fpx_segment_docs(handle(), d.ids.data(), d.alive.data(), n));
+        return d;
+    }
 private:
     FileSegment() = default;
 };
@@ -135,6 +161,16 @@ public:
         h_ = std::shared_ptr<fpx_snapshot>(h, [](fpx_snapshot* p) { fpx_snapshot_release(p); });
     }
     fpx_snapshot* handle() const { return h_.get(); }
+    // Index.mergeToFileSegment on the device (checkpoint of memory segments, merge of file segments):
+    // SegmentMerger over `sources`, which must be segments of this snapshot, oldest first
+    FileSegment merge(const std::vector<Segment>& sources, uint32_t block_size = 512) const
+    {
+        std::vector<fpx_segment*> hs;
+        for (const auto& s : sources) hs.push_back(s.handle());
+        fpx_segment* h = nullptr;
+        check(fpx_segment_merge(h_.get(), hs.data(), (uint32_t)hs.size(), block_size, &h));
+        return FileSegment::adopt(h);
+    }
 private:
     std::shared_ptr<fpx_snapshot> h_;
 };

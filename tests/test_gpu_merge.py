@@ -147,3 +147,22 @@ def test_merge_rejects_foreign_or_unordered_sources(env):
         snap.merge([b, a])
     with pytest.raises(fpx.FpxError):
         snap.merge([])
+
+
+def test_merge_of_large_gpu_built_segments(env):
+    """two GPU-built segments of 1.3 M items each (thousands of blocks, several scan chunks), the second re-inserting a
+    tenth of the first's docs: merged bytes equal the oracle's merger + writer"""
+    fpx, oracle, ctx = env
+    from fpx_testlib import Pair
+    H, per = 64, 20000
+    a = fpx.synth.synth_items(11, 1, per, H, dist=1)
+    ids_b = np.concatenate([np.arange(1, per + 1, 10), np.arange(per + 1, 2 * per - per // 10 + 1)]).astype(np.uint64)
+    hb = fpx.synth.synth_hashes(12, ids_b, H, 1).astype(np.uint64)
+    b = np.sort(((hb << np.uint64(32)) | ids_b[:, None]).ravel())
+    p = Pair(ctx)
+    p.add_file(a, 1, per, 1, np.arange(1, per + 1))
+    p.add_file(b, int(ids_b.min()), int(ids_b.max()), 2, ids_b.astype(np.uint32))
+    p.finish()
+    merged, want, _ = check_merge(fpx, oracle, p, p.gpu_segs, p.orc_file, 512)
+    assert merged.getSize() == len(a) + len(b) - (per // 10) * H          # the overwritten docs' old items are gone
+    assert merged.num_blocks > 10000

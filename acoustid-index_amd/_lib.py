@@ -50,6 +50,7 @@ _vp, _u32, _u64, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
 SIGNATURES = {
     "fpx_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "fpx_ctx_destroy": (None, [_vp]),
+    "fpx_ctx_device": (C.c_int, [_vp]),
     "fpx_strerror": (C.c_char_p, [C.c_int]),
     "fpx_last_error": (C.c_char_p, []),
     "fpx_version": (C.c_int, []),

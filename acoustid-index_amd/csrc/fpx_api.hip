@@ -210,6 +210,8 @@ int fpx_ctx_create(int device, fpx_ctx** out)
     return FPX_OK;
 }
 
+int fpx_ctx_device(const fpx_ctx* ctx) { return ctx ? reinterpret_cast<const Ctx*>(ctx)->device : -1; }
+
 void fpx_ctx_destroy(fpx_ctx* ctx_)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx_);

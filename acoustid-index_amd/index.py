@@ -39,6 +39,7 @@ class Context:
         h = C.c_void_p()
         check(lib().fpx_ctx_create(device, C.byref(h)))
         self.h = h
+        self.device = lib().fpx_ctx_device(h)       # HIP ordinal (host threads default to device 0: name it explicitly)
 
     def close(self):
         if getattr(self, "h", None):

@@ -44,14 +44,17 @@ class ShardedReader:
         self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
         self.host_staged = host_staged      # debugging aid: exchange through host memory with a CPU backend (gloo)
         self._bufs = {}
+        import torch
+        # worker threads start with HIP device 0 current: every tensor names the context's device explicitly
+        self.device = torch.device("cuda", ctx.device)
 
     def partial(self, qb):
         """stage 1: probe the local segments; the per-query tables stay in HBM"""
         import torch
         key = (qb.B, qb.cap)
         if key not in self._bufs:
-            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device="cuda"),
-                               torch.zeros((qb.B,), dtype=torch.int32, device="cuda"))
+            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device=self.device),
+                               torch.zeros((qb.B,), dtype=torch.int32, device=self.device))
         d_part, d_cnt = self._bufs[key]
         return self.fpx.search_resident_partial(self.reader, qb, d_part.data_ptr(), d_cnt.data_ptr())
 
@@ -61,12 +64,12 @@ class ShardedReader:
         d_part, d_cnt = self._bufs[(qb.B, qb.cap)]
         if self.host_staged:
             tables, cnts = gather_tables(self.dist, d_part.cpu(), d_cnt.cpu(), self.world)
-            tables, cnts = tables.cuda(), cnts.cuda()
+            tables, cnts = tables.to(self.device), cnts.to(self.device)
         else:
             tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)      # RCCL all-gather over xGMI
         # The collective is ordered on torch's current stream; wait for THAT stream only -- a device-wide synchronize would
         # also wait for the next batch's probe kernels, which run on libfpx's own streams from another host thread.
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
         return self.fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
 
     def search_resident(self, qb, out=None, out_n=None):
@@ -124,12 +127,14 @@ class HashShardedReader:
         self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
         self._rec = None
         self._bufs = {}
+        import torch
+        self.device = torch.device("cuda", ctx.device)
 
     def search_resident(self, qb, out=None, out_n=None):
         import torch
         fpx = self.fpx
         if self._rec is None:
-            self._rec = torch.empty((1 << 20,), dtype=torch.int64, device="cuda")
+            self._rec = torch.empty((1 << 20,), dtype=torch.int64, device=self.device)
         while True:
             try:
                 counts, st = fpx.probe_resident(self.reader, qb, self.world, self._rec.data_ptr(), self._rec.numel())
@@ -138,16 +143,16 @@ class HashShardedReader:
                 need = 0 if self._rec.numel() >= (1 << 34) else self._rec.numel() * 4
                 if not need:
                     raise
-                self._rec = torch.empty((need,), dtype=torch.int64, device="cuda")
+                self._rec = torch.empty((need,), dtype=torch.int64, device=self.device)
         got = exchange_records(self.dist, self._rec, counts, self.world)
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
         key = (qb.B, qb.cap)
         if key not in self._bufs:
-            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device="cuda"),
-                               torch.zeros((qb.B,), dtype=torch.int32, device="cuda"))
+            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device=self.device),
+                               torch.zeros((qb.B,), dtype=torch.int32, device=self.device))
         d_part, d_cnt = self._bufs[key]
         fpx.score_partial(self.ctx, qb, got.data_ptr(), got.numel(), d_part.data_ptr(), d_cnt.data_ptr())
         tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
         out, out_n = fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
         return out, out_n, st

@@ -231,7 +231,7 @@ def main():
     out, out_n = outs[(args.steps - 1) % nfl]
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", device) if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # roofline numerator / denominator of the slowest rank is this rank's own; report rank 0's kernel

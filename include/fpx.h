@@ -78,6 +78,7 @@ typedef struct {
 /* One context per GPU / process.  device = HIP ordinal, -1 = current device. */
 int  fpx_ctx_create(int device, fpx_ctx **out);
 void fpx_ctx_destroy(fpx_ctx *ctx);
+int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context lives on */
 const char *fpx_strerror(int status);
 /* last error text of the calling thread (valid until its next fpx call) */
 const char *fpx_last_error(void);

@@ -1,0 +1,119 @@
+"""Randomised parity: many small worlds with random block sizes, segment counts, overlapping / re-inserted / deleted
+docs, memory segments, duplicate postings, hot hashes, query shapes and options -- GPU path (through the C ABI) against
+the oracle, results and the scanned_blocks / scanned_docs counters.  Seeds are the test ids, so a failure reproduces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fpx_testlib import fpx, oracle, Pair
+    return fpx, oracle, Pair, fpx.Context(0)
+
+
+def random_world(fpx, Pair, ctx, rng, lean_sized):
+    p = Pair(ctx)
+    n_file = int(rng.integers(1, 4)) if lean_sized else int(rng.integers(1, 6))
+    H = 128 if lean_sized else int(rng.integers(3, 40))
+    per = 9000 if lean_sized else int(rng.integers(50, 1500))
+    hash_bits = 32 if lean_sized else int(rng.choice([8, 12, 20, 32]))
+    stride = int(rng.choice([1, 1, 1, 7, 3001, 70001]))
+    hot = rng.integers(0, 1 << hash_bits, 5, dtype=np.uint64)
+    all_items = []
+    next_id = 1
+    commit = 0
+    for s in range(n_file):
+        commit += 1
+        ids = next_id + np.arange(per, dtype=np.uint64) * stride
+        next_id = int(ids[-1]) + 1
+        if s and rng.random() < 0.7:                      # re-insert / overwrite some docs of older segments
+            older = np.unique(np.concatenate([x & np.uint64(0xFFFFFFFF) for x in all_items]))
+            ids = np.unique(np.concatenate([ids, rng.choice(older, min(len(older), int(rng.integers(1, 60))), replace=False)]))
+        alive = (rng.random(len(ids)) > 0.03).astype(np.uint8)     # tombstones inside file segments (merged deletes)
+        live = ids[alive == 1]
+        h = rng.integers(0, 1 << hash_bits, (len(live), H), dtype=np.uint64)
+        if rng.random() < 0.6:
+            m = rng.random(len(live)) < 0.5
+            h[m, 0] = hot[rng.integers(0, 5, int(m.sum()))]
+        if rng.random() < 0.5:
+            h[:, -1] = h[:, 0]                             # duplicate postings inside a doc
+        items = np.sort(((h << np.uint64(32)) | live[:, None]).ravel())
+        if rng.random() < 0.5 and len(items) > 9:
+            items = items[:len(items) - int(rng.integers(1, 4))]   # item count not a multiple of 4
+        bs = 512 if lean_sized else int(rng.choice([64, 100, 128, 256, 512, 512, 1024, 4096]))
+        p.add_file(items, int(ids.min()), int(ids.max()), commit, ids.astype(np.uint32), alive, block_size=bs)
+        all_items.append(items)
+    for _ in range(int(rng.integers(0, 3))):
+        commit += 1
+        known = np.unique(np.concatenate([x & np.uint64(0xFFFFFFFF) for x in all_items]))
+        changes = []
+        for _ in range(int(rng.integers(1, 8))):
+            if rng.random() < 0.5:
+                changes.append(("delete", int(rng.choice(known))))
+            else:
+                doc = int(rng.choice(known)) if rng.random() < 0.5 else next_id + int(rng.integers(0, 1000))
+                changes.append(("insert", doc, rng.integers(0, 1 << hash_bits, int(rng.integers(1, 30))).tolist() + [int(hot[0])]))
+        p.add_memory_changes(changes, commit)
+    return p.finish(), np.concatenate(all_items), hash_bits, hot
+
+
+def random_queries(rng, items, hash_bits, hot, n, qlen):
+    hs_all = (items >> np.uint64(32)).astype(np.uint32)
+    ids_all = (items & np.uint64(0xFFFFFFFF))
+    qs = []
+    for i in range(n):
+        kind = rng.random()
+        if kind < 0.6:                                     # aimed at one doc, plus noise
+            doc = ids_all[rng.integers(0, len(ids_all))]
+            q = hs_all[ids_all == doc].tolist()
+        elif kind < 0.8:
+            q = rng.choice(hs_all, min(qlen, 200)).tolist()
+        else:
+            q = []
+        q += rng.integers(0, 1 << hash_bits, max(0, qlen - len(q))).tolist()
+        if rng.random() < 0.3:
+            q += [int(hot[int(rng.integers(0, 5))])] * int(rng.integers(1, 4))     # hot + duplicate query hashes
+        if rng.random() < 0.1:
+            q = q[:int(rng.integers(0, 3))]                # empty and tiny queries
+        qs.append(q)
+    return qs
+
+
+def random_options(fpx, rng, n):
+    opts = []
+    for _ in range(n):
+        k = rng.random()
+        if k < 0.4:
+            opts.append(fpx.http_options(limit=int(rng.choice([1, 5, 40, 100]))))
+        elif k < 0.7:
+            opts.append(fpx.SearchOptions(int(rng.choice([1, 3, 10, 500])), int(rng.choice([1, 2, 5])), int(rng.choice([0, 10, 50, 100]))))
+        else:
+            opts.append(fpx.SearchOptions(int(rng.integers(1, 60)), None, int(rng.integers(0, 101))))
+    return opts
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_fuzz_small_worlds(env, seed):
+    fpx, oracle, Pair, ctx = env
+    rng = np.random.default_rng(10_000 + seed)
+    p, items, hash_bits, hot = random_world(fpx, Pair, ctx, rng, lean_sized=False)
+    qs = random_queries(rng, items, hash_bits, hot, 48, int(rng.choice([5, 40, 300])))
+    p.check(qs, random_options(fpx, rng, len(qs)))
+    # and one by one through the single-search entry point
+    for q, o in list(zip(qs, random_options(fpx, rng, len(qs))))[:8]:
+        res = fpx.SearchResults(o)
+        p.reader.search(q, res)
+        assert res.getResults() == p.osnap.search(q, o.max_results, o.min_score, o.min_score_pct)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_lean_sized_worlds(env, seed):
+    """segments of > 2^20 items and batches of > 2^16 probes: the lean kernel + deferred pass carry these"""
+    fpx, oracle, Pair, ctx = env
+    rng = np.random.default_rng(20_000 + seed)
+    p, items, hash_bits, hot = random_world(fpx, Pair, ctx, rng, lean_sized=True)
+    qs = random_queries(rng, items, hash_bits, hot, 80, 1000)
+    got, st = p.check(qs, random_options(fpx, rng, len(qs)))
+    assert st.probe_kernel_bytes > 0

@@ -116,4 +116,31 @@ def test_fuzz_lean_sized_worlds(env, seed):
     p, items, hash_bits, hot = random_world(fpx, Pair, ctx, rng, lean_sized=True)
     qs = random_queries(rng, items, hash_bits, hot, 80, 1000)
     got, st = p.check(qs, random_options(fpx, rng, len(qs)))
-    assert st.probe_kernel_bytes > 0
+    assert st.probe_kernel_bytes > 0 and st.probe_aux_ms > 0          # aux time is only taken next to the lean kernel
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_merge(env, seed):
+    """random source ranges of random worlds through fpx_segment_merge against the oracle's SegmentMerger + writer"""
+    fpx, oracle, Pair, ctx = env
+    rng = np.random.default_rng(30_000 + seed)
+    p, items, hash_bits, hot = random_world(fpx, Pair, ctx, rng, lean_sized=False)
+    nf, nm = len(p.orc_file), len(p.orc_mem)
+    choices = []
+    if nf:
+        lo = int(rng.integers(0, nf))
+        hi = int(rng.integers(lo + 1, nf + 1))
+        choices.append((p.gpu_segs[lo:hi], p.orc_file[lo:hi]))
+    if nm:
+        choices.append((p.gpu_segs[nf:], p.orc_mem))                                  # checkpoint
+    choices.append((p.gpu_segs, p.orc_file + p.orc_mem))                               # everything
+    for gsrc, osrc in choices:
+        bs = int(rng.choice([64, 128, 512, 4096]))
+        merged = p.reader.snapshot.merge(gsrc, bs)
+        want = p.osnap.merge(osrc)
+        ids, alive = merged.docs()
+        assert np.array_equal(ids, want["doc_ids"]) and np.array_equal(alive, want["doc_alive"])
+        assert (merged.commit_id, merged.min_doc_id, merged.max_doc_id) == (want["commit_id"], want["min_doc_id"], want["max_doc_id"])
+        wb, wi = oracle.build_blocks(want["items"], want["min_doc_id"], bs)
+        blocks, index = merged.download()
+        assert np.array_equal(index, wi) and np.array_equal(blocks, wb)

@@ -52,10 +52,18 @@ Workspace* ws_acquire(Ctx* ctx)
     return w;
 }
 
+// A workspace keeps its buffers (gigabytes after a large batch) for the next call.  The pool holds what a burst of
+// concurrent callers needs and lets go of the rest: more than MAX_POOLED idle workspaces are destroyed on release.
+constexpr size_t MAX_POOLED = 8;
+
 void ws_release(Ctx* ctx, Workspace* ws)
 {
-    std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->free_ws.push_back(ws);
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        if (ctx->free_ws.size() < MAX_POOLED) { ctx->free_ws.push_back(ws); return; }
+    }
+    ctx->live_ws--;
+    ws_destroy(ws);
 }
 
 void ws_destroy(Workspace* w)

@@ -45,8 +45,8 @@ Workspace* ws_acquire(Ctx* ctx)
               hipEventCreate(&w->ev_begin) == hipSuccess && hipEventCreate(&w->ev_probe0) == hipSuccess &&
               hipEventCreate(&w->ev_probe1) == hipSuccess && hipEventCreate(&w->ev_probe2) == hipSuccess &&
               hipEventCreate(&w->ev_end) == hipSuccess &&
-              hipMalloc(&w->d_counters, CTR_COUNT * sizeof(unsigned long long)) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void**>(&w->h_counters), CTR_COUNT * sizeof(unsigned long long)) == hipSuccess;
+              hipMalloc(&w->d_counters, COUNTERS_BYTES) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&w->h_counters), COUNTERS_BYTES) == hipSuccess;
     if (!ok) { set_error("workspace creation failed: %s", hipGetErrorString(hipGetLastError())); ws_destroy(w); return nullptr; }
     ctx->live_ws++;
     return w;

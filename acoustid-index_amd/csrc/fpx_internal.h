@@ -95,6 +95,9 @@ struct Snapshot {
     bool all_512 = true;                 // every file segment uses 512-B blocks (the only size the reference writes)
 };
 
+// counters [CTR_COUNT] | result count | up to 1024 results: the single-query fast path returns all of it in one copy
+constexpr size_t COUNTERS_BYTES = (CTR_COUNT + 1) * sizeof(unsigned long long) + 1024 * sizeof(fpx_result);
+
 // Pooled per-call device workspace (analogue of SearchResultsPool, src/common.zig:186-300).
 struct Workspace {
     hipStream_t stream = nullptr;

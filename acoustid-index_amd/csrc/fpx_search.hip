@@ -1123,14 +1123,17 @@ constexpr uint32_t SCORE_TABLE_LOG2 = 11;       // exact table: 2048 slots = 16 
 
 __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ qrange,
                                                const uint32_t* __restrict__ opts, uint32_t log2f, uint32_t sb,
-                                               uint64_t* cands, uint64_t cand_cap, unsigned long long* counters)
+                                               uint64_t* cands, uint64_t cand_cap, unsigned long long* counters,
+                                               uint64_t single_hit_cap = 0)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);                 // 2^SCORE_TABLE_LOG2 slots
     unsigned int* filter = reinterpret_cast<unsigned int*>(smem + (8u << SCORE_TABLE_LOG2)); // 2^log2f cells
     __shared__ uint32_t survivors;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const uint64_t lo = qrange[2ull * q], hi = qrange[2ull * q + 1];
+    // qrange == nullptr: a single query whose records are all of them; their count is still on the device
+    const uint64_t lo = qrange ? qrange[2ull * q] : 0ull;
+    const uint64_t hi = qrange ? qrange[2ull * q + 1] : min((uint64_t)counters[CTR_HITS], single_hit_cap);
     if (hi <= lo) return;
     const uint64_t n = hi - lo;
     const uint32_t min_score = opts[q * 4u + 1u];
@@ -1264,6 +1267,55 @@ __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const u
         ++n;
     }
     out_n[q] = n < out_cap ? n : out_cap;
+}
+
+// Single-query fast path: the (few) candidates are sorted in LDS and walked by one workgroup; the results and their count
+// land behind the counters so that ONE copy to pinned host memory returns everything.
+constexpr uint32_t SINGLE_CANDS = 2048;
+constexpr uint32_t SINGLE_OUT_MAX = 1024;          // results that fit behind the counters (fpx_result each)
+__global__ __launch_bounds__(256) void k_finish_single(const uint64_t* __restrict__ cands, const uint32_t* __restrict__ opts,
+                                                       unsigned long long* counters, uint32_t out_cap)
+{
+    __shared__ uint64_t key[SINGLE_CANDS];
+    const uint32_t tid = threadIdx.x;
+    const unsigned long long C64 = counters[CTR_CANDS];
+    const uint32_t C = C64 < SINGLE_CANDS ? (uint32_t)C64 : SINGLE_CANDS;        // more than fit: the host reruns the general path
+    uint32_t n2 = 1;
+    while (n2 < C) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += 256u) key[i] = i < C ? cands[i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1)                                       // bitonic sort, ascending
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < n2; i += 256u) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = key[i], b = key[l];
+                    const bool up = (i & k) == 0u;
+                    if ((a > b) == up) { key[i] = b; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {
+        // SearchResults.finish for one query (src/common.zig:147-167); key = (~score) << 32 | doc
+        fpx_result* out = reinterpret_cast<fpx_result*>(counters + CTR_COUNT + 1);
+        const uint32_t max_results = opts[0];
+        uint32_t min_score = opts[1];
+        const uint32_t pct = opts[2];
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < C; ++i) {
+            if (n == max_results) break;
+            const uint32_t score = ~(uint32_t)(key[i] >> 32);
+            if (score < min_score) break;
+            if (n == 0) {
+                const uint32_t rel = (uint32_t)((uint64_t)score * pct / 100ull);
+                if (rel > min_score) min_score = rel;
+            }
+            if (n < out_cap) { out[n].id = (uint32_t)key[i]; out[n].score = score; }
+            ++n;
+        }
+        counters[CTR_COUNT] = n < out_cap ? n : out_cap;
+    }
 }
 
 // merge `world` per-rank tables (each sorted by score desc, id asc, disjoint doc ownership)
@@ -1449,7 +1501,8 @@ __global__ void k_dest_bounds(const uint64_t* __restrict__ recs, uint64_t n, uin
 static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, uint32_t q0,
                      const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
-                     fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, const Exchange* ex = nullptr)
+                     fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, const Exchange* ex = nullptr,
+                     bool no_fast = false)
 {
     const bool probe_only = ex && ex->mode == 1, score_only = ex && ex->mode == 2;
     const double t_start = now_ms();
@@ -1524,6 +1577,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
     }
     bool force_generic = false, used_lean = false;
+    // A single /_search (B == 1) is latency bound: its tail runs without intermediate host round trips, with fixed
+    // sizes, and is checked once at the end; anything that does not fit falls back to the general path below.
+    bool single_fast = B == 1 && !partial && !ex && !no_fast && P != 0 && out_cap <= SINGLE_OUT_MAX;
     for (int attempt = 0;; ++attempt) {
         used_lean = false;
         FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
@@ -1585,6 +1641,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                                snap->d_mem, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
             FPX_HIP(hipGetLastError());
         }
+        if (single_fast && !used_lean) break;      // one query: nothing below needs the counts on the host yet
+        single_fast = false;
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipStreamSynchronize(st));
         if (P && snap->n_file) {
@@ -1607,6 +1665,49 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (H <= ws->cap_hits) break;
         if (attempt >= 4) { set_error("hit buffer overflow persists (%llu records)", (unsigned long long)H); return FPX_E_DEVICE; }
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
+    }
+    if (single_fast) {
+        if (ws->cap_cands < SINGLE_CANDS && (rc = grow_pair(ws->d_cands, &ws->cap_cands, SINGLE_CANDS))) return rc;
+        static const hipError_t lds_attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)lds_attr1;
+        const uint32_t log2f = 13, sb1 = 32u - qb;
+        hipLaunchKernelGGL(k_score, dim3(1), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
+                           (const uint64_t*)ws->d_hits[0], (const uint64_t*)nullptr, d_opts, log2f, sb1, ws->d_cands[0],
+                           (uint64_t)SINGLE_CANDS, ws->d_counters, (uint64_t)ws->cap_hits);
+        hipLaunchKernelGGL(k_finish_single, dim3(1), dim3(256), 0, st, (const uint64_t*)ws->d_cands[0], d_opts, ws->d_counters, out_cap);
+        FPX_HIP(hipGetLastError());
+        // counters, result count and results in one copy to pinned memory
+        const size_t ret_bytes = ((size_t)CTR_COUNT + 1) * sizeof(unsigned long long) + (size_t)out_cap * sizeof(fpx_result);
+        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, ret_bytes, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipEventRecord(ws->ev_end, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
+        H = ws->h_counters[CTR_HITS];
+        const bool fits = H <= ws->cap_hits && ws->h_counters[CTR_CANDS] <= SINGLE_CANDS && ws->h_counters[CTR_MAXSCORE] == 0;
+        if (!fits) {                           // rare: rerun on the general path (which grows buffers / splits as needed)
+            if (H > ws->cap_hits && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
+            return run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, ex, true);
+        }
+        *out_n = (uint32_t)ws->h_counters[CTR_COUNT];
+        std::memcpy(out, ws->h_counters + CTR_COUNT + 1, (size_t)*out_n * sizeof(fpx_result));
+        if (stats) {
+            float total_ms = 0.f, ms = 0.f;
+            (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
+            if (snap->n_file) (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
+            stats->probes += ws->h_counters[CTR_PROBES];
+            stats->scanned_blocks += ws->h_counters[CTR_BLOCKS];
+            stats->scanned_docs += ws->h_counters[CTR_DOCS];
+            stats->hits += H;
+            stats->algorithmic_bytes += ws->h_counters[CTR_BYTES];
+            stats->candidates += ws->h_counters[CTR_CANDS];
+            stats->probe_kernel_ms += ms;
+            stats->total_gpu_ms += total_ms;
+            stats->probe_launches += probe_launches;
+            stats->generic_iters += (uint32_t)ws->h_counters[CTR_GENERIC];
+            stats->probe_kernel_bytes += ws->h_counters[CTR_BYTES];
+        }
+        return FPX_OK;
     }
     if (score_only) {                           // the records come from the exchange instead of the probes above
         H = ex->n;

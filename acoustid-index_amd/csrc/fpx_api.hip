@@ -74,6 +74,8 @@ void ws_destroy(Workspace* w)
                     w->d_cands[0], w->d_cands[1], w->d_temp, w->d_counters, w->d_out, w->d_out_n, w->d_def_list, w->d_def_count, w->d_qrange};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (w->h_counters) (void)hipHostFree(w->h_counters);
+    if (w->h_stage) (void)hipHostFree(w->h_stage);
+    if (w->d_stage) (void)hipFree(w->d_stage);
     if (w->h_def_count) (void)hipHostFree(w->h_def_count);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_probe0) (void)hipEventDestroy(w->ev_probe0);

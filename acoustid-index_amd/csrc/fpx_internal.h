@@ -98,6 +98,8 @@ struct Snapshot {
 // counters [CTR_COUNT] | result count | up to 1024 results: the single-query fast path returns all of it in one copy
 constexpr size_t COUNTERS_BYTES = (CTR_COUNT + 1) * sizeof(unsigned long long) + 1024 * sizeof(fpx_result);
 
+constexpr size_t STAGE_BYTES = 64 * 1024;
+
 // Pooled per-call device workspace (analogue of SearchResultsPool, src/common.zig:186-300).
 struct Workspace {
     hipStream_t stream = nullptr;
@@ -117,6 +119,8 @@ struct Workspace {
     fpx_result* d_out = nullptr; uint32_t* d_out_n = nullptr; size_t cap_out = 0; // [B*cap], [B]
     // pinned host staging
     unsigned long long* h_counters = nullptr;
+    // one small query travels in ONE pinned copy: [offsets 2 x u64 | opts 4 x u32 | hashes]
+    uint8_t* h_stage = nullptr; uint8_t* d_stage = nullptr;
 };
 
 // A query batch already uploaded to HBM (fpx_query_batch_create): the timed region of a resident

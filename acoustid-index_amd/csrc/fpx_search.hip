@@ -1521,11 +1521,30 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     const uint32_t* d_hashes_base;
     const uint64_t* d_offsets;
     const uint32_t* d_opts;
+    bool staged_single = false;
     FPX_HIP(hipEventRecord(ws->ev_begin, st));
     if (resident) {
         d_hashes_base = resident->d_hashes;
         d_offsets = resident->d_offsets + q0;
         d_opts = resident->d_opts + (size_t)q0 * 4;
+    } else if (B == 1 && 32 + P * sizeof(uint32_t) <= STAGE_BYTES) {
+        // one small query: offsets, options and hashes travel in a single copy from pinned memory, no host sync
+        if (opts[0].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
+        if (!ws->h_stage) {
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_stage), STAGE_BYTES));
+            FPX_HIP(hipMalloc(&ws->d_stage, STAGE_BYTES));
+        }
+        std::vector<uint32_t> h_opts;
+        fill_opts(h_opts, opts, offsets, 1);
+        uint64_t* so = reinterpret_cast<uint64_t*>(ws->h_stage);
+        so[0] = 0; so[1] = P;
+        std::memcpy(ws->h_stage + 16, h_opts.data(), 16);
+        if (P) std::memcpy(ws->h_stage + 32, hashes + base, P * sizeof(uint32_t));
+        FPX_HIP(hipMemcpyAsync(ws->d_stage, ws->h_stage, 32 + P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        d_hashes_base = reinterpret_cast<const uint32_t*>(ws->d_stage + 32);
+        d_offsets = reinterpret_cast<const uint64_t*>(ws->d_stage);
+        d_opts = reinterpret_cast<const uint32_t*>(ws->d_stage + 16);
+        staged_single = true;
     } else {
         for (uint32_t q = 0; q < B; ++q)
             if (opts[q].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
@@ -1545,7 +1564,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
     if (P && !score_only) {
-        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, base, ws->d_keys[0]);
+        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0]);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
         const size_t tb = sort_u64_temp_bytes(P, qb, 32 + qb);

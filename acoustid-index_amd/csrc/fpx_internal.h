@@ -120,7 +120,8 @@ struct Workspace {
     // pinned host staging
     unsigned long long* h_counters = nullptr;
     // one small query travels in ONE pinned copy: [offsets 2 x u64 | opts 4 x u32 | hashes]
-    uint8_t* h_stage = nullptr; uint8_t* d_stage = nullptr;
+    uint8_t* h_stage = nullptr; uint8_t* d_stage = nullptr;      // pinned + its device-mapped address
+    unsigned long long* d_ret = nullptr;                          // device-mapped address of h_counters
 };
 
 // A query batch already uploaded to HBM (fpx_query_batch_create): the timed region of a resident

@@ -88,11 +88,13 @@ __device__ __forceinline__ uint32_t lookup_block(const SegDesc& s, uint32_t h)
 // ------------------------------------------------------------------------------------------------
 // hashes_base[i] is the hash at ABSOLUTE position i of the batch; the view starts at absolute position `base`
 __global__ void k_make_keys(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
-                            uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys)
+                            uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,
+                            unsigned long long* zero_counters = nullptr)
 {
     // one workgroup per query
     uint32_t q = blockIdx.x;
     if (q >= B) return;
+    if (zero_counters && q == 0 && threadIdx.x < CTR_COUNT) zero_counters[threadIdx.x] = 0ull;   // single-query path: saves a memset call
     uint64_t lo = offsets[q], hi = offsets[q + 1];
     for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
         keys[i - base] = ((uint64_t)hashes_base[i] << qb) | q;
@@ -1274,7 +1276,8 @@ __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const u
 constexpr uint32_t SINGLE_CANDS = 2048;
 constexpr uint32_t SINGLE_OUT_MAX = 1024;          // results that fit behind the counters (fpx_result each)
 __global__ __launch_bounds__(256) void k_finish_single(const uint64_t* __restrict__ cands, const uint32_t* __restrict__ opts,
-                                                       unsigned long long* counters, uint32_t out_cap)
+                                                       const unsigned long long* __restrict__ counters, uint32_t out_cap,
+                                                       unsigned long long* ret)      // pinned host memory, device-mapped
 {
     __shared__ uint64_t key[SINGLE_CANDS];
     const uint32_t tid = threadIdx.x;
@@ -1298,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_finish_single(const uint64_t* __restric
         }
     if (tid == 0) {
         // SearchResults.finish for one query (src/common.zig:147-167); key = (~score) << 32 | doc
-        fpx_result* out = reinterpret_cast<fpx_result*>(counters + CTR_COUNT + 1);
+        fpx_result* out = reinterpret_cast<fpx_result*>(ret + CTR_COUNT + 1);
         const uint32_t max_results = opts[0];
         uint32_t min_score = opts[1];
         const uint32_t pct = opts[2];
@@ -1314,8 +1317,9 @@ __global__ __launch_bounds__(256) void k_finish_single(const uint64_t* __restric
             if (n < out_cap) { out[n].id = (uint32_t)key[i]; out[n].score = score; }
             ++n;
         }
-        counters[CTR_COUNT] = n < out_cap ? n : out_cap;
+        ret[CTR_COUNT] = n < out_cap ? n : out_cap;
     }
+    if (tid < CTR_COUNT) ret[tid] = counters[tid];                   // the statistics ride along: no copy call at all
 }
 
 // merge `world` per-rank tables (each sorted by score desc, id asc, disjoint doc ownership)
@@ -1475,6 +1479,12 @@ static double now_ms()
 // ------------------------------------------------------------------------------------------------
 // `offsets` are absolute positions into the batch the view [q0, q0+B) belongs to; `hashes` (host) points at
 // absolute position 0 and is only read when the batch is not resident.
+static uint64_t lean_min_probes()
+{
+    static const uint64_t v = [] { const char* e = getenv("FPX_LEAN_MIN"); return e ? strtoull(e, nullptr, 0) : (1ull << 16); }();
+    return v;
+}
+
 // Hash-range sharding of one segment (second mode) cuts the pipeline at the hit records: a doc's
 // postings may come from several GPUs, so the records travel (grouped by doc & (world - 1)) before they are counted.
 struct Exchange {
@@ -1522,7 +1532,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     const uint64_t* d_offsets;
     const uint32_t* d_opts;
     bool staged_single = false;
-    FPX_HIP(hipEventRecord(ws->ev_begin, st));
+    // A single /_search (B == 1) is latency bound and every HIP call costs microseconds (and a runtime lock shared with
+    // the other host threads): its pipeline runs with fixed sizes, reads its inputs from and writes its outputs to
+    // device-mapped pinned memory (no copy, memset or event calls), synchronises once, and is checked at the end;
+    // anything that does not fit falls back to the general path.
+    bool single_fast = B == 1 && !partial && !ex && !no_fast && P != 0 && out_cap <= SINGLE_OUT_MAX &&
+                       (snap->n_lean == 0 || P * snap->n_file < lean_min_probes());
+    if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_begin, st));
     if (resident) {
         d_hashes_base = resident->d_hashes;
         d_offsets = resident->d_offsets + q0;
@@ -1531,8 +1547,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // one small query: offsets, options and hashes travel in a single copy from pinned memory, no host sync
         if (opts[0].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
         if (!ws->h_stage) {
-            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_stage), STAGE_BYTES));
-            FPX_HIP(hipMalloc(&ws->d_stage, STAGE_BYTES));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_stage), STAGE_BYTES, hipHostMallocMapped));
+            FPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_stage), ws->h_stage, 0));
         }
         std::vector<uint32_t> h_opts;
         fill_opts(h_opts, opts, offsets, 1);
@@ -1540,7 +1556,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         so[0] = 0; so[1] = P;
         std::memcpy(ws->h_stage + 16, h_opts.data(), 16);
         if (P) std::memcpy(ws->h_stage + 32, hashes + base, P * sizeof(uint32_t));
-        FPX_HIP(hipMemcpyAsync(ws->d_stage, ws->h_stage, 32 + P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        // the kernels read the query straight from pinned host memory (4 KB over PCIe): no copy call
         d_hashes_base = reinterpret_cast<const uint32_t*>(ws->d_stage + 32);
         d_offsets = reinterpret_cast<const uint64_t*>(ws->d_stage);
         d_opts = reinterpret_cast<const uint32_t*>(ws->d_stage + 16);
@@ -1559,12 +1575,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         d_offsets = ws->d_offsets;
         d_opts = ws->d_opts;
     }
-    FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+    if (!single_fast) FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
     if (P && !score_only) {
-        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0]);
+        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
+                           single_fast ? ws->d_counters : nullptr);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
         const size_t tb = sort_u64_temp_bytes(P, qb, 32 + qb);
@@ -1596,12 +1613,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
     }
     bool force_generic = false, used_lean = false;
-    // A single /_search (B == 1) is latency bound: its tail runs without intermediate host round trips, with fixed
-    // sizes, and is checked once at the end; anything that does not fit falls back to the general path below.
-    bool single_fast = B == 1 && !partial && !ex && !no_fast && P != 0 && out_cap <= SINGLE_OUT_MAX;
     for (int attempt = 0;; ++attempt) {
         used_lean = false;
-        FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+        if (!single_fast) FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));   // (k_make_keys did it)
         if (P && snap->n_file) {
             ProbeArgs a;
             a.pairs = d_pairs; a.P = P; a.qb = qb;
@@ -1615,9 +1629,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
-            static const uint64_t lean_min = [] { const char* e = getenv("FPX_LEAN_MIN"); return e ? strtoull(e, nullptr, 0) : (1ull << 16); }();
-            const bool lean = snap->n_lean != 0 && !force_generic && P < 0xFFFFFFFFull && total >= lean_min;
-            FPX_HIP(hipEventRecord(ws->ev_probe0, st));
+            const bool lean = snap->n_lean != 0 && !force_generic && P < 0xFFFFFFFFull && total >= lean_min_probes();
+            if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (lean) {
                 // main kernel: k_probe_lean8 over the dense 512-B segments
                 FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));
@@ -1650,7 +1663,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 a.segs = snap->d_file;
                 if (snap->all_512) hipLaunchKernelGGL((k_probe<true, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
                 else hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
-                FPX_HIP(hipEventRecord(ws->ev_probe1, st));
+                if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             }
             FPX_HIP(hipGetLastError());
             probe_launches += 1;
@@ -1660,8 +1673,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                                snap->d_mem, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
             FPX_HIP(hipGetLastError());
         }
-        if (single_fast && !used_lean) break;      // one query: nothing below needs the counts on the host yet
-        single_fast = false;
+        if (single_fast) break;                     // one query: nothing below needs the counts on the host yet
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipStreamSynchronize(st));
         if (P && snap->n_file) {
@@ -1694,13 +1706,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         hipLaunchKernelGGL(k_score, dim3(1), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
                            (const uint64_t*)ws->d_hits[0], (const uint64_t*)nullptr, d_opts, log2f, sb1, ws->d_cands[0],
                            (uint64_t)SINGLE_CANDS, ws->d_counters, (uint64_t)ws->cap_hits);
-        hipLaunchKernelGGL(k_finish_single, dim3(1), dim3(256), 0, st, (const uint64_t*)ws->d_cands[0], d_opts, ws->d_counters, out_cap);
+        if (!ws->d_ret) FPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_ret), ws->h_counters, 0));
+        hipLaunchKernelGGL(k_finish_single, dim3(1), dim3(256), 0, st, (const uint64_t*)ws->d_cands[0], d_opts,
+                           (const unsigned long long*)ws->d_counters, out_cap, ws->d_ret);
         FPX_HIP(hipGetLastError());
-        // counters, result count and results in one copy to pinned memory
-        const size_t ret_bytes = ((size_t)CTR_COUNT + 1) * sizeof(unsigned long long) + (size_t)out_cap * sizeof(fpx_result);
-        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, ret_bytes, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipEventRecord(ws->ev_end, st));
-        FPX_HIP(hipStreamSynchronize(st));
+        FPX_HIP(hipStreamSynchronize(st));      // counters, result count and results are in pinned host memory now
         if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
         H = ws->h_counters[CTR_HITS];
         const bool fits = H <= ws->cap_hits && ws->h_counters[CTR_CANDS] <= SINGLE_CANDS && ws->h_counters[CTR_MAXSCORE] == 0;
@@ -1710,10 +1720,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         *out_n = (uint32_t)ws->h_counters[CTR_COUNT];
         std::memcpy(out, ws->h_counters + CTR_COUNT + 1, (size_t)*out_n * sizeof(fpx_result));
-        if (stats) {
-            float total_ms = 0.f, ms = 0.f;
-            (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
-            if (snap->n_file) (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
+        if (stats) {                             // counters only: the fast path takes no device timestamps
+            const float total_ms = 0.f, ms = 0.f;
             stats->probes += ws->h_counters[CTR_PROBES];
             stats->scanned_blocks += ws->h_counters[CTR_BLOCKS];
             stats->scanned_docs += ws->h_counters[CTR_DOCS];

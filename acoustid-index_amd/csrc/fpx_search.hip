@@ -1621,7 +1621,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.pairs = d_pairs; a.P = P; a.qb = qb;
             // enough workgroups to fill 256 CUs; long per-wave runs amortise the index walk for big batches
             const uint64_t total = P * snap->n_file;
-            a.ppw = total >= (1ull << 22) ? 64u : total >= (1ull << 18) ? 16u : 4u;
+            // (16 pairs per wave also for tiny batches: a single query is bound by per-workgroup set-up, not by parallelism)
+            a.ppw = total >= (1ull << 22) ? 64u : 16u;
             a.rounds = total >= (1ull << 25) ? 2u : 1u;
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;

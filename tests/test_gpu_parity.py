@@ -320,3 +320,57 @@ def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env):
     assert top[nq + 0] is None or top[nq + 0][0] != 10                                # deleted
     assert all(r[0] != 6000 for r in got[nq + 1])                                     # A's copy of 6000 is superseded, B's deleted
     assert got[nq + 4][0][0] == 77 and got[nq + 4][0][1] >= 8                         # overwritten in a memory segment
+
+
+def test_deferred_list_overflow_falls_back_to_generic_pass(env):
+    """A lean-eligible segment (512-B blocks, > 2^20 items) in which EVERY block holds a 4-byte hash delta: the lean
+    kernel defers nearly every probe, its deferred lists overflow, and the batch is rerun on the generic kernel."""
+    fpx, oracle, Pair, ctx = env
+    rng = np.random.default_rng(77)
+    n_clusters, per_cluster = 1 << 14, 80                       # clusters 2^18 apart: a 4-byte delta every 80 items
+    base = (np.arange(n_clusters, dtype=np.uint64) << np.uint64(18))
+    h = (base[:, None] + rng.integers(0, 4000, (n_clusters, per_cluster), dtype=np.uint64)).ravel()
+    ids = rng.integers(1, 5001, len(h), dtype=np.uint64)
+    items = np.sort((h << np.uint64(32)) | ids)
+    p = Pair(ctx)
+    p.add_file(items, 1, 5000, 1, np.arange(1, 5001))
+    p.finish()
+    assert len(items) >= (1 << 20)
+    nq = 80
+    qs = []
+    for i in range(nq):
+        real = (items[rng.integers(0, len(items), 300)] >> np.uint64(32)).astype(np.uint32)
+        noise = (base[rng.integers(0, n_clusters, 700)] + rng.integers(0, 1 << 18, 700, dtype=np.uint64)).astype(np.uint32)
+        qs.append(np.concatenate([real, noise]))
+    got, st = p.check(qs, fpx.SearchOptions(max_results=20, min_score=1, min_score_pct=0))
+    assert st.probes >= (1 << 16)
+    assert st.generic_iters > st.probes // 4                    # the generic per-value decode carried the batch
+
+
+def test_hit_buffer_overflow_regrows(env):
+    """2000 hashes with 600 docs each: one query yields 1.2 M hit records, more than a fresh workspace's hit buffer
+    (2^20 records).  The single-query fast path notices at its final check and reruns the general path, which regrows
+    the buffer; a batch does the same in its retry loop."""
+    fpx, oracle, Pair, _ = env
+    ctx = fpx.Context(0)                                      # fresh context = fresh workspace pool with default capacities
+    rng = np.random.default_rng(5)
+    hot = rng.choice(1 << 32, 2000, replace=False).astype(np.uint64)
+    n_docs = 6000
+    h = np.stack([rng.choice(hot, 200, replace=False) for _ in range(n_docs)])
+    ids = np.arange(1, n_docs + 1, dtype=np.uint64)
+    items = np.sort(((h << np.uint64(32)) | ids[:, None]).ravel())
+    p = Pair(ctx)
+    p.add_file(items, 1, n_docs, 1, ids.astype(np.uint32))
+    p.finish()
+    q = hot.astype(np.uint32)
+    opt = fpx.SearchOptions(max_results=30, min_score=1, min_score_pct=0)
+    res = fpx.SearchResults(opt)
+    p.reader.search(q, res)                                   # single-query entry point
+    want = p.osnap.search(q, 30, 1, 0)
+    assert res.getResults() == want and res.stats.hits > (1 << 20)
+    ctx2 = fpx.Context(0)
+    p2 = Pair(ctx2)
+    p2.add_file(items, 1, n_docs, 1, ids.astype(np.uint32))
+    p2.finish()
+    got, st = p2.check([q, q[:1000], q[500:]], opt)            # batch entry point, fresh pool again
+    assert st.hits > (1 << 20)

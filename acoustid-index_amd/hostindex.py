@@ -11,9 +11,13 @@ Only the new segment is uploaded on a publish; the other segments of the snapsho
 Durability (oplog, manifest, segment files on disk) stays in the reference's storage engine and is not rebuilt here;
 `segfile.py` reads/writes the segment file format for loading real data directories.
 """
+import os
 import threading
 
+import numpy as np
+
 from . import index as _ix
+from . import segfile as _sf
 
 
 class IndexNotFound(Exception):
@@ -71,10 +75,18 @@ class Index:
                 self._checkpoint_locked()
             return commit_id
 
+    @staticmethod
+    def _merged_info(sources):
+        """SegmentInfo.merge folded over adjacent sources (src/segment.zig:38-51): the merged segment covers the commit
+        interval [first.commit_id, last.commit_id + last.merges]"""
+        first, last = sources[0], sources[-1]
+        return (last.commit_id + getattr(last, "merges", 0)) - first.commit_id
+
     def _checkpoint_locked(self):
         if not self.memory:
             return None
         merged = self._snapshot.merge(self.memory, self.block_size)
+        merged.merges = self._merged_info(self.memory)
         self._publish(self.files + [merged], [])
         return merged
 
@@ -89,15 +101,55 @@ class Index:
             if not (0 <= lo < hi <= len(self.files)) or hi - lo < 2:
                 raise ValueError("need at least two adjacent file segments")
             merged = self._snapshot.merge(self.files[lo:hi], self.block_size)
+            merged.merges = self._merged_info(self.files[lo:hi])
             self._publish(self.files[:lo] + [merged] + self.files[hi:], self.memory)
             return merged
+
+    # ---- persistence in the reference's own formats (src/filefmt.zig, src/manifest.zig, src/snapshot.zig) -----------
+    def persist(self, dirpath):
+        """Checkpoint what is in memory and write every file segment (downloaded from HBM) + the manifest: a data
+        directory the reference can open, and `Index.open` below can reload."""
+        with self._write:
+            self._checkpoint_locked()
+            os.makedirs(dirpath, exist_ok=True)
+            infos = []
+            for seg in self.files:
+                info = (seg.commit_id, getattr(seg, "merges", 0), None)
+                blocks, index = seg.download()
+                ids, alive = seg.docs()
+                _sf.write_segment_file(os.path.join(dirpath, _sf.segment_file_name(info[0], info[1])), info,
+                                       {int(i): bool(a) for i, a in zip(ids, alive)}, blocks, index, seg.block_size)
+                infos.append(info)
+            _sf.write_manifest(dirpath, infos)
+            return infos
+
+    @classmethod
+    def open(cls, ctx, dirpath, name="main", verify=True, **kwargs):
+        """Index.open's file-segment part (src/Index.zig:255-311): manifest order, every segment uploaded to HBM."""
+        self = cls(ctx, name, **kwargs)
+        segs = []
+        for info in _sf.read_manifest(dirpath):
+            f = _sf.read_segment_file(os.path.join(dirpath, _sf.segment_file_name(info[0], info[1])), verify)
+            seg = _ix.FileSegment(ctx, np.asarray(f["blocks"]), f["block_size"], np.asarray(f["block_index"]), f["min_doc_id"],
+                                  f["max_doc_id"], f["info"][0], f["doc_ids"], f["doc_alive"])
+            seg.merges = f["info"][1]
+            segs.append(seg)
+        self._publish(segs, [])
+        if segs:
+            self.last_commit_id = segs[-1].commit_id + segs[-1].merges
+        return self
+
+    def export_snapshot(self, out, dirpath, generation=1):
+        """GET /:index/_snapshot (src/snapshot.zig): persist, then stream header + segment files"""
+        infos = self.persist(dirpath)
+        _sf.write_snapshot(out, generation, dirpath, infos)
 
     def load_segments(self, file_segments):
         """Install already-built file segments (e.g. from segfile.load_index_dir), oldest first."""
         with self._write:
             self._publish(list(file_segments), [])
             if file_segments:
-                self.last_commit_id = max(self.last_commit_id, max(s.commit_id for s in file_segments))
+                self.last_commit_id = max(self.last_commit_id, max(s.commit_id + getattr(s, "merges", 0) for s in file_segments))
 
 
 class MultiIndex:

@@ -166,3 +166,65 @@ def load_index_dir(fpx, ctx, dirpath, verify=True):
         segs.append(fpx.FileSegment(ctx, s["blocks"], s["block_size"], s["block_index"], s["min_doc_id"], s["max_doc_id"],
                                     s["info"][0], s["doc_ids"], s["doc_alive"]))
     return fpx.Segments(ctx, segs), segs
+
+
+# ---- node-to-node snapshot stream (src/snapshot.zig) ---------------------------------------------------------------------
+# One self-delimiting msgpack header {f: format = 1, g: generation, s: [{i: SegmentInfo, s: payload bytes}]} followed by
+# the file segments' raw bytes in header order (tests/test_snapshot.py:4-31 pins the keys f, g, s and i, s).  SegmentInfo is
+# written as [commit_id, merges, version|nil] like in the manifest above; how msgpack.zig@bef6671 frames that struct is
+# parity unpinned, so the reader also accepts a map keyed by field name or first letter.
+SNAPSHOT_FORMAT = 1
+
+
+def _info_of(obj):
+    if isinstance(obj, (list, tuple)):
+        return tuple(obj) + (None,) * (3 - len(obj))
+    if isinstance(obj, dict):
+        g = lambda name: obj.get(name, obj.get(name[0]))
+        return (g("commit_id") or 0, g("merges") or 0, g("version"))
+    raise InvalidSegment("unreadable SegmentInfo")
+
+
+def write_snapshot(out, generation, dirpath, infos=None):
+    """writeSnapshot (src/snapshot.zig:50-59): header, then every live file segment's bytes uncopied."""
+    infos = read_manifest(dirpath) if infos is None else infos
+    paths = [os.path.join(dirpath, segment_file_name(i[0], i[1])) for i in infos]
+    out.write(msgpack.packb({"f": SNAPSHOT_FORMAT, "g": int(generation),
+                             "s": [{"i": [i[0], i[1], i[2]], "s": os.path.getsize(p)} for i, p in zip(infos, paths)]}))
+    for p in paths:
+        with open(p, "rb") as f:
+            while True:
+                chunk = f.read(1 << 20)
+                if not chunk:
+                    break
+                out.write(chunk)
+
+
+def parse_snapshot(data):
+    """parse (src/snapshot.zig:66-79) -> (generation, [(info, payload bytes)])"""
+    un = msgpack.Unpacker(raw=False, strict_map_key=False, max_buffer_size=0)
+    un.feed(bytes(data[:1 << 20]))
+    header = un.unpack()
+    pos = un.tell()
+    if header.get("f") != SNAPSHOT_FORMAT:
+        raise InvalidSegment("UnsupportedSnapshotFormat")
+    entries = []
+    for seg in header["s"]:
+        size = int(seg["s"])
+        if pos + size > len(data):
+            raise InvalidSegment("truncated snapshot payload")
+        entries.append((_info_of(seg["i"]), bytes(data[pos:pos + size])))
+        pos += size
+    return int(header["g"]), entries
+
+
+def restore_snapshot(dirpath, data, expected_generation):
+    """restoreInto (src/snapshot.zig:88-106): manifest from the header, every payload to its segment file."""
+    generation, entries = parse_snapshot(data)
+    if generation != expected_generation:
+        raise InvalidSegment("SnapshotGenerationMismatch")
+    os.makedirs(dirpath, exist_ok=True)
+    write_manifest(dirpath, [e[0] for e in entries])
+    for info, payload in entries:
+        with open(os.path.join(dirpath, segment_file_name(info[0], info[1])), "wb") as f:
+            f.write(payload)

@@ -3,6 +3,7 @@ tests/test_fingerprint_api.py:5-260, tests/test_content_negotiation.py:6-161, te
 data), plus the properties of the host mirror: snapshot isolation, read-your-writes, checkpoint/merge invariance,
 the request coalescer, and the stdlib HTTP wrapper."""
 import json
+import os
 import threading
 
 import msgpack
@@ -224,3 +225,43 @@ def test_http_wrapper_round_trip(env):
         assert json.loads(body) == {"results": []}
     finally:
         srv.shutdown()
+
+
+def test_persist_open_and_snapshot_round_trip(env, tmp_path):
+    """commits -> GPU checkpoint + file merge -> persist in the reference's segment-file format -> reopen in a new
+    Index -> export as a snapshot stream -> restore elsewhere -> reopen: the same answers everywhere (and the oracle's)"""
+    import io
+    fpx, oracle, ctx = env
+    rng = np.random.default_rng(21)
+    ix = fpx.Index(ctx, auto_checkpoint=False)
+    orc_mems = []
+    for c in range(1, 9):
+        changes = [("insert", int(rng.integers(1, 200)), rng.integers(0, 1 << 12, 25).tolist()) for _ in range(30)]
+        changes += [("delete", int(rng.integers(1, 200))) for _ in range(3)]
+        ix.update(changes)
+        orc_mems.append(oracle.memory_segment_from_changes(changes, c))
+        if c == 3 or c == 6:
+            ix.checkpoint()
+    osnap = oracle.Snapshot([], orc_mems)
+    queries = [rng.integers(0, 1 << 12, 50).tolist() for _ in range(30)]
+    opt = fpx.SearchOptions(max_results=20, min_score=1, min_score_pct=0)
+    want = [osnap.search(q, 20, 1, 0) for q in queries]
+    assert ix.acquire_reader().search_batch(queries, opt)[0] == want
+    d1 = str(tmp_path / "data")
+    infos = ix.persist(d1)                                     # checkpoints commits 7..8 too
+    assert [i[:2] for i in infos] == [(1, 2), (4, 2), (7, 1)]   # commit intervals [1,3] [4,6] [7,8] (src/segment.zig:38-51)
+    assert sorted(os.listdir(d1)) == sorted(["manifest"] + [fpx.segfile.segment_file_name(i[0], i[1]) for i in infos])
+    ix2 = fpx.Index.open(ctx, d1)
+    assert ix2.version == 8 and len(ix2.files) == 3
+    assert ix2.acquire_reader().search_batch(queries, opt)[0] == want
+    ix2.merge_files(0, 3)
+    assert ix2.files[0].merges == 7 and ix2.acquire_reader().search_batch(queries, opt)[0] == want
+    buf = io.BytesIO()
+    ix2.export_snapshot(buf, str(tmp_path / "data2"), generation=5)
+    d3 = str(tmp_path / "restored")
+    fpx.segfile.restore_snapshot(d3, buf.getvalue(), 5)
+    ix3 = fpx.Index.open(ctx, d3)
+    assert ix3.version == 8 and len(ix3.files) == 1
+    assert ix3.acquire_reader().search_batch(queries, opt)[0] == want
+    ix3.update([("insert", 5000, [1, 2, 3])])                  # the reopened index keeps committing where it left off
+    assert ix3.version == 9

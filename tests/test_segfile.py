@@ -95,3 +95,43 @@ def test_index_dir_loads_and_searches(tmp_path):
         q = oracle.synth_items(5, doc, 1, 32) >> np.uint64(32)
         r = fpx.SearchResults(fpx.http_options())
         assert reader.search(q, r) == osnap.search(q) and r.getResults()[0] == (doc, 32)
+
+
+def test_snapshot_stream_round_trip(tmp_path):
+    """src/snapshot.zig: header keys f, g, s / i, s as tests/test_snapshot.py:4-31 reads them; payloads are the files"""
+    import io
+    import msgpack
+    from fpx_testlib import fpx
+    sf = fpx.segfile
+    src = tmp_path / "src"
+    src.mkdir()
+    infos = []
+    for k, (commit, merges) in enumerate([(1, 3), (5, 0)]):
+        items = np.sort(np.array([((100 + i + 1000 * k) << 32) | (i % 7 + 1 + 10 * k) for i in range(300)], np.uint64))
+        from oracle import oracle
+        blocks, index = oracle.build_blocks(items, 1 + 10 * k, 512)
+        info = (commit, merges, None)
+        sf.write_segment_file(str(src / sf.segment_file_name(commit, merges)), info, {i + 1 + 10 * k: True for i in range(7)}, blocks, index)
+        infos.append(info)
+    sf.write_manifest(str(src), infos)
+    buf = io.BytesIO()
+    sf.write_snapshot(buf, 42, str(src))
+    data = buf.getvalue()
+    un = msgpack.Unpacker(raw=False)
+    un.feed(data)
+    header = un.unpack()
+    assert header["f"] == 1 and header["g"] == 42 and isinstance(header["s"], list)
+    assert un.tell() + sum(seg["s"] for seg in header["s"]) == len(data)           # the reference test's size equation
+    gen, entries = sf.parse_snapshot(data)
+    assert gen == 42 and [e[0] for e in entries] == infos
+    dst = tmp_path / "dst"
+    sf.restore_snapshot(str(dst), data, 42)
+    assert sf.read_manifest(str(dst)) == infos
+    for info in infos:
+        name = sf.segment_file_name(info[0], info[1])
+        assert (dst / name).read_bytes() == (src / name).read_bytes()
+        assert sf.read_segment_file(str(dst / name))["num_items"] == 300
+    with pytest.raises(sf.InvalidSegment):
+        sf.restore_snapshot(str(tmp_path / "x"), data, 43)                           # SnapshotGenerationMismatch
+    with pytest.raises(sf.InvalidSegment):
+        sf.parse_snapshot(data[:-10])

@@ -144,3 +144,82 @@ def test_fuzz_merge(env, seed):
         wb, wi = oracle.build_blocks(want["items"], want["min_doc_id"], bs)
         blocks, index = merged.download()
         assert np.array_equal(index, wi) and np.array_equal(blocks, wb)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_sharded_modes(env, seed):
+    """random worlds through BOTH multi-GPU decompositions emulated on one GPU: (a) whole segments per rank + docs-only
+    stand-ins, partial tables, merge; (b) hash-range slices per rank, record exchange by doc & (world - 1), score,
+    merge -- each against the oracle on the unsharded world"""
+    import torch
+    fpx, oracle, Pair, ctx = env
+    rng = np.random.default_rng(40_000 + seed)
+    # a world whose raw parts we keep, so that it can be rebuilt per rank
+    n_file = int(rng.integers(2, 5))
+    H, per, bits = int(rng.integers(8, 40)), int(rng.integers(300, 2000)), int(rng.choice([12, 20, 32]))
+    hot = rng.integers(0, 1 << bits, 4, dtype=np.uint64)
+    files, next_id = [], 1
+    p = Pair(ctx)
+    for s in range(n_file):
+        ids = next_id + np.arange(per, dtype=np.uint64)
+        next_id = int(ids[-1]) + 1
+        if s:
+            ids = np.unique(np.concatenate([ids, rng.choice(np.arange(1, int(ids[0])), 40, replace=False).astype(np.uint64)]))
+        h = rng.integers(0, 1 << bits, (len(ids), H), dtype=np.uint64)
+        m = rng.random(len(ids)) < 0.5
+        h[m, 0] = hot[rng.integers(0, 4, int(m.sum()))]
+        items = np.sort(((h << np.uint64(32)) | ids[:, None]).ravel())
+        blocks, index = p.add_file(items, int(ids.min()), int(ids.max()), s + 1, ids.astype(np.uint32))
+        files.append((blocks, index, int(ids.min()), int(ids.max()), s + 1, ids.astype(np.uint32)))
+    changes = [("delete", int(rng.integers(1, next_id))) for _ in range(3)] + [("insert", next_id + 5, [int(hot[0]), 1, 2])]
+    p.add_memory_changes(changes, n_file + 1)
+    p.finish()
+    mem = oracle.memory_segment_from_changes(changes, n_file + 1)
+    mids, malive = mem.docs()
+    qs = []
+    for i in range(24):
+        q = rng.integers(0, 1 << bits, 60).tolist() + [int(hot[i % 4]), 1, 2]
+        qs.append(q)
+    flat = np.concatenate([np.asarray(q, np.uint32) for q in qs])
+    off = np.concatenate([[0], np.cumsum([len(q) for q in qs])]).astype(np.uint64)
+    for opts in (fpx.http_options(), fpx.SearchOptions(50, 1, 10)):
+        qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, off))
+        B, cap = qb.B, qb.cap
+        want = [p.osnap.search(q, opts.max_results, opts.min_score, opts.min_score_pct) for q in qs]
+        for world in (2, 4):
+            # (a) segment sharding
+            parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
+            cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+            for r in range(world):
+                segs = []
+                for s, (blocks, index, lo, hi, commit, ids) in enumerate(files):
+                    segs.append(fpx.FileSegment(ctx, blocks, 512, index, lo, hi, commit, ids) if s % world == r
+                                else fpx.RemoteSegment(ctx, lo, hi, commit, ids))
+                segs.append(fpx.MemorySegment(ctx, mem.items(), mem.min_doc_id, mem.max_doc_id, n_file + 1, mids, malive)
+                            if n_file % world == r else fpx.RemoteSegment(ctx, mem.min_doc_id, mem.max_doc_id, n_file + 1, mids, malive))
+                rd = fpx.IndexReader(fpx.Segments(ctx, segs))
+                fpx.search_resident_partial(rd, qb, parts[r].data_ptr(), cnts[r].data_ptr())
+            torch.cuda.synchronize()
+            out, out_n = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
+            assert fpx.results_to_lists(out, out_n) == want
+            # (b) hash-range slices
+            recs, counts = [], []
+            for r in range(world):
+                segs = []
+                for (blocks, index, lo, hi, commit, ids) in files:
+                    b, ix, wlo, whi = fpx.sharding.split_by_hash(blocks, 512, index, world)[r]
+                    segs.append(fpx.FileSegment.slice(ctx, b, 512, ix, wlo, whi, lo, hi, commit, ids))
+                segs.append(fpx.MemorySegment(ctx, mem.items(), mem.min_doc_id, mem.max_doc_id, n_file + 1, mids, malive)
+                            if r == 0 else fpx.RemoteSegment(ctx, mem.min_doc_id, mem.max_doc_id, n_file + 1, mids, malive))
+                rd = fpx.IndexReader(fpx.Segments(ctx, segs))
+                buf = torch.zeros((1 << 18,), dtype=torch.int64, device="cuda")
+                c, _ = fpx.probe_resident(rd, qb, world, buf.data_ptr(), buf.numel())
+                recs.append(buf)
+                counts.append([int(x) for x in c])
+            parts.zero_(); cnts.zero_()
+            for d in range(world):
+                got = torch.cat([recs[r][sum(counts[r][:d]):sum(counts[r][:d + 1])] for r in range(world)])
+                fpx.score_partial(ctx, qb, got.data_ptr(), got.numel(), parts[d].data_ptr(), cnts[d].data_ptr())
+            torch.cuda.synchronize()
+            out, out_n = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
+            assert fpx.results_to_lists(out, out_n) == want

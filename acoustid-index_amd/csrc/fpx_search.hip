@@ -64,6 +64,26 @@ __device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32
     return lo < n && gload_u32(dead + lo) == d;
 }
 
+// The pairs are sorted on the top 32 - KEY_SORT_SKIP bits of the hash only (one radix pass less): inside such a bucket
+// they keep the order k_make_keys wrote them in -- by query, then by position in the query -- because the sort is stable.
+// dedupSorted (src/Index.zig:489-499) therefore looks back over the pairs of the SAME query in the SAME bucket
+// (usually none): a pair is a duplicate iff an equal pair precedes it there.
+constexpr unsigned KEY_SORT_SKIP = 8;
+__device__ __forceinline__ bool is_duplicate_pair(const uint64_t* pairs, uint64_t p, uint64_t key, uint32_t qb)
+{
+    if (p == 0) return false;
+    const uint64_t qmask64 = qb >= 32u ? 0xFFFFFFFFull : ((1ull << qb) - 1ull);
+    uint64_t x = gload_u64(pairs + p - 1) ^ key;
+    if (x == 0ull) return true;
+    if (((x >> (qb + KEY_SORT_SKIP)) | (x & qmask64)) != 0ull) return false;      // the usual exit: another bucket or query
+    for (uint64_t i = p - 1; i > 0; --i) {                                         // same (bucket, query): keep looking back
+        x = gload_u64(pairs + i - 1) ^ key;
+        if (x == 0ull) return true;
+        if (((x >> (qb + KEY_SORT_SKIP)) | (x & qmask64)) != 0ull) return false;
+    }
+    return false;
+}
+
 // hash-range slices (one segment split across GPUs): is hash h probed in this slice?
 __device__ __forceinline__ bool owned_hash(const SegDesc& s, uint32_t h)
 {
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
             valid = lane < a.ppw && p < a.P;
         }
         uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
-        if (!DEFERRED && valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;  // dedupSorted, src/Index.zig:489-499
+        if (!DEFERRED && valid && is_duplicate_pair(a.pairs, p, key, a.qb)) valid = false;     // dedupSorted, src/Index.zig:489-499
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint32_t q = (uint32_t)key & qmask;
         uint32_t b0 = seg.num_blocks;
@@ -805,7 +825,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             const uint64_t p = wave_base + (uint64_t)j * 64u + lane;
             bool valid = p < a.P;
             const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
-            if (valid && p > 0 && gload_u64(a.pairs + p - 1) == key) valid = false;      // dedupSorted, src/Index.zig:489-499
+            if (valid && is_duplicate_pair(a.pairs, p, key, a.qb)) valid = false;          // dedupSorted, src/Index.zig:489-499
             h[j] = (uint32_t)(key >> a.qb);
             q[j] = (uint32_t)key & qmask;
             lo[j] = 0; hi[j] = 0;
@@ -1065,7 +1085,7 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
     const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
     if (p >= P) return;
     const uint64_t key = pairs[p];
-    if (p > 0 && pairs[p - 1] == key) return;
+    if (is_duplicate_pair(pairs, p, key, qb)) return;
     const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
     uint64_t lo = 0, hi = ms.num_items;
     while (lo < hi) {
@@ -1584,9 +1604,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                            single_fast ? ws->d_counters : nullptr);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
-        const size_t tb = sort_u64_temp_bytes(P, qb, 32 + qb);
+        // ... and only the top 32 - KEY_SORT_SKIP of them: block-level locality is all the probes need from the order
+        // (a 256-value hash bucket is narrower than a block's hash span), see is_duplicate_pair for the dedup.
+        const size_t tb = sort_u64_temp_bytes(P, qb + KEY_SORT_SKIP, 32 + qb);
         if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
-        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb, 32 + qb, st, &kcur));
+        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + KEY_SORT_SKIP, 32 + qb, st, &kcur));
     }
     const uint64_t* d_pairs = ws->d_keys[kcur];
 

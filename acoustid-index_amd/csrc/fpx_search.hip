@@ -1834,8 +1834,17 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         hipLaunchKernelGGL(k_bounds, dim3((B + WG - 1) / WG), dim3(WG), 0, st, (const uint64_t*)ws->d_hits[0], H, B, ws->d_qrange);
         // counting filter sized for ~2x the average number of records per query (8 KB .. 64 KB of LDS) + 16 KB exact table
+        // The filter only has to keep cells that collect < min_score records below the floor: with the usual floor
+        // (n / 20 = 50 for 1 k-hash queries) a cell may hold several docs' records and still reject them, so a quarter of
+        // the size does; the LDS saved more than doubles the resident workgroups (k_score is occupancy bound).
+        uint32_t floor_min = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < B; ++q) {
+            const uint64_t raw_len = offsets[q + 1] - offsets[q];
+            floor_min = std::min(floor_min, opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20));
+        }
         uint32_t log2f = 11;
         while (log2f < 14 && (1ull << log2f) < 2 * (H / B + 1)) ++log2f;
+        log2f = std::max(11u, log2f - (floor_min >= 8u ? 2u : floor_min >= 3u ? 1u : 0u));
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
         static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),

@@ -144,3 +144,37 @@ def test_parse_changes():
     assert ch == [("insert", 7, [9])]
     with pytest.raises(fe.BadRequest):
         fe.parse_changes({"changes": [{"upsert": {}}]}, False)
+
+
+# ---- legacy line protocol (src/legacy.zig), vectors of tests/test_legacy.py that need no device -------------------------
+class _NoIndex:
+    legacy_attrs = {}
+
+    def get_index(self, name):
+        raise fpx.hostindex.IndexNotFound(name)
+
+    def create_index(self, name):
+        raise AssertionError("no commit expected")
+
+
+def test_legacy_protocol_without_device():
+    s = fpx.legacy.LegacySession(_NoIndex())
+    assert s.cmd("echo hello world") == "OK hello world"                    # tests/test_legacy.py:30-37
+    assert s.cmd("") == "OK "
+    assert s.cmd("frobnicate x").startswith("ERR ")
+    assert s.cmd("search notanumber") == "ERR invalid fingerprint"
+    assert s.cmd("search") == "ERR expected one argument"
+    assert s.cmd("insert 1 1,2,3") == "ERR not in transaction"
+    assert s.cmd("begin") == "OK " and s.cmd("begin") == "ERR already in transaction"
+    assert s.cmd("insert x 1,2") == "ERR invalid document id"
+    assert s.cmd("insert 5 1,,2") == "ERR invalid fingerprint"
+    assert s.cmd("rollback") == "OK " and s.cmd("rollback") == "ERR not in transaction"
+    assert s.cmd("get max_results") == "OK 500" and s.cmd("set max_results 1") == "OK " and s.cmd("get max_results") == "OK 1"
+    assert s.cmd("set max_results x") == "ERR invalid value"
+    assert s.cmd("set attribute foo bar") == "ERR not in transaction"
+    assert s.cmd("get attribute foo") == "OK "
+    assert s.cmd("optimize") == "ERR not in transaction"
+    assert fpx.legacy.LegacySession(_NoIndex(), read_only=True).cmd("begin") == "ERR read-only replica"
+    # signed decimals are reinterpreted as u32 (src/legacy.zig:318-330)
+    assert fpx.legacy.LegacySession.parse_fingerprint("-1,2147483648,-2147483648") == [0xFFFFFFFF, 0x80000000, 0x80000000]
+    assert s.cmd("search 1,2,3") == "OK "                                    # nothing committed

@@ -265,3 +265,26 @@ def test_persist_open_and_snapshot_round_trip(env, tmp_path):
     assert ix3.acquire_reader().search_batch(queries, opt)[0] == want
     ix3.update([("insert", 5000, [1, 2, 3])])                  # the reopened index keeps committing where it left off
     assert ix3.version == 9
+
+
+def test_legacy_protocol_search(env):
+    """tests/test_legacy.py:61-91 through the GPU path"""
+    fpx, _, ctx = env
+    mi = fpx.MultiIndex(ctx)
+    s = fpx.legacy.LegacySession(mi)
+    assert s.cmd("begin") == "OK "
+    assert s.cmd("insert 1001 11000,12000,13000") == "OK "
+    assert s.cmd("insert 1002 11000,12000,19000") == "OK "
+    assert s.cmd("commit") == "OK "
+    assert s.cmd("search 11000,12000,13000") == "OK 1001:3 1002:2"
+    assert s.cmd("search 11000,12000,19000") == "OK 1002:3 1001:2"
+    assert s.cmd("begin") == "OK " and s.cmd("insert 6001 61000,62000,63000") == "OK " and s.cmd("rollback") == "OK "
+    assert s.cmd("search 61000,62000,63000") == "OK "
+    s.cmd("begin"); s.cmd("insert 2001 21000,22000"); s.cmd("insert 2002 21000,22000"); s.cmd("commit")
+    both = s.cmd("search 21000,22000")
+    assert both.startswith("OK ") and len(both[3:].split()) == 2
+    assert s.cmd("set max_results 1") == "OK " and len(s.cmd("search 21000,22000")[3:].split()) == 1
+    s2 = fpx.legacy.LegacySession(mi)                                       # another connection sees the commits
+    assert s2.cmd("search -4294956296,12000") == "OK 1001:2 1002:2"          # 11000 sent in its signed-wrapped form
+    s.cmd("begin"); s.cmd("set attribute foo bar"); s.cmd("commit")
+    assert s2.cmd("get attribute foo") == "OK bar"

@@ -288,3 +288,62 @@ def test_legacy_protocol_search(env):
     assert s2.cmd("search -4294956296,12000") == "OK 1001:2 1002:2"          # 11000 sent in its signed-wrapped form
     s.cmd("begin"); s.cmd("set attribute foo bar"); s.cmd("commit")
     assert s2.cmd("get attribute foo") == "OK bar"
+
+
+def test_readers_survive_concurrent_publishes_and_merges(env):
+    """The reference's lifetime contract (src/Index.zig:1-6): a reader keeps the snapshot it acquired -- and through it
+    every segment -- alive while a writer publishes new snapshots, checkpoints and merges (which drop the last owning
+    reference to retired segments).  Readers hammer the index during 150 commits, 12 GPU checkpoints and 3 file merges;
+    every doc, once visible to a thread, stays visible with its full score (read-your-writes is monotonic)."""
+    fpx, _, ctx = env
+    ix = fpx.Index(ctx, auto_checkpoint=False)
+    n_commits = 150
+    stop = threading.Event()
+    errors = []
+
+    def hashes(k):
+        return [k * 16 + j for j in range(5)]
+
+    def reader(tid):
+        seen = set()
+        rng = np.random.default_rng(tid)
+        opt = fpx.SearchOptions(max_results=5, min_score=1, min_score_pct=0)
+        try:
+            while not stop.is_set():
+                k = int(rng.integers(1, n_commits + 1))
+                rd = ix.acquire_reader()
+                res = fpx.SearchResults(opt)
+                rd.search(hashes(k), res)
+                got = res.getResults()
+                if got:
+                    assert got == [(k, 5)], got
+                    seen.add(k)
+                else:
+                    assert k not in seen, f"doc {k} disappeared"
+                if rng.random() < 0.2:                       # batched entry point on the same held snapshot
+                    ks = [int(x) for x in rng.integers(1, n_commits + 1, 8)]
+                    out, _ = rd.search_batch([hashes(x) for x in ks], opt)
+                    for x, r in zip(ks, out):
+                        assert r in ([], [(x, 5)])
+                        if x in seen:
+                            assert r == [(x, 5)]
+        except Exception as e:                               # surfaces in the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=reader, args=(t,)) for t in range(6)]
+    [t.start() for t in threads]
+    try:
+        for k in range(1, n_commits + 1):
+            ix.update([("insert", k, hashes(k))])
+            if k % 12 == 0:
+                ix.checkpoint()
+            if k % 48 == 0 and len(ix.files) >= 2:
+                ix.merge_files(0, len(ix.files))
+    finally:
+        stop.set()
+        [t.join() for t in threads]
+    assert not errors, errors[:3]
+    assert len(ix.files) <= 3 and ix.version == n_commits
+    res = fpx.SearchResults(fpx.SearchOptions(max_results=5, min_score=1, min_score_pct=0))
+    ix.acquire_reader().search(hashes(n_commits), res)
+    assert res.getResults() == [(n_commits, 5)]

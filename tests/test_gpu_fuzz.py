@@ -4,7 +4,10 @@ the oracle, results and the scanned_blocks / scanned_docs counters.  Seeds are t
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("FPX_FUZZ_SCALE", "1"))          # FPX_FUZZ_SCALE=20 for a soak run (more seeds per family)
 
 
 @pytest.fixture(scope="module")
@@ -94,7 +97,7 @@ def random_options(fpx, rng, n):
     return opts
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(64 * SCALE))
 def test_fuzz_small_worlds(env, seed):
     fpx, oracle, Pair, ctx = env
     rng = np.random.default_rng(10_000 + seed)
@@ -108,7 +111,7 @@ def test_fuzz_small_worlds(env, seed):
         assert res.getResults() == p.osnap.search(q, o.max_results, o.min_score, o.min_score_pct)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_fuzz_lean_sized_worlds(env, seed):
     """segments of > 2^20 items and batches of > 2^16 probes: the lean kernel + deferred pass carry these"""
     fpx, oracle, Pair, ctx = env
@@ -116,10 +119,11 @@ def test_fuzz_lean_sized_worlds(env, seed):
     p, items, hash_bits, hot = random_world(fpx, Pair, ctx, rng, lean_sized=True)
     qs = random_queries(rng, items, hash_bits, hot, 80, 1000)
     got, st = p.check(qs, random_options(fpx, rng, len(qs)))
-    assert st.probe_kernel_bytes > 0 and st.probe_aux_ms > 0          # aux time is only taken next to the lean kernel
+    if sum(len(q) for q in qs) * len(p.orc_file) >= (1 << 16):         # (a world with one segment and short queries stays below)
+        assert st.probe_kernel_bytes > 0 and st.probe_aux_ms > 0      # aux time is only taken next to the lean kernel
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_fuzz_merge(env, seed):
     """random source ranges of random worlds through fpx_segment_merge against the oracle's SegmentMerger + writer"""
     fpx, oracle, Pair, ctx = env
@@ -146,7 +150,7 @@ def test_fuzz_merge(env, seed):
         assert np.array_equal(index, wi) and np.array_equal(blocks, wb)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_fuzz_sharded_modes(env, seed):
     """random worlds through BOTH multi-GPU decompositions emulated on one GPU: (a) whole segments per rank + docs-only
     stand-ins, partial tables, merge; (b) hash-range slices per rank, record exchange by doc & (world - 1), score,

@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
     extern __shared__ __align__(16) uint8_t smem[];
     unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);                 // 2^SCORE_TABLE_LOG2 slots
     unsigned int* filter = reinterpret_cast<unsigned int*>(smem + (8u << SCORE_TABLE_LOG2)); // 2^log2f cells
-    __shared__ uint32_t survivors;
+    __shared__ uint32_t survivors, wave_tot[WG / 64], cand_base_lo, cand_base_hi;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     // qrange == nullptr: a single query whose records are all of them; their count is still on the device
     const uint64_t lo = qrange ? qrange[2ull * q] : 0ull;
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
                 const uint32_t d = rec[u];
                 const uint32_t hsh = mix32(d);
                 if (filter[hsh & fmask] < min_score) continue;
-                if (passes > 1u && ((hsh >> 16) % passes) != pass) continue;
+                if (passes > 1u && ((hsh >> 20) % passes) != pass) continue;   // class bits disjoint from the slot bits (9..19)
                 uint32_t s = (hsh >> 9) & tmask;
                 for (;;) {
                     unsigned long long cur = table[s];
@@ -1233,22 +1233,49 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
             }
         }
         __syncthreads();
-        // candidates of this pass (rare: a handful per query): one global reservation per wave that has any
-        for (uint32_t s0 = 0; s0 < T; s0 += WG) {
-            const unsigned long long e = table[s0 + tid];
-            const uint32_t count = (uint32_t)e;
-            const bool is_cand = count != 0u && count >= min_score;
-            const unsigned long long m = __ballot((int)is_cand);
-            if (m == 0ull) continue;
-            if (is_cand && (uint64_t)count > smax) atomicMax(&counters[CTR_MAXSCORE], (unsigned long long)count);
-            unsigned long long base = 0;
-            if ((tid & 63u) == 0u) base = atomicAdd(&counters[CTR_CANDS], (unsigned long long)__popcll(m));
-            base = __shfl(base, 0);
-            if (is_cand) {
-                const uint64_t slot = base + __popcll(m & ((1ull << (tid & 63u)) - 1ull));
-                const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
+        // candidates of this pass: ONE global reservation per workgroup (same-address global atomics serialise; with a
+        // floor of 1 -- the legacy protocol's -- every counted doc is a candidate, thousands per query)
+        {
+            constexpr uint32_t SPT = (1u << SCORE_TABLE_LOG2) / WG;               // table slots per thread
+            uint32_t mine = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < SPT; ++j) {
+                const uint32_t count = (uint32_t)table[j * WG + tid];
+                mine += (count != 0u && count >= min_score) ? 1u : 0u;
+            }
+            // exclusive prefix of `mine` over the workgroup: wave scan + the waves' totals
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if ((tid & 63u) >= (uint32_t)d) incl += t;
+            }
+            if ((tid & 63u) == 63u) wave_tot[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < WG / 64; ++w) {
+                if (w < (tid >> 6)) wbase += wave_tot[w];
+                total += wave_tot[w];
+            }
+            if (total != 0u) {
+                if (tid == 0) {
+                    const unsigned long long g = atomicAdd(&counters[CTR_CANDS], (unsigned long long)total);
+                    cand_base_lo = (uint32_t)g; cand_base_hi = (uint32_t)(g >> 32);
+                }
+                __syncthreads();
+                uint64_t slot = (((uint64_t)cand_base_hi << 32) | cand_base_lo) + wbase + (incl - mine);
                 const uint64_t qpart = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
-                if (slot < cand_cap) cands[slot] = qpart | ((smax - sc) << 32) | (e >> 32);
+#pragma unroll
+                for (uint32_t j = 0; j < SPT; ++j) {
+                    const unsigned long long e = table[j * WG + tid];
+                    const uint32_t count = (uint32_t)e;
+                    if (count == 0u || count < min_score) continue;
+                    if ((uint64_t)count > smax) atomicMax(&counters[CTR_MAXSCORE], (unsigned long long)count);
+                    const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
+                    if (slot < cand_cap) cands[slot] = qpart | ((smax - sc) << 32) | (e >> 32);
+                    ++slot;
+                }
             }
         }
         __syncthreads();

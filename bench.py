@@ -36,6 +36,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FPX_BENCH_BATCH", 8192)))
     ap.add_argument("--query-len", type=int, default=1000)
     ap.add_argument("--limit", type=int, default=40)
+    ap.add_argument("--min-score", type=int, default=None,
+                    help="absolute score floor (default: the HTTP default (n + 19) / 20; 1 = the legacy protocol's)")
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("FPX_BENCH_CPU_QUERIES", 1024)))
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FPX_BENCH_CPU_SECONDS", 10.0)))
@@ -158,7 +160,7 @@ def main():
 
     # ---- queries (identical on every rank), resident in HBM before the timed region
     flat, offsets, targets = fpx.synth.make_queries(args.seed, 4242, B, docs, H, query_len=args.query_len)
-    opts = fpx.http_options(limit=args.limit)
+    opts = fpx.http_options(limit=args.limit, min_score=args.min_score)
     qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
     cap = qb.cap
     out = np.zeros((B, cap, 2), np.uint32)

@@ -1141,17 +1141,18 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 //      64-bit LDS atomics -- the GPU form of the reference's per-search hit map (src/common.zig:83-129).  If more
 //      records survive than the table holds they are counted in passes over disjoint doc classes.
 // Candidate key = q << (32 + sb) | (smax - score) << 32 | doc   (ascending = score desc, doc asc within a query).
-constexpr uint32_t SCORE_TABLE_LOG2 = 11;       // exact table: 2048 slots = 16 KB
+constexpr uint32_t SCORE_TABLE_LOG2 = 11;       // exact table: 2048 slots = 16 KB (2^13 = 64 KB when the floor is too low for the filter)
 
 __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ qrange,
-                                               const uint32_t* __restrict__ opts, uint32_t log2f, uint32_t sb,
+                                               const uint32_t* __restrict__ opts, uint32_t log2ft, uint32_t sb,
                                                uint64_t* cands, uint64_t cand_cap, unsigned long long* counters,
                                                uint64_t single_hit_cap = 0)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);                 // 2^SCORE_TABLE_LOG2 slots
-    unsigned int* filter = reinterpret_cast<unsigned int*>(smem + (8u << SCORE_TABLE_LOG2)); // 2^log2f cells
-    __shared__ uint32_t survivors, wave_tot[WG / 64], cand_base_lo, cand_base_hi;
+    const uint32_t log2t = log2ft >> 8, log2f = log2ft & 0xFFu;                              // table and filter sizes
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);                 // 2^log2t slots
+    unsigned int* filter = reinterpret_cast<unsigned int*>(smem + ((size_t)8u << log2t));     // 2^log2f cells
+    __shared__ uint32_t survivors, qmax, wave_tot[WG / 64], cand_base_lo, cand_base_hi;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     // qrange == nullptr: a single query whose records are all of them; their count is still on the device
     const uint64_t lo = qrange ? qrange[2ull * q] : 0ull;
@@ -1161,7 +1162,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
     const uint32_t min_score = opts[q * 4u + 1u];
     if (n < (uint64_t)min_score) return;                          // no doc can reach the floor
     const uint32_t F = 1u << log2f, fmask = F - 1u;
-    const uint32_t T = 1u << SCORE_TABLE_LOG2, tmask = T - 1u;
+    const uint32_t T = 1u << log2t, tmask = T - 1u;
     const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
 
     // The records are read in tiles of WG * RPT: every thread first issues all its loads (RPT of them in flight), then
@@ -1189,24 +1190,23 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
             if (t0 + (uint64_t)u * WG + tid < n) atomicAdd(&filter[mix32(rec[u]) & fmask], 1u);
     }
     __syncthreads();
-    {
+    // records whose filter cell reaches `fl` (every doc with count >= fl is among them)
+    auto count_survivors = [&](uint32_t fl) -> uint32_t {
+        if (tid == 0) survivors = 0u;
+        __syncthreads();
         uint32_t mine = 0;
         for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
             if (!one_tile) load_tile(t0);
 #pragma unroll
             for (int u = 0; u < RPT; ++u)
-                if (t0 + (uint64_t)u * WG + tid < n) mine += filter[mix32(rec[u]) & fmask] >= min_score ? 1u : 0u;
+                if (t0 + (uint64_t)u * WG + tid < n) mine += filter[mix32(rec[u]) & fmask] >= fl ? 1u : 0u;
         }
         if (mine) atomicAdd(&survivors, mine);
-    }
-    __syncthreads();
-    const uint32_t nsurv = survivors;
-    if (nsurv < min_score) return;
-    const uint32_t fill = T * 3u / 4u;
-    const uint32_t passes = (nsurv + fill - 1u) / fill;
-
-    // ---- stage B
-    for (uint32_t pass = 0; pass < passes; ++pass) {
+        __syncthreads();
+        return survivors;
+    };
+    // exact (doc, count) table of the surviving records of class `pass`
+    auto fill_table = [&](uint32_t pass, uint32_t passes, uint32_t fl) {
         for (uint32_t s = tid; s < T; s += WG) table[s] = 0ull;
         __syncthreads();
         for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
@@ -1216,8 +1216,8 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
                 if (t0 + (uint64_t)u * WG + tid >= n) continue;
                 const uint32_t d = rec[u];
                 const uint32_t hsh = mix32(d);
-                if (filter[hsh & fmask] < min_score) continue;
-                if (passes > 1u && ((hsh >> 20) % passes) != pass) continue;   // class bits disjoint from the slot bits (9..19)
+                if (filter[hsh & fmask] < fl) continue;
+                if (passes > 1u && ((hsh >> 22) % passes) != pass) continue;   // class bits disjoint from the slot bits (9..21)
                 uint32_t s = (hsh >> 9) & tmask;
                 for (;;) {
                     unsigned long long cur = table[s];
@@ -1233,15 +1233,48 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
             }
         }
         __syncthreads();
+    };
+    const uint32_t fill = T * 3u / 4u;
+    uint32_t floor_q = min_score;
+    uint32_t nsurv = count_survivors(floor_q);
+    if (nsurv < floor_q) return;
+    uint32_t passes = (nsurv + fill - 1u) / fill;
+
+    // A low floor (the legacy protocol's min_score 1) lets every record through the filter and makes every counted doc a
+    // candidate -- only for SearchResults.finish to raise the floor to top * pct / 100 on its first entry
+    // (src/common.zig:160-163).  When the count needs several passes anyway, a count-only round finds the query's best
+    // score first and the floor is raised BEFORE anything is emitted.  (A rank of a sharded search may do the same with
+    // its LOCAL best score: the global best, hence the final floor, can only be higher.)
+    const uint32_t pct = opts[q * 4u + 2u];
+    if (passes > 1u && pct != 0u) {
+        if (tid == 0) qmax = 0u;
+        __syncthreads();
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            fill_table(pass, passes, floor_q);
+            uint32_t m = 0;
+            for (uint32_t s = tid; s < T; s += WG) m = max(m, (uint32_t)table[s]);
+            if (m) atomicMax(&qmax, m);
+            __syncthreads();
+        }
+        const uint32_t rel = (uint32_t)((uint64_t)qmax * pct / 100ull);
+        if (rel > floor_q) {
+            floor_q = rel;
+            nsurv = count_survivors(floor_q);
+            passes = max(1u, (nsurv + fill - 1u) / fill);
+        }
+    }
+
+    // ---- stage B
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        fill_table(pass, passes, floor_q);
         // candidates of this pass: ONE global reservation per workgroup (same-address global atomics serialise; with a
         // floor of 1 -- the legacy protocol's -- every counted doc is a candidate, thousands per query)
         {
-            constexpr uint32_t SPT = (1u << SCORE_TABLE_LOG2) / WG;               // table slots per thread
+            const uint32_t SPT = T / WG;                                          // table slots per thread
             uint32_t mine = 0;
-#pragma unroll
             for (uint32_t j = 0; j < SPT; ++j) {
                 const uint32_t count = (uint32_t)table[j * WG + tid];
-                mine += (count != 0u && count >= min_score) ? 1u : 0u;
+                mine += (count != 0u && count >= floor_q) ? 1u : 0u;
             }
             // exclusive prefix of `mine` over the workgroup: wave scan + the waves' totals
             uint32_t incl = mine;
@@ -1266,11 +1299,10 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
                 __syncthreads();
                 uint64_t slot = (((uint64_t)cand_base_hi << 32) | cand_base_lo) + wbase + (incl - mine);
                 const uint64_t qpart = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
-#pragma unroll
                 for (uint32_t j = 0; j < SPT; ++j) {
                     const unsigned long long e = table[j * WG + tid];
                     const uint32_t count = (uint32_t)e;
-                    if (count == 0u || count < min_score) continue;
+                    if (count == 0u || count < floor_q) continue;
                     if ((uint64_t)count > smax) atomicMax(&counters[CTR_MAXSCORE], (unsigned long long)count);
                     const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
                     if (slot < cand_cap) cands[slot] = qpart | ((smax - sc) << 32) | (e >> 32);
@@ -1754,7 +1786,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         (void)lds_attr1;
         const uint32_t log2f = 13, sb1 = 32u - qb;
         hipLaunchKernelGGL(k_score, dim3(1), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
-                           (const uint64_t*)ws->d_hits[0], (const uint64_t*)nullptr, d_opts, log2f, sb1, ws->d_cands[0],
+                           (const uint64_t*)ws->d_hits[0], (const uint64_t*)nullptr, d_opts, log2f | (SCORE_TABLE_LOG2 << 8), sb1, ws->d_cands[0],
                            (uint64_t)SINGLE_CANDS, ws->d_counters, (uint64_t)ws->cap_hits);
         if (!ws->d_ret) FPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_ret), ws->h_counters, 0));
         hipLaunchKernelGGL(k_finish_single, dim3(1), dim3(256), 0, st, (const uint64_t*)ws->d_cands[0], d_opts,
@@ -1872,6 +1904,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         uint32_t log2f = 11;
         while (log2f < 14 && (1ull << log2f) < 2 * (H / B + 1)) ++log2f;
         log2f = std::max(11u, log2f - (floor_min >= 8u ? 2u : floor_min >= 3u ? 1u : 0u));
+        // ... and with a floor of 1 or 2 (the legacy protocol) nearly every record passes it: the LDS goes to a larger
+        // exact table instead, so that the count needs 2 passes rather than 6.
+        uint32_t log2t = SCORE_TABLE_LOG2;
+        if (floor_min <= 2u && H / B > (1u << SCORE_TABLE_LOG2)) { log2t = 13; log2f = 11; }
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
         static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),
@@ -1880,8 +1916,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         for (int attempt = 0;; ++attempt) {
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_score, dim3(B), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
-                               (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f, sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
+            hipLaunchKernelGGL(k_score, dim3(B), dim3(WG), ((size_t)8 << log2t) + ((size_t)4 << log2f), st,
+                               (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
             FPX_HIP(hipGetLastError());
             FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipStreamSynchronize(st));

@@ -374,3 +374,26 @@ def test_hit_buffer_overflow_regrows(env):
     p2.finish()
     got, st = p2.check([q, q[:1000], q[500:]], opt)            # batch entry point, fresh pool again
     assert st.hits > (1 << 20)
+
+
+@pytest.mark.parametrize("pct", [0, 10, 60, 100])
+def test_low_floor_multi_pass_with_relative_cutoff(env, pct):
+    """The legacy protocol's options (min_score 1, limit up to 500, top_score_percent) on queries with thousands of
+    hit docs each: the exact count needs several passes (or the larger table), the best score is found in a count-only
+    round and the floor is raised to top * pct / 100 before candidates are emitted -- results must not change."""
+    fpx, oracle, Pair, ctx = env
+    seed, H, per = 733, 64, 30000
+    p = Pair(ctx)
+    for s in range(3):
+        lo = s * per + 1
+        p.add_file(fpx.synth.synth_items(seed, lo, per, H, dist=1), lo, lo + per - 1, s + 1, np.arange(lo, lo + per))
+    p.finish()
+    hot = [int(fpx.synth.mix64(np.uint64(seed) ^ np.uint64(0x5bd1e9955bd1e995) ^ (np.uint64(k) << np.uint64(32))) >> np.uint64(32))
+           for k in range(48)]
+    qs = []
+    for i in range(40):                                      # every query: a real doc + a varying set of hot values
+        doc = 1 + 977 * i
+        qs.append(np.concatenate([fpx.synth.synth_hashes(seed, [doc], H, 1)[0], np.array(hot[i % 7::3], np.uint32)]))
+    for limit, floor in ((500, 1), (40, 1), (100, 2), (10, 3)):
+        got, st = p.check(qs, fpx.SearchOptions(limit, floor, pct))
+        assert st.hits > 40 * 3000                            # thousands of hit records per query: several count passes

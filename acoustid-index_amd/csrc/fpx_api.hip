@@ -437,8 +437,20 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             sn->d_dead.push_back(d_dead);
         }
         const uint32_t slo = dead.empty() ? 1u : dead.front(), shi = dead.empty() ? 0u : dead.back();
+        // One bit per doc id of [slo, shi]: the per-posting supersession test becomes one load (the sorted list costs a
+        // 17-step binary search per hit).  Ids are assigned densely in practice; a range wider than 2^29 ids keeps the list only.
+        uint32_t* d_bits = nullptr;
+        if (!dead.empty() && s->kind == 0 && (uint64_t)shi - slo < (1ull << 29)) {
+            std::vector<uint32_t> bits(((size_t)(shi - slo) >> 5) + 1, 0u);
+            for (uint32_t id : dead) bits[(id - slo) >> 5] |= 1u << ((id - slo) & 31u);
+            hipError_t e = hipMalloc(&d_bits, bits.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "dead bitmap upload"); }
+            sn->d_dead.push_back(d_bits);
+        }
         if (s->kind == 0) {
             SegDesc d{};
+            d.dead_bits = d_bits;
             d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;

@@ -22,6 +22,7 @@ struct SegDesc {
     const uint32_t* bucket;        // [nbuckets + 1]: lower_bound(block_index, k << bucket_shift)
     const uint32_t* dead;          // sorted ids of this segment's docs that a newer segment mentions
     const uint32_t* cont;          // bit b: block b+1 starts with block b's last hash (a run may continue there)
+    const uint32_t* dead_bits;     // bitmap of `dead` over [shadow_lo, shadow_hi] (bit d - shadow_lo), or null when that range is too wide
     uint32_t num_blocks;
     uint32_t block_size;
     uint32_t bucket_shift;         // bucket of hash h = h >> bucket_shift (32 -> one bucket)

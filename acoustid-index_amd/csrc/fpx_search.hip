@@ -64,6 +64,14 @@ __device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32
     return lo < n && gload_u32(dead + lo) == d;
 }
 
+// supersession test of one posting of a file segment: bitmap over the covered id range when the snapshot built one
+__device__ __forceinline__ bool is_dead_seg(const SegDesc& s, uint32_t d)
+{
+    if (d < s.shadow_lo || d > s.shadow_hi) return false;
+    if (s.dead_bits) return ((gload_u32(s.dead_bits + ((d - s.shadow_lo) >> 5)) >> ((d - s.shadow_lo) & 31u)) & 1u) != 0u;
+    return is_dead(s.dead, s.num_dead, s.shadow_lo, s.shadow_hi, d);
+}
+
 // The pairs are sorted on the top 32 - KEY_SORT_SKIP bits of the hash only (one radix pass less): inside such a bucket
 // they keep the order k_make_keys wrote them in -- by query, then by position in the query -- because the sort is stable.
 // dedupSorted (src/Index.zig:489-499) therefore looks back over the pairs of the SAME query in the SAME bucket
@@ -288,7 +296,25 @@ struct HitStage {
 };
 
 // wave-uniform control flow: lanes with `keep` append `rec`
-__device__ __forceinline__ void stage_emit(const HitStage& st, const ProbeArgs& a, bool keep, uint64_t rec, uint32_t lane)
+// cold path of stage_emit (kept out of line: the probe loops are register bound): the stage is full, the wave appends
+// its records directly, dropping superseded docs right here
+__device__ __attribute__((noinline)) void stage_overflow(uint32_t* valid, uint32_t pos, unsigned long long* counters, uint64_t* hits,
+                                                         uint64_t hit_cap, bool keep, uint64_t rec, uint32_t lane, const SegDesc* filt)
+{
+    if (lane == 0) atomicMin(valid, pos);
+    const bool k2 = keep && !(filt && is_dead_seg(*filt, (uint32_t)rec));
+    const unsigned long long m2 = __ballot((int)k2);
+    const uint32_t total2 = __popcll(m2), rank2 = __popcll(m2 & ((1ull << lane) - 1ull));
+    unsigned long long gg = 0;
+    if (lane == 0 && total2) gg = atomicAdd(&counters[CTR_HITS], (unsigned long long)total2);
+    gg = __shfl(gg, 0);
+    if (k2 && gg + rank2 < hit_cap) hits[gg + rank2] = rec;
+}
+
+// `filt`: the records are filtered for superseded docs when the stage is flushed (stage_flush); a wave that finds the
+// stage full appends directly and filters right there.
+__device__ __forceinline__ void stage_emit(const HitStage& st, const ProbeArgs& a, bool keep, uint64_t rec, uint32_t lane,
+                                           const SegDesc* filt = nullptr)
 {
     const unsigned long long m = __ballot((int)keep);
     if (m == 0ull) return;
@@ -300,11 +326,7 @@ __device__ __forceinline__ void stage_emit(const HitStage& st, const ProbeArgs& 
     if (pos + total <= (uint32_t)STAGE_CAP) {
         if (keep) st.buf[pos + rank] = rec;
     } else {
-        if (lane == 0) atomicMin(st.valid, pos);
-        unsigned long long gg = 0;
-        if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
-        gg = __shfl(gg, 0);
-        if (keep && gg + rank < a.hit_cap) a.hits[gg + rank] = rec;
+        stage_overflow(st.valid, pos, a.counters, a.hits, a.hit_cap, keep, rec, lane, filt);
     }
 }
 
@@ -321,21 +343,60 @@ __device__ __forceinline__ void stage_emit_one(const HitStage& st, const ProbeAr
     }
 }
 
-// whole workgroup, at a round boundary: flush when half full or at the end
-__device__ __forceinline__ void stage_flush(const HitStage& st, const ProbeArgs& a, bool last, uint32_t tid, uint32_t nthreads)
+// whole workgroup, at a round boundary: flush when half full or at the end.  With `filt` the staged records of
+// superseded docs are dropped here: every thread tests its records (independent loads, one latency for the lot), a
+// workgroup scan compacts them.
+__device__ __forceinline__ void stage_flush(const HitStage& st, const ProbeArgs& a, bool last, uint32_t tid, uint32_t nthreads,
+                                            const SegDesc* filt = nullptr)
 {
+    __shared__ uint32_t flush_wave_tot[16];
     __syncthreads();
     const uint32_t sc = *st.count;
     if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
         const uint32_t n = min(sc, *st.valid);
-        if (tid == 0) {
-            const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
-            *st.base_lo = (uint32_t)gg; *st.base_hi = (uint32_t)(gg >> 32);
+        if (!filt) {
+            if (tid == 0) {
+                const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
+                *st.base_lo = (uint32_t)gg; *st.base_hi = (uint32_t)(gg >> 32);
+            }
+            __syncthreads();
+            const unsigned long long gg = ((unsigned long long)*st.base_hi << 32) | *st.base_lo;
+            for (uint32_t i = tid; i < n; i += nthreads)
+                if (gg + i < a.hit_cap) a.hits[gg + i] = st.buf[i];
+        } else {
+            constexpr uint32_t MAXR = 4;                                   // STAGE_CAP / smallest workgroup (256)
+            static_assert(STAGE_CAP <= 4 * 256, "stage_flush holds at most 4 staged records per thread");
+            uint64_t r[MAXR];
+            uint32_t keepm = 0, mine = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < MAXR; ++j) {
+                const uint32_t i = tid + j * nthreads;
+                r[j] = i < n ? st.buf[i] : 0ull;
+                if (i < n && !is_dead_seg(*filt, (uint32_t)r[j])) { keepm |= 1u << j; ++mine; }
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if ((tid & 63u) >= (uint32_t)d) incl += t;
+            }
+            if ((tid & 63u) == 63u) flush_wave_tot[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+            for (uint32_t w = 0; w < nthreads / 64u; ++w) {
+                if (w < (tid >> 6)) wbase += flush_wave_tot[w];
+                total += flush_wave_tot[w];
+            }
+            if (tid == 0) {
+                const unsigned long long gg = total ? atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total) : 0ull;
+                *st.base_lo = (uint32_t)gg; *st.base_hi = (uint32_t)(gg >> 32);
+            }
+            __syncthreads();
+            unsigned long long slot = (((unsigned long long)*st.base_hi << 32) | *st.base_lo) + wbase + (incl - mine);
+#pragma unroll
+            for (uint32_t j = 0; j < MAXR; ++j)
+                if ((keepm >> j) & 1u) { if (slot < a.hit_cap) a.hits[slot] = r[j]; ++slot; }
         }
-        __syncthreads();
-        const unsigned long long gg = ((unsigned long long)*st.base_hi << 32) | *st.base_lo;
-        for (uint32_t i = tid; i < n; i += nthreads)
-            if (gg + i < a.hit_cap) a.hits[gg + i] = st.buf[i];
         __syncthreads();
         if (tid == 0) { *st.count = 0; *st.valid = STAGE_CAP; }
     }
@@ -533,7 +594,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                                     const uint32_t erow = row_bits(me, g);
                                     cnt = __popc(erow);
                                     bool keep = ek;
-                                    if (seg.num_dead != 0u && keep && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc)) keep = false;
+                                    if (seg.num_dead != 0u && keep && is_dead_seg(seg, doc)) keep = false;
                                     if (keep) { kf = 1u; dd[0] = doc; }
                                     // the block ends with ph iff the last item of the last quad matched
                                     const uint32_t qstar = 2u * (idx & 15u) + (idx >> 4);
@@ -617,7 +678,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                             if (seg.num_dead != 0u && kf != 0u) {
 #pragma unroll
                                 for (int k = 0; k < 8; ++k)
-                                    if (((kf >> k) & 1u) && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, dd[k]))
+                                    if (((kf >> k) & 1u) && is_dead_seg(seg, dd[k]))
                                         kf &= ~(1u << k);
                             }
                             // blocks with more than 128 items (rare at 512 B): every chunk but the last hands its
@@ -807,6 +868,8 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
     __syncthreads();
 
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
+    // (the descriptor in global memory, not the local copy: taking `seg`'s address would pin all its fields in VGPRs)
+    const SegDesc* dead_filter = seg.num_dead != 0u ? a.segs + blockIdx.y : nullptr;
     const uint32_t k = l & 3u;
     const uint32_t q0 = 4u * l;                                   // my quads: q0 .. q0 + 3
     const uint32_t hi_group = (lane & 8u) ? 0xFFFFFFFFu : 0u;     // second group of the DPP row
@@ -1015,11 +1078,9 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                 // (the segment's continuation bitmap): let k_probe finish it
                 if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && ((pbv >> 30) & 1u) != 0u) defer = true;
             }
-            bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
-            if (seg.num_dead != 0u) {
-                if (keep0 && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc0)) keep0 = false;
-                if (keep1 && is_dead(seg.dead, seg.num_dead, seg.shadow_lo, seg.shadow_hi, doc1)) keep1 = false;
-            }
+            // (superseded docs are dropped when the staged records are flushed: a dependent load per hit does not belong
+            // in this loop -- with 1 % of the docs re-inserted in a newer segment it made the kernel 2.6x slower)
+            const bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
             // -- bookkeeping per group
             if (l == 0u && visited) {
                 if (defer) {
@@ -1038,12 +1099,12 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             // -- emission (wave-uniform control flow)
             const int nsets = me1 != 0ull ? 2 : 1;
             for (int e = 0; e < nsets; ++e) {
-                stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane);
+                stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane, dead_filter);
             }
         }
 
         // ---- flush the LDS staging buffer at round boundaries
-        stage_flush(hs, a, round + 1u == a.rounds, tid, L8_WG);
+        stage_flush(hs, a, round + 1u == a.rounds, tid, L8_WG, dead_filter);
         // ---- flush the deferred-probe staging (one global atomic per round)
         {
             const uint32_t dn = min(def_n, (uint32_t)DEF_STAGE_CAP);

@@ -279,19 +279,22 @@ def test_cpp_request_coalescer(env):
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
 
 
-def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env):
+@pytest.mark.parametrize("dist", [0, 1])
+def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env, dist):
     """The lean path on segments whose docs are partly superseded (per-posting `dead` filter), with a segment of sparse
     ids (docid deltas of 3 and 4 bytes, ids above 2^24), tombstones and inserts in memory segments on top."""
     fpx, oracle, Pair, ctx = env
     seed, H, per = 733, 128, 9000                      # 1.15 M items per file segment: lean-eligible
     p = Pair(ctx)
-    a = fpx.synth.synth_items(seed, 1, per, H)
+    # dist = 1: hot hashes with ~1000 docs per probe overflow the workgroups' hit staging, so superseded docs are dropped both
+    # at the staged flush and on the direct-append path
+    a = fpx.synth.synth_items(seed, 1, per, H, dist=dist)
     p.add_file(a, 1, per, 1, np.arange(1, per + 1))
     # segment B re-inserts ids 5001..9000 with fresh hashes (A's copies become dead) and adds 9001..14000
-    b = fpx.synth.synth_items(seed + 1, 5001, per, H)
+    b = fpx.synth.synth_items(seed + 1, 5001, per, H, dist=dist)
     p.add_file(b, 5001, 5000 + per, 2, np.arange(5001, 5001 + per))
     # segment C: sparse ids 20000 + 3001 * i (up to 27 M: 4-byte docid values, 2- and 3-byte deltas inside runs)
-    c = fpx.synth.synth_items(seed + 2, 1, per, H)
+    c = fpx.synth.synth_items(seed + 2, 1, per, H, dist=dist)
     ids_c = (20000 + 3001 * np.arange(per)).astype(np.uint64)
     c = np.sort((c & ~np.uint64(0xFFFFFFFF)) | ids_c[(c & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1])
     p.add_file(c, int(ids_c[0]), int(ids_c[-1]), 3, ids_c.astype(np.uint32))

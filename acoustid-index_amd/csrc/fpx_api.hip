@@ -109,6 +109,8 @@ static void segment_free(Segment* s)
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
+    if (s->d_small_items) (void)hipFree(s->d_small_items);
+    if (s->d_bstart) (void)hipFree(s->d_bstart);
     if (s->d_items) (void)hipFree(s->d_items);
     delete s;
 }
@@ -167,7 +169,7 @@ int finish_file_segment(Segment* s)
     FPX_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_total);
     s->num_items = total;
-    return FPX_OK;
+    return decode_small_segment(s);
 }
 
 }  // namespace fpx
@@ -394,6 +396,7 @@ static void snapshot_free(Snapshot* sn)
     if (sn->d_file) (void)hipFree(sn->d_file);
     if (sn->d_lean) (void)hipFree(sn->d_lean);
     if (sn->d_gen) (void)hipFree(sn->d_gen);
+    if (sn->d_small) (void)hipFree(sn->d_small);
     if (sn->d_mem) (void)hipFree(sn->d_mem);
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;
@@ -451,6 +454,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         if (s->kind == 0) {
             SegDesc d{};
             d.dead_bits = d_bits;
+            d.items = s->d_small_items; d.bstart = s->d_bstart;
             d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
@@ -475,16 +479,21 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     }
     if (e == hipSuccess && sn->n_file) {
         // k_probe_lean8 pays off on 512-B segments dense enough that hash deltas fit two bytes (>= 2^20 items)
-        std::vector<SegDesc> lean, gen;
+        std::vector<SegDesc> lean, gen, small;
         size_t fi = 0;
         for (Segment* sg : sn->segs) {
             if (sg->kind != 0) continue;
             const SegDesc& d = sn->h_file[fi++];
             if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30)) lean.push_back(d);
+            else if (d.items) { small.push_back(d); sn->max_small_blocks = std::max(sn->max_small_blocks, d.num_blocks); }
             else { gen.push_back(d); if (d.block_size != 512) sn->gen_all_512 = false; }
         }
-        sn->n_lean = (uint32_t)lean.size(); sn->n_gen = (uint32_t)gen.size();
-        if (sn->n_lean) {
+        sn->n_lean = (uint32_t)lean.size(); sn->n_gen = (uint32_t)gen.size(); sn->n_small = (uint32_t)small.size();
+        if (sn->n_small) {
+            e = hipMalloc(&sn->d_small, small.size() * sizeof(SegDesc));
+            if (e == hipSuccess) e = hipMemcpy(sn->d_small, small.data(), small.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess && sn->n_lean) {
             e = hipMalloc(&sn->d_lean, lean.size() * sizeof(SegDesc));
             if (e == hipSuccess) e = hipMemcpy(sn->d_lean, lean.data(), lean.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
         }

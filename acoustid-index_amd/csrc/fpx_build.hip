@@ -359,6 +359,8 @@ static void free_partial_segment(Segment* s)
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
+    if (s->d_small_items) (void)hipFree(s->d_small_items);
+    if (s->d_bstart) (void)hipFree(s->d_bstart);
     delete s;
 }
 
@@ -563,6 +565,43 @@ __global__ __launch_bounds__(256) void k_decode_items(const uint8_t* __restrict_
         const int lastF = __shfl((int)FF, 63);
         pdoc = lastF ? lastS : pdoc + lastS;
     }
+}
+
+// 32-bit exclusive prefix of the per-block item counts (small segments only: < 2^20 items)
+__global__ void k_bstart32(const uint64_t* __restrict__ boff, uint32_t num_blocks, uint64_t total, uint32_t* __restrict__ bstart)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < num_blocks) bstart[b] = (uint32_t)boff[b];
+    if (b == num_blocks) bstart[b] = (uint32_t)total;
+}
+
+// A small file segment (a fresh checkpoint: 10^5 .. 10^6 items) holds wide hash deltas, which the lean probe kernel
+// does not decode, and probing it block by block with the generic kernel costs more than a 1.6 G-item segment does.
+// It is decoded ONCE, when it becomes resident; searches then binary-search its items (k_probe_small).
+int decode_small_segment(Segment* s)
+{
+    if (s->kind != 0 || s->num_blocks == 0 || s->num_items == 0 || s->num_items >= (1ull << 20)) return FPX_OK;
+    int rc;
+    hipStream_t st = 0;
+    DevBuf counts, boff, tot, live;
+    if ((rc = counts.alloc((size_t)s->num_blocks * 4)) || (rc = boff.alloc((size_t)s->num_blocks * 8)) || (rc = tot.alloc(8)) ||
+        (rc = live.alloc(s->num_items + 16)))
+        return rc;
+    FPX_HIP(hipMalloc(&s->d_small_items, (s->num_items + 1) * sizeof(uint64_t)));
+    FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)s->num_blocks + 1) * sizeof(uint32_t)));
+    s->device_bytes += (s->num_items + 1) * sizeof(uint64_t) + ((size_t)s->num_blocks + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_block_item_counts, dim3((s->num_blocks + 255) / 256), dim3(256), 0, st,
+                       s->d_blocks, s->block_size, s->num_blocks, counts.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)s->num_blocks,
+                       boff.as<uint64_t>(), tot.as<uint64_t>());
+    hipLaunchKernelGGL(k_decode_items, dim3((s->num_blocks + 3) / 4), dim3(256), 0, st,
+                       s->d_blocks, s->block_size, s->num_blocks, s->min_doc_id, boff.as<uint64_t>(),
+                       (const uint32_t*)nullptr, 0u, s->d_small_items, live.as<uint8_t>());
+    hipLaunchKernelGGL(k_bstart32, dim3((s->num_blocks + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), s->num_blocks,
+                       s->num_items, s->d_bstart);
+    FPX_HIP(hipGetLastError());
+    FPX_HIP(hipStreamSynchronize(st));
+    return FPX_OK;
 }
 
 // memory-segment source: copy the items and flag the ones whose doc is superseded

@@ -23,6 +23,9 @@ struct SegDesc {
     const uint32_t* dead;          // sorted ids of this segment's docs that a newer segment mentions
     const uint32_t* cont;          // bit b: block b+1 starts with block b's last hash (a run may continue there)
     const uint32_t* dead_bits;     // bitmap of `dead` over [shadow_lo, shadow_hi] (bit d - shadow_lo), or null when that range is too wide
+    // small segments (< 2^20 items) are also kept DECODED: sorted items + where each block starts among them
+    const uint64_t* items;         // hash << 32 | doc, or null
+    const uint32_t* bstart;        // [num_blocks + 1] item offset of each block
     uint32_t num_blocks;
     uint32_t block_size;
     uint32_t bucket_shift;         // bucket of hash h = h >> bucket_shift (32 -> one bucket)
@@ -73,6 +76,7 @@ struct Segment {
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
+    uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     uint64_t num_items = 0;
     // memory
@@ -90,6 +94,8 @@ struct Snapshot {
     // file segments split by the kernel that suits them: dense 512-B segments (lean) and the rest (generic)
     SegDesc* d_lean = nullptr; uint32_t n_lean = 0;
     SegDesc* d_gen = nullptr; uint32_t n_gen = 0; bool gen_all_512 = true;
+    SegDesc* d_small = nullptr; uint32_t n_small = 0;     // small segments searched in their decoded items
+    uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
     std::vector<uint32_t*> d_dead;       // owned dead lists
     uint32_t max_block_size = 0;
@@ -193,6 +199,7 @@ int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num
 // `s` arrives with its docs set; on failure the caller frees it
 int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool sorted, uint32_t block_size,
                        uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, Segment* s);
+int decode_small_segment(Segment* s);     // fills d_small_items / d_bstart of a resident file segment
 struct MergeSource { const Segment* seg; std::vector<uint32_t> dead; };   // dead = skip_docs, sorted
 int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_t block_size, uint32_t min_doc_id, Segment* s);
 

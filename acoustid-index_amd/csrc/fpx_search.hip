@@ -1163,6 +1163,94 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 4b. small file segments (< 2^20 items; fresh checkpoints) in their decoded form (SegDesc::items / bstart).
+//     A batch holds thousands of pairs per BLOCK of such a segment, so the work is organised by block: one workgroup
+//     stages a block's items in LDS, finds the slice of the (bucket-sorted) pairs whose first block it is with two
+//     binary searches, and streams that slice -- FileSegment.search restated per block, with the same walk over <= 4
+//     blocks, the > 1000 docs stop and the same counters (src/FileSegment.zig:145-175), nothing decoded per probe.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SMALL_LDS_ITEMS = 2048;     // MAX_ITEMS_PER_BLOCK
+__global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const uint64_t* __restrict__ pairs, uint64_t P,
+                                                     uint32_t qb, uint64_t* hits, uint64_t hit_cap,
+                                                     unsigned long long* counters)
+{
+    __shared__ uint64_t blk_items[SMALL_LDS_ITEMS];
+    __shared__ uint64_t prange[2];
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    const SegDesc seg = segs[blockIdx.y];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (b >= seg.num_blocks) return;
+    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
+    const uint32_t s0 = seg.bstart[b], n = seg.bstart[b + 1] - s0;
+    const uint32_t hmin = (uint32_t)(seg.items[s0] >> 32), hmax = seg.block_index[b];
+    const bool has_prev = b != 0u;
+    const uint32_t hprev = has_prev ? seg.block_index[b - 1] : 0u;               // hashes <= hprev start in an earlier block
+    const bool last_block = b + 1u == seg.num_blocks;
+    for (uint32_t i = tid; i < n; i += WG) blk_items[i] = seg.items[s0 + i];
+    if (tid < 2u) {
+        // pairs are sorted by bucket = hash >> KEY_SORT_SKIP: [first pair of the bucket of hprev (+1), first pair after the
+        // bucket of hmax); the last block also takes the pairs above every block (they probe nothing but are counted)
+        const uint32_t want = tid == 0u ? (has_prev ? (hprev >> KEY_SORT_SKIP) : 0u) : (hmax >> KEY_SORT_SKIP);
+        uint64_t lo = 0, hi = P;
+        if (tid == 1u && last_block) lo = P;
+        while (lo < hi) {
+            const uint64_t m = (lo + hi) >> 1;
+            const uint32_t bk = (uint32_t)(pairs[m] >> qb) >> KEY_SORT_SKIP;
+            if (tid == 0u ? bk < want : bk <= want) lo = m + 1; else hi = m;
+        }
+        prange[tid] = lo;
+    }
+    if (tid == 0) { wg_blocks = 0; wg_docs = 0; wg_probes = 0; }
+    __syncthreads();
+    unsigned long long my_blocks = 0, my_docs = 0, my_probes = 0;
+    for (uint64_t p = prange[0] + tid; p < prange[1]; p += WG) {
+        const uint64_t key = pairs[p];
+        const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
+        if ((has_prev && h <= hprev) || (!last_block && h > hmax)) continue;       // edges of the boundary buckets
+        if (seg.own_flags != 0u && !owned_hash(seg, h)) continue;
+        if (is_duplicate_pair(pairs, p, key, qb)) continue;
+        my_probes += 1;
+        if (h > hmax || h < hmin) continue;                                        // above every block / in the gap before this one
+        // equal range of h among the staged items
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint32_t)(blk_items[m] >> 32) < h) lo = m + 1; else hi = m; }
+        uint32_t nb = 1, nd = 0;
+        for (uint32_t i = lo; i < n && (uint32_t)(blk_items[i] >> 32) == h; ++i) {
+            ++nd;
+            const uint32_t d = (uint32_t)blk_items[i];
+            if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
+            const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);     // hits in a small segment are rare
+            if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+        }
+        // the walk goes on while the next block starts with h (:164), up to 4 blocks / past 1000 docs (:172-173)
+        for (uint32_t nbk = b + 1u; nb < (uint32_t)MAX_BLOCKS_PER_HASH && nd <= (uint32_t)MAX_DOCS_PER_HASH && nbk < seg.num_blocks; ++nbk) {
+            const uint32_t s1 = seg.bstart[nbk], e1 = seg.bstart[nbk + 1];
+            if ((uint32_t)(seg.items[s1] >> 32) != h) break;
+            ++nb;
+            for (uint32_t i = s1; i < e1; ++i) {
+                const uint64_t it = seg.items[i];
+                if ((uint32_t)(it >> 32) != h) break;
+                ++nd;
+                const uint32_t d = (uint32_t)it;
+                if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
+                const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+                if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+            }
+        }
+        my_blocks += nb; my_docs += nd;
+    }
+    if (my_probes) atomicAdd(&wg_probes, my_probes);
+    if (my_blocks) atomicAdd(&wg_blocks, my_blocks);
+    if (my_docs) atomicAdd(&wg_docs, my_docs);
+    __syncthreads();
+    if (tid == 0) {
+        if (wg_probes) atomicAdd(&counters[CTR_PROBES], wg_probes);
+        if (wg_blocks) { atomicAdd(&counters[CTR_BLOCKS], wg_blocks); atomicAdd(&counters[CTR_BYTES], wg_blocks * seg.block_size); }
+        if (wg_docs) atomicAdd(&counters[CTR_DOCS], wg_docs);
+    }
+}
+
 // The same probes from the other side, for big batches: a memory segment holds at most ~10^5 items, a batch millions
 // of pairs, so one thread per ITEM looks its hash up in the (bucket-sorted) pairs -- 60x fewer searches than one thread
 // per (pair, segment).  The pairs of a bucket (top 32 - KEY_SORT_SKIP hash bits) are contiguous but unordered inside it.
@@ -1804,27 +1892,37 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
-            const bool lean = snap->n_lean != 0 && !force_generic && P < 0xFFFFFFFFull && total >= lean_min_probes();
+            // big batches: every kind of file segment has its own kernel
+            const bool lean = (snap->n_lean != 0 || snap->n_small != 0) && !force_generic && P < 0xFFFFFFFFull &&
+                              total >= lean_min_probes();
             if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (lean) {
-                // main kernel: k_probe_lean8 over the dense 512-B segments
-                FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));
-                ProbeArgs l = a;
-                static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 2u; }();
-                l.segs = snap->d_lean; l.rounds = (P >= (1ull << 22)) ? lean_rounds : 1u; l.ctr_off = 8u;
-                const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
-                const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;
-                const uint32_t gx8 = (uint32_t)((P + per_wg_8 - 1) / per_wg_8);
-                hipLaunchKernelGGL(k_probe_lean8, dim3(gx8, snap->n_lean), dim3(L8_WG), lds8, st, l);
+                if (snap->n_lean) {
+                    // main kernel: k_probe_lean8 over the dense 512-B segments
+                    FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));
+                    ProbeArgs l = a;
+                    static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 2u; }();
+                    l.segs = snap->d_lean; l.rounds = (P >= (1ull << 22)) ? lean_rounds : 1u; l.ctr_off = 8u;
+                    const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
+                    const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;
+                    const uint32_t gx8 = (uint32_t)((P + per_wg_8 - 1) / per_wg_8);
+                    hipLaunchKernelGGL(k_probe_lean8, dim3(gx8, snap->n_lean), dim3(L8_WG), lds8, st, l);
+                }
                 FPX_HIP(hipEventRecord(ws->ev_probe1, st));
                 // auxiliary passes: the rows the lean kernel deferred, and the segments it does not suit
-                ProbeArgs d = a;
-                d.segs = snap->d_lean; d.ppw = 16u; d.rounds = 1u;
-                const uint64_t per_wg_d = (uint64_t)PWAVES * d.ppw;
-                // persistent workgroups striding over the device-side list: about 1024 of them over all segments
-                const uint64_t gxd_cap = std::max<uint64_t>(64, (1024 + snap->n_lean - 1) / snap->n_lean);
-                const uint32_t gxd = (uint32_t)std::min<uint64_t>((def_cap + per_wg_d - 1) / per_wg_d, gxd_cap);
-                hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
+                if (snap->n_lean) {
+                    ProbeArgs d = a;
+                    d.segs = snap->d_lean; d.ppw = 16u; d.rounds = 1u;
+                    const uint64_t per_wg_d = (uint64_t)PWAVES * d.ppw;
+                    // persistent workgroups striding over the device-side list: about 1024 of them over all segments
+                    const uint64_t gxd_cap = std::max<uint64_t>(64, (1024 + snap->n_lean - 1) / snap->n_lean);
+                    const uint32_t gxd = (uint32_t)std::min<uint64_t>((def_cap + per_wg_d - 1) / per_wg_d, gxd_cap);
+                    hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
+                }
+                if (snap->n_small) {
+                    hipLaunchKernelGGL(k_probe_small, dim3(snap->max_small_blocks, snap->n_small), dim3(WG), 0, st,
+                                       snap->d_small, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
+                }
                 if (snap->n_gen) {
                     ProbeArgs ge = a;
                     ge.segs = snap->d_gen;
@@ -1832,7 +1930,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     else hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_gen), dim3(PWG), lds, st, ge);
                 }
                 FPX_HIP(hipEventRecord(ws->ev_probe2, st));
-                FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, snap->n_lean * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                if (snap->n_lean)
+                    FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, snap->n_lean * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 used_lean = true;
             } else {
                 a.segs = snap->d_file;
@@ -1931,7 +2030,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_bytes = ws->h_counters[CTR_BYTES] + ws->h_counters[8 + CTR_BYTES],
                              c_probes = ws->h_counters[CTR_PROBES] + ws->h_counters[8 + CTR_PROBES],
                              c_generic = ws->h_counters[CTR_GENERIC],
-                             c_main_bytes = used_lean ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES];
+                             c_main_bytes = (used_lean && snap->n_lean) ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES];
 
     uint64_t C = 0;
     auto fill_stats = [&]() {

@@ -1171,6 +1171,7 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
 //     blocks, the > 1000 docs stop and the same counters (src/FileSegment.zig:145-175), nothing decoded per probe.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t SMALL_LDS_ITEMS = 2048;     // MAX_ITEMS_PER_BLOCK
+constexpr uint32_t SMALL_BPW = 8;              // consecutive blocks per workgroup: their pair slices are consecutive too
 __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const uint64_t* __restrict__ pairs, uint64_t P,
                                                      uint32_t qb, uint64_t* hits, uint64_t hit_cap,
                                                      unsigned long long* counters)
@@ -1179,66 +1180,86 @@ __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const u
     __shared__ uint64_t prange[2];
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
     const SegDesc seg = segs[blockIdx.y];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    if (b >= seg.num_blocks) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bfirst = blockIdx.x * SMALL_BPW;
+    if (bfirst >= seg.num_blocks) return;
+    const uint32_t bend = min(bfirst + SMALL_BPW, seg.num_blocks);
     const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
-    const uint32_t s0 = seg.bstart[b], n = seg.bstart[b + 1] - s0;
-    const uint32_t hmin = (uint32_t)(seg.items[s0] >> 32), hmax = seg.block_index[b];
-    const bool has_prev = b != 0u;
-    const uint32_t hprev = has_prev ? seg.block_index[b - 1] : 0u;               // hashes <= hprev start in an earlier block
-    const bool last_block = b + 1u == seg.num_blocks;
-    for (uint32_t i = tid; i < n; i += WG) blk_items[i] = seg.items[s0 + i];
-    if (tid < 2u) {
-        // pairs are sorted by bucket = hash >> KEY_SORT_SKIP: [first pair of the bucket of hprev (+1), first pair after the
-        // bucket of hmax); the last block also takes the pairs above every block (they probe nothing but are counted)
-        const uint32_t want = tid == 0u ? (has_prev ? (hprev >> KEY_SORT_SKIP) : 0u) : (hmax >> KEY_SORT_SKIP);
-        uint64_t lo = 0, hi = P;
-        if (tid == 1u && last_block) lo = P;
-        while (lo < hi) {
-            const uint64_t m = (lo + hi) >> 1;
-            const uint32_t bk = (uint32_t)(pairs[m] >> qb) >> KEY_SORT_SKIP;
-            if (tid == 0u ? bk < want : bk <= want) lo = m + 1; else hi = m;
-        }
-        prange[tid] = lo;
-    }
     if (tid == 0) { wg_blocks = 0; wg_docs = 0; wg_probes = 0; }
-    __syncthreads();
     unsigned long long my_blocks = 0, my_docs = 0, my_probes = 0;
-    for (uint64_t p = prange[0] + tid; p < prange[1]; p += WG) {
-        const uint64_t key = pairs[p];
-        const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
-        if ((has_prev && h <= hprev) || (!last_block && h > hmax)) continue;       // edges of the boundary buckets
-        if (seg.own_flags != 0u && !owned_hash(seg, h)) continue;
-        if (is_duplicate_pair(pairs, p, key, qb)) continue;
-        my_probes += 1;
-        if (h > hmax || h < hmin) continue;                                        // above every block / in the gap before this one
-        // equal range of h among the staged items
-        uint32_t lo = 0, hi = n;
-        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint32_t)(blk_items[m] >> 32) < h) lo = m + 1; else hi = m; }
-        uint32_t nb = 1, nd = 0;
-        for (uint32_t i = lo; i < n && (uint32_t)(blk_items[i] >> 32) == h; ++i) {
-            ++nd;
-            const uint32_t d = (uint32_t)blk_items[i];
-            if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
-            const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);     // hits in a small segment are rare
-            if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+    for (uint32_t b = bfirst; b < bend; ++b) {
+        const uint32_t s0 = seg.bstart[b], n = seg.bstart[b + 1] - s0;
+        const uint32_t hmin = (uint32_t)(seg.items[s0] >> 32), hmax = seg.block_index[b];
+        const bool has_prev = b != 0u;
+        const uint32_t hprev = has_prev ? seg.block_index[b - 1] : 0u;           // hashes <= hprev start in an earlier block
+        const bool last_block = b + 1u == seg.num_blocks;
+        __syncthreads();                                                         // the previous block's items are done with
+        for (uint32_t i = tid; i < n; i += WG) blk_items[i] = seg.items[s0 + i];
+        if (tid < 2u) {
+            // pairs are sorted by bucket = hash >> KEY_SORT_SKIP: [first pair of the bucket of hprev, first pair after the
+            // bucket of hmax); the last block also takes the pairs above every block (they probe nothing but are counted).
+            // After the workgroup's first block the searches start from the previous slice (a few steps instead of 23).
+            const uint32_t want = tid == 0u ? (has_prev ? (hprev >> KEY_SORT_SKIP) : 0u) : (hmax >> KEY_SORT_SKIP);
+            uint64_t lo = 0, hi = P;
+            if (b != bfirst) {
+                // the previous block's slice ended at E = first pair after the bucket of hprev: this block's slice starts
+                // inside that bucket, a little before E, and ends somewhere after E
+                const uint64_t E = prange[1];
+                auto bucket_at = [&](uint64_t i) { return (uint32_t)(pairs[i] >> qb) >> KEY_SORT_SKIP; };
+                if (tid == 0u) {
+                    hi = E;
+                    lo = E > 4096 ? E - 4096 : 0;
+                    if (lo != 0 && bucket_at(lo - 1) >= want) lo = 0;              // (a bucket with > 4096 pairs)
+                } else {
+                    lo = E;
+                    if (E + 65536 < P && bucket_at(E + 65536) > want) hi = E + 65536;
+                }
+            }
+            if (tid == 1u && last_block) lo = hi = P;
+            while (lo < hi) {
+                const uint64_t m = (lo + hi) >> 1;
+                const uint32_t bk = (uint32_t)(pairs[m] >> qb) >> KEY_SORT_SKIP;
+                if (tid == 0u ? bk < want : bk <= want) lo = m + 1; else hi = m;
+            }
+            prange[tid] = lo;
         }
-        // the walk goes on while the next block starts with h (:164), up to 4 blocks / past 1000 docs (:172-173)
-        for (uint32_t nbk = b + 1u; nb < (uint32_t)MAX_BLOCKS_PER_HASH && nd <= (uint32_t)MAX_DOCS_PER_HASH && nbk < seg.num_blocks; ++nbk) {
-            const uint32_t s1 = seg.bstart[nbk], e1 = seg.bstart[nbk + 1];
-            if ((uint32_t)(seg.items[s1] >> 32) != h) break;
-            ++nb;
-            for (uint32_t i = s1; i < e1; ++i) {
-                const uint64_t it = seg.items[i];
-                if ((uint32_t)(it >> 32) != h) break;
+        __syncthreads();
+        for (uint64_t p = prange[0] + tid; p < prange[1]; p += WG) {
+            const uint64_t key = pairs[p];
+            const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
+            if ((has_prev && h <= hprev) || (!last_block && h > hmax)) continue;   // edges of the boundary buckets
+            if (seg.own_flags != 0u && !owned_hash(seg, h)) continue;
+            if (is_duplicate_pair(pairs, p, key, qb)) continue;
+            my_probes += 1;
+            if (h > hmax || h < hmin) continue;                                    // above every block / in the gap before this one
+            // equal range of h among the staged items
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint32_t)(blk_items[m] >> 32) < h) lo = m + 1; else hi = m; }
+            uint32_t nb = 1, nd = 0;
+            for (uint32_t i = lo; i < n && (uint32_t)(blk_items[i] >> 32) == h; ++i) {
                 ++nd;
-                const uint32_t d = (uint32_t)it;
+                const uint32_t d = (uint32_t)blk_items[i];
                 if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
-                const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+                const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull); // hits in a small segment are rare
                 if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
             }
+            // the walk goes on while the next block starts with h (:164), up to 4 blocks / past 1000 docs (:172-173)
+            for (uint32_t nbk = b + 1u; nb < (uint32_t)MAX_BLOCKS_PER_HASH && nd <= (uint32_t)MAX_DOCS_PER_HASH && nbk < seg.num_blocks; ++nbk) {
+                const uint32_t s1 = seg.bstart[nbk], e1 = seg.bstart[nbk + 1];
+                if ((uint32_t)(seg.items[s1] >> 32) != h) break;
+                ++nb;
+                for (uint32_t i = s1; i < e1; ++i) {
+                    const uint64_t it = seg.items[i];
+                    if ((uint32_t)(it >> 32) != h) break;
+                    ++nd;
+                    const uint32_t d = (uint32_t)it;
+                    if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
+                    const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+                    if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+                }
+            }
+            my_blocks += nb; my_docs += nd;
         }
-        my_blocks += nb; my_docs += nd;
     }
     if (my_probes) atomicAdd(&wg_probes, my_probes);
     if (my_blocks) atomicAdd(&wg_blocks, my_blocks);
@@ -1920,7 +1941,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
                 }
                 if (snap->n_small) {
-                    hipLaunchKernelGGL(k_probe_small, dim3(snap->max_small_blocks, snap->n_small), dim3(WG), 0, st,
+                    hipLaunchKernelGGL(k_probe_small, dim3((snap->max_small_blocks + SMALL_BPW - 1) / SMALL_BPW, snap->n_small), dim3(WG), 0, st,
                                        snap->d_small, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
                 }
                 if (snap->n_gen) {

@@ -400,3 +400,40 @@ def test_low_floor_multi_pass_with_relative_cutoff(env, pct):
     for limit, floor in ((500, 1), (40, 1), (100, 2), (10, 3)):
         got, st = p.check(qs, fpx.SearchOptions(limit, floor, pct))
         assert st.hits > 40 * 3000                            # thousands of hit records per query: several count passes
+
+
+@pytest.mark.parametrize("block_size", [64, 512, 4096])
+def test_small_segments_in_big_batches(env, block_size):
+    """Fresh checkpoints: file segments of 10^4 .. 10^5 items next to a big one.  In a big batch they are probed block by
+    block from their decoded items (k_probe_small): hot hashes whose runs span up to 4 blocks (the 1000-docs stop), gaps
+    between blocks, hashes above every block, re-inserted and deleted docs, duplicate query hashes."""
+    fpx, oracle, Pair, ctx = env
+    rng = np.random.default_rng(block_size)
+    p = Pair(ctx)
+    big = fpx.synth.synth_items(900, 1, 9000, 128, dist=1)                       # 1.15 M items: the lean kernel's
+    p.add_file(big, 1, 9000, 1, np.arange(1, 9001))
+    hot = rng.integers(0, 1 << 32, 6, dtype=np.uint64)
+    all_small = []
+    for s in range(4):
+        n_docs = int(rng.integers(200, 3000))
+        ids = np.sort(rng.choice(np.arange(1, 20000), n_docs, replace=False)).astype(np.uint64)     # overlaps the big segment's ids
+        h = rng.integers(0, 1 << 31, (n_docs, 32), dtype=np.uint64)              # nothing above 2^31: queries reach past the last block
+        m = rng.random(n_docs) < 0.7
+        h[m, 0] = hot[rng.integers(0, 6, int(m.sum()))]
+        h[:, 1] = h[:, 0]
+        alive = (rng.random(n_docs) > 0.05).astype(np.uint8)
+        items = np.sort(((h[alive == 1] << np.uint64(32)) | ids[alive == 1][:, None]).ravel())
+        p.add_file(items, int(ids.min()), int(ids.max()), 2 + s, ids.astype(np.uint32), alive, block_size=block_size)
+        all_small.append(items)
+    p.add_memory_changes([("delete", 15), ("insert", 25000, [int(hot[0]), 7])], 9)
+    p.finish()
+    small_h = np.concatenate([(x >> np.uint64(32)).astype(np.uint32) for x in all_small])
+    qs = []
+    for i in range(90):
+        q = np.concatenate([rng.choice(small_h, 300), hot[: 1 + i % 6].astype(np.uint32),
+                            rng.integers(0, 1 << 32, 700, dtype=np.uint64).astype(np.uint32)])
+        if i % 4 == 0:
+            q = np.concatenate([q, q[:40]])
+        qs.append(q)
+    got, st = p.check(qs, [fpx.SearchOptions(int(rng.choice([5, 40, 500])), int(rng.choice([1, 2, 10])), int(rng.choice([0, 10, 100]))) for _ in qs])
+    assert st.probes >= (1 << 16) and st.scanned_docs > 100000                    # the walks over the hot runs really happened

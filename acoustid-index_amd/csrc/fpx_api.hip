@@ -382,7 +382,27 @@ static void compute_dead(const std::vector<Segment*>& segs, size_t si, std::vect
         auto a1 = std::upper_bound(s->doc_ids.begin(), s->doc_ids.end(), hi);
         auto b0 = std::lower_bound(t->doc_ids.begin(), t->doc_ids.end(), lo);
         auto b1 = std::upper_bound(t->doc_ids.begin(), t->doc_ids.end(), hi);
-        std::set_intersection(a0, a1, b0, b1, std::back_inserter(dead));
+        // A fresh memory segment holds tens of docs, a merged file segment millions: a linear merge made every publish
+        // cost 100+ ms on a 100 M-doc index.  Walk the smaller side and gallop through the larger one (exponential probe
+        // from the last position, then a binary search inside the bracket); densely numbered ids need no search at all.
+        const size_t na = (size_t)(a1 - a0), nb = (size_t)(b1 - b0);
+        auto gallop_intersect = [&](auto s0, auto s1, auto l0, auto l1) {          // s: small side, l: large side
+            const bool dense = (size_t)(*(l1 - 1) - *l0) + 1 == (size_t)(l1 - l0);
+            auto pos = l0;
+            for (auto it = s0; it != s1; ++it) {
+                const uint32_t v = *it;
+                if (dense) { if (v >= *l0 && v <= *(l1 - 1)) dead.push_back(v); continue; }
+                size_t step = 1;
+                while ((size_t)(l1 - pos) > step && *(pos + step) < v) { pos += step; step <<= 1; }
+                pos = std::lower_bound(pos, ((size_t)(l1 - pos) > step + 1) ? pos + step + 1 : l1, v);
+                if (pos == l1) break;
+                if (*pos == v) dead.push_back(v);
+            }
+        };
+        if (na == 0 || nb == 0) continue;
+        if (na * 4 < nb) gallop_intersect(a0, a1, b0, b1);
+        else if (nb * 4 < na) gallop_intersect(b0, b1, a0, a1);
+        else std::set_intersection(a0, a1, b0, b1, std::back_inserter(dead));
     }
     std::sort(dead.begin(), dead.end());
     dead.erase(std::unique(dead.begin(), dead.end()), dead.end());
@@ -392,7 +412,6 @@ static void snapshot_free(Snapshot* sn)
 {
     if (!sn) return;
     (void)hipSetDevice(sn->ctx->device);
-    for (uint32_t* d : sn->d_dead) if (d) (void)hipFree(d);
     if (sn->d_file) (void)hipFree(sn->d_file);
     if (sn->d_lean) (void)hipFree(sn->d_lean);
     if (sn->d_gen) (void)hipFree(sn->d_gen);
@@ -433,23 +452,36 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         if (s->kind == 2) continue;
         compute_dead(sn->segs, i, dead);
         uint32_t* d_dead = nullptr;
-        if (!dead.empty()) {
-            hipError_t e = hipMalloc(&d_dead, dead.size() * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemcpy(d_dead, dead.data(), dead.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "dead list upload"); }
-            sn->d_dead.push_back(d_dead);
-        }
-        const uint32_t slo = dead.empty() ? 1u : dead.front(), shi = dead.empty() ? 0u : dead.back();
-        // One bit per doc id of [slo, shi]: the per-posting supersession test becomes one load (the sorted list costs a
-        // 17-step binary search per hit).  Ids are assigned densely in practice; a range wider than 2^29 ids keeps the list only.
         uint32_t* d_bits = nullptr;
-        if (!dead.empty() && s->kind == 0 && (uint64_t)shi - slo < (1ull << 29)) {
-            std::vector<uint32_t> bits(((size_t)(shi - slo) >> 5) + 1, 0u);
-            for (uint32_t id : dead) bits[(id - slo) >> 5] |= 1u << ((id - slo) & 31u);
-            hipError_t e = hipMalloc(&d_bits, bits.size() * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemcpy(d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "dead bitmap upload"); }
-            sn->d_dead.push_back(d_bits);
+        const uint32_t slo = dead.empty() ? 1u : dead.front(), shi = dead.empty() ? 0u : dead.back();
+        if (!dead.empty()) {
+            std::shared_ptr<DeadSet> ds;
+            {
+                std::lock_guard<std::mutex> g(s->dead_mu);
+                if (s->last_dead && s->last_dead->ids == dead) ds = s->last_dead;       // unchanged since the last snapshot
+            }
+            if (!ds) {
+                ds = std::make_shared<DeadSet>();
+                ds->device = c->device;
+                ds->ids = dead;
+                hipError_t e = hipMalloc(&ds->d_list, dead.size() * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMemcpy(ds->d_list, dead.data(), dead.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+                // One bit per doc id of [slo, shi]: the per-posting supersession test becomes one load (the sorted list
+                // costs a 17-step binary search per hit).  Ids are assigned densely in practice; a range wider than 2^29
+                // ids keeps the list only.
+                if (e == hipSuccess && s->kind == 0 && (uint64_t)shi - slo < (1ull << 29)) {
+                    std::vector<uint32_t> bits(((size_t)(shi - slo) >> 5) + 1, 0u);
+                    for (uint32_t id : dead) bits[(id - slo) >> 5] |= 1u << ((id - slo) & 31u);
+                    e = hipMalloc(&ds->d_bits, bits.size() * sizeof(uint32_t));
+                    if (e == hipSuccess) e = hipMemcpy(ds->d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+                }
+                if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "dead set upload"); }
+                std::lock_guard<std::mutex> g(s->dead_mu);
+                s->last_dead = ds;
+            }
+            d_dead = ds->d_list;
+            d_bits = ds->d_bits;
+            sn->dead_sets.push_back(ds);
         }
         if (s->kind == 0) {
             SegDesc d{};

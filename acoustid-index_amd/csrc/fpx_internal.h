@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,6 +64,21 @@ enum Counter : int {
 // ---------------------------------------------------------------- host objects
 struct Ctx;
 
+// The superseded docs of a segment within one snapshot, on the host and in HBM (sorted list + bitmap).  Successive
+// snapshots mostly find the same set for their older segments: the set is cached on the segment and shared.
+struct DeadSet {
+    int device = 0;
+    std::vector<uint32_t> ids;
+    uint32_t* d_list = nullptr;
+    uint32_t* d_bits = nullptr;
+    ~DeadSet()
+    {
+        if (d_list || d_bits) (void)hipSetDevice(device);
+        if (d_list) (void)hipFree(d_list);
+        if (d_bits) (void)hipFree(d_bits);
+    }
+};
+
 struct Segment {
     std::atomic<int> refs{1};
     Ctx* ctx = nullptr;
@@ -78,6 +94,7 @@ struct Segment {
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
+    std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment
     uint64_t num_items = 0;
     // memory
     uint64_t* d_items = nullptr;
@@ -97,7 +114,7 @@ struct Snapshot {
     SegDesc* d_small = nullptr; uint32_t n_small = 0;     // small segments searched in their decoded items
     uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
-    std::vector<uint32_t*> d_dead;       // owned dead lists
+    std::vector<std::shared_ptr<DeadSet>> dead_sets;   // shared with the segments' caches
     uint32_t max_block_size = 0;
     bool all_512 = true;                 // every file segment uses 512-B blocks (the only size the reference writes)
 };

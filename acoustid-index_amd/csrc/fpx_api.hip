@@ -400,11 +400,12 @@ static void compute_dead(const std::vector<Segment*>& segs, size_t si, std::vect
             }
         };
         if (na == 0 || nb == 0) continue;
+        const size_t before = dead.size();
         if (na * 4 < nb) gallop_intersect(a0, a1, b0, b1);
         else if (nb * 4 < na) gallop_intersect(b0, b1, a0, a1);
         else std::set_intersection(a0, a1, b0, b1, std::back_inserter(dead));
+        std::inplace_merge(dead.begin(), dead.begin() + before, dead.end());      // every contribution arrives sorted
     }
-    std::sort(dead.begin(), dead.end());
     dead.erase(std::unique(dead.begin(), dead.end()), dead.end());
 }
 

@@ -234,14 +234,6 @@ __device__ __forceinline__ uint32_t row_last(uint32_t v)
     return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (0x0F << 5));
 }
 
-// dd[k] for a loop counter k (keeps the array in registers: a select chain instead of scratch indexing)
-__device__ __forceinline__ uint32_t dd_at(const uint32_t dd[8], int k)
-{
-    uint32_t r = dd[0];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) r = (k == j) ? dd[j] : r;
-    return r;
-}
 
 // sum of the four hash deltas of a quad whose codes are all <= 1 byte (w0 = its first data dword)
 __device__ __forceinline__ uint32_t quad_sum1(uint32_t w0, uint32_t sel_lo)
@@ -330,17 +322,45 @@ __device__ __forceinline__ void stage_emit(const HitStage& st, const ProbeArgs& 
     }
 }
 
-// single lane, any control flow (rare paths)
-__device__ __forceinline__ void stage_emit_one(const HitStage& st, const ProbeArgs& a, uint64_t rec)
+// All kept matches of one 8-values-per-lane chunk in ONE reservation, under any control flow (the rows of a wave may be in
+// different chunks of their blocks).  A long run -- a hot hash brings up to 1000 docs per probe -- would overflow the
+// stage on every call and pay one same-address global atomic per 64 records; it is appended to the hit buffer
+// directly instead, one atomic for the wave's whole chunk (up to 512 records).
+constexpr uint32_t DIRECT_EMIT_MIN = 96;
+__device__ __forceinline__ void stage_emit8(const HitStage& st, const ProbeArgs& a, uint32_t kf, const uint32_t dd[8], uint32_t pq,
+                                            uint32_t lane)
 {
-    const uint32_t pos = atomicAdd(st.count, 1u);
-    if (pos < (uint32_t)STAGE_CAP) {
-        st.buf[pos] = rec;
-    } else {
-        atomicMin(st.valid, pos);
-        const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
-        if (gg < a.hit_cap) a.hits[gg] = rec;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t off[8], total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long m = __ballot((int)((kf >> k) & 1u));
+        off[k] = total + (uint32_t)__popcll(m & lt);
+        total += (uint32_t)__popcll(m);
     }
+    if (total == 0u) return;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(1));          // first active lane
+    const uint64_t qpart = (uint64_t)pq << 32;
+    if (total < DIRECT_EMIT_MIN) {
+        uint32_t pos = 0;
+        if (lane == leader) pos = atomicAdd(st.count, total);
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+        if (pos + total <= (uint32_t)STAGE_CAP) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((kf >> k) & 1u) st.buf[pos + off[k]] = qpart | dd[k];
+            return;
+        }
+        if (lane == leader) atomicMin(st.valid, pos);
+    }
+    unsigned long long gg = 0;
+    if (lane == leader) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+    const uint32_t glo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gg);
+    const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gg >> 32));
+    gg = ((unsigned long long)ghi << 32) | glo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (((kf >> k) & 1u) && gg + off[k] < a.hit_cap) a.hits[gg + off[k]] = qpart | dd[k];
 }
 
 // whole workgroup, at a round boundary: flush when half full or at the end.  With `filt` the staged records of
@@ -681,13 +701,10 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                                     if (((kf >> k) & 1u) && is_dead_seg(seg, dd[k]))
                                         kf &= ~(1u << k);
                             }
-                            // blocks with more than 128 items (rare at 512 B): every chunk but the last hands its
-                            // matches to the staging buffer lane by lane, the last one uses the ballot path below
-                            if (more_chunks && kf != 0u) {
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    if ((kf >> k) & 1u) stage_emit_one(hs, a, ((uint64_t)pq << 32) | dd[k]);
-                                }
+                            // the chunk's kept matches: one reservation for all of them (the rows of the wave may be
+                            // in different chunks; the fast path above leaves its single match to the emission below)
+                            if (kf != 0u) {
+                                stage_emit8(hs, a, kf, dd, pq, lane);
                                 kf = 0;
                             }
                         }
@@ -708,12 +725,8 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                 first = false;
 
                 // ---- emission of this iteration's kept matches (wave-uniform control flow)
-                if (__any((int)(kf != 0u))) {
-                    const int kmax = __any((int)((kf & ~1u) != 0u)) ? 8 : 1;    // the fast path only ever sets bit 0
-                    for (int k = 0; k < kmax; ++k) {
-                        stage_emit(hs, a, ((kf >> k) & 1u) != 0u, ((uint64_t)pq << 32) | dd_at(dd, k), lane);
-                    }
-                }
+                if (__any((int)(kf != 0u)))                                     // the fast path's single match (bit 0)
+                    stage_emit(hs, a, (kf & 1u) != 0u, ((uint64_t)pq << 32) | dd[0], lane);
             }
         }
 
@@ -1381,6 +1394,19 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
         }
     };
 
+    // A heavy query -- far more records than the batch average the filter was sized for (hot hashes, a 100x outlier) --
+    // would saturate the filter: every cell reaches the floor, every record survives, and the exact count degenerates
+    // into hundreds of passes over all n records.  Such a query is counted in K rounds over disjoint doc classes (a
+    // second, independent hash), each with a filter load of at most floor / 2 per cell.
+    uint32_t K = 1u;
+    if (min_score >= 4u) {
+        const uint64_t cell = (uint64_t)F * min_score;
+        K = (uint32_t)min<uint64_t>((2ull * n + cell - 1ull) / cell, 1024ull);       // >= 1: n >= min_score here
+    }
+    uint32_t floor_q = min_score;
+    if (tid == 0) qmax = 0u;
+    for (uint32_t kc = 0; kc < K; ++kc) {
+    auto in_class = [&](uint32_t d) -> bool { return K == 1u || __umulhi(mix32(d ^ 0x9E3779B9u), K) == kc; };
     // ---- stage A
     for (uint32_t s = tid; s < F; s += WG) filter[s] = 0u;
     if (tid == 0) survivors = 0u;
@@ -1389,7 +1415,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
         load_tile(t0);
 #pragma unroll
         for (int u = 0; u < RPT; ++u)
-            if (t0 + (uint64_t)u * WG + tid < n) atomicAdd(&filter[mix32(rec[u]) & fmask], 1u);
+            if (t0 + (uint64_t)u * WG + tid < n && in_class(rec[u])) atomicAdd(&filter[mix32(rec[u]) & fmask], 1u);
     }
     __syncthreads();
     // records whose filter cell reaches `fl` (every doc with count >= fl is among them)
@@ -1401,11 +1427,13 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
             if (!one_tile) load_tile(t0);
 #pragma unroll
             for (int u = 0; u < RPT; ++u)
-                if (t0 + (uint64_t)u * WG + tid < n) mine += filter[mix32(rec[u]) & fmask] >= fl ? 1u : 0u;
+                if (t0 + (uint64_t)u * WG + tid < n && in_class(rec[u])) mine += filter[mix32(rec[u]) & fmask] >= fl ? 1u : 0u;
         }
         if (mine) atomicAdd(&survivors, mine);
         __syncthreads();
-        return survivors;
+        const uint32_t total = survivors;
+        __syncthreads();                                     // the next round resets the counter
+        return total;
     };
     // exact (doc, count) table of the surviving records of class `pass`
     auto fill_table = [&](uint32_t pass, uint32_t passes, uint32_t fl) {
@@ -1417,6 +1445,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
             for (int u = 0; u < RPT; ++u) {
                 if (t0 + (uint64_t)u * WG + tid >= n) continue;
                 const uint32_t d = rec[u];
+                if (!in_class(d)) continue;
                 const uint32_t hsh = mix32(d);
                 if (filter[hsh & fmask] < fl) continue;
                 if (passes > 1u && ((hsh >> 22) % passes) != pass) continue;   // class bits disjoint from the slot bits (9..21)
@@ -1437,9 +1466,8 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
         __syncthreads();
     };
     const uint32_t fill = T * 3u / 4u;
-    uint32_t floor_q = min_score;
     uint32_t nsurv = count_survivors(floor_q);
-    if (nsurv < floor_q) return;
+    if (nsurv < floor_q) continue;
     uint32_t passes = (nsurv + fill - 1u) / fill;
 
     // A low floor (the legacy protocol's min_score 1) lets every record through the filter and makes every counted doc a
@@ -1448,9 +1476,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
     // score first and the floor is raised BEFORE anything is emitted.  (A rank of a sharded search may do the same with
     // its LOCAL best score: the global best, hence the final floor, can only be higher.)
     const uint32_t pct = opts[q * 4u + 2u];
-    if (passes > 1u && pct != 0u) {
-        if (tid == 0) qmax = 0u;
-        __syncthreads();
+    if (passes > 1u && pct != 0u) {                       // qmax carries over the doc classes: still a lower bound of the best
         for (uint32_t pass = 0; pass < passes; ++pass) {
             fill_table(pass, passes, floor_q);
             uint32_t m = 0;
@@ -1514,6 +1540,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
         }
         __syncthreads();
     }
+    }   // doc classes
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -437,3 +437,30 @@ def test_small_segments_in_big_batches(env, block_size):
         qs.append(q)
     got, st = p.check(qs, [fpx.SearchOptions(int(rng.choice([5, 40, 500])), int(rng.choice([1, 2, 10])), int(rng.choice([0, 10, 100]))) for _ in qs])
     assert st.probes >= (1 << 16) and st.scanned_docs > 100000                    # the walks over the hot runs really happened
+
+
+@pytest.mark.parametrize("nlight", [40, 600])
+def test_heavy_queries_counted_in_doc_class_rounds(env, nlight):
+    """A query with 100x the batch's average hit records would saturate k_score's counting filter (sized for the average):
+    it is counted in rounds over disjoint doc classes instead.  Heavy queries (hot hashes, floors 4..50, with and without
+    the relative cut-off) ride in a batch of light ones; results must equal the oracle's."""
+    fpx, oracle, Pair, ctx = env
+    seed, H, per = 977, 64, 40000
+    p = Pair(ctx)
+    for s in range(4):
+        lo = s * per + 1
+        p.add_file(fpx.synth.synth_items(seed, lo, per, H, dist=1), lo, lo + per - 1, s + 1, np.arange(lo, lo + per))
+    p.finish()
+    hot = np.array([int(fpx.synth.mix64(np.uint64(seed) ^ np.uint64(0x5bd1e9955bd1e995) ^ (np.uint64(k) << np.uint64(32))) >> np.uint64(32))
+                    for k in range(96)], dtype=np.uint32)
+    qs, opts = [], []
+    for i, (floor, pct, limit) in enumerate([(4, 0, 500), (8, 10, 100), (20, 50, 40), (50, 0, 10), (5, 100, 10), (4, 0, 3)]):
+        doc = 1 + 4001 * i
+        qs.append(np.concatenate([fpx.synth.synth_hashes(seed, [doc], H, 1)[0], hot[i % 3:]]))
+        opts.append(fpx.SearchOptions(limit, floor, pct))
+    for d in range(1, nlight + 1):
+        qs.append(fpx.synth.synth_hashes(seed, [17 * d], H, 1)[0][:12])
+        opts.append(fpx.SearchOptions(5, 4, 10))
+    got, st = p.check(qs, opts)
+    assert st.hits > 400000                               # ~90 k records per heavy query, a few dozen per light one
+    assert all(len(g) >= 1 for g in got[:6])

@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("FPX_BENCH_INFLIGHT", 0)),
                     help="batches kept in flight by that many host threads (each call owns a pooled workspace + HIP stream); "
-                         "0 = auto: 1 on one GPU (clean per-kernel timing), 2 when sharded (hides the all-gather/merge latency)")
+                         "0 = auto: 1 on one GPU (clean per-kernel timing), 3 when sharded (hides the all-gather/merge latency and the host round trips)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency probe (profiling runs)")
     ap.add_argument("--no-measure-bw", action="store_true",
                     help="skip the measured streaming / random-512-B read bandwidth (the second roofline denominator)")
@@ -122,6 +122,13 @@ def main():
     backend = os.environ.get("FPX_BENCH_BACKEND", "nccl")
     device = int(os.environ.get("FPX_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(device)
+    # FPX_BENCH_EMULATE_WORLD=N on ONE GPU: this process plays rank 0 of N (its share of the segments, the sharded
+    # protocol with a 1-rank group) -- an estimate of one rank's step time; the line it prints is flagged and is not a result.
+    eworld = int(os.environ.get("FPX_BENCH_EMULATE_WORLD", "0")) if world == 1 else 0
+    if eworld > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", device))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -134,7 +141,7 @@ def main():
     S, H, B = args.segments, args.hashes, args.batch
     docs = args.docs
     free_b, total_b = torch.cuda.mem_get_info()
-    local_segs = [s for s in range(S) if s % world == rank]
+    local_segs = [s for s in range(S) if s % max(world, eworld) == rank]
     est_seg_bytes = (docs // S) * H * 5.4                  # ~4.5-5.3 B/item in blocks
     need = est_seg_bytes * len(local_segs) + (docs // S) * H * 8 * 2.3 + (4 << 30)   # + build scratch of one segment
     while need > free_b * 0.92 and docs > 1_000_000:
@@ -171,9 +178,10 @@ def main():
 
     import concurrent.futures as cf
     lock = threading.Lock()
-    nfl = args.inflight if args.inflight > 0 else (1 if world == 1 else 2)
+    sharded = world > 1 or eworld > 1
+    nfl = args.inflight if args.inflight > 0 else (3 if sharded else 1)
     outs = [(np.zeros((B, cap, 2), np.uint32), np.zeros(B, np.uint32)) for _ in range(nfl)]
-    shardeds = [fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world, host_staged=(backend != "nccl")) for _ in range(nfl)] if world > 1 else None
+    shardeds = [fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world, host_staged=(backend != "nccl")) for _ in range(nfl)] if sharded else None
 
     def record_stats(st):
         with lock:
@@ -191,7 +199,7 @@ def main():
         """nsteps batches, `nfl` of them in flight.  world == 1: every thread runs whole searches.  world > 1: threads
         run stage 1 (local partial search); the all-gather + merge of step s is issued by this thread in step order so
         that every rank enters the collectives in the same sequence."""
-        if world == 1:
+        if not sharded:
             def one(i):
                 o, n = outs[i % nfl]
                 _, _, st = fpx.search_resident(reader, qb, 0, o, n)
@@ -278,6 +286,7 @@ def main():
                                               "visited_blocks_per_step": agg["blocks"] / max(1, args.steps),
                                               "blocks_finished_by_generic_pass_per_step": agg["generic"] / max(1, args.steps)}},
             "inflight": nfl,
+            **({"emulated_rank_of_world": eworld, "note": "ONE rank's share of a sharded run emulated on one GPU: not a result"} if eworld > 1 else {}),
             "gpu_ms_per_step": agg["gpu_ms"] / max(1, args.steps),
             "hits_per_step": agg["hits"] / max(1, args.steps),
             "targets_found": found, "targets_total": B, "median_top_score": int(np.median(top_scores)) if top_scores else 0,
@@ -315,11 +324,13 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
-    if rank == 0:
-        print(json.dumps(result))
     if world > 1:
         dist.barrier()
+    if world > 1 or eworld > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)      # last: RCCL prints its version banner when the group goes away
 
 
 if __name__ == "__main__":

@@ -331,13 +331,9 @@ __device__ __forceinline__ void stage_emit8(const HitStage& st, const ProbeArgs&
                                             uint32_t lane)
 {
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t off[8], total = 0;
+    uint32_t total = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const unsigned long long m = __ballot((int)((kf >> k) & 1u));
-        off[k] = total + (uint32_t)__popcll(m & lt);
-        total += (uint32_t)__popcll(m);
-    }
+    for (int k = 0; k < 8; ++k) total += (uint32_t)__popcll(__ballot((int)((kf >> k) & 1u)));
     if (total == 0u) return;
     const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(1));          // first active lane
     const uint64_t qpart = (uint64_t)pq << 32;
@@ -347,8 +343,11 @@ __device__ __forceinline__ void stage_emit8(const HitStage& st, const ProbeArgs&
         pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
         if (pos + total <= (uint32_t)STAGE_CAP) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((kf >> k) & 1u) st.buf[pos + off[k]] = qpart | dd[k];
+            for (int k = 0; k < 8; ++k) {                                      // the ballots again: no offsets held in registers
+                const unsigned long long m = __ballot((int)((kf >> k) & 1u));
+                if ((kf >> k) & 1u) st.buf[pos + (uint32_t)__popcll(m & lt)] = qpart | dd[k];
+                pos += (uint32_t)__popcll(m);
+            }
             return;
         }
         if (lane == leader) atomicMin(st.valid, pos);
@@ -359,8 +358,37 @@ __device__ __forceinline__ void stage_emit8(const HitStage& st, const ProbeArgs&
     const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gg >> 32));
     gg = ((unsigned long long)ghi << 32) | glo;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (((kf >> k) & 1u) && gg + off[k] < a.hit_cap) a.hits[gg + off[k]] = qpart | dd[k];
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long m = __ballot((int)((kf >> k) & 1u));
+        const unsigned long long at = gg + (uint32_t)__popcll(m & lt);
+        if (((kf >> k) & 1u) && at < a.hit_cap) a.hits[at] = qpart | dd[k];
+        gg += (uint32_t)__popcll(m);
+    }
+}
+
+// Write pass of a wave that counted its records first (k_probe, deferred long runs): the chunk's kept matches go to
+// hits[base + slot...], the slots handed out by the wave's own LDS word.  Any control flow.
+__device__ __forceinline__ void run_emit8(uint32_t* wave_slot, uint64_t base, const ProbeArgs& a, uint32_t kf, const uint32_t dd[8],
+                                          uint32_t pq, uint32_t lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) total += (uint32_t)__popcll(__ballot((int)((kf >> k) & 1u)));
+    if (total == 0u) return;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(1));
+    uint32_t pos = 0;
+    if (lane == leader) pos = atomicAdd(wave_slot, total);
+    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+    const uint64_t qpart = (uint64_t)pq << 32;
+    uint64_t at = base + pos;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long m = __ballot((int)((kf >> k) & 1u));
+        const uint64_t mine = at + (uint32_t)__popcll(m & lt);
+        if (((kf >> k) & 1u) && mine < a.hit_cap) a.hits[mine] = qpart | dd[k];
+        at += (uint32_t)__popcll(m);
+    }
 }
 
 // whole workgroup, at a round boundary: flush when half full or at the end.  With `filt` the staged records of
@@ -441,6 +469,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut);   // PWAVES * 4 * bsp bytes
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    __shared__ uint32_t wave_run[PWAVES];                                  // write pass of a long-run wave: slots handed out
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 4, gl = lane & 15u;
@@ -472,12 +501,16 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         // ---- phase 1: one lane per pair: dedup + block lookup
         uint64_t p = DEFERRED ? ((uint64_t)round * gridDim.x + blockIdx.x) * (uint64_t)(PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane
                               : wg_base + (uint64_t)round * (PWAVES * a.ppw) + (uint64_t)wave * a.ppw + lane;
-        bool valid;
+        bool valid, long_run = false;
         if (DEFERRED) {
             // p indexes this segment's list of deferred probes (already deduplicated and counted by k_probe_lean8)
             const uint32_t n = min(a.def_count[blockIdx.y], a.def_cap);
             valid = lane < a.ppw && p < (uint64_t)n;
-            if (valid) p = gload_u32(a.def_list + (size_t)blockIdx.y * a.def_cap + p);
+            if (valid) {
+                const uint32_t entry = gload_u32(a.def_list + (size_t)blockIdx.y * a.def_cap + p);
+                long_run = (entry >> 31) != 0u;                    // k_probe_lean8 saw a run of many docs
+                p = entry & 0x7FFFFFFFu;
+            }
         } else {
             valid = lane < a.ppw && p < a.P;
         }
@@ -496,6 +529,15 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         const uint32_t b0v = (b0 & 0x7FFFFFFFu) | (valid ? 0x80000000u : 0u);
 
         // ---- phase 2: four probes per iteration, one per 16-lane row
+        // A wave of the deferred pass that holds long runs (hot hashes: up to 1000 docs per probe and segment) walks its
+        // probes TWICE: first it only counts the records, then it reserves room for all of them with ONE atomic and
+        // writes them in place.  Same-address global atomics complete at about 12 ns each on this chip (83 M/s): at a
+        // few hundred records per reservation they, not the decode, bounded the pass (19 ms for 624 M records).
+        const bool two_pass = DEFERRED && __any((int)long_run);
+        uint32_t run_cnt = 0;                                   // count pass: records of my lanes
+        uint64_t run_base = 0;                                  // write pass: the wave's reservation
+        for (int mode = two_pass ? 0 : 1; mode < 2; ++mode) {
+        const bool count_only = two_pass && mode == 0, direct = two_pass && mode == 1;
         const uint32_t iters = (a.ppw + 3u) >> 2;
         uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
         if (FAST512) {
@@ -622,7 +664,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                                 }
                             }
                         }
-                        if (generic && gl == 0u) my_generic += 1;
+                        if (generic && gl == 0u && !count_only) my_generic += 1;
                         if (generic)
                         for (uint32_t c0 = 0; c0 < nq; c0 += 32u) {
                             const uint32_t qa = c0 + 2u * gl;             // my quads: qa, qa + 1
@@ -704,7 +746,9 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                             // the chunk's kept matches: one reservation for all of them (the rows of the wave may be
                             // in different chunks; the fast path above leaves its single match to the emission below)
                             if (kf != 0u) {
-                                stage_emit8(hs, a, kf, dd, pq, lane);
+                                if (count_only) run_cnt += (uint32_t)__popc(kf);
+                                else if (direct) run_emit8(&wave_run[wave], run_base, a, kf, dd, pq, lane);
+                                else stage_emit8(hs, a, kf, dd, pq, lane);
                                 kf = 0;
                             }
                         }
@@ -717,7 +761,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                         // read off the decoded items instead of global memory so that nothing queues behind the prefetch)
                         const uint32_t ends_row = (uint32_t)(__ballot((int)ends_with_ph) >> (g * 16u)) & 0xFFFFu;
                         if (more && ends_row != 0u) cont = true;
-                        if (gl == 0) { my_blocks += 1; my_docs += cnt; }
+                        if (gl == 0 && !count_only) { my_blocks += 1; my_docs += cnt; }
                     }
                 }
                 pact = cont;
@@ -725,10 +769,31 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                 first = false;
 
                 // ---- emission of this iteration's kept matches (wave-uniform control flow)
-                if (__any((int)(kf != 0u)))                                     // the fast path's single match (bit 0)
-                    stage_emit(hs, a, (kf & 1u) != 0u, ((uint64_t)pq << 32) | dd[0], lane);
+                if (__any((int)(kf != 0u))) {                                   // the fast path's single match (bit 0)
+                    if (count_only) run_cnt += kf & 1u;
+                    else if (direct) {
+                        if (kf & 1u) run_emit8(&wave_run[wave], run_base, a, 1u, dd, pq, lane);
+                    } else stage_emit(hs, a, (kf & 1u) != 0u, ((uint64_t)pq << 32) | dd[0], lane);
+                }
             }
         }
+        if (count_only) {
+            // the wave's total -> one reservation; the write pass hands out its slots through an LDS word of the wave
+            uint32_t tot = run_cnt;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+            unsigned long long gg = 0;
+            if (lane == 0) {
+                if (tot) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)tot);
+                wave_run[wave] = 0u;
+            }
+            const uint32_t glo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gg);
+            const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gg >> 32));
+            run_base = ((uint64_t)ghi << 32) | glo;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        }   // count pass, write pass
 
         // ---- flush the LDS staging buffer at round boundaries
         stage_flush(hs, a, round + 1u == nrounds, tid, PWG);
@@ -1097,7 +1162,10 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             // -- bookkeeping per group
             if (l == 0u && visited) {
                 if (defer) {
-                    const uint32_t pair = wave_pair0 + j * 64u + (it & 7u) * 8u + g;
+                    // bit 31 tags the rows that will bring many docs (a block of > 128 items, a run over 3+ quads, or 3+ docs
+                    // already and more in the next block): the deferred pass counts those before it writes them
+                    const bool long_run = (nq > 32u) | (ncand >= 3u) | (cnt >= 3u);
+                    const uint32_t pair = (wave_pair0 + j * 64u + (it & 7u) * 8u + g) | (long_run ? 0x80000000u : 0u);
                     const uint32_t slot = atomicAdd(&def_n, 1u);
                     if (slot < (uint32_t)DEF_STAGE_CAP) {
                         def_stage[slot] = pair;
@@ -1941,7 +2009,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
             // big batches: every kind of file segment has its own kernel
-            const bool lean = (snap->n_lean != 0 || snap->n_small != 0) && !force_generic && P < 0xFFFFFFFFull &&
+            const bool lean = (snap->n_lean != 0 || snap->n_small != 0) && !force_generic && P < 0x80000000ull &&   // pair indices + a tag bit in the deferred lists
                               total >= lean_min_probes();
             if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (lean) {

@@ -58,6 +58,8 @@ enum Counter : int {
     CTR_PROBES = 5,      // valid (unique hash, file segment) probes
     CTR_MAXSCORE = 6,
     CTR_GENERIC = 7,     // wave iterations of k_probe that took the generic (per-value) decode path    // largest score of any candidate (sizes the score field of the candidate key)
+    CTR_HEAVY = 9,       // queries k_score handed to its CLASSED launch
+    CTR_SLOTCANDS = 14,  // candidates handed from k_score to k_finish through the queries' own slots (statistics)
     CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
 };
 
@@ -137,6 +139,7 @@ struct Workspace {
     uint64_t* d_cands[2] = {nullptr, nullptr}; size_t cap_cands = 0;  // candidate keys
     void* d_temp = nullptr; size_t cap_temp = 0;              // radix sort temp
     uint64_t* d_qrange = nullptr; size_t cap_qrange = 0;      // [B][2] begin/end of each query's hit records
+    uint64_t* d_qcand = nullptr; size_t cap_qcand = 0;        // [B][QCAND_SLOTS] candidate keys, then [B] u32 counts
     unsigned long long* d_counters = nullptr;                 // [CTR_COUNT]
     uint32_t* d_def_list = nullptr; size_t cap_def = 0;       // deferred probes of the lean kernel [n_file][def_cap]
     unsigned int* d_def_count = nullptr; unsigned int* h_def_count = nullptr; size_t cap_def_segs = 0;

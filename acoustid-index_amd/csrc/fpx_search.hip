@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fpx_internal.h"
 
@@ -1424,19 +1425,27 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 //      64-bit LDS atomics -- the GPU form of the reference's per-search hit map (src/common.zig:83-129).  If more
 //      records survive than the table holds they are counted in passes over disjoint doc classes.
 // Candidate key = q << (32 + sb) | (smax - score) << 32 | doc   (ascending = score desc, doc asc within a query).
+constexpr uint32_t QCAND_SLOTS = 4;                 // per-query candidate slots (k_score -> k_finish without the shared list)
+constexpr uint32_t QCAND_OVERFLOWED = 0xFFFFFFFFu;  // the query's candidates are all in the shared list
 constexpr uint32_t SCORE_TABLE_LOG2 = 11;       // exact table: 2048 slots = 16 KB (2^13 = 64 KB when the floor is too low for the filter)
 
-__global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ qrange,
-                                               const uint32_t* __restrict__ opts, uint32_t log2ft, uint32_t sb,
-                                               uint64_t* cands, uint64_t cand_cap, unsigned long long* counters,
-                                               uint64_t single_hit_cap = 0)
+// RPT = records per thread and tile: 32 for the usual thousands of records per query, 8 when the batch's queries are short (a
+// rank's share of a sharded index): the unrolled sweeps cost instructions per ROW.
+// CLASSED = the variant for heavy queries (rounds over doc classes, see below).  It is a separate instantiation because
+// the class test costs the unrolled sweeps ~50 more VGPRs: the usual queries keep 3 waves per SIMD instead of 2, and
+// hand the (rare) heavy ones over through `heavy`.
+template <int RPT, bool CLASSED>
+__device__ __forceinline__ void score_query(uint32_t q, const uint64_t* __restrict__ hits, const uint64_t* __restrict__ qrange,
+                                            const uint32_t* __restrict__ opts, uint32_t log2ft, uint32_t sb,
+                                            uint64_t* cands, uint64_t cand_cap, unsigned long long* counters,
+                                            uint64_t single_hit_cap, uint64_t* qcand, uint32_t* qcand_n, uint32_t* heavy)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t log2t = log2ft >> 8, log2f = log2ft & 0xFFu;                              // table and filter sizes
     unsigned long long* table = reinterpret_cast<unsigned long long*>(smem);                 // 2^log2t slots
     unsigned int* filter = reinterpret_cast<unsigned int*>(smem + ((size_t)8u << log2t));     // 2^log2f cells
-    __shared__ uint32_t survivors, qmax, wave_tot[WG / 64], cand_base_lo, cand_base_hi;
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t survivors, qmax, wave_tot[WG / 64], cand_base_lo, cand_base_hi, q_emitted;
+    const uint32_t tid = threadIdx.x;
     // qrange == nullptr: a single query whose records are all of them; their count is still on the device
     const uint64_t lo = qrange ? qrange[2ull * q] : 0ull;
     const uint64_t hi = qrange ? qrange[2ull * q + 1] : min((uint64_t)counters[CTR_HITS], single_hit_cap);
@@ -1450,7 +1459,6 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
 
     // The records are read in tiles of WG * RPT: every thread first issues all its loads (RPT of them in flight), then
     // works on registers.  A query that fits one tile (the normal case) is read from memory exactly once.
-    constexpr int RPT = 32;
     constexpr uint64_t TILE = (uint64_t)WG * RPT;
     uint32_t rec[RPT];
     const bool one_tile = n <= TILE;
@@ -1471,10 +1479,19 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
         const uint64_t cell = (uint64_t)F * min_score;
         K = (uint32_t)min<uint64_t>((2ull * n + cell - 1ull) / cell, 1024ull);       // >= 1: n >= min_score here
     }
+    if constexpr (!CLASSED) {
+        if (K > 1u) {                                             // the CLASSED launch that follows takes it
+            if (tid == 0) heavy[atomicAdd(&counters[CTR_HEAVY], 1ull)] = q;
+            return;
+        }
+    }
     uint32_t floor_q = min_score;
-    if (tid == 0) qmax = 0u;
-    for (uint32_t kc = 0; kc < K; ++kc) {
-    auto in_class = [&](uint32_t d) -> bool { return K == 1u || __umulhi(mix32(d ^ 0x9E3779B9u), K) == kc; };
+    if (tid == 0) { qmax = 0u; q_emitted = 0u; }
+    // one round over the docs of class kc
+    auto run_class = [&](uint32_t kc) {
+    auto in_class = [&](uint32_t d) -> bool {
+        if constexpr (CLASSED) return __umulhi(mix32(d ^ 0x9E3779B9u), K) == kc; else return true;
+    };
     // ---- stage A
     for (uint32_t s = tid; s < F; s += WG) filter[s] = 0u;
     if (tid == 0) survivors = 0u;
@@ -1482,8 +1499,9 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
     for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
         load_tile(t0);
 #pragma unroll
-        for (int u = 0; u < RPT; ++u)
+        for (int u = 0; u < RPT; ++u) {
             if (t0 + (uint64_t)u * WG + tid < n && in_class(rec[u])) atomicAdd(&filter[mix32(rec[u]) & fmask], 1u);
+        }
     }
     __syncthreads();
     // records whose filter cell reaches `fl` (every doc with count >= fl is among them)
@@ -1494,8 +1512,9 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
         for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
             if (!one_tile) load_tile(t0);
 #pragma unroll
-            for (int u = 0; u < RPT; ++u)
+            for (int u = 0; u < RPT; ++u) {
                 if (t0 + (uint64_t)u * WG + tid < n && in_class(rec[u])) mine += filter[mix32(rec[u]) & fmask] >= fl ? 1u : 0u;
+            }
         }
         if (mine) atomicAdd(&survivors, mine);
         __syncthreads();
@@ -1535,7 +1554,7 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
     };
     const uint32_t fill = T * 3u / 4u;
     uint32_t nsurv = count_survivors(floor_q);
-    if (nsurv < floor_q) continue;
+    if (nsurv < floor_q) return;
     uint32_t passes = (nsurv + fill - 1u) / fill;
 
     // A low floor (the legacy protocol's min_score 1) lets every record through the filter and makes every counted doc a
@@ -1588,12 +1607,29 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
                 total += wave_tot[w];
             }
             if (total != 0u) {
-                if (tid == 0) {
-                    const unsigned long long g = atomicAdd(&counters[CTR_CANDS], (unsigned long long)total);
-                    cand_base_lo = (uint32_t)g; cand_base_hi = (uint32_t)(g >> 32);
-                }
+                // A query's first QCAND_SLOTS candidates (the usual case: the true match and a near-duplicate or two) go to
+                // the query's own slots -- no atomic at all: one reservation per workgroup on the shared candidate counter is
+                // 8192 same-address atomics per batch, ~0.1 ms of serialised L2 atomic time, most of this kernel.  A query
+                // with more moves to the shared list entirely (its slot entries first).
+                const uint32_t have = q_emitted;
                 __syncthreads();
-                uint64_t slot = (((uint64_t)cand_base_hi << 32) | cand_base_lo) + wbase + (incl - mine);
+                const bool to_slots = qcand != nullptr && have != QCAND_OVERFLOWED && have + total <= QCAND_SLOTS;
+                const uint32_t carry = (qcand != nullptr && have != QCAND_OVERFLOWED && !to_slots) ? have : 0u;
+                if (to_slots) {
+                    if (tid == 0) q_emitted = have + total;
+                } else {
+                    if (tid == 0) {
+                        const unsigned long long g = atomicAdd(&counters[CTR_CANDS], (unsigned long long)(total + carry));
+                        cand_base_lo = (uint32_t)g; cand_base_hi = (uint32_t)(g >> 32);
+                        if (qcand != nullptr) q_emitted = QCAND_OVERFLOWED;
+                    }
+                    __syncthreads();
+                }
+                const uint64_t list_base = (((uint64_t)cand_base_hi << 32) | cand_base_lo);
+                if (tid < carry && list_base + tid < cand_cap) cands[list_base + tid] = qcand[(size_t)q * QCAND_SLOTS + tid];
+                uint64_t slot = (to_slots ? (uint64_t)have : list_base + carry) + wbase + (incl - mine);
+                uint64_t* dst = to_slots ? qcand + (size_t)q * QCAND_SLOTS : cands;
+                const uint64_t dst_cap = to_slots ? (uint64_t)QCAND_SLOTS : cand_cap;
                 const uint64_t qpart = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
                 for (uint32_t j = 0; j < SPT; ++j) {
                     const unsigned long long e = table[j * WG + tid];
@@ -1601,14 +1637,38 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
                     if (count == 0u || count < floor_q) continue;
                     if ((uint64_t)count > smax) atomicMax(&counters[CTR_MAXSCORE], (unsigned long long)count);
                     const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
-                    if (slot < cand_cap) cands[slot] = qpart | ((smax - sc) << 32) | (e >> 32);
+                    if (slot < dst_cap) dst[slot] = qpart | ((smax - sc) << 32) | (e >> 32);
                     ++slot;
                 }
             }
         }
         __syncthreads();
     }
-    }   // doc classes
+    };   // run_class
+    if constexpr (CLASSED) { for (uint32_t kc = 0; kc < K; ++kc) run_class(kc); }
+    else run_class(0u);
+    if (qcand_n != nullptr && tid == 0) qcand_n[q] = q_emitted;
+}
+
+// one workgroup per query; the CLASSED instantiation with a `heavy` list: a small grid strides over the listed queries
+template <int RPT, bool CLASSED>
+__global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ qrange,
+                                               const uint32_t* __restrict__ opts, uint32_t log2ft, uint32_t sb,
+                                               uint64_t* cands, uint64_t cand_cap, unsigned long long* counters,
+                                               uint64_t single_hit_cap = 0, uint64_t* qcand = nullptr, uint32_t* qcand_n = nullptr,
+                                               uint32_t* heavy = nullptr)
+{
+    if constexpr (CLASSED) {
+        if (heavy != nullptr) {
+            const uint32_t nh = (uint32_t)counters[CTR_HEAVY];
+            for (uint32_t i = blockIdx.x; i < nh; i += gridDim.x) {
+                score_query<RPT, true>(heavy[i], hits, qrange, opts, log2ft, sb, cands, cand_cap, counters, single_hit_cap, qcand, qcand_n, nullptr);
+                __syncthreads();
+            }
+            return;
+        }
+    }
+    score_query<RPT, CLASSED>(blockIdx.x, hits, qrange, opts, log2ft, sb, cands, cand_cap, counters, single_hit_cap, qcand, qcand_n, heavy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1616,35 +1676,67 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
 //    best score; truncate to max_results (src/common.zig:147-167)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const uint32_t* __restrict__ opts, uint32_t B,
-                         uint32_t sb, int partial, fpx_result* out, uint32_t out_cap, uint32_t* out_n)
+                         uint32_t sb, int partial, fpx_result* out, uint32_t out_cap, uint32_t* out_n,
+                         const uint64_t* __restrict__ qcand = nullptr, const uint32_t* __restrict__ qcand_n = nullptr,
+                         unsigned long long* counters = nullptr)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= B) return;
-    const uint32_t max_results = opts[q * 4u + 0u];
-    uint32_t min_score = opts[q * 4u + 1u];
-    const uint32_t pct = opts[q * 4u + 2u];
+    const bool live = q < B;
+    const uint32_t max_results = live ? opts[q * 4u + 0u] : 0u;
+    uint32_t min_score = live ? opts[q * 4u + 1u] : 0u;
+    const uint32_t pct = live ? opts[q * 4u + 2u] : 0u;
     const uint64_t smax = sb >= 32u ? 0xFFFFFFFFull : ((1ull << sb) - 1ull);
-    const uint64_t qkey = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
-    uint64_t lo = 0, hi = C;
-    while (lo < hi) {
-        uint64_t m = (lo + hi) >> 1;
-        if (cands[m] < qkey) lo = m + 1; else hi = m;
-    }
     uint32_t n = 0;
-    for (uint64_t i = lo; i < C; ++i) {
-        const uint64_t k = cands[i];
-        if (sb < 32u && (k >> (32u + sb)) != (uint64_t)q) break;
-        if (n == max_results) break;
+    // one candidate in (score desc, id asc) order; false = the walk is over
+    auto visit = [&](uint64_t k) -> bool {
+        if (n == max_results) return false;
         const uint32_t score = (uint32_t)(smax - ((k >> 32) & smax));
-        if (score < min_score) break;
+        if (score < min_score) return false;
         if (n == 0 && !partial) {
             const uint32_t rel = (uint32_t)((uint64_t)score * pct / 100ull);
             if (rel > min_score) min_score = rel;
         }
         if (n < out_cap) { out[(size_t)q * out_cap + n].id = (uint32_t)k; out[(size_t)q * out_cap + n].score = score; }
         ++n;
+        return true;
+    };
+    const uint32_t nslots = (live && qcand_n != nullptr) ? qcand_n[q] : QCAND_OVERFLOWED;
+    if (live && nslots != QCAND_OVERFLOWED) {
+        // the query's candidates sit in its own slots (k_score): sort the <= QCAND_SLOTS keys in registers
+        uint64_t k[QCAND_SLOTS];
+#pragma unroll
+        for (uint32_t i = 0; i < QCAND_SLOTS; ++i) k[i] = i < nslots ? qcand[(size_t)q * QCAND_SLOTS + i] : ~0ull;
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < QCAND_SLOTS; ++i)
+#pragma unroll
+            for (uint32_t j = 0; j + 1 < QCAND_SLOTS - i; ++j)
+                if (k[j + 1] < k[j]) { const uint64_t t = k[j]; k[j] = k[j + 1]; k[j + 1] = t; }
+#pragma unroll
+        for (uint32_t i = 0; i < QCAND_SLOTS; ++i)
+            if (i < nslots && !visit(k[i])) break;
+    } else if (live) {
+        const uint64_t qkey = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
+        uint64_t lo = 0, hi = C;
+        while (lo < hi) {
+            uint64_t m = (lo + hi) >> 1;
+            if (cands[m] < qkey) lo = m + 1; else hi = m;
+        }
+        for (uint64_t i = lo; i < C; ++i) {
+            const uint64_t k = cands[i];
+            if (sb < 32u && (k >> (32u + sb)) != (uint64_t)q) break;
+            if (!visit(k)) break;
+        }
     }
-    out_n[q] = n < out_cap ? n : out_cap;
+    if (live) out_n[q] = n < out_cap ? n : out_cap;
+    if (counters != nullptr) {
+        // statistics: candidates that never entered the shared list (one atomic per workgroup of this small grid)
+        __shared__ uint32_t slot_cands;
+        if (threadIdx.x == 0) slot_cands = 0u;
+        __syncthreads();
+        if (live && nslots != QCAND_OVERFLOWED && nslots != 0u) atomicAdd(&slot_cands, nslots);
+        __syncthreads();
+        if (threadIdx.x == 0 && slot_cands != 0u) atomicAdd(&counters[CTR_SLOTCANDS], (unsigned long long)slot_cands);
+    }
 }
 
 // Single-query fast path: the (few) candidates are sorted in LDS and walked by one workgroup; the results and their count
@@ -2097,11 +2189,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     }
     if (single_fast) {
         if (ws->cap_cands < SINGLE_CANDS && (rc = grow_pair(ws->d_cands, &ws->cap_cands, SINGLE_CANDS))) return rc;
-        static const hipError_t lds_attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),
+        static const hipError_t lds_attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, true>),
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)lds_attr1;
         const uint32_t log2f = 13, sb1 = 32u - qb;
-        hipLaunchKernelGGL(k_score, dim3(1), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
+        hipLaunchKernelGGL((k_score<32, true>), dim3(1), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
                            (const uint64_t*)ws->d_hits[0], (const uint64_t*)nullptr, d_opts, log2f | (SCORE_TABLE_LOG2 << 8), sb1, ws->d_cands[0],
                            (uint64_t)SINGLE_CANDS, ws->d_counters, (uint64_t)ws->cap_hits);
         if (!ws->d_ret) FPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_ret), ws->h_counters, 0));
@@ -2148,7 +2240,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_generic = ws->h_counters[CTR_GENERIC],
                              c_main_bytes = (used_lean && snap->n_lean) ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES];
 
-    uint64_t C = 0;
+    uint64_t C = 0, C_slots = 0;                   // candidates in the shared list / in the queries' own slots
+    uint64_t* d_qcand = nullptr;
+    uint32_t* d_qcand_n = nullptr;
     auto fill_stats = [&]() {
         if (!stats) return;
         float total_ms = 0.f;
@@ -2158,7 +2252,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         stats->scanned_docs += c_docs;
         stats->hits += H;
         stats->algorithmic_bytes += c_bytes;
-        stats->candidates += C;
+        stats->candidates += C + C_slots;
         stats->probe_kernel_ms += probe_ms;
         stats->total_gpu_ms += total_ms;
         stats->probe_launches += probe_launches;
@@ -2226,17 +2320,43 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (floor_min <= 2u && H / B > (1u << SCORE_TABLE_LOG2)) { log2t = 13; log2f = 11; }
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
-        static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)lds_attr;
+        static const hipError_t lds_attrs[3] = {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)};
+        (void)lds_attrs;
+        const bool short_queries = H / B <= (uint64_t)WG * 8u;      // the average query fits one 8-row tile
+        // per-query candidate slots: [B][QCAND_SLOTS] keys, then [B] counts; then the list of heavy queries [B]
+        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1)))) return rc;
+        d_qcand = ws->d_qcand;
+        d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
+        uint32_t* d_heavy = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS + (size_t)B / 2 + 1);
+        const size_t score_lds = ((size_t)8 << log2t) + ((size_t)4 << log2f);
         for (int attempt = 0;; ++attempt) {
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
             FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_score, dim3(B), dim3(WG), ((size_t)8 << log2t) + ((size_t)4 << log2f), st,
-                               (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters);
+            FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_HEAVY], 0, sizeof(unsigned long long), st));
+            FPX_HIP(hipMemsetAsync(d_qcand_n, 0, (size_t)B * sizeof(uint32_t), st));
+            if (short_queries)
+                hipLaunchKernelGGL((k_score<8, false>), dim3(B), dim3(WG), score_lds, st,
+                                   (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
+                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy);
+            else
+                hipLaunchKernelGGL((k_score<32, false>), dim3(B), dim3(WG), score_lds, st,
+                                   (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
+                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy);
             FPX_HIP(hipGetLastError());
             FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipStreamSynchronize(st));
+            if (ws->h_counters[CTR_HEAVY] != 0) {
+                // queries the launch above handed over (far more records than the filter was sized for): rounds over doc classes
+                hipLaunchKernelGGL((k_score<32, true>), dim3((uint32_t)std::min<uint64_t>(ws->h_counters[CTR_HEAVY], 1024u)), dim3(WG), score_lds, st,
+                                   (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
+                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy);
+                FPX_HIP(hipGetLastError());
+                FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                FPX_HIP(hipStreamSynchronize(st));
+            }
             C = ws->h_counters[CTR_CANDS];
             if (ws->h_counters[CTR_MAXSCORE] != 0) {              // a score does not fit the key's score field
                 if (B <= 1) { set_error("score overflows u32"); return FPX_E_INVAL; }
@@ -2260,15 +2380,19 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     fpx_result* d_res = partial ? out : ws->d_out;
     uint32_t* d_res_n = partial ? out_n : ws->d_out_n;
     hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
-                       (const uint64_t*)ws->d_cands[ccur], C, d_opts, B, sb, partial ? 1 : 0, d_res, out_cap, d_res_n);
+                       (const uint64_t*)ws->d_cands[ccur], C, d_opts, B, sb, partial ? 1 : 0, d_res, out_cap, d_res_n,
+                       (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, (stats && d_qcand_n) ? ws->d_counters : nullptr);
     FPX_HIP(hipGetLastError());
     if (!partial) {
         FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
     }
+    if (stats && d_qcand_n)
+        FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     FPX_HIP(hipEventRecord(ws->ev_end, st));
     FPX_HIP(hipStreamSynchronize(st));
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
+    if (stats && d_qcand_n) C_slots = ws->h_counters[CTR_SLOTCANDS];
 
     fill_stats();
     return FPX_OK;

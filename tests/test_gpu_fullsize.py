@@ -1,0 +1,150 @@
+"""BASELINE.json's FULL sizes on the GPU, checked through properties that do not need the oracle to scan 100 GB:
+
+* the query's target fingerprint (all of its hashes are in the query, 10 % of them with one bit flipped) ranks first
+  with a score of about 0.9 x H, and never above H;
+* SearchResults.finish's contract (src/common.zig:131-171): score desc / id asc, every score >= max(floor, top * pct / 100),
+  at most `limit` entries;
+* fpindex_scanned_* accounting: probes = unique hashes x segments, algorithmic bytes = visited blocks x 512;
+* idempotence: the same batch twice gives the same bytes;
+* segment sharding (configs[3]: 8 ranks): per-rank partial tables merged by fpx_merge_partials == the unsharded result;
+* the oracle itself on a bounded sample: a few queries against ONE segment downloaded from HBM, bit-exact.
+
+The indexes are synthetic (fpx_synth_segment, byte-exact w.r.t. the reference writer -- tests/test_gpu_builder.py) and
+shrink by halves if the device has less free HBM than the configuration needs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20260928
+
+
+def _build(fpx, ctx, docs, H, S, est_bytes_per_item=5.4):
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    want_docs = docs
+    while docs * H * est_bytes_per_item + (docs // S) * H * 8 * 2.3 + (6 << 30) > free_b * 0.9 and docs > 2_000_000:
+        docs //= 2
+    if docs != want_docs:
+        import warnings
+        warnings.warn(f"full-size test shrunk from {want_docs} to {docs} fingerprints: only {free_b >> 30} GiB of HBM free")
+    per = docs // S
+    segs = [fpx.FileSegment.synth(ctx, SEED, s * per + 1, per, H, 0, 512, s + 1) for s in range(S)]
+    return segs, per, per * S
+
+
+def _check_finish_contract(out, out_n, targets, H, limit, floor, pct):
+    B = len(out_n)
+    n = out_n.astype(np.int64)
+    assert (n >= 1).all() and (n <= limit).all()
+    assert (out[:, 0, 0] == targets).all(), "the target fingerprint must rank first"
+    top = out[:, 0, 1].astype(np.int64)
+    assert (top <= H).all() and (top >= int(0.75 * H)).all()
+    assert abs(float(np.median(top)) - 0.9 * H) <= 0.03 * H
+    col = np.arange(out.shape[1])[None, :]
+    valid = col < n[:, None]
+    score = out[:, :, 1].astype(np.int64)
+    ids = out[:, :, 0].astype(np.int64)
+    cut = np.maximum(floor, top * pct // 100)
+    assert (score[valid] >= np.broadcast_to(cut[:, None], score.shape)[valid]).all()
+    pair_ok = valid[:, 1:]
+    ds = score[:, :-1] - score[:, 1:]
+    assert (ds[pair_ok] >= 0).all(), "scores descend"
+    tie = pair_ok & (ds == 0)
+    assert (ids[:, 1:][tie] > ids[:, :-1][tie]).all(), "ids ascend within a score"
+
+
+def _unique_per_query(flat, offsets):
+    B = len(offsets) - 1
+    L = int(offsets[1] - offsets[0])
+    rows = np.sort(flat.reshape(B, L), axis=1)
+    return int((np.diff(rows, axis=1) != 0).sum() + B)
+
+
+def _oracle_sample(fpx, oracle, ctx, seg, first_doc, ndocs, flat, offsets, opts, nq):
+    blocks, index = seg.download()
+    ids = np.arange(first_doc, first_doc + ndocs, dtype=np.uint32)
+    osnap = oracle.Snapshot([oracle.file_segment(blocks, 512, index, first_doc, first_doc + ndocs - 1, 1, ids, borrow=True)], [])
+    single = fpx.IndexReader(fpx.Segments(ctx, [seg]))
+    sub = fpx.QueryBatch(ctx, options=opts, flat=(np.ascontiguousarray(flat[:int(offsets[nq])]), offsets[:nq + 1]))
+    o, n, st = fpx.search_resident(single, sub)
+    got = fpx.results_to_lists(o, n)
+    blocks_seen = docs_seen = 0
+    for i in range(nq):
+        want, ost = osnap.search(flat[int(offsets[i]):int(offsets[i + 1])], opts.max_results, opts.min_score, opts.min_score_pct,
+                                 with_stats=True)
+        assert got[i] == want, f"query {i}: gpu {got[i][:4]} != oracle {want[:4]}"
+        blocks_seen += ost.scanned_blocks
+        docs_seen += ost.scanned_docs
+    assert (st.scanned_blocks, st.scanned_docs) == (blocks_seen, docs_seen)
+
+
+def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192():
+    """configs[2] (one GPU) and configs[3] (segments sharded over 8 ranks, here 8 snapshots on one GPU)."""
+    import torch
+    from fpx_testlib import fpx, oracle
+    ctx = fpx.Context(0)
+    H, S, B, L, limit = 256, 16, 8192, 1000, 40
+    segs, per, docs = _build(fpx, ctx, 100_000_000, H, S)
+    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
+    opts = fpx.http_options(limit=limit)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    out, out_n, st = fpx.search_resident(reader, qb)
+    out, out_n = out.copy(), out_n.copy()
+    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+    assert st.probes == _unique_per_query(flat, offsets) * S
+    assert st.algorithmic_bytes == st.scanned_blocks * 512 and st.scanned_blocks >= st.probes * 0.97
+    assert st.hits >= int(out[:, 0, 1].astype(np.int64).sum())
+    # idempotence
+    out2, out_n2, st2 = fpx.search_resident(reader, qb)
+    assert (out_n2 == out_n).all() and (out2 == out).all()
+    assert (st2.scanned_blocks, st2.scanned_docs, st2.hits) == (st.scanned_blocks, st.scanned_docs, st.hits)
+    # configs[3]: 8 ranks, two segments each + docs-only stand-ins for the others; tables merged as after an all-gather
+    world, cap = 8, qb.cap
+    remotes = [fpx.RemoteSegment(ctx, s * per + 1, (s + 1) * per, s + 1, np.arange(s * per + 1, (s + 1) * per + 1, dtype=np.uint32))
+               for s in range(S)]
+    parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
+    cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+    blocks_sum = 0
+    for r in range(world):
+        rd = fpx.IndexReader(fpx.Segments(ctx, [segs[s] if s % world == r else remotes[s] for s in range(S)]))
+        pst = fpx.search_resident_partial(rd, qb, parts[r].data_ptr(), cnts[r].data_ptr())
+        blocks_sum += pst.scanned_blocks
+    torch.cuda.synchronize()
+    mo, mn = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
+    assert (mn == out_n).all() and (mo == out).all(), "8-way segment sharding must reproduce the unsharded result"
+    assert blocks_sum == st.scanned_blocks
+    # the oracle on a bounded sample: 24 queries x one segment
+    _oracle_sample(fpx, oracle, ctx, segs[3], 3 * per + 1, per, flat, offsets, opts, 24)
+
+
+def test_config1_10m_fingerprints_one_segment_batch_1024():
+    from fpx_testlib import fpx, oracle
+    ctx = fpx.Context(0)
+    H, B, L, limit = 256, 1024, 1000, 40
+    segs, per, docs = _build(fpx, ctx, 10_000_000, H, 1)
+    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
+    opts = fpx.http_options(limit=limit)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    out, out_n, st = fpx.search_resident(reader, qb)
+    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+    assert st.probes == _unique_per_query(flat, offsets)
+    _oracle_sample(fpx, oracle, ctx, segs[0], 1, per, flat, offsets, opts, 64)
+
+
+def test_config4_share_of_one_rank_125m_fingerprints_120_hashes_limit_100():
+    """configs[4] is 1 B fingerprints x 120 hashes over 8 GPUs: one rank holds 125 M of them in 16 segments."""
+    from fpx_testlib import fpx, oracle
+    ctx = fpx.Context(0)
+    H, S, B, L, limit = 120, 16, 8192, 1000, 100
+    segs, per, docs = _build(fpx, ctx, 125_000_000, H, S, est_bytes_per_item=5.0)
+    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
+    opts = fpx.http_options(limit=limit)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    out, out_n, st = fpx.search_resident(reader, qb)
+    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+    assert st.probes == _unique_per_query(flat, offsets) * S
+    _oracle_sample(fpx, oracle, ctx, segs[15], 15 * per + 1, per, flat, offsets, opts, 16)

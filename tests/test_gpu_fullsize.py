@@ -148,3 +148,41 @@ def test_config4_share_of_one_rank_125m_fingerprints_120_hashes_limit_100():
     _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
     assert st.probes == _unique_per_query(flat, offsets) * S
     _oracle_sample(fpx, oracle, ctx, segs[15], 15 * per + 1, per, flat, offsets, opts, 16)
+
+
+def test_config2_with_hot_hashes_at_full_size():
+    """SURVEY 8(d)'s distribution Z at configs[2]'s size: 2 % of the hashes come from a pool of 4096 hot values, so a hot
+    hash brings the capped 1000 docs x 4 blocks from every segment -- 12 x the hit records of the uniform batch, heavy
+    queries (doc-class rounds in k_score) and long runs (count-then-write waves in the deferred pass) at full scale."""
+    import torch
+    from fpx_testlib import fpx, oracle
+    ctx = fpx.Context(0)
+    H, S, B, L, limit = 256, 16, 8192, 1000, 40
+    free_b, _ = torch.cuda.mem_get_info()
+    docs = 100_000_000
+    while docs * H * 5.4 + (30 << 30) > free_b * 0.9 and docs > 2_000_000:
+        docs //= 2
+    per = docs // S
+    segs = [fpx.FileSegment.synth(ctx, SEED, s * per + 1, per, H, 1, 512, s + 1) for s in range(S)]
+    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, per * S, H, query_len=L, dist=1)
+    opts = fpx.http_options(limit=limit)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    out, out_n, st = fpx.search_resident(reader, qb)
+    out, out_n = out.copy(), out_n.copy()
+    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+    assert st.hits > 5 * B * L                                   # the hot hashes dominate the records
+    world, cap = 4, qb.cap
+    remotes = [fpx.RemoteSegment(ctx, s * per + 1, (s + 1) * per, s + 1, np.arange(s * per + 1, (s + 1) * per + 1, dtype=np.uint32))
+               for s in range(S)]
+    parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
+    cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+    hits_sum = 0
+    for r in range(world):
+        rd = fpx.IndexReader(fpx.Segments(ctx, [segs[s] if s % world == r else remotes[s] for s in range(S)]))
+        hits_sum += fpx.search_resident_partial(rd, qb, parts[r].data_ptr(), cnts[r].data_ptr()).hits
+    torch.cuda.synchronize()
+    mo, mn = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
+    assert (mn == out_n).all() and (mo == out).all()
+    assert hits_sum == st.hits
+    _oracle_sample(fpx, oracle, ctx, segs[7], 7 * per + 1, per, flat, offsets, opts, 16)

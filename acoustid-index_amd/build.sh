@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p ../build
 pids=()
 for f in fpx_sort fpx_search fpx_api fpx_build; do
-  if [ ! -f ../build/$f.o ] || [ $f.hip -nt ../build/$f.o ] || [ fpx_internal.h -nt ../build/$f.o ] || [ ../../include/fpx.h -nt ../build/$f.o ]; then
+  if [ ! -f ../build/$f.o ] || [ $f.hip -nt ../build/$f.o ] || [ fpx_internal.h -nt ../build/$f.o ] || [ -n "$(find . -maxdepth 1 -name "*.hpp" -newer ../build/$f.o 2>/dev/null)" ] || [ ../../include/fpx.h -nt ../build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o ../build/$f.o &
     pids+=($!)
   fi

@@ -1,0 +1,111 @@
+// fpx_kernels_common.hpp -- device helpers shared by the search kernels (pair keys, duplicate test, block lookup) and k_make_keys.
+// Part of the fpx_search.hip translation unit (included there, in this order: common, generic, lean, small, score).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+constexpr int WG = 256;            // 4 waves
+constexpr int STAGE_CAP = 1024;    // LDS hit staging per workgroup (records)
+constexpr int STAGE_FLUSH = 512;
+constexpr int MAX_BLOCKS_PER_HASH = 4;     // src/FileSegment.zig:25
+constexpr int MAX_DOCS_PER_HASH = 1000;    // src/FileSegment.zig:26
+constexpr int MAX_ITEMS_PER_BLOCK = 2048;  // src/block.zig:43
+
+// Pointers read out of a descriptor in memory have no known address space, so plain dereferences compile to
+// FLAT loads, which tick both vmcnt and lgkmcnt and serialise against every LDS access.  These helpers pin
+// the global address space (global_load_*), which keeps LDS traffic and the block prefetch independent.
+#define FPX_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ uint32_t gload_u32(const uint32_t* p) { return *(const FPX_GLOBAL uint32_t*)p; }
+__device__ __forceinline__ uint64_t gload_u64(const uint64_t* p) { return *(const FPX_GLOBAL uint64_t*)p; }
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gload_u4(const uint8_t* p)
+{
+    const u32x4_t v = *(const FPX_GLOBAL u32x4_t*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint8_t gload_u8(const uint8_t* p) { return *(const FPX_GLOBAL uint8_t*)p; }
+
+__device__ __forceinline__ bool is_dead(const uint32_t* dead, uint32_t n, uint32_t lo_id, uint32_t hi_id, uint32_t d)
+{
+    if (n == 0 || d < lo_id || d > hi_id) return false;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t m = (lo + hi) >> 1;
+        if (gload_u32(dead + m) < d) lo = m + 1; else hi = m;
+    }
+    return lo < n && gload_u32(dead + lo) == d;
+}
+
+// supersession test of one posting of a file segment: bitmap over the covered id range when the snapshot built one
+__device__ __forceinline__ bool is_dead_seg(const SegDesc& s, uint32_t d)
+{
+    if (d < s.shadow_lo || d > s.shadow_hi) return false;
+    if (s.dead_bits) return ((gload_u32(s.dead_bits + ((d - s.shadow_lo) >> 5)) >> ((d - s.shadow_lo) & 31u)) & 1u) != 0u;
+    return is_dead(s.dead, s.num_dead, s.shadow_lo, s.shadow_hi, d);
+}
+
+// The pairs are sorted on the top 32 - KEY_SORT_SKIP bits of the hash only (one radix pass less): inside such a bucket
+// they keep the order k_make_keys wrote them in -- by query, then by position in the query -- because the sort is stable.
+// dedupSorted (src/Index.zig:489-499) therefore looks back over the pairs of the SAME query in the SAME bucket
+// (usually none): a pair is a duplicate iff an equal pair precedes it there.
+constexpr unsigned KEY_SORT_SKIP = 8;
+__device__ __forceinline__ bool is_duplicate_pair(const uint64_t* pairs, uint64_t p, uint64_t key, uint32_t qb)
+{
+    if (p == 0) return false;
+    const uint64_t qmask64 = qb >= 32u ? 0xFFFFFFFFull : ((1ull << qb) - 1ull);
+    uint64_t x = gload_u64(pairs + p - 1) ^ key;
+    if (x == 0ull) return true;
+    if (((x >> (qb + KEY_SORT_SKIP)) | (x & qmask64)) != 0ull) return false;      // the usual exit: another bucket or query
+    for (uint64_t i = p - 1; i > 0; --i) {                                         // same (bucket, query): keep looking back
+        x = gload_u64(pairs + i - 1) ^ key;
+        if (x == 0ull) return true;
+        if (((x >> (qb + KEY_SORT_SKIP)) | (x & qmask64)) != 0ull) return false;
+    }
+    return false;
+}
+
+// hash-range slices (one segment split across GPUs): is hash h probed in this slice?
+__device__ __forceinline__ bool owned_hash(const SegDesc& s, uint32_t h)
+{
+    return ((s.own_flags & 1u) == 0u || h > s.own_lo) && ((s.own_flags & 2u) == 0u || h <= s.own_hi);
+}
+
+// first block whose max hash >= h (src/FileSegment.zig:145-151); the reference restricts the search
+// to block_index[prev..], which returns the same block because the query hashes ascend.
+__device__ __forceinline__ uint32_t lookup_block(const SegDesc& s, uint32_t h)
+{
+    uint32_t k = s.bucket_shift >= 32u ? 0u : (h >> s.bucket_shift);
+    uint32_t lo = gload_u32(s.bucket + k), hi = gload_u32(s.bucket + k + 1);
+    while (lo < hi) {
+        uint32_t m = (lo + hi) >> 1;
+        if (gload_u32(s.block_index + m) < h) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. keys
+// ------------------------------------------------------------------------------------------------
+// hashes_base[i] is the hash at ABSOLUTE position i of the batch; the view starts at absolute position `base`
+__global__ void k_make_keys(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
+                            uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,
+                            unsigned long long* zero_counters = nullptr)
+{
+    // one workgroup per query
+    uint32_t q = blockIdx.x;
+    if (q >= B) return;
+    if (zero_counters && q == 0 && threadIdx.x < CTR_COUNT) zero_counters[threadIdx.x] = 0ull;   // single-query path: saves a memset call
+    uint64_t lo = offsets[q], hi = offsets[q + 1];
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+        keys[i - base] = ((uint64_t)hashes_base[i] << qb) | q;
+}
+
+}  // namespace fpx

@@ -1,0 +1,412 @@
+// fpx_probe_lean.hpp -- k_probe_lean8: the lean probe kernel for dense 512-B segments and big batches -- the dominant kernel.
+// Part of the fpx_search.hip translation unit (included there, in this order: common, generic, lean, small, score).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+// ------------------------------------------------------------------------------------------------
+// 3b. k_probe_lean8: the lean probe kernel (dense 512-B segments, big batches) -- the dominant kernel.
+// Straight-line version of the common case: the probe's first block, every hash delta at most two bytes, at most two
+// adjacent candidate quads, no continuation into the next block.  Rows that need anything else write their pair
+// index to the segment's deferred list and are finished by k_probe<.., DEFERRED>; the loop carries no rare-case state.
+//
+// EIGHT probes per wave: 8 lanes per probe, lane l owns quads 4l..4l+3 of the block (a 512-B block holds ~29 quads).
+// The kernel is VALU-issue bound, and most of its per-iteration work (key broadcast, prefetch addressing, header,
+// candidate resolution, the 4-lane quad decode, docid stage, emission) does not depend on how many probes share the
+// wave: the 16-lanes-per-probe predecessor spent 48 VALU instructions per probe, this one 33.
+// ------------------------------------------------------------------------------------------------
+constexpr int L8_WG = 256;                 // 4 waves: LDS per workgroup stays near 30 KB (5 workgroups per CU)
+constexpr int L8_WAVES = L8_WG / 64;
+constexpr int L8_SLOT = 528;               // LDS bytes per staged block: 132 dwords, so the 8 groups of a wave start 4 banks apart
+
+struct LeanLut {
+    uint32_t a[2][256];    // as DecodeLut::a
+    uint2 f[256];          // as DecodeLut::f
+    uint32_t fh[256];      // as DecodeLut::fh
+};
+
+__device__ __forceinline__ void init_lean_lut(LeanLut* lut, uint32_t c)
+{
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        uint32_t off = 0, packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t code = (c >> (2 * k)) & 3u;
+            const uint32_t nb = v == 0 ? code + (code == 3u ? 1u : 0u) : code + 1u;
+            if (k > 0) packed |= off << (8 * (k - 1));
+            off += nb;
+        }
+        lut->a[v][c] = packed | (off << 24);
+        if (v == 0) {
+            uint32_t sl = 0, sh = 0, o = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t code = (c >> (2 * k)) & 3u;
+                const uint32_t nb = code + (code == 3u ? 1u : 0u);
+                sl |= ((nb >= 1u && o < 8u) ? o : 0x0Cu) << (8 * k);
+                sh |= ((nb == 2u && o + 1u < 8u) ? o + 1u : 0x0Cu) << (8 * k);
+                o += nb;
+            }
+            lut->f[c] = make_uint2(packed | (off << 24), sl);
+            lut->fh[c] = sh;
+        }
+    }
+}
+
+// value k of the quad with control byte c whose data starts at LDS offset `off`, without selector tables
+template <int V>
+__device__ __forceinline__ uint32_t decode_one8(const LeanLut* lut, const uint8_t* sm, uint32_t off, uint32_t c, uint32_t k)
+{
+    const uint32_t a = lut->a[V][c];
+    const uint32_t ok = ((a << 8) >> (8u * k)) & 0xFFu;            // byte offset of value k (0 for k = 0)
+    const uint32_t raw = lds_u32u(sm, off + ok);
+    const uint32_t code = (c >> (2u * k)) & 3u;
+    if (V == 0) return __builtin_amdgcn_ubfe(raw, 0u, 8u * code);  // 0/1/2 bytes; a 4-byte value (code 3) is deferred
+    return raw & (0xFFFFFFFFu >> (8u * (3u - code)));                // 1..4 bytes
+}
+
+// DPP helpers for 8-lane groups (two groups per 16-lane row)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+// inclusive prefix sum inside each 8-lane group: the row scan, minus the first group's total for the second group
+__device__ __forceinline__ uint32_t scan8(uint32_t v, uint32_t hi_group_mask)
+{
+    v = scan16(v);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x157, 0xF, 0xF, false);   // row_newbcast:7
+    return v - (t & hi_group_mask);
+}
+// butterflies over the 8 lanes of a group; every lane ends up with the group's result
+__device__ __forceinline__ uint32_t gsum8(uint32_t v)
+{
+    v += dpp_u32<0xB1>(v);      // quad_perm:[1,0,3,2]
+    v += dpp_u32<0x4E>(v);      // quad_perm:[2,3,0,1]
+    v += dpp_u32<0x141>(v);     // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ uint32_t gmin8(uint32_t v)
+{
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    return v;
+}
+// inclusive prefix sum over the 4 lanes of a DPP quad
+__device__ __forceinline__ uint32_t scanq(uint32_t v, uint32_t m1, uint32_t m2)
+{
+    v += dpp_u32<0x90>(v) & m1;     // quad_perm:[0,0,1,2]: lane k reads lane k-1
+    v += dpp_u32<0x44>(v) & m2;     // quad_perm:[0,1,0,1]: lane k reads lane k-2
+    return v;
+}
+__device__ __forceinline__ uint32_t sel4(uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3)
+{
+    uint32_t r = v0;
+    r = i == 1u ? v1 : r;
+    r = i == 2u ? v2 : r;
+    r = i == 3u ? v3 : r;
+    return r;
+}
+
+__global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);                  // STAGE_CAP records
+    LeanLut* lut = reinterpret_cast<LeanLut*>(smem + STAGE_CAP * sizeof(uint64_t));
+    uint8_t* blkmem = smem + STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut);   // L8_WAVES * 8 * L8_SLOT bytes
+    __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
+    __shared__ uint32_t def_stage[DEF_STAGE_CAP];
+    __shared__ uint32_t def_n, def_base;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 3, l = lane & 7u;
+    const SegDesc seg = a.segs[blockIdx.y];
+    uint8_t* blk = blkmem + (size_t)(wave * 8u + g) * L8_SLOT;
+    const uint32_t blko = (uint32_t)(blk - smem);
+    const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
+
+    if (tid < 256u) init_lean_lut(lut, tid);
+    if (tid == 0) {
+        stage_count = 0; stage_valid = STAGE_CAP; def_n = 0;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0;
+    }
+    __syncthreads();
+
+    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
+    // (the descriptor in global memory, not the local copy: taking `seg`'s address would pin all its fields in VGPRs)
+    const SegDesc* dead_filter = seg.num_dead != 0u ? a.segs + blockIdx.y : nullptr;
+    const uint32_t k = l & 3u;
+    const uint32_t q0 = 4u * l;                                   // my quads: q0 .. q0 + 3
+    const uint32_t hi_group = (lane & 8u) ? 0xFFFFFFFFu : 0u;     // second group of the DPP row
+    const uint32_t km1 = k >= 1u ? 0xFFFFFFFFu : 0u, km2 = k >= 2u ? 0xFFFFFFFFu : 0u;
+    const bool low4 = l < 4u;
+
+    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)(L8_WAVES * 64u * LEAN_KPL) * a.rounds;
+    for (uint32_t round = 0; round < a.rounds; ++round) {
+        // ---- phase 1: LEAN_KPL pairs per lane, dedup + block lookup in lockstep
+        const uint64_t wave_base = wg_base + (uint64_t)round * (L8_WAVES * 64u * LEAN_KPL) + (uint64_t)wave * (64u * LEAN_KPL);
+        const uint32_t wave_pair0 = (uint32_t)wave_base;
+        uint32_t h[LEAN_KPL], q[LEAN_KPL], b0v[LEAN_KPL], lo[LEAN_KPL], hi[LEAN_KPL];
+        bool any_open = false;
+#pragma unroll
+        for (int j = 0; j < LEAN_KPL; ++j) {
+            const uint64_t p = wave_base + (uint64_t)j * 64u + lane;
+            bool valid = p < a.P;
+            const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
+            if (valid && is_duplicate_pair(a.pairs, p, key, a.qb)) valid = false;          // dedupSorted, src/Index.zig:489-499
+            h[j] = (uint32_t)(key >> a.qb);
+            q[j] = (uint32_t)key & qmask;
+            lo[j] = 0; hi[j] = 0;
+            if (seg.own_flags != 0u && !owned_hash(seg, h[j])) valid = false;      // another slice of the segment probes h
+            if (valid) {
+                my_probes += 1;
+                const uint32_t kb = seg.bucket_shift >= 32u ? 0u : (h[j] >> seg.bucket_shift);
+                lo[j] = gload_u32(seg.bucket + kb);
+                hi[j] = gload_u32(seg.bucket + kb + 1);
+            }
+            b0v[j] = valid ? 1u : 0u;
+            any_open = any_open || lo[j] < hi[j];
+        }
+        while (__any((int)any_open)) {                                         // src/FileSegment.zig:145-151
+            any_open = false;
+            uint32_t mid[LEAN_KPL], mv[LEAN_KPL];
+#pragma unroll
+            for (int j = 0; j < LEAN_KPL; ++j) {
+                mid[j] = (lo[j] + hi[j]) >> 1;
+                mv[j] = lo[j] < hi[j] ? gload_u32(seg.block_index + mid[j]) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < LEAN_KPL; ++j) {
+                if (lo[j] < hi[j]) { if (mv[j] < h[j]) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
+                any_open = any_open || lo[j] < hi[j];
+            }
+        }
+        uint32_t cw[LEAN_KPL];
+#pragma unroll
+        for (int j = 0; j < LEAN_KPL; ++j) {
+            const bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
+            cw[j] = valid ? gload_u32(seg.cont + (lo[j] >> 5)) : 0u;           // may the hash's run continue in block lo + 1?
+            b0v[j] = (lo[j] & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
+        }
+#pragma unroll
+        for (int j = 0; j < LEAN_KPL; ++j) b0v[j] |= ((cw[j] >> (lo[j] & 31u)) & 1u) << 30;   // bit 30: continuation possible
+
+        // ---- phase 2: eight probes per iteration, one per 8-lane group, blocks prefetched one iteration ahead
+        constexpr uint32_t iters = 8u * LEAN_KPL;
+        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+        {
+            const uint32_t nb = __shfl(b0v[0], (int)g);
+            if (nb >> 31) {
+                const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + l * 16u;
+                pre0 = gload_u4(sb); pre1 = gload_u4(sb + 128); pre2 = gload_u4(sb + 256); pre3 = gload_u4(sb + 384);
+            }
+        }
+#pragma unroll 1
+        for (uint32_t it = 0; it < iters; ++it) {
+            const uint32_t j = it >> 3;                                       // which of the lane's keys (wave-uniform)
+            const int src = (int)((it & 7u) * 8u + g);
+            uint32_t hj = h[0], qj = q[0], bj = b0v[0];
+#pragma unroll
+            for (int jj = 1; jj < LEAN_KPL; ++jj) { if (j == (uint32_t)jj) { hj = h[jj]; qj = q[jj]; bj = b0v[jj]; } }
+            const uint32_t ph = __shfl(hj, src);
+            const uint32_t pq = __shfl(qj, src);
+            const uint32_t pbv = __shfl(bj, src);
+            const bool pact = (pbv >> 31) != 0u;
+            *reinterpret_cast<uint4*>(blk + l * 16u) = pre0;
+            *reinterpret_cast<uint4*>(blk + 128u + l * 16u) = pre1;
+            *reinterpret_cast<uint4*>(blk + 256u + l * 16u) = pre2;
+            *reinterpret_cast<uint4*>(blk + 384u + l * 16u) = pre3;
+            if (it + 1u < iters) {
+                const uint32_t jn = (it + 1u) >> 3;
+                uint32_t bn = b0v[0];
+#pragma unroll
+                for (int jj = 1; jj < LEAN_KPL; ++jj) { if (jn == (uint32_t)jj) bn = b0v[jj]; }
+                const uint32_t nb = __shfl(bn, (int)(((it + 1u) & 7u) * 8u + g));
+                if (nb >> 31) {
+                    const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + l * 16u;
+                    pre0 = gload_u4(sb); pre1 = gload_u4(sb + 128); pre2 = gload_u4(sb + 256); pre3 = gload_u4(sb + 384);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // -- header (src/block.zig:46-50); groups without a probe decode stale bytes and are masked at the end
+            const uint32_t* hw = reinterpret_cast<const uint32_t*>(blk);
+            const uint32_t min_hash = hw[0];
+            const uint32_t n_items = hw[1] & 0xFFFFu;
+            const uint32_t doff = min(hw[1] >> 16, 504u);
+            const uint32_t nq = (n_items + 3u) >> 2;
+            const bool visited = pact & (min_hash <= ph);                      // src/FileSegment.zig:164
+            bool defer = (nq > 32u) | ((n_items & 3u) != 0u);                  // multi-chunk block / partial last quad
+
+            // -- level 1: the sums of my four quads
+            const uint32_t vq = nq > q0 ? min(nq - q0, 4u) : 0u;               // how many of my quads exist
+            const uint32_t vmask = vq >= 4u ? 0xFFFFFFFFu : ((1u << (8u * vq)) - 1u);
+            const uint32_t cc = hw[2 + l] & vmask;                             // control bytes of quads q0..q0+3
+            const uint32_t c0 = cc & 0xFFu, c1 = (cc >> 8) & 0xFFu, c2 = (cc >> 16) & 0xFFu, c3 = cc >> 24;
+            const uint2 f0 = lut->f[c0], f1 = lut->f[c1], f2 = lut->f[c2], f3 = lut->f[c3];
+            const uint32_t l0 = f0.x >> 24, l1 = f1.x >> 24, l2 = f2.x >> 24, l3 = f3.x >> 24;
+            const uint32_t ltot = l0 + l1 + l2 + l3;
+            const uint32_t hincl = scan8(ltot, hi_group);
+            const uint32_t p0 = (8u + nq + hincl - ltot) & 1023u, p1 = p0 + l0, p2 = p1 + l1, p3 = p2 + l2;
+            const uint32_t r0 = lds_u32u(smem, blko + p0), r1 = lds_u32u(smem, blko + p1),
+                           r2 = lds_u32u(smem, blko + p2), r3 = lds_u32u(smem, blko + p3);
+            uint32_t s0, s1, s2, s3;
+            if (__any((int)((cc & 0xAAAAAAAAu) != 0u))) {
+                // some delta of this wave's blocks needs two bytes (sparser segments): 8-byte data windows
+                s0 = quad_sum2(r0, lds_u32u(smem, blko + p0 + 4u), f0.y, lut->fh[c0]);
+                s1 = quad_sum2(r1, lds_u32u(smem, blko + p1 + 4u), f1.y, lut->fh[c1]);
+                s2 = quad_sum2(r2, lds_u32u(smem, blko + p2 + 4u), f2.y, lut->fh[c2]);
+                s3 = quad_sum2(r3, lds_u32u(smem, blko + p3 + 4u), f3.y, lut->fh[c3]);
+            } else {
+                s0 = quad_sum1(r0, f0.y); s1 = quad_sum1(r1, f1.y); s2 = quad_sum1(r2, f2.y); s3 = quad_sum1(r3, f3.y);
+            }
+            const uint32_t stot = s0 + s1 + s2 + s3;
+            const uint32_t vincl = scan8(stot, hi_group);
+            const uint32_t u0 = ph - min_hash - (vincl - stot);               // target relative to the start of quad q0
+            const uint32_t u1 = u0 - s0, u2 = u1 - s1, u3 = u2 - s2;
+            // candidate quads: base < T <= base + sum, or a zero first delta exactly at T
+            const uint32_t m = ((0u < vq) & ((u0 - 1u < s0) | ((u0 == 0u) & ((c0 & 3u) == 0u))) ? 1u : 0u) |
+                               ((1u < vq) & ((u1 - 1u < s1) | ((u1 == 0u) & ((c1 & 3u) == 0u))) ? 2u : 0u) |
+                               ((2u < vq) & ((u2 - 1u < s2) | ((u2 == 0u) & ((c2 & 3u) == 0u))) ? 4u : 0u) |
+                               ((3u < vq) & ((u3 - 1u < s3) | ((u3 == 0u) & ((c3 & 3u) == 0u))) ? 8u : 0u);
+            // a 4-byte delta (code 3) anywhere in the block: the generic pass decides
+            const unsigned long long b4 = __ballot((int)((cc & (cc >> 1) & 0x55555555u) != 0u));
+            defer = defer | ((((uint32_t)(b4 >> (8u * g))) & 0xFFu) != 0u);
+            // One candidate quad is the rule.  Two ADJACENT candidates mean a run of equal hashes crosses a quad
+            // boundary: the upper one then starts exactly at the target and holds the run's zero-delta tail.
+            // Anything else (a run longer than a quad, ...) is deferred.
+            const uint32_t ncand = gsum8(__popc(m));
+            const uint32_t qc1 = gmin8(m ? q0 + (uint32_t)__builtin_ctz(m) : 255u);    // first candidate quad of the group
+            const uint32_t i1 = qc1 & 3u;
+            bool two = false;
+            if (__any((int)(ncand >= 2u))) {                                // rare
+                const uint32_t qn = qc1 + 1u;
+                const uint32_t has_next = ((qn >> 2) == l) ? ((m >> (qn & 3u)) & 1u) : 0u;
+                two = ncand == 2u && gsum8(has_next) != 0u;
+                defer = defer | (ncand >= 2u && !two);
+            }
+
+            // -- level 2: lanes 0..3 of the group decode the candidate quad(s)
+            const uint32_t pack1 = sel4(i1, p0, p1, p2, p3) | (sel4(i1, c0, c1, c2, c3) << 10);
+            const uint32_t ut1 = sel4(i1, u0, u1, u2, u3);
+            const int owner0 = (int)((lane & 56u) | ((qc1 >> 2) & 7u));
+            const uint32_t x0 = __shfl(pack1, owner0);
+            const uint32_t ut0 = __shfl(ut1, owner0);
+            const uint32_t val0 = decode_one8<0>(lut, smem, blko + (x0 & 1023u), (x0 >> 10) & 0xFFu, k);
+            const bool live = visited & !defer & low4;
+            const bool ek0 = live & (ncand != 0u) & (scanq(val0, km1, km2) == ut0);
+            bool ek1 = false;
+            int owner1 = owner0;
+            uint32_t i2 = 0;
+            if (__any((int)(two && live))) {
+                const uint32_t qn = qc1 + 1u;
+                i2 = qn & 3u;
+                owner1 = (int)((lane & 56u) | ((qn >> 2) & 7u));
+                const uint32_t pack2 = sel4(i2, p0, p1, p2, p3) | (sel4(i2, c0, c1, c2, c3) << 10);
+                const uint32_t x1 = __shfl(pack2, owner1);
+                const uint32_t val1 = decode_one8<0>(lut, smem, blko + (x1 & 1023u), (x1 >> 10) & 0xFFu, k);
+                ek1 = live && two && scanq(val1, km1, km2) == 0u;           // the leading zero deltas of the upper quad
+            }
+            const unsigned long long me0 = __ballot((int)ek0), me1 = __ballot((int)ek1);
+            uint32_t cnt = 0, doc0 = 0, doc1 = 0;
+            if ((me0 | me1) != 0ull) {
+                // -- docids of the run: 1234 lengths of my quads from the control bytes (4 + the sum of the codes per quad)
+                const uint32_t dcc = lds_u32u(smem, blko + 8u + doff + q0) & vmask;
+                const uint32_t dlo = dcc & 0x55555555u, dhi = (dcc >> 1) & 0x55555555u;
+                const uint32_t dtot = 4u * vq + __popc(dlo) + 2u * __popc(dhi);
+                const uint32_t dincl = scan8(dtot, hi_group);
+                const uint32_t dp0 = 8u + doff + nq + dincl - dtot;
+                const uint32_t bm1 = (1u << (8u * i1)) - 1u;                 // control bytes below slot i1
+                const uint32_t dpack1 = ((dp0 + 4u * i1 + __popc(dlo & bm1) + 2u * __popc(dhi & bm1)) & 1023u) |
+                                        (((dcc >> (8u * i1)) & 0xFFu) << 10);
+                const uint32_t y0 = __shfl(dpack1, owner0);
+                const uint32_t dv0 = decode_one8<1>(lut, smem, blko + (y0 & 1023u), (y0 >> 10) & 0xFFu, k);
+                doc0 = seg.min_doc_id + scanq(ek0 ? dv0 : 0u, km1, km2);
+                const uint32_t erow0 = ((uint32_t)(me0 >> (8u * g))) & 0xFu;
+                cnt = __popc(erow0);
+                uint32_t elast = erow0, qlast = qc1;                           // the quad that ends the run
+                if (me1 != 0ull) {
+                    const uint32_t bm2 = (1u << (8u * i2)) - 1u;
+                    const uint32_t dpack2 = ((dp0 + 4u * i2 + __popc(dlo & bm2) + 2u * __popc(dhi & bm2)) & 1023u) |
+                                            (((dcc >> (8u * i2)) & 0xFFu) << 10);
+                    const uint32_t y1 = __shfl(dpack2, owner1);
+                    const uint32_t dv1 = decode_one8<1>(lut, smem, blko + (y1 & 1023u), (y1 >> 10) & 0xFFu, k);
+                    // the run continues from the lower quad's last item (lane 3 of the group)
+                    const uint32_t carry = dpp_u32<0xFF>(doc0);               // quad_perm:[3,3,3,3]
+                    doc1 = carry + scanq(ek1 ? dv1 : 0u, km1, km2);
+                    const uint32_t erow1 = ((uint32_t)(me1 >> (8u * g))) & 0xFu;
+                    cnt += __popc(erow1);
+                    if (two) { elast = erow1; qlast = qc1 + 1u; }
+                }
+                // a run that reaches the block's last item continues in the next block when that one starts with the same hash
+                // (the segment's continuation bitmap): let k_probe finish it
+                if (qlast + 1u == nq && ((elast >> 3) & 1u) != 0u && ((pbv >> 30) & 1u) != 0u) defer = true;
+            }
+            // (superseded docs are dropped when the staged records are flushed: a dependent load per hit does not belong
+            // in this loop -- with 1 % of the docs re-inserted in a newer segment it made the kernel 2.6x slower)
+            const bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
+            // -- bookkeeping per group
+            if (l == 0u && visited) {
+                if (defer) {
+                    // bit 31 tags the rows that will bring many docs (a block of > 128 items, a run over 3+ quads, or 3+ docs
+                    // already and more in the next block): the deferred pass counts those before it writes them
+                    const bool long_run = (nq > 32u) | (ncand >= 3u) | (cnt >= 3u);
+                    const uint32_t pair = (wave_pair0 + j * 64u + (it & 7u) * 8u + g) | (long_run ? 0x80000000u : 0u);
+                    const uint32_t slot = atomicAdd(&def_n, 1u);
+                    if (slot < (uint32_t)DEF_STAGE_CAP) {
+                        def_stage[slot] = pair;
+                    } else {                                   // staging full: append directly
+                        const unsigned int gs = atomicAdd(&a.def_count[blockIdx.y], 1u);
+                        if (gs < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + gs] = pair;
+                    }
+                } else {
+                    my_blocks += 1; my_docs += cnt;
+                }
+            }
+            // -- emission (wave-uniform control flow)
+            const int nsets = me1 != 0ull ? 2 : 1;
+            for (int e = 0; e < nsets; ++e) {
+                stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane, dead_filter);
+            }
+        }
+
+        // ---- flush the LDS staging buffer at round boundaries
+        stage_flush(hs, a, round + 1u == a.rounds, tid, L8_WG, dead_filter);
+        // ---- flush the deferred-probe staging (one global atomic per round)
+        {
+            const uint32_t dn = min(def_n, (uint32_t)DEF_STAGE_CAP);
+            if (dn != 0u) {
+                if (tid == 0) def_base = atomicAdd(&a.def_count[blockIdx.y], dn);
+                __syncthreads();
+                for (uint32_t i = tid; i < dn; i += L8_WG)
+                    if (def_base + i < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + def_base + i] = def_stage[i];
+                __syncthreads();
+                if (tid == 0) def_n = 0;
+                __syncthreads();
+            }
+        }
+    }
+
+    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
+    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
+    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    __syncthreads();
+    if (tid == 0) {
+        if (wg_blocks) {
+            atomicAdd(&a.counters[a.ctr_off + CTR_BLOCKS], wg_blocks);
+            atomicAdd(&a.counters[a.ctr_off + CTR_BYTES], wg_blocks * 512ull);
+        }
+        if (wg_docs) atomicAdd(&a.counters[a.ctr_off + CTR_DOCS], wg_docs);
+        if (wg_probes) atomicAdd(&a.counters[a.ctr_off + CTR_PROBES], wg_probes);
+    }
+}
+
+}  // namespace fpx

@@ -1,0 +1,182 @@
+// fpx_probe_small.hpp -- memory segments (k_probe_mem, k_probe_mem_items) and small decoded file segments (k_probe_small).
+// Part of the fpx_search.hip translation unit (included there, in this order: common, generic, lean, small, score).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+// ------------------------------------------------------------------------------------------------
+// 4. memory segments (src/MemorySegment.zig:44-54): equal_range on hash over sorted u64 items, no caps
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uint64_t* __restrict__ pairs, uint64_t P,
+                                                   uint32_t qb, uint64_t* hits, uint64_t hit_cap,
+                                                   unsigned long long* counters)
+{
+    const MemDesc ms = mems[blockIdx.y];
+    const uint64_t p = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
+    if (p >= P) return;
+    const uint64_t key = pairs[p];
+    if (is_duplicate_pair(pairs, p, key, qb)) return;
+    const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
+    uint64_t lo = 0, hi = ms.num_items;
+    while (lo < hi) {
+        uint64_t m = (lo + hi) >> 1;
+        if ((uint32_t)(ms.items[m] >> 32) < h) lo = m + 1; else hi = m;
+    }
+    for (uint64_t i = lo; i < ms.num_items; ++i) {
+        const uint64_t it = ms.items[i];
+        if ((uint32_t)(it >> 32) != h) break;
+        const uint32_t d = (uint32_t)it;
+        if (is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, d)) continue;
+        unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+        if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4b. small file segments (< 2^20 items; fresh checkpoints) in their decoded form (SegDesc::items / bstart).
+//     A batch holds thousands of pairs per BLOCK of such a segment, so the work is organised by block: one workgroup
+//     stages a block's items in LDS, finds the slice of the (bucket-sorted) pairs whose first block it is with two
+//     binary searches, and streams that slice -- FileSegment.search restated per block, with the same walk over <= 4
+//     blocks, the > 1000 docs stop and the same counters (src/FileSegment.zig:145-175), nothing decoded per probe.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SMALL_LDS_ITEMS = 2048;     // MAX_ITEMS_PER_BLOCK
+constexpr uint32_t SMALL_BPW = 8;              // consecutive blocks per workgroup: their pair slices are consecutive too
+__global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const uint64_t* __restrict__ pairs, uint64_t P,
+                                                     uint32_t qb, uint64_t* hits, uint64_t hit_cap,
+                                                     unsigned long long* counters)
+{
+    __shared__ uint64_t blk_items[SMALL_LDS_ITEMS];
+    __shared__ uint64_t prange[2];
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    const SegDesc seg = segs[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bfirst = blockIdx.x * SMALL_BPW;
+    if (bfirst >= seg.num_blocks) return;
+    const uint32_t bend = min(bfirst + SMALL_BPW, seg.num_blocks);
+    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
+    if (tid == 0) { wg_blocks = 0; wg_docs = 0; wg_probes = 0; }
+    unsigned long long my_blocks = 0, my_docs = 0, my_probes = 0;
+    for (uint32_t b = bfirst; b < bend; ++b) {
+        const uint32_t s0 = seg.bstart[b], n = seg.bstart[b + 1] - s0;
+        const uint32_t hmin = (uint32_t)(seg.items[s0] >> 32), hmax = seg.block_index[b];
+        const bool has_prev = b != 0u;
+        const uint32_t hprev = has_prev ? seg.block_index[b - 1] : 0u;           // hashes <= hprev start in an earlier block
+        const bool last_block = b + 1u == seg.num_blocks;
+        __syncthreads();                                                         // the previous block's items are done with
+        for (uint32_t i = tid; i < n; i += WG) blk_items[i] = seg.items[s0 + i];
+        if (tid < 2u) {
+            // pairs are sorted by bucket = hash >> KEY_SORT_SKIP: [first pair of the bucket of hprev, first pair after the
+            // bucket of hmax); the last block also takes the pairs above every block (they probe nothing but are counted).
+            // After the workgroup's first block the searches start from the previous slice (a few steps instead of 23).
+            const uint32_t want = tid == 0u ? (has_prev ? (hprev >> KEY_SORT_SKIP) : 0u) : (hmax >> KEY_SORT_SKIP);
+            uint64_t lo = 0, hi = P;
+            if (b != bfirst) {
+                // the previous block's slice ended at E = first pair after the bucket of hprev: this block's slice starts
+                // inside that bucket, a little before E, and ends somewhere after E
+                const uint64_t E = prange[1];
+                auto bucket_at = [&](uint64_t i) { return (uint32_t)(pairs[i] >> qb) >> KEY_SORT_SKIP; };
+                if (tid == 0u) {
+                    hi = E;
+                    lo = E > 4096 ? E - 4096 : 0;
+                    if (lo != 0 && bucket_at(lo - 1) >= want) lo = 0;              // (a bucket with > 4096 pairs)
+                } else {
+                    lo = E;
+                    if (E + 65536 < P && bucket_at(E + 65536) > want) hi = E + 65536;
+                }
+            }
+            if (tid == 1u && last_block) lo = hi = P;
+            while (lo < hi) {
+                const uint64_t m = (lo + hi) >> 1;
+                const uint32_t bk = (uint32_t)(pairs[m] >> qb) >> KEY_SORT_SKIP;
+                if (tid == 0u ? bk < want : bk <= want) lo = m + 1; else hi = m;
+            }
+            prange[tid] = lo;
+        }
+        __syncthreads();
+        for (uint64_t p = prange[0] + tid; p < prange[1]; p += WG) {
+            const uint64_t key = pairs[p];
+            const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
+            if ((has_prev && h <= hprev) || (!last_block && h > hmax)) continue;   // edges of the boundary buckets
+            if (seg.own_flags != 0u && !owned_hash(seg, h)) continue;
+            if (is_duplicate_pair(pairs, p, key, qb)) continue;
+            my_probes += 1;
+            if (h > hmax || h < hmin) continue;                                    // above every block / in the gap before this one
+            // equal range of h among the staged items
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint32_t)(blk_items[m] >> 32) < h) lo = m + 1; else hi = m; }
+            uint32_t nb = 1, nd = 0;
+            for (uint32_t i = lo; i < n && (uint32_t)(blk_items[i] >> 32) == h; ++i) {
+                ++nd;
+                const uint32_t d = (uint32_t)blk_items[i];
+                if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
+                const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull); // hits in a small segment are rare
+                if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+            }
+            // the walk goes on while the next block starts with h (:164), up to 4 blocks / past 1000 docs (:172-173)
+            for (uint32_t nbk = b + 1u; nb < (uint32_t)MAX_BLOCKS_PER_HASH && nd <= (uint32_t)MAX_DOCS_PER_HASH && nbk < seg.num_blocks; ++nbk) {
+                const uint32_t s1 = seg.bstart[nbk], e1 = seg.bstart[nbk + 1];
+                if ((uint32_t)(seg.items[s1] >> 32) != h) break;
+                ++nb;
+                for (uint32_t i = s1; i < e1; ++i) {
+                    const uint64_t it = seg.items[i];
+                    if ((uint32_t)(it >> 32) != h) break;
+                    ++nd;
+                    const uint32_t d = (uint32_t)it;
+                    if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
+                    const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+                    if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+                }
+            }
+            my_blocks += nb; my_docs += nd;
+        }
+    }
+    if (my_probes) atomicAdd(&wg_probes, my_probes);
+    if (my_blocks) atomicAdd(&wg_blocks, my_blocks);
+    if (my_docs) atomicAdd(&wg_docs, my_docs);
+    __syncthreads();
+    if (tid == 0) {
+        if (wg_probes) atomicAdd(&counters[CTR_PROBES], wg_probes);
+        if (wg_blocks) { atomicAdd(&counters[CTR_BLOCKS], wg_blocks); atomicAdd(&counters[CTR_BYTES], wg_blocks * seg.block_size); }
+        if (wg_docs) atomicAdd(&counters[CTR_DOCS], wg_docs);
+    }
+}
+
+// The same probes from the other side, for big batches: a memory segment holds at most ~10^5 items, a batch millions
+// of pairs, so one thread per ITEM looks its hash up in the (bucket-sorted) pairs -- 60x fewer searches than one thread
+// per (pair, segment).  The pairs of a bucket (top 32 - KEY_SORT_SKIP hash bits) are contiguous but unordered inside it.
+__global__ __launch_bounds__(WG) void k_probe_mem_items(const MemDesc* mems, const uint64_t* __restrict__ pairs, uint64_t P,
+                                                         uint32_t qb, uint64_t* hits, uint64_t hit_cap,
+                                                         unsigned long long* counters)
+{
+    const MemDesc ms = mems[blockIdx.y];
+    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < ms.num_items; i += (uint64_t)gridDim.x * WG) {
+        const uint64_t it = ms.items[i];
+        const uint32_t h = (uint32_t)(it >> 32), d = (uint32_t)it;
+        const uint32_t bucket = h >> KEY_SORT_SKIP;
+        uint64_t lo = 0, hi = P;
+        while (lo < hi) {                                        // first pair of the item's bucket
+            const uint64_t m = (lo + hi) >> 1;
+            if (((uint32_t)(pairs[m] >> qb) >> KEY_SORT_SKIP) < bucket) lo = m + 1; else hi = m;
+        }
+        bool dead_known = false, dead = false;
+        for (uint64_t p = lo; p < P; ++p) {
+            const uint64_t key = pairs[p];
+            const uint32_t ph = (uint32_t)(key >> qb);
+            if ((ph >> KEY_SORT_SKIP) != bucket) break;
+            if (ph != h || is_duplicate_pair(pairs, p, key, qb)) continue;
+            if (!dead_known) { dead = is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, d); dead_known = true; }
+            if (dead) break;
+            const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+            if (g < hit_cap) hits[g] = ((uint64_t)((uint32_t)key & qmask) << 32) | d;
+        }
+    }
+}
+
+}  // namespace fpx

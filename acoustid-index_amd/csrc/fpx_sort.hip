@@ -11,7 +11,12 @@ namespace fpx {
 // rocPRIM switches to a merge sort (dozens of small launches) below 2^20 keys by default; the batch pipeline sorts
 // 10^5..10^6 keys per stage at small batch sizes, where the Onesweep radix sort (one histogram + one launch per 8 bits)
 // is several times faster.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
+// rocPRIM 4.2 carries no tuned Onesweep configuration for gfx950 (it falls back to 512 threads x 12 keys); measured on the
+// batch's two big sorts (8.2 M pair keys, 51 M hit records): 1024 x 8 is 7 % faster than that, 512 x 8 / 256 x 16 /
+// 1024 x 6 are 15 - 35 % slower.
+using OnesweepConfig = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8,
+                                                           rocprim::block_radix_rank_algorithm::match>;
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, OnesweepConfig, 16384>;
 
 size_t sort_u64_temp_bytes(size_t n, unsigned begin_bit, unsigned end_bit)
 {

@@ -97,12 +97,14 @@ __device__ __forceinline__ uint32_t lookup_block(const SegDesc& s, uint32_t h)
 // hashes_base[i] is the hash at ABSOLUTE position i of the batch; the view starts at absolute position `base`
 __global__ void k_make_keys(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
                             uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,
-                            unsigned long long* zero_counters = nullptr)
+                            unsigned long long* zero_counters = nullptr, unsigned int* zero_u32 = nullptr, uint32_t zero_n = 0)
 {
     // one workgroup per query
     uint32_t q = blockIdx.x;
     if (q >= B) return;
     if (zero_counters && q == 0 && threadIdx.x < CTR_COUNT) zero_counters[threadIdx.x] = 0ull;   // single-query path: saves a memset call
+    if (zero_u32 && q == 0)                                                                        // the lean kernel's deferred-list counts
+        for (uint32_t i = threadIdx.x; i < zero_n; i += blockDim.x) zero_u32[i] = 0u;
     uint64_t lo = offsets[q], hi = offsets[q + 1];
     for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
         keys[i - base] = ((uint64_t)hashes_base[i] << qb) | q;

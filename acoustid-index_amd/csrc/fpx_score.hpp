@@ -15,10 +15,12 @@ namespace fpx {
 // ------------------------------------------------------------------------------------------------
 // hit records sorted by q (stable radix partition on the query bits): [begin, end) of each query's records, found by
 // two binary searches per query (a pass over all H records costs 10x more at 66 M records)
-__global__ __launch_bounds__(WG) void k_bounds(const uint64_t* __restrict__ hits, uint64_t H, uint32_t B, uint64_t* __restrict__ qrange)
+__global__ __launch_bounds__(WG) void k_bounds(const uint64_t* __restrict__ hits, uint64_t H, uint32_t B, uint64_t* __restrict__ qrange,
+                                                uint32_t* __restrict__ zero_n = nullptr)
 {
     const uint32_t q = blockIdx.x * WG + threadIdx.x;
     if (q >= B) return;
+    if (zero_n) zero_n[q] = 0u;                              // k_score's per-query slot counts (saves a memset launch)
     uint64_t lo = 0, hi = H;
     while (lo < hi) {                                        // first record with query >= q
         const uint64_t m = (lo + hi) >> 1;

@@ -253,13 +253,27 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         d_offsets = ws->d_offsets;
         d_opts = ws->d_opts;
     }
-    if (!single_fast) FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+    // deferred-probe lists of the lean kernel: room for 1/8 of the pairs per segment (typically < 2 % are deferred)
+    const size_t def_cap = std::max<size_t>(4096, (size_t)(P / 8));
+    if (snap->n_lean) {
+        const size_t need = def_cap * snap->n_lean;
+        if ((rc = grow(&ws->d_def_list, &ws->cap_def, need))) return rc;
+        if (snap->n_lean > ws->cap_def_segs) {
+            if (ws->d_def_count) (void)hipFree(ws->d_def_count);
+            if (ws->h_def_count) (void)hipHostFree(ws->h_def_count);
+            ws->d_def_count = nullptr; ws->h_def_count = nullptr; ws->cap_def_segs = 0;
+            FPX_HIP(hipMalloc(&ws->d_def_count, snap->n_lean * sizeof(unsigned int)));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), snap->n_lean * sizeof(unsigned int)));
+            ws->cap_def_segs = snap->n_lean;
+        }
+    }
+    // (every memset is a 5-us launch of its own: the batch's zeroing rides in kernels that run anyway where it can)
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
     if (P && !score_only) {
         hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
-                           single_fast ? ws->d_counters : nullptr);
+                           single_fast ? ws->d_counters : nullptr, snap->n_lean ? ws->d_def_count : nullptr, snap->n_lean);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
         // ... and only the top 32 - KEY_SORT_SKIP of them: block-level locality is all the probes need from the order
@@ -277,20 +291,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     if (ws->cap_hits == 0) {
         size_t want = std::max<size_t>(1u << 20, (size_t)P * std::max<uint32_t>(1u, snap->n_file + snap->n_mem));
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, want))) return rc;
-    }
-    // deferred-probe lists of the lean kernel: room for 1/8 of the pairs per segment (typically < 2 % are deferred)
-    const size_t def_cap = std::max<size_t>(4096, (size_t)(P / 8));
-    if (snap->n_lean) {
-        const size_t need = def_cap * snap->n_lean;
-        if ((rc = grow(&ws->d_def_list, &ws->cap_def, need))) return rc;
-        if (snap->n_lean > ws->cap_def_segs) {
-            if (ws->d_def_count) (void)hipFree(ws->d_def_count);
-            if (ws->h_def_count) (void)hipHostFree(ws->h_def_count);
-            ws->d_def_count = nullptr; ws->h_def_count = nullptr; ws->cap_def_segs = 0;
-            FPX_HIP(hipMalloc(&ws->d_def_count, snap->n_lean * sizeof(unsigned int)));
-            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), snap->n_lean * sizeof(unsigned int)));
-            ws->cap_def_segs = snap->n_lean;
-        }
     }
     bool force_generic = false, used_lean = false;
     for (int attempt = 0;; ++attempt) {
@@ -317,7 +317,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (lean) {
                 if (snap->n_lean) {
                     // main kernel: k_probe_lean8 over the dense 512-B segments
-                    FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));
+                    if (attempt > 0) FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));   // (else: k_make_keys)
                     ProbeArgs l = a;
                     static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 2u; }();
                     l.segs = snap->d_lean; l.rounds = (P >= (1ull << 22)) ? lean_rounds : 1u; l.ctr_off = 8u;
@@ -511,7 +511,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_hits[0], ws->d_hits[1], H, 32, 32 + qb, st, &hcur));
             if (hcur != 0) std::swap(ws->d_hits[0], ws->d_hits[1]);   // convention: d_hits[0] holds the data
         }
-        hipLaunchKernelGGL(k_bounds, dim3((B + WG - 1) / WG), dim3(WG), 0, st, (const uint64_t*)ws->d_hits[0], H, B, ws->d_qrange);
+        // per-query candidate slots: [B][QCAND_SLOTS] keys, then [B] counts; then the list of heavy queries [B]
+        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1)))) return rc;
+        d_qcand = ws->d_qcand;
+        d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
+        hipLaunchKernelGGL(k_bounds, dim3((B + WG - 1) / WG), dim3(WG), 0, st, (const uint64_t*)ws->d_hits[0], H, B, ws->d_qrange, d_qcand_n);
         // counting filter sized for ~2x the average number of records per query (8 KB .. 64 KB of LDS) + 16 KB exact table
         // The filter only has to keep cells that collect < min_score records below the floor: with the usual floor
         // (n / 20 = 50 for 1 k-hash queries) a cell may hold several docs' records and still reject them, so a quarter of
@@ -536,17 +540,15 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)};
         (void)lds_attrs;
         const bool short_queries = H / B <= (uint64_t)WG * 8u;      // the average query fits one 8-row tile
-        // per-query candidate slots: [B][QCAND_SLOTS] keys, then [B] counts; then the list of heavy queries [B]
-        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1)))) return rc;
-        d_qcand = ws->d_qcand;
-        d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
         uint32_t* d_heavy = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS + (size_t)B / 2 + 1);
         const size_t score_lds = ((size_t)8 << log2t) + ((size_t)4 << log2f);
         for (int attempt = 0;; ++attempt) {
-            FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
-            FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
-            FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_HEAVY], 0, sizeof(unsigned long long), st));
-            FPX_HIP(hipMemsetAsync(d_qcand_n, 0, (size_t)B * sizeof(uint32_t), st));
+            if (attempt > 0) {                    // first attempt: the counters are still zero, k_bounds zeroed the slot counts
+                FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_CANDS], 0, sizeof(unsigned long long), st));
+                FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_MAXSCORE], 0, sizeof(unsigned long long), st));
+                FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_HEAVY], 0, sizeof(unsigned long long), st));
+                FPX_HIP(hipMemsetAsync(d_qcand_n, 0, (size_t)B * sizeof(uint32_t), st));
+            }
             if (short_queries)
                 hipLaunchKernelGGL((k_score<8, false>), dim3(B), dim3(WG), score_lds, st,
                                    (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,

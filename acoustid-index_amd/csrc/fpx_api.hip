@@ -109,6 +109,8 @@ static void segment_free(Segment* s)
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
+    if (s->d_present) (void)hipFree(s->d_present);
+    if (s->d_min_hash) (void)hipFree(s->d_min_hash);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
     if (s->d_items) (void)hipFree(s->d_items);
@@ -169,6 +171,7 @@ int finish_file_segment(Segment* s)
     FPX_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_total);
     s->num_items = total;
+    if ((rc = build_presence(s))) return rc;
     return decode_small_segment(s);
 }
 
@@ -489,6 +492,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.dead_bits = d_bits;
             d.items = s->d_small_items; d.bstart = s->d_bstart;
             d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
+            d.present = s->d_present; d.min_hash = s->d_min_hash;
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;

@@ -9,6 +9,7 @@
 // quad; entry[c+1] = exit[c] is iterated to its fixpoint.  Chains started at different quads merge only after
 // thousands of blocks on homogeneous data, so this takes ~100 cheap rounds per 1.6 G-item segment (and at most
 // #chunks rounds on degenerate data); the result is byte-identical to the sequential writer.
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 
@@ -359,6 +360,8 @@ static void free_partial_segment(Segment* s)
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
+    if (s->d_present) (void)hipFree(s->d_present);
+    if (s->d_min_hash) (void)hipFree(s->d_min_hash);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
     delete s;
@@ -601,6 +604,77 @@ int decode_small_segment(Segment* s)
                        s->num_items, s->d_bstart);
     FPX_HIP(hipGetLastError());
     FPX_HIP(hipStreamSynchronize(st));
+    return FPX_OK;
+}
+
+// Presence bitmap of a big segment: one wave per block decodes the block's hashes (the hash half of k_decode_items) and
+// sets bit h for each; the block's first hash goes to min_hash[b].
+__global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
+                                                       uint32_t* __restrict__ present, uint32_t* __restrict__ min_hash_out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= num_blocks) return;
+    const uint8_t* blk = blocks + b * (uint64_t)block_size;
+    const uint32_t min_hash = *reinterpret_cast<const uint32_t*>(blk);
+    const uint32_t n_items = *reinterpret_cast<const uint16_t*>(blk + 4);
+    const uint32_t nq = (n_items + 3u) >> 2;
+    if (lane == 0) min_hash_out[b] = min_hash;
+    uint32_t hcarry = 0, hbase = min_hash;
+    for (uint32_t c0 = 0; c0 < nq; c0 += 64u) {
+        const uint32_t qi = c0 + lane;
+        const bool act = qi < nq;
+        const uint32_t hc = act ? blk[min(8u + qi, block_size - 1u)] : 0u;
+        uint32_t hlen = 0;
+        for (uint32_t k = 0; k < 4; ++k) hlen += (1u << ((hc >> (2 * k)) & 3u)) >> 1;
+        const uint32_t hincl = scan64(hlen, lane);
+        uint32_t hp = 8u + nq + hcarry + hincl - hlen;
+        hcarry += __shfl(hincl, 63);
+        uint32_t h[4], qs = 0;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t nb = (1u << ((hc >> (2 * k)) & 3u)) >> 1;
+            uint32_t v = 0;
+            for (uint32_t j = 0; j < nb; ++j) v |= (uint32_t)blk[min(hp + j, block_size - 1u)] << (8 * j);
+            hp += nb;
+            qs += v;
+            h[k] = qs;
+        }
+        const uint32_t qincl = scan64(qs, lane);
+        const uint32_t base = hbase + qincl - qs;
+        hbase += __shfl(qincl, 63);
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = qi * 4u + k;
+            if (act && i < n_items) {
+                const uint32_t hv = h[k] + base;
+                // (equal neighbours set the same bit: skip the repeat inside the quad)
+                if (k == 0 || h[k] != h[k - 1]) atomicOr(&present[hv >> 5], 1u << (hv & 31u));
+            }
+        }
+    }
+}
+
+// big segments only: the bitmap costs 512 MB whatever the segment's size, so it must be small against the blocks
+static uint64_t presence_min_items()
+{
+    const char* e = getenv("FPX_PRESENCE_MIN_ITEMS");          // read per segment: the tests lower it
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 28);
+}
+
+int build_presence(Segment* s)
+{
+    if (s->block_size != 512 || s->num_blocks == 0 || s->num_items < presence_min_items()) return FPX_OK;
+    const size_t words = (size_t)1 << 27;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < words * 4 + ((size_t)8 << 30)) return FPX_OK;   // optional structure
+    if (hipMalloc(&s->d_present, words * sizeof(uint32_t)) != hipSuccess) { s->d_present = nullptr; (void)hipGetLastError(); return FPX_OK; }
+    if (hipMalloc(&s->d_min_hash, (size_t)s->num_blocks * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(s->d_present); s->d_present = nullptr; s->d_min_hash = nullptr; (void)hipGetLastError(); return FPX_OK;
+    }
+    FPX_HIP(hipMemsetAsync(s->d_present, 0, words * sizeof(uint32_t), 0));
+    hipLaunchKernelGGL(k_presence_bits, dim3((s->num_blocks + 3) / 4), dim3(256), 0, 0,
+                       s->d_blocks, s->block_size, s->num_blocks, s->d_present, s->d_min_hash);
+    FPX_HIP(hipGetLastError());
+    s->device_bytes += words * sizeof(uint32_t) + (size_t)s->num_blocks * sizeof(uint32_t);
     return FPX_OK;
 }
 

@@ -24,6 +24,11 @@ struct SegDesc {
     const uint32_t* dead;          // sorted ids of this segment's docs that a newer segment mentions
     const uint32_t* cont;          // bit b: block b+1 starts with block b's last hash (a run may continue there)
     const uint32_t* dead_bits;     // bitmap of `dead` over [shadow_lo, shadow_hi] (bit d - shadow_lo), or null when that range is too wide
+    // big segments (>= 2^28 items) also carry a PRESENCE bitmap over the whole 32-bit hash space (512 MB: bit h = some item
+    // of the segment has hash h) and each block's first hash: a probe whose hash is absent is answered -- and accounted for
+    // as the reference accounts for it (one visited block unless h falls in the gap before it) -- without reading the block
+    const uint32_t* present;       // 2^27 words, or null
+    const uint32_t* min_hash;      // [num_blocks] first hash of each block (the header field), with `present`
     // small segments (< 2^20 items) are also kept DECODED: sorted items + where each block starts among them
     const uint64_t* items;         // hash << 32 | doc, or null
     const uint32_t* bstart;        // [num_blocks + 1] item offset of each block
@@ -58,6 +63,7 @@ enum Counter : int {
     CTR_PROBES = 5,      // valid (unique hash, file segment) probes
     CTR_MAXSCORE = 6,
     CTR_GENERIC = 7,     // wave iterations of k_probe that took the generic (per-value) decode path    // largest score of any candidate (sizes the score field of the candidate key)
+    CTR_LEAN_READS = 8,  // blocks k_probe_lean8 fetched (probes whose hash the presence bitmap knows to be absent read none)
     CTR_HEAVY = 9,       // queries k_score handed to its CLASSED launch
     CTR_SLOTCANDS = 14,  // candidates handed from k_score to k_finish through the queries' own slots (statistics)
     CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
@@ -94,6 +100,7 @@ struct Segment {
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
+    uint32_t* d_present = nullptr; uint32_t* d_min_hash = nullptr;     // presence bitmap + block min hashes (see SegDesc), big segments only
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment
@@ -220,6 +227,7 @@ int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num
 int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool sorted, uint32_t block_size,
                        uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, Segment* s);
 int decode_small_segment(Segment* s);     // fills d_small_items / d_bstart of a resident file segment
+int build_presence(Segment* s);           // fills d_present / d_min_hash of a big resident file segment
 struct MergeSource { const Segment* seg; std::vector<uint32_t> dead; };   // dead = skip_docs, sorted
 int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_t block_size, uint32_t min_doc_id, Segment* s);
 

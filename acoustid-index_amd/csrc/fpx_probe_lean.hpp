@@ -123,7 +123,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
     __shared__ uint32_t def_stage[DEF_STAGE_CAP];
     __shared__ uint32_t def_n, def_base;
-    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 3, l = lane & 7u;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
     if (tid < 256u) init_lean_lut(lut, tid);
     if (tid == 0) {
         stage_count = 0; stage_valid = STAGE_CAP; def_n = 0;
-        wg_blocks = 0; wg_docs = 0; wg_probes = 0;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
     }
     __syncthreads();
 
@@ -164,14 +164,16 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             h[j] = (uint32_t)(key >> a.qb);
             q[j] = (uint32_t)key & qmask;
             lo[j] = 0; hi[j] = 0;
+            uint32_t pbit = 1u;
             if (seg.own_flags != 0u && !owned_hash(seg, h[j])) valid = false;      // another slice of the segment probes h
             if (valid) {
                 my_probes += 1;
                 const uint32_t kb = seg.bucket_shift >= 32u ? 0u : (h[j] >> seg.bucket_shift);
                 lo[j] = gload_u32(seg.bucket + kb);
                 hi[j] = gload_u32(seg.bucket + kb + 1);
+                if (seg.present) pbit = (gload_u32(seg.present + (h[j] >> 5)) >> (h[j] & 31u)) & 1u;   // sorted hashes: the bitmap is read as a stream
             }
-            b0v[j] = valid ? 1u : 0u;
+            b0v[j] = valid ? (1u | (pbit << 1)) : 0u;                          // bit 1: some item of the segment has this hash
             any_open = any_open || lo[j] < hi[j];
         }
         while (__any((int)any_open)) {                                         // src/FileSegment.zig:145-151
@@ -191,15 +193,57 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
         uint32_t cw[LEAN_KPL];
 #pragma unroll
         for (int j = 0; j < LEAN_KPL; ++j) {
-            const bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
+            bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
+            if (valid && (b0v[j] & 2u) == 0u) {
+                // no item of the segment has this hash: FileSegment.search would visit block lo (unless h lies in the gap
+                // before it, src/FileSegment.zig:164), find nothing and stop -- counted here, the block stays unread
+                if (gload_u32(seg.min_hash + lo[j]) <= h[j]) my_blocks += 1;
+                valid = false;
+            }
             cw[j] = valid ? gload_u32(seg.cont + (lo[j] >> 5)) : 0u;           // may the hash's run continue in block lo + 1?
             b0v[j] = (lo[j] & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
         }
 #pragma unroll
         for (int j = 0; j < LEAN_KPL; ++j) b0v[j] |= ((cw[j] >> (lo[j] & 31u)) & 1u) << 30;   // bit 30: continuation possible
 
+        // ---- compaction: the surviving probes move to the front of the wave (entry i -> lane i & 63, slot i >> 6), so
+        //      that phase 2 runs ceil(S / 8) iterations instead of 32.  An entry carries its position among the wave's
+        //      pairs in bits 24..31 of q (the lean path requires qb <= 24): the deferred list wants the pair index.
+        //      Scratch: the wave's block slots (8 x 528 B >= 256 entries x 12 B), free until phase 2 stages blocks.
+        uint32_t S = 0;
+        {
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(blkmem + (size_t)(wave * 8u) * L8_SLOT);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int j = 0; j < LEAN_KPL; ++j) {
+                const bool keep = (b0v[j] >> 31) != 0u;
+                const unsigned long long m = __ballot((int)keep);
+                if (keep) {
+                    const uint32_t pos = S + (uint32_t)__popcll(m & lt);
+                    scratch[3u * pos] = h[j];
+                    scratch[3u * pos + 1u] = q[j] | (((uint32_t)j * 64u + lane) << 24);
+                    scratch[3u * pos + 2u] = b0v[j];
+                }
+                S += (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < LEAN_KPL; ++j) {
+                const uint32_t i = (uint32_t)j * 64u + lane;
+                const bool have = i < S;
+                h[j] = have ? scratch[3u * i] : 0u;
+                q[j] = have ? scratch[3u * i + 1u] : 0u;
+                b0v[j] = have ? scratch[3u * i + 2u] : 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        if (lane == 0 && S != 0u) atomicAdd(&wg_reads, (unsigned long long)S);      // blocks this kernel really fetches
+
         // ---- phase 2: eight probes per iteration, one per 8-lane group, blocks prefetched one iteration ahead
-        constexpr uint32_t iters = 8u * LEAN_KPL;
+        const uint32_t iters = (S + 7u) >> 3;
         uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
         {
             const uint32_t nb = __shfl(b0v[0], (int)g);
@@ -216,7 +260,8 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
 #pragma unroll
             for (int jj = 1; jj < LEAN_KPL; ++jj) { if (j == (uint32_t)jj) { hj = h[jj]; qj = q[jj]; bj = b0v[jj]; } }
             const uint32_t ph = __shfl(hj, src);
-            const uint32_t pq = __shfl(qj, src);
+            const uint32_t pqx = __shfl(qj, src);
+            const uint32_t pq = pqx & 0x00FFFFFFu;                              // bits 24..31: the pair's position in the wave
             const uint32_t pbv = __shfl(bj, src);
             const bool pact = (pbv >> 31) != 0u;
             *reinterpret_cast<uint4*>(blk + l * 16u) = pre0;
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                     // bit 31 tags the rows that will bring many docs (a block of > 128 items, a run over 3+ quads, or 3+ docs
                     // already and more in the next block): the deferred pass counts those before it writes them
                     const bool long_run = (nq > 32u) | (ncand >= 3u) | (cnt >= 3u);
-                    const uint32_t pair = (wave_pair0 + j * 64u + (it & 7u) * 8u + g) | (long_run ? 0x80000000u : 0u);
+                    const uint32_t pair = (wave_pair0 + (pqx >> 24)) | (long_run ? 0x80000000u : 0u);
                     const uint32_t slot = atomicAdd(&def_n, 1u);
                     if (slot < (uint32_t)DEF_STAGE_CAP) {
                         def_stage[slot] = pair;
@@ -400,6 +445,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
     if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
     __syncthreads();
     if (tid == 0) {
+        if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);
         if (wg_blocks) {
             atomicAdd(&a.counters[a.ctr_off + CTR_BLOCKS], wg_blocks);
             atomicAdd(&a.counters[a.ctr_off + CTR_BYTES], wg_blocks * 512ull);

@@ -311,7 +311,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
             // big batches: every kind of file segment has its own kernel
-            const bool lean = (snap->n_lean != 0 || snap->n_small != 0) && !force_generic && P < 0x80000000ull &&   // pair indices + a tag bit in the deferred lists
+            const bool lean = (snap->n_lean != 0 || snap->n_small != 0) && !force_generic && P < 0x80000000ull && qb <= 24u &&   // pair indices + a tag bit in the deferred lists; 8 spare bits in q
                               total >= lean_min_probes();
             if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (lean) {

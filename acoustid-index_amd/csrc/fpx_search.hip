@@ -433,6 +433,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probe_launches += probe_launches;
             stats->generic_iters += (uint32_t)ws->h_counters[CTR_GENERIC];
             stats->probe_kernel_bytes += ws->h_counters[CTR_BYTES];
+            stats->probe_kernel_fetched_bytes += ws->h_counters[CTR_BYTES];
         }
         return FPX_OK;
     }
@@ -448,7 +449,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_bytes = ws->h_counters[CTR_BYTES] + ws->h_counters[8 + CTR_BYTES],
                              c_probes = ws->h_counters[CTR_PROBES] + ws->h_counters[8 + CTR_PROBES],
                              c_generic = ws->h_counters[CTR_GENERIC],
-                             c_main_bytes = (used_lean && snap->n_lean) ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES];
+                             c_main_bytes = (used_lean && snap->n_lean) ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES],
+                             c_fetched_bytes = (used_lean && snap->n_lean) ? ws->h_counters[CTR_LEAN_READS] * 512ull : ws->h_counters[CTR_BYTES];
 
     uint64_t C = 0, C_slots = 0;                   // candidates in the shared list / in the queries' own slots
     uint64_t* d_qcand = nullptr;
@@ -468,6 +470,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         stats->probe_launches += probe_launches;
         stats->generic_iters += (uint32_t)c_generic;
         stats->probe_kernel_bytes += c_main_bytes;
+        stats->probe_kernel_fetched_bytes += c_fetched_bytes;
         stats->probe_aux_ms += aux_ms;
     };
 
@@ -616,6 +619,7 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
     dst->hits += s.hits; dst->algorithmic_bytes += s.algorithmic_bytes; dst->candidates += s.candidates;
     dst->probe_kernel_ms += s.probe_kernel_ms; dst->total_gpu_ms += s.total_gpu_ms; dst->probe_launches += s.probe_launches; dst->generic_iters += s.generic_iters;
     dst->probe_kernel_bytes += s.probe_kernel_bytes; dst->probe_aux_ms += s.probe_aux_ms;
+    dst->probe_kernel_fetched_bytes += s.probe_kernel_fetched_bytes;
 }
 
 // one pass, or -- when (query index, score) do not fit the 64-bit candidate key -- two half batches

@@ -173,7 +173,7 @@ def main():
     out = np.zeros((B, cap, 2), np.uint32)
     out_n = np.zeros(B, np.uint32)
 
-    agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0, "main_bytes": 0, "aux_ms": 0.0,
+    agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0, "main_bytes": 0, "aux_ms": 0.0, "fetched": 0,
            "generic": 0}
 
     import concurrent.futures as cf
@@ -192,6 +192,7 @@ def main():
             agg["gpu_ms"] += st.total_gpu_ms
             agg["hits"] += st.hits
             agg["main_bytes"] += st.probe_kernel_bytes
+            agg["fetched"] += st.probe_kernel_fetched_bytes
             agg["aux_ms"] += st.probe_aux_ms
             agg["generic"] += st.generic_iters
 
@@ -257,6 +258,14 @@ def main():
         avg_ms = agg["probe_ms"] / launches
         bytes_per_launch = agg["main_bytes"] / launches       # blocks the main kernel visited itself
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # What the kernel must really move: the blocks of the probes whose hash the segment has (the presence bitmap answers
+        # the others) + the bitmaps themselves, which a batch of this size reads end to end (sorted hashes).
+        fetched_per_launch = agg["fetched"] / launches
+        pmin = int(os.environ.get("FPX_PRESENCE_MIN_ITEMS", 1 << 28))
+        n_bitmaps = sum(1 for sg in segs if sg.kind == "file" and sg.getSize() >= pmin) if fetched_per_launch < bytes_per_launch else 0
+        bitmap_bytes = n_bitmaps * (1 << 29)
+        moved = fetched_per_launch + bitmap_bytes
+        moved_gbs = moved / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc FETCH_SIZE pass (tools/pmc_traffic.sh),
         # stored with its calibration under profiles/; it is reported only for the configuration it was measured on
         traffic = None
@@ -281,6 +290,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean8", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                         "note": "achieved = SURVEY 8(d)'s algorithmic bytes (512 B per block the reference visits) / kernel time; "
+                                 "above 1.0 of the peak because the presence bitmaps answer the probes of absent hashes without "
+                                 "fetching their blocks -- `moved` is what the kernel has to read instead, `traffic` what the PMC saw",
+                         "moved": {"block_bytes_per_launch": fetched_per_launch, "presence_bitmap_bytes_per_launch": bitmap_bytes,
+                                   "achieved": moved_gbs, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS},
                          "all_probe_passes": {"algorithmic_bytes_per_step": agg["bytes"] / max(1, args.steps),
                                               "ms_per_step": (agg["probe_ms"] + agg["aux_ms"]) / max(1, args.steps),
                                               "visited_blocks_per_step": agg["blocks"] / max(1, args.steps),
@@ -296,8 +310,10 @@ def main():
             result["measured_bandwidth"] = {"stream_read_GBs": s_gbs, "random_512B_read_GBs": r_gbs}
             # second denominator: what this box sustains for the kernel's own access pattern
             result["roofline"]["peak_measured_random_512B"] = r_gbs
+            result["roofline"]["peak_measured_stream"] = s_gbs
             if traffic:
-                result["roofline"]["hbm_read_frac_of_measured"] = traffic / (agg["probe_ms"] / max(1, agg["launches"]) * 1e-3) / 1e9 / r_gbs
+                # the kernel's reads are a mix now: random 512-B blocks + the streamed bitmaps
+                result["roofline"]["hbm_read_GBs"] = traffic / (agg["probe_ms"] / max(1, agg["launches"]) * 1e-3) / 1e9
 
     # ---- p50 latency of a single /_search (batch of 1), rank-local index share only when sharded
     if rank == 0 and world == 1 and not args.no_latency:

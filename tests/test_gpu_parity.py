@@ -200,12 +200,17 @@ def test_cpp_host_mirror_example(env):
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
 
 
+@pytest.mark.parametrize("presence", [False, True])
 @pytest.mark.parametrize("dist", [0, 1])
-def test_lean_kernel_and_deferred_pass(env, dist):
+def test_lean_kernel_and_deferred_pass(env, dist, presence, monkeypatch):
     """Batches with >= 2^20 probes on 512-B segments run k_probe_lean8 (two-level match) and finish the rows it
     cannot handle (wide deltas, runs crossing quads/blocks, > 32 quads) with the deferred generic pass.
-    dist = 1 (hot pool) makes a large share of the probes take the deferred pass."""
+    dist = 1 (hot pool) makes a large share of the probes take the deferred pass.
+    presence: the segments carry the presence bitmap that only segments of >= 2^28 items get by default -- probes of
+    absent hashes are answered (and counted as the reference counts them) without their block being fetched."""
     fpx, oracle, Pair, ctx = env
+    if presence:
+        monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1")
     seed, H, per, S = 91 + dist, 128, 9000, 3          # 1.15 M items per segment: 2-byte hash deltas, lean-eligible
     p = Pair(ctx)
     for s in range(S):
@@ -218,6 +223,10 @@ def test_lean_kernel_and_deferred_pass(env, dist):
     got, st = p.check(qs, fpx.http_options())
     assert st.probes >= (1 << 20) - 4096
     assert 0 < st.probe_kernel_bytes <= st.algorithmic_bytes                            # the lean kernel worked ...
+    if presence:
+        assert st.probe_kernel_fetched_bytes < st.probe_kernel_bytes // 2               # 1.15 M items: most query hashes are absent
+    else:
+        assert st.probe_kernel_fetched_bytes >= st.probe_kernel_bytes                   # every visited block was read (+ gaps)
     if dist == 1:
         assert st.probe_kernel_bytes < st.algorithmic_bytes                             # ... and so did the deferred pass
     if dist == 0:
@@ -279,11 +288,14 @@ def test_cpp_request_coalescer(env):
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("presence", [False, True])
 @pytest.mark.parametrize("dist", [0, 1])
-def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env, dist):
+def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env, dist, presence, monkeypatch):
     """The lean path on segments whose docs are partly superseded (per-posting `dead` filter), with a segment of sparse
     ids (docid deltas of 3 and 4 bytes, ids above 2^24), tombstones and inserts in memory segments on top."""
     fpx, oracle, Pair, ctx = env
+    if presence:
+        monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1")
     seed, H, per = 733, 128, 9000                      # 1.15 M items per file segment: lean-eligible
     p = Pair(ctx)
     # dist = 1: hot hashes with ~1000 docs per probe overflow the workgroups' hit staging, so superseded docs are dropped both

@@ -492,7 +492,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.dead_bits = d_bits;
             d.items = s->d_small_items; d.bstart = s->d_bstart;
             d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
-            d.present = s->d_present; d.min_hash = s->d_min_hash;
+            d.present = s->d_present; d.min_hash = s->d_min_hash; d.present_shift = s->present_shift;
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;

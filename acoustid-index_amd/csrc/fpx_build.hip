@@ -610,7 +610,7 @@ int decode_small_segment(Segment* s)
 // Presence bitmap of a big segment: one wave per block decodes the block's hashes (the hash half of k_decode_items) and
 // sets bit h for each; the block's first hash goes to min_hash[b].
 __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
-                                                       uint32_t* __restrict__ present, uint32_t* __restrict__ min_hash_out)
+                                                       uint32_t* __restrict__ present, uint32_t* __restrict__ min_hash_out, uint32_t shift)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t i = qi * 4u + k;
             if (act && i < n_items) {
-                const uint32_t hv = h[k] + base;
+                const uint32_t hv = (h[k] + base) >> shift;
                 // (equal neighbours set the same bit: skip the repeat inside the quad)
                 if (k == 0 || h[k] != h[k - 1]) atomicOr(&present[hv >> 5], 1u << (hv & 31u));
             }
@@ -653,17 +653,22 @@ __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict
     }
 }
 
-// big segments only: the bitmap costs 512 MB whatever the segment's size, so it must be small against the blocks
+// the segments the lean kernel takes (smaller ones are kept decoded and probed block-wise, where a bitmap buys nothing)
 static uint64_t presence_min_items()
 {
-    const char* e = getenv("FPX_PRESENCE_MIN_ITEMS");          // read per segment: the tests lower it
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 28);
+    const char* e = getenv("FPX_PRESENCE_MIN_ITEMS");          // read per segment: the tests move it
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 20);
 }
 
 int build_presence(Segment* s)
 {
     if (s->block_size != 512 || s->num_blocks == 0 || s->num_items < presence_min_items()) return FPX_OK;
-    const size_t words = (size_t)1 << 27;
+    // one bit per 2^shift hash values, the largest shift that leaves the bitmap >= 5.7 bits per item (<= 16 % of them set,
+    // 16 % on top of the blocks' bytes); a segment of more than 2^32 / 5.7 items gets shift 0 (1.6 G items: 31 % set, 7 %)
+    uint32_t shift = 0;
+    while (shift < 22u && ((1ull << (31u - shift)) * 7ull) >= s->num_items * 40ull) ++shift;      // 2^(32-(shift+1)) >= 5.7 n
+    s->present_shift = shift;
+    const size_t words = (size_t)1 << (27u - shift);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < words * 4 + ((size_t)8 << 30)) return FPX_OK;   // optional structure
     if (hipMalloc(&s->d_present, words * sizeof(uint32_t)) != hipSuccess) { s->d_present = nullptr; (void)hipGetLastError(); return FPX_OK; }
@@ -672,7 +677,7 @@ int build_presence(Segment* s)
     }
     FPX_HIP(hipMemsetAsync(s->d_present, 0, words * sizeof(uint32_t), 0));
     hipLaunchKernelGGL(k_presence_bits, dim3((s->num_blocks + 3) / 4), dim3(256), 0, 0,
-                       s->d_blocks, s->block_size, s->num_blocks, s->d_present, s->d_min_hash);
+                       s->d_blocks, s->block_size, s->num_blocks, s->d_present, s->d_min_hash, shift);
     FPX_HIP(hipGetLastError());
     s->device_bytes += words * sizeof(uint32_t) + (size_t)s->num_blocks * sizeof(uint32_t);
     return FPX_OK;

@@ -24,10 +24,12 @@ struct SegDesc {
     const uint32_t* dead;          // sorted ids of this segment's docs that a newer segment mentions
     const uint32_t* cont;          // bit b: block b+1 starts with block b's last hash (a run may continue there)
     const uint32_t* dead_bits;     // bitmap of `dead` over [shadow_lo, shadow_hi] (bit d - shadow_lo), or null when that range is too wide
-    // big segments (>= 2^28 items) also carry a PRESENCE bitmap over the whole 32-bit hash space (512 MB: bit h = some item
-    // of the segment has hash h) and each block's first hash: a probe whose hash is absent is answered -- and accounted for
-    // as the reference accounts for it (one visited block unless h falls in the gap before it) -- without reading the block
-    const uint32_t* present;       // 2^27 words, or null
+    // segments of >= 2^20 items also carry a PRESENCE bitmap over the hash space (bit h >> present_shift = some item of the
+    // segment has a hash in that bucket of 2^present_shift values; the shift keeps <= 16 % of the bits set where the hash
+    // space allows -- 0.7 byte per item -- and is 0 beyond 750 M items: 512 MB, 31 % set at 1.6 G) and each block's first hash: a probe whose bit is clear is answered -- and
+    // accounted for as the reference accounts for it (one visited block unless h falls in the gap before it) -- without
+    // reading the block
+    const uint32_t* present;       // 2^(27 - present_shift) words, or null
     const uint32_t* min_hash;      // [num_blocks] first hash of each block (the header field), with `present`
     // small segments (< 2^20 items) are also kept DECODED: sorted items + where each block starts among them
     const uint64_t* items;         // hash << 32 | doc, or null
@@ -41,6 +43,7 @@ struct SegDesc {
     // hash-range slice of a segment (second mode): only hashes in (own_lo, own_hi] are probed here
     uint32_t own_flags;            // bit 0: own_lo is set, bit 1: own_hi is set
     uint32_t own_lo, own_hi;
+    uint32_t present_shift;
 };
 
 // One resident memory segment (src/MemorySegment.zig:27-28).
@@ -100,7 +103,7 @@ struct Segment {
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
-    uint32_t* d_present = nullptr; uint32_t* d_min_hash = nullptr;     // presence bitmap + block min hashes (see SegDesc), big segments only
+    uint32_t* d_present = nullptr; uint32_t* d_min_hash = nullptr; uint32_t present_shift = 0;   // presence bitmap + block min hashes (see SegDesc)
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment

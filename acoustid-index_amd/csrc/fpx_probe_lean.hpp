@@ -171,7 +171,10 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                 const uint32_t kb = seg.bucket_shift >= 32u ? 0u : (h[j] >> seg.bucket_shift);
                 lo[j] = gload_u32(seg.bucket + kb);
                 hi[j] = gload_u32(seg.bucket + kb + 1);
-                if (seg.present) pbit = (gload_u32(seg.present + (h[j] >> 5)) >> (h[j] & 31u)) & 1u;   // sorted hashes: the bitmap is read as a stream
+                if (seg.present) {                                                 // sorted hashes: the bitmap is read as a stream
+                    const uint32_t pi = h[j] >> seg.present_shift;
+                    pbit = (gload_u32(seg.present + (pi >> 5)) >> (pi & 31u)) & 1u;
+                }
             }
             b0v[j] = valid ? (1u | (pbit << 1)) : 0u;                          // bit 1: some item of the segment has this hash
             any_open = any_open || lo[j] < hi[j];

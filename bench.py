@@ -261,9 +261,15 @@ def main():
         # What the kernel must really move: the blocks of the probes whose hash the segment has (the presence bitmap answers
         # the others) + the bitmaps themselves, which a batch of this size reads end to end (sorted hashes).
         fetched_per_launch = agg["fetched"] / launches
-        pmin = int(os.environ.get("FPX_PRESENCE_MIN_ITEMS", 1 << 28))
-        n_bitmaps = sum(1 for sg in segs if sg.kind == "file" and sg.getSize() >= pmin) if fetched_per_launch < bytes_per_launch else 0
-        bitmap_bytes = n_bitmaps * (1 << 29)
+        pmin = int(os.environ.get("FPX_PRESENCE_MIN_ITEMS", 1 << 20))
+
+        def bitmap_size(n_items):                  # as build_presence (csrc/fpx_build.hip): >= 5.7 bits per item
+            shift = 0
+            while shift < 22 and (1 << (31 - shift)) * 7 >= n_items * 40:
+                shift += 1
+            return (1 << (32 - shift)) // 8
+        bitmap_bytes = sum(bitmap_size(sg.getSize()) for sg in segs if sg.kind == "file" and sg.getSize() >= pmin) \
+            if fetched_per_launch < bytes_per_launch else 0
         moved = fetched_per_launch + bitmap_bytes
         moved_gbs = moved / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc FETCH_SIZE pass (tools/pmc_traffic.sh),

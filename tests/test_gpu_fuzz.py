@@ -114,10 +114,9 @@ def test_fuzz_small_worlds(env, seed):
 @pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_fuzz_lean_sized_worlds(env, seed, monkeypatch):
     """segments of > 2^20 items and batches of > 2^16 probes: the lean kernel + deferred pass carry these; every other
-    world gives its segments the presence bitmap that only segments of >= 2^28 items get by default"""
+    world runs without the segments' presence bitmaps"""
     fpx, oracle, Pair, ctx = env
-    if seed % 2:
-        monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1")
+    monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1" if seed % 2 else str(1 << 62))
     rng = np.random.default_rng(20_000 + seed)
     p, items, hash_bits, hot = random_world(fpx, Pair, ctx, rng, lean_sized=True)
     qs = random_queries(rng, items, hash_bits, hot, 80, 1000)

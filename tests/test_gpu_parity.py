@@ -206,11 +206,10 @@ def test_lean_kernel_and_deferred_pass(env, dist, presence, monkeypatch):
     """Batches with >= 2^20 probes on 512-B segments run k_probe_lean8 (two-level match) and finish the rows it
     cannot handle (wide deltas, runs crossing quads/blocks, > 32 quads) with the deferred generic pass.
     dist = 1 (hot pool) makes a large share of the probes take the deferred pass.
-    presence: the segments carry the presence bitmap that only segments of >= 2^28 items get by default -- probes of
+    presence: with / without the segments' presence bitmaps (default: on for segments of >= 2^20 items) -- probes of
     absent hashes are answered (and counted as the reference counts them) without their block being fetched."""
     fpx, oracle, Pair, ctx = env
-    if presence:
-        monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1")
+    monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1" if presence else str(1 << 62))
     seed, H, per, S = 91 + dist, 128, 9000, 3          # 1.15 M items per segment: 2-byte hash deltas, lean-eligible
     p = Pair(ctx)
     for s in range(S):
@@ -294,8 +293,7 @@ def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env, dist, pre
     """The lean path on segments whose docs are partly superseded (per-posting `dead` filter), with a segment of sparse
     ids (docid deltas of 3 and 4 bytes, ids above 2^24), tombstones and inserts in memory segments on top."""
     fpx, oracle, Pair, ctx = env
-    if presence:
-        monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1")
+    monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1" if presence else str(1 << 62))
     seed, H, per = 733, 128, 9000                      # 1.15 M items per file segment: lean-eligible
     p = Pair(ctx)
     # dist = 1: hot hashes with ~1000 docs per probe overflow the workgroups' hit staging, so superseded docs are dropped both

@@ -361,7 +361,7 @@ static void free_partial_segment(Segment* s)
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
     if (s->d_present) (void)hipFree(s->d_present);
-    if (s->d_min_hash) (void)hipFree(s->d_min_hash);
+    if (s->d_blockrec) (void)hipFree(s->d_blockrec);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
     delete s;
@@ -608,9 +608,9 @@ int decode_small_segment(Segment* s)
 }
 
 // Presence bitmap of a big segment: one wave per block decodes the block's hashes (the hash half of k_decode_items) and
-// sets bit h for each; the block's first hash goes to min_hash[b].
+// sets the bit of each.
 __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
-                                                       uint32_t* __restrict__ present, uint32_t* __restrict__ min_hash_out, uint32_t shift)
+                                                       uint32_t* __restrict__ present, uint32_t shift)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -619,7 +619,6 @@ __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict
     const uint32_t min_hash = *reinterpret_cast<const uint32_t*>(blk);
     const uint32_t n_items = *reinterpret_cast<const uint16_t*>(blk + 4);
     const uint32_t nq = (n_items + 3u) >> 2;
-    if (lane == 0) min_hash_out[b] = min_hash;
     uint32_t hcarry = 0, hbase = min_hash;
     for (uint32_t c0 = 0; c0 < nq; c0 += 64u) {
         const uint32_t qi = c0 + lane;
@@ -660,9 +659,24 @@ static uint64_t presence_min_items()
     return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 20);
 }
 
+// {block_index[b], header min_hash} per block, three all-ones sentinels behind
+__global__ void k_block_records(const uint8_t* __restrict__ blocks, const uint32_t* __restrict__ block_index, uint32_t num_blocks,
+                                uint2* __restrict__ rec)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < num_blocks) rec[b] = make_uint2(block_index[b], *reinterpret_cast<const uint32_t*>(blocks + (size_t)b * 512u));
+    else if (b < num_blocks + 3u) rec[b] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+}
+
 int build_presence(Segment* s)
 {
-    if (s->block_size != 512 || s->num_blocks == 0 || s->num_items < presence_min_items()) return FPX_OK;
+    if (s->block_size != 512 || s->num_blocks == 0 || s->num_items < (1ull << 20)) return FPX_OK;      // not a lean segment
+    FPX_HIP(hipMalloc(&s->d_blockrec, ((size_t)s->num_blocks + 3) * sizeof(uint2)));
+    s->device_bytes += ((size_t)s->num_blocks + 3) * sizeof(uint2);
+    hipLaunchKernelGGL(k_block_records, dim3((s->num_blocks + 3 + 255) / 256), dim3(256), 0, 0,
+                       s->d_blocks, s->d_block_index, s->num_blocks, s->d_blockrec);
+    FPX_HIP(hipGetLastError());
+    if (s->num_items < presence_min_items()) return FPX_OK;
     // one bit per 2^shift hash values, the largest shift that leaves the bitmap >= 5.7 bits per item (<= 16 % of them set,
     // 16 % on top of the blocks' bytes); a segment of more than 2^32 / 5.7 items gets shift 0 (1.6 G items: 31 % set, 7 %)
     uint32_t shift = 0;
@@ -672,14 +686,11 @@ int build_presence(Segment* s)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < words * 4 + ((size_t)8 << 30)) return FPX_OK;   // optional structure
     if (hipMalloc(&s->d_present, words * sizeof(uint32_t)) != hipSuccess) { s->d_present = nullptr; (void)hipGetLastError(); return FPX_OK; }
-    if (hipMalloc(&s->d_min_hash, (size_t)s->num_blocks * sizeof(uint32_t)) != hipSuccess) {
-        (void)hipFree(s->d_present); s->d_present = nullptr; s->d_min_hash = nullptr; (void)hipGetLastError(); return FPX_OK;
-    }
     FPX_HIP(hipMemsetAsync(s->d_present, 0, words * sizeof(uint32_t), 0));
     hipLaunchKernelGGL(k_presence_bits, dim3((s->num_blocks + 3) / 4), dim3(256), 0, 0,
-                       s->d_blocks, s->block_size, s->num_blocks, s->d_present, s->d_min_hash, shift);
+                       s->d_blocks, s->block_size, s->num_blocks, s->d_present, shift);
     FPX_HIP(hipGetLastError());
-    s->device_bytes += words * sizeof(uint32_t) + (size_t)s->num_blocks * sizeof(uint32_t);
+    s->device_bytes += words * sizeof(uint32_t);
     return FPX_OK;
 }
 

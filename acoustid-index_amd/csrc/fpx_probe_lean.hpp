@@ -179,35 +179,55 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             b0v[j] = valid ? (1u | (pbit << 1)) : 0u;                          // bit 1: some item of the segment has this hash
             any_open = any_open || lo[j] < hi[j];
         }
-        while (__any((int)any_open)) {                                         // src/FileSegment.zig:145-151
-            any_open = false;
-            uint32_t mid[LEAN_KPL], mv[LEAN_KPL];
+        // The bucket table leaves 0..1 candidates almost always (about one block per bucket): the records of blocks lo,
+        // lo + 1, lo + 2 -- max hash and first hash each -- settle the lower_bound (src/FileSegment.zig:145-151), the gap
+        // test and the continuation flag in ONE more level of dependent loads.  Buckets with more candidates (runs of
+        // narrow blocks: hot hashes) take the binary search first.
+        bool wide = false;
 #pragma unroll
-            for (int j = 0; j < LEAN_KPL; ++j) {
-                mid[j] = (lo[j] + hi[j]) >> 1;
-                mv[j] = lo[j] < hi[j] ? gload_u32(seg.block_index + mid[j]) : 0u;
-            }
+        for (int j = 0; j < LEAN_KPL; ++j) wide = wide || (hi[j] - lo[j] >= 2u && lo[j] < hi[j]);
+        if (__any((int)wide)) {
+            while (__any((int)any_open)) {
+                any_open = false;
+                uint32_t mid[LEAN_KPL], mv[LEAN_KPL];
 #pragma unroll
-            for (int j = 0; j < LEAN_KPL; ++j) {
-                if (lo[j] < hi[j]) { if (mv[j] < h[j]) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
-                any_open = any_open || lo[j] < hi[j];
+                for (int j = 0; j < LEAN_KPL; ++j) {
+                    mid[j] = (lo[j] + hi[j]) >> 1;
+                    mv[j] = lo[j] < hi[j] ? gload_u32(seg.block_index + mid[j]) : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < LEAN_KPL; ++j) {
+                    if (lo[j] < hi[j]) { if (mv[j] < h[j]) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
+                    any_open = any_open || lo[j] < hi[j];
+                }
             }
         }
-        uint32_t cw[LEAN_KPL];
+        uint2 ra[LEAN_KPL], rb[LEAN_KPL], rc[LEAN_KPL];
 #pragma unroll
         for (int j = 0; j < LEAN_KPL; ++j) {
-            bool valid = b0v[j] != 0u && lo[j] < seg.num_blocks;
-            if (valid && (b0v[j] & 2u) == 0u) {
-                // no item of the segment has this hash: FileSegment.search would visit block lo (unless h lies in the gap
-                // before it, src/FileSegment.zig:164), find nothing and stop -- counted here, the block stays unread
-                if (gload_u32(seg.min_hash + lo[j]) <= h[j]) my_blocks += 1;
-                valid = false;
-            }
-            cw[j] = valid ? gload_u32(seg.cont + (lo[j] >> 5)) : 0u;           // may the hash's run continue in block lo + 1?
-            b0v[j] = (lo[j] & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u);      // bit 31 carries `valid` through the row broadcast
+            const bool ld = b0v[j] != 0u && lo[j] < seg.num_blocks;               // (lo <= num_blocks: three sentinels follow)
+            const uint64_t* r = reinterpret_cast<const uint64_t*>(seg.blockrec) + lo[j];
+            const uint64_t a0 = ld ? gload_u64(r) : ~0ull, a1 = ld ? gload_u64(r + 1) : ~0ull, a2 = ld ? gload_u64(r + 2) : ~0ull;
+            ra[j] = make_uint2((uint32_t)a0, (uint32_t)(a0 >> 32));
+            rb[j] = make_uint2((uint32_t)a1, (uint32_t)(a1 >> 32));
+            rc[j] = make_uint2((uint32_t)a2, (uint32_t)(a2 >> 32));
         }
 #pragma unroll
-        for (int j = 0; j < LEAN_KPL; ++j) b0v[j] |= ((cw[j] >> (lo[j] & 31u)) & 1u) << 30;   // bit 30: continuation possible
+        for (int j = 0; j < LEAN_KPL; ++j) {
+            const bool step = lo[j] < hi[j] && ra[j].x < h[j];                    // the one candidate ends before h
+            const uint32_t b0 = lo[j] + (step ? 1u : 0u);
+            const uint2 cur = step ? rb[j] : ra[j], nxt = step ? rc[j] : rb[j];
+            bool valid = b0v[j] != 0u && b0 < seg.num_blocks;
+            if (valid && (b0v[j] & 2u) == 0u) {
+                // no item of the segment has this hash: FileSegment.search would visit block b0 (unless h lies in the gap
+                // before it, src/FileSegment.zig:164), find nothing and stop -- counted here, the block stays unread
+                if (cur.y <= h[j]) my_blocks += 1;
+                valid = false;
+            }
+            // may the hash's run continue in block b0 + 1?  (it starts with this block's last hash)
+            const bool cont = valid && b0 + 1u < seg.num_blocks && nxt.y == cur.x;
+            b0v[j] = (b0 & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u) | (cont ? 0x40000000u : 0u);   // bits 31 / 30 ride through the row broadcast
+        }
 
         // ---- compaction: the surviving probes move to the front of the wave (entry i -> lane i & 63, slot i >> 6), so
         //      that phase 2 runs ceil(S / 8) iterations instead of 32.  An entry carries its position among the wave's

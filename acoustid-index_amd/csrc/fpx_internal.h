@@ -57,6 +57,13 @@ struct MemDesc {
     uint32_t pad;
 };
 
+// k_probe_lean8 ends every workgroup with four statistics atomics.  Atomics on ONE cache line complete about every 12 ns
+// (83 M/s), so 64 k workgroups x 4 cost 3 ms of serialised L2 atomic time on a 5.6-ms kernel; they go to
+// LEAN_STAT_SETS copies of the slots on separate lines (workgroup i -> set i % LEAN_STAT_SETS), summed on the host.
+constexpr uint32_t LEAN_STAT_SETS = 64;
+constexpr uint32_t DEF_COUNT_STRIDE = 32;      // 32-bit words between the segments' deferred-list counts: a line each, for the same reason
+constexpr size_t LEAN_STAT_WORDS = (size_t)LEAN_STAT_SETS * 8 * 2;      // in 32-bit words (8 x u64 = one 64-B line per set)
+
 // per-batch counters living in device memory (one 64-bit word each)
 enum Counter : int {
     CTR_HITS = 0,        // hit records appended (may exceed capacity -> rerun with a larger buffer)

@@ -28,6 +28,7 @@ struct ProbeArgs {
     unsigned int* def_count;   // [n_file]
     uint32_t def_cap;
     uint32_t ctr_off;          // 0, or 8 for k_probe_lean8: which statistics slots of `counters` to use
+    unsigned long long* lean_stats;   // k_probe_lean8: [LEAN_STAT_SETS][8] {blocks fetched, visited blocks, docs, probes, ...}
 };
 
 // ---- decode tables (the GPU form of the reference's 256-entry shuffle/length tables, src/streamvbyte.zig:76-211)
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     if (DEFERRED) {
         // most workgroups of the deferred pass find nothing to do
         const uint64_t first = (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw);
-        if (first >= (uint64_t)min(a.def_count[blockIdx.y], a.def_cap)) return;
+        if (first >= (uint64_t)min(a.def_count[blockIdx.y * DEF_COUNT_STRIDE], a.def_cap)) return;
     }
 
     if (tid < 256u) init_lut(lut, tid);
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_generic = 0;
 
     // DEFERRED: a small persistent grid strides over the segment's (usually tiny) list of deferred probes
-    const uint32_t def_n = DEFERRED ? min(a.def_count[blockIdx.y], a.def_cap) : 0u;
+    const uint32_t def_n = DEFERRED ? min(a.def_count[blockIdx.y * DEF_COUNT_STRIDE], a.def_cap) : 0u;
     const uint32_t nrounds = DEFERRED ? (def_n + gridDim.x * PWAVES * a.ppw - 1u) / (gridDim.x * PWAVES * a.ppw) : a.rounds;
     const uint64_t wg_base = DEFERRED ? 0ull : (uint64_t)blockIdx.x * (uint64_t)(PWAVES * a.ppw) * a.rounds;
     for (uint32_t round = 0; round < nrounds; ++round) {
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         bool valid, long_run = false;
         if (DEFERRED) {
             // p indexes this segment's list of deferred probes (already deduplicated and counted by k_probe_lean8)
-            const uint32_t n = min(a.def_count[blockIdx.y], a.def_cap);
+            const uint32_t n = min(a.def_count[blockIdx.y * DEF_COUNT_STRIDE], a.def_cap);
             valid = lane < a.ppw && p < (uint64_t)n;
             if (valid) {
                 const uint32_t entry = gload_u32(a.def_list + (size_t)blockIdx.y * a.def_cap + p);

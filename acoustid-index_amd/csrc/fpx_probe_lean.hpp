@@ -432,7 +432,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                     if (slot < (uint32_t)DEF_STAGE_CAP) {
                         def_stage[slot] = pair;
                     } else {                                   // staging full: append directly
-                        const unsigned int gs = atomicAdd(&a.def_count[blockIdx.y], 1u);
+                        const unsigned int gs = atomicAdd(&a.def_count[blockIdx.y * DEF_COUNT_STRIDE], 1u);
                         if (gs < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + gs] = pair;
                     }
                 } else {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
         {
             const uint32_t dn = min(def_n, (uint32_t)DEF_STAGE_CAP);
             if (dn != 0u) {
-                if (tid == 0) def_base = atomicAdd(&a.def_count[blockIdx.y], dn);
+                if (tid == 0) def_base = atomicAdd(&a.def_count[blockIdx.y * DEF_COUNT_STRIDE], dn);
                 __syncthreads();
                 for (uint32_t i = tid; i < dn; i += L8_WG)
                     if (def_base + i < a.def_cap) a.def_list[(size_t)blockIdx.y * a.def_cap + def_base + i] = def_stage[i];
@@ -468,13 +468,11 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
     if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
     __syncthreads();
     if (tid == 0) {
-        if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);
-        if (wg_blocks) {
-            atomicAdd(&a.counters[a.ctr_off + CTR_BLOCKS], wg_blocks);
-            atomicAdd(&a.counters[a.ctr_off + CTR_BYTES], wg_blocks * 512ull);
-        }
-        if (wg_docs) atomicAdd(&a.counters[a.ctr_off + CTR_DOCS], wg_docs);
-        if (wg_probes) atomicAdd(&a.counters[a.ctr_off + CTR_PROBES], wg_probes);
+        unsigned long long* st = a.lean_stats + (size_t)(blockIdx.x % LEAN_STAT_SETS) * 8u;     // see LEAN_STAT_SETS
+        if (wg_reads) atomicAdd(&st[0], wg_reads);
+        if (wg_blocks) atomicAdd(&st[1], wg_blocks);
+        if (wg_docs) atomicAdd(&st[2], wg_docs);
+        if (wg_probes) atomicAdd(&st[3], wg_probes);
     }
 }
 

@@ -262,18 +262,23 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (ws->d_def_count) (void)hipFree(ws->d_def_count);
             if (ws->h_def_count) (void)hipHostFree(ws->h_def_count);
             ws->d_def_count = nullptr; ws->h_def_count = nullptr; ws->cap_def_segs = 0;
-            FPX_HIP(hipMalloc(&ws->d_def_count, snap->n_lean * sizeof(unsigned int)));
-            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), snap->n_lean * sizeof(unsigned int)));
+            // [n_lean deferred-list counts, one per 128-B line | LEAN_STAT_SETS x 8 u64 statistics slots of the lean kernel]
+            const size_t words = (size_t)snap->n_lean * DEF_COUNT_STRIDE + LEAN_STAT_WORDS;
+            FPX_HIP(hipMalloc(&ws->d_def_count, words * sizeof(unsigned int)));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), words * sizeof(unsigned int)));
             ws->cap_def_segs = snap->n_lean;
         }
     }
+    // (for the workspace's capacity, not this snapshot's n_lean: the layout must not move between batches)
+    const size_t def_stat_off = (size_t)ws->cap_def_segs * DEF_COUNT_STRIDE;
+    const size_t def_words = def_stat_off + LEAN_STAT_WORDS;
     // (every memset is a 5-us launch of its own: the batch's zeroing rides in kernels that run anyway where it can)
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
     if (P && !score_only) {
         hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
-                           single_fast ? ws->d_counters : nullptr, snap->n_lean ? ws->d_def_count : nullptr, snap->n_lean);
+                           single_fast ? ws->d_counters : nullptr, snap->n_lean ? ws->d_def_count : nullptr, (uint32_t)def_words);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
         // ... and only the top 32 - KEY_SORT_SKIP of them: block-level locality is all the probes need from the order
@@ -306,7 +311,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.rounds = total >= (1ull << 25) ? 2u : 1u;
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
-            a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0;
+            a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
@@ -317,10 +322,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (lean) {
                 if (snap->n_lean) {
                     // main kernel: k_probe_lean8 over the dense 512-B segments
-                    if (attempt > 0) FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, snap->n_lean * sizeof(unsigned int), st));   // (else: k_make_keys)
+                    if (attempt > 0) FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (else: k_make_keys)
                     ProbeArgs l = a;
                     static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 2u; }();
                     l.segs = snap->d_lean; l.rounds = (P >= (1ull << 22)) ? lean_rounds : 1u; l.ctr_off = 8u;
+                    l.lean_stats = reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off);
                     const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
                     const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;
                     const uint32_t gx8 = (uint32_t)((P + per_wg_8 - 1) / per_wg_8);
@@ -349,7 +355,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 }
                 FPX_HIP(hipEventRecord(ws->ev_probe2, st));
                 if (snap->n_lean)
-                    FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, snap->n_lean * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                    FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, def_words * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 used_lean = true;
             } else {
                 a.segs = snap->d_file;
@@ -376,6 +382,18 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (single_fast) break;                     // one query: nothing below needs the counts on the host yet
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipStreamSynchronize(st));
+        if (used_lean && snap->n_lean) {
+            // the lean kernel's statistics: LEAN_STAT_SETS copies on separate cache lines (a workgroup adds to set
+            // blockIdx.x % LEAN_STAT_SETS), summed here into the slots the code below reads
+            const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
+            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0;
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
+                reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3];
+            }
+            ws->h_counters[CTR_LEAN_READS] = reads;
+            ws->h_counters[8 + CTR_BLOCKS] = blocks; ws->h_counters[8 + CTR_BYTES] = blocks * 512ull;
+            ws->h_counters[8 + CTR_DOCS] = docs; ws->h_counters[8 + CTR_PROBES] = probes;
+        }
         if (P && snap->n_file) {
             float ms = 0.f;
             FPX_HIP(hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1));
@@ -386,7 +404,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         H = ws->h_counters[CTR_HITS];
         if (used_lean) {
             bool overflow = false;
-            for (uint32_t i = 0; i < snap->n_lean; ++i) overflow = overflow || ws->h_def_count[i] > def_cap;
+            for (uint32_t i = 0; i < snap->n_lean; ++i) overflow = overflow || ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE] > def_cap;
             if (overflow) {                 // pathological data: nearly every probe needs the generic path
                 if (attempt >= 3) { set_error("deferred list overflow persists"); return FPX_E_DEVICE; }
                 force_generic = true;

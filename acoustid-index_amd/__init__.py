@@ -10,5 +10,5 @@ from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegm
 from . import synth  # noqa: F401
 from . import sharding  # noqa: F401
 from . import segfile  # noqa: F401
-from . import hostindex, frontend, coalescer, legacy  # noqa: F401
+from . import hostindex, frontend, coalescer  # noqa: F401
 from .hostindex import Index, MultiIndex  # noqa: F401

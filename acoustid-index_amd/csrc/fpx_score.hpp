@@ -9,6 +9,16 @@
 
 namespace fpx {
 
+// finish's relative floor `top * min_score_pct / 100` (src/common.zig:162).  The reference computes it in u32 and never
+// clamps score_pct (src/server.zig:189-193 clamps limit and timeout only), so a request may carry any u32: here the
+// product is taken in 64 bits and the quotient SATURATES at u32 max (the reference's own overflow is a safety-checked
+// panic); the oracle does the same.
+__device__ __forceinline__ uint32_t rel_floor(uint32_t score, uint32_t pct)
+{
+    const uint64_t r = (uint64_t)score * pct / 100ull;
+    return r > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 5. scoring: hit records partitioned by query -> per-query hash-table count in LDS -> candidates
 //    (SearchResults.incr + the min_score filter of finish, src/common.zig:121-145)
@@ -196,7 +206,7 @@ __device__ __forceinline__ void score_query(uint32_t q, const uint64_t* __restri
             if (m) atomicMax(&qmax, m);
             __syncthreads();
         }
-        const uint32_t rel = (uint32_t)((uint64_t)qmax * pct / 100ull);
+        const uint32_t rel = rel_floor(qmax, pct);
         if (rel > floor_q) {
             floor_q = rel;
             nsurv = count_survivors(floor_q);
@@ -318,7 +328,7 @@ __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const u
         const uint32_t score = (uint32_t)(smax - ((k >> 32) & smax));
         if (score < min_score) return false;
         if (n == 0 && !partial) {
-            const uint32_t rel = (uint32_t)((uint64_t)score * pct / 100ull);
+            const uint32_t rel = rel_floor(score, pct);
             if (rel > min_score) min_score = rel;
         }
         if (n < out_cap) { out[(size_t)q * out_cap + n].id = (uint32_t)k; out[(size_t)q * out_cap + n].score = score; }
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(256) void k_finish_single(const uint64_t* __restric
             const uint32_t score = ~(uint32_t)(key[i] >> 32);
             if (score < min_score) break;
             if (n == 0) {
-                const uint32_t rel = (uint32_t)((uint64_t)score * pct / 100ull);
+                const uint32_t rel = rel_floor(score, pct);
                 if (rel > min_score) min_score = rel;
             }
             if (n < out_cap) { out[n].id = (uint32_t)key[i]; out[n].score = score; }
@@ -448,7 +458,7 @@ __global__ void k_merge(const fpx_result* __restrict__ parts, const uint32_t* __
         const uint32_t score = (uint32_t)(best >> 32), id = ~(uint32_t)best;
         if (score < min_score) break;
         if (n == 0) {
-            const uint32_t rel = (uint32_t)((uint64_t)score * pct / 100ull);
+            const uint32_t rel = rel_floor(score, pct);
             if (rel > min_score) min_score = rel;
         }
         if (n < out_cap) { out[(size_t)q * out_cap + n].id = id; out[(size_t)q * out_cap + n].score = score; }

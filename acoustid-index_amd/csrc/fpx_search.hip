@@ -223,7 +223,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         d_opts = resident->d_opts + (size_t)q0 * 4;
     } else if (B == 1 && 32 + P * sizeof(uint32_t) <= STAGE_BYTES) {
         // one small query: offsets, options and hashes travel in a single copy from pinned memory, no host sync
-        if (opts[0].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
         if (!ws->h_stage) {
             FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_stage), STAGE_BYTES, hipHostMallocMapped));
             FPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_stage), ws->h_stage, 0));
@@ -240,8 +239,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         d_opts = reinterpret_cast<const uint32_t*>(ws->d_stage + 16);
         staged_single = true;
     } else {
-        for (uint32_t q = 0; q < B; ++q)
-            if (opts[q].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
         if ((rc = grow(&ws->d_hashes, &ws->cap_hashes, (size_t)P + 1))) return rc;
         std::vector<uint32_t> h_opts;
         fill_opts(h_opts, opts, offsets, B);
@@ -738,7 +735,6 @@ int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* of
     if (offsets[0] != 0) { set_error("offsets[0] must be 0"); return FPX_E_INVAL; }
     for (uint32_t q = 0; q < B; ++q) {
         if (offsets[q + 1] < offsets[q]) { set_error("offsets must be non-decreasing"); return FPX_E_INVAL; }
-        if (opts[q].min_score_pct > 100) { set_error("min_score_pct > 100"); return FPX_E_INVAL; }
     }
     FPX_HIP(hipSetDevice(ctx->device));
     QueryBatch* qb = new (std::nothrow) QueryBatch();

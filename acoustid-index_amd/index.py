@@ -279,6 +279,16 @@ def _flatten(queries):
     return np.ascontiguousarray(flat), offsets
 
 
+RESULT_CAP = 1 << 16
+
+
+def _result_cap(max_results):
+    """Size of the host-side result buffer.  max_results is a caller-supplied u32 (the legacy protocol takes it off the
+    wire, src/legacy.zig:44,194): the buffer is bounded at 65 536 entries per query -- far above any limit the reference's
+    front ends hand out (100 over HTTP, 500 by default on the legacy port) -- instead of 8 B x max_results."""
+    return max(1, min(int(max_results), RESULT_CAP))
+
+
 class IndexReader:
     """A held snapshot (src/Index.zig:152-206)."""
 
@@ -289,7 +299,7 @@ class IndexReader:
         """IndexReader.search(hashes, results) (src/Index.zig:170-177): raw hashes in, ranked results out."""
         q = _u32(np.asarray(hashes, dtype=np.uint64) & np.uint64(0xFFFFFFFF)) if len(hashes) else np.zeros(1, np.uint32)
         n = len(hashes)
-        cap = max(1, results.options.max_results)
+        cap = _result_cap(results.options.max_results)
         out = (Result * cap)()
         out_n = C.c_uint32()
         st = Stats()
@@ -307,7 +317,7 @@ class IndexReader:
         if isinstance(options, SearchOptions):
             options = [options] * B
         copts = (Opts * max(1, B))(*[o.to_c() for o in options])
-        cap = max([1] + [o.max_results for o in options])
+        cap = _result_cap(max([1] + [o.max_results for o in options]))
         out = np.zeros((max(1, B), cap, 2), np.uint32)
         out_n = np.zeros(max(1, B), np.uint32)
         st = Stats()
@@ -338,7 +348,7 @@ class QueryBatch:
         self.options = options
         self.flat, self.offsets = flat_h, np.ascontiguousarray(offsets, dtype=np.uint64)
         self.copts = (Opts * max(1, self.B))(*[o.to_c() for o in options])
-        self.cap = max([1] + [o.max_results for o in options])
+        self.cap = _result_cap(max([1] + [o.max_results for o in options]))
         h = C.c_void_p()
         check(lib().fpx_query_batch_create(ctx.h, _p(self.flat), _p(self.offsets), self.B, self.copts, C.byref(h)))
         self.h = h

@@ -114,15 +114,18 @@ def read_segment_file(path, verify=True):
     info = tuple(header[1]) + (None,) * (3 - len(header[1]))
     blocks_start = (pos + block_size - 1) // block_size * block_size
     # walk the blocks up to the empty terminator (:253-268)
-    ptr, nb, num_items = blocks_start, 0, 0
-    while ptr + block_size <= data.size:
-        n = int(data[ptr + 4]) | int(data[ptr + 5]) << 8
-        ptr += block_size
-        if n == 0:
-            break
-        num_items += n
-        nb += 1
-    blocks_end = ptr
+    # (vectorised: a real segment holds ~14 M blocks -- strided views of the num_items u16 at offset 4 of every block)
+    whole = (data.size - blocks_start) // block_size
+    if whole > 0:
+        lo8 = data[blocks_start + 4:blocks_start + whole * block_size:block_size]
+        hi8 = data[blocks_start + 5:blocks_start + whole * block_size:block_size]
+        n_items = lo8.astype(np.uint32) | (hi8.astype(np.uint32) << 8)
+        empty = np.flatnonzero(n_items == 0)
+        nb = int(empty[0]) if len(empty) else whole
+        num_items = int(n_items[:nb].sum(dtype=np.uint64))
+        blocks_end = blocks_start + (nb + (1 if len(empty) else 0)) * block_size
+    else:
+        nb, num_items, blocks_end = 0, 0, blocks_start
     index_end = blocks_end + 4 * nb
     if index_end + 4 > data.size:
         raise InvalidSegment("truncated block index")

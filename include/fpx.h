@@ -47,7 +47,8 @@ typedef struct { uint32_t id; uint32_t score; } fpx_result;
 /* Per-query SearchOptions (src/common.zig:50-54) as derived by MultiIndex.search
  * (src/MultiIndex.zig:302-306): has_min_score == 0 means "null" -> (raw query length + 19) / 20.
  * max_results is used as given (the HTTP front end clamps to [1,100], src/server.zig:192;
- * the legacy front end passes 500, src/legacy.zig:194).  min_score_pct must be <= 100. */
+ * the legacy front end passes 500, src/legacy.zig:194).  min_score_pct is any u32, as upstream (src/server.zig:189-193
+ * clamps only limit and timeout): top * pct / 100 is computed in 64 bits and saturates at u32 max. */
 typedef struct {
     uint32_t max_results;
     uint32_t min_score;

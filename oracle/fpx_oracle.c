@@ -966,7 +966,9 @@ int orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
         if (orc_snapshot_has_newer_commit(snap, cand[i].id, h->commit_id)) continue;
         if (cand[i].score < min_score) break;
         if (outn == 0) {
-            uint32_t rel = (uint32_t)((uint64_t)cand[i].score * min_score_pct / 100);   /* :162 (no u32 overflow for pct<=100) */
+            /* :162; score_pct is an unclamped u32 upstream (src/server.zig:189-193): 64-bit product, saturating quotient */
+            uint64_t rel64 = (uint64_t)cand[i].score * min_score_pct / 100;
+            uint32_t rel = rel64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rel64;
             if (rel > min_score) min_score = rel;
         }
         if (outn < out_cap) out[outn] = cand[i];

@@ -20,6 +20,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_present():
+    """One fpx_ctx_create: FPX_E_NODEVICE (-5) means no gfx950 device is visible (or libfpx.so is not built)."""
+    try:
+        from __graft_entry__ import load_package
+        fpx = load_package()
+        fpx.Context(0).close()
+        return True, ""
+    except Exception as e:          # FpxError -5, missing library, ...
+        return False, str(e)
+
+
+def pytest_collection_modifyitems(config, items):
+    """On a machine without a ROCm device a plain `pytest` skips the gpu-marked tests instead of erroring at the first
+    GPU fixture.  `-m gpu` on a GPU box is unaffected; `-m gpu` WITHOUT a device still fails loudly (FPX_REQUIRE_GPU=1
+    is what the driver's GPU tier implies): a silently skipped parity suite must not look green."""
+    gpu_items = [it for it in items if it.get_closest_marker("gpu")]
+    if not gpu_items:
+        return
+    ok, why = _gpu_present()
+    if ok:
+        return
+    if os.environ.get("FPX_REQUIRE_GPU") == "1" or config.getoption("-m") == "gpu":
+        return                       # let them run and fail with FPX_E_NODEVICE
+    skip = pytest.mark.skip(reason=f"no gfx950 device: {why}")
+    for it in gpu_items:
+        it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def orc():
     from oracle import oracle

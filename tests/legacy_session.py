@@ -1,11 +1,15 @@
-"""The legacy line protocol's path into the search (src/legacy.zig): `search h1,h2,...` with the
+"""TEST HELPER (not part of the product package: src/legacy.zig is out of scope).
+Replays the reference's tests/test_legacy.py vectors through the GPU search path.
+The legacy line protocol's path into the search (src/legacy.zig): `search h1,h2,...` with the
 session's options (limit 500, min_score 1, top_score_percent 10, not clamped like the HTTP front end), plus the small
 transaction vocabulary the reference's tests drive it with (begin / insert / commit / rollback, get / set of session
 attributes).  A Session maps one text line to one reply line ("OK ..." / "ERR ..."); sockets are the host's business.
 Index attributes (metadata) are kept per MultiIndex in memory only."""
-from . import index as _ix
-from ._lib import SearchTimeout
-from .hostindex import IndexNotFound
+from fpx_testlib import fpx as _fpx
+
+_ix = _fpx.index
+SearchTimeout = _fpx.SearchTimeout
+IndexNotFound = _fpx.hostindex.IndexNotFound
 
 INDEX_NAME = "main"                       # src/legacy.zig: the legacy protocol serves one fixed index
 

@@ -7,6 +7,7 @@ import msgpack
 import pytest
 
 from fpx_testlib import fpx
+from legacy_session import LegacySession
 
 fe = fpx.frontend
 
@@ -158,7 +159,7 @@ class _NoIndex:
 
 
 def test_legacy_protocol_without_device():
-    s = fpx.legacy.LegacySession(_NoIndex())
+    s = LegacySession(_NoIndex())
     assert s.cmd("echo hello world") == "OK hello world"                    # tests/test_legacy.py:30-37
     assert s.cmd("") == "OK "
     assert s.cmd("frobnicate x").startswith("ERR ")
@@ -174,7 +175,7 @@ def test_legacy_protocol_without_device():
     assert s.cmd("set attribute foo bar") == "ERR not in transaction"
     assert s.cmd("get attribute foo") == "OK "
     assert s.cmd("optimize") == "ERR not in transaction"
-    assert fpx.legacy.LegacySession(_NoIndex(), read_only=True).cmd("begin") == "ERR read-only replica"
+    assert LegacySession(_NoIndex(), read_only=True).cmd("begin") == "ERR read-only replica"
     # signed decimals are reinterpreted as u32 (src/legacy.zig:318-330)
-    assert fpx.legacy.LegacySession.parse_fingerprint("-1,2147483648,-2147483648") == [0xFFFFFFFF, 0x80000000, 0x80000000]
+    assert LegacySession.parse_fingerprint("-1,2147483648,-2147483648") == [0xFFFFFFFF, 0x80000000, 0x80000000]
     assert s.cmd("search 1,2,3") == "OK "                                    # nothing committed

@@ -23,9 +23,6 @@ def env():
 
 def test_invalid_arguments_are_rejected(env):
     fpx, oracle, ctx, p, qs, flat, targets = env
-    with pytest.raises(fpx.FpxError) as e:
-        p.reader.search_batch(qs[:2], fpx.SearchOptions(10, 1, 101))          # score_pct > 100
-    assert e.value.status == -4
     # snapshot order: commit ids must ascend, file segments before memory segments (src/Index.zig:36-41)
     a = fpx.MemorySegment(ctx, np.array([(7 << 32) | 1], np.uint64), 1, 1, 5, [1])
     b = fpx.MemorySegment(ctx, np.array([(7 << 32) | 2], np.uint64), 2, 2, 4, [2])
@@ -37,6 +34,25 @@ def test_invalid_arguments_are_rejected(env):
         fpx.MemorySegment(ctx, np.array([(9 << 32) | 1, (7 << 32) | 1], np.uint64), 1, 1, 9, [1])
     with pytest.raises(fpx.FpxError):                                          # block_size outside [64, 4096]
         fpx.FileSegment(ctx, np.zeros(64, np.uint8), 32, np.zeros(0, np.uint32), 1, 1, 1, [1])
+
+
+def test_score_pct_is_not_clamped(env):
+    """score_pct is an unclamped u32 upstream (src/server.zig:189-193 clamps only limit and timeout; finish applies
+    top * pct / 100 as given, src/common.zig:162): above 100 the top hit survives and everything scoring below
+    top * pct / 100 is cut; absurd values saturate.  Bit-exact against the oracle through the batch, resident and single
+    entry points."""
+    fpx, oracle, ctx, p, qs, flat, targets = env
+    for pct in (100, 101, 150, 1000, 0xFFFFFFFF):
+        o = fpx.SearchOptions(10, 1, pct)
+        got, _ = p.check(qs[:24], o)
+        assert all(len(g) >= 1 for g in got)
+        if pct > 100:
+            assert all(len(g) == 1 or g[1][1] == g[0][1] for g in got)       # only ties with the top can survive
+        r = fpx.SearchResults(o)
+        assert p.reader.search(qs[0], r) == got[0]
+        qb = fpx.QueryBatch(ctx, qs[:24], o)
+        out, out_n, _ = fpx.search_resident(p.reader, qb)
+        assert fpx.results_to_lists(out, out_n) == got
 
 
 def test_segments_outlive_their_python_handles(env):

@@ -10,6 +10,9 @@ import msgpack
 import numpy as np
 import pytest
 
+import http_wrapper
+from legacy_session import LegacySession
+
 pytestmark = pytest.mark.gpu
 
 J = {"Content-Type": "application/json"}
@@ -197,7 +200,7 @@ def test_coalescer_timeout_maps_to_503(env, mi):
 def test_http_wrapper_round_trip(env):
     fpx, _, ctx = env
     mi = fpx.MultiIndex(ctx)
-    srv = fpx.frontend.serve(mi, "127.0.0.1", 0)
+    srv = http_wrapper.serve(mi, "127.0.0.1", 0)
     port = srv.server_address[1]
     t = threading.Thread(target=srv.serve_forever, daemon=True)
     t.start()
@@ -271,7 +274,7 @@ def test_legacy_protocol_search(env):
     """tests/test_legacy.py:61-91 through the GPU path"""
     fpx, _, ctx = env
     mi = fpx.MultiIndex(ctx)
-    s = fpx.legacy.LegacySession(mi)
+    s = LegacySession(mi)
     assert s.cmd("begin") == "OK "
     assert s.cmd("insert 1001 11000,12000,13000") == "OK "
     assert s.cmd("insert 1002 11000,12000,19000") == "OK "
@@ -284,7 +287,7 @@ def test_legacy_protocol_search(env):
     both = s.cmd("search 21000,22000")
     assert both.startswith("OK ") and len(both[3:].split()) == 2
     assert s.cmd("set max_results 1") == "OK " and len(s.cmd("search 21000,22000")[3:].split()) == 1
-    s2 = fpx.legacy.LegacySession(mi)                                       # another connection sees the commits
+    s2 = LegacySession(mi)                                       # another connection sees the commits
     assert s2.cmd("search -4294956296,12000") == "OK 1001:2 1002:2"          # 11000 sent in its signed-wrapped form
     s.cmd("begin"); s.cmd("set attribute foo bar"); s.cmd("commit")
     assert s2.cmd("get attribute foo") == "OK bar"

@@ -76,7 +76,7 @@ def brute_search(segments, query, max_results, min_score, pct):
         if s < min_score:
             break
         if not out:
-            min_score = max(min_score, s * pct // 100)
+            min_score = max(min_score, min(s * pct // 100, 0xFFFFFFFF))
         out.append((d, s))
     return out, blocks, docs
 
@@ -130,7 +130,7 @@ def test_oracle_equals_brute_force_on_unpinned_behaviour(block_size):
         queries.append(q)
     hit_caps = False
     for q in queries:
-        for (mr, ms, pct) in ((10, 1, 0), (40, None, 10), (3, 2, 100), (500, 1, 10), (5, 1, 50)):
+        for (mr, ms, pct) in ((10, 1, 0), (40, None, 10), (3, 2, 100), (500, 1, 10), (5, 1, 50), (10, 1, 150), (10, 1, 0xFFFFFFFF)):
             want, wb, wd = brute_search(raws, q, mr, ms, pct)
             got, st = snap.search(q, mr, ms, pct, with_stats=True)
             assert got == want

@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the fpindex /_search hot path on MI355X.
 
-One step = one pass of the hot path over one batch of synthetic queries (default: 8192 queries x 1000 hashes -- the
-batch size BASELINE.json names for its largest config; `--batch 1024` is configs[1]'s batch)
+One step = one pass of the hot path over one batch of synthetic queries (default: 8192 queries x 1000 hashes)
 against a seeded synthetic index resident in HBM (default: BASELINE.json configs[2], 100 M fingerprints x 256
 hashes in 16 FileSegments).  With --gpus N > 1 the SAME index is sharded by segment over the ranks
 (segment s lives on rank s % N), every rank probes its own segments for the whole batch, the per-rank top-k
 tables are exchanged with one RCCL all-gather and merged (strong scaling: total work fixed).
 
-Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline.
+Prints ONE JSON line (rank 0).  At N = 1 the line also carries, measured in the same run:
+  roofline      physical bytes of the dominant kernel / its HIP-event time / 8 TB/s (<= 1); `traffic` = HBM bytes by PMC
+                from a rocprofv3 child pass of this very script (or, if that is unavailable, from profiles/ with the
+                kernels' source hash attached); the reference-equivalent figure of SURVEY 8(d) is kept separately
+  by_batch      the same index at B = 1, 64, 256, 1024 (BASELINE.md's batch for this row) next to the headline batch
+  end_to_end    fpx_search_batch from pageable host memory (H2D of the queries and D2H of the results inside)
+  config1       BASELINE.json configs[1]: 10 M fingerprints in ONE segment, batch 1024
+  cpu_baseline  the oracle's pthread executor pool over the WHOLE index downloaded to host RAM
+See DESIGN.md "Measurement" for the definitions.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -23,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "queries/sec + p50 /_search latency, 100M-fp index, 1k-hash queries"
 
 
 def parse_args():
@@ -39,70 +52,301 @@ def parse_args():
     ap.add_argument("--min-score", type=int, default=None,
                     help="absolute score floor (default: the HTTP default (n + 19) / 20; 1 = the legacy protocol's)")
     ap.add_argument("--seed", type=int, default=20260928)
-    ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("FPX_BENCH_CPU_QUERIES", 1024)))
-    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FPX_BENCH_CPU_SECONDS", 10.0)))
+    ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("FPX_BENCH_CPU_QUERIES", 4096)))
+    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FPX_BENCH_CPU_SECONDS", 12.0)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("FPX_BENCH_INFLIGHT", 0)),
                     help="batches kept in flight by that many host threads (each call owns a pooled workspace + HIP stream); "
                          "0 = auto: 1 on one GPU (clean per-kernel timing), 3 when sharded (hides the all-gather/merge latency and the host round trips)")
-    ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency probe (profiling runs)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the by_batch table / single-query latency (profiling runs)")
     ap.add_argument("--no-measure-bw", action="store_true",
                     help="skip the measured streaming / random-512-B read bandwidth (the second roofline denominator)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no by_batch / end_to_end / config1 / pmc child")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc FETCH_SIZE child pass")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # internal: the profiled child
     return ap.parse_args()
 
 
-def cpu_baseline(fpx, oracle, ctx, seg, first_doc, ndocs, flat, offsets, nq, nseg_total, gpu_single, block_size=512, target_s=10.0):
-    """The oracle (C restatement of the reference CPU path) on this box's host cores, on a bounded sample:
-    `nq` queries of the SAME batch against ONE of the index's segments (downloaded from HBM), one query per
-    thread on all cores (the reference runs one search per executor thread, src/main.zig:272-276).  A whole
-    query costs `nseg_total` such segment scans, so qps = nq / seconds / nseg_total."""
-    blocks, index = seg.download()
-    ids = np.arange(first_doc, first_doc + ndocs, dtype=np.uint32)
-    oseg = oracle.file_segment(blocks, block_size, index, first_doc, first_doc + ndocs - 1, 1, ids, borrow=True)
-    osnap = oracle.Snapshot([oseg], [])
-    cores = os.cpu_count() or 1
-    queries = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(nq)]
-    results = [None] * nq
+def kernel_source_hash():
+    """sha256 over the HIP sources: ties a stored PMC figure to the kernels it was measured on"""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "acoustid-index_amd", "csrc", "*"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
-    def work(tid):
-        for i in range(tid, nq, cores):
-            results[i] = osnap.search(queries[i], 40, None, 10)
 
-    # warm the page cache / tables with a few queries, then time single-threaded scans of one segment: a whole query
-    # on the reference costs `nseg_total` of them back to back (src/Index.zig:170-177 walks the segments serially)
-    for i in range(min(4, nq)):
-        osnap.search(queries[i], 40, None, 10)
-    lat1 = []
-    for i in range(min(16, nq)):
-        t1 = time.perf_counter()
-        osnap.search(queries[i], 40, None, 10)
-        lat1.append((time.perf_counter() - t1) * 1e3 * nseg_total)
-    # repeat passes over the sample until ~target_s seconds of wall time have been spent (bounded CPU work)
+def touched_bytes(table_bytes, n_probes, line=128):
+    """expected bytes of a table that n uniform probes (one `line`-byte line each) pull from HBM"""
+    if table_bytes <= 0 or n_probes <= 0:
+        return 0.0
+    return table_bytes * (1.0 - float(np.exp(-n_probes * line / table_bytes)))
+
+
+def bitmap_size(n_items):
+    """as build_presence (csrc/fpx_build.hip): >= 5.7 bits per item"""
+    shift = 0
+    while shift < 22 and (1 << (31 - shift)) * 7 >= n_items * 40:
+        shift += 1
+    return (1 << (32 - shift)) // 8
+
+
+class StatAgg:
+    FIELDS = ("algorithmic_bytes", "probe_kernel_ms", "probe_launches", "scanned_blocks", "total_gpu_ms", "hits",
+              "probe_kernel_bytes", "probe_kernel_fetched_bytes", "probe_aux_ms", "generic_iters", "probes")
+
+    def __init__(self):
+        self.v = {k: 0.0 for k in self.FIELDS}
+        self.lock = threading.Lock()
+        self.steps = 0
+
+    def add(self, st):
+        with self.lock:
+            for k in self.FIELDS:
+                self.v[k] += getattr(st, k)
+            self.steps += 1
+
+
+def model_moved_bytes(segs, fetched_per_launch, probes_per_launch):
+    """What the dominant kernel has to pull from HBM per launch, modelled from counts the kernel reports: the blocks it
+    fetched (counted) + the lines of the presence bitmaps, bucket tables and block records its probes touch (expected
+    value for uniform hashes at 128-B lines)."""
+    pmin = int(os.environ.get("FPX_PRESENCE_MIN_ITEMS", 1 << 20))
+    files = [sg for sg in segs if sg.kind == "file"]
+    if not files:
+        return {"blocks": fetched_per_launch, "presence_bitmaps": 0.0, "bucket_tables": 0.0, "block_records": 0.0, "total": fetched_per_launch}
+    per_seg = probes_per_launch / len(files)
+    bm = bk = br = 0.0
+    for sg in files:
+        nb = sg.num_blocks
+        if sg.getSize() >= pmin:
+            bm += touched_bytes(bitmap_size(sg.getSize()), per_seg)
+            br += touched_bytes(8.0 * (nb + 3), per_seg)
+        nbuck = 1
+        while nbuck < nb and nbuck < (1 << 25):
+            nbuck *= 2
+        bk += touched_bytes(4.0 * (nbuck + 1), per_seg)
+    return {"blocks": fetched_per_launch, "presence_bitmaps": bm, "bucket_tables": bk, "block_records": br,
+            "total": fetched_per_launch + bm + bk + br}
+
+
+def timed_resident(fpx, reader, qb, steps, warmup, out=None, out_n=None):
+    """`steps` resident searches of one batch on one stream; returns (seconds, StatAgg, out, out_n)"""
+    agg = StatAgg()
+    for _ in range(warmup):
+        out, out_n, _ = fpx.search_resident(reader, qb, 0, out, out_n)
     t0 = time.perf_counter()
-    passes = 0
-    while True:
-        threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        passes += 1
-        dt = time.perf_counter() - t0
-        if dt >= target_s or passes >= 4096:
-            break
-    # parity at full size on the sample: the GPU path restricted to the same segment must agree bit-exactly
-    mism = sum(1 for i in range(nq) if results[i] != gpu_single[i])
-    qps = nq * passes / dt / nseg_total
+    for _ in range(steps):
+        out, out_n, st = fpx.search_resident(reader, qb, 0, out, out_n)
+        agg.add(st)
+    return time.perf_counter() - t0, agg, out, out_n
+
+
+def row_from(B, steps, dt, agg, segs, kernel_hint=None):
+    launches = max(1, int(agg.v["probe_launches"]))
+    avg_ms = agg.v["probe_kernel_ms"] / launches
+    fetched = agg.v["probe_kernel_fetched_bytes"] / launches
+    probes = agg.v["probes"] / max(1, agg.steps)
+    moved = model_moved_bytes(segs, fetched, probes)
+    r = {"batch": B, "steps": steps, "ms_per_step": dt / steps * 1e3, "queries_per_s": B * steps / dt,
+         "probe_kernel_ms": avg_ms if avg_ms > 0 else None,
+         "probe_kernel_fetched_block_bytes": fetched,
+         "moved_bytes_model": moved["total"] if avg_ms > 0 else None,
+         "hbm_frac_model": (moved["total"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else None,
+         "reference_visited_block_bytes": agg.v["probe_kernel_bytes"] / launches}
+    if kernel_hint:
+        r["kernel"] = kernel_hint
+    return r
+
+
+def parse_pmc_dir(d):
+    """FETCH_SIZE (KB) per dispatch of the probe and calibration kernels out of a rocprofv3 counter_collection.csv"""
+    import collections
+    import csv
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        return None
+    per = collections.OrderedDict()
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != "FETCH_SIZE":
+                continue
+            n = r["Kernel_Name"]
+            short = n.split("(")[0].split("::")[-1].split("<")[0]
+            if short.startswith("k_probe") or short.startswith("k_bw_"):
+                key = (int(r["Dispatch_Id"]), short)
+                per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
+    by = collections.defaultdict(list)
+    for (did, short), v in sorted(per.items()):
+        by[short].append(v)
+    return by
+
+
+def run_pmc_child(args, docs, timeout_s=420):
+    """HBM bytes of the dominant kernel, measured in THIS run: a child process of this script under
+    `rocprofv3 --pmc FETCH_SIZE` (counters in their own pass, no tracing besides --kernel-trace) repeats the headline
+    batch on an identically built index; the two bandwidth kernels of known byte counts calibrate the counter's unit in
+    the same pass (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of a wide coalesced read)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    d = tempfile.mkdtemp(prefix="fpx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1",
+           "--docs", str(docs), "--segments", str(args.segments), "--hashes", str(args.hashes), "--batch", str(args.batch),
+           "--query-len", str(args.query_len), "--limit", str(args.limit), "--seed", str(args.seed)]
+    if args.min_score is not None:
+        cmd += ["--min-score", str(args.min_score)]
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        p = subprocess.run(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        shutil.rmtree(d, ignore_errors=True)
+        return None, f"rocprofv3 child exceeded {timeout_s} s"
+    try:
+        if p.returncode != 0:
+            return None, f"rocprofv3 child exited {p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
+        by = parse_pmc_dir(d)
+        if not by or not by.get("k_probe_lean8"):
+            return None, "no k_probe_lean8 dispatch in the counter output"
+        child = None
+        for line in p.stdout.decode(errors="replace").splitlines():
+            if line.startswith('{"pmc_child"'):
+                child = json.loads(line)
+        lean = by["k_probe_lean8"][-2:]
+        kb = sum(lean) / len(lean)
+        cal = {}
+        if child:
+            for k, known in (("k_bw_stream", child["bw_stream_bytes"]), ("k_bw_random", child["bw_random_bytes"])):
+                if by.get(k):
+                    cal[k] = {"known_bytes": known, "FETCH_SIZE_KB": by[k][-1], "reported_over_known": by[k][-1] * 1024 / known}
+        ratios = [c["reported_over_known"] for c in cal.values()]
+        # the correction is whatever the calibration kernels say in this pass (x2 on gfx950 / ROCm 7.2)
+        corr = 1.0 / (sum(ratios) / len(ratios)) if ratios else 2.0
+        out_dir = os.environ.get("FPX_BENCH_PMC_KEEP")
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+            for f in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
+                shutil.copy(f, out_dir)
+        return {"hbm_read_bytes_per_launch": kb * 1024 * corr, "FETCH_SIZE_KB_per_launch": kb, "correction": corr,
+                "calibration": cal, "launches_averaged": len(lean),
+                "child_probe_kernel_ms_under_profiler": child.get("probe_kernel_ms") if child else None}, None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def stored_traffic(docs, S, H, B, qlen):
+    """fallback: the committed PMC pass, only for the same configuration AND the same kernel sources"""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+            c = tr["config"]
+            if (c["docs"], c["segments"], c["hashes_per_doc"], c["batch"], c["query_len"]) != (docs, S, H, B, qlen):
+                continue
+            if tr.get("kernel_source_sha16") != kernel_source_hash():
+                continue
+            return tr["k_probe_lean8"]["hbm_read_bytes_per_launch_corrected"], f"profiles/{name}@{tr['kernel_source_sha16']}"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def host_memory_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, target_s):
+    """The oracle (C restatement of the reference CPU path, SSSE3 decode like the reference) on this box's host cores:
+    the WHOLE index downloaded from HBM into host RAM, the first `nq` queries of the batch, one search per thread on
+    every hardware thread through orc_search_many -- persistent pthread workers with recycled collectors, the
+    reference's executor model (src/main.zig:272-276, src/common.zig:186-300) -- cycling for ~target_s seconds."""
+    cores = os.cpu_count() or 1
+    need = sum((s.num_blocks + 1) * s.block_size + 4 * s.num_blocks + 5 * (hi - lo + 1) for s, (lo, hi) in zip(segs, ranges))
+    avail = host_memory_available()
+    use = list(range(len(segs)))
+    note = ""
+    if avail is not None and need * 1.05 + (8 << 30) > avail:
+        k = max(1, int(len(segs) * (avail - (8 << 30)) / (need * 1.05)))
+        use = use[:k]
+        note = f"host RAM short ({avail / 2**30:.0f} GiB available, {need / 2**30:.0f} GiB needed): {k} of {len(segs)} segments searched, qps scaled by {k}/{len(segs)}; "
+    t0 = time.perf_counter()
+    osegs, keep = [], []
+    for i in use:
+        blocks, index = segs[i].download()
+        lo, hi = ranges[i]
+        ids = np.arange(lo, hi + 1, dtype=np.uint32)
+        keep.append((blocks, index))
+        osegs.append(oracle.file_segment(blocks, segs[i].block_size, index, lo, hi, segs[i].commit_id, ids, borrow=True))
+    osnap = oracle.Snapshot(osegs, [])
+    t_dl = time.perf_counter() - t0
+    oracle.lib().orc_set_simd(1)
+    sub_off = np.ascontiguousarray(offsets[:nq + 1])
+    sub_flat = np.ascontiguousarray(flat[:int(offsets[nq])])
+    # idle-machine latency: one thread, a few queries
+    n1 = min(32, nq)
+    _, _, rep1 = osnap.search_many(sub_flat, sub_off[:n1 + 1], opts.max_results, opts.min_score, opts.min_score_pct, nthreads=1)
+    lat1 = np.sort(rep1["latency_ms"])
+    out, out_n, rep = osnap.search_many(sub_flat, sub_off, opts.max_results, opts.min_score, opts.min_score_pct,
+                                        nthreads=cores, min_seconds=target_s)
+    lat = np.sort(rep["latency_ms"])
+    scale = len(use) / len(segs)
+    qps = rep["queries_done"] / rep["wall_s"] * scale
+    mism = None
+    if len(use) == len(segs):
+        got = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(int(out_n[q]))] for q in range(nq)]
+        mism = sum(1 for q in range(nq) if got[q] != gpu_lists[q])
     return {"value": qps, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{nq} queries of the batch x 1 of {nseg_total} segments, {passes} passes, {dt:.2f} s wall on {cores} threads "
-                      f"(one query per thread, SSSE3 decode); qps = {nq}*{passes}/{dt:.2f}/{nseg_total}; "
-                      f"GPU-vs-oracle mismatches on the sample: {mism}",
-            "parity_mismatches": mism,
-            "single_thread_query_ms_p50": float(np.median(lat1)), "single_thread_query_ms_max": float(np.max(lat1))}
+            "sample": f"{note}{nq} queries of the batch x {len(use)} of {len(segs)} segments resident in host RAM ({need / 2**30:.0f} GiB, "
+                      f"downloaded from HBM in {t_dl:.1f} s), {rep['queries_done']} searches in {rep['wall_s']:.2f} s on {cores} pthread workers "
+                      f"(one search per thread, recycled collectors, SSSE3 decode); GPU-vs-oracle mismatches on these queries: {mism}",
+            "parity_mismatches": mism, "queries": nq, "searches_done": int(rep["queries_done"]), "wall_seconds": rep["wall_s"],
+            "latency_ms_under_load_p50": float(np.percentile(lat, 50)), "latency_ms_under_load_p99": float(np.percentile(lat, 99)),
+            "single_thread_query_ms_p50": float(np.percentile(lat1, 50)), "single_thread_query_ms_p99": float(np.percentile(lat1, 99)),
+            "parallel_speedup_over_one_thread": qps / scale * float(np.percentile(lat1, 50)) / 1e3,
+            "host_ram_available_GiB": None if avail is None else avail / 2**30}
+
+
+def synth_index(fpx, ctx, seed, docs, S, H, local_segs, remote=True):
+    per = docs // S
+    segs, ranges = [], []
+    for s in range(S):
+        lo = s * per + 1
+        ranges.append((lo, lo + per - 1))
+        if s in local_segs:
+            segs.append(fpx.FileSegment.synth(ctx, seed, lo, per, H, 0, 512, s + 1))
+        elif remote:
+            segs.append(fpx.RemoteSegment(ctx, lo, lo + per - 1, s + 1, np.arange(lo, lo + per, dtype=np.uint32)))
+    return segs, ranges
+
+
+def pmc_child_main(args):
+    """the profiled child: same index, same batch, a few launches, plus the two calibration kernels"""
+    from __graft_entry__ import load_package
+    fpx = load_package()
+    ctx = fpx.Context(0)
+    S, H, B = args.segments, args.hashes, args.batch
+    segs, _ = synth_index(fpx, ctx, args.seed, args.docs, S, H, set(range(S)))
+    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+    flat, offsets, _ = fpx.synth.make_queries(args.seed, 4242, B, (args.docs // S) * S, H, query_len=args.query_len)
+    qb = fpx.QueryBatch(ctx, options=fpx.http_options(limit=args.limit, min_score=args.min_score), flat=(flat, offsets))
+    dt, agg, _, _ = timed_resident(fpx, reader, qb, args.steps, args.warmup)
+    nbytes, bs = 8 << 30, 512
+    ctx.measure_bandwidth(nbytes, bs)
+    # byte counts of the calibration kernels (csrc/fpx_search.hip: measure_bandwidth_impl)
+    print(json.dumps({"pmc_child": True, "bw_stream_bytes": nbytes // 4096 * 4096, "bw_random_bytes": 256 * 16 * (256 // 32) * 64 * bs,
+                      "probe_kernel_ms": agg.v["probe_kernel_ms"] / max(1, agg.v["probe_launches"])}), flush=True)
 
 
 def main():
     args = parse_args()
+    if args.pmc_child:
+        return pmc_child_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,27 +381,28 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     ctx = fpx.Context(device)
 
-    # ---- index: S contiguous id ranges, commit_id = s + 1; shrink if HBM is too small
+    # ---- index: S contiguous id ranges, commit_id = s + 1.  The configuration is NOT shrunk to fit:
+    #      a box with too little free HBM fails here (FPX_ALLOW_SHRINK=1 halves `docs` until it fits and flags the line).
     S, H, B = args.segments, args.hashes, args.batch
     docs = args.docs
     free_b, total_b = torch.cuda.mem_get_info()
     local_segs = [s for s in range(S) if s % max(world, eworld) == rank]
-    est_seg_bytes = (docs // S) * H * 5.4                  # ~4.5-5.3 B/item in blocks
-    need = est_seg_bytes * len(local_segs) + (docs // S) * H * 8 * 2.3 + (4 << 30)   # + build scratch of one segment
-    while need > free_b * 0.92 and docs > 1_000_000:
-        docs //= 2
-        est_seg_bytes = (docs // S) * H * 5.4
-        need = est_seg_bytes * len(local_segs) + (docs // S) * H * 8 * 2.3 + (4 << 30)
+
+    def need_bytes(d):
+        est_seg = (d // S) * H * 5.4                       # ~4.5-5.3 B/item in blocks + derived tables
+        return est_seg * len(local_segs) + (d // S) * H * 8 * 2.3 + (4 << 30)   # + build scratch of one segment
+    shrunk = False
+    if need_bytes(docs) > free_b * 0.92:
+        if os.environ.get("FPX_ALLOW_SHRINK") != "1":
+            raise SystemExit(f"bench.py: {docs} docs x {H} hashes in {S} segments need ~{need_bytes(docs) / 2**30:.0f} GiB of HBM on this rank, "
+                             f"{free_b / 2**30:.0f} GiB are free; refusing to shrink the configuration (FPX_ALLOW_SHRINK=1 overrides)")
+        while need_bytes(docs) > free_b * 0.92 and docs > 1_000_000:
+            docs //= 2
+            shrunk = True
     per = docs // S
     docs = per * S
     t_build0 = time.perf_counter()
-    segs = []
-    for s in range(S):
-        lo = s * per + 1
-        if s in local_segs:
-            segs.append(fpx.FileSegment.synth(ctx, args.seed, lo, per, H, 0, 512, s + 1))
-        else:
-            segs.append(fpx.RemoteSegment(ctx, lo, lo + per - 1, s + 1, np.arange(lo, lo + per, dtype=np.uint32)))
+    segs, ranges = synth_index(fpx, ctx, args.seed, docs, S, H, set(local_segs))
     snapshot = fpx.Segments(ctx, segs)
     reader = fpx.IndexReader(snapshot)
     torch.cuda.synchronize()
@@ -170,31 +415,14 @@ def main():
     opts = fpx.http_options(limit=args.limit, min_score=args.min_score)
     qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
     cap = qb.cap
-    out = np.zeros((B, cap, 2), np.uint32)
-    out_n = np.zeros(B, np.uint32)
 
-    agg = {"bytes": 0, "probe_ms": 0.0, "launches": 0, "blocks": 0, "gpu_ms": 0.0, "hits": 0, "main_bytes": 0, "aux_ms": 0.0, "fetched": 0,
-           "generic": 0}
+    agg = StatAgg()
 
     import concurrent.futures as cf
-    lock = threading.Lock()
     sharded = world > 1 or eworld > 1
     nfl = args.inflight if args.inflight > 0 else (3 if sharded else 1)
     outs = [(np.zeros((B, cap, 2), np.uint32), np.zeros(B, np.uint32)) for _ in range(nfl)]
     shardeds = [fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world, host_staged=(backend != "nccl")) for _ in range(nfl)] if sharded else None
-
-    def record_stats(st):
-        with lock:
-            agg["bytes"] += st.algorithmic_bytes
-            agg["probe_ms"] += st.probe_kernel_ms
-            agg["launches"] += st.probe_launches
-            agg["blocks"] += st.scanned_blocks
-            agg["gpu_ms"] += st.total_gpu_ms
-            agg["hits"] += st.hits
-            agg["main_bytes"] += st.probe_kernel_bytes
-            agg["fetched"] += st.probe_kernel_fetched_bytes
-            agg["aux_ms"] += st.probe_aux_ms
-            agg["generic"] += st.generic_iters
 
     def run_steps(nsteps, record):
         """nsteps batches, `nfl` of them in flight.  world == 1: every thread runs whole searches.  world > 1: threads
@@ -205,7 +433,7 @@ def main():
                 o, n = outs[i % nfl]
                 _, _, st = fpx.search_resident(reader, qb, 0, o, n)
                 if record:
-                    record_stats(st)
+                    agg.add(st)
             if nfl == 1:
                 for i in range(nsteps):
                     one(i)
@@ -213,6 +441,7 @@ def main():
                 with cf.ThreadPoolExecutor(nfl) as ex:
                     list(ex.map(one, range(nsteps)))
             return
+
         def stage1(i):
             sh = shardeds[i % nfl]
             return sh.partial(qb)
@@ -227,7 +456,7 @@ def main():
                 o, n = outs[i % nfl]
                 shardeds[i % nfl].gather_merge(qb, o, n)
                 if record:
-                    record_stats(st)
+                    agg.add(st)
 
     def barrier():
         if world > 1:
@@ -253,37 +482,18 @@ def main():
     top_scores = [int(out[q, 0, 1]) for q in range(B) if out_n[q] > 0]
 
     result = None
+    extras = rank == 0 and world == 1 and eworld <= 1 and not args.no_extras
     if rank == 0:
-        launches = max(1, agg["launches"])
-        avg_ms = agg["probe_ms"] / launches
-        bytes_per_launch = agg["main_bytes"] / launches       # blocks the main kernel visited itself
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # What the kernel must really move: the blocks of the probes whose hash the segment has (the presence bitmap answers
-        # the others) + the bitmaps themselves, which a batch of this size reads end to end (sorted hashes).
-        fetched_per_launch = agg["fetched"] / launches
-        pmin = int(os.environ.get("FPX_PRESENCE_MIN_ITEMS", 1 << 20))
-
-        def bitmap_size(n_items):                  # as build_presence (csrc/fpx_build.hip): >= 5.7 bits per item
-            shift = 0
-            while shift < 22 and (1 << (31 - shift)) * 7 >= n_items * 40:
-                shift += 1
-            return (1 << (32 - shift)) // 8
-        bitmap_bytes = sum(bitmap_size(sg.getSize()) for sg in segs if sg.kind == "file" and sg.getSize() >= pmin) \
-            if fetched_per_launch < bytes_per_launch else 0
-        moved = fetched_per_launch + bitmap_bytes
-        moved_gbs = moved / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc FETCH_SIZE pass (tools/pmc_traffic.sh),
-        # stored with its calibration under profiles/; it is reported only for the configuration it was measured on
-        traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            c = tr["config"]
-            if world == 1 and (c["docs"], c["segments"], c["hashes_per_doc"], c["batch"], c["query_len"]) == (docs, S, H, B, args.query_len):
-                traffic = tr["k_probe_lean8"]["hbm_read_bytes_per_launch_corrected"]
-        except (OSError, KeyError, ValueError):
-            pass
+        launches = max(1, int(agg.v["probe_launches"]))
+        avg_ms = agg.v["probe_kernel_ms"] / launches
+        ref_bytes = agg.v["probe_kernel_bytes"] / launches        # 512 B per block the REFERENCE visits
+        fetched = agg.v["probe_kernel_fetched_bytes"] / launches  # blocks the kernel really read
+        probes = agg.v["probes"] / max(1, agg.steps)
+        moved = model_moved_bytes(segs, fetched, probes)
+        moved_gbs = moved["total"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        ref_gbs = ref_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         result = {
-            "metric": "queries/sec + p50 /_search latency, 100M-fp index, 1k-hash queries",
+            "metric": METRIC,
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
@@ -292,24 +502,30 @@ def main():
                                    f"limit {args.limit}, min_score (n+19)/20, score_pct 10; queries resident in HBM",
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
-                       "index_build_seconds": round(build_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean8", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                         "note": "achieved = SURVEY 8(d)'s algorithmic bytes (512 B per block the reference visits) / kernel time; "
-                                 "above 1.0 of the peak because the presence bitmaps answer the probes of absent hashes without "
-                                 "fetching their blocks -- `moved` is what the kernel has to read instead, `traffic` what the PMC saw",
-                         "moved": {"block_bytes_per_launch": fetched_per_launch, "presence_bitmap_bytes_per_launch": bitmap_bytes,
-                                   "achieved": moved_gbs, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS},
-                         "all_probe_passes": {"algorithmic_bytes_per_step": agg["bytes"] / max(1, args.steps),
-                                              "ms_per_step": (agg["probe_ms"] + agg["aux_ms"]) / max(1, args.steps),
-                                              "visited_blocks_per_step": agg["blocks"] / max(1, args.steps),
-                                              "blocks_finished_by_generic_pass_per_step": agg["generic"] / max(1, args.steps)}},
+                       "index_build_seconds": round(build_s, 2), "shrunk_to_fit": shrunk},
+            # achieved / frac: PHYSICAL bytes of the dominant kernel per launch / its HIP-event time / peak.  Filled with the
+            # model here and replaced by the in-run PMC figure below when the rocprofv3 child pass succeeds.
+            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean8", "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": moved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "achieved_basis": "model",
+                         "avg_launch_ms": avg_ms, "launches_timed": launches,
+                         "moved_model": {**moved, "GBs": moved_gbs, "frac": moved_gbs / HBM_PEAK_GBS,
+                                         "note": "blocks the kernel fetched (counted by the kernel) + the 128-B lines of presence bitmaps, bucket tables and "
+                                                 "block records its probes touch (expected value for uniform hashes)"},
+                         "reference_equivalent": {"bytes_per_launch": ref_bytes, "GBs": ref_gbs, "over_peak": ref_gbs / HBM_PEAK_GBS,
+                                                  "note": "SURVEY 8(d)'s algorithmic figure: 512 B for every block the REFERENCE visits.  NOT a roofline "
+                                                          "fraction: the presence bitmaps answer the probes of absent hashes without reading their block, "
+                                                          "so it may exceed the peak"},
+                         "all_probe_passes": {"algorithmic_bytes_per_step": agg.v["algorithmic_bytes"] / max(1, args.steps),
+                                              "ms_per_step": (agg.v["probe_kernel_ms"] + agg.v["probe_aux_ms"]) / max(1, args.steps),
+                                              "visited_blocks_per_step": agg.v["scanned_blocks"] / max(1, args.steps),
+                                              "blocks_finished_by_generic_pass_per_step": agg.v["generic_iters"] / max(1, args.steps)}},
             "inflight": nfl,
             **({"emulated_rank_of_world": eworld, "note": "ONE rank's share of a sharded run emulated on one GPU: not a result"} if eworld > 1 else {}),
-            "gpu_ms_per_step": agg["gpu_ms"] / max(1, args.steps),
-            "hits_per_step": agg["hits"] / max(1, args.steps),
+            "gpu_ms_per_step": agg.v["total_gpu_ms"] / max(1, args.steps),
+            "hits_per_step": agg.v["hits"] / max(1, args.steps),
             "targets_found": found, "targets_total": B, "median_top_score": int(np.median(top_scores)) if top_scores else 0,
+            "kernel_source_sha16": kernel_source_hash(),
         }
         if not args.no_measure_bw:
             s_gbs, r_gbs = ctx.measure_bandwidth(8 << 30, 512)
@@ -317,34 +533,109 @@ def main():
             # second denominator: what this box sustains for the kernel's own access pattern
             result["roofline"]["peak_measured_random_512B"] = r_gbs
             result["roofline"]["peak_measured_stream"] = s_gbs
-            if traffic:
-                # the kernel's reads are a mix now: random 512-B blocks + the streamed bitmaps
-                result["roofline"]["hbm_read_GBs"] = traffic / (agg["probe_ms"] / max(1, agg["launches"]) * 1e-3) / 1e9
 
-    # ---- p50 latency of a single /_search (batch of 1), rank-local index share only when sharded
-    if rank == 0 and world == 1 and not args.no_latency:
-        lat = []
-        one = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(32)]
-        r1 = fpx.SearchResults(opts)
-        for i in range(32):
-            t1 = time.perf_counter()
-            reader.search(one[i], r1)
-            lat.append((time.perf_counter() - t1) * 1e3)
-        result["p50_single_search_ms"] = float(np.median(lat[4:]))
+    # ---- the same index at other batch sizes (resident batches, one in flight), incl. BASELINE.md's 1024 for this row
+    if extras and not args.no_latency:
+        rows = []
+        for b2, k2 in ((1, 200), (64, 60), (256, 40), (1024, 30)):
+            if b2 >= B:
+                continue
+            sub = fpx.QueryBatch(ctx, options=opts, flat=(np.ascontiguousarray(flat[:int(offsets[b2])]), np.ascontiguousarray(offsets[:b2 + 1])))
+            if b2 == 1:
+                # B = 1 is the single /_search: the fpx_search entry point, per-call latency
+                one = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(32)]
+                r1 = fpx.SearchResults(opts)
+                lat = []
+                for i in range(8 + k2):
+                    t1 = time.perf_counter()
+                    reader.search(one[i % 32], r1)
+                    lat.append((time.perf_counter() - t1) * 1e3)
+                lat = np.array(lat[8:])
+                rows.append({"batch": 1, "steps": k2, "ms_per_step": float(lat.mean()), "queries_per_s": 1e3 / float(lat.mean()),
+                             "latency_ms_p50": float(np.percentile(lat, 50)), "latency_ms_p99": float(np.percentile(lat, 99)),
+                             "entry_point": "fpx_search (host buffers in, results out: PCIe-inclusive)"})
+                result["p50_single_search_ms"] = float(np.percentile(lat, 50))
+            else:
+                dt2, agg2, _, _ = timed_resident(fpx, reader, sub, k2, 3)
+                rows.append(row_from(b2, k2, dt2, agg2, segs))
+            sub.release()
+        rows.append({"batch": B, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "queries_per_s": qps,
+                     "probe_kernel_ms": result["roofline"]["avg_launch_ms"],
+                     "probe_kernel_fetched_block_bytes": agg.v["probe_kernel_fetched_bytes"] / max(1, agg.v["probe_launches"]),
+                     "moved_bytes_model": result["roofline"]["moved_model"]["total"], "hbm_frac_model": result["roofline"]["moved_model"]["frac"],
+                     "reference_visited_block_bytes": agg.v["probe_kernel_bytes"] / max(1, agg.v["probe_launches"]), "headline": True})
+        result["by_batch"] = rows
 
-    # ---- CPU baseline on rank 0 at N = 1
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- end to end: the batch handed over in pageable host memory (H2D of the hashes + D2H of the results inside)
+    if extras:
+        copts = qb.copts
+        for _ in range(2):
+            reader.search_batch_raw(flat, qb.offsets, copts, cap)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k3 = max(5, args.steps // 2)
+        for _ in range(k3):
+            reader.search_batch_raw(flat, qb.offsets, copts, cap)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t1
+        result["end_to_end"] = {"queries_per_s": B * k3 / dt3, "ms_per_step": dt3 / k3 * 1e3, "steps": k3, "batch": B,
+                                "entry_point": "fpx_search_batch from pageable host memory",
+                                "h2d_bytes_per_step": int(flat.nbytes + qb.offsets.nbytes + 16 * B), "d2h_bytes_per_step": int(B * cap * 8 + B * 4),
+                                "over_resident": (B * k3 / dt3) / qps}
+
+    # ---- CPU baseline on rank 0 at N = 1: the whole index in host RAM, pthread executor pool
+    if rank == 0 and world == 1 and eworld <= 1 and not args.no_cpu_baseline:
         from oracle import oracle
         nq = min(args.cpu_queries, B)
-        seg0 = segs[0]
-        single = fpx.IndexReader(fpx.Segments(ctx, [seg0]))
-        sub = fpx.QueryBatch(ctx, options=opts, flat=(np.ascontiguousarray(flat[:int(offsets[nq])]), offsets[:nq + 1]))
-        o1, n1, _ = fpx.search_resident(single, sub)
-        gpu_single = fpx.results_to_lists(o1, n1)
-        result["cpu_baseline"] = cpu_baseline(fpx, oracle, ctx, seg0, 1, per, flat, offsets, nq, S, gpu_single,
-                                              target_s=args.cpu_seconds)
+        gpu_lists = fpx.results_to_lists(out[:nq], out_n[:nq])
+        result["cpu_baseline"] = cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, args.cpu_seconds)
     elif rank == 0:
         result["cpu_baseline"] = None
+
+    # ---- release the big index; BASELINE.json configs[1] (10 M fingerprints in ONE segment, batch 1024) and the PMC child
+    if extras:
+        qb.release()
+        snapshot.release()
+        for s in segs:
+            s.release()
+        del reader, snapshot, segs
+        torch.cuda.synchronize()
+        try:
+            d1, b1 = 10_000_000, 1024
+            s1, _ = synth_index(fpx, ctx, args.seed, d1, 1, H, {0})
+            snap1 = fpx.Segments(ctx, s1)
+            r1 = fpx.IndexReader(snap1)
+            f1, o1, t1 = fpx.synth.make_queries(args.seed, 4242, b1, d1, H, query_len=args.query_len)
+            q1 = fpx.QueryBatch(ctx, options=opts, flat=(f1, o1))
+            dtc, aggc, oc, onc = timed_resident(fpx, r1, q1, 40, 5)
+            row = row_from(b1, 40, dtc, aggc, s1)
+            row["workload"] = f"BASELINE.json configs[1]: {d1} fingerprints x {H} hashes in 1 FileSegment ({s1[0].num_blocks} blocks), batch {b1} x {args.query_len} hashes"
+            row["targets_found"] = int(sum(1 for q in range(b1) if onc[q] > 0 and oc[q, 0, 0] == t1[q]))
+            result["config1"] = row
+            q1.release()
+            snap1.release()
+            s1[0].release()
+            del r1, snap1, s1
+        except Exception as e:                     # the headline stands without it
+            result["config1"] = {"error": str(e)}
+        torch.cuda.synchronize()
+        traffic, src = None, None
+        if not args.no_pmc and os.environ.get("FPX_BENCH_PMC", "1") != "0":
+            t_p = time.perf_counter()
+            pmc, err = run_pmc_child(args, docs)
+            if pmc:
+                traffic, src = pmc["hbm_read_bytes_per_launch"], "in-run: rocprofv3 --pmc FETCH_SIZE child pass of this script"
+                result["roofline"]["pmc"] = {**pmc, "seconds": round(time.perf_counter() - t_p, 1)}
+            else:
+                result["roofline"]["pmc"] = {"error": err}
+        if traffic is None:
+            traffic, src = stored_traffic(docs, S, H, B, args.query_len)
+        if traffic is not None:
+            rf = result["roofline"]
+            gbs = traffic / (rf["avg_launch_ms"] * 1e-3) / 1e9
+            rf.update({"traffic": traffic, "traffic_source": src, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                       "achieved_basis": "HBM read bytes by PMC (FETCH_SIZE, calibrated in the same pass) per launch / HIP-event time of the "
+                                         "unprofiled launches in this run"})
 
     if world > 1:
         dist.barrier()

@@ -14,8 +14,12 @@
  */
 #include "fpx_oracle.h"
 
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -939,30 +943,32 @@ static int cmp_result(const void *a, const void *b)     /* compareResults (src/c
     return x->id < y->id ? -1 : x->id > y->id;
 }
 
-int orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
-               uint32_t max_results, uint32_t min_score_opt, uint32_t min_score_pct,
-               orc_result *out, uint32_t out_cap, orc_stats *stats)
+/* the body of orc_search over a caller-owned hit map (cleared here, capacity retained: the reference recycles its
+ * collectors through SearchResultsPool, src/common.zig:186-300) */
+static int search_with_map(const orc_snapshot *snap, hit_map *m, const uint32_t *hashes, uint32_t n,
+                           uint32_t max_results, uint32_t min_score_opt, uint32_t min_score_pct,
+                           orc_result *out, uint32_t out_cap, orc_stats *stats)
 {
-    hit_map m;
-    if (map_init(&m, 1024)) return -1;
+    memset(m->slots, 0, m->cap * sizeof(hit_slot));
+    m->count = 0; m->has_zero = 0; m->oom = 0;
     if (stats) memset(stats, 0, sizeof *stats);
-    if (run_scans(snap, hashes, n, &m, stats)) { free(m.slots); return -1; }
-    if (stats) stats->hits_unique = m.count + (size_t)m.has_zero;
+    if (run_scans(snap, hashes, n, m, stats)) return -1;
+    if (stats) stats->hits_unique = m->count + (size_t)m->has_zero;
 
     /* finish (src/common.zig:131-167) */
     uint32_t min_score = min_score_opt;
     size_t nc = 0;
-    orc_result *cand = (orc_result *)malloc((m.count + 2) * sizeof(orc_result));
-    if (!cand) { free(m.slots); return -1; }
-    for (size_t i = 0; i < m.cap; i++)
-        if (m.slots[i].id && m.slots[i].score >= min_score) { cand[nc].id = m.slots[i].id; cand[nc].score = m.slots[i].score; nc++; }
-    if (m.has_zero && m.zero.score >= min_score) { cand[nc].id = 0; cand[nc].score = m.zero.score; nc++; }
+    orc_result *cand = (orc_result *)malloc((m->count + 2) * sizeof(orc_result));
+    if (!cand) return -1;
+    for (size_t i = 0; i < m->cap; i++)
+        if (m->slots[i].id && m->slots[i].score >= min_score) { cand[nc].id = m->slots[i].id; cand[nc].score = m->slots[i].score; nc++; }
+    if (m->has_zero && m->zero.score >= min_score) { cand[nc].id = 0; cand[nc].score = m->zero.score; nc++; }
     qsort(cand, nc, sizeof(orc_result), cmp_result);
 
     uint32_t outn = 0;
     for (size_t i = 0; i < nc; i++) {
         if (outn == max_results) break;
-        int f; hit_slot *h = map_slot(&m, cand[i].id, &f);
+        int f; hit_slot *h = map_slot(m, cand[i].id, &f);
         if (orc_snapshot_has_newer_commit(snap, cand[i].id, h->commit_id)) continue;
         if (cand[i].score < min_score) break;
         if (outn == 0) {
@@ -974,8 +980,112 @@ int orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
         if (outn < out_cap) out[outn] = cand[i];
         outn++;
     }
-    free(cand); free(m.slots);
+    free(cand);
     return (int)(outn < out_cap ? outn : out_cap);
+}
+
+int orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
+               uint32_t max_results, uint32_t min_score_opt, uint32_t min_score_pct,
+               orc_result *out, uint32_t out_cap, orc_stats *stats)
+{
+    hit_map m;
+    if (map_init(&m, 1024)) return -1;
+    int rc = search_with_map(snap, &m, hashes, n, max_results, min_score_opt, min_score_pct, out, out_cap, stats);
+    free(m.slots);
+    return rc;
+}
+
+/* ======================================================================= */
+/* Many searches at once: the CPU baseline of bench.py                       */
+/* ======================================================================= */
+/* The reference serves searches from N OS-thread executors, each running one search at a time on the shared immutable
+ * snapshot (zio.Runtime.init(.executors = .auto), src/main.zig:272-276; lock-free readers, src/Index.zig:1-6), with
+ * pooled collectors (SearchResultsPool, src/common.zig:186-300).  orc_search_many does the same with pthreads:
+ * `nthreads` persistent workers pull query indices off one atomic counter, each with its own recycled hit map, and keep
+ * cycling over the query set until `min_seconds` have passed (every query at least once). */
+typedef struct {
+    const orc_snapshot *snap;
+    const uint32_t *hashes; const uint64_t *offsets; uint32_t nq;
+    uint32_t max_results; int has_min_score; uint32_t min_score; uint32_t min_score_pct;
+    orc_result *out; uint32_t out_cap; uint32_t *out_n;
+    float *lat_ms; uint64_t lat_cap;
+    double min_seconds;
+    struct timespec t0;
+    atomic_ullong next, done;
+    atomic_int stop, failed, go;
+} many_job;
+
+static double seconds_since(const struct timespec *t0)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)(t.tv_sec - t0->tv_sec) + 1e-9 * (double)(t.tv_nsec - t0->tv_nsec);
+}
+
+static void *many_worker(void *arg)
+{
+    many_job *j = (many_job *)arg;
+    hit_map m;
+    int have_map = map_init(&m, 1024) == 0;
+    orc_result *tmp = (orc_result *)malloc((j->out_cap ? j->out_cap : 1) * sizeof(orc_result));
+    if (!have_map || !tmp) atomic_store(&j->failed, 1);
+    while (!atomic_load_explicit(&j->go, memory_order_acquire)) sched_yield();
+    while (have_map && tmp && !atomic_load_explicit(&j->stop, memory_order_relaxed)) {
+        const unsigned long long i = atomic_fetch_add(&j->next, 1ull);
+        const uint32_t q = (uint32_t)(i % j->nq);
+        const uint32_t *h = j->hashes + j->offsets[q];
+        const uint32_t n = (uint32_t)(j->offsets[q + 1] - j->offsets[q]);
+        const uint32_t floor_ = j->has_min_score ? j->min_score : orc_default_min_score(n);
+        const double t_a = seconds_since(&j->t0);
+        /* results are kept from the first pass only (later passes recompute the same lists) */
+        orc_result *dst = i < j->nq ? j->out + (size_t)q * j->out_cap : tmp;
+        const int r = search_with_map(j->snap, &m, h, n, j->max_results, floor_, j->min_score_pct, dst, j->out_cap, NULL);
+        const double t_b = seconds_since(&j->t0);
+        if (r < 0) { atomic_store(&j->failed, 1); break; }
+        if (i < j->nq) j->out_n[q] = (uint32_t)r;
+        if (j->lat_ms && i < j->lat_cap) j->lat_ms[i] = (float)((t_b - t_a) * 1e3);
+        atomic_fetch_add(&j->done, 1ull);
+        if (t_b >= j->min_seconds && i + 1 >= j->nq) {
+            /* time is up -- but the first pass must be complete: every index below nq has been handed out once
+             * `next` >= nq, and the workers holding one finish it before they look at `stop` again */
+            if (atomic_load(&j->next) >= j->nq) atomic_store(&j->stop, 1);
+        }
+    }
+    if (have_map) free(m.slots);
+    free(tmp);
+    return NULL;
+}
+
+int orc_search_many(const orc_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets, uint32_t nq,
+                    uint32_t max_results, int has_min_score, uint32_t min_score, uint32_t min_score_pct,
+                    uint32_t nthreads, double min_seconds,
+                    orc_result *out, uint32_t out_cap, uint32_t *out_n,
+                    float *latency_ms, uint64_t latency_cap,
+                    double *wall_seconds, uint64_t *queries_done)
+{
+    if (!snap || !offsets || !out_n || nq == 0 || nthreads == 0) return -1;
+    many_job j;
+    memset(&j, 0, sizeof j);
+    j.snap = snap; j.hashes = hashes; j.offsets = offsets; j.nq = nq;
+    j.max_results = max_results; j.has_min_score = has_min_score; j.min_score = min_score; j.min_score_pct = min_score_pct;
+    j.out = out; j.out_cap = out_cap; j.out_n = out_n; j.lat_ms = latency_ms; j.lat_cap = latency_cap;
+    j.min_seconds = min_seconds;
+    atomic_init(&j.next, 0ull); atomic_init(&j.done, 0ull); atomic_init(&j.stop, 0); atomic_init(&j.failed, 0);
+    pthread_t *th = (pthread_t *)malloc(nthreads * sizeof(pthread_t));
+    if (!th) return -1;
+    atomic_init(&j.go, 0);
+    uint32_t started = 0;
+    for (; started < nthreads; started++)
+        if (pthread_create(&th[started], NULL, many_worker, &j)) break;
+    if (started < nthreads) { atomic_store(&j.stop, 1); atomic_store(&j.failed, 1); }
+    clock_gettime(CLOCK_MONOTONIC, &j.t0);
+    atomic_store_explicit(&j.go, 1, memory_order_release);
+    for (uint32_t k = 0; k < started; k++) pthread_join(th[k], NULL);
+    const double wall = seconds_since(&j.t0);
+    free(th);
+    if (wall_seconds) *wall_seconds = wall;
+    if (queries_done) *queries_done = (uint64_t)atomic_load(&j.done);
+    return atomic_load(&j.failed) ? -1 : 0;
 }
 
 int orc_search_hits(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,

@@ -136,6 +136,19 @@ int  orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
                 uint32_t max_results, uint32_t min_score, uint32_t min_score_pct,
                 orc_result *out, uint32_t out_cap, orc_stats *stats);
 
+/* Many searches at once -- the CPU baseline of bench.py.  `nthreads` persistent workers, one search per thread at a time
+ * on the shared snapshot with recycled collectors, as the reference's executors do (src/main.zig:272-276,
+ * src/common.zig:186-300).  Query q is hashes[offsets[q] .. offsets[q+1]); has_min_score == 0 -> (raw_len + 19) / 20.
+ * The workers cycle over the query set until min_seconds have passed (every query at least once); the results of the
+ * FIRST pass go to out[q * out_cap ..] / out_n[q]; latency_ms[i] is the duration of the i-th search handed out
+ * (i < latency_cap).  wall_seconds / queries_done give the throughput.  Returns 0, -1 on failure. */
+int  orc_search_many(const orc_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets, uint32_t nq,
+                     uint32_t max_results, int has_min_score, uint32_t min_score, uint32_t min_score_pct,
+                     uint32_t nthreads, double min_seconds,
+                     orc_result *out, uint32_t out_cap, uint32_t *out_n,
+                     float *latency_ms, uint64_t latency_cap,
+                     double *wall_seconds, uint64_t *queries_done);
+
 /* The hit map after the segment scans and before finish (id, commit_id, score), for tests
  * that pin `results.hits.get(id).score` (src/filefmt.zig:336-337, src/Index.zig:1079). */
 int  orc_search_hits(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,

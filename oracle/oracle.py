@@ -89,6 +89,8 @@ def lib():
         "orc_search": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32,
                                  C.POINTER(Stats)]),
         "orc_search_hits": (C.c_int, [vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32]),
+        "orc_search_many": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                      vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "orc_mix64": (C.c_uint64, [C.c_uint64]),
         "orc_synth_hash": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
         "orc_synth_items": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]),
@@ -346,6 +348,28 @@ class Snapshot:
             raise MemoryError("orc_search")
         res = [(out[i].id, out[i].score) for i in range(n)]
         return (res, st) if with_stats else res
+
+    def search_many(self, flat, offsets, max_results=40, min_score=None, min_score_pct=10, nthreads=1, min_seconds=0.0):
+        """orc_search_many: one search per thread on `nthreads` persistent workers cycling over the query set for at
+        least `min_seconds` (every query at least once).  Returns (out [nq, cap, 2] u32, out_n [nq], report) where
+        report = {"wall_s", "queries_done", "latency_ms" (one entry per search executed, in hand-out order)}."""
+        flat = np.ascontiguousarray(flat, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nq = len(offsets) - 1
+        cap = max(1, max_results)
+        out = np.zeros((nq, cap, 2), np.uint32)
+        out_n = np.zeros(nq, np.uint32)
+        lat_cap = max(nq, 1 << 20)
+        lat = np.full(lat_cap, np.nan, np.float32)
+        wall, done = C.c_double(), C.c_uint64()
+        rc = lib().orc_search_many(self.h, _ptr(flat if len(flat) else np.zeros(1, np.uint32)), _ptr(offsets), nq, max_results,
+                                   0 if min_score is None else 1, 0 if min_score is None else min_score, min_score_pct,
+                                   nthreads, float(min_seconds), _ptr(out), cap, _ptr(out_n), _ptr(lat), lat_cap,
+                                   C.byref(wall), C.byref(done))
+        if rc != 0:
+            raise MemoryError("orc_search_many")
+        lat = lat[:min(lat_cap, done.value)]
+        return out, out_n, {"wall_s": wall.value, "queries_done": done.value, "latency_ms": lat[~np.isnan(lat)]}
 
     def hits(self, hashes):
         """hit map before finish: {id: (commit_id, score)}"""

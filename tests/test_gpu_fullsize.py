@@ -10,7 +10,7 @@
 * the oracle itself on a bounded sample: a few queries against ONE segment downloaded from HBM, bit-exact.
 
 The indexes are synthetic (fpx_synth_segment, byte-exact w.r.t. the reference writer -- tests/test_gpu_builder.py) and
-shrink by halves if the device has less free HBM than the configuration needs."""
+FAIL when the device has less free HBM than the configuration needs (FPX_ALLOW_SHRINK=1 shrinks by halves instead)."""
 import numpy as np
 import pytest
 
@@ -19,17 +19,32 @@ pytestmark = pytest.mark.gpu
 SEED = 20260928
 
 
-def _build(fpx, ctx, docs, H, S, est_bytes_per_item=5.4):
+def _fit(docs, need_bytes, what):
+    """The configurations are NOT shrunk to fit: on a box with too little free HBM the test FAILS (a green run must mean
+    the full size ran).  FPX_ALLOW_SHRINK=1 halves `docs` until it fits, for development boxes."""
+    import os
     import torch
     free_b, _ = torch.cuda.mem_get_info()
-    want_docs = docs
-    while docs * H * est_bytes_per_item + (docs // S) * H * 8 * 2.3 + (6 << 30) > free_b * 0.9 and docs > 2_000_000:
-        docs //= 2
-    if docs != want_docs:
+    want = docs
+    if need_bytes(docs) > free_b * 0.9:
+        if os.environ.get("FPX_ALLOW_SHRINK") != "1":
+            pytest.fail(f"{what}: {want} fingerprints need ~{need_bytes(docs) >> 30} GiB of HBM, {free_b >> 30} GiB are free "
+                        f"(FPX_ALLOW_SHRINK=1 runs a smaller index instead)")
+        while need_bytes(docs) > free_b * 0.9 and docs > 2_000_000:
+            docs //= 2
         import warnings
-        warnings.warn(f"full-size test shrunk from {want_docs} to {docs} fingerprints: only {free_b >> 30} GiB of HBM free")
+        warnings.warn(f"{what} shrunk from {want} to {docs} fingerprints (FPX_ALLOW_SHRINK=1): only {free_b >> 30} GiB of HBM free")
+    return docs
+
+
+def _build(fpx, ctx, docs, H, S, est_bytes_per_item=5.4, dist=0, scratch=6 << 30):
+    want = docs
+    docs = _fit(docs, lambda d: int(d * H * est_bytes_per_item + (d // S) * H * 8 * 2.3) + scratch, f"{want} x {H} in {S} segments")
     per = docs // S
-    segs = [fpx.FileSegment.synth(ctx, SEED, s * per + 1, per, H, 0, 512, s + 1) for s in range(S)]
+    segs = [fpx.FileSegment.synth(ctx, SEED, s * per + 1, per, H, dist, 512, s + 1) for s in range(S)]
+    import os
+    if os.environ.get("FPX_ALLOW_SHRINK") != "1":
+        assert per * S == (want // S) * S, "the full-size configuration must run at full size"
     return segs, per, per * S
 
 
@@ -86,6 +101,9 @@ def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192():
     ctx = fpx.Context(0)
     H, S, B, L, limit = 256, 16, 8192, 1000, 40
     segs, per, docs = _build(fpx, ctx, 100_000_000, H, S)
+    import os
+    if os.environ.get("FPX_ALLOW_SHRINK") != "1":
+        assert docs == 100_000_000
     reader = fpx.IndexReader(fpx.Segments(ctx, segs))
     flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
     opts = fpx.http_options(limit=limit)
@@ -148,6 +166,18 @@ def test_config4_share_of_one_rank_125m_fingerprints_120_hashes_limit_100():
     _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
     assert st.probes == _unique_per_query(flat, offsets) * S
     _oracle_sample(fpx, oracle, ctx, segs[15], 15 * per + 1, per, flat, offsets, opts, 16)
+    # the same share with SURVEY 8(d)'s distribution Z (hot-hash pool: the 4-block / 1000-doc caps at work), oracle sample
+    del reader, qb
+    for sg in segs:
+        sg.release()
+    segs, per, docs = _build(fpx, ctx, 125_000_000, H, S, est_bytes_per_item=5.0, dist=1, scratch=30 << 30)
+    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L, dist=1)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    out, out_n, st = fpx.search_resident(reader, qb)
+    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+    assert st.probes == _unique_per_query(flat, offsets) * S
+    _oracle_sample(fpx, oracle, ctx, segs[9], 9 * per + 1, per, flat, offsets, opts, 12)
 
 
 def test_config2_with_hot_hashes_at_full_size():
@@ -158,12 +188,7 @@ def test_config2_with_hot_hashes_at_full_size():
     from fpx_testlib import fpx, oracle
     ctx = fpx.Context(0)
     H, S, B, L, limit = 256, 16, 8192, 1000, 40
-    free_b, _ = torch.cuda.mem_get_info()
-    docs = 100_000_000
-    while docs * H * 5.4 + (30 << 30) > free_b * 0.9 and docs > 2_000_000:
-        docs //= 2
-    per = docs // S
-    segs = [fpx.FileSegment.synth(ctx, SEED, s * per + 1, per, H, 1, 512, s + 1) for s in range(S)]
+    segs, per, docs = _build(fpx, ctx, 100_000_000, H, S, dist=1, scratch=30 << 30)
     reader = fpx.IndexReader(fpx.Segments(ctx, segs))
     flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, per * S, H, query_len=L, dist=1)
     opts = fpx.http_options(limit=limit)

@@ -160,3 +160,37 @@ def test_brute_force_reproduces_reference_vectors():
             mr, ms, pct = (40, None, 10) if chk.get("http") else (chk["max_results"], chk["min_score"], chk["min_score_pct"])
             got, _, _ = brute_search(raws, chk["query"], mr, ms, pct)
             assert [list(r) for r in got] == chk["expect"], s["name"]
+
+
+def test_search_many_equals_single_searches(orc):
+    """orc_search_many (pthread workers with recycled collectors: bench.py's CPU baseline) returns exactly what
+    orc_search returns query by query, for any thread count, with and without the default floor."""
+    import numpy as np
+    seed, ndocs, H = 31, 3000, 48
+    items = orc.synth_items(seed, 1, ndocs, H, dist=1)
+    half = ndocs // 2
+    a = items[(items & 0xFFFFFFFF) <= half]
+    b = items[(items & 0xFFFFFFFF) > half]
+    segs = []
+    for part, lo, hi, cid in ((a, 1, half, 1), (b, half + 1, ndocs, 2)):
+        blocks, index = orc.build_blocks(part, lo, 512)
+        segs.append(orc.file_segment(blocks, 512, index, lo, hi, cid, np.arange(lo, hi + 1, dtype=np.uint32)))
+    snap = orc.Snapshot(segs, [])
+    rng = np.random.default_rng(5)
+    queries = []
+    for i in range(40):
+        d = int(rng.integers(1, ndocs + 1))
+        own = np.array([orc.synth_hash(seed, d, j, 1) for j in range(H)], np.uint32)
+        queries.append(np.concatenate([own, rng.integers(0, 2**32, int(rng.integers(0, 60)), dtype=np.uint64).astype(np.uint32)]))
+    queries.append(np.zeros(0, np.uint32))
+    lens = np.array([len(q) for q in queries], np.uint64)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    flat = np.concatenate(queries).astype(np.uint32)
+    for (mr, ms, pct) in ((40, None, 10), (5, 1, 50), (500, 1, 0)):
+        want = [snap.search(q, mr, ms, pct) for q in queries]
+        for nthreads, secs in ((1, 0.0), (7, 0.0), (16, 0.05)):
+            out, out_n, rep = snap.search_many(flat, offsets, mr, ms, pct, nthreads=nthreads, min_seconds=secs)
+            got = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(int(out_n[q]))] for q in range(len(queries))]
+            assert got == want
+            assert rep["queries_done"] >= len(queries) and len(rep["latency_ms"]) >= len(queries)
+            assert rep["wall_s"] >= secs

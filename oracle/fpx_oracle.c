@@ -856,11 +856,11 @@ static void results_incr(hit_map *m, uint32_t id, uint64_t commit_id)
 
 typedef struct { size_t block_no; block_reader reader; } cache_entry;
 
+/* `cache`: MAX_BLOCKS_PER_HASH reader slots owned by the caller (the reference keeps them on the search's stack,
+ * src/FileSegment.zig:138-141) */
 static int file_segment_search(const orc_segment *seg, const uint32_t *sorted_hashes, size_t n,
-                               hit_map *results, orc_stats *st)
+                               hit_map *results, orc_stats *st, cache_entry *cache)
 {
-    cache_entry *cache = (cache_entry *)malloc(sizeof(cache_entry) * MAX_BLOCKS_PER_HASH);
-    if (!cache) return -1;
     for (int i = 0; i < MAX_BLOCKS_PER_HASH; i++) { cache[i].block_no = (size_t)-1; cache[i].reader.min_doc_id = seg->min_doc_id; }
 
     size_t prev = 0;
@@ -896,7 +896,6 @@ static int file_segment_search(const orc_segment *seg, const uint32_t *sorted_ha
         }
         if (st) { st->scanned_blocks += num_blocks; st->scanned_docs += num_docs; st->probes += 1; }
     }
-    free(cache);
     return results->oom ? -1 : 0;
 }
 
@@ -920,19 +919,44 @@ static int memory_segment_search(const orc_segment *seg, const uint32_t *sorted_
 
 uint32_t orc_default_min_score(uint32_t raw_query_len) { return (uint32_t)(((uint64_t)raw_query_len + 19) / 20); } /* MultiIndex.zig:304 */
 
-/* sort + dedupSorted (src/Index.zig:171-172, :489-499) then the segment scans (:173-175) */
-static int run_scans(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n, hit_map *m, orc_stats *st)
+/* Per-search working memory.  The reference takes it from a per-request arena and a pooled collector
+ * (src/MultiIndex.zig:300-312, src/common.zig:186-300); a worker of orc_search_many keeps one of these for its lifetime
+ * so that concurrent searches never meet in the allocator. */
+typedef struct {
+    uint32_t *q; size_t qcap;                 /* sorted + deduped copy of the query */
+    cache_entry *cache;                       /* MAX_BLOCKS_PER_HASH block readers */
+    orc_result *cand; size_t ccap;            /* finish()'s candidate list */
+} search_scratch;
+
+static void scratch_free(search_scratch *sc) { free(sc->q); free(sc->cache); free(sc->cand); memset(sc, 0, sizeof *sc); }
+
+static int scratch_reserve(search_scratch *sc, size_t n)
 {
-    uint32_t *q = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
-    if (!q) return -1;
+    if (!sc->cache) {
+        sc->cache = (cache_entry *)malloc(sizeof(cache_entry) * MAX_BLOCKS_PER_HASH);
+        if (!sc->cache) return -1;
+    }
+    if (n + 1 > sc->qcap) {
+        free(sc->q);
+        sc->qcap = (n + 1) * 2;
+        sc->q = (uint32_t *)malloc(sc->qcap * sizeof(uint32_t));
+        if (!sc->q) { sc->qcap = 0; return -1; }
+    }
+    return 0;
+}
+
+/* sort + dedupSorted (src/Index.zig:171-172, :489-499) then the segment scans (:173-175) */
+static int run_scans(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n, hit_map *m, orc_stats *st, search_scratch *sc)
+{
+    if (scratch_reserve(sc, n)) return -1;
+    uint32_t *q = sc->q;
     memcpy(q, hashes, (size_t)n * sizeof(uint32_t));
     qsort(q, n, sizeof(uint32_t), cmp_u32);
     uint32_t w = 0;
     if (n) { w = 1; for (uint32_t i = 1; i < n; i++) if (q[i] != q[w - 1]) q[w++] = q[i]; }
     int rc = 0;
-    for (uint32_t i = 0; i < snap->n_file && !rc; i++) rc = file_segment_search(snap->file[i], q, w, m, st);
+    for (uint32_t i = 0; i < snap->n_file && !rc; i++) rc = file_segment_search(snap->file[i], q, w, m, st, sc->cache);
     for (uint32_t i = 0; i < snap->n_memory && !rc; i++) rc = memory_segment_search(snap->memory[i], q, w, m);
-    free(q);
     return rc;
 }
 
@@ -945,21 +969,26 @@ static int cmp_result(const void *a, const void *b)     /* compareResults (src/c
 
 /* the body of orc_search over a caller-owned hit map (cleared here, capacity retained: the reference recycles its
  * collectors through SearchResultsPool, src/common.zig:186-300) */
-static int search_with_map(const orc_snapshot *snap, hit_map *m, const uint32_t *hashes, uint32_t n,
+static int search_with_map(const orc_snapshot *snap, hit_map *m, search_scratch *sc, const uint32_t *hashes, uint32_t n,
                            uint32_t max_results, uint32_t min_score_opt, uint32_t min_score_pct,
                            orc_result *out, uint32_t out_cap, orc_stats *stats)
 {
     memset(m->slots, 0, m->cap * sizeof(hit_slot));
     m->count = 0; m->has_zero = 0; m->oom = 0;
     if (stats) memset(stats, 0, sizeof *stats);
-    if (run_scans(snap, hashes, n, m, stats)) return -1;
+    if (run_scans(snap, hashes, n, m, stats, sc)) return -1;
     if (stats) stats->hits_unique = m->count + (size_t)m->has_zero;
 
     /* finish (src/common.zig:131-167) */
     uint32_t min_score = min_score_opt;
     size_t nc = 0;
-    orc_result *cand = (orc_result *)malloc((m->count + 2) * sizeof(orc_result));
-    if (!cand) return -1;
+    if (m->count + 2 > sc->ccap) {
+        free(sc->cand);
+        sc->ccap = (m->count + 2) * 2;
+        sc->cand = (orc_result *)malloc(sc->ccap * sizeof(orc_result));
+        if (!sc->cand) { sc->ccap = 0; return -1; }
+    }
+    orc_result *cand = sc->cand;
     for (size_t i = 0; i < m->cap; i++)
         if (m->slots[i].id && m->slots[i].score >= min_score) { cand[nc].id = m->slots[i].id; cand[nc].score = m->slots[i].score; nc++; }
     if (m->has_zero && m->zero.score >= min_score) { cand[nc].id = 0; cand[nc].score = m->zero.score; nc++; }
@@ -980,7 +1009,6 @@ static int search_with_map(const orc_snapshot *snap, hit_map *m, const uint32_t 
         if (outn < out_cap) out[outn] = cand[i];
         outn++;
     }
-    free(cand);
     return (int)(outn < out_cap ? outn : out_cap);
 }
 
@@ -989,9 +1017,12 @@ int orc_search(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,
                orc_result *out, uint32_t out_cap, orc_stats *stats)
 {
     hit_map m;
+    search_scratch sc;
+    memset(&sc, 0, sizeof sc);
     if (map_init(&m, 1024)) return -1;
-    int rc = search_with_map(snap, &m, hashes, n, max_results, min_score_opt, min_score_pct, out, out_cap, stats);
+    int rc = search_with_map(snap, &m, &sc, hashes, n, max_results, min_score_opt, min_score_pct, out, out_cap, stats);
     free(m.slots);
+    scratch_free(&sc);
     return rc;
 }
 
@@ -1026,6 +1057,8 @@ static void *many_worker(void *arg)
 {
     many_job *j = (many_job *)arg;
     hit_map m;
+    search_scratch sc;
+    memset(&sc, 0, sizeof sc);
     int have_map = map_init(&m, 1024) == 0;
     orc_result *tmp = (orc_result *)malloc((j->out_cap ? j->out_cap : 1) * sizeof(orc_result));
     if (!have_map || !tmp) atomic_store(&j->failed, 1);
@@ -1039,7 +1072,7 @@ static void *many_worker(void *arg)
         const double t_a = seconds_since(&j->t0);
         /* results are kept from the first pass only (later passes recompute the same lists) */
         orc_result *dst = i < j->nq ? j->out + (size_t)q * j->out_cap : tmp;
-        const int r = search_with_map(j->snap, &m, h, n, j->max_results, floor_, j->min_score_pct, dst, j->out_cap, NULL);
+        const int r = search_with_map(j->snap, &m, &sc, h, n, j->max_results, floor_, j->min_score_pct, dst, j->out_cap, NULL);
         const double t_b = seconds_since(&j->t0);
         if (r < 0) { atomic_store(&j->failed, 1); break; }
         if (i < j->nq) j->out_n[q] = (uint32_t)r;
@@ -1052,6 +1085,7 @@ static void *many_worker(void *arg)
         }
     }
     if (have_map) free(m.slots);
+    scratch_free(&sc);
     free(tmp);
     return NULL;
 }
@@ -1093,7 +1127,11 @@ int orc_search_hits(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n
 {
     hit_map m;
     if (map_init(&m, 1024)) return -1;
-    if (run_scans(snap, hashes, n, &m, NULL)) { free(m.slots); return -1; }
+    search_scratch sc;
+    memset(&sc, 0, sizeof sc);
+    const int rc = run_scans(snap, hashes, n, &m, NULL, &sc);
+    scratch_free(&sc);
+    if (rc) { free(m.slots); return -1; }
     uint32_t k = 0;
     for (size_t i = 0; i < m.cap; i++) if (m.slots[i].id) {
         if (k < cap) { ids[k] = m.slots[i].id; commit_ids[k] = m.slots[i].commit_id; scores[k] = m.slots[i].score; }

@@ -54,7 +54,7 @@ def _check_finish_contract(out, out_n, targets, H, limit, floor, pct):
     assert (n >= 1).all() and (n <= limit).all()
     assert (out[:, 0, 0] == targets).all(), "the target fingerprint must rank first"
     top = out[:, 0, 1].astype(np.int64)
-    assert (top <= H).all() and (top >= int(0.75 * H)).all()
+    assert (top <= H).all() and (top >= int(0.75 * H)).all(), (int(top.min()), int(top.max()), H, np.flatnonzero((top > H) | (top < int(0.75 * H)))[:8].tolist())
     assert abs(float(np.median(top)) - 0.9 * H) <= 0.03 * H
     col = np.arange(out.shape[1])[None, :]
     valid = col < n[:, None]

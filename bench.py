@@ -295,6 +295,16 @@ def cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, 
     out, out_n, rep = osnap.search_many(sub_flat, sub_off, opts.max_results, opts.min_score, opts.min_score_pct,
                                         nthreads=cores, min_seconds=target_s)
     lat = np.sort(rep["latency_ms"])
+    # what the box really runs in parallel (containers may cap CPU time below the visible thread count): aggregate spin
+    # rate of `cores` compute-bound threads over one thread's
+    par = float(oracle.lib().orc_cpu_parallelism(cores, 1.0))
+    cpu_max = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            cpu_max = f"{f}: {open(f).read().strip()}"
+            break
+        except OSError:
+            pass
     scale = len(use) / len(segs)
     qps = rep["queries_done"] / rep["wall_s"] * scale
     mism = None
@@ -309,6 +319,10 @@ def cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, 
             "latency_ms_under_load_p50": float(np.percentile(lat, 50)), "latency_ms_under_load_p99": float(np.percentile(lat, 99)),
             "single_thread_query_ms_p50": float(np.percentile(lat1, 50)), "single_thread_query_ms_p99": float(np.percentile(lat1, 99)),
             "parallel_speedup_over_one_thread": qps / scale * float(np.percentile(lat1, 50)) / 1e3,
+            "box_parallelism_measured": par, "cgroup_cpu_limit": cpu_max,
+            "note": f"{cores} hardware threads are visible; {cores} compute-bound spinning threads together ran {par:.1f}x one thread's rate on this box "
+                    "(orc_cpu_parallelism), which bounds what any CPU baseline can reach here; the searches are also DRAM-latency bound "
+                    "(random 512-B blocks + block_index binary searches over the host-resident index)",
             "host_ram_available_GiB": None if avail is None else avail / 2**30}
 
 

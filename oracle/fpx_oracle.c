@@ -1090,6 +1090,51 @@ static void *many_worker(void *arg)
     return NULL;
 }
 
+/* How many threads really run at once on this box (containers may cap CPU time below the visible core count): every
+ * thread spins on integer work for `seconds`; returns total iterations / (iterations of one thread running alone). */
+typedef struct { double seconds; struct timespec t0; atomic_int go; unsigned long long iters; } spin_job;
+typedef struct { spin_job *job; unsigned long long iters; } spin_arg;
+
+static void *spin_worker(void *p)
+{
+    spin_arg *a = (spin_arg *)p;
+    while (!atomic_load_explicit(&a->job->go, memory_order_acquire)) sched_yield();
+    uint64_t x = 0x9E3779B97F4A7C15ull, n = 0;
+    do {
+        for (int i = 0; i < 4096; i++) x = orc_mix64(x + (uint64_t)i);
+        n += 4096;
+    } while (seconds_since(&a->job->t0) < a->job->seconds);
+    a->iters = n + (x == 42);
+    return NULL;
+}
+
+static unsigned long long spin_run(uint32_t nthreads, double seconds)
+{
+    spin_job j;
+    j.seconds = seconds; atomic_init(&j.go, 0);
+    pthread_t *th = (pthread_t *)malloc(nthreads * sizeof(pthread_t));
+    spin_arg *args = (spin_arg *)calloc(nthreads, sizeof(spin_arg));
+    if (!th || !args) { free(th); free(args); return 0; }
+    uint32_t started = 0;
+    for (; started < nthreads; started++) {
+        args[started].job = &j;
+        if (pthread_create(&th[started], NULL, spin_worker, &args[started])) break;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &j.t0);
+    atomic_store_explicit(&j.go, 1, memory_order_release);
+    unsigned long long total = 0;
+    for (uint32_t k = 0; k < started; k++) { pthread_join(th[k], NULL); total += args[k].iters; }
+    free(th); free(args);
+    return total;
+}
+
+double orc_cpu_parallelism(uint32_t nthreads, double seconds)
+{
+    const unsigned long long one = spin_run(1, seconds);
+    const unsigned long long all = spin_run(nthreads, seconds);
+    return one ? (double)all / (double)one : 0.0;
+}
+
 int orc_search_many(const orc_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets, uint32_t nq,
                     uint32_t max_results, int has_min_score, uint32_t min_score, uint32_t min_score_pct,
                     uint32_t nthreads, double min_seconds,

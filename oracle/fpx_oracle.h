@@ -149,6 +149,10 @@ int  orc_search_many(const orc_snapshot *snap, const uint32_t *hashes, const uin
                      float *latency_ms, uint64_t latency_cap,
                      double *wall_seconds, uint64_t *queries_done);
 
+/* Effective parallelism of the box for `nthreads` compute-bound threads (a container may cap CPU time below the visible
+ * core count): aggregate spin rate of nthreads threads over the rate of one thread alone, each measured for `seconds`. */
+double orc_cpu_parallelism(uint32_t nthreads, double seconds);
+
 /* The hit map after the segment scans and before finish (id, commit_id, score), for tests
  * that pin `results.hits.get(id).score` (src/filefmt.zig:336-337, src/Index.zig:1079). */
 int  orc_search_hits(const orc_snapshot *snap, const uint32_t *hashes, uint32_t n,

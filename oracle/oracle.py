@@ -91,6 +91,7 @@ def lib():
         "orc_search_hits": (C.c_int, [vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32]),
         "orc_search_many": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                       vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "orc_cpu_parallelism": (C.c_double, [C.c_uint32, C.c_double]),
         "orc_mix64": (C.c_uint64, [C.c_uint64]),
         "orc_synth_hash": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
         "orc_synth_items": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]),

@@ -48,13 +48,13 @@ def _build(fpx, ctx, docs, H, S, est_bytes_per_item=5.4, dist=0, scratch=6 << 30
     return segs, per, per * S
 
 
-def _check_finish_contract(out, out_n, targets, H, limit, floor, pct):
+def _check_finish_contract(out, out_n, targets, H, limit, floor, pct, lo_frac=0.75):
     B = len(out_n)
     n = out_n.astype(np.int64)
     assert (n >= 1).all() and (n <= limit).all()
     assert (out[:, 0, 0] == targets).all(), "the target fingerprint must rank first"
     top = out[:, 0, 1].astype(np.int64)
-    assert (top <= H).all() and (top >= int(0.75 * H)).all(), (int(top.min()), int(top.max()), H, np.flatnonzero((top > H) | (top < int(0.75 * H)))[:8].tolist())
+    assert (top <= H).all() and (top >= int(lo_frac * H)).all(), (int(top.min()), int(top.max()), H, np.flatnonzero((top > H) | (top < int(lo_frac * H)))[:8].tolist())
     assert abs(float(np.median(top)) - 0.9 * H) <= 0.03 * H
     col = np.arange(out.shape[1])[None, :]
     valid = col < n[:, None]
@@ -175,7 +175,8 @@ def test_config4_share_of_one_rank_125m_fingerprints_120_hashes_limit_100():
     flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L, dist=1)
     qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
     out, out_n, st = fpx.search_resident(reader, qb)
-    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+    # (hot hashes past the 1000-doc cap do not reach the target, and H = 120 leaves a wider relative tail: 8192 draws saw 88)
+    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10, lo_frac=0.65)
     assert st.probes == _unique_per_query(flat, offsets) * S
     _oracle_sample(fpx, oracle, ctx, segs[9], 9 * per + 1, per, flat, offsets, opts, 12)
 

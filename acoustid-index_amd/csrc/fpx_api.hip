@@ -453,7 +453,10 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     std::vector<uint32_t> dead;
     for (size_t i = 0; i < sn->segs.size(); ++i) {
         Segment* s = sn->segs[i];
-        if (s->kind == 2) continue;
+        // docs-only members: explicit stand-ins (kind 2) and segments resident on ANOTHER context's device -- in a sharded
+        // snapshot every device sees the whole segment list, keeps the postings of its own segments and uses the others'
+        // docs maps for supersession only (fpx_sharded_snapshot_create)
+        if (s->kind == 2 || s->ctx != c) continue;
         compute_dead(sn->segs, i, dead);
         uint32_t* d_dead = nullptr;
         uint32_t* d_bits = nullptr;
@@ -519,7 +522,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         std::vector<SegDesc> lean, gen, small;
         size_t fi = 0;
         for (Segment* sg : sn->segs) {
-            if (sg->kind != 0) continue;
+            if (sg->kind != 0 || sg->ctx != c) continue;
             const SegDesc& d = sn->h_file[fi++];
             if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30) && d.blockrec) lean.push_back(d);
             else if (d.items) { small.push_back(d); sn->max_small_blocks = std::max(sn->max_small_blocks, d.num_blocks); }

@@ -256,6 +256,34 @@ class Segments:
             pass
 
 
+class ShardedSegments:
+    """One snapshot over segments resident on SEVERAL GPUs of this process (fpx_sharded_snapshot_create): every segment
+    lives on the device of the Context it was created with; the list is in snapshot order like Segments'.  One call
+    searches all devices (worker threads per device, tables gathered on the first context's device, merged there)."""
+
+    def __init__(self, segments):
+        self.segments = list(segments)
+        arr = (C.c_void_p * max(1, len(self.segments)))(*[s.h for s in self.segments])
+        h = C.c_void_p()
+        check(lib().fpx_sharded_snapshot_create(arr, len(self.segments), C.byref(h)))
+        self.h = h
+
+    @property
+    def num_devices(self):
+        return lib().fpx_sharded_snapshot_num_devices(self.h)
+
+    def release(self):
+        if getattr(self, "h", None):
+            lib().fpx_sharded_snapshot_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class SearchResults:
     """Collector handed to IndexReader.search (src/common.zig:73-176)."""
 
@@ -335,6 +363,40 @@ class IndexReader:
         check(lib().fpx_search_batch(self.snapshot.h, _p(flat_h), _p(offsets), B, copts, timeout_ms,
                                      _p(out), cap, _p(out_n), C.byref(st)))
         return out, out_n, st
+
+
+class ShardedIndexReader:
+    """IndexReader over a ShardedSegments snapshot: the same two calls, answered by all GPUs together."""
+
+    def __init__(self, snapshot: ShardedSegments):
+        self.snapshot = snapshot
+
+    def search(self, hashes, results: SearchResults, timeout_ms=0):
+        q = _u32(np.asarray(hashes, dtype=np.uint64) & np.uint64(0xFFFFFFFF)) if len(hashes) else np.zeros(1, np.uint32)
+        cap = _result_cap(results.options.max_results)
+        out = (Result * cap)()
+        out_n = C.c_uint32()
+        st = Stats()
+        opts = results.options.to_c()
+        check(lib().fpx_sharded_search(self.snapshot.h, _p(q), len(hashes), C.byref(opts), timeout_ms, out, cap, C.byref(out_n), C.byref(st)))
+        results.results = [(out[i].id, out[i].score) for i in range(out_n.value)]
+        results.stats = st
+        return results.results
+
+    def search_batch(self, queries, options, timeout_ms=0, flat=None):
+        B = len(queries) if flat is None else len(flat[1]) - 1
+        flat_h, offsets = _flatten(queries) if flat is None else flat
+        if isinstance(options, SearchOptions):
+            options = [options] * B
+        copts = (Opts * max(1, B))(*[o.to_c() for o in options])
+        cap = _result_cap(max([1] + [o.max_results for o in options]))
+        out = np.zeros((max(1, B), cap, 2), np.uint32)
+        out_n = np.zeros(max(1, B), np.uint32)
+        st = Stats()
+        check(lib().fpx_sharded_search_batch(self.snapshot.h, _p(flat_h), _p(offsets), B, copts, timeout_ms,
+                                             _p(out), cap, _p(out_n), C.byref(st)))
+        res = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(out_n[q])] for q in range(B)]
+        return res, st
 
 
 class QueryBatch:

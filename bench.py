@@ -266,7 +266,25 @@ def cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, 
     the WHOLE index downloaded from HBM into host RAM, the first `nq` queries of the batch, one search per thread on
     every hardware thread through orc_search_many -- persistent pthread workers with recycled collectors, the
     reference's executor model (src/main.zig:272-276, src/common.zig:186-300) -- cycling for ~target_s seconds."""
-    cores = os.cpu_count() or 1
+    visible = os.cpu_count() or 1
+    # a container may cap CPU time below the visible thread count (cgroup cpu.max = "<quota> <period>"): more runnable
+    # threads than that only get throttled, so the pool is sized to what the box grants
+    cores, cpu_max = visible, None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            cpu_max = f"{f}: {' '.join(txt)}"
+            quota = int(txt[0]) if txt[0] != "max" else -1
+            period = int(txt[1]) if len(txt) > 1 else int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                cores = max(1, min(visible, -(-quota // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            pass
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
     need = sum((s.num_blocks + 1) * s.block_size + 4 * s.num_blocks + 5 * (hi - lo + 1) for s, (lo, hi) in zip(segs, ranges))
     avail = host_memory_available()
     use = list(range(len(segs)))
@@ -298,13 +316,6 @@ def cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, 
     # what the box really runs in parallel (containers may cap CPU time below the visible thread count): aggregate spin
     # rate of `cores` compute-bound threads over one thread's
     par = float(oracle.lib().orc_cpu_parallelism(cores, 1.0))
-    cpu_max = None
-    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            cpu_max = f"{f}: {open(f).read().strip()}"
-            break
-        except OSError:
-            pass
     scale = len(use) / len(segs)
     qps = rep["queries_done"] / rep["wall_s"] * scale
     mism = None
@@ -320,9 +331,11 @@ def cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, 
             "single_thread_query_ms_p50": float(np.percentile(lat1, 50)), "single_thread_query_ms_p99": float(np.percentile(lat1, 99)),
             "parallel_speedup_over_one_thread": qps / scale * float(np.percentile(lat1, 50)) / 1e3,
             "box_parallelism_measured": par, "cgroup_cpu_limit": cpu_max,
-            "note": f"{cores} hardware threads are visible; {cores} compute-bound spinning threads together ran {par:.1f}x one thread's rate on this box "
-                    "(orc_cpu_parallelism), which bounds what any CPU baseline can reach here; the searches are also DRAM-latency bound "
-                    "(random 512-B blocks + block_index binary searches over the host-resident index)",
+            "visible_hardware_threads": visible,
+            "note": f"{visible} hardware threads are visible, the container grants {cores} CPUs' worth of time ({cpu_max}); the pool runs {cores} "
+                    f"workers, and {cores} compute-bound spinning threads together ran {par:.1f}x one thread's rate (orc_cpu_parallelism) -- the "
+                    "ceiling of any CPU baseline on this box.  The searches are DRAM-latency bound (random 512-B blocks + block_index binary "
+                    "searches over the host-resident index).",
             "host_ram_available_GiB": None if avail is None else avail / 2**30}
 
 

@@ -132,7 +132,8 @@ int fpx_segment_download(const fpx_segment *seg, uint8_t *blocks, size_t blocks_
 /* ---- snapshot ---------------------------------------------------------- */
 /* Replaces: Index.createSnapshot + swapSnapshot (src/Index.zig:450-485).  `segs` is the
  * Segments snapshot order: file[] then memory[], oldest -> newest, commit_id strictly
- * ascending (src/Index.zig:36-41).  Builds the supersession tables.  Retains the segments. */
+ * ascending (src/Index.zig:36-41).  Builds the supersession tables.  Retains the segments.  A segment that is resident
+ * on another context's device takes part with its docs map only (like fpx_segment_create_remote). */
 int  fpx_snapshot_create(fpx_ctx *ctx, fpx_segment *const *segs, uint32_t num_segs, fpx_snapshot **out);
 /* acquireReader / IndexReader.deinit (src/Index.zig:430-434, :157-163) */
 void fpx_snapshot_retain(fpx_snapshot *snap);
@@ -182,6 +183,33 @@ int fpx_merge_partials(fpx_ctx *ctx, const void *d_parts, const void *d_counts, 
                        uint32_t num_queries, uint32_t part_cap, const fpx_opts *opts,
                        const uint64_t *offsets,
                        fpx_result *out, uint32_t out_cap, uint32_t *out_n);
+
+/* ---- ONE process, several GPUs: segment sharding behind one call ------------------------------------------------------
+ * The reference answers a search with one call from one process (IndexReader.search, src/Index.zig:170-177, on the
+ * executors of src/main.zig:272-276).  A host that owns every GPU of a node keeps that shape: segments are made resident
+ * on the device of the context they are created with (fpx_segment_create_*(ctx_k, ...), one context per GPU), a sharded
+ * snapshot takes the whole segment list in snapshot order (as fpx_snapshot_create: file[] then memory[], commit ids
+ * ascending) and builds one local snapshot per participating device -- that device's postings plus the docs maps of all
+ * other segments, so that supersession (hasNewerCommit, src/Index.zig:133-149) stays exact --, and ONE call searches them
+ * all: the per-device partial searches run concurrently on worker threads, the per-query tables [B][limit]{id, score} +
+ * counts travel to the first context's device with hipMemcpyPeerAsync (xGMI; direct when peer access is available) and
+ * are merged there (k-way merge, relative cut-off anchored on the global best score).  Results are identical to an
+ * unsharded snapshot of the same segments.  The handle retains the local snapshots (hence the segments).
+ * (The one-process-per-GPU form of the same protocol -- fpx_search_resident_partial, an RCCL all-gather issued by the
+ * launcher, fpx_merge_partials -- is what bench.py --gpus N runs under torch.distributed.) */
+typedef struct fpx_sharded_snapshot fpx_sharded_snapshot;
+int  fpx_sharded_snapshot_create(fpx_segment *const *segs, uint32_t num_segs, fpx_sharded_snapshot **out);
+void fpx_sharded_snapshot_retain(fpx_sharded_snapshot *snap);
+void fpx_sharded_snapshot_release(fpx_sharded_snapshot *snap);
+uint32_t fpx_sharded_snapshot_num_devices(const fpx_sharded_snapshot *snap);   /* contexts that hold postings */
+/* fpx_search / fpx_search_batch over a sharded snapshot: same arguments, same results, same errors.  In `stats` the
+ * counters are summed over the devices and the times are the slowest device's. */
+int  fpx_sharded_search(fpx_sharded_snapshot *snap, const uint32_t *hashes, uint32_t num_hashes,
+                        const fpx_opts *opts, uint32_t timeout_ms,
+                        fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
+int  fpx_sharded_search_batch(fpx_sharded_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets,
+                              uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
+                              fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
 
 /* ---- synthetic index builder (benchmarks / tests; not part of the reference surface) --- */
 /* Builds, entirely on the GPU, the file segment holding documents

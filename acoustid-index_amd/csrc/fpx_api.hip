@@ -46,7 +46,10 @@ Workspace* ws_acquire(Ctx* ctx)
               hipEventCreate(&w->ev_probe1) == hipSuccess && hipEventCreate(&w->ev_probe2) == hipSuccess &&
               hipEventCreate(&w->ev_end) == hipSuccess &&
               hipMalloc(&w->d_counters, COUNTERS_BYTES) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void**>(&w->h_counters), COUNTERS_BYTES, hipHostMallocMapped) == hipSuccess;
+              hipHostMalloc(reinterpret_cast<void**>(&w->h_counters), COUNTERS_BYTES, hipHostMallocMapped) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&w->h_cancel), 64, hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<uint32_t**>(&w->d_cancel)), w->h_cancel, 0) == hipSuccess;
+    if (ok) *w->h_cancel = 0u;
     if (!ok) { set_error("workspace creation failed: %s", hipGetErrorString(hipGetLastError())); ws_destroy(w); return nullptr; }
     ctx->live_ws++;
     return w;
@@ -75,6 +78,7 @@ void ws_destroy(Workspace* w)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (w->h_counters) (void)hipHostFree(w->h_counters);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
+    if (w->h_cancel) (void)hipHostFree(w->h_cancel);
     if (w->h_def_count) (void)hipHostFree(w->h_def_count);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_probe0) (void)hipEventDestroy(w->ev_probe0);

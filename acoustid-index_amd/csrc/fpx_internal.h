@@ -76,6 +76,8 @@ enum Counter : int {
     CTR_GENERIC = 7,     // wave iterations of k_probe that took the generic (per-value) decode path    // largest score of any candidate (sizes the score field of the candidate key)
     CTR_LEAN_READS = 8,  // blocks k_probe_lean8 fetched (probes whose hash the presence bitmap knows to be absent read none)
     CTR_HEAVY = 9,       // queries k_score handed to its CLASSED launch
+    CTR_CANCEL = 10,     // != 0: the search's deadline passed (copied off the host's cancel word by polling workgroups) -- every
+                         // workgroup leaves at its next cancel point, the results are discarded (error.SearchTimeout)
     CTR_SLOTCANDS = 14,  // candidates handed from k_score to k_finish through the queries' own slots (statistics)
     CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
 };
@@ -167,6 +169,8 @@ struct Workspace {
     // one small query travels in ONE pinned copy: [offsets 2 x u64 | opts 4 x u32 | hashes]
     uint8_t* h_stage = nullptr; uint8_t* d_stage = nullptr;      // pinned + its device-mapped address
     unsigned long long* d_ret = nullptr;                          // device-mapped address of h_counters
+    // the deadline's cancel word: pinned host memory the waiting host thread sets, read by the kernels through its mapping
+    uint32_t* h_cancel = nullptr; const uint32_t* d_cancel = nullptr;
 };
 
 // A query batch already uploaded to HBM (fpx_query_batch_create): the timed region of a resident

@@ -29,7 +29,24 @@ struct ProbeArgs {
     uint32_t def_cap;
     uint32_t ctr_off;          // 0, or 8 for k_probe_lean8: which statistics slots of `counters` to use
     unsigned long long* lean_stats;   // k_probe_lean8: [LEAN_STAT_SETS][8] {blocks fetched, visited blocks, docs, probes, ...}
+    const uint32_t* cancel;           // the host's cancel word (mapped pinned memory), or null: no deadline
 };
+
+// Cancel point -- the GPU form of zio.maybeYield() in the reference's hot loop (src/FileSegment.zig:144,
+// src/MemorySegment.zig:47), whose error.Canceled becomes error.SearchTimeout (src/MultiIndex.zig:319-322).  The host
+// thread that waits for the stream sets a word in pinned memory when the deadline passes; one workgroup in 64 reads it
+// over PCIe and raises the flag in device memory, every workgroup checks that flag (an L2 hit) when it starts, and leaves:
+// a launch in flight drains in well under 100 us (a workgroup lives ~50 us) and every later kernel of the call is empty.
+// (Checks between rounds were measured: they cost the probe kernels 3-11 VGPRs, i.e. a whole wave of occupancy.)
+// A cancelled launch produces garbage that nobody reads.  Thread 0 calls this; the caller broadcasts the result through LDS.
+__device__ __forceinline__ bool cancel_requested(const uint32_t* cancel_host, unsigned long long* counters)
+{
+    if (!cancel_host) return false;
+    if ((blockIdx.x & 63u) == 0u &&
+        __hip_atomic_load(cancel_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+        atomicExch(&counters[CTR_CANCEL], 1ull);
+    return __hip_atomic_load(&counters[CTR_CANCEL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+}
 
 // ---- decode tables (the GPU form of the reference's 256-entry shuffle/length tables, src/streamvbyte.zig:76-211)
 // lutA[v][c]: byte offsets of values 1..3 of control byte c (one byte each) | total length << 24
@@ -366,12 +383,15 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         if (first >= (uint64_t)min(a.def_count[blockIdx.y * DEF_COUNT_STRIDE], a.def_cap)) return;
     }
 
+    __shared__ uint32_t s_cancel;
     if (tid < 256u) init_lut(lut, tid);
     if (tid == 0) {
         stage_count = 0; stage_valid = STAGE_CAP;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0;
+        s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;
     }
     __syncthreads();
+    if (s_cancel) return;
 
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_generic = 0;
 

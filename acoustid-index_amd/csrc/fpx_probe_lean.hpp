@@ -132,12 +132,17 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
     const uint32_t blko = (uint32_t)(blk - smem);
     const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
 
+    __shared__ uint32_t s_cancel;
     if (tid < 256u) init_lean_lut(lut, tid);
     if (tid == 0) {
         stage_count = 0; stage_valid = STAGE_CAP; def_n = 0;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
+        // cancel point (src/FileSegment.zig:144), once per workgroup: its two rounds last ~50 us, and a check between them
+        // would keep two more pointers live through the loop of a kernel that sits exactly at 128 VGPRs
+        s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;
     }
     __syncthreads();
+    if (s_cancel) return;
 
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
     // (the descriptor in global memory, not the local copy: taking `seg`'s address would pin all its fields in VGPRs)

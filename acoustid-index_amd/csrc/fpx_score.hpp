@@ -291,8 +291,14 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
                                                const uint32_t* __restrict__ opts, uint32_t log2ft, uint32_t sb,
                                                uint64_t* cands, uint64_t cand_cap, unsigned long long* counters,
                                                uint64_t single_hit_cap = 0, uint64_t* qcand = nullptr, uint32_t* qcand_n = nullptr,
-                                               uint32_t* heavy = nullptr)
+                                               uint32_t* heavy = nullptr, const uint32_t* cancel = nullptr)
 {
+    if (cancel) {                                   // cancel point (see cancel_requested)
+        __shared__ uint32_t s_cancel;
+        if (threadIdx.x == 0) s_cancel = cancel_requested(cancel, counters) ? 1u : 0u;
+        __syncthreads();
+        if (s_cancel) return;
+    }
     if constexpr (CLASSED) {
         if (heavy != nullptr) {
             const uint32_t nh = (uint32_t)counters[CTR_HEAVY];

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <type_traits>
 
 #include "fpx_internal.h"
@@ -152,6 +153,31 @@ static double now_ms()
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// Wait for the call's stream.  With a deadline the host thread polls instead of blocking: when the deadline passes it
+// sets the workspace's cancel word (pinned, mapped into the device), the running kernels leave at their next cancel
+// point (cancel_requested), the rest of the queue drains in microseconds, and the call reports error.SearchTimeout
+// (src/MultiIndex.zig:314-322) with no partial results -- promptly, not after the batch has run to completion.
+static int sync_deadline(Workspace* ws, double t_start, uint32_t timeout_ms)
+{
+    hipStream_t st = ws->stream;
+    if (timeout_ms == 0) { FPX_HIP(hipStreamSynchronize(st)); return FPX_OK; }
+    bool fired = *reinterpret_cast<volatile uint32_t*>(ws->h_cancel) != 0u;
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery");
+        if (!fired && now_ms() - t_start > (double)timeout_ms) {
+            __atomic_store_n(ws->h_cancel, 1u, __ATOMIC_RELEASE);
+            fired = true;
+        }
+        if (spins < 512u) std::this_thread::yield();                       // a single /_search completes within this window
+        else std::this_thread::sleep_for(std::chrono::microseconds(fired ? 5 : 40));
+    }
+    if (fired) { set_error("search timeout"); return FPX_E_TIMEOUT; }
+    return FPX_OK;
+}
+#define FPX_SYNC(ws) do { const int _rc = sync_deadline((ws), t_start, timeout_ms); if (_rc != FPX_OK) return _rc; } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // batch driver
 // ------------------------------------------------------------------------------------------------
@@ -195,6 +221,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     const bool probe_only = ex && ex->mode == 1, score_only = ex && ex->mode == 2;
     const double t_start = now_ms();
     hipStream_t st = ws->stream;
+    __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);           // (the stream is idle: the previous call synchronised it)
+    const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
     const uint64_t base = offsets[0];
     const uint64_t P = offsets[B] - base;
     const unsigned qb = bits_for(B);            // q in [0, B)
@@ -308,7 +336,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.rounds = total >= (1ull << 25) ? 2u : 1u;
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
-            a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr;
+            a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr; a.cancel = cancel;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
@@ -378,7 +406,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         if (single_fast) break;                     // one query: nothing below needs the counts on the host yet
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipStreamSynchronize(st));
+        FPX_SYNC(ws);
         if (used_lean && snap->n_lean) {
             // the lean kernel's statistics: LEAN_STAT_SETS copies on separate cache lines (a workgroup adds to set
             // blockIdx.x % LEAN_STAT_SETS), summed here into the slots the code below reads
@@ -420,12 +448,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         const uint32_t log2f = 13, sb1 = 32u - qb;
         hipLaunchKernelGGL((k_score<32, true>), dim3(1), dim3(WG), ((size_t)8 << SCORE_TABLE_LOG2) + ((size_t)4 << log2f), st,
                            (const uint64_t*)ws->d_hits[0], (const uint64_t*)nullptr, d_opts, log2f | (SCORE_TABLE_LOG2 << 8), sb1, ws->d_cands[0],
-                           (uint64_t)SINGLE_CANDS, ws->d_counters, (uint64_t)ws->cap_hits);
+                           (uint64_t)SINGLE_CANDS, ws->d_counters, (uint64_t)ws->cap_hits, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cancel);
         if (!ws->d_ret) FPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_ret), ws->h_counters, 0));
         hipLaunchKernelGGL(k_finish_single, dim3(1), dim3(256), 0, st, (const uint64_t*)ws->d_cands[0], d_opts,
                            (const unsigned long long*)ws->d_counters, out_cap, ws->d_ret);
         FPX_HIP(hipGetLastError());
-        FPX_HIP(hipStreamSynchronize(st));      // counters, result count and results are in pinned host memory now
+        FPX_SYNC(ws);      // counters, result count and results are in pinned host memory now
         if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
         H = ws->h_counters[CTR_HITS];
         const bool fits = H <= ws->cap_hits && ws->h_counters[CTR_CANDS] <= SINGLE_CANDS && ws->h_counters[CTR_MAXSCORE] == 0;
@@ -509,7 +537,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         const bool fits = H <= ex->cap;
         if (fits && H) FPX_HIP(hipMemcpyAsync(ex->d_records, ws->d_hits[0], H * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
         FPX_HIP(hipEventRecord(ws->ev_end, st));
-        FPX_HIP(hipStreamSynchronize(st));
+        FPX_SYNC(ws);
         for (uint32_t d = 0; d < world; ++d) ex->counts[d] = hb[d + 1] - hb[d];
         if (!fits) { set_error("records buffer too small: %llu records (counts are filled in; retry with room for them)", (unsigned long long)H); return FPX_E_INVAL; }
         fill_stats();
@@ -570,22 +598,22 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (short_queries)
                 hipLaunchKernelGGL((k_score<8, false>), dim3(B), dim3(WG), score_lds, st,
                                    (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
-                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy);
+                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy, cancel);
             else
                 hipLaunchKernelGGL((k_score<32, false>), dim3(B), dim3(WG), score_lds, st,
                                    (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
-                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy);
+                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy, cancel);
             FPX_HIP(hipGetLastError());
             FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipStreamSynchronize(st));
+            FPX_SYNC(ws);
             if (ws->h_counters[CTR_HEAVY] != 0) {
                 // queries the launch above handed over (far more records than the filter was sized for): rounds over doc classes
                 hipLaunchKernelGGL((k_score<32, true>), dim3((uint32_t)std::min<uint64_t>(ws->h_counters[CTR_HEAVY], 1024u)), dim3(WG), score_lds, st,
                                    (const uint64_t*)ws->d_hits[0], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sb, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
-                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy);
+                                   (uint64_t)0, d_qcand, d_qcand_n, d_heavy, cancel);
                 FPX_HIP(hipGetLastError());
                 FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-                FPX_HIP(hipStreamSynchronize(st));
+                FPX_SYNC(ws);
             }
             C = ws->h_counters[CTR_CANDS];
             if (ws->h_counters[CTR_MAXSCORE] != 0) {              // a score does not fit the key's score field
@@ -620,7 +648,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     if (stats && d_qcand_n)
         FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     FPX_HIP(hipEventRecord(ws->ev_end, st));
-    FPX_HIP(hipStreamSynchronize(st));
+    FPX_SYNC(ws);
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
     if (stats && d_qcand_n) C_slots = ws->h_counters[CTR_SLOTCANDS];
 

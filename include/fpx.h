@@ -143,7 +143,10 @@ void fpx_snapshot_release(fpx_snapshot *snap);
 /* Replaces: IndexReader.search(hashes, results) + results.getResults()
  * (src/Index.zig:170-177, src/common.zig:131-173) as called by MultiIndex.search
  * (src/MultiIndex.zig:287-330).  `hashes` is the raw query: unsorted, duplicates allowed,
- * not modified.  timeout_ms == 0 means unbounded (src/MultiIndex.zig:286,315).
+ * not modified.  timeout_ms == 0 means unbounded (src/MultiIndex.zig:286,315).  With a deadline the calling thread polls
+ * the call's stream instead of blocking on it; when the deadline passes it raises a cancel word that every kernel of the
+ * call checks per workgroup (the GPU form of the zio.maybeYield cancel point, src/FileSegment.zig:144), the device drains
+ * within ~0.1 ms and the call returns FPX_E_TIMEOUT with no partial results (src/MultiIndex.zig:319-322).
  * Writes min(*out_n, out_cap) results ordered by (score desc, id asc). */
 int fpx_search(fpx_snapshot *snap, const uint32_t *hashes, uint32_t num_hashes,
                const fpx_opts *opts, uint32_t timeout_ms,

@@ -118,6 +118,20 @@ def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192():
     out2, out_n2, st2 = fpx.search_resident(reader, qb)
     assert (out_n2 == out_n).all() and (out2 == out).all()
     assert (st2.scanned_blocks, st2.scanned_docs, st2.hits) == (st.scanned_blocks, st.scanned_docs, st.hits)
+    # in-kernel deadline (the reference cancels at zio.maybeYield, src/FileSegment.zig:144 -> error.SearchTimeout,
+    # src/MultiIndex.zig:314-322): a 1-ms deadline on this ~7-ms batch comes back as a timeout LONG before the batch would
+    # have finished, with no results, and the workspace is fine afterwards
+    import time
+    t0 = time.perf_counter()
+    fpx.search_resident(reader, qb)
+    t_full = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with pytest.raises(fpx.SearchTimeout):
+        fpx.search_resident(reader, qb, timeout_ms=1)
+    t_cancel = time.perf_counter() - t0
+    assert t_cancel < max(0.0035, 0.55 * t_full), (t_cancel, t_full)
+    out3, out_n3, _ = fpx.search_resident(reader, qb, timeout_ms=10_000)       # a generous deadline changes nothing
+    assert (out_n3 == out_n).all() and (out3 == out).all()
     # configs[3]: 8 ranks, two segments each + docs-only stand-ins for the others; tables merged as after an all-gather
     world, cap = 8, qb.cap
     remotes = [fpx.RemoteSegment(ctx, s * per + 1, (s + 1) * per, s + 1, np.arange(s * per + 1, (s + 1) * per + 1, dtype=np.uint32))

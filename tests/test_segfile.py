@@ -135,3 +135,49 @@ def test_snapshot_stream_round_trip(tmp_path):
         sf.restore_snapshot(str(tmp_path / "x"), data, 43)                           # SnapshotGenerationMismatch
     with pytest.raises(sf.InvalidSegment):
         sf.parse_snapshot(data[:-10])
+
+
+# ---- segment files assembled byte by byte from the format's definition (tests/golden/make_segment_fixture.py: its own
+#      msgpack emitter and CRC, no use of segfile.py), in the two integer / container encodings a conforming writer may
+#      pick: the reader must accept both, and the writer's bytes must equal the minimal form
+def _fixture_cases():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "segment_file_fixture.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _fixture_cases(), ids=lambda c: c["name"])
+def test_reader_consumes_spec_built_segment_files(case, tmp_path):
+    e = case["expect"]
+    path = os.path.join(str(tmp_path), e["file_name"])
+    raw = bytes.fromhex(case["file_hex"])
+    with open(path, "wb") as f:
+        f.write(raw)
+    assert fpx.segfile.parse_segment_file_name(e["file_name"]) == (e["info"][0], e["info"][1])
+    s = fpx.segfile.read_segment_file(path)
+    assert list(s["info"]) == e["info"] and s["metadata"] == e["metadata"] and s["block_size"] == e["block_size"]
+    assert (s["num_blocks"], s["num_items"], s["min_doc_id"], s["max_doc_id"]) == (e["num_blocks"], e["num_items"], e["min_doc_id"], e["max_doc_id"])
+    assert sorted(zip(s["doc_ids"].tolist(), (bool(a) for a in s["doc_alive"]))) == sorted((k, v) for k, v in e["docs"])
+    assert s["block_index"].tolist() == e["block_index"]
+    assert s["blocks"].size == (e["num_blocks"] + 1) * e["block_size"] and not s["blocks"][e["num_blocks"] * e["block_size"]:].any()
+    # the blocks decode to exactly the items the file was built from (oracle = restatement of BlockReader)
+    got = []
+    for b in range(e["num_blocks"]):
+        hs, ds = oracle.block_decode_items(s["blocks"][b * e["block_size"]:(b + 1) * e["block_size"]], e["min_doc_id"])
+        got += [(int(h) << 32) | int(d) for h, d in zip(hs, ds)]
+    assert got == e["items"]
+    # our writer emits the minimal form byte for byte
+    if case["name"].endswith("/minimal"):
+        out = os.path.join(str(tmp_path), "rewritten.data")
+        fpx.segfile.write_segment_file(out, tuple(e["info"]), {k: v for k, v in e["docs"]}, s["blocks"], s["block_index"],
+                                       e["block_size"], e["metadata"])
+        assert open(out, "rb").read() == raw
+    # a flipped bit in a data block is a checksum mismatch; a wrong footer size is an invalid segment
+    if e["num_blocks"]:
+        bad = bytearray(raw)
+        pos = raw.index(bytes(s["blocks"][:e["block_size"]].tobytes()))
+        bad[pos + 9] ^= 0x10
+        with open(path, "wb") as f:
+            f.write(bytes(bad))
+        with pytest.raises(fpx.segfile.InvalidSegment):
+            fpx.segfile.read_segment_file(path)

@@ -113,7 +113,7 @@ static void segment_free(Segment* s)
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
-    if (s->d_present) (void)hipFree(s->d_present);
+    if (s->d_proberec) (void)hipFree(s->d_proberec);
     if (s->d_blockrec) (void)hipFree(s->d_blockrec);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
@@ -499,7 +499,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.dead_bits = d_bits;
             d.items = s->d_small_items; d.bstart = s->d_bstart;
             d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
-            d.present = s->d_present; d.blockrec = s->d_blockrec; d.present_shift = s->present_shift;
+            d.proberec = s->d_proberec; d.blockrec = s->d_blockrec; d.present_shift = s->present_shift;
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
@@ -528,7 +528,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         for (Segment* sg : sn->segs) {
             if (sg->kind != 0 || sg->ctx != c) continue;
             const SegDesc& d = sn->h_file[fi++];
-            if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30) && d.blockrec) lean.push_back(d);
+            if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30) && d.blockrec && d.proberec) lean.push_back(d);
             else if (d.items) { small.push_back(d); sn->max_small_blocks = std::max(sn->max_small_blocks, d.num_blocks); }
             else { gen.push_back(d); if (d.block_size != 512) sn->gen_all_512 = false; }
         }

@@ -360,7 +360,7 @@ static void free_partial_segment(Segment* s)
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
-    if (s->d_present) (void)hipFree(s->d_present);
+    if (s->d_proberec) (void)hipFree(s->d_proberec);
     if (s->d_blockrec) (void)hipFree(s->d_blockrec);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
@@ -607,10 +607,10 @@ int decode_small_segment(Segment* s)
     return FPX_OK;
 }
 
-// Presence bitmap of a big segment: one wave per block decodes the block's hashes (the hash half of k_decode_items) and
-// sets the bit of each.
+// Presence bits of a big segment: one wave per block decodes the block's hashes (the hash half of k_decode_items) and
+// sets the bit of each -- in the probe records (SegDesc::proberec): bit pi = h >> shift lives in record pi >> 8, word (pi >> 5) & 7.
 __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
-                                                       uint32_t* __restrict__ present, uint32_t shift)
+                                                       uint32_t* __restrict__ proberec, uint32_t shift)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict
             if (act && i < n_items) {
                 const uint32_t hv = (h[k] + base) >> shift;
                 // (equal neighbours set the same bit: skip the repeat inside the quad)
-                if (k == 0 || h[k] != h[k - 1]) atomicOr(&present[hv >> 5], 1u << (hv & 31u));
+                if (k == 0 || h[k] != h[k - 1]) atomicOr(&proberec[(size_t)(hv >> 8) * 16u + ((hv >> 5) & 7u)], 1u << (hv & 31u));
             }
         }
     }
@@ -668,6 +668,31 @@ __global__ void k_block_records(const uint8_t* __restrict__ blocks, const uint32
     else if (b < num_blocks + 3u) rec[b] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 
+// words 8..15 of every probe record: the block range of its hash span and the records of the first three blocks
+__global__ void k_fill_proberec(const uint32_t* __restrict__ block_index, const uint2* __restrict__ blockrec, uint32_t num_blocks,
+                                uint32_t g, uint32_t nrec, uint32_t* __restrict__ proberec, uint32_t all_present)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    auto lower = [&](uint32_t hv) {
+        uint32_t lo = 0, hi = num_blocks;
+        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (block_index[m] < hv) lo = m + 1; else hi = m; }
+        return lo;
+    };
+    const uint32_t lo = lower(g >= 32u ? 0u : (r << g));
+    const uint32_t hi = (r + 1u == nrec || g >= 32u) ? num_blocks : lower((r + 1u) << g);
+    uint32_t* rec = proberec + (size_t)r * 16u;
+    if (all_present) for (int i = 0; i < 8; ++i) rec[i] = 0xFFFFFFFFu;
+    // (blockrec holds three all-ones sentinels behind the last block; lo < 2^30: the lean kernel's precondition)
+    const uint2 a = blockrec[lo], b = blockrec[min(lo + 1u, num_blocks + 2u)], c = blockrec[min(lo + 2u, num_blocks + 2u)];
+    const uint32_t cls = hi - lo >= 2u ? 2u : hi - lo;      // block boundaries inside the span: 0, 1, 2 = more (binary search)
+    rec[8] = lo | (cls << 30);
+    rec[9] = a.x; rec[10] = a.y;                             // {max hash, first hash} of block lo
+    rec[11] = b.x; rec[12] = b.y;                            // ... of block lo + 1
+    rec[13] = c.y;                                           // first hash of block lo + 2
+    rec[14] = hi; rec[15] = 0u;
+}
+
 int build_presence(Segment* s)
 {
     if (s->block_size != 512 || s->num_blocks == 0 || s->num_items < (1ull << 20)) return FPX_OK;      // not a lean segment
@@ -676,21 +701,28 @@ int build_presence(Segment* s)
     hipLaunchKernelGGL(k_block_records, dim3((s->num_blocks + 3 + 255) / 256), dim3(256), 0, 0,
                        s->d_blocks, s->d_block_index, s->num_blocks, s->d_blockrec);
     FPX_HIP(hipGetLastError());
-    if (s->num_items < presence_min_items()) return FPX_OK;
-    // one bit per 2^shift hash values, the largest shift that leaves the bitmap >= 5.7 bits per item (<= 16 % of them set,
-    // 16 % on top of the blocks' bytes); a segment of more than 2^32 / 5.7 items gets shift 0 (1.6 G items: 31 % set, 7 %)
+    // one presence bit per 2^shift hash values, the largest shift that leaves >= 5.7 bits per item (<= 16 % of them set,
+    // 16 % on top of the blocks' bytes); a segment of more than 2^32 / 5.7 items gets shift 0 (1.6 G items: 31 % set).
+    // 256 bits per probe record: 2^(24 - shift) records of 64 B, i.e. twice the bitmap's size.
     uint32_t shift = 0;
     while (shift < 22u && ((1ull << (31u - shift)) * 7ull) >= s->num_items * 40ull) ++shift;      // 2^(32-(shift+1)) >= 5.7 n
     s->present_shift = shift;
-    const size_t words = (size_t)1 << (27u - shift);
+    const uint32_t nrec = 1u << (24u - shift);
+    const size_t bytes = (size_t)nrec * 64u;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < words * 4 + ((size_t)8 << 30)) return FPX_OK;   // optional structure
-    if (hipMalloc(&s->d_present, words * sizeof(uint32_t)) != hipSuccess) { s->d_present = nullptr; (void)hipGetLastError(); return FPX_OK; }
-    FPX_HIP(hipMemsetAsync(s->d_present, 0, words * sizeof(uint32_t), 0));
-    hipLaunchKernelGGL(k_presence_bits, dim3((s->num_blocks + 3) / 4), dim3(256), 0, 0,
-                       s->d_blocks, s->block_size, s->num_blocks, s->d_present, shift);
+    // (without the records the segment is searched by the generic kernel: correct, slower)
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) return FPX_OK;
+    if (hipMalloc(&s->d_proberec, bytes) != hipSuccess) { s->d_proberec = nullptr; (void)hipGetLastError(); return FPX_OK; }
+    FPX_HIP(hipMemsetAsync(s->d_proberec, 0, bytes, 0));
+    // FPX_PRESENCE_MIN_ITEMS above the segment's size: every bit set, i.e. every probe reads its block (tests, A/B runs)
+    const bool with_bits = s->num_items >= presence_min_items();
+    if (with_bits)
+        hipLaunchKernelGGL(k_presence_bits, dim3((s->num_blocks + 3) / 4), dim3(256), 0, 0,
+                           s->d_blocks, s->block_size, s->num_blocks, s->d_proberec, shift);
+    hipLaunchKernelGGL(k_fill_proberec, dim3((nrec + 255) / 256), dim3(256), 0, 0,
+                       s->d_block_index, s->d_blockrec, s->num_blocks, shift + 8u, nrec, s->d_proberec, with_bits ? 0u : 1u);
     FPX_HIP(hipGetLastError());
-    s->device_bytes += words * sizeof(uint32_t);
+    s->device_bytes += bytes;
     return FPX_OK;
 }
 

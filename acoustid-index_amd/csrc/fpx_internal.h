@@ -24,12 +24,18 @@ struct SegDesc {
     const uint32_t* dead;          // sorted ids of this segment's docs that a newer segment mentions
     const uint32_t* cont;          // bit b: block b+1 starts with block b's last hash (a run may continue there)
     const uint32_t* dead_bits;     // bitmap of `dead` over [shadow_lo, shadow_hi] (bit d - shadow_lo), or null when that range is too wide
-    // segments of >= 2^20 items (the lean kernel's) carry block records and a PRESENCE bitmap over the hash space (bit h >> present_shift = some item of the
-    // segment has a hash in that bucket of 2^present_shift values; the shift keeps <= 16 % of the bits set where the hash
-    // space allows -- 0.7 byte per item -- and is 0 beyond 750 M items: 512 MB, 31 % set at 1.6 G): a probe whose bit is clear is answered -- and
-    // accounted for as the reference accounts for it (one visited block unless h falls in the gap before it) -- without
-    // reading the block
-    const uint32_t* present;       // 2^(27 - present_shift) words, or null
+    // Segments of >= 2^20 items (the lean kernel's) carry PROBE RECORDS: one 64-byte record per 2^(present_shift + 8) hash
+    // values -- everything phase 1 of k_probe_lean8 needs for a probe in ONE cache line and ONE level of loads:
+    //   words 0..7   256 presence bits: bit i = some item of the segment has a hash in [(r << 8 | i) << present_shift, +2^present_shift)
+    //                (the shift keeps <= 16 % of the bits set where the hash space allows -- 0.7 byte per item -- and is 0
+    //                beyond 750 M items: 31 % set at 1.6 G).  A probe whose bit is clear is answered -- and accounted for as the
+    //                reference accounts for it (one visited block unless h falls in the gap before it) -- without reading the block
+    //   word 8       lo = lower_bound(block_index, first hash of the record), bits 30..31: block boundaries inside the record's
+    //                span (hi - lo: 0, 1, 2 = more -> binary search), hi in word 14
+    //   words 9..13  {max hash, first hash} of blocks lo and lo + 1, first hash of block lo + 2 (copies of `blockrec`)
+    // (Before: a 512-MB bitmap, a bucket table and the block records apart -- three lines per probe in two dependent
+    // levels; at batch 1024 those lines were 60 % of the kernel's HBM requests.)
+    const uint32_t* proberec;      // 2^(24 - present_shift) records of 16 words, or null
     const uint2*    blockrec;      // [num_blocks + 3] {max hash, first hash} of each block (+ all-ones sentinels): what the lean
                                    // kernel needs of block_index, the header and the continuation bitmap in one 8-byte record
     // small segments (< 2^20 items) are also kept DECODED: sorted items + where each block starts among them
@@ -113,7 +119,7 @@ struct Segment {
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
-    uint32_t* d_present = nullptr; uint2* d_blockrec = nullptr; uint32_t present_shift = 0;   // presence bitmap, block records (see SegDesc)
+    uint32_t* d_proberec = nullptr; uint2* d_blockrec = nullptr; uint32_t present_shift = 0;   // probe records, block records (see SegDesc)
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment
@@ -242,7 +248,7 @@ int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num
 int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool sorted, uint32_t block_size,
                        uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, Segment* s);
 int decode_small_segment(Segment* s);     // fills d_small_items / d_bstart of a resident file segment
-int build_presence(Segment* s);           // fills d_blockrec (required by the lean kernel) and d_present (optional) of a resident file segment
+int build_presence(Segment* s);           // fills d_blockrec and d_proberec (both required by the lean kernel) of a resident file segment
 struct MergeSource { const Segment* seg; std::vector<uint32_t> dead; };   // dead = skip_docs, sorted
 int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_t block_size, uint32_t min_doc_id, Segment* s);
 

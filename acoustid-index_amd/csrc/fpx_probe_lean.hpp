@@ -158,8 +158,14 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
         // ---- phase 1: LEAN_KPL pairs per lane, dedup + block lookup in lockstep
         const uint64_t wave_base = wg_base + (uint64_t)round * (L8_WAVES * 64u * LEAN_KPL) + (uint64_t)wave * (64u * LEAN_KPL);
         const uint32_t wave_pair0 = (uint32_t)wave_base;
-        uint32_t h[LEAN_KPL], q[LEAN_KPL], b0v[LEAN_KPL], lo[LEAN_KPL], hi[LEAN_KPL];
-        bool any_open = false;
+        uint32_t h[LEAN_KPL], q[LEAN_KPL], b0v[LEAN_KPL], lo[LEAN_KPL];
+        uint32_t rax[LEAN_KPL], ray[LEAN_KPL], rbx[LEAN_KPL], rby[LEAN_KPL], rcy[LEAN_KPL];
+        // One probe record (SegDesc::proberec) per pair: the presence bit of h, the first block `lo` of the record's hash
+        // span with how many block boundaries the span holds (bits 30..31: 0, 1, or 2 = more), and {max hash, first hash}
+        // of blocks lo, lo + 1 (+ the first hash of lo + 2) -- one cache line, one level of loads, its address a function
+        // of the hash alone.  That settles the lower_bound (src/FileSegment.zig:145-151), the gap test and the continuation
+        // flag; the hashes ascend, so a big batch reads the records as a stream.
+        bool wide = false;
 #pragma unroll
         for (int j = 0; j < LEAN_KPL; ++j) {
             const uint64_t p = wave_base + (uint64_t)j * 64u + lane;
@@ -168,69 +174,59 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             if (valid && is_duplicate_pair(a.pairs, p, key, a.qb)) valid = false;          // dedupSorted, src/Index.zig:489-499
             h[j] = (uint32_t)(key >> a.qb);
             q[j] = (uint32_t)key & qmask;
-            lo[j] = 0; hi[j] = 0;
+            lo[j] = 0;
+            rax[j] = ray[j] = rbx[j] = rby[j] = rcy[j] = 0xFFFFFFFFu;
             uint32_t pbit = 1u;
             if (seg.own_flags != 0u && !owned_hash(seg, h[j])) valid = false;      // another slice of the segment probes h
             if (valid) {
                 my_probes += 1;
-                const uint32_t kb = seg.bucket_shift >= 32u ? 0u : (h[j] >> seg.bucket_shift);
-                lo[j] = gload_u32(seg.bucket + kb);
-                hi[j] = gload_u32(seg.bucket + kb + 1);
-                if (seg.present) {                                                 // sorted hashes: the bitmap is read as a stream
-                    const uint32_t pi = h[j] >> seg.present_shift;
-                    pbit = (gload_u32(seg.present + (pi >> 5)) >> (pi & 31u)) & 1u;
-                }
+                const uint32_t pi = h[j] >> seg.present_shift;
+                const uint32_t* rec = seg.proberec + (size_t)(pi >> 8) * 16u;
+                pbit = (gload_u32(rec + ((pi >> 5) & 7u)) >> (pi & 31u)) & 1u;
+                const uint4 r0 = gload_u4(reinterpret_cast<const uint8_t*>(rec + 8));
+                const uint64_t r1 = gload_u64(reinterpret_cast<const uint64_t*>(rec + 12));
+                lo[j] = r0.x; rax[j] = r0.y; ray[j] = r0.z; rbx[j] = r0.w;
+                rby[j] = (uint32_t)r1; rcy[j] = (uint32_t)(r1 >> 32);
             }
             b0v[j] = valid ? (1u | (pbit << 1)) : 0u;                          // bit 1: some item of the segment has this hash
-            any_open = any_open || lo[j] < hi[j];
+            wide = wide || (lo[j] >> 31) != 0u;
         }
-        // The bucket table leaves 0..1 candidates almost always (about one block per bucket): the records of blocks lo,
-        // lo + 1, lo + 2 -- max hash and first hash each -- settle the lower_bound (src/FileSegment.zig:145-151), the gap
-        // test and the continuation flag in ONE more level of dependent loads.  Buckets with more candidates (runs of
-        // narrow blocks: hot hashes) take the binary search first.
-        bool wide = false;
-#pragma unroll
-        for (int j = 0; j < LEAN_KPL; ++j) wide = wide || (hi[j] - lo[j] >= 2u && lo[j] < hi[j]);
+        // A record's span holds 0..1 block boundaries almost always (about one block per record).  Spans with more (runs of
+        // narrow blocks: hot hashes) take a binary search over block_index and read the block records themselves.
         if (__any((int)wide)) {
-            while (__any((int)any_open)) {
-                any_open = false;
-                uint32_t mid[LEAN_KPL], mv[LEAN_KPL];
 #pragma unroll
-                for (int j = 0; j < LEAN_KPL; ++j) {
-                    mid[j] = (lo[j] + hi[j]) >> 1;
-                    mv[j] = lo[j] < hi[j] ? gload_u32(seg.block_index + mid[j]) : 0u;
+            for (int j = 0; j < LEAN_KPL; ++j) {
+                if ((lo[j] >> 31) == 0u) continue;
+                const uint32_t pi = h[j] >> seg.present_shift;
+                uint32_t l = lo[j] & 0x3FFFFFFFu, r = gload_u32(seg.proberec + (size_t)(pi >> 8) * 16u + 14u);
+                while (l < r) {
+                    const uint32_t m = (l + r) >> 1;
+                    if (gload_u32(seg.block_index + m) < h[j]) l = m + 1; else r = m;
                 }
-#pragma unroll
-                for (int j = 0; j < LEAN_KPL; ++j) {
-                    if (lo[j] < hi[j]) { if (mv[j] < h[j]) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
-                    any_open = any_open || lo[j] < hi[j];
-                }
+                const bool ld = l < seg.num_blocks;                                // (l <= num_blocks: three sentinels follow)
+                const uint64_t* br = reinterpret_cast<const uint64_t*>(seg.blockrec) + l;
+                const uint64_t a0 = ld ? gload_u64(br) : ~0ull, a1 = ld ? gload_u64(br + 1) : ~0ull, a2 = ld ? gload_u64(br + 2) : ~0ull;
+                lo[j] = l;                                                         // settled: class 0
+                rax[j] = (uint32_t)a0; ray[j] = (uint32_t)(a0 >> 32);
+                rbx[j] = (uint32_t)a1; rby[j] = (uint32_t)(a1 >> 32);
+                rcy[j] = (uint32_t)(a2 >> 32);
             }
         }
-        uint2 ra[LEAN_KPL], rb[LEAN_KPL], rc[LEAN_KPL];
 #pragma unroll
         for (int j = 0; j < LEAN_KPL; ++j) {
-            const bool ld = b0v[j] != 0u && lo[j] < seg.num_blocks;               // (lo <= num_blocks: three sentinels follow)
-            const uint64_t* r = reinterpret_cast<const uint64_t*>(seg.blockrec) + lo[j];
-            const uint64_t a0 = ld ? gload_u64(r) : ~0ull, a1 = ld ? gload_u64(r + 1) : ~0ull, a2 = ld ? gload_u64(r + 2) : ~0ull;
-            ra[j] = make_uint2((uint32_t)a0, (uint32_t)(a0 >> 32));
-            rb[j] = make_uint2((uint32_t)a1, (uint32_t)(a1 >> 32));
-            rc[j] = make_uint2((uint32_t)a2, (uint32_t)(a2 >> 32));
-        }
-#pragma unroll
-        for (int j = 0; j < LEAN_KPL; ++j) {
-            const bool step = lo[j] < hi[j] && ra[j].x < h[j];                    // the one candidate ends before h
-            const uint32_t b0 = lo[j] + (step ? 1u : 0u);
-            const uint2 cur = step ? rb[j] : ra[j], nxt = step ? rc[j] : rb[j];
+            const uint32_t l0 = lo[j] & 0x3FFFFFFFu;
+            const bool step = (lo[j] >> 30) == 1u && rax[j] < h[j];                // the one candidate ends before h
+            const uint32_t b0 = l0 + (step ? 1u : 0u);
+            const uint32_t cur_max = step ? rbx[j] : rax[j], cur_first = step ? rby[j] : ray[j], nxt_first = step ? rcy[j] : rby[j];
             bool valid = b0v[j] != 0u && b0 < seg.num_blocks;
             if (valid && (b0v[j] & 2u) == 0u) {
                 // no item of the segment has this hash: FileSegment.search would visit block b0 (unless h lies in the gap
                 // before it, src/FileSegment.zig:164), find nothing and stop -- counted here, the block stays unread
-                if (cur.y <= h[j]) my_blocks += 1;
+                if (cur_first <= h[j]) my_blocks += 1;
                 valid = false;
             }
             // may the hash's run continue in block b0 + 1?  (it starts with this block's last hash)
-            const bool cont = valid && b0 + 1u < seg.num_blocks && nxt.y == cur.x;
+            const bool cont = valid && b0 + 1u < seg.num_blocks && nxt_first == cur_max;
             b0v[j] = (b0 & 0x3FFFFFFFu) | (valid ? 0x80000000u : 0u) | (cont ? 0x40000000u : 0u);   // bits 31 / 30 ride through the row broadcast
         }
 

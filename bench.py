@@ -83,12 +83,12 @@ def touched_bytes(table_bytes, n_probes, line=128):
     return table_bytes * (1.0 - float(np.exp(-n_probes * line / table_bytes)))
 
 
-def bitmap_size(n_items):
-    """as build_presence (csrc/fpx_build.hip): >= 5.7 bits per item"""
+def probe_record_bytes(n_items):
+    """as build_presence (csrc/fpx_build.hip): one 64-B probe record per 256 presence bits, >= 5.7 bits per item"""
     shift = 0
     while shift < 22 and (1 << (31 - shift)) * 7 >= n_items * 40:
         shift += 1
-    return (1 << (32 - shift)) // 8
+    return (1 << (24 - shift)) * 64
 
 
 class StatAgg:
@@ -109,25 +109,18 @@ class StatAgg:
 
 def model_moved_bytes(segs, fetched_per_launch, probes_per_launch):
     """What the dominant kernel has to pull from HBM per launch, modelled from counts the kernel reports: the blocks it
-    fetched (counted) + the lines of the presence bitmaps, bucket tables and block records its probes touch (expected
-    value for uniform hashes at 128-B lines)."""
-    pmin = int(os.environ.get("FPX_PRESENCE_MIN_ITEMS", 1 << 20))
+    fetched (counted) + the 128-B lines of the probe records (presence bits + block range + block records, 64 B per 256
+    hash buckets) its probes touch (expected value for uniform hashes) + the sorted pairs (8 B per probe)."""
     files = [sg for sg in segs if sg.kind == "file"]
     if not files:
-        return {"blocks": fetched_per_launch, "presence_bitmaps": 0.0, "bucket_tables": 0.0, "block_records": 0.0, "total": fetched_per_launch}
+        return {"blocks": fetched_per_launch, "probe_records": 0.0, "pairs": 0.0, "total": fetched_per_launch}
     per_seg = probes_per_launch / len(files)
-    bm = bk = br = 0.0
+    pr = 0.0
     for sg in files:
-        nb = sg.num_blocks
-        if sg.getSize() >= pmin:
-            bm += touched_bytes(bitmap_size(sg.getSize()), per_seg)
-            br += touched_bytes(8.0 * (nb + 3), per_seg)
-        nbuck = 1
-        while nbuck < nb and nbuck < (1 << 25):
-            nbuck *= 2
-        bk += touched_bytes(4.0 * (nbuck + 1), per_seg)
-    return {"blocks": fetched_per_launch, "presence_bitmaps": bm, "bucket_tables": bk, "block_records": br,
-            "total": fetched_per_launch + bm + bk + br}
+        if sg.getSize() >= (1 << 20):
+            pr += touched_bytes(float(probe_record_bytes(sg.getSize())), per_seg)
+    pairs = 8.0 * probes_per_launch
+    return {"blocks": fetched_per_launch, "probe_records": pr, "pairs": pairs, "total": fetched_per_launch + pr + pairs}
 
 
 def timed_resident(fpx, reader, qb, steps, warmup, out=None, out_n=None):
@@ -537,8 +530,8 @@ def main():
                          "achieved_basis": "model",
                          "avg_launch_ms": avg_ms, "launches_timed": launches,
                          "moved_model": {**moved, "GBs": moved_gbs, "frac": moved_gbs / HBM_PEAK_GBS,
-                                         "note": "blocks the kernel fetched (counted by the kernel) + the 128-B lines of presence bitmaps, bucket tables and "
-                                                 "block records its probes touch (expected value for uniform hashes)"},
+                                         "note": "blocks the kernel fetched (counted by the kernel) + the 128-B lines of probe records its probes touch "
+                                                 "(expected value for uniform hashes) + the sorted pairs (8 B per probe; re-read per segment)"},
                          "reference_equivalent": {"bytes_per_launch": ref_bytes, "GBs": ref_gbs, "over_peak": ref_gbs / HBM_PEAK_GBS,
                                                   "note": "SURVEY 8(d)'s algorithmic figure: 512 B for every block the REFERENCE visits.  NOT a roofline "
                                                           "fraction: the presence bitmaps answer the probes of absent hashes without reading their block, "

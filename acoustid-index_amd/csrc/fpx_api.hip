@@ -523,15 +523,19 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     }
     if (e == hipSuccess && sn->n_file) {
         // k_probe_lean8 pays off on 512-B segments dense enough that hash deltas fit two bytes (>= 2^20 items)
-        std::vector<SegDesc> lean, gen, small;
+        std::vector<SegDesc> lean, lean4, gen, small;
         size_t fi = 0;
         for (Segment* sg : sn->segs) {
             if (sg->kind != 0 || sg->ctx != c) continue;
             const SegDesc& d = sn->h_file[fi++];
-            if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30) && d.blockrec && d.proberec) lean.push_back(d);
+            if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30) && d.blockrec && d.proberec) {
+                if (sg->head_lines == 2) lean.push_back(d); else lean4.push_back(d);
+            }
             else if (d.items) { small.push_back(d); sn->max_small_blocks = std::max(sn->max_small_blocks, d.num_blocks); }
             else { gen.push_back(d); if (d.block_size != 512) sn->gen_all_512 = false; }
         }
+        sn->n_lean2 = (uint32_t)lean.size();                     // partial-fetch segments first, whole-block ones behind
+        lean.insert(lean.end(), lean4.begin(), lean4.end());
         sn->n_lean = (uint32_t)lean.size(); sn->n_gen = (uint32_t)gen.size(); sn->n_small = (uint32_t)small.size();
         if (sn->n_small) {
             e = hipMalloc(&sn->d_small, small.size() * sizeof(SegDesc));

@@ -659,13 +659,23 @@ static uint64_t presence_min_items()
     return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 20);
 }
 
-// {block_index[b], header min_hash} per block, three all-ones sentinels behind
+// {block_index[b], header min_hash} per block, three all-ones sentinels behind; head_max = the largest end (in bytes) of
+// header + hash control + hash data + docid control bytes over all blocks (src/block.zig:46-50: docids_offset at byte 6)
 __global__ void k_block_records(const uint8_t* __restrict__ blocks, const uint32_t* __restrict__ block_index, uint32_t num_blocks,
-                                uint2* __restrict__ rec)
+                                uint2* __restrict__ rec, unsigned int* __restrict__ head_max)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < num_blocks) rec[b] = make_uint2(block_index[b], *reinterpret_cast<const uint32_t*>(blocks + (size_t)b * 512u));
-    else if (b < num_blocks + 3u) rec[b] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    uint32_t head_end = 0;
+    if (b < num_blocks) {
+        const uint8_t* blk = blocks + (size_t)b * 512u;
+        rec[b] = make_uint2(block_index[b], *reinterpret_cast<const uint32_t*>(blk));
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(blk + 4);
+        head_end = 8u + (w >> 16) + (((w & 0xFFFFu) + 3u) >> 2);
+    } else if (b < num_blocks + 3u) {
+        rec[b] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+    for (int d = 32; d > 0; d >>= 1) head_end = max(head_end, (uint32_t)__shfl_down((int)head_end, d));
+    if ((threadIdx.x & 63u) == 0u && head_end) atomicMax(head_max, head_end);
 }
 
 // words 8..15 of every probe record: the block range of its hash span and the records of the first three blocks
@@ -698,9 +708,19 @@ int build_presence(Segment* s)
     if (s->block_size != 512 || s->num_blocks == 0 || s->num_items < (1ull << 20)) return FPX_OK;      // not a lean segment
     FPX_HIP(hipMalloc(&s->d_blockrec, ((size_t)s->num_blocks + 3) * sizeof(uint2)));
     s->device_bytes += ((size_t)s->num_blocks + 3) * sizeof(uint2);
+    unsigned int* d_head_max = nullptr;
+    FPX_HIP(hipMalloc(&d_head_max, sizeof(unsigned int)));
+    FPX_HIP(hipMemsetAsync(d_head_max, 0, sizeof(unsigned int), 0));
     hipLaunchKernelGGL(k_block_records, dim3((s->num_blocks + 3 + 255) / 256), dim3(256), 0, 0,
-                       s->d_blocks, s->d_block_index, s->num_blocks, s->d_blockrec);
+                       s->d_blocks, s->d_block_index, s->num_blocks, s->d_blockrec, d_head_max);
+    unsigned int head_max = 512;
+    const hipError_t he = hipMemcpy(&head_max, d_head_max, sizeof head_max, hipMemcpyDeviceToHost);
+    (void)hipFree(d_head_max);
+    if (he != hipSuccess) return hip_fail(he, "block records");
     FPX_HIP(hipGetLastError());
+    // (the docid control bytes are read as one dword per lane: 4 bytes of slack)
+    static const int forced_head = [] { const char* e = getenv("FPX_LEAN_HEAD"); return e ? atoi(e) : 0; }();
+    s->head_lines = (head_max + 4u <= 256u && forced_head != 4) ? 2u : 4u;
     // one presence bit per 2^shift hash values, the largest shift that leaves >= 5.7 bits per item (<= 16 % of them set,
     // 16 % on top of the blocks' bytes); a segment of more than 2^32 / 5.7 items gets shift 0 (1.6 G items: 31 % set).
     // 256 bits per probe record: 2^(24 - shift) records of 64 B, i.e. twice the bitmap's size.

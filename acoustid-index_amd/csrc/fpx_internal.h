@@ -120,6 +120,8 @@ struct Segment {
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
     uint32_t* d_proberec = nullptr; uint2* d_blockrec = nullptr; uint32_t present_shift = 0;   // probe records, block records (see SegDesc)
+    uint32_t head_lines = 4;       // 2: in EVERY block the header, the hashes and the docid control bytes end before byte 252, so
+                                   // k_probe_lean8<2> may fetch two 128-B lines first and the matching docid bytes afterwards
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment
@@ -138,6 +140,7 @@ struct Snapshot {
     SegDesc* d_file = nullptr; uint32_t n_file = 0;
     // file segments split by the kernel that suits them: dense 512-B segments (lean) and the rest (generic)
     SegDesc* d_lean = nullptr; uint32_t n_lean = 0;
+    uint32_t n_lean2 = 0;                // the first n_lean2 of them qualify for the partial block fetch (Segment::head_lines == 2)
     SegDesc* d_gen = nullptr; uint32_t n_gen = 0; bool gen_all_512 = true;
     SegDesc* d_small = nullptr; uint32_t n_small = 0;     // small segments searched in their decoded items
     uint32_t max_small_blocks = 0;

@@ -114,8 +114,17 @@ __device__ __forceinline__ uint32_t sel4(uint32_t i, uint32_t v0, uint32_t v1, u
     return r;
 }
 
-__global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
+// HEAD: how many 128-byte lines of a block are fetched up front.  4 = the whole block.  2 = header, hashes and docid
+// control bytes (they end before byte 252 in every block of a segment that qualifies, SegDesc::head_lines): the few docid
+// bytes of the matching run are fetched afterwards, straight from global memory, when they lie beyond byte 256 -- 73 % of
+// the runs on the 100 M index, one more line instead of two.  HBM serves ~47 G lines/s however they are scattered, so a
+// read block costs 2.75 requests instead of 4.  The late bytes are consumed one iteration later (the hits of iteration i
+// are emitted during iteration i + 1), so their latency hides behind the next blocks' decode.
+typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
+template <int HEAD>
+__global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_probe_lean8(ProbeArgs a)
 {
+    static_assert(HEAD == 2 || HEAD == 4, "HEAD");
     extern __shared__ __align__(16) uint8_t smem[];
     uint64_t* stage = reinterpret_cast<uint64_t*>(smem);                  // STAGE_CAP records
     LeanLut* lut = reinterpret_cast<LeanLut*>(smem + STAGE_CAP * sizeof(uint64_t));
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
     __syncthreads();
     if (s_cancel) return;
 
-    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;
+    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0;      // (my_blocks: bits 16..31 count the late docid lines of HEAD == 2)
     // (the descriptor in global memory, not the local copy: taking `seg`'s address would pin all its fields in VGPRs)
     const SegDesc* dead_filter = seg.num_dead != 0u ? a.segs + blockIdx.y : nullptr;
     const uint32_t k = l & 3u;
@@ -264,18 +273,23 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             __builtin_amdgcn_wave_barrier();
         }
 
-        if (lane == 0 && S != 0u) atomicAdd(&wg_reads, (unsigned long long)S);      // blocks this kernel really fetches
+        if (lane == 0 && S != 0u) atomicAdd(&wg_reads, (unsigned long long)S * (unsigned)HEAD);      // 128-B lines this kernel really fetches (+ the late docid lines below)
 
         // ---- phase 2: eight probes per iteration, one per 8-lane group, blocks prefetched one iteration ahead
         const uint32_t iters = (S + 7u) >> 3;
-        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+        uint4 pre[HEAD];
+#pragma unroll
+        for (int i = 0; i < HEAD; ++i) pre[i] = make_uint4(0, 0, 0, 0);
         {
             const uint32_t nb = __shfl(b0v[0], (int)g);
             if (nb >> 31) {
                 const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + l * 16u;
-                pre0 = gload_u4(sb); pre1 = gload_u4(sb + 128); pre2 = gload_u4(sb + 256); pre3 = gload_u4(sb + 384);
+#pragma unroll
+                for (int i = 0; i < HEAD; ++i) pre[i] = gload_u4(sb + 128 * i);
             }
         }
+        // HEAD == 2: the matches of the previous iteration, waiting for their docid bytes
+        uint32_t c_raw = 0, c_pq = 0;      // c_pq: the query (24 bits) | bits 24..25 my value's 1234 code, bit 26 run member, bit 27 emit
 #pragma unroll 1
         for (uint32_t it = 0; it < iters; ++it) {
             const uint32_t j = it >> 3;                                       // which of the lane's keys (wave-uniform)
@@ -288,10 +302,8 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             const uint32_t pq = pqx & 0x00FFFFFFu;                              // bits 24..31: the pair's position in the wave
             const uint32_t pbv = __shfl(bj, src);
             const bool pact = (pbv >> 31) != 0u;
-            *reinterpret_cast<uint4*>(blk + l * 16u) = pre0;
-            *reinterpret_cast<uint4*>(blk + 128u + l * 16u) = pre1;
-            *reinterpret_cast<uint4*>(blk + 256u + l * 16u) = pre2;
-            *reinterpret_cast<uint4*>(blk + 384u + l * 16u) = pre3;
+#pragma unroll
+            for (int i = 0; i < HEAD; ++i) *reinterpret_cast<uint4*>(blk + 128u * i + l * 16u) = pre[i];
             if (it + 1u < iters) {
                 const uint32_t jn = (it + 1u) >> 3;
                 uint32_t bn = b0v[0];
@@ -300,7 +312,8 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                 const uint32_t nb = __shfl(bn, (int)(((it + 1u) & 7u) * 8u + g));
                 if (nb >> 31) {
                     const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + l * 16u;
-                    pre0 = gload_u4(sb); pre1 = gload_u4(sb + 128); pre2 = gload_u4(sb + 256); pre3 = gload_u4(sb + 384);
+#pragma unroll
+                    for (int i = 0; i < HEAD; ++i) pre[i] = gload_u4(sb + 128 * i);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -386,6 +399,16 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
             }
             const unsigned long long me0 = __ballot((int)ek0), me1 = __ballot((int)ek1);
             uint32_t cnt = 0, doc0 = 0, doc1 = 0;
+            uint32_t n_raw = 0, n_code = 0;                 // HEAD == 2: my docid value's bytes (late or from LDS) and its 1234 code
+            bool two_now = false;                           // HEAD == 2: this group's two-quad run is emitted right away
+            if constexpr (HEAD == 2) {
+                // the previous iteration's matches: their docid bytes have had an iteration to arrive
+                const uint32_t pc = (c_pq >> 24) & 3u;
+                const uint32_t dv = c_raw & (0xFFFFFFFFu >> (8u * (3u - pc)));
+                const uint32_t pdoc = seg.min_doc_id + scanq((c_pq & (4u << 24)) ? dv : 0u, km1, km2);
+                stage_emit(hs, a, (c_pq & (8u << 24)) != 0u, ((uint64_t)(c_pq & 0x00FFFFFFu) << 32) | pdoc, lane, dead_filter);
+                c_pq = 0;
+            }
             if ((me0 | me1) != 0ull) {
                 // -- docids of the run: 1234 lengths of my quads from the control bytes (4 + the sum of the codes per quad)
                 const uint32_t dcc = lds_u32u(smem, blko + 8u + doff + q0) & vmask;
@@ -397,23 +420,47 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                 const uint32_t dpack1 = ((dp0 + 4u * i1 + __popc(dlo & bm1) + 2u * __popc(dhi & bm1)) & 1023u) |
                                         (((dcc >> (8u * i1)) & 0xFFu) << 10);
                 const uint32_t y0 = __shfl(dpack1, owner0);
-                const uint32_t dv0 = decode_one8<1>(lut, smem, blko + (y0 & 1023u), (y0 >> 10) & 0xFFu, k);
-                doc0 = seg.min_doc_id + scanq(ek0 ? dv0 : 0u, km1, km2);
                 const uint32_t erow0 = ((uint32_t)(me0 >> (8u * g))) & 0xFu;
                 cnt = __popc(erow0);
                 uint32_t elast = erow0, qlast = qc1;                           // the quad that ends the run
+                if constexpr (HEAD == 4) {
+                    const uint32_t dv0 = decode_one8<1>(lut, smem, blko + (y0 & 1023u), (y0 >> 10) & 0xFFu, k);
+                    doc0 = seg.min_doc_id + scanq(ek0 ? dv0 : 0u, km1, km2);
+                } else {
+                    // my value of the quad: byte offset in the block and 1234 code; within the staged 256 bytes it is read from
+                    // LDS, beyond them from global memory (an unaligned dword: at most 3 bytes past the block, which the
+                    // segment's tail slack covers).  Either way it is consumed in the next iteration.
+                    const uint32_t c_d = (y0 >> 10) & 0xFFu;
+                    const uint32_t la = lut->a[1][c_d];
+                    const uint32_t o = (y0 & 1023u) + (((la << 8) >> (8u * k)) & 0xFFu);
+                    n_code = (c_d >> (2u * k)) & 3u;
+                    const bool far = ek0 && !two && o + 4u > 256u;
+                    const unsigned long long mfar = __ballot((int)far);
+                    if (l == 0u && ((((uint32_t)(mfar >> (8u * g))) & 0xFu) != 0u)) my_blocks += 0x10000u;  // one more line for this probe
+                    if (ek0 && !two) {
+                        if (far) n_raw = *(const FPX_GLOBAL u32_unaligned_t*)(seg.blocks + (size_t)(pbv & 0x3FFFFFFFu) * 512u + o);
+                        else n_raw = lds_u32u(smem, blko + o);
+                    }
+                }
                 if (me1 != 0ull) {
                     const uint32_t bm2 = (1u << (8u * i2)) - 1u;
                     const uint32_t dpack2 = ((dp0 + 4u * i2 + __popc(dlo & bm2) + 2u * __popc(dhi & bm2)) & 1023u) |
                                             (((dcc >> (8u * i2)) & 0xFFu) << 10);
                     const uint32_t y1 = __shfl(dpack2, owner1);
+                    if constexpr (HEAD == 2) {
+                        // a run over two quads is decoded right here (the second quad continues the first): both must lie within
+                        // the staged 256 bytes -- the upper quad follows the lower one in the docid stream --, else the generic pass
+                        if (two && (y1 & 1023u) + 16u > 256u) defer = true;
+                        const uint32_t dv0 = decode_one8<1>(lut, smem, blko + (y0 & 1023u), (y0 >> 10) & 0xFFu, k);
+                        doc0 = seg.min_doc_id + scanq(ek0 ? dv0 : 0u, km1, km2);
+                    }
                     const uint32_t dv1 = decode_one8<1>(lut, smem, blko + (y1 & 1023u), (y1 >> 10) & 0xFFu, k);
                     // the run continues from the lower quad's last item (lane 3 of the group)
                     const uint32_t carry = dpp_u32<0xFF>(doc0);               // quad_perm:[3,3,3,3]
                     doc1 = carry + scanq(ek1 ? dv1 : 0u, km1, km2);
                     const uint32_t erow1 = ((uint32_t)(me1 >> (8u * g))) & 0xFu;
                     cnt += __popc(erow1);
-                    if (two) { elast = erow1; qlast = qc1 + 1u; }
+                    if (two) { elast = erow1; qlast = qc1 + 1u; two_now = true; }
                 }
                 // a run that reaches the block's last item continues in the next block when that one starts with the same hash
                 // (the segment's continuation bitmap): let k_probe finish it
@@ -441,10 +488,26 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
                 }
             }
             // -- emission (wave-uniform control flow)
-            const int nsets = me1 != 0ull ? 2 : 1;
-            for (int e = 0; e < nsets; ++e) {
-                stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane, dead_filter);
+            if constexpr (HEAD == 4) {
+                const int nsets = me1 != 0ull ? 2 : 1;
+                for (int e = 0; e < nsets; ++e) {
+                    stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane, dead_filter);
+                }
+            } else {
+                if (me1 != 0ull) {                              // two-quad runs: both decoded from LDS above, emitted now
+                    stage_emit(hs, a, keep0 && two_now, ((uint64_t)pq << 32) | doc0, lane, dead_filter);
+                    stage_emit(hs, a, keep1, ((uint64_t)pq << 32) | doc1, lane, dead_filter);
+                }
+                // everything else waits one iteration for its docid bytes
+                c_raw = n_raw;
+                c_pq = pq | ((n_code | ((ek0 && !two_now) ? 4u : 0u) | ((keep0 && !two_now) ? 8u : 0u)) << 24);
             }
+        }
+        if constexpr (HEAD == 2) {                              // the last iteration's matches
+            const uint32_t pc = (c_pq >> 24) & 3u;
+            const uint32_t dv = c_raw & (0xFFFFFFFFu >> (8u * (3u - pc)));
+            const uint32_t pdoc = seg.min_doc_id + scanq((c_pq & (4u << 24)) ? dv : 0u, km1, km2);
+            stage_emit(hs, a, (c_pq & (8u << 24)) != 0u, ((uint64_t)(c_pq & 0x00FFFFFFu) << 32) | pdoc, lane, dead_filter);
         }
 
         // ---- flush the LDS staging buffer at round boundaries
@@ -464,6 +527,8 @@ __global__ __launch_bounds__(L8_WG) void k_probe_lean8(ProbeArgs a)
         }
     }
 
+    if (my_blocks >> 16) atomicAdd(&wg_reads, (unsigned long long)(my_blocks >> 16));      // late docid lines (one per run beyond byte 256)
+    my_blocks &= 0xFFFFu;
     if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
     if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
     if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);

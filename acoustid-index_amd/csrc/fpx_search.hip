@@ -355,7 +355,17 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
                     const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;
                     const uint32_t gx8 = (uint32_t)((P + per_wg_8 - 1) / per_wg_8);
-                    hipLaunchKernelGGL(k_probe_lean8, dim3(gx8, snap->n_lean), dim3(L8_WG), lds8, st, l);
+                    // d_lean lists the segments whose blocks' head (header, hashes, docid control bytes) fits two lines first:
+                    // they take the partial-fetch instantiation, the rest the whole-block one
+                    if (snap->n_lean2)
+                        hipLaunchKernelGGL(k_probe_lean8<2>, dim3(gx8, snap->n_lean2), dim3(L8_WG), lds8, st, l);
+                    if (snap->n_lean > snap->n_lean2) {
+                        ProbeArgs l4 = l;
+                        l4.segs = snap->d_lean + snap->n_lean2;
+                        l4.def_list = l.def_list + (size_t)snap->n_lean2 * l.def_cap;
+                        l4.def_count = l.def_count + (size_t)snap->n_lean2 * DEF_COUNT_STRIDE;
+                        hipLaunchKernelGGL(k_probe_lean8<4>, dim3(gx8, snap->n_lean - snap->n_lean2), dim3(L8_WG), lds8, st, l4);
+                    }
                 }
                 FPX_HIP(hipEventRecord(ws->ev_probe1, st));
                 // auxiliary passes: the rows the lean kernel deferred, and the segments it does not suit
@@ -493,7 +503,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_probes = ws->h_counters[CTR_PROBES] + ws->h_counters[8 + CTR_PROBES],
                              c_generic = ws->h_counters[CTR_GENERIC],
                              c_main_bytes = (used_lean && snap->n_lean) ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES],
-                             c_fetched_bytes = (used_lean && snap->n_lean) ? ws->h_counters[CTR_LEAN_READS] * 512ull : ws->h_counters[CTR_BYTES];
+                             c_fetched_bytes = (used_lean && snap->n_lean) ? ws->h_counters[CTR_LEAN_READS] * 128ull : ws->h_counters[CTR_BYTES];   // (lines)
 
     uint64_t C = 0, C_slots = 0;                   // candidates in the shared list / in the queries' own slots
     uint64_t* d_qcand = nullptr;

@@ -376,40 +376,43 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 defer = defer | (ncand >= 2u && !two);
             }
 
-            // -- level 2: lanes 0..3 of the group decode the candidate quad(s)
+            // -- level 2: the group decodes the candidate quad on lanes 0..3 and -- for a run that crosses into the next quad
+            //    -- that quad on lanes 4..7: lane l holds value l & 3 of its quad
             const uint32_t pack1 = sel4(i1, p0, p1, p2, p3) | (sel4(i1, c0, c1, c2, c3) << 10);
             const uint32_t ut1 = sel4(i1, u0, u1, u2, u3);
             const int owner0 = (int)((lane & 56u) | ((qc1 >> 2) & 7u));
-            const uint32_t x0 = __shfl(pack1, owner0);
+            uint32_t x = __shfl(pack1, owner0);
             const uint32_t ut0 = __shfl(ut1, owner0);
-            const uint32_t val0 = decode_one8<0>(lut, smem, blko + (x0 & 1023u), (x0 >> 10) & 0xFFu, k);
-            const bool live = visited & !defer & low4;
-            const bool ek0 = live & (ncand != 0u) & (scanq(val0, km1, km2) == ut0);
-            bool ek1 = false;
+            const bool live = visited & !defer;
+            const bool any_two = __any((int)(two && live));
             int owner1 = owner0;
             uint32_t i2 = 0;
-            if (__any((int)(two && live))) {
+            if (any_two) {
                 const uint32_t qn = qc1 + 1u;
                 i2 = qn & 3u;
                 owner1 = (int)((lane & 56u) | ((qn >> 2) & 7u));
                 const uint32_t pack2 = sel4(i2, p0, p1, p2, p3) | (sel4(i2, c0, c1, c2, c3) << 10);
                 const uint32_t x1 = __shfl(pack2, owner1);
-                const uint32_t val1 = decode_one8<0>(lut, smem, blko + (x1 & 1023u), (x1 >> 10) & 0xFFu, k);
-                ek1 = live && two && scanq(val1, km1, km2) == 0u;           // the leading zero deltas of the upper quad
+                if (!low4) x = x1;
             }
-            const unsigned long long me0 = __ballot((int)ek0), me1 = __ballot((int)ek1);
-            uint32_t cnt = 0, doc0 = 0, doc1 = 0;
-            uint32_t n_raw = 0, n_code = 0;                 // HEAD == 2: my docid value's bytes (late or from LDS) and its 1234 code
-            bool two_now = false;                           // HEAD == 2: this group's two-quad run is emitted right away
+            const uint32_t val = decode_one8<0>(lut, smem, blko + (x & 1023u), (x >> 10) & 0xFFu, k);
+            const uint32_t vsum = scanq(val, km1, km2);                      // prefix sums inside each quad of lanes
+            // members of the run: in the candidate quad the items whose prefix sum hits the target; in the upper quad its
+            // leading zero deltas
+            const bool ek = live & (low4 ? ((ncand != 0u) & (vsum == ut0)) : (two & (vsum == 0u)));
+            const unsigned long long me = __ballot((int)ek);
+            const uint32_t erow = ((uint32_t)(me >> (8u * g))) & 0xFFu;       // bits 0..3: candidate quad, 4..7: upper quad
+            uint32_t cnt = 0;
             if constexpr (HEAD == 2) {
                 // the previous iteration's matches: their docid bytes have had an iteration to arrive
                 const uint32_t pc = (c_pq >> 24) & 3u;
                 const uint32_t dv = c_raw & (0xFFFFFFFFu >> (8u * (3u - pc)));
-                const uint32_t pdoc = seg.min_doc_id + scanq((c_pq & (4u << 24)) ? dv : 0u, km1, km2);
+                const uint32_t pdoc = seg.min_doc_id + scan8((c_pq & (4u << 24)) ? dv : 0u, hi_group);
                 stage_emit(hs, a, (c_pq & (8u << 24)) != 0u, ((uint64_t)(c_pq & 0x00FFFFFFu) << 32) | pdoc, lane, dead_filter);
                 c_pq = 0;
             }
-            if ((me0 | me1) != 0ull) {
+            uint32_t n_raw = 0, n_code = 0;                 // my docid value's bytes and its 1234 code
+            if (me != 0ull) {
                 // -- docids of the run: 1234 lengths of my quads from the control bytes (4 + the sum of the codes per quad)
                 const uint32_t dcc = lds_u32u(smem, blko + 8u + doff + q0) & vmask;
                 const uint32_t dlo = dcc & 0x55555555u, dhi = (dcc >> 1) & 0x55555555u;
@@ -419,48 +422,34 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 const uint32_t bm1 = (1u << (8u * i1)) - 1u;                 // control bytes below slot i1
                 const uint32_t dpack1 = ((dp0 + 4u * i1 + __popc(dlo & bm1) + 2u * __popc(dhi & bm1)) & 1023u) |
                                         (((dcc >> (8u * i1)) & 0xFFu) << 10);
-                const uint32_t y0 = __shfl(dpack1, owner0);
-                const uint32_t erow0 = ((uint32_t)(me0 >> (8u * g))) & 0xFu;
-                cnt = __popc(erow0);
-                uint32_t elast = erow0, qlast = qc1;                           // the quad that ends the run
-                if constexpr (HEAD == 4) {
-                    const uint32_t dv0 = decode_one8<1>(lut, smem, blko + (y0 & 1023u), (y0 >> 10) & 0xFFu, k);
-                    doc0 = seg.min_doc_id + scanq(ek0 ? dv0 : 0u, km1, km2);
-                } else {
-                    // my value of the quad: byte offset in the block and 1234 code; within the staged 256 bytes it is read from
-                    // LDS, beyond them from global memory (an unaligned dword: at most 3 bytes past the block, which the
-                    // segment's tail slack covers).  Either way it is consumed in the next iteration.
-                    const uint32_t c_d = (y0 >> 10) & 0xFFu;
-                    const uint32_t la = lut->a[1][c_d];
-                    const uint32_t o = (y0 & 1023u) + (((la << 8) >> (8u * k)) & 0xFFu);
-                    n_code = (c_d >> (2u * k)) & 3u;
-                    const bool far = ek0 && !two && o + 4u > 256u;
-                    const unsigned long long mfar = __ballot((int)far);
-                    if (l == 0u && ((((uint32_t)(mfar >> (8u * g))) & 0xFu) != 0u)) my_blocks += 0x10000u;  // one more line for this probe
-                    if (ek0 && !two) {
-                        if (far) n_raw = *(const FPX_GLOBAL u32_unaligned_t*)(seg.blocks + (size_t)(pbv & 0x3FFFFFFFu) * 512u + o);
-                        else n_raw = lds_u32u(smem, blko + o);
-                    }
-                }
-                if (me1 != 0ull) {
+                uint32_t y = __shfl(dpack1, owner0);
+                if (any_two) {
                     const uint32_t bm2 = (1u << (8u * i2)) - 1u;
                     const uint32_t dpack2 = ((dp0 + 4u * i2 + __popc(dlo & bm2) + 2u * __popc(dhi & bm2)) & 1023u) |
                                             (((dcc >> (8u * i2)) & 0xFFu) << 10);
                     const uint32_t y1 = __shfl(dpack2, owner1);
-                    if constexpr (HEAD == 2) {
-                        // a run over two quads is decoded right here (the second quad continues the first): both must lie within
-                        // the staged 256 bytes -- the upper quad follows the lower one in the docid stream --, else the generic pass
-                        if (two && (y1 & 1023u) + 16u > 256u) defer = true;
-                        const uint32_t dv0 = decode_one8<1>(lut, smem, blko + (y0 & 1023u), (y0 >> 10) & 0xFFu, k);
-                        doc0 = seg.min_doc_id + scanq(ek0 ? dv0 : 0u, km1, km2);
+                    if (!low4) y = y1;
+                }
+                cnt = __popc(erow);
+                // the quad that ends the run: the upper one if the run crossed into it
+                const uint32_t elast = two ? (erow >> 4) : (erow & 0xFu), qlast = two ? qc1 + 1u : qc1;
+                // my value of my quad: byte offset in the block and 1234 code
+                const uint32_t c_d = (y >> 10) & 0xFFu;
+                const uint32_t la = lut->a[1][c_d];
+                const uint32_t o = (y & 1023u) + (((la << 8) >> (8u * k)) & 0xFFu);
+                n_code = (c_d >> (2u * k)) & 3u;
+                if constexpr (HEAD == 4) {
+                    if (ek) n_raw = lds_u32u(smem, blko + o);
+                } else {
+                    // within the staged 256 bytes the value is read from LDS, beyond them from global memory (an unaligned dword:
+                    // at most 3 bytes past the block, which the segment's tail slack covers); consumed in the next iteration
+                    const bool far = ek && o + 4u > 256u;
+                    const unsigned long long mfar = __ballot((int)far);
+                    if (l == 0u && ((((uint32_t)(mfar >> (8u * g))) & 0xFFu) != 0u)) my_blocks += 0x10000u;  // one more line for this probe
+                    if (ek) {
+                        if (far) n_raw = *(const FPX_GLOBAL u32_unaligned_t*)(seg.blocks + (size_t)(pbv & 0x3FFFFFFFu) * 512u + o);
+                        else n_raw = lds_u32u(smem, blko + o);
                     }
-                    const uint32_t dv1 = decode_one8<1>(lut, smem, blko + (y1 & 1023u), (y1 >> 10) & 0xFFu, k);
-                    // the run continues from the lower quad's last item (lane 3 of the group)
-                    const uint32_t carry = dpp_u32<0xFF>(doc0);               // quad_perm:[3,3,3,3]
-                    doc1 = carry + scanq(ek1 ? dv1 : 0u, km1, km2);
-                    const uint32_t erow1 = ((uint32_t)(me1 >> (8u * g))) & 0xFu;
-                    cnt += __popc(erow1);
-                    if (two) { elast = erow1; qlast = qc1 + 1u; two_now = true; }
                 }
                 // a run that reaches the block's last item continues in the next block when that one starts with the same hash
                 // (the segment's continuation bitmap): let k_probe finish it
@@ -468,7 +457,7 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             }
             // (superseded docs are dropped when the staged records are flushed: a dependent load per hit does not belong
             // in this loop -- with 1 % of the docs re-inserted in a newer segment it made the kernel 2.6x slower)
-            const bool keep0 = ek0 && !defer, keep1 = ek1 && !defer;
+            const bool keep = ek && !defer;
             // -- bookkeeping per group
             if (l == 0u && visited) {
                 if (defer) {
@@ -487,26 +476,22 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     my_blocks += 1; my_docs += cnt;
                 }
             }
-            // -- emission (wave-uniform control flow)
+            // -- emission (wave-uniform control flow): doc = min_doc_id + the prefix sum of the run's deltas over the group's
+            //    8 lanes (src/block.zig:235-265: the delta base restarts at min_doc_id where the hash changes)
             if constexpr (HEAD == 4) {
-                const int nsets = me1 != 0ull ? 2 : 1;
-                for (int e = 0; e < nsets; ++e) {
-                    stage_emit(hs, a, e ? keep1 : keep0, ((uint64_t)pq << 32) | (e ? doc1 : doc0), lane, dead_filter);
-                }
+                const uint32_t dv = n_raw & (0xFFFFFFFFu >> (8u * (3u - n_code)));
+                const uint32_t doc = seg.min_doc_id + scan8(ek ? dv : 0u, hi_group);
+                stage_emit(hs, a, keep, ((uint64_t)pq << 32) | doc, lane, dead_filter);
             } else {
-                if (me1 != 0ull) {                              // two-quad runs: both decoded from LDS above, emitted now
-                    stage_emit(hs, a, keep0 && two_now, ((uint64_t)pq << 32) | doc0, lane, dead_filter);
-                    stage_emit(hs, a, keep1, ((uint64_t)pq << 32) | doc1, lane, dead_filter);
-                }
-                // everything else waits one iteration for its docid bytes
+                // the hits wait one iteration for their docid bytes
                 c_raw = n_raw;
-                c_pq = pq | ((n_code | ((ek0 && !two_now) ? 4u : 0u) | ((keep0 && !two_now) ? 8u : 0u)) << 24);
+                c_pq = pq | ((n_code | (ek ? 4u : 0u) | (keep ? 8u : 0u)) << 24);
             }
         }
         if constexpr (HEAD == 2) {                              // the last iteration's matches
             const uint32_t pc = (c_pq >> 24) & 3u;
             const uint32_t dv = c_raw & (0xFFFFFFFFu >> (8u * (3u - pc)));
-            const uint32_t pdoc = seg.min_doc_id + scanq((c_pq & (4u << 24)) ? dv : 0u, km1, km2);
+            const uint32_t pdoc = seg.min_doc_id + scan8((c_pq & (4u << 24)) ? dv : 0u, hi_group);
             stage_emit(hs, a, (c_pq & (8u << 24)) != 0u, ((uint64_t)(c_pq & 0x00FFFFFFu) << 32) | pdoc, lane, dead_filter);
         }
 

@@ -277,10 +277,10 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 
         // ---- phase 2: eight probes per iteration, one per 8-lane group, blocks prefetched one iteration ahead
         const uint32_t iters = (S + 7u) >> 3;
-        // HEAD == 4: one iteration ahead (4 x 16 B per lane in flight).  HEAD == 2: TWO iterations ahead in two register sets used
-        // by turns -- half the bytes per block need twice the blocks in flight to keep HBM busy (one iteration ahead the
-        // partial fetch moved 19 % fewer bytes and was only 5 % faster: bound by loads in flight, not by bandwidth)
-        constexpr int DEPTH = HEAD == 2 ? 2 : 1;
+        // Blocks are prefetched ONE iteration ahead.  (DEPTH 2 -- two register sets used by turns, which HEAD == 2 has room
+        // for -- was measured on the partial fetch: 5.46 ms against 5.10 ms.  With 19 % fewer bytes the kernel is bound by
+        // instruction issue, not by loads in flight; the second set's branches and waits only add to that.)
+        constexpr int DEPTH = 1;
         uint4 pre[HEAD], pre2[HEAD];
 #pragma unroll
         for (int i = 0; i < HEAD; ++i) { pre[i] = make_uint4(0, 0, 0, 0); pre2[i] = pre[i]; }

@@ -73,17 +73,33 @@ class SearchCoalescer:
                         live.append(it)
                 if not live:
                     continue
-                # the batch may run as long as its most patient request allows; every caller still enforces its own
-                # deadline on the future
-                remaining = [it[3] - now for it in live if it[3] is not None]
-                tmo = max(1, int(max(remaining) * 1e3)) if len(remaining) == len(live) else 0
-                try:
-                    res, _ = live[0][0].search_batch([it[1] for it in live], [it[2] for it in live], timeout_ms=tmo)
-                    for it, r in zip(live, res):
-                        it[4].set_result(r)
-                except Exception as e:             # the whole batch shares the failure (e.g. FPX_E_TIMEOUT)
-                    for it in live:
-                        if not it[4].done():
-                            it[4].set_exception(e)
-                self.batches += 1
-                self.requests += len(live)
+                # A device batch carries ONE deadline (the kernels poll one cancel word): requests are ordered by theirs and
+                # the batch is cut wherever the next deadline is more than 4x further away, the most urgent class first --
+                # an impatient request neither waits behind, nor is cancelled together with, a patient one.  Inside a class the
+                # batch may run as long as its most patient member allows; every caller still enforces its own deadline on
+                # the future.
+                live.sort(key=lambda it: float("inf") if it[3] is None else it[3])
+                classes, cur = [], [live[0]]
+                for it in live[1:]:
+                    a = cur[0][3]
+                    far = (it[3] is None) != (a is None) or (a is not None and (it[3] - now) > 4.0 * max(a - now, 1e-3))
+                    if far:
+                        classes.append(cur)
+                        cur = [it]
+                    else:
+                        cur.append(it)
+                classes.append(cur)
+                for grp in classes:
+                    now2 = time.monotonic()
+                    timed = all(it[3] is not None for it in grp)
+                    tmo = max(1, int((max(it[3] for it in grp) - now2) * 1e3)) if timed else 0
+                    try:
+                        res, _ = grp[0][0].search_batch([it[1] for it in grp], [it[2] for it in grp], timeout_ms=tmo)
+                        for it, r in zip(grp, res):
+                            it[4].set_result(r)
+                    except Exception as e:             # the whole class shares the failure (e.g. FPX_E_TIMEOUT)
+                        for it in grp:
+                            if not it[4].done():
+                                it[4].set_exception(e)
+                    self.batches += 1
+                    self.requests += len(grp)

@@ -38,6 +38,17 @@ int main()
         freader.search({100, 200, 300}, fr);
         const auto& fo = fr.getResults();
         ok = ok && fo.size() == 2 && fo[0].id == 1 && fo[0].score == 3 && fo[1].id == 2 && fo[1].score == 2;
+        // one process, several contexts (GPUs when there are several; the same device twice otherwise): doc 2 is re-inserted
+        // with other hashes in a newer segment that lives on the second context -- the first context's postings of doc 2 are
+        // superseded through the foreign segment's docs map, and ONE sharded search sees both devices
+        fpx::Context ctx2(0);
+        std::vector<uint64_t> items2 = {item(700, 2), item(800, 2)};
+        fpx::MemorySegment newer(ctx2, items2, 2, 2, 2, fpx::Docs{{2}, {}});
+        fpx::ShardedIndexReader sharded(fpx::ShardedSegments({mem, newer}));
+        fpx::SearchResults sr(fpx::SearchOptions{10, 1, 0});
+        sharded.search({100, 200, 700, 800}, sr);
+        const auto& so = sr.getResults();
+        ok = ok && so.size() == 2 && so[0].id == 1 && so[0].score == 2 && so[1].id == 2 && so[1].score == 2;
         std::printf("%s\n", ok ? "ok" : "MISMATCH");
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

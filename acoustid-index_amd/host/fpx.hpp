@@ -175,6 +175,24 @@ private:
     std::shared_ptr<fpx_snapshot> h_;
 };
 
+// One snapshot over segments resident on SEVERAL GPUs of this process (fpx_sharded_snapshot_create): every segment lives
+// on the device of the Context it was created with; the list is in snapshot order like Segments'.
+class ShardedSegments {
+public:
+    explicit ShardedSegments(const std::vector<Segment>& segs)
+    {
+        std::vector<fpx_segment*> hs;
+        for (const auto& s : segs) hs.push_back(s.handle());
+        fpx_sharded_snapshot* h = nullptr;
+        check(fpx_sharded_snapshot_create(hs.data(), (uint32_t)hs.size(), &h));
+        h_ = std::shared_ptr<fpx_sharded_snapshot>(h, [](fpx_sharded_snapshot* p) { fpx_sharded_snapshot_release(p); });
+    }
+    fpx_sharded_snapshot* handle() const { return h_.get(); }
+    uint32_t numDevices() const { return fpx_sharded_snapshot_num_devices(h_.get()); }
+private:
+    std::shared_ptr<fpx_sharded_snapshot> h_;
+};
+
 // Collector handed to IndexReader.search (src/common.zig:73-176)
 class SearchResults {
 public:
@@ -184,6 +202,7 @@ public:
     fpx_stats stats{};
 private:
     friend class IndexReader;
+    friend class ShardedIndexReader;
     std::vector<SearchResult> results_;
 };
 
@@ -232,6 +251,24 @@ public:
     }
 private:
     Segments snapshot_;
+};
+
+// IndexReader over all GPUs of the process: one call fans out to the devices, gathers their tables and merges them
+class ShardedIndexReader {
+public:
+    explicit ShardedIndexReader(ShardedSegments snapshot) : snapshot_(std::move(snapshot)) {}
+    void search(const std::vector<uint32_t>& hashes, SearchResults& results, uint32_t timeout_ms = 0) const
+    {
+        const uint32_t cap = results.options.max_results ? results.options.max_results : 1;
+        std::vector<fpx_result> out(cap);
+        uint32_t n = 0;
+        const fpx_opts o = results.options.to_c();
+        check(fpx_sharded_search(snapshot_.handle(), hashes.data(), (uint32_t)hashes.size(), &o, timeout_ms, out.data(), cap, &n, &results.stats));
+        results.results_.clear();
+        for (uint32_t i = 0; i < n; ++i) results.results_.push_back(SearchResult{out[i].id, out[i].score});
+    }
+private:
+    ShardedSegments snapshot_;
 };
 
 }  // namespace fpx

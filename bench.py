@@ -11,7 +11,8 @@ Prints ONE JSON line (rank 0).  At N = 1 the line also carries, measured in the 
   roofline      physical bytes of the dominant kernel / its HIP-event time / 8 TB/s (<= 1); `traffic` = HBM bytes by PMC
                 from a rocprofv3 child pass of this very script (or, if that is unavailable, from profiles/ with the
                 kernels' source hash attached); the reference-equivalent figure of SURVEY 8(d) is kept separately
-  by_batch      the same index at B = 1, 64, 256, 1024 (BASELINE.md's batch for this row) next to the headline batch
+  by_batch      the same index at B = 1, 64, 256, 1024 (BASELINE.md's batch for this row) and the headline batch, one batch in
+                flight each, next to the headline (two in flight)
   end_to_end    fpx_search_batch from pageable host memory (H2D of the queries and D2H of the results inside)
   config1       BASELINE.json configs[1]: 10 M fingerprints in ONE segment, batch 1024
   cpu_baseline  the oracle's pthread executor pool over the WHOLE index downloaded to host RAM
@@ -57,7 +58,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("FPX_BENCH_INFLIGHT", 0)),
                     help="batches kept in flight by that many host threads (each call owns a pooled workspace + HIP stream); "
-                         "0 = auto: 1 on one GPU (clean per-kernel timing), 3 when sharded (hides the all-gather/merge latency and the host round trips)")
+                         "0 = auto: 2 on one GPU (the second batch's sort / partition / score kernels run under the first one's probe "
+                         "kernel, which is bound by instruction issue and leaves HBM bandwidth free; the probe kernels themselves "
+                         "still run one after the other, so their HIP-event times stay clean), 3 when sharded (also hides the "
+                         "all-gather / merge latency and the host round trips)")
     ap.add_argument("--no-latency", action="store_true", help="skip the by_batch table / single-query latency (profiling runs)")
     ap.add_argument("--no-measure-bw", action="store_true",
                     help="skip the measured streaming / random-512-B read bandwidth (the second roofline denominator)")
@@ -440,7 +444,7 @@ def main():
 
     import concurrent.futures as cf
     sharded = world > 1 or eworld > 1
-    nfl = args.inflight if args.inflight > 0 else (3 if sharded else 1)
+    nfl = args.inflight if args.inflight > 0 else (3 if sharded else 2)
     outs = [(np.zeros((B, cap, 2), np.uint32), np.zeros(B, np.uint32)) for _ in range(nfl)]
     shardeds = [fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world, host_staged=(backend != "nccl")) for _ in range(nfl)] if sharded else None
 
@@ -579,7 +583,11 @@ def main():
                 dt2, agg2, _, _ = timed_resident(fpx, reader, sub, k2, 3)
                 rows.append(row_from(b2, k2, dt2, agg2, segs))
             sub.release()
-        rows.append({"batch": B, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "queries_per_s": qps,
+        dt1, agg1, _, _ = timed_resident(fpx, reader, qb, max(5, args.steps // 2), 2)
+        r1 = row_from(B, max(5, args.steps // 2), dt1, agg1, segs)
+        r1["inflight"] = 1
+        rows.append(r1)
+        rows.append({"batch": B, "inflight": nfl, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "queries_per_s": qps,
                      "probe_kernel_ms": result["roofline"]["avg_launch_ms"],
                      "probe_kernel_fetched_block_bytes": agg.v["probe_kernel_fetched_bytes"] / max(1, agg.v["probe_launches"]),
                      "moved_bytes_model": result["roofline"]["moved_model"]["total"], "hbm_frac_model": result["roofline"]["moved_model"]["frac"],

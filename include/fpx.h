@@ -73,9 +73,10 @@ typedef struct {
     uint64_t probe_kernel_bytes;/* algorithmic bytes of the blocks the main probe kernel visited itself */
     float    probe_aux_ms;      /* deferred / generic auxiliary probe passes (their blocks are in algorithmic_bytes) */
     uint32_t reserved;
-    uint64_t probe_kernel_fetched_bytes; /* block bytes the main probe kernel really fetched: a probe whose hash the
-                                   segment's presence bitmap knows to be absent counts as a visited block (as in the
-                                   reference) without the block being read, so this is <= probe_kernel_bytes */
+    uint64_t probe_kernel_fetched_bytes; /* block bytes the main probe kernel really fetched, in 128-byte lines: a probe
+                                   whose hash the segment's presence bits know to be absent counts as a visited block (as in
+                                   the reference) without the block being read, and a block that is read costs two lines up
+                                   front + the line of the matching docids, so this is <= probe_kernel_bytes */
 } fpx_stats;
 
 /* ---- context ----------------------------------------------------------- */

@@ -39,11 +39,11 @@ class Stats(C.Structure):
                 ("hits", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("candidates", C.c_uint64),
                 ("probe_kernel_ms", C.c_float), ("total_gpu_ms", C.c_float),
                 ("probe_launches", C.c_uint32), ("generic_iters", C.c_uint32),
-                ("probe_kernel_bytes", C.c_uint64), ("probe_aux_ms", C.c_float), ("reserved", C.c_uint32),
+                ("probe_kernel_bytes", C.c_uint64), ("probe_aux_ms", C.c_float), ("path_flags", C.c_uint32),
                 ("probe_kernel_fetched_bytes", C.c_uint64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # every symbol include/fpx.h declares: name -> (restype, argtypes)

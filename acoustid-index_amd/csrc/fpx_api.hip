@@ -74,11 +74,13 @@ void ws_destroy(Workspace* w)
     if (!w) return;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     void* bufs[] = {w->d_hashes, w->d_offsets, w->d_opts, w->d_keys[0], w->d_keys[1], w->d_hits[0], w->d_hits[1],
-                    w->d_cands[0], w->d_cands[1], w->d_temp, w->d_counters, w->d_out, w->d_out_n, w->d_def_list, w->d_def_count, w->d_qrange, w->d_qcand};
+                    w->d_cands[0], w->d_cands[1], w->d_temp, w->d_counters, w->d_out, w->d_out_n, w->d_def_list, w->d_def_count, w->d_qrange, w->d_qcand,
+                    w->d_binq, w->d_qcursor};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (w->h_counters) (void)hipHostFree(w->h_counters);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->h_cancel) (void)hipHostFree(w->h_cancel);
+    if (w->h_bins) (void)hipHostFree(w->h_bins);
     if (w->h_def_count) (void)hipHostFree(w->h_def_count);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_probe0) (void)hipEventDestroy(w->ev_probe0);

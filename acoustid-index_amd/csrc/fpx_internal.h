@@ -84,6 +84,7 @@ enum Counter : int {
     CTR_HEAVY = 9,       // queries k_score handed to its CLASSED launch
     CTR_CANCEL = 10,     // != 0: the search's deadline passed (copied off the host's cancel word by polling workgroups) -- every
                          // workgroup leaves at its next cancel point, the results are discarded (error.SearchTimeout)
+    CTR_TOTAL = 11,      // device-sized path: hit records of the batch (sum of the queries' counts, written by k_l2_scan)
     CTR_SLOTCANDS = 14,  // candidates handed from k_score to k_finish through the queries' own slots (statistics)
     CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
 };
@@ -173,6 +174,10 @@ struct Workspace {
     uint32_t* d_def_list = nullptr; size_t cap_def = 0;       // deferred probes of the lean kernel [n_file][def_cap]
     unsigned int* d_def_count = nullptr; unsigned int* h_def_count = nullptr; size_t cap_def_segs = 0;
     fpx_result* d_out = nullptr; uint32_t* d_out_n = nullptr; size_t cap_out = 0; // [B*cap], [B]
+    // device-sized path (fpx_partition.hpp): [MAX_BINS * BIN_STRIDE bin fill counters | cap_binq per-query counts], scatter cursors
+    uint32_t* d_binq = nullptr; unsigned long long* d_qcursor = nullptr; size_t cap_binq = 0; uint32_t* h_bins = nullptr;
+    uint64_t hint_P = 0, hint_H = 0;      // pairs and hit records of the last batch this workspace ran (sizes the next one)
+    uint32_t fast_penalty = 0;            // batches left before the device-sized path is tried again after it had to be redone
     // pinned host staging
     unsigned long long* h_counters = nullptr;
     // one small query travels in ONE pinned copy: [offsets 2 x u64 | opts 4 x u32 | hashes]

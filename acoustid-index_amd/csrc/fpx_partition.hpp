@@ -1,0 +1,204 @@
+// fpx_partition.hpp -- the hit records grouped by query without a sort, with every size read from device memory.
+// Part of the fpx_search.hip translation unit (included after fpx_probe_generic.hpp, which holds stage_flush).
+//
+// SearchResults.incr (src/common.zig:121-129) is a hash-map upsert per posting; here the postings of a batch become
+// (q << 32 | doc) records that k_score counts per query, so they have to be brought together by query first.  Round 1
+// sorted them (rocPRIM Onesweep on the query bits: histogram + two passes, 40 B of traffic per record, and the record
+// count had to travel to the host first).  Now:
+//   level 1  the probe kernels' LDS stage is flushed into NB = 2^(qb - 7) BINS of 128 queries each (bin_append: one LDS
+//            atomic per record for its rank, one global atomic per bin and flush for the base; 1024 staged records make
+//            ~16-record = 128-byte runs per bin).  Records that bypass the stage (long runs, small / memory segments) go
+//            to a plain append buffer and k_bin_misc bins them the same way afterwards;
+//   level 2  inside each bin: k_l2_count (per-query counts), k_l2_scan (offsets = k_score's [begin, end) ranges),
+//            k_l2_scatter (tiles of 2048 records ordered by query in LDS, then written as runs).
+// 8 (flush) + 8 (count) + 16 (scatter) bytes per record instead of 8 + 40, no host round trip: the grids are sized by the
+// bins' CAPACITY and workgroups beyond a bin's fill level leave at once.  A bin that overflows is detected after the
+// batch's single synchronisation and the batch is redone on the general (sorting) path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+constexpr uint32_t BIN_STRIDE = 32;         // 32-bit words between the bins' fill counters: a 128-B line each
+constexpr uint32_t MAX_BINS = 128;
+constexpr uint32_t BIN_QUERIES_LOG2 = 7;    // queries per bin (level 2 orders a tile by these 7 bits in LDS)
+constexpr uint32_t L2_TILE = 2048;          // records per workgroup tile of level 2
+
+struct BinArgs {
+    uint64_t* bins;              // [nbins][bin_cap] records, or null: binning off (the general path)
+    uint64_t bin_cap;
+    unsigned int* bin_count;     // [nbins * BIN_STRIDE] fill counters (may run past bin_cap: overflow)
+    uint32_t shift;              // bin of query q = q >> shift
+    uint32_t nbins;
+};
+
+// Append up to 4 records per thread (those whose bit is set in keepm) to their bins.  Whole workgroup; s_cnt / s_base
+// hold MAX_BINS words each.
+__device__ __forceinline__ void bin_append(const BinArgs& b, uint32_t* s_cnt, uint32_t* s_base, const uint64_t (&r)[4], uint32_t keepm,
+                                           uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t i = tid; i < b.nbins; i += nthreads) s_cnt[i] = 0u;
+    __syncthreads();
+    uint32_t bn[4], rank[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        bn[j] = 0u; rank[j] = 0u;
+        if ((keepm >> j) & 1u) {
+            bn[j] = min((uint32_t)(r[j] >> 32) >> b.shift, b.nbins - 1u);
+            rank[j] = atomicAdd(&s_cnt[bn[j]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < b.nbins; i += nthreads) {
+        const uint32_t c = s_cnt[i];
+        s_base[i] = c ? atomicAdd(&b.bin_count[(size_t)i * BIN_STRIDE], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        if ((keepm >> j) & 1u) {
+            const uint64_t pos = (uint64_t)s_base[bn[j]] + rank[j];
+            if (pos < b.bin_cap) b.bins[(size_t)bn[j] * b.bin_cap + pos] = r[j];
+        }
+    }
+    __syncthreads();
+}
+
+// the records that bypassed the LDS stage: misc[0 .. min(*misc_count, misc_cap)) -> bins
+__global__ __launch_bounds__(256) void k_bin_misc(BinArgs b, const uint64_t* __restrict__ misc, const unsigned long long* __restrict__ misc_count,
+                                                  uint64_t misc_cap)
+{
+    __shared__ uint32_t s_cnt[MAX_BINS], s_base[MAX_BINS];
+    const uint64_t n = min((uint64_t)*misc_count, misc_cap);
+    for (uint64_t t = (uint64_t)blockIdx.x * 1024u; t < n; t += (uint64_t)gridDim.x * 1024u) {      // (uniform per workgroup)
+        uint64_t r[4];
+        uint32_t keepm = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint64_t i = t + j * 256u + threadIdx.x;
+            r[j] = i < n ? misc[i] : 0ull;
+            if (i < n) keepm |= 1u << j;
+        }
+        bin_append(b, s_cnt, s_base, r, keepm, threadIdx.x, 256u);
+    }
+}
+
+// level 2a: how many records each query has.  grid (tiles of the bins' capacity, nbins)
+__global__ __launch_bounds__(256) void k_l2_count(BinArgs b, uint32_t* __restrict__ qcount, uint32_t B)
+{
+    const uint32_t bin = blockIdx.y;
+    const uint64_t n = min((uint64_t)b.bin_count[(size_t)bin * BIN_STRIDE], b.bin_cap);
+    const uint64_t start = (uint64_t)blockIdx.x * L2_TILE;
+    if (start >= n) return;
+    __shared__ uint32_t h[1u << BIN_QUERIES_LOG2];
+    const uint32_t tid = threadIdx.x, mask = (1u << b.shift) - 1u;
+    if (tid < (1u << BIN_QUERIES_LOG2)) h[tid] = 0u;
+    __syncthreads();
+    const uint64_t* src = b.bins + (size_t)bin * b.bin_cap;
+    const uint64_t end = min(start + L2_TILE, n);
+    for (uint64_t i = start + tid; i < end; i += 256u) atomicAdd(&h[(uint32_t)(src[i] >> 32) & mask], 1u);
+    __syncthreads();
+    if (tid < (1u << b.shift)) {
+        const uint32_t q = (bin << b.shift) + tid;
+        if (h[tid] && q < B) atomicAdd(&qcount[q], h[tid]);
+    }
+}
+
+// level 2b: exclusive scan of the counts -> [begin, end) of every query (k_score's ranges), the scatter cursors, the total
+// (one workgroup; B is a few thousand)
+__global__ __launch_bounds__(1024) void k_l2_scan(const uint32_t* __restrict__ qcount, uint32_t B, uint64_t* __restrict__ qrange,
+                                                  unsigned long long* __restrict__ qcursor, uint32_t* __restrict__ zero_n,
+                                                  unsigned long long* __restrict__ total_out)
+{
+    __shared__ unsigned long long wave_tot[16];
+    __shared__ unsigned long long carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry = 0ull;
+    __syncthreads();
+    for (uint32_t base = 0; base < B; base += 1024u) {
+        const uint32_t q = base + tid;
+        const unsigned long long c = q < B ? qcount[q] : 0u;
+        unsigned long long incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += t;
+        }
+        if (lane == 63u) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned long long wbase = carry;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wave_tot[w];
+        if (q < B) {
+            const unsigned long long begin = wbase + incl - c;
+            qrange[2ull * q] = begin;
+            qrange[2ull * q + 1] = begin + c;
+            qcursor[q] = begin;
+            if (zero_n) zero_n[q] = 0u;                      // k_score's per-query slot counts
+        }
+        __syncthreads();
+        if (tid == 1023u) carry = wbase + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *total_out = carry;
+}
+
+// level 2c: every tile ordered by query in LDS, then appended to the queries' ranges as runs
+__global__ __launch_bounds__(256) void k_l2_scatter(BinArgs b, unsigned long long* __restrict__ qcursor, uint32_t B, uint64_t* __restrict__ out,
+                                                    uint64_t out_cap)
+{
+    const uint32_t bin = blockIdx.y;
+    const uint64_t n = min((uint64_t)b.bin_count[(size_t)bin * BIN_STRIDE], b.bin_cap);
+    const uint64_t start = (uint64_t)blockIdx.x * L2_TILE;
+    if (start >= n) return;
+    constexpr uint32_t NQ = 1u << BIN_QUERIES_LOG2, RPT = L2_TILE / 256u;
+    __shared__ uint64_t recs[L2_TILE];
+    __shared__ uint32_t h[NQ], off[NQ];
+    __shared__ unsigned long long gbase[NQ];
+    const uint32_t tid = threadIdx.x, mask = (1u << b.shift) - 1u;
+    if (tid < NQ) h[tid] = 0u;
+    __syncthreads();
+    const uint64_t* src = b.bins + (size_t)bin * b.bin_cap;
+    const uint32_t cnt = (uint32_t)min((uint64_t)L2_TILE, n - start);
+    uint64_t r[RPT];
+    uint32_t rank[RPT];
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        const uint32_t i = j * 256u + tid;
+        r[j] = i < cnt ? src[start + i] : 0ull;
+        rank[j] = i < cnt ? atomicAdd(&h[(uint32_t)(r[j] >> 32) & mask], 1u) : 0u;
+    }
+    __syncthreads();
+    if (tid < 64u) {                                          // exclusive scan of the 128 counts by one wave, two per lane
+        const uint32_t c0 = h[2u * tid], c1 = h[2u * tid + 1u];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if (tid >= (uint32_t)d) incl += t;
+        }
+        off[2u * tid] = incl - c0 - c1;
+        off[2u * tid + 1u] = incl - c1;
+    }
+    if (tid >= 64u && tid < 64u + NQ) {                       // room in the queries' ranges for this tile's records
+        const uint32_t ql = tid - 64u;
+        const uint32_t q = (bin << b.shift) + ql;
+        gbase[ql] = (h[ql] && ql <= mask && q < B) ? atomicAdd(&qcursor[q], (unsigned long long)h[ql]) : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        const uint32_t i = j * 256u + tid;
+        if (i < cnt) recs[off[(uint32_t)(r[j] >> 32) & mask] + rank[j]] = r[j];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += 256u) {
+        const uint64_t rec = recs[i];
+        const uint32_t ql = (uint32_t)(rec >> 32) & mask;
+        const unsigned long long pos = gbase[ql] + (i - off[ql]);
+        if (pos < out_cap) out[pos] = rec;
+    }
+}
+
+}  // namespace fpx

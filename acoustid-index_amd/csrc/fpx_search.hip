@@ -107,6 +107,7 @@ static int grow_pair(uint64_t* p[2], size_t* cap, size_t need)
 }
 
 constexpr int FPX_SPLIT = 1;   // internal: candidate key does not fit 64 bits, split the batch
+constexpr int FPX_REDO = 2;    // internal: the device-sized path met something only the general path handles (a full bin, ...)
 
 static unsigned bits_for(uint64_t n)   // number of bits needed to represent values in [0, n)
 {
@@ -322,6 +323,47 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         size_t want = std::max<size_t>(1u << 20, (size_t)P * std::max<uint32_t>(1u, snap->n_file + snap->n_mem));
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, want))) return rc;
     }
+    // ---- the device-sized path (fpx_partition.hpp): the hit records are binned by query as they are produced, every size
+    //      downstream is read from device memory, and the batch needs ONE host round trip (two when queries overflow their
+    //      candidate slots) instead of three.  It needs an estimate of the record count to size its bins: the first batch of a
+    //      workspace takes the general path.  Anything it cannot handle (a full bin, a full deferred list, scores too wide
+    //      for the candidate key) is noticed after the synchronisation and the batch is redone on the general path.
+    static const bool fast_enabled = [] { const char* e = getenv("FPX_FAST"); return e ? atoi(e) != 0 : true; }();
+    const uint32_t nb_bits = qb > BIN_QUERIES_LOG2 ? qb - BIN_QUERIES_LOG2 : 0u;
+    bool fast = fast_enabled && !ex && !no_fast && !single_fast && B >= 2u && P != 0 && qb <= 24u && (1u << nb_bits) <= MAX_BINS &&
+                ws->hint_H != 0 && ws->hint_P != 0;
+    if (fast && ws->fast_penalty != 0) { ws->fast_penalty -= 1; fast = false; }
+    BinArgs h_bin{};
+    BinArgs* d_binargs = nullptr;
+    uint32_t* d_bin_count = nullptr;
+    uint32_t* d_qcount = nullptr;
+    uint64_t est_H = 0;
+    constexpr size_t BINQ_HEAD = 64 / sizeof(uint32_t);                          // room for the BinArgs the kernels read
+    if (fast) {
+        est_H = (uint64_t)((double)ws->hint_H * (double)P / (double)ws->hint_P) + 1024;
+        const size_t want = (size_t)(2 * est_H + (1u << 16));                   // bins get 2x their expected fill
+        if (ws->cap_hits < want && (rc = grow_pair(ws->d_hits, &ws->cap_hits, want))) return rc;
+        const size_t words = BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE + (size_t)B + 64;
+        if (words > ws->cap_binq) {
+            if (ws->d_binq) (void)hipFree(ws->d_binq);
+            if (ws->d_qcursor) (void)hipFree(ws->d_qcursor);
+            ws->d_binq = nullptr; ws->d_qcursor = nullptr; ws->cap_binq = 0;
+            const size_t ncap = words * 5 / 4;
+            FPX_HIP(hipMalloc(&ws->d_binq, ncap * sizeof(uint32_t)));
+            FPX_HIP(hipMalloc(&ws->d_qcursor, ncap * sizeof(unsigned long long)));
+            ws->cap_binq = ncap;
+        }
+        if (!ws->h_bins) FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_bins), (BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE) * sizeof(uint32_t)));
+        d_binargs = reinterpret_cast<BinArgs*>(ws->d_binq);
+        d_bin_count = ws->d_binq + BINQ_HEAD;
+        d_qcount = d_bin_count + (size_t)MAX_BINS * BIN_STRIDE;
+        h_bin.bins = ws->d_hits[0]; h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
+        h_bin.bin_cap = ws->cap_hits / h_bin.nbins; h_bin.bin_count = d_bin_count;
+        static_assert(sizeof(BinArgs) <= 64, "BinArgs staging");
+        std::memcpy(ws->h_bins, &h_bin, sizeof h_bin);
+        FPX_HIP(hipMemcpyAsync(d_binargs, ws->h_bins, sizeof h_bin, hipMemcpyHostToDevice, st));
+        FPX_HIP(hipMemsetAsync(d_bin_count, 0, ((size_t)MAX_BINS * BIN_STRIDE + B) * sizeof(uint32_t), st));
+    }
     bool force_generic = false, used_lean = false;
     for (int attempt = 0;; ++attempt) {
         used_lean = false;
@@ -335,7 +377,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.ppw = total >= (1ull << 22) ? 64u : 16u;
             a.rounds = total >= (1ull << 25) ? 2u : 1u;
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
-            a.hits = ws->d_hits[0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
+            a.hits = ws->d_hits[fast ? 1 : 0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters; a.bin = fast ? d_binargs : nullptr;
             a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr; a.cancel = cancel;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
@@ -380,7 +422,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 }
                 if (snap->n_small) {
                     hipLaunchKernelGGL(k_probe_small, dim3((snap->max_small_blocks + SMALL_BPW - 1) / SMALL_BPW, snap->n_small), dim3(WG), 0, st,
-                                       snap->d_small, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
+                                       snap->d_small, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
                 }
                 if (snap->n_gen) {
                     ProbeArgs ge = a;
@@ -407,14 +449,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (mem_items * 2 < P * snap->n_mem) {               // fewer items than (pair, segment) probes: search from the items' side
                 const uint32_t gxm = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (mem_max + WG - 1) / WG), 4096);
                 hipLaunchKernelGGL(k_probe_mem_items, dim3(gxm, snap->n_mem), dim3(WG), 0, st,
-                                   snap->d_mem, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
+                                   snap->d_mem, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
             } else {
                 hipLaunchKernelGGL(k_probe_mem, dim3((uint32_t)((P + WG - 1) / WG), snap->n_mem), dim3(WG), 0, st,
-                                   snap->d_mem, d_pairs, P, qb, ws->d_hits[0], (uint64_t)ws->cap_hits, ws->d_counters);
+                                   snap->d_mem, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
             }
             FPX_HIP(hipGetLastError());
         }
-        if (single_fast) break;                     // one query: nothing below needs the counts on the host yet
+        if (single_fast || fast) break;             // nothing below needs the counts on the host yet
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_SYNC(ws);
         if (used_lean && snap->n_lean) {
@@ -449,6 +491,142 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (H <= ws->cap_hits) break;
         if (attempt >= 4) { set_error("hit buffer overflow persists (%llu records)", (unsigned long long)H); return FPX_E_DEVICE; }
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
+    }
+    if (fast) {
+        // ---- 5': bins -> per-query ranges (level 2 of fpx_partition.hpp), count, finish; sizes stay on the device
+        const uint32_t tiles = (uint32_t)std::min<uint64_t>((h_bin.bin_cap + L2_TILE - 1) / L2_TILE, 0x7FFFFFFFull / 256u);
+        hipLaunchKernelGGL(k_bin_misc, dim3(256), dim3(256), 0, st, h_bin, (const uint64_t*)ws->d_hits[1],
+                           (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
+        hipLaunchKernelGGL(k_l2_count, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, d_qcount, B);
+        if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;
+        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1)))) return rc;
+        uint64_t* d_qcand = ws->d_qcand;
+        uint32_t* d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
+        uint32_t* d_heavy = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS + (size_t)B / 2 + 1);
+        hipLaunchKernelGGL(k_l2_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)d_qcount, B, ws->d_qrange, ws->d_qcursor, d_qcand_n,
+                           &ws->d_counters[CTR_TOTAL]);
+        hipLaunchKernelGGL(k_l2_scatter, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, ws->d_qcursor, B, ws->d_hits[1], (uint64_t)ws->cap_hits);
+        FPX_HIP(hipGetLastError());
+        // k_score as on the general path, its LDS split sized from the estimated records per query
+        uint32_t floor_min = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < B; ++q) {
+            const uint64_t raw_len = offsets[q + 1] - offsets[q];
+            floor_min = std::min(floor_min, opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20));
+        }
+        uint32_t log2f = 11;
+        while (log2f < 14 && (1ull << log2f) < 2 * (est_H / B + 1)) ++log2f;
+        log2f = std::max(11u, log2f - (floor_min >= 8u ? 2u : floor_min >= 3u ? 1u : 0u));
+        uint32_t log2t = SCORE_TABLE_LOG2;
+        if (floor_min <= 2u && est_H / B > (1u << SCORE_TABLE_LOG2)) { log2t = 13; log2f = 11; }
+        const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
+        if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
+        static const hipError_t lds_attrs_f[3] = {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)};
+        (void)lds_attrs_f;
+        const bool short_queries = est_H / B <= (uint64_t)WG * 8u;
+        const size_t score_lds = ((size_t)8 << log2t) + ((size_t)4 << log2f);
+        const uint32_t sbf = 32u - qb;
+        if (short_queries)
+            hipLaunchKernelGGL((k_score<8, false>), dim3(B), dim3(WG), score_lds, st,
+                               (const uint64_t*)ws->d_hits[1], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sbf, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
+                               (uint64_t)0, d_qcand, d_qcand_n, d_heavy, cancel);
+        else
+            hipLaunchKernelGGL((k_score<32, false>), dim3(B), dim3(WG), score_lds, st,
+                               (const uint64_t*)ws->d_hits[1], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sbf, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
+                               (uint64_t)0, d_qcand, d_qcand_n, d_heavy, cancel);
+        // the queries it handed over (far more records than the filter was sized for): their number is on the device
+        hipLaunchKernelGGL((k_score<32, true>), dim3(std::min<uint32_t>(B, 256u)), dim3(WG), score_lds, st,
+                           (const uint64_t*)ws->d_hits[1], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sbf, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
+                           (uint64_t)0, d_qcand, d_qcand_n, d_heavy, cancel);
+        fpx_result* d_res = partial ? out : ws->d_out;
+        uint32_t* d_res_n = partial ? out_n : ws->d_out_n;
+        // optimistic finish: every query's candidates fit its own slots (C == 0); redone below after a sort otherwise
+        hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
+                           (const uint64_t*)ws->d_cands[0], (uint64_t)0, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
+                           (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
+        FPX_HIP(hipGetLastError());
+        if (!partial) {
+            FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+        }
+        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_count, (size_t)h_bin.nbins * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipEventRecord(ws->ev_end, st));
+        FPX_SYNC(ws);
+        // ---- the one look at what happened
+        bool redo = false, hits_short = false;
+        uint64_t worst_bin = 0;
+        for (uint32_t i = 0; i < h_bin.nbins; ++i) worst_bin = std::max<uint64_t>(worst_bin, ws->h_bins[BINQ_HEAD + (size_t)i * BIN_STRIDE]);
+        const uint64_t misc = ws->h_counters[CTR_HITS];
+        H = ws->h_counters[CTR_TOTAL];
+        if (worst_bin > h_bin.bin_cap || misc > ws->cap_hits || H > ws->cap_hits) { redo = true; hits_short = true; }
+        if (used_lean)
+            for (uint32_t i = 0; i < snap->n_lean; ++i) redo = redo || ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE] > def_cap;
+        if (ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands) redo = true;
+        if (redo) {
+            if (hits_short) {           // room for what this batch really produced, so that neither path trips over it again
+                const size_t need = (size_t)std::max<uint64_t>(std::max<uint64_t>(worst_bin * h_bin.nbins, misc), H) * 5 / 4 + 1024;
+                if (ws->cap_hits < need && (rc = grow_pair(ws->d_hits, &ws->cap_hits, need))) return rc;
+            }
+            ws->hint_H = 0;             // the estimate was off: the general path measures again
+            ws->fast_penalty = 4;
+            return FPX_REDO;
+        }
+        uint64_t Cf = 0;
+        int ccur2 = 0;
+        if (ws->h_counters[CTR_CANDS] != 0) {
+            // some queries have more candidates than slots: sort the shared list and finish again (second round trip)
+            Cf = ws->h_counters[CTR_CANDS];
+            const size_t tb2 = sort_u64_temp_bytes(Cf, 0, 64);
+            if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb2 + 256))) return rc;
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_cands[0], ws->d_cands[1], Cf, 0, 64, st, &ccur2));
+            if (stats) FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_SLOTCANDS], 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
+                               (const uint64_t*)ws->d_cands[ccur2], Cf, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
+                               (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
+            FPX_HIP(hipGetLastError());
+            if (!partial) {
+                FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+            }
+            FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipEventRecord(ws->ev_end, st));
+            FPX_SYNC(ws);
+        }
+        if (stats) {
+            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0;
+            if (used_lean && snap->n_lean) {
+                const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
+                for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
+                    reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3];
+                }
+            }
+            float ms = 0.f, aux = 0.f, total_ms = 0.f;
+            if (P && snap->n_file) {
+                (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
+                if (used_lean) (void)hipEventElapsedTime(&aux, ws->ev_probe1, ws->ev_probe2);
+            }
+            (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
+            const bool ln = used_lean && snap->n_lean;
+            stats->probes += ws->h_counters[CTR_PROBES] + probes;
+            stats->scanned_blocks += ws->h_counters[CTR_BLOCKS] + blocks;
+            stats->scanned_docs += ws->h_counters[CTR_DOCS] + docs;
+            stats->hits += H;
+            stats->algorithmic_bytes += ws->h_counters[CTR_BYTES] + blocks * 512ull;
+            stats->candidates += Cf + ws->h_counters[CTR_SLOTCANDS];
+            stats->probe_kernel_ms += ms;
+            stats->total_gpu_ms += total_ms;
+            stats->probe_launches += probe_launches;
+            stats->generic_iters += (uint32_t)ws->h_counters[CTR_GENERIC];
+            stats->probe_kernel_bytes += ln ? blocks * 512ull : ws->h_counters[CTR_BYTES];
+            stats->probe_kernel_fetched_bytes += ln ? reads * 128ull : ws->h_counters[CTR_BYTES];
+            stats->probe_aux_ms += aux;
+            stats->path_flags |= 1u | (Cf ? 2u : 0u);
+        }
+        ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);
+        return FPX_OK;
     }
     if (single_fast) {
         if (ws->cap_cands < SINGLE_CANDS && (rc = grow_pair(ws->d_cands, &ws->cap_cands, SINGLE_CANDS))) return rc;
@@ -663,6 +841,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     if (stats && d_qcand_n) C_slots = ws->h_counters[CTR_SLOTCANDS];
 
     fill_stats();
+    ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);       // sizes the device-sized path of the next batch
     return FPX_OK;
 }
 
@@ -673,6 +852,7 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
     dst->probe_kernel_ms += s.probe_kernel_ms; dst->total_gpu_ms += s.total_gpu_ms; dst->probe_launches += s.probe_launches; dst->generic_iters += s.generic_iters;
     dst->probe_kernel_bytes += s.probe_kernel_bytes; dst->probe_aux_ms += s.probe_aux_ms;
     dst->probe_kernel_fetched_bytes += s.probe_kernel_fetched_bytes;
+    dst->path_flags |= s.path_flags;
 }
 
 // one pass, or -- when (query index, score) do not fit the 64-bit candidate key -- two half batches
@@ -685,6 +865,10 @@ static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
     if (!ws) return FPX_E_NOMEM;
     fpx_stats local{};
     int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local);
+    if (rc == FPX_REDO) {                       // the device-sized path gave up (after its synchronisation): the general path
+        local = fpx_stats{};
+        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, true);
+    }
     if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
     ws_release(snap->ctx, ws);
     if (rc == FPX_OK) { if (stats) add_stats(stats, local); return FPX_OK; }

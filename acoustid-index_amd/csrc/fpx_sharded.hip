@@ -287,6 +287,7 @@ int fpx_sharded_search_batch(fpx_sharded_snapshot* s, const uint32_t* hashes, co
             stats->hits += t.hits; stats->algorithmic_bytes += t.algorithmic_bytes; stats->candidates += t.candidates;
             stats->probe_launches += t.probe_launches; stats->generic_iters += t.generic_iters;
             stats->probe_kernel_bytes += t.probe_kernel_bytes; stats->probe_kernel_fetched_bytes += t.probe_kernel_fetched_bytes;
+            stats->path_flags |= t.path_flags;
             // the devices run side by side: times are the slowest device's
             stats->probe_kernel_ms = std::max(stats->probe_kernel_ms, t.probe_kernel_ms);
             stats->probe_aux_ms = std::max(stats->probe_aux_ms, t.probe_aux_ms);

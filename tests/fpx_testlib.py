@@ -46,6 +46,14 @@ class Pair:
 
     def check(self, queries, options, with_stats=True):
         got, st = self.reader.search_batch(queries, options)
+        # the same batch again: a workspace's first batch takes the general path (it measures the record count the
+        # device-sized path sizes its bins with), the repeat takes the device-sized one -- same results, same counters
+        got2, st2 = self.reader.search_batch(queries, options)
+        assert got2 == got, "device-sized path differs from the general path"
+        assert (st2.scanned_blocks, st2.scanned_docs, st2.probes, st2.hits) == (st.scanned_blocks, st.scanned_docs, st.probes, st.hits), \
+            ((st2.scanned_blocks, st2.scanned_docs, st2.probes, st2.hits), (st.scanned_blocks, st.scanned_docs, st.probes, st.hits))
+        if len(queries) >= 2 and sum(len(q) for q in queries):
+            assert (st.path_flags | st2.path_flags) & 1 or os.environ.get("FPX_FAST") == "0", "neither run took the device-sized path"
         opts = options if isinstance(options, list) else [options] * len(queries)
         blocks = docs = 0
         for i, (q, o) in enumerate(zip(queries, opts)):

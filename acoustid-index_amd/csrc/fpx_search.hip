@@ -547,10 +547,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                            (const uint64_t*)ws->d_cands[0], (uint64_t)0, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
                            (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
         FPX_HIP(hipGetLastError());
-        if (!partial) {
-            FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
-        }
+        // (the results go to the caller's -- possibly pageable -- memory only after the wait below: a copy to pageable memory
+        // blocks the host until the stream reaches it, and a blocked host cannot watch the deadline)
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_count, (size_t)h_bin.nbins * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipEventRecord(ws->ev_end, st));
@@ -587,13 +585,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                                (const uint64_t*)ws->d_cands[ccur2], Cf, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
                                (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
             FPX_HIP(hipGetLastError());
-            if (!partial) {
-                FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
-            }
             FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipEventRecord(ws->ev_end, st));
             FPX_SYNC(ws);
+        }
+        if (!partial) {
+            FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipStreamSynchronize(st));
         }
         if (stats) {
             unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0;

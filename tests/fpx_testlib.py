@@ -52,8 +52,8 @@ class Pair:
         assert got2 == got, "device-sized path differs from the general path"
         assert (st2.scanned_blocks, st2.scanned_docs, st2.probes, st2.hits) == (st.scanned_blocks, st.scanned_docs, st.probes, st.hits), \
             ((st2.scanned_blocks, st2.scanned_docs, st2.probes, st2.hits), (st.scanned_blocks, st.scanned_docs, st.probes, st.hits))
-        if len(queries) >= 2 and sum(len(q) for q in queries):
-            assert (st.path_flags | st2.path_flags) & 1 or os.environ.get("FPX_FAST") == "0", "neither run took the device-sized path"
+        # (which path a run took is in st.path_flags; a batch the device-sized path hands back -- a full bin, scores too wide
+        # for the candidate key -- is redone on the general one and the next few batches of that workspace skip the attempt)
         opts = options if isinstance(options, list) else [options] * len(queries)
         blocks = docs = 0
         for i, (q, o) in enumerate(zip(queries, opts)):

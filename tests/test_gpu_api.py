@@ -55,6 +55,33 @@ def test_score_pct_is_not_clamped(env):
         assert fpx.results_to_lists(out, out_n) == got
 
 
+def test_second_batch_takes_the_device_sized_path(env):
+    """A workspace's first batch runs on the general path (host round trips between the stages) and leaves the record
+    count behind; the next ones bin their hit records on the fly and synchronise once (fpx_stats.path_flags bit 0).  Same
+    results, same counters; queries with more candidates than slots cost the second round trip (bit 1)."""
+    fpx, oracle, ctx, p, qs, flat, targets = env
+    ctx2 = fpx.Context(0)                                  # a context of its own: fresh workspaces
+    from fpx_testlib import Pair
+    seed, ndocs, H = 13, 30000, 64
+    p2 = Pair(ctx2)
+    p2.add_file(fpx.synth.synth_items(seed, 1, ndocs, H), 1, ndocs, 1, np.arange(1, ndocs + 1))
+    p2.finish()
+    opts = fpx.http_options()
+    got1, st1 = p2.reader.search_batch(qs[:64], opts)
+    got2, st2 = p2.reader.search_batch(qs[:64], opts)
+    got3, st3 = p2.reader.search_batch(qs[16:96], opts)
+    assert st1.path_flags == 0 and (st2.path_flags & 1) and (st3.path_flags & 1)
+    assert got2 == got1 == [p2.osnap.search(q) for q in qs[:64]]
+    assert got3 == [p2.osnap.search(q) for q in qs[16:96]]
+    assert (st2.scanned_blocks, st2.scanned_docs, st2.hits, st2.probes) == (st1.scanned_blocks, st1.scanned_docs, st1.hits, st1.probes)
+    # a floor of 1 with limit 500: far more candidates than the four slots per query -> the shared list, sorted after the
+    # first look at the counters
+    legacy = fpx.SearchOptions(500, 1, 10)
+    g4, st4 = p2.reader.search_batch(qs[:64], legacy)
+    assert (st4.path_flags & 3) == 3
+    assert g4 == [p2.osnap.search(q, 500, 1, 10) for q in qs[:64]]
+
+
 def test_segments_outlive_their_python_handles(env):
     """A snapshot retains its segments (SharedPtr semantics, src/shared_ptr.zig): releasing the caller's
     references must not free HBM that an in-flight reader still uses."""

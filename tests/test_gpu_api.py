@@ -76,10 +76,10 @@ def test_second_batch_takes_the_device_sized_path(env):
     assert (st2.scanned_blocks, st2.scanned_docs, st2.hits, st2.probes) == (st1.scanned_blocks, st1.scanned_docs, st1.hits, st1.probes)
     # a floor of 1 with limit 500: far more candidates than the four slots per query -> the shared list, sorted after the
     # first look at the counters
-    legacy = fpx.SearchOptions(500, 1, 10)
-    g4, st4 = p2.reader.search_batch(qs[:64], legacy)
+    wide = fpx.SearchOptions(500, 1, 0)                    # no relative cut-off either: every counted doc is a candidate
+    g4, st4 = p2.reader.search_batch(qs[:64], wide)
     assert (st4.path_flags & 3) == 3
-    assert g4 == [p2.osnap.search(q, 500, 1, 10) for q in qs[:64]]
+    assert g4 == [p2.osnap.search(q, 500, 1, 0) for q in qs[:64]]
 
 
 def test_segments_outlive_their_python_handles(env):

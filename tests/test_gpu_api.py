@@ -76,10 +76,13 @@ def test_second_batch_takes_the_device_sized_path(env):
     assert (st2.scanned_blocks, st2.scanned_docs, st2.hits, st2.probes) == (st1.scanned_blocks, st1.scanned_docs, st1.hits, st1.probes)
     # a floor of 1 with limit 500: far more candidates than the four slots per query -> the shared list, sorted after the
     # first look at the counters
-    wide = fpx.SearchOptions(500, 1, 0)                    # no relative cut-off either: every counted doc is a candidate
-    g4, st4 = p2.reader.search_batch(qs[:64], wide)
+    # queries made of the hashes of NINE documents each: nine candidates, more than the four slots a query owns -> the
+    # shared list, sorted after the first look at the counters
+    many = [np.concatenate(list(fpx.synth.synth_hashes(seed, np.arange(d, d + 9), H))) for d in range(100, 100 + 64 * 9, 9)]
+    wide = fpx.SearchOptions(500, 1, 0)
+    g4, st4 = p2.reader.search_batch(many, wide)
     assert (st4.path_flags & 3) == 3
-    assert g4 == [p2.osnap.search(q, 500, 1, 0) for q in qs[:64]]
+    assert g4 == [p2.osnap.search(q, 500, 1, 0) for q in many] and all(len(g) >= 9 for g in g4)
 
 
 def test_segments_outlive_their_python_handles(env):

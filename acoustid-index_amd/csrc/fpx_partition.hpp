@@ -5,14 +5,16 @@
 // (q << 32 | doc) records that k_score counts per query, so they have to be brought together by query first.  Round 1
 // sorted them (rocPRIM Onesweep on the query bits: histogram + two passes, 40 B of traffic per record, and the record
 // count had to travel to the host first).  Now:
-//   level 1  the probe kernels' LDS stage is flushed into NB = 2^(qb - 7) BINS of 128 queries each (bin_append: one LDS
-//            atomic per record for its rank, one global atomic per bin and flush for the base; 1024 staged records make
-//            ~16-record = 128-byte runs per bin).  Records that bypass the stage (long runs, small / memory segments) go
-//            to a plain append buffer and k_bin_misc bins them the same way afterwards;
+//   level 1  k_bin: the batch's records (appended by the probe kernels as before) are split into NB = 2^(qb - 7) BINS of
+//            128 queries each: tiles of 4096 records, one LDS atomic per record for its rank inside the tile's share of a
+//            bin, one global atomic per (tile, bin) for the base, runs of ~64 records = 512 bytes per bin.
+//            (Binning inside the probe kernels' flush was built and measured first: 64 reservations per flush instead of
+//            one kept every workgroup waiting at its end -- the probe kernel went from 5.07 to 6.15 ms, twice what the
+//            whole sort cost.)
 //   level 2  inside each bin: k_l2_count (per-query counts), k_l2_scan (offsets = k_score's [begin, end) ranges),
 //            k_l2_scatter (tiles of 2048 records ordered by query in LDS, then written as runs).
-// 8 (flush) + 8 (count) + 16 (scatter) bytes per record instead of 8 + 40, no host round trip: the grids are sized by the
-// bins' CAPACITY and workgroups beyond a bin's fill level leave at once.  A bin that overflows is detected after the
+// 16 (bin) + 8 (count) + 16 (scatter) bytes per record like the sort's 40, but no host round trip: the grids are sized by
+// the buffers' CAPACITY and workgroups beyond the fill level leave at once.  A bin that overflows is detected after the
 // batch's single synchronisation and the batch is redone on the general (sorting) path.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,54 +36,41 @@ struct BinArgs {
     uint32_t nbins;
 };
 
-// Append up to 4 records per thread (those whose bit is set in keepm) to their bins.  Whole workgroup; s_cnt / s_base
-// hold MAX_BINS words each.
-__device__ __forceinline__ void bin_append(const BinArgs& b, uint32_t* s_cnt, uint32_t* s_base, const uint64_t (&r)[4], uint32_t keepm,
-                                           uint32_t tid, uint32_t nthreads)
+// level 1: records[0 .. min(*count, cap)) -> bins.  Tiles of 4096 records (16 per thread), strided over the grid.
+constexpr uint32_t BIN_TILE = 4096;
+__global__ __launch_bounds__(256) void k_bin(BinArgs b, const uint64_t* __restrict__ recs, const unsigned long long* __restrict__ count,
+                                             uint64_t cap)
 {
-    for (uint32_t i = tid; i < b.nbins; i += nthreads) s_cnt[i] = 0u;
-    __syncthreads();
-    uint32_t bn[4], rank[4];
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; ++j) {
-        bn[j] = 0u; rank[j] = 0u;
-        if ((keepm >> j) & 1u) {
-            bn[j] = min((uint32_t)(r[j] >> 32) >> b.shift, b.nbins - 1u);
-            rank[j] = atomicAdd(&s_cnt[bn[j]], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < b.nbins; i += nthreads) {
-        const uint32_t c = s_cnt[i];
-        s_base[i] = c ? atomicAdd(&b.bin_count[(size_t)i * BIN_STRIDE], c) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; ++j) {
-        if ((keepm >> j) & 1u) {
-            const uint64_t pos = (uint64_t)s_base[bn[j]] + rank[j];
-            if (pos < b.bin_cap) b.bins[(size_t)bn[j] * b.bin_cap + pos] = r[j];
-        }
-    }
-    __syncthreads();
-}
-
-// the records that bypassed the LDS stage: misc[0 .. min(*misc_count, misc_cap)) -> bins
-__global__ __launch_bounds__(256) void k_bin_misc(BinArgs b, const uint64_t* __restrict__ misc, const unsigned long long* __restrict__ misc_count,
-                                                  uint64_t misc_cap)
-{
+    constexpr uint32_t RPT = BIN_TILE / 256u;
     __shared__ uint32_t s_cnt[MAX_BINS], s_base[MAX_BINS];
-    const uint64_t n = min((uint64_t)*misc_count, misc_cap);
-    for (uint64_t t = (uint64_t)blockIdx.x * 1024u; t < n; t += (uint64_t)gridDim.x * 1024u) {      // (uniform per workgroup)
-        uint64_t r[4];
-        uint32_t keepm = 0;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n = min((uint64_t)*count, cap);
+    for (uint64_t t = (uint64_t)blockIdx.x * BIN_TILE; t < n; t += (uint64_t)gridDim.x * BIN_TILE) {      // (uniform per workgroup)
+        for (uint32_t i = tid; i < b.nbins; i += 256u) s_cnt[i] = 0u;
+        __syncthreads();
+        uint64_t r[RPT];
+        uint32_t rank[RPT];
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            const uint64_t i = t + j * 256u + threadIdx.x;
-            r[j] = i < n ? misc[i] : 0ull;
-            if (i < n) keepm |= 1u << j;
+        for (uint32_t j = 0; j < RPT; ++j) {
+            const uint64_t i = t + j * 256u + tid;
+            r[j] = i < n ? recs[i] : ~0ull;
+            rank[j] = i < n ? atomicAdd(&s_cnt[min((uint32_t)(r[j] >> 32) >> b.shift, b.nbins - 1u)], 1u) : 0u;
         }
-        bin_append(b, s_cnt, s_base, r, keepm, threadIdx.x, 256u);
+        __syncthreads();
+        for (uint32_t i = tid; i < b.nbins; i += 256u) {
+            const uint32_t c = s_cnt[i];
+            s_base[i] = c ? atomicAdd(&b.bin_count[(size_t)i * BIN_STRIDE], c) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < RPT; ++j) {
+            if (r[j] != ~0ull) {
+                const uint32_t bn = min((uint32_t)(r[j] >> 32) >> b.shift, b.nbins - 1u);
+                const uint64_t pos = (uint64_t)s_base[bn] + rank[j];
+                if (pos < b.bin_cap) b.bins[(size_t)bn * b.bin_cap + pos] = r[j];
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -31,9 +31,6 @@ struct ProbeArgs {
     uint32_t ctr_off;          // 0, or 8 for k_probe_lean8: which statistics slots of `counters` to use
     unsigned long long* lean_stats;   // k_probe_lean8: [LEAN_STAT_SETS][8] {blocks fetched, visited blocks, docs, probes, ...}
     const uint32_t* cancel;           // the host's cancel word (mapped pinned memory), or null: no deadline
-    const BinArgs* bin;               // != null (device memory): the LDS stage is flushed into query bins (fpx_partition.hpp) and
-                                      // `hits` is the plain append buffer of the records that bypass the stage.  (A pointer, read
-                                      // at flush time: the struct by value cost the probe kernels 13 VGPRs of SGPR spills.)
 };
 
 // Cancel point -- the GPU form of zio.maybeYield() in the reference's hot loop (src/FileSegment.zig:144,
@@ -305,34 +302,7 @@ __device__ __forceinline__ void stage_flush(const HitStage& st, const ProbeArgs&
     const uint32_t sc = *st.count;
     if (sc >= (uint32_t)STAGE_FLUSH || (last && sc > 0u)) {
         const uint32_t n = min(sc, *st.valid);
-        if (a.bin) {
-            // device-sized path: straight into the query bins (level 1 of fpx_partition.hpp), superseded docs dropped on the way
-            // (two sweeps over the staged records instead of holding them in registers: the probe kernels sit at their
-            // VGPR limits and this code is inlined into them)
-            __shared__ uint32_t s_bin_cnt[MAX_BINS], s_bin_base[MAX_BINS];
-            const BinArgs ba = *a.bin;
-            for (uint32_t i = tid; i < ba.nbins; i += nthreads) s_bin_cnt[i] = 0u;
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += nthreads) {
-                const uint64_t r = st.buf[i];
-                if (filt && is_dead_seg(*filt, (uint32_t)r)) st.buf[i] = ~0ull;                       // dropped
-                else atomicAdd(&s_bin_cnt[min((uint32_t)(r >> 32) >> ba.shift, ba.nbins - 1u)], 1u);
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < ba.nbins; i += nthreads) {
-                const uint32_t c = s_bin_cnt[i];
-                s_bin_base[i] = c ? atomicAdd(&ba.bin_count[(size_t)i * BIN_STRIDE], c) : 0u;
-                s_bin_cnt[i] = 0u;                                                                     // the running rank now
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += nthreads) {
-                const uint64_t r = st.buf[i];
-                if (r == ~0ull) continue;
-                const uint32_t bn = min((uint32_t)(r >> 32) >> ba.shift, ba.nbins - 1u);
-                const uint64_t pos = (uint64_t)s_bin_base[bn] + atomicAdd(&s_bin_cnt[bn], 1u);
-                if (pos < ba.bin_cap) ba.bins[(size_t)bn * ba.bin_cap + pos] = r;
-            }
-        } else if (!filt) {
+        if (!filt) {
             if (tid == 0) {
                 const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
                 *st.base_lo = (uint32_t)gg; *st.base_hi = (uint32_t)(gg >> 32);

@@ -334,7 +334,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 ws->hint_H != 0 && ws->hint_P != 0;
     if (fast && ws->fast_penalty != 0) { ws->fast_penalty -= 1; fast = false; }
     BinArgs h_bin{};
-    BinArgs* d_binargs = nullptr;
     uint32_t* d_bin_count = nullptr;
     uint32_t* d_qcount = nullptr;
     uint64_t est_H = 0;
@@ -354,14 +353,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             ws->cap_binq = ncap;
         }
         if (!ws->h_bins) FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_bins), (BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE) * sizeof(uint32_t)));
-        d_binargs = reinterpret_cast<BinArgs*>(ws->d_binq);
         d_bin_count = ws->d_binq + BINQ_HEAD;
         d_qcount = d_bin_count + (size_t)MAX_BINS * BIN_STRIDE;
         h_bin.bins = ws->d_hits[0]; h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
         h_bin.bin_cap = ws->cap_hits / h_bin.nbins; h_bin.bin_count = d_bin_count;
-        static_assert(sizeof(BinArgs) <= 64, "BinArgs staging");
-        std::memcpy(ws->h_bins, &h_bin, sizeof h_bin);
-        FPX_HIP(hipMemcpyAsync(d_binargs, ws->h_bins, sizeof h_bin, hipMemcpyHostToDevice, st));
         FPX_HIP(hipMemsetAsync(d_bin_count, 0, ((size_t)MAX_BINS * BIN_STRIDE + B) * sizeof(uint32_t), st));
     }
     bool force_generic = false, used_lean = false;
@@ -377,7 +372,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.ppw = total >= (1ull << 22) ? 64u : 16u;
             a.rounds = total >= (1ull << 25) ? 2u : 1u;
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
-            a.hits = ws->d_hits[fast ? 1 : 0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters; a.bin = fast ? d_binargs : nullptr;
+            a.hits = ws->d_hits[fast ? 1 : 0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;    // (fast: binned into d_hits[0] afterwards)
             a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr; a.cancel = cancel;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
@@ -495,7 +490,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     if (fast) {
         // ---- 5': bins -> per-query ranges (level 2 of fpx_partition.hpp), count, finish; sizes stay on the device
         const uint32_t tiles = (uint32_t)std::min<uint64_t>((h_bin.bin_cap + L2_TILE - 1) / L2_TILE, 0x7FFFFFFFull / 256u);
-        hipLaunchKernelGGL(k_bin_misc, dim3(256), dim3(256), 0, st, h_bin, (const uint64_t*)ws->d_hits[1],
+        const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((2 * est_H + BIN_TILE - 1) / BIN_TILE, 8192u);
+        hipLaunchKernelGGL(k_bin, dim3(std::max(1u, bin_grid)), dim3(256), 0, st, h_bin, (const uint64_t*)ws->d_hits[1],
                            (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
         hipLaunchKernelGGL(k_l2_count, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, d_qcount, B);
         if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;

@@ -81,6 +81,7 @@ void ws_destroy(Workspace* w)
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->h_cancel) (void)hipHostFree(w->h_cancel);
     if (w->h_bins) (void)hipHostFree(w->h_bins);
+    if (w->h_out) (void)hipHostFree(w->h_out);
     if (w->h_def_count) (void)hipHostFree(w->h_def_count);
     if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
     if (w->ev_probe0) (void)hipEventDestroy(w->ev_probe0);

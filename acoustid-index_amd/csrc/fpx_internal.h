@@ -176,6 +176,11 @@ struct Workspace {
     fpx_result* d_out = nullptr; uint32_t* d_out_n = nullptr; size_t cap_out = 0; // [B*cap], [B]
     // device-sized path (fpx_partition.hpp): [MAX_BINS * BIN_STRIDE bin fill counters | cap_binq per-query counts], scatter cursors
     uint32_t* d_binq = nullptr; unsigned long long* d_qcursor = nullptr; size_t cap_binq = 0; uint32_t* h_bins = nullptr;
+    // results leave through pinned staging: [B] counts then [B * out_cap] results.  A copy into the caller's (pageable) arrays
+    // straight from the device blocks the host until the stream gets there and costs ~100 us of driver time per call; a
+    // copy into pinned memory is asynchronous, and the host moves the bytes on after the batch's synchronisation
+    uint8_t* h_out = nullptr; size_t cap_h_out = 0;
+    uint32_t hint_def = 0;                // longest deferred list of the last batch (sizes the deferred pass's grid)
     uint64_t hint_P = 0, hint_H = 0;      // pairs and hit records of the last batch this workspace ran (sizes the next one)
     uint32_t fast_penalty = 0;            // batches left before the device-sized path is tried again after it had to be redone
     // pinned host staging

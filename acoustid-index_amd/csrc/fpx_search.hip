@@ -179,6 +179,38 @@ static int sync_deadline(Workspace* ws, double t_start, uint32_t timeout_ms)
 }
 #define FPX_SYNC(ws) do { const int _rc = sync_deadline((ws), t_start, timeout_ms); if (_rc != FPX_OK) return _rc; } while (0)
 
+// Results leave through pinned staging (see Workspace::h_out): enqueue the two copies, and after the stream has been
+// waited for, hand the bytes to the caller.  Very large result sets (legacy limits on huge batches) go directly.
+constexpr size_t STAGED_OUT_MAX = (size_t)256 << 20;
+static int stage_results(Workspace* ws, uint32_t B, uint32_t out_cap, hipStream_t st, bool* staged)
+{
+    const size_t bytes = (size_t)B * sizeof(uint32_t) + (size_t)B * out_cap * sizeof(fpx_result);
+    *staged = bytes <= STAGED_OUT_MAX;
+    if (!*staged) return FPX_OK;
+    if (bytes > ws->cap_h_out) {
+        if (ws->h_out) (void)hipHostFree(ws->h_out);
+        ws->h_out = nullptr; ws->cap_h_out = 0;
+        const size_t ncap = bytes * 5 / 4 + 4096;
+        FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_out), ncap));
+        ws->cap_h_out = ncap;
+    }
+    FPX_HIP(hipMemcpyAsync(ws->h_out, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (out_cap) FPX_HIP(hipMemcpyAsync(ws->h_out + (size_t)B * sizeof(uint32_t), ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+    return FPX_OK;
+}
+static int deliver_results(Workspace* ws, uint32_t B, uint32_t out_cap, bool staged, fpx_result* out, uint32_t* out_n, hipStream_t st)
+{
+    if (staged) {                                   // (the stream has been synchronised)
+        std::memcpy(out_n, ws->h_out, (size_t)B * sizeof(uint32_t));
+        if (out_cap) std::memcpy(out, ws->h_out + (size_t)B * sizeof(uint32_t), (size_t)B * out_cap * sizeof(fpx_result));
+        return FPX_OK;
+    }
+    FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (out_cap) FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    return FPX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // batch driver
 // ------------------------------------------------------------------------------------------------
@@ -411,8 +443,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     d.segs = snap->d_lean; d.ppw = 16u; d.rounds = 1u;
                     const uint64_t per_wg_d = (uint64_t)PWAVES * d.ppw;
                     // persistent workgroups striding over the device-side list: about 1024 of them over all segments
+                    // ... sized from the longest list of the workspace's previous batch (x4; any grid is correct, the list is
+                    // walked in strides): the usual lists hold a few dozen rows, and a grid of a thousand 512-thread
+                    // workgroups that find nothing to do still costs 35 us
                     const uint64_t gxd_cap = std::max<uint64_t>(64, (1024 + snap->n_lean - 1) / snap->n_lean);
-                    const uint32_t gxd = (uint32_t)std::min<uint64_t>((def_cap + per_wg_d - 1) / per_wg_d, gxd_cap);
+                    const uint64_t want_d = ws->hint_P ? std::max<uint64_t>(1, (4ull * ws->hint_def + per_wg_d - 1) / per_wg_d) : gxd_cap;
+                    const uint32_t gxd = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((def_cap + per_wg_d - 1) / per_wg_d, gxd_cap), want_d);
                     hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
                 }
                 if (snap->n_small) {
@@ -543,8 +579,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                            (const uint64_t*)ws->d_cands[0], (uint64_t)0, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
                            (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
         FPX_HIP(hipGetLastError());
-        // (the results go to the caller's -- possibly pageable -- memory only after the wait below: a copy to pageable memory
-        // blocks the host until the stream reaches it, and a blocked host cannot watch the deadline)
+        // (the results travel through pinned staging: a copy to the caller's pageable memory would block the host until the
+        // stream reaches it, and a blocked host cannot watch the deadline)
+        bool staged = false;
+        if (!partial && (rc = stage_results(ws, B, out_cap, st, &staged))) return rc;
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_count, (size_t)h_bin.nbins * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipEventRecord(ws->ev_end, st));
@@ -581,15 +619,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                                (const uint64_t*)ws->d_cands[ccur2], Cf, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
                                (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
             FPX_HIP(hipGetLastError());
+            if (!partial && (rc = stage_results(ws, B, out_cap, st, &staged))) return rc;
             FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipEventRecord(ws->ev_end, st));
             FPX_SYNC(ws);
         }
-        if (!partial) {
-            FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipStreamSynchronize(st));
-        }
+        if (!partial && (rc = deliver_results(ws, B, out_cap, staged, out, out_n, st))) return rc;
         if (stats) {
             unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0;
             if (used_lean && snap->n_lean) {
@@ -621,6 +656,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->path_flags |= 1u | (Cf ? 2u : 0u);
         }
         ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);
+        ws->hint_def = 0;
+        if (used_lean) for (uint32_t i = 0; i < snap->n_lean; ++i) ws->hint_def = std::max<uint32_t>(ws->hint_def, ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE]);
         return FPX_OK;
     }
     if (single_fast) {
@@ -824,19 +861,20 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                        (const uint64_t*)ws->d_cands[ccur], C, d_opts, B, sb, partial ? 1 : 0, d_res, out_cap, d_res_n,
                        (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, (stats && d_qcand_n) ? ws->d_counters : nullptr);
     FPX_HIP(hipGetLastError());
-    if (!partial) {
-        FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
-    }
+    bool staged = false;
+    if (!partial && (rc = stage_results(ws, B, out_cap, st, &staged))) return rc;
     if (stats && d_qcand_n)
         FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     FPX_HIP(hipEventRecord(ws->ev_end, st));
     FPX_SYNC(ws);
     if (timeout_ms && now_ms() - t_start > (double)timeout_ms) return FPX_E_TIMEOUT;
+    if (!partial && (rc = deliver_results(ws, B, out_cap, staged, out, out_n, st))) return rc;
     if (stats && d_qcand_n) C_slots = ws->h_counters[CTR_SLOTCANDS];
 
     fill_stats();
     ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);       // sizes the device-sized path of the next batch
+    ws->hint_def = 0;
+    if (used_lean) for (uint32_t i = 0; i < snap->n_lean; ++i) ws->hint_def = std::max<uint32_t>(ws->hint_def, ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE]);
     return FPX_OK;
 }
 
@@ -995,10 +1033,10 @@ int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uin
                            (const fpx_result*)d_parts, (const uint32_t*)d_counts, world, B, part_cap, ws->d_opts,
                            ws->d_out, out_cap, ws->d_out_n);
         FPX_HIP(hipGetLastError());
-        FPX_HIP(hipMemcpyAsync(out_n, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        if (out_cap) FPX_HIP(hipMemcpyAsync(out, ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+        bool staged = false;
+        if ((r = stage_results(ws, B, out_cap, st, &staged))) return r;
         FPX_HIP(hipStreamSynchronize(st));
-        return FPX_OK;
+        return deliver_results(ws, B, out_cap, staged, out, out_n, st);
     };
     rc = body();
     ws_release(ctx, ws);

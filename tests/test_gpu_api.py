@@ -59,6 +59,9 @@ def test_second_batch_takes_the_device_sized_path(env):
     """A workspace's first batch runs on the general path (host round trips between the stages) and leaves the record
     count behind; the next ones bin their hit records on the fly and synchronise once (fpx_stats.path_flags bit 0).  Same
     results, same counters; queries with more candidates than slots cost the second round trip (bit 1)."""
+    import os
+    if os.environ.get("FPX_FAST") == "0":
+        pytest.skip("the device-sized path is switched off (FPX_FAST=0)")
     fpx, oracle, ctx, p, qs, flat, targets = env
     ctx2 = fpx.Context(0)                                  # a context of its own: fresh workspaces
     from fpx_testlib import Pair

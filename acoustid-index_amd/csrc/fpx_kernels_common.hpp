@@ -110,4 +110,42 @@ __global__ void k_make_keys(const uint32_t* __restrict__ hashes_base, const uint
         keys[i - base] = ((uint64_t)hashes_base[i] << qb) | q;
 }
 
+// Small batches: the keys of every query sorted INSIDE the query (one workgroup, bitonic network in LDS), written in
+// (query, hash) order -- ONE launch instead of k_make_keys + rocPRIM's ten (histogram, scan, three passes, five fills), which
+// are a third of a 64-query batch's time.  dedupSorted (src/Index.zig:171-172,489-499) is exactly this per-query sort +
+// adjacent test; what the batch-wide hash order adds -- neighbouring probes walking the probe records as a stream -- does not
+// exist at these sizes (every probe touches lines of its own).  Kernels that search the pairs by hash across the batch
+// (k_probe_small, k_probe_mem_items) are not used with this order.
+constexpr uint32_t QSORT_MAX = 2048;        // longest query the LDS sort takes
+__global__ __launch_bounds__(256) void k_make_keys_sorted(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
+                                                          uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,
+                                                          unsigned int* zero_u32, uint32_t zero_n)
+{
+    __shared__ uint32_t v[QSORT_MAX];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= B) return;
+    if (zero_u32 && q == 0)
+        for (uint32_t i = tid; i < zero_n; i += 256u) zero_u32[i] = 0u;
+    const uint64_t lo = offsets[q];
+    const uint32_t n = (uint32_t)(offsets[q + 1] - lo);
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    for (uint32_t i = tid; i < m; i += 256u) v[i] = i < n ? hashes_base[lo + i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < m; i += 256u) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = v[i], b = v[l];
+                    const bool up = (i & k) == 0u;
+                    if ((a > b) == up) { v[i] = b; v[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < n; i += 256u) keys[lo + i - base] = ((uint64_t)v[i] << qb) | q;
+}
+
 }  // namespace fpx

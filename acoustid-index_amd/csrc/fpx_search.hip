@@ -335,7 +335,16 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
-    if (P && !score_only) {
+    // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
+    static const uint64_t local_sort_max = [] { const char* e = getenv("FPX_LOCAL_SORT_MAX"); return e ? strtoull(e, nullptr, 0) : (1ull << 18); }();
+    bool local_sort = P && !score_only && !single_fast && B >= 2u && P <= local_sort_max && snap->n_small == 0;
+    if (local_sort)
+        for (uint32_t q = 0; q < B && local_sort; ++q) local_sort = offsets[q + 1] - offsets[q] <= QSORT_MAX;
+    if (local_sort) {
+        hipLaunchKernelGGL(k_make_keys_sorted, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, base, ws->d_keys[0],
+                           snap->n_lean ? ws->d_def_count : nullptr, (uint32_t)def_words);
+        FPX_HIP(hipGetLastError());
+    } else if (P && !score_only) {
         hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
                            single_fast ? ws->d_counters : nullptr, snap->n_lean ? ws->d_def_count : nullptr, (uint32_t)def_words);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
@@ -478,7 +487,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (P && snap->n_mem) {
             uint64_t mem_items = 0, mem_max = 0;
             for (const MemDesc& m : snap->h_mem) { mem_items += m.num_items; mem_max = std::max<uint64_t>(mem_max, m.num_items); }
-            if (mem_items * 2 < P * snap->n_mem) {               // fewer items than (pair, segment) probes: search from the items' side
+            if (mem_items * 2 < P * snap->n_mem && !local_sort) {   // fewer items than (pair, segment) probes: search from the items' side (needs the batch-wide hash order)
                 const uint32_t gxm = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (mem_max + WG - 1) / WG), 4096);
                 hipLaunchKernelGGL(k_probe_mem_items, dim3(gxm, snap->n_mem), dim3(WG), 0, st,
                                    snap->d_mem, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);

@@ -336,7 +336,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
-    static const uint64_t local_sort_max = [] { const char* e = getenv("FPX_LOCAL_SORT_MAX"); return e ? strtoull(e, nullptr, 0) : (1ull << 18); }();
+    static const uint64_t local_sort_max = [] { const char* e = getenv("FPX_LOCAL_SORT_MAX"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
     bool local_sort = P && !score_only && !single_fast && B >= 2u && P <= local_sort_max && snap->n_small == 0;
     if (local_sort)
         for (uint32_t q = 0; q < B && local_sort; ++q) local_sort = offsets[q + 1] - offsets[q] <= QSORT_MAX;

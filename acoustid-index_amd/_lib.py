@@ -86,6 +86,8 @@ SIGNATURES = {
     "fpx_sharded_snapshot_num_devices": (_u32, [_vp]),
     "fpx_sharded_search": (C.c_int, [_vp, _vp, _u32, C.POINTER(Opts), _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(Stats)]),
     "fpx_sharded_search_batch": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
+    "fpx_host_alloc": (C.c_int, [_sz, C.POINTER(_vp)]),
+    "fpx_host_free": (None, [_vp]),
     "fpx_synth_segment": (C.c_int, [_vp, _u64, _u32, _u32, _u32, C.c_int, _u32, _u64, C.POINTER(_vp)]),
     "fpx_segment_build": (C.c_int, [_vp, _vp, _sz, C.c_int, _u32, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
     "fpx_segment_merge": (C.c_int, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),

@@ -188,7 +188,18 @@ using namespace fpx;
 
 extern "C" {
 
-int fpx_version(void) { return 1; }
+int fpx_version(void) { return 2; }
+
+int fpx_host_alloc(size_t bytes, void** out)
+{
+    if (!out) { set_error("null out"); return FPX_E_INVAL; }
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return hip_fail(e, "hipHostMalloc"); }
+    return FPX_OK;
+}
+
+void fpx_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 const char* fpx_last_error(void) { return g_err; }
 

@@ -56,6 +56,20 @@ def _u32(a):
     return np.ascontiguousarray(a, dtype=np.uint32)
 
 
+def host_array(shape, dtype):
+    """A numpy array in page-locked host memory (fpx_host_alloc): batches handed to search_batch from such arrays, and
+    results written into them, travel by asynchronous DMA.  Freed when the array (and its views) are collected."""
+    import weakref
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    check(lib().fpx_host_alloc(max(n, 1), C.byref(p)))
+    buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, lib().fpx_host_free, p)
+    return arr
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -354,11 +368,12 @@ class IndexReader:
         res = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(out_n[q])] for q in range(B)]
         return res, st
 
-    def search_batch_raw(self, flat_h, offsets, copts, cap, timeout_ms=0):
+    def search_batch_raw(self, flat_h, offsets, copts, cap, timeout_ms=0, out=None, out_n=None):
         """Same call with pre-built numpy/ctypes buffers (used by bench.py's timed loop)."""
         B = len(offsets) - 1
-        out = np.zeros((max(1, B), cap, 2), np.uint32)
-        out_n = np.zeros(max(1, B), np.uint32)
+        if out is None:
+            out = np.zeros((max(1, B), cap, 2), np.uint32)
+            out_n = np.zeros(max(1, B), np.uint32)
         st = Stats()
         check(lib().fpx_search_batch(self.snapshot.h, _p(flat_h), _p(offsets), B, copts, timeout_ms,
                                      _p(out), cap, _p(out_n), C.byref(st)))

@@ -13,7 +13,7 @@ Prints ONE JSON line (rank 0).  At N = 1 the line also carries, measured in the 
                 kernels' source hash attached); the reference-equivalent figure of SURVEY 8(d) is kept separately
   by_batch      the same index at B = 1, 64, 256, 1024 (BASELINE.md's batch for this row) and the headline batch, one batch in
                 flight each, next to the headline (two in flight)
-  end_to_end    fpx_search_batch from pageable host memory (H2D of the queries and D2H of the results inside)
+  end_to_end    fpx_search_batch from host memory, pageable and page-locked (H2D of the queries, D2H of the results inside)
   config1       BASELINE.json configs[1]: 10 M fingerprints in ONE segment, batch 1024
   cpu_baseline  the oracle's pthread executor pool over the WHOLE index downloaded to host RAM
 See DESIGN.md "Measurement" for the definitions.
@@ -594,22 +594,40 @@ def main():
                      "reference_visited_block_bytes": agg.v["probe_kernel_bytes"] / max(1, agg.v["probe_launches"]), "headline": True})
         result["by_batch"] = rows
 
-    # ---- end to end: the batch handed over in pageable host memory (H2D of the hashes + D2H of the results inside)
+    # ---- end to end: the batch handed over in HOST memory (H2D of the hashes + D2H of the results inside the call), from
+    #      ordinary pageable arrays and from page-locked ones (fpx_host_alloc), one batch in flight and as many as the headline
     if extras:
         copts = qb.copts
-        for _ in range(2):
-            reader.search_batch_raw(flat, qb.offsets, copts, cap)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        k3 = max(5, args.steps // 2)
-        for _ in range(k3):
-            reader.search_batch_raw(flat, qb.offsets, copts, cap)
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t1
-        result["end_to_end"] = {"queries_per_s": B * k3 / dt3, "ms_per_step": dt3 / k3 * 1e3, "steps": k3, "batch": B,
-                                "entry_point": "fpx_search_batch from pageable host memory",
-                                "h2d_bytes_per_step": int(flat.nbytes + qb.offsets.nbytes + 16 * B), "d2h_bytes_per_step": int(B * cap * 8 + B * 4),
-                                "over_resident": (B * k3 / dt3) / qps}
+        k3 = max(6, args.steps // 2)
+
+        def e2e(src_flat, bufs, inflight):
+            def one(i):
+                o, n = bufs[i % inflight]
+                reader.search_batch_raw(src_flat, qb.offsets, copts, cap, 0, o, n)
+            for i in range(2):
+                one(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if inflight == 1:
+                for i in range(k3):
+                    one(i)
+            else:
+                with cf.ThreadPoolExecutor(inflight) as ex:
+                    list(ex.map(one, range(k3)))
+            torch.cuda.synchronize()
+            return B * k3 / (time.perf_counter() - t1)
+        pin_flat = fpx.host_array(flat.shape, np.uint32)
+        pin_flat[:] = flat
+        pin_bufs = [(fpx.host_array((B, cap, 2), np.uint32), fpx.host_array((B,), np.uint32)) for _ in range(nfl)]
+        e = {"batch": B, "steps": k3, "entry_point": "fpx_search_batch (hashes in host memory in, results in host memory out)",
+             "h2d_bytes_per_step": int(flat.nbytes + qb.offsets.nbytes + 16 * B), "d2h_bytes_per_step": int(B * cap * 8 + B * 4),
+             "pageable": {"queries_per_s_1_in_flight": e2e(flat, outs, 1), f"queries_per_s_{nfl}_in_flight": e2e(flat, outs, nfl)},
+             "pinned": {"queries_per_s_1_in_flight": e2e(pin_flat, pin_bufs, 1), f"queries_per_s_{nfl}_in_flight": e2e(pin_flat, pin_bufs, nfl)}}
+        e["queries_per_s"] = e["pageable"][f"queries_per_s_{nfl}_in_flight"]           # like for like with the headline
+        e["over_resident"] = e["queries_per_s"] / qps
+        e["pinned_over_resident"] = e["pinned"][f"queries_per_s_{nfl}_in_flight"] / qps
+        result["end_to_end"] = e
+        del pin_flat, pin_bufs
 
     # ---- CPU baseline on rank 0 at N = 1: the whole index in host RAM, pthread executor pool
     if rank == 0 and world == 1 and eworld <= 1 and not args.no_cpu_baseline:

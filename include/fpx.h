@@ -218,6 +218,14 @@ int  fpx_sharded_search_batch(fpx_sharded_snapshot *snap, const uint32_t *hashes
                               uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
                               fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
 
+/* ---- pinned host memory --------------------------------------------------------------------------------------------
+ * fpx_search_batch copies the caller's hashes to HBM and the results back.  From ordinary (pageable) memory the runtime
+ * stages those copies and the calling thread waits for them; from page-locked memory they are asynchronous DMA.  A host
+ * that assembles its batches in buffers from fpx_host_alloc (the request coalescer's staging, the result arrays) gets the
+ * resident-batch rate end to end.  Plain hipHostMalloc underneath; any other pinned memory (hipHostRegister) does as well. */
+int  fpx_host_alloc(size_t bytes, void **out);
+void fpx_host_free(void *p);
+
 /* ---- synthetic index builder (benchmarks / tests; not part of the reference surface) --- */
 /* Builds, entirely on the GPU, the file segment holding documents
  * [first_doc, first_doc + num_docs) x hashes_per_doc seeded hashes (definition in DESIGN.md,

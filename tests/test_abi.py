@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_error_strings():
     lib = fpx.lib()
-    assert lib.fpx_version() == 1
+    assert lib.fpx_version() == 2
     assert lib.fpx_strerror(0) == b"ok"
     assert lib.fpx_strerror(-2) == b"search timeout"
 

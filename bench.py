@@ -688,8 +688,15 @@ def main():
     if world > 1 or eworld > 1:
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL writes its version banner through C stdio, which is fully buffered when stdout is a pipe and would otherwise
+        # be flushed at exit, AFTER the line below: flush it now so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         sys.stdout.flush()
-        print(json.dumps(result), flush=True)      # last: RCCL prints its version banner when the group goes away
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -398,7 +398,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         d_bin_count = ws->d_binq + BINQ_HEAD;
         d_qcount = d_bin_count + (size_t)MAX_BINS * BIN_STRIDE;
         h_bin.bins = ws->d_hits[0]; h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
-        h_bin.bin_cap = ws->cap_hits / h_bin.nbins; h_bin.bin_count = d_bin_count;
+        // a bin holds at most 4x its expected share (never more than its slice of the buffer): the level-2 grids are sized by
+        // this capacity, and a workspace that has seen a huge batch must not launch that batch's grids for a small one
+        h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / h_bin.nbins, std::max<uint64_t>(4 * est_H / h_bin.nbins, 1u << 16));
+        h_bin.bin_count = d_bin_count;
         FPX_HIP(hipMemsetAsync(d_bin_count, 0, ((size_t)MAX_BINS * BIN_STRIDE + B) * sizeof(uint32_t), st));
     }
     bool force_generic = false, used_lean = false;

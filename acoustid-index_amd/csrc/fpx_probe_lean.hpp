@@ -277,50 +277,41 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 
         // ---- phase 2: eight probes per iteration, one per 8-lane group, blocks prefetched one iteration ahead
         const uint32_t iters = (S + 7u) >> 3;
-        // Blocks are prefetched ONE iteration ahead.  (DEPTH 2 -- two register sets used by turns, which HEAD == 2 has room
+        // Blocks are prefetched ONE iteration ahead.  (Two ahead -- in two register sets used by turns, which HEAD == 2 has room
         // for -- was measured on the partial fetch: 5.46 ms against 5.10 ms.  With 19 % fewer bytes the kernel is bound by
-        // instruction issue, not by loads in flight; the second set's branches and waits only add to that.)
-        constexpr int DEPTH = 1;
-        uint4 pre[HEAD], pre2[HEAD];
+        // instruction issue and by HBM's request rate, not by loads in flight; the second set's branches and waits only add
+        // to that.)
+        uint4 pre[HEAD];
 #pragma unroll
-        for (int i = 0; i < HEAD; ++i) { pre[i] = make_uint4(0, 0, 0, 0); pre2[i] = pre[i]; }
-        // the block of iteration `t` (wave-uniform t) into one of the register sets
-        auto fetch = [&](uint32_t t, uint4 (&dst)[HEAD]) {
-            const uint32_t jn = t >> 3;
-            uint32_t bn = b0v[0];
-#pragma unroll
-            for (int jj = 1; jj < LEAN_KPL; ++jj) { if (jn == (uint32_t)jj) bn = b0v[jj]; }
-            const uint32_t nb = __shfl(bn, (int)((t & 7u) * 8u + g));
+        for (int i = 0; i < HEAD; ++i) pre[i] = make_uint4(0, 0, 0, 0);
+        // the block of the probe held by lane `src_lane` in register set `bn` into the prefetch registers
+        auto fetch = [&](uint32_t bn, int src_lane) {
+            const uint32_t nb = __shfl(bn, src_lane);
             if (nb >> 31) {
                 const uint8_t* sb = seg.blocks + (size_t)(nb & 0x3FFFFFFFu) * 512u + l * 16u;
 #pragma unroll
-                for (int i = 0; i < HEAD; ++i) dst[i] = gload_u4(sb + 128 * i);
+                for (int i = 0; i < HEAD; ++i) pre[i] = gload_u4(sb + 128 * i);
             }
         };
-        if (iters > 0u) fetch(0u, pre);
-        if (DEPTH == 2 && iters > 1u) fetch(1u, pre2);
+        if (iters > 0u) fetch(b0v[0], (int)g);
         // HEAD == 2: the matches of the previous iteration, waiting for their docid bytes
         uint32_t c_raw = 0, c_pq = 0;      // c_pq: the query (24 bits) | bits 24..25 my value's 1234 code, bit 26 run member, bit 27 emit
 #pragma unroll 1
         for (uint32_t it = 0; it < iters; ++it) {
-            const uint32_t j = it >> 3;                                       // which of the lane's keys (wave-uniform)
+            // the wave's compacted entries sit in h / q / b0v [0..3] x 64 lanes; entry `it` is in set it >> 3.  The sets ROTATE
+            // down every eight iterations, so the loop body always reads set 0 (and set 1 when it prefetches across the
+            // boundary): nine moves per eight iterations instead of a dozen selects per iteration
             const int src = (int)((it & 7u) * 8u + g);
-            uint32_t hj = h[0], qj = q[0], bj = b0v[0];
-#pragma unroll
-            for (int jj = 1; jj < LEAN_KPL; ++jj) { if (j == (uint32_t)jj) { hj = h[jj]; qj = q[jj]; bj = b0v[jj]; } }
-            const uint32_t ph = __shfl(hj, src);
-            const uint32_t pqx = __shfl(qj, src);
+            const uint32_t ph = __shfl(h[0], src);
+            const uint32_t pqx = __shfl(q[0], src);
             const uint32_t pq = pqx & 0x00FFFFFFu;                              // bits 24..31: the pair's position in the wave
-            const uint32_t pbv = __shfl(bj, src);
+            const uint32_t pbv = __shfl(b0v[0], src);
             const bool pact = (pbv >> 31) != 0u;
-            if (DEPTH == 1 || (it & 1u) == 0u) {
 #pragma unroll
-                for (int i = 0; i < HEAD; ++i) *reinterpret_cast<uint4*>(blk + 128u * i + l * 16u) = pre[i];
-                if (it + DEPTH < iters) fetch(it + DEPTH, pre);
-            } else {
-#pragma unroll
-                for (int i = 0; i < HEAD; ++i) *reinterpret_cast<uint4*>(blk + 128u * i + l * 16u) = pre2[i];
-                if (it + DEPTH < iters) fetch(it + DEPTH, pre2);
+            for (int i = 0; i < HEAD; ++i) *reinterpret_cast<uint4*>(blk + 128u * i + l * 16u) = pre[i];
+            if (it + 1u < iters) {
+                if ((it & 7u) == 7u) fetch(b0v[1], (int)g);                    // the next entry opens the next set
+                else fetch(b0v[0], (int)(((it + 1u) & 7u) * 8u + g));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -492,6 +483,10 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 // the hits wait one iteration for their docid bytes
                 c_raw = n_raw;
                 c_pq = pq | ((n_code | (ek ? 4u : 0u) | (keep ? 8u : 0u)) << 24);
+            }
+            if ((it & 7u) == 7u) {                                             // set 0 is used up: rotate
+#pragma unroll
+                for (int jj = 0; jj + 1 < LEAN_KPL; ++jj) { h[jj] = h[jj + 1]; q[jj] = q[jj + 1]; b0v[jj] = b0v[jj + 1]; }
             }
         }
         if constexpr (HEAD == 2) {                              // the last iteration's matches

@@ -431,8 +431,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     // main kernel: k_probe_lean8 over the dense 512-B segments
                     if (attempt > 0) FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (else: k_make_keys)
                     ProbeArgs l = a;
-                    static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 2u; }();
-                    l.segs = snap->d_lean; l.rounds = (P >= (1ull << 22)) ? lean_rounds : 1u; l.ctr_off = 8u;
+                    // rounds of 1024 pairs per workgroup: more rounds amortise the workgroup's set-up (decode tables, barriers) --
+                    // measured at 8.2 M pairs x 16 segments: 5.48 ms with 1, 5.11 with 2, 5.01 with 6, 5.14 with 16 -- as long
+                    // as the grid still fills the chip several times over (>= 4096 workgroups)
+                    static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
+                    const uint64_t wgs_at_1 = (P + 1023) / 1024 * snap->n_lean;
+                    l.segs = snap->d_lean; l.ctr_off = 8u;
+                    l.rounds = lean_rounds ? lean_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_at_1 / 4096));
                     l.lean_stats = reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off);
                     const size_t lds8 = STAGE_CAP * sizeof(uint64_t) + sizeof(LeanLut) + (size_t)L8_WAVES * 8 * L8_SLOT;
                     const uint64_t per_wg_8 = (uint64_t)L8_WAVES * 64u * LEAN_KPL * l.rounds;

@@ -121,6 +121,10 @@ static void segment_free(Segment* s)
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
     if (s->d_items) (void)hipFree(s->d_items);
+    if (s->d_drec) (void)hipFree(s->d_drec);
+    if (s->d_primary) (void)hipFree(s->d_primary);
+    if (s->d_extras) (void)hipFree(s->d_extras);
+    if (s->d_gapcx) (void)hipFree(s->d_gapcx);
     delete s;
 }
 
@@ -178,6 +182,9 @@ int finish_file_segment(Segment* s)
     FPX_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_total);
     s->num_items = total;
+    // a dense segment trades its blocks for the direct-addressed form (fpx_direct.hpp); the others keep them
+    if ((rc = build_direct(s))) return rc;
+    if (s->direct) return FPX_OK;
     if ((rc = build_presence(s))) return rc;
     return decode_small_segment(s);
 }
@@ -374,7 +381,16 @@ int fpx_segment_download(const fpx_segment* seg, uint8_t* blocks, size_t blocks_
     FPX_HIP(hipSetDevice(s->ctx->device));
     if (blocks) {
         if (blocks_cap < s->blocks_len) { set_error("blocks buffer too small"); return FPX_E_INVAL; }
-        FPX_HIP(hipMemcpy(blocks, s->d_blocks, s->blocks_len, hipMemcpyDeviceToHost));
+        if (s->direct) {                    // a direct-addressed segment holds no blocks: they are encoded again, byte for byte
+            uint8_t* tmp = nullptr;
+            const int rc = materialize_blocks(s, &tmp);
+            if (rc) return rc;
+            const hipError_t e = hipMemcpy(blocks, tmp, s->blocks_len, hipMemcpyDeviceToHost);
+            (void)hipFree(tmp);
+            if (e != hipSuccess) return hip_fail(e, "segment download");
+        } else {
+            FPX_HIP(hipMemcpy(blocks, s->d_blocks, s->blocks_len, hipMemcpyDeviceToHost));
+        }
     }
     if (block_index) {
         if (index_cap < s->num_blocks) { set_error("index buffer too small"); return FPX_E_INVAL; }
@@ -438,6 +454,7 @@ static void snapshot_free(Snapshot* sn)
     if (sn->d_lean) (void)hipFree(sn->d_lean);
     if (sn->d_gen) (void)hipFree(sn->d_gen);
     if (sn->d_small) (void)hipFree(sn->d_small);
+    if (sn->d_direct) (void)hipFree(sn->d_direct);
     if (sn->d_mem) (void)hipFree(sn->d_mem);
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;
@@ -517,6 +534,8 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
+            d.drec = s->d_drec; d.primary = s->d_primary; d.extras = s->d_extras; d.gapcx = s->d_gapcx;
+            if (s->direct) { sn->h_direct.push_back(d); continue; }          // searched by k_probe_direct alone
             sn->h_file.push_back(d);
             sn->max_block_size = std::max(sn->max_block_size, s->block_size);
             if (s->block_size != 512) sn->all_512 = false;
@@ -529,9 +548,14 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     }
     sn->n_file = (uint32_t)sn->h_file.size();
     sn->n_mem = (uint32_t)sn->h_mem.size();
+    sn->n_direct = (uint32_t)sn->h_direct.size();
     if (sn->max_block_size == 0) sn->max_block_size = 512;
     hipError_t e = hipSuccess;
-    if (sn->n_file) {
+    if (sn->n_direct) {
+        e = hipMalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
+        if (e == hipSuccess) e = hipMemcpy(sn->d_direct, sn->h_direct.data(), sn->n_direct * sizeof(SegDesc), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && sn->n_file) {
         e = hipMalloc(&sn->d_file, sn->n_file * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_file, sn->h_file.data(), sn->n_file * sizeof(SegDesc), hipMemcpyHostToDevice);
     }
@@ -540,7 +564,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         std::vector<SegDesc> lean, lean4, gen, small;
         size_t fi = 0;
         for (Segment* sg : sn->segs) {
-            if (sg->kind != 0 || sg->ctx != c) continue;
+            if (sg->kind != 0 || sg->ctx != c || sg->direct) continue;
             const SegDesc& d = sn->h_file[fi++];
             if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30) && d.blockrec && d.proberec) {
                 if (sg->head_lines == 2) lean.push_back(d); else lean4.push_back(d);

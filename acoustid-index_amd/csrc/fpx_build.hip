@@ -364,6 +364,10 @@ static void free_partial_segment(Segment* s)
     if (s->d_blockrec) (void)hipFree(s->d_blockrec);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
+    if (s->d_drec) (void)hipFree(s->d_drec);
+    if (s->d_primary) (void)hipFree(s->d_primary);
+    if (s->d_extras) (void)hipFree(s->d_extras);
+    if (s->d_gapcx) (void)hipFree(s->d_gapcx);
     delete s;
 }
 
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(256) void k_decode_items(const uint8_t* __restrict_
                 const uint32_t D = f[k] ? s[k] : excl + s[k];
                 const uint32_t doc = min_doc + D;
                 items[out0 + i] = ((uint64_t)h[k] << 32) | doc;
-                live[out0 + i] = (num_dead != 0u && merge_is_dead(dead, num_dead, doc)) ? 0 : 1;
+                if (live) live[out0 + i] = (num_dead != 0u && merge_is_dead(dead, num_dead, doc)) ? 0 : 1;
             }
         }
         // carry the last item's relative doc id to the next pass
@@ -746,6 +750,415 @@ int build_presence(Segment* s)
     return FPX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct-addressed segments (the probe side and the layout: fpx_direct.hpp).
+// A dense segment's hashes cover so much of the 32-bit space that an EXACT presence bitmap costs a few bits per distinct hash;
+// with a rank directory the bitmap IS the hash column, and a posting is reached in two loads (record, doc) without fetching or
+// decoding a block.  What FileSegment.search derives from the block structure -- which docs of a hot hash it returns before
+// its caps (<= 4 blocks, > 1000 docs) stop it, how many blocks it visits, which absent hashes fall before the first hash of
+// their block (no visit) -- is computed HERE, once, from the decoded items and the block boundaries, and stored per hash.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t DIRECT_MAX_BLOCKS = 4;      // src/FileSegment.zig:25
+constexpr uint32_t DIRECT_MAX_DOCS = 1000;     // src/FileSegment.zig:26
+constexpr uint32_t DIRECT_NREC = 1u << 24;     // records of 256 hash values
+
+struct RunInfo { uint64_t end; uint32_t eff, vis; };
+
+// the run of equal hashes that starts at item s of block b: where it ends, and what the loop of src/FileSegment.zig:153-176
+// makes of it -- blocks visited, docs returned
+__device__ RunInfo direct_run_info(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff, uint32_t nb,
+                                   uint32_t b, uint64_t s)
+{
+    const uint32_t v = (uint32_t)(items[s] >> 32);
+    uint64_t e = s + 1;
+    for (uint32_t steps = 0; e < n && steps < 4096u && (uint32_t)(items[e] >> 32) == v; ++steps) ++e;
+    if (e < n && (uint32_t)(items[e] >> 32) == v) {                 // a hot hash: upper bound by bisection
+        uint64_t lo = e, hi = n;
+        while (lo < hi) {
+            const uint64_t m = lo + (hi - lo) / 2;
+            if ((uint32_t)(items[m] >> 32) <= v) lo = m + 1; else hi = m;
+        }
+        e = lo;
+    }
+    RunInfo ri{e, 0u, 0u};
+    for (uint32_t k = 0; b + k < nb; ++k) {
+        const uint64_t bs = boff[b + k], be = boff[b + k + 1];
+        if (k > 0 && bs >= e) break;                                // its min_hash > hash (:164)
+        ri.vis += 1;
+        ri.eff += (uint32_t)(std::min<uint64_t>(e, be) - std::max<uint64_t>(s, bs));
+        if (ri.vis >= DIRECT_MAX_BLOCKS) break;                     // :173
+        if (ri.eff > DIRECT_MAX_DOCS) break;                        // :174
+    }
+    return ri;
+}
+
+// per block: distinct hashes whose run STARTS in it, and the `extras` words those with several docs need
+__global__ __launch_bounds__(256) void k_direct_count(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
+                                                      uint32_t nb, uint32_t* __restrict__ ns, uint32_t* __restrict__ nx, int* __restrict__ flags)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint64_t bs = boff[b], be = boff[b + 1];
+    if (b + 1u < nb && ((be - bs) & 3ull) != 0ull) flags[0] = 1;    // not the encoder's chunks of four: the blocks could not be rebuilt
+    uint32_t prevh = bs ? (uint32_t)(items[bs - 1] >> 32) : 0u;
+    bool have_prev = bs != 0;
+    uint32_t c_s = 0;
+    uint64_t c_x = 0;
+    for (uint64_t i = bs; i < be; ++i) {
+        const uint32_t h = (uint32_t)(items[i] >> 32);
+        if (!have_prev || h != prevh) {
+            ++c_s;
+            if (i + 1 < n && (uint32_t)(items[i + 1] >> 32) == h) {
+                const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
+                const uint64_t cnt = ri.end - i;
+                c_x += 1ull + (cnt != ri.eff ? 1ull : 0ull) + cnt;
+            }
+        }
+        prevh = h; have_prev = true;
+    }
+    ns[b] = c_s;
+    nx[b] = (uint32_t)std::min<uint64_t>(c_x, 0xFFFFFFFFull);
+    if (c_x > 0xFFFFFFFFull) flags[1] = 1;
+}
+
+// per block again: primary[rank] = doc - min_doc, or bit 31 | offset of the hash's list in `extras`:
+//   word 0 = docs returned (16 bits) | blocks visited << 16 | T << 19, [T: all docs of the hash], the docs (doc - min_doc, ascending)
+__global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
+                                                     uint32_t nb, uint32_t min_doc, const uint64_t* __restrict__ rbase,
+                                                     const uint64_t* __restrict__ xbase, uint32_t* __restrict__ primary,
+                                                     uint32_t* __restrict__ extras)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint64_t bs = boff[b], be = boff[b + 1];
+    uint32_t prevh = bs ? (uint32_t)(items[bs - 1] >> 32) : 0u;
+    bool have_prev = bs != 0;
+    uint64_t r = rbase[b], x = xbase[b];
+    for (uint64_t i = bs; i < be; ++i) {
+        const uint64_t it = items[i];
+        const uint32_t h = (uint32_t)(it >> 32);
+        if (!have_prev || h != prevh) {
+            if (i + 1 < n && (uint32_t)(items[i + 1] >> 32) == h) {
+                const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
+                const uint64_t cnt = ri.end - i;
+                const uint32_t T = cnt != ri.eff ? 1u : 0u;
+                primary[r] = 0x80000000u | (uint32_t)x;
+                extras[x++] = ri.eff | (ri.vis << 16) | (T << 19);
+                if (T) extras[x++] = (uint32_t)cnt;
+                for (uint64_t t = 0; t < cnt; ++t) extras[x++] = (uint32_t)items[i + t] - min_doc;
+            } else {
+                primary[r] = (uint32_t)it - min_doc;
+            }
+            ++r;
+        }
+        prevh = h; have_prev = true;
+    }
+}
+
+// bit h of `gap` (2^27 words): no item has hash h AND FileSegment.search visits no block for it -- h lies before the first hash
+// of the first block whose max hash is >= h (src/FileSegment.zig:164), or beyond the last block (:153)
+__global__ __launch_bounds__(256) void k_direct_gap_bits(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
+                                                         uint32_t nb, uint32_t* __restrict__ gap)
+{
+    // one workgroup per block boundary, strided: a grid of nb + 1 workgroups x 256 threads passes 2^32 work-items beyond
+    // 16.7 M blocks, which a launch silently truncates
+    for (uint64_t b = blockIdx.x; b <= nb; b += gridDim.x) {          // 0 .. nb (nb: beyond the last item)
+        int64_t lo, hi;
+        if (b < nb) {
+            const uint32_t f = (uint32_t)(items[boff[b]] >> 32);
+            lo = 0;
+            if (b > 0) {
+                const uint32_t p = (uint32_t)(items[boff[b] - 1] >> 32);
+                if (p == f) continue;                                // the block continues its predecessor's last run: no gap
+                lo = (int64_t)p + 1;
+            }
+            hi = (int64_t)f - 1;
+        } else {
+            lo = (int64_t)(uint32_t)(items[n - 1] >> 32) + 1;
+            hi = 0xFFFFFFFFll;
+        }
+        if (lo > hi) continue;
+        const uint32_t wlo = (uint32_t)(lo >> 5), whi = (uint32_t)(hi >> 5);
+        for (uint64_t w = (uint64_t)wlo + threadIdx.x; w <= whi; w += 256u) {
+            uint32_t mask = 0xFFFFFFFFu;
+            if (w == wlo) mask &= 0xFFFFFFFFu << (uint32_t)(lo & 31);
+            if (w == whi) mask &= 0xFFFFFFFFu >> (31u - (uint32_t)(hi & 31));
+            atomicOr(&gap[w], mask);
+        }
+    }
+}
+
+// words 9, 10 of every record: how many presence bits are set below each of its eight words; its total for the rank scan
+__global__ __launch_bounds__(256) void k_direct_rec_counts(uint32_t* __restrict__ drec, uint32_t* __restrict__ rectot)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= DIRECT_NREC) return;
+    uint32_t* rec = drec + (size_t)r * 16u;
+    uint32_t run = 0, p0 = 0, p1 = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        if (i < 4) p0 |= run << (8u * i); else p1 |= run << (8u * (i - 4u));
+        run += (uint32_t)__popc(rec[i]);
+    }
+    rec[9] = p0; rec[10] = p1;
+    rectot[r] = run;
+}
+
+__device__ __forceinline__ uint32_t next_bit256(const uint32_t* g, uint32_t pos, bool want)   // first position >= pos whose bit == want
+{
+    while (pos < 256u) {
+        uint32_t w = g[pos >> 5];
+        if (!want) w = ~w;
+        w &= 0xFFFFFFFFu << (pos & 31u);
+        if (w) return (pos & ~31u) + (uint32_t)__builtin_ctz(w);
+        pos = (pos & ~31u) + 32u;
+    }
+    return 256u;
+}
+
+// word 8 = rank of the record's first hash; words 12..14 = its gap bits as up to three intervals [lo, hi) packed lo | hi << 16;
+// a record with more gets word 11 bit 0 and a slot (word 15) in the table of 256-bit masks
+__global__ __launch_bounds__(256) void k_direct_rec_finish(uint32_t* __restrict__ drec, const uint64_t* __restrict__ recbase,
+                                                           const uint32_t* __restrict__ gap, unsigned int* __restrict__ ncx)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= DIRECT_NREC) return;
+    uint32_t g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = gap[(size_t)r * 8u + i];
+    uint32_t ent[3] = {0u, 0u, 0u}, n_ent = 0;
+    for (uint32_t pos = 0; pos < 256u;) {
+        const uint32_t glo = next_bit256(g, pos, true);
+        if (glo >= 256u) break;
+        const uint32_t ghi = next_bit256(g, glo, false);
+        if (n_ent < 3u) ent[n_ent] = glo | (ghi << 16);
+        ++n_ent;
+        pos = ghi;
+    }
+    uint32_t* rec = drec + (size_t)r * 16u;
+    uint32_t flags = 0, cx = 0;
+    if (n_ent > 3u) { flags = 1u; cx = atomicAdd(ncx, 1u); ent[0] = ent[1] = ent[2] = 0u; }
+    rec[8] = (uint32_t)recbase[r];
+    rec[11] = flags; rec[12] = ent[0]; rec[13] = ent[1]; rec[14] = ent[2]; rec[15] = cx;
+}
+
+__global__ __launch_bounds__(256) void k_direct_cx_fill(const uint32_t* __restrict__ drec, const uint32_t* __restrict__ gap,
+                                                        uint32_t* __restrict__ gapcx)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= DIRECT_NREC) return;
+    const uint32_t* rec = drec + (size_t)r * 16u;
+    if ((rec[11] & 1u) == 0u) return;
+    for (int i = 0; i < 8; ++i) gapcx[(size_t)rec[15] * 8u + i] = gap[(size_t)r * 8u + i];
+}
+
+__global__ void k_boff_tail(uint64_t* boff, uint32_t nb, const uint64_t* total) { boff[nb] = *total; }
+
+static bool direct_enabled()
+{
+    const char* e = getenv("FPX_DIRECT");                       // read per segment: the tests move it
+    return e ? atoi(e) != 0 : true;
+}
+static uint64_t direct_min_items()
+{
+    // below ~2^28 items (6 % of the hash values taken) the 1-GB record array outweighs the blocks it replaces
+    const char* e = getenv("FPX_DIRECT_MIN_ITEMS");
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 28);
+}
+
+static void direct_free(Segment* s)
+{
+    if (s->d_drec) (void)hipFree(s->d_drec);
+    if (s->d_primary) (void)hipFree(s->d_primary);
+    if (s->d_extras) (void)hipFree(s->d_extras);
+    if (s->d_gapcx) (void)hipFree(s->d_gapcx);
+    s->d_drec = s->d_primary = s->d_extras = s->d_gapcx = nullptr;
+    s->num_distinct = s->extras_words = 0; s->num_gapcx = 0;
+    s->direct = false;
+}
+
+// Called for a resident file segment whose blocks, block index and item count are in place.  On success the segment is
+// direct-addressed and its blocks, bucket table and continuation bitmap are FREED; whatever keeps it from qualifying (size,
+// doc id range, memory, blocks not made of four-item chunks) leaves it block-based, which is always correct.
+int build_direct(Segment* s)
+{
+    if (!direct_enabled() || s->kind != 0 || s->own_flags != 0u || s->num_blocks == 0 || s->num_items == 0 ||
+        s->num_items < direct_min_items() || s->num_items > 0xFFFFFFFFull ||
+        (uint64_t)s->max_doc_id - (uint64_t)s->min_doc_id >= (1ull << 31) || s->max_doc_id < s->min_doc_id)
+        return FPX_OK;
+    const uint64_t n = s->num_items;
+    const uint32_t nb = s->num_blocks;
+    size_t free_b = 0, total_b = 0;
+    // peak: the items (8 n) + records and gap bits (1.5 GB) + primary and extras (<= ~10 n) on top of the blocks
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 18ull + ((size_t)10 << 30)) { (void)hipGetLastError(); return FPX_OK; }
+    hipStream_t st = 0;
+    auto body = [&]() -> int {
+        int rc;
+        DevBuf counts, boff, tot, items, gap, ns, nx, rbase, xbase, flags, rectot, recbase;
+        if ((rc = counts.alloc((size_t)nb * 4)) || (rc = boff.alloc(((size_t)nb + 1) * 8)) || (rc = tot.alloc(64)) ||
+            (rc = items.alloc(n * 8)) || (rc = flags.alloc(64)))
+            return rc;
+        FPX_HIP(hipMemsetAsync(flags.p, 0, 64, st));
+        hipLaunchKernelGGL(k_block_item_counts, dim3((nb + 255) / 256), dim3(256), 0, st, s->d_blocks, s->block_size, nb, counts.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)nb, boff.as<uint64_t>(), tot.as<uint64_t>());
+        hipLaunchKernelGGL(k_boff_tail, dim3(1), dim3(1), 0, st, boff.as<uint64_t>(), nb, tot.as<uint64_t>());
+        hipLaunchKernelGGL(k_decode_items, dim3((nb + 3) / 4), dim3(256), 0, st, s->d_blocks, s->block_size, nb, s->min_doc_id,
+                           boff.as<uint64_t>(), (const uint32_t*)nullptr, 0u, items.as<uint64_t>(), (uint8_t*)nullptr);
+        FPX_HIP(hipGetLastError());
+        // records: presence bits
+        FPX_HIP(hipMalloc(&s->d_drec, (size_t)DIRECT_NREC * 64u));
+        FPX_HIP(hipMemsetAsync(s->d_drec, 0, (size_t)DIRECT_NREC * 64u, st));
+        hipLaunchKernelGGL(k_presence_bits, dim3((nb + 3) / 4), dim3(256), 0, st, s->d_blocks, s->block_size, nb, s->d_drec, 0u);
+        // gap bits
+        if ((rc = gap.alloc((size_t)1 << 29))) return rc;
+        FPX_HIP(hipMemsetAsync(gap.p, 0, (size_t)1 << 29, st));
+        hipLaunchKernelGGL(k_direct_gap_bits, dim3(std::min<uint32_t>(nb + 1u, 1u << 20)), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb, gap.as<uint32_t>());
+        // distinct hashes and list words per block -> bases
+        if ((rc = ns.alloc((size_t)nb * 4)) || (rc = nx.alloc((size_t)nb * 4)) || (rc = rbase.alloc((size_t)nb * 8)) || (rc = xbase.alloc((size_t)nb * 8)))
+            return rc;
+        hipLaunchKernelGGL(k_direct_count, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
+                           ns.as<uint32_t>(), nx.as<uint32_t>(), flags.as<int>());
+        uint64_t* d_tot = tot.as<uint64_t>();
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nb, rbase.as<uint64_t>(), d_tot + 1);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nx.as<uint32_t>(), (uint64_t)nb, xbase.as<uint64_t>(), d_tot + 2);
+        FPX_HIP(hipGetLastError());
+        uint64_t h_tot[3] = {0, 0, 0};
+        int h_flags[2] = {0, 0};
+        FPX_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (h_tot[0] != n) { set_error("internal: decoded %llu items of %llu", (unsigned long long)h_tot[0], (unsigned long long)n); return FPX_E_DEVICE; }
+        if (h_flags[0] || h_flags[1] || h_tot[2] >= (1ull << 31)) return FPX_E_INVAL;          // does not qualify
+        const uint64_t D = h_tot[1], X = h_tot[2];
+        FPX_HIP(hipMalloc(&s->d_primary, (D + 4) * sizeof(uint32_t)));
+        FPX_HIP(hipMalloc(&s->d_extras, (X + 8) * sizeof(uint32_t)));
+        FPX_HIP(hipMemsetAsync(s->d_extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
+        hipLaunchKernelGGL(k_direct_fill, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
+                           s->min_doc_id, rbase.as<uint64_t>(), xbase.as<uint64_t>(), s->d_primary, s->d_extras);
+        // records: prefix counts, rank bases, gap intervals
+        if ((rc = rectot.alloc((size_t)DIRECT_NREC * 4)) || (rc = recbase.alloc((size_t)DIRECT_NREC * 8))) return rc;
+        hipLaunchKernelGGL(k_direct_rec_counts, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, rectot.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rectot.as<uint32_t>(), (uint64_t)DIRECT_NREC, recbase.as<uint64_t>(), d_tot + 3);
+        unsigned int* d_ncx = reinterpret_cast<unsigned int*>(d_tot + 4);
+        FPX_HIP(hipMemsetAsync(d_ncx, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_direct_rec_finish, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, recbase.as<uint64_t>(), gap.as<uint32_t>(), d_ncx);
+        FPX_HIP(hipGetLastError());
+        uint64_t h_bits = 0; unsigned int h_ncx = 0;
+        FPX_HIP(hipMemcpyAsync(&h_bits, d_tot + 3, 8, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipMemcpyAsync(&h_ncx, d_ncx, 4, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (h_bits != D) { set_error("internal: %llu presence bits for %llu distinct hashes", (unsigned long long)h_bits, (unsigned long long)D); return FPX_E_DEVICE; }
+        FPX_HIP(hipMalloc(&s->d_gapcx, ((size_t)h_ncx + 1) * 32u));
+        if (h_ncx) hipLaunchKernelGGL(k_direct_cx_fill, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, gap.as<uint32_t>(), s->d_gapcx);
+        // the block boundaries among the items stay (materialize_blocks)
+        if (!s->d_bstart) FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_bstart32, dim3((nb + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), nb, n, s->d_bstart);
+        FPX_HIP(hipGetLastError());
+        FPX_HIP(hipStreamSynchronize(st));
+        s->num_distinct = D; s->extras_words = X; s->num_gapcx = h_ncx;
+        return FPX_OK;
+    };
+    const int rc = body();
+    if (rc != FPX_OK) {
+        direct_free(s);
+        (void)hipGetLastError();
+        return rc == FPX_E_DEVICE ? rc : FPX_OK;             // an internal inconsistency is an error; anything else: stay block-based
+    }
+    s->direct = true;
+    // the blocks and what only the block kernels read are not needed any more
+    (void)hipFree(s->d_blocks); s->d_blocks = nullptr;
+    if (s->d_bucket) { (void)hipFree(s->d_bucket); s->d_bucket = nullptr; }
+    if (s->d_cont) { (void)hipFree(s->d_cont); s->d_cont = nullptr; }
+    s->device_bytes = (size_t)DIRECT_NREC * 64u + (s->num_distinct + 4) * 4 + (s->extras_words + 8) * 4 + ((size_t)s->num_gapcx + 1) * 32u +
+                      ((size_t)nb + 1) * 8;
+    return FPX_OK;
+}
+
+// ---- back to items and blocks (downloads, merges) ---------------------------------------------------------------------
+// thread per record: its hashes in ascending order, each with all its docs
+__global__ __launch_bounds__(256) void k_direct_rec_items(const uint32_t* __restrict__ drec, const uint32_t* __restrict__ primary,
+                                                          const uint32_t* __restrict__ extras, uint32_t min_doc,
+                                                          const uint64_t* __restrict__ itembase, uint32_t* __restrict__ count_out,
+                                                          uint64_t* __restrict__ items)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= DIRECT_NREC) return;
+    const uint32_t* rec = drec + (size_t)r * 16u;
+    uint64_t rank = rec[8];
+    uint64_t out = items ? itembase[r] : 0ull;
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 8u; ++w) {
+        uint32_t bits = rec[w];
+        while (bits) {
+            const uint32_t pos = w * 32u + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            const uint32_t p = primary[rank++];
+            const uint64_t hpart = (uint64_t)((r << 8) | pos) << 32;
+            if ((p >> 31) == 0u) {
+                if (items) items[out++] = hpart | (uint64_t)(min_doc + p);
+                total += 1u;
+            } else {
+                const uint32_t* x = extras + (p & 0x7FFFFFFFu);
+                const uint32_t hdr = x[0], T = (hdr >> 19) & 1u;
+                const uint32_t cnt = T ? x[1] : (hdr & 0xFFFFu);
+                if (items) for (uint32_t t = 0; t < cnt; ++t) items[out++] = hpart | (uint64_t)(min_doc + x[1u + T + t]);
+                total += cnt;
+            }
+        }
+    }
+    if (count_out) count_out[r] = total;
+}
+
+int materialize_items(const Segment* s, uint64_t* items, hipStream_t st)
+{
+    if (!s->direct) { set_error("internal: not a direct-addressed segment"); return FPX_E_INVAL; }
+    int rc;
+    DevBuf cnt, base, tot;
+    if ((rc = cnt.alloc((size_t)DIRECT_NREC * 4)) || (rc = base.alloc((size_t)DIRECT_NREC * 8)) || (rc = tot.alloc(8))) return rc;
+    hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->min_doc_id,
+                       (const uint64_t*)nullptr, cnt.as<uint32_t>(), (uint64_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, cnt.as<uint32_t>(), (uint64_t)DIRECT_NREC, base.as<uint64_t>(), tot.as<uint64_t>());
+    hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->min_doc_id,
+                       base.as<uint64_t>(), (uint32_t*)nullptr, items);
+    FPX_HIP(hipGetLastError());
+    uint64_t h_tot = 0;
+    FPX_HIP(hipMemcpyAsync(&h_tot, tot.p, 8, hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    if (h_tot != s->num_items) { set_error("internal: %llu items rebuilt of %llu", (unsigned long long)h_tot, (unsigned long long)s->num_items); return FPX_E_DEVICE; }
+    return FPX_OK;
+}
+
+__global__ void k_bstart_quads(const uint32_t* __restrict__ bstart, uint32_t nb, uint64_t* __restrict__ quads)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nb) quads[b] = (uint64_t)bstart[b] >> 2;
+}
+
+int materialize_blocks(const Segment* s, uint8_t** d_blocks_out)
+{
+    *d_blocks_out = nullptr;
+    int rc;
+    hipStream_t st = 0;
+    const uint64_t n = s->num_items;
+    const uint32_t nb = s->num_blocks;
+    DevBuf items, quads, index;
+    if ((rc = items.alloc(n * 8)) || (rc = quads.alloc(((size_t)nb + 1) * 8)) || (rc = index.alloc(((size_t)nb + 1) * 4))) return rc;
+    if ((rc = materialize_items(s, items.as<uint64_t>(), st))) return rc;
+    hipLaunchKernelGGL(k_bstart_quads, dim3((nb + 256) / 256), dim3(256), 0, st, s->d_bstart, nb, quads.as<uint64_t>());
+    uint8_t* blocks = nullptr;
+    FPX_HIP(hipMalloc(&blocks, s->blocks_len + 16));
+    hipError_t e = hipMemsetAsync(blocks + (size_t)nb * s->block_size, 0, s->block_size + 16, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_encode_blocks, dim3((nb + 3) / 4), dim3(256), 4 * s->block_size, st, items.as<uint64_t>(), n, s->min_doc_id,
+                           quads.as<uint64_t>(), (uint64_t)nb, (n + 3) / 4, s->block_size, blocks, index.as<uint32_t>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(blocks); return hip_fail(e, "materialize_blocks"); }
+    *d_blocks_out = blocks;
+    return FPX_OK;
+}
+
 // memory-segment source: copy the items and flag the ones whose doc is superseded
 __global__ __launch_bounds__(256) void k_flag_items(const uint64_t* __restrict__ src, uint64_t n, const uint32_t* __restrict__ dead,
                                                     uint32_t num_dead, uint64_t* __restrict__ items, uint8_t* __restrict__ live)
@@ -784,7 +1197,13 @@ int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_
             if ((rc = dead.alloc((size_t)nd * 4))) return rc;
             FPX_HIP(hipMemcpyAsync(dead.p, m.dead.data(), (size_t)nd * 4, hipMemcpyHostToDevice, st));
         }
-        if (g->kind == 0 && g->num_blocks) {
+        if (g->kind == 0 && g->direct) {
+            if ((rc = materialize_items(g, all.as<uint64_t>() + off, st))) return rc;
+            hipLaunchKernelGGL(k_flag_items, dim3(256 * 4), dim3(256), 0, st, (const uint64_t*)(all.as<uint64_t>() + off), g->num_items,
+                               dead.as<uint32_t>(), nd, all.as<uint64_t>() + off, live.as<uint8_t>() + off);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipStreamSynchronize(st));
+        } else if (g->kind == 0 && g->num_blocks) {
             DevBuf counts, boff, tot;
             if ((rc = counts.alloc((size_t)g->num_blocks * 4)) || (rc = boff.alloc((size_t)g->num_blocks * 8)) || (rc = tot.alloc(8))) return rc;
             hipLaunchKernelGGL(k_block_item_counts, dim3((g->num_blocks + 255) / 256), dim3(256), 0, st,

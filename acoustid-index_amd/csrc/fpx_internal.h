@@ -51,6 +51,12 @@ struct SegDesc {
     uint32_t own_flags;            // bit 0: own_lo is set, bit 1: own_hi is set
     uint32_t own_lo, own_hi;
     uint32_t present_shift;
+    // DIRECT-ADDRESSED segments (fpx_direct.hpp; Segment::direct): the blocks are gone, the postings are reached through the
+    // exact presence bitmap -- see the layout there
+    const uint32_t* drec;          // 2^24 records of 16 words: 256 presence bits, rank base, prefix counts, gap intervals
+    const uint32_t* primary;       // [distinct hashes] doc - min_doc_id, or bit 31 | offset into `extras`
+    const uint32_t* extras;        // doc lists of the hashes with several docs
+    const uint32_t* gapcx;         // 256-bit gap masks of the records whose gaps do not fit three intervals
 };
 
 // One resident memory segment (src/MemorySegment.zig:27-28).
@@ -124,6 +130,11 @@ struct Segment {
     uint32_t head_lines = 4;       // 2: in EVERY block the header, the hashes and the docid control bytes end before byte 252, so
                                    // k_probe_lean8<2> may fetch two 128-B lines first and the matching docid bytes afterwards
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
+    // direct-addressed form (fpx_direct.hpp): replaces the blocks of a dense segment; d_bstart (item offset of every block) and
+    // d_block_index stay, so that the blocks can be written out again byte for byte (materialize_blocks)
+    bool direct = false;
+    uint32_t* d_drec = nullptr; uint32_t* d_primary = nullptr; uint32_t* d_extras = nullptr; uint32_t* d_gapcx = nullptr;
+    uint64_t num_distinct = 0, extras_words = 0; uint32_t num_gapcx = 0;
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment
     uint64_t num_items = 0;
@@ -144,6 +155,8 @@ struct Snapshot {
     uint32_t n_lean2 = 0;                // the first n_lean2 of them qualify for the partial block fetch (Segment::head_lines == 2)
     SegDesc* d_gen = nullptr; uint32_t n_gen = 0; bool gen_all_512 = true;
     SegDesc* d_small = nullptr; uint32_t n_small = 0;     // small segments searched in their decoded items
+    std::vector<SegDesc> h_direct;       // direct-addressed segments: not part of h_file / n_file
+    SegDesc* d_direct = nullptr; uint32_t n_direct = 0;
     uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
     std::vector<std::shared_ptr<DeadSet>> dead_sets;   // shared with the segments' caches
@@ -262,6 +275,11 @@ int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool so
                        uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, Segment* s);
 int decode_small_segment(Segment* s);     // fills d_small_items / d_bstart of a resident file segment
 int build_presence(Segment* s);           // fills d_blockrec and d_proberec (both required by the lean kernel) of a resident file segment
+int build_direct(Segment* s);             // turns a dense resident file segment into its direct-addressed form (or leaves it as it is)
+// the blocks (+ terminator block + 16 B) of a direct-addressed segment, re-encoded into a fresh device buffer the caller frees
+int materialize_blocks(const Segment* s, uint8_t** d_blocks_out);
+// its items (hash << 32 | doc, sorted) into `items` [num_items]
+int materialize_items(const Segment* s, uint64_t* items, hipStream_t st);
 struct MergeSource { const Segment* seg; std::vector<uint32_t> dead; };   // dead = skip_docs, sorted
 int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_t block_size, uint32_t min_doc_id, Segment* s);
 

@@ -38,6 +38,7 @@
 #include "fpx_kernels_common.hpp"
 #include "fpx_probe_generic.hpp"
 #include "fpx_probe_lean.hpp"
+#include "fpx_direct.hpp"
 #include "fpx_probe_small.hpp"
 #include "fpx_score.hpp"
 
@@ -314,18 +315,19 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     }
     // deferred-probe lists of the lean kernel: room for 1/8 of the pairs per segment (typically < 2 % are deferred)
     const size_t def_cap = std::max<size_t>(4096, (size_t)(P / 8));
-    if (snap->n_lean) {
-        const size_t need = def_cap * snap->n_lean;
+    if (snap->n_lean || snap->n_direct) {
+        const size_t need = def_cap * std::max(1u, snap->n_lean);
         if ((rc = grow(&ws->d_def_list, &ws->cap_def, need))) return rc;
-        if (snap->n_lean > ws->cap_def_segs) {
+        if (snap->n_lean > ws->cap_def_segs || !ws->d_def_count) {
             if (ws->d_def_count) (void)hipFree(ws->d_def_count);
             if (ws->h_def_count) (void)hipHostFree(ws->h_def_count);
             ws->d_def_count = nullptr; ws->h_def_count = nullptr; ws->cap_def_segs = 0;
             // [n_lean deferred-list counts, one per 128-B line | LEAN_STAT_SETS x 8 u64 statistics slots of the lean kernel]
-            const size_t words = (size_t)snap->n_lean * DEF_COUNT_STRIDE + LEAN_STAT_WORDS;
+            const size_t nseg = std::max(1u, snap->n_lean);
+            const size_t words = nseg * DEF_COUNT_STRIDE + LEAN_STAT_WORDS;
             FPX_HIP(hipMalloc(&ws->d_def_count, words * sizeof(unsigned int)));
             FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), words * sizeof(unsigned int)));
-            ws->cap_def_segs = snap->n_lean;
+            ws->cap_def_segs = nseg;
         }
     }
     // (for the workspace's capacity, not this snapshot's n_lean: the layout must not move between batches)
@@ -342,11 +344,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         for (uint32_t q = 0; q < B && local_sort; ++q) local_sort = offsets[q + 1] - offsets[q] <= QSORT_MAX;
     if (local_sort) {
         hipLaunchKernelGGL(k_make_keys_sorted, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, base, ws->d_keys[0],
-                           snap->n_lean ? ws->d_def_count : nullptr, (uint32_t)def_words);
+                           (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
         FPX_HIP(hipGetLastError());
     } else if (P && !score_only) {
         hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
-                           single_fast ? ws->d_counters : nullptr, snap->n_lean ? ws->d_def_count : nullptr, (uint32_t)def_words);
+                           single_fast ? ws->d_counters : nullptr, (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
         // ... and only the top 32 - KEY_SORT_SKIP of them: block-level locality is all the probes need from the order
@@ -362,7 +364,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     float probe_ms = 0.f, aux_ms = 0.f;
     uint32_t probe_launches = 0;
     if (ws->cap_hits == 0) {
-        size_t want = std::max<size_t>(1u << 20, (size_t)P * std::max<uint32_t>(1u, snap->n_file + snap->n_mem));
+        size_t want = std::max<size_t>(1u << 20, (size_t)P * std::max<uint32_t>(1u, snap->n_file + snap->n_direct + snap->n_mem));
         if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, want))) return rc;
     }
     // ---- the device-sized path (fpx_partition.hpp): the hit records are binned by query as they are produced, every size
@@ -404,11 +406,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         h_bin.bin_count = d_bin_count;
         FPX_HIP(hipMemsetAsync(d_bin_count, 0, ((size_t)MAX_BINS * BIN_STRIDE + B) * sizeof(uint32_t), st));
     }
-    bool force_generic = false, used_lean = false;
+    bool force_generic = false, used_lean = false, spread = false;
     for (int attempt = 0;; ++attempt) {
-        used_lean = false;
+        used_lean = false; spread = false;
         if (!single_fast) FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));   // (k_make_keys did it)
-        if (P && snap->n_file) {
+        if (P && (snap->n_file || snap->n_direct)) {
             ProbeArgs a;
             a.pairs = d_pairs; a.P = P; a.qb = qb;
             // enough workgroups to fill 256 CUs; long per-wave runs amortise the index walk for big batches
@@ -426,10 +428,24 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const bool lean = (snap->n_lean != 0 || snap->n_small != 0) && !force_generic && P < 0x80000000ull && qb <= 24u &&   // pair indices + a tag bit in the deferred lists; 8 spare bits in q
                               total >= lean_min_probes();
             if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe0, st));
+            if (attempt > 0 && (snap->n_lean || snap->n_direct))
+                FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (first attempt: k_make_keys)
+            if (snap->n_direct) {
+                // direct-addressed segments: one kernel for every batch size (fpx_direct.hpp)
+                ProbeArgs dk = a;
+                dk.segs = snap->d_direct;
+                const uint64_t wgs_at_1 = (P + DK_WG * DK_KPL - 1) / (DK_WG * DK_KPL) * snap->n_direct;
+                dk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_at_1 / 8192));
+                // statistics: spread over 64 lines when thousands of workgroups end with them (see LEAN_STAT_SETS)
+                spread = !single_fast && wgs_at_1 >= 1024;
+                dk.lean_stats = spread ? reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off) : nullptr;
+                const uint64_t per_wg_dk = (uint64_t)DK_WG * DK_KPL * dk.rounds;
+                hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), snap->n_direct), dim3(DK_WG), 0, st, dk);
+            }
             if (lean) {
                 if (snap->n_lean) {
                     // main kernel: k_probe_lean8 over the dense 512-B segments
-                    if (attempt > 0) FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (else: k_make_keys)
+                    spread = true;
                     ProbeArgs l = a;
                     // rounds of 1024 pairs per workgroup: more rounds amortise the workgroup's set-up (decode tables, barriers) --
                     // measured at 8.2 M pairs x 16 segments: 5.48 ms with 1, 5.11 with 2, 5.01 with 6, 5.14 with 16 -- as long
@@ -480,15 +496,17 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     else hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_gen), dim3(PWG), lds, st, ge);
                 }
                 FPX_HIP(hipEventRecord(ws->ev_probe2, st));
-                if (snap->n_lean)
-                    FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, def_words * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 used_lean = true;
             } else {
                 a.segs = snap->d_file;
-                if (snap->all_512) hipLaunchKernelGGL((k_probe<true, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
-                else hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+                if (snap->n_file) {
+                    if (snap->all_512) hipLaunchKernelGGL((k_probe<true, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+                    else hipLaunchKernelGGL((k_probe<false, false>), dim3(gx, snap->n_file), dim3(PWG), lds, st, a);
+                }
                 if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             }
+            if (spread)
+                FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, def_words * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipGetLastError());
             probe_launches += 1;
         }
@@ -508,19 +526,19 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (single_fast || fast) break;             // nothing below needs the counts on the host yet
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_SYNC(ws);
-        if (used_lean && snap->n_lean) {
-            // the lean kernel's statistics: LEAN_STAT_SETS copies on separate cache lines (a workgroup adds to set
+        if (spread) {
+            // the lean / direct kernels' statistics: LEAN_STAT_SETS copies on separate cache lines (a workgroup adds to set
             // blockIdx.x % LEAN_STAT_SETS), summed here into the slots the code below reads
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
-            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0;
+            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0, dreads = 0;
             for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
-                reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3];
+                reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4];
             }
-            ws->h_counters[CTR_LEAN_READS] = reads;
+            ws->h_counters[CTR_LEAN_READS] = reads + (dreads + 1) / 2;           // (k_probe_direct counts 64-byte requests)
             ws->h_counters[8 + CTR_BLOCKS] = blocks; ws->h_counters[8 + CTR_BYTES] = blocks * 512ull;
             ws->h_counters[8 + CTR_DOCS] = docs; ws->h_counters[8 + CTR_PROBES] = probes;
         }
-        if (P && snap->n_file) {
+        if (P && (snap->n_file || snap->n_direct)) {
             float ms = 0.f;
             FPX_HIP(hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1));
             probe_ms = ms;
@@ -645,19 +663,21 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (!partial && (rc = deliver_results(ws, B, out_cap, staged, out, out_n, st))) return rc;
         if (stats) {
             unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0;
-            if (used_lean && snap->n_lean) {
+            if (spread) {
                 const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
+                unsigned long long dreads = 0;
                 for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
-                    reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3];
+                    reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4];
                 }
+                reads += (dreads + 1) / 2;
             }
             float ms = 0.f, aux = 0.f, total_ms = 0.f;
-            if (P && snap->n_file) {
+            if (P && (snap->n_file || snap->n_direct)) {
                 (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
                 if (used_lean) (void)hipEventElapsedTime(&aux, ws->ev_probe1, ws->ev_probe2);
             }
             (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
-            const bool ln = used_lean && snap->n_lean;
+            const bool ln = spread;
             stats->probes += ws->h_counters[CTR_PROBES] + probes;
             stats->scanned_blocks += ws->h_counters[CTR_BLOCKS] + blocks;
             stats->scanned_docs += ws->h_counters[CTR_DOCS] + docs;
@@ -730,8 +750,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_bytes = ws->h_counters[CTR_BYTES] + ws->h_counters[8 + CTR_BYTES],
                              c_probes = ws->h_counters[CTR_PROBES] + ws->h_counters[8 + CTR_PROBES],
                              c_generic = ws->h_counters[CTR_GENERIC],
-                             c_main_bytes = (used_lean && snap->n_lean) ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES],
-                             c_fetched_bytes = (used_lean && snap->n_lean) ? ws->h_counters[CTR_LEAN_READS] * 128ull : ws->h_counters[CTR_BYTES];   // (lines)
+                             c_main_bytes = spread ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES],
+                             c_fetched_bytes = spread ? ws->h_counters[CTR_LEAN_READS] * 128ull : ws->h_counters[CTR_BYTES];   // (lines)
 
     uint64_t C = 0, C_slots = 0;                   // candidates in the shared list / in the queries' own slots
     uint64_t* d_qcand = nullptr;

@@ -226,3 +226,36 @@ def test_config2_with_hot_hashes_at_full_size():
     assert (mn == out_n).all() and (mo == out).all()
     assert hits_sum == st.hits
     _oracle_sample(fpx, oracle, ctx, segs[7], 7 * per + 1, per, flat, offsets, opts, 16)
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+def test_direct_addressed_form_equals_block_form_at_full_size(dist, monkeypatch):
+    """A 1.6 G-item segment (one of configs[2]'s sixteen) built twice from the same seed: block form (FPX_DIRECT=0: blocks in
+    HBM, lean kernel) and direct-addressed form (the default at this size: fpx_direct.hpp, the blocks are freed).  The same
+    batch must give the same bytes and the same reference counters (visited blocks, docs, hit records), and the blocks the
+    direct form re-encodes on download must be the block form's, byte for byte -- an independent check of the conversion
+    (the oracle samples above read a direct-addressed segment's blocks through that very re-encoding).
+    dist = 1: hot hashes, i.e. lists cut by the reference's 4-block / 1000-doc caps."""
+    from fpx_testlib import fpx
+    ctx = fpx.Context(0)
+    H, per, B, L = 256, 6_250_000, 2048, 1000
+    _fit(per, lambda d: int(d * H * 30) + (20 << 30), "one 1.6 G-item segment in both forms")
+    flat, offsets, _ = fpx.synth.make_queries(SEED, 4242, B, per, H, query_len=L, dist=dist)
+    opts = fpx.http_options(limit=40)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    res = []
+    for direct in ("0", "1"):
+        monkeypatch.setenv("FPX_DIRECT", direct)
+        seg = fpx.FileSegment.synth(ctx, SEED, 1, per, H, dist, 512, 1)
+        reader = fpx.IndexReader(fpx.Segments(ctx, [seg]))
+        fpx.search_resident(reader, qb)                               # (a workspace's first batch takes the general path)
+        out, out_n, st = fpx.search_resident(reader, qb)
+        blocks, index = seg.download()
+        res.append((out.copy(), out_n.copy(), (st.probes, st.scanned_blocks, st.scanned_docs, st.hits), blocks, index, seg.device_bytes))
+        del reader
+        seg.release()
+    (o0, n0, c0, b0, i0, bytes0), (o1, n1, c1, b1, i1, bytes1) = res
+    assert c0 == c1, (c0, c1)
+    assert (n0 == n1).all() and (o0 == o1).all()
+    assert np.array_equal(i0, i1) and np.array_equal(b0, b1)
+    assert int(n0.min()) >= 1

@@ -1,9 +1,14 @@
 """GPU parity tests: the HIP path through the C ABI vs the CPU oracle, bit-exact {id, score} lists,
 plus the reference's scanned-blocks / scanned-docs totals."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# every file segment direct-addressed (tests/test_gpu_variants.py): results and counters must not change, but the assertions
+# about which block kernel carried a batch do not apply
+DIRECT_FORCED = os.environ.get("FPX_DIRECT_MIN_ITEMS") == "0"
 
 
 @pytest.fixture(scope="module")
@@ -221,6 +226,9 @@ def test_lean_kernel_and_deferred_pass(env, dist, presence, monkeypatch):
     qs = [flat[int(off[i]):int(off[i + 1])] for i in range(nq)]
     got, st = p.check(qs, fpx.http_options())
     assert st.probes >= (1 << 20) - 4096
+    if DIRECT_FORCED:
+        assert all(g and g[0][0] == int(t) for g, t in zip(got, targets))
+        return
     assert 0 < st.probe_kernel_bytes <= st.algorithmic_bytes                            # the lean kernel worked ...
     if presence:
         assert st.probe_kernel_fetched_bytes < st.probe_kernel_bytes // 2               # 1.15 M items: most query hashes are absent
@@ -357,7 +365,7 @@ def test_deferred_list_overflow_falls_back_to_generic_pass(env):
         qs.append(np.concatenate([real, noise]))
     got, st = p.check(qs, fpx.SearchOptions(max_results=20, min_score=1, min_score_pct=0))
     assert st.probes >= (1 << 16)
-    assert st.generic_iters > st.probes // 4                    # the generic per-value decode carried the batch
+    assert DIRECT_FORCED or st.generic_iters > st.probes // 4   # the generic per-value decode carried the batch
 
 
 def test_hit_buffer_overflow_regrows(env):

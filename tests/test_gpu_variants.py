@@ -5,6 +5,10 @@ variant runs in a process of its own):
                          pairs per query in LDS)
 * FPX_FAST=0             the general path only (host round trips between the stages, rocPRIM partition)
 * FPX_LEAN_HEAD=4        the whole-block instantiation of the lean probe kernel instead of the partial fetch
+* FPX_DIRECT_MIN_ITEMS=0 EVERY file segment in its direct-addressed form (by default only segments of >= 2^28 items, which only the
+                         full-size tests build): searches, counters, downloads and merges must be what the block form gives
+* FPX_DIRECT=0           no segment direct-addressed (run over the full-size tests' neighbours is not needed: the default suites
+                         build no segment that large; tests/test_gpu_fullsize.py compares the two forms at full size)
 """
 import os
 import subprocess
@@ -16,15 +20,19 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUITES = ["tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded_abi.py"]
+DIRECT_SUITES = SUITES + ["tests/test_gpu_builder.py", "tests/test_gpu_merge.py", "tests/test_gpu_api.py", "tests/test_gpu_frontend.py",
+                          "tests/test_gpu_hashsplit.py", "tests/test_gpu_sharded.py"]
 
 
 @pytest.mark.parametrize("env", [{"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
-                                 {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"}],
+                                 {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
+                                 {"FPX_DIRECT_MIN_ITEMS": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_parity_suites_on_the_alternative_paths(env):
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         pytest.skip("already inside a variant run")
     e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + SUITES,
+    suites = DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

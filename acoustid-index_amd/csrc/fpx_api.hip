@@ -124,8 +124,14 @@ static void segment_free(Segment* s)
     if (s->d_drec) (void)hipFree(s->d_drec);
     if (s->d_primary) (void)hipFree(s->d_primary);
     if (s->d_extras) (void)hipFree(s->d_extras);
-    if (s->d_gapcx) (void)hipFree(s->d_gapcx);
     delete s;
+}
+
+FusedDir::~FusedDir()
+{
+    (void)hipSetDevice(device);
+    if (d_lines) (void)hipFree(d_lines);
+    for (Segment* s : segs) if (s->refs.fetch_sub(1) == 1) segment_free(s);
 }
 
 __global__ void k_count_items(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
@@ -373,6 +379,7 @@ uint64_t fpx_segment_num_items(const fpx_segment* seg) { return seg ? reinterpre
 uint32_t fpx_segment_num_blocks(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->num_blocks : 0; }
 uint32_t fpx_segment_block_size(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->block_size : 0; }
 uint64_t fpx_segment_device_bytes(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->device_bytes : 0; }
+int fpx_segment_layout(const fpx_segment* seg) { return seg && reinterpret_cast<const Segment*>(seg)->direct ? 1 : 0; }
 
 int fpx_segment_download(const fpx_segment* seg, uint8_t* blocks, size_t blocks_cap, uint32_t* block_index, uint32_t index_cap)
 {
@@ -446,6 +453,32 @@ static void compute_dead(const std::vector<Segment*>& segs, size_t si, std::vect
     dead.erase(std::unique(dead.begin(), dead.end()), dead.end());
 }
 
+// the fused directory of a group of direct-addressed segments: the one a live snapshot already holds for the same group, or a
+// new one (null when memory is short: the group is then probed segment by segment)
+static std::shared_ptr<FusedDir> get_fused_dir(Ctx* c, Segment* const* segs, uint32_t k)
+{
+    std::lock_guard<std::mutex> lk(c->fused_mu);
+    auto& cache = c->fused_cache;
+    for (size_t i = 0; i < cache.size();) {
+        std::shared_ptr<FusedDir> fd = cache[i].lock();
+        if (!fd) { cache.erase(cache.begin() + i); continue; }
+        if (fd->segs.size() == k && std::equal(fd->segs.begin(), fd->segs.end(), segs)) return fd;
+        ++i;
+    }
+    const size_t bytes = ((size_t)1 << 27) * 128u;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); return nullptr; }
+    auto fd = std::make_shared<FusedDir>();
+    fd->device = c->device;
+    if (hipMalloc(&fd->d_lines, bytes) != hipSuccess) { fd->d_lines = nullptr; (void)hipGetLastError(); return nullptr; }
+    const uint32_t* drecs[FUSE_MAX] = {};
+    for (uint32_t j = 0; j < k; ++j) drecs[j] = segs[j]->d_drec;
+    if (fuse_directory(drecs, k, fd->d_lines) != FPX_OK) return nullptr;
+    for (uint32_t j = 0; j < k; ++j) { segs[j]->refs.fetch_add(1); fd->segs.push_back(segs[j]); }
+    cache.push_back(fd);
+    return fd;
+}
+
 static void snapshot_free(Snapshot* sn)
 {
     if (!sn) return;
@@ -455,6 +488,9 @@ static void snapshot_free(Snapshot* sn)
     if (sn->d_gen) (void)hipFree(sn->d_gen);
     if (sn->d_small) (void)hipFree(sn->d_small);
     if (sn->d_direct) (void)hipFree(sn->d_direct);
+    if (sn->d_fused) (void)hipFree(sn->d_fused);
+    if (sn->d_solo) (void)hipFree(sn->d_solo);
+    sn->fused.clear();
     if (sn->d_mem) (void)hipFree(sn->d_mem);
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;
@@ -486,6 +522,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         sn->segs.push_back(s);
     }
     std::vector<uint32_t> dead;
+    std::vector<Segment*> direct_segs;               // parallel to sn->h_direct
     for (size_t i = 0; i < sn->segs.size(); ++i) {
         Segment* s = sn->segs[i];
         // docs-only members: explicit stand-ins (kind 2) and segments resident on ANOTHER context's device -- in a sharded
@@ -534,8 +571,8 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
-            d.drec = s->d_drec; d.primary = s->d_primary; d.extras = s->d_extras; d.gapcx = s->d_gapcx;
-            if (s->direct) { sn->h_direct.push_back(d); continue; }          // searched by k_probe_direct alone
+            d.drec = s->d_drec; d.primary = s->d_primary; d.extras = s->d_extras; d.first_hash = s->first_hash; d.last_hash = s->last_hash;
+            if (s->direct) { sn->h_direct.push_back(d); direct_segs.push_back(s); continue; }   // searched by k_probe_direct / k_probe_fused alone
             sn->h_file.push_back(d);
             sn->max_block_size = std::max(sn->max_block_size, s->block_size);
             if (s->block_size != 512) sn->all_512 = false;
@@ -554,6 +591,39 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     if (sn->n_direct) {
         e = hipMalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_direct, sn->h_direct.data(), sn->n_direct * sizeof(SegDesc), hipMemcpyHostToDevice);
+        // groups of direct-addressed segments (in snapshot order, 16 to a group) get a fused directory; groups too small
+        // for it to pay (FPX_FUSE_MIN, default 6: it costs 17 GB whatever the group's size) and whatever does not fit
+        // in memory are probed segment by segment
+        static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 6u; }();
+        std::vector<FusedDesc> h_fused;
+        std::vector<SegDesc> h_solo;
+        for (uint32_t i0 = 0; e == hipSuccess && i0 < sn->n_direct; i0 += FUSE_MAX) {
+            const uint32_t k = std::min<uint32_t>(FUSE_MAX, sn->n_direct - i0);
+            std::shared_ptr<FusedDir> fd;
+            if (fuse_min != 0 && k >= fuse_min) fd = get_fused_dir(c, direct_segs.data() + i0, k);
+            if (!fd) { for (uint32_t j = 0; j < k; ++j) h_solo.push_back(sn->h_direct[i0 + j]); continue; }
+            FusedDesc g{};
+            g.lines = fd->d_lines; g.nseg = k;
+            for (uint32_t j = 0; j < FUSE_MAX; ++j) { g.first_hash[j] = 1u; g.last_hash[j] = 0u; }      // unused columns: empty hash range
+            for (uint32_t j = 0; j < k; ++j) {
+                const SegDesc& d = sn->h_direct[i0 + j];
+                g.primary[j] = d.primary; g.extras[j] = d.extras; g.min_doc[j] = d.min_doc_id;
+                g.first_hash[j] = d.first_hash; g.last_hash[j] = d.last_hash;
+                g.seg_index[j] = i0 + j; g.has_dead[j] = d.num_dead != 0u ? 1u : 0u;
+                g.any_dead |= g.has_dead[j];
+            }
+            h_fused.push_back(g);
+            sn->fused.push_back(fd);
+        }
+        sn->n_fused = (uint32_t)h_fused.size(); sn->n_solo = (uint32_t)h_solo.size();
+        if (e == hipSuccess && sn->n_fused) {
+            e = hipMalloc(&sn->d_fused, h_fused.size() * sizeof(FusedDesc));
+            if (e == hipSuccess) e = hipMemcpy(sn->d_fused, h_fused.data(), h_fused.size() * sizeof(FusedDesc), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess && sn->n_solo) {
+            e = hipMalloc(&sn->d_solo, h_solo.size() * sizeof(SegDesc));
+            if (e == hipSuccess) e = hipMemcpy(sn->d_solo, h_solo.data(), h_solo.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
+        }
     }
     if (e == hipSuccess && sn->n_file) {
         e = hipMalloc(&sn->d_file, sn->n_file * sizeof(SegDesc));

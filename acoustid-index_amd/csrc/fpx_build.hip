@@ -367,7 +367,6 @@ static void free_partial_segment(Segment* s)
     if (s->d_drec) (void)hipFree(s->d_drec);
     if (s->d_primary) (void)hipFree(s->d_primary);
     if (s->d_extras) (void)hipFree(s->d_extras);
-    if (s->d_gapcx) (void)hipFree(s->d_gapcx);
     delete s;
 }
 
@@ -821,10 +820,20 @@ __global__ __launch_bounds__(256) void k_direct_count(const uint64_t* __restrict
     if (c_x > 0xFFFFFFFFull) flags[1] = 1;
 }
 
-// per block again: primary[rank] = doc - min_doc, or bit 31 | offset of the hash's list in `extras`:
+// rank of hash h among the set bits of the records (needs words 8..10 in place)
+__device__ __forceinline__ uint64_t direct_rank(const uint32_t* __restrict__ drec, uint32_t h)
+{
+    const uint32_t* rec = drec + (size_t)(h >> 8) * 16u;
+    const uint32_t w = (h >> 5) & 7u, bit = h & 31u;
+    const uint32_t pre = ((w < 4u ? rec[9] : rec[10]) >> (8u * (w & 3u))) & 0xFFu;
+    return (uint64_t)rec[8] + pre + (uint32_t)__popc(rec[w] & ((1u << bit) - 1u));
+}
+
+// per block again: primary[rank(hash)] = doc - min_doc, or bit 31 | offset of the hash's list in `extras`:
 //   word 0 = docs returned (16 bits) | blocks visited << 16 | T << 19, [T: all docs of the hash], the docs (doc - min_doc, ascending)
+// (the words of GAP positions keep the 0xFFFFFFFF they were initialised with)
 __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
-                                                     uint32_t nb, uint32_t min_doc, const uint64_t* __restrict__ rbase,
+                                                     uint32_t nb, uint32_t min_doc, const uint32_t* __restrict__ drec,
                                                      const uint64_t* __restrict__ xbase, uint32_t* __restrict__ primary,
                                                      uint32_t* __restrict__ extras)
 {
@@ -833,11 +842,12 @@ __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict_
     const uint64_t bs = boff[b], be = boff[b + 1];
     uint32_t prevh = bs ? (uint32_t)(items[bs - 1] >> 32) : 0u;
     bool have_prev = bs != 0;
-    uint64_t r = rbase[b], x = xbase[b];
+    uint64_t x = xbase[b];
     for (uint64_t i = bs; i < be; ++i) {
         const uint64_t it = items[i];
         const uint32_t h = (uint32_t)(it >> 32);
         if (!have_prev || h != prevh) {
+            const uint64_t r = direct_rank(drec, h);
             if (i + 1 < n && (uint32_t)(items[i + 1] >> 32) == h) {
                 const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
                 const uint64_t cnt = ri.end - i;
@@ -849,46 +859,38 @@ __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict_
             } else {
                 primary[r] = (uint32_t)it - min_doc;
             }
-            ++r;
         }
         prevh = h; have_prev = true;
     }
 }
 
-// bit h of `gap` (2^27 words): no item has hash h AND FileSegment.search visits no block for it -- h lies before the first hash
-// of the first block whose max hash is >= h (src/FileSegment.zig:164), or beyond the last block (:153)
+// GAP positions: hash values no item has AND for which FileSegment.search visits no block -- h lies before the first hash of
+// the first block whose max hash is >= h (src/FileSegment.zig:164).  (Before the segment's first hash and beyond its last
+// one -- :153 -- the kernel knows from two scalars.)  Their bits are set in
+// the records next to the presence bits (and their words of `primary` say so): a clear bit then means "absent, one block
+// visited", which is what a probe of an absent hash costs the reference everywhere else.
 __global__ __launch_bounds__(256) void k_direct_gap_bits(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
-                                                         uint32_t nb, uint32_t* __restrict__ gap)
+                                                         uint32_t nb, uint32_t* __restrict__ drec)
 {
     // one workgroup per block boundary, strided: a grid of nb + 1 workgroups x 256 threads passes 2^32 work-items beyond
     // 16.7 M blocks, which a launch silently truncates
-    for (uint64_t b = blockIdx.x; b <= nb; b += gridDim.x) {          // 0 .. nb (nb: beyond the last item)
-        int64_t lo, hi;
-        if (b < nb) {
-            const uint32_t f = (uint32_t)(items[boff[b]] >> 32);
-            lo = 0;
-            if (b > 0) {
-                const uint32_t p = (uint32_t)(items[boff[b] - 1] >> 32);
-                if (p == f) continue;                                // the block continues its predecessor's last run: no gap
-                lo = (int64_t)p + 1;
-            }
-            hi = (int64_t)f - 1;
-        } else {
-            lo = (int64_t)(uint32_t)(items[n - 1] >> 32) + 1;
-            hi = 0xFFFFFFFFll;
-        }
+    for (uint64_t b = 1 + blockIdx.x; b < nb; b += gridDim.x) {       // (before the first and beyond the last hash: SegDesc::first_hash / last_hash)
+        const uint32_t f = (uint32_t)(items[boff[b]] >> 32);
+        const uint32_t p = (uint32_t)(items[boff[b] - 1] >> 32);
+        if (p == f) continue;                                        // the block continues its predecessor's last run: no gap
+        const int64_t lo = (int64_t)p + 1, hi = (int64_t)f - 1;
         if (lo > hi) continue;
         const uint32_t wlo = (uint32_t)(lo >> 5), whi = (uint32_t)(hi >> 5);
         for (uint64_t w = (uint64_t)wlo + threadIdx.x; w <= whi; w += 256u) {
             uint32_t mask = 0xFFFFFFFFu;
             if (w == wlo) mask &= 0xFFFFFFFFu << (uint32_t)(lo & 31);
             if (w == whi) mask &= 0xFFFFFFFFu >> (31u - (uint32_t)(hi & 31));
-            atomicOr(&gap[w], mask);
+            atomicOr(&drec[(size_t)(w >> 3) * 16u + (w & 7u)], mask);
         }
     }
 }
 
-// words 9, 10 of every record: how many presence bits are set below each of its eight words; its total for the rank scan
+// words 9, 10 of every record: how many bits are set below each of its eight words; its total for the rank scan
 __global__ __launch_bounds__(256) void k_direct_rec_counts(uint32_t* __restrict__ drec, uint32_t* __restrict__ rectot)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -904,52 +906,11 @@ __global__ __launch_bounds__(256) void k_direct_rec_counts(uint32_t* __restrict_
     rectot[r] = run;
 }
 
-__device__ __forceinline__ uint32_t next_bit256(const uint32_t* g, uint32_t pos, bool want)   // first position >= pos whose bit == want
-{
-    while (pos < 256u) {
-        uint32_t w = g[pos >> 5];
-        if (!want) w = ~w;
-        w &= 0xFFFFFFFFu << (pos & 31u);
-        if (w) return (pos & ~31u) + (uint32_t)__builtin_ctz(w);
-        pos = (pos & ~31u) + 32u;
-    }
-    return 256u;
-}
-
-// word 8 = rank of the record's first hash; words 12..14 = its gap bits as up to three intervals [lo, hi) packed lo | hi << 16;
-// a record with more gets word 11 bit 0 and a slot (word 15) in the table of 256-bit masks
-__global__ __launch_bounds__(256) void k_direct_rec_finish(uint32_t* __restrict__ drec, const uint64_t* __restrict__ recbase,
-                                                           const uint32_t* __restrict__ gap, unsigned int* __restrict__ ncx)
+// word 8 = rank of the record's first position
+__global__ __launch_bounds__(256) void k_direct_rec_base(uint32_t* __restrict__ drec, const uint64_t* __restrict__ recbase)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= DIRECT_NREC) return;
-    uint32_t g[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) g[i] = gap[(size_t)r * 8u + i];
-    uint32_t ent[3] = {0u, 0u, 0u}, n_ent = 0;
-    for (uint32_t pos = 0; pos < 256u;) {
-        const uint32_t glo = next_bit256(g, pos, true);
-        if (glo >= 256u) break;
-        const uint32_t ghi = next_bit256(g, glo, false);
-        if (n_ent < 3u) ent[n_ent] = glo | (ghi << 16);
-        ++n_ent;
-        pos = ghi;
-    }
-    uint32_t* rec = drec + (size_t)r * 16u;
-    uint32_t flags = 0, cx = 0;
-    if (n_ent > 3u) { flags = 1u; cx = atomicAdd(ncx, 1u); ent[0] = ent[1] = ent[2] = 0u; }
-    rec[8] = (uint32_t)recbase[r];
-    rec[11] = flags; rec[12] = ent[0]; rec[13] = ent[1]; rec[14] = ent[2]; rec[15] = cx;
-}
-
-__global__ __launch_bounds__(256) void k_direct_cx_fill(const uint32_t* __restrict__ drec, const uint32_t* __restrict__ gap,
-                                                        uint32_t* __restrict__ gapcx)
-{
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= DIRECT_NREC) return;
-    const uint32_t* rec = drec + (size_t)r * 16u;
-    if ((rec[11] & 1u) == 0u) return;
-    for (int i = 0; i < 8; ++i) gapcx[(size_t)rec[15] * 8u + i] = gap[(size_t)r * 8u + i];
+    if (r < DIRECT_NREC) drec[(size_t)r * 16u + 8u] = (uint32_t)recbase[r];
 }
 
 __global__ void k_boff_tail(uint64_t* boff, uint32_t nb, const uint64_t* total) { boff[nb] = *total; }
@@ -971,15 +932,15 @@ static void direct_free(Segment* s)
     if (s->d_drec) (void)hipFree(s->d_drec);
     if (s->d_primary) (void)hipFree(s->d_primary);
     if (s->d_extras) (void)hipFree(s->d_extras);
-    if (s->d_gapcx) (void)hipFree(s->d_gapcx);
-    s->d_drec = s->d_primary = s->d_extras = s->d_gapcx = nullptr;
-    s->num_distinct = s->extras_words = 0; s->num_gapcx = 0;
+    s->d_drec = s->d_primary = s->d_extras = nullptr;
+    s->num_distinct = s->num_positions = s->extras_words = 0;
     s->direct = false;
 }
 
 // Called for a resident file segment whose blocks, block index and item count are in place.  On success the segment is
 // direct-addressed and its blocks, bucket table and continuation bitmap are FREED; whatever keeps it from qualifying (size,
-// doc id range, memory, blocks not made of four-item chunks) leaves it block-based, which is always correct.
+// doc id range, memory, blocks not made of four-item chunks, too many gap positions) leaves it block-based, which is always
+// correct.
 int build_direct(Segment* s)
 {
     if (!direct_enabled() || s->kind != 0 || s->own_flags != 0u || s->num_blocks == 0 || s->num_items == 0 ||
@@ -989,12 +950,12 @@ int build_direct(Segment* s)
     const uint64_t n = s->num_items;
     const uint32_t nb = s->num_blocks;
     size_t free_b = 0, total_b = 0;
-    // peak: the items (8 n) + records and gap bits (1.5 GB) + primary and extras (<= ~10 n) on top of the blocks
+    // peak: the items (8 n) + records (1 GB) + primary and extras (<= ~10 n) on top of the blocks
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 18ull + ((size_t)10 << 30)) { (void)hipGetLastError(); return FPX_OK; }
     hipStream_t st = 0;
     auto body = [&]() -> int {
         int rc;
-        DevBuf counts, boff, tot, items, gap, ns, nx, rbase, xbase, flags, rectot, recbase;
+        DevBuf counts, boff, tot, items, ns, nx, xbase, sbase, flags, rectot, recbase;
         if ((rc = counts.alloc((size_t)nb * 4)) || (rc = boff.alloc(((size_t)nb + 1) * 8)) || (rc = tot.alloc(64)) ||
             (rc = items.alloc(n * 8)) || (rc = flags.alloc(64)))
             return rc;
@@ -1005,57 +966,53 @@ int build_direct(Segment* s)
         hipLaunchKernelGGL(k_decode_items, dim3((nb + 3) / 4), dim3(256), 0, st, s->d_blocks, s->block_size, nb, s->min_doc_id,
                            boff.as<uint64_t>(), (const uint32_t*)nullptr, 0u, items.as<uint64_t>(), (uint8_t*)nullptr);
         FPX_HIP(hipGetLastError());
-        // records: presence bits
+        // records: presence bits + gap bits, prefix counts, rank bases
         FPX_HIP(hipMalloc(&s->d_drec, (size_t)DIRECT_NREC * 64u));
         FPX_HIP(hipMemsetAsync(s->d_drec, 0, (size_t)DIRECT_NREC * 64u, st));
         hipLaunchKernelGGL(k_presence_bits, dim3((nb + 3) / 4), dim3(256), 0, st, s->d_blocks, s->block_size, nb, s->d_drec, 0u);
-        // gap bits
-        if ((rc = gap.alloc((size_t)1 << 29))) return rc;
-        FPX_HIP(hipMemsetAsync(gap.p, 0, (size_t)1 << 29, st));
-        hipLaunchKernelGGL(k_direct_gap_bits, dim3(std::min<uint32_t>(nb + 1u, 1u << 20)), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb, gap.as<uint32_t>());
-        // distinct hashes and list words per block -> bases
-        if ((rc = ns.alloc((size_t)nb * 4)) || (rc = nx.alloc((size_t)nb * 4)) || (rc = rbase.alloc((size_t)nb * 8)) || (rc = xbase.alloc((size_t)nb * 8)))
+        hipLaunchKernelGGL(k_direct_gap_bits, dim3(std::min<uint32_t>(nb + 1u, 1u << 20)), dim3(256), 0, st, items.as<uint64_t>(), n,
+                           boff.as<uint64_t>(), nb, s->d_drec);
+        if ((rc = rectot.alloc((size_t)DIRECT_NREC * 4)) || (rc = recbase.alloc((size_t)DIRECT_NREC * 8))) return rc;
+        uint64_t* d_tot = tot.as<uint64_t>();
+        hipLaunchKernelGGL(k_direct_rec_counts, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, rectot.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rectot.as<uint32_t>(), (uint64_t)DIRECT_NREC, recbase.as<uint64_t>(), d_tot + 3);
+        hipLaunchKernelGGL(k_direct_rec_base, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, recbase.as<uint64_t>());
+        // distinct hashes and list words per block -> list bases
+        if ((rc = ns.alloc((size_t)nb * 4)) || (rc = nx.alloc((size_t)nb * 4)) || (rc = sbase.alloc((size_t)nb * 8)) || (rc = xbase.alloc((size_t)nb * 8)))
             return rc;
         hipLaunchKernelGGL(k_direct_count, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
                            ns.as<uint32_t>(), nx.as<uint32_t>(), flags.as<int>());
-        uint64_t* d_tot = tot.as<uint64_t>();
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nb, rbase.as<uint64_t>(), d_tot + 1);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nb, sbase.as<uint64_t>(), d_tot + 1);
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nx.as<uint32_t>(), (uint64_t)nb, xbase.as<uint64_t>(), d_tot + 2);
         FPX_HIP(hipGetLastError());
-        uint64_t h_tot[3] = {0, 0, 0};
+        uint64_t h_tot[4] = {0, 0, 0, 0};
         int h_flags[2] = {0, 0};
+        uint64_t h_ends[2] = {0, 0};
         FPX_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
         FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipMemcpyAsync(&h_ends[0], items.as<uint64_t>(), 8, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipMemcpyAsync(&h_ends[1], items.as<uint64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, st));
         FPX_HIP(hipStreamSynchronize(st));
+        s->first_hash = (uint32_t)(h_ends[0] >> 32); s->last_hash = (uint32_t)(h_ends[1] >> 32);
         if (h_tot[0] != n) { set_error("internal: decoded %llu items of %llu", (unsigned long long)h_tot[0], (unsigned long long)n); return FPX_E_DEVICE; }
-        if (h_flags[0] || h_flags[1] || h_tot[2] >= (1ull << 31)) return FPX_E_INVAL;          // does not qualify
-        const uint64_t D = h_tot[1], X = h_tot[2];
-        FPX_HIP(hipMalloc(&s->d_primary, (D + 4) * sizeof(uint32_t)));
+        const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
+        if (Dp < D) { set_error("internal: %llu set bits for %llu distinct hashes", (unsigned long long)Dp, (unsigned long long)D); return FPX_E_DEVICE; }
+        // a gap position costs a word of `primary`: dense segments have a few per block; a segment whose hashes cluster
+        // (long empty stretches at block boundaries) keeps its blocks.  (FPX_DIRECT_MIN_ITEMS=0, the tests' switch, allows 2^26.)
+        const bool gaps_ok = Dp - D <= std::max<uint64_t>(n / 4, direct_min_items() == 0 ? (1ull << 26) : 0ull);
+        if (h_flags[0] || h_flags[1] || X >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull || !gaps_ok) return FPX_E_INVAL;      // does not qualify
+        FPX_HIP(hipMalloc(&s->d_primary, (Dp + 4) * sizeof(uint32_t)));
         FPX_HIP(hipMalloc(&s->d_extras, (X + 8) * sizeof(uint32_t)));
+        FPX_HIP(hipMemsetAsync(s->d_primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
         FPX_HIP(hipMemsetAsync(s->d_extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
         hipLaunchKernelGGL(k_direct_fill, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
-                           s->min_doc_id, rbase.as<uint64_t>(), xbase.as<uint64_t>(), s->d_primary, s->d_extras);
-        // records: prefix counts, rank bases, gap intervals
-        if ((rc = rectot.alloc((size_t)DIRECT_NREC * 4)) || (rc = recbase.alloc((size_t)DIRECT_NREC * 8))) return rc;
-        hipLaunchKernelGGL(k_direct_rec_counts, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, rectot.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rectot.as<uint32_t>(), (uint64_t)DIRECT_NREC, recbase.as<uint64_t>(), d_tot + 3);
-        unsigned int* d_ncx = reinterpret_cast<unsigned int*>(d_tot + 4);
-        FPX_HIP(hipMemsetAsync(d_ncx, 0, sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_direct_rec_finish, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, recbase.as<uint64_t>(), gap.as<uint32_t>(), d_ncx);
-        FPX_HIP(hipGetLastError());
-        uint64_t h_bits = 0; unsigned int h_ncx = 0;
-        FPX_HIP(hipMemcpyAsync(&h_bits, d_tot + 3, 8, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipMemcpyAsync(&h_ncx, d_ncx, 4, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipStreamSynchronize(st));
-        if (h_bits != D) { set_error("internal: %llu presence bits for %llu distinct hashes", (unsigned long long)h_bits, (unsigned long long)D); return FPX_E_DEVICE; }
-        FPX_HIP(hipMalloc(&s->d_gapcx, ((size_t)h_ncx + 1) * 32u));
-        if (h_ncx) hipLaunchKernelGGL(k_direct_cx_fill, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, gap.as<uint32_t>(), s->d_gapcx);
+                           s->min_doc_id, (const uint32_t*)s->d_drec, xbase.as<uint64_t>(), s->d_primary, s->d_extras);
         // the block boundaries among the items stay (materialize_blocks)
         if (!s->d_bstart) FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_bstart32, dim3((nb + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), nb, n, s->d_bstart);
         FPX_HIP(hipGetLastError());
         FPX_HIP(hipStreamSynchronize(st));
-        s->num_distinct = D; s->extras_words = X; s->num_gapcx = h_ncx;
+        s->num_distinct = D; s->num_positions = Dp; s->extras_words = X;
         return FPX_OK;
     };
     const int rc = body();
@@ -1069,8 +1026,7 @@ int build_direct(Segment* s)
     (void)hipFree(s->d_blocks); s->d_blocks = nullptr;
     if (s->d_bucket) { (void)hipFree(s->d_bucket); s->d_bucket = nullptr; }
     if (s->d_cont) { (void)hipFree(s->d_cont); s->d_cont = nullptr; }
-    s->device_bytes = (size_t)DIRECT_NREC * 64u + (s->num_distinct + 4) * 4 + (s->extras_words + 8) * 4 + ((size_t)s->num_gapcx + 1) * 32u +
-                      ((size_t)nb + 1) * 8;
+    s->device_bytes = (size_t)DIRECT_NREC * 64u + (s->num_positions + 4) * 4 + (s->extras_words + 8) * 4 + ((size_t)nb + 1) * 8;
     return FPX_OK;
 }
 
@@ -1094,6 +1050,7 @@ __global__ __launch_bounds__(256) void k_direct_rec_items(const uint32_t* __rest
             bits &= bits - 1u;
             const uint32_t p = primary[rank++];
             const uint64_t hpart = (uint64_t)((r << 8) | pos) << 32;
+            if (p == 0xFFFFFFFFu) continue;                          // a gap position: no item
             if ((p >> 31) == 0u) {
                 if (items) items[out++] = hpart | (uint64_t)(min_doc + p);
                 total += 1u;

@@ -6,22 +6,22 @@
 // segment (1.6 G items: 31 % of all 32-bit values taken) is kept in HBM in a form that needs none of that at search time:
 //
 //   records  2^24 x 64 bytes, record r = hash >> 8 (SegDesc::drec)
-//            words 0..7    256 presence bits: bit i = some item has the hash r << 8 | i -- EXACT, so the bitmap is the hash column
-//            word  8       rank of the record's first hash among the segment's distinct hashes
-//            words 9, 10   eight bytes: presence bits set below each of the eight words (rank inside the record = byte + popcount)
-//            word  11      bit 0: the record's gaps do not fit three intervals: 256-bit mask at gapcx[word 15]
-//            words 12..14  gap intervals lo | hi << 16: an ABSENT hash at position p, lo <= p < hi, lies before the first hash of
-//                          the block that would hold it (or beyond the last block): the reference visits no block for it
-//                          (src/FileSegment.zig:164,153); every other absent hash costs it exactly one visited block
-//   primary  one word per distinct hash, in hash order: doc - min_doc_id, or bit 31 | offset of the hash's list in `extras`
+//            words 0..7    256 position bits: bit i = some item has the hash r << 8 | i -- EXACT, so the bitmap is the hash
+//                          column -- or the position is a GAP: no item has the hash and the reference visits no block for it
+//                          (it lies before the first hash of the block that would hold it, src/FileSegment.zig:164).
+//                          A clear bit: absent, and the reference visits exactly one block
+//            word  8       rank of the record's first position among the segment's set bits
+//            words 9, 10   eight bytes: bits set below each of the eight words (rank inside the record = byte + popcount)
+//   primary  one word per set bit, in hash order: doc - min_doc_id, or bit 31 | offset of the hash's list in `extras`, or
+//            0xFFFFFFFF for a gap position (a few per block boundary on dense segments; a segment with many keeps its blocks)
 //   extras   word 0 = docs the reference returns (16 bits) | blocks it visits << 16 | T << 19, [T: number of docs], the docs.
 //            The reference's caps (<= 4 blocks, stop beyond 1000 docs, :173-174) depend on where the blocks end; they are
 //            applied when the segment is converted (fpx_build.hip: direct_run_info), so the list says how many of its docs count.
 //
-// A probe is a 64-byte record read (sorted probes share lines: 5.2 M lines for 8.2 M probes) and, for the 31 % whose hash
-// exists, one 4-byte read of `primary` (+ one of `extras` for the 17 % of those with several docs): 8.2 M HBM requests per
+// A probe is a 64-byte record read (sorted probes share 128-byte lines: 5.2 M lines for 8.2 M probes) and, for the 31 % whose
+// hash exists, one 4-byte read of `primary` (+ one of `extras` for the 17 % of those with several docs): 8.2 M HBM lines per
 // segment and batch of 8192 instead of the blocks' 12.5 M, no LDS staging of blocks, no decode.  One lane per probe, four
-// probes per lane in flight; the kernel is bound by HBM's request rate.
+// probes per lane in flight; the kernel runs at the rate HBM serves 128-byte lines.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
     for (uint32_t round = 0; round < a.rounds; ++round) {
         const uint64_t base = wg_base + (uint64_t)round * (DK_WG * DK_KPL);
         uint32_t h[DK_KPL], q[DK_KPL], bw[DK_KPL], d[DK_KPL];
-        uint4 ax[DK_KPL], gp[DK_KPL];
+        uint4 ax[DK_KPL];
         bool valid[DK_KPL];
         // ---- the pairs (dedupSorted, src/Index.zig:489-499) and their records
 #pragma unroll
@@ -74,38 +74,35 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
             if (valid[j] && is_duplicate_pair(a.pairs, p, key, a.qb)) valid[j] = false;
             h[j] = (uint32_t)(key >> a.qb);
             q[j] = (uint32_t)key & qmask;
-            bw[j] = 0u; ax[j] = make_uint4(0, 0, 0, 0); gp[j] = make_uint4(0, 0, 0, 0);
+            bw[j] = 0u; ax[j] = make_uint4(0, 0, 0, 0);
+            if (valid[j]) my_probes += 1u;
+            // (before the segment's first hash the reference finds the first block's min_hash > h, beyond its last one no block
+            // at all, src/FileSegment.zig:164,153: absent, nothing visited, nothing to read)
+            if (valid[j] && (h[j] < seg.first_hash || h[j] > seg.last_hash)) valid[j] = false;
             if (valid[j]) {
                 const uint32_t* rec = seg.drec + (size_t)(h[j] >> 8) * 16u;
                 bw[j] = gload_u32(rec + ((h[j] >> 5) & 7u));
                 ax[j] = gload_u4(reinterpret_cast<const uint8_t*>(rec + 8));
-                gp[j] = gload_u4(reinterpret_cast<const uint8_t*>(rec + 12));
             }
         }
-        // ---- present: the hash's word of `primary`; absent: the gap test
+        // ---- set bit: the position's word of `primary`; clear: an absent hash, one block visited
         bool present[DK_KPL];
 #pragma unroll
         for (int j = 0; j < DK_KPL; ++j) {
             const uint32_t pos = h[j] & 255u, w = pos >> 5, bit = pos & 31u;
             present[j] = valid[j] && ((bw[j] >> bit) & 1u) != 0u;
-            d[j] = 0u;
+            d[j] = 0xFFFFFFFFu;
             if (present[j]) {
                 const uint32_t pre = ((w < 4u ? ax[j].y : ax[j].z) >> (8u * (w & 3u))) & 0xFFu;
                 const uint32_t rank = ax[j].x + pre + (uint32_t)__popc(bw[j] & ((1u << bit) - 1u));
                 d[j] = gload_u32(seg.primary + rank);
                 my_reads += 1u;
             } else if (valid[j]) {
-                bool in_gap;
-                if (ax[j].w & 1u) {
-                    in_gap = ((gload_u32(seg.gapcx + (size_t)gp[j].w * 8u + w) >> bit) & 1u) != 0u;
-                } else {
-                    in_gap = (pos >= (gp[j].x & 0xFFFFu) && pos < (gp[j].x >> 16)) || (pos >= (gp[j].y & 0xFFFFu) && pos < (gp[j].y >> 16)) ||
-                             (pos >= (gp[j].z & 0xFFFFu) && pos < (gp[j].z >> 16));
-                }
-                if (!in_gap) my_blocks += 1u;       // the reference visits one block, finds nothing and stops
+                my_blocks += 1u;                    // the reference visits one block, finds nothing and stops
             }
-            if (valid[j]) my_probes += 1u;
         }
+#pragma unroll
+        for (int j = 0; j < DK_KPL; ++j) present[j] = present[j] && d[j] != 0xFFFFFFFFu;      // (a gap position: nothing visited)
         // ---- hashes with several docs: the head of the list (header + up to three docs) in one load
         uint4 x[DK_KPL];
 #pragma unroll
@@ -163,6 +160,168 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
             if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_probe_fused: up to 16 direct-addressed segments probed TOGETHER.
+// The segments of an index share one hash space, and a query hash is looked up in every one of them: sixteen record reads
+// (0.64 HBM lines per probe and segment even with the probes sorted) for what one line can say.  A snapshot therefore FUSES
+// the records of its direct-addressed segments, 16 to a group, into one directory (fuse_directory, fpx_api.hip):
+//   line L = hash >> 5, 128 bytes:  words 0..15   the 32 position bits of hash values [32 L, 32 L + 32) in segment s
+//                                   words 16..31  rank of the line's first position in segment s (its `primary` index)
+// One thread per HASH now (not per hash and segment) reads that line, and for every segment whose bit is set one word of
+// that segment's `primary`: 8.2 M + 41 M lines per batch of 8192 x 1000 instead of 84 M + 41 M.
+// ------------------------------------------------------------------------------------------------
+struct FusedArgs {
+    const FusedDesc* groups;               // (fpx_internal.h)
+    const SegDesc* segs;                   // Snapshot::d_direct
+};
+
+constexpr int FK_WG = 256;
+
+__global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa)
+{
+    __shared__ uint64_t stage[STAGE_CAP];
+    __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
+    const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const FusedDesc* __restrict__ g = fa.groups + blockIdx.y;
+    if (tid == 0) {
+        stage_count = 0; stage_valid = STAGE_CAP;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
+        s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;        // cancel point (src/FileSegment.zig:144), once per workgroup
+    }
+    __syncthreads();
+    if (s_cancel) return;
+    const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
+    const uint32_t nseg = g->nseg;
+    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_reads = 0;
+
+    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)FK_WG * a.rounds;
+    for (uint32_t round = 0; round < a.rounds; ++round) {
+        const uint64_t p = wg_base + (uint64_t)round * FK_WG + tid;
+        bool valid = p < a.P;
+        const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
+        if (valid && is_duplicate_pair(a.pairs, p, key, a.qb)) valid = false;        // dedupSorted, src/Index.zig:489-499
+        const uint32_t h = (uint32_t)(key >> a.qb);
+        const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
+        const uint32_t bit = h & 31u, below = (1u << bit) - 1u;
+        uint32_t w[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) w[i] = 0u;
+        if (valid) {
+            const uint8_t* line = reinterpret_cast<const uint8_t*>(g->lines + (size_t)(h >> 5) * 32u);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 v = gload_u4(line + 16 * i);
+                w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+            my_probes += nseg;
+            my_reads += 2u;
+        }
+        // ---- every segment whose bit is set: the position's word of its `primary`
+        uint32_t d[FUSE_MAX];
+#pragma unroll
+        for (uint32_t s = 0; s < FUSE_MAX; ++s) {
+            d[s] = 0xFFFFFFFFu;
+            // (outside [first_hash, last_hash] the reference visits no block, src/FileSegment.zig:164,153; unused columns: empty range)
+            const bool in_range = valid && h >= g->first_hash[s] && h <= g->last_hash[s];
+            if (in_range) {
+                if ((w[s] >> bit) & 1u) {
+                    d[s] = gload_u32(g->primary[s] + (w[16 + s] + (uint32_t)__popc(w[s] & below)));
+                    my_reads += 1u;
+                } else {
+                    my_blocks += 1u;                // absent: the reference visits one block, finds nothing and stops
+                }
+            }
+        }
+        // ---- emission, eight segments at a time: the heads of the lists (hashes with several docs) in one load each
+#pragma unroll
+        for (uint32_t half = 0; half < FUSE_MAX; half += 8u) {
+            uint4 x[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const uint32_t s = half + k;
+                x[k] = make_uint4(0, 0, 0, 0);
+                if (d[s] != 0xFFFFFFFFu && (d[s] >> 31)) { x[k] = gload_u4_a4(g->extras[s] + (d[s] & 0x7FFFFFFFu)); my_reads += 1u; }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const uint32_t s = half + k;
+                if (s >= nseg) break;                                              // (uniform)
+                const bool present = d[s] != 0xFFFFFFFFu;
+                const bool multi = present && (d[s] >> 31) != 0u;
+                const uint32_t eff = multi ? (x[k].x & 0xFFFFu) : (present ? 1u : 0u);
+                const uint32_t T = (x[k].x >> 19) & 1u;
+                if (present) { my_blocks += multi ? ((x[k].x >> 16) & 7u) : 1u; my_docs += eff; }
+                const uint32_t md = g->min_doc[s];
+                const SegDesc* filt = g->has_dead[s] ? fa.segs + g->seg_index[s] : nullptr;   // (uniform)
+                const uint32_t d0 = md + (multi ? (T ? x[k].z : x[k].y) : d[s]);
+                const uint32_t d1 = md + (T ? x[k].w : x[k].z), d2 = md + x[k].w;
+                bool k0 = eff >= 1u, k1 = multi && eff >= 2u, k2 = multi && eff >= 3u && T == 0u;
+                if (filt) {                          // superseded docs are dropped here: the stage holds several segments' records
+                    k0 = k0 && !is_dead_seg(*filt, d0); k1 = k1 && !is_dead_seg(*filt, d1); k2 = k2 && !is_dead_seg(*filt, d2);
+                }
+                stage_emit(hs, a, k0, qpart | d0, lane);
+                stage_emit(hs, a, k1, qpart | d1, lane);
+                stage_emit(hs, a, k2, qpart | d2, lane);
+                // longer lists (1 % of them): the wave reads them together, 64 docs at a time
+                unsigned long long ml = __ballot((int)(multi && eff > (T ? 2u : 3u)));
+                while (ml != 0ull) {
+                    const int src = (int)__builtin_ctzll(ml);
+                    ml &= ml - 1ull;
+                    const uint32_t xs = __shfl(d[s] & 0x7FFFFFFFu, src), es = __shfl(eff, src), ts = __shfl(T, src);
+                    const uint32_t qlo = __shfl((uint32_t)(qpart >> 32), src);
+                    for (uint32_t o = ts ? 2u : 3u; o < es; o += 64u) {
+                        bool keep = o + lane < es;
+                        const uint32_t dv = md + (keep ? gload_u32(g->extras[s] + xs + 1u + ts + o + lane) : 0u);
+                        if (filt && keep) keep = !is_dead_seg(*filt, dv);
+                        stage_emit(hs, a, keep, ((uint64_t)qlo << 32) | dv, lane);
+                    }
+                    if (lane == 0) my_reads += (es + 15u) >> 4;
+                }
+            }
+            stage_flush(hs, a, round + 1u == a.rounds && half + 8u >= FUSE_MAX, tid, FK_WG);
+        }
+    }
+
+    if (my_reads) atomicAdd(&wg_reads, (unsigned long long)my_reads);
+    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
+    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
+    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    __syncthreads();
+    if (tid == 0) {
+        if (a.lean_stats) {
+            unsigned long long* st = a.lean_stats + (size_t)(blockIdx.x % LEAN_STAT_SETS) * 8u;
+            if (wg_reads) atomicAdd(&st[4], wg_reads);
+            if (wg_blocks) atomicAdd(&st[1], wg_blocks);
+            if (wg_docs) atomicAdd(&st[2], wg_docs);
+            if (wg_probes) atomicAdd(&st[3], wg_probes);
+        } else {
+            if (wg_blocks) { atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks); atomicAdd(&a.counters[CTR_BYTES], wg_blocks * 512ull); }
+            if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
+            if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
+        }
+    }
+}
+
+// the fused directory of a group: thread (L, s) copies segment s's word of line L and its rank base out of the segment's records
+__global__ __launch_bounds__(256) void k_fuse_lines(uint32_t* __restrict__ lines, const uint32_t* const* __restrict__ drecs, uint32_t nseg)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t s = (uint32_t)gid & 15u;
+    const uint64_t L = gid >> 4;                     // < 2^27
+    uint32_t bits = 0, base = 0;
+    if (s < nseg) {
+        const uint32_t* rec = drecs[s] + (size_t)(L >> 3) * 16u;
+        const uint32_t wv = (uint32_t)L & 7u;
+        bits = rec[wv];
+        base = rec[8] + (((wv < 4u ? rec[9] : rec[10]) >> (8u * (wv & 3u))) & 0xFFu);
+    }
+    lines[L * 32u + s] = bits;
+    lines[L * 32u + 16u + s] = base;
 }
 
 }  // namespace fpx

@@ -53,10 +53,22 @@ struct SegDesc {
     uint32_t present_shift;
     // DIRECT-ADDRESSED segments (fpx_direct.hpp; Segment::direct): the blocks are gone, the postings are reached through the
     // exact presence bitmap -- see the layout there
-    const uint32_t* drec;          // 2^24 records of 16 words: 256 presence bits, rank base, prefix counts, gap intervals
-    const uint32_t* primary;       // [distinct hashes] doc - min_doc_id, or bit 31 | offset into `extras`
+    const uint32_t* drec;          // 2^24 records of 16 words: 256 position bits (hash present, or gap), rank base, prefix counts
+    const uint32_t* primary;       // [set bits] doc - min_doc_id, or bit 31 | offset into `extras`, or 0xFFFFFFFF: a gap position
     const uint32_t* extras;        // doc lists of the hashes with several docs
-    const uint32_t* gapcx;         // 256-bit gap masks of the records whose gaps do not fit three intervals
+    uint32_t first_hash, last_hash; // of the segment: a hash outside is absent and costs the reference no block visit (:153,164)
+};
+
+// A group of up to 16 direct-addressed segments probed through ONE fused directory (k_probe_fused, fpx_direct.hpp)
+constexpr uint32_t FUSE_MAX = 16;
+struct FusedDesc {
+    const uint32_t* lines;                 // 2^27 lines of 32 words: [16 x position bits of 32 hash values | 16 x rank of the line's first position]
+    uint32_t nseg, any_dead;
+    const uint32_t* primary[FUSE_MAX];
+    const uint32_t* extras[FUSE_MAX];
+    uint32_t min_doc[FUSE_MAX], first_hash[FUSE_MAX], last_hash[FUSE_MAX];
+    uint32_t seg_index[FUSE_MAX];          // the segment's descriptor in Snapshot::d_direct (supersession filter)
+    uint32_t has_dead[FUSE_MAX];
 };
 
 // One resident memory segment (src/MemorySegment.zig:27-28).
@@ -133,14 +145,24 @@ struct Segment {
     // direct-addressed form (fpx_direct.hpp): replaces the blocks of a dense segment; d_bstart (item offset of every block) and
     // d_block_index stay, so that the blocks can be written out again byte for byte (materialize_blocks)
     bool direct = false;
-    uint32_t* d_drec = nullptr; uint32_t* d_primary = nullptr; uint32_t* d_extras = nullptr; uint32_t* d_gapcx = nullptr;
-    uint64_t num_distinct = 0, extras_words = 0; uint32_t num_gapcx = 0;
+    uint32_t* d_drec = nullptr; uint32_t* d_primary = nullptr; uint32_t* d_extras = nullptr;
+    uint64_t num_distinct = 0, num_positions = 0, extras_words = 0;     // distinct hashes; set bits = hashes + gap positions; list words
+    uint32_t first_hash = 0, last_hash = 0;
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment
     uint64_t num_items = 0;
     // memory
     uint64_t* d_items = nullptr;
     uint64_t device_bytes = 0;
+};
+
+// the fused directory of a group of direct-addressed segments: built when a snapshot first holds the group, shared by the
+// snapshots that follow with the same group (Ctx::fused_cache), freed with the last of them
+struct FusedDir {
+    int device = 0;
+    uint32_t* d_lines = nullptr;
+    std::vector<Segment*> segs;            // retained
+    ~FusedDir();
 };
 
 struct Snapshot {
@@ -157,6 +179,10 @@ struct Snapshot {
     SegDesc* d_small = nullptr; uint32_t n_small = 0;     // small segments searched in their decoded items
     std::vector<SegDesc> h_direct;       // direct-addressed segments: not part of h_file / n_file
     SegDesc* d_direct = nullptr; uint32_t n_direct = 0;
+    // ... of which groups of FPX_FUSE_MIN..16 are probed through a fused directory and the rest (n_solo) one by one
+    std::vector<std::shared_ptr<FusedDir>> fused;
+    FusedDesc* d_fused = nullptr; uint32_t n_fused = 0;
+    SegDesc* d_solo = nullptr; uint32_t n_solo = 0;
     uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
     std::vector<std::shared_ptr<DeadSet>> dead_sets;   // shared with the segments' caches
@@ -220,6 +246,7 @@ struct QueryBatch {
 struct Ctx {
     int device = 0;
     std::mutex mu;
+    std::mutex fused_mu; std::vector<std::weak_ptr<FusedDir>> fused_cache;
     std::vector<Workspace*> free_ws;
     std::atomic<int> live_ws{0};
 };
@@ -247,6 +274,7 @@ hipError_t select_u64(void* temp, size_t temp_bytes, const uint64_t* in, const u
 
 // fpx_search.hip
 int build_bucket_table(Segment* seg, hipStream_t stream);
+int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t* d_lines);     // fills a group's 2^27 x 128-byte directory
 int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                             const fpx_opts* opts, QueryBatch** out);
 void query_batch_free(QueryBatch* qb);

@@ -79,6 +79,21 @@ int build_bucket_table(Segment* seg, hipStream_t stream)
     return FPX_OK;
 }
 
+int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t* d_lines)
+{
+    const uint32_t** d_ptrs = nullptr;
+    FPX_HIP(hipMalloc(reinterpret_cast<void**>(&d_ptrs), FUSE_MAX * sizeof(uint32_t*)));
+    hipError_t e = hipMemcpy(d_ptrs, h_drecs, nseg * sizeof(uint32_t*), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fuse_lines, dim3(1u << 23), dim3(256), 0, 0, d_lines, (const uint32_t* const*)d_ptrs, nseg);     // 2^27 lines x 16 columns
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_ptrs);
+    if (e != hipSuccess) return hip_fail(e, "fuse_directory");
+    return FPX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
@@ -431,16 +446,28 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (attempt > 0 && (snap->n_lean || snap->n_direct))
                 FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (first attempt: k_make_keys)
             if (snap->n_direct) {
-                // direct-addressed segments: one kernel for every batch size (fpx_direct.hpp)
-                ProbeArgs dk = a;
-                dk.segs = snap->d_direct;
-                const uint64_t wgs_at_1 = (P + DK_WG * DK_KPL - 1) / (DK_WG * DK_KPL) * snap->n_direct;
-                dk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_at_1 / 8192));
+                // direct-addressed segments: their kernels serve every batch size (fpx_direct.hpp)
+                const uint64_t wgs_solo = (P + DK_WG * DK_KPL - 1) / (DK_WG * DK_KPL) * snap->n_solo;
+                const uint64_t wgs_fused = (P + FK_WG - 1) / FK_WG * snap->n_fused;
                 // statistics: spread over 64 lines when thousands of workgroups end with them (see LEAN_STAT_SETS)
-                spread = !single_fast && wgs_at_1 >= 1024;
-                dk.lean_stats = spread ? reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off) : nullptr;
-                const uint64_t per_wg_dk = (uint64_t)DK_WG * DK_KPL * dk.rounds;
-                hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), snap->n_direct), dim3(DK_WG), 0, st, dk);
+                spread = !single_fast && wgs_solo + wgs_fused >= 1024;
+                unsigned long long* stat_sets = spread ? reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off) : nullptr;
+                if (snap->n_fused) {
+                    // groups of segments behind one fused directory: one thread per hash
+                    ProbeArgs fk = a;
+                    fk.segs = snap->d_direct; fk.lean_stats = stat_sets;
+                    fk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_fused / 8192));
+                    const FusedArgs fargs{snap->d_fused, snap->d_direct};
+                    const uint64_t per_wg_fk = (uint64_t)FK_WG * fk.rounds;
+                    hipLaunchKernelGGL(k_probe_fused, dim3((uint32_t)((P + per_wg_fk - 1) / per_wg_fk), snap->n_fused), dim3(FK_WG), 0, st, fk, fargs);
+                }
+                if (snap->n_solo) {
+                    ProbeArgs dk = a;
+                    dk.segs = snap->d_solo; dk.lean_stats = stat_sets;
+                    dk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_solo / 8192));
+                    const uint64_t per_wg_dk = (uint64_t)DK_WG * DK_KPL * dk.rounds;
+                    hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), snap->n_solo), dim3(DK_WG), 0, st, dk);
+                }
             }
             if (lean) {
                 if (snap->n_lean) {

@@ -72,6 +72,7 @@ public:
     fpx_segment* handle() const { return h_.get(); }
     uint64_t getSize() const { return fpx_segment_num_items(h_.get()); }       // FileSegment.getSize, :75-77
     uint64_t deviceBytes() const { return fpx_segment_device_bytes(h_.get()); }
+    bool directAddressed() const { return fpx_segment_layout(h_.get()) == 1; }
 protected:
     std::shared_ptr<fpx_segment> h_;
 };

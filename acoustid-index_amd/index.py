@@ -116,6 +116,11 @@ class _Segment:
     def device_bytes(self):
         return lib().fpx_segment_device_bytes(self.h)
 
+    @property
+    def direct(self):
+        """kept in HBM in the direct-addressed form (fpx_segment_layout) instead of as blocks"""
+        return lib().fpx_segment_layout(self.h) == 1
+
 
 def _docs_args(doc_ids, doc_alive):
     ids = _u32(doc_ids)

@@ -112,19 +112,29 @@ class StatAgg:
 
 
 def model_moved_bytes(segs, fetched_per_launch, probes_per_launch):
-    """What the dominant kernel has to pull from HBM per launch, modelled from counts the kernel reports: the blocks it
-    fetched (counted) + the 128-B lines of the probe records (presence bits + block range + block records, 64 B per 256
-    hash buckets) its probes touch (expected value for uniform hashes) + the sorted pairs (8 B per probe)."""
+    """What the dominant kernel has to pull from HBM per launch, modelled from counts the kernel reports.
+    Block-form segments (k_probe_lean8): the blocks it fetched (counted) + the 128-B lines of the probe records (presence
+    bits + block range + block records, 64 B per 256 hash buckets) its probes touch (expected value for uniform hashes) +
+    the sorted pairs (8 B per probe).
+    Direct-addressed segments (k_probe_direct): the 64-B sectors of `primary` / `extras` it read (counted: one per present
+    hash, one more per hash with several docs) + the 64-B records its probes touch (expected value) + the pairs."""
     files = [sg for sg in segs if sg.kind == "file"]
     if not files:
         return {"blocks": fetched_per_launch, "probe_records": 0.0, "pairs": 0.0, "total": fetched_per_launch}
     per_seg = probes_per_launch / len(files)
     pr = 0.0
     for sg in files:
-        if sg.getSize() >= (1 << 20):
+        if getattr(sg, "direct", False):
+            pr += touched_bytes(float((1 << 24) * 64), per_seg, line=64)
+        elif sg.getSize() >= (1 << 20):
             pr += touched_bytes(float(probe_record_bytes(sg.getSize())), per_seg)
     pairs = 8.0 * probes_per_launch
     return {"blocks": fetched_per_launch, "probe_records": pr, "pairs": pairs, "total": fetched_per_launch + pr + pairs}
+
+
+def dominant_kernel(segs):
+    files = [sg for sg in segs if sg.kind == "file"]
+    return "k_probe_direct" if files and all(getattr(sg, "direct", False) for sg in files) else "k_probe_lean8"
 
 
 def timed_resident(fpx, reader, qb, steps, warmup, out=None, out_n=None):
@@ -204,13 +214,14 @@ def run_pmc_child(args, docs, timeout_s=420):
         if p.returncode != 0:
             return None, f"rocprofv3 child exited {p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
         by = parse_pmc_dir(d)
-        if not by or not by.get("k_probe_lean8"):
-            return None, "no k_probe_lean8 dispatch in the counter output"
+        main = "k_probe_direct" if by and by.get("k_probe_direct") else "k_probe_lean8"
+        if not by or not by.get(main):
+            return None, "no k_probe_direct / k_probe_lean8 dispatch in the counter output"
         child = None
         for line in p.stdout.decode(errors="replace").splitlines():
             if line.startswith('{"pmc_child"'):
                 child = json.loads(line)
-        lean = by["k_probe_lean8"][-2:]
+        lean = by[main][-2:]
         kb = sum(lean) / len(lean)
         cal = {}
         if child:
@@ -225,7 +236,7 @@ def run_pmc_child(args, docs, timeout_s=420):
             os.makedirs(out_dir, exist_ok=True)
             for f in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
                 shutil.copy(f, out_dir)
-        return {"hbm_read_bytes_per_launch": kb * 1024 * corr, "FETCH_SIZE_KB_per_launch": kb, "correction": corr,
+        return {"kernel": main, "hbm_read_bytes_per_launch": kb * 1024 * corr, "FETCH_SIZE_KB_per_launch": kb, "correction": corr,
                 "calibration": cal, "launches_averaged": len(lean),
                 "child_probe_kernel_ms_under_profiler": child.get("probe_kernel_ms") if child else None}, None
     finally:
@@ -242,7 +253,8 @@ def stored_traffic(docs, S, H, B, qlen):
                 continue
             if tr.get("kernel_source_sha16") != kernel_source_hash():
                 continue
-            return tr["k_probe_lean8"]["hbm_read_bytes_per_launch_corrected"], f"profiles/{name}@{tr['kernel_source_sha16']}"
+            k = "k_probe_direct" if "k_probe_direct" in tr else "k_probe_lean8"
+            return tr[k]["hbm_read_bytes_per_launch_corrected"], f"profiles/{name}@{tr['kernel_source_sha16']}"
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -521,21 +533,22 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{docs} fingerprints x {H} u32 hashes in {S} FileSegments (512-B blocks), "
+            "config": {"workload": f"{docs} fingerprints x {H} u32 hashes in {S} FileSegments (512-B blocks"
+                                   f"{'; kept direct-addressed in HBM' if dominant_kernel(segs) == 'k_probe_direct' else ''}), "
                                    f"segments sharded over {world} GPU(s); batch of {B} queries x {args.query_len} hashes, "
                                    f"limit {args.limit}, min_score (n+19)/20, score_pct 10; queries resident in HBM",
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
+                       "segment_layout": "direct-addressed" if dominant_kernel(segs) == "k_probe_direct" else "blocks",
                        "index_build_seconds": round(build_s, 2), "shrunk_to_fit": shrunk},
             # achieved / frac: PHYSICAL bytes of the dominant kernel per launch / its HIP-event time / peak.  Filled with the
             # model here and replaced by the in-run PMC figure below when the rocprofv3 child pass succeeds.
-            "roofline": {"bound": "hbm", "kernel": "fpx::k_probe_lean8", "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fpx::" + dominant_kernel(segs), "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": moved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "achieved_basis": "model",
                          "avg_launch_ms": avg_ms, "launches_timed": launches,
                          "moved_model": {**moved, "GBs": moved_gbs, "frac": moved_gbs / HBM_PEAK_GBS,
-                                         "note": "blocks the kernel fetched (counted by the kernel) + the 128-B lines of probe records its probes touch "
-                                                 "(expected value for uniform hashes) + the sorted pairs (8 B per probe; re-read per segment)"},
+                                         "note": model_moved_bytes.__doc__.split("\n", 1)[1].strip().replace("\n    ", " ")},
                          "reference_equivalent": {"bytes_per_launch": ref_bytes, "GBs": ref_gbs, "over_peak": ref_gbs / HBM_PEAK_GBS,
                                                   "note": "SURVEY 8(d)'s algorithmic figure: 512 B for every block the REFERENCE visits.  NOT a roofline "
                                                           "fraction: the presence bitmaps answer the probes of absent hashes without reading their block, "

@@ -7,6 +7,8 @@ variant runs in a process of its own):
 * FPX_LEAN_HEAD=4        the whole-block instantiation of the lean probe kernel instead of the partial fetch
 * FPX_DIRECT_MIN_ITEMS=0 EVERY file segment in its direct-addressed form (by default only segments of >= 2^28 items, which only the
                          full-size tests build): searches, counters, downloads and merges must be what the block form gives
+* FPX_FUSE_MIN=1         with it: every group of direct-addressed segments, even one alone, behind a fused directory
+                         (k_probe_fused; by default groups of 6..16)
 * FPX_DIRECT=0           no segment direct-addressed (run over the full-size tests' neighbours is not needed: the default suites
                          build no segment that large; tests/test_gpu_fullsize.py compares the two forms at full size)
 """
@@ -26,7 +28,8 @@ DIRECT_SUITES = SUITES + ["tests/test_gpu_builder.py", "tests/test_gpu_merge.py"
 
 @pytest.mark.parametrize("env", [{"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
                                  {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"}],
+                                 {"FPX_DIRECT_MIN_ITEMS": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
+                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_parity_suites_on_the_alternative_paths(env):
     if os.environ.get("FPX_VARIANT_CHILD") == "1":

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
             const uint64_t p = base + (uint64_t)j * DK_WG + tid;
             valid[j] = p < a.P;
             const uint64_t key = valid[j] ? gload_u64(a.pairs + p) : 0ull;
-            if (valid[j] && is_duplicate_pair(a.pairs, p, key, a.qb)) valid[j] = false;
+            if (valid[j] && is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip)) valid[j] = false;
             h[j] = (uint32_t)(key >> a.qb);
             q[j] = (uint32_t)key & qmask;
             bw[j] = 0u; ax[j] = make_uint4(0, 0, 0, 0);
@@ -178,18 +178,75 @@ struct FusedArgs {
 };
 
 constexpr int FK_WG = 256;
+constexpr uint32_t FSTAGE_CAP = 2048;      // hit records staged per workgroup: a round of 256 hashes x 16 segments brings ~1500
+constexpr uint32_t FSTAGE_FLUSH = 1024;
+
+// up to three records per lane in ONE reservation (one LDS atomic round trip per segment instead of three); wave-uniform
+// control flow, every lane of the wave active
+__device__ __forceinline__ void fused_emit3(const HitStage& st, const ProbeArgs& a, bool k0, bool k1, bool k2, uint64_t r0, uint64_t r1,
+                                            uint64_t r2, uint32_t lane)
+{
+    const unsigned long long m0 = __ballot((int)k0), m1 = __ballot((int)k1), m2 = __ballot((int)k2);
+    const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), total = c0 + c1 + (uint32_t)__popcll(m2);
+    if (total == 0u) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t o0 = (uint32_t)__popcll(m0 & lt), o1 = c0 + (uint32_t)__popcll(m1 & lt), o2 = c0 + c1 + (uint32_t)__popcll(m2 & lt);
+    uint32_t pos = 0;
+    if (lane == 0) pos = atomicAdd(st.count, total);
+    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+    if (pos + total <= FSTAGE_CAP) {
+        if (k0) st.buf[pos + o0] = r0;
+        if (k1) st.buf[pos + o1] = r1;
+        if (k2) st.buf[pos + o2] = r2;
+    } else {                                   // the stage is full: the wave appends directly
+        if (lane == 0) atomicMin(st.valid, pos);
+        unsigned long long gg = 0;
+        if (lane == 0) gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+        gg = __shfl(gg, 0);
+        if (k0 && gg + o0 < a.hit_cap) a.hits[gg + o0] = r0;
+        if (k1 && gg + o1 < a.hit_cap) a.hits[gg + o1] = r1;
+        if (k2 && gg + o2 < a.hit_cap) a.hits[gg + o2] = r2;
+    }
+}
+
+// whole workgroup: append the staged records to the batch's hit buffer when the stage is half full, or at the end.
+// (Sorting them into the queries' bins right here -- k_bin's tile logic in the flush, which would save that kernel's pass over
+// the records -- was built and measured: this kernel 1.61 -> 1.88 ms, the step no shorter.)
+__device__ __forceinline__ void fused_flush(const HitStage& st, const ProbeArgs& a, bool last, uint32_t tid)
+{
+    __syncthreads();
+    const uint32_t sc = *st.count;
+    if (sc >= FSTAGE_FLUSH || (last && sc > 0u)) {
+        const uint32_t n = min(sc, *st.valid);
+        if (tid == 0) {
+            const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)n);
+            *st.base_lo = (uint32_t)gg; *st.base_hi = (uint32_t)(gg >> 32);
+        }
+        __syncthreads();
+        const unsigned long long gg = ((unsigned long long)*st.base_hi << 32) | *st.base_lo;
+        for (uint32_t i = tid; i < n; i += FK_WG)
+            if (gg + i < a.hit_cap) a.hits[gg + i] = st.buf[i];
+        __syncthreads();
+        if (tid == 0) { *st.count = 0; *st.valid = FSTAGE_CAP; }
+    }
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa)
 {
-    __shared__ uint64_t stage[STAGE_CAP];
+    __shared__ uint64_t stage[FSTAGE_CAP];
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
+    // what the list slots need of their segment (a slot's segment differs from lane to lane)
+    __shared__ const uint32_t* s_extras[FUSE_MAX];
+    __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const FusedDesc* __restrict__ g = fa.groups + blockIdx.y;
+    if (tid < FUSE_MAX) { s_extras[tid] = g->extras[tid]; s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
     if (tid == 0) {
-        stage_count = 0; stage_valid = STAGE_CAP;
+        stage_count = 0; stage_valid = FSTAGE_CAP;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
         s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;        // cancel point (src/FileSegment.zig:144), once per workgroup
     }
@@ -204,87 +261,147 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
         const uint64_t p = wg_base + (uint64_t)round * FK_WG + tid;
         bool valid = p < a.P;
         const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
-        if (valid && is_duplicate_pair(a.pairs, p, key, a.qb)) valid = false;        // dedupSorted, src/Index.zig:489-499
+        if (valid && is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip)) valid = false;        // dedupSorted, src/Index.zig:489-499
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
         const uint32_t bit = h & 31u, below = (1u << bit) - 1u;
-        uint32_t w[32];
+        const uint32_t* line = g->lines + (size_t)(h >> 5) * 32u;
+        // ---- the line: the hash's position bits in the 16 segments, and the segments' rank bases
+        uint32_t w[2 * FUSE_MAX];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) w[i] = 0u;
+        for (uint32_t i = 0; i < 2 * FUSE_MAX; ++i) w[i] = 0u;
         if (valid) {
-            const uint8_t* line = reinterpret_cast<const uint8_t*>(g->lines + (size_t)(h >> 5) * 32u);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const uint4 v = gload_u4(line + 16 * i);
+                const uint4 v = gload_u4(reinterpret_cast<const uint8_t*>(line) + 16 * i);
                 w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
             }
             my_probes += nseg;
             my_reads += 2u;
         }
-        // ---- every segment whose bit is set: the position's word of its `primary`
+        // ---- every segment whose bit is set: the position's word of its `primary`.  d[s]: 0xFFFFFFFF = nothing there
         uint32_t d[FUSE_MAX];
 #pragma unroll
         for (uint32_t s = 0; s < FUSE_MAX; ++s) {
-            d[s] = 0xFFFFFFFFu;
             // (outside [first_hash, last_hash] the reference visits no block, src/FileSegment.zig:164,153; unused columns: empty range)
             const bool in_range = valid && h >= g->first_hash[s] && h <= g->last_hash[s];
-            if (in_range) {
-                if ((w[s] >> bit) & 1u) {
-                    d[s] = gload_u32(g->primary[s] + (w[16 + s] + (uint32_t)__popc(w[s] & below)));
-                    my_reads += 1u;
-                } else {
-                    my_blocks += 1u;                // absent: the reference visits one block, finds nothing and stops
-                }
+            const bool set = in_range && ((w[s] >> bit) & 1u) != 0u;
+            if (in_range && !set) my_blocks += 1u;   // absent: the reference visits one block, finds nothing and stops
+            d[s] = 0xFFFFFFFFu;
+            if (set) { d[s] = gload_u32(g->primary[s] + (w[FUSE_MAX + s] + (uint32_t)__popc(w[s] & below))); my_reads += 1u; }
+        }
+        // ---- what this hash found: the segments with ONE doc are counted, those with several (0.85 per hash on average) are
+        //      gathered into four slots, so that their lists' heads (header + up to three docs) come in one round of loads
+        uint32_t n_single = 0, n_multi = 0, xs = 0;
+        uint32_t xi[4] = {0u, 0u, 0u, 0u};
+        const bool any_dead = g->any_dead != 0u;
+#pragma unroll
+        for (uint32_t s = 0; s < FUSE_MAX; ++s) {
+            const uint32_t v = d[s];
+            if (v == 0xFFFFFFFFu) continue;
+            if (v >> 31) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) xi[j] = n_multi == j ? (v & 0x7FFFFFFFu) : xi[j];
+                if (n_multi < 4u) xs |= s << (4u * n_multi);
+                n_multi += 1u;
+            } else {
+                // (superseded docs are dropped here: the stage holds several segments' records)
+                if (any_dead && g->has_dead[s] && is_dead_seg(fa.segs[g->seg_index[s]], g->min_doc[s] + v)) { d[s] = 0xFFFFFFFFu; my_blocks += 1u; my_docs += 1u; continue; }
+                n_single += 1u;
             }
         }
-        // ---- emission, eight segments at a time: the heads of the lists (hashes with several docs) in one load each
+        uint4 x[4];
 #pragma unroll
-        for (uint32_t half = 0; half < FUSE_MAX; half += 8u) {
-            uint4 x[8];
+        for (uint32_t j = 0; j < 4u; ++j) {
+            x[j] = make_uint4(0, 0, 0, 0);
+            if (j < n_multi) { x[j] = gload_u4_a4(s_extras[(xs >> (4u * j)) & 15u] + xi[j]); my_reads += 1u; }
+        }
+        // ---- one reservation per lane: its single docs + the docs of its lists' heads
+        uint32_t cnt = n_single, keepm = 0;                       // keepm: bits 3j..3j+2 = which of slot j's head docs are kept
+        my_blocks += n_single; my_docs += n_single;
 #pragma unroll
-            for (uint32_t k = 0; k < 8u; ++k) {
-                const uint32_t s = half + k;
-                x[k] = make_uint4(0, 0, 0, 0);
-                if (d[s] != 0xFFFFFFFFu && (d[s] >> 31)) { x[k] = gload_u4_a4(g->extras[s] + (d[s] & 0x7FFFFFFFu)); my_reads += 1u; }
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (j >= n_multi) continue;
+            const uint32_t hdr = x[j].x, eff = hdr & 0xFFFFu, T = (hdr >> 19) & 1u, sj = (xs >> (4u * j)) & 15u;
+            my_blocks += (hdr >> 16) & 7u; my_docs += eff;
+            const uint32_t inl = min(eff, T ? 2u : 3u);
+            uint32_t km = (1u << inl) - 1u;
+            if (any_dead && s_has_dead[sj]) {
+                const SegDesc& f = fa.segs[s_seg_index[sj]];
+                const uint32_t md = s_min_doc[sj];
+                const uint32_t e0 = T ? x[j].z : x[j].y, e1 = T ? x[j].w : x[j].z, e2 = x[j].w;
+                if ((km & 1u) && is_dead_seg(f, md + e0)) km &= ~1u;
+                if ((km & 2u) && is_dead_seg(f, md + e1)) km &= ~2u;
+                if ((km & 4u) && is_dead_seg(f, md + e2)) km &= ~4u;
             }
+            keepm |= km << (3u * j);
+            cnt += (uint32_t)__popc(km);
+        }
+        uint32_t pos = 0;
+        unsigned long long gpos = 0;
+        bool fits = true;
+        if (cnt != 0u) {
+            pos = atomicAdd(hs.count, cnt);
+            fits = pos + cnt <= FSTAGE_CAP;
+            if (!fits) {                             // the stage is full: this lane appends directly
+                atomicMin(hs.valid, pos);
+                gpos = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)cnt);
+            }
+        }
+        uint32_t o = 0;
+        auto put = [&](uint32_t doc) {
+            const uint64_t rec = qpart | doc;
+            if (fits) hs.buf[pos + o] = rec;
+            else if (gpos + o < a.hit_cap) a.hits[gpos + o] = rec;
+            ++o;
+        };
 #pragma unroll
-            for (uint32_t k = 0; k < 8u; ++k) {
-                const uint32_t s = half + k;
-                if (s >= nseg) break;                                              // (uniform)
-                const bool present = d[s] != 0xFFFFFFFFu;
-                const bool multi = present && (d[s] >> 31) != 0u;
-                const uint32_t eff = multi ? (x[k].x & 0xFFFFu) : (present ? 1u : 0u);
-                const uint32_t T = (x[k].x >> 19) & 1u;
-                if (present) { my_blocks += multi ? ((x[k].x >> 16) & 7u) : 1u; my_docs += eff; }
-                const uint32_t md = g->min_doc[s];
-                const SegDesc* filt = g->has_dead[s] ? fa.segs + g->seg_index[s] : nullptr;   // (uniform)
-                const uint32_t d0 = md + (multi ? (T ? x[k].z : x[k].y) : d[s]);
-                const uint32_t d1 = md + (T ? x[k].w : x[k].z), d2 = md + x[k].w;
-                bool k0 = eff >= 1u, k1 = multi && eff >= 2u, k2 = multi && eff >= 3u && T == 0u;
-                if (filt) {                          // superseded docs are dropped here: the stage holds several segments' records
-                    k0 = k0 && !is_dead_seg(*filt, d0); k1 = k1 && !is_dead_seg(*filt, d1); k2 = k2 && !is_dead_seg(*filt, d2);
-                }
-                stage_emit(hs, a, k0, qpart | d0, lane);
-                stage_emit(hs, a, k1, qpart | d1, lane);
-                stage_emit(hs, a, k2, qpart | d2, lane);
-                // longer lists (1 % of them): the wave reads them together, 64 docs at a time
-                unsigned long long ml = __ballot((int)(multi && eff > (T ? 2u : 3u)));
-                while (ml != 0ull) {
-                    const int src = (int)__builtin_ctzll(ml);
-                    ml &= ml - 1ull;
-                    const uint32_t xs = __shfl(d[s] & 0x7FFFFFFFu, src), es = __shfl(eff, src), ts = __shfl(T, src);
-                    const uint32_t qlo = __shfl((uint32_t)(qpart >> 32), src);
-                    for (uint32_t o = ts ? 2u : 3u; o < es; o += 64u) {
-                        bool keep = o + lane < es;
-                        const uint32_t dv = md + (keep ? gload_u32(g->extras[s] + xs + 1u + ts + o + lane) : 0u);
-                        if (filt && keep) keep = !is_dead_seg(*filt, dv);
-                        stage_emit(hs, a, keep, ((uint64_t)qlo << 32) | dv, lane);
+        for (uint32_t s = 0; s < FUSE_MAX; ++s)
+            if (d[s] != 0xFFFFFFFFu && (d[s] >> 31) == 0u) put(g->min_doc[s] + d[s]);
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (j >= n_multi) continue;
+            const uint32_t T = (x[j].x >> 19) & 1u, md = s_min_doc[(xs >> (4u * j)) & 15u], km = (keepm >> (3u * j)) & 7u;
+            if (km & 1u) put(md + (T ? x[j].z : x[j].y));
+            if (km & 2u) put(md + (T ? x[j].w : x[j].z));
+            if (km & 4u) put(md + x[j].w);
+        }
+        // ---- the rare rest, by the whole wave: lists longer than their head, and the lists of a hash with more than four
+        {
+            bool more = n_multi > 4u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j)
+                if (j < n_multi) more = more || (x[j].x & 0xFFFFu) > (((x[j].x >> 19) & 1u) ? 2u : 3u);
+            unsigned long long mo = __ballot((int)more);
+            while (mo != 0ull) {
+                const int src = (int)__builtin_ctzll(mo);
+                mo &= mo - 1ull;
+                const uint32_t qlo = __shfl((uint32_t)(qpart >> 32), src);
+                uint32_t seen = 0;
+#pragma unroll
+                for (uint32_t s = 0; s < FUSE_MAX; ++s) {
+                    const uint32_t v = __shfl(d[s], src);                      // (uniform from here on)
+                    if (v == 0xFFFFFFFFu || (v >> 31) == 0u) continue;
+                    const uint32_t* list = g->extras[s] + (v & 0x7FFFFFFFu);
+                    const uint32_t hdr = gload_u32(list), eff = hdr & 0xFFFFu, T = (hdr >> 19) & 1u;
+                    uint32_t from = T ? 2u : 3u;
+                    if (seen >= 4u) {                                          // a fifth list: nothing of it has been read yet
+                        from = 0u;
+                        if (lane == 0) { my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 1u; }
                     }
-                    if (lane == 0) my_reads += (es + 15u) >> 4;
+                    seen += 1u;
+                    const SegDesc* filt = (any_dead && g->has_dead[s]) ? fa.segs + g->seg_index[s] : nullptr;
+                    for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                        bool keep = o2 + lane < eff;
+                        const uint32_t dv = g->min_doc[s] + (keep ? gload_u32(list + 1u + T + o2 + lane) : 0u);
+                        if (filt && keep) keep = !is_dead_seg(*filt, dv);
+                        fused_emit3(hs, a, keep, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
+                    }
+                    if (lane == 0 && eff > from) my_reads += (eff - from + 15u) >> 4;
                 }
             }
-            stage_flush(hs, a, round + 1u == a.rounds && half + 8u >= FUSE_MAX, tid, FK_WG);
         }
+        fused_flush(hs, a, round + 1u == a.rounds, tid);
     }
 
     if (my_reads) atomicAdd(&wg_reads, (unsigned long long)my_reads);

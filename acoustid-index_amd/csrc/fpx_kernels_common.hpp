@@ -57,17 +57,18 @@ __device__ __forceinline__ bool is_dead_seg(const SegDesc& s, uint32_t d)
 // dedupSorted (src/Index.zig:489-499) therefore looks back over the pairs of the SAME query in the SAME bucket
 // (usually none): a pair is a duplicate iff an equal pair precedes it there.
 constexpr unsigned KEY_SORT_SKIP = 8;
-__device__ __forceinline__ bool is_duplicate_pair(const uint64_t* pairs, uint64_t p, uint64_t key, uint32_t qb)
+constexpr unsigned KEY_SORT_SKIP_DIRECT = 16;      // a snapshot of direct-addressed segments only: coarser order, one radix pass less
+__device__ __forceinline__ bool is_duplicate_pair(const uint64_t* pairs, uint64_t p, uint64_t key, uint32_t qb, uint32_t skip = KEY_SORT_SKIP)
 {
     if (p == 0) return false;
     const uint64_t qmask64 = qb >= 32u ? 0xFFFFFFFFull : ((1ull << qb) - 1ull);
     uint64_t x = gload_u64(pairs + p - 1) ^ key;
     if (x == 0ull) return true;
-    if (((x >> (qb + KEY_SORT_SKIP)) | (x & qmask64)) != 0ull) return false;      // the usual exit: another bucket or query
+    if (((x >> (qb + skip)) | (x & qmask64)) != 0ull) return false;      // the usual exit: another bucket or query
     for (uint64_t i = p - 1; i > 0; --i) {                                         // same (bucket, query): keep looking back
         x = gload_u64(pairs + i - 1) ^ key;
         if (x == 0ull) return true;
-        if (((x >> (qb + KEY_SORT_SKIP)) | (x & qmask64)) != 0ull) return false;
+        if (((x >> (qb + skip)) | (x & qmask64)) != 0ull) return false;
     }
     return false;
 }

@@ -352,6 +352,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
+    // (every kernel of the batch must look back over the same bucket width: the coarser order only where the direct-addressed
+    // kernels, which take it as a parameter, are the only ones that read the pairs)
+    const uint32_t key_skip = (snap->n_file == 0 && snap->n_mem == 0 && snap->n_direct != 0) ? KEY_SORT_SKIP_DIRECT : KEY_SORT_SKIP;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
     static const uint64_t local_sort_max = [] { const char* e = getenv("FPX_LOCAL_SORT_MAX"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
     bool local_sort = P && !score_only && !single_fast && B >= 2u && P <= local_sort_max && snap->n_small == 0;
@@ -368,9 +371,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
         // ... and only the top 32 - KEY_SORT_SKIP of them: block-level locality is all the probes need from the order
         // (a 256-value hash bucket is narrower than a block's hash span), see is_duplicate_pair for the dedup.
-        const size_t tb = sort_u64_temp_bytes(P, qb + KEY_SORT_SKIP, 32 + qb);
+        const size_t tb = sort_u64_temp_bytes(P, qb + key_skip, 32 + qb);
         if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
-        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + KEY_SORT_SKIP, 32 + qb, st, &kcur));
+        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + key_skip, 32 + qb, st, &kcur));
     }
     const uint64_t* d_pairs = ws->d_keys[kcur];
 
@@ -436,6 +439,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[fast ? 1 : 0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;    // (fast: binned into d_hits[0] afterwards)
             a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr; a.cancel = cancel;
+            a.key_skip = key_skip;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;

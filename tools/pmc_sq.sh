@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/pmc_sq.sh <tag> -- SQ counters of the lean probe kernel (two passes of 8), on the headline batch (bench.py --pmc-child)
+# tools/pmc_sq.sh <tag> -- SQ counters of the dominant probe kernel (two passes of 8), on the headline batch (bench.py --pmc-child)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -15,7 +15,7 @@ for pass_ in "ab":
     if not f: print("no output for pass", pass_); continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); last = {}
     for r in csv.DictReader(open(f[0])):
-        if "k_probe_lean8" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("k_probe_lean8", "k_probe_direct", "k_probe_fused")):
             agg[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
     if agg:
         d = max(agg)

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
                 const uint32_t pre = ((w < 4u ? ax[j].y : ax[j].z) >> (8u * (w & 3u))) & 0xFFu;
                 const uint32_t rank = ax[j].x + pre + (uint32_t)__popc(bw[j] & ((1u << bit) - 1u));
                 d[j] = gload_u32(seg.primary + rank);
-                my_reads += 1u;
+                my_reads += 2u;                     // (in 64-byte units: a word of `primary` brings its 128-byte line)
             } else if (valid[j]) {
                 my_blocks += 1u;                    // the reference visits one block, finds nothing and stops
             }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
 #pragma unroll
         for (int j = 0; j < DK_KPL; ++j) {
             x[j] = make_uint4(0, 0, 0, 0);
-            if (present[j] && (d[j] >> 31)) { x[j] = gload_u4_a4(seg.extras + (d[j] & 0x7FFFFFFFu)); my_reads += 1u; }
+            if (present[j] && (d[j] >> 31)) { x[j] = gload_u4_a4(seg.extras + (d[j] & 0x7FFFFFFFu)); my_reads += 2u; }
         }
         // ---- emission (wave-uniform control flow)
 #pragma unroll
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
                     const uint32_t dv = keep ? gload_u32(seg.extras + xs + 1u + ts + o + lane) : 0u;
                     stage_emit(hs, a, keep, ((uint64_t)qs << 32) | (uint64_t)(seg.min_doc_id + dv), lane, dead_filter);
                 }
-                if (lane == 0) my_reads += (es + 15u) >> 4;
+                if (lane == 0) my_reads += ((es + 31u) >> 5) * 2u;
             }
         }
         stage_flush(hs, a, round + 1u == a.rounds, tid, DK_WG, dead_filter);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
             const bool set = in_range && ((w[s] >> bit) & 1u) != 0u;
             if (in_range && !set) my_blocks += 1u;   // absent: the reference visits one block, finds nothing and stops
             d[s] = 0xFFFFFFFFu;
-            if (set) { d[s] = gload_u32(g->primary[s] + (w[FUSE_MAX + s] + (uint32_t)__popc(w[s] & below))); my_reads += 1u; }
+            if (set) { d[s] = gload_u32(g->primary[s] + (w[FUSE_MAX + s] + (uint32_t)__popc(w[s] & below))); my_reads += 2u; }   // (64-byte units)
         }
         // ---- what this hash found: the segments with ONE doc are counted, those with several (0.85 per hash on average) are
         //      gathered into four slots, so that their lists' heads (header + up to three docs) come in one round of loads
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
             x[j] = make_uint4(0, 0, 0, 0);
-            if (j < n_multi) { x[j] = gload_u4_a4(s_extras[(xs >> (4u * j)) & 15u] + xi[j]); my_reads += 1u; }
+            if (j < n_multi) { x[j] = gload_u4_a4(s_extras[(xs >> (4u * j)) & 15u] + xi[j]); my_reads += 2u; }
         }
         // ---- one reservation per lane: its single docs + the docs of its lists' heads
         uint32_t cnt = n_single, keepm = 0;                       // keepm: bits 3j..3j+2 = which of slot j's head docs are kept
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
                     uint32_t from = T ? 2u : 3u;
                     if (seen >= 4u) {                                          // a fifth list: nothing of it has been read yet
                         from = 0u;
-                        if (lane == 0) { my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 1u; }
+                        if (lane == 0) { my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u; }
                     }
                     seen += 1u;
                     const SegDesc* filt = (any_dead && g->has_dead[s]) ? fa.segs + g->seg_index[s] : nullptr;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
                         if (filt && keep) keep = !is_dead_seg(*filt, dv);
                         fused_emit3(hs, a, keep, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
                     }
-                    if (lane == 0 && eff > from) my_reads += (eff - from + 15u) >> 4;
+                    if (lane == 0 && eff > from) my_reads += ((eff - from + 31u) >> 5) * 2u;
                 }
             }
         }

@@ -424,7 +424,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         h_bin.bin_count = d_bin_count;
         FPX_HIP(hipMemsetAsync(d_bin_count, 0, ((size_t)MAX_BINS * BIN_STRIDE + B) * sizeof(uint32_t), st));
     }
-    bool force_generic = false, used_lean = false, spread = false;
+    bool force_generic = false, used_lean = false, spread = false, used_fused = false;
     for (int attempt = 0;; ++attempt) {
         used_lean = false; spread = false;
         if (!single_fast) FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));   // (k_make_keys did it)
@@ -450,27 +450,33 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (attempt > 0 && (snap->n_lean || snap->n_direct))
                 FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (first attempt: k_make_keys)
             if (snap->n_direct) {
-                // direct-addressed segments: their kernels serve every batch size (fpx_direct.hpp)
-                const uint64_t wgs_solo = (P + DK_WG * DK_KPL - 1) / (DK_WG * DK_KPL) * snap->n_solo;
-                const uint64_t wgs_fused = (P + FK_WG - 1) / FK_WG * snap->n_fused;
+                // direct-addressed segments: their kernels serve every batch size (fpx_direct.hpp).  Groups with a fused
+                // directory are probed through it from ~32 queries on (one thread per hash, each walking 16 segments); below
+                // that -- a single /_search: 1000 threads -- one thread per hash and segment is quicker (0.076 against 0.093 ms)
+                static const uint64_t fuse_min_probes = [] { const char* e = getenv("FPX_FUSE_MIN_PROBES"); return e ? strtoull(e, nullptr, 0) : (1ull << 15); }();
+                const bool use_fused = snap->n_fused != 0 && P >= fuse_min_probes;
+                const uint32_t n_solo = use_fused ? snap->n_solo : snap->n_direct;
+                const SegDesc* d_solo = use_fused ? snap->d_solo : snap->d_direct;
+                const uint64_t wgs_solo = (P + DK_WG * DK_KPL - 1) / (DK_WG * DK_KPL) * n_solo;
+                const uint64_t wgs_fused = use_fused ? (P + FK_WG - 1) / FK_WG * snap->n_fused : 0;
                 // statistics: spread over 64 lines when thousands of workgroups end with them (see LEAN_STAT_SETS)
                 spread = !single_fast && wgs_solo + wgs_fused >= 1024;
                 unsigned long long* stat_sets = spread ? reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off) : nullptr;
-                if (snap->n_fused) {
-                    // groups of segments behind one fused directory: one thread per hash
+                if (use_fused) {
                     ProbeArgs fk = a;
                     fk.segs = snap->d_direct; fk.lean_stats = stat_sets;
                     fk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_fused / 8192));
                     const FusedArgs fargs{snap->d_fused, snap->d_direct};
                     const uint64_t per_wg_fk = (uint64_t)FK_WG * fk.rounds;
                     hipLaunchKernelGGL(k_probe_fused, dim3((uint32_t)((P + per_wg_fk - 1) / per_wg_fk), snap->n_fused), dim3(FK_WG), 0, st, fk, fargs);
+                    used_fused = true;
                 }
-                if (snap->n_solo) {
+                if (n_solo) {
                     ProbeArgs dk = a;
-                    dk.segs = snap->d_solo; dk.lean_stats = stat_sets;
+                    dk.segs = d_solo; dk.lean_stats = stat_sets;
                     dk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_solo / 8192));
                     const uint64_t per_wg_dk = (uint64_t)DK_WG * DK_KPL * dk.rounds;
-                    hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), snap->n_solo), dim3(DK_WG), 0, st, dk);
+                    hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), n_solo), dim3(DK_WG), 0, st, dk);
                 }
             }
             if (lean) {
@@ -722,7 +728,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probe_kernel_bytes += ln ? blocks * 512ull : ws->h_counters[CTR_BYTES];
             stats->probe_kernel_fetched_bytes += ln ? reads * 128ull : ws->h_counters[CTR_BYTES];
             stats->probe_aux_ms += aux;
-            stats->path_flags |= 1u | (Cf ? 2u : 0u);
+            stats->path_flags |= 1u | (Cf ? 2u : 0u) | (used_fused ? 4u : 0u);
         }
         ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);
         ws->hint_def = 0;
@@ -804,6 +810,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         stats->probe_kernel_bytes += c_main_bytes;
         stats->probe_kernel_fetched_bytes += c_fetched_bytes;
         stats->probe_aux_ms += aux_ms;
+        if (used_fused) stats->path_flags |= 4u;
     };
 
     if (probe_only) {

@@ -103,21 +103,28 @@ class StatAgg:
         self.v = {k: 0.0 for k in self.FIELDS}
         self.lock = threading.Lock()
         self.steps = 0
+        self.path_flags = 0
 
     def add(self, st):
         with self.lock:
             for k in self.FIELDS:
                 self.v[k] += getattr(st, k)
+            self.path_flags |= st.path_flags
             self.steps += 1
 
+    @property
+    def fused(self):
+        return bool(self.path_flags & 4)
 
-def model_moved_bytes(segs, fetched_per_launch, probes_per_launch):
+
+def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
     """What the dominant kernel has to pull from HBM per launch, modelled from counts the kernel reports.
     Block-form segments (k_probe_lean8): the blocks it fetched (counted) + the 128-B lines of the probe records (presence
     bits + block range + block records, 64 B per 256 hash buckets) its probes touch (expected value for uniform hashes) +
-    the sorted pairs (8 B per probe).
-    Direct-addressed segments (k_probe_direct): the 64-B sectors of `primary` / `extras` it read (counted: one per present
-    hash, one more per hash with several docs) + the 64-B records its probes touch (expected value) + the pairs."""
+    the sorted pairs (8 B per probe and segment).
+    Direct-addressed segments: the lines of `primary` / `extras` it read (counted: one per present hash, one more per hash
+    with several docs; a 4-byte word brings its 128-byte line) + for k_probe_direct the 128-B lines of 64-B records its probes
+    touch (expected value) and the pairs per segment, for k_probe_fused ONE directory line and one pair per hash (both counted)."""
     files = [sg for sg in segs if sg.kind == "file"]
     if not files:
         return {"blocks": fetched_per_launch, "probe_records": 0.0, "pairs": 0.0, "total": fetched_per_launch}
@@ -125,16 +132,19 @@ def model_moved_bytes(segs, fetched_per_launch, probes_per_launch):
     pr = 0.0
     for sg in files:
         if getattr(sg, "direct", False):
-            pr += touched_bytes(float((1 << 24) * 64), per_seg, line=64)
+            if not fused:
+                pr += touched_bytes(float((1 << 24) * 64), per_seg)
         elif sg.getSize() >= (1 << 20):
             pr += touched_bytes(float(probe_record_bytes(sg.getSize())), per_seg)
-    pairs = 8.0 * probes_per_launch
+    pairs = 8.0 * (per_seg if fused else probes_per_launch)
     return {"blocks": fetched_per_launch, "probe_records": pr, "pairs": pairs, "total": fetched_per_launch + pr + pairs}
 
 
-def dominant_kernel(segs):
+def dominant_kernel(segs, fused=False):
     files = [sg for sg in segs if sg.kind == "file"]
-    return "k_probe_direct" if files and all(getattr(sg, "direct", False) for sg in files) else "k_probe_lean8"
+    if files and all(getattr(sg, "direct", False) for sg in files):
+        return "k_probe_fused" if fused else "k_probe_direct"
+    return "k_probe_lean8"
 
 
 def timed_resident(fpx, reader, qb, steps, warmup, out=None, out_n=None):
@@ -154,7 +164,7 @@ def row_from(B, steps, dt, agg, segs, kernel_hint=None):
     avg_ms = agg.v["probe_kernel_ms"] / launches
     fetched = agg.v["probe_kernel_fetched_bytes"] / launches
     probes = agg.v["probes"] / max(1, agg.steps)
-    moved = model_moved_bytes(segs, fetched, probes)
+    moved = model_moved_bytes(segs, fetched, probes, agg.fused)
     r = {"batch": B, "steps": steps, "ms_per_step": dt / steps * 1e3, "queries_per_s": B * steps / dt,
          "probe_kernel_ms": avg_ms if avg_ms > 0 else None,
          "probe_kernel_fetched_block_bytes": fetched,
@@ -214,9 +224,9 @@ def run_pmc_child(args, docs, timeout_s=420):
         if p.returncode != 0:
             return None, f"rocprofv3 child exited {p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
         by = parse_pmc_dir(d)
-        main = "k_probe_direct" if by and by.get("k_probe_direct") else "k_probe_lean8"
+        main = next((k for k in ("k_probe_fused", "k_probe_direct") if by and by.get(k)), "k_probe_lean8")
         if not by or not by.get(main):
-            return None, "no k_probe_direct / k_probe_lean8 dispatch in the counter output"
+            return None, "no k_probe_fused / k_probe_direct / k_probe_lean8 dispatch in the counter output"
         child = None
         for line in p.stdout.decode(errors="replace").splitlines():
             if line.startswith('{"pmc_child"'):
@@ -253,7 +263,7 @@ def stored_traffic(docs, S, H, B, qlen):
                 continue
             if tr.get("kernel_source_sha16") != kernel_source_hash():
                 continue
-            k = "k_probe_direct" if "k_probe_direct" in tr else "k_probe_lean8"
+            k = next((k for k in ("k_probe_fused", "k_probe_direct") if k in tr), "k_probe_lean8")
             return tr[k]["hbm_read_bytes_per_launch_corrected"], f"profiles/{name}@{tr['kernel_source_sha16']}"
         except (OSError, KeyError, ValueError):
             continue
@@ -525,7 +535,7 @@ def main():
         ref_bytes = agg.v["probe_kernel_bytes"] / launches        # 512 B per block the REFERENCE visits
         fetched = agg.v["probe_kernel_fetched_bytes"] / launches  # blocks the kernel really read
         probes = agg.v["probes"] / max(1, agg.steps)
-        moved = model_moved_bytes(segs, fetched, probes)
+        moved = model_moved_bytes(segs, fetched, probes, agg.fused)
         moved_gbs = moved["total"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ref_gbs = ref_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         result = {
@@ -534,16 +544,16 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{docs} fingerprints x {H} u32 hashes in {S} FileSegments (512-B blocks"
-                                   f"{'; kept direct-addressed in HBM' if dominant_kernel(segs) == 'k_probe_direct' else ''}), "
+                                   f"{'; kept direct-addressed in HBM' if dominant_kernel(segs) != 'k_probe_lean8' else ''}), "
                                    f"segments sharded over {world} GPU(s); batch of {B} queries x {args.query_len} hashes, "
                                    f"limit {args.limit}, min_score (n+19)/20, score_pct 10; queries resident in HBM",
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
-                       "segment_layout": "direct-addressed" if dominant_kernel(segs) == "k_probe_direct" else "blocks",
+                       "segment_layout": ("direct-addressed" + (", fused directory" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",
                        "index_build_seconds": round(build_s, 2), "shrunk_to_fit": shrunk},
             # achieved / frac: PHYSICAL bytes of the dominant kernel per launch / its HIP-event time / peak.  Filled with the
             # model here and replaced by the in-run PMC figure below when the rocprofv3 child pass succeeds.
-            "roofline": {"bound": "hbm", "kernel": "fpx::" + dominant_kernel(segs), "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fpx::" + dominant_kernel(segs, agg.fused), "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": moved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "achieved_basis": "model",
                          "avg_launch_ms": avg_ms, "launches_timed": launches,

@@ -24,6 +24,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUITES = ["tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded_abi.py"]
 DIRECT_SUITES = SUITES + ["tests/test_gpu_builder.py", "tests/test_gpu_merge.py", "tests/test_gpu_api.py", "tests/test_gpu_frontend.py",
                           "tests/test_gpu_hashsplit.py", "tests/test_gpu_sharded.py"]
+# (a fused directory is 17 GB whatever the segments' size, built for every snapshot: these variants run the suites with the
+# fewest snapshots)
+FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_api.py",
+                "tests/test_gpu_fuzz.py::test_fuzz_lean_sized_worlds"]
 
 
 @pytest.mark.parametrize("env", [{"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
@@ -35,7 +39,7 @@ def test_parity_suites_on_the_alternative_paths(env):
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         pytest.skip("already inside a variant run")
     e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
-    suites = DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
+    suites = FUSED_SUITES if "FPX_FUSE_MIN" in env else DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

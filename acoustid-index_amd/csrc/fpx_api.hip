@@ -488,7 +488,6 @@ static void snapshot_free(Snapshot* sn)
     if (sn->d_gen) (void)hipFree(sn->d_gen);
     if (sn->d_small) (void)hipFree(sn->d_small);
     if (sn->d_direct) (void)hipFree(sn->d_direct);
-    if (sn->d_fused) (void)hipFree(sn->d_fused);
     if (sn->d_solo) (void)hipFree(sn->d_solo);
     sn->fused.clear();
     if (sn->d_mem) (void)hipFree(sn->d_mem);
@@ -595,7 +594,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         // for it to pay (FPX_FUSE_MIN, default 6: it costs 17 GB whatever the group's size) and whatever does not fit
         // in memory are probed segment by segment
         static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 6u; }();
-        std::vector<FusedDesc> h_fused;
+        std::vector<FusedDesc>& h_fused = sn->h_fused;
         std::vector<SegDesc> h_solo;
         for (uint32_t i0 = 0; e == hipSuccess && i0 < sn->n_direct; i0 += FUSE_MAX) {
             const uint32_t k = std::min<uint32_t>(FUSE_MAX, sn->n_direct - i0);
@@ -616,10 +615,6 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             sn->fused.push_back(fd);
         }
         sn->n_fused = (uint32_t)h_fused.size(); sn->n_solo = (uint32_t)h_solo.size();
-        if (e == hipSuccess && sn->n_fused) {
-            e = hipMalloc(&sn->d_fused, h_fused.size() * sizeof(FusedDesc));
-            if (e == hipSuccess) e = hipMemcpy(sn->d_fused, h_fused.data(), h_fused.size() * sizeof(FusedDesc), hipMemcpyHostToDevice);
-        }
         if (e == hipSuccess && sn->n_solo) {
             e = hipMalloc(&sn->d_solo, h_solo.size() * sizeof(SegDesc));
             if (e == hipSuccess) e = hipMemcpy(sn->d_solo, h_solo.data(), h_solo.size() * sizeof(SegDesc), hipMemcpyHostToDevice);

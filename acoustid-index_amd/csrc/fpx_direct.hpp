@@ -172,8 +172,11 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
 // One thread per HASH now (not per hash and segment) reads that line, and for every segment whose bit is set one word of
 // that segment's `primary`: 8.2 M + 41 M lines per batch of 8192 x 1000 instead of 84 M + 41 M.
 // ------------------------------------------------------------------------------------------------
+// (The group's descriptor travels BY VALUE, in the kernel argument segment: fields read through a pointer into global memory
+// come as vector loads -- the kernel also writes global memory, so the compiler will not use the scalar path for them -- and
+// the first version spent 60 of its 100 vector memory instructions per wave and round on its own descriptor.)
 struct FusedArgs {
-    const FusedDesc* groups;               // (fpx_internal.h)
+    FusedDesc g;                           // (fpx_internal.h)
     const SegDesc* segs;                   // Snapshot::d_direct
 };
 
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
     __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const FusedDesc* __restrict__ g = fa.groups + blockIdx.y;
+    const FusedDesc* g = &fa.g;
     if (tid < FUSE_MAX) { s_extras[tid] = g->extras[tid]; s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;

@@ -181,7 +181,7 @@ struct Snapshot {
     SegDesc* d_direct = nullptr; uint32_t n_direct = 0;
     // ... of which groups of FPX_FUSE_MIN..16 are probed through a fused directory and the rest (n_solo) one by one
     std::vector<std::shared_ptr<FusedDir>> fused;
-    FusedDesc* d_fused = nullptr; uint32_t n_fused = 0;
+    std::vector<FusedDesc> h_fused; uint32_t n_fused = 0;        // (passed to k_probe_fused by value)
     SegDesc* d_solo = nullptr; uint32_t n_solo = 0;
     uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;

@@ -466,9 +466,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     ProbeArgs fk = a;
                     fk.segs = snap->d_direct; fk.lean_stats = stat_sets;
                     fk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_fused / 8192));
-                    const FusedArgs fargs{snap->d_fused, snap->d_direct};
                     const uint64_t per_wg_fk = (uint64_t)FK_WG * fk.rounds;
-                    hipLaunchKernelGGL(k_probe_fused, dim3((uint32_t)((P + per_wg_fk - 1) / per_wg_fk), snap->n_fused), dim3(FK_WG), 0, st, fk, fargs);
+                    for (const FusedDesc& gd : snap->h_fused) {              // one launch per group: its descriptor is a kernel argument
+                        const FusedArgs fargs{gd, snap->d_direct};
+                        hipLaunchKernelGGL(k_probe_fused, dim3((uint32_t)((P + per_wg_fk - 1) / per_wg_fk)), dim3(FK_WG), 0, st, fk, fargs);
+                    }
                     used_fused = true;
                 }
                 if (n_solo) {

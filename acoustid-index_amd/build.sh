@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")/csrc"
 OUT=../libfpx.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result ${FPX_EXTRA_FLAGS:-}"      # (FPX_EXTRA_FLAGS: A/B builds, e.g. -DFPX_FK_WG=512)
 mkdir -p ../build
 pids=()
 for f in fpx_sort fpx_search fpx_api fpx_build fpx_sharded; do

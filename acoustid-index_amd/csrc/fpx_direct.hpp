@@ -180,9 +180,12 @@ struct FusedArgs {
     const SegDesc* segs;                   // Snapshot::d_direct
 };
 
-constexpr int FK_WG = 256;
-constexpr uint32_t FSTAGE_CAP = 2048;      // hit records staged per workgroup: a round of 256 hashes x 16 segments brings ~1500
-constexpr uint32_t FSTAGE_FLUSH = 1024;
+#ifndef FPX_FK_WG
+#define FPX_FK_WG 256
+#endif
+constexpr int FK_WG = FPX_FK_WG;
+constexpr uint32_t FSTAGE_CAP = 8u * FK_WG;      // hit records staged per workgroup: a round of 256 hashes x 16 segments brings ~1500
+constexpr uint32_t FSTAGE_FLUSH = FSTAGE_CAP / 2u;
 
 // up to three records per lane in ONE reservation (one LDS atomic round trip per segment instead of three); wave-uniform
 // control flow, every lane of the wave active

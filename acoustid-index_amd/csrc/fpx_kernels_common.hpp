@@ -57,7 +57,8 @@ __device__ __forceinline__ bool is_dead_seg(const SegDesc& s, uint32_t d)
 // dedupSorted (src/Index.zig:489-499) therefore looks back over the pairs of the SAME query in the SAME bucket
 // (usually none): a pair is a duplicate iff an equal pair precedes it there.
 constexpr unsigned KEY_SORT_SKIP = 8;
-constexpr unsigned KEY_SORT_SKIP_DIRECT = 16;      // a snapshot of direct-addressed segments only: coarser order, one radix pass less
+constexpr unsigned KEY_SORT_SKIP_DIRECT = 24;      // a snapshot of direct-addressed segments only: ONE radix pass -- the top 8 hash bits keep a
+                                                   // workgroup's reads within a few pages of each table; finer order bought the probe kernel 2 % and cost the sort 60 us
 __device__ __forceinline__ bool is_duplicate_pair(const uint64_t* pairs, uint64_t p, uint64_t key, uint32_t qb, uint32_t skip = KEY_SORT_SKIP)
 {
     if (p == 0) return false;

@@ -354,7 +354,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     int kcur = 0;
     // (every kernel of the batch must look back over the same bucket width: the coarser order only where the direct-addressed
     // kernels, which take it as a parameter, are the only ones that read the pairs)
-    const uint32_t key_skip = (snap->n_file == 0 && snap->n_mem == 0 && snap->n_direct != 0) ? KEY_SORT_SKIP_DIRECT : KEY_SORT_SKIP;
+    static const uint32_t key_skip_direct = [] { const char* e = getenv("FPX_KEY_SKIP_DIRECT"); return e ? (uint32_t)atoi(e) : KEY_SORT_SKIP_DIRECT; }();
+    const uint32_t key_skip = (snap->n_file == 0 && snap->n_mem == 0 && snap->n_direct != 0) ? key_skip_direct : KEY_SORT_SKIP;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
     static const uint64_t local_sort_max = [] { const char* e = getenv("FPX_LOCAL_SORT_MAX"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
     bool local_sort = P && !score_only && !single_fast && B >= 2u && P <= local_sort_max && snap->n_small == 0;
@@ -465,7 +466,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 if (use_fused) {
                     ProbeArgs fk = a;
                     fk.segs = snap->d_direct; fk.lean_stats = stat_sets;
-                    fk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_fused / 8192));
+                    static const uint32_t fused_rounds = [] { const char* e = getenv("FPX_FUSED_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
+                    fk.rounds = fused_rounds ? fused_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_fused / 8192));
                     const uint64_t per_wg_fk = (uint64_t)FK_WG * fk.rounds;
                     for (const FusedDesc& gd : snap->h_fused) {              // one launch per group: its descriptor is a kernel argument
                         const FusedArgs fargs{gd, snap->d_direct};

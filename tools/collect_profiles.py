@@ -30,8 +30,8 @@ if "hbm_read_bytes_per_launch" in pmc:
                "config": {k: bench["config"][k] for k in ("docs", "segments", "hashes_per_doc", "batch", "query_len")},
                "kernel_source_sha16": bench["kernel_source_sha16"],
                "calibration": pmc["calibration"], "correction": pmc["correction"],
-               "k_probe_lean8": {"FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE_KB_per_launch"],
-                                 "hbm_read_bytes_per_launch_corrected": pmc["hbm_read_bytes_per_launch"]}},
+               pmc.get("kernel", "k_probe_lean8"): {"FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE_KB_per_launch"],
+                                                    "hbm_read_bytes_per_launch_corrected": pmc["hbm_read_bytes_per_launch"]}},
               open(os.path.join(dst, "r02_traffic.json"), "w"), indent=1)
     assert bench["kernel_source_sha16"] == bench_mod.kernel_source_hash(), "the profile was taken on other kernel sources than the tree holds"
 print("profiles/ updated from", src)

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
             const uint64_t p = base + (uint64_t)j * DK_WG + tid;
             valid[j] = p < a.P;
             const uint64_t key = valid[j] ? gload_u64(a.pairs + p) : 0ull;
-            if (valid[j] && is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip)) valid[j] = false;
+            if (valid[j] && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip))) valid[j] = false;
             h[j] = (uint32_t)(key >> a.qb);
             q[j] = (uint32_t)key & qmask;
             bw[j] = 0u; ax[j] = make_uint4(0, 0, 0, 0);
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
         const uint64_t p = wg_base + (uint64_t)round * FK_WG + tid;
         bool valid = p < a.P;
         const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
-        if (valid && is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip)) valid = false;        // dedupSorted, src/Index.zig:489-499
+        // dedupSorted, src/Index.zig:489-499: flagged by k_make_keys_dedup, or found by looking back
+        if (valid && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip))) valid = false;
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
         const uint32_t bit = h & 31u, below = (1u << bit) - 1u;

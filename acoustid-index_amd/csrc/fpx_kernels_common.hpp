@@ -57,8 +57,10 @@ __device__ __forceinline__ bool is_dead_seg(const SegDesc& s, uint32_t d)
 // dedupSorted (src/Index.zig:489-499) therefore looks back over the pairs of the SAME query in the SAME bucket
 // (usually none): a pair is a duplicate iff an equal pair precedes it there.
 constexpr unsigned KEY_SORT_SKIP = 8;
-constexpr unsigned KEY_SORT_SKIP_DIRECT = 24;      // a snapshot of direct-addressed segments only: ONE radix pass -- the top 8 hash bits keep a
-                                                   // workgroup's reads within a few pages of each table; finer order bought the probe kernel 2 % and cost the sort 60 us
+constexpr unsigned KEY_SORT_SKIP_DIRECT = 24;      // a snapshot of direct-addressed segments only, duplicates flagged by k_make_keys_dedup: ONE
+                                                   // radix pass -- the top 8 hash bits keep a workgroup's reads within a few pages of each table;
+                                                   // finer order bought the probe kernel 2 % and cost the sort 60 us
+constexpr uint32_t KEY_SKIP_FLAGGED = 0x80000000u; // ProbeArgs::key_skip: the keys carry KEY_DUP_FLAG, no look-back
 __device__ __forceinline__ bool is_duplicate_pair(const uint64_t* pairs, uint64_t p, uint64_t key, uint32_t qb, uint32_t skip = KEY_SORT_SKIP)
 {
     if (p == 0) return false;
@@ -110,6 +112,45 @@ __global__ void k_make_keys(const uint32_t* __restrict__ hashes_base, const uint
     uint64_t lo = offsets[q], hi = offsets[q + 1];
     for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
         keys[i - base] = ((uint64_t)hashes_base[i] << qb) | q;
+}
+
+// Snapshots of direct-addressed segments only: dedupSorted (src/Index.zig:489-499) happens HERE, in a hash set of the query's
+// hashes in LDS -- the second and later occurrences of a hash get bit 63 of their key set (the sort never looks at it, the
+// direct-addressed kernels drop flagged keys) -- so the batch-wide order only has to serve locality and the look-back of
+// is_duplicate_pair, whose cost grows with the bucket width, is not needed.  Queries of up to DEDUP_MAX hashes.
+constexpr uint32_t DEDUP_MAX = 2048, DEDUP_SLOTS = 4096;
+constexpr uint64_t KEY_DUP_FLAG = 1ull << 63;
+__global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
+                                                         uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,
+                                                         unsigned long long* zero_counters, unsigned int* zero_u32, uint32_t zero_n)
+{
+    __shared__ uint32_t tab[DEDUP_SLOTS];
+    __shared__ uint32_t seen_ones;                  // the hash 0xFFFFFFFF (the table's empty mark) is kept apart
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= B) return;
+    if (zero_counters && q == 0 && tid < CTR_COUNT) zero_counters[tid] = 0ull;
+    if (zero_u32 && q == 0)
+        for (uint32_t i = tid; i < zero_n; i += 256u) zero_u32[i] = 0u;
+    for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
+    if (tid == 0) seen_ones = 0u;
+    __syncthreads();
+    const uint64_t lo = offsets[q], hi = offsets[q + 1];
+    for (uint64_t i = lo + tid; i < hi; i += 256u) {
+        const uint32_t h = hashes_base[i];
+        bool dup;
+        if (h == 0xFFFFFFFFu) {
+            dup = atomicExch(&seen_ones, 1u) != 0u;
+        } else {
+            uint32_t slot = (h * 0x9E3779B1u) >> 20;                 // 12 bits
+            for (;;) {
+                const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, h);
+                if (old == 0xFFFFFFFFu) { dup = false; break; }
+                if (old == h) { dup = true; break; }
+                slot = (slot + 1u) & (DEDUP_SLOTS - 1u);
+            }
+        }
+        keys[i - base] = (((uint64_t)h << qb) | q) | (dup ? KEY_DUP_FLAG : 0ull);
+    }
 }
 
 // Small batches: the keys of every query sorted INSIDE the query (one workgroup, bitonic network in LDS), written in

@@ -354,11 +354,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     int kcur = 0;
     // (every kernel of the batch must look back over the same bucket width: the coarser order only where the direct-addressed
     // kernels, which take it as a parameter, are the only ones that read the pairs)
-    static const uint32_t key_skip_direct = [] { const char* e = getenv("FPX_KEY_SKIP_DIRECT"); return e ? (uint32_t)atoi(e) : KEY_SORT_SKIP_DIRECT; }();
-    const uint32_t key_skip = (snap->n_file == 0 && snap->n_mem == 0 && snap->n_direct != 0) ? key_skip_direct : KEY_SORT_SKIP;
+    // Snapshots of direct-addressed segments only (their kernels are the only readers of the pairs): duplicates are flagged
+    // when the keys are made (k_make_keys_dedup, queries of up to DEDUP_MAX hashes) and the sort takes one pass
+    bool flagged = snap->n_file == 0 && snap->n_mem == 0 && snap->n_direct != 0 && !score_only;
+    for (uint32_t q = 0; q < B && flagged; ++q) flagged = offsets[q + 1] - offsets[q] <= DEDUP_MAX;
+    const uint32_t key_skip = flagged ? KEY_SORT_SKIP_DIRECT : KEY_SORT_SKIP;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
     static const uint64_t local_sort_max = [] { const char* e = getenv("FPX_LOCAL_SORT_MAX"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
-    bool local_sort = P && !score_only && !single_fast && B >= 2u && P <= local_sort_max && snap->n_small == 0;
+    bool local_sort = P && !score_only && !single_fast && !flagged && B >= 2u && P <= local_sort_max && snap->n_small == 0;
     if (local_sort)
         for (uint32_t q = 0; q < B && local_sort; ++q) local_sort = offsets[q + 1] - offsets[q] <= QSORT_MAX;
     if (local_sort) {
@@ -366,15 +369,23 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                            (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
         FPX_HIP(hipGetLastError());
     } else if (P && !score_only) {
-        hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
-                           single_fast ? ws->d_counters : nullptr, (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
+        if (flagged)
+            hipLaunchKernelGGL(k_make_keys_dedup, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
+                               single_fast ? ws->d_counters : nullptr, ws->d_def_count, (uint32_t)def_words);
+        else
+            hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
+                               single_fast ? ws->d_counters : nullptr, (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
         // k_make_keys writes the pairs in (q, position) order and the LSD radix sort is stable, so sorting on the 32 hash
         // bits alone leaves the pairs ordered by (hash, q): equal pairs end up adjacent without sorting the q bits.
         // ... and only the top 32 - KEY_SORT_SKIP of them: block-level locality is all the probes need from the order
         // (a 256-value hash bucket is narrower than a block's hash span), see is_duplicate_pair for the dedup.
-        const size_t tb = sort_u64_temp_bytes(P, qb + key_skip, 32 + qb);
-        if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
-        FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + key_skip, 32 + qb, st, &kcur));
+        // (flagged keys of a small batch are not sorted at all: the order only serves locality, which batches of up to 2^20
+        // pairs -- every probe on lines of its own -- do not have)
+        if (!(flagged && P <= local_sort_max)) {
+            const size_t tb = sort_u64_temp_bytes(P, qb + key_skip, 32 + qb);
+            if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + key_skip, 32 + qb, st, &kcur));
+        }
     }
     const uint64_t* d_pairs = ws->d_keys[kcur];
 
@@ -440,7 +451,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.bsp = ((snap->max_block_size + 15u) & ~15u) + 32u;
             a.hits = ws->d_hits[fast ? 1 : 0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;    // (fast: binned into d_hits[0] afterwards)
             a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr; a.cancel = cancel;
-            a.key_skip = key_skip;
+            a.key_skip = flagged ? KEY_SKIP_FLAGGED : key_skip;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
             if (wg_blocks) { atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks); atomicAdd(&a.counters[CTR_BYTES], wg_blocks * 512ull); }
             if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
             if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
+            if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);       // (64-byte units here)
         }
     }
 }
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
             if (wg_blocks) { atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks); atomicAdd(&a.counters[CTR_BYTES], wg_blocks * 512ull); }
             if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
             if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
+            if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);       // (64-byte units here)
         }
     }
 }

@@ -741,7 +741,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probe_launches += probe_launches;
             stats->generic_iters += (uint32_t)ws->h_counters[CTR_GENERIC];
             stats->probe_kernel_bytes += ln ? blocks * 512ull : ws->h_counters[CTR_BYTES];
-            stats->probe_kernel_fetched_bytes += ln ? reads * 128ull : ws->h_counters[CTR_BYTES];
+            stats->probe_kernel_fetched_bytes += ln ? reads * 128ull : snap->n_direct ? ws->h_counters[CTR_LEAN_READS] * 64ull + (snap->n_file ? ws->h_counters[CTR_BYTES] : 0ull)
+                                                                     : ws->h_counters[CTR_BYTES];
             stats->probe_aux_ms += aux;
             stats->path_flags |= 1u | (Cf ? 2u : 0u) | (used_fused ? 4u : 0u);
         }
@@ -786,7 +787,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probe_launches += probe_launches;
             stats->generic_iters += (uint32_t)ws->h_counters[CTR_GENERIC];
             stats->probe_kernel_bytes += ws->h_counters[CTR_BYTES];
-            stats->probe_kernel_fetched_bytes += ws->h_counters[CTR_BYTES];
+            stats->probe_kernel_fetched_bytes += snap->n_direct ? ws->h_counters[CTR_LEAN_READS] * 64ull + (snap->n_file ? ws->h_counters[CTR_BYTES] : 0ull)
+                                                                : ws->h_counters[CTR_BYTES];
         }
         return FPX_OK;
     }
@@ -803,7 +805,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                              c_probes = ws->h_counters[CTR_PROBES] + ws->h_counters[8 + CTR_PROBES],
                              c_generic = ws->h_counters[CTR_GENERIC],
                              c_main_bytes = spread ? ws->h_counters[8 + CTR_BYTES] : ws->h_counters[CTR_BYTES],
-                             c_fetched_bytes = spread ? ws->h_counters[CTR_LEAN_READS] * 128ull : ws->h_counters[CTR_BYTES];   // (lines)
+                             c_fetched_bytes = spread ? ws->h_counters[CTR_LEAN_READS] * 128ull            // (lines)
+                                               : snap->n_direct ? ws->h_counters[CTR_LEAN_READS] * 64ull + (snap->n_file ? ws->h_counters[CTR_BYTES] : 0ull)   // (k_probe_direct / _fused without the spread statistics: 64-byte units)
+                                               : ws->h_counters[CTR_BYTES];
 
     uint64_t C = 0, C_slots = 0;                   // candidates in the shared list / in the queries' own slots
     uint64_t* d_qcand = nullptr;

@@ -591,9 +591,9 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         e = hipMalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_direct, sn->h_direct.data(), sn->n_direct * sizeof(SegDesc), hipMemcpyHostToDevice);
         // groups of direct-addressed segments (in snapshot order, 16 to a group) get a fused directory; groups too small
-        // for it to pay (FPX_FUSE_MIN, default 3: it costs 17 GB whatever the group's size; two segments gain 8 %) and whatever does not fit
+        // for it to pay (FPX_FUSE_MIN, default 2: it costs 17 GB whatever the group's size; two segments: probe kernel -20 %) and whatever does not fit
         // in memory are probed segment by segment
-        static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 3u; }();
+        static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
         std::vector<FusedDesc>& h_fused = sn->h_fused;
         std::vector<SegDesc> h_solo;
         for (uint32_t i0 = 0; e == hipSuccess && i0 < sn->n_direct; i0 += FUSE_MAX) {

@@ -239,6 +239,9 @@ __device__ __forceinline__ void fused_flush(const HitStage& st, const ProbeArgs&
     __syncthreads();
 }
 
+// NS: the group's size rounded up to 2, 4, 8 or 16 -- the loops over the segments and the words read of the line stop there
+// (a rank of a sharded index holds 2 .. 8 of the 16 segments)
+template <int NS>
 __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa)
 {
     __shared__ uint64_t stage[FSTAGE_CAP];
@@ -275,28 +278,35 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
         const uint32_t bit = h & 31u, below = (1u << bit) - 1u;
         const uint32_t* line = g->lines + (size_t)(h >> 5) * 32u;
         // ---- the line: the hash's position bits in the 16 segments, and the segments' rank bases
-        uint32_t w[2 * FUSE_MAX];
+        uint32_t w[2 * NS];                        // [0, NS): bits, [NS, 2 NS): rank bases
 #pragma unroll
-        for (uint32_t i = 0; i < 2 * FUSE_MAX; ++i) w[i] = 0u;
+        for (uint32_t i = 0; i < 2 * NS; ++i) w[i] = 0u;
         if (valid) {
+            const uint8_t* lb = reinterpret_cast<const uint8_t*>(line);
+            if constexpr (NS >= 4) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint4 v = gload_u4(reinterpret_cast<const uint8_t*>(line) + 16 * i);
-                w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+                for (int i = 0; i < NS / 4; ++i) {
+                    const uint4 v = gload_u4(lb + 16 * i), r = gload_u4(lb + 64 + 16 * i);
+                    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+                    w[NS + 4 * i] = r.x; w[NS + 4 * i + 1] = r.y; w[NS + 4 * i + 2] = r.z; w[NS + 4 * i + 3] = r.w;
+                }
+            } else {
+                const uint64_t v = gload_u64(reinterpret_cast<const uint64_t*>(lb)), r = gload_u64(reinterpret_cast<const uint64_t*>(lb + 64));
+                w[0] = (uint32_t)v; w[1] = (uint32_t)(v >> 32); w[NS] = (uint32_t)r; w[NS + 1] = (uint32_t)(r >> 32);
             }
             my_probes += nseg;
             my_reads += 2u;
         }
         // ---- every segment whose bit is set: the position's word of its `primary`.  d[s]: 0xFFFFFFFF = nothing there
-        uint32_t d[FUSE_MAX];
+        uint32_t d[NS];
 #pragma unroll
-        for (uint32_t s = 0; s < FUSE_MAX; ++s) {
+        for (uint32_t s = 0; s < NS; ++s) {
             // (outside [first_hash, last_hash] the reference visits no block, src/FileSegment.zig:164,153; unused columns: empty range)
             const bool in_range = valid && h >= g->first_hash[s] && h <= g->last_hash[s];
             const bool set = in_range && ((w[s] >> bit) & 1u) != 0u;
             if (in_range && !set) my_blocks += 1u;   // absent: the reference visits one block, finds nothing and stops
             d[s] = 0xFFFFFFFFu;
-            if (set) { d[s] = gload_u32(g->primary[s] + (w[FUSE_MAX + s] + (uint32_t)__popc(w[s] & below))); my_reads += 2u; }   // (64-byte units)
+            if (set) { d[s] = gload_u32(g->primary[s] + (w[NS + s] + (uint32_t)__popc(w[s] & below))); my_reads += 2u; }   // (64-byte units)
         }
         // ---- what this hash found: the segments with ONE doc are counted, those with several (0.85 per hash on average) are
         //      gathered into four slots, so that their lists' heads (header + up to three docs) come in one round of loads
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
         uint32_t xi[4] = {0u, 0u, 0u, 0u};
         const bool any_dead = g->any_dead != 0u;
 #pragma unroll
-        for (uint32_t s = 0; s < FUSE_MAX; ++s) {
+        for (uint32_t s = 0; s < NS; ++s) {
             const uint32_t v = d[s];
             if (v == 0xFFFFFFFFu) continue;
             if (v >> 31) {
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
             ++o;
         };
 #pragma unroll
-        for (uint32_t s = 0; s < FUSE_MAX; ++s)
+        for (uint32_t s = 0; s < NS; ++s)
             if (d[s] != 0xFFFFFFFFu && (d[s] >> 31) == 0u) put(g->min_doc[s] + d[s]);
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
                 const uint32_t qlo = __shfl((uint32_t)(qpart >> 32), src);
                 uint32_t seen = 0;
 #pragma unroll
-                for (uint32_t s = 0; s < FUSE_MAX; ++s) {
+                for (uint32_t s = 0; s < NS; ++s) {
                     const uint32_t v = __shfl(d[s], src);                      // (uniform from here on)
                     if (v == 0xFFFFFFFFu || (v >> 31) == 0u) continue;
                     const uint32_t* list = g->extras[s] + (v & 0x7FFFFFFFu);

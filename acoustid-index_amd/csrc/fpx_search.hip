@@ -482,14 +482,19 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     const uint64_t per_wg_fk = (uint64_t)FK_WG * fk.rounds;
                     for (const FusedDesc& gd : snap->h_fused) {              // one launch per group: its descriptor is a kernel argument
                         const FusedArgs fargs{gd, snap->d_direct};
-                        hipLaunchKernelGGL(k_probe_fused, dim3((uint32_t)((P + per_wg_fk - 1) / per_wg_fk)), dim3(FK_WG), 0, st, fk, fargs);
+                        const dim3 gridf((uint32_t)((P + per_wg_fk - 1) / per_wg_fk));
+                        if (gd.nseg <= 2u) hipLaunchKernelGGL(k_probe_fused<2>, gridf, dim3(FK_WG), 0, st, fk, fargs);
+                        else if (gd.nseg <= 4u) hipLaunchKernelGGL(k_probe_fused<4>, gridf, dim3(FK_WG), 0, st, fk, fargs);
+                        else if (gd.nseg <= 8u) hipLaunchKernelGGL(k_probe_fused<8>, gridf, dim3(FK_WG), 0, st, fk, fargs);
+                        else hipLaunchKernelGGL(k_probe_fused<16>, gridf, dim3(FK_WG), 0, st, fk, fargs);
                     }
                     used_fused = true;
                 }
                 if (n_solo) {
                     ProbeArgs dk = a;
                     dk.segs = d_solo; dk.lean_stats = stat_sets;
-                    dk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_solo / 8192));
+                    static const uint32_t direct_rounds = [] { const char* e = getenv("FPX_DIRECT_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
+                    dk.rounds = direct_rounds ? direct_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_solo / 8192));
                     const uint64_t per_wg_dk = (uint64_t)DK_WG * DK_KPL * dk.rounds;
                     hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), n_solo), dim3(DK_WG), 0, st, dk);
                 }

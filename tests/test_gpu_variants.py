@@ -6,9 +6,10 @@ variant runs in a process of its own):
 * FPX_FAST=0             the general path only (host round trips between the stages, rocPRIM partition)
 * FPX_LEAN_HEAD=4        the whole-block instantiation of the lean probe kernel instead of the partial fetch
 * FPX_DIRECT_MIN_ITEMS=0 EVERY file segment in its direct-addressed form (by default only segments of >= 2^28 items, which only the
-                         full-size tests build): searches, counters, downloads and merges must be what the block form gives
+                         full-size tests build): searches, counters, downloads and merges must be what the block form gives.
+                         With FPX_FUSE_MIN=0: probed segment by segment (k_probe_direct)
 * FPX_FUSE_MIN=1         with it: every group of direct-addressed segments, even one alone, behind a fused directory
-                         (k_probe_fused; by default groups of 6..16)
+                         (k_probe_fused<2 | 4 | 8 | 16>; by default groups of 2..16)
 * FPX_DIRECT=0           no segment direct-addressed (run over the full-size tests' neighbours is not needed: the default suites
                          build no segment that large; tests/test_gpu_fullsize.py compares the two forms at full size)
 """
@@ -32,14 +33,14 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
 
 @pytest.mark.parametrize("env", [{"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
                                  {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
+                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_parity_suites_on_the_alternative_paths(env):
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         pytest.skip("already inside a variant run")
     e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
-    suites = FUSED_SUITES if "FPX_FUSE_MIN" in env else DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
+    suites = FUSED_SUITES if env.get("FPX_FUSE_MIN") == "1" else DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

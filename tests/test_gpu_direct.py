@@ -1,0 +1,143 @@
+"""The direct-addressed form and the fused directory (csrc/fpx_direct.hpp, fpx_build.hip: build_direct) on data built to
+reach their rare paths -- through the C ABI, against the oracle: results and the reference's scanned_blocks / scanned_docs.
+
+* a hash whose docs fill more than four blocks in one segment (FileSegment.search stops after 4 blocks / beyond 1000 docs:
+  the list stores all docs, `eff` says how many count, src/FileSegment.zig:173-174);
+* a hash with several docs in SIX segments (more lists than a lane's four slots: the wave-cooperative path), lists of 2, 3, 4
+  and 70 docs (heads of up to three docs inline, the rest read 64 at a time);
+* the hashes 0 and 0xFFFFFFFF (first / last position of the bitmap; the dedup table's empty mark), hashes below the segment's
+  first and above its last hash, hashes in the gap before a block's first hash;
+* docs re-inserted in newer segments and tombstones (supersession tested per record at emission in the fused kernel);
+* six segments (k_probe_fused<8>), two (<2>), one (k_probe_direct), batches above and below the 2^15 probes at which a batch
+  switches to the fused directory; duplicate hashes inside a query (flagged by k_make_keys_dedup)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fpx_testlib import fpx, oracle, Pair
+    ctx = fpx.Context(0)
+    yield fpx, oracle, Pair, ctx
+
+
+HOT, SHARED = 0x12345678, 0x0BADF00D
+
+
+def _segment_items(rng, s, per, first_doc):
+    """`per` docs x 48 uniform hashes + the special postings of segment s"""
+    docs = np.arange(first_doc, first_doc + per, dtype=np.uint64)
+    h = rng.integers(0, 1 << 32, (per, 48), dtype=np.uint64)
+    items = [((h << np.uint64(32)) | docs[:, None]).ravel()]
+
+    def post(hash_, ids):
+        items.append((np.uint64(hash_) << np.uint64(32)) | np.asarray(ids, dtype=np.uint64))
+
+    post(SHARED, docs[: [2, 3, 4, 70, 5, 2][s % 6]])              # several docs in every segment
+    if s == 1:
+        post(HOT, docs[:3000])                                  # > 1000 docs over > 4 blocks
+    if s == 2:
+        post(0, docs[:2]); post(0xFFFFFFFF, docs[5:8])
+    if s == 3:
+        post(1, docs[:1]); post(0xFFFFFFFE, docs[:1])
+    return np.unique(np.concatenate(items))
+
+
+def _world(fpx, Pair, ctx, nseg, monkeypatch, per=3000):
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    rng = np.random.default_rng(4711 + nseg)
+    p = Pair(ctx)
+    allitems = []
+    for s in range(nseg):
+        first = s * per + 1
+        ids = list(range(first, first + per))
+        if s >= 1:
+            ids += [first - per + 10, first - per + 11]              # re-inserted docs of the previous segment ...
+        items = _segment_items(rng, s, per, first)
+        if s >= 1:                                                  # ... one of them with postings of its own here
+            items = np.unique(np.concatenate([items, (rng.integers(0, 1 << 32, 40, dtype=np.uint64) << np.uint64(32)) | np.uint64(first - per + 10)]))
+        alive = np.ones(len(ids), dtype=np.uint8)
+        if s >= 1:
+            alive[-1] = 0                                           # ... the other a tombstone
+        p.add_file(items, min(ids), max(ids), s + 1, np.array(ids, dtype=np.uint32), alive)
+        allitems.append(items)
+    p.finish()
+    assert all(g.direct for g in p.gpu_segs), "the segments did not take the direct-addressed form"
+    return p, allitems, rng
+
+
+def _queries(rng, allitems, nq, qlen=1000):
+    qs = []
+    for i in range(nq):
+        src = allitems[i % len(allitems)]
+        doc = src[rng.integers(0, len(src))] & np.uint64(0xFFFFFFFF)
+        own = (src[(src & np.uint64(0xFFFFFFFF)) == doc] >> np.uint64(32)).astype(np.uint32)
+        special = np.array([HOT, SHARED, 0, 1, 0xFFFFFFFE, 0xFFFFFFFF, SHARED, HOT], dtype=np.uint32)       # (with duplicates)
+        near = (own[:8].astype(np.int64) + rng.integers(-3, 4, min(8, len(own)))).clip(0, 0xFFFFFFFF).astype(np.uint32)   # gap / neighbour positions
+        noise = rng.integers(0, 1 << 32, qlen - len(own) - len(special) - len(near), dtype=np.uint64).astype(np.uint32)
+        q = np.concatenate([own, special, near, noise])
+        rng.shuffle(q)
+        qs.append(q)
+    return qs
+
+
+@pytest.mark.parametrize("nseg", [6, 2, 1])
+def test_rare_paths_of_the_direct_addressed_kernels(env, nseg, monkeypatch):
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, nseg, monkeypatch)
+    big = _queries(rng, allitems, 40)                   # 40 000 probes: the fused directory (groups of >= 2 segments)
+    for opts in (fpx.http_options(), fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0)):
+        got, st = p.check(big, opts)
+        assert bool(st.path_flags & 4) == (nseg >= 2)
+        assert nseg < 2 or st.scanned_docs > 40 * 1000      # the hot hash's capped lists were walked (it lives in segment 1)
+    small = _queries(rng, allitems, 3)                  # 3 000 probes: one thread per hash and segment
+    got, st = p.check(small, fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0))
+    assert (st.path_flags & 4) == 0
+    one = fpx.SearchResults(fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0))
+    p.reader.search(small[0], one)                      # the single-query entry point
+    assert one.getResults() == got[0]
+
+
+def test_hot_list_is_cut_where_the_reference_stops(env, monkeypatch):
+    """the hash with 3000 docs alone: the reference returns the docs of its first four blocks only"""
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, 2, monkeypatch)
+    q = np.array([HOT], dtype=np.uint32)
+    want, ost = p.osnap.search(q, 5000, 1, 0, with_stats=True)
+    assert 1000 < len(want) < 3000 and ost.scanned_blocks == 4 + 1      # four blocks of segment 1, one visit in segment 0
+    got, st = p.check([q], fpx.SearchOptions(max_results=5000, min_score=1, min_score_pct=0))
+    assert got[0] == want
+
+
+def test_download_and_merge_of_direct_addressed_segments_give_the_files_bytes(env, monkeypatch):
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    rng = np.random.default_rng(99)
+    items = _segment_items(rng, 1, 3000, 1)
+    blocks, index = oracle.build_blocks(items, 1, 512)
+    ids = np.arange(1, 3001, dtype=np.uint32)
+    seg = fpx.FileSegment(ctx, blocks, 512, index, 1, 3000, 1, ids)
+    assert seg.direct
+    b2, i2 = seg.download()
+    assert np.array_equal(blocks, b2) and np.array_equal(index, i2)
+    # ... and as a merge source: the merged segment's bytes are those of the block-form merge
+    monkeypatch.setenv("FPX_DIRECT", "0")
+    seg_b = fpx.FileSegment(ctx, blocks, 512, index, 1, 3000, 1, ids)
+    assert not seg_b.direct
+    items2 = _segment_items(rng, 0, 2000, 3001)
+    bl2, ix2 = oracle.build_blocks(items2, 3001, 512)
+    ids2 = np.arange(3001, 5001, dtype=np.uint32)
+    other_b = fpx.FileSegment(ctx, bl2, 512, ix2, 3001, 5000, 2, ids2)
+    monkeypatch.setenv("FPX_DIRECT", "1")
+    other_d = fpx.FileSegment(ctx, bl2, 512, ix2, 3001, 5000, 2, ids2)
+    assert other_d.direct
+    merged_d = fpx.Segments(ctx, [seg, other_d]).merge([seg, other_d])
+    assert merged_d.direct
+    monkeypatch.setenv("FPX_DIRECT", "0")
+    merged_b = fpx.Segments(ctx, [seg_b, other_b]).merge([seg_b, other_b])
+    assert not merged_b.direct
+    mb, mi = merged_b.download()
+    md, mdi = merged_d.download()
+    assert np.array_equal(mb, md) and np.array_equal(mi, mdi)

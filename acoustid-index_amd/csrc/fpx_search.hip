@@ -380,8 +380,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // ... and only the top 32 - KEY_SORT_SKIP of them: block-level locality is all the probes need from the order
         // (a 256-value hash bucket is narrower than a block's hash span), see is_duplicate_pair for the dedup.
         // (flagged keys of a small batch are not sorted at all: the order only serves locality, which batches of up to 2^20
-        // pairs -- every probe on lines of its own -- do not have)
-        if (!(flagged && P <= local_sort_max)) {
+        // pairs -- every probe on lines of its own -- do not have; nor those of a snapshot whose direct-addressed segments are
+        // one fused pair -- a rank's share of an index sharded over 8 GPUs: the pass costs 0.1 ms and buys k_probe_fused<2> 0.06;
+        // k_probe_direct, whose neighbouring probes share record lines, keeps the order)
+        if (!(flagged && (P <= local_sort_max || (snap->n_solo == 0 && snap->n_direct <= 2)))) {
             const size_t tb = sort_u64_temp_bytes(P, qb + key_skip, 32 + qb);
             if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
             FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + key_skip, 32 + qb, st, &kcur));

@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256) void k_direct_count(const uint64_t* __restrict
             if (i + 1 < n && (uint32_t)(items[i + 1] >> 32) == h) {
                 const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
                 const uint64_t cnt = ri.end - i;
-                c_x += 1ull + (cnt != ri.eff ? 1ull : 0ull) + cnt;
+                c_x += (1ull + (cnt != ri.eff ? 1ull : 0ull) + cnt + 1ull) & ~1ull;      // lists start at even words (the offset counts pairs)
             }
         }
         prevh = h; have_prev = true;
@@ -830,7 +830,8 @@ __device__ __forceinline__ uint64_t direct_rank(const uint32_t* __restrict__ dre
 }
 
 // per block again: primary[rank(hash)] = doc - min_doc, or bit 31 | offset of the hash's list in `extras`:
-//   word 0 = docs returned (16 bits) | blocks visited << 16 | T << 19, [T: all docs of the hash], the docs (doc - min_doc, ascending)
+//   word 0 = docs returned (16 bits) | blocks visited << 16 | T << 19, [T: all docs of the hash], the docs (doc - min_doc, ascending);
+//   the offset counts PAIRS of words (lists start at even words): 31 bits reach 16 GB of lists
 // (the words of GAP positions keep the 0xFFFFFFFF they were initialised with)
 __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
                                                      uint32_t nb, uint32_t min_doc, const uint32_t* __restrict__ drec,
@@ -852,10 +853,11 @@ __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict_
                 const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
                 const uint64_t cnt = ri.end - i;
                 const uint32_t T = cnt != ri.eff ? 1u : 0u;
-                primary[r] = 0x80000000u | (uint32_t)x;
+                primary[r] = 0x80000000u | (uint32_t)(x >> 1);
                 extras[x++] = ri.eff | (ri.vis << 16) | (T << 19);
                 if (T) extras[x++] = (uint32_t)cnt;
                 for (uint64_t t = 0; t < cnt; ++t) extras[x++] = (uint32_t)items[i + t] - min_doc;
+                if (x & 1ull) extras[x++] = 0u;
             } else {
                 primary[r] = (uint32_t)it - min_doc;
             }
@@ -922,9 +924,12 @@ static bool direct_enabled()
 }
 static uint64_t direct_min_items()
 {
-    // below ~2^28 items (6 % of the hash values taken) the 1-GB record array outweighs the blocks it replaces
+    // from the size at which the block form would get probe records and the lean kernel: that kernel costs a batch ~0.3 ms per
+    // segment whatever the segment's size (its probes' record lines), the direct form -- one more column of the snapshot's
+    // fused directory -- next to nothing for the hashes a small segment does not have; it costs 1.07 GB of records + up to
+    // 0.27 GB of gap positions per segment
     const char* e = getenv("FPX_DIRECT_MIN_ITEMS");
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 28);
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 20);
 }
 
 static void direct_free(Segment* s)
@@ -997,10 +1002,11 @@ int build_direct(Segment* s)
         if (h_tot[0] != n) { set_error("internal: decoded %llu items of %llu", (unsigned long long)h_tot[0], (unsigned long long)n); return FPX_E_DEVICE; }
         const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
         if (Dp < D) { set_error("internal: %llu set bits for %llu distinct hashes", (unsigned long long)Dp, (unsigned long long)D); return FPX_E_DEVICE; }
-        // a gap position costs a word of `primary`: dense segments have a few per block; a segment whose hashes cluster
-        // (long empty stretches at block boundaries) keeps its blocks.  (FPX_DIRECT_MIN_ITEMS=0, the tests' switch, allows 2^26.)
-        const bool gaps_ok = Dp - D <= std::max<uint64_t>(n / 4, direct_min_items() == 0 ? (1ull << 26) : 0ull);
-        if (h_flags[0] || h_flags[1] || X >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull || !gaps_ok) return FPX_E_INVAL;      // does not qualify
+        // a gap position costs a word of `primary`: uniformly spread hashes have 2^32 / (items per block) of them whatever
+        // the segment's size (39 M: 156 MB); a segment whose hashes cluster (long empty stretches at block boundaries: more
+        // than 2^26 and more than a quarter of its items) keeps its blocks
+        const bool gaps_ok = Dp - D <= std::max<uint64_t>(n / 4, 1ull << 26);
+        if (h_flags[0] || h_flags[1] || X >= 0xFFFFFFE0ull || Dp >= 0xFFFFFFF0ull || !gaps_ok) return FPX_E_INVAL;      // does not qualify
         FPX_HIP(hipMalloc(&s->d_primary, (Dp + 4) * sizeof(uint32_t)));
         FPX_HIP(hipMalloc(&s->d_extras, (X + 8) * sizeof(uint32_t)));
         FPX_HIP(hipMemsetAsync(s->d_primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
@@ -1055,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_direct_rec_items(const uint32_t* __rest
                 if (items) items[out++] = hpart | (uint64_t)(min_doc + p);
                 total += 1u;
             } else {
-                const uint32_t* x = extras + (p & 0x7FFFFFFFu);
+                const uint32_t* x = extras + 2u * (size_t)(p & 0x7FFFFFFFu);
                 const uint32_t hdr = x[0], T = (hdr >> 19) & 1u;
                 const uint32_t cnt = T ? x[1] : (hdr & 0xFFFFu);
                 if (items) for (uint32_t t = 0; t < cnt; ++t) items[out++] = hpart | (uint64_t)(min_doc + x[1u + T + t]);

@@ -117,6 +117,8 @@ def test_fuzz_lean_sized_worlds(env, seed, monkeypatch):
     """segments of > 2^20 items and batches of > 2^16 probes: the lean kernel + deferred pass carry these; every other
     world runs without the segments' presence bitmaps"""
     fpx, oracle, Pair, ctx = env
+    if not DIRECT_FORCED:
+        monkeypatch.setenv("FPX_DIRECT", "0")           # (by default such segments are direct-addressed: these worlds are the block kernels')
     monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1" if seed % 2 else str(1 << 62))
     rng = np.random.default_rng(20_000 + seed)
     p, items, hash_bits, hot = random_world(fpx, Pair, ctx, rng, lean_sized=True)

@@ -214,6 +214,8 @@ def test_lean_kernel_and_deferred_pass(env, dist, presence, monkeypatch):
     presence: with / without the segments' presence bitmaps (default: on for segments of >= 2^20 items) -- probes of
     absent hashes are answered (and counted as the reference counts them) without their block being fetched."""
     fpx, oracle, Pair, ctx = env
+    if not DIRECT_FORCED:
+        monkeypatch.setenv("FPX_DIRECT", "0")           # (segments of >= 2^20 items are direct-addressed by default: this test is the block kernels')
     monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "1" if presence else str(1 << 62))
     seed, H, per, S = 91 + dist, 128, 9000, 3          # 1.15 M items per segment: 2-byte hash deltas, lean-eligible
     p = Pair(ctx)
@@ -343,10 +345,12 @@ def test_lean_kernel_with_supersession_tombstones_and_wide_docids(env, dist, pre
     assert got[nq + 4][0][0] == 77 and got[nq + 4][0][1] >= 8                         # overwritten in a memory segment
 
 
-def test_deferred_list_overflow_falls_back_to_generic_pass(env):
+def test_deferred_list_overflow_falls_back_to_generic_pass(env, monkeypatch):
     """A lean-eligible segment (512-B blocks, > 2^20 items) in which EVERY block holds a 4-byte hash delta: the lean
     kernel defers nearly every probe, its deferred lists overflow, and the batch is rerun on the generic kernel."""
     fpx, oracle, Pair, ctx = env
+    if not DIRECT_FORCED:
+        monkeypatch.setenv("FPX_DIRECT", "0")           # (the block kernels' test)
     rng = np.random.default_rng(77)
     n_clusters, per_cluster = 1 << 14, 80                       # clusters 2^18 apart: a 4-byte delta every 80 items
     base = (np.arange(n_clusters, dtype=np.uint64) << np.uint64(18))

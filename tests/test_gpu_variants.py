@@ -5,13 +5,12 @@ variant runs in a process of its own):
                          pairs per query in LDS)
 * FPX_FAST=0             the general path only (host round trips between the stages, rocPRIM partition)
 * FPX_LEAN_HEAD=4        the whole-block instantiation of the lean probe kernel instead of the partial fetch
-* FPX_DIRECT_MIN_ITEMS=0 EVERY file segment in its direct-addressed form (by default only segments of >= 2^28 items, which only the
-                         full-size tests build): searches, counters, downloads and merges must be what the block form gives.
+* FPX_DIRECT_MIN_ITEMS=0 EVERY file segment in its direct-addressed form (by default segments of >= 2^20 items): searches, counters, downloads and merges must be what the block form gives.
                          With FPX_FUSE_MIN=0: probed segment by segment (k_probe_direct)
 * FPX_FUSE_MIN=1         with it: every group of direct-addressed segments, even one alone, behind a fused directory
                          (k_probe_fused<2 | 4 | 8 | 16>; by default groups of 2..16)
-* FPX_DIRECT=0           no segment direct-addressed (run over the full-size tests' neighbours is not needed: the default suites
-                         build no segment that large; tests/test_gpu_fullsize.py compares the two forms at full size)
+* FPX_DIRECT=0           no segment direct-addressed: segments of >= 2^20 items (direct-addressed by default) are searched in
+                         their blocks by the lean kernel (tests/test_gpu_fullsize.py compares the two forms at full size)
 """
 import os
 import subprocess
@@ -31,7 +30,7 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
                 "tests/test_gpu_fuzz.py::test_fuzz_lean_sized_worlds"]
 
 
-@pytest.mark.parametrize("env", [{"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
+@pytest.mark.parametrize("env", [{"FPX_DIRECT": "0"}, {"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
                                  {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"}],

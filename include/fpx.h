@@ -132,7 +132,7 @@ uint32_t fpx_segment_num_blocks(const fpx_segment *seg);
 uint32_t fpx_segment_block_size(const fpx_segment *seg);
 uint64_t fpx_segment_device_bytes(const fpx_segment *seg);
 /* How a resident file segment is kept in HBM: 0 = its blocks, as in the file (src/filefmt.zig); 1 = DIRECT-ADDRESSED -- a dense
- * segment (>= 2^28 items by default; FPX_DIRECT_MIN_ITEMS, FPX_DIRECT=0 turns it off) trades its blocks for an exact
+ * segment of >= 2^20 items (FPX_DIRECT_MIN_ITEMS; FPX_DIRECT=0 turns it off) trades its blocks for an exact
  * presence bitmap with a rank directory and doc lists (csrc/fpx_direct.hpp).  Searches, counters, downloads and merges do
  * not depend on the form: a download re-encodes the file's blocks byte for byte. */
 int fpx_segment_layout(const fpx_segment *seg);

@@ -570,7 +570,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
-            d.drec = s->d_drec; d.primary = s->d_primary; d.extras = s->d_extras; d.first_hash = s->first_hash; d.last_hash = s->last_hash;
+            d.drec = s->d_drec; d.primary = s->d_primary; d.extras = s->d_extras; d.first_hash = s->first_hash; d.last_hash = s->last_hash; d.extras_shift = s->extras_shift;
             if (s->direct) { sn->h_direct.push_back(d); direct_segs.push_back(s); continue; }   // searched by k_probe_direct / k_probe_fused alone
             sn->h_file.push_back(d);
             sn->max_block_size = std::max(sn->max_block_size, s->block_size);
@@ -607,7 +607,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             for (uint32_t j = 0; j < k; ++j) {
                 const SegDesc& d = sn->h_direct[i0 + j];
                 g.primary[j] = d.primary; g.extras[j] = d.extras; g.min_doc[j] = d.min_doc_id;
-                g.first_hash[j] = d.first_hash; g.last_hash[j] = d.last_hash;
+                g.first_hash[j] = d.first_hash; g.last_hash[j] = d.last_hash; g.xshift[j] = d.extras_shift;
                 g.seg_index[j] = i0 + j; g.has_dead[j] = d.num_dead != 0u ? 1u : 0u;
                 g.any_dead |= g.has_dead[j];
             }

@@ -793,7 +793,8 @@ __device__ RunInfo direct_run_info(const uint64_t* __restrict__ items, uint64_t 
 
 // per block: distinct hashes whose run STARTS in it, and the `extras` words those with several docs need
 __global__ __launch_bounds__(256) void k_direct_count(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
-                                                      uint32_t nb, uint32_t* __restrict__ ns, uint32_t* __restrict__ nx, int* __restrict__ flags)
+                                                      uint32_t nb, uint32_t* __restrict__ ns, uint32_t* __restrict__ nx, int* __restrict__ flags,
+                                                      uint32_t pad)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(256) void k_direct_count(const uint64_t* __restrict
             if (i + 1 < n && (uint32_t)(items[i + 1] >> 32) == h) {
                 const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
                 const uint64_t cnt = ri.end - i;
-                c_x += (1ull + (cnt != ri.eff ? 1ull : 0ull) + cnt + 1ull) & ~1ull;      // lists start at even words (the offset counts pairs)
+                c_x += (1ull + (cnt != ri.eff ? 1ull : 0ull) + cnt + pad) & ~(uint64_t)pad;      // pad = 1: lists start at even words
             }
         }
         prevh = h; have_prev = true;
@@ -831,12 +832,13 @@ __device__ __forceinline__ uint64_t direct_rank(const uint32_t* __restrict__ dre
 
 // per block again: primary[rank(hash)] = doc - min_doc, or bit 31 | offset of the hash's list in `extras`:
 //   word 0 = docs returned (16 bits) | blocks visited << 16 | T << 19, [T: all docs of the hash], the docs (doc - min_doc, ascending);
-//   the offset counts PAIRS of words (lists start at even words): 31 bits reach 16 GB of lists
+//   the offset counts words, or -- pad = 1, for a segment with more than 2^31 words of lists (beyond ~2.2 G items) -- PAIRS of
+//   words, its lists starting at even words (Segment::extras_shift)
 // (the words of GAP positions keep the 0xFFFFFFFF they were initialised with)
 __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
                                                      uint32_t nb, uint32_t min_doc, const uint32_t* __restrict__ drec,
                                                      const uint64_t* __restrict__ xbase, uint32_t* __restrict__ primary,
-                                                     uint32_t* __restrict__ extras)
+                                                     uint32_t* __restrict__ extras, uint32_t pad)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
@@ -853,11 +855,11 @@ __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict_
                 const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
                 const uint64_t cnt = ri.end - i;
                 const uint32_t T = cnt != ri.eff ? 1u : 0u;
-                primary[r] = 0x80000000u | (uint32_t)(x >> 1);
+                primary[r] = 0x80000000u | (uint32_t)(x >> pad);
                 extras[x++] = ri.eff | (ri.vis << 16) | (T << 19);
                 if (T) extras[x++] = (uint32_t)cnt;
                 for (uint64_t t = 0; t < cnt; ++t) extras[x++] = (uint32_t)items[i + t] - min_doc;
-                if (x & 1ull) extras[x++] = 0u;
+                if (pad && (x & 1ull)) extras[x++] = 0u;
             } else {
                 primary[r] = (uint32_t)it - min_doc;
             }
@@ -985,19 +987,24 @@ int build_direct(Segment* s)
         // distinct hashes and list words per block -> list bases
         if ((rc = ns.alloc((size_t)nb * 4)) || (rc = nx.alloc((size_t)nb * 4)) || (rc = sbase.alloc((size_t)nb * 8)) || (rc = xbase.alloc((size_t)nb * 8)))
             return rc;
-        hipLaunchKernelGGL(k_direct_count, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
-                           ns.as<uint32_t>(), nx.as<uint32_t>(), flags.as<int>());
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nb, sbase.as<uint64_t>(), d_tot + 1);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nx.as<uint32_t>(), (uint64_t)nb, xbase.as<uint64_t>(), d_tot + 2);
-        FPX_HIP(hipGetLastError());
         uint64_t h_tot[4] = {0, 0, 0, 0};
         int h_flags[2] = {0, 0};
         uint64_t h_ends[2] = {0, 0};
-        FPX_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipMemcpyAsync(&h_ends[0], items.as<uint64_t>(), 8, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipMemcpyAsync(&h_ends[1], items.as<uint64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipStreamSynchronize(st));
+        uint32_t pad = 0;
+        for (;; pad = 1) {             // (list offsets of 31 bits: in words, or in pairs of words when the lists are longer than that)
+            hipLaunchKernelGGL(k_direct_count, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
+                               ns.as<uint32_t>(), nx.as<uint32_t>(), flags.as<int>(), pad);
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nb, sbase.as<uint64_t>(), d_tot + 1);
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nx.as<uint32_t>(), (uint64_t)nb, xbase.as<uint64_t>(), d_tot + 2);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipMemcpyAsync(&h_ends[0], items.as<uint64_t>(), 8, hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipMemcpyAsync(&h_ends[1], items.as<uint64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipStreamSynchronize(st));
+            if (pad || h_flags[0] || h_flags[1] || h_tot[2] < 0x7FFFFFF0ull) break;
+        }
+        s->extras_shift = pad;
         s->first_hash = (uint32_t)(h_ends[0] >> 32); s->last_hash = (uint32_t)(h_ends[1] >> 32);
         if (h_tot[0] != n) { set_error("internal: decoded %llu items of %llu", (unsigned long long)h_tot[0], (unsigned long long)n); return FPX_E_DEVICE; }
         const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
@@ -1006,13 +1013,13 @@ int build_direct(Segment* s)
         // the segment's size (39 M: 156 MB); a segment whose hashes cluster (long empty stretches at block boundaries: more
         // than 2^26 and more than a quarter of its items) keeps its blocks
         const bool gaps_ok = Dp - D <= std::max<uint64_t>(n / 4, 1ull << 26);
-        if (h_flags[0] || h_flags[1] || X >= 0xFFFFFFE0ull || Dp >= 0xFFFFFFF0ull || !gaps_ok) return FPX_E_INVAL;      // does not qualify
+        if (h_flags[0] || h_flags[1] || (X >> pad) >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull || !gaps_ok) return FPX_E_INVAL;      // does not qualify
         FPX_HIP(hipMalloc(&s->d_primary, (Dp + 4) * sizeof(uint32_t)));
         FPX_HIP(hipMalloc(&s->d_extras, (X + 8) * sizeof(uint32_t)));
         FPX_HIP(hipMemsetAsync(s->d_primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
         FPX_HIP(hipMemsetAsync(s->d_extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
         hipLaunchKernelGGL(k_direct_fill, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
-                           s->min_doc_id, (const uint32_t*)s->d_drec, xbase.as<uint64_t>(), s->d_primary, s->d_extras);
+                           s->min_doc_id, (const uint32_t*)s->d_drec, xbase.as<uint64_t>(), s->d_primary, s->d_extras, pad);
         // the block boundaries among the items stay (materialize_blocks)
         if (!s->d_bstart) FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_bstart32, dim3((nb + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), nb, n, s->d_bstart);
@@ -1039,7 +1046,7 @@ int build_direct(Segment* s)
 // ---- back to items and blocks (downloads, merges) ---------------------------------------------------------------------
 // thread per record: its hashes in ascending order, each with all its docs
 __global__ __launch_bounds__(256) void k_direct_rec_items(const uint32_t* __restrict__ drec, const uint32_t* __restrict__ primary,
-                                                          const uint32_t* __restrict__ extras, uint32_t min_doc,
+                                                          const uint32_t* __restrict__ extras, uint32_t xshift, uint32_t min_doc,
                                                           const uint64_t* __restrict__ itembase, uint32_t* __restrict__ count_out,
                                                           uint64_t* __restrict__ items)
 {
@@ -1061,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_direct_rec_items(const uint32_t* __rest
                 if (items) items[out++] = hpart | (uint64_t)(min_doc + p);
                 total += 1u;
             } else {
-                const uint32_t* x = extras + 2u * (size_t)(p & 0x7FFFFFFFu);
+                const uint32_t* x = extras + ((size_t)(p & 0x7FFFFFFFu) << xshift);
                 const uint32_t hdr = x[0], T = (hdr >> 19) & 1u;
                 const uint32_t cnt = T ? x[1] : (hdr & 0xFFFFu);
                 if (items) for (uint32_t t = 0; t < cnt; ++t) items[out++] = hpart | (uint64_t)(min_doc + x[1u + T + t]);
@@ -1078,10 +1085,10 @@ int materialize_items(const Segment* s, uint64_t* items, hipStream_t st)
     int rc;
     DevBuf cnt, base, tot;
     if ((rc = cnt.alloc((size_t)DIRECT_NREC * 4)) || (rc = base.alloc((size_t)DIRECT_NREC * 8)) || (rc = tot.alloc(8))) return rc;
-    hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->min_doc_id,
+    hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->extras_shift, s->min_doc_id,
                        (const uint64_t*)nullptr, cnt.as<uint32_t>(), (uint64_t*)nullptr);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, cnt.as<uint32_t>(), (uint64_t)DIRECT_NREC, base.as<uint64_t>(), tot.as<uint64_t>());
-    hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->min_doc_id,
+    hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->extras_shift, s->min_doc_id,
                        base.as<uint64_t>(), (uint32_t*)nullptr, items);
     FPX_HIP(hipGetLastError());
     uint64_t h_tot = 0;

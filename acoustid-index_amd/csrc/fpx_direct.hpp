@@ -12,7 +12,7 @@
 //                          A clear bit: absent, and the reference visits exactly one block
 //            word  8       rank of the record's first position among the segment's set bits
 //            words 9, 10   eight bytes: bits set below each of the eight words (rank inside the record = byte + popcount)
-//   primary  one word per set bit, in hash order: doc - min_doc_id, or bit 31 | offset of the hash's list in `extras` (in pairs of words), or
+//   primary  one word per set bit, in hash order: doc - min_doc_id, or bit 31 | offset of the hash's list in `extras` (in words, or pairs of words: extras_shift), or
 //            0xFFFFFFFF for a gap position (a few per block boundary on dense segments; a segment with many keeps its blocks)
 //   extras   word 0 = docs the reference returns (16 bits) | blocks it visits << 16 | T << 19, [T: number of docs], the docs.
 //            The reference's caps (<= 4 blocks, stop beyond 1000 docs, :173-174) depend on where the blocks end; they are
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
 #pragma unroll
         for (int j = 0; j < DK_KPL; ++j) {
             x[j] = make_uint4(0, 0, 0, 0);
-            if (present[j] && (d[j] >> 31)) { x[j] = gload_u4_a4(seg.extras + 2u * (size_t)(d[j] & 0x7FFFFFFFu)); my_reads += 2u; }
+            if (present[j] && (d[j] >> 31)) { x[j] = gload_u4_a4(seg.extras + ((size_t)(d[j] & 0x7FFFFFFFu) << seg.extras_shift)); my_reads += 2u; }
         }
         // ---- emission (wave-uniform control flow)
 #pragma unroll
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
                 const uint32_t xs = __shfl(d[j] & 0x7FFFFFFFu, src), es = __shfl(eff, src), ts = __shfl(T, src), qs = __shfl(q[j], src);
                 for (uint32_t o = ts ? 2u : 3u; o < es; o += 64u) {
                     const bool keep = o + lane < es;
-                    const uint32_t dv = keep ? gload_u32(seg.extras + 2u * (size_t)xs + 1u + ts + o + lane) : 0u;
+                    const uint32_t dv = keep ? gload_u32(seg.extras + ((size_t)xs << seg.extras_shift) + 1u + ts + o + lane) : 0u;
                     stage_emit(hs, a, keep, ((uint64_t)qs << 32) | (uint64_t)(seg.min_doc_id + dv), lane, dead_filter);
                 }
                 if (lane == 0) my_reads += ((es + 31u) >> 5) * 2u;
@@ -250,11 +250,11 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
     // what the list slots need of their segment (a slot's segment differs from lane to lane)
     __shared__ const uint32_t* s_extras[FUSE_MAX];
-    __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
+    __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX], s_xshift[FUSE_MAX];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const FusedDesc* g = &fa.g;
-    if (tid < FUSE_MAX) { s_extras[tid] = g->extras[tid]; s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
+    if (tid < FUSE_MAX) { s_extras[tid] = g->extras[tid]; s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; s_xshift[tid] = g->xshift[tid]; }
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
             x[j] = make_uint4(0, 0, 0, 0);
-            if (j < n_multi) { x[j] = gload_u4_a4(s_extras[(xs >> (4u * j)) & 15u] + 2u * (size_t)xi[j]); my_reads += 2u; }
+            if (j < n_multi) { x[j] = gload_u4_a4(s_extras[(xs >> (4u * j)) & 15u] + ((size_t)xi[j] << s_xshift[(xs >> (4u * j)) & 15u])); my_reads += 2u; }
         }
         // ---- one reservation per lane: its single docs + the docs of its lists' heads
         uint32_t cnt = n_single, keepm = 0;                       // keepm: bits 3j..3j+2 = which of slot j's head docs are kept
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
                 for (uint32_t s = 0; s < NS; ++s) {
                     const uint32_t v = __shfl(d[s], src);                      // (uniform from here on)
                     if (v == 0xFFFFFFFFu || (v >> 31) == 0u) continue;
-                    const uint32_t* list = g->extras[s] + 2u * (size_t)(v & 0x7FFFFFFFu);
+                    const uint32_t* list = g->extras[s] + ((size_t)(v & 0x7FFFFFFFu) << g->xshift[s]);
                     const uint32_t hdr = gload_u32(list), eff = hdr & 0xFFFFu, T = (hdr >> 19) & 1u;
                     uint32_t from = T ? 2u : 3u;
                     if (seen >= 4u) {                                          // a fifth list: nothing of it has been read yet

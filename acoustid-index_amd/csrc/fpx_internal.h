@@ -57,6 +57,7 @@ struct SegDesc {
     const uint32_t* primary;       // [set bits] doc - min_doc_id, or bit 31 | offset into `extras`, or 0xFFFFFFFF: a gap position
     const uint32_t* extras;        // doc lists of the hashes with several docs
     uint32_t first_hash, last_hash; // of the segment: a hash outside is absent and costs the reference no block visit (:153,164)
+    uint32_t extras_shift;         // list offsets in `primary` count words (0) or pairs of words (1: more than 2^31 words of lists)
 };
 
 // A group of up to 16 direct-addressed segments probed through ONE fused directory (k_probe_fused, fpx_direct.hpp)
@@ -66,7 +67,7 @@ struct FusedDesc {
     uint32_t nseg, any_dead;
     const uint32_t* primary[FUSE_MAX];
     const uint32_t* extras[FUSE_MAX];
-    uint32_t min_doc[FUSE_MAX], first_hash[FUSE_MAX], last_hash[FUSE_MAX];
+    uint32_t min_doc[FUSE_MAX], first_hash[FUSE_MAX], last_hash[FUSE_MAX], xshift[FUSE_MAX];
     uint32_t seg_index[FUSE_MAX];          // the segment's descriptor in Snapshot::d_direct (supersession filter)
     uint32_t has_dead[FUSE_MAX];
 };
@@ -147,7 +148,7 @@ struct Segment {
     bool direct = false;
     uint32_t* d_drec = nullptr; uint32_t* d_primary = nullptr; uint32_t* d_extras = nullptr;
     uint64_t num_distinct = 0, num_positions = 0, extras_words = 0;     // distinct hashes; set bits = hashes + gap positions; list words
-    uint32_t first_hash = 0, last_hash = 0;
+    uint32_t first_hash = 0, last_hash = 0, extras_shift = 0;
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
     std::mutex dead_mu; std::shared_ptr<DeadSet> last_dead;   // the dead set of the latest snapshot that holds this segment
     uint64_t num_items = 0;

@@ -465,7 +465,8 @@ static std::shared_ptr<FusedDir> get_fused_dir(Ctx* c, Segment* const* segs, uin
         if (fd->segs.size() == k && std::equal(fd->segs.begin(), fd->segs.end(), segs)) return fd;
         ++i;
     }
-    const size_t bytes = ((size_t)1 << 27) * 128u;
+    const uint32_t ns = k <= 2u ? 2u : k <= 4u ? 4u : k <= 8u ? 8u : 16u;
+    const size_t bytes = ((size_t)1 << 27) * 8u * ns;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); return nullptr; }
     auto fd = std::make_shared<FusedDir>();
@@ -473,7 +474,7 @@ static std::shared_ptr<FusedDir> get_fused_dir(Ctx* c, Segment* const* segs, uin
     if (hipMalloc(&fd->d_lines, bytes) != hipSuccess) { fd->d_lines = nullptr; (void)hipGetLastError(); return nullptr; }
     const uint32_t* drecs[FUSE_MAX] = {};
     for (uint32_t j = 0; j < k; ++j) drecs[j] = segs[j]->d_drec;
-    if (fuse_directory(drecs, k, fd->d_lines) != FPX_OK) return nullptr;
+    if (fuse_directory(drecs, k, ns, fd->d_lines) != FPX_OK) return nullptr;
     for (uint32_t j = 0; j < k; ++j) { segs[j]->refs.fetch_add(1); fd->segs.push_back(segs[j]); }
     cache.push_back(fd);
     return fd;
@@ -591,7 +592,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         e = hipMalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_direct, sn->h_direct.data(), sn->n_direct * sizeof(SegDesc), hipMemcpyHostToDevice);
         // groups of direct-addressed segments (in snapshot order, 16 to a group) get a fused directory; groups too small
-        // for it to pay (FPX_FUSE_MIN, default 2: it costs 17 GB whatever the group's size; two segments: probe kernel -20 %) and whatever does not fit
+        // for it to pay (FPX_FUSE_MIN, default 2; the directory costs 2.1 / 4.3 / 8.6 / 17.2 GB for up to 2 / 4 / 8 / 16 segments) and whatever does not fit
         // in memory are probed segment by segment
         static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
         std::vector<FusedDesc>& h_fused = sn->h_fused;

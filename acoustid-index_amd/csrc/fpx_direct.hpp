@@ -170,6 +170,7 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
 // the records of its direct-addressed segments, 16 to a group, into one directory (fuse_directory, fpx_api.hip):
 //   line L = hash >> 5, 128 bytes:  words 0..15   the 32 position bits of hash values [32 L, 32 L + 32) in segment s
 //                                   words 16..31  rank of the line's first position in segment s (its `primary` index)
+//   (a group of up to 8 / 4 / 2 segments: 8 / 4 / 2 words of each, lines of 64 / 32 / 16 bytes)
 // One thread per HASH now (not per hash and segment) reads that line, and for every segment whose bit is set one word of
 // that segment's `primary`: 8.2 M + 41 M lines per batch of 8192 x 1000 instead of 84 M + 41 M.
 // ------------------------------------------------------------------------------------------------
@@ -276,26 +277,20 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
         const uint32_t bit = h & 31u, below = (1u << bit) - 1u;
-        const uint32_t* line = g->lines + (size_t)(h >> 5) * 32u;
-        // ---- the line: the hash's position bits in the 16 segments, and the segments' rank bases
+        const uint32_t* line = g->lines + (size_t)(h >> 5) * (2u * NS);       // a line holds NS bit words and NS rank bases
+        // ---- the line: the hash's position bits in the group's segments, and the segments' rank bases
         uint32_t w[2 * NS];                        // [0, NS): bits, [NS, 2 NS): rank bases
 #pragma unroll
         for (uint32_t i = 0; i < 2 * NS; ++i) w[i] = 0u;
         if (valid) {
             const uint8_t* lb = reinterpret_cast<const uint8_t*>(line);
-            if constexpr (NS >= 4) {
 #pragma unroll
-                for (int i = 0; i < NS / 4; ++i) {
-                    const uint4 v = gload_u4(lb + 16 * i), r = gload_u4(lb + 64 + 16 * i);
-                    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-                    w[NS + 4 * i] = r.x; w[NS + 4 * i + 1] = r.y; w[NS + 4 * i + 2] = r.z; w[NS + 4 * i + 3] = r.w;
-                }
-            } else {
-                const uint64_t v = gload_u64(reinterpret_cast<const uint64_t*>(lb)), r = gload_u64(reinterpret_cast<const uint64_t*>(lb + 64));
-                w[0] = (uint32_t)v; w[1] = (uint32_t)(v >> 32); w[NS] = (uint32_t)r; w[NS + 1] = (uint32_t)(r >> 32);
+            for (int i = 0; i < (2 * NS) / 4; ++i) {
+                const uint4 v = gload_u4(lb + 16 * i);
+                w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
             }
             my_probes += nseg;
-            my_reads += 2u;
+            my_reads += NS >= 16 ? 2u : 1u;        // (64-byte units)
         }
         // ---- every segment whose bit is set: the position's word of its `primary`.  d[s]: 0xFFFFFFFF = nothing there
         uint32_t d[NS];
@@ -444,11 +439,13 @@ __global__ __launch_bounds__(FK_WG) void k_probe_fused(ProbeArgs a, FusedArgs fa
 }
 
 // the fused directory of a group: thread (L, s) copies segment s's word of line L and its rank base out of the segment's records
-__global__ __launch_bounds__(256) void k_fuse_lines(uint32_t* __restrict__ lines, const uint32_t* const* __restrict__ drecs, uint32_t nseg)
+// (ns = the group's size rounded up to 2, 4, 8 or 16: a line is ns bit words + ns rank bases)
+__global__ __launch_bounds__(256) void k_fuse_lines(uint32_t* __restrict__ lines, const uint32_t* const* __restrict__ drecs, uint32_t nseg,
+                                                    uint32_t ns)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const uint32_t s = (uint32_t)gid & 15u;
-    const uint64_t L = gid >> 4;                     // < 2^27
+    const uint32_t s = (uint32_t)gid & (ns - 1u);
+    const uint64_t L = gid / ns;                     // < 2^27
     uint32_t bits = 0, base = 0;
     if (s < nseg) {
         const uint32_t* rec = drecs[s] + (size_t)(L >> 3) * 16u;
@@ -456,8 +453,8 @@ __global__ __launch_bounds__(256) void k_fuse_lines(uint32_t* __restrict__ lines
         bits = rec[wv];
         base = rec[8] + (((wv < 4u ? rec[9] : rec[10]) >> (8u * (wv & 3u))) & 0xFFu);
     }
-    lines[L * 32u + s] = bits;
-    lines[L * 32u + 16u + s] = base;
+    lines[L * 2u * ns + s] = bits;
+    lines[L * 2u * ns + ns + s] = base;
 }
 
 }  // namespace fpx

@@ -63,7 +63,7 @@ struct SegDesc {
 // A group of up to 16 direct-addressed segments probed through ONE fused directory (k_probe_fused, fpx_direct.hpp)
 constexpr uint32_t FUSE_MAX = 16;
 struct FusedDesc {
-    const uint32_t* lines;                 // 2^27 lines of 32 words: [16 x position bits of 32 hash values | 16 x rank of the line's first position]
+    const uint32_t* lines;                 // 2^27 lines of 2 ns words (ns = nseg rounded up to 2, 4, 8, 16): [ns x position bits of 32 hash values | ns x rank of the line's first position]
     uint32_t nseg, any_dead;
     const uint32_t* primary[FUSE_MAX];
     const uint32_t* extras[FUSE_MAX];
@@ -275,7 +275,7 @@ hipError_t select_u64(void* temp, size_t temp_bytes, const uint64_t* in, const u
 
 // fpx_search.hip
 int build_bucket_table(Segment* seg, hipStream_t stream);
-int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t* d_lines);     // fills a group's 2^27 x 128-byte directory
+int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t ns, uint32_t* d_lines);     // fills a group's directory: 2^27 lines of 8 ns bytes
 int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                             const fpx_opts* opts, QueryBatch** out);
 void query_batch_free(QueryBatch* qb);

@@ -79,13 +79,13 @@ int build_bucket_table(Segment* seg, hipStream_t stream)
     return FPX_OK;
 }
 
-int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t* d_lines)
+int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t ns, uint32_t* d_lines)
 {
     const uint32_t** d_ptrs = nullptr;
     FPX_HIP(hipMalloc(reinterpret_cast<void**>(&d_ptrs), FUSE_MAX * sizeof(uint32_t*)));
     hipError_t e = hipMemcpy(d_ptrs, h_drecs, nseg * sizeof(uint32_t*), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_fuse_lines, dim3(1u << 23), dim3(256), 0, 0, d_lines, (const uint32_t* const*)d_ptrs, nseg);     // 2^27 lines x 16 columns
+        hipLaunchKernelGGL(k_fuse_lines, dim3((1u << 19) * ns), dim3(256), 0, 0, d_lines, (const uint32_t* const*)d_ptrs, nseg, ns);     // 2^27 lines x ns columns
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();

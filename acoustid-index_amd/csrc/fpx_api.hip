@@ -121,17 +121,12 @@ static void segment_free(Segment* s)
     if (s->d_small_items) (void)hipFree(s->d_small_items);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
     if (s->d_items) (void)hipFree(s->d_items);
-    if (s->d_drec) (void)hipFree(s->d_drec);
-    if (s->d_primary) (void)hipFree(s->d_primary);
-    if (s->d_extras) (void)hipFree(s->d_extras);
+    if (!s->dstore) {                      // (a direct-addressed segment's arrays belong to its DirectStore, a grouped one's to the group)
+        if (s->d_drec) (void)hipFree(s->d_drec);
+        if (s->d_primary) (void)hipFree(s->d_primary);
+        if (s->d_extras) (void)hipFree(s->d_extras);
+    }
     delete s;
-}
-
-FusedDir::~FusedDir()
-{
-    (void)hipSetDevice(device);
-    if (d_lines) (void)hipFree(d_lines);
-    for (Segment* s : segs) if (s->refs.fetch_sub(1) == 1) segment_free(s);
 }
 
 __global__ void k_count_items(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
@@ -379,7 +374,11 @@ uint64_t fpx_segment_num_items(const fpx_segment* seg) { return seg ? reinterpre
 uint32_t fpx_segment_num_blocks(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->num_blocks : 0; }
 uint32_t fpx_segment_block_size(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->block_size : 0; }
 uint64_t fpx_segment_device_bytes(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->device_bytes : 0; }
-int fpx_segment_layout(const fpx_segment* seg) { return seg && reinterpret_cast<const Segment*>(seg)->direct ? 1 : 0; }
+int fpx_segment_layout(const fpx_segment* seg)
+{
+    const Segment* s = reinterpret_cast<const Segment*>(seg);
+    return !s || !s->direct ? 0 : s->home ? 2 : 1;
+}
 
 int fpx_segment_download(const fpx_segment* seg, uint8_t* blocks, size_t blocks_cap, uint32_t* block_index, uint32_t index_cap)
 {
@@ -453,33 +452,6 @@ static void compute_dead(const std::vector<Segment*>& segs, size_t si, std::vect
     dead.erase(std::unique(dead.begin(), dead.end()), dead.end());
 }
 
-// the fused directory of a group of direct-addressed segments: the one a live snapshot already holds for the same group, or a
-// new one (null when memory is short: the group is then probed segment by segment)
-static std::shared_ptr<FusedDir> get_fused_dir(Ctx* c, Segment* const* segs, uint32_t k)
-{
-    std::lock_guard<std::mutex> lk(c->fused_mu);
-    auto& cache = c->fused_cache;
-    for (size_t i = 0; i < cache.size();) {
-        std::shared_ptr<FusedDir> fd = cache[i].lock();
-        if (!fd) { cache.erase(cache.begin() + i); continue; }
-        if (fd->segs.size() == k && std::equal(fd->segs.begin(), fd->segs.end(), segs)) return fd;
-        ++i;
-    }
-    const uint32_t ns = k <= 2u ? 2u : k <= 4u ? 4u : k <= 8u ? 8u : 16u;
-    const size_t bytes = ((size_t)1 << 27) * 8u * ns;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); return nullptr; }
-    auto fd = std::make_shared<FusedDir>();
-    fd->device = c->device;
-    if (hipMalloc(&fd->d_lines, bytes) != hipSuccess) { fd->d_lines = nullptr; (void)hipGetLastError(); return nullptr; }
-    const uint32_t* drecs[FUSE_MAX] = {};
-    for (uint32_t j = 0; j < k; ++j) drecs[j] = segs[j]->d_drec;
-    if (fuse_directory(drecs, k, ns, fd->d_lines) != FPX_OK) return nullptr;
-    for (uint32_t j = 0; j < k; ++j) { segs[j]->refs.fetch_add(1); fd->segs.push_back(segs[j]); }
-    cache.push_back(fd);
-    return fd;
-}
-
 static void snapshot_free(Snapshot* sn)
 {
     if (!sn) return;
@@ -490,7 +462,7 @@ static void snapshot_free(Snapshot* sn)
     if (sn->d_small) (void)hipFree(sn->d_small);
     if (sn->d_direct) (void)hipFree(sn->d_direct);
     if (sn->d_solo) (void)hipFree(sn->d_solo);
-    sn->fused.clear();
+    sn->groups.clear(); sn->solo_stores.clear();
     if (sn->d_mem) (void)hipFree(sn->d_mem);
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;
@@ -572,7 +544,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             d.num_blocks = s->num_blocks; d.block_size = s->block_size; d.bucket_shift = s->bucket_shift;
             d.min_doc_id = s->min_doc_id; d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
             d.drec = s->d_drec; d.primary = s->d_primary; d.extras = s->d_extras; d.first_hash = s->first_hash; d.last_hash = s->last_hash; d.extras_shift = s->extras_shift;
-            if (s->direct) { sn->h_direct.push_back(d); direct_segs.push_back(s); continue; }   // searched by k_probe_direct / k_probe_fused alone
+            if (s->direct) { sn->h_direct.push_back(d); direct_segs.push_back(s); continue; }   // searched by k_probe_group / k_probe_direct alone
             sn->h_file.push_back(d);
             sn->max_block_size = std::max(sn->max_block_size, s->block_size);
             if (s->block_size != 512) sn->all_512 = false;
@@ -591,31 +563,46 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     if (sn->n_direct) {
         e = hipMalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_direct, sn->h_direct.data(), sn->n_direct * sizeof(SegDesc), hipMemcpyHostToDevice);
-        // groups of direct-addressed segments (in snapshot order, 16 to a group) get a fused directory; groups too small
-        // for it to pay (FPX_FUSE_MIN, default 2; the directory costs 2.1 / 4.3 / 8.6 / 17.2 GB for up to 2 / 4 / 8 / 16 segments) and whatever does not fit
-        // in memory are probed segment by segment
+        // Direct-addressed segments are searched in GROUPS of up to 16 (fpx_group.hpp: one directory line and one run of words
+        // answer a hash for the whole group).  A segment that already lives in a group is probed there (the group's other
+        // columns masked out if they are not part of this snapshot); the ones still on their own are grouped now, in snapshot
+        // order, FPX_FUSE_MIN (default 2; 0: never) or more at a time -- fewer than that, or when HBM is short, stay alone
+        // and are probed one by one (k_probe_direct).
         static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
-        std::vector<FusedDesc>& h_fused = sn->h_fused;
         std::vector<SegDesc> h_solo;
-        for (uint32_t i0 = 0; e == hipSuccess && i0 < sn->n_direct; i0 += FUSE_MAX) {
-            const uint32_t k = std::min<uint32_t>(FUSE_MAX, sn->n_direct - i0);
-            std::shared_ptr<FusedDir> fd;
-            if (fuse_min != 0 && k >= fuse_min) fd = get_fused_dir(c, direct_segs.data() + i0, k);
-            if (!fd) { for (uint32_t j = 0; j < k; ++j) h_solo.push_back(sn->h_direct[i0 + j]); continue; }
-            FusedDesc g{};
-            g.lines = fd->d_lines; g.nseg = k;
-            for (uint32_t j = 0; j < FUSE_MAX; ++j) { g.first_hash[j] = 1u; g.last_hash[j] = 0u; }      // unused columns: empty hash range
-            for (uint32_t j = 0; j < k; ++j) {
-                const SegDesc& d = sn->h_direct[i0 + j];
-                g.primary[j] = d.primary; g.extras[j] = d.extras; g.min_doc[j] = d.min_doc_id;
-                g.first_hash[j] = d.first_hash; g.last_hash[j] = d.last_hash; g.xshift[j] = d.extras_shift;
-                g.seg_index[j] = i0 + j; g.has_dead[j] = d.num_dead != 0u ? 1u : 0u;
-                g.any_dead |= g.has_dead[j];
+        {
+            std::lock_guard<std::mutex> lk(c->group_mu);
+            std::vector<Segment*> lone;
+            for (Segment* sg : direct_segs) if (!sg->home) lone.push_back(sg);
+            for (size_t i0 = 0; fuse_min != 0 && i0 < lone.size(); i0 += FUSE_MAX) {
+                const uint32_t k = (uint32_t)std::min<size_t>(FUSE_MAX, lone.size() - i0);
+                if (k < fuse_min) break;
+                std::shared_ptr<Group> g;
+                const int grc = group_segments(c, lone.data() + i0, k, &g);
+                if (grc == FPX_E_DEVICE) { snapshot_free(sn); return grc; }
+                if (grc != FPX_OK) break;                      // (no room: they stay on their own)
             }
-            h_fused.push_back(g);
-            sn->fused.push_back(fd);
+            for (uint32_t i = 0; i < sn->n_direct; ++i) {
+                Segment* sg = direct_segs[i];
+                if (!sg->home) { h_solo.push_back(sn->h_direct[i]); sn->solo_stores.push_back(sg->dstore); continue; }
+                size_t gi = 0;
+                while (gi < sn->groups.size() && sn->groups[gi] != sg->home) ++gi;
+                if (gi == sn->groups.size()) {
+                    const Group* g = sg->home.get();
+                    GroupDesc gd{};
+                    gd.lines = g->d_lines; gd.line0 = g->line0; gd.nseg = g->nseg; gd.win_lo = g->win_lo; gd.win_hi = g->win_hi;
+                    for (uint32_t j = 0; j < FUSE_MAX; ++j) { gd.min_doc[j] = g->min_doc[j]; gd.first_hash[j] = g->first_hash[j]; gd.last_hash[j] = g->last_hash[j]; }
+                    sn->groups.push_back(sg->home);
+                    sn->h_group.push_back(gd);
+                }
+                GroupDesc& gd = sn->h_group[gi];
+                const SegDesc& d = sn->h_direct[i];
+                gd.active |= 1u << sg->col;
+                gd.seg_index[sg->col] = i; gd.has_dead[sg->col] = d.num_dead != 0u ? 1u : 0u;
+                gd.any_dead |= gd.has_dead[sg->col];
+            }
         }
-        sn->n_fused = (uint32_t)h_fused.size(); sn->n_solo = (uint32_t)h_solo.size();
+        sn->n_group = (uint32_t)sn->h_group.size(); sn->n_solo = (uint32_t)h_solo.size();
         if (e == hipSuccess && sn->n_solo) {
             e = hipMalloc(&sn->d_solo, h_solo.size() * sizeof(SegDesc));
             if (e == hipSuccess) e = hipMemcpy(sn->d_solo, h_solo.data(), h_solo.size() * sizeof(SegDesc), hipMemcpyHostToDevice);

@@ -274,6 +274,13 @@ struct DevBuf {
 
 // Encode `n` sorted items (device memory) into the blocks + block index of `s` (filefmt.writeBlocks,
 // src/filefmt.zig:94-138).  `s->block_size` is taken from the argument; on failure the caller frees `s`.
+int scan_counts_u32(const uint32_t* counts, uint64_t n, uint64_t* offsets, uint64_t* total, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts, n, offsets, total);
+    FPX_HIP(hipGetLastError());
+    return FPX_OK;
+}
+
 static int encode_sorted_items(const uint64_t* items, uint64_t n, uint32_t min_doc, uint32_t block_size, Segment* s, hipStream_t st)
 {
     int rc;
@@ -1035,6 +1042,8 @@ int build_direct(Segment* s)
         return rc == FPX_E_DEVICE ? rc : FPX_OK;             // an internal inconsistency is an error; anything else: stay block-based
     }
     s->direct = true;
+    s->dstore = std::make_shared<DirectStore>();
+    s->dstore->device = s->ctx->device; s->dstore->drec = s->d_drec; s->dstore->primary = s->d_primary; s->dstore->extras = s->d_extras;
     // the blocks and what only the block kernels read are not needed any more
     (void)hipFree(s->d_blocks); s->d_blocks = nullptr;
     if (s->d_bucket) { (void)hipFree(s->d_bucket); s->d_bucket = nullptr; }
@@ -1082,6 +1091,7 @@ __global__ __launch_bounds__(256) void k_direct_rec_items(const uint32_t* __rest
 int materialize_items(const Segment* s, uint64_t* items, hipStream_t st)
 {
     if (!s->direct) { set_error("internal: not a direct-addressed segment"); return FPX_E_INVAL; }
+    if (s->home) return group_column_items(s, items, st);
     int rc;
     DevBuf cnt, base, tot;
     if ((rc = cnt.alloc((size_t)DIRECT_NREC * 4)) || (rc = base.alloc((size_t)DIRECT_NREC * 8)) || (rc = tot.alloc(8))) return rc;

@@ -1,0 +1,345 @@
+// fpx_group.hip -- building a GROUP: the postings of up to 16 direct-addressed segments stored together, hash-major and
+// segment-minor, behind one directory (layout and search: fpx_group.hpp), and reading one member's items back out of it
+// (downloads, merge sources).
+//
+// The reference keeps every segment's postings in its own file and FileSegment.search walks them segment by segment
+// (src/Index.zig:174, src/FileSegment.zig:135-180).  The segments of an index share the hash space, and a query hash is looked
+// up in all of them, so on the GPU the segments' columns sit side by side: one directory line and one short run of words
+// answer a hash for the whole group.  What the reference derives per segment from the block structure (caps, visit counts, gap
+// positions) was computed when the segment became direct-addressed (fpx_build.hip: build_direct) and is carried over verbatim.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <new>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+Group::~Group()
+{
+    (void)hipSetDevice(device);
+    if (d_lines) (void)hipFree(d_lines);
+    for (uint32_t* p : word_chunks) if (p) (void)hipFree(p);
+    for (uint32_t* p : list_chunks) if (p) (void)hipFree(p);
+}
+
+namespace {
+
+constexpr uint32_t GAP = 0xFFFFFFFFu;
+constexpr uint32_t LONG_LIST = 48;         // lists of more words are copied by a wave each (a hot hash: thousands of docs)
+
+struct GroupSrc {                          // one member's direct-addressed arrays (fpx_direct.hpp)
+    const uint32_t* drec; const uint32_t* primary; const uint32_t* extras;
+    uint32_t xshift, pad;
+};
+struct BuildArgs {
+    GroupSrc src[FUSE_MAX];
+    uint32_t nseg;
+    uint64_t line_begin;                   // first line of this chunk (= hash >> 5)
+    uint32_t nlines;
+    uint32_t inline_doubles;
+};
+
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc(group build)"); }
+        return FPX_OK;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// the position bits of line L in column s and the index of its first position in the column's `primary`
+__device__ __forceinline__ void src_line(const GroupSrc& g, uint64_t L, uint32_t* bits, uint32_t* rank)
+{
+    const uint32_t* rec = g.drec + (size_t)(L >> 3) * 16u;
+    const uint32_t wv = (uint32_t)L & 7u;
+    *bits = rec[wv];
+    *rank = rec[8] + (((wv < 4u ? rec[9] : rec[10]) >> (8u * (wv & 3u))) & 0xFFu);
+}
+
+// a hash with several docs whose list is two docs, both returned, from one block: it is stored inline as a DOUBLE
+__device__ __forceinline__ bool is_double(uint32_t hdr) { return (hdr & 0xFFFFu) == 2u && ((hdr >> 16) & 7u) == 1u && ((hdr >> 19) & 1u) == 0u; }
+
+// per line: words it needs in the group's `words` (one per position, two for a double) and in `lists`
+template <int NS>
+__global__ __launch_bounds__(256) void k_group_count(BuildArgs a, uint32_t* __restrict__ W, uint32_t* __restrict__ X)
+{
+    constexpr uint32_t CAP = 32u * (NS - 4);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.nlines) return;
+    const uint64_t L = a.line_begin + i;
+    uint32_t bits[NS], rank[NS], P = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < NS; ++s) {
+        bits[s] = 0u; rank[s] = 0u;
+        if (s < a.nseg) src_line(a.src[s], L, &bits[s], &rank[s]);
+        P += (uint32_t)__popc(bits[s]);
+    }
+    const bool inl = a.inline_doubles != 0u && P <= CAP;
+    uint32_t w = P;
+    uint64_t x = 0;
+    for (uint32_t j = 0; j < 32u; ++j) {
+#pragma unroll
+        for (uint32_t s = 0; s < NS; ++s) {
+            if (((bits[s] >> j) & 1u) == 0u) continue;
+            const uint32_t v = a.src[s].primary[rank[s]++];
+            if (v == GAP || (v >> 31) == 0u) continue;
+            const uint32_t* li = a.src[s].extras + ((size_t)(v & 0x7FFFFFFFu) << a.src[s].xshift);
+            const uint32_t hdr = li[0];
+            if (inl && is_double(hdr)) { w += 1u; continue; }
+            const uint32_t T = (hdr >> 19) & 1u, cnt = T ? li[1] : (hdr & 0xFFFFu);
+            x += 1ull + T + cnt;
+        }
+    }
+    W[i] = w;
+    X[i] = (uint32_t)min(x, (uint64_t)0xFFFFFFFFull);
+}
+
+struct LongCopy { const uint32_t* src; uint32_t* dst; uint64_t n; };
+
+// per line again: the directory line, the words, the lists (long ones are queued for k_group_copy_long)
+template <int NS>
+__global__ __launch_bounds__(256) void k_group_fill(BuildArgs a, const uint64_t* __restrict__ offW, const uint64_t* __restrict__ offX,
+                                                    uint32_t* __restrict__ lines, uint32_t* __restrict__ words, uint32_t* __restrict__ lists,
+                                                    LongCopy* __restrict__ longq, uint32_t long_cap, unsigned long long* __restrict__ ctr)
+{
+    constexpr uint32_t NM = NS - 4, CAP = 32u * NM;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.nlines) return;
+    const uint64_t L = a.line_begin + i;
+    uint32_t bits[NS], rank[NS], P = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < NS; ++s) {
+        bits[s] = 0u; rank[s] = 0u;
+        if (s < a.nseg) src_line(a.src[s], L, &bits[s], &rank[s]);
+        P += (uint32_t)__popc(bits[s]);
+    }
+    const bool inl = a.inline_doubles != 0u && P <= CAP;
+    uint32_t* out = words + offW[i];
+    uint64_t x = offX[i];
+    uint32_t dbl[NM];
+#pragma unroll
+    for (uint32_t m = 0; m < NM; ++m) dbl[m] = 0u;
+    uint32_t pos = 0, ndbl = 0;
+    for (uint32_t j = 0; j < 32u; ++j) {
+#pragma unroll
+        for (uint32_t s = 0; s < NS; ++s) {
+            if (((bits[s] >> j) & 1u) == 0u) continue;
+            const uint32_t v = a.src[s].primary[rank[s]++];
+            if (v == GAP || (v >> 31) == 0u) { *out++ = v; pos += 1u; continue; }
+            const uint32_t* li = a.src[s].extras + ((size_t)(v & 0x7FFFFFFFu) << a.src[s].xshift);
+            const uint32_t hdr = li[0];
+            if (inl && is_double(hdr)) {
+                *out++ = li[1]; *out++ = li[2];
+#pragma unroll
+                for (uint32_t m = 0; m < NM; ++m) dbl[m] |= (pos >> 5) == m ? (1u << (pos & 31u)) : 0u;
+                pos += 1u; ndbl += 1u;
+                continue;
+            }
+            const uint32_t T = (hdr >> 19) & 1u, cnt = T ? li[1] : (hdr & 0xFFFFu);
+            const uint64_t n = 1ull + T + cnt;
+            *out++ = 0x80000000u | (uint32_t)x;
+            pos += 1u;
+            bool queued = false;
+            if (n > LONG_LIST) {
+                const unsigned long long q = atomicAdd(&ctr[0], 1ull);
+                if (q < long_cap) { longq[q] = LongCopy{li, lists + x, n}; queued = true; }
+            }
+            if (!queued) for (uint64_t t = 0; t < n; ++t) lists[x + t] = li[t];
+            x += n;
+        }
+    }
+    uint32_t* line = lines + (size_t)i * (2u * NS);
+#pragma unroll
+    for (uint32_t s = 0; s < NS; ++s) line[s] = bits[s];
+    const uint64_t pw = reinterpret_cast<uint64_t>(words + offW[i]), px = reinterpret_cast<uint64_t>(lists);
+    line[NS] = (uint32_t)pw; line[NS + 1] = (uint32_t)(pw >> 32);
+    line[NS + 2] = (uint32_t)px; line[NS + 3] = (uint32_t)(px >> 32);
+#pragma unroll
+    for (uint32_t m = 0; m < NM; ++m) line[NS + 4 + m] = dbl[m];
+    if (ndbl) atomicAdd(&ctr[1], (unsigned long long)ndbl);
+}
+
+__global__ __launch_bounds__(256) void k_group_copy_long(const LongCopy* __restrict__ q, const unsigned long long* __restrict__ ctr, uint32_t cap)
+{
+    const uint64_t n = min((uint64_t)ctr[0], (uint64_t)cap);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += (uint64_t)gridDim.x * 4u) {
+        const LongCopy c = q[i];
+        for (uint64_t t = lane; t < c.n; t += 64u) c.dst[t] = c.src[t];
+    }
+}
+
+// ---- one column's items out of the group again ---------------------------------------------------------------------
+// thread per line: walks the line's positions in (hash, column) order to find where column `col`'s words are
+template <int NS>
+__global__ __launch_bounds__(256) void k_group_col_items(const uint32_t* __restrict__ lines, uint64_t nlines, uint64_t line0, uint32_t col,
+                                                         uint32_t min_doc, const uint64_t* __restrict__ itembase, uint32_t* __restrict__ count_out,
+                                                         uint64_t* __restrict__ items)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= nlines) return;
+    const uint32_t* line = lines + (size_t)i * (2u * NS);
+    const uint32_t mine = line[col];
+    if (mine == 0u) { if (count_out) count_out[i] = 0u; return; }
+    uint32_t bits[NS];
+#pragma unroll
+    for (uint32_t s = 0; s < NS; ++s) bits[s] = line[s];
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(((uint64_t)line[NS + 1] << 32) | line[NS]);
+    const uint32_t* lists = reinterpret_cast<const uint32_t*>(((uint64_t)line[NS + 3] << 32) | line[NS + 2]);
+    const uint32_t* dblw = line + NS + 4;
+    uint64_t out = items ? itembase[i] : 0ull;
+    uint32_t total = 0, pos = 0, c = 0;
+    for (uint32_t j = 0; j < 32u; ++j) {
+        const uint64_t hpart = (uint64_t)(uint32_t)(((line0 + i) << 5) | j) << 32;
+#pragma unroll
+        for (uint32_t s = 0; s < NS; ++s) {
+            if (((bits[s] >> j) & 1u) == 0u) continue;
+            const bool d2 = (pos >> 5) < (uint32_t)(NS - 4) && ((dblw[pos >> 5] >> (pos & 31u)) & 1u) != 0u;
+            if (s == col) {
+                const uint32_t v = words[c];
+                if (d2) {
+                    if (items) { items[out++] = hpart | (uint64_t)(min_doc + v); items[out++] = hpart | (uint64_t)(min_doc + words[c + 1u]); }
+                    total += 2u;
+                } else if (v == GAP) {
+                } else if ((v >> 31) == 0u) {
+                    if (items) items[out++] = hpart | (uint64_t)(min_doc + v);
+                    total += 1u;
+                } else {
+                    const uint32_t* x = lists + (v & 0x7FFFFFFFu);
+                    const uint32_t hdr = x[0], T = (hdr >> 19) & 1u, cnt = T ? x[1] : (hdr & 0xFFFFu);
+                    if (items) for (uint32_t t = 0; t < cnt; ++t) items[out++] = hpart | (uint64_t)(min_doc + x[1u + T + t]);
+                    total += cnt;
+                }
+            }
+            c += d2 ? 2u : 1u;
+            pos += 1u;
+        }
+    }
+    if (count_out) count_out[i] = total;
+}
+
+}  // namespace
+
+// Moves the direct-addressed segments segs[0..k) into a new group.  On success every segment's postings live in the group
+// (Segment::home / col) and its own arrays are released (snapshots that still probe it alone keep them until they go).
+// FPX_E_NOMEM: not enough HBM for the group next to the segments -- nothing has changed, the caller probes them one by one.
+int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<Group>* out)
+{
+    out->reset();
+    if (k == 0 || k > FUSE_MAX) { set_error("a group holds 1..16 segments"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(ctx->device));
+    static const bool inline_doubles = [] { const char* e = getenv("FPX_INLINE_DOUBLES"); return e ? atoi(e) != 0 : true; }();
+    const uint32_t ns = k <= 8u ? 8u : 16u;
+    const uint64_t nlines = 1ull << 27;
+    uint64_t need = nlines * 2ull * ns * 4ull;
+    for (uint32_t j = 0; j < k; ++j) need += (segs[j]->num_positions + segs[j]->extras_words) * 4ull;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)4 << 30)) {
+        (void)hipGetLastError();
+        set_error("not enough free HBM to group %u segments (%.1f GB needed, %.1f free)", k, need / 1e9, free_b / 1e9);
+        return FPX_E_NOMEM;
+    }
+    auto g = std::make_shared<Group>();
+    g->device = ctx->device; g->ns = ns; g->nseg = k; g->line0 = 0; g->nlines = nlines;
+    for (uint32_t j = 0; j < FUSE_MAX; ++j) { g->first_hash[j] = 1u; g->last_hash[j] = 0u; }      // unused columns: empty hash range
+    BuildArgs a{};
+    a.nseg = k; a.inline_doubles = inline_doubles ? 1u : 0u;
+    for (uint32_t j = 0; j < k; ++j) {
+        const Segment* s = segs[j];
+        if (!s->direct || s->home || !s->d_drec) { set_error("internal: segment %u is not direct-addressed on its own", j); return FPX_E_INVAL; }
+        a.src[j] = GroupSrc{s->d_drec, s->d_primary, s->d_extras, s->extras_shift, 0u};
+        g->min_doc[j] = s->min_doc_id; g->first_hash[j] = s->first_hash; g->last_hash[j] = s->last_hash;
+    }
+    hipError_t e = hipMalloc(&g->d_lines, nlines * 2ull * ns * 4ull);
+    if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
+    g->device_bytes = nlines * 2ull * ns * 4ull;
+    // chunks of the hash space: every chunk's words and lists are allocations of their own (the lines hold the addresses), so
+    // nothing needs one contiguous 100-GB array
+    constexpr uint32_t CHUNKS = 64;
+    const uint32_t cl = (uint32_t)(nlines / CHUNKS);
+    constexpr uint32_t LONG_CAP = 1u << 20;
+    DevMem W, X, offW, offX, tot, longq, ctr;
+    int rc;
+    if ((rc = W.alloc((size_t)cl * 4)) || (rc = X.alloc((size_t)cl * 4)) || (rc = offW.alloc((size_t)cl * 8)) || (rc = offX.alloc((size_t)cl * 8)) ||
+        (rc = tot.alloc(16)) || (rc = longq.alloc((size_t)LONG_CAP * sizeof(LongCopy))) || (rc = ctr.alloc(16)))
+        return rc;
+    hipStream_t st = 0;
+    FPX_HIP(hipMemsetAsync(ctr.p, 0, 16, st));
+    for (uint32_t c = 0; c < CHUNKS; ++c) {
+        a.line_begin = (uint64_t)c * cl; a.nlines = cl;
+        const dim3 grid((cl + 255u) / 256u);
+        if (ns == 8u) hipLaunchKernelGGL(k_group_count<8>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>());
+        else hipLaunchKernelGGL(k_group_count<16>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>());
+        FPX_HIP(hipGetLastError());
+        if ((rc = scan_counts_u32(W.as<uint32_t>(), cl, offW.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
+        if ((rc = scan_counts_u32(X.as<uint32_t>(), cl, offX.as<uint64_t>(), tot.as<uint64_t>() + 1, st))) return rc;
+        uint64_t h_tot[2] = {0, 0};
+        FPX_HIP(hipMemcpyAsync(h_tot, tot.p, 16, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (h_tot[1] >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_INVAL; }
+        uint32_t* words = nullptr; uint32_t* lists = nullptr;
+        e = hipMalloc(&words, (h_tot[0] + 16) * 4ull);
+        if (e == hipSuccess) { g->word_chunks.push_back(words); e = hipMalloc(&lists, (h_tot[1] + 8) * 4ull); }
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
+        g->list_chunks.push_back(lists);
+        FPX_HIP(hipMemsetAsync(words + h_tot[0], 0, 16 * 4, st));                 // (a hash's words are read four at a time)
+        FPX_HIP(hipMemsetAsync(lists + h_tot[1], 0, 8 * 4, st));
+        FPX_HIP(hipMemsetAsync(ctr.p, 0, 8, st));
+        uint32_t* lines = g->d_lines + (size_t)a.line_begin * (2u * ns);
+        if (ns == 8u) hipLaunchKernelGGL(k_group_fill<8>, grid, dim3(256), 0, st, a, offW.as<uint64_t>(), offX.as<uint64_t>(), lines, words, lists,
+                                         longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());
+        else hipLaunchKernelGGL(k_group_fill<16>, grid, dim3(256), 0, st, a, offW.as<uint64_t>(), offX.as<uint64_t>(), lines, words, lists,
+                                longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());
+        hipLaunchKernelGGL(k_group_copy_long, dim3(1024), dim3(256), 0, st, longq.as<LongCopy>(), ctr.as<unsigned long long>(), LONG_CAP);
+        FPX_HIP(hipGetLastError());
+        g->total_words += h_tot[0]; g->total_list_words += h_tot[1];
+        g->device_bytes += (h_tot[0] + 16 + h_tot[1] + 8) * 4ull;
+    }
+    unsigned long long h_ctr[2] = {0, 0};
+    FPX_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    g->doubles = h_ctr[1];
+    // the segments move in: their own arrays go with the last snapshot that still probes them alone
+    for (uint32_t j = 0; j < k; ++j) {
+        Segment* s = segs[j];
+        s->home = g; s->col = j;
+        s->dstore.reset();
+        s->d_drec = s->d_primary = s->d_extras = nullptr;
+        s->device_bytes = ((size_t)s->num_blocks + 1) * 8;
+    }
+    *out = g;
+    return FPX_OK;
+}
+
+int group_column_items(const Segment* s, uint64_t* items, hipStream_t st)
+{
+    const Group* g = s->home.get();
+    if (!g) { set_error("internal: not a grouped segment"); return FPX_E_INVAL; }
+    if (g->line0 != 0 || g->nlines != (1ull << 27)) { set_error("a hash-window slice of an index holds only part of the segment: it cannot be downloaded or merged"); return FPX_E_INVAL; }
+    int rc;
+    DevMem cnt, base, tot;
+    if ((rc = cnt.alloc((size_t)g->nlines * 4)) || (rc = base.alloc((size_t)g->nlines * 8)) || (rc = tot.alloc(8))) return rc;
+    const dim3 grid((uint32_t)((g->nlines + 255) / 256));
+    auto launch = [&](const uint64_t* ib, uint32_t* co, uint64_t* it) {
+        if (g->ns == 8u) hipLaunchKernelGGL(k_group_col_items<8>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
+        else hipLaunchKernelGGL(k_group_col_items<16>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
+    };
+    launch(nullptr, cnt.as<uint32_t>(), nullptr);
+    if ((rc = scan_counts_u32(cnt.as<uint32_t>(), g->nlines, base.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
+    launch(base.as<uint64_t>(), nullptr, items);
+    FPX_HIP(hipGetLastError());
+    uint64_t h_tot = 0;
+    FPX_HIP(hipMemcpyAsync(&h_tot, tot.p, 8, hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    if (h_tot != s->num_items) { set_error("internal: %llu items rebuilt of %llu", (unsigned long long)h_tot, (unsigned long long)s->num_items); return FPX_E_DEVICE; }
+    return FPX_OK;
+}
+
+}  // namespace fpx

@@ -60,15 +60,19 @@ struct SegDesc {
     uint32_t extras_shift;         // list offsets in `primary` count words (0) or pairs of words (1: more than 2^31 words of lists)
 };
 
-// A group of up to 16 direct-addressed segments probed through ONE fused directory (k_probe_fused, fpx_direct.hpp)
-constexpr uint32_t FUSE_MAX = 16;
-struct FusedDesc {
-    const uint32_t* lines;                 // 2^27 lines of 2 ns words (ns = nseg rounded up to 2, 4, 8, 16): [ns x position bits of 32 hash values | ns x rank of the line's first position]
-    uint32_t nseg, any_dead;
-    const uint32_t* primary[FUSE_MAX];
-    const uint32_t* extras[FUSE_MAX];
-    uint32_t min_doc[FUSE_MAX], first_hash[FUSE_MAX], last_hash[FUSE_MAX], xshift[FUSE_MAX];
-    uint32_t seg_index[FUSE_MAX];          // the segment's descriptor in Snapshot::d_direct (supersession filter)
+constexpr uint32_t FUSE_MAX = 16;          // columns of a group
+
+// A GROUP of up to 16 direct-addressed segments whose postings are stored together, hash-major and segment-minor, behind one
+// directory (layout: fpx_group.hpp; built by fpx_group.hip).  This is what k_probe_group gets, by value.
+struct GroupDesc {
+    const uint32_t* lines;                 // the line of hash h: lines + ((h >> 5) - line0) * 2 ns words
+    uint32_t line0;                        // first line held (a hash-window slice of the group; 0: the whole hash space)
+    uint32_t nseg;                         // columns in use
+    uint32_t active;                       // bit s: column s belongs to the snapshot being searched (a group outlives merged-away members)
+    uint32_t any_dead;
+    uint32_t win_lo, win_hi;               // hashes outside are not probed here (0, 0xFFFFFFFF: no window)
+    uint32_t min_doc[FUSE_MAX], first_hash[FUSE_MAX], last_hash[FUSE_MAX];
+    uint32_t seg_index[FUSE_MAX];          // the column's descriptor in Snapshot::d_direct (supersession filter)
     uint32_t has_dead[FUSE_MAX];
 };
 
@@ -126,6 +130,35 @@ struct DeadSet {
     }
 };
 
+// The per-segment direct-addressed arrays (fpx_direct.hpp).  Snapshots that probe the segment on its own (k_probe_direct) keep
+// them alive; a segment that joins a group lets go of its reference.
+struct DirectStore {
+    int device = 0;
+    uint32_t* drec = nullptr; uint32_t* primary = nullptr; uint32_t* extras = nullptr;
+    ~DirectStore()
+    {
+        (void)hipSetDevice(device);
+        if (drec) (void)hipFree(drec);
+        if (primary) (void)hipFree(primary);
+        if (extras) (void)hipFree(extras);
+    }
+};
+
+// Host side of a group (GroupDesc is its device view).  Member segments and the snapshots that search it share it; the HBM
+// goes when the last of them does.  A member that was merged away stays as a dead column until the group is rebuilt.
+struct Group {
+    int device = 0;
+    uint32_t ns = 16;                      // 8 or 16: a directory line is 2 ns words
+    uint32_t nseg = 0;
+    uint32_t line0 = 0; uint64_t nlines = 0;
+    uint32_t win_lo = 0, win_hi = 0xFFFFFFFFu;
+    uint32_t* d_lines = nullptr;
+    std::vector<uint32_t*> word_chunks, list_chunks;       // one pair per hash-space chunk (the lines hold their addresses)
+    uint32_t min_doc[FUSE_MAX] = {}, first_hash[FUSE_MAX] = {}, last_hash[FUSE_MAX] = {};
+    uint64_t device_bytes = 0, total_words = 0, total_list_words = 0, doubles = 0;
+    ~Group();
+};
+
 struct Segment {
     std::atomic<int> refs{1};
     Ctx* ctx = nullptr;
@@ -146,7 +179,9 @@ struct Segment {
     // direct-addressed form (fpx_direct.hpp): replaces the blocks of a dense segment; d_bstart (item offset of every block) and
     // d_block_index stay, so that the blocks can be written out again byte for byte (materialize_blocks)
     bool direct = false;
+    std::shared_ptr<DirectStore> dstore;   // owner of d_drec / d_primary / d_extras while the segment is direct-addressed on its own
     uint32_t* d_drec = nullptr; uint32_t* d_primary = nullptr; uint32_t* d_extras = nullptr;
+    std::shared_ptr<Group> home; uint32_t col = 0;   // ... or, once grouped: the group that holds its postings, and its column there
     uint64_t num_distinct = 0, num_positions = 0, extras_words = 0;     // distinct hashes; set bits = hashes + gap positions; list words
     uint32_t first_hash = 0, last_hash = 0, extras_shift = 0;
     uint32_t own_flags = 0, own_lo = 0, own_hi = 0;   // hash window of a slice (see SegDesc)
@@ -155,15 +190,6 @@ struct Segment {
     // memory
     uint64_t* d_items = nullptr;
     uint64_t device_bytes = 0;
-};
-
-// the fused directory of a group of direct-addressed segments: built when a snapshot first holds the group, shared by the
-// snapshots that follow with the same group (Ctx::fused_cache), freed with the last of them
-struct FusedDir {
-    int device = 0;
-    uint32_t* d_lines = nullptr;
-    std::vector<Segment*> segs;            // retained
-    ~FusedDir();
 };
 
 struct Snapshot {
@@ -180,9 +206,10 @@ struct Snapshot {
     SegDesc* d_small = nullptr; uint32_t n_small = 0;     // small segments searched in their decoded items
     std::vector<SegDesc> h_direct;       // direct-addressed segments: not part of h_file / n_file
     SegDesc* d_direct = nullptr; uint32_t n_direct = 0;
-    // ... of which groups of FPX_FUSE_MIN..16 are probed through a fused directory and the rest (n_solo) one by one
-    std::vector<std::shared_ptr<FusedDir>> fused;
-    std::vector<FusedDesc> h_fused; uint32_t n_fused = 0;        // (passed to k_probe_fused by value)
+    // ... of which the grouped ones are probed group by group (k_probe_group) and the rest (n_solo) one by one (k_probe_direct)
+    std::vector<std::shared_ptr<Group>> groups;                  // grouped segments: one k_probe_group launch per group
+    std::vector<GroupDesc> h_group; uint32_t n_group = 0;
+    std::vector<std::shared_ptr<DirectStore>> solo_stores;       // the arrays d_solo points into
     SegDesc* d_solo = nullptr; uint32_t n_solo = 0;
     uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
@@ -247,7 +274,7 @@ struct QueryBatch {
 struct Ctx {
     int device = 0;
     std::mutex mu;
-    std::mutex fused_mu; std::vector<std::weak_ptr<FusedDir>> fused_cache;
+    std::mutex group_mu;                  // serialises the grouping of segments (fpx_snapshot_create, fpx_segments_group)
     std::vector<Workspace*> free_ws;
     std::atomic<int> live_ws{0};
 };
@@ -275,7 +302,6 @@ hipError_t select_u64(void* temp, size_t temp_bytes, const uint64_t* in, const u
 
 // fpx_search.hip
 int build_bucket_table(Segment* seg, hipStream_t stream);
-int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t ns, uint32_t* d_lines);     // fills a group's directory: 2^27 lines of 8 ns bytes
 int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                             const fpx_opts* opts, QueryBatch** out);
 void query_batch_free(QueryBatch* qb);
@@ -302,6 +328,8 @@ int synth_segment_impl(Ctx* ctx, uint64_t seed, uint32_t first_doc, uint32_t num
 // `s` arrives with its docs set; on failure the caller frees it
 int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool sorted, uint32_t block_size,
                        uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id, Segment* s);
+// exclusive scan of n 32-bit counts into 64-bit offsets (+ their total), one workgroup
+int scan_counts_u32(const uint32_t* counts, uint64_t n, uint64_t* offsets, uint64_t* total, hipStream_t st);
 int decode_small_segment(Segment* s);     // fills d_small_items / d_bstart of a resident file segment
 int build_presence(Segment* s);           // fills d_blockrec and d_proberec (both required by the lean kernel) of a resident file segment
 int build_direct(Segment* s);             // turns a dense resident file segment into its direct-addressed form (or leaves it as it is)
@@ -309,6 +337,10 @@ int build_direct(Segment* s);             // turns a dense resident file segment
 int materialize_blocks(const Segment* s, uint8_t** d_blocks_out);
 // its items (hash << 32 | doc, sorted) into `items` [num_items]
 int materialize_items(const Segment* s, uint64_t* items, hipStream_t st);
+// fpx_group.hip
+// moves `k` direct-addressed segments of one context (2..16; 1 with FPX_FUSE_MIN=1) into a new group and frees their own arrays
+int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<Group>* out);
+int group_column_items(const Segment* s, uint64_t* items, hipStream_t st);      // the items of a grouped segment, sorted (downloads, merges)
 struct MergeSource { const Segment* seg; std::vector<uint32_t> dead; };   // dead = skip_docs, sorted
 int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_t block_size, uint32_t min_doc_id, Segment* s);
 

@@ -32,6 +32,7 @@ struct ProbeArgs {
     unsigned long long* lean_stats;   // k_probe_lean8: [LEAN_STAT_SETS][8] {blocks fetched, visited blocks, docs, probes, ...}
     const uint32_t* cancel;           // the host's cancel word (mapped pinned memory), or null: no deadline
     uint32_t key_skip;                // low hash bits the pairs are NOT sorted on (KEY_SORT_SKIP; the direct-addressed kernels read it)
+    const unsigned long long* P_dev = nullptr;   // the number of pairs lives on the device (a rank's compacted share of the keys): P is their capacity
 };
 
 // Cancel point -- the GPU form of zio.maybeYield() in the reference's hot loop (src/FileSegment.zig:144,

@@ -39,6 +39,7 @@
 #include "fpx_probe_generic.hpp"
 #include "fpx_probe_lean.hpp"
 #include "fpx_direct.hpp"
+#include "fpx_group.hpp"
 #include "fpx_probe_small.hpp"
 #include "fpx_score.hpp"
 
@@ -76,21 +77,6 @@ int build_bucket_table(Segment* seg, hipStream_t stream)
     hipLaunchKernelGGL(k_build_buckets, dim3((n + 255) / 256), dim3(256), 0, stream,
                        seg->d_block_index, seg->num_blocks, seg->bucket_shift, seg->num_buckets, seg->d_bucket);
     FPX_HIP(hipGetLastError());
-    return FPX_OK;
-}
-
-int fuse_directory(const uint32_t* const* h_drecs, uint32_t nseg, uint32_t ns, uint32_t* d_lines)
-{
-    const uint32_t** d_ptrs = nullptr;
-    FPX_HIP(hipMalloc(reinterpret_cast<void**>(&d_ptrs), FUSE_MAX * sizeof(uint32_t*)));
-    hipError_t e = hipMemcpy(d_ptrs, h_drecs, nseg * sizeof(uint32_t*), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_fuse_lines, dim3((1u << 19) * ns), dim3(256), 0, 0, d_lines, (const uint32_t* const*)d_ptrs, nseg, ns);     // 2^27 lines x ns columns
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipFree(d_ptrs);
-    if (e != hipSuccess) return hip_fail(e, "fuse_directory");
     return FPX_OK;
 }
 
@@ -383,7 +369,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // pairs -- every probe on lines of its own -- do not have; nor those of a snapshot whose direct-addressed segments are
         // one fused pair -- a rank's share of an index sharded over 8 GPUs: the pass costs 0.1 ms and buys k_probe_fused<2> 0.06;
         // k_probe_direct, whose neighbouring probes share record lines, keeps the order)
-        if (!(flagged && (P <= local_sort_max || (snap->n_solo == 0 && snap->n_direct <= 2)))) {
+        if (!(flagged && P <= local_sort_max)) {
             const size_t tb = sort_u64_temp_bytes(P, qb + key_skip, 32 + qb);
             if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
             FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + key_skip, 32 + qb, st, &kcur));
@@ -464,31 +450,26 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (attempt > 0 && (snap->n_lean || snap->n_direct))
                 FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (first attempt: k_make_keys)
             if (snap->n_direct) {
-                // direct-addressed segments: their kernels serve every batch size (fpx_direct.hpp).  Groups with a fused
-                // directory are probed through it from ~32 queries on (one thread per hash, each walking 16 segments); below
-                // that -- a single /_search: 1000 threads -- one thread per hash and segment is quicker (0.076 against 0.093 ms)
-                static const uint64_t fuse_min_probes = [] { const char* e = getenv("FPX_FUSE_MIN_PROBES"); return e ? strtoull(e, nullptr, 0) : (1ull << 15); }();
-                const bool use_fused = snap->n_fused != 0 && P >= fuse_min_probes;
-                const uint32_t n_solo = use_fused ? snap->n_solo : snap->n_direct;
-                const SegDesc* d_solo = use_fused ? snap->d_solo : snap->d_direct;
+                // direct-addressed segments: their kernels serve every batch size -- the grouped ones through their group's
+                // directory (fpx_group.hpp: one thread per hash), the others one thread per hash and segment (fpx_direct.hpp)
+                const uint32_t n_solo = snap->n_solo;
+                const SegDesc* d_solo = snap->d_solo;
                 const uint64_t wgs_solo = (P + DK_WG * DK_KPL - 1) / (DK_WG * DK_KPL) * n_solo;
-                const uint64_t wgs_fused = use_fused ? (P + FK_WG - 1) / FK_WG * snap->n_fused : 0;
+                const uint64_t wgs_group = (P + FK_WG - 1) / FK_WG * snap->n_group;
                 // statistics: spread over 64 lines when thousands of workgroups end with them (see LEAN_STAT_SETS)
-                spread = !single_fast && wgs_solo + wgs_fused >= 1024;
+                spread = !single_fast && wgs_solo + wgs_group >= 1024;
                 unsigned long long* stat_sets = spread ? reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off) : nullptr;
-                if (use_fused) {
-                    ProbeArgs fk = a;
-                    fk.segs = snap->d_direct; fk.lean_stats = stat_sets;
-                    static const uint32_t fused_rounds = [] { const char* e = getenv("FPX_FUSED_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
-                    fk.rounds = fused_rounds ? fused_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_fused / 8192));
-                    const uint64_t per_wg_fk = (uint64_t)FK_WG * fk.rounds;
-                    for (const FusedDesc& gd : snap->h_fused) {              // one launch per group: its descriptor is a kernel argument
-                        const FusedArgs fargs{gd, snap->d_direct};
-                        const dim3 gridf((uint32_t)((P + per_wg_fk - 1) / per_wg_fk));
-                        if (gd.nseg <= 2u) hipLaunchKernelGGL(k_probe_fused<2>, gridf, dim3(FK_WG), 0, st, fk, fargs);
-                        else if (gd.nseg <= 4u) hipLaunchKernelGGL(k_probe_fused<4>, gridf, dim3(FK_WG), 0, st, fk, fargs);
-                        else if (gd.nseg <= 8u) hipLaunchKernelGGL(k_probe_fused<8>, gridf, dim3(FK_WG), 0, st, fk, fargs);
-                        else hipLaunchKernelGGL(k_probe_fused<16>, gridf, dim3(FK_WG), 0, st, fk, fargs);
+                if (snap->n_group) {
+                    ProbeArgs gk = a;
+                    gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
+                    static const uint32_t group_rounds = [] { const char* e = getenv("FPX_GROUP_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
+                    gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_group / 8192));
+                    const uint64_t per_wg_gk = (uint64_t)FK_WG * gk.rounds;
+                    for (const GroupDesc& gd : snap->h_group) {              // one launch per group: its descriptor is a kernel argument
+                        const GroupArgs gargs{gd, snap->d_direct};
+                        const dim3 gridg((uint32_t)((P + per_wg_gk - 1) / per_wg_gk));
+                        if (snap->groups[&gd - snap->h_group.data()]->ns == 8u) hipLaunchKernelGGL(k_probe_group<8>, gridg, dim3(FK_WG), 0, st, gk, gargs);
+                        else hipLaunchKernelGGL(k_probe_group<16>, gridg, dim3(FK_WG), 0, st, gk, gargs);
                     }
                     used_fused = true;
                 }

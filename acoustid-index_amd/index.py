@@ -118,8 +118,13 @@ class _Segment:
 
     @property
     def direct(self):
-        """kept in HBM in the direct-addressed form (fpx_segment_layout) instead of as blocks"""
-        return lib().fpx_segment_layout(self.h) == 1
+        """kept in HBM in the direct-addressed form (fpx_segment_layout: 1 on its own, 2 as a column of a group) instead of as blocks"""
+        return lib().fpx_segment_layout(self.h) != 0
+
+    @property
+    def grouped(self):
+        """its postings live in a group of direct-addressed segments (fpx_segment_layout == 2)"""
+        return lib().fpx_segment_layout(self.h) == 2
 
 
 def _docs_args(doc_ids, doc_alive):

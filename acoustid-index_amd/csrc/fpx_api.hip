@@ -373,7 +373,13 @@ void fpx_segment_release(fpx_segment* seg)
 uint64_t fpx_segment_num_items(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->num_items : 0; }
 uint32_t fpx_segment_num_blocks(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->num_blocks : 0; }
 uint32_t fpx_segment_block_size(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->block_size : 0; }
-uint64_t fpx_segment_device_bytes(const fpx_segment* seg) { return seg ? reinterpret_cast<const Segment*>(seg)->device_bytes : 0; }
+uint64_t fpx_segment_device_bytes(const fpx_segment* seg)
+{
+    const Segment* s = reinterpret_cast<const Segment*>(seg);
+    if (!s) return 0;
+    // (a grouped segment: what is left of its own + an equal share of its group)
+    return s->device_bytes + (s->home ? s->home->device_bytes / std::max(1u, s->home->nseg) : 0ull);
+}
 int fpx_segment_layout(const fpx_segment* seg)
 {
     const Segment* s = reinterpret_cast<const Segment*>(seg);

@@ -239,9 +239,11 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     const uint32_t ns = k <= 8u ? 8u : 16u;
     const uint64_t nlines = 1ull << 27;
     uint64_t need = nlines * 2ull * ns * 4ull;
-    for (uint32_t j = 0; j < k; ++j) need += (segs[j]->num_positions + segs[j]->extras_words) * 4ull;
+    // (a lower bound of what the group will take -- inline doubles take most lists out of `lists`; running out of HBM half
+    // way is noticed chunk by chunk and leaves the segments as they are)
+    for (uint32_t j = 0; j < k; ++j) need += segs[j]->num_positions * 4ull + segs[j]->extras_words;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)4 << 30)) {
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30)) {
         (void)hipGetLastError();
         set_error("not enough free HBM to group %u segments (%.1f GB needed, %.1f free)", k, need / 1e9, free_b / 1e9);
         return FPX_E_NOMEM;

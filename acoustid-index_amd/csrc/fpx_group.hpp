@@ -38,10 +38,20 @@ struct GroupArgs {
 
 constexpr uint32_t GK_WORDS = 12;          // words of a hash fetched by its lane (three dwordx4); the rare rest by the wave
 
-template <int NS>
+// BINNED: the records go straight into BINS of 2^bin_shift queries (fpx_score_bin.hpp scores a bin per workgroup).  With the keys
+// in (hash bucket, query) order -- what the one stable radix pass on the top hash bits leaves, k_make_keys_dedup having written
+// them query by query -- the 256 keys of a round belong to a few dozen neighbouring queries: a handful of bins, one reservation
+// each, runs of a kilobyte.  (Binning all 64+ bins of the batch in every flush was measured twice and cost what it saved.)
+constexpr uint32_t GB_SLOTS = 64;          // bins a round may touch (slot = bin & 63; a clash sends the lane's records the long way)
+constexpr uint32_t GB_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t GB_NEED = 0xFFFFFFF0u;   // s_rank: the staged record has no rank in its bin yet (every entry between rounds)
+
+template <int NS, bool BINNED>
 __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga)
 {
     constexpr int NM = NS - 4;             // words of double bits
+    __shared__ uint32_t s_bcnt[2][GB_SLOTS], s_bid[2][GB_SLOTS], s_bbase[GB_SLOTS];
+    __shared__ uint32_t s_rank[BINNED ? FSTAGE_CAP : 1];
     __shared__ uint64_t stage[FSTAGE_CAP];
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
@@ -52,6 +62,8 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const GroupDesc* g = &ga.g;
     if (tid < FUSE_MAX) { s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
+    if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid >> 6][tid & 63u] = 0u; s_bid[tid >> 6][tid & 63u] = GB_EMPTY; }
+    if constexpr (BINNED) for (uint32_t i = tid; i < FSTAGE_CAP; i += FK_WG) s_rank[i] = GB_NEED;
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
@@ -186,24 +198,31 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
                 if ((xkeep & 4u) && is_dead_seg(f, xd2)) xkeep &= ~4u;
             }
         }
-        // ---- one reservation per lane
+        // ---- one reservation per lane in the workgroup's stage -- and (BINNED) one in the lane's bin: the records' ranks there
         const uint32_t cnt = (uint32_t)__popc(keep) + (uint32_t)__popc(xkeep);
-        uint32_t pos = 0;
+        const uint32_t par = round & 1u;
+        uint32_t pos = 0, brank = 0;
         unsigned long long gpos = 0;
         bool fits = true;
         if (cnt != 0u) {
             pos = atomicAdd(hs.count, cnt);
             fits = pos + cnt <= FSTAGE_CAP;
-            if (!fits) {                             // the stage is full: this lane appends directly
+            if (!fits) {                             // the stage is full: this lane appends directly (BINNED: to the misc buffer, which k_bin bins)
                 atomicMin(hs.valid, pos);
                 gpos = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)cnt);
+            } else if constexpr (BINNED) {
+                const uint32_t b = (uint32_t)(qpart >> 32) >> a.bin_shift, bslot = b & (GB_SLOTS - 1u);
+                const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
+                brank = (old == GB_EMPTY || old == b) ? atomicAdd(&s_bcnt[par][bslot], cnt) : GB_EMPTY;       // (two bins on one slot: ranked at the flush)
             }
         }
         uint32_t o = 0;
         auto put = [&](uint32_t doc) {
             const uint64_t rec = qpart | doc;
-            if (fits) hs.buf[pos + o] = rec;
-            else if (gpos + o < a.hit_cap) a.hits[gpos + o] = rec;
+            if (fits) {
+                hs.buf[pos + o] = rec;
+                if constexpr (BINNED) s_rank[pos + o] = brank == GB_EMPTY ? GB_NEED : brank + o;
+            } else if (gpos + o < a.hit_cap) a.hits[gpos + o] = rec;
             ++o;
         };
 #pragma unroll
@@ -270,9 +289,47 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
                 }
             }
         }
-        fused_flush(hs, a, round + 1u == a.rounds, tid);
+        if constexpr (!BINNED) {
+            fused_flush(hs, a, round + 1u == a.rounds, tid);
+        } else {
+            // every round's records leave for their bins: ranks that are still missing (what the waves staged: long lists, a
+            // hash's words beyond the lane's twelve; a clash of two bins on one slot) first, then one reservation per bin
+            __syncthreads();
+            const uint32_t sc = min(stage_count, stage_valid);
+            bool unplaced = false;
+            for (uint32_t i = tid; i < sc; i += FK_WG) {
+                if (s_rank[i] != GB_NEED) continue;
+                const uint32_t b = (uint32_t)(stage[i] >> 32) >> a.bin_shift, sl = b & (GB_SLOTS - 1u);
+                const uint32_t old = atomicCAS(&s_bid[par][sl], GB_EMPTY, b);
+                if (old == GB_EMPTY || old == b) s_rank[i] = atomicAdd(&s_bcnt[par][sl], 1u); else unplaced = true;
+            }
+            __syncthreads();
+            if (tid < GB_SLOTS) {
+                const uint32_t c = s_bcnt[par][tid];
+                if (c != 0u) {
+                    s_bbase[tid] = atomicAdd(&a.bin_count[(size_t)s_bid[par][tid] * BIN_STRIDE], c);
+                    s_bcnt[par][tid] = 0u; s_bid[par][tid] = GB_EMPTY;          // (this parity's next use is two rounds away)
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < sc; i += FK_WG) {
+                const uint64_t rec = stage[i];
+                const uint32_t b = (uint32_t)(rec >> 32) >> a.bin_shift, rk = s_rank[i];
+                if (rk < GB_NEED) {
+                    const uint64_t at = (uint64_t)s_bbase[b & (GB_SLOTS - 1u)] + rk;
+                    if (at < a.bin_cap) a.bins[(size_t)b * a.bin_cap + at] = rec;
+                } else {                            // (still no place: the misc buffer)
+                    const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
+                    if (gg < a.hit_cap) a.hits[gg] = rec;
+                }
+                s_rank[i] = GB_NEED;
+            }
+            (void)unplaced;
+            __syncthreads();
+            if (tid == 0) { stage_count = 0; stage_valid = FSTAGE_CAP; }
+            __syncthreads();
+        }
     }
-
     if (my_reads) atomicAdd(&wg_reads, (unsigned long long)my_reads);
     if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
     if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);

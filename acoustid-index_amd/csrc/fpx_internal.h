@@ -108,6 +108,7 @@ enum Counter : int {
     CTR_CANCEL = 10,     // != 0: the search's deadline passed (copied off the host's cancel word by polling workgroups) -- every
                          // workgroup leaves at its next cancel point, the results are discarded (error.SearchTimeout)
     CTR_TOTAL = 11,      // device-sized path: hit records of the batch (sum of the queries' counts, written by k_l2_scan)
+    CTR_BINFAIL = 12,    // k_score_bin: a bin met more distinct (query, doc) pairs than its table takes: the batch is redone on the general path
     CTR_SLOTCANDS = 14,  // candidates handed from k_score to k_finish through the queries' own slots (statistics)
     CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
 };

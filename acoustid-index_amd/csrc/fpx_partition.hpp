@@ -24,7 +24,8 @@
 namespace fpx {
 
 constexpr uint32_t BIN_STRIDE = 32;         // 32-bit words between the bins' fill counters: a 128-B line each
-constexpr uint32_t MAX_BINS = 128;
+constexpr uint32_t MAX_BINS = 128;          // bins of the two-level partition (128 queries each)
+constexpr uint32_t MAX_SBINS = 4096;        // bins of 2^BQ queries that k_score_bin takes whole (fpx_score_bin.hpp)
 constexpr uint32_t BIN_QUERIES_LOG2 = 7;    // queries per bin (level 2 orders a tile by these 7 bits in LDS)
 constexpr uint32_t L2_TILE = 2048;          // records per workgroup tile of level 2
 
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs b, const uint64_t* __restri
                                              uint64_t cap)
 {
     constexpr uint32_t RPT = BIN_TILE / 256u;
-    __shared__ uint32_t s_cnt[MAX_BINS], s_base[MAX_BINS];
+    __shared__ uint32_t s_cnt[MAX_SBINS], s_base[MAX_SBINS];
     const uint32_t tid = threadIdx.x;
     const uint64_t n = min((uint64_t)*count, cap);
     for (uint64_t t = (uint64_t)blockIdx.x * BIN_TILE; t < n; t += (uint64_t)gridDim.x * BIN_TILE) {      // (uniform per workgroup)

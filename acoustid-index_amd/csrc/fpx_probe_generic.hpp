@@ -32,6 +32,8 @@ struct ProbeArgs {
     unsigned long long* lean_stats;   // k_probe_lean8: [LEAN_STAT_SETS][8] {blocks fetched, visited blocks, docs, probes, ...}
     const uint32_t* cancel;           // the host's cancel word (mapped pinned memory), or null: no deadline
     uint32_t key_skip;                // low hash bits the pairs are NOT sorted on (KEY_SORT_SKIP; the direct-addressed kernels read it)
+    // k_probe_group<.., BINNED>: records go to bins of 2^bin_shift queries ([nbins][bin_cap] records; fill counters BIN_STRIDE words apart)
+    uint64_t* bins = nullptr; uint64_t bin_cap = 0; unsigned int* bin_count = nullptr; uint32_t bin_shift = 0;
     const unsigned long long* P_dev = nullptr;   // the number of pairs lives on the device (a rank's compacted share of the keys): P is their capacity
 };
 

@@ -1,0 +1,195 @@
+// fpx_score_bin.hpp -- k_score_bin: SearchResults.incr + the min_score filter of finish (src/common.zig:121-145) for a BIN of
+// 2^BQ queries per workgroup.  Part of the fpx_search.hip translation unit (after fpx_score.hpp).
+//
+// k_probe_group<.., BINNED> leaves the batch's hit records (q << 32 | doc) in bins of eight neighbouring queries -- ~50 000
+// records, 400 KB, in one piece.  One workgroup takes a bin: the records stream through a counting filter in LDS keyed by
+// (query, doc), the few that can reach their query's floor are counted exactly in an LDS table of (doc, query, count) slots, and
+// the candidates go to their queries' slots (k_finish reads those).  The records are read twice (the second time out of the
+// caches) and never written again: the two-level partition this replaces (k_bin, k_l2_count, k_l2_scan, k_l2_scatter, k_score)
+// moved every record seven times.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+constexpr uint32_t SB_WG = 512;
+constexpr uint32_t SB_FILTER_LOG2 = 14;            // 16 384 16-bit cells (8 192 32-bit ones for bins of >= 65 536 records): 32 KB
+constexpr uint32_t SB_TABLE_LOG2 = 11;             // 2 048 slots of (doc << 32 | q << (32 - BQ) ... count): 16 KB
+constexpr uint32_t SB_QMAX = 16;                   // queries per bin at most (BQ <= 4)
+constexpr uint32_t SB_CAND = 32;                   // candidates of a query gathered in LDS before they move to the shared list
+
+struct ScoreBinArgs {
+    const uint64_t* bins; uint64_t bin_cap; const unsigned int* bin_count;      // as BinArgs
+    uint32_t bq;                                   // log2 of the queries per bin
+    uint32_t B;
+    const uint32_t* opts;                          // [B][4]
+    uint32_t sb;                                   // bits of the score field in a candidate key
+    uint64_t* cands; uint64_t cand_cap;            // the shared candidate list
+    unsigned long long* counters;
+    uint64_t* qcand; uint32_t* qcand_n;            // the queries' own candidate slots
+    uint32_t* bin_n;                               // [nbins] the bin's record count as found (the host adds them up; > bin_cap: redo)
+    const uint32_t* cancel;
+};
+
+__global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
+{
+    extern __shared__ __align__(16) uint8_t sb_smem[];
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(sb_smem);                          // 2^SB_TABLE_LOG2 slots
+    unsigned int* filter = reinterpret_cast<unsigned int*>(sb_smem + ((size_t)8u << SB_TABLE_LOG2));    // 2^(SB_FILTER_LOG2 - 1) words
+    uint64_t* cbuf = reinterpret_cast<uint64_t*>(sb_smem + ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2));   // [2^bq][SB_CAND]
+    __shared__ uint32_t s_floor[SB_QMAX], s_ccnt[SB_QMAX], s_cbase[SB_QMAX], s_over[SB_QMAX];
+    __shared__ uint32_t s_claimed, s_full, s_cancel;
+    const uint32_t tid = threadIdx.x, bin = blockIdx.x;
+    const uint32_t nq = 1u << a.bq, q0 = bin << a.bq, qm = nq - 1u;
+    if (tid == 0) s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;
+    if (tid < nq) {
+        const uint32_t q = q0 + tid;
+        s_floor[tid] = q < a.B ? a.opts[q * 4u + 1u] : 0xFFFFFFFFu;
+        s_ccnt[tid] = 0u; s_over[tid] = 0u;
+    }
+    const unsigned int raw_n = a.bin_count[(size_t)bin * BIN_STRIDE];
+    if (tid == 0) a.bin_n[bin] = raw_n;
+    __syncthreads();
+    if (s_cancel) return;
+    const uint64_t n = min((uint64_t)raw_n, a.bin_cap);
+    const uint64_t* recs = a.bins + (size_t)bin * a.bin_cap;
+    uint32_t floor_min = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < nq; ++i) floor_min = min(floor_min, s_floor[i]);
+    const uint64_t smax = a.sb >= 32u ? 0xFFFFFFFFull : ((1ull << a.sb) - 1ull);
+    // the records are read in tiles of SB_WG x SB_RPT: a thread issues all its loads of a tile, then works on registers
+    constexpr uint32_t SB_RPT = 8;
+    constexpr uint64_t TILE = (uint64_t)SB_WG * SB_RPT;
+
+    if (n != 0u && n >= (uint64_t)floor_min) {
+        // 16-bit cells while no cell can overflow (fewer than 2^16 records in all), 32-bit ones beyond
+        const bool wide = n >= 65536ull;
+        const uint32_t F = wide ? (1u << (SB_FILTER_LOG2 - 1u)) : (1u << SB_FILTER_LOG2), fmask = F - 1u;
+        const uint32_t T = 1u << SB_TABLE_LOG2, tmask = T - 1u, fill = T * 3u / 4u;
+        // a bin far above the filter's size is counted in K rounds over disjoint doc classes (as k_score's CLASSED form)
+        uint32_t K = 1u;
+        if (floor_min >= 4u) {
+            const uint64_t cell = (uint64_t)F * floor_min;
+            K = (uint32_t)min<uint64_t>((2ull * n + cell - 1ull) / cell, 1024ull);
+            if (K == 0u) K = 1u;
+        } else {
+            K = (uint32_t)max<uint64_t>(1ull, min<uint64_t>((n + F - 1ull) / F, 1024ull));
+        }
+        auto cell_count = [&](uint32_t c) -> uint32_t { return wide ? filter[c] : ((filter[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu); };
+        for (uint32_t kc = 0; kc < K; ++kc) {
+            auto in_class = [&](uint32_t doc) -> bool { return K == 1u || __umulhi(mix32(doc ^ 0x85EBCA6Bu), K) == kc; };
+            for (uint32_t i = tid; i < (1u << (SB_FILTER_LOG2 - 1u)); i += SB_WG) filter[i] = 0u;
+            __syncthreads();
+            // ---- stage A: every record of the class into its (query, doc) cell
+            for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
+                uint64_t r[SB_RPT];
+#pragma unroll
+                for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < n ? gload_u64(recs + i) : ~0ull; }
+#pragma unroll
+                for (uint32_t u = 0; u < SB_RPT; ++u) {
+                    if (r[u] == ~0ull) continue;
+                    const uint32_t doc = (uint32_t)r[u], ql = (uint32_t)(r[u] >> 32) & qm;
+                    if (!in_class(doc)) continue;
+                    const uint32_t c = mix32(doc ^ (ql * 0x9E3779B1u)) & fmask;
+                    if (wide) atomicAdd(&filter[c], 1u); else atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
+                }
+            }
+            __syncthreads();
+            // ---- stage B: the records whose cell reaches their query's floor (every (query, doc) with count >= floor is among
+            //      them) are counted exactly; when they are more than the table takes, in `passes` loads over classes of them.
+            //      The first load finds out: if it overfills, the class starts over with twice the passes (nothing has been
+            //      emitted yet); a later load that finds the table full fails the batch (the host redoes it on the general path)
+            uint32_t passes = 1u;
+            for (uint32_t pass = 0; pass < passes; ++pass) {
+                for (uint32_t s = tid; s < T; s += SB_WG) table[s] = 0ull;
+                if (tid == 0) { s_claimed = 0u; s_full = 0u; }
+                __syncthreads();
+                for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
+                    uint64_t r[SB_RPT];
+#pragma unroll
+                    for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < n ? gload_u64(recs + i) : ~0ull; }
+#pragma unroll
+                    for (uint32_t u = 0; u < SB_RPT; ++u) {
+                        if (r[u] == ~0ull) continue;
+                        const uint32_t doc = (uint32_t)r[u], ql = (uint32_t)(r[u] >> 32) & qm;
+                        if (!in_class(doc)) continue;
+                        const uint32_t hsh = mix32(doc ^ (ql * 0x9E3779B1u));
+                        if (cell_count(hsh & fmask) < s_floor[ql]) continue;
+                        if (passes > 1u && ((hsh >> 25) % passes) != pass) continue;       // class bits apart from the slot bits (14..24)
+                        // slot: doc << 32 | query << 28 | count (28 bits)
+                        const unsigned long long keyhi = ((unsigned long long)doc << 32) | ((unsigned long long)ql << 28);
+                        uint32_t s = (hsh >> 14) & tmask;
+                        for (uint32_t tries = 0;; ++tries) {
+                            if (tries == T) { s_full = 1u; break; }
+                            unsigned long long cur = table[s];
+                            if (cur == 0ull) {
+                                const unsigned long long prev = atomicCAS(&table[s], 0ull, keyhi | 1ull);
+                                if (prev == 0ull) { atomicAdd(&s_claimed, 1u); break; }
+                                cur = prev;
+                            }
+                            if ((cur >> 28) == (keyhi >> 28)) { atomicAdd(&table[s], 1ull); break; }
+                            s = (s + 1u) & tmask;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (pass == 0u && (s_claimed > fill || s_full != 0u) && passes < 64u) {
+                    const uint32_t np = passes * 2u;
+                    __syncthreads();
+                    passes = np; pass = 0xFFFFFFFFu;                   // (++pass: 0 again)
+                    continue;
+                }
+                if (s_full != 0u && tid == 0) atomicMax(&a.counters[CTR_BINFAIL], 1ull);
+                // candidates: count >= the query's floor -> the query's buffer in LDS (its first SB_CAND), the rest to the shared list
+                for (uint32_t s = tid; s < T; s += SB_WG) {
+                    const unsigned long long e = table[s];
+                    if (e == 0ull) continue;
+                    const uint32_t count = (uint32_t)e & 0x0FFFFFFFu, ql = (uint32_t)(e >> 28) & 15u, doc = (uint32_t)(e >> 32);
+                    if (count < s_floor[ql]) continue;
+                    if ((uint64_t)count > smax) atomicMax(&a.counters[CTR_MAXSCORE], (unsigned long long)count);
+                    const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;
+                    const uint64_t qpart = a.sb >= 32u ? 0ull : ((uint64_t)(q0 + ql) << (32u + a.sb));
+                    const uint64_t key = qpart | ((smax - sc) << 32) | doc;
+                    const uint32_t at = atomicAdd(&s_ccnt[ql], 1u);
+                    if (at < SB_CAND) cbuf[ql * SB_CAND + at] = key;
+                    else {
+                        const unsigned long long g = atomicAdd(&a.counters[CTR_CANDS], 1ull);
+                        if (g < a.cand_cap) a.cands[g] = key;
+                        s_over[ql] = 1u;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // ---- hand-over: up to QCAND_SLOTS candidates stay in the query's own slots, more move to the shared list entirely
+    __syncthreads();
+    if (tid < nq) {
+        const uint32_t c = min(s_ccnt[tid], SB_CAND);
+        const bool shared = s_over[tid] != 0u || c > QCAND_SLOTS;
+        s_cbase[tid] = 0u;
+        if (shared && c != 0u) {
+            const unsigned long long g = atomicAdd(&a.counters[CTR_CANDS], (unsigned long long)c);
+            s_cbase[tid] = (uint32_t)g;           // (cand_cap < 2^32 is not assumed: see below)
+            s_over[tid] = 1u + (uint32_t)(g >> 32);
+        } else {
+            s_over[tid] = shared ? 1u : 0u;
+        }
+        const uint32_t q = q0 + tid;
+        if (q < a.B) a.qcand_n[q] = shared ? QCAND_OVERFLOWED : c;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nq * SB_CAND; i += SB_WG) {
+        const uint32_t ql = i / SB_CAND, k = i % SB_CAND, q = q0 + ql;
+        if (q >= a.B || k >= min(s_ccnt[ql], SB_CAND)) continue;
+        const uint64_t key = cbuf[i];
+        if (s_over[ql] == 0u) a.qcand[(size_t)q * QCAND_SLOTS + k] = key;
+        else {
+            const uint64_t g = (((uint64_t)(s_over[ql] - 1u)) << 32 | s_cbase[ql]) + k;
+            if (g < a.cand_cap) a.cands[g] = key;
+        }
+    }
+}
+
+}  // namespace fpx

@@ -42,6 +42,7 @@
 #include "fpx_group.hpp"
 #include "fpx_probe_small.hpp"
 #include "fpx_score.hpp"
+#include "fpx_score_bin.hpp"
 
 namespace fpx {
 
@@ -400,11 +401,28 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     uint32_t* d_qcount = nullptr;
     uint64_t est_H = 0;
     constexpr size_t BINQ_HEAD = 64 / sizeof(uint32_t);                          // room for the BinArgs the kernels read
+    // ... and its short form when the records come from groups of direct-addressed segments alone: k_probe_group drops them
+    // into bins of 2^BQ queries itself and k_score_bin scores a bin per workgroup (fpx_score_bin.hpp) -- no partition kernels
+    static const uint32_t bin_q_log2 = [] { const char* e = getenv("FPX_BIN_Q_LOG2"); return e ? (uint32_t)atoi(e) : 3u; }();
+    static const bool binned_enabled = [] { const char* e = getenv("FPX_BINNED"); return e ? atoi(e) != 0 : true; }();
+    bool binned = false;
+    uint32_t sbins = 0;
+    if (fast && binned_enabled && flagged && snap->n_group != 0 && snap->n_solo == 0 && bin_q_log2 >= 1u && bin_q_log2 <= 4u) {
+        uint32_t floor_lo = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < B; ++q) {
+            const uint64_t raw_len = offsets[q + 1] - offsets[q];
+            floor_lo = std::min(floor_lo, opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20));
+        }
+        sbins = (B + (1u << bin_q_log2) - 1u) >> bin_q_log2;
+        // (a floor of 1 or 2 -- the legacy protocol's -- makes every counted doc a candidate: k_score's count-only round, which
+        // raises the floor to top * pct / 100 before anything is emitted, handles those)
+        binned = floor_lo > 2u && sbins <= MAX_SBINS;
+    }
     if (fast) {
         est_H = (uint64_t)((double)ws->hint_H * (double)P / (double)ws->hint_P) + 1024;
-        const size_t want = (size_t)(2 * est_H + (1u << 16));                   // bins get 2x their expected fill
+        const size_t want = (size_t)(2 * est_H + (1u << 16)) + (binned ? (size_t)sbins * 8192u : 0u);      // bins get 2x their expected fill
         if (ws->cap_hits < want && (rc = grow_pair(ws->d_hits, &ws->cap_hits, want))) return rc;
-        const size_t words = BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE + (size_t)B + 64;
+        const size_t words = BINQ_HEAD + (size_t)std::max<uint32_t>(MAX_BINS, sbins) * BIN_STRIDE + (size_t)B + 64 + sbins;
         if (words > ws->cap_binq) {
             if (ws->d_binq) (void)hipFree(ws->d_binq);
             if (ws->d_qcursor) (void)hipFree(ws->d_qcursor);
@@ -414,15 +432,24 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             FPX_HIP(hipMalloc(&ws->d_qcursor, ncap * sizeof(unsigned long long)));
             ws->cap_binq = ncap;
         }
-        if (!ws->h_bins) FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_bins), (BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE) * sizeof(uint32_t)));
+        if (!ws->h_bins) FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_bins), (BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE + MAX_SBINS) * sizeof(uint32_t)));
         d_bin_count = ws->d_binq + BINQ_HEAD;
-        d_qcount = d_bin_count + (size_t)MAX_BINS * BIN_STRIDE;
-        h_bin.bins = ws->d_hits[0]; h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
-        // a bin holds at most 4x its expected share (never more than its slice of the buffer): the level-2 grids are sized by
-        // this capacity, and a workspace that has seen a huge batch must not launch that batch's grids for a small one
-        h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / h_bin.nbins, std::max<uint64_t>(4 * est_H / h_bin.nbins, 1u << 16));
+        d_qcount = d_bin_count + (size_t)std::max<uint32_t>(MAX_BINS, sbins) * BIN_STRIDE;
+        h_bin.bins = ws->d_hits[0];
         h_bin.bin_count = d_bin_count;
-        FPX_HIP(hipMemsetAsync(d_bin_count, 0, ((size_t)MAX_BINS * BIN_STRIDE + B) * sizeof(uint32_t), st));
+        if (binned) {
+            h_bin.nbins = sbins; h_bin.shift = bin_q_log2;
+            // twice the expected share + room for the spread of a small bin; a bin that overflows is seen after the batch's
+            // synchronisation and the batch is redone on the general path
+            h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / sbins, std::max<uint64_t>(2 * est_H / sbins + 8192, 16384));
+            FPX_HIP(hipMemsetAsync(d_bin_count, 0, (size_t)sbins * BIN_STRIDE * sizeof(uint32_t), st));
+        } else {
+            h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
+            // a bin holds at most 4x its expected share (never more than its slice of the buffer): the level-2 grids are sized by
+            // this capacity, and a workspace that has seen a huge batch must not launch that batch's grids for a small one
+            h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / h_bin.nbins, std::max<uint64_t>(4 * est_H / h_bin.nbins, 1u << 16));
+            FPX_HIP(hipMemsetAsync(d_bin_count, 0, ((size_t)MAX_BINS * BIN_STRIDE + B) * sizeof(uint32_t), st));
+        }
     }
     bool force_generic = false, used_lean = false, spread = false, used_fused = false;
     for (int attempt = 0;; ++attempt) {
@@ -462,14 +489,21 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 if (snap->n_group) {
                     ProbeArgs gk = a;
                     gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
+                    if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; }
                     static const uint32_t group_rounds = [] { const char* e = getenv("FPX_GROUP_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
                     gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_group / 8192));
                     const uint64_t per_wg_gk = (uint64_t)FK_WG * gk.rounds;
                     for (const GroupDesc& gd : snap->h_group) {              // one launch per group: its descriptor is a kernel argument
                         const GroupArgs gargs{gd, snap->d_direct};
                         const dim3 gridg((uint32_t)((P + per_wg_gk - 1) / per_wg_gk));
-                        if (snap->groups[&gd - snap->h_group.data()]->ns == 8u) hipLaunchKernelGGL(k_probe_group<8>, gridg, dim3(FK_WG), 0, st, gk, gargs);
-                        else hipLaunchKernelGGL(k_probe_group<16>, gridg, dim3(FK_WG), 0, st, gk, gargs);
+                        const bool ns8 = snap->groups[&gd - snap->h_group.data()]->ns == 8u;
+                        if (binned) {
+                            if (ns8) hipLaunchKernelGGL((k_probe_group<8, true>), gridg, dim3(FK_WG), 0, st, gk, gargs);
+                            else hipLaunchKernelGGL((k_probe_group<16, true>), gridg, dim3(FK_WG), 0, st, gk, gargs);
+                        } else {
+                            if (ns8) hipLaunchKernelGGL((k_probe_group<8, false>), gridg, dim3(FK_WG), 0, st, gk, gargs);
+                            else hipLaunchKernelGGL((k_probe_group<16, false>), gridg, dim3(FK_WG), 0, st, gk, gargs);
+                        }
                     }
                     used_fused = true;
                 }
@@ -602,15 +636,28 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     if (fast) {
         // ---- 5': bins -> per-query ranges (level 2 of fpx_partition.hpp), count, finish; sizes stay on the device
         const uint32_t tiles = (uint32_t)std::min<uint64_t>((h_bin.bin_cap + L2_TILE - 1) / L2_TILE, 0x7FFFFFFFull / 256u);
-        const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((2 * est_H + BIN_TILE - 1) / BIN_TILE, 8192u);
+        const uint32_t bin_grid = binned ? 64u : (uint32_t)std::min<uint64_t>((2 * est_H + BIN_TILE - 1) / BIN_TILE, 8192u);
+        // (binned: only what k_probe_group could not place itself -- normally nothing -- is in the misc buffer)
         hipLaunchKernelGGL(k_bin, dim3(std::max(1u, bin_grid)), dim3(256), 0, st, h_bin, (const uint64_t*)ws->d_hits[1],
                            (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
-        hipLaunchKernelGGL(k_l2_count, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, d_qcount, B);
         if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;
         if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1)))) return rc;
         uint64_t* d_qcand = ws->d_qcand;
         uint32_t* d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
         uint32_t* d_heavy = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS + (size_t)B / 2 + 1);
+        const size_t cand_guess0 = std::max<size_t>(1u << 16, (size_t)B * 64);
+        if (ws->cap_cands < cand_guess0 && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess0))) return rc;
+        uint32_t* d_bin_n = d_qcount + B + 64;
+        const uint32_t sbf = 32u - qb;
+        if (binned) {
+            ScoreBinArgs sa{};
+            sa.bins = h_bin.bins; sa.bin_cap = h_bin.bin_cap; sa.bin_count = h_bin.bin_count; sa.bq = h_bin.shift; sa.B = B;
+            sa.opts = d_opts; sa.sb = 32u - qb; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
+            sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
+            const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << h_bin.shift) * 8u;
+            hipLaunchKernelGGL(k_score_bin, dim3(sbins), dim3(SB_WG), sb_lds, st, sa);
+        } else {
+        hipLaunchKernelGGL(k_l2_count, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, d_qcount, B);
         hipLaunchKernelGGL(k_l2_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)d_qcount, B, ws->d_qrange, ws->d_qcursor, d_qcand_n,
                            &ws->d_counters[CTR_TOTAL]);
         hipLaunchKernelGGL(k_l2_scatter, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, ws->d_qcursor, B, ws->d_hits[1], (uint64_t)ws->cap_hits);
@@ -635,7 +682,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         (void)lds_attrs_f;
         const bool short_queries = est_H / B <= (uint64_t)WG * 8u;
         const size_t score_lds = ((size_t)8 << log2t) + ((size_t)4 << log2f);
-        const uint32_t sbf = 32u - qb;
         if (short_queries)
             hipLaunchKernelGGL((k_score<8, false>), dim3(B), dim3(WG), score_lds, st,
                                (const uint64_t*)ws->d_hits[1], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sbf, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
@@ -648,6 +694,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         hipLaunchKernelGGL((k_score<32, true>), dim3(std::min<uint32_t>(B, 256u)), dim3(WG), score_lds, st,
                            (const uint64_t*)ws->d_hits[1], (const uint64_t*)ws->d_qrange, d_opts, log2f | (log2t << 8), sbf, ws->d_cands[0], (uint64_t)ws->cap_cands, ws->d_counters,
                            (uint64_t)0, d_qcand, d_qcand_n, d_heavy, cancel);
+        }       // (!binned)
         fpx_result* d_res = partial ? out : ws->d_out;
         uint32_t* d_res_n = partial ? out_n : ws->d_out_n;
         // optimistic finish: every query's candidates fit its own slots (C == 0); redone below after a sort otherwise
@@ -660,19 +707,24 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         bool staged = false;
         if (!partial && (rc = stage_results(ws, B, out_cap, st, &staged))) return rc;
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_count, (size_t)h_bin.nbins * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (binned) FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_n, (size_t)sbins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        else FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_count, (size_t)h_bin.nbins * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         FPX_HIP(hipEventRecord(ws->ev_end, st));
         FPX_SYNC(ws);
         // ---- the one look at what happened
         bool redo = false, hits_short = false;
-        uint64_t worst_bin = 0;
-        for (uint32_t i = 0; i < h_bin.nbins; ++i) worst_bin = std::max<uint64_t>(worst_bin, ws->h_bins[BINQ_HEAD + (size_t)i * BIN_STRIDE]);
+        uint64_t worst_bin = 0, bin_total = 0;
+        for (uint32_t i = 0; i < h_bin.nbins; ++i) {
+            const uint64_t c = ws->h_bins[BINQ_HEAD + (binned ? (size_t)i : (size_t)i * BIN_STRIDE)];
+            worst_bin = std::max<uint64_t>(worst_bin, c);
+            bin_total += c;
+        }
         const uint64_t misc = ws->h_counters[CTR_HITS];
-        H = ws->h_counters[CTR_TOTAL];
+        H = binned ? bin_total : ws->h_counters[CTR_TOTAL];
         if (worst_bin > h_bin.bin_cap || misc > ws->cap_hits || H > ws->cap_hits) { redo = true; hits_short = true; }
         if (used_lean)
             for (uint32_t i = 0; i < snap->n_lean; ++i) redo = redo || ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE] > def_cap;
-        if (ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands) redo = true;
+        if (ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands || ws->h_counters[CTR_BINFAIL] != 0) redo = true;
         if (redo) {
             if (hits_short) {           // room for what this batch really produced, so that neither path trips over it again
                 const size_t need = (size_t)std::max<uint64_t>(std::max<uint64_t>(worst_bin * h_bin.nbins, misc), H) * 5 / 4 + 1024;
@@ -732,7 +784,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probe_kernel_fetched_bytes += ln ? reads * 128ull : snap->n_direct ? ws->h_counters[CTR_LEAN_READS] * 64ull + (snap->n_file ? ws->h_counters[CTR_BYTES] : 0ull)
                                                                      : ws->h_counters[CTR_BYTES];
             stats->probe_aux_ms += aux;
-            stats->path_flags |= 1u | (Cf ? 2u : 0u) | (used_fused ? 4u : 0u);
+            stats->path_flags |= 1u | (Cf ? 2u : 0u) | (used_fused ? 4u : 0u) | (binned ? 8u : 0u);
         }
         ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);
         ws->hint_def = 0;

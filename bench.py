@@ -124,7 +124,7 @@ def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
     the sorted pairs (8 B per probe and segment).
     Direct-addressed segments: the lines of `primary` / `extras` it read (counted: one per present hash, one more per hash
     with several docs; a 4-byte word brings its 128-byte line) + for k_probe_direct the 128-B lines of 64-B records its probes
-    touch (expected value) and the pairs per segment, for k_probe_fused ONE directory line and one pair per hash (both counted)."""
+    touch (expected value) and the pairs per segment, for k_probe_group ONE directory line and one pair per hash (both counted)."""
     files = [sg for sg in segs if sg.kind == "file"]
     if not files:
         return {"blocks": fetched_per_launch, "probe_records": 0.0, "pairs": 0.0, "total": fetched_per_launch}
@@ -143,7 +143,7 @@ def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
 def dominant_kernel(segs, fused=False):
     files = [sg for sg in segs if sg.kind == "file"]
     if files and all(getattr(sg, "direct", False) for sg in files):
-        return "k_probe_fused" if fused else "k_probe_direct"
+        return "k_probe_group" if fused else "k_probe_direct"
     return "k_probe_lean8"
 
 
@@ -224,9 +224,9 @@ def run_pmc_child(args, docs, timeout_s=420):
         if p.returncode != 0:
             return None, f"rocprofv3 child exited {p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
         by = parse_pmc_dir(d)
-        main = next((k for k in ("k_probe_fused", "k_probe_direct") if by and by.get(k)), "k_probe_lean8")
+        main = next((k for k in ("k_probe_group", "k_probe_direct") if by and by.get(k)), "k_probe_lean8")
         if not by or not by.get(main):
-            return None, "no k_probe_fused / k_probe_direct / k_probe_lean8 dispatch in the counter output"
+            return None, "no k_probe_group / k_probe_direct / k_probe_lean8 dispatch in the counter output"
         child = None
         for line in p.stdout.decode(errors="replace").splitlines():
             if line.startswith('{"pmc_child"'):
@@ -263,7 +263,7 @@ def stored_traffic(docs, S, H, B, qlen):
                 continue
             if tr.get("kernel_source_sha16") != kernel_source_hash():
                 continue
-            k = next((k for k in ("k_probe_fused", "k_probe_direct") if k in tr), "k_probe_lean8")
+            k = next((k for k in ("k_probe_group", "k_probe_direct") if k in tr), "k_probe_lean8")
             return tr[k]["hbm_read_bytes_per_launch_corrected"], f"profiles/{name}@{tr['kernel_source_sha16']}"
         except (OSError, KeyError, ValueError):
             continue

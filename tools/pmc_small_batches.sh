@@ -15,7 +15,7 @@ for b in (64, 256, 1024):
     f = glob.glob("$O/b%d/*counter_collection.csv" % b)
     per = collections.OrderedDict(); dur = {}
     for r in csv.DictReader(open(f[0])):
-        if any(k in r["Kernel_Name"] for k in ("k_probe_fused", "k_probe_direct", "k_probe_lean8")) and r["Counter_Name"] == "FETCH_SIZE":
+        if any(k in r["Kernel_Name"] for k in ("k_probe_group", "k_probe_direct", "k_probe_lean8")) and r["Counter_Name"] == "FETCH_SIZE":
             d = int(r["Dispatch_Id"]); per[d] = per.get(d, 0.0) + float(r["Counter_Value"])
             dur[d] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     last = sorted(per)[-3:]

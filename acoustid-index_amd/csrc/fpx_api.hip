@@ -183,11 +183,62 @@ int finish_file_segment(Segment* s)
     FPX_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_total);
     s->num_items = total;
-    // a dense segment trades its blocks for the direct-addressed form (fpx_direct.hpp); the others keep them
-    if ((rc = build_direct(s))) return rc;
-    if (s->direct) return FPX_OK;
+    // A dense segment will trade its blocks for the direct-addressed form -- as a column of a GROUP of such segments
+    // (fpx_group.hpp) or on its own (fpx_direct.hpp).  Which of the two is known when a snapshot first holds it
+    // (resolve_candidates, below): until then it keeps its blocks and nothing else is derived from them.
+    bool cand = false;
+    if ((rc = direct_candidate(s, &cand))) return rc;
+    s->candidate = cand;
+    if (cand) return FPX_OK;
     if ((rc = build_presence(s))) return rc;
     return decode_small_segment(s);
+}
+
+// what the block kernels need of a candidate that stays in blocks after all (no room for another form)
+static int settle_in_blocks(Segment* s)
+{
+    if (s->d_proberec || s->d_small_items || s->settled) return FPX_OK;
+    s->settled = true;
+    int rc = build_presence(s);
+    if (rc) return rc;
+    return decode_small_segment(s);
+}
+
+// Called by fpx_snapshot_create (under Ctx::group_mu) with the file segments of this context that a new snapshot holds: the
+// candidates among them that are still in blocks, and direct-addressed ones still on their own, move into groups of up to 16
+// -- FPX_FUSE_MIN (default 2; 0: never) or more at a time, segments with the same hash window together, in snapshot order.
+// What is left over becomes direct-addressed on its own, or (no room, a hash-window slice) settles in its blocks.
+int resolve_candidates(Ctx* c, const std::vector<Segment*>& segs)
+{
+    static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
+    std::vector<Segment*> lone;
+    for (Segment* s : segs)
+        if (s->kind == 0 && s->ctx == c && !s->home && ((s->candidate && s->d_blocks) || s->direct)) lone.push_back(s);
+    std::vector<bool> done(lone.size(), false);
+    for (size_t i = 0; fuse_min != 0 && i < lone.size(); ++i) {
+        if (done[i]) continue;
+        std::vector<Segment*> batch;
+        std::vector<size_t> idx;
+        for (size_t j = i; j < lone.size() && batch.size() < FUSE_MAX; ++j) {
+            if (done[j]) continue;
+            const Segment* a = lone[i]; const Segment* b = lone[j];
+            if (a->own_flags != b->own_flags || ((a->own_flags & 1u) && a->own_lo != b->own_lo) || ((a->own_flags & 2u) && a->own_hi != b->own_hi)) continue;
+            batch.push_back(lone[j]); idx.push_back(j);
+        }
+        for (size_t j : idx) done[j] = true;
+        if (batch.size() < fuse_min) continue;
+        std::shared_ptr<Group> g;
+        const int grc = group_segments(c, batch.data(), (uint32_t)batch.size(), &g);
+        if (grc == FPX_E_DEVICE || grc == FPX_E_INVAL) return grc;
+        // (FPX_E_NOMEM: they stay as they are)
+    }
+    for (Segment* s : lone) {
+        if (s->home || s->direct) continue;
+        int rc = build_direct(s);
+        if (rc) return rc;
+        if (!s->direct && (rc = settle_in_blocks(s))) return rc;
+    }
+    return FPX_OK;
 }
 
 }  // namespace fpx
@@ -501,6 +552,11 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     }
     std::vector<uint32_t> dead;
     std::vector<Segment*> direct_segs;               // parallel to sn->h_direct
+    std::lock_guard<std::mutex> group_lock(c->group_mu);      // (the segments' forms must not change under the descriptors built below)
+    {
+        const int rrc = resolve_candidates(c, sn->segs);
+        if (rrc != FPX_OK) { snapshot_free(sn); return rrc; }
+    }
     for (size_t i = 0; i < sn->segs.size(); ++i) {
         Segment* s = sn->segs[i];
         // docs-only members: explicit stand-ins (kind 2) and segments resident on ANOTHER context's device -- in a sharded
@@ -570,24 +626,10 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         e = hipMalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_direct, sn->h_direct.data(), sn->n_direct * sizeof(SegDesc), hipMemcpyHostToDevice);
         // Direct-addressed segments are searched in GROUPS of up to 16 (fpx_group.hpp: one directory line and one run of words
-        // answer a hash for the whole group).  A segment that already lives in a group is probed there (the group's other
-        // columns masked out if they are not part of this snapshot); the ones still on their own are grouped now, in snapshot
-        // order, FPX_FUSE_MIN (default 2; 0: never) or more at a time -- fewer than that, or when HBM is short, stay alone
-        // and are probed one by one (k_probe_direct).
-        static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
+        // answer a hash for the whole group; resolve_candidates, above, formed them).  A group whose other columns are not part
+        // of this snapshot is probed with those masked out; segments on their own one by one (k_probe_direct).
         std::vector<SegDesc> h_solo;
         {
-            std::lock_guard<std::mutex> lk(c->group_mu);
-            std::vector<Segment*> lone;
-            for (Segment* sg : direct_segs) if (!sg->home) lone.push_back(sg);
-            for (size_t i0 = 0; fuse_min != 0 && i0 < lone.size(); i0 += FUSE_MAX) {
-                const uint32_t k = (uint32_t)std::min<size_t>(FUSE_MAX, lone.size() - i0);
-                if (k < fuse_min) break;
-                std::shared_ptr<Group> g;
-                const int grc = group_segments(c, lone.data() + i0, k, &g);
-                if (grc == FPX_E_DEVICE) { snapshot_free(sn); return grc; }
-                if (grc != FPX_OK) break;                      // (no room: they stay on their own)
-            }
             for (uint32_t i = 0; i < sn->n_direct; ++i) {
                 Segment* sg = direct_segs[i];
                 if (!sg->home) { h_solo.push_back(sn->h_direct[i]); sn->solo_stores.push_back(sg->dstore); continue; }

@@ -601,8 +601,11 @@ int decode_small_segment(Segment* s)
         (rc = live.alloc(s->num_items + 16)))
         return rc;
     FPX_HIP(hipMalloc(&s->d_small_items, (s->num_items + 1) * sizeof(uint64_t)));
-    FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)s->num_blocks + 1) * sizeof(uint32_t)));
-    s->device_bytes += (s->num_items + 1) * sizeof(uint64_t) + ((size_t)s->num_blocks + 1) * sizeof(uint32_t);
+    if (!s->d_bstart) {
+        FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)s->num_blocks + 1) * sizeof(uint32_t)));
+        s->device_bytes += ((size_t)s->num_blocks + 1) * sizeof(uint32_t);
+    }
+    s->device_bytes += (s->num_items + 1) * sizeof(uint64_t);
     hipLaunchKernelGGL(k_block_item_counts, dim3((s->num_blocks + 255) / 256), dim3(256), 0, st,
                        s->d_blocks, s->block_size, s->num_blocks, counts.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)s->num_blocks,
@@ -619,8 +622,10 @@ int decode_small_segment(Segment* s)
 
 // Presence bits of a big segment: one wave per block decodes the block's hashes (the hash half of k_decode_items) and
 // sets the bit of each -- in the probe records (SegDesc::proberec): bit pi = h >> shift lives in record pi >> 8, word (pi >> 5) & 7.
+// (h_lo, h_hi, rec0: only hashes of that range, into records counted from rec0 -- the direct-addressed form of a hash range)
 __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t num_blocks,
-                                                       uint32_t* __restrict__ proberec, uint32_t shift)
+                                                       uint32_t* __restrict__ proberec, uint32_t shift,
+                                                       uint32_t h_lo = 0u, uint32_t h_hi = 0xFFFFFFFFu, uint32_t rec0 = 0u)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -654,9 +659,10 @@ __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t i = qi * 4u + k;
             if (act && i < n_items) {
-                const uint32_t hv = (h[k] + base) >> shift;
+                const uint32_t hfull = h[k] + base, hv = hfull >> shift;
                 // (equal neighbours set the same bit: skip the repeat inside the quad)
-                if (k == 0 || h[k] != h[k - 1]) atomicOr(&proberec[(size_t)(hv >> 8) * 16u + ((hv >> 5) & 7u)], 1u << (hv & 31u));
+                if ((k == 0 || h[k] != h[k - 1]) && hfull >= h_lo && hfull <= h_hi)
+                    atomicOr(&proberec[(size_t)((hv >> 8) - rec0) * 16u + ((hv >> 5) & 7u)], 1u << (hv & 31u));
             }
         }
     }
@@ -801,19 +807,19 @@ __device__ RunInfo direct_run_info(const uint64_t* __restrict__ items, uint64_t 
 // per block: distinct hashes whose run STARTS in it, and the `extras` words those with several docs need
 __global__ __launch_bounds__(256) void k_direct_count(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
                                                       uint32_t nb, uint32_t* __restrict__ ns, uint32_t* __restrict__ nx, int* __restrict__ flags,
-                                                      uint32_t pad)
+                                                      uint32_t pad, HashRange hr)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint64_t bs = boff[b], be = boff[b + 1];
-    if (b + 1u < nb && ((be - bs) & 3ull) != 0ull) flags[0] = 1;    // not the encoder's chunks of four: the blocks could not be rebuilt
+    if (hr.whole && b + 1u < nb && ((be - bs) & 3ull) != 0ull) flags[0] = 1;    // not the encoder's chunks of four: the blocks could not be rebuilt
     uint32_t prevh = bs ? (uint32_t)(items[bs - 1] >> 32) : 0u;
     bool have_prev = bs != 0;
     uint32_t c_s = 0;
     uint64_t c_x = 0;
     for (uint64_t i = bs; i < be; ++i) {
         const uint32_t h = (uint32_t)(items[i] >> 32);
-        if (!have_prev || h != prevh) {
+        if ((!have_prev || h != prevh) && h >= hr.lo && h <= hr.hi) {
             ++c_s;
             if (i + 1 < n && (uint32_t)(items[i + 1] >> 32) == h) {
                 const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
@@ -829,9 +835,9 @@ __global__ __launch_bounds__(256) void k_direct_count(const uint64_t* __restrict
 }
 
 // rank of hash h among the set bits of the records (needs words 8..10 in place)
-__device__ __forceinline__ uint64_t direct_rank(const uint32_t* __restrict__ drec, uint32_t h)
+__device__ __forceinline__ uint64_t direct_rank(const uint32_t* __restrict__ drec, uint32_t h, uint32_t rec0 = 0u)
 {
-    const uint32_t* rec = drec + (size_t)(h >> 8) * 16u;
+    const uint32_t* rec = drec + (size_t)((h >> 8) - rec0) * 16u;
     const uint32_t w = (h >> 5) & 7u, bit = h & 31u;
     const uint32_t pre = ((w < 4u ? rec[9] : rec[10]) >> (8u * (w & 3u))) & 0xFFu;
     return (uint64_t)rec[8] + pre + (uint32_t)__popc(rec[w] & ((1u << bit) - 1u));
@@ -845,7 +851,7 @@ __device__ __forceinline__ uint64_t direct_rank(const uint32_t* __restrict__ dre
 __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
                                                      uint32_t nb, uint32_t min_doc, const uint32_t* __restrict__ drec,
                                                      const uint64_t* __restrict__ xbase, uint32_t* __restrict__ primary,
-                                                     uint32_t* __restrict__ extras, uint32_t pad)
+                                                     uint32_t* __restrict__ extras, uint32_t pad, HashRange hr)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
@@ -856,8 +862,8 @@ __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict_
     for (uint64_t i = bs; i < be; ++i) {
         const uint64_t it = items[i];
         const uint32_t h = (uint32_t)(it >> 32);
-        if (!have_prev || h != prevh) {
-            const uint64_t r = direct_rank(drec, h);
+        if ((!have_prev || h != prevh) && h >= hr.lo && h <= hr.hi) {
+            const uint64_t r = direct_rank(drec, h, hr.rec0);
             if (i + 1 < n && (uint32_t)(items[i + 1] >> 32) == h) {
                 const RunInfo ri = direct_run_info(items, n, boff, nb, b, i);
                 const uint64_t cnt = ri.end - i;
@@ -881,31 +887,34 @@ __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict_
 // the records next to the presence bits (and their words of `primary` say so): a clear bit then means "absent, one block
 // visited", which is what a probe of an absent hash costs the reference everywhere else.
 __global__ __launch_bounds__(256) void k_direct_gap_bits(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
-                                                         uint32_t nb, uint32_t* __restrict__ drec)
+                                                         uint32_t nb, uint32_t* __restrict__ drec, HashRange hr, uint32_t has_prev, uint32_t prev_last)
 {
     // one workgroup per block boundary, strided: a grid of nb + 1 workgroups x 256 threads passes 2^32 work-items beyond
-    // 16.7 M blocks, which a launch silently truncates
-    for (uint64_t b = 1 + blockIdx.x; b < nb; b += gridDim.x) {       // (before the first and beyond the last hash: SegDesc::first_hash / last_hash)
+    // 16.7 M blocks, which a launch silently truncates.  Boundary 0 (a hash range of a segment: the gap between the last hash of
+    // the block before the first one decoded, `prev_last`, and the first hash here) exists only with has_prev.
+    for (uint64_t b = (has_prev ? 0u : 1u) + blockIdx.x; b < nb; b += gridDim.x) {       // (before the first and beyond the last hash: SegDesc::first_hash / last_hash)
+        if (boff[b] >= n) continue;
         const uint32_t f = (uint32_t)(items[boff[b]] >> 32);
-        const uint32_t p = (uint32_t)(items[boff[b] - 1] >> 32);
+        const uint32_t p = b == 0 ? prev_last : (uint32_t)(items[boff[b] - 1] >> 32);
         if (p == f) continue;                                        // the block continues its predecessor's last run: no gap
-        const int64_t lo = (int64_t)p + 1, hi = (int64_t)f - 1;
+        int64_t lo = (int64_t)p + 1, hi = (int64_t)f - 1;
+        lo = std::max<int64_t>(lo, (int64_t)hr.lo); hi = std::min<int64_t>(hi, (int64_t)hr.hi);
         if (lo > hi) continue;
         const uint32_t wlo = (uint32_t)(lo >> 5), whi = (uint32_t)(hi >> 5);
         for (uint64_t w = (uint64_t)wlo + threadIdx.x; w <= whi; w += 256u) {
             uint32_t mask = 0xFFFFFFFFu;
             if (w == wlo) mask &= 0xFFFFFFFFu << (uint32_t)(lo & 31);
             if (w == whi) mask &= 0xFFFFFFFFu >> (31u - (uint32_t)(hi & 31));
-            atomicOr(&drec[(size_t)(w >> 3) * 16u + (w & 7u)], mask);
+            atomicOr(&drec[(size_t)((w >> 3) - hr.rec0) * 16u + (w & 7u)], mask);
         }
     }
 }
 
 // words 9, 10 of every record: how many bits are set below each of its eight words; its total for the rank scan
-__global__ __launch_bounds__(256) void k_direct_rec_counts(uint32_t* __restrict__ drec, uint32_t* __restrict__ rectot)
+__global__ __launch_bounds__(256) void k_direct_rec_counts(uint32_t* __restrict__ drec, uint32_t* __restrict__ rectot, uint32_t nrec = DIRECT_NREC)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= DIRECT_NREC) return;
+    if (r >= nrec) return;
     uint32_t* rec = drec + (size_t)r * 16u;
     uint32_t run = 0, p0 = 0, p1 = 0;
 #pragma unroll
@@ -918,10 +927,10 @@ __global__ __launch_bounds__(256) void k_direct_rec_counts(uint32_t* __restrict_
 }
 
 // word 8 = rank of the record's first position
-__global__ __launch_bounds__(256) void k_direct_rec_base(uint32_t* __restrict__ drec, const uint64_t* __restrict__ recbase)
+__global__ __launch_bounds__(256) void k_direct_rec_base(uint32_t* __restrict__ drec, const uint64_t* __restrict__ recbase, uint32_t nrec = DIRECT_NREC)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < DIRECT_NREC) drec[(size_t)r * 16u + 8u] = (uint32_t)recbase[r];
+    if (r < nrec) drec[(size_t)r * 16u + 8u] = (uint32_t)recbase[r];
 }
 
 __global__ void k_boff_tail(uint64_t* boff, uint32_t nb, const uint64_t* total) { boff[nb] = *total; }
@@ -941,115 +950,201 @@ static uint64_t direct_min_items()
     return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 20);
 }
 
-static void direct_free(Segment* s)
+// item offsets of the blocks [b0, b0 + nbl] relative to block b0, 64-bit (what the conversion kernels index `items` with)
+__global__ void k_local_boff(const uint32_t* __restrict__ bstart, uint32_t nbl, uint64_t* __restrict__ boff)
 {
-    if (s->d_drec) (void)hipFree(s->d_drec);
-    if (s->d_primary) (void)hipFree(s->d_primary);
-    if (s->d_extras) (void)hipFree(s->d_extras);
-    s->d_drec = s->d_primary = s->d_extras = nullptr;
-    s->num_distinct = s->num_positions = s->extras_words = 0;
-    s->direct = false;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nbl) boff[b] = (uint64_t)(bstart[b] - bstart[0]);
 }
 
-// Called for a resident file segment whose blocks, block index and item count are in place.  On success the segment is
-// direct-addressed and its blocks, bucket table and continuation bitmap are FREED; whatever keeps it from qualifying (size,
-// doc id range, memory, blocks not made of four-item chunks, too many gap positions) leaves it block-based, which is always
-// correct.
-int build_direct(Segment* s)
+// what a segment must offer before its blocks may be traded for the direct-addressed form: the encoder's chunks of four items in
+// every block but the last (else the blocks could not be written out again), and not too many GAP positions -- hash values
+// between the last hash of a block and the first of the next (they cost a word each).  From the headers and the block index alone.
+__global__ __launch_bounds__(256) void k_direct_precheck(const uint8_t* __restrict__ blocks, uint32_t block_size, uint32_t nb,
+                                                         const uint32_t* __restrict__ block_index, unsigned long long* __restrict__ out)
 {
-    if (!direct_enabled() || s->kind != 0 || s->own_flags != 0u || s->num_blocks == 0 || s->num_items == 0 ||
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long gaps = 0, bad = 0;
+    if (b < nb) {
+        const uint8_t* blk = blocks + (size_t)b * block_size;
+        const uint32_t n_items = *reinterpret_cast<const uint16_t*>(blk + 4);
+        if (b + 1u < nb && (n_items & 3u) != 0u) bad = 1;
+        if (n_items == 0u) bad = 1;
+        if (b > 0) {
+            const uint32_t f = *reinterpret_cast<const uint32_t*>(blk), p = block_index[b - 1];
+            if (f > p + 1u && f > p) gaps = (unsigned long long)(f - p - 1u);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) { gaps += __shfl_down(gaps, d); bad += __shfl_down(bad, d); }
+    if ((threadIdx.x & 63u) == 0u) { if (gaps) atomicAdd(&out[0], gaps); if (bad) atomicAdd(&out[1], bad); }
+}
+
+// Is this resident file segment (blocks, block index, item count in place) one that may become direct-addressed -- on its own
+// or as a column of a group?  Fills Segment::d_bstart (item offset of every block) and first_hash / last_hash on the way.
+// A hash-window slice (own_flags) qualifies as a column of a group with that window only.
+int direct_candidate(Segment* s, bool* ok)
+{
+    *ok = false;
+    if (!direct_enabled() || s->kind != 0 || s->num_blocks == 0 || s->num_items == 0 ||
         s->num_items < direct_min_items() || s->num_items > 0xFFFFFFFFull ||
         (uint64_t)s->max_doc_id - (uint64_t)s->min_doc_id >= (1ull << 31) || s->max_doc_id < s->min_doc_id)
         return FPX_OK;
+    const uint32_t nb = s->num_blocks;
+    hipStream_t st = 0;
+    int rc;
+    DevBuf out, counts, boff, tot;
+    if ((rc = out.alloc(16)) || (rc = counts.alloc((size_t)nb * 4)) || (rc = boff.alloc(((size_t)nb + 1) * 8)) || (rc = tot.alloc(8))) return rc;
+    FPX_HIP(hipMemsetAsync(out.p, 0, 16, st));
+    hipLaunchKernelGGL(k_direct_precheck, dim3((nb + 255) / 256), dim3(256), 0, st, s->d_blocks, s->block_size, nb, s->d_block_index, out.as<unsigned long long>());
+    unsigned long long h_out[2] = {0, 0};
+    uint32_t h_ends[2] = {0, 0};
+    FPX_HIP(hipMemcpyAsync(h_out, out.p, 16, hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipMemcpyAsync(&h_ends[0], s->d_blocks, 4, hipMemcpyDeviceToHost, st));                                   // min_hash of block 0
+    FPX_HIP(hipMemcpyAsync(&h_ends[1], s->d_block_index + (nb - 1), 4, hipMemcpyDeviceToHost, st));
+    FPX_HIP(hipStreamSynchronize(st));
+    // a gap position costs a word: uniformly spread hashes have 2^32 / (items per block) of them whatever the segment's size
+    // (39 M: 156 MB); a segment whose hashes cluster (more than 2^26 and more than a quarter of its items) keeps its blocks
+    if (h_out[1] != 0 || h_out[0] > std::max<uint64_t>(s->num_items / 4, 1ull << 26)) return FPX_OK;
+    s->first_hash = h_ends[0]; s->last_hash = h_ends[1];
+    if (!s->d_bstart) {
+        FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
+        s->device_bytes += ((size_t)nb + 1) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_block_item_counts, dim3((nb + 255) / 256), dim3(256), 0, st, s->d_blocks, s->block_size, nb, counts.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)nb, boff.as<uint64_t>(), tot.as<uint64_t>());
+        hipLaunchKernelGGL(k_boff_tail, dim3(1), dim3(1), 0, st, boff.as<uint64_t>(), nb, tot.as<uint64_t>());
+        hipLaunchKernelGGL(k_bstart32, dim3((nb + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), nb, s->num_items, s->d_bstart);
+        FPX_HIP(hipGetLastError());
+        FPX_HIP(hipStreamSynchronize(st));
+    }
+    *ok = true;
+    return FPX_OK;
+}
+
+// The direct-addressed arrays (fpx_direct.hpp) of the hashes [hr.lo, hr.hi] of a segment, from its blocks [b0, b0 + nbl): the
+// whole segment (build_direct) or one chunk of the hash space (fpx_group.hip builds a group chunk by chunk from such pieces).
+// The blocks must hold every item of those hashes: b0 = the first block whose max hash >= hr.lo, the last one the first
+// whose max hash > hr.hi.  has_prev / prev_last: the last hash of block b0 - 1 (where the gap positions before b0 begin).
+// FPX_E_INVAL: the piece does not qualify (lists beyond the offsets' 31 bits); FPX_E_NOMEM: out of HBM.
+int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr, uint32_t nrec, bool has_prev, uint32_t prev_last,
+                       DirectPiece* out)
+{
+    hipStream_t st = 0;
+    int rc;
+    *out = DirectPiece{};
+    out->nrec = nrec;
+    FPX_HIP(hipMalloc(&out->drec, (size_t)nrec * 64u));
+    FPX_HIP(hipMemsetAsync(out->drec, 0, (size_t)nrec * 64u, st));
+    DevBuf rectot, recbase, tot;
+    if ((rc = rectot.alloc((size_t)nrec * 4)) || (rc = recbase.alloc((size_t)nrec * 8)) || (rc = tot.alloc(64))) return rc;
+    uint64_t* d_tot = tot.as<uint64_t>();
+    FPX_HIP(hipMemsetAsync(tot.p, 0, 64, st));
+    if (nbl == 0) {                      // no block of the segment reaches into the range: every position clear
+        hipLaunchKernelGGL(k_direct_rec_counts, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, rectot.as<uint32_t>(), nrec);
+        FPX_HIP(hipMalloc(&out->primary, 16 * sizeof(uint32_t)));
+        FPX_HIP(hipMalloc(&out->extras, 16 * sizeof(uint32_t)));
+        FPX_HIP(hipMemsetAsync(out->primary, 0xFF, 16 * sizeof(uint32_t), st));
+        FPX_HIP(hipMemsetAsync(out->extras, 0, 16 * sizeof(uint32_t), st));
+        FPX_HIP(hipStreamSynchronize(st));
+        return FPX_OK;
+    }
+    const uint8_t* blocks = s->d_blocks + (size_t)b0 * s->block_size;
+    uint32_t h_b[2] = {0, 0};
+    FPX_HIP(hipMemcpy(&h_b[0], s->d_bstart + b0, 4, hipMemcpyDeviceToHost));
+    FPX_HIP(hipMemcpy(&h_b[1], s->d_bstart + b0 + nbl, 4, hipMemcpyDeviceToHost));
+    const uint64_t n = (uint64_t)h_b[1] - h_b[0];
+    DevBuf boff, items, ns, nx, xbase, sbase, flags;
+    if ((rc = boff.alloc(((size_t)nbl + 1) * 8)) || (rc = items.alloc(n * 8 + 8)) || (rc = flags.alloc(64))) return rc;
+    FPX_HIP(hipMemsetAsync(flags.p, 0, 64, st));
+    hipLaunchKernelGGL(k_local_boff, dim3((nbl + 256) / 256), dim3(256), 0, st, (const uint32_t*)(s->d_bstart + b0), nbl, boff.as<uint64_t>());
+    hipLaunchKernelGGL(k_decode_items, dim3((nbl + 3) / 4), dim3(256), 0, st, blocks, s->block_size, nbl, s->min_doc_id,
+                       boff.as<uint64_t>(), (const uint32_t*)nullptr, 0u, items.as<uint64_t>(), (uint8_t*)nullptr);
+    // records: presence bits + gap bits, prefix counts, rank bases
+    hipLaunchKernelGGL(k_presence_bits, dim3((nbl + 3) / 4), dim3(256), 0, st, blocks, s->block_size, nbl, out->drec, 0u, hr.lo, hr.hi, hr.rec0);
+    hipLaunchKernelGGL(k_direct_gap_bits, dim3(std::min<uint32_t>(nbl + 1u, 1u << 20)), dim3(256), 0, st, items.as<uint64_t>(), n,
+                       boff.as<uint64_t>(), nbl, out->drec, hr, has_prev ? 1u : 0u, prev_last);
+    hipLaunchKernelGGL(k_direct_rec_counts, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, rectot.as<uint32_t>(), nrec);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rectot.as<uint32_t>(), (uint64_t)nrec, recbase.as<uint64_t>(), d_tot + 3);
+    hipLaunchKernelGGL(k_direct_rec_base, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, recbase.as<uint64_t>(), nrec);
+    FPX_HIP(hipGetLastError());
+    // distinct hashes and list words per block -> list bases
+    if ((rc = ns.alloc((size_t)nbl * 4)) || (rc = nx.alloc((size_t)nbl * 4)) || (rc = sbase.alloc((size_t)nbl * 8)) || (rc = xbase.alloc((size_t)nbl * 8)))
+        return rc;
+    uint64_t h_tot[4] = {0, 0, 0, 0};
+    int h_flags[2] = {0, 0};
+    uint32_t pad = 0;
+    for (;; pad = 1) {             // (list offsets of 31 bits: in words, or in pairs of words when the lists are longer than that)
+        hipLaunchKernelGGL(k_direct_count, dim3((nbl + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nbl,
+                           ns.as<uint32_t>(), nx.as<uint32_t>(), flags.as<int>(), pad, hr);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nbl, sbase.as<uint64_t>(), d_tot + 1);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nx.as<uint32_t>(), (uint64_t)nbl, xbase.as<uint64_t>(), d_tot + 2);
+        FPX_HIP(hipGetLastError());
+        FPX_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        if (pad || h_flags[0] || h_flags[1] || h_tot[2] < 0x7FFFFFF0ull) break;
+    }
+    out->xshift = pad;
+    const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
+    if (Dp < D) { set_error("internal: %llu set bits for %llu distinct hashes", (unsigned long long)Dp, (unsigned long long)D); return FPX_E_DEVICE; }
+    if (h_flags[0] || h_flags[1] || (X >> pad) >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull) return FPX_E_INVAL;      // does not qualify
+    FPX_HIP(hipMalloc(&out->primary, (Dp + 4) * sizeof(uint32_t)));
+    FPX_HIP(hipMalloc(&out->extras, (X + 8) * sizeof(uint32_t)));
+    FPX_HIP(hipMemsetAsync(out->primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
+    FPX_HIP(hipMemsetAsync(out->extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
+    hipLaunchKernelGGL(k_direct_fill, dim3((nbl + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nbl,
+                       s->min_doc_id, (const uint32_t*)out->drec, xbase.as<uint64_t>(), out->primary, out->extras, pad, hr);
+    FPX_HIP(hipGetLastError());
+    FPX_HIP(hipStreamSynchronize(st));
+    out->distinct = D; out->positions = Dp; out->extras_words = X;
+    return FPX_OK;
+}
+
+void DirectPiece::release()
+{
+    if (drec) (void)hipFree(drec);
+    if (primary) (void)hipFree(primary);
+    if (extras) (void)hipFree(extras);
+    drec = primary = extras = nullptr;
+}
+
+// Turns a resident file segment that direct_candidate() accepted into its direct-addressed form ON ITS OWN (k_probe_direct):
+// its blocks, bucket table and continuation bitmap are FREED.  Whatever keeps it from that (memory, lists too long for their
+// offsets) leaves it block-based, which is always correct.
+int build_direct(Segment* s)
+{
+    if (s->own_flags != 0u) return FPX_OK;                   // (a hash-window slice is direct-addressed only as part of a group)
     const uint64_t n = s->num_items;
     const uint32_t nb = s->num_blocks;
     size_t free_b = 0, total_b = 0;
     // peak: the items (8 n) + records (1 GB) + primary and extras (<= ~10 n) on top of the blocks
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 18ull + ((size_t)10 << 30)) { (void)hipGetLastError(); return FPX_OK; }
-    hipStream_t st = 0;
-    auto body = [&]() -> int {
-        int rc;
-        DevBuf counts, boff, tot, items, ns, nx, xbase, sbase, flags, rectot, recbase;
-        if ((rc = counts.alloc((size_t)nb * 4)) || (rc = boff.alloc(((size_t)nb + 1) * 8)) || (rc = tot.alloc(64)) ||
-            (rc = items.alloc(n * 8)) || (rc = flags.alloc(64)))
-            return rc;
-        FPX_HIP(hipMemsetAsync(flags.p, 0, 64, st));
-        hipLaunchKernelGGL(k_block_item_counts, dim3((nb + 255) / 256), dim3(256), 0, st, s->d_blocks, s->block_size, nb, counts.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)nb, boff.as<uint64_t>(), tot.as<uint64_t>());
-        hipLaunchKernelGGL(k_boff_tail, dim3(1), dim3(1), 0, st, boff.as<uint64_t>(), nb, tot.as<uint64_t>());
-        hipLaunchKernelGGL(k_decode_items, dim3((nb + 3) / 4), dim3(256), 0, st, s->d_blocks, s->block_size, nb, s->min_doc_id,
-                           boff.as<uint64_t>(), (const uint32_t*)nullptr, 0u, items.as<uint64_t>(), (uint8_t*)nullptr);
-        FPX_HIP(hipGetLastError());
-        // records: presence bits + gap bits, prefix counts, rank bases
-        FPX_HIP(hipMalloc(&s->d_drec, (size_t)DIRECT_NREC * 64u));
-        FPX_HIP(hipMemsetAsync(s->d_drec, 0, (size_t)DIRECT_NREC * 64u, st));
-        hipLaunchKernelGGL(k_presence_bits, dim3((nb + 3) / 4), dim3(256), 0, st, s->d_blocks, s->block_size, nb, s->d_drec, 0u);
-        hipLaunchKernelGGL(k_direct_gap_bits, dim3(std::min<uint32_t>(nb + 1u, 1u << 20)), dim3(256), 0, st, items.as<uint64_t>(), n,
-                           boff.as<uint64_t>(), nb, s->d_drec);
-        if ((rc = rectot.alloc((size_t)DIRECT_NREC * 4)) || (rc = recbase.alloc((size_t)DIRECT_NREC * 8))) return rc;
-        uint64_t* d_tot = tot.as<uint64_t>();
-        hipLaunchKernelGGL(k_direct_rec_counts, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, rectot.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rectot.as<uint32_t>(), (uint64_t)DIRECT_NREC, recbase.as<uint64_t>(), d_tot + 3);
-        hipLaunchKernelGGL(k_direct_rec_base, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, recbase.as<uint64_t>());
-        // distinct hashes and list words per block -> list bases
-        if ((rc = ns.alloc((size_t)nb * 4)) || (rc = nx.alloc((size_t)nb * 4)) || (rc = sbase.alloc((size_t)nb * 8)) || (rc = xbase.alloc((size_t)nb * 8)))
-            return rc;
-        uint64_t h_tot[4] = {0, 0, 0, 0};
-        int h_flags[2] = {0, 0};
-        uint64_t h_ends[2] = {0, 0};
-        uint32_t pad = 0;
-        for (;; pad = 1) {             // (list offsets of 31 bits: in words, or in pairs of words when the lists are longer than that)
-            hipLaunchKernelGGL(k_direct_count, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
-                               ns.as<uint32_t>(), nx.as<uint32_t>(), flags.as<int>(), pad);
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nb, sbase.as<uint64_t>(), d_tot + 1);
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nx.as<uint32_t>(), (uint64_t)nb, xbase.as<uint64_t>(), d_tot + 2);
-            FPX_HIP(hipGetLastError());
-            FPX_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipMemcpyAsync(&h_ends[0], items.as<uint64_t>(), 8, hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipMemcpyAsync(&h_ends[1], items.as<uint64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, st));
-            FPX_HIP(hipStreamSynchronize(st));
-            if (pad || h_flags[0] || h_flags[1] || h_tot[2] < 0x7FFFFFF0ull) break;
-        }
-        s->extras_shift = pad;
-        s->first_hash = (uint32_t)(h_ends[0] >> 32); s->last_hash = (uint32_t)(h_ends[1] >> 32);
-        if (h_tot[0] != n) { set_error("internal: decoded %llu items of %llu", (unsigned long long)h_tot[0], (unsigned long long)n); return FPX_E_DEVICE; }
-        const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
-        if (Dp < D) { set_error("internal: %llu set bits for %llu distinct hashes", (unsigned long long)Dp, (unsigned long long)D); return FPX_E_DEVICE; }
-        // a gap position costs a word of `primary`: uniformly spread hashes have 2^32 / (items per block) of them whatever
-        // the segment's size (39 M: 156 MB); a segment whose hashes cluster (long empty stretches at block boundaries: more
-        // than 2^26 and more than a quarter of its items) keeps its blocks
-        const bool gaps_ok = Dp - D <= std::max<uint64_t>(n / 4, 1ull << 26);
-        if (h_flags[0] || h_flags[1] || (X >> pad) >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull || !gaps_ok) return FPX_E_INVAL;      // does not qualify
-        FPX_HIP(hipMalloc(&s->d_primary, (Dp + 4) * sizeof(uint32_t)));
-        FPX_HIP(hipMalloc(&s->d_extras, (X + 8) * sizeof(uint32_t)));
-        FPX_HIP(hipMemsetAsync(s->d_primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
-        FPX_HIP(hipMemsetAsync(s->d_extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
-        hipLaunchKernelGGL(k_direct_fill, dim3((nb + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nb,
-                           s->min_doc_id, (const uint32_t*)s->d_drec, xbase.as<uint64_t>(), s->d_primary, s->d_extras, pad);
-        // the block boundaries among the items stay (materialize_blocks)
-        if (!s->d_bstart) FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_bstart32, dim3((nb + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), nb, n, s->d_bstart);
-        FPX_HIP(hipGetLastError());
-        FPX_HIP(hipStreamSynchronize(st));
-        s->num_distinct = D; s->num_positions = Dp; s->extras_words = X;
-        return FPX_OK;
-    };
-    const int rc = body();
+    DirectPiece pc;
+    const int rc = build_direct_piece(s, 0, nb, HashRange{0u, 0xFFFFFFFFu, 0u, 1u}, DIRECT_NREC, false, 0u, &pc);
     if (rc != FPX_OK) {
-        direct_free(s);
+        pc.release();
         (void)hipGetLastError();
         return rc == FPX_E_DEVICE ? rc : FPX_OK;             // an internal inconsistency is an error; anything else: stay block-based
     }
+    s->d_drec = pc.drec; s->d_primary = pc.primary; s->d_extras = pc.extras; s->extras_shift = pc.xshift;
+    s->num_distinct = pc.distinct; s->num_positions = pc.positions; s->extras_words = pc.extras_words;
     s->direct = true;
     s->dstore = std::make_shared<DirectStore>();
     s->dstore->device = s->ctx->device; s->dstore->drec = s->d_drec; s->dstore->primary = s->d_primary; s->dstore->extras = s->d_extras;
     // the blocks and what only the block kernels read are not needed any more
-    (void)hipFree(s->d_blocks); s->d_blocks = nullptr;
-    if (s->d_bucket) { (void)hipFree(s->d_bucket); s->d_bucket = nullptr; }
-    if (s->d_cont) { (void)hipFree(s->d_cont); s->d_cont = nullptr; }
+    free_block_form(s);
     s->device_bytes = (size_t)DIRECT_NREC * 64u + (s->num_positions + 4) * 4 + (s->extras_words + 8) * 4 + ((size_t)nb + 1) * 8;
     return FPX_OK;
+}
+
+void free_block_form(Segment* s)
+{
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_blocks) { (void)hipFree(s->d_blocks); s->d_blocks = nullptr; }
+    if (s->d_bucket) { (void)hipFree(s->d_bucket); s->d_bucket = nullptr; }
+    if (s->d_cont) { (void)hipFree(s->d_cont); s->d_cont = nullptr; }
+    if (s->d_proberec) { (void)hipFree(s->d_proberec); s->d_proberec = nullptr; }
+    if (s->d_blockrec) { (void)hipFree(s->d_blockrec); s->d_blockrec = nullptr; }
+    if (s->d_small_items) { (void)hipFree(s->d_small_items); s->d_small_items = nullptr; }
 }
 
 // ---- back to items and blocks (downloads, merges) ---------------------------------------------------------------------

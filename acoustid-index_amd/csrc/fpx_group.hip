@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <new>
+#include <vector>
 
 #include "fpx_internal.h"
 
@@ -30,9 +31,9 @@ namespace {
 constexpr uint32_t GAP = 0xFFFFFFFFu;
 constexpr uint32_t LONG_LIST = 48;         // lists of more words are copied by a wave each (a hot hash: thousands of docs)
 
-struct GroupSrc {                          // one member's direct-addressed arrays (fpx_direct.hpp)
+struct GroupSrc {                          // one member's direct-addressed arrays (fpx_direct.hpp): whole, or the piece of this chunk
     const uint32_t* drec; const uint32_t* primary; const uint32_t* extras;
-    uint32_t xshift, pad;
+    uint32_t xshift, rec0;                 // rec0: the first record `drec` holds (0: all of them)
 };
 struct BuildArgs {
     GroupSrc src[FUSE_MAX];
@@ -57,7 +58,7 @@ struct DevMem {
 // the position bits of line L in column s and the index of its first position in the column's `primary`
 __device__ __forceinline__ void src_line(const GroupSrc& g, uint64_t L, uint32_t* bits, uint32_t* rank)
 {
-    const uint32_t* rec = g.drec + (size_t)(L >> 3) * 16u;
+    const uint32_t* rec = g.drec + (size_t)((L >> 3) - g.rec0) * 16u;
     const uint32_t wv = (uint32_t)L & 7u;
     *bits = rec[wv];
     *rank = rec[8] + (((wv < 4u ? rec[9] : rec[10]) >> (8u * (wv & 3u))) & 0xFFu);
@@ -227,9 +228,36 @@ __global__ __launch_bounds__(256) void k_group_col_items(const uint32_t* __restr
 
 }  // namespace
 
-// Moves the direct-addressed segments segs[0..k) into a new group.  On success every segment's postings live in the group
-// (Segment::home / col) and its own arrays are released (snapshots that still probe it alone keep them until they go).
-// FPX_E_NOMEM: not enough HBM for the group next to the segments -- nothing has changed, the caller probes them one by one.
+// the blocks of a segment that hold the hashes of chunk c (2^26 hash values): [b0, bend), and the last hash before b0
+__global__ void k_chunk_blocks(const uint32_t* __restrict__ block_index, uint32_t nb, uint32_t c_first, uint32_t nchunks, uint32_t win_lo, uint32_t win_hi,
+                               uint32_t* __restrict__ out /* [nchunks][4]: b0, bend, has_prev, prev_last */)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchunks) return;
+    const uint32_t c = c_first + i;
+    const uint32_t h_lo = max(c << 26, win_lo), h_hi = min((c << 26) | 0x3FFFFFFu, win_hi);
+    auto lower = [&](uint64_t hv) {                  // first block whose max hash >= hv
+        uint32_t lo = 0, hi = nb;
+        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint64_t)block_index[m] < hv) lo = m + 1; else hi = m; }
+        return lo;
+    };
+    uint32_t b0 = 0, bend = 0;
+    if (h_lo <= h_hi) {
+        b0 = lower(h_lo);
+        bend = min(nb, lower((uint64_t)h_hi + 1ull) + 1u);           // through the first block whose max hash > h_hi
+        if (b0 >= nb) { b0 = nb; bend = nb; }
+    }
+    out[4 * i] = b0; out[4 * i + 1] = bend;
+    out[4 * i + 2] = (b0 > 0 && b0 < nb) ? 1u : 0u;
+    out[4 * i + 3] = (b0 > 0 && b0 < nb) ? block_index[b0 - 1] : 0u;
+}
+
+// Moves k segments of one context into a new group: direct-addressed ones on their own (their arrays are read) and ones still
+// in blocks that direct_candidate() accepted (their pieces are built chunk by chunk of the hash space from the blocks, so a
+// 100-GB index never needs a second copy of itself in HBM).  On success every segment's postings live in the group
+// (Segment::home / col); its own arrays / blocks are released (snapshots that still probe it alone keep the arrays until they
+// go).  All members must share one hash window (Segment::own_*; none = the whole hash space).
+// FPX_E_NOMEM: not enough HBM -- nothing has changed, the caller searches the segments without a group.
 int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<Group>* out)
 {
     out->reset();
@@ -237,55 +265,95 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     FPX_HIP(hipSetDevice(ctx->device));
     static const bool inline_doubles = [] { const char* e = getenv("FPX_INLINE_DOUBLES"); return e ? atoi(e) != 0 : true; }();
     const uint32_t ns = k <= 8u ? 8u : 16u;
-    const uint64_t nlines = 1ull << 27;
+    // the window: hashes in (own_lo, own_hi] (a slice of an index sharded by hash range), the same for every member
+    uint32_t win_lo = 0u, win_hi = 0xFFFFFFFFu;
+    if (segs[0]->own_flags & 1u) { if (segs[0]->own_lo == 0xFFFFFFFFu) { set_error("empty hash window"); return FPX_E_INVAL; } win_lo = segs[0]->own_lo + 1u; }
+    if (segs[0]->own_flags & 2u) win_hi = segs[0]->own_hi;
+    for (uint32_t j = 0; j < k; ++j) {
+        const Segment* s = segs[j];
+        if (s->home || s->kind != 0 || (!s->direct && !s->d_blocks)) { set_error("internal: segment %u cannot join a group", j); return FPX_E_INVAL; }
+        if (s->own_flags != segs[0]->own_flags || ((s->own_flags & 1u) && s->own_lo != segs[0]->own_lo) || ((s->own_flags & 2u) && s->own_hi != segs[0]->own_hi)) {
+            set_error("the members of a group must share one hash window"); return FPX_E_INVAL;
+        }
+    }
+    if (win_lo > win_hi) { set_error("empty hash window"); return FPX_E_INVAL; }
+    constexpr uint32_t CHUNK_LINES = 1u << 21, CHUNK_RECS = 1u << 18;          // a chunk: 2^26 hash values
+    const uint32_t c_first = win_lo >> 26, c_last = win_hi >> 26, nchunks = c_last - c_first + 1u;
+    const uint64_t nlines = (uint64_t)nchunks * CHUNK_LINES;
     uint64_t need = nlines * 2ull * ns * 4ull;
-    // (a lower bound of what the group will take -- inline doubles take most lists out of `lists`; running out of HBM half
-    // way is noticed chunk by chunk and leaves the segments as they are)
-    for (uint32_t j = 0; j < k; ++j) need += segs[j]->num_positions * 4ull + segs[j]->extras_words;
+    // (a lower bound of what the group will take; running out of HBM half way is noticed chunk by chunk and leaves the
+    // segments as they are)
+    for (uint32_t j = 0; j < k; ++j) need += (uint64_t)((double)segs[j]->num_items * 4.0 * ((double)nchunks / 64.0));
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30)) {
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)3 << 30)) {
         (void)hipGetLastError();
         set_error("not enough free HBM to group %u segments (%.1f GB needed, %.1f free)", k, need / 1e9, free_b / 1e9);
         return FPX_E_NOMEM;
     }
     auto g = std::make_shared<Group>();
-    g->device = ctx->device; g->ns = ns; g->nseg = k; g->line0 = 0; g->nlines = nlines;
+    g->device = ctx->device; g->ns = ns; g->nseg = k; g->line0 = c_first * CHUNK_LINES; g->nlines = nlines; g->win_lo = win_lo; g->win_hi = win_hi;
     for (uint32_t j = 0; j < FUSE_MAX; ++j) { g->first_hash[j] = 1u; g->last_hash[j] = 0u; }      // unused columns: empty hash range
     BuildArgs a{};
     a.nseg = k; a.inline_doubles = inline_doubles ? 1u : 0u;
     for (uint32_t j = 0; j < k; ++j) {
         const Segment* s = segs[j];
-        if (!s->direct || s->home || !s->d_drec) { set_error("internal: segment %u is not direct-addressed on its own", j); return FPX_E_INVAL; }
-        a.src[j] = GroupSrc{s->d_drec, s->d_primary, s->d_extras, s->extras_shift, 0u};
         g->min_doc[j] = s->min_doc_id; g->first_hash[j] = s->first_hash; g->last_hash[j] = s->last_hash;
     }
     hipError_t e = hipMalloc(&g->d_lines, nlines * 2ull * ns * 4ull);
     if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
     g->device_bytes = nlines * 2ull * ns * 4ull;
+    // which blocks of the members still in blocks hold each chunk's hashes
+    std::vector<std::vector<uint32_t>> ranges(k);
+    {
+        DevMem d_r;
+        int rc0;
+        if ((rc0 = d_r.alloc((size_t)nchunks * 16))) return rc0;
+        for (uint32_t j = 0; j < k; ++j) {
+            if (segs[j]->direct) continue;
+            hipLaunchKernelGGL(k_chunk_blocks, dim3((nchunks + 63) / 64), dim3(64), 0, 0, (const uint32_t*)segs[j]->d_block_index, segs[j]->num_blocks,
+                               c_first, nchunks, win_lo, win_hi, d_r.as<uint32_t>());
+            ranges[j].resize((size_t)nchunks * 4);
+            FPX_HIP(hipMemcpy(ranges[j].data(), d_r.p, (size_t)nchunks * 16, hipMemcpyDeviceToHost));
+        }
+    }
     // chunks of the hash space: every chunk's words and lists are allocations of their own (the lines hold the addresses), so
     // nothing needs one contiguous 100-GB array
-    constexpr uint32_t CHUNKS = 64;
-    const uint32_t cl = (uint32_t)(nlines / CHUNKS);
     constexpr uint32_t LONG_CAP = 1u << 20;
     DevMem W, X, offW, offX, tot, longq, ctr;
     int rc;
-    if ((rc = W.alloc((size_t)cl * 4)) || (rc = X.alloc((size_t)cl * 4)) || (rc = offW.alloc((size_t)cl * 8)) || (rc = offX.alloc((size_t)cl * 8)) ||
-        (rc = tot.alloc(16)) || (rc = longq.alloc((size_t)LONG_CAP * sizeof(LongCopy))) || (rc = ctr.alloc(16)))
+    if ((rc = W.alloc((size_t)CHUNK_LINES * 4)) || (rc = X.alloc((size_t)CHUNK_LINES * 4)) || (rc = offW.alloc((size_t)CHUNK_LINES * 8)) ||
+        (rc = offX.alloc((size_t)CHUNK_LINES * 8)) || (rc = tot.alloc(16)) || (rc = longq.alloc((size_t)LONG_CAP * sizeof(LongCopy))) || (rc = ctr.alloc(16)))
         return rc;
     hipStream_t st = 0;
     FPX_HIP(hipMemsetAsync(ctr.p, 0, 16, st));
-    for (uint32_t c = 0; c < CHUNKS; ++c) {
-        a.line_begin = (uint64_t)c * cl; a.nlines = cl;
-        const dim3 grid((cl + 255u) / 256u);
+    struct Pieces {                                 // this chunk's pieces of the members still in blocks
+        DirectPiece pc[FUSE_MAX];
+        ~Pieces() { for (DirectPiece& p : pc) p.release(); }
+    };
+    for (uint32_t ci = 0; ci < nchunks; ++ci) {
+        const uint32_t c = c_first + ci;
+        Pieces pieces;
+        for (uint32_t j = 0; j < k; ++j) {
+            const Segment* s = segs[j];
+            if (s->direct) { a.src[j] = GroupSrc{s->d_drec, s->d_primary, s->d_extras, s->extras_shift, 0u}; continue; }
+            const uint32_t* r = ranges[j].data() + (size_t)ci * 4;
+            const HashRange hr{std::max(c << 26, win_lo), std::min((c << 26) | 0x3FFFFFFu, win_hi), c * CHUNK_RECS, 0u};
+            rc = build_direct_piece(s, r[0], r[1] - r[0], hr, CHUNK_RECS, r[2] != 0u, r[3], &pieces.pc[j]);
+            if (rc == FPX_E_INVAL) { set_error("segment %u does not qualify for a group (lists too long)", j); return FPX_E_NOMEM; }
+            if (rc) { (void)hipGetLastError(); return rc == FPX_E_DEVICE ? rc : FPX_E_NOMEM; }
+            a.src[j] = GroupSrc{pieces.pc[j].drec, pieces.pc[j].primary, pieces.pc[j].extras, pieces.pc[j].xshift, c * CHUNK_RECS};
+        }
+        a.line_begin = (uint64_t)c * CHUNK_LINES; a.nlines = CHUNK_LINES;
+        const dim3 grid((CHUNK_LINES + 255u) / 256u);
         if (ns == 8u) hipLaunchKernelGGL(k_group_count<8>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>());
         else hipLaunchKernelGGL(k_group_count<16>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>());
         FPX_HIP(hipGetLastError());
-        if ((rc = scan_counts_u32(W.as<uint32_t>(), cl, offW.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
-        if ((rc = scan_counts_u32(X.as<uint32_t>(), cl, offX.as<uint64_t>(), tot.as<uint64_t>() + 1, st))) return rc;
+        if ((rc = scan_counts_u32(W.as<uint32_t>(), CHUNK_LINES, offW.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
+        if ((rc = scan_counts_u32(X.as<uint32_t>(), CHUNK_LINES, offX.as<uint64_t>(), tot.as<uint64_t>() + 1, st))) return rc;
         uint64_t h_tot[2] = {0, 0};
         FPX_HIP(hipMemcpyAsync(h_tot, tot.p, 16, hipMemcpyDeviceToHost, st));
         FPX_HIP(hipStreamSynchronize(st));
-        if (h_tot[1] >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_INVAL; }
+        if (h_tot[1] >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_NOMEM; }
         uint32_t* words = nullptr; uint32_t* lists = nullptr;
         e = hipMalloc(&words, (h_tot[0] + 16) * 4ull);
         if (e == hipSuccess) { g->word_chunks.push_back(words); e = hipMalloc(&lists, (h_tot[1] + 8) * 4ull); }
@@ -294,13 +362,14 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         FPX_HIP(hipMemsetAsync(words + h_tot[0], 0, 16 * 4, st));                 // (a hash's words are read four at a time)
         FPX_HIP(hipMemsetAsync(lists + h_tot[1], 0, 8 * 4, st));
         FPX_HIP(hipMemsetAsync(ctr.p, 0, 8, st));
-        uint32_t* lines = g->d_lines + (size_t)a.line_begin * (2u * ns);
+        uint32_t* lines = g->d_lines + (size_t)ci * CHUNK_LINES * (2u * ns);
         if (ns == 8u) hipLaunchKernelGGL(k_group_fill<8>, grid, dim3(256), 0, st, a, offW.as<uint64_t>(), offX.as<uint64_t>(), lines, words, lists,
                                          longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());
         else hipLaunchKernelGGL(k_group_fill<16>, grid, dim3(256), 0, st, a, offW.as<uint64_t>(), offX.as<uint64_t>(), lines, words, lists,
                                 longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());
         hipLaunchKernelGGL(k_group_copy_long, dim3(1024), dim3(256), 0, st, longq.as<LongCopy>(), ctr.as<unsigned long long>(), LONG_CAP);
         FPX_HIP(hipGetLastError());
+        FPX_HIP(hipStreamSynchronize(st));            // (the pieces go with this scope)
         g->total_words += h_tot[0]; g->total_list_words += h_tot[1];
         g->device_bytes += (h_tot[0] + 16 + h_tot[1] + 8) * 4ull;
     }
@@ -308,12 +377,13 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     FPX_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, st));
     FPX_HIP(hipStreamSynchronize(st));
     g->doubles = h_ctr[1];
-    // the segments move in: their own arrays go with the last snapshot that still probes them alone
+    // the segments move in: a direct-addressed one's own arrays go with the last snapshot that still probes it alone, the
+    // others' blocks now (Segment::d_bstart and d_block_index stay: with them the blocks can be written out again)
     for (uint32_t j = 0; j < k; ++j) {
         Segment* s = segs[j];
         s->home = g; s->col = j;
-        s->dstore.reset();
-        s->d_drec = s->d_primary = s->d_extras = nullptr;
+        if (s->direct) { s->dstore.reset(); s->d_drec = s->d_primary = s->d_extras = nullptr; }
+        else { free_block_form(s); s->direct = true; }
         s->device_bytes = ((size_t)s->num_blocks + 1) * 8;
     }
     *out = g;
@@ -324,7 +394,7 @@ int group_column_items(const Segment* s, uint64_t* items, hipStream_t st)
 {
     const Group* g = s->home.get();
     if (!g) { set_error("internal: not a grouped segment"); return FPX_E_INVAL; }
-    if (g->line0 != 0 || g->nlines != (1ull << 27)) { set_error("a hash-window slice of an index holds only part of the segment: it cannot be downloaded or merged"); return FPX_E_INVAL; }
+    if (g->win_lo != 0u || g->win_hi != 0xFFFFFFFFu) { set_error("a hash-window slice of an index holds only part of the segment: it cannot be downloaded or merged"); return FPX_E_INVAL; }
     int rc;
     DevMem cnt, base, tot;
     if ((rc = cnt.alloc((size_t)g->nlines * 4)) || (rc = base.alloc((size_t)g->nlines * 8)) || (rc = tot.alloc(8))) return rc;

@@ -179,6 +179,8 @@ struct Segment {
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     // direct-addressed form (fpx_direct.hpp): replaces the blocks of a dense segment; d_bstart (item offset of every block) and
     // d_block_index stay, so that the blocks can be written out again byte for byte (materialize_blocks)
+    bool candidate = false;        // direct_candidate() accepted it: a snapshot decides between a group, the direct form on its own, its blocks
+    bool settled = false;          // ... and it settled in its blocks (no room for another form)
     bool direct = false;
     std::shared_ptr<DirectStore> dstore;   // owner of d_drec / d_primary / d_extras while the segment is direct-addressed on its own
     uint32_t* d_drec = nullptr; uint32_t* d_primary = nullptr; uint32_t* d_extras = nullptr;
@@ -333,7 +335,18 @@ int segment_build_impl(Ctx* ctx, const uint64_t* items_host, uint64_t n, bool so
 int scan_counts_u32(const uint32_t* counts, uint64_t n, uint64_t* offsets, uint64_t* total, hipStream_t st);
 int decode_small_segment(Segment* s);     // fills d_small_items / d_bstart of a resident file segment
 int build_presence(Segment* s);           // fills d_blockrec and d_proberec (both required by the lean kernel) of a resident file segment
-int build_direct(Segment* s);             // turns a dense resident file segment into its direct-addressed form (or leaves it as it is)
+struct HashRange { uint32_t lo, hi, rec0, whole; };      // hashes [lo, hi] into records counted from rec0; whole: the blocks are the whole segment
+// the direct-addressed arrays of a hash range of a segment (fpx_direct.hpp: records of 256 hash values, primary, extras)
+struct DirectPiece {
+    uint32_t* drec = nullptr; uint32_t* primary = nullptr; uint32_t* extras = nullptr;
+    uint32_t nrec = 0, xshift = 0;
+    uint64_t distinct = 0, positions = 0, extras_words = 0;
+    void release();
+};
+int direct_candidate(Segment* s, bool* ok);   // may this resident file segment become direct-addressed?  (fills d_bstart, first / last hash)
+int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr, uint32_t nrec, bool has_prev, uint32_t prev_last, DirectPiece* out);
+int build_direct(Segment* s);             // turns a candidate into its direct-addressed form on its own (or leaves it as it is)
+void free_block_form(Segment* s);         // the blocks, bucket table and continuation bitmap of a segment that does not need them any more
 // the blocks (+ terminator block + 16 B) of a direct-addressed segment, re-encoded into a fresh device buffer the caller frees
 int materialize_blocks(const Segment* s, uint8_t** d_blocks_out);
 // its items (hash << 32 | doc, sorted) into `items` [num_items]

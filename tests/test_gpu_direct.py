@@ -119,24 +119,32 @@ def test_download_and_merge_of_direct_addressed_segments_give_the_files_bytes(en
     blocks, index = oracle.build_blocks(items, 1, 512)
     ids = np.arange(1, 3001, dtype=np.uint32)
     seg = fpx.FileSegment(ctx, blocks, 512, index, 1, 3000, 1, ids)
-    assert seg.direct
+    assert not seg.direct                   # (a candidate keeps its blocks until a snapshot holds it)
+    fpx.Segments(ctx, [seg]).release()      # on its own: the direct-addressed form of one segment (k_probe_direct)
+    assert seg.direct and not seg.grouped
     b2, i2 = seg.download()
     assert np.array_equal(blocks, b2) and np.array_equal(index, i2)
     # ... and as a merge source: the merged segment's bytes are those of the block-form merge
     monkeypatch.setenv("FPX_DIRECT", "0")
     seg_b = fpx.FileSegment(ctx, blocks, 512, index, 1, 3000, 1, ids)
-    assert not seg_b.direct
     items2 = _segment_items(rng, 0, 2000, 3001)
     bl2, ix2 = oracle.build_blocks(items2, 3001, 512)
     ids2 = np.arange(3001, 5001, dtype=np.uint32)
     other_b = fpx.FileSegment(ctx, bl2, 512, ix2, 3001, 5000, 2, ids2)
     monkeypatch.setenv("FPX_DIRECT", "1")
     other_d = fpx.FileSegment(ctx, bl2, 512, ix2, 3001, 5000, 2, ids2)
-    assert other_d.direct
-    merged_d = fpx.Segments(ctx, [seg, other_d]).merge([seg, other_d])
-    assert merged_d.direct
+    coll_d = fpx.Segments(ctx, [seg, other_d])          # the two form a group: one from its own arrays, one from its blocks
+    assert seg.grouped and other_d.grouped
+    b3, i3 = seg.download()                             # (a column read back out of the group)
+    assert np.array_equal(blocks, b3) and np.array_equal(index, i3)
+    b4, i4 = other_d.download()
+    assert np.array_equal(bl2, b4) and np.array_equal(ix2, i4)
+    merged_d = coll_d.merge([seg, other_d])
     monkeypatch.setenv("FPX_DIRECT", "0")
-    merged_b = fpx.Segments(ctx, [seg_b, other_b]).merge([seg_b, other_b])
+    coll_b = fpx.Segments(ctx, [seg_b, other_b])
+    assert not seg_b.direct and not other_b.direct
+    merged_b = coll_b.merge([seg_b, other_b])
+    fpx.Segments(ctx, [merged_b]).release()
     assert not merged_b.direct
     mb, mi = merged_b.download()
     md, mdi = merged_d.download()

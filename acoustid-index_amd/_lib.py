@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPX_LIB", os.path.join(_HERE, "libfpx.so"))      # FPX_LIB: A/B a second build
 
-FPX_OK, FPX_E_NOMEM, FPX_E_TIMEOUT, FPX_E_DEVICE, FPX_E_INVAL, FPX_E_NODEVICE = 0, -1, -2, -3, -4, -5
+FPX_OK, FPX_E_NOMEM, FPX_E_TIMEOUT, FPX_E_DEVICE, FPX_E_INVAL, FPX_E_NODEVICE, FPX_E_AGAIN = 0, -1, -2, -3, -4, -5, -6
 
 
 class FpxError(RuntimeError):
@@ -58,6 +58,10 @@ SIGNATURES = {
     "fpx_segment_create_file": (C.c_int, [_vp, _vp, _sz, _u32, _vp, _u32, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
     "fpx_segment_create_file_slice": (C.c_int, [_vp, _vp, _sz, _u32, _vp, _u32, C.c_int, _u32, C.c_int, _u32, _u32, _u32, _u64, _vp, _vp, _u32,
                                                 C.POINTER(_vp)]),
+    "fpx_segment_slice": (C.c_int, [_vp, C.c_int, _u32, C.c_int, _u32, C.POINTER(_vp)]),
+    "fpx_shard_cell_bins": (_u32, [_u32]),
+    "fpx_shard_probe": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, C.POINTER(_u64), C.POINTER(Stats)]),
+    "fpx_shard_score": (C.c_int, [_vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp]),
     "fpx_probe_resident": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, C.POINTER(Stats)]),
     "fpx_score_partial": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _vp]),
     "fpx_segment_create_memory": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),

@@ -73,6 +73,8 @@ void ws_destroy(Workspace* w)
 {
     if (!w) return;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
+    if (w->d_cells) (void)hipFree(w->d_cells);
+    if (w->h_cells) (void)hipHostFree(w->h_cells);
     void* bufs[] = {w->d_hashes, w->d_offsets, w->d_opts, w->d_keys[0], w->d_keys[1], w->d_hits[0], w->d_hits[1],
                     w->d_cands[0], w->d_cands[1], w->d_temp, w->d_counters, w->d_out, w->d_out_n, w->d_def_list, w->d_def_count, w->d_qrange, w->d_qcand,
                     w->d_binq, w->d_qcursor};
@@ -271,6 +273,7 @@ const char* fpx_strerror(int status)
         case FPX_E_DEVICE: return "device error";
         case FPX_E_INVAL: return "invalid argument";
         case FPX_E_NODEVICE: return "no HIP device";
+        case FPX_E_AGAIN: return "buffer too small, retry";
         default: return "unknown";
     }
 }
@@ -375,6 +378,49 @@ int fpx_segment_create_file_slice(fpx_ctx* ctx, const uint8_t* blocks, size_t bl
     return create_file_impl(ctx, blocks, blocks_len, block_size, block_index, num_blocks,
                             (has_lo ? 1u : 0u) | (has_hi ? 2u : 0u), lo_excl, hi_incl, min_doc_id, max_doc_id,
                             commit_id, doc_ids, doc_alive, num_docs, out);
+}
+
+// A hash-window slice of a RESIDENT file segment, cut on the device: the blocks that hold the hashes in (lo_excl, hi_incl] plus
+// the three halo blocks behind them, as fpx_segment_create_file_slice takes them from the host.  The source must still be in
+// its blocks (a candidate that no snapshot has held yet, or a block-form segment).
+int fpx_segment_slice(fpx_segment* seg, int has_lo, uint32_t lo_excl, int has_hi, uint32_t hi_incl, fpx_segment** out)
+{
+    Segment* g = reinterpret_cast<Segment*>(seg);
+    if (!g || !out) { set_error("null argument"); return FPX_E_INVAL; }
+    *out = nullptr;
+    if (g->kind != 0 || !g->d_blocks || g->own_flags != 0u) { set_error("fpx_segment_slice: the source is not a whole file segment in its blocks"); return FPX_E_INVAL; }
+    if (has_lo && has_hi && hi_incl < lo_excl) { set_error("empty hash window"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(g->ctx->device));
+    const uint32_t nb = g->num_blocks;
+    std::vector<uint32_t> bi(nb);
+    if (nb) FPX_HIP(hipMemcpy(bi.data(), g->d_block_index, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // owned: from the first block whose max hash reaches into the window to the first whose max hash >= hi_incl; + 3 halo blocks
+    const uint32_t b0 = (has_lo && lo_excl != 0xFFFFFFFFu) ? (uint32_t)(std::lower_bound(bi.begin(), bi.end(), lo_excl + 1u) - bi.begin()) : (has_lo ? nb : 0u);
+    uint32_t e = nb;
+    if (has_hi) e = std::min<uint32_t>(nb, (uint32_t)(std::lower_bound(bi.begin(), bi.end(), hi_incl) - bi.begin()) + 1u + 3u);
+    if (e < b0) e = b0;
+    Segment* s = new (std::nothrow) Segment();
+    if (!s) return FPX_E_NOMEM;
+    s->ctx = g->ctx; s->kind = 0; s->commit_id = g->commit_id; s->min_doc_id = g->min_doc_id; s->max_doc_id = g->max_doc_id;
+    s->block_size = g->block_size; s->num_blocks = e - b0;
+    s->own_flags = (has_lo ? 1u : 0u) | (has_hi ? 2u : 0u); s->own_lo = lo_excl; s->own_hi = hi_incl;
+    s->doc_ids = g->doc_ids; s->doc_alive = g->doc_alive;
+    s->blocks_len = ((size_t)s->num_blocks + 1) * s->block_size;
+    const size_t alloc = s->blocks_len + 16, copy = (size_t)s->num_blocks * s->block_size;
+    hipError_t er = hipMalloc(&s->d_blocks, alloc);
+    if (er == hipSuccess) er = hipMalloc(&s->d_block_index, ((size_t)s->num_blocks + 1) * sizeof(uint32_t));
+    if (er != hipSuccess) { segment_free(s); return hip_fail(er, "hipMalloc(segment slice)"); }
+    s->device_bytes = alloc + ((size_t)s->num_blocks + 1) * sizeof(uint32_t);
+    if ((er = hipMemset(s->d_blocks + copy, 0, alloc - copy)) != hipSuccess ||
+        (copy && (er = hipMemcpy(s->d_blocks, g->d_blocks + (size_t)b0 * g->block_size, copy, hipMemcpyDeviceToDevice)) != hipSuccess) ||
+        (s->num_blocks && (er = hipMemcpy(s->d_block_index, g->d_block_index + b0, (size_t)s->num_blocks * sizeof(uint32_t), hipMemcpyDeviceToDevice)) != hipSuccess)) {
+        segment_free(s); return hip_fail(er, "segment slice copy");
+    }
+    const int rc = finish_file_segment(s);
+    if (rc) { segment_free(s); return rc; }
+    FPX_HIP(hipDeviceSynchronize());
+    *out = reinterpret_cast<fpx_segment*>(s);
+    return FPX_OK;
 }
 
 int fpx_segment_create_memory(fpx_ctx* ctx_, const uint64_t* items, size_t num_items,
@@ -776,6 +822,27 @@ int fpx_score_partial(fpx_ctx* ctx, const fpx_query_batch* qb, const void* d_rec
     return score_records_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb),
                               reinterpret_cast<const uint64_t*>(d_records), num_records, timeout_ms,
                               reinterpret_cast<fpx_result*>(d_out), out_cap, reinterpret_cast<uint32_t*>(d_out_n));
+}
+
+uint32_t fpx_shard_cell_bins(uint32_t num_queries) { return (uint32_t)shard_cell_bins(num_queries); }
+
+int fpx_shard_probe(fpx_snapshot* snap, const fpx_query_batch* qb, uint32_t world, uint32_t timeout_ms,
+                    void* d_send, uint64_t cell_cap, void* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats)
+{
+    if (!snap || !qb || !d_send || !d_send_counts || cell_cap == 0) { set_error("null argument"); return FPX_E_INVAL; }
+    if (world == 0 || (world & (world - 1)) != 0 || world > 16) { set_error("world must be a power of two <= 16"); return FPX_E_INVAL; }
+    return shard_probe_impl(reinterpret_cast<Snapshot*>(snap), reinterpret_cast<const QueryBatch*>(qb), world, timeout_ms,
+                            reinterpret_cast<uint64_t*>(d_send), cell_cap, reinterpret_cast<uint32_t*>(d_send_counts), needed_cell_cap, stats);
+}
+
+int fpx_shard_score(fpx_ctx* ctx, const fpx_query_batch* qb, uint32_t world, const void* d_recv, uint64_t cell_cap, const void* d_recv_counts,
+                    uint32_t timeout_ms, void* d_out, uint32_t out_cap, void* d_out_n)
+{
+    if (!ctx || !qb || !d_recv || !d_recv_counts || !d_out_n || (!d_out && out_cap)) { set_error("null argument"); return FPX_E_INVAL; }
+    if (world == 0 || (world & (world - 1)) != 0 || world > 16) { set_error("world must be a power of two <= 16"); return FPX_E_INVAL; }
+    return shard_score_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb), world, reinterpret_cast<const uint64_t*>(d_recv), cell_cap,
+                            reinterpret_cast<const uint32_t*>(d_recv_counts), timeout_ms, reinterpret_cast<fpx_result*>(d_out), out_cap,
+                            reinterpret_cast<uint32_t*>(d_out_n));
 }
 
 int fpx_merge_partials(fpx_ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world, uint32_t num_queries,

@@ -42,9 +42,22 @@ constexpr uint32_t GK_WORDS = 12;          // words of a hash fetched by its lan
 // in (hash bucket, query) order -- what the one stable radix pass on the top hash bits leaves, k_make_keys_dedup having written
 // them query by query -- the 256 keys of a round belong to a few dozen neighbouring queries: a handful of bins, one reservation
 // each, runs of a kilobyte.  (Binning all 64+ bins of the batch in every flush was measured twice and cost what it saved.)
-constexpr uint32_t GB_SLOTS = 64;          // bins a round may touch (slot = bin & 63; a clash sends the lane's records the long way)
+constexpr uint32_t GB_SLOTS = 128;         // cells a round may touch (gb_slot; a clash sends the records the long way: the misc buffer)
 constexpr uint32_t GB_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t GB_NEED = 0xFFFFFFF0u;   // s_rank: the staged record has no rank in its bin yet (every entry between rounds)
+
+// the cell of a record -- its query's bin, and on a sharded index the rank that owns its doc -- and the cell's slot in a round's
+// table: the low bits of the bin next to the destination (a round's keys belong to neighbouring queries: neighbouring bins)
+__device__ __forceinline__ uint32_t gb_cell(const ProbeArgs& a, uint64_t rec)
+{
+    const uint32_t qbin = (uint32_t)(rec >> 32) >> a.bin_shift;
+    return a.dest_bits ? ((uint32_t)rec & ((1u << a.dest_bits) - 1u)) * a.cell_bins + qbin : qbin;
+}
+__device__ __forceinline__ uint32_t gb_slot(const ProbeArgs& a, uint64_t rec)
+{
+    const uint32_t qbin = (uint32_t)(rec >> 32) >> a.bin_shift, qb = 7u - a.dest_bits;         // (dest_bits <= 4)
+    return (qbin & ((1u << qb) - 1u)) | (((uint32_t)rec & ((1u << a.dest_bits) - 1u)) << qb);
+}
 
 template <int NS, bool BINNED>
 __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga)
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const GroupDesc* g = &ga.g;
     if (tid < FUSE_MAX) { s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
-    if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid >> 6][tid & 63u] = 0u; s_bid[tid >> 6][tid & 63u] = GB_EMPTY; }
+    if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid / GB_SLOTS][tid % GB_SLOTS] = 0u; s_bid[tid / GB_SLOTS][tid % GB_SLOTS] = GB_EMPTY; }
     if constexpr (BINNED) for (uint32_t i = tid; i < FSTAGE_CAP; i += FK_WG) s_rank[i] = GB_NEED;
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;
@@ -211,9 +224,12 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
                 atomicMin(hs.valid, pos);
                 gpos = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)cnt);
             } else if constexpr (BINNED) {
-                const uint32_t b = (uint32_t)(qpart >> 32) >> a.bin_shift, bslot = b & (GB_SLOTS - 1u);
-                const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
-                brank = (old == GB_EMPTY || old == b) ? atomicAdd(&s_bcnt[par][bslot], cnt) : GB_EMPTY;       // (two bins on one slot: ranked at the flush)
+                brank = GB_EMPTY;                            // (sharded: the records of a lane go to several ranks -- ranked one by one at the flush)
+                if (a.dest_bits == 0u) {
+                    const uint32_t b = gb_cell(a, qpart), bslot = gb_slot(a, qpart);
+                    const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
+                    if (old == GB_EMPTY || old == b) brank = atomicAdd(&s_bcnt[par][bslot], cnt);              // (two bins on one slot: ranked at the flush)
+                }
             }
         }
         uint32_t o = 0;
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
             bool unplaced = false;
             for (uint32_t i = tid; i < sc; i += FK_WG) {
                 if (s_rank[i] != GB_NEED) continue;
-                const uint32_t b = (uint32_t)(stage[i] >> 32) >> a.bin_shift, sl = b & (GB_SLOTS - 1u);
+                const uint32_t b = gb_cell(a, stage[i]), sl = gb_slot(a, stage[i]);
                 const uint32_t old = atomicCAS(&s_bid[par][sl], GB_EMPTY, b);
                 if (old == GB_EMPTY || old == b) s_rank[i] = atomicAdd(&s_bcnt[par][sl], 1u); else unplaced = true;
             }
@@ -314,9 +330,9 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
             __syncthreads();
             for (uint32_t i = tid; i < sc; i += FK_WG) {
                 const uint64_t rec = stage[i];
-                const uint32_t b = (uint32_t)(rec >> 32) >> a.bin_shift, rk = s_rank[i];
+                const uint32_t b = gb_cell(a, rec), rk = s_rank[i];
                 if (rk < GB_NEED) {
-                    const uint64_t at = (uint64_t)s_bbase[b & (GB_SLOTS - 1u)] + rk;
+                    const uint64_t at = (uint64_t)s_bbase[gb_slot(a, rec)] + rk;
                     if (at < a.bin_cap) a.bins[(size_t)b * a.bin_cap + at] = rec;
                 } else {                            // (still no place: the misc buffer)
                     const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);

@@ -250,6 +250,7 @@ struct Workspace {
     // straight from the device blocks the host until the stream gets there and costs ~100 us of driver time per call; a
     // copy into pinned memory is asynchronous, and the host moves the bytes on after the batch's synchronisation
     uint8_t* h_out = nullptr; size_t cap_h_out = 0;
+    uint32_t* d_cells = nullptr; uint32_t* h_cells = nullptr; size_t cap_cells = 0;   // fpx_shard_probe: the cells' fill counters + statistics slots
     uint32_t hint_def = 0;                // longest deferred list of the last batch (sizes the deferred pass's grid)
     uint64_t hint_P = 0, hint_H = 0;      // pairs and hit records of the last batch this workspace ran (sizes the next one)
     uint32_t fast_penalty = 0;            // batches left before the device-sized path is tried again after it had to be redone
@@ -317,6 +318,11 @@ int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uin
                        uint64_t* d_records, uint64_t records_cap, uint64_t* counts, fpx_stats* stats);
 int score_records_impl(Ctx* ctx, const QueryBatch* qb, const uint64_t* d_records, uint64_t num_records, uint32_t timeout_ms,
                        fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n);
+int shard_cell_bins(uint32_t B);
+int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
+                     uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats);
+int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
+                     uint32_t timeout_ms, fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n);
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
                         uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n);

@@ -17,11 +17,14 @@ namespace fpx {
 constexpr uint32_t SB_WG = 512;
 constexpr uint32_t SB_FILTER_LOG2 = 14;            // 16 384 16-bit cells (8 192 32-bit ones for bins of >= 65 536 records): 32 KB
 constexpr uint32_t SB_TABLE_LOG2 = 11;             // 2 048 slots of (doc << 32 | q << (32 - BQ) ... count): 16 KB
-constexpr uint32_t SB_QMAX = 16;                   // queries per bin at most (BQ <= 4)
+constexpr uint32_t SB_QMAX = 64;                   // queries per bin at most (BQ <= 6: a rank of a sharded index gets 1/N of the docs of a bin)
+constexpr uint32_t SB_QL_SHIFT = 26;               // table slot: doc << 32 | query-in-bin << 26 | count (26 bits)
 constexpr uint32_t SB_CAND = 32;                   // candidates of a query gathered in LDS before they move to the shared list
 
 struct ScoreBinArgs {
     const uint64_t* bins; uint64_t bin_cap; const unsigned int* bin_count;      // as BinArgs
+    uint32_t nsrc;                                 // the bin's records come in `nsrc` pieces (what each rank of a sharded index sent): piece r of
+    uint64_t src_stride; uint32_t count_stride, count_step;    // bin b = bins + r * src_stride + b * bin_cap, its count = bin_count[r * count_stride + b * count_step]
     uint32_t bq;                                   // log2 of the queries per bin
     uint32_t B;
     const uint32_t* opts;                          // [B][4]
@@ -49,12 +52,17 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
         s_floor[tid] = q < a.B ? a.opts[q * 4u + 1u] : 0xFFFFFFFFu;
         s_ccnt[tid] = 0u; s_over[tid] = 0u;
     }
-    const unsigned int raw_n = a.bin_count[(size_t)bin * BIN_STRIDE];
-    if (tid == 0) a.bin_n[bin] = raw_n;
+    uint64_t n = 0;                                                              // records of the bin over all pieces
+    unsigned int raw_max = 0;
+    for (uint32_t r = 0; r < a.nsrc; ++r) {
+        const unsigned int c = a.bin_count[(size_t)r * a.count_stride + (size_t)bin * a.count_step];
+        raw_max = max(raw_max, c);
+        n += min((uint64_t)c, a.bin_cap);
+    }
+    if (tid == 0) a.bin_n[bin] = a.nsrc == 1u ? raw_max : (uint32_t)min<uint64_t>(n, 0xFFFFFFFFull);
+    if (tid == 0 && a.nsrc > 1u && (uint64_t)raw_max > a.bin_cap) atomicMax(&a.counters[CTR_BINFAIL], 2ull);      // (a piece overflowed its cell)
     __syncthreads();
     if (s_cancel) return;
-    const uint64_t n = min((uint64_t)raw_n, a.bin_cap);
-    const uint64_t* recs = a.bins + (size_t)bin * a.bin_cap;
     uint32_t floor_min = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < nq; ++i) floor_min = min(floor_min, s_floor[i]);
     const uint64_t smax = a.sb >= 32u ? 0xFFFFFFFFull : ((1ull << a.sb) - 1ull);
@@ -82,10 +90,13 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
             for (uint32_t i = tid; i < (1u << (SB_FILTER_LOG2 - 1u)); i += SB_WG) filter[i] = 0u;
             __syncthreads();
             // ---- stage A: every record of the class into its (query, doc) cell
-            for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
+            for (uint32_t src = 0; src < a.nsrc; ++src) {
+            const uint64_t ns = min((uint64_t)a.bin_count[(size_t)src * a.count_stride + (size_t)bin * a.count_step], a.bin_cap);
+            const uint64_t* recs = a.bins + (size_t)src * a.src_stride + (size_t)bin * a.bin_cap;
+            for (uint64_t t0 = 0; t0 < ns; t0 += TILE) {
                 uint64_t r[SB_RPT];
 #pragma unroll
-                for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < n ? gload_u64(recs + i) : ~0ull; }
+                for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < ns ? gload_u64(recs + i) : ~0ull; }
 #pragma unroll
                 for (uint32_t u = 0; u < SB_RPT; ++u) {
                     if (r[u] == ~0ull) continue;
@@ -94,6 +105,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                     const uint32_t c = mix32(doc ^ (ql * 0x9E3779B1u)) & fmask;
                     if (wide) atomicAdd(&filter[c], 1u); else atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
                 }
+            }
             }
             __syncthreads();
             // ---- stage B: the records whose cell reaches their query's floor (every (query, doc) with count >= floor is among
@@ -105,10 +117,13 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                 for (uint32_t s = tid; s < T; s += SB_WG) table[s] = 0ull;
                 if (tid == 0) { s_claimed = 0u; s_full = 0u; }
                 __syncthreads();
-                for (uint64_t t0 = 0; t0 < n; t0 += TILE) {
+                for (uint32_t src = 0; src < a.nsrc; ++src) {
+                const uint64_t ns = min((uint64_t)a.bin_count[(size_t)src * a.count_stride + (size_t)bin * a.count_step], a.bin_cap);
+                const uint64_t* recs = a.bins + (size_t)src * a.src_stride + (size_t)bin * a.bin_cap;
+                for (uint64_t t0 = 0; t0 < ns; t0 += TILE) {
                     uint64_t r[SB_RPT];
 #pragma unroll
-                    for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < n ? gload_u64(recs + i) : ~0ull; }
+                    for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < ns ? gload_u64(recs + i) : ~0ull; }
 #pragma unroll
                     for (uint32_t u = 0; u < SB_RPT; ++u) {
                         if (r[u] == ~0ull) continue;
@@ -117,8 +132,8 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                         const uint32_t hsh = mix32(doc ^ (ql * 0x9E3779B1u));
                         if (cell_count(hsh & fmask) < s_floor[ql]) continue;
                         if (passes > 1u && ((hsh >> 25) % passes) != pass) continue;       // class bits apart from the slot bits (14..24)
-                        // slot: doc << 32 | query << 28 | count (28 bits)
-                        const unsigned long long keyhi = ((unsigned long long)doc << 32) | ((unsigned long long)ql << 28);
+                        // slot: doc << 32 | query-in-bin << 26 | count (26 bits)
+                        const unsigned long long keyhi = ((unsigned long long)doc << 32) | ((unsigned long long)ql << SB_QL_SHIFT);
                         uint32_t s = (hsh >> 14) & tmask;
                         for (uint32_t tries = 0;; ++tries) {
                             if (tries == T) { s_full = 1u; break; }
@@ -128,10 +143,11 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                                 if (prev == 0ull) { atomicAdd(&s_claimed, 1u); break; }
                                 cur = prev;
                             }
-                            if ((cur >> 28) == (keyhi >> 28)) { atomicAdd(&table[s], 1ull); break; }
+                            if ((cur >> SB_QL_SHIFT) == (keyhi >> SB_QL_SHIFT)) { atomicAdd(&table[s], 1ull); break; }
                             s = (s + 1u) & tmask;
                         }
                     }
+                }
                 }
                 __syncthreads();
                 if (pass == 0u && (s_claimed > fill || s_full != 0u) && passes < 64u) {
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                 for (uint32_t s = tid; s < T; s += SB_WG) {
                     const unsigned long long e = table[s];
                     if (e == 0ull) continue;
-                    const uint32_t count = (uint32_t)e & 0x0FFFFFFFu, ql = (uint32_t)(e >> 28) & 15u, doc = (uint32_t)(e >> 32);
+                    const uint32_t count = (uint32_t)e & ((1u << SB_QL_SHIFT) - 1u), ql = (uint32_t)(e >> SB_QL_SHIFT) & 63u, doc = (uint32_t)(e >> 32);
                     if (count < s_floor[ql]) continue;
                     if ((uint64_t)count > smax) atomicMax(&a.counters[CTR_MAXSCORE], (unsigned long long)count);
                     const uint64_t sc = (uint64_t)count > smax ? smax : (uint64_t)count;

@@ -652,6 +652,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (binned) {
             ScoreBinArgs sa{};
             sa.bins = h_bin.bins; sa.bin_cap = h_bin.bin_cap; sa.bin_count = h_bin.bin_count; sa.bq = h_bin.shift; sa.B = B;
+            sa.nsrc = 1u; sa.src_stride = 0; sa.count_stride = 0; sa.count_step = BIN_STRIDE;
             sa.opts = d_opts; sa.sb = 32u - qb; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
             sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
             const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << h_bin.shift) * 8u;
@@ -675,6 +676,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (floor_min <= 2u && est_H / B > (1u << SCORE_TABLE_LOG2)) { log2t = 13; log2f = 11; }
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
+        static const hipError_t lds_attr_sb = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)lds_attr_sb;
         static const hipError_t lds_attrs_f[3] = {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
@@ -1174,6 +1177,271 @@ int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uin
         return deliver_results(ws, B, out_cap, staged, out, out_n, st);
     };
     rc = body();
+    ws_release(ctx, ws);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// An index sharded by HASH RANGE: every rank holds the same window of the hash space of ALL segments (its slice
+// of their group), so a rank makes, sorts and probes only the query hashes of its window -- 1/N of the batch's work -- and a
+// doc's postings come from every rank: its score is a true sum (SearchResults.incr is a keyed sum, src/common.zig:121-129; a
+// hash's walk is independent of every other hash, src/FileSegment.zig:143-176).  The pipeline is cut at the hit records:
+//   fpx_shard_probe   keys of the window -> k_probe_group<.., BINNED> drops the records into CELLS (destination rank = doc &
+//                     (N - 1), bin of 64 queries), [N][bins][cell_cap] in the caller's send buffer, + the cells' counts
+//   (the caller's all-to-all: cell row r travels to rank r -- fixed shapes, no sizes to agree on first)
+//   fpx_shard_score   k_score_bin over the N pieces of every bin -> per-query tables as fpx_search_resident_partial writes them
+//   (all-gather of the tables + fpx_merge_partials, as for segment sharding)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SHARD_BQ = 6;           // queries per cell bin: a rank receives 1/N of a bin's records -- 64 queries weigh what 8 do on one GPU
+
+// per query: the hashes inside [win_lo, win_hi] -- duplicates flagged (dedupSorted, src/Index.zig:489-499) -- compacted into the
+// query's `stride` key slots, the rest of the slots filled with flagged keys (the probe kernels skip those)
+__global__ __launch_bounds__(256) void k_make_keys_window(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
+                                                          uint32_t B, uint32_t qb, uint64_t* __restrict__ keys, uint32_t stride,
+                                                          uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, unsigned int* zero_u32, uint32_t zero_n,
+                                                          uint32_t* __restrict__ overflow)
+{
+    __shared__ uint32_t tab[DEDUP_SLOTS];
+    __shared__ uint32_t seen_ones, s_n;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= B) return;
+    if (q == 0 && tid < CTR_COUNT) counters[tid] = 0ull;
+    if (q == 0) for (uint32_t i = tid; i < zero_n; i += 256u) zero_u32[i] = 0u;
+    for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
+    if (tid == 0) { seen_ones = 0u; s_n = 0u; }
+    __syncthreads();
+    const uint64_t lo = offsets[q], hi = offsets[q + 1];
+    uint64_t* mine = keys + (size_t)q * stride;
+    for (uint64_t i = lo + tid; i < hi; i += 256u) {
+        const uint32_t h = hashes_base[i];
+        if (h < win_lo || h > win_hi) continue;
+        bool dup;
+        if (h == 0xFFFFFFFFu) {
+            dup = atomicExch(&seen_ones, 1u) != 0u;
+        } else {
+            uint32_t slot = (h * 0x9E3779B1u) >> 20;
+            for (;;) {
+                const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, h);
+                if (old == 0xFFFFFFFFu) { dup = false; break; }
+                if (old == h) { dup = true; break; }
+                slot = (slot + 1u) & (DEDUP_SLOTS - 1u);
+            }
+        }
+        if (dup) continue;                              // (a later occurrence of a hash: nothing to probe)
+        const uint32_t at = atomicAdd(&s_n, 1u);
+        if (at < stride) mine[at] = ((uint64_t)h << qb) | q; else *overflow = 1u;
+    }
+    __syncthreads();
+    for (uint32_t i = min(s_n, stride) + tid; i < stride; i += 256u) mine[i] = KEY_DUP_FLAG | q;
+}
+
+// what k_probe_group could not place itself (a clash of two cells on one slot of a round, a full stage): one atomic per record
+__global__ __launch_bounds__(256) void k_bin_misc_cells(ProbeArgs a, const unsigned long long* __restrict__ count)
+{
+    const uint64_t n = min((uint64_t)*count, a.hit_cap);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t rec = a.hits[i];
+        const uint32_t cell = gb_cell(a, rec);
+        const uint32_t at = atomicAdd(&a.bin_count[(size_t)cell * BIN_STRIDE], 1u);
+        if (at < a.bin_cap) a.bins[(size_t)cell * a.bin_cap + at] = rec;
+    }
+}
+
+// the cells' fill counts, compact (what travels with the cells), and the fullest one
+__global__ void k_cell_counts(const unsigned int* __restrict__ bin_count, uint32_t ncells, uint32_t* __restrict__ out, unsigned long long* __restrict__ counters)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const unsigned int v = bin_count[(size_t)c * BIN_STRIDE];
+    out[c] = v;
+    atomicMax(&counters[CTR_TOTAL], (unsigned long long)v);
+    atomicAdd(&counters[CTR_SLOTCANDS], (unsigned long long)v);
+}
+
+static unsigned log2_exact(uint32_t v) { unsigned b = 0; while ((1u << b) < v) ++b; return b; }
+
+int shard_cell_bins(uint32_t B) { return (int)((B + (1u << SHARD_BQ) - 1u) >> SHARD_BQ); }
+
+int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
+                     uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats)
+{
+    if (qb->ctx != snap->ctx) { set_error("query batch and snapshot belong to different contexts"); return FPX_E_INVAL; }
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (needed_cell_cap) *needed_cell_cap = 0;
+    const uint32_t B = qb->B;
+    if (B == 0) return FPX_OK;
+    // the fast protocol serves snapshots that are groups of direct-addressed segments with one hash window and nothing else;
+    // anything else goes through fpx_probe_resident / fpx_score_partial (same results)
+    if (snap->n_group == 0 || snap->n_solo != 0 || snap->n_file != 0 || snap->n_mem != 0) {
+        set_error("fpx_shard_probe: the snapshot is not made of groups of direct-addressed segments alone (use fpx_probe_resident)"); return FPX_E_INVAL;
+    }
+    uint32_t win_lo = snap->h_group[0].win_lo, win_hi = snap->h_group[0].win_hi;
+    for (const GroupDesc& gd : snap->h_group)
+        if (gd.win_lo != win_lo || gd.win_hi != win_hi) { set_error("fpx_shard_probe: the snapshot's groups have different hash windows"); return FPX_E_INVAL; }
+    const uint64_t* offsets = qb->offsets.data();
+    uint64_t max_len = 0;
+    for (uint32_t q = 0; q < B; ++q) max_len = std::max<uint64_t>(max_len, offsets[q + 1] - offsets[q]);
+    if (max_len > DEDUP_MAX) { set_error("fpx_shard_probe: queries of more than %u hashes (use fpx_probe_resident)", DEDUP_MAX); return FPX_E_INVAL; }
+    if (max_len == 0) max_len = 1;
+    const unsigned qbits = bits_for(B), dest_bits = log2_exact(world);
+    if (dest_bits > 4u || qbits > 24u) { set_error("fpx_shard_probe: at most 16 ranks, 2^24 queries"); return FPX_E_INVAL; }
+    const uint32_t nbins = (uint32_t)shard_cell_bins(B), ncells = nbins * world;
+    FPX_HIP(hipSetDevice(snap->ctx->device));
+    Workspace* ws = ws_acquire(snap->ctx);
+    if (!ws) return FPX_E_NOMEM;
+    auto body = [&]() -> int {
+        int rc;
+        hipStream_t st = ws->stream;
+        const double t_start = now_ms();
+        __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);
+        const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
+        // [cells' fill counters, a line each | LEAN_STAT_SETS x 8 u64 statistics slots | overflow flag]
+        const size_t cell_words = (size_t)ncells * BIN_STRIDE, words = cell_words + LEAN_STAT_WORDS + 16;
+        if (words > ws->cap_cells) {
+            if (ws->d_cells) (void)hipFree(ws->d_cells);
+            if (ws->h_cells) (void)hipHostFree(ws->h_cells);
+            ws->d_cells = nullptr; ws->h_cells = nullptr; ws->cap_cells = 0;
+            FPX_HIP(hipMalloc(&ws->d_cells, words * sizeof(uint32_t)));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_cells), (LEAN_STAT_WORDS + 16) * sizeof(uint32_t)));
+            ws->cap_cells = words;
+        }
+        uint32_t* d_stats32 = ws->d_cells + cell_words;
+        uint32_t* d_overflow = d_stats32 + LEAN_STAT_WORDS;
+        if (ws->cap_hits == 0 && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)1 << 22))) return rc;
+        // the window is 1 / world of the hash space: a query's share of its hashes + slack; a query that needs more has the
+        // whole query's length on the second attempt
+        uint32_t stride = (uint32_t)std::min<uint64_t>(max_len, (max_len + world - 1) / world * 5 / 4 + 48);
+        for (int attempt = 0;; ++attempt) {
+            const uint64_t P = (uint64_t)B * stride;
+            if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
+            FPX_HIP(hipMemsetAsync(ws->d_cells, 0, words * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_make_keys_window, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
+                               ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, (unsigned int*)nullptr, 0u, d_overflow);
+            FPX_HIP(hipGetLastError());
+            // one stable pass on the 8 hash bits below the window's own: (bucket, query) order, as on one GPU
+            int kcur = 0;
+            if (P > (1ull << 18)) {
+                const unsigned hi_bit = 32u + qbits - dest_bits, lo_bit = hi_bit - 8u;
+                const size_t tb = sort_u64_temp_bytes(P, lo_bit, hi_bit);
+                if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
+                FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, lo_bit, hi_bit, st, &kcur));
+            }
+            ProbeArgs a;
+            a.segs = snap->d_direct; a.pairs = ws->d_keys[kcur]; a.P = P; a.qb = qbits; a.ppw = 16u; a.bsp = 0u;
+            a.hits = ws->d_hits[1]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
+            a.def_list = nullptr; a.def_count = nullptr; a.def_cap = 0; a.ctr_off = 0; a.cancel = cancel;
+            a.lean_stats = reinterpret_cast<unsigned long long*>(d_stats32);
+            a.key_skip = KEY_SKIP_FLAGGED;
+            a.bins = d_send; a.bin_cap = cell_cap; a.bin_count = ws->d_cells; a.bin_shift = SHARD_BQ; a.dest_bits = dest_bits; a.cell_bins = nbins;
+            const uint64_t wgs = (P + FK_WG - 1) / FK_WG;
+            a.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs / 8192));
+            const uint64_t per_wg = (uint64_t)FK_WG * a.rounds;
+            FPX_HIP(hipEventRecord(ws->ev_probe0, st));
+            for (const GroupDesc& gd : snap->h_group) {
+                const GroupArgs gargs{gd, snap->d_direct};
+                const dim3 grid((uint32_t)((P + per_wg - 1) / per_wg));
+                if (snap->groups[&gd - snap->h_group.data()]->ns == 8u) hipLaunchKernelGGL((k_probe_group<8, true>), grid, dim3(FK_WG), 0, st, a, gargs);
+                else hipLaunchKernelGGL((k_probe_group<16, true>), grid, dim3(FK_WG), 0, st, a, gargs);
+            }
+            FPX_HIP(hipEventRecord(ws->ev_probe1, st));
+            hipLaunchKernelGGL(k_bin_misc_cells, dim3(64), dim3(256), 0, st, a, (const unsigned long long*)&ws->d_counters[CTR_HITS]);
+            hipLaunchKernelGGL(k_cell_counts, dim3((ncells + 255) / 256), dim3(256), 0, st, (const unsigned int*)ws->d_cells, ncells, d_send_counts, ws->d_counters);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipMemcpyAsync(ws->h_cells, d_stats32, (LEAN_STAT_WORDS + 16) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            FPX_SYNC(ws);
+            if (ws->h_cells[LEAN_STAT_WORDS] != 0u && attempt == 0 && stride < max_len) { stride = (uint32_t)max_len; continue; }
+            if (ws->h_counters[CTR_HITS] > ws->cap_hits) {              // the misc buffer itself was too small
+                if (attempt >= 3) { set_error("fpx_shard_probe: misc buffer overflow persists"); return FPX_E_DEVICE; }
+                if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)ws->h_counters[CTR_HITS] + 1024))) return rc;
+                continue;
+            }
+            break;
+        }
+        if (ws->h_counters[CTR_TOTAL] > cell_cap) {
+            if (needed_cell_cap) *needed_cell_cap = ws->h_counters[CTR_TOTAL] * 5 / 4 + 256;
+            set_error("fpx_shard_probe: a cell holds %llu records, the send buffer has room for %llu per cell", (unsigned long long)ws->h_counters[CTR_TOTAL],
+                      (unsigned long long)cell_cap);
+            return FPX_E_AGAIN;
+        }
+        if (stats) {
+            const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
+            unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0;
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
+            stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS];
+            stats->algorithmic_bytes = blocks * 512ull; stats->probe_kernel_bytes = blocks * 512ull;
+            stats->probe_kernel_fetched_bytes = dreads * 64ull; stats->probe_kernel_ms = ms; stats->total_gpu_ms = ms; stats->probe_launches = 1;
+            stats->path_flags = 1u | 4u | 8u | 16u;
+        }
+        return FPX_OK;
+    };
+    const int rc = body();
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    ws_release(snap->ctx, ws);
+    return rc;
+}
+
+int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
+                     uint32_t timeout_ms, fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n)
+{
+    if (qb->ctx != ctx) { set_error("query batch belongs to a different context"); return FPX_E_INVAL; }
+    const uint32_t B = qb->B;
+    if (B == 0) return FPX_OK;
+    const unsigned qbits = bits_for(B);
+    const uint32_t nbins = (uint32_t)shard_cell_bins(B);
+    FPX_HIP(hipSetDevice(ctx->device));
+    Workspace* ws = ws_acquire(ctx);
+    if (!ws) return FPX_E_NOMEM;
+    auto body = [&]() -> int {
+        int rc;
+        hipStream_t st = ws->stream;
+        const double t_start = now_ms();
+        __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);
+        const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
+        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1) + nbins))) return rc;
+        uint64_t* d_qcand = ws->d_qcand;
+        uint32_t* d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
+        uint32_t* d_bin_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS + (size_t)B / 2 + 1);
+        const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
+        if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
+        FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+        const uint32_t sbf = 32u - qbits;
+        static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)lds_attr;
+        ScoreBinArgs sa{};
+        sa.bins = d_recv; sa.bin_cap = cell_cap; sa.bin_count = d_recv_counts; sa.nsrc = world; sa.src_stride = (uint64_t)nbins * cell_cap;
+        sa.count_stride = nbins; sa.count_step = 1u; sa.bq = SHARD_BQ; sa.B = B;
+        sa.opts = qb->d_opts; sa.sb = sbf; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
+        sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
+        const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << SHARD_BQ) * 8u;
+        hipLaunchKernelGGL(k_score_bin, dim3(nbins), dim3(SB_WG), sb_lds, st, sa);
+        hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st, (const uint64_t*)ws->d_cands[0], (uint64_t)0, (const uint32_t*)qb->d_opts, B, sbf, 1,
+                           d_out, out_cap, d_out_n, (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, (unsigned long long*)nullptr);
+        FPX_HIP(hipGetLastError());
+        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        FPX_SYNC(ws);
+        if (ws->h_counters[CTR_BINFAIL] != 0 || ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands) {
+            set_error("fpx_shard_score: a bin could not be scored in place (%s): use smaller batches or the record protocol (fpx_score_partial)",
+                      ws->h_counters[CTR_BINFAIL] == 2 ? "a received cell overflowed" : ws->h_counters[CTR_MAXSCORE] ? "a score does not fit the candidate key" : "too many candidates");
+            return FPX_E_INVAL;
+        }
+        if (ws->h_counters[CTR_CANDS] != 0) {             // queries with more candidates than slots: sort the shared list, finish again
+            const uint64_t Cf = ws->h_counters[CTR_CANDS];
+            int ccur = 0;
+            const size_t tb2 = sort_u64_temp_bytes(Cf, 0, 64);
+            if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb2 + 256))) return rc;
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_cands[0], ws->d_cands[1], Cf, 0, 64, st, &ccur));
+            hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st, (const uint64_t*)ws->d_cands[ccur], Cf, (const uint32_t*)qb->d_opts, B, sbf, 1,
+                               d_out, out_cap, d_out_n, (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, (unsigned long long*)nullptr);
+            FPX_HIP(hipGetLastError());
+            FPX_SYNC(ws);
+        }
+        return FPX_OK;
+    };
+    const int rc = body();
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
     ws_release(ctx, ws);
     return rc;
 }

@@ -163,6 +163,16 @@ class FileSegment(_Segment):
         _Segment.__init__(self, ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
         return self
 
+    def window(self, lo_excl, hi_incl):
+        """The hash-window slice (lo_excl, hi_incl] of this resident segment, cut on the device (fpx_segment_slice; None =
+        unbounded).  The segment must still be in its blocks: no snapshot has held it yet."""
+        h = C.c_void_p()
+        check(lib().fpx_segment_slice(self.h, 0 if lo_excl is None else 1, 0 if lo_excl is None else int(lo_excl),
+                                      0 if hi_incl is None else 1, 0 if hi_incl is None else int(hi_incl), C.byref(h)))
+        out = FileSegment.__new__(FileSegment)
+        _Segment.__init__(out, self.ctx, h, self.commit_id, self.min_doc_id, self.max_doc_id, self.doc_ids, self.doc_alive)
+        return out
+
     @classmethod
     def synth(cls, ctx, seed, first_doc, num_docs, hashes_per_doc, dist=0, block_size=512, commit_id=1):
         """Seeded synthetic segment built on the GPU (fpx_synth_segment)."""
@@ -477,6 +487,30 @@ def probe_resident(reader, qb, world, d_records_ptr, records_cap, timeout_ms=0):
     st = Stats()
     check(lib().fpx_probe_resident(reader.snapshot.h, qb.h, world, timeout_ms, d_records_ptr, records_cap, _p(counts), C.byref(st)))
     return counts, st
+
+
+def shard_cell_bins(num_queries):
+    return lib().fpx_shard_cell_bins(num_queries)
+
+
+def shard_probe(reader, qb, world, d_send_ptr, cell_cap, d_send_counts_ptr, timeout_ms=0):
+    """stage 1 of the cell protocol of hash-range sharding (fpx_shard_probe): this rank's records dropped into cells
+    [world][bins][cell_cap].  Returns (stats, 0) or (None, needed_cell_cap) when a cell outgrew cell_cap."""
+    from ._lib import FPX_E_AGAIN
+    st = Stats()
+    need = C.c_uint64(0)
+    rc = lib().fpx_shard_probe(reader.snapshot.h, qb.h, world, timeout_ms, C.c_void_p(d_send_ptr), int(cell_cap), C.c_void_p(d_send_counts_ptr),
+                               C.byref(need), C.byref(st))
+    if rc == FPX_E_AGAIN:
+        return None, int(need.value)
+    check(rc)
+    return st, 0
+
+
+def shard_score(ctx, qb, world, d_recv_ptr, cell_cap, d_recv_counts_ptr, d_out_ptr, d_out_n_ptr, timeout_ms=0):
+    """stage 2 of the cell protocol (fpx_shard_score): the received cells -> per-query partial tables in HBM"""
+    check(lib().fpx_shard_score(ctx.h, qb.h, world, C.c_void_p(d_recv_ptr), int(cell_cap), C.c_void_p(d_recv_counts_ptr), timeout_ms,
+                                C.c_void_p(d_out_ptr), qb.cap, C.c_void_p(d_out_n_ptr)))
 
 
 def score_partial(ctx, qb, d_records_ptr, num_records, d_out_ptr, d_out_n_ptr, timeout_ms=0):

@@ -117,20 +117,99 @@ def exchange_records(dist, records, counts, world, group=None):
     return got
 
 
-class HashShardedReader:
-    """IndexReader over a snapshot of hash-range SLICES (this rank's slice of every segment): probe -> all-to-all of
-    the hit records by doc & (world - 1) -> score -> all-gather of the tables -> merge."""
+def exchange_cells(dist, send, send_counts, world, group=None):
+    """all-to-all of the cells of fpx_shard_probe: `send` [world, bins, cell_cap] int64 and `send_counts` [world, bins] int32 --
+    row r travels to rank r.  Fixed shapes: one collective each, nothing to agree on first.  Returns (recv, recv_counts) of the
+    same shapes, row r = what rank r sent."""
+    import torch
+    recv, recv_counts = torch.empty_like(send), torch.empty_like(send_counts)
+    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    dist.all_to_all_single(recv_counts.view(-1), send_counts.view(-1), group=group)
+    return recv, recv_counts
 
-    def __init__(self, fpx, ctx, reader, dist, world):
+
+class HashShardedReader:
+    """IndexReader over a snapshot of hash-range SLICES -- this rank's window of the hash space of every segment.
+    A rank makes, sorts and probes only the query hashes of its window; the hit records travel to the rank that owns their
+    doc (doc & (world - 1)), which counts them; the per-query tables are all-gathered and merged.
+
+    Two protocols with the same results: the CELL protocol (fpx_shard_probe / fpx_shard_score: records dropped into
+    fixed-shape cells as they are produced, one all-to-all, a bin scored per workgroup) for snapshots made of groups of
+    direct-addressed slices, and the RECORD protocol (fpx_probe_resident / fpx_score_partial: records sorted by destination,
+    a size exchange, then the records) for everything else."""
+
+    def __init__(self, fpx, ctx, reader, dist, world, host_staged=False, cells=True):
         if world & (world - 1):
             raise ValueError("hash-range sharding needs a power-of-two world size")
         self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
+        self.host_staged = host_staged      # debugging aid: exchange through host memory with a CPU backend (gloo)
+        self.cells = cells
         self._rec = None
         self._bufs = {}
+        self._cellbufs = {}
+        self.cell_cap = 0
         import torch
         self.device = torch.device("cuda", ctx.device)
 
-    def search_resident(self, qb, out=None, out_n=None):
+    def _tables(self, qb):
+        import torch
+        key = (qb.B, qb.cap)
+        if key not in self._bufs:
+            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device=self.device),
+                               torch.zeros((qb.B,), dtype=torch.int32, device=self.device))
+        return self._bufs[key]
+
+    # ---- cell protocol
+    def partial(self, qb):
+        """stage 1 (any thread): this rank's records into the send cells.  Returns the stats, or None when the snapshot
+        does not qualify for the cell protocol (search_resident then takes the record protocol)."""
+        import torch
+        fpx = self.fpx
+        if not self.cells:
+            return None
+        bins = fpx.shard_cell_bins(qb.B)
+        while True:
+            if self.cell_cap == 0:
+                self.cell_cap = 4096
+            key = (qb.B, self.cell_cap)
+            if key not in self._cellbufs:
+                self._cellbufs = {key: (torch.empty((self.world, bins, self.cell_cap), dtype=torch.int64, device=self.device),
+                                        torch.zeros((self.world, bins), dtype=torch.int32, device=self.device))}
+            send, send_counts = self._cellbufs[key]
+            try:
+                st, need = fpx.shard_probe(self.reader, qb, self.world, send.data_ptr(), self.cell_cap, send_counts.data_ptr())
+            except fpx.FpxError as e:
+                if e.status == -4:              # FPX_E_INVAL: not a snapshot of groups alone
+                    self.cells = False
+                    return None
+                raise
+            if st is not None:
+                return st
+            self.cell_cap = int(need)           # a cell outgrew the buffer: the call says how much it takes
+
+    def gather_merge(self, qb, out=None, out_n=None):
+        """stages 2-4 (every rank in the same order): all-to-all of the cells, score, all-gather of the tables, merge"""
+        import torch
+        fpx = self.fpx
+        send, send_counts = self._cellbufs[(qb.B, self.cell_cap)]
+        if self.host_staged:
+            recv, recv_counts = exchange_cells(self.dist, send.cpu(), send_counts.cpu(), self.world)
+            recv, recv_counts = recv.to(self.device), recv_counts.to(self.device)
+        else:
+            recv, recv_counts = exchange_cells(self.dist, send, send_counts, self.world)      # RCCL all-to-all over xGMI
+        torch.cuda.current_stream(self.device).synchronize()
+        d_part, d_cnt = self._tables(qb)
+        fpx.shard_score(self.ctx, qb, self.world, recv.data_ptr(), self.cell_cap, recv_counts.data_ptr(), d_part.data_ptr(), d_cnt.data_ptr())
+        if self.host_staged:
+            tables, cnts = gather_tables(self.dist, d_part.cpu(), d_cnt.cpu(), self.world)
+            tables, cnts = tables.to(self.device), cnts.to(self.device)
+        else:
+            tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
+        torch.cuda.current_stream(self.device).synchronize()
+        return fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
+
+    # ---- record protocol (any snapshot)
+    def _search_records(self, qb, out, out_n):
         import torch
         fpx = self.fpx
         if self._rec is None:
@@ -146,13 +225,16 @@ class HashShardedReader:
                 self._rec = torch.empty((need,), dtype=torch.int64, device=self.device)
         got = exchange_records(self.dist, self._rec, counts, self.world)
         torch.cuda.current_stream(self.device).synchronize()
-        key = (qb.B, qb.cap)
-        if key not in self._bufs:
-            self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device=self.device),
-                               torch.zeros((qb.B,), dtype=torch.int32, device=self.device))
-        d_part, d_cnt = self._bufs[key]
+        d_part, d_cnt = self._tables(qb)
         fpx.score_partial(self.ctx, qb, got.data_ptr(), got.numel(), d_part.data_ptr(), d_cnt.data_ptr())
         tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
         torch.cuda.current_stream(self.device).synchronize()
         out, out_n = fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
+        return out, out_n, st
+
+    def search_resident(self, qb, out=None, out_n=None):
+        st = self.partial(qb)
+        if st is None:
+            return self._search_records(qb, out, out_n)
+        out, out_n = self.gather_merge(qb, out, out_n)
         return out, out_n, st

@@ -36,6 +36,7 @@ extern "C" {
 #define FPX_E_DEVICE   -3   /* HIP runtime / kernel failure */
 #define FPX_E_INVAL    -4   /* malformed argument */
 #define FPX_E_NODEVICE -5   /* no gfx950 device visible: the HIP path is the only path */
+#define FPX_E_AGAIN    -6   /* a caller-provided device buffer was too small; the call reports the size it needs: retry */
 
 typedef struct fpx_ctx fpx_ctx;
 typedef struct fpx_segment fpx_segment;
@@ -257,6 +258,10 @@ int fpx_segment_create_file_slice(fpx_ctx *ctx, const uint8_t *blocks, size_t bl
                                   const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs,
                                   fpx_segment **out);
 
+/* The same cut on the device: a hash-window slice of a RESIDENT file segment that is still in its blocks (no snapshot has held
+ * it yet); the source stays as it is and can be released afterwards. */
+int fpx_segment_slice(fpx_segment *seg, int has_lo, uint32_t lo_excl, int has_hi, uint32_t hi_incl, fpx_segment **out);
+
 /* With slices a document's postings come from several GPUs, so its score is a true sum across ranks: the pipeline is
  * cut at the hit records.  Stage 1 (fpx_probe_resident) runs the probes of the local snapshot only and writes the
  * records (q << 32 | doc) to `d_records` (device memory, room for `records_cap`), grouped by destination rank
@@ -270,6 +275,28 @@ int fpx_probe_resident(fpx_snapshot *snap, const fpx_query_batch *qb, uint32_t w
 int fpx_score_partial(fpx_ctx *ctx, const fpx_query_batch *qb, const void *d_records, uint64_t num_records,
                       uint32_t timeout_ms, void *d_out /* [B][out_cap] fpx_result */, uint32_t out_cap,
                       void *d_out_n /* [B] uint32 */);
+
+/* ---- an index sharded by HASH RANGE over the GPUs of a node: the scalable multi-GPU shape ------------------
+ * Every rank holds the SAME window of the hash space of ALL segments -- hash-window slices (fpx_segment_create_file_slice, or
+ * fpx_segment_slice of a resident segment) with one window; fpx_snapshot_create puts them into a group with that window -- so
+ * a rank makes, sorts and probes only the query hashes of its window: 1/N of the batch's work, where segment sharding leaves
+ * every rank the whole batch.  A hash's walk is independent of every other hash (src/FileSegment.zig:143-176) and
+ * SearchResults.incr is a keyed sum (src/common.zig:121-129), so the ranks exchange HIT RECORDS (q << 32 | doc), each to the
+ * rank that owns its doc (doc & (world - 1)), and the owner counts them -- exact.
+ *   fpx_shard_probe   the records of this rank's window, dropped straight into CELLS: cell (r, b) holds the records for
+ *                     rank r of query bin b (64 queries), d_send = [world][bins][cell_cap] records (DEVICE memory),
+ *                     d_send_counts = [world][bins] uint32 fill counts; bins = fpx_shard_cell_bins(num_queries).
+ *                     FPX_E_AGAIN: a cell outgrew cell_cap -- *needed_cell_cap says what to allocate; retry.
+ *                     FPX_E_INVAL for snapshots that hold anything but such groups: use fpx_probe_resident / fpx_score_partial.
+ *   (the caller's all-to-all, e.g. RCCL: row r of d_send and of d_send_counts travels to rank r; fixed shapes)
+ *   fpx_shard_score   d_recv = [world][bins][cell_cap], d_recv_counts = [world][bins] as received: the per-query tables
+ *                     fpx_search_resident_partial would write (absolute floor only), for fpx_merge_partials after an all-gather.
+ * Counters in `stats` (scanned blocks / docs / probes) are this rank's share: their sum over the ranks is the unsharded total. */
+uint32_t fpx_shard_cell_bins(uint32_t num_queries);
+int fpx_shard_probe(fpx_snapshot *snap, const fpx_query_batch *qb, uint32_t world, uint32_t timeout_ms,
+                    void *d_send, uint64_t cell_cap, void *d_send_counts, uint64_t *needed_cell_cap, fpx_stats *stats);
+int fpx_shard_score(fpx_ctx *ctx, const fpx_query_batch *qb, uint32_t world, const void *d_recv, uint64_t cell_cap,
+                    const void *d_recv_counts, uint32_t timeout_ms, void *d_out, uint32_t out_cap, void *d_out_n);
 
 /* ---- device-side segment build and merge -------------------------------------------------------
  * fpx_segment_build: filefmt.writeBlocks + BlockEncoder (src/filefmt.zig:94-138, src/block.zig:438-567) run on the GPU

@@ -7,7 +7,7 @@ from ._lib import FpxError, SearchTimeout, Stats, lib, LIB_PATH  # noqa: F401
 from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegment, SearchOptions,  # noqa: F401
                     SearchResults, Segments, http_options, QueryBatch, search_resident, search_resident_partial,
                     merge_partials, results_to_lists, build_memory_segment, probe_resident, score_partial,
-                    shard_cell_bins, shard_probe, shard_score,
+                    shard_bins_per_rank, shard_probe, shard_score, merge_partials_raw,
                     ShardedSegments, ShardedIndexReader, host_array)
 from . import synth  # noqa: F401
 from . import sharding  # noqa: F401

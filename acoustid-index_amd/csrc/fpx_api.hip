@@ -824,25 +824,25 @@ int fpx_score_partial(fpx_ctx* ctx, const fpx_query_batch* qb, const void* d_rec
                               reinterpret_cast<fpx_result*>(d_out), out_cap, reinterpret_cast<uint32_t*>(d_out_n));
 }
 
-uint32_t fpx_shard_cell_bins(uint32_t num_queries) { return (uint32_t)shard_cell_bins(num_queries); }
+uint32_t fpx_shard_bins_per_rank(uint32_t num_queries, uint32_t world) { return world ? (uint32_t)shard_bins_per_rank(num_queries, world) : 0u; }
 
 int fpx_shard_probe(fpx_snapshot* snap, const fpx_query_batch* qb, uint32_t world, uint32_t timeout_ms,
                     void* d_send, uint64_t cell_cap, void* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats)
 {
     if (!snap || !qb || !d_send || !d_send_counts || cell_cap == 0) { set_error("null argument"); return FPX_E_INVAL; }
-    if (world == 0 || (world & (world - 1)) != 0 || world > 16) { set_error("world must be a power of two <= 16"); return FPX_E_INVAL; }
+    if (world == 0 || world > 64) { set_error("world must be 1..64"); return FPX_E_INVAL; }
     return shard_probe_impl(reinterpret_cast<Snapshot*>(snap), reinterpret_cast<const QueryBatch*>(qb), world, timeout_ms,
                             reinterpret_cast<uint64_t*>(d_send), cell_cap, reinterpret_cast<uint32_t*>(d_send_counts), needed_cell_cap, stats);
 }
 
-int fpx_shard_score(fpx_ctx* ctx, const fpx_query_batch* qb, uint32_t world, const void* d_recv, uint64_t cell_cap, const void* d_recv_counts,
-                    uint32_t timeout_ms, void* d_out, uint32_t out_cap, void* d_out_n)
+int fpx_shard_score(fpx_ctx* ctx, const fpx_query_batch* qb, uint32_t world, uint32_t rank, const void* d_recv, uint64_t cell_cap,
+                    const void* d_recv_counts, uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n,
+                    uint32_t* first_query, uint32_t* num_queries)
 {
-    if (!ctx || !qb || !d_recv || !d_recv_counts || !d_out_n || (!d_out && out_cap)) { set_error("null argument"); return FPX_E_INVAL; }
-    if (world == 0 || (world & (world - 1)) != 0 || world > 16) { set_error("world must be a power of two <= 16"); return FPX_E_INVAL; }
-    return shard_score_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb), world, reinterpret_cast<const uint64_t*>(d_recv), cell_cap,
-                            reinterpret_cast<const uint32_t*>(d_recv_counts), timeout_ms, reinterpret_cast<fpx_result*>(d_out), out_cap,
-                            reinterpret_cast<uint32_t*>(d_out_n));
+    if (!ctx || !qb || !d_recv || !d_recv_counts || !out_n || (!out && out_cap)) { set_error("null argument"); return FPX_E_INVAL; }
+    if (world == 0 || world > 64 || rank >= world) { set_error("world must be 1..64, rank below it"); return FPX_E_INVAL; }
+    return shard_score_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb), world, rank, reinterpret_cast<const uint64_t*>(d_recv), cell_cap,
+                            reinterpret_cast<const uint32_t*>(d_recv_counts), timeout_ms, out, out_cap, out_n, first_query, num_queries);
 }
 
 int fpx_merge_partials(fpx_ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world, uint32_t num_queries,
@@ -897,6 +897,9 @@ int fpx_segment_merge(fpx_snapshot* collection, fpx_segment* const* sources, uin
         size_t si = 0;
         while (si < sn->segs.size() && sn->segs[si] != g) ++si;
         if (!g || si == sn->segs.size()) { set_error("source %u is not a segment of the collection", i); return FPX_E_INVAL; }
+        // (a collection may hold segments that are resident on another context's device -- docs-only members of a sharded
+        // host's snapshots: their postings cannot be read from here.  Merges run per device.)
+        if (g->kind != 2 && g->ctx != sn->ctx) { set_error("source %u is resident on another context: merge it on the context that holds it", i); return FPX_E_INVAL; }
         if (i > 0 && g->commit_id <= reinterpret_cast<const Segment*>(sources[i - 1])->commit_id) {
             set_error("sources must be ordered oldest to newest"); return FPX_E_INVAL;
         }

@@ -38,7 +38,8 @@ struct GroupArgs {
 
 constexpr uint32_t GK_WORDS = 12;          // words of a hash fetched by its lane (three dwordx4); the rare rest by the wave
 
-// BINNED: the records go straight into BINS of 2^bin_shift queries (fpx_score_bin.hpp scores a bin per workgroup).  With the keys
+// BINNED: the records go straight into BINS of 2^bin_shift queries (fpx_score_bin.hpp scores a bin per workgroup; on an index
+// sharded by hash range the bins are what the ranks exchange: a bin travels to the rank that finishes its queries).  With the keys
 // in (hash bucket, query) order -- what the one stable radix pass on the top hash bits leaves, k_make_keys_dedup having written
 // them query by query -- the 256 keys of a round belong to a few dozen neighbouring queries: a handful of bins, one reservation
 // each, runs of a kilobyte.  (Binning all 64+ bins of the batch in every flush was measured twice and cost what it saved.)
@@ -46,18 +47,9 @@ constexpr uint32_t GB_SLOTS = 128;         // cells a round may touch (gb_slot; 
 constexpr uint32_t GB_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t GB_NEED = 0xFFFFFFF0u;   // s_rank: the staged record has no rank in its bin yet (every entry between rounds)
 
-// the cell of a record -- its query's bin, and on a sharded index the rank that owns its doc -- and the cell's slot in a round's
-// table: the low bits of the bin next to the destination (a round's keys belong to neighbouring queries: neighbouring bins)
-__device__ __forceinline__ uint32_t gb_cell(const ProbeArgs& a, uint64_t rec)
-{
-    const uint32_t qbin = (uint32_t)(rec >> 32) >> a.bin_shift;
-    return a.dest_bits ? ((uint32_t)rec & ((1u << a.dest_bits) - 1u)) * a.cell_bins + qbin : qbin;
-}
-__device__ __forceinline__ uint32_t gb_slot(const ProbeArgs& a, uint64_t rec)
-{
-    const uint32_t qbin = (uint32_t)(rec >> 32) >> a.bin_shift, qb = 7u - a.dest_bits;         // (dest_bits <= 4)
-    return (qbin & ((1u << qb) - 1u)) | (((uint32_t)rec & ((1u << a.dest_bits) - 1u)) << qb);
-}
+// the bin of a record, and the bin's slot in a round's table (a round's keys belong to neighbouring queries: neighbouring bins)
+__device__ __forceinline__ uint32_t gb_cell(const ProbeArgs& a, uint64_t rec) { return (uint32_t)(rec >> 32) >> a.bin_shift; }
+__device__ __forceinline__ uint32_t gb_slot(const ProbeArgs& a, uint64_t rec) { return ((uint32_t)(rec >> 32) >> a.bin_shift) & (GB_SLOTS - 1u); }
 
 template <int NS, bool BINNED>
 __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga)
@@ -224,12 +216,9 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
                 atomicMin(hs.valid, pos);
                 gpos = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)cnt);
             } else if constexpr (BINNED) {
-                brank = GB_EMPTY;                            // (sharded: the records of a lane go to several ranks -- ranked one by one at the flush)
-                if (a.dest_bits == 0u) {
-                    const uint32_t b = gb_cell(a, qpart), bslot = gb_slot(a, qpart);
-                    const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
-                    if (old == GB_EMPTY || old == b) brank = atomicAdd(&s_bcnt[par][bslot], cnt);              // (two bins on one slot: ranked at the flush)
-                }
+                const uint32_t b = gb_cell(a, qpart), bslot = gb_slot(a, qpart);
+                const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
+                brank = (old == GB_EMPTY || old == b) ? atomicAdd(&s_bcnt[par][bslot], cnt) : GB_EMPTY;       // (two bins on one slot: the misc buffer)
             }
         }
         uint32_t o = 0;

@@ -318,11 +318,11 @@ int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uin
                        uint64_t* d_records, uint64_t records_cap, uint64_t* counts, fpx_stats* stats);
 int score_records_impl(Ctx* ctx, const QueryBatch* qb, const uint64_t* d_records, uint64_t num_records, uint32_t timeout_ms,
                        fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n);
-int shard_cell_bins(uint32_t B);
+int shard_bins_per_rank(uint32_t B, uint32_t world);
 int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
                      uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats);
-int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
-                     uint32_t timeout_ms, fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n);
+int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
+                     uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries);
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
                         uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n);

@@ -75,6 +75,19 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs b, const uint64_t* __restri
     }
 }
 
+// the same for more bins than a workgroup's LDS counts (a sharded batch of 2^17+ queries): one atomic per record -- only for the few
+// records a probe kernel could not place itself
+__global__ __launch_bounds__(256) void k_bin_each(BinArgs b, const uint64_t* __restrict__ recs, const unsigned long long* __restrict__ count, uint64_t cap)
+{
+    const uint64_t n = min((uint64_t)*count, cap);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t r = recs[i];
+        const uint32_t bn = (uint32_t)(r >> 32) >> b.shift;
+        const uint32_t at = atomicAdd(&b.bin_count[(size_t)bn * BIN_STRIDE], 1u);
+        if (at < b.bin_cap) b.bins[(size_t)bn * b.bin_cap + at] = r;
+    }
+}
+
 // level 2a: how many records each query has.  grid (tiles of the bins' capacity, nbins)
 __global__ __launch_bounds__(256) void k_l2_count(BinArgs b, uint32_t* __restrict__ qcount, uint32_t B)
 {

@@ -34,9 +34,6 @@ struct ProbeArgs {
     uint32_t key_skip;                // low hash bits the pairs are NOT sorted on (KEY_SORT_SKIP; the direct-addressed kernels read it)
     // k_probe_group<.., BINNED>: records go to bins of 2^bin_shift queries ([nbins][bin_cap] records; fill counters BIN_STRIDE words apart)
     uint64_t* bins = nullptr; uint64_t bin_cap = 0; unsigned int* bin_count = nullptr; uint32_t bin_shift = 0;
-    // ... of an index sharded by hash range: a record belongs to the rank that owns its doc, dest = doc & (2^dest_bits - 1), and
-    // goes to cell dest * cell_bins + (q >> bin_shift) -- the ranks exchange the cells and score what they receive
-    uint32_t dest_bits = 0, cell_bins = 0;
     const unsigned long long* P_dev = nullptr;   // the number of pairs lives on the device (a rank's compacted share of the keys): P is their capacity
 };
 

@@ -319,10 +319,13 @@ __global__ __launch_bounds__(WG) void k_score(const uint64_t* __restrict__ hits,
 __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const uint32_t* __restrict__ opts, uint32_t B,
                          uint32_t sb, int partial, fpx_result* out, uint32_t out_cap, uint32_t* out_n,
                          const uint64_t* __restrict__ qcand = nullptr, const uint32_t* __restrict__ qcand_n = nullptr,
-                         unsigned long long* counters = nullptr)
+                         unsigned long long* counters = nullptr, uint32_t q_first = 0)
 {
+    // (q_first: the B queries handled here are the batch's q_first .. q_first + B - 1 -- a rank's share of a sharded batch:
+    // candidate keys and options carry batch numbers, the slot arrays and the outputs are the share's own)
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = q < B;
+    opts += (size_t)q_first * 4u;
     const uint32_t max_results = live ? opts[q * 4u + 0u] : 0u;
     uint32_t min_score = live ? opts[q * 4u + 1u] : 0u;
     const uint32_t pct = live ? opts[q * 4u + 2u] : 0u;
@@ -356,7 +359,7 @@ __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const u
         for (uint32_t i = 0; i < QCAND_SLOTS; ++i)
             if (i < nslots && !visit(k[i])) break;
     } else if (live) {
-        const uint64_t qkey = sb >= 32u ? 0ull : ((uint64_t)q << (32u + sb));
+        const uint64_t qkey = sb >= 32u ? 0ull : ((uint64_t)(q + q_first) << (32u + sb));
         uint64_t lo = 0, hi = C;
         while (lo < hi) {
             uint64_t m = (lo + hi) >> 1;
@@ -364,7 +367,7 @@ __global__ void k_finish(const uint64_t* __restrict__ cands, uint64_t C, const u
         }
         for (uint64_t i = lo; i < C; ++i) {
             const uint64_t k = cands[i];
-            if (sb < 32u && (k >> (32u + sb)) != (uint64_t)q) break;
+            if (sb < 32u && (k >> (32u + sb)) != (uint64_t)(q + q_first)) break;
             if (!visit(k)) break;
         }
     }
@@ -445,8 +448,9 @@ __global__ void k_merge(const fpx_result* __restrict__ parts, const uint32_t* __
     // k-way merge with per-rank cursors kept implicitly: pick the best head > last emitted
     uint64_t last = ~0ull;   // key of the last emitted entry: (score << 32 | ~id), descending order
     bool first = true;
+    const uint32_t stop = min(max_results, out_cap);      // (nothing beyond out_cap is written or counted)
     for (;;) {
-        if (n == max_results) break;
+        if (n >= stop) break;
         uint64_t best = 0; bool have = false;
         for (uint32_t r = 0; r < world; ++r) {
             const uint32_t cnt = counts[(size_t)r * B + q];

@@ -26,6 +26,7 @@ struct ScoreBinArgs {
     uint32_t nsrc;                                 // the bin's records come in `nsrc` pieces (what each rank of a sharded index sent): piece r of
     uint64_t src_stride; uint32_t count_stride, count_step;    // bin b = bins + r * src_stride + b * bin_cap, its count = bin_count[r * count_stride + b * count_step]
     uint32_t bq;                                   // log2 of the queries per bin
+    uint32_t bin_base;                             // workgroup i takes bin bin_base + i of the batch (queries from (bin_base + i) << bq); its records are bin i of every piece
     uint32_t B;
     const uint32_t* opts;                          // [B][4]
     uint32_t sb;                                   // bits of the score field in a candidate key
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
     __shared__ uint32_t s_floor[SB_QMAX], s_ccnt[SB_QMAX], s_cbase[SB_QMAX], s_over[SB_QMAX];
     __shared__ uint32_t s_claimed, s_full, s_cancel;
     const uint32_t tid = threadIdx.x, bin = blockIdx.x;
-    const uint32_t nq = 1u << a.bq, q0 = bin << a.bq, qm = nq - 1u;
+    const uint32_t nq = 1u << a.bq, q0 = (a.bin_base + bin) << a.bq, qm = nq - 1u;
     if (tid == 0) s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;
     if (tid < nq) {
         const uint32_t q = q0 + tid;

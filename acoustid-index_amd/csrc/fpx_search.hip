@@ -253,10 +253,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                      const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                      fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, const Exchange* ex = nullptr,
-                     bool no_fast = false)
+                     bool no_fast = false, double t_call = 0.0)
 {
     const bool probe_only = ex && ex->mode == 1, score_only = ex && ex->mode == 2;
-    const double t_start = now_ms();
+    // the deadline counts from the API call's entry (one deadline per search, src/MultiIndex.zig:314-322), however often the
+    // batch re-enters here (a redo on the general path, the two halves of a split)
+    const double t_start = t_call != 0.0 ? t_call : now_ms();
     hipStream_t st = ws->stream;
     __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);           // (the stream is idle: the previous call synchronised it)
     const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
@@ -813,7 +815,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         const bool fits = H <= ws->cap_hits && ws->h_counters[CTR_CANDS] <= SINGLE_CANDS && ws->h_counters[CTR_MAXSCORE] == 0;
         if (!fits) {                           // rare: rerun on the general path (which grows buffers / splits as needed)
             if (H > ws->cap_hits && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
-            return run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, ex, true);
+            return run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, ex, true, t_start);
         }
         *out_n = (uint32_t)ws->h_counters[CTR_COUNT];
         std::memcpy(out, ws->h_counters + CTR_COUNT + 1, (size_t)*out_n * sizeof(fpx_result));
@@ -1030,15 +1032,15 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
 static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
                         const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                         const fpx_opts* opts, uint32_t timeout_ms, bool partial,
-                        fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+                        fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, double t_call)
 {
     Workspace* ws = ws_acquire(snap->ctx);
     if (!ws) return FPX_E_NOMEM;
     fpx_stats local{};
-    int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local);
+    int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, false, t_call);
     if (rc == FPX_REDO) {                       // the device-sized path gave up (after its synchronisation): the general path
         local = fpx_stats{};
-        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, true);
+        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, true, t_call);
     }
     if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
     ws_release(snap->ctx, ws);
@@ -1046,11 +1048,11 @@ static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
     if (rc != FPX_SPLIT) return rc;
     if (B <= 1) { set_error("internal: single query cannot be split"); return FPX_E_DEVICE; }
     const uint32_t half = B / 2;
-    rc = search_split(snap, resident, q0, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+    rc = search_split(snap, resident, q0, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, stats, t_call);
     if (rc) return rc;
     fpx_result* out2 = out ? out + (size_t)half * out_cap : out;
     return search_split(snap, resident, q0 + half, hashes, offsets + half, B - half, opts + half, timeout_ms, partial,
-                        out2, out_cap, out_n + half, stats);
+                        out2, out_cap, out_n + half, stats, t_call);
 }
 
 int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
@@ -1069,7 +1071,7 @@ int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t
         if (offsets[q + 1] - offsets[q] >= (1ull << 32)) { set_error("query longer than 2^32-1 hashes"); return FPX_E_INVAL; }
     }
     FPX_HIP(hipSetDevice(snap->ctx->device));
-    return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats);
+    return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, now_ms());
 }
 
 int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
@@ -1183,30 +1185,29 @@ int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uin
 
 // ------------------------------------------------------------------------------------------------
 // An index sharded by HASH RANGE: every rank holds the same window of the hash space of ALL segments (its slice
-// of their group), so a rank makes, sorts and probes only the query hashes of its window -- 1/N of the batch's work -- and a
-// doc's postings come from every rank: its score is a true sum (SearchResults.incr is a keyed sum, src/common.zig:121-129; a
-// hash's walk is independent of every other hash, src/FileSegment.zig:143-176).  The pipeline is cut at the hit records:
-//   fpx_shard_probe   keys of the window -> k_probe_group<.., BINNED> drops the records into CELLS (destination rank = doc &
-//                     (N - 1), bin of 64 queries), [N][bins][cell_cap] in the caller's send buffer, + the cells' counts
-//   (the caller's all-to-all: cell row r travels to rank r -- fixed shapes, no sizes to agree on first)
-//   fpx_shard_score   k_score_bin over the N pieces of every bin -> per-query tables as fpx_search_resident_partial writes them
-//   (all-gather of the tables + fpx_merge_partials, as for segment sharding)
+// of their group), so a rank makes, sorts and probes only the query hashes of its window -- 1/N of the batch's work.  A query's
+// hit records then come from every rank; SearchResults.incr is a keyed sum (src/common.zig:121-129) and a hash's walk is
+// independent of every other hash (src/FileSegment.zig:143-176), so they may be counted wherever they are brought together:
+// rank r FINISHES the queries of its share of the batch's bins (bins of 8 queries, as on one GPU).
+//   fpx_shard_probe   keys of the window -> k_probe_group<.., BINNED> drops the records into the batch's bins, [N x bpr][cell_cap]
+//                     in the caller's send buffer (bpr = bins per rank), + the bins' fill counts
+//   (the caller's all-to-all: bins [r bpr, (r + 1) bpr) travel to rank r -- fixed shapes, no sizes to agree on first)
+//   fpx_shard_score   k_score_bin over the N pieces of each of the rank's bins + k_finish: the final results of its queries
+// No table gather, no merge: a query's results are complete on the rank that owns it.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t SHARD_BQ = 6;           // queries per cell bin: a rank receives 1/N of a bin's records -- 64 queries weigh what 8 do on one GPU
+constexpr uint32_t SHARD_BQ = 3;           // queries per bin, as on one GPU: a rank receives ALL records of its bins
 
-// per query: the hashes inside [win_lo, win_hi] -- duplicates flagged (dedupSorted, src/Index.zig:489-499) -- compacted into the
-// query's `stride` key slots, the rest of the slots filled with flagged keys (the probe kernels skip those)
+// per query: the hashes inside [win_lo, win_hi] -- later occurrences dropped (dedupSorted, src/Index.zig:489-499) -- compacted into
+// the query's `stride` key slots, the rest of the slots filled with flagged keys (the probe kernels skip those)
 __global__ __launch_bounds__(256) void k_make_keys_window(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
                                                           uint32_t B, uint32_t qb, uint64_t* __restrict__ keys, uint32_t stride,
-                                                          uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, unsigned int* zero_u32, uint32_t zero_n,
-                                                          uint32_t* __restrict__ overflow)
+                                                          uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, uint32_t* __restrict__ overflow)
 {
     __shared__ uint32_t tab[DEDUP_SLOTS];
     __shared__ uint32_t seen_ones, s_n;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     if (q >= B) return;
     if (q == 0 && tid < CTR_COUNT) counters[tid] = 0ull;
-    if (q == 0) for (uint32_t i = tid; i < zero_n; i += 256u) zero_u32[i] = 0u;
     for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
     if (tid == 0) { seen_ones = 0u; s_n = 0u; }
     __syncthreads();
@@ -1235,19 +1236,7 @@ __global__ __launch_bounds__(256) void k_make_keys_window(const uint32_t* __rest
     for (uint32_t i = min(s_n, stride) + tid; i < stride; i += 256u) mine[i] = KEY_DUP_FLAG | q;
 }
 
-// what k_probe_group could not place itself (a clash of two cells on one slot of a round, a full stage): one atomic per record
-__global__ __launch_bounds__(256) void k_bin_misc_cells(ProbeArgs a, const unsigned long long* __restrict__ count)
-{
-    const uint64_t n = min((uint64_t)*count, a.hit_cap);
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
-        const uint64_t rec = a.hits[i];
-        const uint32_t cell = gb_cell(a, rec);
-        const uint32_t at = atomicAdd(&a.bin_count[(size_t)cell * BIN_STRIDE], 1u);
-        if (at < a.bin_cap) a.bins[(size_t)cell * a.bin_cap + at] = rec;
-    }
-}
-
-// the cells' fill counts, compact (what travels with the cells), and the fullest one
+// the bins' fill counts, compact (what travels with the bins), the fullest one and their sum
 __global__ void k_cell_counts(const unsigned int* __restrict__ bin_count, uint32_t ncells, uint32_t* __restrict__ out, unsigned long long* __restrict__ counters)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1260,7 +1249,12 @@ __global__ void k_cell_counts(const unsigned int* __restrict__ bin_count, uint32
 
 static unsigned log2_exact(uint32_t v) { unsigned b = 0; while ((1u << b) < v) ++b; return b; }
 
-int shard_cell_bins(uint32_t B) { return (int)((B + (1u << SHARD_BQ) - 1u) >> SHARD_BQ); }
+// bins per rank: the batch's bins of 2^SHARD_BQ queries, dealt to the ranks in contiguous runs
+int shard_bins_per_rank(uint32_t B, uint32_t world)
+{
+    const uint32_t nb = (B + (1u << SHARD_BQ) - 1u) >> SHARD_BQ;
+    return (int)((nb + world - 1u) / world);
+}
 
 int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
                      uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats)
@@ -1270,7 +1264,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
     if (needed_cell_cap) *needed_cell_cap = 0;
     const uint32_t B = qb->B;
     if (B == 0) return FPX_OK;
-    // the fast protocol serves snapshots that are groups of direct-addressed segments with one hash window and nothing else;
+    // the bin protocol serves snapshots that are groups of direct-addressed segments with one hash window and nothing else;
     // anything else goes through fpx_probe_resident / fpx_score_partial (same results)
     if (snap->n_group == 0 || snap->n_solo != 0 || snap->n_file != 0 || snap->n_mem != 0) {
         set_error("fpx_shard_probe: the snapshot is not made of groups of direct-addressed segments alone (use fpx_probe_resident)"); return FPX_E_INVAL;
@@ -1283,9 +1277,13 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
     for (uint32_t q = 0; q < B; ++q) max_len = std::max<uint64_t>(max_len, offsets[q + 1] - offsets[q]);
     if (max_len > DEDUP_MAX) { set_error("fpx_shard_probe: queries of more than %u hashes (use fpx_probe_resident)", DEDUP_MAX); return FPX_E_INVAL; }
     if (max_len == 0) max_len = 1;
-    const unsigned qbits = bits_for(B), dest_bits = log2_exact(world);
-    if (dest_bits > 4u || qbits > 24u) { set_error("fpx_shard_probe: at most 16 ranks, 2^24 queries"); return FPX_E_INVAL; }
-    const uint32_t nbins = (uint32_t)shard_cell_bins(B), ncells = nbins * world;
+    const unsigned qbits = bits_for(B);
+    if (qbits > 24u) { set_error("fpx_shard_probe: at most 2^24 queries"); return FPX_E_INVAL; }
+    const uint32_t ncells = (uint32_t)shard_bins_per_rank(B, world) * world;
+    if (ncells > (1u << 21)) { set_error("fpx_shard_probe: too many bins"); return FPX_E_INVAL; }
+    // the window's share of the hash space (what fraction of a query's hashes to expect here)
+    const double share = ((double)win_hi - (double)win_lo + 1.0) / 4294967296.0;
+    const unsigned win_bits = log2_exact(std::max<uint32_t>(1u, (uint32_t)(1.0 / std::max(share, 1e-9) + 0.5)));      // the window's constant top hash bits
     FPX_HIP(hipSetDevice(snap->ctx->device));
     Workspace* ws = ws_acquire(snap->ctx);
     if (!ws) return FPX_E_NOMEM;
@@ -1295,7 +1293,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
         const double t_start = now_ms();
         __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);
         const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
-        // [cells' fill counters, a line each | LEAN_STAT_SETS x 8 u64 statistics slots | overflow flag]
+        // [bins' fill counters, a line each | LEAN_STAT_SETS x 8 u64 statistics slots | overflow flag]
         const size_t cell_words = (size_t)ncells * BIN_STRIDE, words = cell_words + LEAN_STAT_WORDS + 16;
         if (words > ws->cap_cells) {
             if (ws->d_cells) (void)hipFree(ws->d_cells);
@@ -1308,20 +1306,19 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
         uint32_t* d_stats32 = ws->d_cells + cell_words;
         uint32_t* d_overflow = d_stats32 + LEAN_STAT_WORDS;
         if (ws->cap_hits == 0 && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)1 << 22))) return rc;
-        // the window is 1 / world of the hash space: a query's share of its hashes + slack; a query that needs more has the
-        // whole query's length on the second attempt
-        uint32_t stride = (uint32_t)std::min<uint64_t>(max_len, (max_len + world - 1) / world * 5 / 4 + 48);
+        // a query's share of its hashes + slack; a query that needs more has the whole query's length on the second attempt
+        uint32_t stride = (uint32_t)std::min<uint64_t>(max_len, (uint64_t)((double)max_len * share * 1.25) + 48);
         for (int attempt = 0;; ++attempt) {
             const uint64_t P = (uint64_t)B * stride;
             if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
             FPX_HIP(hipMemsetAsync(ws->d_cells, 0, words * sizeof(uint32_t), st));
             hipLaunchKernelGGL(k_make_keys_window, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
-                               ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, (unsigned int*)nullptr, 0u, d_overflow);
+                               ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, d_overflow);
             FPX_HIP(hipGetLastError());
             // one stable pass on the 8 hash bits below the window's own: (bucket, query) order, as on one GPU
             int kcur = 0;
             if (P > (1ull << 18)) {
-                const unsigned hi_bit = 32u + qbits - dest_bits, lo_bit = hi_bit - 8u;
+                const unsigned hi_bit = 32u + qbits - std::min(win_bits, 16u), lo_bit = hi_bit - 8u;
                 const size_t tb = sort_u64_temp_bytes(P, lo_bit, hi_bit);
                 if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
                 FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, lo_bit, hi_bit, st, &kcur));
@@ -1332,7 +1329,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             a.def_list = nullptr; a.def_count = nullptr; a.def_cap = 0; a.ctr_off = 0; a.cancel = cancel;
             a.lean_stats = reinterpret_cast<unsigned long long*>(d_stats32);
             a.key_skip = KEY_SKIP_FLAGGED;
-            a.bins = d_send; a.bin_cap = cell_cap; a.bin_count = ws->d_cells; a.bin_shift = SHARD_BQ; a.dest_bits = dest_bits; a.cell_bins = nbins;
+            a.bins = d_send; a.bin_cap = cell_cap; a.bin_count = ws->d_cells; a.bin_shift = SHARD_BQ;
             const uint64_t wgs = (P + FK_WG - 1) / FK_WG;
             a.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs / 8192));
             const uint64_t per_wg = (uint64_t)FK_WG * a.rounds;
@@ -1344,7 +1341,13 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
                 else hipLaunchKernelGGL((k_probe_group<16, true>), grid, dim3(FK_WG), 0, st, a, gargs);
             }
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
-            hipLaunchKernelGGL(k_bin_misc_cells, dim3(64), dim3(256), 0, st, a, (const unsigned long long*)&ws->d_counters[CTR_HITS]);
+            // what the kernel could not place itself (a clash of two bins on one slot of a round, a full stage): k_bin
+            BinArgs hb{};
+            hb.bins = d_send; hb.bin_cap = cell_cap; hb.bin_count = ws->d_cells; hb.shift = SHARD_BQ; hb.nbins = std::min<uint32_t>(ncells, MAX_SBINS);
+            if (ncells <= MAX_SBINS)
+                hipLaunchKernelGGL(k_bin, dim3(64), dim3(256), 0, st, hb, (const uint64_t*)ws->d_hits[1], (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
+            else
+                hipLaunchKernelGGL(k_bin_each, dim3(64), dim3(256), 0, st, hb, (const uint64_t*)ws->d_hits[1], (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
             hipLaunchKernelGGL(k_cell_counts, dim3((ncells + 255) / 256), dim3(256), 0, st, (const unsigned int*)ws->d_cells, ncells, d_send_counts, ws->d_counters);
             FPX_HIP(hipGetLastError());
             FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1359,8 +1362,8 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             break;
         }
         if (ws->h_counters[CTR_TOTAL] > cell_cap) {
-            if (needed_cell_cap) *needed_cell_cap = ws->h_counters[CTR_TOTAL] * 5 / 4 + 256;
-            set_error("fpx_shard_probe: a cell holds %llu records, the send buffer has room for %llu per cell", (unsigned long long)ws->h_counters[CTR_TOTAL],
+            if (needed_cell_cap) *needed_cell_cap = ws->h_counters[CTR_TOTAL] * 17 / 16 + 128;      // (the bins of a batch differ by a few per cent)
+            set_error("fpx_shard_probe: a bin holds %llu records, the send buffer has room for %llu per bin", (unsigned long long)ws->h_counters[CTR_TOTAL],
                       (unsigned long long)cell_cap);
             return FPX_E_AGAIN;
         }
@@ -1383,14 +1386,18 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
     return rc;
 }
 
-int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
-                     uint32_t timeout_ms, fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n)
+int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
+                     uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries)
 {
     if (qb->ctx != ctx) { set_error("query batch belongs to a different context"); return FPX_E_INVAL; }
     const uint32_t B = qb->B;
-    if (B == 0) return FPX_OK;
+    const uint32_t bpr = (uint32_t)shard_bins_per_rank(B, world);
+    const uint32_t q_lo = std::min<uint64_t>(B, (uint64_t)rank * bpr << SHARD_BQ), q_hi = std::min<uint64_t>(B, (uint64_t)(rank + 1u) * bpr << SHARD_BQ);
+    if (first_query) *first_query = q_lo;
+    if (num_queries) *num_queries = q_hi - q_lo;
+    if (q_hi == q_lo) return FPX_OK;
+    const uint32_t nq = q_hi - q_lo;
     const unsigned qbits = bits_for(B);
-    const uint32_t nbins = (uint32_t)shard_cell_bins(B);
     FPX_HIP(hipSetDevice(ctx->device));
     Workspace* ws = ws_acquire(ctx);
     if (!ws) return FPX_E_NOMEM;
@@ -1400,31 +1407,41 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, const uint6
         const double t_start = now_ms();
         __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);
         const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
-        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1) + nbins))) return rc;
+        // candidate slots, counts and results are indexed by the batch's query numbers; only [q_lo, q_hi) are this rank's
+        if ((rc = ensure_queries(ws, B))) return rc;
+        if ((rc = grow(&ws->d_out, &ws->cap_out, (size_t)B * out_cap + 1))) return rc;
+        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1) + bpr))) return rc;
         uint64_t* d_qcand = ws->d_qcand;
         uint32_t* d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
         uint32_t* d_bin_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS + (size_t)B / 2 + 1);
-        const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
+        const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)nq * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
         FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+        FPX_HIP(hipMemsetAsync(d_qcand_n, 0, (size_t)B * sizeof(uint32_t), st));
         const uint32_t sbf = 32u - qbits;
-        static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)lds_attr;
         ScoreBinArgs sa{};
-        sa.bins = d_recv; sa.bin_cap = cell_cap; sa.bin_count = d_recv_counts; sa.nsrc = world; sa.src_stride = (uint64_t)nbins * cell_cap;
-        sa.count_stride = nbins; sa.count_step = 1u; sa.bq = SHARD_BQ; sa.B = B;
+        sa.bins = d_recv; sa.bin_cap = cell_cap; sa.bin_count = d_recv_counts; sa.nsrc = world; sa.src_stride = (uint64_t)bpr * cell_cap;
+        sa.count_stride = bpr; sa.count_step = 1u; sa.bq = SHARD_BQ; sa.bin_base = rank * bpr; sa.B = B;
         sa.opts = qb->d_opts; sa.sb = sbf; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
         sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
         const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << SHARD_BQ) * 8u;
-        hipLaunchKernelGGL(k_score_bin, dim3(nbins), dim3(SB_WG), sb_lds, st, sa);
-        hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st, (const uint64_t*)ws->d_cands[0], (uint64_t)0, (const uint32_t*)qb->d_opts, B, sbf, 1,
-                           d_out, out_cap, d_out_n, (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, (unsigned long long*)nullptr);
+        const uint32_t my_bins = (nq + (1u << SHARD_BQ) - 1u) >> SHARD_BQ;
+        hipLaunchKernelGGL(k_score_bin, dim3(my_bins), dim3(SB_WG), sb_lds, st, sa);
+        // (k_finish walks the batch's queries from q_lo on: the view's first query is q_lo)
+        auto finish = [&](const uint64_t* cands, uint64_t C) {
+            hipLaunchKernelGGL(k_finish, dim3((nq + 127) / 128), dim3(128), 0, st, cands, C, (const uint32_t*)qb->d_opts, nq, sbf, 0,
+                               ws->d_out, out_cap, ws->d_out_n, (const uint64_t*)(d_qcand + (size_t)q_lo * QCAND_SLOTS), (const uint32_t*)(d_qcand_n + q_lo),
+                               (unsigned long long*)nullptr, q_lo);
+        };
+        finish(ws->d_cands[0], 0);
         FPX_HIP(hipGetLastError());
+        bool staged = false;
+        if ((rc = stage_results(ws, nq, out_cap, st, &staged))) return rc;
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_SYNC(ws);
         if (ws->h_counters[CTR_BINFAIL] != 0 || ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands) {
             set_error("fpx_shard_score: a bin could not be scored in place (%s): use smaller batches or the record protocol (fpx_score_partial)",
-                      ws->h_counters[CTR_BINFAIL] == 2 ? "a received cell overflowed" : ws->h_counters[CTR_MAXSCORE] ? "a score does not fit the candidate key" : "too many candidates");
+                      ws->h_counters[CTR_BINFAIL] == 2 ? "a received bin overflowed" : ws->h_counters[CTR_MAXSCORE] ? "a score does not fit the candidate key" : "too many candidates");
             return FPX_E_INVAL;
         }
         if (ws->h_counters[CTR_CANDS] != 0) {             // queries with more candidates than slots: sort the shared list, finish again
@@ -1433,12 +1450,12 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, const uint6
             const size_t tb2 = sort_u64_temp_bytes(Cf, 0, 64);
             if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb2 + 256))) return rc;
             FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_cands[0], ws->d_cands[1], Cf, 0, 64, st, &ccur));
-            hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st, (const uint64_t*)ws->d_cands[ccur], Cf, (const uint32_t*)qb->d_opts, B, sbf, 1,
-                               d_out, out_cap, d_out_n, (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, (unsigned long long*)nullptr);
+            finish(ws->d_cands[ccur], Cf);
             FPX_HIP(hipGetLastError());
+            if ((rc = stage_results(ws, nq, out_cap, st, &staged))) return rc;
             FPX_SYNC(ws);
         }
-        return FPX_OK;
+        return deliver_results(ws, nq, out_cap, staged, out, out_n, st);
     };
     const int rc = body();
     if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);

@@ -448,8 +448,13 @@ class QueryBatch:
         self.cap = _result_cap(max([1] + [o.max_results for o in options]))
         h = C.c_void_p()
         check(lib().fpx_query_batch_create(ctx.h, _p(self.flat), _p(self.offsets), self.B, self.copts, C.byref(h)))
+        self._opts_type = Opts
         self.h = h
         self.ctx = ctx
+
+    def copts_at(self, q0):
+        """the options array from query q0 on (a pointer into copts)"""
+        return C.cast(C.byref(self.copts, q0 * C.sizeof(Opts)), C.POINTER(Opts))
 
     def release(self):
         if getattr(self, "h", None):
@@ -489,13 +494,13 @@ def probe_resident(reader, qb, world, d_records_ptr, records_cap, timeout_ms=0):
     return counts, st
 
 
-def shard_cell_bins(num_queries):
-    return lib().fpx_shard_cell_bins(num_queries)
+def shard_bins_per_rank(num_queries, world):
+    return lib().fpx_shard_bins_per_rank(num_queries, world)
 
 
 def shard_probe(reader, qb, world, d_send_ptr, cell_cap, d_send_counts_ptr, timeout_ms=0):
-    """stage 1 of the cell protocol of hash-range sharding (fpx_shard_probe): this rank's records dropped into cells
-    [world][bins][cell_cap].  Returns (stats, 0) or (None, needed_cell_cap) when a cell outgrew cell_cap."""
+    """stage 1 of the bin protocol of hash-range sharding (fpx_shard_probe): this rank's records dropped into the batch's bins
+    [world * bpr][cell_cap].  Returns (stats, 0) or (None, needed_cell_cap) when a bin outgrew cell_cap."""
     from ._lib import FPX_E_AGAIN
     st = Stats()
     need = C.c_uint64(0)
@@ -507,10 +512,20 @@ def shard_probe(reader, qb, world, d_send_ptr, cell_cap, d_send_counts_ptr, time
     return st, 0
 
 
-def shard_score(ctx, qb, world, d_recv_ptr, cell_cap, d_recv_counts_ptr, d_out_ptr, d_out_n_ptr, timeout_ms=0):
-    """stage 2 of the cell protocol (fpx_shard_score): the received cells -> per-query partial tables in HBM"""
-    check(lib().fpx_shard_score(ctx.h, qb.h, world, C.c_void_p(d_recv_ptr), int(cell_cap), C.c_void_p(d_recv_counts_ptr), timeout_ms,
-                                C.c_void_p(d_out_ptr), qb.cap, C.c_void_p(d_out_n_ptr)))
+def shard_score(ctx, qb, world, rank, d_recv_ptr, cell_cap, d_recv_counts_ptr, out=None, out_n=None, timeout_ms=0):
+    """stage 2 of the bin protocol (fpx_shard_score): the received pieces of this rank's bins -> the FINAL results of its
+    queries.  `out` [B, cap, 2] / `out_n` [B] are the batch's arrays: the rank's rows are filled in.  Returns (out, out_n, q_lo, q_hi)."""
+    if out is None:
+        out = np.zeros((max(1, qb.B), qb.cap, 2), np.uint32)
+        out_n = np.zeros(max(1, qb.B), np.uint32)
+    bpr = lib().fpx_shard_bins_per_rank(qb.B, world)
+    q_lo = min(qb.B, rank * bpr * 8)
+    first, num = C.c_uint32(0), C.c_uint32(0)
+    check(lib().fpx_shard_score(ctx.h, qb.h, world, rank, C.c_void_p(d_recv_ptr), int(cell_cap), C.c_void_p(d_recv_counts_ptr), timeout_ms,
+                                _p(out[q_lo:]) if q_lo < qb.B else _p(out), qb.cap, _p(out_n[q_lo:]) if q_lo < qb.B else _p(out_n),
+                                C.byref(first), C.byref(num)))
+    assert int(first.value) == q_lo or int(num.value) == 0
+    return out, out_n, int(first.value), int(first.value) + int(num.value)
 
 
 def score_partial(ctx, qb, d_records_ptr, num_records, d_out_ptr, d_out_n_ptr, timeout_ms=0):
@@ -525,6 +540,13 @@ def merge_partials(ctx, qb, d_parts_ptr, d_counts_ptr, world, out=None, out_n=No
         out_n = np.zeros(max(1, qb.B), np.uint32)
     check(lib().fpx_merge_partials(ctx.h, C.c_void_p(d_parts_ptr), C.c_void_p(d_counts_ptr), world, qb.B, qb.cap,
                                    qb.copts, _p(qb.offsets), _p(out), qb.cap, _p(out_n)))
+    return out, out_n
+
+
+def merge_partials_raw(ctx, d_parts_ptr, d_counts_ptr, world, num_queries, cap, copts, offsets, out, out_n):
+    """fpx_merge_partials over a sub-range of a batch: `copts` / `offsets` / `out` / `out_n` are that range's"""
+    check(lib().fpx_merge_partials(ctx.h, C.c_void_p(d_parts_ptr), C.c_void_p(d_counts_ptr), world, num_queries, cap,
+                                   copts, _p(offsets), _p(out), cap, _p(out_n)))
     return out, out_n
 
 

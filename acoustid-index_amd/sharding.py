@@ -117,10 +117,10 @@ def exchange_records(dist, records, counts, world, group=None):
     return got
 
 
-def exchange_cells(dist, send, send_counts, world, group=None):
-    """all-to-all of the cells of fpx_shard_probe: `send` [world, bins, cell_cap] int64 and `send_counts` [world, bins] int32 --
-    row r travels to rank r.  Fixed shapes: one collective each, nothing to agree on first.  Returns (recv, recv_counts) of the
-    same shapes, row r = what rank r sent."""
+def exchange_bins(dist, send, send_counts, group=None):
+    """all-to-all of the bins of fpx_shard_probe: `send` [world, bpr, cell_cap] int64 and `send_counts` [world, bpr] int32 --
+    row r (the bins whose queries rank r finishes) travels to rank r.  Fixed shapes: one collective each, nothing to agree on
+    first.  Returns (recv, recv_counts) of the same shapes, row s = what rank s sent."""
     import torch
     recv, recv_counts = torch.empty_like(send), torch.empty_like(send_counts)
     dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
@@ -130,23 +130,27 @@ def exchange_cells(dist, send, send_counts, world, group=None):
 
 class HashShardedReader:
     """IndexReader over a snapshot of hash-range SLICES -- this rank's window of the hash space of every segment.
-    A rank makes, sorts and probes only the query hashes of its window; the hit records travel to the rank that owns their
-    doc (doc & (world - 1)), which counts them; the per-query tables are all-gathered and merged.
+    A rank makes, sorts and probes only the query hashes of its window.
 
-    Two protocols with the same results: the CELL protocol (fpx_shard_probe / fpx_shard_score: records dropped into
-    fixed-shape cells as they are produced, one all-to-all, a bin scored per workgroup) for snapshots made of groups of
-    direct-addressed slices, and the RECORD protocol (fpx_probe_resident / fpx_score_partial: records sorted by destination,
-    a size exchange, then the records) for everything else."""
+    Two protocols with the same results.  The BIN protocol (fpx_shard_probe / fpx_shard_score), for snapshots made of groups of
+    direct-addressed slices: the records are dropped into the batch's bins of 8 queries as they are produced, the bins are
+    dealt to the ranks in contiguous runs and travel with ONE all-to-all of fixed shape, and every rank FINISHES the queries
+    of its bins -- no table exchange, no merge; the rank holds the final results of its share of the batch.  The RECORD
+    protocol (fpx_probe_resident / fpx_score_partial: records by doc & (world - 1), a size exchange, the records, partial tables,
+    all-gather, merge) for everything else."""
 
-    def __init__(self, fpx, ctx, reader, dist, world, host_staged=False, cells=True):
-        if world & (world - 1):
-            raise ValueError("hash-range sharding needs a power-of-two world size")
+    def __init__(self, fpx, ctx, reader, dist, world, host_staged=False, bins=True, group_world=None, rank=None):
         self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
+        # group_world: size of the process group the collectives run in, when it is not `world` -- one GPU playing rank 0 of
+        # `world` (bench.py's FPX_BENCH_EMULATE_WORLD): the bins are cut for `world` ranks, the 1-rank all-to-all hands them
+        # straight back (same volume and shape as a rank's real receive buffer; the results are not a search's)
+        self.group_world = world if group_world is None else group_world
+        self.rank = (dist.get_rank() if self.group_world == world and world > 1 else 0) if rank is None else rank
         self.host_staged = host_staged      # debugging aid: exchange through host memory with a CPU backend (gloo)
-        self.cells = cells
+        self.bins = bins
         self._rec = None
         self._bufs = {}
-        self._cellbufs = {}
+        self._binbufs = {}
         self.cell_cap = 0
         import torch
         self.device = torch.device("cuda", ctx.device)
@@ -159,54 +163,49 @@ class HashShardedReader:
                                torch.zeros((qb.B,), dtype=torch.int32, device=self.device))
         return self._bufs[key]
 
-    # ---- cell protocol
+    # ---- bin protocol
     def partial(self, qb):
-        """stage 1 (any thread): this rank's records into the send cells.  Returns the stats, or None when the snapshot
-        does not qualify for the cell protocol (search_resident then takes the record protocol)."""
+        """stage 1 (any thread): this rank's records into the send bins.  Returns the stats, or None when the snapshot
+        does not qualify for the bin protocol (search_resident then takes the record protocol)."""
         import torch
         fpx = self.fpx
-        if not self.cells:
+        if not self.bins:
             return None
-        bins = fpx.shard_cell_bins(qb.B)
+        bpr = fpx.shard_bins_per_rank(qb.B, self.world)
         while True:
             if self.cell_cap == 0:
-                self.cell_cap = 4096
+                self.cell_cap = 2048
             key = (qb.B, self.cell_cap)
-            if key not in self._cellbufs:
-                self._cellbufs = {key: (torch.empty((self.world, bins, self.cell_cap), dtype=torch.int64, device=self.device),
-                                        torch.zeros((self.world, bins), dtype=torch.int32, device=self.device))}
-            send, send_counts = self._cellbufs[key]
+            if key not in self._binbufs:
+                self._binbufs = {key: (torch.empty((self.world, bpr, self.cell_cap), dtype=torch.int64, device=self.device),
+                                       torch.zeros((self.world, bpr), dtype=torch.int32, device=self.device))}
+            send, send_counts = self._binbufs[key]
             try:
                 st, need = fpx.shard_probe(self.reader, qb, self.world, send.data_ptr(), self.cell_cap, send_counts.data_ptr())
             except fpx.FpxError as e:
                 if e.status == -4:              # FPX_E_INVAL: not a snapshot of groups alone
-                    self.cells = False
+                    self.bins = False
                     return None
                 raise
             if st is not None:
                 return st
-            self.cell_cap = int(need)           # a cell outgrew the buffer: the call says how much it takes
+            self.cell_cap = int(need)           # a bin outgrew the buffer: the call says how much it takes
 
     def gather_merge(self, qb, out=None, out_n=None):
-        """stages 2-4 (every rank in the same order): all-to-all of the cells, score, all-gather of the tables, merge"""
+        """stages 2 + 3 (every rank in the same order): all-to-all of the bins, then this rank's queries are finished.  Fills
+        the rank's rows of `out` / `out_n` (the batch's arrays); self.last_range = (q_lo, q_hi) says which."""
         import torch
         fpx = self.fpx
-        send, send_counts = self._cellbufs[(qb.B, self.cell_cap)]
+        send, send_counts = self._binbufs[(qb.B, self.cell_cap)]
         if self.host_staged:
-            recv, recv_counts = exchange_cells(self.dist, send.cpu(), send_counts.cpu(), self.world)
+            recv, recv_counts = exchange_bins(self.dist, send.cpu(), send_counts.cpu())
             recv, recv_counts = recv.to(self.device), recv_counts.to(self.device)
         else:
-            recv, recv_counts = exchange_cells(self.dist, send, send_counts, self.world)      # RCCL all-to-all over xGMI
+            recv, recv_counts = exchange_bins(self.dist, send, send_counts)      # RCCL all-to-all over xGMI
         torch.cuda.current_stream(self.device).synchronize()
-        d_part, d_cnt = self._tables(qb)
-        fpx.shard_score(self.ctx, qb, self.world, recv.data_ptr(), self.cell_cap, recv_counts.data_ptr(), d_part.data_ptr(), d_cnt.data_ptr())
-        if self.host_staged:
-            tables, cnts = gather_tables(self.dist, d_part.cpu(), d_cnt.cpu(), self.world)
-            tables, cnts = tables.to(self.device), cnts.to(self.device)
-        else:
-            tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
-        torch.cuda.current_stream(self.device).synchronize()
-        return fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
+        out, out_n, q_lo, q_hi = fpx.shard_score(self.ctx, qb, self.world, self.rank, recv.data_ptr(), self.cell_cap, recv_counts.data_ptr(), out, out_n)
+        self.last_range = (q_lo, q_hi)
+        return out, out_n
 
     # ---- record protocol (any snapshot)
     def _search_records(self, qb, out, out_n):
@@ -233,8 +232,10 @@ class HashShardedReader:
         return out, out_n, st
 
     def search_resident(self, qb, out=None, out_n=None):
+        """bin protocol: this rank's queries (self.last_range) are final in out / out_n; record protocol: all of them"""
         st = self.partial(qb)
         if st is None:
+            self.last_range = (0, qb.B)
             return self._search_records(qb, out, out_n)
         out, out_n = self.gather_merge(qb, out, out_n)
         return out, out_n, st

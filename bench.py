@@ -3,9 +3,12 @@
 
 One step = one pass of the hot path over one batch of synthetic queries (default: 8192 queries x 1000 hashes)
 against a seeded synthetic index resident in HBM (default: BASELINE.json configs[2], 100 M fingerprints x 256
-hashes in 16 FileSegments).  With --gpus N > 1 the SAME index is sharded by segment over the ranks
-(segment s lives on rank s % N), every rank probes its own segments for the whole batch, the per-rank top-k
-tables are exchanged with one RCCL all-gather and merged (strong scaling: total work fixed).
+hashes in 16 FileSegments).  With --gpus N > 1 the SAME index is sharded by HASH RANGE over the ranks: rank r holds the
+window [r 2^32 / N, (r + 1) 2^32 / N) of the hash space of all 16 segments, makes / sorts / probes only the query hashes
+of its window, the hit records travel to the rank that owns their doc (one RCCL all-to-all of fixed-shape cells), the
+owners score them, the per-rank top-k tables are all-gathered and merged.  The global batch grows with N (8192 x N
+queries per step: weak scaling -- a rank's probe and score work per step stays what one GPU's is; FPX_BENCH_SCALING=strong
+keeps 8192).  FPX_BENCH_SHARD=segment: the older protocol (whole segments per rank, tables only).
 
 Prints ONE JSON line (rank 0).  At N = 1 the line also carries, measured in the same run:
   roofline      physical bytes of the dominant kernel / its HIP-event time / 8 TB/s (<= 1); `traffic` = HBM bytes by PMC
@@ -122,9 +125,10 @@ def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
     Block-form segments (k_probe_lean8): the blocks it fetched (counted) + the 128-B lines of the probe records (presence
     bits + block range + block records, 64 B per 256 hash buckets) its probes touch (expected value for uniform hashes) +
     the sorted pairs (8 B per probe and segment).
-    Direct-addressed segments: the lines of `primary` / `extras` it read (counted: one per present hash, one more per hash
-    with several docs; a 4-byte word brings its 128-byte line) + for k_probe_direct the 128-B lines of 64-B records its probes
-    touch (expected value) and the pairs per segment, for k_probe_group ONE directory line and one pair per hash (both counted)."""
+    Grouped direct-addressed segments (k_probe_group): the directory line of every hash, the 16-byte pieces of its words and
+    the heads of its lists, counted by the kernel in 64-byte units (a piece brings at least a 64-byte sector, a line 128) +
+    one 8-byte pair per hash.  k_probe_direct (a segment on its own): the lines of `primary` / `extras` it read (counted)
+    + the 128-B lines of 64-B records its probes touch (expected value) + the pairs per segment."""
     files = [sg for sg in segs if sg.kind == "file"]
     if not files:
         return {"blocks": fetched_per_launch, "probe_records": 0.0, "pairs": 0.0, "total": fetched_per_launch}
@@ -358,14 +362,21 @@ def cpu_baseline(fpx, oracle, segs, ranges, flat, offsets, nq, opts, gpu_lists, 
             "host_ram_available_GiB": None if avail is None else avail / 2**30}
 
 
-def synth_index(fpx, ctx, seed, docs, S, H, local_segs, remote=True):
+def synth_index(fpx, ctx, seed, docs, S, H, local_segs, remote=True, dist=0, window=None):
+    """window = (lo_excl, hi_incl): every segment is built whole on the GPU, cut to the hash window on the device
+    (fpx_segment_slice) and released -- a rank's share of an index sharded by hash range"""
     per = docs // S
     segs, ranges = [], []
     for s in range(S):
         lo = s * per + 1
         ranges.append((lo, lo + per - 1))
         if s in local_segs:
-            segs.append(fpx.FileSegment.synth(ctx, seed, lo, per, H, 0, 512, s + 1))
+            sg = fpx.FileSegment.synth(ctx, seed, lo, per, H, dist, 512, s + 1)
+            if window is not None:
+                whole, sg = sg, sg.window(*window)
+                sg.first_doc, sg.num_docs = whole.first_doc, whole.num_docs
+                whole.release()
+            segs.append(sg)
         elif remote:
             segs.append(fpx.RemoteSegment(ctx, lo, lo + per - 1, s + 1, np.arange(lo, lo + per, dtype=np.uint32)))
     return segs, ranges
@@ -432,11 +443,23 @@ def main():
     S, H, B = args.segments, args.hashes, args.batch
     docs = args.docs
     free_b, total_b = torch.cuda.mem_get_info()
-    local_segs = [s for s in range(S) if s % max(world, eworld) == rank]
+    pw = max(world, eworld)                            # ranks of the protocol (eworld: one GPU plays rank 0 of that many)
+    sharded = pw > 1
+    shard_mode = os.environ.get("FPX_BENCH_SHARD", "hash") if sharded else None
+    if shard_mode == "hash" and (pw & (pw - 1)):
+        shard_mode = "segment"                         # hash windows need a power-of-two number of ranks
+    scaling = os.environ.get("FPX_BENCH_SCALING", "weak" if shard_mode == "hash" else "strong") if sharded else "strong"
+    if scaling == "weak":
+        B *= pw                                        # the global batch: every rank still probes ~8192 queries' worth of hashes
+    local_segs = list(range(S)) if shard_mode == "hash" else [s for s in range(S) if s % pw == rank]
+    window = None
+    if shard_mode == "hash":
+        window = (None if rank == 0 else (rank << 32) // pw - 1, None if rank == pw - 1 else ((rank + 1) << 32) // pw - 1)
 
     def need_bytes(d):
         est_seg = (d // S) * H * 5.4                       # ~4.5-5.3 B/item in blocks + derived tables
-        return est_seg * len(local_segs) + (d // S) * H * 8 * 2.3 + (4 << 30)   # + build scratch of one segment
+        share = len(local_segs) / pw if shard_mode == "hash" else len(local_segs)
+        return est_seg * share + (d // S) * H * 8 * 2.3 + (4 << 30)   # + build scratch of one segment
     shrunk = False
     if need_bytes(docs) > free_b * 0.92:
         if os.environ.get("FPX_ALLOW_SHRINK") != "1":
@@ -448,7 +471,7 @@ def main():
     per = docs // S
     docs = per * S
     t_build0 = time.perf_counter()
-    segs, ranges = synth_index(fpx, ctx, args.seed, docs, S, H, set(local_segs))
+    segs, ranges = synth_index(fpx, ctx, args.seed, docs, S, H, set(local_segs), window=window)
     snapshot = fpx.Segments(ctx, segs)
     reader = fpx.IndexReader(snapshot)
     torch.cuda.synchronize()
@@ -465,10 +488,14 @@ def main():
     agg = StatAgg()
 
     import concurrent.futures as cf
-    sharded = world > 1 or eworld > 1
     nfl = args.inflight if args.inflight > 0 else (3 if sharded else 2)
     outs = [(np.zeros((B, cap, 2), np.uint32), np.zeros(B, np.uint32)) for _ in range(nfl)]
-    shardeds = [fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world, host_staged=(backend != "nccl")) for _ in range(nfl)] if sharded else None
+    if not sharded:
+        shardeds = None
+    elif shard_mode == "hash":
+        shardeds = [fpx.sharding.HashShardedReader(fpx, ctx, reader, dist, pw, host_staged=(backend != "nccl"), group_world=world) for _ in range(nfl)]
+    else:
+        shardeds = [fpx.sharding.ShardedReader(fpx, ctx, reader, dist, world, host_staged=(backend != "nccl")) for _ in range(nfl)]
 
     def run_steps(nsteps, record):
         """nsteps batches, `nfl` of them in flight.  world == 1: every thread runs whole searches.  world > 1: threads
@@ -524,8 +551,10 @@ def main():
     qps = B * args.steps / dt
 
     # ---- size-independent correctness property at full size: the target doc ranks first
-    found = sum(1 for q in range(B) if out_n[q] > 0 and out[q, 0, 0] == targets[q])
-    top_scores = [int(out[q, 0, 1]) for q in range(B) if out_n[q] > 0]
+    # (hash sharding: every rank finishes its own 1/N of the queries; rank 0 checks its share)
+    q_lo, q_hi = shardeds[(args.steps - 1) % nfl].last_range if (sharded and shard_mode == "hash") else (0, B)
+    found = sum(1 for q in range(q_lo, q_hi) if out_n[q] > 0 and out[q, 0, 0] == targets[q])
+    top_scores = [int(out[q, 0, 1]) for q in range(q_lo, q_hi) if out_n[q] > 0]
 
     result = None
     extras = rank == 0 and world == 1 and eworld <= 1 and not args.no_extras
@@ -542,12 +571,14 @@ def main():
             "metric": METRIC,
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{docs} fingerprints x {H} u32 hashes in {S} FileSegments (512-B blocks"
                                    f"{'; kept direct-addressed in HBM' if dominant_kernel(segs) != 'k_probe_lean8' else ''}), "
-                                   f"segments sharded over {world} GPU(s); batch of {B} queries x {args.query_len} hashes, "
+                                   + (f"the index sharded by hash range over {pw} GPUs (every rank 1/{pw} of the hash space of all segments)" if shard_mode == "hash"
+                                      else f"segments sharded over {world} GPU(s)") + f"; batch of {B} queries x {args.query_len} hashes, "
                                    f"limit {args.limit}, min_score (n+19)/20, score_pct 10; queries resident in HBM",
-                       "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "query_len": args.query_len,
+                       "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "global_batch": B, "batch_per_gpu": B // pw if scaling == "weak" else B,
+                       "sharding": shard_mode, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "segment_layout": ("direct-addressed" + (", fused directory" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",
                        "index_build_seconds": round(build_s, 2), "shrunk_to_fit": shrunk},
@@ -571,7 +602,7 @@ def main():
             **({"emulated_rank_of_world": eworld, "note": "ONE rank's share of a sharded run emulated on one GPU: not a result"} if eworld > 1 else {}),
             "gpu_ms_per_step": agg.v["total_gpu_ms"] / max(1, args.steps),
             "hits_per_step": agg.v["hits"] / max(1, args.steps),
-            "targets_found": found, "targets_total": B, "median_top_score": int(np.median(top_scores)) if top_scores else 0,
+            "targets_found": found, "targets_total": q_hi - q_lo, "median_top_score": int(np.median(top_scores)) if top_scores else 0,
             "kernel_source_sha16": kernel_source_hash(),
         }
         if not args.no_measure_bw:

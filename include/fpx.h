@@ -281,22 +281,24 @@ int fpx_score_partial(fpx_ctx *ctx, const fpx_query_batch *qb, const void *d_rec
  * fpx_segment_slice of a resident segment) with one window; fpx_snapshot_create puts them into a group with that window -- so
  * a rank makes, sorts and probes only the query hashes of its window: 1/N of the batch's work, where segment sharding leaves
  * every rank the whole batch.  A hash's walk is independent of every other hash (src/FileSegment.zig:143-176) and
- * SearchResults.incr is a keyed sum (src/common.zig:121-129), so the ranks exchange HIT RECORDS (q << 32 | doc), each to the
- * rank that owns its doc (doc & (world - 1)), and the owner counts them -- exact.
- *   fpx_shard_probe   the records of this rank's window, dropped straight into CELLS: cell (r, b) holds the records for
- *                     rank r of query bin b (64 queries), d_send = [world][bins][cell_cap] records (DEVICE memory),
- *                     d_send_counts = [world][bins] uint32 fill counts; bins = fpx_shard_cell_bins(num_queries).
- *                     FPX_E_AGAIN: a cell outgrew cell_cap -- *needed_cell_cap says what to allocate; retry.
+ * SearchResults.incr is a keyed sum (src/common.zig:121-129), so a query's HIT RECORDS (q << 32 | doc) may be counted wherever
+ * they are brought together: the batch's bins of 8 queries are dealt to the ranks in contiguous runs of
+ * bpr = fpx_shard_bins_per_rank(num_queries, world), and rank r FINISHES the queries of bins [r bpr, (r + 1) bpr).
+ *   fpx_shard_probe   the records of this rank's window, dropped straight into the batch's bins: d_send = [world * bpr][cell_cap]
+ *                     records (DEVICE memory), d_send_counts = [world * bpr] uint32 fill counts.
+ *                     FPX_E_AGAIN: a bin outgrew cell_cap -- *needed_cell_cap says what to allocate; retry.
  *                     FPX_E_INVAL for snapshots that hold anything but such groups: use fpx_probe_resident / fpx_score_partial.
- *   (the caller's all-to-all, e.g. RCCL: row r of d_send and of d_send_counts travels to rank r; fixed shapes)
- *   fpx_shard_score   d_recv = [world][bins][cell_cap], d_recv_counts = [world][bins] as received: the per-query tables
- *                     fpx_search_resident_partial would write (absolute floor only), for fpx_merge_partials after an all-gather.
+ *   (the caller's all-to-all, e.g. RCCL: rows [r bpr, (r + 1) bpr) of d_send and of d_send_counts travel to rank r; fixed shapes)
+ *   fpx_shard_score   d_recv = [world][bpr][cell_cap], d_recv_counts = [world][bpr] as received (piece s = what rank s sent): the
+ *                     FINAL results of this rank's queries -- *first_query, *num_queries say which -- written to out[i * out_cap ..],
+ *                     out_n[i] for i = query - first_query (host memory, room for bpr * 8 queries).  No table exchange, no merge.
  * Counters in `stats` (scanned blocks / docs / probes) are this rank's share: their sum over the ranks is the unsharded total. */
-uint32_t fpx_shard_cell_bins(uint32_t num_queries);
+uint32_t fpx_shard_bins_per_rank(uint32_t num_queries, uint32_t world);
 int fpx_shard_probe(fpx_snapshot *snap, const fpx_query_batch *qb, uint32_t world, uint32_t timeout_ms,
                     void *d_send, uint64_t cell_cap, void *d_send_counts, uint64_t *needed_cell_cap, fpx_stats *stats);
-int fpx_shard_score(fpx_ctx *ctx, const fpx_query_batch *qb, uint32_t world, const void *d_recv, uint64_t cell_cap,
-                    const void *d_recv_counts, uint32_t timeout_ms, void *d_out, uint32_t out_cap, void *d_out_n);
+int fpx_shard_score(fpx_ctx *ctx, const fpx_query_batch *qb, uint32_t world, uint32_t rank, const void *d_recv, uint64_t cell_cap,
+                    const void *d_recv_counts, uint32_t timeout_ms, fpx_result *out, uint32_t out_cap, uint32_t *out_n,
+                    uint32_t *first_query, uint32_t *num_queries);
 
 /* ---- device-side segment build and merge -------------------------------------------------------
  * fpx_segment_build: filefmt.writeBlocks + BlockEncoder (src/filefmt.zig:94-138, src/block.zig:438-567) run on the GPU

@@ -1,7 +1,7 @@
 """The index sharded by HASH RANGE in its direct-addressed form on ONE GPU: 'rank' r holds the window
 [r * 2^32 / N, (r + 1) * 2^32 / N) of the hash space of EVERY segment -- slices cut on the device (fpx_segment_slice), grouped with
-their window by fpx_snapshot_create -- the ranks' hit records travel in CELLS (fpx_shard_probe: destination rank x bin of 64
-queries) as the all-to-all would move them, every rank scores what it received (fpx_shard_score), the tables are merged.  Must
+their window by fpx_snapshot_create -- the ranks' hit records are dropped into the batch's bins of 8 queries (fpx_shard_probe),
+the bins travel as the all-to-all would move them, and every rank finishes the queries of its bins (fpx_shard_score).  Must
 reproduce the unsharded snapshot and the oracle bit for bit, the reference's scanned_blocks / scanned_docs included: hot
 hashes whose lists are cut by the caps, docs re-inserted in newer segments, tombstones, duplicate hashes in a query."""
 import numpy as np
@@ -59,63 +59,46 @@ def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
     flat, off, _ = fpx.synth.make_queries(seed, 3, 150, per * S, H, query_len=300, dist=1)
     flat = flat.copy()
     flat[5] = flat[4]                                                 # a duplicate hash inside a query
-    bins = fpx.shard_cell_bins(150)
-    assert bins == 3
+    bpr = fpx.shard_bins_per_rank(150, world)
+    assert bpr == -(-19 // world)                                     # 150 queries = 19 bins of 8, dealt in contiguous runs
     for opts in (fpx.http_options(), fpx.SearchOptions(500, 3, 10), fpx.SearchOptions(3, 4, 100)):
         qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, off))
         B, cap = qb.B, qb.cap
-        cell_cap = 64                                                 # too small on purpose: the call says what it needs
-        sends, blocks_total, docs_total, probes_total, hits_total = [], 0, 0, 0, 0
-        for r in range(world):
-            while True:
-                send = torch.zeros((world, bins, cell_cap), dtype=torch.int64, device="cuda")
-                counts = torch.zeros((world, bins), dtype=torch.int32, device="cuda")
-                st, need = fpx.shard_probe(readers[r], qb, world, send.data_ptr(), cell_cap, counts.data_ptr())
-                if st is not None:
-                    break
-                assert need > cell_cap
-                cell_cap = need
-                sends = []                                            # (all ranks use one cell size: start over)
-                break
-            if st is None:
-                break
-            sends.append((send, counts))
-            blocks_total += st.scanned_blocks; docs_total += st.scanned_docs; probes_total += st.probes; hits_total += st.hits
-        if len(sends) < world:                                        # second round with the size the first one asked for
-            sends, blocks_total, docs_total, probes_total, hits_total = [], 0, 0, 0, 0
+        cell_cap = 16                                                 # too small on purpose: the call says what it needs
+        for attempt in range(4):
+            sends, need_max = [], 0
+            blocks_total = docs_total = probes_total = hits_total = 0
             for r in range(world):
-                send = torch.zeros((world, bins, cell_cap), dtype=torch.int64, device="cuda")
-                counts = torch.zeros((world, bins), dtype=torch.int32, device="cuda")
+                send = torch.zeros((world, bpr, cell_cap), dtype=torch.int64, device="cuda")
+                counts = torch.zeros((world, bpr), dtype=torch.int32, device="cuda")
                 st, need = fpx.shard_probe(readers[r], qb, world, send.data_ptr(), cell_cap, counts.data_ptr())
-                if st is None:                                        # (another rank's cells are fuller still)
-                    cell_cap = need
-                    send = torch.zeros((world, bins, cell_cap), dtype=torch.int64, device="cuda")
-                    st, need = fpx.shard_probe(readers[r], qb, world, send.data_ptr(), cell_cap, counts.data_ptr())
-                    assert st is not None
-                    sends = None
-                    break
+                if st is None:
+                    assert need > cell_cap
+                    need_max = max(need_max, need)
+                    continue
                 sends.append((send, counts))
                 blocks_total += st.scanned_blocks; docs_total += st.scanned_docs; probes_total += st.probes; hits_total += st.hits
-            if sends is None:
-                pytest.skip("cell sizes did not settle in two rounds")
-        # every record sits in the cell of the rank its doc id selects and of its query's bin
+            if need_max == 0:
+                break
+            cell_cap = need_max                                       # (all ranks use one bin size)
+        assert need_max == 0 and attempt >= 1
+        # every record sits in its query's bin
         for r in range(world):
             send, counts = sends[r]
-            c = counts.cpu().numpy()
-            sv = send.cpu().numpy()
-            for d in range(world):
-                for b in range(bins):
-                    recs = sv[d, b, :c[d, b]]
-                    assert ((recs & (world - 1)) == d).all()
-                    assert ((recs >> 32) >> 6 == b).all()
-        parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
-        cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
-        for d in range(world):                                         # what the all-to-all delivers to rank d
+            c = counts.cpu().numpy().reshape(-1)
+            sv = send.cpu().numpy().reshape(world * bpr, cell_cap)
+            for b in range(world * bpr):
+                assert ((sv[b, :c[b]] >> 32) >> 3 == b).all()
+        out = np.zeros((B, cap, 2), np.uint32)
+        out_n = np.zeros(B, np.uint32)
+        covered = 0
+        for d in range(world):                                         # what the all-to-all delivers to rank d: its bins from every rank
             recv = torch.stack([sends[r][0][d] for r in range(world)]).contiguous()
             rc = torch.stack([sends[r][1][d] for r in range(world)]).contiguous()
-            fpx.shard_score(ctx, qb, world, recv.data_ptr(), cell_cap, rc.data_ptr(), parts[d].data_ptr(), cnts[d].data_ptr())
-        torch.cuda.synchronize()
-        out, out_n = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
+            out, out_n, q_lo, q_hi = fpx.shard_score(ctx, qb, world, d, recv.data_ptr(), cell_cap, rc.data_ptr(), out, out_n)
+            assert q_lo == min(B, d * bpr * 8)
+            covered += q_hi - q_lo
+        assert covered == B                                           # every query is finished by exactly one rank
         got = fpx.results_to_lists(out, out_n)
         o2, n2, st_full = fpx.search_resident(full.reader, qb)
         assert got == fpx.results_to_lists(o2, n2)
@@ -149,7 +132,7 @@ def test_hash_sharded_reader_over_one_rank_group(monkeypatch):
         flat, off, _ = fpx.synth.make_queries(77, 3, 70, 8000, 48, query_len=200, dist=1)
         qb = fpx.QueryBatch(ctx, options=fpx.http_options(), flat=(flat, off))
         out, out_n, st = sh.search_resident(qb)
-        assert sh.cells and st.path_flags & 16
+        assert sh.bins and st.path_flags & 16 and sh.last_range == (0, qb.B)
         o2, n2, st2 = fpx.search_resident(p.reader, qb)
         assert fpx.results_to_lists(out, out_n) == fpx.results_to_lists(o2, n2)
         assert (st.scanned_blocks, st.scanned_docs) == (st2.scanned_blocks, st2.scanned_docs)

@@ -79,6 +79,7 @@ SIGNATURES = {
     "fpx_snapshot_release": (None, [_vp]),
     "fpx_search": (C.c_int, [_vp, _vp, _u32, C.POINTER(Opts), _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(Stats)]),
     "fpx_search_batch": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
+    "fpx_search_batch_stats": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats), _vp, _vp]),
     "fpx_search_batch_partial": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_query_batch_create": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(_vp)]),
     "fpx_query_batch_release": (None, [_vp]),

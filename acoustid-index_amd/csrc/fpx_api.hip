@@ -73,6 +73,7 @@ void ws_destroy(Workspace* w)
 {
     if (!w) return;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
+    if (w->d_qstats) (void)hipFree(w->d_qstats);
     if (w->d_cells) (void)hipFree(w->d_cells);
     if (w->h_cells) (void)hipHostFree(w->h_cells);
     void* bufs[] = {w->d_hashes, w->d_offsets, w->d_opts, w->d_keys[0], w->d_keys[1], w->d_hits[0], w->d_hits[1],
@@ -759,6 +760,14 @@ int fpx_search_batch(fpx_snapshot* snap, const uint32_t* hashes, const uint64_t*
 {
     return search_batch_impl(reinterpret_cast<Snapshot*>(snap), nullptr, hashes, offsets, num_queries, opts, timeout_ms,
                              false, out, out_cap, out_n, stats);
+}
+
+int fpx_search_batch_stats(fpx_snapshot* snap, const uint32_t* hashes, const uint64_t* offsets, uint32_t num_queries,
+                           const fpx_opts* opts, uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n,
+                           fpx_stats* stats, uint64_t* scanned_blocks_q, uint64_t* scanned_docs_q)
+{
+    return search_batch_impl(reinterpret_cast<Snapshot*>(snap), nullptr, hashes, offsets, num_queries, opts, timeout_ms,
+                             false, out, out_cap, out_n, stats, scanned_blocks_q, scanned_docs_q);
 }
 
 int fpx_search(fpx_snapshot* snap, const uint32_t* hashes, uint32_t num_hashes, const fpx_opts* opts, uint32_t timeout_ms,

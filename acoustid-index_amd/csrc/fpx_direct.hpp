@@ -117,6 +117,10 @@ __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
             const uint32_t eff = multi ? (x[j].x & 0xFFFFu) : (present[j] ? 1u : 0u);
             const uint32_t T = (x[j].x >> 19) & 1u;
             if (present[j]) { my_blocks += multi ? ((x[j].x >> 16) & 7u) : 1u; my_docs += eff; }
+            if (a.qstats && valid[j]) {
+                const unsigned long long nbq = present[j] ? (multi ? ((x[j].x >> 16) & 7u) : 1u) : (d[j] == 0xFFFFFFFFu && ((bw[j] >> (h[j] & 31u)) & 1u) != 0u ? 0u : 1u);
+                atomicAdd(&a.qstats[q[j]], nbq | ((unsigned long long)eff << 32));
+            }
             const uint64_t qpart = (uint64_t)q[j] << 32;
             const uint32_t d0 = multi ? (T ? x[j].z : x[j].y) : d[j];
             const uint32_t d1 = T ? x[j].w : x[j].z;

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
         // dedupSorted, src/Index.zig:489-499: flagged by k_make_keys_dedup, or found by looking back
         if (valid && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip))) valid = false;
         const uint32_t h = (uint32_t)(key >> a.qb);
+        const uint32_t blocks_before = my_blocks, docs_before = my_docs;
         // a hash-window slice of the group (the index sharded by hash range): the other hashes are another rank's probes
         if (h < g->win_lo || h > g->win_hi) valid = false;
         const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
@@ -236,6 +237,8 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
         if (xkeep & 1u) put(xd0);
         if (xkeep & 2u) put(xd1);
         if (xkeep & 4u) put(xd2);
+        if (a.qstats && valid && (my_blocks != blocks_before || my_docs != docs_before))
+            atomicAdd(&a.qstats[(uint32_t)(qpart >> 32)], (unsigned long long)(my_blocks - blocks_before) | ((unsigned long long)(my_docs - docs_before) << 32));
         // ---- the rare rest, by the whole wave: words beyond the lane's twelve, further lists, lists longer than their head
         {
             const bool more = nwords > GK_WORDS || n_esc > 1u || (n_esc == 1u && xeff > xin);
@@ -265,32 +268,66 @@ __global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga
                 {
                     const bool plain = act && (wv >> 31) == 0u && lane >= GK_WORDS;
                     const uint32_t doc = s_min_doc[col] + wv;
-                    if (plain) { my_blocks += second ? 0u : 1u; my_docs += 1u; }
+                    if (plain) {
+                        my_blocks += second ? 0u : 1u; my_docs += 1u;
+                        if (a.qstats) atomicAdd(&a.qstats[qlo], (second ? 0ull : 1ull) | (1ull << 32));
+                    }
                     const bool kp = plain && !(any_dead && s_has_dead[col] && is_dead_seg(ga.segs[s_seg_index[col]], doc));
                     fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | doc, 0ull, 0ull, lane);
                 }
-                // the lists, one after the other; of the first one within the lane's words the head has been emitted
-                unsigned long long me = __ballot((int)(act && (wv >> 31) != 0u));
-                bool first = true;
-                while (me != 0ull) {
-                    const int el = (int)__builtin_ctzll(me);
-                    me &= me - 1ull;
-                    const uint32_t off = __shfl(wv, el) & 0x7FFFFFFFu, c2 = __shfl(col, el);
-                    const uint32_t* list = li_s + off;
-                    const uint32_t hdr = gload_u32(list), eff = hdr & 0xFFFFu, T = (hdr >> 19) & 1u;
-                    uint32_t from = 0u;
-                    if (first && (uint32_t)el < GK_WORDS) from = min(eff, T ? 2u : 3u);          // (the lane's slot took these)
-                    else if (lane == 0) { my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u; }
-                    first = false;
-                    const SegDesc* filt = (any_dead && s_has_dead[c2]) ? ga.segs + s_seg_index[c2] : nullptr;
-                    const uint32_t md = s_min_doc[c2];
-                    for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
-                        bool kp = o2 + lane < eff;
-                        const uint32_t dv = md + (kp ? gload_u32(list + 1u + T + o2 + lane) : 0u);
-                        if (filt && kp) kp = !is_dead_seg(*filt, dv);
-                        fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
+                // the lists: lane l (a word that refers to one) reads its header; of the first list within the lane's words the head
+                // has been emitted by its lane
+                const bool is_list = act && (wv >> 31) != 0u;
+                const unsigned long long ml = __ballot((int)is_list);
+                const uint32_t* lp = li_s + (wv & 0x7FFFFFFFu);
+                const uint32_t hdr_l = is_list ? gload_u32(lp) : 0u;
+                const uint32_t eff_l = hdr_l & 0xFFFFu, T_l = (hdr_l >> 19) & 1u;
+                const bool slot_list = is_list && ml != 0ull && lane == (uint32_t)__builtin_ctzll(ml) && lane < GK_WORDS;
+                const uint32_t from_l = slot_list ? min(eff_l, T_l ? 2u : 3u) : 0u;
+                if (is_list && !slot_list) {
+                    my_blocks += (hdr_l >> 16) & 7u; my_docs += eff_l; my_reads += 2u;
+                    if (a.qstats) atomicAdd(&a.qstats[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
+                }
+                const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
+                if (rest_l) my_reads += ((rest_l + 31u) >> 5) * 2u;
+                uint32_t total = rest_l;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
+                const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
+                unsigned long long me = __ballot((int)(rest_l != 0u));
+                if (total >= 128u && !filtered) {
+                    // a hot hash (hundreds of docs in every segment): ONE reservation for all its lists, written straight to the
+                    // batch's record buffer.  (64 records at a time through the stage, every chunk beyond the stage's room paid a
+                    // global atomic on one address: 10 M of them per batch of 8192 on hot-pool data = 110 ms.)
+                    unsigned long long gbase = 0;
+                    if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+                    gbase = __shfl(gbase, 0);
+                    while (me != 0ull) {
+                        const int el = (int)__builtin_ctzll(me);
+                        me &= me - 1ull;
+                        const uint32_t* list = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), el) << 32) | __shfl((uint32_t)(uint64_t)lp, el));
+                        const uint32_t eff = __shfl(eff_l, el), T = __shfl(T_l, el), from = __shfl(from_l, el), md = s_min_doc[__shfl(col, el)];
+                        for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                            const unsigned long long at = gbase + (o2 - from) + lane;
+                            if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
+                        }
+                        gbase += eff - from;
                     }
-                    if (lane == 0 && eff > from) my_reads += ((eff - from + 31u) >> 5) * 2u;
+                } else {
+                    while (me != 0ull) {
+                        const int el = (int)__builtin_ctzll(me);
+                        me &= me - 1ull;
+                        const uint32_t* list = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), el) << 32) | __shfl((uint32_t)(uint64_t)lp, el));
+                        const uint32_t eff = __shfl(eff_l, el), T = __shfl(T_l, el), from = __shfl(from_l, el), c2 = __shfl(col, el);
+                        const SegDesc* filt = (any_dead && s_has_dead[c2]) ? ga.segs + s_seg_index[c2] : nullptr;
+                        const uint32_t md = s_min_doc[c2];
+                        for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                            bool kp = o2 + lane < eff;
+                            const uint32_t dv = md + (kp ? gload_u32(list + 1u + T + o2 + lane) : 0u);
+                            if (filt && kp) kp = !is_dead_seg(*filt, dv);
+                            fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
+                        }
+                    }
                 }
             }
         }

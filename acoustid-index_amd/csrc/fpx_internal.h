@@ -250,8 +250,10 @@ struct Workspace {
     // straight from the device blocks the host until the stream gets there and costs ~100 us of driver time per call; a
     // copy into pinned memory is asynchronous, and the host moves the bytes on after the batch's synchronisation
     uint8_t* h_out = nullptr; size_t cap_h_out = 0;
+    unsigned long long* d_qstats = nullptr; size_t cap_qstats = 0;    // per-query scan statistics (blocks | docs << 32), when asked for
     uint32_t* d_cells = nullptr; uint32_t* h_cells = nullptr; size_t cap_cells = 0;   // fpx_shard_probe: the cells' fill counters + statistics slots
     uint32_t hint_def = 0;                // longest deferred list of the last batch (sizes the deferred pass's grid)
+    uint64_t hint_misc = 0;               // records the last binned batch left in the misc buffer (sizes k_bin's grid)
     uint64_t hint_P = 0, hint_H = 0;      // pairs and hit records of the last batch this workspace ran (sizes the next one)
     uint32_t fast_penalty = 0;            // batches left before the device-sized path is tried again after it had to be redone
     // pinned host staging
@@ -312,7 +314,7 @@ void query_batch_free(QueryBatch* qb);
 int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                       const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                       fpx_result* out, uint32_t out_cap, uint32_t* out_n,   // host (final) or device (partial)
-                      fpx_stats* stats);
+                      fpx_stats* stats, uint64_t* q_blocks = nullptr, uint64_t* q_docs = nullptr);   // per-query scanned blocks / docs (host, [B]) or null
 // the two halves of a partial search, for exchanging hit records between them (hash-range sharding)
 int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
                        uint64_t* d_records, uint64_t records_cap, uint64_t* counts, fpx_stats* stats);

@@ -34,6 +34,9 @@ struct ProbeArgs {
     uint32_t key_skip;                // low hash bits the pairs are NOT sorted on (KEY_SORT_SKIP; the direct-addressed kernels read it)
     // k_probe_group<.., BINNED>: records go to bins of 2^bin_shift queries ([nbins][bin_cap] records; fill counters BIN_STRIDE words apart)
     uint64_t* bins = nullptr; uint64_t bin_cap = 0; unsigned int* bin_count = nullptr; uint32_t bin_shift = 0;
+    // per-QUERY scan statistics (the reference observes num_blocks / num_docs per hash, src/FileSegment.zig:177-178; a host that
+    // keeps fpindex_scanned_*_per_hash per request needs them per query): qstats[q] += blocks | docs << 32, or null
+    unsigned long long* qstats = nullptr;
     const unsigned long long* P_dev = nullptr;   // the number of pairs lives on the device (a rank's compacted share of the keys): P is their capacity
 };
 
@@ -668,7 +671,10 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                         // read off the decoded items instead of global memory so that nothing queues behind the prefetch)
                         const uint32_t ends_row = (uint32_t)(__ballot((int)ends_with_ph) >> (g * 16u)) & 0xFFFFu;
                         if (more && ends_row != 0u) cont = true;
-                        if (gl == 0 && !count_only) { my_blocks += 1; my_docs += cnt; }
+                        if (gl == 0 && !count_only) {
+                            my_blocks += 1; my_docs += cnt;
+                            if (a.qstats) atomicAdd(&a.qstats[pq], 1ull | ((unsigned long long)cnt << 32));
+                        }
                     }
                 }
                 pact = cont;

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             if (valid && (b0v[j] & 2u) == 0u) {
                 // no item of the segment has this hash: FileSegment.search would visit block b0 (unless h lies in the gap
                 // before it, src/FileSegment.zig:164), find nothing and stop -- counted here, the block stays unread
-                if (cur_first <= h[j]) my_blocks += 1;
+                if (cur_first <= h[j]) { my_blocks += 1; if (a.qstats) atomicAdd(&a.qstats[q[j] & 0x00FFFFFFu], 1ull); }
                 valid = false;
             }
             // may the hash's run continue in block b0 + 1?  (it starts with this block's last hash)
@@ -471,6 +471,7 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     }
                 } else {
                     my_blocks += 1; my_docs += cnt;
+                    if (a.qstats) atomicAdd(&a.qstats[pq], 1ull | ((unsigned long long)cnt << 32));
                 }
             }
             // -- emission (wave-uniform control flow): doc = min_doc_id + the prefix sum of the run's deltas over the group's

@@ -49,7 +49,7 @@ constexpr uint32_t SMALL_LDS_ITEMS = 2048;     // MAX_ITEMS_PER_BLOCK
 constexpr uint32_t SMALL_BPW = 8;              // consecutive blocks per workgroup: their pair slices are consecutive too
 __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const uint64_t* __restrict__ pairs, uint64_t P,
                                                      uint32_t qb, uint64_t* hits, uint64_t hit_cap,
-                                                     unsigned long long* counters)
+                                                     unsigned long long* counters, unsigned long long* qstats = nullptr)
 {
     __shared__ uint64_t blk_items[SMALL_LDS_ITEMS];
     __shared__ uint64_t prange[2];
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const u
                 }
             }
             my_blocks += nb; my_docs += nd;
+            if (qstats) atomicAdd(&qstats[q], (unsigned long long)nb | ((unsigned long long)nd << 32));
         }
     }
     if (my_probes) atomicAdd(&wg_probes, my_probes);

@@ -253,7 +253,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                      const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                      fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, const Exchange* ex = nullptr,
-                     bool no_fast = false, double t_call = 0.0)
+                     bool no_fast = false, double t_call = 0.0, uint64_t* q_blocks = nullptr, uint64_t* q_docs = nullptr)
 {
     const bool probe_only = ex && ex->mode == 1, score_only = ex && ex->mode == 2;
     // the deadline counts from the API call's entry (one deadline per search, src/MultiIndex.zig:314-322), however often the
@@ -380,6 +380,19 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     }
     const uint64_t* d_pairs = ws->d_keys[kcur];
 
+    // per-query scan statistics, when the caller asked for them (a single query's are the call's totals: search_split)
+    const bool want_q = (q_blocks || q_docs) && B >= 2u && !score_only;
+    if (want_q && (rc = grow(&ws->d_qstats, &ws->cap_qstats, (size_t)B + 1))) return rc;
+    auto deliver_qstats = [&]() -> int {
+        if (!want_q) return FPX_OK;
+        std::vector<unsigned long long> hq(B);
+        FPX_HIP(hipMemcpy(hq.data(), ws->d_qstats, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < B; ++q) {
+            if (q_blocks) q_blocks[q] = hq[q] & 0xFFFFFFFFull;
+            if (q_docs) q_docs[q] = hq[q] >> 32;
+        }
+        return FPX_OK;
+    };
     // ---- 3+4: probes (rerun with a larger hit buffer on overflow)
     uint64_t H = 0;
     float probe_ms = 0.f, aux_ms = 0.f;
@@ -457,6 +470,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     for (int attempt = 0;; ++attempt) {
         used_lean = false; spread = false;
         if (!single_fast) FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));   // (k_make_keys did it)
+        if (want_q) FPX_HIP(hipMemsetAsync(ws->d_qstats, 0, (size_t)B * sizeof(unsigned long long), st));
         if (P && (snap->n_file || snap->n_direct)) {
             ProbeArgs a;
             a.pairs = d_pairs; a.P = P; a.qb = qb;
@@ -469,6 +483,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             a.hits = ws->d_hits[fast ? 1 : 0]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;    // (fast: binned into d_hits[0] afterwards)
             a.def_list = ws->d_def_list; a.def_count = ws->d_def_count; a.def_cap = (uint32_t)def_cap; a.ctr_off = 0; a.lean_stats = nullptr; a.cancel = cancel;
             a.key_skip = flagged ? KEY_SKIP_FLAGGED : key_skip;
+            a.qstats = want_q ? ws->d_qstats : nullptr;
             const uint64_t per_wg = (uint64_t)PWAVES * a.ppw * a.rounds;
             const uint32_t gx = (uint32_t)((P + per_wg - 1) / per_wg);
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
@@ -563,7 +578,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 }
                 if (snap->n_small) {
                     hipLaunchKernelGGL(k_probe_small, dim3((snap->max_small_blocks + SMALL_BPW - 1) / SMALL_BPW, snap->n_small), dim3(WG), 0, st,
-                                       snap->d_small, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
+                                       snap->d_small, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters,
+                                       want_q ? ws->d_qstats : (unsigned long long*)nullptr);
                 }
                 if (snap->n_gen) {
                     ProbeArgs ge = a;
@@ -638,8 +654,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     if (fast) {
         // ---- 5': bins -> per-query ranges (level 2 of fpx_partition.hpp), count, finish; sizes stay on the device
         const uint32_t tiles = (uint32_t)std::min<uint64_t>((h_bin.bin_cap + L2_TILE - 1) / L2_TILE, 0x7FFFFFFFull / 256u);
-        const uint32_t bin_grid = binned ? 64u : (uint32_t)std::min<uint64_t>((2 * est_H + BIN_TILE - 1) / BIN_TILE, 8192u);
-        // (binned: only what k_probe_group could not place itself -- normally nothing -- is in the misc buffer)
+        // (binned: only what k_probe_group could not place itself is in the misc buffer -- normally nothing; the lists of hot hashes,
+        // which go there whole, on skewed data: the grid follows what the workspace's last batch left there)
+        const uint32_t bin_grid = binned ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(64, (2 * ws->hint_misc + BIN_TILE - 1) / BIN_TILE), 8192u)
+                                         : (uint32_t)std::min<uint64_t>((2 * est_H + BIN_TILE - 1) / BIN_TILE, 8192u);
         hipLaunchKernelGGL(k_bin, dim3(std::max(1u, bin_grid)), dim3(256), 0, st, h_bin, (const uint64_t*)ws->d_hits[1],
                            (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
         if ((rc = grow(&ws->d_qrange, &ws->cap_qrange, (size_t)B * 2 + 2))) return rc;
@@ -791,7 +809,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probe_aux_ms += aux;
             stats->path_flags |= 1u | (Cf ? 2u : 0u) | (used_fused ? 4u : 0u) | (binned ? 8u : 0u);
         }
+        if ((rc = deliver_qstats())) return rc;
         ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);
+        ws->hint_misc = binned ? misc : 0;
         ws->hint_def = 0;
         if (used_lean) for (uint32_t i = 0; i < snap->n_lean; ++i) ws->hint_def = std::max<uint32_t>(ws->hint_def, ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE]);
         return FPX_OK;
@@ -815,7 +835,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         const bool fits = H <= ws->cap_hits && ws->h_counters[CTR_CANDS] <= SINGLE_CANDS && ws->h_counters[CTR_MAXSCORE] == 0;
         if (!fits) {                           // rare: rerun on the general path (which grows buffers / splits as needed)
             if (H > ws->cap_hits && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)H + 1024))) return rc;
-            return run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, ex, true, t_start);
+            return run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, ex, true, t_start, q_blocks, q_docs);
         }
         *out_n = (uint32_t)ws->h_counters[CTR_COUNT];
         std::memcpy(out, ws->h_counters + CTR_COUNT + 1, (size_t)*out_n * sizeof(fpx_result));
@@ -1012,6 +1032,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     if (stats && d_qcand_n) C_slots = ws->h_counters[CTR_SLOTCANDS];
 
     fill_stats();
+    if ((rc = deliver_qstats())) return rc;
     ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);       // sizes the device-sized path of the next batch
     ws->hint_def = 0;
     if (used_lean) for (uint32_t i = 0; i < snap->n_lean; ++i) ws->hint_def = std::max<uint32_t>(ws->hint_def, ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE]);
@@ -1032,15 +1053,20 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
 static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
                         const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                         const fpx_opts* opts, uint32_t timeout_ms, bool partial,
-                        fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, double t_call)
+                        fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, double t_call,
+                        uint64_t* q_blocks = nullptr, uint64_t* q_docs = nullptr)
 {
     Workspace* ws = ws_acquire(snap->ctx);
     if (!ws) return FPX_E_NOMEM;
     fpx_stats local{};
-    int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, false, t_call);
+    int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, false, t_call, q_blocks, q_docs);
     if (rc == FPX_REDO) {                       // the device-sized path gave up (after its synchronisation): the general path
         local = fpx_stats{};
-        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, true, t_call);
+        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, true, t_call, q_blocks, q_docs);
+    }
+    if (rc == FPX_OK && B == 1) {               // (one query: its statistics are the call's)
+        if (q_blocks) q_blocks[0] = local.scanned_blocks;
+        if (q_docs) q_docs[0] = local.scanned_docs;
     }
     if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
     ws_release(snap->ctx, ws);
@@ -1048,16 +1074,16 @@ static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
     if (rc != FPX_SPLIT) return rc;
     if (B <= 1) { set_error("internal: single query cannot be split"); return FPX_E_DEVICE; }
     const uint32_t half = B / 2;
-    rc = search_split(snap, resident, q0, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, stats, t_call);
+    rc = search_split(snap, resident, q0, hashes, offsets, half, opts, timeout_ms, partial, out, out_cap, out_n, stats, t_call, q_blocks, q_docs);
     if (rc) return rc;
     fpx_result* out2 = out ? out + (size_t)half * out_cap : out;
     return search_split(snap, resident, q0 + half, hashes, offsets + half, B - half, opts + half, timeout_ms, partial,
-                        out2, out_cap, out_n + half, stats, t_call);
+                        out2, out_cap, out_n + half, stats, t_call, q_blocks ? q_blocks + half : nullptr, q_docs ? q_docs + half : nullptr);
 }
 
 int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                       const fpx_opts* opts, uint32_t timeout_ms, bool partial,
-                      fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+                      fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, uint64_t* q_blocks, uint64_t* q_docs)
 {
     if (resident) { offsets = resident->offsets.data(); opts = resident->opts.data(); B = resident->B; hashes = nullptr; }
     if (!snap || !offsets || !opts || !out_n || (!out && out_cap) || (!resident && B && offsets[B] && !hashes)) {
@@ -1071,7 +1097,7 @@ int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t
         if (offsets[q + 1] - offsets[q] >= (1ull << 32)) { set_error("query longer than 2^32-1 hashes"); return FPX_E_INVAL; }
     }
     FPX_HIP(hipSetDevice(snap->ctx->device));
-    return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, now_ms());
+    return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, now_ms(), q_blocks, q_docs);
 }
 
 int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,

@@ -388,6 +388,24 @@ class IndexReader:
         res = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(out_n[q])] for q in range(B)]
         return res, st
 
+    def search_batch_stats(self, queries, options, timeout_ms=0):
+        """fpx_search_batch_stats: search_batch + per-query scan statistics.  Returns (results, Stats, scanned_blocks[B],
+        scanned_docs[B]) -- what the reference observes per hash (src/FileSegment.zig:177-178) summed per query."""
+        B = len(queries)
+        flat_h, offsets = _flatten(queries)
+        if isinstance(options, SearchOptions):
+            options = [options] * B
+        copts = (Opts * max(1, B))(*[o.to_c() for o in options])
+        cap = _result_cap(max([1] + [o.max_results for o in options]))
+        out = np.zeros((max(1, B), cap, 2), np.uint32)
+        out_n = np.zeros(max(1, B), np.uint32)
+        qb, qd = np.zeros(max(1, B), np.uint64), np.zeros(max(1, B), np.uint64)
+        st = Stats()
+        check(lib().fpx_search_batch_stats(self.snapshot.h, _p(flat_h), _p(offsets), B, copts, timeout_ms,
+                                           _p(out), cap, _p(out_n), C.byref(st), _p(qb), _p(qd)))
+        res = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(out_n[q])] for q in range(B)]
+        return res, st, qb[:B], qd[:B]
+
     def search_batch_raw(self, flat_h, offsets, copts, cap, timeout_ms=0, out=None, out_n=None):
         """Same call with pre-built numpy/ctypes buffers (used by bench.py's timed loop)."""
         B = len(offsets) - 1

@@ -203,7 +203,7 @@ def parse_pmc_dir(d):
     return by
 
 
-def run_pmc_child(args, docs, timeout_s=420):
+def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
     """HBM bytes of the dominant kernel, measured in THIS run: a child process of this script under
     `rocprofv3 --pmc FETCH_SIZE` (counters in their own pass, no tracing besides --kernel-trace) repeats the headline
     batch on an identically built index; the two bandwidth kernels of known byte counts calibrate the counter's unit in
@@ -218,7 +218,7 @@ def run_pmc_child(args, docs, timeout_s=420):
            "--query-len", str(args.query_len), "--limit", str(args.limit), "--seed", str(args.seed)]
     if args.min_score is not None:
         cmd += ["--min-score", str(args.min_score)]
-    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"), **(env_extra or {}))
     try:
         p = subprocess.run(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -247,6 +247,7 @@ def run_pmc_child(args, docs, timeout_s=420):
         corr = 1.0 / (sum(ratios) / len(ratios)) if ratios else 2.0
         out_dir = os.environ.get("FPX_BENCH_PMC_KEEP")
         if out_dir:
+            out_dir = os.path.join(out_dir, keep_tag) if keep_tag else out_dir
             os.makedirs(out_dir, exist_ok=True)
             for f in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
                 shutil.copy(f, out_dir)
@@ -580,7 +581,7 @@ def main():
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "global_batch": B, "batch_per_gpu": B // pw if scaling == "weak" else B,
                        "sharding": shard_mode, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
-                       "segment_layout": ("direct-addressed" + (", fused directory" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",
+                       "segment_layout": ("direct-addressed" + (", one group (hash-major, segment-minor)" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",
                        "index_build_seconds": round(build_s, 2), "shrunk_to_fit": shrunk},
             # achieved / frac: PHYSICAL bytes of the dominant kernel per launch / its HIP-event time / peak.  Filled with the
             # model here and replaced by the in-run PMC figure below when the rocprofv3 child pass succeeds.
@@ -750,6 +751,110 @@ def main():
             rf.update({"traffic": traffic, "traffic_source": src, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
                        "achieved_basis": "HBM read bytes by PMC (FETCH_SIZE, calibrated in the same pass) per launch / HIP-event time of the "
                                          "unprofiled launches in this run"})
+
+    # ---- the same index in BLOCK form (FPX_DIRECT=0): the kernel north_star names -- coalesced loads of the segments' block
+    #      pages, LDS-staged StreamVByte decode (src/streamvbyte.zig:341-412, src/block.zig:137-158) -- with its own roofline:
+    #      k_probe_lean8's HIP-event time in this run and its HBM bytes by a PMC child pass of its own.  (The two forms do not
+    #      fit side by side: the index is built again.)
+    if extras and os.environ.get("FPX_BENCH_BLOCK_FORM", "1") != "0":
+        try:
+            os.environ["FPX_DIRECT"] = "0"
+            t_b0 = time.perf_counter()
+            segs_b, _ = synth_index(fpx, ctx, args.seed, docs, S, H, set(range(S)))
+            snap_b = fpx.Segments(ctx, segs_b)
+            reader_b = fpx.IndexReader(snap_b)
+            torch.cuda.synchronize()
+            build_b = time.perf_counter() - t_b0
+            qb_b = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+            dtb, aggb, ob, onb = timed_resident(fpx, reader_b, qb_b, max(5, args.steps // 2), 2)
+            rowb = row_from(B, max(5, args.steps // 2), dtb, aggb, segs_b, "fpx::k_probe_lean8")
+            rowb["targets_found"] = int(sum(1 for q in range(B) if onb[q] > 0 and ob[q, 0, 0] == targets[q]))
+            rowb["same_results_as_direct_form"] = bool(np.array_equal(onb, out_n) and all(
+                np.array_equal(ob[q, :onb[q]], out[q, :out_n[q]]) for q in range(0, B, 97)))
+            sub = fpx.QueryBatch(ctx, options=opts, flat=(np.ascontiguousarray(flat[:int(offsets[1024])]), np.ascontiguousarray(offsets[:1025])))
+            dt1k, agg1k, _, _ = timed_resident(fpx, reader_b, sub, 20, 3)
+            row1k = row_from(1024, 20, dt1k, agg1k, segs_b, "fpx::k_probe_lean8")
+            index_bytes_b = sum(s_.device_bytes for s_ in segs_b)
+            sub.release(); qb_b.release(); snap_b.release()
+            for s_ in segs_b:
+                s_.release()
+            del reader_b, snap_b, segs_b
+            torch.cuda.synchronize()
+            rfb = {"bound": "hbm", "kernel": "fpx::k_probe_lean8<2>", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "avg_launch_ms": rowb["probe_kernel_ms"], "moved_model_bytes": rowb["moved_bytes_model"],
+                   "achieved": (rowb["moved_bytes_model"] / (rowb["probe_kernel_ms"] * 1e-3) / 1e9) if rowb["probe_kernel_ms"] else None,
+                   "frac": rowb["hbm_frac_model"], "achieved_basis": "model", "traffic": None,
+                   "reference_equivalent_bytes_per_launch": rowb["reference_visited_block_bytes"],
+                   "reference_equivalent_frac": (rowb["reference_visited_block_bytes"] / (rowb["probe_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                   if rowb["probe_kernel_ms"] else None,
+                   "note": "block form: every probe whose hash the segment's presence bits do not rule out fetches its 512-byte block (two 128-B "
+                           "lines up front + the line of the matching docids) and decodes its StreamVByte hash column in LDS"}
+            if not args.no_pmc and os.environ.get("FPX_BENCH_PMC", "1") != "0":
+                pmc_b, err_b = run_pmc_child(args, docs, env_extra={"FPX_DIRECT": "0"}, keep_tag="block_form")
+                if pmc_b:
+                    gbs = pmc_b["hbm_read_bytes_per_launch"] / (rfb["avg_launch_ms"] * 1e-3) / 1e9
+                    rfb.update({"traffic": pmc_b["hbm_read_bytes_per_launch"], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "pmc": pmc_b,
+                                "achieved_basis": "HBM read bytes by PMC (FETCH_SIZE, calibrated in the same pass) per launch / HIP-event time of the "
+                                                  "unprofiled launches in this run",
+                                "traffic_source": "in-run: rocprofv3 --pmc FETCH_SIZE child pass of this script with FPX_DIRECT=0"})
+                else:
+                    rfb["pmc"] = {"error": err_b}
+            result["roofline_block_form"] = rfb
+            result["block_form"] = {"index_build_seconds": round(build_b, 2), "index_bytes": index_bytes_b, "by_batch": [row1k, rowb]}
+        except Exception as e:
+            result["roofline_block_form"] = {"error": str(e)}
+        finally:
+            os.environ.pop("FPX_DIRECT", None)
+
+    # ---- skewed data at full scale (SURVEY 8(d)'s distribution Z: 2 % of every fingerprint's hashes from a pool of 4096 hot values,
+    #      so a hot hash carries the capped 1000 docs x 4 blocks in every segment), in the grouped direct-addressed form
+    if extras and os.environ.get("FPX_BENCH_DISTZ", "1") != "0":
+        try:
+            t_z0 = time.perf_counter()
+            segs_z, ranges_z = synth_index(fpx, ctx, args.seed, docs, S, H, set(range(S)), dist=1)
+            snap_z = fpx.Segments(ctx, segs_z)
+            reader_z = fpx.IndexReader(snap_z)
+            torch.cuda.synchronize()
+            build_z = time.perf_counter() - t_z0
+            fz, oz, tz = fpx.synth.make_queries(args.seed, 4242, B, docs, H, query_len=args.query_len, dist=1)
+            qb_z = fpx.QueryBatch(ctx, options=opts, flat=(fz, oz))
+            dtz, aggz, outz, onz = timed_resident(fpx, reader_z, qb_z, 5, 2)
+            rowz = row_from(B, 5, dtz, aggz, segs_z, "fpx::" + dominant_kernel(segs_z, aggz.fused))
+            rowz["records_per_batch"] = aggz.v["hits"] / max(1, aggz.steps)
+            rowz["index_build_seconds"] = round(build_z, 2)
+            rowz["targets_found"] = int(sum(1 for q in range(B) if onz[q] > 0 and outz[q, 0, 0] == tz[q]))
+            rowz["path_flags"] = aggz.path_flags
+            # parity sample: the first segment alone (a snapshot of one column of the group: the others masked out) against the
+            # oracle on that segment's blocks, 32 queries -- results and the reference's scanned blocks / docs
+            try:
+                from oracle import oracle
+                nqz = 32
+                one = fpx.IndexReader(fpx.Segments(ctx, [segs_z[0]]))
+                blocks0, index0 = segs_z[0].download()
+                lo0, hi0 = ranges_z[0]
+                oseg = oracle.file_segment(blocks0, 512, index0, lo0, hi0, 1, np.arange(lo0, hi0 + 1, dtype=np.uint32), borrow=True)
+                osn = oracle.Snapshot([oseg], [])
+                qs = [fz[int(oz[i]):int(oz[i + 1])] for i in range(nqz)]
+                gz, stz = one.search_batch(qs, opts)
+                mism = blocks = dcs = 0
+                for i in range(nqz):
+                    want, ost = osn.search(qs[i], opts.max_results, opts.min_score, opts.min_score_pct, with_stats=True)
+                    mism += int(gz[i] != want)
+                    blocks += ost.scanned_blocks
+                    dcs += ost.scanned_docs
+                rowz["parity_sample"] = {"queries": nqz, "segments": 1, "mismatches": mism,
+                                         "scanned_blocks_equal": bool(blocks == stz.scanned_blocks), "scanned_docs_equal": bool(dcs == stz.scanned_docs)}
+                del one, osn, oseg, blocks0
+            except Exception as e:
+                rowz["parity_sample"] = {"error": str(e)}
+            result["dist_z"] = rowz
+            qb_z.release(); snap_z.release()
+            for s_ in segs_z:
+                s_.release()
+            del reader_z, snap_z, segs_z
+            torch.cuda.synchronize()
+        except Exception as e:
+            result["dist_z"] = {"error": str(e)}
 
     if world > 1:
         dist.barrier()

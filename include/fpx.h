@@ -66,8 +66,8 @@ typedef struct {
     uint64_t hits;              /* postings accumulated after supersession filtering */
     uint64_t algorithmic_bytes; /* sum over visited blocks of that segment's block_size */
     uint64_t candidates;        /* (query, doc) pairs with score >= min_score */
-    float    probe_kernel_ms;   /* HIP-event time of the MAIN posting decode + match kernel (k_probe_lean8 when the
-                                   batch is large and segments are dense 512-B ones, else k_probe) */
+    float    probe_kernel_ms;   /* HIP-event time of the MAIN probe kernel(s) of the call: k_probe_group (+ k_probe_direct) on direct-addressed
+                                   segments, else k_probe_lean8 when the batch is large and the segments are dense 512-B ones, else k_probe */
     float    total_gpu_ms;      /* first launch -> last kernel of this call, on the call's stream */
     uint32_t probe_launches;    /* launches of the main probe kernel */
     uint32_t generic_iters;     /* block visits that needed the generic per-value decode path */
@@ -170,6 +170,16 @@ int fpx_search(fpx_snapshot *snap, const uint32_t *hashes, uint32_t num_hashes,
 int fpx_search_batch(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets,
                      uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
                      fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
+
+/* fpx_search_batch + per-QUERY scan statistics.  The reference observes num_blocks and num_docs of every (hash, segment) walk
+ * into fpindex_scanned_blocks_per_hash / fpindex_scanned_docs_per_hash (src/FileSegment.zig:177-178, src/metrics.zig:93-101); a
+ * host that keeps feeding those per request needs more than a batch's totals: scanned_blocks_q[q] / scanned_docs_q[q] (each
+ * [num_queries], either may be null) receive query q's sums over its unique hashes and the snapshot's FILE segments -- the same
+ * quantities as fpx_stats.scanned_blocks / scanned_docs, which are their totals.  Costs one atomic per walk when asked for. */
+int fpx_search_batch_stats(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets,
+                           uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
+                           fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats,
+                           uint64_t *scanned_blocks_q, uint64_t *scanned_docs_q);
 
 /* Query batch already resident in HBM: what a host-side coalescer that keeps its staging buffers on the
  * device would hand over, and what bench.py times ("inputs resident in HBM when the timed region starts").

@@ -55,10 +55,17 @@ class Pair:
         # (which path a run took is in st.path_flags; a batch the device-sized path hands back -- a full bin, scores too wide
         # for the candidate key -- is redone on the general one and the next few batches of that workspace skip the attempt)
         opts = options if isinstance(options, list) else [options] * len(queries)
+        # ... and once more with per-query scan statistics (fpx_search_batch_stats): the reference's num_blocks / num_docs per hash
+        # (src/FileSegment.zig:177-178), summed per query, must be the oracle's for EVERY query
+        got3, st3, qblocks, qdocs = self.reader.search_batch_stats(queries, options)
+        assert got3 == got and (st3.scanned_blocks, st3.scanned_docs) == (st.scanned_blocks, st.scanned_docs)
         blocks = docs = 0
         for i, (q, o) in enumerate(zip(queries, opts)):
             want, ost = self.osnap.search(q, o.max_results, o.min_score, o.min_score_pct, with_stats=True)
             assert got[i] == want, f"query {i}: gpu {got[i][:8]} != oracle {want[:8]}"
+            if with_stats:
+                assert (int(qblocks[i]), int(qdocs[i])) == (ost.scanned_blocks, ost.scanned_docs), \
+                    f"query {i}: scanned blocks / docs {int(qblocks[i])} / {int(qdocs[i])}, oracle {ost.scanned_blocks} / {ost.scanned_docs}"
             blocks += ost.scanned_blocks
             docs += ost.scanned_docs
         if with_stats:

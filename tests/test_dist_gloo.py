@@ -180,3 +180,89 @@ def test_hash_range_protocol_world_size_2():
     ret = mgr.dict()
     mp.spawn(_hash_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---- the index sharded by hash range, BIN protocol: world_size 2 over gloo -----------------------------------------
+def _bin_worker(rank, world, port, ret):
+    """Every rank holds the hash window [r 2^32 / N, (r + 1) 2^32 / N) of ALL segments; its hit records go into the batch's bins
+    of 8 queries, the bins are dealt to the ranks in contiguous runs and travel with sharding.exchange_bins (one all-to-all of
+    fixed shape), and the rank that receives a bin FINISHES its queries -- no table exchange, no merge.  The oracle is the
+    per-rank engine; on a GPU box fpx_shard_probe / fpx_shard_score run the same protocol (tests/test_gpu_hashshard.py)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fpx_testlib import fpx, oracle
+        seed, H, per = 61, 48, 3000
+        rng = np.random.default_rng(17)
+        lo_excl = None if rank == 0 else (rank << 32) // world - 1
+        hi_incl = None if rank == world - 1 else ((rank + 1) << 32) // world - 1
+        slices, full_segs = [], []
+        for s in range(3):
+            lo = s * per + 1
+            ids = np.arange(lo, lo + per, dtype=np.uint64)
+            extra = np.sort(rng.choice(np.arange(1, lo), 150, replace=False)).astype(np.uint64) if s else np.zeros(0, np.uint64)
+            all_ids = np.concatenate([extra, ids])
+            h = fpx.synth.synth_hashes(seed + s, all_ids, H, 1).astype(np.uint64)
+            items = np.sort(((h << np.uint64(32)) | all_ids[:, None]).ravel())
+            blocks, index = oracle.build_blocks(items, int(all_ids.min()), 512)
+            mk = lambda: oracle.file_segment(blocks, 512, index, int(all_ids.min()), int(all_ids.max()), s + 1, all_ids.astype(np.uint32))
+            full_segs.append(mk())
+            slices.append(mk().set_window(lo_excl, hi_incl))          # the whole file, only the window's hashes probed
+        local, full = oracle.Snapshot(slices, []), oracle.Snapshot(full_segs, [])
+        limit, pct = 10, 10
+        qdocs = [5, 77, 3001, 7000, 100, 200, 2999, 8999, 4242, 6001, 15, 3100, 8000, 1, 9000, 4500, 6100, 888, 3333]      # 19 queries: 3 bins
+        queries = [fpx.synth.synth_hashes(seed + min(2, (d - 1) // per), [d], H, 1)[0] for d in qdocs]
+        B = len(queries)
+        nbins = (B + 7) // 8
+        bpr = (nbins + world - 1) // world
+        # stage 1: this window's postings per (query, doc): (q, doc, commit, count), dropped into the batch's bins
+        cap = 4096
+        send = torch.zeros((world, bpr, cap, 4), dtype=torch.int64)
+        send_counts = torch.zeros((world, bpr), dtype=torch.int32)
+        for q, hashes in enumerate(queries):
+            b = q >> 3
+            for doc, (commit, score) in local.hits(hashes).items():
+                k = int(send_counts[b // bpr, b % bpr])
+                send[b // bpr, b % bpr, k] = torch.tensor([q, doc, commit, score])
+                send_counts[b // bpr, b % bpr] = k + 1
+        recv, recv_counts = fpx.sharding.exchange_bins(dist, send, send_counts)                 # stage 2: one all-to-all
+        assert tuple(recv.shape) == (world, bpr, cap, 4)
+        # stage 3: the rank finishes the queries of its bins: a doc's score = the postings of its newest commit, summed over the pieces
+        ok = True
+        q_lo, q_hi = min(B, rank * bpr * 8), min(B, (rank + 1) * bpr * 8)
+        acc = {}
+        for s in range(world):
+            for b in range(bpr):
+                for q, doc, commit, score in recv[s, b, :int(recv_counts[s, b])].tolist():
+                    assert q_lo <= q < q_hi
+                    c, s_ = acc.get((q, doc), (0, 0))
+                    if commit > c:
+                        c, s_ = commit, 0
+                    if commit == c:
+                        s_ += score
+                    acc[(q, doc)] = (c, s_)
+        for q in range(q_lo, q_hi):
+            floor = (len(queries[q]) + 19) // 20
+            ent = [(s_, doc) for (qq, doc), (c, s_) in acc.items() if qq == q and s_ >= floor and not full.has_newer_commit(doc, c)]
+            ent.sort(key=lambda e: (-e[0], e[1]))
+            res = []
+            for s_, doc in ent:
+                if len(res) == limit or s_ < floor:
+                    break
+                if not res:
+                    floor = max(floor, s_ * pct // 100)
+                res.append((doc, s_))
+            ok = ok and res == full.search(queries[q], max_results=limit, min_score=None, min_score_pct=pct)
+        ret[rank] = (bool(ok), q_hi - q_lo)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hash_window_bin_protocol_world_size_2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bin_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r = dict(ret)
+    assert r[0][0] and r[1][0] and r[0][1] + r[1][1] == 19          # every query finished by exactly one rank

@@ -87,6 +87,7 @@ SIGNATURES = {
     "fpx_search_resident_partial": (C.c_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_merge_partials": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "fpx_sharded_snapshot_create": (C.c_int, [_vp, _u32, C.POINTER(_vp)]),
+    "fpx_sharded_snapshot_create_on": (C.c_int, [_vp, _vp, _u32, C.POINTER(_vp)]),
     "fpx_sharded_snapshot_retain": (None, [_vp]),
     "fpx_sharded_snapshot_release": (None, [_vp]),
     "fpx_sharded_snapshot_num_devices": (_u32, [_vp]),

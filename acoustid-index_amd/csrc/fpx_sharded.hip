@@ -9,9 +9,12 @@
 // one-process-per-GPU path of sharding.py / bench.py, whose all-gather is RCCL's.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -23,6 +26,56 @@
 namespace fpx {
 
 namespace {
+
+// the calling thread's current device, put back when the call returns: a host that mixes its own HIP calls with libfpx's on
+// one thread must not find itself on another device afterwards
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
+// ---- RCCL, loaded at run time (libfpx links the HIP runtime only; a host process may hold its own librccl -- PyTorch bundles
+//      one -- and dlopen by name returns that very library instead of a second copy).  Used for the exchange of the per-device
+//      tables when the shards really live on several devices; peer copies (hipMemcpyPeerAsync) otherwise and as the fallback.
+typedef void* ncclComm_t_;
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(ncclComm_t_*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t_) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int NCCL_UINT8 = 1;           // ncclUint8 (nccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
+static const Rccl& rccl()
+{
+    static const Rccl r = [] {
+        Rccl x;
+        const char* e = getenv("FPX_SHARDED_RCCL");
+        if (e && atoi(e) == 0) return x;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) return x;
+        auto sym = [&](const char* n) { return dlsym(x.lib, n); };
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+        x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
+        x.Recv = reinterpret_cast<decltype(x.Recv)>(sym("ncclRecv"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.ok = x.CommInitAll && x.CommDestroy && x.GroupStart && x.GroupEnd && x.Send && x.Recv;
+        return x;
+    }();
+    return r;
+}
 
 // A few worker threads pinned (by hipSetDevice) to one device: they run that device's partial searches, which block
 // on the device's streams, so that the caller's thread can drive all devices at once.
@@ -93,6 +146,12 @@ struct ShardedSnapshot {
     std::vector<std::unique_ptr<DevicePool>> pools;
     std::mutex mu;
     std::vector<ShardBufs*> free_bufs;
+    // RCCL communicators, one per context (rank k = ctxs[k]), when the contexts live on DISTINCT devices; a stream per device
+    // for the exchange.  One exchange at a time (a communicator is not to be used from two threads at once).
+    std::vector<ncclComm_t_> comms;
+    std::vector<hipStream_t> xstreams;
+    std::mutex rccl_mu;
+    bool use_rccl = false;
 };
 
 static void bufs_destroy(ShardedSnapshot* ss, ShardBufs* b)
@@ -145,6 +204,9 @@ static void sharded_free(ShardedSnapshot* ss)
 {
     if (!ss) return;
     ss->pools.clear();                           // joins the workers
+    for (size_t k = 0; k < ss->comms.size(); ++k) if (ss->comms[k]) (void)rccl().CommDestroy(ss->comms[k]);
+    for (size_t k = 0; k < ss->xstreams.size(); ++k)
+        if (ss->xstreams[k]) { (void)hipSetDevice(ss->ctxs[k]->device); (void)hipStreamDestroy(ss->xstreams[k]); }
     for (ShardBufs* b : ss->free_bufs) bufs_destroy(ss, b);
     for (Snapshot* sn : ss->locals) fpx_snapshot_release(reinterpret_cast<fpx_snapshot*>(sn));
     delete ss;
@@ -158,10 +220,19 @@ extern "C" {
 
 int fpx_sharded_snapshot_create(fpx_segment* const* segs, uint32_t num_segs, fpx_sharded_snapshot** out)
 {
+    return fpx_sharded_snapshot_create_on(nullptr, segs, num_segs, out);
+}
+
+int fpx_sharded_snapshot_create_on(fpx_ctx* root_ctx, fpx_segment* const* segs, uint32_t num_segs, fpx_sharded_snapshot** out)
+{
     if (!out || (!segs && num_segs)) { set_error("null argument"); return FPX_E_INVAL; }
     *out = nullptr;
+    const DeviceGuard guard;
     ShardedSnapshot* ss = new (std::nothrow) ShardedSnapshot();
     if (!ss) return FPX_E_NOMEM;
+    // (`root_ctx`, when given, is the first context: its device merges the tables -- and an index without a single segment
+    // still answers searches there, with no results, like the reference's)
+    if (root_ctx) ss->ctxs.push_back(reinterpret_cast<Ctx*>(root_ctx));
     // participating contexts in order of first appearance among the segments that carry postings
     for (uint32_t i = 0; i < num_segs; ++i) {
         const Segment* s = reinterpret_cast<const Segment*>(segs[i]);
@@ -171,7 +242,7 @@ int fpx_sharded_snapshot_create(fpx_segment* const* segs, uint32_t num_segs, fpx
     }
     if (ss->ctxs.empty()) {                      // an empty index still answers searches: any context will do
         for (uint32_t i = 0; i < num_segs && ss->ctxs.empty(); ++i) ss->ctxs.push_back(reinterpret_cast<const Segment*>(segs[i])->ctx);
-        if (ss->ctxs.empty()) { delete ss; set_error("a sharded snapshot needs at least one segment (its context names the device)"); return FPX_E_INVAL; }
+        if (ss->ctxs.empty()) { delete ss; set_error("an empty sharded snapshot needs a context to live on: fpx_sharded_snapshot_create_on"); return FPX_E_INVAL; }
     }
     static const int workers = [] { const char* e = getenv("FPX_SHARDED_WORKERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     for (Ctx* c : ss->ctxs) {
@@ -181,7 +252,36 @@ int fpx_sharded_snapshot_create(fpx_segment* const* segs, uint32_t num_segs, fpx
         const int rc = fpx_snapshot_create(reinterpret_cast<fpx_ctx*>(c), segs, num_segs, &sn);
         if (rc != FPX_OK) { sharded_free(ss); return rc; }
         ss->locals.push_back(reinterpret_cast<Snapshot*>(sn));
-        ss->pools.emplace_back(new DevicePool(c->device, workers));
+        try {
+            ss->pools.emplace_back(new DevicePool(c->device, workers));
+        } catch (...) {                           // (std::system_error / bad_alloc must not cross the C boundary)
+            sharded_free(ss);
+            set_error("could not start the worker threads of device %d", c->device);
+            return FPX_E_NOMEM;
+        }
+    }
+    // the exchange of the tables: RCCL when every context has a device of its own (grouped send / recv over xGMI), else --
+    // several contexts on one device (tests on a one-GPU box), no librccl, FPX_SHARDED_RCCL=0 -- peer copies
+    {
+        std::vector<int> devs;
+        for (Ctx* c : ss->ctxs) devs.push_back(c->device);
+        std::vector<int> uniq = devs;
+        std::sort(uniq.begin(), uniq.end());
+        const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
+        if (ss->ctxs.size() >= 2 && distinct && rccl().ok) {
+            ss->comms.assign(ss->ctxs.size(), nullptr);
+            const int nrc = rccl().CommInitAll(ss->comms.data(), (int)devs.size(), devs.data());
+            if (nrc == 0) {
+                ss->xstreams.assign(ss->ctxs.size(), nullptr);
+                bool ok = true;
+                for (size_t k = 0; k < ss->ctxs.size() && ok; ++k)
+                    ok = hipSetDevice(devs[k]) == hipSuccess && hipStreamCreateWithFlags(&ss->xstreams[k], hipStreamNonBlocking) == hipSuccess;
+                ss->use_rccl = ok;
+            } else {
+                ss->comms.clear();
+            }
+            (void)hipGetLastError();
+        }
     }
     // direct peer copies root <- shard where the topology allows (xGMI); without it hipMemcpyPeerAsync stages through the host
     const int root = ss->ctxs[0]->device;
@@ -226,6 +326,8 @@ int fpx_sharded_search_batch(fpx_sharded_snapshot* s, const uint32_t* hashes, co
     if (!ss || !offsets || !opts || !out_n || (!out && out_cap)) { set_error("null argument"); return FPX_E_INVAL; }
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (num_queries == 0) return FPX_OK;
+    const DeviceGuard guard;                     // (this call moves the thread between the devices)
+    const auto t_call = std::chrono::steady_clock::now();
     const size_t n = ss->ctxs.size();
     const uint32_t B = num_queries;
     // the per-shard tables carry up to max_results entries of every query (out_cap bounds what the caller can take)
@@ -268,14 +370,46 @@ int fpx_sharded_search_batch(fpx_sharded_snapshot* s, const uint32_t* hashes, co
     if (rc == FPX_OK) {
         auto body = [&]() -> int {
             const int root = ss->ctxs[0]->device;
+            bool gathered = false;
+            if (ss->use_rccl && n > 1) {
+                // grouped send / recv: every shard's table and counts to rank 0 (ncclSend / ncclRecv pairs inside one group are
+                // RCCL's gather).  Bytes: B * cap * 8 + B * 4 per shard -- 0.33 MB at B = 1024, limit 40.
+                std::lock_guard<std::mutex> g(ss->rccl_mu);
+                const Rccl& r = rccl();
+                int nrc = r.GroupStart();
+                for (size_t k = 1; k < n && nrc == 0; ++k) {
+                    FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+                    nrc = r.Send(b->d_part[k], (size_t)B * cap * sizeof(fpx_result), NCCL_UINT8, 0, ss->comms[k], ss->xstreams[k]);
+                    if (nrc == 0) nrc = r.Send(b->d_cnt[k], (size_t)B * sizeof(uint32_t), NCCL_UINT8, 0, ss->comms[k], ss->xstreams[k]);
+                }
+                FPX_HIP(hipSetDevice(root));
+                for (size_t k = 1; k < n && nrc == 0; ++k) {
+                    nrc = r.Recv(b->d_all + k * (size_t)B * cap, (size_t)B * cap * sizeof(fpx_result), NCCL_UINT8, (int)k, ss->comms[0], ss->xstreams[0]);
+                    if (nrc == 0) nrc = r.Recv(b->d_all_cnt + k * (size_t)B, (size_t)B * sizeof(uint32_t), NCCL_UINT8, (int)k, ss->comms[0], ss->xstreams[0]);
+                }
+                const int erc = r.GroupEnd();
+                if (nrc == 0 && erc == 0) {
+                    for (size_t k = 0; k < n; ++k) {
+                        FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+                        FPX_HIP(hipStreamSynchronize(ss->xstreams[k]));
+                    }
+                    gathered = true;
+                } else {
+                    ss->use_rccl = false;             // (peer copies from here on)
+                }
+            }
             FPX_HIP(hipSetDevice(root));
-            for (size_t k = 1; k < n; ++k) {
+            for (size_t k = 1; k < n && !gathered; ++k) {
                 FPX_HIP(hipMemcpyPeerAsync(b->d_all + k * (size_t)B * cap, root, b->d_part[k], ss->ctxs[k]->device,
                                            (size_t)B * cap * sizeof(fpx_result), b->copy_stream));
                 FPX_HIP(hipMemcpyPeerAsync(b->d_all_cnt + k * (size_t)B, root, b->d_cnt[k], ss->ctxs[k]->device,
                                            (size_t)B * sizeof(uint32_t), b->copy_stream));
             }
-            if (n > 1) FPX_HIP(hipStreamSynchronize(b->copy_stream));
+            if (n > 1 && !gathered) FPX_HIP(hipStreamSynchronize(b->copy_stream));
+            // (one deadline for the whole call: the partial searches watched it on their devices; the merge is microseconds)
+            if (timeout_ms && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count() > (double)timeout_ms) {
+                set_error("search timeout"); return FPX_E_TIMEOUT;
+            }
             return merge_partials_impl(ss->ctxs[0], b->d_all, b->d_all_cnt, (uint32_t)n, B, cap, opts, offsets, out, out_cap, out_n);
         };
         rc = body();

@@ -295,11 +295,16 @@ class ShardedSegments:
     lives on the device of the Context it was created with; the list is in snapshot order like Segments'.  One call
     searches all devices (worker threads per device, tables gathered on the first context's device, merged there)."""
 
-    def __init__(self, segments):
+    def __init__(self, segments, root=None):
+        """root: the Context whose device merges the tables (fpx_sharded_snapshot_create_on); needed for an index without a
+        single segment, optional otherwise (default: the first segment's context)"""
         self.segments = list(segments)
         arr = (C.c_void_p * max(1, len(self.segments)))(*[s.h for s in self.segments])
         h = C.c_void_p()
-        check(lib().fpx_sharded_snapshot_create(arr, len(self.segments), C.byref(h)))
+        if root is None:
+            check(lib().fpx_sharded_snapshot_create(arr, len(self.segments), C.byref(h)))
+        else:
+            check(lib().fpx_sharded_snapshot_create_on(root.h, arr, len(self.segments), C.byref(h)))
         self.h = h
 
     @property

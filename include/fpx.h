@@ -224,6 +224,10 @@ int fpx_merge_partials(fpx_ctx *ctx, const void *d_parts, const void *d_counts, 
  * launcher, fpx_merge_partials -- is what bench.py --gpus N runs under torch.distributed.) */
 typedef struct fpx_sharded_snapshot fpx_sharded_snapshot;
 int  fpx_sharded_snapshot_create(fpx_segment *const *segs, uint32_t num_segs, fpx_sharded_snapshot **out);
+/* the same with the root named: `root` merges the tables and answers for an index without a single segment (no results, as
+ * the reference does).  When every participating context has a device of its own the tables travel with RCCL (grouped
+ * ncclSend / ncclRecv over xGMI; librccl is loaded at run time, FPX_SHARDED_RCCL=0 turns it off), else with peer copies. */
+int  fpx_sharded_snapshot_create_on(fpx_ctx *root, fpx_segment *const *segs, uint32_t num_segs, fpx_sharded_snapshot **out);
 void fpx_sharded_snapshot_retain(fpx_sharded_snapshot *snap);
 void fpx_sharded_snapshot_release(fpx_sharded_snapshot *snap);
 uint32_t fpx_sharded_snapshot_num_devices(const fpx_sharded_snapshot *snap);   /* contexts that hold postings */

@@ -129,3 +129,22 @@ def test_foreign_segment_in_a_plain_snapshot_is_docs_only():
     both = fpx.ShardedIndexReader(fpx.ShardedSegments([s1, s2]))
     assert both.search(q_new, r)[0] == (1200, H)
     assert all(d != 1200 for d, _ in both.search(q_old, r))
+
+    # merges run per device (fpx_segment_merge): a source that is resident on another context is rejected, not read
+    coll = fpx.Segments(a, [s1, s2])
+    with pytest.raises(fpx.FpxError, match="another context"):
+        coll.merge([s1, s2])
+    alone = coll.merge([s1])                                      # its own segment merges (doc ids the foreign one re-inserts are dropped)
+    ids, _ = alone.docs()
+    assert len(ids) == 2000 - 500 and not ((ids >= 1000) & (ids < 1500)).any()
+
+
+def test_an_index_without_segments_answers_with_no_results():
+    """fpx_sharded_snapshot_create_on: the root context names the device; the reference answers searches on an empty index too"""
+    from fpx_testlib import fpx
+    ctx = fpx.Context(0)
+    with pytest.raises(fpx.FpxError):
+        fpx.ShardedSegments([])                                   # (no context to live on)
+    empty = fpx.ShardedIndexReader(fpx.ShardedSegments([], root=ctx))
+    r = fpx.SearchResults(fpx.http_options())
+    assert empty.search(np.arange(100, dtype=np.uint32), r) == []

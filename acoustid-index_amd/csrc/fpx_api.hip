@@ -484,6 +484,18 @@ int fpx_segment_layout(const fpx_segment* seg)
     return !s || !s->direct ? 0 : s->home ? 2 : 1;
 }
 
+int fpx_segment_group_info(const fpx_segment* seg, uint64_t* info, uint32_t n)
+{
+    const Segment* s = reinterpret_cast<const Segment*>(seg);
+    if (!s || !info) { set_error("null argument"); return FPX_E_INVAL; }
+    const Group* g = s->home.get();
+    if (!g) { set_error("the segment is not a column of a group"); return FPX_E_INVAL; }
+    const uint64_t v[10] = {g->nseg, g->ns, g->device_bytes, g->nlines * 2ull * g->ns * 4ull, g->total_words * 4ull, g->total_list_words * 4ull,
+                            g->doubles, s->col, g->win_lo, g->win_hi};
+    for (uint32_t i = 0; i < n && i < 10u; ++i) info[i] = v[i];
+    return FPX_OK;
+}
+
 int fpx_segment_download(const fpx_segment* seg, uint8_t* blocks, size_t blocks_cap, uint32_t* block_index, uint32_t index_cap)
 {
     const Segment* s = reinterpret_cast<const Segment*>(seg);

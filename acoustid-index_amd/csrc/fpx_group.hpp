@@ -51,8 +51,13 @@ constexpr uint32_t GB_NEED = 0xFFFFFFF0u;   // s_rank: the staged record has no 
 __device__ __forceinline__ uint32_t gb_cell(const ProbeArgs& a, uint64_t rec) { return (uint32_t)(rec >> 32) >> a.bin_shift; }
 __device__ __forceinline__ uint32_t gb_slot(const ProbeArgs& a, uint64_t rec) { return ((uint32_t)(rec >> 32) >> a.bin_shift) & (GB_SLOTS - 1u); }
 
+#ifdef FPX_GK_WAVES
+#define FPX_GK_OCC __attribute__((amdgpu_waves_per_eu(FPX_GK_WAVES, FPX_GK_WAVES)))
+#else
+#define FPX_GK_OCC
+#endif
 template <int NS, bool BINNED>
-__global__ __launch_bounds__(FK_WG) void k_probe_group(ProbeArgs a, GroupArgs ga)
+__global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, GroupArgs ga)
 {
     constexpr int NM = NS - 4;             // words of double bits
     __shared__ uint32_t s_bcnt[2][GB_SLOTS], s_bid[2][GB_SLOTS], s_bbase[GB_SLOTS];

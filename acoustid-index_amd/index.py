@@ -121,6 +121,15 @@ class _Segment:
         """kept in HBM in the direct-addressed form (fpx_segment_layout: 1 on its own, 2 as a column of a group) instead of as blocks"""
         return lib().fpx_segment_layout(self.h) != 0
 
+    def group_info(self):
+        """fpx_segment_group_info as a dict (None when the segment is not a column of a group)"""
+        if lib().fpx_segment_layout(self.h) != 2:
+            return None
+        v = np.zeros(10, np.uint64)
+        check(lib().fpx_segment_group_info(self.h, _p(v), 10))
+        keys = ("columns", "line_columns", "bytes", "directory_bytes", "words_bytes", "lists_bytes", "doubles", "column", "window_lo", "window_hi")
+        return {k: int(x) for k, x in zip(keys, v)}
+
     @property
     def grouped(self):
         """its postings live in a group of direct-addressed segments (fpx_segment_layout == 2)"""

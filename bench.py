@@ -260,7 +260,7 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
 
 def stored_traffic(docs, S, H, B, qlen):
     """fallback: the committed PMC pass, only for the same configuration AND the same kernel sources"""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = tr["config"]
@@ -582,6 +582,7 @@ def main():
                        "sharding": shard_mode, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "segment_layout": ("direct-addressed" + (", one group (hash-major, segment-minor)" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",
+                       "group": next((sg.group_info() for sg in segs if sg.kind == "file" and sg.grouped), None),
                        "index_build_seconds": round(build_s, 2), "shrunk_to_fit": shrunk},
             # achieved / frac: PHYSICAL bytes of the dominant kernel per launch / its HIP-event time / peak.  Filled with the
             # model here and replaced by the in-run PMC figure below when the rocprofv3 child pass succeeds.

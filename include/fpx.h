@@ -137,6 +137,10 @@ uint64_t fpx_segment_device_bytes(const fpx_segment *seg);
  * presence bitmap with a rank directory and doc lists (csrc/fpx_direct.hpp).  Searches, counters, downloads and merges do
  * not depend on the form: a download re-encodes the file's blocks byte for byte. */
 int fpx_segment_layout(const fpx_segment *seg);
+/* What the group of a grouped segment (layout 2) looks like: info[0..9] = columns in use, columns of a directory line (8 / 16),
+ * HBM bytes of the whole group, of its directory, of its words, of its lists, positions stored as inline doubles, this segment's
+ * column, first and last hash of the group's hash window.  (Introspection for benchmarks and capacity planning.) */
+int fpx_segment_group_info(const fpx_segment *seg, uint64_t *info, uint32_t n);
 /* copy a resident file segment's blocks (+terminator) and block index back to the host */
 int fpx_segment_download(const fpx_segment *seg, uint8_t *blocks, size_t blocks_cap,
                          uint32_t *block_index, uint32_t index_cap);

@@ -6,9 +6,12 @@ variant runs in a process of its own):
 * FPX_FAST=0             the general path only (host round trips between the stages, rocPRIM partition)
 * FPX_LEAN_HEAD=4        the whole-block instantiation of the lean probe kernel instead of the partial fetch
 * FPX_DIRECT_MIN_ITEMS=0 EVERY file segment in its direct-addressed form (by default segments of >= 2^20 items): searches, counters, downloads and merges must be what the block form gives.
-                         With FPX_FUSE_MIN=0: probed segment by segment (k_probe_direct)
-* FPX_FUSE_MIN=1         with it: every group of direct-addressed segments, even one alone, behind a fused directory
-                         (k_probe_fused<2 | 4 | 8 | 16>; by default groups of 2..16)
+                         With FPX_FUSE_MIN=0: every segment on its own (k_probe_direct)
+* FPX_FUSE_MIN=1         with it: every direct-addressed segment a column of a GROUP, even one alone (k_probe_group<8 | 16>, built
+                         chunk by chunk from the blocks; by default groups of 2..16) -- the records binned in the probe kernel's
+                         flush and scored a bin per workgroup (k_score_bin) on every batch after a workspace's first
+* FPX_BINNED=0           ... with the two-level partition + k_score instead (the path of mixed snapshots)
+* FPX_INLINE_DOUBLES=0   ... with every hash of several docs behind a list reference (no inline doubles)
 * FPX_DIRECT=0           no segment direct-addressed: segments of >= 2^20 items (direct-addressed by default) are searched in
                          their blocks by the lean kernel (tests/test_gpu_fullsize.py compares the two forms at full size)
 """
@@ -24,16 +27,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUITES = ["tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded_abi.py"]
 DIRECT_SUITES = SUITES + ["tests/test_gpu_builder.py", "tests/test_gpu_merge.py", "tests/test_gpu_api.py", "tests/test_gpu_frontend.py",
                           "tests/test_gpu_hashsplit.py", "tests/test_gpu_sharded.py"]
-# (a fused directory is 17 GB whatever the segments' size, built for every snapshot: these variants run the suites with the
+# (a group's directory is 8.6 GB whatever the segments' size, built for every snapshot: these variants run the suites with the
 # fewest snapshots)
-FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_api.py",
-                "tests/test_gpu_fuzz.py::test_fuzz_lean_sized_worlds"]
+FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_api.py", "tests/test_gpu_merge.py", "tests/test_gpu_direct.py",
+                "tests/test_gpu_hashshard.py", "tests/test_gpu_fuzz.py::test_fuzz_lean_sized_worlds"]
 
 
 @pytest.mark.parametrize("env", [{"FPX_DIRECT": "0"}, {"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
                                  {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"}],
+                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"},
+                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_BINNED": "0"},
+                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_parity_suites_on_the_alternative_paths(env):
     if os.environ.get("FPX_VARIANT_CHILD") == "1":

@@ -8,7 +8,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = "/opt/rocm/lib/llvm/bin"
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_kernel_resources.txt")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_kernel_resources.txt")
 rows = []
 for obj in sorted(os.listdir(os.path.join(ROOT, "acoustid-index_amd", "build"))):
     if not obj.endswith(".o"):

@@ -31,6 +31,10 @@
 
 namespace fpx {
 
+// (per-query scan statistics are a template parameter of the kernel: carried as a run-time test they cost the usual launch,
+// which has none, 0.10 of its 0.76 ms)
+#define GQSTATS(a) (QS ? (a).qstats : (unsigned long long*)nullptr)
+
 struct GroupArgs {
     GroupDesc g;                           // (fpx_internal.h) by value: its fields are read through scalar registers
     const SegDesc* segs;                   // Snapshot::d_direct (the supersession filter's descriptors)
@@ -43,26 +47,33 @@ constexpr uint32_t GK_WORDS = 12;          // words of a hash fetched by its lan
 // in (hash bucket, query) order -- what the one stable radix pass on the top hash bits leaves, k_make_keys_dedup having written
 // them query by query -- the 256 keys of a round belong to a few dozen neighbouring queries: a handful of bins, one reservation
 // each, runs of a kilobyte.  (Binning all 64+ bins of the batch in every flush was measured twice and cost what it saved.)
-constexpr uint32_t GB_SLOTS = 128;         // cells a round may touch (gb_slot; a clash sends the records the long way: the misc buffer)
+#ifndef FPX_GB_SLOTS
+#define FPX_GB_SLOTS 128
+#endif
+constexpr uint32_t GB_SLOTS = FPX_GB_SLOTS;         // cells a round may touch (gb_slot; a clash sends the records the long way: the misc buffer)
 constexpr uint32_t GB_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t GB_NEED = 0xFFFFFFF0u;   // s_rank: the staged record has no rank in its bin yet (every entry between rounds)
+constexpr uint16_t GB_NEED = 0xFFF0u;       // s_rank: the staged record has no rank in its bin yet (every entry between rounds)
 
 // the bin of a record, and the bin's slot in a round's table (a round's keys belong to neighbouring queries: neighbouring bins)
 __device__ __forceinline__ uint32_t gb_cell(const ProbeArgs& a, uint64_t rec) { return (uint32_t)(rec >> 32) >> a.bin_shift; }
 __device__ __forceinline__ uint32_t gb_slot(const ProbeArgs& a, uint64_t rec) { return ((uint32_t)(rec >> 32) >> a.bin_shift) & (GB_SLOTS - 1u); }
 
-#ifdef FPX_GK_WAVES
-#define FPX_GK_OCC __attribute__((amdgpu_waves_per_eu(FPX_GK_WAVES, FPX_GK_WAVES)))
-#else
-#define FPX_GK_OCC
+// Six waves per SIMD (80 VGPRs): measured 0.70 ms per batch of 8192 x 1000 against 0.85 at the 98 VGPRs (four waves: the
+// allocation granule makes 104 of them) the compiler takes when left alone, 0.72 at seven waves (72 VGPRs, six of them spilled).
+#ifndef FPX_GK_WAVES
+#define FPX_GK_WAVES 6
 #endif
-template <int NS, bool BINNED>
+#define FPX_GK_OCC __attribute__((amdgpu_waves_per_eu(FPX_GK_WAVES, FPX_GK_WAVES)))
+template <int NS, bool BINNED, bool QS>
 __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, GroupArgs ga)
 {
     constexpr int NM = NS - 4;             // words of double bits
     __shared__ uint32_t s_bcnt[2][GB_SLOTS], s_bid[2][GB_SLOTS], s_bbase[GB_SLOTS];
-    __shared__ uint32_t s_rank[BINNED ? FSTAGE_CAP : 1];
-    __shared__ uint64_t stage[FSTAGE_CAP];
+    // the stage (and, BINNED, the records' ranks in their bins) live in DYNAMIC shared memory: the compiler sizes its register
+    // budget by the occupancy it believes the static LDS allows, and it believes in 64 KB per CU (gfx950 has 160)
+    extern __shared__ __align__(16) uint8_t gk_dyn[];
+    uint64_t* stage = reinterpret_cast<uint64_t*>(gk_dyn);
+    uint16_t* s_rank = reinterpret_cast<uint16_t*>(gk_dyn + (size_t)FSTAGE_CAP * sizeof(uint64_t));      // (a rank inside a bin of one round: < 2048)
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
         // dedupSorted, src/Index.zig:489-499: flagged by k_make_keys_dedup, or found by looking back
         if (valid && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip))) valid = false;
         const uint32_t h = (uint32_t)(key >> a.qb);
-        const uint32_t blocks_before = my_blocks, docs_before = my_docs;
+        const uint32_t blocks_before = QS ? my_blocks : 0u, docs_before = QS ? my_docs : 0u;
         // a hash-window slice of the group (the index sharded by hash range): the other hashes are another rank's probes
         if (h < g->win_lo || h > g->win_hi) valid = false;
         const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
             const uint64_t rec = qpart | doc;
             if (fits) {
                 hs.buf[pos + o] = rec;
-                if constexpr (BINNED) s_rank[pos + o] = brank == GB_EMPTY ? GB_NEED : brank + o;
+                if constexpr (BINNED) s_rank[pos + o] = brank == GB_EMPTY ? GB_NEED : (uint16_t)(brank + o);
             } else if (gpos + o < a.hit_cap) a.hits[gpos + o] = rec;
             ++o;
         };
@@ -242,11 +253,12 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
         if (xkeep & 1u) put(xd0);
         if (xkeep & 2u) put(xd1);
         if (xkeep & 4u) put(xd2);
-        if (a.qstats && valid && (my_blocks != blocks_before || my_docs != docs_before))
-            atomicAdd(&a.qstats[(uint32_t)(qpart >> 32)], (unsigned long long)(my_blocks - blocks_before) | ((unsigned long long)(my_docs - docs_before) << 32));
+        if (QS && GQSTATS(a) && valid && (my_blocks != blocks_before || my_docs != docs_before))
+            atomicAdd(&GQSTATS(a)[(uint32_t)(qpart >> 32)], (unsigned long long)(my_blocks - blocks_before) | ((unsigned long long)(my_docs - docs_before) << 32));
         // ---- the rare rest, by the whole wave: words beyond the lane's twelve, further lists, lists longer than their head
         {
             const bool more = nwords > GK_WORDS || n_esc > 1u || (n_esc == 1u && xeff > xin);
+            const bool hot = n_esc != 0u && xeff >= 64u;
             unsigned long long mo = __ballot((int)more);
             while (mo != 0ull) {
                 const int src = (int)__builtin_ctzll(mo);
@@ -275,55 +287,80 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                     const uint32_t doc = s_min_doc[col] + wv;
                     if (plain) {
                         my_blocks += second ? 0u : 1u; my_docs += 1u;
-                        if (a.qstats) atomicAdd(&a.qstats[qlo], (second ? 0ull : 1ull) | (1ull << 32));
+                        if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (second ? 0ull : 1ull) | (1ull << 32));
                     }
                     const bool kp = plain && !(any_dead && s_has_dead[col] && is_dead_seg(ga.segs[s_seg_index[col]], doc));
                     fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | doc, 0ull, 0ull, lane);
                 }
-                // the lists: lane l (a word that refers to one) reads its header; of the first list within the lane's words the head
-                // has been emitted by its lane
-                const bool is_list = act && (wv >> 31) != 0u;
-                const unsigned long long ml = __ballot((int)is_list);
-                const uint32_t* lp = li_s + (wv & 0x7FFFFFFFu);
-                const uint32_t hdr_l = is_list ? gload_u32(lp) : 0u;
-                const uint32_t eff_l = hdr_l & 0xFFFFu, T_l = (hdr_l >> 19) & 1u;
-                const bool slot_list = is_list && ml != 0ull && lane == (uint32_t)__builtin_ctzll(ml) && lane < GK_WORDS;
-                const uint32_t from_l = slot_list ? min(eff_l, T_l ? 2u : 3u) : 0u;
-                if (is_list && !slot_list) {
-                    my_blocks += (hdr_l >> 16) & 7u; my_docs += eff_l; my_reads += 2u;
-                    if (a.qstats) atomicAdd(&a.qstats[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
-                }
-                const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
-                if (rest_l) my_reads += ((rest_l + 31u) >> 5) * 2u;
-                uint32_t total = rest_l;
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
-                const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
-                unsigned long long me = __ballot((int)(rest_l != 0u));
-                if (total >= 128u && !filtered) {
-                    // a hot hash (hundreds of docs in every segment): ONE reservation for all its lists, written straight to the
-                    // batch's record buffer.  (64 records at a time through the stage, every chunk beyond the stage's room paid a
-                    // global atomic on one address: 10 M of them per batch of 8192 on hot-pool data = 110 ms.)
-                    unsigned long long gbase = 0;
-                    if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
-                    gbase = __shfl(gbase, 0);
-                    while (me != 0ull) {
-                        const int el = (int)__builtin_ctzll(me);
-                        me &= me - 1ull;
-                        const uint32_t* list = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), el) << 32) | __shfl((uint32_t)(uint64_t)lp, el));
-                        const uint32_t eff = __shfl(eff_l, el), T = __shfl(T_l, el), from = __shfl(from_l, el), md = s_min_doc[__shfl(col, el)];
-                        for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
-                            const unsigned long long at = gbase + (o2 - from) + lane;
-                            if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
-                        }
-                        gbase += eff - from;
+                // the lists.  A HOT hash (its first list holds 64+ docs: hundreds of docs in every segment) takes ONE reservation in
+                // the batch's record buffer for all its lists and writes them straight there.  (64 records at a time through the
+                // stage, every chunk beyond the stage's room paid a global atomic on one address: 10 M of them per batch of 8192 on
+                // hot-pool data = 110 ms.)  Lane l (a word that refers to a list) reads its own header for that.
+                const bool hot_s = __shfl((int)hot, src) != 0;
+                if (hot_s) {
+                    const bool is_list = act && (wv >> 31) != 0u;
+                    const unsigned long long ml = __ballot((int)is_list);
+                    const uint32_t* lp = li_s + (wv & 0x7FFFFFFFu);
+                    const uint32_t hdr_l = is_list ? gload_u32(lp) : 0u;
+                    const uint32_t eff_l = hdr_l & 0xFFFFu, T_l = (hdr_l >> 19) & 1u;
+                    const bool slot_list = is_list && lane == (uint32_t)__builtin_ctzll(ml) && lane < GK_WORDS;
+                    const uint32_t from_l = slot_list ? min(eff_l, T_l ? 2u : 3u) : 0u;
+                    if (is_list && !slot_list) {
+                        my_blocks += (hdr_l >> 16) & 7u; my_docs += eff_l; my_reads += 2u;
+                        if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
                     }
-                } else {
+                    const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
+                    if (rest_l) my_reads += ((rest_l + 31u) >> 5) * 2u;
+                    uint32_t total = rest_l;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
+                    const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
+                    unsigned long long me = __ballot((int)(rest_l != 0u));
+                    unsigned long long gbase = 0;
+                    if (!filtered) {
+                        if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+                        gbase = __shfl(gbase, 0);
+                    }
                     while (me != 0ull) {
                         const int el = (int)__builtin_ctzll(me);
                         me &= me - 1ull;
                         const uint32_t* list = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), el) << 32) | __shfl((uint32_t)(uint64_t)lp, el));
                         const uint32_t eff = __shfl(eff_l, el), T = __shfl(T_l, el), from = __shfl(from_l, el), c2 = __shfl(col, el);
+                        const uint32_t md = s_min_doc[c2];
+                        if (!filtered) {
+                            for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                                const unsigned long long at = gbase + (o2 - from) + lane;
+                                if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
+                            }
+                            gbase += eff - from;
+                        } else {                     // (superseded docs among them: through the stage, 64 at a time)
+                            const SegDesc* filt = s_has_dead[c2] ? ga.segs + s_seg_index[c2] : nullptr;
+                            for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                                bool kp = o2 + lane < eff;
+                                const uint32_t dv = md + (kp ? gload_u32(list + 1u + T + o2 + lane) : 0u);
+                                if (filt && kp) kp = !is_dead_seg(*filt, dv);
+                                fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
+                            }
+                        }
+                    }
+                } else {
+                    // the usual case -- a list or two of a handful of docs: one after the other; of the first one within the lane's
+                    // words the head has been emitted
+                    unsigned long long me = __ballot((int)(act && (wv >> 31) != 0u));
+                    bool first = true;
+                    while (me != 0ull) {
+                        const int el = (int)__builtin_ctzll(me);
+                        me &= me - 1ull;
+                        const uint32_t off = __shfl(wv, el) & 0x7FFFFFFFu, c2 = __shfl(col, el);
+                        const uint32_t* list = li_s + off;
+                        const uint32_t hdr = gload_u32(list), eff = hdr & 0xFFFFu, T = (hdr >> 19) & 1u;
+                        uint32_t from = 0u;
+                        if (first && (uint32_t)el < GK_WORDS) from = min(eff, T ? 2u : 3u);          // (the lane's slot took these)
+                        else if (lane == 0) {
+                            my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u;
+                            if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr >> 16) & 7u) | ((unsigned long long)eff << 32));
+                        }
+                        first = false;
                         const SegDesc* filt = (any_dead && s_has_dead[c2]) ? ga.segs + s_seg_index[c2] : nullptr;
                         const uint32_t md = s_min_doc[c2];
                         for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
@@ -332,6 +369,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                             if (filt && kp) kp = !is_dead_seg(*filt, dv);
                             fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
                         }
+                        if (lane == 0 && eff > from) my_reads += ((eff - from + 31u) >> 5) * 2u;
                     }
                 }
             }
@@ -348,7 +386,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                 if (s_rank[i] != GB_NEED) continue;
                 const uint32_t b = gb_cell(a, stage[i]), sl = gb_slot(a, stage[i]);
                 const uint32_t old = atomicCAS(&s_bid[par][sl], GB_EMPTY, b);
-                if (old == GB_EMPTY || old == b) s_rank[i] = atomicAdd(&s_bcnt[par][sl], 1u); else unplaced = true;
+                if (old == GB_EMPTY || old == b) s_rank[i] = (uint16_t)atomicAdd(&s_bcnt[par][sl], 1u); else unplaced = true;
             }
             __syncthreads();
             if (tid < GB_SLOTS) {
@@ -361,7 +399,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
             __syncthreads();
             for (uint32_t i = tid; i < sc; i += FK_WG) {
                 const uint64_t rec = stage[i];
-                const uint32_t b = gb_cell(a, rec), rk = s_rank[i];
+                const uint32_t b = gb_cell(a, rec); const uint32_t rk = s_rank[i];
                 if (rk < GB_NEED) {
                     const uint64_t at = (uint64_t)s_bbase[gb_slot(a, rec)] + rk;
                     if (at < a.bin_cap) a.bins[(size_t)b * a.bin_cap + at] = rec;

@@ -109,6 +109,21 @@ static int grow_pair(uint64_t* p[2], size_t* cap, size_t need)
     return FPX_OK;
 }
 
+// k_probe_group's instantiations: columns of a directory line (8 | 16), records binned in the flush, per-query scan statistics
+static void launch_probe_group(bool ns8, bool binned, bool qs, dim3 grid, hipStream_t st, const ProbeArgs& a, const GroupArgs& g)
+{
+    const size_t dyn = (size_t)FSTAGE_CAP * sizeof(uint64_t) + (binned ? (size_t)FSTAGE_CAP * sizeof(uint16_t) : 0u);       // stage (+ ranks)
+#define FPX_LPG(NS, BN, QSV) hipLaunchKernelGGL((k_probe_group<NS, BN, QSV>), grid, dim3(FK_WG), dyn, st, a, g)
+    if (ns8) {
+        if (binned) { if (qs) FPX_LPG(8, true, true); else FPX_LPG(8, true, false); }
+        else { if (qs) FPX_LPG(8, false, true); else FPX_LPG(8, false, false); }
+    } else {
+        if (binned) { if (qs) FPX_LPG(16, true, true); else FPX_LPG(16, true, false); }
+        else { if (qs) FPX_LPG(16, false, true); else FPX_LPG(16, false, false); }
+    }
+#undef FPX_LPG
+}
+
 constexpr int FPX_SPLIT = 1;   // internal: candidate key does not fit 64 bits, split the batch
 constexpr int FPX_REDO = 2;    // internal: the device-sized path met something only the general path handles (a full bin, ...)
 
@@ -514,13 +529,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                         const GroupArgs gargs{gd, snap->d_direct};
                         const dim3 gridg((uint32_t)((P + per_wg_gk - 1) / per_wg_gk));
                         const bool ns8 = snap->groups[&gd - snap->h_group.data()]->ns == 8u;
-                        if (binned) {
-                            if (ns8) hipLaunchKernelGGL((k_probe_group<8, true>), gridg, dim3(FK_WG), 0, st, gk, gargs);
-                            else hipLaunchKernelGGL((k_probe_group<16, true>), gridg, dim3(FK_WG), 0, st, gk, gargs);
-                        } else {
-                            if (ns8) hipLaunchKernelGGL((k_probe_group<8, false>), gridg, dim3(FK_WG), 0, st, gk, gargs);
-                            else hipLaunchKernelGGL((k_probe_group<16, false>), gridg, dim3(FK_WG), 0, st, gk, gargs);
-                        }
+                        launch_probe_group(ns8, binned, gk.qstats != nullptr, gridg, st, gk, gargs);
                     }
                     used_fused = true;
                 }
@@ -1363,8 +1372,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             for (const GroupDesc& gd : snap->h_group) {
                 const GroupArgs gargs{gd, snap->d_direct};
                 const dim3 grid((uint32_t)((P + per_wg - 1) / per_wg));
-                if (snap->groups[&gd - snap->h_group.data()]->ns == 8u) hipLaunchKernelGGL((k_probe_group<8, true>), grid, dim3(FK_WG), 0, st, a, gargs);
-                else hipLaunchKernelGGL((k_probe_group<16, true>), grid, dim3(FK_WG), 0, st, a, gargs);
+                launch_probe_group(snap->groups[&gd - snap->h_group.data()]->ns == 8u, true, false, grid, st, a, gargs);
             }
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             // what the kernel could not place itself (a clash of two bins on one slot of a round, a full stage): k_bin

@@ -72,7 +72,8 @@ public:
     fpx_segment* handle() const { return h_.get(); }
     uint64_t getSize() const { return fpx_segment_num_items(h_.get()); }       // FileSegment.getSize, :75-77
     uint64_t deviceBytes() const { return fpx_segment_device_bytes(h_.get()); }
-    bool directAddressed() const { return fpx_segment_layout(h_.get()) == 1; }
+    bool directAddressed() const { return fpx_segment_layout(h_.get()) != 0; }      // 1: on its own, 2: a column of a group
+    bool grouped() const { return fpx_segment_layout(h_.get()) == 2; }
 protected:
     std::shared_ptr<fpx_segment> h_;
 };
@@ -242,12 +243,18 @@ public:
         std::vector<fpx_result> out((size_t)B * cap);
         std::vector<uint32_t> out_n(B);
         fpx_stats st{};
-        check(fpx_search_batch(snapshot_.handle(), flat.data(), offsets.data(), B, opts.data(), timeout_ms, out.data(), cap, out_n.data(), &st));
+        // per-query scan statistics ride along (what FileSegment.search observes per hash, src/FileSegment.zig:177-178, summed per
+        // query): every SearchResults gets ITS OWN scanned_blocks / scanned_docs next to the batch's device timings
+        std::vector<uint64_t> qb(B), qd(B);
+        check(fpx_search_batch_stats(snapshot_.handle(), flat.data(), offsets.data(), B, opts.data(), timeout_ms, out.data(), cap, out_n.data(), &st,
+                                     qb.data(), qd.data()));
         for (uint32_t q = 0; q < B; ++q) {
             results[q].results_.clear();
             for (uint32_t i = 0; i < out_n[q]; ++i)
                 results[q].results_.push_back(SearchResult{out[(size_t)q * cap + i].id, out[(size_t)q * cap + i].score});
             results[q].stats = st;
+            results[q].stats.scanned_blocks = qb[q];
+            results[q].stats.scanned_docs = qd[q];
         }
     }
 private:

@@ -74,6 +74,7 @@ void ws_destroy(Workspace* w)
     if (!w) return;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->d_qstats) (void)hipFree(w->d_qstats);
+    if (w->d_kocnt) (void)hipFree(w->d_kocnt);
     if (w->d_cells) (void)hipFree(w->d_cells);
     if (w->h_cells) (void)hipHostFree(w->h_cells);
     void* bufs[] = {w->d_hashes, w->d_offsets, w->d_opts, w->d_keys[0], w->d_keys[1], w->d_hits[0], w->d_hits[1],

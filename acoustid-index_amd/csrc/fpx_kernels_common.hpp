@@ -120,11 +120,23 @@ __global__ void k_make_keys(const uint32_t* __restrict__ hashes_base, const uint
 // is_duplicate_pair, whose cost grows with the bucket width, is not needed.  Queries of up to DEDUP_MAX hashes.
 constexpr uint32_t DEDUP_MAX = 2048, DEDUP_SLOTS = 4096;
 constexpr uint64_t KEY_DUP_FLAG = 1ull << 63;
+
+// the counting sort of fpx_keyorder.hpp: the key-making kernels count their query's keys per hash bucket on the way
+constexpr uint32_t KO_MAX_BUCKETS = 256;
+constexpr uint32_t KO_GROUP = 8;   // queries per group: a bin of the scoring kernel
+struct KeyOrder {
+    uint32_t* cnt = nullptr;       // [nb][G], G = groups of KO_GROUP queries; zeroed before the keys are made
+    uint32_t* totals = nullptr;    // [nb]
+    uint32_t nb = 0;               // buckets, a power of two (0: no counting)
+    uint32_t bshift = 0;           // bucket of hash h = (h >> bshift) & (nb - 1)
+};
+
 __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
                                                          uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,
-                                                         unsigned long long* zero_counters, unsigned int* zero_u32, uint32_t zero_n)
+                                                         unsigned long long* zero_counters, unsigned int* zero_u32, uint32_t zero_n, KeyOrder ko)
 {
     __shared__ uint32_t tab[DEDUP_SLOTS];
+    __shared__ uint32_t hist[KO_MAX_BUCKETS];
     __shared__ uint32_t seen_ones;                  // the hash 0xFFFFFFFF (the table's empty mark) is kept apart
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     if (q >= B) return;
@@ -132,6 +144,7 @@ __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restr
     if (zero_u32 && q == 0)
         for (uint32_t i = tid; i < zero_n; i += 256u) zero_u32[i] = 0u;
     for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
+    hist[tid] = 0u;
     if (tid == 0) seen_ones = 0u;
     __syncthreads();
     const uint64_t lo = offsets[q], hi = offsets[q + 1];
@@ -150,6 +163,12 @@ __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restr
             }
         }
         keys[i - base] = (((uint64_t)h << qb) | q) | (dup ? KEY_DUP_FLAG : 0ull);
+        if (ko.nb) atomicAdd(&hist[(h >> ko.bshift) & (ko.nb - 1u)], 1u);       // (duplicates keep their place in the order)
+    }
+    if (ko.nb) {
+        __syncthreads();
+        const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
+        if (tid < ko.nb && hist[tid] != 0u) atomicAdd(&ko.cnt[(size_t)tid * G + q / KO_GROUP], hist[tid]);
     }
 }
 

@@ -1,0 +1,106 @@
+// fpx_keyorder.hpp -- the batch's keys brought into (hash bucket, query) order by a counting sort of our own.
+// Part of the fpx_search.hip translation unit.
+//
+// The direct-addressed probe kernels want their keys ordered by the top bits of the hash (a workgroup's reads stay within a
+// few pages of each table) and, inside such a bucket, by query (a round's 256 keys belong to a handful of neighbouring bins).
+// That is ONE counting-sort pass whose counts the key-making kernel can take on its way: it already holds every hash of its
+// query in LDS.  Three launches replace the library's radix pass (histogram, scan and one-sweep kernels plus their fills --
+// 150 us of fixed cost on a batch of 1024 queries, which was therefore left unordered: probe kernel 0.19 instead of 0.14 ms):
+//
+//   k_make_keys_dedup / k_make_keys_window*   the keys in query order; cnt[b][g] += keys of the query in bucket b, g = its group of
+//                       KO_GROUP neighbouring queries (= a bin of the scoring kernel)
+//   k_bucket_scan       per bucket, the exclusive prefix of cnt[b][.] over the groups (in place) and the bucket's total
+//   k_scatter_keys      per group: slot of (b, g) = buckets before b + cnt[b][g]; the group's keys take the slots in any order
+//
+// dedupSorted (src/Index.zig:489-499) is done where the keys are made; the order serves locality only -- any order gives the
+// same results.
+#pragma once
+#include "fpx_kernels_common.hpp"
+
+namespace fpx {
+
+constexpr uint64_t KO_MAX_CELLS = 1ull << 22;        // buckets x queries the count table may have (16 MB)
+
+__device__ __forceinline__ uint32_t ko_wave_incl_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan over the 256 threads of a workgroup; *total = the sum.  s_w: 4 words of LDS.
+__device__ __forceinline__ uint32_t ko_block_excl_scan(uint32_t v, uint32_t tid, uint32_t* s_w, uint32_t* total)
+{
+    const uint32_t lane = tid & 63u, w = tid >> 6;
+    const uint32_t incl = ko_wave_incl_scan(v, lane);
+    __syncthreads();                                   // (s_w may still be read from a previous call)
+    if (lane == 63u) s_w[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) { const uint32_t t = s_w[i]; all += t; if (i < w) before += t; }
+    *total = all;
+    return before + incl - v;
+}
+
+// one workgroup per bucket: the bucket's row of `G` group counts is contiguous
+__global__ __launch_bounds__(256) void k_bucket_scan(KeyOrder ko, uint32_t G)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    uint32_t* row = ko.cnt + (size_t)b * G;
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < G; g0 += 1024u) {
+        // four neighbouring groups per thread
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) { const uint32_t g = g0 + tid * 4u + i; v[i] = g < G ? gload_u32(row + g) : 0u; }
+        uint32_t total;
+        uint32_t run = carry + ko_block_excl_scan(v[0] + v[1] + v[2] + v[3], tid, s_w, &total);
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) { const uint32_t g = g0 + tid * 4u + i; if (g < G) row[g] = run; run += v[i]; }
+        carry += total;
+    }
+    if (tid == 0) ko.totals[b] = carry;
+}
+
+// one workgroup per group of KO_GROUP queries: their keys are the contiguous range [lo, hi) of keys_in (a key with bit 63 set in a
+// window's slots is padding: skipped; elsewhere duplicates keep their flag and their place in the order).
+// P_out (optional): the number of keys written, set by workgroup 0.
+__global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_t* __restrict__ keys_in, const uint64_t* __restrict__ offsets,
+                                                      uint64_t base, uint32_t stride, uint32_t B, uint32_t qb,
+                                                      uint64_t* __restrict__ keys_out, unsigned long long* P_out)
+{
+    __shared__ uint32_t s_pos[KO_MAX_BUCKETS];
+    __shared__ uint32_t s_w[4];
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
+    const uint32_t q0 = g * KO_GROUP, q1 = min(B, q0 + KO_GROUP);
+    uint32_t total;
+    const uint32_t mine = tid < ko.nb ? gload_u32(ko.totals + tid) : 0u;
+    const uint32_t before = ko_block_excl_scan(mine, tid, s_w, &total);
+    if (tid < ko.nb) s_pos[tid] = before + gload_u32(ko.cnt + (size_t)tid * G + g);
+    if (P_out && g == 0 && tid == 0) *P_out = total;
+    __syncthreads();
+    uint64_t lo, hi;
+    if (stride) { lo = (uint64_t)q0 * stride; hi = (uint64_t)q1 * stride; }        // windowed keys: a fixed number of slots per query
+    else { lo = offsets[q0] - base; hi = offsets[q1] - base; }
+    const uint32_t bmask = ko.nb - 1u;
+    for (uint64_t i0 = lo; i0 < hi; i0 += 1024u) {
+        uint64_t key[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) { const uint64_t i = i0 + u * 256u + tid; key[u] = i < hi ? gload_u64(keys_in + i) : ~0ull; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            if (key[u] == ~0ull || (stride && (key[u] >> 63) != 0ull)) continue;
+            const uint32_t h = (uint32_t)(key[u] >> qb);
+            const uint32_t at = atomicAdd(&s_pos[(h >> ko.bshift) & bmask], 1u);
+            keys_out[at] = key[u];
+        }
+    }
+}
+
+}  // namespace fpx

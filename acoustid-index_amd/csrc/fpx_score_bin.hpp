@@ -71,6 +71,42 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
     constexpr uint32_t SB_RPT = 8;
     constexpr uint64_t TILE = (uint64_t)SB_WG * SB_RPT;
 
+    // The tiles of the bin's pieces, one after the other, with the NEXT tile's loads in flight while a tile is worked on: without
+    // the look-ahead a workgroup's life was a chain of load latencies (24 tiles x ~3.8 us for a bin of 50 000 records).
+    struct Cursor { uint32_t src; uint64_t t0, ns; const uint64_t* recs; };
+    auto piece = [&](Cursor& c) {
+        c.ns = min((uint64_t)a.bin_count[(size_t)c.src * a.count_stride + (size_t)bin * a.count_step], a.bin_cap);
+        c.recs = a.bins + (size_t)c.src * a.src_stride + (size_t)bin * a.bin_cap;
+    };
+    auto first = [&](Cursor& c) -> bool {
+        for (c.src = 0, c.t0 = 0; c.src < a.nsrc; ++c.src) { piece(c); if (c.ns != 0u) return true; }
+        return false;
+    };
+    auto next = [&](Cursor& c) -> bool {
+        c.t0 += TILE;
+        if (c.t0 < c.ns) return true;
+        for (c.t0 = 0, ++c.src; c.src < a.nsrc; ++c.src) { piece(c); if (c.ns != 0u) return true; }
+        return false;
+    };
+    auto load = [&](const Cursor& c, uint64_t (&r)[SB_RPT]) {
+#pragma unroll
+        for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = c.t0 + (uint64_t)u * SB_WG + tid; r[u] = i < c.ns ? gload_u64(c.recs + i) : ~0ull; }
+    };
+    auto for_each_record = [&](auto&& fn) {
+        Cursor c;
+        uint64_t cur[SB_RPT], nxt[SB_RPT];
+        bool more = first(c);
+        if (more) load(c, cur);
+        while (more) {
+            more = next(c);
+            if (more) load(c, nxt);
+#pragma unroll
+            for (uint32_t u = 0; u < SB_RPT; ++u) if (cur[u] != ~0ull) fn(cur[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < SB_RPT; ++u) cur[u] = nxt[u];
+        }
+    };
+
     if (n != 0u && n >= (uint64_t)floor_min) {
         // 16-bit cells while no cell can overflow (fewer than 2^16 records in all), 32-bit ones beyond
         const bool wide = n >= 65536ull;
@@ -91,23 +127,12 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
             for (uint32_t i = tid; i < (1u << (SB_FILTER_LOG2 - 1u)); i += SB_WG) filter[i] = 0u;
             __syncthreads();
             // ---- stage A: every record of the class into its (query, doc) cell
-            for (uint32_t src = 0; src < a.nsrc; ++src) {
-            const uint64_t ns = min((uint64_t)a.bin_count[(size_t)src * a.count_stride + (size_t)bin * a.count_step], a.bin_cap);
-            const uint64_t* recs = a.bins + (size_t)src * a.src_stride + (size_t)bin * a.bin_cap;
-            for (uint64_t t0 = 0; t0 < ns; t0 += TILE) {
-                uint64_t r[SB_RPT];
-#pragma unroll
-                for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < ns ? gload_u64(recs + i) : ~0ull; }
-#pragma unroll
-                for (uint32_t u = 0; u < SB_RPT; ++u) {
-                    if (r[u] == ~0ull) continue;
-                    const uint32_t doc = (uint32_t)r[u], ql = (uint32_t)(r[u] >> 32) & qm;
-                    if (!in_class(doc)) continue;
-                    const uint32_t c = mix32(doc ^ (ql * 0x9E3779B1u)) & fmask;
-                    if (wide) atomicAdd(&filter[c], 1u); else atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
-                }
-            }
-            }
+            for_each_record([&](uint64_t rec) {
+                const uint32_t doc = (uint32_t)rec, ql = (uint32_t)(rec >> 32) & qm;
+                if (!in_class(doc)) return;
+                const uint32_t c = mix32(doc ^ (ql * 0x9E3779B1u)) & fmask;
+                if (wide) atomicAdd(&filter[c], 1u); else atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
+            });
             __syncthreads();
             // ---- stage B: the records whose cell reaches their query's floor (every (query, doc) with count >= floor is among
             //      them) are counted exactly; when they are more than the table takes, in `passes` loads over classes of them.
@@ -118,38 +143,27 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                 for (uint32_t s = tid; s < T; s += SB_WG) table[s] = 0ull;
                 if (tid == 0) { s_claimed = 0u; s_full = 0u; }
                 __syncthreads();
-                for (uint32_t src = 0; src < a.nsrc; ++src) {
-                const uint64_t ns = min((uint64_t)a.bin_count[(size_t)src * a.count_stride + (size_t)bin * a.count_step], a.bin_cap);
-                const uint64_t* recs = a.bins + (size_t)src * a.src_stride + (size_t)bin * a.bin_cap;
-                for (uint64_t t0 = 0; t0 < ns; t0 += TILE) {
-                    uint64_t r[SB_RPT];
-#pragma unroll
-                    for (uint32_t u = 0; u < SB_RPT; ++u) { const uint64_t i = t0 + (uint64_t)u * SB_WG + tid; r[u] = i < ns ? gload_u64(recs + i) : ~0ull; }
-#pragma unroll
-                    for (uint32_t u = 0; u < SB_RPT; ++u) {
-                        if (r[u] == ~0ull) continue;
-                        const uint32_t doc = (uint32_t)r[u], ql = (uint32_t)(r[u] >> 32) & qm;
-                        if (!in_class(doc)) continue;
-                        const uint32_t hsh = mix32(doc ^ (ql * 0x9E3779B1u));
-                        if (cell_count(hsh & fmask) < s_floor[ql]) continue;
-                        if (passes > 1u && ((hsh >> 25) % passes) != pass) continue;       // class bits apart from the slot bits (14..24)
-                        // slot: doc << 32 | query-in-bin << 26 | count (26 bits)
-                        const unsigned long long keyhi = ((unsigned long long)doc << 32) | ((unsigned long long)ql << SB_QL_SHIFT);
-                        uint32_t s = (hsh >> 14) & tmask;
-                        for (uint32_t tries = 0;; ++tries) {
-                            if (tries == T) { s_full = 1u; break; }
-                            unsigned long long cur = table[s];
-                            if (cur == 0ull) {
-                                const unsigned long long prev = atomicCAS(&table[s], 0ull, keyhi | 1ull);
-                                if (prev == 0ull) { atomicAdd(&s_claimed, 1u); break; }
-                                cur = prev;
-                            }
-                            if ((cur >> SB_QL_SHIFT) == (keyhi >> SB_QL_SHIFT)) { atomicAdd(&table[s], 1ull); break; }
-                            s = (s + 1u) & tmask;
+                for_each_record([&](uint64_t rec) {
+                    const uint32_t doc = (uint32_t)rec, ql = (uint32_t)(rec >> 32) & qm;
+                    if (!in_class(doc)) return;
+                    const uint32_t hsh = mix32(doc ^ (ql * 0x9E3779B1u));
+                    if (cell_count(hsh & fmask) < s_floor[ql]) return;
+                    if (passes > 1u && ((hsh >> 25) % passes) != pass) return;       // class bits apart from the slot bits (14..24)
+                    // slot: doc << 32 | query-in-bin << 26 | count (26 bits)
+                    const unsigned long long keyhi = ((unsigned long long)doc << 32) | ((unsigned long long)ql << SB_QL_SHIFT);
+                    uint32_t s = (hsh >> 14) & tmask;
+                    for (uint32_t tries = 0;; ++tries) {
+                        if (tries == T) { s_full = 1u; break; }
+                        unsigned long long cur = table[s];
+                        if (cur == 0ull) {
+                            const unsigned long long prev = atomicCAS(&table[s], 0ull, keyhi | 1ull);
+                            if (prev == 0ull) { atomicAdd(&s_claimed, 1u); break; }
+                            cur = prev;
                         }
+                        if ((cur >> SB_QL_SHIFT) == (keyhi >> SB_QL_SHIFT)) { atomicAdd(&table[s], 1ull); break; }
+                        s = (s + 1u) & tmask;
                     }
-                }
-                }
+                });
                 __syncthreads();
                 if (pass == 0u && (s_claimed > fill || s_full != 0u) && passes < 64u) {
                     const uint32_t np = passes * 2u;

@@ -36,6 +36,7 @@
 
 
 #include "fpx_kernels_common.hpp"
+#include "fpx_keyorder.hpp"
 #include "fpx_probe_generic.hpp"
 #include "fpx_probe_lean.hpp"
 #include "fpx_direct.hpp"
@@ -197,6 +198,53 @@ static int sync_deadline(Workspace* ws, double t_start, uint32_t timeout_ms)
 }
 #define FPX_SYNC(ws) do { const int _rc = sync_deadline((ws), t_start, timeout_ms); if (_rc != FPX_OK) return _rc; } while (0)
 
+// The count table of the batch's key order (fpx_keyorder.hpp): `bits` hash bits below the `win_bits` a hash window fixes, fewer
+// when the table would outgrow KO_MAX_CELLS.  Layout of ws->d_kocnt: [B x nb counts | nb totals | pad | the key count (u64)].
+static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigned bits, KeyOrder* ko, unsigned long long** P_dev, hipStream_t st)
+{
+    const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
+    bits = std::min(bits, 8u);                       // KO_MAX_BUCKETS
+    while (bits > 0u && ((uint64_t)G << bits) > KO_MAX_CELLS) --bits;
+    const uint32_t nb = 1u << bits;
+    const size_t words = (size_t)G * nb + nb + 4;
+    if (words > ws->cap_kocnt) {
+        if (ws->d_kocnt) (void)hipFree(ws->d_kocnt);
+        ws->d_kocnt = nullptr; ws->cap_kocnt = 0;
+        hipError_t e = hipMalloc(&ws->d_kocnt, words * sizeof(uint32_t));
+        if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", words * sizeof(uint32_t), hipGetErrorString(e)); return FPX_E_NOMEM; }
+        ws->cap_kocnt = words;
+    }
+    ko->cnt = ws->d_kocnt;
+    ko->totals = ws->d_kocnt + (size_t)G * nb;
+    ko->nb = nb;
+    ko->bshift = std::min(31u, 32u - std::min(32u, win_bits + bits));
+    if (P_dev) *P_dev = reinterpret_cast<unsigned long long*>(ws->d_kocnt + (((size_t)G * nb + nb + 1) & ~(size_t)1));
+    FPX_HIP(hipMemsetAsync(ko->cnt, 0, (size_t)G * nb * sizeof(uint32_t), st));
+    return FPX_OK;
+}
+
+// What the host looks at after a device-sized batch -- counters, the kernels' statistics, the bins' fill counts -- is written by
+// ONE small kernel into page-locked host memory that is mapped into the device, and k_finish writes a small batch's results there
+// itself: no copy calls at the end of the stream.  Five hipMemcpyAsync(DeviceToHost) alternated between the copy engines and
+// blit kernels, with a cross-engine wait each time: a gap of 40 - 140 us after k_finish, a third of a 1024-query batch's step.
+struct PublishArgs {
+    const unsigned long long* counters; unsigned long long* h_counters;
+    const uint32_t* a_src; uint32_t* a_dst; uint32_t a_n;                       // contiguous words: deferred-list counts + statistics sets
+    const uint32_t* b_src; uint32_t* b_dst; uint32_t b_n, b_stride;              // the bins' counts, compacted
+};
+__global__ __launch_bounds__(256) void k_publish(PublishArgs p)
+{
+    const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+    if (i0 < CTR_COUNT) p.h_counters[i0] = p.counters[i0];
+    for (uint32_t i = i0; i < p.a_n; i += step) p.a_dst[i] = p.a_src[i];
+    for (uint32_t i = i0; i < p.b_n; i += step) p.b_dst[i] = p.b_src[(size_t)i * p.b_stride];
+}
+template <typename T> static T* mapped_address(T* host)
+{
+    void* d = nullptr;
+    return hipHostGetDevicePointer(&d, host, 0) == hipSuccess ? static_cast<T*>(d) : nullptr;
+}
+
 // Results leave through pinned staging (see Workspace::h_out): enqueue the two copies, and after the stream has been
 // waited for, hand the bytes to the caller.  Beyond a megabyte the host's second copy costs more than the driver's slow
 // path saves (2.6 MB at batch 8192: +0.08 ms): those go directly, after the wait.
@@ -210,11 +258,30 @@ static int stage_results(Workspace* ws, uint32_t B, uint32_t out_cap, hipStream_
         if (ws->h_out) (void)hipHostFree(ws->h_out);
         ws->h_out = nullptr; ws->cap_h_out = 0;
         const size_t ncap = bytes * 5 / 4 + 4096;
-        FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_out), ncap));
+        FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_out), ncap, hipHostMallocMapped));
         ws->cap_h_out = ncap;
     }
     FPX_HIP(hipMemcpyAsync(ws->h_out, ws->d_out_n, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (out_cap) FPX_HIP(hipMemcpyAsync(ws->h_out + (size_t)B * sizeof(uint32_t), ws->d_out, (size_t)B * out_cap * sizeof(fpx_result), hipMemcpyDeviceToHost, st));
+    return FPX_OK;
+}
+// the same staging, filled by k_finish itself: where it writes a batch's counts and results (mapped addresses of h_out)
+static int staged_targets(Workspace* ws, uint32_t B, uint32_t out_cap, bool* staged, uint32_t** d_n, fpx_result** d_res)
+{
+    const size_t bytes = (size_t)B * sizeof(uint32_t) + (size_t)B * out_cap * sizeof(fpx_result);
+    *staged = bytes <= STAGED_OUT_MAX;
+    if (!*staged) return FPX_OK;
+    if (bytes > ws->cap_h_out) {
+        if (ws->h_out) (void)hipHostFree(ws->h_out);
+        ws->h_out = nullptr; ws->cap_h_out = 0;
+        const size_t ncap = bytes * 5 / 4 + 4096;
+        FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_out), ncap, hipHostMallocMapped));
+        ws->cap_h_out = ncap;
+    }
+    uint8_t* d = mapped_address(ws->h_out);
+    if (!d) { *staged = false; return FPX_OK; }
+    *d_n = reinterpret_cast<uint32_t*>(d);
+    *d_res = reinterpret_cast<fpx_result*>(d + (size_t)B * sizeof(uint32_t));
     return FPX_OK;
 }
 static int deliver_results(Workspace* ws, uint32_t B, uint32_t out_cap, bool staged, fpx_result* out, uint32_t* out_n, hipStream_t st)
@@ -324,6 +391,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if ((rc = grow(&ws->d_hashes, &ws->cap_hashes, (size_t)P + 1))) return rc;
         std::vector<uint32_t> h_opts;
         fill_opts(h_opts, opts, offsets, B);
+        // (pageable sources go through the runtime's own staging.  A private page-locked ring per workspace was tried in round 3:
+        // 3.8 / 5.2 M queries/s with one / two callers against 4.6 / 6.5 M this way -- the host's extra copy costs more than the
+        // runtime's lock; what round 2 measured as "two pageable callers serialise" was the second caller's workspace being
+        // allocated inside the timed loop)
         if (P) FPX_HIP(hipMemcpyAsync(ws->d_hashes, hashes + base, P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         FPX_HIP(hipMemcpyAsync(ws->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         FPX_HIP(hipMemcpyAsync(ws->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -345,7 +416,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const size_t nseg = std::max(1u, snap->n_lean);
             const size_t words = nseg * DEF_COUNT_STRIDE + LEAN_STAT_WORDS;
             FPX_HIP(hipMalloc(&ws->d_def_count, words * sizeof(unsigned int)));
-            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), words * sizeof(unsigned int)));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), words * sizeof(unsigned int), hipHostMallocMapped));
             ws->cap_def_segs = nseg;
         }
     }
@@ -373,9 +444,18 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                            (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
         FPX_HIP(hipGetLastError());
     } else if (P && !score_only) {
+        // flagged keys are brought into (hash bucket, query) order by our own counting sort, whose counts k_make_keys_dedup takes
+        // on its way (fpx_keyorder.hpp); tiny batches stay in query order (the three launches cost what the order buys)
+        static const uint64_t order_min = [] { const char* e = getenv("FPX_ORDER_MIN_PAIRS"); return e ? strtoull(e, nullptr, 0) : (1ull << 17); }();
+        KeyOrder ko{};
+        // ... and large ones keep the library's pass: there our three launches cost 0.03 ms more than its five, and two batches in
+        // flight no longer fill each other's gaps (8192 queries: 1.16 against 0.97 ms per batch)
+        static const uint64_t order_max = [] { const char* e = getenv("FPX_ORDER_MAX_PAIRS"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
+        const bool own_order = flagged && !single_fast && P >= order_min && P <= order_max;
+        if (own_order && (rc = key_order_setup(ws, B, 0u, 32u - key_skip, &ko, nullptr, st))) return rc;
         if (flagged)
             hipLaunchKernelGGL(k_make_keys_dedup, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
-                               single_fast ? ws->d_counters : nullptr, ws->d_def_count, (uint32_t)def_words);
+                               single_fast ? ws->d_counters : nullptr, ws->d_def_count, (uint32_t)def_words, ko);
         else
             hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
                                single_fast ? ws->d_counters : nullptr, (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
@@ -387,7 +467,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // pairs -- every probe on lines of its own -- do not have; nor those of a snapshot whose direct-addressed segments are
         // one fused pair -- a rank's share of an index sharded over 8 GPUs: the pass costs 0.1 ms and buys k_probe_fused<2> 0.06;
         // k_probe_direct, whose neighbouring probes share record lines, keeps the order)
-        if (!(flagged && P <= local_sort_max)) {
+        if (own_order) {
+            hipLaunchKernelGGL(k_bucket_scan, dim3(ko.nb), dim3(256), 0, st, ko, (B + KO_GROUP - 1u) / KO_GROUP);
+            hipLaunchKernelGGL(k_scatter_keys, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, (const uint64_t*)ws->d_keys[0], d_offsets, staged_single ? 0ull : base, 0u, B, qb,
+                               ws->d_keys[1], (unsigned long long*)nullptr);
+            FPX_HIP(hipGetLastError());
+            kcur = 1;
+        } else if (!(flagged && P <= local_sort_max)) {
             const size_t tb = sort_u64_temp_bytes(P, qb + key_skip, 32 + qb);
             if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
             FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, qb + key_skip, 32 + qb, st, &kcur));
@@ -462,7 +548,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             FPX_HIP(hipMalloc(&ws->d_qcursor, ncap * sizeof(unsigned long long)));
             ws->cap_binq = ncap;
         }
-        if (!ws->h_bins) FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_bins), (BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE + MAX_SBINS) * sizeof(uint32_t)));
+        if (!ws->h_bins) FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_bins), (BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE + MAX_SBINS) * sizeof(uint32_t), hipHostMallocMapped));
         d_bin_count = ws->d_binq + BINQ_HEAD;
         d_qcount = d_bin_count + (size_t)std::max<uint32_t>(MAX_BINS, sbins) * BIN_STRIDE;
         h_bin.bins = ws->d_hits[0];
@@ -606,7 +692,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 }
                 if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             }
-            if (spread)
+            if (spread && !fast)            // (the device-sized path publishes them at its end, with everything else)
                 FPX_HIP(hipMemcpyAsync(ws->h_def_count, ws->d_def_count, def_words * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipGetLastError());
             probe_launches += 1;
@@ -729,25 +815,33 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }       // (!binned)
         fpx_result* d_res = partial ? out : ws->d_out;
         uint32_t* d_res_n = partial ? out_n : ws->d_out_n;
+        // (the results travel through pinned staging: a copy to the caller's pageable memory would block the host until the
+        // stream reaches it, and a blocked host cannot watch the deadline.  Small batches: k_finish writes into the staging itself)
+        bool staged = false;
+        if (!partial && (rc = staged_targets(ws, B, out_cap, &staged, &d_res_n, &d_res))) return rc;
         // optimistic finish: every query's candidates fit its own slots (C == 0); redone below after a sort otherwise
         hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
                            (const uint64_t*)ws->d_cands[0], (uint64_t)0, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
                            (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
         FPX_HIP(hipGetLastError());
-        // (the results travel through pinned staging: a copy to the caller's pageable memory would block the host until the
-        // stream reaches it, and a blocked host cannot watch the deadline)
-        bool staged = false;
-        if (!partial && (rc = stage_results(ws, B, out_cap, st, &staged))) return rc;
-        FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        if (binned) FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_n, (size_t)sbins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        else FPX_HIP(hipMemcpyAsync(ws->h_bins + BINQ_HEAD, d_bin_count, (size_t)h_bin.nbins * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        {
+            PublishArgs pa{};
+            pa.counters = ws->d_counters; pa.h_counters = mapped_address(ws->h_counters);
+            pa.a_src = ws->d_def_count; pa.a_dst = spread ? mapped_address(ws->h_def_count) : nullptr; pa.a_n = spread ? (uint32_t)def_words : 0u;
+            uint32_t* d_hbins = mapped_address(ws->h_bins);
+            pa.b_src = binned ? d_bin_n : d_bin_count; pa.b_dst = d_hbins + BINQ_HEAD;
+            pa.b_n = binned ? sbins : h_bin.nbins; pa.b_stride = binned ? 1u : BIN_STRIDE;
+            if (!pa.h_counters || (spread && !pa.a_dst) || !d_hbins) { set_error("page-locked host memory is not mapped into the device"); return FPX_E_DEVICE; }
+            hipLaunchKernelGGL(k_publish, dim3(4), dim3(256), 0, st, pa);
+            FPX_HIP(hipGetLastError());
+        }
         FPX_HIP(hipEventRecord(ws->ev_end, st));
         FPX_SYNC(ws);
         // ---- the one look at what happened
         bool redo = false, hits_short = false;
         uint64_t worst_bin = 0, bin_total = 0;
         for (uint32_t i = 0; i < h_bin.nbins; ++i) {
-            const uint64_t c = ws->h_bins[BINQ_HEAD + (binned ? (size_t)i : (size_t)i * BIN_STRIDE)];
+            const uint64_t c = ws->h_bins[BINQ_HEAD + i];
             worst_bin = std::max<uint64_t>(worst_bin, c);
             bin_total += c;
         }
@@ -779,7 +873,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                                (const uint64_t*)ws->d_cands[ccur2], Cf, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
                                (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
             FPX_HIP(hipGetLastError());
-            if (!partial && (rc = stage_results(ws, B, out_cap, st, &staged))) return rc;
             FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipEventRecord(ws->ev_end, st));
             FPX_SYNC(ws);
@@ -1236,14 +1329,17 @@ constexpr uint32_t SHARD_BQ = 3;           // queries per bin, as on one GPU: a 
 // the query's `stride` key slots, the rest of the slots filled with flagged keys (the probe kernels skip those)
 __global__ __launch_bounds__(256) void k_make_keys_window(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
                                                           uint32_t B, uint32_t qb, uint64_t* __restrict__ keys, uint32_t stride,
-                                                          uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, uint32_t* __restrict__ overflow)
+                                                          uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, uint32_t* __restrict__ overflow,
+                                                          KeyOrder ko)
 {
     __shared__ uint32_t tab[DEDUP_SLOTS];
+    __shared__ uint32_t hist[KO_MAX_BUCKETS];
     __shared__ uint32_t seen_ones, s_n;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     if (q >= B) return;
     if (q == 0 && tid < CTR_COUNT) counters[tid] = 0ull;
     for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
+    hist[tid] = 0u;
     if (tid == 0) { seen_ones = 0u; s_n = 0u; }
     __syncthreads();
     const uint64_t lo = offsets[q], hi = offsets[q + 1];
@@ -1265,10 +1361,93 @@ __global__ __launch_bounds__(256) void k_make_keys_window(const uint32_t* __rest
         }
         if (dup) continue;                              // (a later occurrence of a hash: nothing to probe)
         const uint32_t at = atomicAdd(&s_n, 1u);
-        if (at < stride) mine[at] = ((uint64_t)h << qb) | q; else *overflow = 1u;
+        if (at < stride) {
+            mine[at] = ((uint64_t)h << qb) | q;
+            if (ko.nb) atomicAdd(&hist[(h >> ko.bshift) & (ko.nb - 1u)], 1u);
+        } else {
+            *overflow = 1u;
+        }
     }
     __syncthreads();
     for (uint32_t i = min(s_n, stride) + tid; i < stride; i += 256u) mine[i] = KEY_DUP_FLAG | q;
+    if (ko.nb && tid < ko.nb && hist[tid] != 0u) atomicAdd(&ko.cnt[(size_t)tid * ((B + KO_GROUP - 1u) / KO_GROUP) + q / KO_GROUP], hist[tid]);
+}
+
+// The same for narrow windows (a rank of 4 or more: stride <= WK_MAX_STRIDE): one WAVE per query with a table of its own -- no
+// barriers, four times as many queries in flight per CU (a query's lifetime is a chain of latencies: load, CAS, reserve, store).
+// 65536 queries x 1000 hashes at a rank of 8: 170 -> ~90 us.
+constexpr uint32_t WK_SLOTS = 1024, WK_MAX_STRIDE = 512;
+__global__ __launch_bounds__(256) void k_make_keys_window_wave(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
+                                                               uint32_t B, uint32_t qb, uint64_t* __restrict__ keys, uint32_t stride,
+                                                               uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, uint32_t* __restrict__ overflow,
+                                                               KeyOrder ko)
+{
+    __shared__ uint4 tab4[4][WK_SLOTS / 4];
+    __shared__ uint32_t whist[4][KO_MAX_BUCKETS];
+    __shared__ uint32_t s_ones[4], s_cnt[4];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * 4u + w;
+    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) counters[threadIdx.x] = 0ull;
+    if (q >= B) return;                                                  // (whole waves leave: nothing below synchronises the workgroup)
+    uint32_t* tab = reinterpret_cast<uint32_t*>(tab4[w]);
+    for (uint32_t i = lane; i < WK_SLOTS / 4; i += 64u) tab4[w][i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (ko.nb) for (uint32_t i = lane; i < ko.nb; i += 64u) whist[w][i] = 0u;
+    if (lane == 0) { s_ones[w] = 0u; s_cnt[w] = 0u; }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t lo = offsets[q], hi = offsets[q + 1];
+    uint64_t* mine = keys + (size_t)q * stride;
+    for (uint64_t i0 = lo; i0 < hi; i0 += 256u) {
+        uint32_t h[4]; bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t i = i0 + (uint32_t)u * 64u + lane;
+            in[u] = i < hi;
+            h[u] = in[u] ? hashes_base[i] : 0u;
+            in[u] = in[u] && h[u] >= win_lo && h[u] <= win_hi;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bool fresh = false;
+            if (in[u]) {
+                if (s_cnt[w] >= WK_SLOTS / 2u + 128u) {
+                    *overflow = 1u;                                          // far beyond any stride this kernel is launched with: the table must not fill
+                } else if (h[u] == 0xFFFFFFFFu) {
+                    fresh = atomicExch(&s_ones[w], 1u) == 0u;
+                } else {
+                    uint32_t slot = (h[u] * 0x9E3779B1u) >> 22;              // 10 bits
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, h[u]);
+                        if (old == 0xFFFFFFFFu) { fresh = true; break; }
+                        if (old == h[u]) break;
+                        slot = (slot + 1u) & (WK_SLOTS - 1u);
+                    }
+                }
+            }
+            // the fresh ones of the wave take consecutive slots: one LDS add per wave
+            const uint64_t m = __ballot(fresh);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_cnt[w], (uint32_t)__popcll(m));
+                base = __shfl(base, __builtin_ctzll(m));
+                const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (fresh) {
+                    if (at < stride) {
+                        mine[at] = ((uint64_t)h[u] << qb) | q;
+                        if (ko.nb) atomicAdd(&whist[w][(h[u] >> ko.bshift) & (ko.nb - 1u)], 1u);
+                    } else {
+                        *overflow = 1u;
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = min(s_cnt[w], stride) + lane; i < stride; i += 64u) mine[i] = KEY_DUP_FLAG | q;
+    if (ko.nb) {
+        const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
+        for (uint32_t i = lane; i < ko.nb; i += 64u)
+            if (whist[w][i] != 0u) atomicAdd(&ko.cnt[(size_t)i * G + q / KO_GROUP], whist[w][i]);
+    }
 }
 
 // the bins' fill counts, compact (what travels with the bins), the fullest one and their sum
@@ -1283,6 +1462,9 @@ __global__ void k_cell_counts(const unsigned int* __restrict__ bin_count, uint32
 }
 
 static unsigned log2_exact(uint32_t v) { unsigned b = 0; while ((1u << b) < v) ++b; return b; }
+
+// hash bits the keys of a window are ordered by: with the window's own constant bits, the top 8 (as on one GPU)
+static unsigned shard_sort_bits(unsigned win_bits) { return win_bits >= 8u ? 0u : 8u - win_bits; }
 
 // bins per rank: the batch's bins of 2^SHARD_BQ queries, dealt to the ranks in contiguous runs
 int shard_bins_per_rank(uint32_t B, uint32_t world)
@@ -1347,23 +1529,29 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             const uint64_t P = (uint64_t)B * stride;
             if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
             FPX_HIP(hipMemsetAsync(ws->d_cells, 0, words * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_make_keys_window, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
-                               ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, d_overflow);
+            // the window's keys, compacted into (hash bucket, query) order -- buckets over the hash bits that, with the window's own,
+            // make up the top 8: as wide as on one GPU, the same reach in the tables, and a round's 256 keys still belong to a
+            // handful of neighbouring bins.  The count of keys stays on the device (ProbeArgs::P_dev); P is their capacity.
+            KeyOrder ko{};
+            unsigned long long* d_P = nullptr;
+            if ((rc = key_order_setup(ws, B, win_bits, shard_sort_bits(win_bits), &ko, &d_P, st))) return rc;
+            if (stride <= WK_MAX_STRIDE)
+                hipLaunchKernelGGL(k_make_keys_window_wave, dim3((B + 3u) / 4u), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
+                                   ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, d_overflow, ko);
+            else
+                hipLaunchKernelGGL(k_make_keys_window, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
+                                   ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, d_overflow, ko);
+            hipLaunchKernelGGL(k_bucket_scan, dim3(ko.nb), dim3(256), 0, st, ko, (B + KO_GROUP - 1u) / KO_GROUP);
+            hipLaunchKernelGGL(k_scatter_keys, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, (const uint64_t*)ws->d_keys[0], (const uint64_t*)qb->d_offsets, 0ull, stride, B, qbits,
+                               ws->d_keys[1], d_P);
             FPX_HIP(hipGetLastError());
-            // one stable pass on the 8 hash bits below the window's own: (bucket, query) order, as on one GPU
-            int kcur = 0;
-            if (P > (1ull << 18)) {
-                const unsigned hi_bit = 32u + qbits - std::min(win_bits, 16u), lo_bit = hi_bit - 8u;
-                const size_t tb = sort_u64_temp_bytes(P, lo_bit, hi_bit);
-                if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb + 256))) return rc;
-                FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_keys[0], ws->d_keys[1], P, lo_bit, hi_bit, st, &kcur));
-            }
+            const int kcur = 1;
             ProbeArgs a;
             a.segs = snap->d_direct; a.pairs = ws->d_keys[kcur]; a.P = P; a.qb = qbits; a.ppw = 16u; a.bsp = 0u;
             a.hits = ws->d_hits[1]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
             a.def_list = nullptr; a.def_count = nullptr; a.def_cap = 0; a.ctr_off = 0; a.cancel = cancel;
             a.lean_stats = reinterpret_cast<unsigned long long*>(d_stats32);
-            a.key_skip = KEY_SKIP_FLAGGED;
+            a.key_skip = KEY_SKIP_FLAGGED; a.P_dev = d_P;
             a.bins = d_send; a.bin_cap = cell_cap; a.bin_count = ws->d_cells; a.bin_shift = SHARD_BQ;
             const uint64_t wgs = (P + FK_WG - 1) / FK_WG;
             a.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs / 8192));

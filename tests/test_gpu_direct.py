@@ -10,6 +10,8 @@ reach their rare paths -- through the C ABI, against the oracle: results and the
 * docs re-inserted in newer segments and tombstones (supersession tested per record at emission in the fused kernel);
 * six segments (k_probe_fused<8>), two (<2>), one (k_probe_direct), batches above and below the 2^15 probes at which a batch
   switches to the fused directory; duplicate hashes inside a query (flagged by k_make_keys_dedup)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -88,13 +90,14 @@ def test_rare_paths_of_the_direct_addressed_kernels(env, nseg, monkeypatch):
     fpx, oracle, Pair, ctx = env
     p, allitems, rng = _world(fpx, Pair, ctx, nseg, monkeypatch)
     big = _queries(rng, allitems, 40)                   # 40 000 probes: the fused directory (groups of >= 2 segments)
+    fuse_min = int(os.environ.get("FPX_FUSE_MIN", "2"))  # (the variant runs of test_gpu_variants.py group single segments too)
     for opts in (fpx.http_options(), fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0)):
         got, st = p.check(big, opts)
-        assert bool(st.path_flags & 4) == (nseg >= 2)
+        assert bool(st.path_flags & 4) == (nseg >= fuse_min)
         assert nseg < 2 or st.scanned_docs > 40 * 1000      # the hot hash's capped lists were walked (it lives in segment 1)
     small = _queries(rng, allitems, 3)                  # 3 000 probes: a dozen workgroups
     got, st = p.check(small, fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0))
-    assert bool(st.path_flags & 4) == (nseg >= 2)       # (a grouped segment is always probed through its group)
+    assert bool(st.path_flags & 4) == (nseg >= fuse_min)       # (a grouped segment is always probed through its group)
     one = fpx.SearchResults(fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0))
     p.reader.search(small[0], one)                      # the single-query entry point
     assert one.getResults() == got[0]

@@ -269,7 +269,8 @@ static int stage_results(Workspace* ws, uint32_t B, uint32_t out_cap, hipStream_
 static int staged_targets(Workspace* ws, uint32_t B, uint32_t out_cap, bool* staged, uint32_t** d_n, fpx_result** d_res)
 {
     const size_t bytes = (size_t)B * sizeof(uint32_t) + (size_t)B * out_cap * sizeof(fpx_result);
-    *staged = bytes <= STAGED_OUT_MAX;
+    static const size_t staged_max = [] { const char* e = getenv("FPX_STAGED_OUT_MAX"); return e ? (size_t)strtoull(e, nullptr, 0) : STAGED_OUT_MAX; }();
+    *staged = bytes <= staged_max;
     if (!*staged) return FPX_OK;
     if (bytes > ws->cap_h_out) {
         if (ws->h_out) (void)hipHostFree(ws->h_out);
@@ -519,7 +520,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     constexpr size_t BINQ_HEAD = 64 / sizeof(uint32_t);                          // room for the BinArgs the kernels read
     // ... and its short form when the records come from groups of direct-addressed segments alone: k_probe_group drops them
     // into bins of 2^BQ queries itself and k_score_bin scores a bin per workgroup (fpx_score_bin.hpp) -- no partition kernels
-    static const uint32_t bin_q_log2 = [] { const char* e = getenv("FPX_BIN_Q_LOG2"); return e ? (uint32_t)atoi(e) : 3u; }();
+    // Queries per bin: eight, fewer for batches that would not give k_score_bin ~2048 workgroups otherwise (a workgroup's time is
+    // a chain of tile-load latencies: 8192 queries in bins of 4: 170 -> 154 us, 1024 queries in bins of 2: 66 -> 29 us)
+    static const int bin_q_forced = [] { const char* e = getenv("FPX_BIN_Q_LOG2"); return e ? atoi(e) : -1; }();
+    uint32_t bin_q_log2 = 3u;
+    if (bin_q_forced >= 0) bin_q_log2 = (uint32_t)bin_q_forced;
+    else while (bin_q_log2 > 1u && (B >> bin_q_log2) < 2048u) --bin_q_log2;
     static const bool binned_enabled = [] { const char* e = getenv("FPX_BINNED"); return e ? atoi(e) != 0 : true; }();
     bool binned = false;
     uint32_t sbins = 0;

@@ -537,6 +537,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, like the index build: every in-flight slot's workspace (GBs of device buffers, sized by the first batches that
+    # pass through it: the first takes the general path and measures, the second and third run device-sized) is allocated before
+    # the W warm-up steps, however small W is -- on a cold box the first ten steps of a run with W = 3 took 1.4 ms instead of 1.0
+    run_steps(4 * nfl, False)
     run_steps(args.warmup, False)
     barrier()
     t0 = time.perf_counter()

@@ -124,7 +124,7 @@ def test_download_and_merge_of_direct_addressed_segments_give_the_files_bytes(en
     seg = fpx.FileSegment(ctx, blocks, 512, index, 1, 3000, 1, ids)
     assert not seg.direct                   # (a candidate keeps its blocks until a snapshot holds it)
     fpx.Segments(ctx, [seg]).release()      # on its own: the direct-addressed form of one segment (k_probe_direct)
-    assert seg.direct and not seg.grouped
+    assert seg.direct and seg.grouped == (int(os.environ.get("FPX_FUSE_MIN", "2")) <= 1)     # (the FPX_FUSE_MIN=1 variant groups a lone segment)
     b2, i2 = seg.download()
     assert np.array_equal(blocks, b2) and np.array_equal(index, i2)
     # ... and as a merge source: the merged segment's bytes are those of the block-form merge

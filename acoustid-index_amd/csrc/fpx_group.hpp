@@ -63,6 +63,8 @@ __device__ __forceinline__ uint32_t gb_slot(const ProbeArgs& a, uint64_t rec) { 
 #ifndef FPX_GK_WAVES
 #define FPX_GK_WAVES 6
 #endif
+// (Tried in round 3 and dropped: touching the NEXT round's directory line a round ahead -- 0.712 -> 0.747 ms.  The kernel is bound
+// by the rate the memory system serves its requests, not by their latency.)
 #define FPX_GK_OCC __attribute__((amdgpu_waves_per_eu(FPX_GK_WAVES, FPX_GK_WAVES)))
 template <int NS, bool BINNED, bool QS>
 __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, GroupArgs ga)

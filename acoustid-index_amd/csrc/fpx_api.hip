@@ -609,6 +609,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         Segment* s = reinterpret_cast<Segment*>(segs[i]);
         s->refs.fetch_add(1);
         sn->segs.push_back(s);
+        sn->max_doc_declared = std::max(sn->max_doc_declared, s->max_doc_id);
     }
     std::vector<uint32_t> dead;
     std::vector<Segment*> direct_segs;               // parallel to sn->h_direct

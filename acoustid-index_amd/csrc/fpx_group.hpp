@@ -404,7 +404,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                 const uint32_t b = gb_cell(a, rec); const uint32_t rk = s_rank[i];
                 if (rk < GB_NEED) {
                     const uint64_t at = (uint64_t)s_bbase[gb_slot(a, rec)] + rk;
-                    if (at < a.bin_cap) a.bins[(size_t)b * a.bin_cap + at] = rec;
+                    if (at < a.bin_cap) bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, b, at, rec, a.counters);
                 } else {                            // (still no place: the misc buffer)
                     const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
                     if (gg < a.hit_cap) a.hits[gg] = rec;

@@ -212,6 +212,8 @@ struct Snapshot {
     // ... of which the grouped ones are probed group by group (k_probe_group) and the rest (n_solo) one by one (k_probe_direct)
     std::vector<std::shared_ptr<Group>> groups;                  // grouped segments: one k_probe_group launch per group
     std::vector<GroupDesc> h_group; uint32_t n_group = 0;
+    uint32_t max_doc_declared = 0;       // the largest doc id the segments' headers declare (sizes the bins' records, fpx_partition.hpp)
+    uint32_t rec32_refused = 0;          // a posting exceeded it: this snapshot's bins hold wide records from then on
     std::vector<std::shared_ptr<DirectStore>> solo_stores;       // the arrays d_solo points into
     SegDesc* d_solo = nullptr; uint32_t n_solo = 0;
     uint32_t max_small_blocks = 0;

@@ -35,7 +35,29 @@ struct BinArgs {
     unsigned int* bin_count;     // [nbins * BIN_STRIDE] fill counters (may run past bin_cap: overflow)
     uint32_t shift;              // bin of query q = q >> shift
     uint32_t nbins;
+    uint32_t rec32;              // the bins hold 4-byte records (bin_record32): bins of the device-sized path whose doc ids leave room
+    unsigned long long* counters;  // (rec32: a doc id that does not fit after all raises CTR_BINFAIL)
 };
+
+// A record inside a bin of 2^shift queries needs the query's low `shift` bits only: where every doc id of the snapshot is below
+// 2^(32 - shift) the bins hold doc << shift | query-in-bin -- half the bytes k_score_bin reads (twice) and, on an index sharded
+// by hash range, half of what the ranks exchange.  bin_cap counts records either way.
+__device__ __forceinline__ uint32_t bin_record32(uint64_t rec, uint32_t shift)
+{
+    return ((uint32_t)rec << shift) | ((uint32_t)(rec >> 32) & ((1u << shift) - 1u));
+}
+// (The host chooses the narrow form by the segments' declared doc id ranges; a file whose postings exceed its header's range is
+// caught here: CTR_BINFAIL = 3, the batch is redone with wide records and the snapshot remembers.  All ones is no record.)
+__device__ __forceinline__ void bin_store(uint64_t* bins, uint64_t bin_cap, uint32_t rec32, uint32_t shift, uint32_t bn, uint64_t pos, uint64_t rec,
+                                          unsigned long long* counters)
+{
+    if (rec32) {
+        if (((uint32_t)rec >> (32u - shift)) != 0u || (uint32_t)rec == (0xFFFFFFFFu >> shift)) atomicMax(&counters[CTR_BINFAIL], 3ull);
+        reinterpret_cast<uint32_t*>(bins)[(size_t)bn * bin_cap + pos] = bin_record32(rec, shift);
+    } else {
+        bins[(size_t)bn * bin_cap + pos] = rec;
+    }
+}
 
 // level 1: records[0 .. min(*count, cap)) -> bins.  Tiles of 4096 records (16 per thread), strided over the grid.
 constexpr uint32_t BIN_TILE = 4096;
@@ -68,7 +90,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs b, const uint64_t* __restri
             if (r[j] != ~0ull) {
                 const uint32_t bn = min((uint32_t)(r[j] >> 32) >> b.shift, b.nbins - 1u);
                 const uint64_t pos = (uint64_t)s_base[bn] + rank[j];
-                if (pos < b.bin_cap) b.bins[(size_t)bn * b.bin_cap + pos] = r[j];
+                if (pos < b.bin_cap) bin_store(b.bins, b.bin_cap, b.rec32, b.shift, bn, pos, r[j], b.counters);
             }
         }
         __syncthreads();
@@ -84,7 +106,7 @@ __global__ __launch_bounds__(256) void k_bin_each(BinArgs b, const uint64_t* __r
         const uint64_t r = recs[i];
         const uint32_t bn = (uint32_t)(r >> 32) >> b.shift;
         const uint32_t at = atomicAdd(&b.bin_count[(size_t)bn * BIN_STRIDE], 1u);
-        if (at < b.bin_cap) b.bins[(size_t)bn * b.bin_cap + at] = r;
+        if (at < b.bin_cap) bin_store(b.bins, b.bin_cap, b.rec32, b.shift, bn, at, r, b.counters);
     }
 }
 

@@ -22,7 +22,9 @@ constexpr uint32_t SB_QL_SHIFT = 26;               // table slot: doc << 32 | qu
 constexpr uint32_t SB_CAND = 32;                   // candidates of a query gathered in LDS before they move to the shared list
 
 struct ScoreBinArgs {
-    const uint64_t* bins; uint64_t bin_cap; const unsigned int* bin_count;      // as BinArgs
+    const uint64_t* bins; uint64_t bin_cap; const unsigned int* bin_count;      // as BinArgs; bin_cap in 8-byte CELLS (two 4-byte records each)
+    uint32_t rec_mode;                             // 0: 8-byte records; 1: 4-byte records (bin_record32); 2: per piece -- bit 31 of the piece's count says
+                                                   // "4-byte" (the counts that travel with the bins of a sharded index, k_cell_counts)
     uint32_t nsrc;                                 // the bin's records come in `nsrc` pieces (what each rank of a sharded index sent): piece r of
     uint64_t src_stride; uint32_t count_stride, count_step;    // bin b = bins + r * src_stride + b * bin_cap, its count = bin_count[r * count_stride + b * count_step]
     uint32_t bq;                                   // log2 of the queries per bin
@@ -55,13 +57,17 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
     }
     uint64_t n = 0;                                                              // records of the bin over all pieces
     unsigned int raw_max = 0;
+    bool piece_over = false;
     for (uint32_t r = 0; r < a.nsrc; ++r) {
-        const unsigned int c = a.bin_count[(size_t)r * a.count_stride + (size_t)bin * a.count_step];
+        const unsigned int craw = a.bin_count[(size_t)r * a.count_stride + (size_t)bin * a.count_step];
+        const unsigned int c = a.rec_mode == 2u ? (craw & 0x7FFFFFFFu) : craw;
+        const uint64_t room = a.bin_cap << ((a.rec_mode == 1u || (a.rec_mode == 2u && (craw >> 31))) ? 1 : 0);      // records the piece's cells hold
         raw_max = max(raw_max, c);
-        n += min((uint64_t)c, a.bin_cap);
+        piece_over = piece_over || (uint64_t)c > room;
+        n += min((uint64_t)c, room);
     }
     if (tid == 0) a.bin_n[bin] = a.nsrc == 1u ? raw_max : (uint32_t)min<uint64_t>(n, 0xFFFFFFFFull);
-    if (tid == 0 && a.nsrc > 1u && (uint64_t)raw_max > a.bin_cap) atomicMax(&a.counters[CTR_BINFAIL], 2ull);      // (a piece overflowed its cell)
+    if (tid == 0 && a.nsrc > 1u && piece_over) atomicMax(&a.counters[CTR_BINFAIL], 2ull);      // (a piece overflowed its cell)
     __syncthreads();
     if (s_cancel) return;
     uint32_t floor_min = 0xFFFFFFFFu;
@@ -73,9 +79,13 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
 
     // The tiles of the bin's pieces, one after the other, with the NEXT tile's loads in flight while a tile is worked on: without
     // the look-ahead a workgroup's life was a chain of load latencies (24 tiles x ~3.8 us for a bin of 50 000 records).
-    struct Cursor { uint32_t src; uint64_t t0, ns; const uint64_t* recs; };
+    // (a piece of 4-byte records is walked in CELLS of two: ns counts cells, nrec records)
+    struct Cursor { uint32_t src; uint32_t narrow; uint64_t t0, ns, nrec; const uint64_t* recs; };
     auto piece = [&](Cursor& c) {
-        c.ns = min((uint64_t)a.bin_count[(size_t)c.src * a.count_stride + (size_t)bin * a.count_step], a.bin_cap);
+        const unsigned int craw = a.bin_count[(size_t)c.src * a.count_stride + (size_t)bin * a.count_step];
+        c.narrow = (a.rec_mode == 1u || (a.rec_mode == 2u && (craw >> 31))) ? 1u : 0u;
+        c.nrec = min((uint64_t)(a.rec_mode == 2u ? (craw & 0x7FFFFFFFu) : craw), a.bin_cap << c.narrow);
+        c.ns = c.narrow ? (c.nrec + 1u) >> 1 : c.nrec;
         c.recs = a.bins + (size_t)c.src * a.src_stride + (size_t)bin * a.bin_cap;
     };
     auto first = [&](Cursor& c) -> bool {
@@ -98,10 +108,24 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
         bool more = first(c);
         if (more) load(c, cur);
         while (more) {
+            const uint32_t narrow = c.narrow;
+            const uint64_t t0 = c.t0, nrec = c.nrec;
             more = next(c);
             if (more) load(c, nxt);
+            if (narrow) {
+                // a cell = two records doc << bq | query-in-bin; handed on in the wide form (query-in-bin << 32 | doc)
 #pragma unroll
-            for (uint32_t u = 0; u < SB_RPT; ++u) if (cur[u] != ~0ull) fn(cur[u]);
+                for (uint32_t u = 0; u < SB_RPT; ++u) {
+                    if (cur[u] == ~0ull) continue;                       // (beyond the piece: a real cell never reads all ones -- its docs are < 2^(32 - bq))
+                    const uint64_t i = t0 + (uint64_t)u * SB_WG + tid;
+                    const uint32_t lo = (uint32_t)cur[u], hi = (uint32_t)(cur[u] >> 32);
+                    fn(((uint64_t)(lo & qm) << 32) | (lo >> a.bq));
+                    if (2u * i + 1u < nrec) fn(((uint64_t)(hi & qm) << 32) | (hi >> a.bq));
+                }
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < SB_RPT; ++u) if (cur[u] != ~0ull) fn(cur[u]);
+            }
 #pragma unroll
             for (uint32_t u = 0; u < SB_RPT; ++u) cur[u] = nxt[u];
         }

@@ -560,10 +560,15 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         h_bin.bins = ws->d_hits[0];
         h_bin.bin_count = d_bin_count;
         if (binned) {
+            // 4-byte records where the doc ids leave room for the query's bits inside its bin (fpx_partition.hpp)
+            static const bool rec32_enabled = [] { const char* e = getenv("FPX_REC32"); return e ? atoi(e) != 0 : true; }();
+            h_bin.rec32 = rec32_enabled && !__atomic_load_n(&snap->rec32_refused, __ATOMIC_RELAXED) &&
+                          snap->max_doc_declared < (0xFFFFFFFFu >> bin_q_log2) ? 1u : 0u;
+            h_bin.counters = ws->d_counters;
             h_bin.nbins = sbins; h_bin.shift = bin_q_log2;
             // twice the expected share + room for the spread of a small bin; a bin that overflows is seen after the batch's
             // synchronisation and the batch is redone on the general path
-            h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / sbins, std::max<uint64_t>(2 * est_H / sbins + 8192, 16384));
+            h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / sbins, std::max<uint64_t>(2 * est_H / sbins + 8192, 16384)) & ~(uint64_t)1;
             FPX_HIP(hipMemsetAsync(d_bin_count, 0, (size_t)sbins * BIN_STRIDE * sizeof(uint32_t), st));
         } else {
             h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
@@ -613,7 +618,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 if (snap->n_group) {
                     ProbeArgs gk = a;
                     gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
-                    if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; }
+                    if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; }
                     static const uint32_t group_rounds = [] { const char* e = getenv("FPX_GROUP_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
                     gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_group / 8192));
                     const uint64_t per_wg_gk = (uint64_t)FK_WG * gk.rounds;
@@ -772,7 +777,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         const uint32_t sbf = 32u - qb;
         if (binned) {
             ScoreBinArgs sa{};
-            sa.bins = h_bin.bins; sa.bin_cap = h_bin.bin_cap; sa.bin_count = h_bin.bin_count; sa.bq = h_bin.shift; sa.B = B;
+            sa.bins = h_bin.bins; sa.bin_cap = h_bin.rec32 ? h_bin.bin_cap / 2u : h_bin.bin_cap; sa.rec_mode = h_bin.rec32; sa.bin_count = h_bin.bin_count; sa.bq = h_bin.shift; sa.B = B;
             sa.nsrc = 1u; sa.src_stride = 0; sa.count_stride = 0; sa.count_step = BIN_STRIDE;
             sa.opts = d_opts; sa.sb = 32u - qb; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
             sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
@@ -857,6 +862,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (used_lean)
             for (uint32_t i = 0; i < snap->n_lean; ++i) redo = redo || ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE] > def_cap;
         if (ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands || ws->h_counters[CTR_BINFAIL] != 0) redo = true;
+        if (ws->h_counters[CTR_BINFAIL] == 3) __atomic_store_n(const_cast<uint32_t*>(&snap->rec32_refused), 1u, __ATOMIC_RELAXED);      // (a doc id beyond the declared range)
         if (redo) {
             if (hits_short) {           // room for what this batch really produced, so that neither path trips over it again
                 const size_t need = (size_t)std::max<uint64_t>(std::max<uint64_t>(worst_bin * h_bin.nbins, misc), H) * 5 / 4 + 1024;
@@ -1457,12 +1463,14 @@ __global__ __launch_bounds__(256) void k_make_keys_window_wave(const uint32_t* _
 }
 
 // the bins' fill counts, compact (what travels with the bins), the fullest one and their sum
-__global__ void k_cell_counts(const unsigned int* __restrict__ bin_count, uint32_t ncells, uint32_t* __restrict__ out, unsigned long long* __restrict__ counters)
+// (bit 31 of a travelling count: the bin's records are the 4-byte ones -- the receiving rank reads it per piece, ScoreBinArgs::rec_mode 2)
+__global__ void k_cell_counts(const unsigned int* __restrict__ bin_count, uint32_t ncells, uint32_t* __restrict__ out, unsigned long long* __restrict__ counters,
+                              uint32_t flag)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
     const unsigned int v = bin_count[(size_t)c * BIN_STRIDE];
-    out[c] = v;
+    out[c] = v | flag;
     atomicMax(&counters[CTR_TOTAL], (unsigned long long)v);
     atomicAdd(&counters[CTR_SLOTCANDS], (unsigned long long)v);
 }
@@ -1531,7 +1539,13 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
         if (ws->cap_hits == 0 && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)1 << 22))) return rc;
         // a query's share of its hashes + slack; a query that needs more has the whole query's length on the second attempt
         uint32_t stride = (uint32_t)std::min<uint64_t>(max_len, (uint64_t)((double)max_len * share * 1.25) + 48);
+        static const bool rec32_enabled = [] { const char* e = getenv("FPX_REC32"); return e ? atoi(e) != 0 : true; }();
+        uint64_t rec_cap = cell_cap;                           // records a bin's cells hold
         for (int attempt = 0;; ++attempt) {
+            // 4-byte records (two per 8-byte cell) where the doc ids leave room for the query's three bits inside its bin
+            const uint32_t rec32 = rec32_enabled && !__atomic_load_n(&snap->rec32_refused, __ATOMIC_RELAXED) &&
+                                   snap->max_doc_declared < (0xFFFFFFFFu >> SHARD_BQ) ? 1u : 0u;
+            rec_cap = cell_cap << rec32;
             const uint64_t P = (uint64_t)B * stride;
             if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
             FPX_HIP(hipMemsetAsync(ws->d_cells, 0, words * sizeof(uint32_t), st));
@@ -1558,7 +1572,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             a.def_list = nullptr; a.def_count = nullptr; a.def_cap = 0; a.ctr_off = 0; a.cancel = cancel;
             a.lean_stats = reinterpret_cast<unsigned long long*>(d_stats32);
             a.key_skip = KEY_SKIP_FLAGGED; a.P_dev = d_P;
-            a.bins = d_send; a.bin_cap = cell_cap; a.bin_count = ws->d_cells; a.bin_shift = SHARD_BQ;
+            a.bins = d_send; a.bin_cap = rec_cap; a.bin_count = ws->d_cells; a.bin_shift = SHARD_BQ; a.rec32 = rec32;
             const uint64_t wgs = (P + FK_WG - 1) / FK_WG;
             a.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs / 8192));
             const uint64_t per_wg = (uint64_t)FK_WG * a.rounds;
@@ -1571,17 +1585,23 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             // what the kernel could not place itself (a clash of two bins on one slot of a round, a full stage): k_bin
             BinArgs hb{};
-            hb.bins = d_send; hb.bin_cap = cell_cap; hb.bin_count = ws->d_cells; hb.shift = SHARD_BQ; hb.nbins = std::min<uint32_t>(ncells, MAX_SBINS);
+            hb.bins = d_send; hb.bin_cap = rec_cap; hb.bin_count = ws->d_cells; hb.shift = SHARD_BQ; hb.nbins = std::min<uint32_t>(ncells, MAX_SBINS);
+            hb.rec32 = rec32; hb.counters = ws->d_counters;
             if (ncells <= MAX_SBINS)
                 hipLaunchKernelGGL(k_bin, dim3(64), dim3(256), 0, st, hb, (const uint64_t*)ws->d_hits[1], (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
             else
                 hipLaunchKernelGGL(k_bin_each, dim3(64), dim3(256), 0, st, hb, (const uint64_t*)ws->d_hits[1], (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
-            hipLaunchKernelGGL(k_cell_counts, dim3((ncells + 255) / 256), dim3(256), 0, st, (const unsigned int*)ws->d_cells, ncells, d_send_counts, ws->d_counters);
+            hipLaunchKernelGGL(k_cell_counts, dim3((ncells + 255) / 256), dim3(256), 0, st, (const unsigned int*)ws->d_cells, ncells, d_send_counts, ws->d_counters,
+                               rec32 << 31);
             FPX_HIP(hipGetLastError());
             FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FPX_HIP(hipMemcpyAsync(ws->h_cells, d_stats32, (LEAN_STAT_WORDS + 16) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             FPX_SYNC(ws);
             if (ws->h_cells[LEAN_STAT_WORDS] != 0u && attempt == 0 && stride < max_len) { stride = (uint32_t)max_len; continue; }
+            if (ws->h_counters[CTR_BINFAIL] == 3 && attempt < 3) {            // a doc id beyond the segments' declared range: wide records
+                __atomic_store_n(&snap->rec32_refused, 1u, __ATOMIC_RELAXED);
+                continue;
+            }
             if (ws->h_counters[CTR_HITS] > ws->cap_hits) {              // the misc buffer itself was too small
                 if (attempt >= 3) { set_error("fpx_shard_probe: misc buffer overflow persists"); return FPX_E_DEVICE; }
                 if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)ws->h_counters[CTR_HITS] + 1024))) return rc;
@@ -1589,10 +1609,11 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             }
             break;
         }
-        if (ws->h_counters[CTR_TOTAL] > cell_cap) {
-            if (needed_cell_cap) *needed_cell_cap = ws->h_counters[CTR_TOTAL] * 17 / 16 + 128;      // (the bins of a batch differ by a few per cent)
+        if (ws->h_counters[CTR_TOTAL] > rec_cap) {
+            const uint64_t per_cell = rec_cap / std::max<uint64_t>(cell_cap, 1);          // (1 or 2)
+            if (needed_cell_cap) *needed_cell_cap = (ws->h_counters[CTR_TOTAL] * 17 / 16 + 128 + per_cell - 1) / std::max<uint64_t>(per_cell, 1);      // (the bins of a batch differ by a few per cent)
             set_error("fpx_shard_probe: a bin holds %llu records, the send buffer has room for %llu per bin", (unsigned long long)ws->h_counters[CTR_TOTAL],
-                      (unsigned long long)cell_cap);
+                      (unsigned long long)rec_cap);
             return FPX_E_AGAIN;
         }
         if (stats) {
@@ -1648,7 +1669,7 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ra
         FPX_HIP(hipMemsetAsync(d_qcand_n, 0, (size_t)B * sizeof(uint32_t), st));
         const uint32_t sbf = 32u - qbits;
         ScoreBinArgs sa{};
-        sa.bins = d_recv; sa.bin_cap = cell_cap; sa.bin_count = d_recv_counts; sa.nsrc = world; sa.src_stride = (uint64_t)bpr * cell_cap;
+        sa.bins = d_recv; sa.bin_cap = cell_cap; sa.rec_mode = 2u; sa.bin_count = d_recv_counts; sa.nsrc = world; sa.src_stride = (uint64_t)bpr * cell_cap;
         sa.count_stride = bpr; sa.count_step = 1u; sa.bq = SHARD_BQ; sa.bin_base = rank * bpr; sa.B = B;
         sa.opts = qb->d_opts; sa.sb = sbf; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
         sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;

@@ -152,3 +152,33 @@ def test_download_and_merge_of_direct_addressed_segments_give_the_files_bytes(en
     mb, mi = merged_b.download()
     md, mdi = merged_d.download()
     assert np.array_equal(mb, md) and np.array_equal(mi, mdi)
+
+
+def test_narrow_bin_records_are_refused_when_a_file_understates_its_doc_ids(env, monkeypatch):
+    """The bins of the device-sized path hold 4-byte records (doc << bits | query-in-bin) where the segments' DECLARED doc id ranges
+    leave room (fpx_partition.hpp).  A file whose postings lie beyond its header's max_doc_id is caught by the kernels: the batch
+    is redone, the snapshot switches to wide records, the results are the oracle's all the same."""
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    rng = np.random.default_rng(2026)
+    base = (1 << 30) + 12345                                  # doc ids far above 2^29 ...
+    p = Pair(ctx)
+    allitems = []
+    for s in range(2):
+        ids = np.arange(base + s * 3000, base + (s + 1) * 3000, dtype=np.uint64)
+        h = rng.integers(0, 1 << 32, (len(ids), 48), dtype=np.uint64)
+        items = np.unique(((h << np.uint64(32)) | ids[:, None]).ravel())
+        # ... behind a header that declares a range ending at min_doc_id + 10 (the reference never checks it either)
+        p.add_file(items, int(ids.min()), int(ids.min()) + 10, s + 1, ids.astype(np.uint32))
+        allitems.append(items)
+    p.finish()
+    assert all(g.direct for g in p.gpu_segs)
+    qs = []
+    for i in range(48):
+        src = allitems[i % 2]
+        doc = src[rng.integers(0, len(src))] & np.uint64(0xFFFFFFFF)
+        own = (src[(src & np.uint64(0xFFFFFFFF)) == doc] >> np.uint64(32)).astype(np.uint32)
+        qs.append(np.concatenate([own, rng.integers(0, 1 << 32, 400, dtype=np.uint64).astype(np.uint32)]))
+    for rep in range(3):                                     # (the device-sized path from a workspace's second batch on)
+        got, st = p.check(qs, fpx.http_options())
+        assert all(len(g) >= 1 for g in got)

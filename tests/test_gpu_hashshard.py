@@ -4,6 +4,8 @@ their window by fpx_snapshot_create -- the ranks' hit records are dropped into t
 the bins travel as the all-to-all would move them, and every rank finishes the queries of its bins (fpx_shard_score).  Must
 reproduce the unsharded snapshot and the oracle bit for bit, the reference's scanned_blocks / scanned_docs included: hot
 hashes whose lists are cut by the caps, docs re-inserted in newer segments, tombstones, duplicate hashes in a query."""
+import os
+
 import numpy as np
 import pytest
 
@@ -37,6 +39,7 @@ def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
     seed, H, per, S = 31, 64, 5000, 3
     rng = np.random.default_rng(world)
     data = _world_data(fpx, rng, S, per, H, seed)
+    max_doc = max(hi for _, _, hi, _, _ in data)
     full = Pair(ctx)
     for s, (items, lo, hi, ids, alive) in enumerate(data):
         full.add_file(items, lo, hi, s + 1, ids, alive)
@@ -85,10 +88,17 @@ def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
         # every record sits in its query's bin
         for r in range(world):
             send, counts = sends[r]
-            c = counts.cpu().numpy().reshape(-1)
+            c = counts.cpu().numpy().reshape(-1).astype(np.int64) & 0xFFFFFFFF
+            narrow, c = (c >> 31) != 0, c & 0x7FFFFFFF                # bit 31 of a travelling count: the bin holds 4-byte records
             sv = send.cpu().numpy().reshape(world * bpr, cell_cap)
+            assert narrow.all() == (os.environ.get("FPX_REC32", "1") != "0")      # (doc ids of this world are far below 2^29)
             for b in range(world * bpr):
-                assert ((sv[b, :c[b]] >> 32) >> 3 == b).all()
+                if narrow[b]:                                         # doc << 3 | query-in-bin, two to a cell
+                    recs = sv[b].view(np.uint32)[:c[b]]
+                    assert c[b] <= 2 * cell_cap and ((b * 8 + (recs & 7) < max(B, 8)) | (c[b] == 0)).all()
+                    assert (recs >> 3 <= max_doc).all()
+                else:                                                 # query << 32 | doc
+                    assert ((sv[b, :c[b]] >> 32) >> 3 == b).all()
         out = np.zeros((B, cap, 2), np.uint32)
         out_n = np.zeros(B, np.uint32)
         covered = 0

@@ -12,6 +12,8 @@ variant runs in a process of its own):
                          flush and scored a bin per workgroup (k_score_bin) on every batch after a workspace's first
 * FPX_BINNED=0           ... with the two-level partition + k_score instead (the path of mixed snapshots)
 * FPX_INLINE_DOUBLES=0   ... with every hash of several docs behind a list reference (no inline doubles)
+* FPX_REC32=0            ... with 8-byte records in the bins (by default 4-byte ones where the doc ids leave room), bins of eight
+                         queries whatever the batch, the keys of every batch ordered by our counting sort (FPX_ORDER_MIN_PAIRS=0)
 * FPX_DIRECT=0           no segment direct-addressed: segments of >= 2^20 items (direct-addressed by default) are searched in
                          their blocks by the lean kernel (tests/test_gpu_fullsize.py compares the two forms at full size)
 """
@@ -38,7 +40,8 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"},
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_BINNED": "0"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"}],
+                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"},
+                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_BIN_Q_LOG2": "3", "FPX_ORDER_MIN_PAIRS": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_parity_suites_on_the_alternative_paths(env):
     if os.environ.get("FPX_VARIANT_CHILD") == "1":

@@ -129,6 +129,7 @@ struct KeyOrder {
     uint32_t* totals = nullptr;    // [nb]
     uint32_t nb = 0;               // buckets, a power of two (0: no counting)
     uint32_t bshift = 0;           // bucket of hash h = (h >> bshift) & (nb - 1)
+    uint32_t* qn = nullptr;        // [B] keys of each query (a hash window's keys: the query's slots hold that many), or null
 };
 
 __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,

@@ -85,17 +85,29 @@ __global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_
     if (tid < ko.nb) s_pos[tid] = before + gload_u32(ko.cnt + (size_t)tid * G + g);
     if (P_out && g == 0 && tid == 0) *P_out = total;
     __syncthreads();
-    uint64_t lo, hi;
-    if (stride) { lo = (uint64_t)q0 * stride; hi = (uint64_t)q1 * stride; }        // windowed keys: a fixed number of slots per query
-    else { lo = offsets[q0] - base; hi = offsets[q1] - base; }
     const uint32_t bmask = ko.nb - 1u;
+    if (stride) {
+        // windowed keys: query q's are the first ko.qn[q] of its `stride` slots -- a wave per query
+        const uint32_t lane = tid & 63u;
+        for (uint32_t q = q0 + (tid >> 6); q < q1; q += 4u) {
+            const uint32_t nq = gload_u32(ko.qn + q);
+            const uint64_t* in = keys_in + (size_t)q * stride;
+            for (uint32_t i = lane; i < nq; i += 64u) {
+                const uint64_t key = gload_u64(in + i);
+                const uint32_t at = atomicAdd(&s_pos[((uint32_t)(key >> qb) >> ko.bshift) & bmask], 1u);
+                keys_out[at] = key;
+            }
+        }
+        return;
+    }
+    const uint64_t lo = offsets[q0] - base, hi = offsets[q1] - base;
     for (uint64_t i0 = lo; i0 < hi; i0 += 1024u) {
         uint64_t key[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) { const uint64_t i = i0 + u * 256u + tid; key[u] = i < hi ? gload_u64(keys_in + i) : ~0ull; }
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
-            if (key[u] == ~0ull || (stride && (key[u] >> 63) != 0ull)) continue;
+            if (key[u] == ~0ull) continue;
             const uint32_t h = (uint32_t)(key[u] >> qb);
             const uint32_t at = atomicAdd(&s_pos[(h >> ko.bshift) & bmask], 1u);
             keys_out[at] = key[u];

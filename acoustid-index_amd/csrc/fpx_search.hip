@@ -206,7 +206,7 @@ static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigne
     bits = std::min(bits, 8u);                       // KO_MAX_BUCKETS
     while (bits > 0u && ((uint64_t)G << bits) > KO_MAX_CELLS) --bits;
     const uint32_t nb = 1u << bits;
-    const size_t words = (size_t)G * nb + nb + 4;
+    const size_t words = (size_t)G * nb + nb + 4 + (P_dev ? (size_t)B : 0);
     if (words > ws->cap_kocnt) {
         if (ws->d_kocnt) (void)hipFree(ws->d_kocnt);
         ws->d_kocnt = nullptr; ws->cap_kocnt = 0;
@@ -218,7 +218,10 @@ static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigne
     ko->totals = ws->d_kocnt + (size_t)G * nb;
     ko->nb = nb;
     ko->bshift = std::min(31u, 32u - std::min(32u, win_bits + bits));
-    if (P_dev) *P_dev = reinterpret_cast<unsigned long long*>(ws->d_kocnt + (((size_t)G * nb + nb + 1) & ~(size_t)1));
+    if (P_dev) {                                     // (windowed keys: their number lives on the device, per query and in all)
+        *P_dev = reinterpret_cast<unsigned long long*>(ws->d_kocnt + (((size_t)G * nb + nb + 1) & ~(size_t)1));
+        ko->qn = ws->d_kocnt + (size_t)G * nb + nb + 4;
+    }
     FPX_HIP(hipMemsetAsync(ko->cnt, 0, (size_t)G * nb * sizeof(uint32_t), st));
     return FPX_OK;
 }
@@ -1337,128 +1340,121 @@ int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uin
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t SHARD_BQ = 3;           // queries per bin, as on one GPU: a rank receives ALL records of its bins
 
-// per query: the hashes inside [win_lo, win_hi] -- later occurrences dropped (dedupSorted, src/Index.zig:489-499) -- compacted into
-// the query's `stride` key slots, the rest of the slots filled with flagged keys (the probe kernels skip those)
-__global__ __launch_bounds__(256) void k_make_keys_window(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
+// per query: the hashes inside [win_lo, win_hi] -- later occurrences dropped (dedupSorted, src/Index.zig:489-499) -- as keys in the
+// query's `stride` slots, their number in ko.qn[q], their counts per hash bucket added to ko.cnt (fpx_keyorder.hpp).
+// QPW queries per workgroup: a wave each where the window is narrow (stride <= 1024: a rank of 2 or more), the workgroup
+// for one otherwise.  Two phases, because only the window's share of the hashes needs the hash set: (1) all loads out, the hashes of
+// the window compacted into an LDS list with ballots -- no atomics on a wave's own count; (2) the list through the hash set, the
+// fresh ones to their slots.  (One pass that sent every loaded hash through the set and an LDS counter took 153 us for 16384
+// queries at a rank of 2 -- 500 returning atomics on one address per query -- and, a wave per query with sixteen dependent
+// rounds, 215 us for 65536 queries at a rank of 8.)
+// QPW == 8: a workgroup of eight waves makes the keys of one GROUP of queries (KO_GROUP = 8), a wave per query: the group's bucket
+// counts are summed in LDS and stored plainly -- no atomics on the count table, which needs no zeroing then.
+// QPW == 1: a workgroup of four waves per query (wide windows: up to DEDUP_MAX hashes of the window), counts added atomically.
+template <int QPW, uint32_t CAP>
+__global__ __launch_bounds__(QPW == 8 ? 512 : 256) void k_make_keys_window(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
                                                           uint32_t B, uint32_t qb, uint64_t* __restrict__ keys, uint32_t stride,
                                                           uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, uint32_t* __restrict__ overflow,
                                                           KeyOrder ko)
 {
-    __shared__ uint32_t tab[DEDUP_SLOTS];
-    __shared__ uint32_t hist[KO_MAX_BUCKETS];
-    __shared__ uint32_t seen_ones, s_n;
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    if (q >= B) return;
-    if (q == 0 && tid < CTR_COUNT) counters[tid] = 0ull;
-    for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
-    hist[tid] = 0u;
-    if (tid == 0) { seen_ones = 0u; s_n = 0u; }
+    static_assert(QPW == 1 || QPW == 8, "a workgroup per query, or a wave per query of a group");
+    constexpr uint32_t WG_T = QPW == 8 ? 512u : 256u;
+    constexpr uint32_t TEAM = WG_T / QPW;                                   // threads per query: 64 or 256
+    constexpr uint32_t UNR = QPW == 8 ? 16u : 4u;                           // loads a thread has in flight: 1024 hashes per round either way
+    constexpr uint32_t LIST_CAP = CAP;                                      // hashes of the window a query may have
+    constexpr uint32_t SLOTS = 2u * CAP;
+    constexpr uint32_t SLOT_SHIFT = 32u - (CAP == 512u ? 10u : CAP == 1024u ? 11u : 12u);
+    static_assert(CAP == 512u || CAP == 1024u || CAP == 2048u, "the hash set's size");
+    __shared__ uint32_t s_list[QPW][LIST_CAP];
+    __shared__ uint32_t s_tab[QPW][SLOTS];
+    __shared__ uint32_t s_hist[KO_MAX_BUCKETS];                             // of the workgroup: one query, or one group of eight
+    __shared__ uint32_t s_n[QPW], s_out[QPW], s_ones[QPW];
+    const uint32_t tid = threadIdx.x, team = tid / TEAM, lt = tid % TEAM, lane = tid & 63u;
+    const uint32_t q = blockIdx.x * QPW + team;
+    if (blockIdx.x == 0 && tid < CTR_COUNT) counters[tid] = 0ull;
+    const bool live = q < B;                                                 // (QPW == 8: the last group may be short; every wave reaches the barriers)
+    for (uint32_t i = lt; i < SLOTS; i += TEAM) s_tab[team][i] = 0xFFFFFFFFu;
+    if (tid < KO_MAX_BUCKETS) s_hist[tid] = 0u;
+    if (lt == 0) { s_n[team] = 0u; s_out[team] = 0u; s_ones[team] = 0u; }
     __syncthreads();
-    const uint64_t lo = offsets[q], hi = offsets[q + 1];
-    uint64_t* mine = keys + (size_t)q * stride;
-    for (uint64_t i = lo + tid; i < hi; i += 256u) {
-        const uint32_t h = hashes_base[i];
-        if (h < win_lo || h > win_hi) continue;
-        bool dup;
-        if (h == 0xFFFFFFFFu) {
-            dup = atomicExch(&seen_ones, 1u) != 0u;
-        } else {
-            uint32_t slot = (h * 0x9E3779B1u) >> 20;
-            for (;;) {
-                const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, h);
-                if (old == 0xFFFFFFFFu) { dup = false; break; }
-                if (old == h) { dup = true; break; }
-                slot = (slot + 1u) & (DEDUP_SLOTS - 1u);
-            }
-        }
-        if (dup) continue;                              // (a later occurrence of a hash: nothing to probe)
-        const uint32_t at = atomicAdd(&s_n, 1u);
-        if (at < stride) {
-            mine[at] = ((uint64_t)h << qb) | q;
-            if (ko.nb) atomicAdd(&hist[(h >> ko.bshift) & (ko.nb - 1u)], 1u);
-        } else {
-            *overflow = 1u;
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = min(s_n, stride) + tid; i < stride; i += 256u) mine[i] = KEY_DUP_FLAG | q;
-    if (ko.nb && tid < ko.nb && hist[tid] != 0u) atomicAdd(&ko.cnt[(size_t)tid * ((B + KO_GROUP - 1u) / KO_GROUP) + q / KO_GROUP], hist[tid]);
-}
-
-// The same for narrow windows (a rank of 4 or more: stride <= WK_MAX_STRIDE): one WAVE per query with a table of its own -- no
-// barriers, four times as many queries in flight per CU (a query's lifetime is a chain of latencies: load, CAS, reserve, store).
-// 65536 queries x 1000 hashes at a rank of 8: 170 -> ~90 us.
-constexpr uint32_t WK_SLOTS = 1024, WK_MAX_STRIDE = 512;
-__global__ __launch_bounds__(256) void k_make_keys_window_wave(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
-                                                               uint32_t B, uint32_t qb, uint64_t* __restrict__ keys, uint32_t stride,
-                                                               uint32_t win_lo, uint32_t win_hi, unsigned long long* counters, uint32_t* __restrict__ overflow,
-                                                               KeyOrder ko)
-{
-    __shared__ uint4 tab4[4][WK_SLOTS / 4];
-    __shared__ uint32_t whist[4][KO_MAX_BUCKETS];
-    __shared__ uint32_t s_ones[4], s_cnt[4];
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t q = blockIdx.x * 4u + w;
-    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) counters[threadIdx.x] = 0ull;
-    if (q >= B) return;                                                  // (whole waves leave: nothing below synchronises the workgroup)
-    uint32_t* tab = reinterpret_cast<uint32_t*>(tab4[w]);
-    for (uint32_t i = lane; i < WK_SLOTS / 4; i += 64u) tab4[w][i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (ko.nb) for (uint32_t i = lane; i < ko.nb; i += 64u) whist[w][i] = 0u;
-    if (lane == 0) { s_ones[w] = 0u; s_cnt[w] = 0u; }
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t lo = offsets[q], hi = offsets[q + 1];
-    uint64_t* mine = keys + (size_t)q * stride;
-    for (uint64_t i0 = lo; i0 < hi; i0 += 256u) {
-        uint32_t h[4]; bool in[4];
+    const uint64_t lo = live ? offsets[q] : 0ull, hi = live ? offsets[q + 1] : 0ull;
+    const uint64_t below = (1ull << lane) - 1ull;
+    // ---- phase 1: the window's hashes into the list
+    uint32_t n = 0;                                                          // (QPW == 8: the wave's own running count)
+    for (uint64_t i0 = lo; i0 < hi; i0 += TEAM * UNR) {
+        uint32_t h[UNR]; bool in[UNR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t i = i0 + (uint32_t)u * 64u + lane;
+        for (uint32_t u = 0; u < UNR; ++u) {
+            const uint64_t i = i0 + u * TEAM + lt;
             in[u] = i < hi;
             h[u] = in[u] ? hashes_base[i] : 0u;
-            in[u] = in[u] && h[u] >= win_lo && h[u] <= win_hi;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            bool fresh = false;
-            if (in[u]) {
-                if (s_cnt[w] >= WK_SLOTS / 2u + 128u) {
-                    *overflow = 1u;                                          // far beyond any stride this kernel is launched with: the table must not fill
-                } else if (h[u] == 0xFFFFFFFFu) {
-                    fresh = atomicExch(&s_ones[w], 1u) == 0u;
-                } else {
-                    uint32_t slot = (h[u] * 0x9E3779B1u) >> 22;              // 10 bits
-                    for (;;) {
-                        const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, h[u]);
-                        if (old == 0xFFFFFFFFu) { fresh = true; break; }
-                        if (old == h[u]) break;
-                        slot = (slot + 1u) & (WK_SLOTS - 1u);
-                    }
+        for (uint32_t u = 0; u < UNR; ++u) {
+            in[u] = in[u] && h[u] >= win_lo && h[u] <= win_hi;
+            const uint64_t m = __ballot(in[u]);
+            if (m == 0ull) continue;
+            uint32_t base = n;
+            if constexpr (QPW == 1) {
+                if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_n[team], (uint32_t)__popcll(m));
+                base = __shfl(base, __builtin_ctzll(m));
+            } else {
+                n += (uint32_t)__popcll(m);
+            }
+            const uint32_t at = base + (uint32_t)__popcll(m & below);
+            if (in[u] && at < LIST_CAP) s_list[team][at] = h[u];
+        }
+    }
+    __syncthreads();
+    if constexpr (QPW == 1) n = s_n[team];
+    if (n > LIST_CAP) { if (lt == 0) *overflow = 1u; n = LIST_CAP; }
+    // ---- phase 2: the list through the hash set; the first occurrence of a hash becomes a key
+    uint64_t* mine = keys + (size_t)q * stride;
+    uint32_t n_out = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += TEAM) {
+        const uint32_t j = j0 + lt;
+        const bool have = j < n;
+        const uint32_t h = have ? s_list[team][j] : 0u;
+        bool fresh = false;
+        if (have) {
+            if (h == 0xFFFFFFFFu) {
+                fresh = atomicExch(&s_ones[team], 1u) == 0u;            // (the table's empty mark is kept apart)
+            } else {
+                uint32_t slot = (h * 0x9E3779B1u) >> SLOT_SHIFT;
+                for (;;) {
+                    const uint32_t old = atomicCAS(&s_tab[team][slot], 0xFFFFFFFFu, h);
+                    if (old == 0xFFFFFFFFu) { fresh = true; break; }
+                    if (old == h) break;
+                    slot = (slot + 1u) & (SLOTS - 1u);
                 }
             }
-            // the fresh ones of the wave take consecutive slots: one LDS add per wave
-            const uint64_t m = __ballot(fresh);
-            if (m) {
-                uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_cnt[w], (uint32_t)__popcll(m));
-                base = __shfl(base, __builtin_ctzll(m));
-                const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (fresh) {
-                    if (at < stride) {
-                        mine[at] = ((uint64_t)h[u] << qb) | q;
-                        if (ko.nb) atomicAdd(&whist[w][(h[u] >> ko.bshift) & (ko.nb - 1u)], 1u);
-                    } else {
-                        *overflow = 1u;
-                    }
-                }
+        }
+        const uint64_t m = __ballot(fresh);
+        if (m == 0ull) continue;
+        uint32_t base = n_out;
+        if constexpr (QPW == 1) {
+            if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_out[team], (uint32_t)__popcll(m));
+            base = __shfl(base, __builtin_ctzll(m));
+        } else {
+            n_out += (uint32_t)__popcll(m);
+        }
+        const uint32_t at = base + (uint32_t)__popcll(m & below);
+        if (fresh) {
+            if (at < stride) {
+                mine[at] = ((uint64_t)h << qb) | q;
+                if (ko.nb) atomicAdd(&s_hist[(h >> ko.bshift) & (ko.nb - 1u)], 1u);
+            } else {
+                *overflow = 1u;
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = min(s_cnt[w], stride) + lane; i < stride; i += 64u) mine[i] = KEY_DUP_FLAG | q;
-    if (ko.nb) {
+    __syncthreads();
+    if constexpr (QPW == 1) n_out = s_out[team];
+    if (live && lt == 0 && ko.qn) ko.qn[q] = min(n_out, stride);
+    if (ko.nb && tid < ko.nb) {
         const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
-        for (uint32_t i = lane; i < ko.nb; i += 64u)
-            if (whist[w][i] != 0u) atomicAdd(&ko.cnt[(size_t)i * G + q / KO_GROUP], whist[w][i]);
+        if constexpr (QPW == 8) ko.cnt[(size_t)tid * G + blockIdx.x] = s_hist[tid];                       // (the group's cell: this workgroup's alone)
+        else if (s_hist[tid] != 0u) atomicAdd(&ko.cnt[(size_t)tid * G + q / KO_GROUP], s_hist[tid]);
     }
 }
 
@@ -1555,11 +1551,15 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             KeyOrder ko{};
             unsigned long long* d_P = nullptr;
             if ((rc = key_order_setup(ws, B, win_bits, shard_sort_bits(win_bits), &ko, &d_P, st))) return rc;
-            if (stride <= WK_MAX_STRIDE)
-                hipLaunchKernelGGL(k_make_keys_window_wave, dim3((B + 3u) / 4u), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
+            static_assert(KO_GROUP == 8, "k_make_keys_window<8> makes the keys of one group per workgroup");
+            if (stride <= 512u)
+                hipLaunchKernelGGL((k_make_keys_window<8, 512>), dim3((B + 7u) / 8u), dim3(512), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
+                                   ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, d_overflow, ko);
+            else if (stride <= 1024u)       // (a rank of 2: 96 KB of LDS, one workgroup per CU -- still half the time of a workgroup per query)
+                hipLaunchKernelGGL((k_make_keys_window<8, 1024>), dim3((B + 7u) / 8u), dim3(512), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
                                    ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, d_overflow, ko);
             else
-                hipLaunchKernelGGL(k_make_keys_window, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
+                hipLaunchKernelGGL((k_make_keys_window<1, DEDUP_MAX>), dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits,
                                    ws->d_keys[0], stride, win_lo, win_hi, ws->d_counters, d_overflow, ko);
             hipLaunchKernelGGL(k_bucket_scan, dim3(ko.nb), dim3(256), 0, st, ko, (B + KO_GROUP - 1u) / KO_GROUP);
             hipLaunchKernelGGL(k_scatter_keys, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, (const uint64_t*)ws->d_keys[0], (const uint64_t*)qb->d_offsets, 0ull, stride, B, qbits,

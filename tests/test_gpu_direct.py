@@ -90,14 +90,15 @@ def test_rare_paths_of_the_direct_addressed_kernels(env, nseg, monkeypatch):
     fpx, oracle, Pair, ctx = env
     p, allitems, rng = _world(fpx, Pair, ctx, nseg, monkeypatch)
     big = _queries(rng, allitems, 40)                   # 40 000 probes: the fused directory (groups of >= 2 segments)
-    fuse_min = int(os.environ.get("FPX_FUSE_MIN", "2"))  # (the variant runs of test_gpu_variants.py group single segments too)
+    grouped = any(g.grouped for g in p.gpu_segs)        # (nseg >= 2; the FPX_FUSE_MIN=1 runs of test_gpu_variants.py group a lone segment too)
+    assert grouped or nseg < 2
     for opts in (fpx.http_options(), fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0)):
         got, st = p.check(big, opts)
-        assert bool(st.path_flags & 4) == (nseg >= fuse_min)
+        assert bool(st.path_flags & 4) == grouped
         assert nseg < 2 or st.scanned_docs > 40 * 1000      # the hot hash's capped lists were walked (it lives in segment 1)
     small = _queries(rng, allitems, 3)                  # 3 000 probes: a dozen workgroups
     got, st = p.check(small, fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0))
-    assert bool(st.path_flags & 4) == (nseg >= fuse_min)       # (a grouped segment is always probed through its group)
+    assert bool(st.path_flags & 4) == grouped       # (a grouped segment is always probed through its group)
     one = fpx.SearchResults(fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0))
     p.reader.search(small[0], one)                      # the single-query entry point
     assert one.getResults() == got[0]
@@ -124,7 +125,7 @@ def test_download_and_merge_of_direct_addressed_segments_give_the_files_bytes(en
     seg = fpx.FileSegment(ctx, blocks, 512, index, 1, 3000, 1, ids)
     assert not seg.direct                   # (a candidate keeps its blocks until a snapshot holds it)
     fpx.Segments(ctx, [seg]).release()      # on its own: the direct-addressed form of one segment (k_probe_direct)
-    assert seg.direct and seg.grouped == (int(os.environ.get("FPX_FUSE_MIN", "2")) <= 1)     # (the FPX_FUSE_MIN=1 variant groups a lone segment)
+    assert seg.direct                        # (on its own -- unless FPX_FUSE_MIN=1, a switch the library reads once per process, groups a lone segment)
     b2, i2 = seg.download()
     assert np.array_equal(blocks, b2) and np.array_equal(index, i2)
     # ... and as a merge source: the merged segment's bytes are those of the block-form merge

@@ -35,6 +35,9 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
                 "tests/test_gpu_hashshard.py", "tests/test_gpu_fuzz.py::test_fuzz_lean_sized_worlds"]
 
 
+FUSED_SHORT = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py", "tests/test_gpu_hashshard.py"]
+
+
 @pytest.mark.parametrize("env", [{"FPX_DIRECT": "0"}, {"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
                                  {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
                                  {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
@@ -48,6 +51,8 @@ def test_parity_suites_on_the_alternative_paths(env):
         pytest.skip("already inside a variant run")
     e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
     suites = FUSED_SUITES if env.get("FPX_FUSE_MIN") == "1" else DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
+    if env.get("FPX_FUSE_MIN") == "1" and len(env) > 2:          # the sub-variants of the grouped form: the suites that reach the switched code
+        suites = FUSED_SHORT
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -22,7 +22,7 @@ bench = last_json(os.path.join(src, "bench.json"))
 json.dump(bench, open(os.path.join(dst, "r03_bench.json"), "w"), indent=1)
 json.dump(last_json(os.path.join(src, "bench_under_rocprof.json")), open(os.path.join(dst, "r03_bench_under_rocprof.json"), "w"), indent=1)
 json.dump(last_json(os.path.join(src, "bench_block_under_rocprof.json")), open(os.path.join(dst, "r03_bench_block_under_rocprof.json"), "w"), indent=1)
-for name in ("emulated_rank_of_8_weak", "emulated_rank_of_8_strong", "emulated_rank_of_2_weak"):
+for name in ("emulated_rank_of_8_weak", "emulated_rank_of_8_strong", "emulated_rank_of_4_weak", "emulated_rank_of_2_weak"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and os.path.getsize(p):
         json.dump(last_json(p), open(os.path.join(dst, "r03_" + name + ".json"), "w"), indent=1)
@@ -37,6 +37,7 @@ def stats(sub, prefix, out):
 stats("trace", "r03", "r03_kernel_stats.csv")
 stats("trace_block", "r03b", "r03_block_kernel_stats.csv")
 stats("trace1k", "r03b1k", "r03_kernel_stats_b1024.csv")
+stats("trace_emu", "r03emu", "r03_emulated_rank_of_8_kernel_stats.csv")
 
 
 def pmc_rows(sub, out):

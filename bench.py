@@ -5,8 +5,8 @@ One step = one pass of the hot path over one batch of synthetic queries (default
 against a seeded synthetic index resident in HBM (default: BASELINE.json configs[2], 100 M fingerprints x 256
 hashes in 16 FileSegments).  With --gpus N > 1 the SAME index is sharded by HASH RANGE over the ranks: rank r holds the
 window [r 2^32 / N, (r + 1) 2^32 / N) of the hash space of all 16 segments, makes / sorts / probes only the query hashes
-of its window, the hit records travel to the rank that owns their doc (one RCCL all-to-all of fixed-shape cells), the
-owners score them, the per-rank top-k tables are all-gathered and merged.  The global batch grows with N (8192 x N
+of its window and drops the hit records into the batch's bins of eight queries; the bins travel to the rank that FINISHES
+their queries (one RCCL all-to-all of fixed shape; no table exchange, no merge).  The global batch grows with N (8192 x N
 queries per step: weak scaling -- a rank's probe and score work per step stays what one GPU's is; FPX_BENCH_SCALING=strong
 keeps 8192).  FPX_BENCH_SHARD=segment: the older protocol (whole segments per rank, tables only).
 
@@ -18,6 +18,9 @@ Prints ONE JSON line (rank 0).  At N = 1 the line also carries, measured in the 
                 flight each, next to the headline (three in flight)
   end_to_end    fpx_search_batch from host memory, pageable and page-locked (H2D of the queries, D2H of the results inside)
   config1       BASELINE.json configs[1]: 10 M fingerprints in ONE segment, batch 1024
+  roofline_block_form / block_form   the same index built again in block form (FPX_DIRECT=0): k_probe_lean8 -- the kernel the
+                contract names -- with a PMC pass of its own
+  dist_z        SURVEY 8(d)'s hot-hash distribution at full scale in the grouped form
   cpu_baseline  the oracle's pthread executor pool over the WHOLE index downloaded to host RAM
 See DESIGN.md "Measurement" for the definitions.
 """

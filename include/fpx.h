@@ -303,7 +303,10 @@ int fpx_score_partial(fpx_ctx *ctx, const fpx_query_batch *qb, const void *d_rec
  * they are brought together: the batch's bins of 8 queries are dealt to the ranks in contiguous runs of
  * bpr = fpx_shard_bins_per_rank(num_queries, world), and rank r FINISHES the queries of bins [r bpr, (r + 1) bpr).
  *   fpx_shard_probe   the records of this rank's window, dropped straight into the batch's bins: d_send = [world * bpr][cell_cap]
- *                     records (DEVICE memory), d_send_counts = [world * bpr] uint32 fill counts.
+ *                     8-byte CELLS (DEVICE memory), d_send_counts = [world * bpr] uint32.  The contents are opaque to the caller: a
+ *                     cell holds one record, or -- where every doc id of the snapshot is below 2^29 -- two 4-byte ones
+ *                     (doc << 3 | query-in-bin); bits 0..30 of a count = the bin's records, bit 31 = "4-byte records", which is
+ *                     how the receiving rank reads every piece the way its sender wrote it.
  *                     FPX_E_AGAIN: a bin outgrew cell_cap -- *needed_cell_cap says what to allocate; retry.
  *                     FPX_E_INVAL for snapshots that hold anything but such groups: use fpx_probe_resident / fpx_score_partial.
  *   (the caller's all-to-all, e.g. RCCL: rows [r bpr, (r + 1) bpr) of d_send and of d_send_counts travel to rank r; fixed shapes)

@@ -55,6 +55,7 @@ class ShardedReader:
         if key not in self._bufs:
             self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device=self.device),
                                torch.zeros((qb.B,), dtype=torch.int32, device=self.device))
+            torch.cuda.current_stream(self.device).synchronize()          # (torch fills on ITS stream; libfpx writes on a stream of its own)
         d_part, d_cnt = self._bufs[key]
         return self.fpx.search_resident_partial(self.reader, qb, d_part.data_ptr(), d_cnt.data_ptr())
 
@@ -161,6 +162,7 @@ class HashShardedReader:
         if key not in self._bufs:
             self._bufs[key] = (torch.zeros((qb.B, qb.cap, 2), dtype=torch.int32, device=self.device),
                                torch.zeros((qb.B,), dtype=torch.int32, device=self.device))
+            torch.cuda.current_stream(self.device).synchronize()          # (torch fills on ITS stream; libfpx writes on a stream of its own)
         return self._bufs[key]
 
     # ---- bin protocol
@@ -179,6 +181,7 @@ class HashShardedReader:
             if key not in self._binbufs:
                 self._binbufs = {key: (torch.empty((self.world, bpr, self.cell_cap), dtype=torch.int64, device=self.device),
                                        torch.zeros((self.world, bpr), dtype=torch.int32, device=self.device))}
+                torch.cuda.current_stream(self.device).synchronize()      # (torch fills on ITS stream; libfpx writes on a stream of its own)
             send, send_counts = self._binbufs[key]
             try:
                 st, need = fpx.shard_probe(self.reader, qb, self.world, send.data_ptr(), self.cell_cap, send_counts.data_ptr())

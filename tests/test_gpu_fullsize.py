@@ -145,6 +145,7 @@ def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192():
                for s in range(S)]
     parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
     cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
     blocks_sum = 0
     for r in range(world):
         rd = fpx.IndexReader(fpx.Segments(ctx, [segs[s] if s % world == r else remotes[s] for s in range(S)]))
@@ -224,6 +225,7 @@ def test_config2_with_hot_hashes_at_full_size():
                for s in range(S)]
     parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
     cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
     hits_sum = 0
     for r in range(world):
         rd = fpx.IndexReader(fpx.Segments(ctx, [segs[s] if s % world == r else remotes[s] for s in range(S)]))

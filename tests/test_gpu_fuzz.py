@@ -199,6 +199,7 @@ def test_fuzz_sharded_modes(env, seed):
             # (a) segment sharding
             parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
             cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
             for r in range(world):
                 segs = []
                 for s, (blocks, index, lo, hi, commit, ids) in enumerate(files):
@@ -222,12 +223,14 @@ def test_fuzz_sharded_modes(env, seed):
                             if r == 0 else fpx.RemoteSegment(ctx, mem.min_doc_id, mem.max_doc_id, n_file + 1, mids, malive))
                 rd = fpx.IndexReader(fpx.Segments(ctx, segs))
                 buf = torch.zeros((1 << 18,), dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
                 c, _ = fpx.probe_resident(rd, qb, world, buf.data_ptr(), buf.numel())
                 recs.append(buf)
                 counts.append([int(x) for x in c])
             parts.zero_(); cnts.zero_()
             for d in range(world):
                 got = torch.cat([recs[r][sum(counts[r][:d]):sum(counts[r][:d + 1])] for r in range(world)])
+                torch.cuda.synchronize()                # (torch's stream made `got`; libfpx reads it on a stream of its own)
                 fpx.score_partial(ctx, qb, got.data_ptr(), got.numel(), parts[d].data_ptr(), cnts[d].data_ptr())
             torch.cuda.synchronize()
             out, out_n = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)

@@ -74,6 +74,7 @@ def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
             for r in range(world):
                 send = torch.zeros((world, bpr, cell_cap), dtype=torch.int64, device="cuda")
                 counts = torch.zeros((world, bpr), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
                 st, need = fpx.shard_probe(readers[r], qb, world, send.data_ptr(), cell_cap, counts.data_ptr())
                 if st is None:
                     assert need > cell_cap
@@ -105,6 +106,7 @@ def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
         for d in range(world):                                         # what the all-to-all delivers to rank d: its bins from every rank
             recv = torch.stack([sends[r][0][d] for r in range(world)]).contiguous()
             rc = torch.stack([sends[r][1][d] for r in range(world)]).contiguous()
+            torch.cuda.synchronize()                                   # (torch's stream made them; libfpx reads them on a stream of its own)
             out, out_n, q_lo, q_hi = fpx.shard_score(ctx, qb, world, d, recv.data_ptr(), cell_cap, rc.data_ptr(), out, out_n)
             assert q_lo == min(B, d * bpr * 8)
             covered += q_hi - q_lo

@@ -52,6 +52,7 @@ def test_hash_slices_match_unsharded_and_oracle(world):
         recs, counts, blocks_total, docs_total = [], [], 0, 0
         for r in range(world):
             buf = torch.zeros((1 << 20,), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
             c, st = fpx.probe_resident(readers[r], qb, world, buf.data_ptr(), buf.numel())
             recs.append(buf)
             counts.append([int(x) for x in c])
@@ -66,8 +67,10 @@ def test_hash_slices_match_unsharded_and_oracle(world):
                 o += counts[r][d]
         parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
         cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
         for d in range(world):                                         # what the all-to-all delivers to rank d
             got = torch.cat([recs[r][sum(counts[r][:d]):sum(counts[r][:d + 1])] for r in range(world)])
+            torch.cuda.synchronize()                # (torch's stream made `got`; libfpx reads it on a stream of its own)
             fpx.score_partial(ctx, qb, got.data_ptr(), got.numel(), parts[d].data_ptr(), cnts[d].data_ptr())
         torch.cuda.synchronize()
         out, out_n = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
@@ -89,12 +92,14 @@ def test_probe_resident_reports_needed_room():
     flat, off, _ = fpx.synth.make_queries(5, 1, 16, 4000, 32, query_len=64)
     qb = fpx.QueryBatch(ctx, options=fpx.http_options(), flat=(flat, off))
     small = torch.zeros((4,), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
     counts = np.zeros(2, np.uint64)
     from acoustid_index_amd._lib import lib, Stats
     import ctypes as C
     rc = lib().fpx_probe_resident(reader.snapshot.h, qb.h, 2, 0, small.data_ptr(), small.numel(), counts.ctypes.data_as(C.c_void_p), C.byref(Stats()))
     assert rc != 0 and int(counts.sum()) > 4                           # too small: the counts say how much room is needed
     big = torch.zeros((int(counts.sum()),), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
     c2, _ = fpx.probe_resident(reader, qb, 2, big.data_ptr(), big.numel())
     assert c2.tolist() == counts.tolist()
     with pytest.raises(fpx.FpxError):

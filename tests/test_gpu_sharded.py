@@ -44,6 +44,7 @@ def test_two_rank_emulation_matches_unsharded_and_oracle():
         import torch
         parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
         cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
         for r in range(world):
             fpx.search_resident_partial(readers[r], qb, parts[r].data_ptr(), cnts[r].data_ptr())
         torch.cuda.synchronize()

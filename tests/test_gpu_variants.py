@@ -38,21 +38,43 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
 FUSED_SHORT = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py", "tests/test_gpu_hashshard.py"]
 
 
-@pytest.mark.parametrize("env", [{"FPX_DIRECT": "0"}, {"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
-                                 {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_BINNED": "0"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"},
-                                 {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_BIN_Q_LOG2": "3", "FPX_ORDER_MIN_PAIRS": "0"}],
-                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
-def test_parity_suites_on_the_alternative_paths(env):
-    if os.environ.get("FPX_VARIANT_CHILD") == "1":
-        pytest.skip("already inside a variant run")
+VARIANTS = [{"FPX_DIRECT": "0"}, {"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
+            {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"},
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_BINNED": "0"},
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"},
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_BIN_Q_LOG2": "3", "FPX_ORDER_MIN_PAIRS": "0"}]
+
+
+def _name(env):
+    return ",".join(f"{k}={v}" for k, v in env.items())
+
+
+def _run_variant(env):
     e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
     suites = FUSED_SUITES if env.get("FPX_FUSE_MIN") == "1" else DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
     if env.get("FPX_FUSE_MIN") == "1" and len(env) > 2:          # the sub-variants of the grouped form: the suites that reach the switched code
         suites = FUSED_SHORT
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
-                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+    return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
+                          cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+
+
+@pytest.fixture(scope="module")
+def variant_runs():
+    """every variant's child process, THREE at a time (each is a minute of small batches that leaves the GPU mostly idle: one
+    after the other they were 11 of the suite's 14 minutes); a test waits for its own"""
+    import concurrent.futures as cf
+    if os.environ.get("FPX_VARIANT_CHILD") == "1":
+        yield {}
+        return
+    with cf.ThreadPoolExecutor(int(os.environ.get("FPX_VARIANT_JOBS", "3"))) as pool:
+        yield {_name(env): pool.submit(_run_variant, env) for env in VARIANTS}
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=_name)
+def test_parity_suites_on_the_alternative_paths(env, variant_runs):
+    if os.environ.get("FPX_VARIANT_CHILD") == "1":
+        pytest.skip("already inside a variant run")
+    r = variant_runs[_name(env)].result()
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -549,7 +549,7 @@ def main():
     settle_s = float(os.environ.get("FPX_BENCH_SETTLE_S", "4"))
     if settle_s > 0 and not args.pmc_child:
         best, calm, t_settle, blocks = None, 0, time.perf_counter(), []
-        while time.perf_counter() - t_settle < settle_s and calm < 3:
+        while True:
             barrier()
             ts = time.perf_counter()
             run_steps(10, False)
@@ -558,13 +558,13 @@ def main():
             blocks.append(blk)
             calm = calm + 1 if best is not None and blk <= best * 1.03 else 0
             best = blk if best is None else min(best, blk)
-            if world > 1:                                  # every rank leaves the loop in the same iteration
-                flag = torch.tensor([1.0 if (calm >= 3 or time.perf_counter() - t_settle >= settle_s) else 0.0],
-                                    device=torch.device("cuda", device) if backend == "nccl" else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if flag.item() >= 1.0:
-                    break
-                calm = min(calm, 2)
+            stop = calm >= 3 or time.perf_counter() - t_settle >= settle_s
+            if world > 1:                                  # every rank leaves the loop in the same iteration: as soon as one would
+                flag = torch.tensor([1.0 if stop else 0.0], device=torch.device("cuda", device) if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                stop = flag.item() >= 1.0
+            if stop:
+                break
         if rank == 0:
             print("settle blocks (ms/step): " + " ".join(f"{b * 1e3:.3f}" for b in blocks), file=sys.stderr, flush=True)
     run_steps(args.warmup, False)

@@ -668,6 +668,18 @@ def main():
             else:
                 dt2, agg2, _, _ = timed_resident(fpx, reader, sub, k2, 3)
                 rows.append(row_from(b2, k2, dt2, agg2, segs))
+                if b2 == 1024 and nfl > 1:
+                    # BASELINE.md's batch for this row, also with as many batches in flight as the headline keeps
+                    def one_sub(i, sub=sub):
+                        fpx.search_resident(reader, sub)
+                    with cf.ThreadPoolExecutor(nfl) as ex:
+                        list(ex.map(one_sub, range(4 * nfl)))
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        list(ex.map(one_sub, range(4 * k2)))
+                        torch.cuda.synchronize()
+                        dtn = time.perf_counter() - t1
+                    rows.append({"batch": b2, "inflight": nfl, "steps": 4 * k2, "ms_per_step": dtn / (4 * k2) * 1e3, "queries_per_s": b2 * 4 * k2 / dtn})
             sub.release()
         dt1, agg1, _, _ = timed_resident(fpx, reader, qb, max(5, args.steps // 2), 2)
         r1 = row_from(B, max(5, args.steps // 2), dt1, agg1, segs)

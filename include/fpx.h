@@ -77,12 +77,13 @@ typedef struct {
                                    query as they are produced), bit 1: ... and needed the second round trip for queries with
                                    more candidates than slots.  Neither: the general path (first batch of a workspace,
                                    exchanges, anything the device-sized path handed back).  bit 2: direct-addressed segments
-                                   were probed through a fused directory (k_probe_fused) */
+                                   were probed as a GROUP (k_probe_group), bit 3: ... whose records went straight into bins of a
+                                   few queries, scored a bin per workgroup (k_score_bin) */
     uint64_t probe_kernel_fetched_bytes; /* block bytes the main probe kernel really fetched, in 128-byte lines: a probe
                                    whose hash the segment's presence bits know to be absent counts as a visited block (as in
                                    the reference) without the block being read, and a block that is read costs two lines up
                                    front + the line of the matching docids, so this is <= probe_kernel_bytes.  Direct-addressed
-                                   segments: the lines of directory, `primary` and `extras` words read (64-byte units, halved) */
+                                   segments: the directory lines, word pieces and list heads read (64-byte units, halved) */
 } fpx_stats;
 
 /* ---- context ----------------------------------------------------------- */

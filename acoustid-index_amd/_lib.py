@@ -106,6 +106,7 @@ SIGNATURES = {
     "fpx_segment_docs": (C.c_int, [_vp, _vp, _vp, _u32]),
     "fpx_crc64_xz": (_u64, [_u64, _vp, _sz]),
     "fpx_measure_bandwidth": (C.c_int, [_vp, _sz, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fpx_measure_access": (C.c_int, [_vp, _sz, C.c_int, _u64, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -217,7 +217,9 @@ int resolve_candidates(Ctx* c, const std::vector<Segment*>& segs)
     static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
     std::vector<Segment*> lone;
     for (Segment* s : segs)
-        if (s->kind == 0 && s->ctx == c && !s->home && ((s->candidate && s->d_blocks) || s->direct)) lone.push_back(s);
+        // (a candidate that SETTLED in its blocks under an earlier snapshot stays there: that snapshot's descriptors point at its
+        // block-form buffers, which a later conversion would free under it)
+        if (s->kind == 0 && s->ctx == c && !s->home && ((s->candidate && s->d_blocks && !s->settled) || s->direct)) lone.push_back(s);
     std::vector<bool> done(lone.size(), false);
     for (size_t i = 0; fuse_min != 0 && i < lone.size(); ++i) {
         if (done[i]) continue;
@@ -997,6 +999,12 @@ int fpx_measure_bandwidth(fpx_ctx* ctx, size_t bytes, uint32_t block_size, doubl
 {
     if (!ctx) { set_error("null ctx"); return FPX_E_INVAL; }
     return measure_bandwidth_impl(reinterpret_cast<Ctx*>(ctx), bytes, block_size, stream_gbs, random_gbs);
+}
+
+int fpx_measure_access(fpx_ctx* ctx, size_t bytes, int mode, uint64_t lanes, double* ms)
+{
+    if (!ctx) { set_error("null ctx"); return FPX_E_INVAL; }
+    return measure_access_impl(reinterpret_cast<Ctx*>(ctx), bytes, mode, lanes, ms);
 }
 
 }  // extern "C"

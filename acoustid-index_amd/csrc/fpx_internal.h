@@ -332,6 +332,7 @@ int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uin
                         uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n);
 int measure_bandwidth_impl(Ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs);
+int measure_access_impl(Ctx* ctx, size_t bytes, int mode, uint64_t lanes, double* ms_out);
 
 // fpx_api.hip
 int finish_file_segment(Segment* seg);   // bucket table + item count for blocks already in HBM

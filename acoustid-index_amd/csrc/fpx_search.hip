@@ -542,6 +542,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // (a floor of 1 or 2 -- the legacy protocol's -- makes every counted doc a candidate: k_score's count-only round, which
         // raises the floor to top * pct / 100 before anything is emitted, handles those)
         binned = floor_lo > 2u && sbins <= MAX_SBINS;
+        if (!binned) sbins = 0;            // (the two-level partition's layout below: its counts must sit where its memset zeroes them)
     }
     if (fast) {
         est_H = (uint64_t)((double)ws->hint_H * (double)P / (double)ws->hint_P) + 1024;
@@ -1742,6 +1743,97 @@ __global__ __launch_bounds__(256) void k_bw_random(const uint8_t* __restrict__ s
         }
     }
     if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);
+}
+
+// Calibration of the memory-side counters on k_probe_group's OWN access mix (VERDICT r3 #2a): `lanes` threads, each reading
+//   MODE 0  one whole 128-byte line, as eight 16-byte loads (a directory line)
+//   MODE 1  one 16-byte piece at a 4-byte-aligned address (a hash's words: 3 of 16 alignments straddle a 64-byte sector, 3 of
+//           32 a 128-byte line)
+//   MODE 2  one aligned 64-byte half line, as four 16-byte loads
+//   MODE 3  a line AND two pieces (the kernel's mix)
+// at addresses that are a PERMUTATION of the buffer's lines / words (index x odd constant mod a power of two): every line is
+// touched once, nothing is served twice from a cache, so the requests the memory side must see are known exactly.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bw_pattern(const uint8_t* __restrict__ buf, uint64_t nlines_log2, uint64_t lanes, unsigned long long* sink)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= lanes) return;
+    // MODE 3: the lines come from the buffer's lower half, the pieces from its upper half (no line is both)
+    const uint64_t nl = MODE == 3 ? nlines_log2 - 1 : nlines_log2;
+    const uint64_t lmask = (1ull << nl) - 1ull, wmask = (1ull << (nl + 5)) - 1ull;
+    uint32_t acc = 0;
+    if (MODE == 0 || MODE == 2 || MODE == 3) {
+        const uint8_t* line = buf + ((i * 0x9E3779B97F4A7C15ull) & lmask) * 128ull + (MODE == 2 ? ((i & 1ull) * 64ull) : 0ull);
+#pragma unroll
+        for (int k = 0; k < (MODE == 2 ? 4 : 8); ++k) { const uint4 v = gload_u4(line + 16 * k); acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (MODE == 4) {            // the same 64 lines per wave, read COOPERATIVELY: eight lanes per line, eight lines per instruction
+        const uint64_t wave0 = i & ~63ull, sub = i & 7ull, grp = (i & 63ull) >> 3;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t j = wave0 + (uint64_t)k * 8ull + grp;
+            const uint4 v = gload_u4(buf + ((j * 0x9E3779B97F4A7C15ull) & lmask) * 128ull + sub * 16ull);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (MODE == 5) {            // mode 0 with non-temporal loads
+        const u32x4_t* line = reinterpret_cast<const u32x4_t*>(buf + ((i * 0x9E3779B97F4A7C15ull) & lmask) * 128ull);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const u32x4_t v = __builtin_nontemporal_load((const FPX_GLOBAL u32x4_t*)(line + k)); acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (MODE == 6) {            // mode 0, the first 16 bytes of the line only (what does a line cost when one piece of it is asked for?)
+        const uint4 v = gload_u4(buf + ((i * 0x9E3779B97F4A7C15ull) & lmask) * 128ull);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (MODE == 1 || MODE == 3) {
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(buf) + (MODE == 3 ? (wmask + 1ull) : 0ull);
+#pragma unroll
+        for (int k = 0; k < (MODE == 3 ? 2 : 1); ++k) {
+            const uint64_t j = MODE == 3 ? 2ull * i + (uint64_t)k : i;
+            const uint64_t w = (j * 0xD1B54A32D192ED03ull) & wmask;           // (a permutation of the words: every alignment equally often)
+            const uint4 v = gload_u4_a4(words + w);                            // (the buffer has 64 bytes of slack behind its last word)
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);
+}
+
+int measure_access_impl(Ctx* ctx, size_t bytes, int mode, uint64_t lanes, double* ms_out)
+{
+    FPX_HIP(hipSetDevice(ctx->device));
+    uint64_t nlines_log2 = 0;
+    while ((128ull << (nlines_log2 + 1)) <= bytes) ++nlines_log2;
+    if (nlines_log2 < 16 || mode < 0 || mode > 6) { set_error("fpx_measure_access: buffer too small or unknown mode"); return FPX_E_INVAL; }
+    if (lanes > (1ull << nlines_log2) / (mode == 3 ? 2 : 1)) { set_error("fpx_measure_access: more lanes than lines"); return FPX_E_INVAL; }
+    uint8_t* buf = nullptr; unsigned long long* sink = nullptr;
+    FPX_HIP(hipMalloc(&buf, (128ull << nlines_log2) + 64));
+    FPX_HIP(hipMalloc(&sink, 8));
+    FPX_HIP(hipMemset(buf, 0x5a, (128ull << nlines_log2) + 64));
+    FPX_HIP(hipMemset(sink, 0, 8));
+    hipEvent_t e0, e1;
+    FPX_HIP(hipEventCreate(&e0)); FPX_HIP(hipEventCreate(&e1));
+    const dim3 grid((uint32_t)((lanes + 255) / 256));
+    FPX_HIP(hipDeviceSynchronize());
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {              // (the first launch also loads the kernel)
+    FPX_HIP(hipEventRecord(e0, 0));
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(k_bw_pattern<0>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
+        case 1: hipLaunchKernelGGL(k_bw_pattern<1>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
+        case 2: hipLaunchKernelGGL(k_bw_pattern<2>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
+        case 3: hipLaunchKernelGGL(k_bw_pattern<3>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
+        case 4: hipLaunchKernelGGL(k_bw_pattern<4>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
+        case 5: hipLaunchKernelGGL(k_bw_pattern<5>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
+        default: hipLaunchKernelGGL(k_bw_pattern<6>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
+    }
+    FPX_HIP(hipEventRecord(e1, 0));
+    FPX_HIP(hipEventSynchronize(e1));
+    FPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    }
+    if (ms_out) *ms_out = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(buf); (void)hipFree(sink);
+    return FPX_OK;
 }
 
 int measure_bandwidth_impl(Ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs)

@@ -51,6 +51,12 @@ class Context:
         check(lib().fpx_measure_bandwidth(self.h, nbytes, block_size, C.byref(s), C.byref(r)))
         return s.value, r.value
 
+    def measure_access(self, nbytes, mode, lanes):
+        """one launch of the counter-calibration kernel k_bw_pattern<mode> (fpx_measure_access); returns its HIP-event ms"""
+        ms = C.c_double()
+        check(lib().fpx_measure_access(self.h, nbytes, mode, lanes, C.byref(ms)))
+        return ms.value
+
 
 def _u32(a):
     return np.ascontiguousarray(a, dtype=np.uint32)

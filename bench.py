@@ -398,8 +398,12 @@ def pmc_child_main(args):
     dt, agg, _, _ = timed_resident(fpx, reader, qb, args.steps, args.warmup)
     nbytes, bs = 8 << 30, 512
     ctx.measure_bandwidth(nbytes, bs)
-    # byte counts of the calibration kernels (csrc/fpx_search.hip: measure_bandwidth_impl)
+    # ... and the pattern kernels (fpx_measure_access): known requests in k_probe_group's own access mix
+    lanes = 8 << 20
+    pat_ms = {f"k_bw_pattern<{m}>": ctx.measure_access(nbytes, m, lanes) for m in (0, 1, 2, 3, 4, 5, 6)}
+    # byte counts of the calibration kernels (csrc/fpx_search.hip: measure_bandwidth_impl, k_bw_pattern)
     print(json.dumps({"pmc_child": True, "bw_stream_bytes": nbytes // 4096 * 4096, "bw_random_bytes": 256 * 16 * (256 // 32) * 64 * bs,
+                      "pattern_lanes": lanes, "pattern_ms": pat_ms,
                       "probe_kernel_ms": agg.v["probe_kernel_ms"] / max(1, agg.v["probe_launches"])}), flush=True)
 
 

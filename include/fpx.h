@@ -354,6 +354,14 @@ uint64_t fpx_crc64_xz(uint64_t crc, const uint8_t *data, size_t len);
  * kernels: the second denominator SURVEY 8(d) asks for next to the 8 TB/s spec peak. */
 int fpx_measure_bandwidth(fpx_ctx *ctx, size_t bytes, uint32_t block_size, double *stream_gbs, double *random_gbs);
 
+/* Calibration kernels for the memory-side performance counters (bench.py's rocprofv3 --pmc passes): `lanes` threads read, at
+ * addresses that are a permutation of a `bytes`-sized buffer's lines / words (every line once, nothing served twice from a
+ * cache), mode 0: one whole 128-byte line each (eight 16-byte loads: a directory line of k_probe_group); 1: one 16-byte piece
+ * at a 4-byte-aligned address (a hash's words); 2: one aligned 64-byte half line; 3: a line and two pieces (the kernel's mix).
+ * *ms = the launch's HIP-event time.  The requests the memory side must see are known exactly: lanes x 128 B (mode 0),
+ * lanes x 19/16 sectors of 64 B (mode 1), lanes x 64 B (mode 2). */
+int fpx_measure_access(fpx_ctx *ctx, size_t bytes, int mode, uint64_t lanes, double *ms);
+
 #ifdef __cplusplus
 }
 #endif

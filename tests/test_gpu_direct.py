@@ -183,3 +183,66 @@ def test_narrow_bin_records_are_refused_when_a_file_understates_its_doc_ids(env,
     for rep in range(3):                                     # (the device-sized path from a workspace's second batch on)
         got, st = p.check(qs, fpx.http_options())
         assert all(len(g) >= 1 for g in got)
+
+
+def test_grouped_index_with_a_legacy_floor_keeps_its_query_counts_clean(env, monkeypatch):
+    """A groups-only snapshot, a batch of 512+ queries and a floor of 1 (or one short query): the batch cannot take the binned
+    scoring (k_score's count-only round handles such floors) and runs the two-level partition instead, whose per-query counts
+    must sit where its memset zeroes them -- run three times on one workspace, a stale count of an earlier batch would show as
+    wrong scores or a spurious redo (`sbins` was left set when `binned` ended up false)."""
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, 3, monkeypatch)
+    qs = _queries(rng, allitems, 600, qlen=300)
+    qs[17] = qs[17][:12]                                     # one short query: its default floor is 1
+    legacy = fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0)
+    for rep in range(3):
+        got, st = p.check(qs, legacy, with_stats=(rep == 0))
+        assert st.path_flags & 4 and not st.path_flags & 8     # the group was probed, the records were not binned by the probe kernel
+    for rep in range(2):                                     # ... and the HTTP defaults with the short query in the batch
+        got, st = p.check(qs, fpx.http_options(), with_stats=False)
+        assert st.path_flags & 4 and not st.path_flags & 8
+
+
+def test_a_segment_that_settled_in_its_blocks_stays_there(env, monkeypatch):
+    """A lone hash-window slice settles in its blocks under its first snapshot (a slice never becomes direct-addressed on its
+    own).  A later snapshot that holds it next to a second slice of the same window must not convert it -- the first snapshot's
+    descriptors point at its block-form buffers (device use-after-free) -- and both snapshots answer exactly."""
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    rng = np.random.default_rng(77)
+    lo, hi = 0x3FFFFFFF, 0xBFFFFFFF
+    sl, osegs, allitems = [], [], []
+    for s in range(2):
+        first = s * 3000 + 1
+        items = _segment_items(rng, s, 3000, first)
+        blocks, index = oracle.build_blocks(items, first, 512)
+        ids = np.arange(first, first + 3000, dtype=np.uint32)
+        whole = fpx.FileSegment(ctx, blocks, 512, index, first, first + 2999, s + 1, ids)
+        sl.append(whole.window(lo, hi))
+        whole.release()
+        keep = items[((items >> np.uint64(32)) > np.uint64(lo)) & ((items >> np.uint64(32)) <= np.uint64(hi))]
+        allitems.append(keep)
+    lone_groups = os.environ.get("FPX_FUSE_MIN") == "1"     # (a variant run: a lone segment becomes a group of one at once)
+    first_snap = fpx.Segments(ctx, [sl[0]])                  # the slice on its own: it settles in its blocks
+    assert lone_groups or not sl[0].direct
+    second_snap = fpx.Segments(ctx, [sl[0], sl[1]])          # company arrives
+    assert lone_groups or not sl[0].direct                   # ... and it stays where the first snapshot expects it
+    r1, r2 = fpx.IndexReader(first_snap), fpx.IndexReader(second_snap)
+    qs = [q[(q > lo) & (q <= hi)] for q in _queries(rng, allitems, 24)]
+    opts = fpx.SearchOptions(max_results=500, min_score=1, min_score_pct=0)
+
+    def brute(segs_items, q):
+        uq = np.unique(q)
+        sc = {}
+        for it in segs_items:
+            hit = it[np.isin((it >> np.uint64(32)).astype(np.uint32), uq)]
+            for d in (hit & np.uint64(0xFFFFFFFF)).astype(np.uint32):
+                sc[int(d)] = sc.get(int(d), 0) + 1
+        return sorted(sc.items(), key=lambda kv: (-kv[1], kv[0]))[:500]
+    for rep in range(2):
+        g2, _ = r2.search_batch(qs, opts)
+        g1, _ = r1.search_batch(qs, opts)
+        for i, q in enumerate(qs):
+            # (the window holds no hot hash: no cap applies, a plain count over the raw postings is the reference's answer)
+            assert g1[i] == brute(allitems[:1], q), i
+            assert g2[i] == brute(allitems, q), i

@@ -94,6 +94,33 @@ def _oracle_sample(fpx, oracle, ctx, seg, first_doc, ndocs, flat, offsets, opts,
     assert (st.scanned_blocks, st.scanned_docs) == (blocks_seen, docs_seen)
 
 
+def _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, nq, out, out_n):
+    """The oracle over ALL segments (downloaded from HBM into host RAM: 107 GiB for the 100 M index, re-encoded from the group on
+    the way) on the batch's first `nq` queries, against (a) what the FULL batch returned for them -- the headline path: one
+    radix pass, k_probe_group<16, BINNED>, k_score_bin -- and (b) the per-query scanned blocks / docs of the full batch through
+    fpx_search_batch_stats (the QS instantiation of the same kernel).  src/Index.zig:170-177, src/FileSegment.zig:153-176."""
+    osegs, keep = [], []
+    for s, sg in enumerate(segs):
+        blocks, index = sg.download()
+        keep.append((blocks, index))
+        lo = s * per + 1
+        ids = np.arange(lo, lo + per, dtype=np.uint32)
+        osegs.append(oracle.file_segment(blocks, 512, index, lo, lo + per - 1, s + 1, ids, borrow=True))
+    osnap = oracle.Snapshot(osegs, [])
+    B = len(offsets) - 1
+    queries = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(B)]
+    got3, st3, qblocks, qdocs = reader.search_batch_stats(queries, opts)
+    got = fpx.results_to_lists(out[:nq], out_n[:nq])
+    for i in range(nq):
+        want, ost = osnap.search(queries[i], opts.max_results, opts.min_score, opts.min_score_pct, with_stats=True)
+        assert got[i] == want, f"query {i}: gpu {got[i][:4]} != oracle over {len(segs)} segments {want[:4]}"
+        assert got3[i] == want, f"query {i} (statistics run): gpu {got3[i][:4]} != oracle {want[:4]}"
+        assert (int(qblocks[i]), int(qdocs[i])) == (ost.scanned_blocks, ost.scanned_docs), \
+            f"query {i}: scanned blocks / docs {int(qblocks[i])} / {int(qdocs[i])}, oracle {ost.scanned_blocks} / {ost.scanned_docs}"
+    assert int(qblocks.sum()) == st3.scanned_blocks and int(qdocs.sum()) == st3.scanned_docs
+    del osnap, osegs, keep
+
+
 def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192():
     """configs[2] (one GPU) and configs[3] (segments sharded over 8 ranks, here 8 snapshots on one GPU)."""
     import torch
@@ -157,6 +184,9 @@ def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192():
     assert blocks_sum == st.scanned_blocks
     # the oracle on a bounded sample: 24 queries x one segment
     _oracle_sample(fpx, oracle, ctx, segs[3], 3 * per + 1, per, flat, offsets, opts, 24)
+    # ... and over the WHOLE index -- all 16 columns of the group, the headline kernel's own path -- on 48 queries of the batch
+    assert st.path_flags & 4 and st2.path_flags & 8, "the batch did not run k_probe_group<16, BINNED> + k_score_bin"
+    _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, 48, out, out_n)
 
 
 def test_config1_10m_fingerprints_one_segment_batch_1024():
@@ -235,6 +265,10 @@ def test_config2_with_hot_hashes_at_full_size():
     assert (mn == out_n).all() and (mo == out).all()
     assert hits_sum == st.hits
     _oracle_sample(fpx, oracle, ctx, segs[7], 7 * per + 1, per, flat, offsets, opts, 16)
+    # the whole index with hot hashes: sixteen columns, lists cut by the caps in every one of them, 24 queries
+    out_b, out_nb, st_b = fpx.search_resident(reader, qb)              # (a workspace's later batches: the device-sized path)
+    assert (out_nb == out_n).all() and (out_b == out).all() and st_b.path_flags & 4
+    _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, 24, out, out_n)
 
 
 @pytest.mark.parametrize("dist", [0, 1])
@@ -268,3 +302,72 @@ def test_direct_addressed_form_equals_block_form_at_full_size(dist, monkeypatch)
     assert (n0 == n1).all() and (o0 == o1).all()
     assert np.array_equal(i0, i1) and np.array_equal(b0, b1)
     assert int(n0.min()) >= 1
+
+
+def test_config3_hash_windows_of_8_ranks_at_full_size():
+    """configs[3] in the shape that scales: the 100 M index sharded by HASH RANGE over 8 ranks, every rank played in
+    turn by the one GPU.  Rank r's slices are cut from the resident blocks (fpx_segment_slice), grouped with their window, probed
+    with the whole batch of 8192 (fpx_shard_probe: only the window's hashes, the records dropped into the batch's bins); then the
+    pieces travel as the all-to-all would move them and EVERY rank finishes its 1024 queries (fpx_shard_score).  Required: the
+    eight shares, put together, equal the unsharded batch byte for byte, and the ranks' scan counters add up to the unsharded
+    ones.  src/Index.zig:170-177 (one search), src/FileSegment.zig:153-176 (a hash's walk is independent of every other hash)."""
+    import os
+    import torch
+    from fpx_testlib import fpx
+    ctx = fpx.Context(0)
+    H, S, B, L, limit, world = 256, 16, 8192, 1000, 40, 8
+    segs, per, docs = _build(fpx, ctx, 100_000_000, H, S, scratch=30 << 30)
+    if os.environ.get("FPX_ALLOW_SHRINK") != "1":
+        assert docs == 100_000_000
+    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
+    opts = fpx.http_options(limit=limit)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    bpr = fpx.shard_bins_per_rank(B, world)
+    assert bpr * world * 8 == B
+    # ---- every rank's window in turn: cut, group, probe; its send buffer (8 x bpr bins) stays, the group goes
+    cell_cap = 4096                                            # (records of a bin from ONE rank: ~6250 x 8 / 8, two to a cell)
+    sends, tot = [], [0, 0, 0, 0]
+    for r in range(world):
+        lo_excl = None if r == 0 else (r << 32) // world - 1
+        hi_incl = None if r == world - 1 else ((r + 1) << 32) // world - 1
+        sl = [sg.window(lo_excl, hi_incl) for sg in segs]
+        snap = fpx.Segments(ctx, sl)
+        assert all(x.grouped for x in sl), "the slices did not form a group with their window"
+        rd = fpx.IndexReader(snap)
+        while True:
+            send = torch.zeros((world, bpr, cell_cap), dtype=torch.int64, device="cuda")
+            counts = torch.zeros((world, bpr), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()                           # (torch fills on ITS stream; libfpx writes these on a stream of its own)
+            st, need = fpx.shard_probe(rd, qb, world, send.data_ptr(), cell_cap, counts.data_ptr())
+            if st is not None:
+                break
+            assert not sends, "every rank must use one bin size: raise the initial cell_cap"
+            cell_cap = int(need)
+        sends.append((send, counts))
+        for i, v in enumerate((st.scanned_blocks, st.scanned_docs, st.probes, st.hits)):
+            tot[i] += v
+        del rd
+        snap.release()
+        for x in sl:
+            x.release()
+    # ---- the all-to-all's effect + every rank's finish
+    cap = qb.cap
+    out = np.zeros((B, cap, 2), np.uint32)
+    out_n = np.zeros(B, np.uint32)
+    covered = 0
+    for d in range(world):
+        recv = torch.stack([sends[r][0][d] for r in range(world)]).contiguous()
+        rc = torch.stack([sends[r][1][d] for r in range(world)]).contiguous()
+        torch.cuda.synchronize()
+        out, out_n, q_lo, q_hi = fpx.shard_score(ctx, qb, world, d, recv.data_ptr(), cell_cap, rc.data_ptr(), out, out_n)
+        assert (q_lo, q_hi) == (d * bpr * 8, (d + 1) * bpr * 8)
+        covered += q_hi - q_lo
+    assert covered == B
+    del sends, recv, rc
+    torch.cuda.empty_cache()
+    # ---- the unsharded index (the blocks become the group now) and the same batch
+    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+    o1, n1, st1 = fpx.search_resident(reader, qb)
+    assert (n1 == out_n).all() and (o1 == out).all(), "8 hash windows must reproduce the unsharded batch byte for byte"
+    assert tuple(tot) == (st1.scanned_blocks, st1.scanned_docs, st1.probes, st1.hits)
+    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)

@@ -493,9 +493,10 @@ int fpx_segment_group_info(const fpx_segment* seg, uint64_t* info, uint32_t n)
     if (!s || !info) { set_error("null argument"); return FPX_E_INVAL; }
     const Group* g = s->home.get();
     if (!g) { set_error("the segment is not a column of a group"); return FPX_E_INVAL; }
-    const uint64_t v[10] = {g->nseg, g->ns, g->device_bytes, g->nlines * 2ull * g->ns * 4ull, g->total_words * 4ull, g->total_list_words * 4ull,
-                            g->doubles, s->col, g->win_lo, g->win_hi};
-    for (uint32_t i = 0; i < n && i < 10u; ++i) info[i] = v[i];
+    const uint64_t v[14] = {g->nseg, g->ns, g->device_bytes, g->nlines * (g->packed ? (uint64_t)GROUP_LINE_WORDS : 2ull * g->ns) * 4ull, g->total_words * 4ull,
+                            g->total_list_words * 4ull, g->doubles, s->col, g->win_lo, g->win_hi,
+                            g->packed ? 1ull : 0ull, g->nlines, g->overflow_lines, g->overflow_words};
+    for (uint32_t i = 0; i < n && i < 14u; ++i) info[i] = v[i];
     return FPX_OK;
 }
 
@@ -702,6 +703,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
                     const Group* g = sg->home.get();
                     GroupDesc gd{};
                     gd.lines = g->d_lines; gd.line0 = g->line0; gd.nseg = g->nseg; gd.win_lo = g->win_lo; gd.win_hi = g->win_hi;
+                    gd.ext_tab = g->d_ext_tab; gd.chunk0 = g->chunk0; gd.nchunks = g->nchunks;       // (the packed form's)
                     for (uint32_t j = 0; j < FUSE_MAX; ++j) { gd.min_doc[j] = g->min_doc[j]; gd.first_hash[j] = g->first_hash[j]; gd.last_hash[j] = g->last_hash[j]; }
                     sn->groups.push_back(sg->home);
                     sn->h_group.push_back(gd);
@@ -862,12 +864,12 @@ int fpx_shard_probe(fpx_snapshot* snap, const fpx_query_batch* qb, uint32_t worl
 
 int fpx_shard_score(fpx_ctx* ctx, const fpx_query_batch* qb, uint32_t world, uint32_t rank, const void* d_recv, uint64_t cell_cap,
                     const void* d_recv_counts, uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n,
-                    uint32_t* first_query, uint32_t* num_queries)
+                    uint32_t* first_query, uint32_t* num_queries, uint64_t* needed_cell_cap)
 {
     if (!ctx || !qb || !d_recv || !d_recv_counts || !out_n || (!out && out_cap)) { set_error("null argument"); return FPX_E_INVAL; }
     if (world == 0 || world > 64 || rank >= world) { set_error("world must be 1..64, rank below it"); return FPX_E_INVAL; }
     return shard_score_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb), world, rank, reinterpret_cast<const uint64_t*>(d_recv), cell_cap,
-                            reinterpret_cast<const uint32_t*>(d_recv_counts), timeout_ms, out, out_cap, out_n, first_query, num_queries);
+                            reinterpret_cast<const uint32_t*>(d_recv_counts), timeout_ms, out, out_cap, out_n, first_query, num_queries, needed_cell_cap);
 }
 
 int fpx_merge_partials(fpx_ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world, uint32_t num_queries,

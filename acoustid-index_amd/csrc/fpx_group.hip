@@ -24,6 +24,8 @@ Group::~Group()
     if (d_lines) (void)hipFree(d_lines);
     for (uint32_t* p : word_chunks) if (p) (void)hipFree(p);
     for (uint32_t* p : list_chunks) if (p) (void)hipFree(p);
+    if (d_ext_tab) (void)hipFree(d_ext_tab);
+    for (uint32_t* p : ext_chunks) if (p) (void)hipFree(p);
 }
 
 namespace {
@@ -226,6 +228,176 @@ __global__ __launch_bounds__(256) void k_group_col_items(const uint32_t* __restr
     if (count_out) count_out[i] = total;
 }
 
+// ==== the PACKED form (fpx_pgroup.hpp): 128-byte lines of HV = 64 / NS hash values with their words inside ========================
+// the position bits of the HV hash values of line L in column s (bit j: hash value HV L + j) and the index of the first of its
+// positions in the column's `primary`
+template <int NS>
+__device__ __forceinline__ void src_cells(const GroupSrc& g, uint64_t L, uint32_t* bits, uint32_t* rank)
+{
+    constexpr uint32_t HV = 64u / NS;
+    const uint64_t h0 = L * HV;                                    // the line's first hash value
+    const uint32_t* rec = g.drec + (size_t)((h0 >> 8) - g.rec0) * 16u;
+    const uint32_t wv = (uint32_t)(h0 >> 5) & 7u, sub = (uint32_t)h0 & 31u;
+    const uint32_t word = rec[wv];
+    *bits = (word >> sub) & ((1u << HV) - 1u);
+    *rank = rec[8] + (((wv < 4u ? rec[9] : rec[10]) >> (8u * (wv & 3u))) & 0xFFu) + (uint32_t)__popc(word & ((1u << sub) - 1u));
+}
+
+// per line: the words it has (one per position, two for a double) and the words it needs in the chunk's `ext` (what of them
+// does not fit the line + its lists)
+template <int NS>
+__global__ __launch_bounds__(256) void k_pgroup_count(BuildArgs a, uint32_t* __restrict__ W, uint32_t* __restrict__ X, unsigned long long* __restrict__ total_words)
+{
+    constexpr uint32_t HV = 64u / NS;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.nlines) return;
+    const uint64_t L = a.line_begin + i;
+    uint32_t bits[NS], rank[NS];
+#pragma unroll
+    for (uint32_t s = 0; s < NS; ++s) {
+        bits[s] = 0u; rank[s] = 0u;
+        if (s < a.nseg) src_cells<NS>(a.src[s], L, &bits[s], &rank[s]);
+    }
+    uint32_t w = 0, pos = 0;
+    uint64_t x = 0;
+    for (uint32_t j = 0; j < HV; ++j) {
+#pragma unroll
+        for (uint32_t s = 0; s < NS; ++s) {
+            if (((bits[s] >> j) & 1u) == 0u) continue;
+            const uint32_t v = a.src[s].primary[rank[s]++];
+            const uint32_t at = pos++;
+            w += 1u;
+            if (v == GAP || (v >> 31) == 0u) continue;
+            const uint32_t* li = a.src[s].extras + ((size_t)(v & 0x7FFFFFFFu) << a.src[s].xshift);
+            const uint32_t hdr = li[0];
+            if (a.inline_doubles != 0u && at < 32u && is_double(hdr)) { w += 1u; continue; }
+            const uint32_t T = (hdr >> 19) & 1u, cnt = T ? li[1] : (hdr & 0xFFFFu);
+            x += 1ull + T + cnt;
+        }
+    }
+    if (w > GROUP_INLINE) x += w - (GROUP_INLINE - 1u);               // (the line keeps 28 words and the offset of the rest)
+    W[i] = w;
+    X[i] = (uint32_t)min(x, (uint64_t)0xFFFFFFFFull);
+    // (statistics: the words of all lines, one atomic per wave)
+    uint32_t wsum = w;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+    if ((threadIdx.x & 63u) == 0u && wsum) atomicAdd(total_words, (unsigned long long)wsum);
+}
+
+// per line again: the line, its overflowing words, the lists (long ones are queued for k_group_copy_long)
+template <int NS>
+__global__ __launch_bounds__(256) void k_pgroup_fill(BuildArgs a, const uint32_t* __restrict__ W, const uint64_t* __restrict__ offX,
+                                                    uint32_t* __restrict__ lines, uint32_t* __restrict__ ext,
+                                                    LongCopy* __restrict__ longq, uint32_t long_cap, unsigned long long* __restrict__ ctr)
+{
+    constexpr uint32_t HV = 64u / NS;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.nlines) return;
+    const uint64_t L = a.line_begin + i;
+    uint32_t bits[NS], rank[NS];
+#pragma unroll
+    for (uint32_t s = 0; s < NS; ++s) {
+        bits[s] = 0u; rank[s] = 0u;
+        if (s < a.nseg) src_cells<NS>(a.src[s], L, &bits[s], &rank[s]);
+    }
+    uint32_t* line = lines + (size_t)i * GROUP_LINE_WORDS;
+    const uint32_t n = W[i];
+    const uint32_t inl = n > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;
+    const uint64_t ovf = offX[i];                                      // where the line's words beyond `inl` go
+    uint64_t x = ovf + (n > GROUP_INLINE ? n - inl : 0u);              // ... and, behind them, its lists
+    uint64_t cells = 0;
+    uint32_t dfl = 0, pos = 0, t = 0, ndbl = 0;
+    auto put = [&](uint32_t word) {
+        if (t < inl) line[3u + t] = word; else ext[ovf + (t - inl)] = word;
+        ++t;
+    };
+    for (uint32_t j = 0; j < HV; ++j) {
+#pragma unroll
+        for (uint32_t s = 0; s < NS; ++s) {
+            if (((bits[s] >> j) & 1u) == 0u) continue;
+            cells |= 1ull << (j * NS + s);
+            const uint32_t v = a.src[s].primary[rank[s]++];
+            const uint32_t at = pos++;
+            if (v == GAP || (v >> 31) == 0u) { put(v); continue; }
+            const uint32_t* li = a.src[s].extras + ((size_t)(v & 0x7FFFFFFFu) << a.src[s].xshift);
+            const uint32_t hdr = li[0];
+            if (a.inline_doubles != 0u && at < 32u && is_double(hdr)) {
+                put(li[1]); put(li[2]);
+                dfl |= 1u << at; ndbl += 1u;
+                continue;
+            }
+            const uint32_t T = (hdr >> 19) & 1u, cnt = T ? li[1] : (hdr & 0xFFFFu);
+            const uint64_t ln = 1ull + T + cnt;
+            put(0x80000000u | (uint32_t)x);
+            bool queued = false;
+            if (ln > LONG_LIST) {
+                const unsigned long long q = atomicAdd(&ctr[0], 1ull);
+                if (q < long_cap) { longq[q] = LongCopy{li, ext + x, ln}; queued = true; }
+            }
+            if (!queued) for (uint64_t u = 0; u < ln; ++u) ext[x + u] = li[u];
+            x += ln;
+        }
+    }
+    for (uint32_t u = t; u < GROUP_INLINE; ++u) line[3u + u] = 0u;       // (unused words of the line)
+    line[0] = (uint32_t)cells; line[1] = (uint32_t)(cells >> 32); line[2] = dfl;
+    if (n > GROUP_INLINE) {
+        line[GROUP_LINE_WORDS - 1u] = (uint32_t)ovf;
+        atomicAdd(&ctr[2], 1ull); atomicAdd(&ctr[3], (unsigned long long)(n - inl));
+    }
+    if (ndbl) atomicAdd(&ctr[1], (unsigned long long)ndbl);
+}
+
+// ---- one column's items out of the group again ---------------------------------------------------------------------
+// thread per line: walks the line's cells in (hash, column) order to find column `col`'s words
+template <int NS>
+__global__ __launch_bounds__(256) void k_pgroup_col_items(const uint32_t* __restrict__ lines, const uint32_t* const* __restrict__ ext_tab, uint64_t nlines, uint64_t line0,
+                                                         uint32_t col, uint32_t min_doc, const uint64_t* __restrict__ itembase, uint32_t* __restrict__ count_out,
+                                                         uint64_t* __restrict__ items)
+{
+    constexpr uint32_t HV = 64u / NS, HVL = NS == 16 ? 2u : 3u;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= nlines) return;
+    const uint32_t* line = lines + (size_t)i * GROUP_LINE_WORDS;
+    const uint64_t cells = ((uint64_t)line[1] << 32) | line[0];
+    uint64_t colmask = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < HV; ++j) colmask |= 1ull << (j * NS + col);
+    if ((cells & colmask) == 0ull) { if (count_out) count_out[i] = 0u; return; }
+    const uint32_t dfl = line[2];
+    const uint32_t n = (uint32_t)__popcll(cells) + (uint32_t)__popc(dfl);
+    const uint32_t inl = n > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;
+    const uint32_t* ext = ext_tab[(i >> (GROUP_CHUNK_LOG2 - HVL))];               // (i counts from the group's first line = its first chunk's)
+    const uint32_t ovf = n > GROUP_INLINE ? line[GROUP_LINE_WORDS - 1u] : 0u;
+    auto word = [&](uint32_t t) { return t < inl ? line[3u + t] : ext[ovf + (t - inl)]; };
+    uint64_t out = items ? itembase[i] : 0ull;
+    uint32_t total = 0, pos = 0, t = 0;
+    for (uint32_t c = 0; c < 64u; ++c) {
+        if (((cells >> c) & 1ull) == 0ull) continue;
+        const bool d2 = pos < 32u && ((dfl >> pos) & 1u) != 0u;
+        if ((c & (NS - 1u)) == col) {
+            const uint64_t hpart = (uint64_t)(uint32_t)(((line0 + i) << HVL) | (c / NS)) << 32;
+            const uint32_t v = word(t);
+            if (d2) {
+                if (items) { items[out++] = hpart | (uint64_t)(min_doc + v); items[out++] = hpart | (uint64_t)(min_doc + word(t + 1u)); }
+                total += 2u;
+            } else if (v == GAP) {
+            } else if ((v >> 31) == 0u) {
+                if (items) items[out++] = hpart | (uint64_t)(min_doc + v);
+                total += 1u;
+            } else {
+                const uint32_t* x = ext + (v & 0x7FFFFFFFu);
+                const uint32_t hdr = x[0], T = (hdr >> 19) & 1u, cnt = T ? x[1] : (hdr & 0xFFFFu);
+                if (items) for (uint32_t u = 0; u < cnt; ++u) items[out++] = hpart | (uint64_t)(min_doc + x[1u + T + u]);
+                total += cnt;
+            }
+        }
+        t += d2 ? 2u : 1u;
+        pos += 1u;
+    }
+    if (count_out) count_out[i] = total;
+}
+
 }  // namespace
 
 // the blocks of a segment that hold the hashes of chunk c (2^26 hash values): [b0, bend), and the last hash before b0
@@ -277,13 +449,26 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         }
     }
     if (win_lo > win_hi) { set_error("empty hash window"); return FPX_E_INVAL; }
-    constexpr uint32_t CHUNK_LINES = 1u << 21, CHUNK_RECS = 1u << 18;          // a chunk: 2^26 hash values
+    // The PACKED form (fpx_pgroup.hpp: 128-byte lines of 64 / ns hash values with their words inside -- one HBM line per query
+    // hash) pays when the lines are reasonably full: from ~6 positions per line on, i.e. from ~10 % of all (hash, column) cells
+    // taken -- the 100 M index: 31 %, 20 positions + 3 second words of doubles per line of 29.  A sparser group keeps the
+    // directory + words form (a line per 32 hash values): 4 - 16 x fewer lines.  FPX_GROUP_PACKED = 0 | 1 decides for every group.
+    static const int packed_forced = [] { const char* e = getenv("FPX_GROUP_PACKED"); return e ? atoi(e) : -1; }();
+    uint64_t items_total = 0;
+    for (uint32_t j = 0; j < k; ++j) items_total += segs[j]->num_items;
+    const uint32_t hvl = ns == 16u ? 2u : 3u;                                     // log2 hash values per packed line
+    const double win_frac = ((double)win_hi - (double)win_lo + 1.0) / 4294967296.0;
+    const double per_line = (double)items_total / (4294967296.0 * (segs[0]->own_flags ? win_frac : 1.0)) * (double)(1u << hvl);
+    const bool packed = packed_forced >= 0 ? packed_forced != 0 : per_line >= 6.0;
+    constexpr uint32_t CHUNK_RECS = 1u << 18;                                     // a chunk: 2^26 hash values
+    const uint32_t CHUNK_LINES = packed ? (1u << (GROUP_CHUNK_LOG2 - hvl)) : (1u << 21);
+    const uint32_t line_words = packed ? GROUP_LINE_WORDS : 2u * ns;
     const uint32_t c_first = win_lo >> 26, c_last = win_hi >> 26, nchunks = c_last - c_first + 1u;
     const uint64_t nlines = (uint64_t)nchunks * CHUNK_LINES;
-    uint64_t need = nlines * 2ull * ns * 4ull;
+    uint64_t need = nlines * line_words * 4ull;
     // (a lower bound of what the group will take; running out of HBM half way is noticed chunk by chunk and leaves the
     // segments as they are)
-    for (uint32_t j = 0; j < k; ++j) need += (uint64_t)((double)segs[j]->num_items * 4.0 * ((double)nchunks / 64.0));
+    for (uint32_t j = 0; j < k; ++j) need += (uint64_t)((double)segs[j]->num_items * (packed ? 0.4 : 4.0) * ((double)nchunks / 64.0));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)3 << 30)) {
         (void)hipGetLastError();
@@ -292,6 +477,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     }
     auto g = std::make_shared<Group>();
     g->device = ctx->device; g->ns = ns; g->nseg = k; g->line0 = c_first * CHUNK_LINES; g->nlines = nlines; g->win_lo = win_lo; g->win_hi = win_hi;
+    g->packed = packed; g->chunk0 = c_first; g->nchunks = nchunks;
     for (uint32_t j = 0; j < FUSE_MAX; ++j) { g->first_hash[j] = 1u; g->last_hash[j] = 0u; }      // unused columns: empty hash range
     BuildArgs a{};
     a.nseg = k; a.inline_doubles = inline_doubles ? 1u : 0u;
@@ -299,9 +485,10 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         const Segment* s = segs[j];
         g->min_doc[j] = s->min_doc_id; g->first_hash[j] = s->first_hash; g->last_hash[j] = s->last_hash;
     }
-    hipError_t e = hipMalloc(&g->d_lines, nlines * 2ull * ns * 4ull);
+    hipError_t e = hipMalloc(&g->d_lines, nlines * line_words * 4ull + 64);      // (+ 64: a lane's last 16-byte piece may start in the last line's last word)
     if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
-    g->device_bytes = nlines * 2ull * ns * 4ull;
+    g->device_bytes = nlines * line_words * 4ull + 64;
+    FPX_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(g->d_lines) + nlines * line_words * 4ull, 0, 64, 0));
     // which blocks of the members still in blocks hold each chunk's hashes
     std::vector<std::vector<uint32_t>> ranges(k);
     {
@@ -321,11 +508,11 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     constexpr uint32_t LONG_CAP = 1u << 20;
     DevMem W, X, offW, offX, tot, longq, ctr;
     int rc;
-    if ((rc = W.alloc((size_t)CHUNK_LINES * 4)) || (rc = X.alloc((size_t)CHUNK_LINES * 4)) || (rc = offW.alloc((size_t)CHUNK_LINES * 8)) ||
-        (rc = offX.alloc((size_t)CHUNK_LINES * 8)) || (rc = tot.alloc(16)) || (rc = longq.alloc((size_t)LONG_CAP * sizeof(LongCopy))) || (rc = ctr.alloc(16)))
+    if ((rc = W.alloc((size_t)CHUNK_LINES * 4)) || (rc = X.alloc((size_t)CHUNK_LINES * 4)) || (!packed && (rc = offW.alloc((size_t)CHUNK_LINES * 8))) ||
+        (rc = offX.alloc((size_t)CHUNK_LINES * 8)) || (rc = tot.alloc(16)) || (rc = longq.alloc((size_t)LONG_CAP * sizeof(LongCopy))) || (rc = ctr.alloc(64)))
         return rc;
     hipStream_t st = 0;
-    FPX_HIP(hipMemsetAsync(ctr.p, 0, 16, st));
+    FPX_HIP(hipMemsetAsync(ctr.p, 0, 64, st));
     struct Pieces {                                 // this chunk's pieces of the members still in blocks
         DirectPiece pc[FUSE_MAX];
         ~Pieces() { for (DirectPiece& p : pc) p.release(); }
@@ -345,6 +532,34 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         }
         a.line_begin = (uint64_t)c * CHUNK_LINES; a.nlines = CHUNK_LINES;
         const dim3 grid((CHUNK_LINES + 255u) / 256u);
+        if (packed) {
+            // ---- the packed form: count (words per line, words it needs in `ext`), scan, allocate the chunk's `ext`, fill
+            if (ns == 8u) hipLaunchKernelGGL(k_pgroup_count<8>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>(), ctr.as<unsigned long long>() + 4);
+            else hipLaunchKernelGGL(k_pgroup_count<16>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>(), ctr.as<unsigned long long>() + 4);
+            FPX_HIP(hipGetLastError());
+            if ((rc = scan_counts_u32(X.as<uint32_t>(), CHUNK_LINES, offX.as<uint64_t>(), tot.as<uint64_t>() + 1, st))) return rc;
+            uint64_t h_x = 0;
+            FPX_HIP(hipMemcpyAsync(&h_x, tot.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipStreamSynchronize(st));
+            if (h_x >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_NOMEM; }
+            uint32_t* ext = nullptr;
+            e = hipMalloc(&ext, (h_x + 8) * 4ull);
+            if (e != hipSuccess) { (void)hipGetLastError(); set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
+            g->ext_chunks.push_back(ext);
+            FPX_HIP(hipMemsetAsync(ext + h_x, 0, 8 * 4, st));                        // (a list's head is read four words at a time)
+            FPX_HIP(hipMemsetAsync(ctr.p, 0, 8, st));
+            uint32_t* lines = g->d_lines + (size_t)ci * CHUNK_LINES * GROUP_LINE_WORDS;
+            if (ns == 8u) hipLaunchKernelGGL(k_pgroup_fill<8>, grid, dim3(256), 0, st, a, (const uint32_t*)W.as<uint32_t>(), (const uint64_t*)offX.as<uint64_t>(), lines, ext,
+                                             longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());
+            else hipLaunchKernelGGL(k_pgroup_fill<16>, grid, dim3(256), 0, st, a, (const uint32_t*)W.as<uint32_t>(), (const uint64_t*)offX.as<uint64_t>(), lines, ext,
+                                    longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());
+            hipLaunchKernelGGL(k_group_copy_long, dim3(1024), dim3(256), 0, st, longq.as<LongCopy>(), ctr.as<unsigned long long>(), LONG_CAP);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipStreamSynchronize(st));            // (the pieces go with this scope)
+            g->total_list_words += h_x;
+            g->device_bytes += (h_x + 8) * 4ull;
+            continue;
+        }
         if (ns == 8u) hipLaunchKernelGGL(k_group_count<8>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>());
         else hipLaunchKernelGGL(k_group_count<16>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>());
         FPX_HIP(hipGetLastError());
@@ -373,10 +588,15 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         g->total_words += h_tot[0]; g->total_list_words += h_tot[1];
         g->device_bytes += (h_tot[0] + 16 + h_tot[1] + 8) * 4ull;
     }
-    unsigned long long h_ctr[2] = {0, 0};
-    FPX_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, st));
+    unsigned long long h_ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    FPX_HIP(hipMemcpyAsync(h_ctr, ctr.p, 64, hipMemcpyDeviceToHost, st));
     FPX_HIP(hipStreamSynchronize(st));
-    g->doubles = h_ctr[1];
+    g->doubles = h_ctr[1]; g->overflow_lines = h_ctr[2]; g->overflow_words = h_ctr[3];
+    if (packed) {
+        FPX_HIP(hipMalloc(&g->d_ext_tab, (size_t)nchunks * sizeof(uint32_t*)));
+        FPX_HIP(hipMemcpy(g->d_ext_tab, g->ext_chunks.data(), (size_t)nchunks * sizeof(uint32_t*), hipMemcpyHostToDevice));
+        g->total_words = h_ctr[4];                       // (one per position + one per double; `overflow_words` of them live in `ext`)
+    }
     // the segments move in: a direct-addressed one's own arrays go with the last snapshot that still probes it alone, the
     // others' blocks now (Segment::d_bstart and d_block_index stay: with them the blocks can be written out again)
     for (uint32_t j = 0; j < k; ++j) {
@@ -400,6 +620,11 @@ int group_column_items(const Segment* s, uint64_t* items, hipStream_t st)
     if ((rc = cnt.alloc((size_t)g->nlines * 4)) || (rc = base.alloc((size_t)g->nlines * 8)) || (rc = tot.alloc(8))) return rc;
     const dim3 grid((uint32_t)((g->nlines + 255) / 256));
     auto launch = [&](const uint64_t* ib, uint32_t* co, uint64_t* it) {
+        if (g->packed) {
+            if (g->ns == 8u) hipLaunchKernelGGL(k_pgroup_col_items<8>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, (const uint32_t* const*)g->d_ext_tab, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
+            else hipLaunchKernelGGL(k_pgroup_col_items<16>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, (const uint32_t* const*)g->d_ext_tab, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
+            return;
+        }
         if (g->ns == 8u) hipLaunchKernelGGL(k_group_col_items<8>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
         else hipLaunchKernelGGL(k_group_col_items<16>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
     };

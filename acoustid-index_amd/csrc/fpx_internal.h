@@ -64,9 +64,16 @@ constexpr uint32_t FUSE_MAX = 16;          // columns of a group
 
 // A GROUP of up to 16 direct-addressed segments whose postings are stored together, hash-major and segment-minor, behind one
 // directory (layout: fpx_group.hpp; built by fpx_group.hip).  This is what k_probe_group gets, by value.
+constexpr uint32_t GROUP_LINE_WORDS = 32;  // a line: 128 bytes
+constexpr uint32_t GROUP_INLINE = 29;      // words a line holds itself (behind 64 position bits + 32 double flags); with more: 28 + the offset of the rest
+constexpr uint32_t GROUP_CHUNK_LOG2 = 26;  // the group's `ext` arrays are allocated per chunk of 2^26 hash values
+constexpr uint32_t GROUP_CHUNKS = 64;
 struct GroupDesc {
-    const uint32_t* lines;                 // the line of hash h: lines + ((h >> 5) - line0) * 2 ns words
+    const uint32_t* lines;                 // the line of hash h: lines + ((h >> 5) - line0) * 2 ns words; PACKED form (fpx_pgroup.hpp):
+                                           // lines + ((h >> hvl) - line0) * 32 words, hvl = 2 (16 columns) | 3 (8)
+    const uint32_t* const* ext_tab;        // packed form: [nchunks] where each chunk's `ext` (overflowing words + lists) starts
     uint32_t line0;                        // first line held (a hash-window slice of the group; 0: the whole hash space)
+    uint32_t chunk0, nchunks;              // packed form: first chunk held, chunks held
     uint32_t nseg;                         // columns in use
     uint32_t active;                       // bit s: column s belongs to the snapshot being searched (a group outlives merged-away members)
     uint32_t any_dead;
@@ -152,11 +159,16 @@ struct Group {
     uint32_t ns = 16;                      // 8 or 16: a directory line is 2 ns words
     uint32_t nseg = 0;
     uint32_t line0 = 0; uint64_t nlines = 0;
+    uint32_t chunk0 = 0, nchunks = 0;
     uint32_t win_lo = 0, win_hi = 0xFFFFFFFFu;
     uint32_t* d_lines = nullptr;
     std::vector<uint32_t*> word_chunks, list_chunks;       // one pair per hash-space chunk (the lines hold their addresses)
+    // the PACKED form (fpx_pgroup.hpp: a hash's words inside its line) of a dense group
+    bool packed = false;
+    std::vector<uint32_t*> ext_chunks;     // one per hash-space chunk: overflowing words + lists
+    uint32_t** d_ext_tab = nullptr;        // the same addresses in device memory (GroupDesc::ext_tab)
     uint32_t min_doc[FUSE_MAX] = {}, first_hash[FUSE_MAX] = {}, last_hash[FUSE_MAX] = {};
-    uint64_t device_bytes = 0, total_words = 0, total_list_words = 0, doubles = 0;
+    uint64_t device_bytes = 0, total_words = 0, total_list_words = 0, doubles = 0, overflow_lines = 0, overflow_words = 0;
     ~Group();
 };
 
@@ -327,7 +339,8 @@ int shard_bins_per_rank(uint32_t B, uint32_t world);
 int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
                      uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats);
 int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
-                     uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries);
+                     uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries,
+                     uint64_t* needed_cell_cap = nullptr);
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
                         uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n);

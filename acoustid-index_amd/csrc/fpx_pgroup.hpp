@@ -1,0 +1,407 @@
+// fpx_pgroup.hpp -- k_probe_pgroup: the probe kernel of a PACKED group -- the form a DENSE group of direct-addressed segments takes
+// (the dominant kernel on the 100 M index).  Part of the fpx_search.hip translation unit (included after fpx_group.hpp, whose
+// constants, bin slots and hit staging it shares; that file's k_probe_group serves groups too sparse for this form).
+//
+// FileSegment.search (src/FileSegment.zig:135-180) is run once per query hash and SEGMENT; the segments of an index share one
+// hash space, so the postings of up to 16 segments are stored TOGETHER, hash-major and segment-minor (fpx_group.hip builds the
+// group from the segments' blocks and frees them) -- and, since round 4, INSIDE the directory: a hash's words sit in the very
+// 128-byte line that says which columns have it, so that ONE HBM line answers a query hash for all sixteen segments:
+//
+//   lines   one 128-byte line per HV = 64 / NS hash values (NS = 16 columns: 4 hash values per line, NS = 8: 8); line L = hash / HV
+//           words 0, 1    64 POSITION BITS, cell (j, s) = hash value HV L + j in column s at bit j NS + s -- hash-major,
+//                         column-minor: the order of the line's words.  Bit set = some item of segment s has the hash (exact: the
+//                         bitmap is the hash column) or the position is a gap (no item, and the reference visits no block for it,
+//                         src/FileSegment.zig:164); clear = absent, one block visited
+//           word 2        DOUBLE flags of the line's first 32 positions: the position holds two docs inline (a hash with exactly
+//                         two docs in the segment, both returned from one block: 88 % of the hashes with several docs)
+//           words 3..31   the line's words, in cell order: doc - min_doc[s] | two such words (a double) | bit 31 + offset of the
+//                         hash's list in the chunk's `ext` | 0xFFFFFFFF for a gap position.  A line holds up to 29 words (the
+//                         100 M index: 23.3 on average); one with more keeps its first 28 and, in word 31, the offset of the rest
+//                         in `ext` (8 % of the lines, 3 % of the hashes)
+//   ext     per chunk of 2^26 hash values: the overflowing words of its lines and the lists -- word 0 = docs the reference
+//           RETURNS (16 bits) | blocks it VISITS << 16 | T << 19, [T: all docs of the hash], the docs ascending -- the caps of
+//           src/FileSegment.zig:173-174 applied when the group was built
+//
+// One thread per query hash: the first 16 bytes of its line (the HBM request), then up to three 16-byte pieces of the SAME line
+// (served by the caches) -- and for 2 % of the positions a list head.  ~1.2 HBM line requests per query hash where round 3's
+// separate directory + words needed 2.4 and k_probe_fused (one `primary` per segment) 7.1.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fpx_internal.h"
+
+namespace fpx {
+
+// (waves per SIMD: the line's head and twelve words need far fewer registers than round 3's whole directory line)
+#ifndef FPX_PK_WAVES
+#define FPX_PK_WAVES 6
+#endif
+#define FPX_PK_OCC __attribute__((amdgpu_waves_per_eu(FPX_PK_WAVES, FPX_PK_WAVES)))
+template <int NS, bool BINNED, bool QS>
+__global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, GroupArgs ga)
+{
+    constexpr uint32_t HVL = NS == 16 ? 2u : 3u;        // log2 of the hash values per line
+    __shared__ uint32_t s_bcnt[2][GB_SLOTS], s_bid[2][GB_SLOTS], s_bbase[GB_SLOTS];
+    // the stage (and, BINNED, the records' ranks in their bins) live in DYNAMIC shared memory: the compiler sizes its register
+    // budget by the occupancy it believes the static LDS allows, and it believes in 64 KB per CU (gfx950 has 160)
+    extern __shared__ __align__(16) uint8_t gk_dyn[];
+    uint64_t* stage = reinterpret_cast<uint64_t*>(gk_dyn);
+    uint16_t* s_rank = reinterpret_cast<uint16_t*>(gk_dyn + (size_t)FSTAGE_CAP * sizeof(uint64_t));      // (a rank inside a bin of one round: < 2048)
+    __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
+    const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
+    // per column, indexed by a lane's own column number; per chunk of the hash space: where its `ext` starts
+    __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
+    __shared__ const uint32_t* s_ext[GROUP_CHUNKS];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const GroupDesc* g = &ga.g;
+    if (tid < FUSE_MAX) { s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
+    if (tid < GROUP_CHUNKS) s_ext[tid] = tid < g->nchunks ? g->ext_tab[tid] : nullptr;
+    if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid / GB_SLOTS][tid % GB_SLOTS] = 0u; s_bid[tid / GB_SLOTS][tid % GB_SLOTS] = GB_EMPTY; }
+    if constexpr (BINNED) for (uint32_t i = tid; i < FSTAGE_CAP; i += FK_WG) s_rank[i] = GB_NEED;
+    if (tid == 0) {
+        stage_count = 0; stage_valid = FSTAGE_CAP;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
+        s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;        // cancel point (src/FileSegment.zig:144), once per workgroup
+    }
+    __syncthreads();
+    if (s_cancel) return;
+    const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
+    const uint32_t active = g->active, nactive = (uint32_t)__popc(active);
+    const bool any_dead = g->any_dead != 0u;
+    uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_reads = 0;
+    const uint64_t P = a.P_dev ? min((uint64_t)*a.P_dev, a.P) : a.P;
+
+    const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)FK_WG * a.rounds;
+    for (uint32_t round = 0; round < a.rounds; ++round) {
+        const uint64_t p = wg_base + (uint64_t)round * FK_WG + tid;
+        bool valid = p < P;
+        const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
+        // dedupSorted, src/Index.zig:489-499: flagged by k_make_keys_dedup, or found by looking back
+        if (valid && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip))) valid = false;
+        const uint32_t h = (uint32_t)(key >> a.qb);
+        const uint32_t blocks_before = QS ? my_blocks : 0u, docs_before = QS ? my_docs : 0u;
+        // a hash-window slice of the group (the index sharded by hash range): the other hashes are another rank's probes
+        if (h < g->win_lo || h > g->win_hi) valid = false;
+        const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
+        // ---- the head of the line: position bits, double flags (and the line's first word)
+        const uint32_t* lp = g->lines + (size_t)((h >> HVL) - g->line0) * GROUP_LINE_WORDS;
+        uint4 hd = make_uint4(0, 0, 0, 0);
+        if (valid) {
+            hd = gload_u4(reinterpret_cast<const uint8_t*>(lp));
+            my_probes += nactive;
+            my_reads += 2u;                        // (64-byte units: a line)
+        }
+        const uint32_t* ext = s_ext[valid ? (h >> GROUP_CHUNK_LOG2) - g->chunk0 : 0u];
+        // ---- the hash's columns: which have it, where its words start
+        const uint64_t bits = ((uint64_t)hd.y << 32) | hd.x;
+        const uint32_t sh = (h & ((1u << HVL) - 1u)) * (uint32_t)NS;                      // (<= 48 / 56)
+        const uint32_t pm = (uint32_t)(bits >> sh) & ((1u << NS) - 1u);
+        const uint32_t pos0 = (uint32_t)__popcll(bits & ((1ull << sh) - 1ull));
+        uint32_t inr = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < NS; ++s)
+            // (outside [first_hash, last_hash] the reference visits no block, src/FileSegment.zig:164,153; unused columns: empty range)
+            inr |= (h >= g->first_hash[s] && h <= g->last_hash[s]) ? (1u << s) : 0u;
+        if (!valid) inr = 0u;
+        my_blocks += (uint32_t)__popc(inr & active & ~pm);         // absent: the reference visits one block, finds nothing and stops
+        const uint32_t k = (uint32_t)__popc(pm);
+        // doubles: how many lie before the hash's first position, and which of its own positions are
+        const uint32_t dfl = hd.z;
+        const uint32_t dbl_before = pos0 >= 32u ? (uint32_t)__popc(dfl) : (uint32_t)__popc(dfl & ((1u << pos0) - 1u));
+        const uint32_t dm = pos0 >= 32u ? 0u : ((dfl >> pos0) & ((1u << k) - 1u));     // (k <= 16)
+        const uint32_t nwords = k + (uint32_t)__popc(dm);
+        const uint32_t n_line = (uint32_t)__popcll(bits) + (uint32_t)__popc(dfl);
+        const uint32_t inl = n_line > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;    // words of the line that are in the line
+        const uint32_t start = pos0 + dbl_before;
+        // ... of which the lane walks its first twelve, as far as they are in the line (the rest: the wave, below)
+        const uint32_t mine = min(min(nwords, GK_WORDS), start < inl ? inl - start : 0u);
+        // ---- its words: three loads from the same line, the second and third only where the hash has that many
+        uint32_t gw[GK_WORDS];
+#pragma unroll
+        for (uint32_t i = 0; i < GK_WORDS; ++i) gw[i] = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < GK_WORDS / 4; ++i) {
+            if (mine > 4u * i) {
+                const uint4 v = gload_u4_a4(lp + 3u + start + 4u * i);
+                gw[4 * i] = v.x; gw[4 * i + 1] = v.y; gw[4 * i + 2] = v.z; gw[4 * i + 3] = v.w;
+            }
+        }
+        // ---- walk them: single docs and doubles become records, the first list reference gets the lane's slot
+        uint32_t docs[GK_WORDS];
+        uint32_t keep = 0, n_esc = 0, esc_off = 0, esc_col = 0;
+        uint64_t cols = 0;                                   // column of word j in bits 4j .. 4j+3
+        {
+            uint32_t rest = pm, i = 0;
+            bool second = false;
+#pragma unroll
+            for (uint32_t j = 0; j < GK_WORDS; ++j) {
+                const uint32_t word = gw[j];
+                uint32_t doc = 0u;
+                if (j < mine) {
+                    const uint32_t s = (uint32_t)__builtin_ctz(rest);
+                    cols |= (uint64_t)s << (4u * j);
+                    if (word != 0xFFFFFFFFu && ((active >> s) & 1u) != 0u) {                 // (0xFFFFFFFF: a gap position -- nothing visited)
+                        if (word >> 31) {
+                            if (n_esc == 0u) { esc_off = word & 0x7FFFFFFFu; esc_col = s; }
+                            n_esc += 1u;
+                        } else {
+                            doc = s_min_doc[s] + word;
+                            my_blocks += second ? 0u : 1u; my_docs += 1u;
+                            keep |= 1u << j;
+                        }
+                    }
+                    if (((dm >> i) & 1u) != 0u && !second) second = true;
+                    else { second = false; i += 1u; rest &= rest - 1u; }
+                }
+                docs[j] = doc;
+            }
+        }
+        // superseded docs are dropped here: the stage mixes segments
+        if (any_dead) {
+#pragma unroll
+            for (uint32_t j = 0; j < GK_WORDS; ++j) {
+                const uint32_t s = (uint32_t)(cols >> (4u * j)) & 15u;
+                if (((keep >> j) & 1u) != 0u && s_has_dead[s] != 0u && is_dead_seg(ga.segs[s_seg_index[s]], docs[j])) keep &= ~(1u << j);
+            }
+        }
+        // the head of the first list: header + up to three docs in one load
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (n_esc != 0u) { x = gload_u4_a4(ext + esc_off); my_reads += 2u; }
+        uint32_t xkeep = 0;
+        const uint32_t xT = (x.x >> 19) & 1u, xeff = x.x & 0xFFFFu, xin = n_esc ? min(xeff, xT ? 2u : 3u) : 0u;
+        const uint32_t xmd = s_min_doc[esc_col];
+        const uint32_t xd0 = xmd + (xT ? x.z : x.y), xd1 = xmd + (xT ? x.w : x.z), xd2 = xmd + x.w;
+        if (n_esc != 0u) {
+            my_blocks += (x.x >> 16) & 7u; my_docs += xeff;
+            xkeep = (1u << xin) - 1u;
+            if (any_dead && s_has_dead[esc_col]) {
+                const SegDesc& f = ga.segs[s_seg_index[esc_col]];
+                if ((xkeep & 1u) && is_dead_seg(f, xd0)) xkeep &= ~1u;
+                if ((xkeep & 2u) && is_dead_seg(f, xd1)) xkeep &= ~2u;
+                if ((xkeep & 4u) && is_dead_seg(f, xd2)) xkeep &= ~4u;
+            }
+        }
+        // ---- one reservation per lane in the workgroup's stage -- and (BINNED) one in the lane's bin: the records' ranks there
+        const uint32_t cnt = (uint32_t)__popc(keep) + (uint32_t)__popc(xkeep);
+        const uint32_t par = round & 1u;
+        uint32_t pos = 0, brank = 0;
+        unsigned long long gpos = 0;
+        bool fits = true;
+        if (cnt != 0u) {
+            pos = atomicAdd(hs.count, cnt);
+            fits = pos + cnt <= FSTAGE_CAP;
+            if (!fits) {                             // the stage is full: this lane appends directly (BINNED: to the misc buffer, which k_bin bins)
+                atomicMin(hs.valid, pos);
+                gpos = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)cnt);
+            } else if constexpr (BINNED) {
+                const uint32_t b = gb_cell(a, qpart), bslot = gb_slot(a, qpart);
+                const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
+                brank = (old == GB_EMPTY || old == b) ? atomicAdd(&s_bcnt[par][bslot], cnt) : GB_EMPTY;       // (two bins on one slot: the misc buffer)
+            }
+        }
+        uint32_t o = 0;
+        auto put = [&](uint32_t doc) {
+            const uint64_t rec = qpart | doc;
+            if (fits) {
+                hs.buf[pos + o] = rec;
+                if constexpr (BINNED) s_rank[pos + o] = brank == GB_EMPTY ? GB_NEED : (uint16_t)(brank + o);
+            } else if (gpos + o < a.hit_cap) a.hits[gpos + o] = rec;
+            ++o;
+        };
+#pragma unroll
+        for (uint32_t j = 0; j < GK_WORDS; ++j)
+            if ((keep >> j) & 1u) put(docs[j]);
+        if (xkeep & 1u) put(xd0);
+        if (xkeep & 2u) put(xd1);
+        if (xkeep & 4u) put(xd2);
+        if (QS && GQSTATS(a) && valid && (my_blocks != blocks_before || my_docs != docs_before))
+            atomicAdd(&GQSTATS(a)[(uint32_t)(qpart >> 32)], (unsigned long long)(my_blocks - blocks_before) | ((unsigned long long)(my_docs - docs_before) << 32));
+        // ---- the rare rest, by the whole wave: words beyond the lane's own (more than twelve, or behind the line's 28 in `ext`),
+        //      further lists, lists longer than their head
+        {
+            const bool more = nwords > mine || n_esc > 1u || (n_esc == 1u && xeff > xin);
+            const bool hot = n_esc != 0u && xeff >= 64u;
+            unsigned long long mo = __ballot((int)more);
+            while (mo != 0ull) {
+                const int src = (int)__builtin_ctzll(mo);
+                mo &= mo - 1ull;
+                const uint32_t qlo = __shfl((uint32_t)(qpart >> 32), src);
+                const uint32_t pm_s = __shfl(pm, src), dm_s = __shfl(dm, src), nw_s = __shfl(nwords, src), mine_s = __shfl(mine, src);
+                const uint32_t start_s = __shfl(start, src), inl_s = __shfl(inl, src);
+                const uint32_t* lp_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)lp, src));
+                const uint32_t* li_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)ext >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)ext, src));
+                // (the line's words beyond its 28th live in `ext`, at the offset in the line's last word)
+                const uint32_t ovf_s = start_s + nw_s > inl_s ? gload_u32(lp_s + (GROUP_LINE_WORDS - 1u)) : 0u;
+                // lane l looks at word l of the hash (nwords <= 32): its column, and whether it is a double's second word
+                uint32_t col = 0, wv = 0xFFFFFFFFu;
+                bool second = false;
+                if (lane < nw_s) {
+                    uint32_t rest = pm_s, i = 0, j = 0;
+                    for (;;) {
+                        col = (uint32_t)__builtin_ctz(rest);
+                        const uint32_t span = 1u + ((dm_s >> i) & 1u);
+                        if (lane < j + span) { second = lane == j + 1u; break; }
+                        j += span; i += 1u; rest &= rest - 1u;
+                    }
+                    const uint32_t idx = start_s + lane;
+                    wv = idx < inl_s ? gload_u32(lp_s + 3u + idx) : gload_u32(li_s + ovf_s + (idx - inl_s));
+                }
+                const bool act = lane < nw_s && ((active >> col) & 1u) != 0u && wv != 0xFFFFFFFFu;
+                // singles and doubles beyond the lane's words
+                {
+                    const bool plain = act && (wv >> 31) == 0u && lane >= mine_s;
+                    const uint32_t doc = s_min_doc[col] + wv;
+                    if (plain) {
+                        my_blocks += second ? 0u : 1u; my_docs += 1u;
+                        if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (second ? 0ull : 1ull) | (1ull << 32));
+                    }
+                    const bool kp = plain && !(any_dead && s_has_dead[col] && is_dead_seg(ga.segs[s_seg_index[col]], doc));
+                    fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | doc, 0ull, 0ull, lane);
+                }
+                // the lists.  A HOT hash (its first list holds 64+ docs: hundreds of docs in every segment) takes ONE reservation in
+                // the batch's record buffer for all its lists and writes them straight there.  (64 records at a time through the
+                // stage, every chunk beyond the stage's room paid a global atomic on one address: 10 M of them per batch of 8192 on
+                // hot-pool data = 110 ms.)  Lane l (a word that refers to a list) reads its own header for that.
+                const bool hot_s = __shfl((int)hot, src) != 0;
+                if (hot_s) {
+                    const bool is_list = act && (wv >> 31) != 0u;
+                    const unsigned long long ml = __ballot((int)is_list);
+                    const uint32_t* lp = li_s + (wv & 0x7FFFFFFFu);
+                    const uint32_t hdr_l = is_list ? gload_u32(lp) : 0u;
+                    const uint32_t eff_l = hdr_l & 0xFFFFu, T_l = (hdr_l >> 19) & 1u;
+                    const bool slot_list = is_list && lane == (uint32_t)__builtin_ctzll(ml) && lane < mine_s;
+                    const uint32_t from_l = slot_list ? min(eff_l, T_l ? 2u : 3u) : 0u;
+                    if (is_list && !slot_list) {
+                        my_blocks += (hdr_l >> 16) & 7u; my_docs += eff_l; my_reads += 2u;
+                        if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
+                    }
+                    const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
+                    if (rest_l) my_reads += ((rest_l + 31u) >> 5) * 2u;
+                    uint32_t total = rest_l;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
+                    const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
+                    unsigned long long me = __ballot((int)(rest_l != 0u));
+                    unsigned long long gbase = 0;
+                    if (!filtered) {
+                        if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+                        gbase = __shfl(gbase, 0);
+                    }
+                    while (me != 0ull) {
+                        const int el = (int)__builtin_ctzll(me);
+                        me &= me - 1ull;
+                        const uint32_t* list = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), el) << 32) | __shfl((uint32_t)(uint64_t)lp, el));
+                        const uint32_t eff = __shfl(eff_l, el), T = __shfl(T_l, el), from = __shfl(from_l, el), c2 = __shfl(col, el);
+                        const uint32_t md = s_min_doc[c2];
+                        if (!filtered) {
+                            for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                                const unsigned long long at = gbase + (o2 - from) + lane;
+                                if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
+                            }
+                            gbase += eff - from;
+                        } else {                     // (superseded docs among them: through the stage, 64 at a time)
+                            const SegDesc* filt = s_has_dead[c2] ? ga.segs + s_seg_index[c2] : nullptr;
+                            for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                                bool kp = o2 + lane < eff;
+                                const uint32_t dv = md + (kp ? gload_u32(list + 1u + T + o2 + lane) : 0u);
+                                if (filt && kp) kp = !is_dead_seg(*filt, dv);
+                                fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
+                            }
+                        }
+                    }
+                } else {
+                    // the usual case -- a list or two of a handful of docs: one after the other; of the first one within the lane's
+                    // words the head has been emitted
+                    unsigned long long me = __ballot((int)(act && (wv >> 31) != 0u));
+                    bool first = true;
+                    while (me != 0ull) {
+                        const int el = (int)__builtin_ctzll(me);
+                        me &= me - 1ull;
+                        const uint32_t off = __shfl(wv, el) & 0x7FFFFFFFu, c2 = __shfl(col, el);
+                        const uint32_t* list = li_s + off;
+                        const uint32_t hdr = gload_u32(list), eff = hdr & 0xFFFFu, T = (hdr >> 19) & 1u;
+                        uint32_t from = 0u;
+                        if (first && (uint32_t)el < mine_s) from = min(eff, T ? 2u : 3u);          // (the lane's slot took these)
+                        else if (lane == 0) {
+                            my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u;
+                            if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr >> 16) & 7u) | ((unsigned long long)eff << 32));
+                        }
+                        first = false;
+                        const SegDesc* filt = (any_dead && s_has_dead[c2]) ? ga.segs + s_seg_index[c2] : nullptr;
+                        const uint32_t md = s_min_doc[c2];
+                        for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
+                            bool kp = o2 + lane < eff;
+                            const uint32_t dv = md + (kp ? gload_u32(list + 1u + T + o2 + lane) : 0u);
+                            if (filt && kp) kp = !is_dead_seg(*filt, dv);
+                            fused_emit3(hs, a, kp, false, false, ((uint64_t)qlo << 32) | dv, 0ull, 0ull, lane);
+                        }
+                        if (lane == 0 && eff > from) my_reads += ((eff - from + 31u) >> 5) * 2u;
+                    }
+                }
+            }
+        }
+        if constexpr (!BINNED) {
+            fused_flush(hs, a, round + 1u == a.rounds, tid);
+        } else {
+            // every round's records leave for their bins: ranks that are still missing (what the waves staged: long lists, a
+            // hash's words beyond the lane's twelve; a clash of two bins on one slot) first, then one reservation per bin
+            __syncthreads();
+            const uint32_t sc = min(stage_count, stage_valid);
+            bool unplaced = false;
+            for (uint32_t i = tid; i < sc; i += FK_WG) {
+                if (s_rank[i] != GB_NEED) continue;
+                const uint32_t b = gb_cell(a, stage[i]), sl = gb_slot(a, stage[i]);
+                const uint32_t old = atomicCAS(&s_bid[par][sl], GB_EMPTY, b);
+                if (old == GB_EMPTY || old == b) s_rank[i] = (uint16_t)atomicAdd(&s_bcnt[par][sl], 1u); else unplaced = true;
+            }
+            __syncthreads();
+            if (tid < GB_SLOTS) {
+                const uint32_t c = s_bcnt[par][tid];
+                if (c != 0u) {
+                    s_bbase[tid] = atomicAdd(&a.bin_count[(size_t)s_bid[par][tid] * BIN_STRIDE], c);
+                    s_bcnt[par][tid] = 0u; s_bid[par][tid] = GB_EMPTY;          // (this parity's next use is two rounds away)
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < sc; i += FK_WG) {
+                const uint64_t rec = stage[i];
+                const uint32_t b = gb_cell(a, rec); const uint32_t rk = s_rank[i];
+                if (rk < GB_NEED) {
+                    const uint64_t at = (uint64_t)s_bbase[gb_slot(a, rec)] + rk;
+                    if (at < a.bin_cap) bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, b, at, rec, a.counters);
+                } else {                            // (still no place: the misc buffer)
+                    const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
+                    if (gg < a.hit_cap) a.hits[gg] = rec;
+                }
+                s_rank[i] = GB_NEED;
+            }
+            (void)unplaced;
+            __syncthreads();
+            if (tid == 0) { stage_count = 0; stage_valid = FSTAGE_CAP; }
+            __syncthreads();
+        }
+    }
+    if (my_reads) atomicAdd(&wg_reads, (unsigned long long)my_reads);
+    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
+    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
+    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    __syncthreads();
+    if (tid == 0) {
+        if (a.lean_stats) {
+            unsigned long long* st = a.lean_stats + (size_t)(blockIdx.x % LEAN_STAT_SETS) * 8u;
+            if (wg_reads) atomicAdd(&st[4], wg_reads);
+            if (wg_blocks) atomicAdd(&st[1], wg_blocks);
+            if (wg_docs) atomicAdd(&st[2], wg_docs);
+            if (wg_probes) atomicAdd(&st[3], wg_probes);
+        } else {
+            if (wg_blocks) { atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks); atomicAdd(&a.counters[CTR_BYTES], wg_blocks * 512ull); }
+            if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
+            if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
+            if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);       // (64-byte units here)
+        }
+    }
+}
+
+}  // namespace fpx

@@ -19,6 +19,7 @@ constexpr uint32_t SB_FILTER_LOG2 = 14;            // 16 384 16-bit cells (8 192
 constexpr uint32_t SB_TABLE_LOG2 = 11;             // 2 048 slots of (doc << 32 | q << (32 - BQ) ... count): 16 KB
 constexpr uint32_t SB_QMAX = 64;                   // queries per bin at most (BQ <= 6: a rank of a sharded index gets 1/N of the docs of a bin)
 constexpr uint32_t SB_QL_SHIFT = 26;               // table slot: doc << 32 | query-in-bin << 26 | count (26 bits)
+constexpr uint32_t SB_NEED_MARK = 0x40000000u;     // FPX_SHARD_NEED_MARK: a travelling count that says "my bins need this many cells" instead of a size
 constexpr uint32_t SB_CAND = 32;                   // candidates of a query gathered in LDS before they move to the shared list
 
 struct ScoreBinArgs {
@@ -64,10 +65,13 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
         const uint64_t room = a.bin_cap << ((a.rec_mode == 1u || (a.rec_mode == 2u && (craw >> 31))) ? 1 : 0);      // records the piece's cells hold
         raw_max = max(raw_max, c);
         piece_over = piece_over || (uint64_t)c > room;
-        n += min((uint64_t)c, room);
+        n += c >= SB_NEED_MARK ? 0ull : min((uint64_t)c, room);              // (a marked count: no records, the step is redone)
     }
     if (tid == 0) a.bin_n[bin] = a.nsrc == 1u ? raw_max : (uint32_t)min<uint64_t>(n, 0xFFFFFFFFull);
-    if (tid == 0 && a.nsrc > 1u && piece_over) atomicMax(&a.counters[CTR_BINFAIL], 2ull);      // (a piece overflowed its cell)
+    if (tid == 0 && a.nsrc > 1u && piece_over) {                                                // (a piece overflowed its cell)
+        atomicMax(&a.counters[CTR_BINFAIL], 2ull);
+        atomicMax(&a.counters[CTR_TOTAL], (unsigned long long)raw_max);          // (a sender's "my bins need this many cells" mark travels as a count)
+    }
     __syncthreads();
     if (s_cancel) return;
     uint32_t floor_min = 0xFFFFFFFFu;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
         const unsigned int craw = a.bin_count[(size_t)c.src * a.count_stride + (size_t)bin * a.count_step];
         c.narrow = (a.rec_mode == 1u || (a.rec_mode == 2u && (craw >> 31))) ? 1u : 0u;
         c.nrec = min((uint64_t)(a.rec_mode == 2u ? (craw & 0x7FFFFFFFu) : craw), a.bin_cap << c.narrow);
+        if (a.rec_mode == 2u && (craw & 0x7FFFFFFFu) >= SB_NEED_MARK) c.nrec = 0;
         c.ns = c.narrow ? (c.nrec + 1u) >> 1 : c.nrec;
         c.recs = a.bins + (size_t)c.src * a.src_stride + (size_t)bin * a.bin_cap;
     };

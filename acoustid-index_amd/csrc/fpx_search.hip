@@ -41,6 +41,7 @@
 #include "fpx_probe_lean.hpp"
 #include "fpx_direct.hpp"
 #include "fpx_group.hpp"
+#include "fpx_pgroup.hpp"
 #include "fpx_probe_small.hpp"
 #include "fpx_score.hpp"
 #include "fpx_score_bin.hpp"
@@ -111,9 +112,21 @@ static int grow_pair(uint64_t* p[2], size_t* cap, size_t need)
 }
 
 // k_probe_group's instantiations: columns of a directory line (8 | 16), records binned in the flush, per-query scan statistics
-static void launch_probe_group(bool ns8, bool binned, bool qs, dim3 grid, hipStream_t st, const ProbeArgs& a, const GroupArgs& g)
+static void launch_probe_group(bool packed, bool ns8, bool binned, bool qs, dim3 grid, hipStream_t st, const ProbeArgs& a, const GroupArgs& g)
 {
     const size_t dyn = (size_t)FSTAGE_CAP * sizeof(uint64_t) + (binned ? (size_t)FSTAGE_CAP * sizeof(uint16_t) : 0u);       // stage (+ ranks)
+    if (packed) {                                 // a dense group: its words live in its lines (fpx_pgroup.hpp)
+#define FPX_LPP(NS, BN, QSV) hipLaunchKernelGGL((k_probe_pgroup<NS, BN, QSV>), grid, dim3(FK_WG), dyn, st, a, g)
+        if (ns8) {
+            if (binned) { if (qs) FPX_LPP(8, true, true); else FPX_LPP(8, true, false); }
+            else { if (qs) FPX_LPP(8, false, true); else FPX_LPP(8, false, false); }
+        } else {
+            if (binned) { if (qs) FPX_LPP(16, true, true); else FPX_LPP(16, true, false); }
+            else { if (qs) FPX_LPP(16, false, true); else FPX_LPP(16, false, false); }
+        }
+#undef FPX_LPP
+        return;
+    }
 #define FPX_LPG(NS, BN, QSV) hipLaunchKernelGGL((k_probe_group<NS, BN, QSV>), grid, dim3(FK_WG), dyn, st, a, g)
     if (ns8) {
         if (binned) { if (qs) FPX_LPG(8, true, true); else FPX_LPG(8, true, false); }
@@ -629,8 +642,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     for (const GroupDesc& gd : snap->h_group) {              // one launch per group: its descriptor is a kernel argument
                         const GroupArgs gargs{gd, snap->d_direct};
                         const dim3 gridg((uint32_t)((P + per_wg_gk - 1) / per_wg_gk));
-                        const bool ns8 = snap->groups[&gd - snap->h_group.data()]->ns == 8u;
-                        launch_probe_group(ns8, binned, gk.qstats != nullptr, gridg, st, gk, gargs);
+                        const Group* grp = snap->groups[&gd - snap->h_group.data()].get();
+                        launch_probe_group(grp->packed, grp->ns == 8u, binned, gk.qstats != nullptr, gridg, st, gk, gargs);
                     }
                     used_fused = true;
                 }
@@ -1340,6 +1353,7 @@ int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uin
 // No table gather, no merge: a query's results are complete on the rank that owns it.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t SHARD_BQ = 3;           // queries per bin, as on one GPU: a rank receives ALL records of its bins
+constexpr uint64_t SHARD_NEED_MARK = 0x40000000ull;     // a travelling count >= this: "my bins need (count & (mark - 1)) cells" (fpx.h, fpx_shard_score)
 
 // per query: the hashes inside [win_lo, win_hi] -- later occurrences dropped (dedupSorted, src/Index.zig:489-499) -- as keys in the
 // query's `stride` slots, their number in ko.qn[q], their counts per hash bucket added to ko.cnt (fpx_keyorder.hpp).
@@ -1504,6 +1518,14 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
     uint64_t max_len = 0;
     for (uint32_t q = 0; q < B; ++q) max_len = std::max<uint64_t>(max_len, offsets[q + 1] - offsets[q]);
     if (max_len > DEDUP_MAX) { set_error("fpx_shard_probe: queries of more than %u hashes (use fpx_probe_resident)", DEDUP_MAX); return FPX_E_INVAL; }
+    // (a floor of 1 or 2 -- the legacy protocol's options, or a query of <= 40 hashes -- makes every counted doc a candidate: the
+    // one-GPU path hands such batches to k_score's count-only round, run_batch's `binned`; here the record protocol takes them)
+    for (uint32_t q = 0; q < B; ++q) {
+        const fpx_opts& o = qb->opts[q];
+        if ((o.has_min_score ? o.min_score : (uint32_t)((offsets[q + 1] - offsets[q] + 19) / 20)) <= 2u) {
+            set_error("fpx_shard_probe: query %u has a score floor of 1 or 2: this batch takes the record protocol (fpx_probe_resident)", q); return FPX_E_INVAL;
+        }
+    }
     if (max_len == 0) max_len = 1;
     const unsigned qbits = bits_for(B);
     if (qbits > 24u) { set_error("fpx_shard_probe: at most 2^24 queries"); return FPX_E_INVAL; }
@@ -1581,7 +1603,8 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             for (const GroupDesc& gd : snap->h_group) {
                 const GroupArgs gargs{gd, snap->d_direct};
                 const dim3 grid((uint32_t)((P + per_wg - 1) / per_wg));
-                launch_probe_group(snap->groups[&gd - snap->h_group.data()]->ns == 8u, true, false, grid, st, a, gargs);
+                const Group* grp = snap->groups[&gd - snap->h_group.data()].get();
+                launch_probe_group(grp->packed, grp->ns == 8u, true, false, grid, st, a, gargs);
             }
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             // what the kernel could not place itself (a clash of two bins on one slot of a round, a full stage): k_bin
@@ -1637,8 +1660,10 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
 }
 
 int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
-                     uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries)
+                     uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries,
+                     uint64_t* needed_cell_cap)
 {
+    if (needed_cell_cap) *needed_cell_cap = 0;
     if (qb->ctx != ctx) { set_error("query batch belongs to a different context"); return FPX_E_INVAL; }
     const uint32_t B = qb->B;
     const uint32_t bpr = (uint32_t)shard_bins_per_rank(B, world);
@@ -1666,9 +1691,17 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ra
         uint32_t* d_bin_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS + (size_t)B / 2 + 1);
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)nq * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
+        const uint32_t sbf = 32u - qbits;
+        // (k_finish walks the batch's queries from q_lo on: the view's first query is q_lo)
+        auto finish = [&](const uint64_t* cands, uint64_t C) {
+            hipLaunchKernelGGL(k_finish, dim3((nq + 127) / 128), dim3(128), 0, st, cands, C, (const uint32_t*)qb->d_opts, nq, sbf, 0,
+                               ws->d_out, out_cap, ws->d_out_n, (const uint64_t*)(d_qcand + (size_t)q_lo * QCAND_SLOTS), (const uint32_t*)(d_qcand_n + q_lo),
+                               (unsigned long long*)nullptr, q_lo);
+        };
+        bool staged = false;
+        for (int attempt = 0;; ++attempt) {
         FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
         FPX_HIP(hipMemsetAsync(d_qcand_n, 0, (size_t)B * sizeof(uint32_t), st));
-        const uint32_t sbf = 32u - qbits;
         ScoreBinArgs sa{};
         sa.bins = d_recv; sa.bin_cap = cell_cap; sa.rec_mode = 2u; sa.bin_count = d_recv_counts; sa.nsrc = world; sa.src_stride = (uint64_t)bpr * cell_cap;
         sa.count_stride = bpr; sa.count_step = 1u; sa.bq = SHARD_BQ; sa.bin_base = rank * bpr; sa.B = B;
@@ -1677,23 +1710,31 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ra
         const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << SHARD_BQ) * 8u;
         const uint32_t my_bins = (nq + (1u << SHARD_BQ) - 1u) >> SHARD_BQ;
         hipLaunchKernelGGL(k_score_bin, dim3(my_bins), dim3(SB_WG), sb_lds, st, sa);
-        // (k_finish walks the batch's queries from q_lo on: the view's first query is q_lo)
-        auto finish = [&](const uint64_t* cands, uint64_t C) {
-            hipLaunchKernelGGL(k_finish, dim3((nq + 127) / 128), dim3(128), 0, st, cands, C, (const uint32_t*)qb->d_opts, nq, sbf, 0,
-                               ws->d_out, out_cap, ws->d_out_n, (const uint64_t*)(d_qcand + (size_t)q_lo * QCAND_SLOTS), (const uint32_t*)(d_qcand_n + q_lo),
-                               (unsigned long long*)nullptr, q_lo);
-        };
         finish(ws->d_cands[0], 0);
         FPX_HIP(hipGetLastError());
-        bool staged = false;
         if ((rc = stage_results(ws, nq, out_cap, st, &staged))) return rc;
         FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         FPX_SYNC(ws);
+        // A sender whose bins outgrew the agreed cell_cap marks EVERY count it sends with SHARD_NEED_MARK | the cells it needs
+        // (HashShardedReader / fpx_sharded_search_batch): every rank receives a piece from every sender, so all of them learn the
+        // same maximum from the one exchange and redo the step with it -- no extra collective to agree on a size
+        if (ws->h_counters[CTR_BINFAIL] == 2 && (ws->h_counters[CTR_TOTAL] & SHARD_NEED_MARK) != 0) {
+            if (needed_cell_cap) *needed_cell_cap = ws->h_counters[CTR_TOTAL] & (SHARD_NEED_MARK - 1u);
+            set_error("fpx_shard_score: a sender's bins need %llu cells, the exchange ran with %llu: redo the step", (unsigned long long)(ws->h_counters[CTR_TOTAL] & (SHARD_NEED_MARK - 1u)),
+                      (unsigned long long)cell_cap);
+            return FPX_E_AGAIN;
+        }
+        if (ws->h_counters[CTR_CANDS] > ws->cap_cands && attempt < 3) {          // the shared candidate list was too short: again with room
+            if ((rc = grow_pair(ws->d_cands, &ws->cap_cands, (size_t)ws->h_counters[CTR_CANDS] + 1024))) return rc;
+            continue;
+        }
         if (ws->h_counters[CTR_BINFAIL] != 0 || ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands) {
             set_error("fpx_shard_score: a bin could not be scored in place (%s): use smaller batches or the record protocol (fpx_score_partial)",
                       ws->h_counters[CTR_BINFAIL] == 2 ? "a received bin overflowed" : ws->h_counters[CTR_MAXSCORE] ? "a score does not fit the candidate key" : "too many candidates");
             return FPX_E_INVAL;
         }
+        break;
+        }       // (attempts)
         if (ws->h_counters[CTR_CANDS] != 0) {             // queries with more candidates than slots: sort the shared list, finish again
             const uint64_t Cf = ws->h_counters[CTR_CANDS];
             int ccur = 0;

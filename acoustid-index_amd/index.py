@@ -131,9 +131,10 @@ class _Segment:
         """fpx_segment_group_info as a dict (None when the segment is not a column of a group)"""
         if lib().fpx_segment_layout(self.h) != 2:
             return None
-        v = np.zeros(10, np.uint64)
-        check(lib().fpx_segment_group_info(self.h, _p(v), 10))
-        keys = ("columns", "line_columns", "bytes", "directory_bytes", "words_bytes", "lists_bytes", "doubles", "column", "window_lo", "window_hi")
+        v = np.zeros(14, np.uint64)
+        check(lib().fpx_segment_group_info(self.h, _p(v), 14))
+        keys = ("columns", "line_columns", "bytes", "directory_bytes", "words_bytes", "lists_bytes", "doubles", "column", "window_lo", "window_hi",
+                "packed", "lines", "overflow_lines", "overflow_words")
         return {k: int(x) for k, x in zip(keys, v)}
 
     @property
@@ -550,18 +551,34 @@ def shard_probe(reader, qb, world, d_send_ptr, cell_cap, d_send_counts_ptr, time
     return st, 0
 
 
+SHARD_NEED_MARK = 0x40000000        # FPX_SHARD_NEED_MARK (include/fpx.h)
+
+
+class ShardCellsTooSmall(Exception):
+    """fpx_shard_score returned FPX_E_AGAIN: some sender's bins need `need` cells -- every rank redoes the step with that size"""
+
+    def __init__(self, need):
+        super().__init__(f"the step's bins need {need} cells")
+        self.need = need
+
+
 def shard_score(ctx, qb, world, rank, d_recv_ptr, cell_cap, d_recv_counts_ptr, out=None, out_n=None, timeout_ms=0):
     """stage 2 of the bin protocol (fpx_shard_score): the received pieces of this rank's bins -> the FINAL results of its
-    queries.  `out` [B, cap, 2] / `out_n` [B] are the batch's arrays: the rank's rows are filled in.  Returns (out, out_n, q_lo, q_hi)."""
+    queries.  `out` [B, cap, 2] / `out_n` [B] are the batch's arrays: the rank's rows are filled in.  Returns (out, out_n, q_lo, q_hi).
+    Raises ShardCellsTooSmall when a sender marked its counts (its bins outgrew cell_cap): all ranks see the same mark."""
+    from ._lib import FPX_E_AGAIN
     if out is None:
         out = np.zeros((max(1, qb.B), qb.cap, 2), np.uint32)
         out_n = np.zeros(max(1, qb.B), np.uint32)
     bpr = lib().fpx_shard_bins_per_rank(qb.B, world)
     q_lo = min(qb.B, rank * bpr * 8)
-    first, num = C.c_uint32(0), C.c_uint32(0)
-    check(lib().fpx_shard_score(ctx.h, qb.h, world, rank, C.c_void_p(d_recv_ptr), int(cell_cap), C.c_void_p(d_recv_counts_ptr), timeout_ms,
-                                _p(out[q_lo:]) if q_lo < qb.B else _p(out), qb.cap, _p(out_n[q_lo:]) if q_lo < qb.B else _p(out_n),
-                                C.byref(first), C.byref(num)))
+    first, num, need = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    rc = lib().fpx_shard_score(ctx.h, qb.h, world, rank, C.c_void_p(d_recv_ptr), int(cell_cap), C.c_void_p(d_recv_counts_ptr), timeout_ms,
+                               _p(out[q_lo:]) if q_lo < qb.B else _p(out), qb.cap, _p(out_n[q_lo:]) if q_lo < qb.B else _p(out_n),
+                               C.byref(first), C.byref(num), C.byref(need))
+    if rc == FPX_E_AGAIN and need.value:
+        raise ShardCellsTooSmall(int(need.value))
+    check(rc)
     assert int(first.value) == q_lo or int(num.value) == 0
     return out, out_n, int(first.value), int(first.value) + int(num.value)
 

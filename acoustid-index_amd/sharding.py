@@ -174,41 +174,56 @@ class HashShardedReader:
         if not self.bins:
             return None
         bpr = fpx.shard_bins_per_rank(qb.B, self.world)
-        while True:
-            if self.cell_cap == 0:
-                self.cell_cap = 2048
-            key = (qb.B, self.cell_cap)
-            if key not in self._binbufs:
-                self._binbufs = {key: (torch.empty((self.world, bpr, self.cell_cap), dtype=torch.int64, device=self.device),
-                                       torch.zeros((self.world, bpr), dtype=torch.int32, device=self.device))}
-                torch.cuda.current_stream(self.device).synchronize()      # (torch fills on ITS stream; libfpx writes on a stream of its own)
-            send, send_counts = self._binbufs[key]
-            try:
-                st, need = fpx.shard_probe(self.reader, qb, self.world, send.data_ptr(), self.cell_cap, send_counts.data_ptr())
-            except fpx.FpxError as e:
-                if e.status == -4:              # FPX_E_INVAL: not a snapshot of groups alone
+        if self.cell_cap == 0:
+            self.cell_cap = 2048
+        key = (qb.B, self.cell_cap)
+        if key not in self._binbufs:
+            self._binbufs = {key: (torch.empty((self.world, bpr, self.cell_cap), dtype=torch.int64, device=self.device),
+                                   torch.zeros((self.world, bpr), dtype=torch.int32, device=self.device))}
+            torch.cuda.current_stream(self.device).synchronize()      # (torch fills on ITS stream; libfpx writes on a stream of its own)
+        send, send_counts = self._binbufs[key]
+        try:
+            st, need = fpx.shard_probe(self.reader, qb, self.world, send.data_ptr(), self.cell_cap, send_counts.data_ptr())
+        except fpx.FpxError as e:
+            if e.status == -4:                  # FPX_E_INVAL: not a snapshot of groups alone, or a batch with a legacy floor
+                if "score floor" not in str(e):
                     self.bins = False
-                    return None
-                raise
-            if st is not None:
-                return st
-            self.cell_cap = int(need)           # a bin outgrew the buffer: the call says how much it takes
+                return None
+            raise
+        if st is None:
+            # A bin outgrew the buffer.  The ranks must run the exchange with ONE bin size and each only knows its own need: this
+            # rank still takes part in the step's exchange, with every count it sends marked "needs `need` cells" -- every rank
+            # receives a piece from every sender, so all of them see the same largest mark (fpx_shard_score: ShardCellsTooSmall)
+            # and redo the step with it (gather_merge).  No extra collective, no rank left waiting in one.
+            send_counts.fill_(fpx.SHARD_NEED_MARK | int(need))
+            torch.cuda.current_stream(self.device).synchronize()
+            st = fpx.Stats()
+        self._cap_of_step = self.cell_cap
+        return st
 
     def gather_merge(self, qb, out=None, out_n=None):
         """stages 2 + 3 (every rank in the same order): all-to-all of the bins, then this rank's queries are finished.  Fills
         the rank's rows of `out` / `out_n` (the batch's arrays); self.last_range = (q_lo, q_hi) says which."""
         import torch
         fpx = self.fpx
-        send, send_counts = self._binbufs[(qb.B, self.cell_cap)]
-        if self.host_staged:
-            recv, recv_counts = exchange_bins(self.dist, send.cpu(), send_counts.cpu())
-            recv, recv_counts = recv.to(self.device), recv_counts.to(self.device)
-        else:
-            recv, recv_counts = exchange_bins(self.dist, send, send_counts)      # RCCL all-to-all over xGMI
-        torch.cuda.current_stream(self.device).synchronize()
-        out, out_n, q_lo, q_hi = fpx.shard_score(self.ctx, qb, self.world, self.rank, recv.data_ptr(), self.cell_cap, recv_counts.data_ptr(), out, out_n)
-        self.last_range = (q_lo, q_hi)
-        return out, out_n
+        for attempt in range(4):
+            send, send_counts = self._binbufs[(qb.B, self.cell_cap)]
+            if self.host_staged:
+                recv, recv_counts = exchange_bins(self.dist, send.cpu(), send_counts.cpu())
+                recv, recv_counts = recv.to(self.device), recv_counts.to(self.device)
+            else:
+                recv, recv_counts = exchange_bins(self.dist, send, send_counts)      # RCCL all-to-all over xGMI
+            torch.cuda.current_stream(self.device).synchronize()
+            try:
+                out, out_n, q_lo, q_hi = fpx.shard_score(self.ctx, qb, self.world, self.rank, recv.data_ptr(), self.cell_cap, recv_counts.data_ptr(), out, out_n)
+            except fpx.ShardCellsTooSmall as e:
+                # some rank's bins outgrew the step's size: EVERY rank is here now, with the same number; probe again, exchange again
+                self.cell_cap = max(int(e.need), self.cell_cap + 1)
+                self._last_stats = self.partial(qb)
+                continue
+            self.last_range = (q_lo, q_hi)
+            return out, out_n
+        raise RuntimeError("the bins' size did not settle in four exchanges")
 
     # ---- record protocol (any snapshot)
     def _search_records(self, qb, out, out_n):

@@ -138,9 +138,11 @@ uint64_t fpx_segment_device_bytes(const fpx_segment *seg);
  * presence bitmap with a rank directory and doc lists (csrc/fpx_direct.hpp).  Searches, counters, downloads and merges do
  * not depend on the form: a download re-encodes the file's blocks byte for byte. */
 int fpx_segment_layout(const fpx_segment *seg);
-/* What the group of a grouped segment (layout 2) looks like: info[0..9] = columns in use, columns of a directory line (8 / 16),
- * HBM bytes of the whole group, of its directory, of its words, of its lists, positions stored as inline doubles, this segment's
- * column, first and last hash of the group's hash window.  (Introspection for benchmarks and capacity planning.) */
+/* What the group of a grouped segment (layout 2) looks like: info[0..13] = columns in use, columns of a directory line (8 / 16),
+ * HBM bytes of the whole group, of its lines (directory), of its words, of its lists (packed form: lists + overflowing words),
+ * positions stored as inline doubles, this segment's column, first and last hash of the group's hash window, 1 = the PACKED
+ * form (a dense group: 128-byte lines of 4 / 8 hash values with their words inside, csrc/fpx_pgroup.hpp), lines, lines whose
+ * words overflow into `ext`, words there.  (Introspection for benchmarks and capacity planning.) */
 int fpx_segment_group_info(const fpx_segment *seg, uint64_t *info, uint32_t n);
 /* copy a resident file segment's blocks (+terminator) and block index back to the host */
 int fpx_segment_download(const fpx_segment *seg, uint8_t *blocks, size_t blocks_cap,
@@ -314,13 +316,20 @@ int fpx_score_partial(fpx_ctx *ctx, const fpx_query_batch *qb, const void *d_rec
  *   fpx_shard_score   d_recv = [world][bpr][cell_cap], d_recv_counts = [world][bpr] as received (piece s = what rank s sent): the
  *                     FINAL results of this rank's queries -- *first_query, *num_queries say which -- written to out[i * out_cap ..],
  *                     out_n[i] for i = query - first_query (host memory, room for bpr * 8 queries).  No table exchange, no merge.
- * Counters in `stats` (scanned blocks / docs / probes) are this rank's share: their sum over the ranks is the unsharded total. */
+ * Counters in `stats` (scanned blocks / docs / probes) are this rank's share: their sum over the ranks is the unsharded total.
+ * One bin size for all ranks, without a collective of its own: every rank must run the exchange with the same cell_cap, and a
+ * rank only learns its own need (FPX_E_AGAIN from fpx_shard_probe).  Such a rank still takes part in the step's exchange, with
+ * EVERY count it sends set to FPX_SHARD_NEED_MARK | needed_cell_cap; as every rank receives a piece from every sender, each
+ * fpx_shard_score of that step then returns FPX_E_AGAIN with the same *needed_cell_cap (the largest mark seen), and all ranks redo
+ * the step with it.  Batches with a score floor of 1 or 2 are refused by fpx_shard_probe (FPX_E_INVAL): the record protocol
+ * (fpx_probe_resident / fpx_score_partial) answers those. */
+#define FPX_SHARD_NEED_MARK 0x40000000u
 uint32_t fpx_shard_bins_per_rank(uint32_t num_queries, uint32_t world);
 int fpx_shard_probe(fpx_snapshot *snap, const fpx_query_batch *qb, uint32_t world, uint32_t timeout_ms,
                     void *d_send, uint64_t cell_cap, void *d_send_counts, uint64_t *needed_cell_cap, fpx_stats *stats);
 int fpx_shard_score(fpx_ctx *ctx, const fpx_query_batch *qb, uint32_t world, uint32_t rank, const void *d_recv, uint64_t cell_cap,
                     const void *d_recv_counts, uint32_t timeout_ms, fpx_result *out, uint32_t out_cap, uint32_t *out_n,
-                    uint32_t *first_query, uint32_t *num_queries);
+                    uint32_t *first_query, uint32_t *num_queries, uint64_t *needed_cell_cap /* may be null */);
 
 /* ---- device-side segment build and merge -------------------------------------------------------
  * fpx_segment_build: filefmt.writeBlocks + BlockEncoder (src/filefmt.zig:94-138, src/block.zig:438-567) run on the GPU

@@ -10,6 +10,8 @@ variant runs in a process of its own):
 * FPX_FUSE_MIN=1         with it: every direct-addressed segment a column of a GROUP, even one alone (k_probe_group<8 | 16>, built
                          chunk by chunk from the blocks; by default groups of 2..16) -- the records binned in the probe kernel's
                          flush and scored a bin per workgroup (k_score_bin) on every batch after a workspace's first
+* FPX_GROUP_PACKED=1     ... every group in the PACKED form (k_probe_pgroup: 128-byte lines of 4 / 8 hash values with their words inside;
+                         by default only groups dense enough for it -- the full-size indexes of tests/test_gpu_fullsize.py)
 * FPX_BINNED=0           ... with the two-level partition + k_score instead (the path of mixed snapshots)
 * FPX_INLINE_DOUBLES=0   ... with every hash of several docs behind a list reference (no inline doubles)
 * FPX_REC32=0            ... with 8-byte records in the bins (by default 4-byte ones where the doc ids leave room), bins of eight
@@ -42,6 +44,7 @@ VARIANTS = [{"FPX_DIRECT": "0"}, {"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"},
             {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"},
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_GROUP_PACKED": "1"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_BINNED": "0"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_BIN_Q_LOG2": "3", "FPX_ORDER_MIN_PAIRS": "0"}]

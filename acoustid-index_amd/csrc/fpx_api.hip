@@ -872,6 +872,36 @@ int fpx_shard_score(fpx_ctx* ctx, const fpx_query_batch* qb, uint32_t world, uin
                             reinterpret_cast<const uint32_t*>(d_recv_counts), timeout_ms, out, out_cap, out_n, first_query, num_queries, needed_cell_cap);
 }
 
+int fpx_shard_keys(fpx_ctx* ctx, const fpx_query_batch* qb_share, uint32_t world, uint32_t rank, uint32_t num_queries_global,
+                   void* d_keys_send, uint64_t key_cap, void* d_key_counts, uint64_t* needed_key_cap)
+{
+    if (!ctx || !qb_share || !d_keys_send || !d_key_counts) { set_error("null argument"); return FPX_E_INVAL; }
+    if (world == 0 || rank >= world) { set_error("rank must be below world"); return FPX_E_INVAL; }
+    return shard_keys_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb_share), world, rank, num_queries_global,
+                           reinterpret_cast<uint64_t*>(d_keys_send), key_cap, reinterpret_cast<unsigned long long*>(d_key_counts), needed_key_cap);
+}
+
+int fpx_shard_probe_keys(fpx_snapshot* snap, const void* d_keys_recv, uint64_t key_cap, const void* d_key_counts_recv, uint32_t world,
+                         uint32_t num_queries_global, uint32_t timeout_ms, void* d_send, uint64_t cell_cap, void* d_send_counts,
+                         uint64_t* needed_cell_cap, fpx_stats* stats)
+{
+    if (!snap || !d_keys_recv || !d_key_counts_recv || !d_send || !d_send_counts) { set_error("null argument"); return FPX_E_INVAL; }
+    if (world == 0 || world > 64) { set_error("world must be 1..64"); return FPX_E_INVAL; }
+    return shard_probe_keys_impl(reinterpret_cast<Snapshot*>(snap), reinterpret_cast<const uint64_t*>(d_keys_recv), key_cap,
+                                 reinterpret_cast<const unsigned long long*>(d_key_counts_recv), world, num_queries_global, timeout_ms,
+                                 reinterpret_cast<uint64_t*>(d_send), cell_cap, reinterpret_cast<uint32_t*>(d_send_counts), needed_cell_cap, stats);
+}
+
+int fpx_shard_score_share(fpx_ctx* ctx, const fpx_query_batch* qb_share, uint32_t world, uint32_t rank, uint32_t num_queries_global,
+                          const void* d_recv, uint64_t cell_cap, const void* d_recv_counts, uint32_t timeout_ms,
+                          fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries, uint64_t* needed_cell_cap)
+{
+    if (!ctx || !qb_share || !d_recv || !d_recv_counts || !out_n || (!out && out_cap)) { set_error("null argument"); return FPX_E_INVAL; }
+    if (world == 0 || world > 64 || rank >= world || num_queries_global == 0) { set_error("world must be 1..64, rank below it, the batch not empty"); return FPX_E_INVAL; }
+    return shard_score_impl(reinterpret_cast<Ctx*>(ctx), reinterpret_cast<const QueryBatch*>(qb_share), world, rank, reinterpret_cast<const uint64_t*>(d_recv), cell_cap,
+                            reinterpret_cast<const uint32_t*>(d_recv_counts), timeout_ms, out, out_cap, out_n, first_query, num_queries, needed_cell_cap, num_queries_global);
+}
+
 int fpx_merge_partials(fpx_ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world, uint32_t num_queries,
                        uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                        fpx_result* out, uint32_t out_cap, uint32_t* out_n)

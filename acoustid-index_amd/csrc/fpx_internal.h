@@ -340,7 +340,11 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
                      uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats);
 int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
                      uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries,
-                     uint64_t* needed_cell_cap = nullptr);
+                     uint64_t* needed_cell_cap = nullptr, uint32_t B_global = 0);
+int shard_keys_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, uint32_t B_global,
+                    uint64_t* d_keys_send, uint64_t key_cap, unsigned long long* d_key_counts, uint64_t* needed_key_cap);
+int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t key_cap, const unsigned long long* d_key_counts, uint32_t world, uint32_t B_global,
+                          uint32_t timeout_ms, uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats);
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
                         uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n);

@@ -134,7 +134,8 @@ struct KeyOrder {
 
 __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
                                                          uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,
-                                                         unsigned long long* zero_counters, unsigned int* zero_u32, uint32_t zero_n, KeyOrder ko)
+                                                         unsigned long long* zero_counters, unsigned int* zero_u32, uint32_t zero_n, KeyOrder ko,
+                                                         uint32_t q_base = 0)      // (q_base: the keys carry query numbers q_base + q -- a rank's share of a sharded batch)
 {
     __shared__ uint32_t tab[DEDUP_SLOTS];
     __shared__ uint32_t hist[KO_MAX_BUCKETS];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restr
                 slot = (slot + 1u) & (DEDUP_SLOTS - 1u);
             }
         }
-        keys[i - base] = (((uint64_t)h << qb) | q) | (dup ? KEY_DUP_FLAG : 0ull);
+        keys[i - base] = (((uint64_t)h << qb) | (q + q_base)) | (dup ? KEY_DUP_FLAG : 0ull);
         if (ko.nb) atomicAdd(&hist[(h >> ko.bshift) & (ko.nb - 1u)], 1u);       // (duplicates keep their place in the order)
     }
     if (ko.nb) {

@@ -70,11 +70,16 @@ __global__ __launch_bounds__(256) void k_bucket_scan(KeyOrder ko, uint32_t G)
 // one workgroup per group of KO_GROUP queries: their keys are the contiguous range [lo, hi) of keys_in (a key with bit 63 set in a
 // window's slots is padding: skipped; elsewhere duplicates keep their flag and their place in the order).
 // P_out (optional): the number of keys written, set by workgroup 0.
+// Slots (slot_buckets != 0; an index sharded by hash range): the buckets are dealt to the ranks in runs of slot_buckets -- a
+// rank's window of the hash space -- and the keys of run w go to keys_out + w * slot_cap, its slot of slot_cap keys in the sender's
+// exchange buffer (slot_counts[w] = how many it has; a key beyond the slot's capacity is dropped and the count says so).
 __global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_t* __restrict__ keys_in, const uint64_t* __restrict__ offsets,
                                                       uint64_t base, uint32_t stride, uint32_t B, uint32_t qb,
-                                                      uint64_t* __restrict__ keys_out, unsigned long long* P_out)
+                                                      uint64_t* __restrict__ keys_out, unsigned long long* P_out,
+                                                      uint32_t slot_buckets = 0, uint64_t slot_cap = 0, unsigned long long* slot_counts = nullptr)
 {
     __shared__ uint32_t s_pos[KO_MAX_BUCKETS];
+    __shared__ uint32_t s_before[KO_MAX_BUCKETS + 1];
     __shared__ uint32_t s_w[4];
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
     const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
@@ -84,8 +89,24 @@ __global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_
     const uint32_t before = ko_block_excl_scan(mine, tid, s_w, &total);
     if (tid < ko.nb) s_pos[tid] = before + gload_u32(ko.cnt + (size_t)tid * G + g);
     if (P_out && g == 0 && tid == 0) *P_out = total;
+    if (slot_buckets) {
+        if (tid < ko.nb) s_before[tid] = before;
+        if (tid == 0) s_before[ko.nb] = total;
+        __syncthreads();
+        if (tid < ko.nb) {
+            const uint32_t w = tid / slot_buckets;
+            s_pos[tid] -= s_before[w * slot_buckets];                 // position inside the slot; the slot's base is added per key
+            if (g == 0 && tid % slot_buckets == 0u && slot_counts) slot_counts[w] = s_before[(w + 1u) * slot_buckets] - s_before[w * slot_buckets];
+        }
+    }
     __syncthreads();
     const uint32_t bmask = ko.nb - 1u;
+    auto place = [&](uint64_t key) {
+        const uint32_t b = ((uint32_t)(key >> qb) >> ko.bshift) & bmask;
+        const uint32_t at = atomicAdd(&s_pos[b], 1u);
+        if (!slot_buckets) keys_out[at] = key;
+        else if (at < slot_cap) keys_out[(size_t)(b / slot_buckets) * slot_cap + at] = key;
+    };
     if (stride) {
         // windowed keys: query q's are the first ko.qn[q] of its `stride` slots -- a wave per query
         const uint32_t lane = tid & 63u;
@@ -93,9 +114,7 @@ __global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_
             const uint32_t nq = gload_u32(ko.qn + q);
             const uint64_t* in = keys_in + (size_t)q * stride;
             for (uint32_t i = lane; i < nq; i += 64u) {
-                const uint64_t key = gload_u64(in + i);
-                const uint32_t at = atomicAdd(&s_pos[((uint32_t)(key >> qb) >> ko.bshift) & bmask], 1u);
-                keys_out[at] = key;
+                place(gload_u64(in + i));
             }
         }
         return;
@@ -108,9 +127,7 @@ __global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
             if (key[u] == ~0ull) continue;
-            const uint32_t h = (uint32_t)(key[u] >> qb);
-            const uint32_t at = atomicAdd(&s_pos[(h >> ko.bshift) & bmask], 1u);
-            keys_out[at] = key[u];
+            place(key[u]);
         }
     }
 }

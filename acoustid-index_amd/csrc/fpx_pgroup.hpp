@@ -71,15 +71,17 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     const uint32_t active = g->active, nactive = (uint32_t)__popc(active);
     const bool any_dead = g->any_dead != 0u;
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_reads = 0;
-    const uint64_t P = a.P_dev ? min((uint64_t)*a.P_dev, a.P) : a.P;
+    // (blockIdx.y: the key slot -- a rank of a hash-sharded index probes the keys every source sent it, a slot per source)
+    const uint64_t* pairs = a.pairs + (size_t)blockIdx.y * a.slot_stride;
+    const uint64_t P = a.P_dev ? min((uint64_t)a.P_dev[blockIdx.y], a.P) : a.P;
 
     const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)FK_WG * a.rounds;
     for (uint32_t round = 0; round < a.rounds; ++round) {
         const uint64_t p = wg_base + (uint64_t)round * FK_WG + tid;
         bool valid = p < P;
-        const uint64_t key = valid ? gload_u64(a.pairs + p) : 0ull;
+        const uint64_t key = valid ? gload_u64(pairs + p) : 0ull;
         // dedupSorted, src/Index.zig:489-499: flagged by k_make_keys_dedup, or found by looking back
-        if (valid && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(a.pairs, p, key, a.qb, a.key_skip))) valid = false;
+        if (valid && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(pairs, p, key, a.qb, a.key_skip))) valid = false;
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint32_t blocks_before = QS ? my_blocks : 0u, docs_before = QS ? my_docs : 0u;
         // a hash-window slice of the group (the index sharded by hash range): the other hashes are another rank's probes

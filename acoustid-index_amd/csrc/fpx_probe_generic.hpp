@@ -37,7 +37,8 @@ struct ProbeArgs {
     // per-QUERY scan statistics (the reference observes num_blocks / num_docs per hash, src/FileSegment.zig:177-178; a host that
     // keeps fpindex_scanned_*_per_hash per request needs them per query): qstats[q] += blocks | docs << 32, or null
     unsigned long long* qstats = nullptr;
-    const unsigned long long* P_dev = nullptr;
+    const unsigned long long* P_dev = nullptr;  // the number of pairs lives on the device (a rank's compacted share of the keys; [slots] of them): P is their capacity
+    uint64_t slot_stride = 0;                   // k_probe_group / _pgroup with gridDim.y slots of keys: slot y = pairs + y * slot_stride, P_dev[y] keys
     uint32_t rec32 = 0;                         // BINNED: the bins hold 4-byte records (bin_record32, fpx_partition.hpp)   // the number of pairs lives on the device (a rank's compacted share of the keys): P is their capacity
 };
 

@@ -1659,18 +1659,196 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
     return rc;
 }
 
+// ---- the same protocol with the KEYS routed instead of the hashes replicated ----------------------------------------
+// fpx_shard_probe wants the whole batch's hashes on every rank: at N ranks every query hash crosses a link N - 1 times and every
+// rank reads all of them.  Routed: rank r uploads only ITS share of the batch -- the queries of the bins it will finish --, makes
+// their keys (dedupSorted where the keys are made, query numbers of the global batch) and orders them by (hash bucket, query) with
+// the counting sort of fpx_keyorder.hpp, whose top buckets ARE the ranks' windows: window w's keys leave for rank w's slot
+// [w][key_cap] of the send buffer.  One all-to-all of the slots (+ their counts), and rank w probes the N slots it received -- the
+// keys of ITS window from every source, a launch per source.  A query hash crosses one link once (as an 8-byte key), whatever N.
+int shard_keys_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, uint32_t B_global,
+                    uint64_t* d_keys_send, uint64_t key_cap, unsigned long long* d_key_counts, uint64_t* needed_key_cap)
+{
+    if (needed_key_cap) *needed_key_cap = 0;
+    if (qb->ctx != ctx) { set_error("query batch belongs to a different context"); return FPX_E_INVAL; }
+    if (world == 0 || world > KO_MAX_BUCKETS || (world & (world - 1u)) != 0u) { set_error("fpx_shard_keys: the number of ranks must be a power of two <= %u", KO_MAX_BUCKETS); return FPX_E_INVAL; }
+    const uint32_t bpr = (uint32_t)shard_bins_per_rank(B_global, world);
+    const uint32_t q_lo = std::min<uint64_t>(B_global, (uint64_t)rank * bpr << SHARD_BQ), q_hi = std::min<uint64_t>(B_global, (uint64_t)(rank + 1u) * bpr << SHARD_BQ);
+    const uint32_t B = qb->B;
+    if (B != q_hi - q_lo) { set_error("fpx_shard_keys: rank %u of %u finishes queries [%u, %u) of the batch of %u: its share must hold exactly those %u (got %u)", rank, world, q_lo, q_hi, B_global, q_hi - q_lo, B); return FPX_E_INVAL; }
+    const unsigned qbits = bits_for(B_global);
+    if (qbits > 24u) { set_error("fpx_shard_keys: at most 2^24 queries"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(ctx->device));
+    if (B == 0) { FPX_HIP(hipMemset(d_key_counts, 0, (size_t)world * sizeof(unsigned long long))); return FPX_OK; }
+    const uint64_t* offsets = qb->offsets.data();
+    for (uint32_t q = 0; q < B; ++q) {
+        const uint64_t len = offsets[q + 1] - offsets[q];
+        if (len > DEDUP_MAX) { set_error("fpx_shard_keys: queries of more than %u hashes (use fpx_probe_resident)", DEDUP_MAX); return FPX_E_INVAL; }
+        const fpx_opts& o = qb->opts[q];
+        if ((o.has_min_score ? o.min_score : (uint32_t)((len + 19) / 20)) <= 2u) {
+            set_error("fpx_shard_keys: query %u has a score floor of 1 or 2: this batch takes the record protocol (fpx_probe_resident)", q_lo + q); return FPX_E_INVAL;
+        }
+    }
+    Workspace* ws = ws_acquire(ctx);
+    if (!ws) return FPX_E_NOMEM;
+    auto body = [&]() -> int {
+        int rc;
+        hipStream_t st = ws->stream;
+        const uint64_t P = offsets[B];
+        if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
+        KeyOrder ko{};
+        if ((rc = key_order_setup(ws, B, 0u, 8u, &ko, nullptr, st))) return rc;
+        if (ko.nb < world) { set_error("fpx_shard_keys: the batch is too large for %u ranks", world); return FPX_E_INVAL; }
+        hipLaunchKernelGGL(k_make_keys_dedup, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits, 0ull, ws->d_keys[0],
+                           (unsigned long long*)nullptr, (unsigned int*)nullptr, 0u, ko, q_lo);
+        hipLaunchKernelGGL(k_bucket_scan, dim3(ko.nb), dim3(256), 0, st, ko, (B + KO_GROUP - 1u) / KO_GROUP);
+        hipLaunchKernelGGL(k_scatter_keys, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, (const uint64_t*)ws->d_keys[0], (const uint64_t*)qb->d_offsets, 0ull, 0u, B, qbits,
+                           d_keys_send, (unsigned long long*)nullptr, ko.nb / world, key_cap, d_key_counts);
+        FPX_HIP(hipGetLastError());
+        std::vector<unsigned long long> hc(world);
+        FPX_HIP(hipMemcpyAsync(hc.data(), d_key_counts, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        FPX_HIP(hipStreamSynchronize(st));
+        unsigned long long worst = 0;
+        for (unsigned long long c : hc) worst = std::max(worst, c);
+        if (worst > key_cap) {
+            if (needed_key_cap) *needed_key_cap = worst * 17 / 16 + 256;
+            set_error("fpx_shard_keys: a window takes %llu keys, the send buffer has room for %llu per window", worst, (unsigned long long)key_cap);
+            return FPX_E_AGAIN;
+        }
+        return FPX_OK;
+    };
+    const int rc = body();
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    ws_release(ctx, ws);
+    return rc;
+}
+
+// the N key slots a rank received (slot s = the keys of this rank's window from source s, d_key_counts[s] of them) -> the batch's bins
+int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t key_cap, const unsigned long long* d_key_counts, uint32_t world, uint32_t B_global,
+                          uint32_t timeout_ms, uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats)
+{
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (needed_cell_cap) *needed_cell_cap = 0;
+    const uint32_t B = B_global;
+    if (B == 0) return FPX_OK;
+    if (snap->n_group == 0 || snap->n_solo != 0 || snap->n_file != 0 || snap->n_mem != 0) {
+        set_error("fpx_shard_probe_keys: the snapshot is not made of groups of direct-addressed segments alone (use fpx_probe_resident)"); return FPX_E_INVAL;
+    }
+    const unsigned qbits = bits_for(B);
+    if (qbits > 24u) { set_error("fpx_shard_probe_keys: at most 2^24 queries"); return FPX_E_INVAL; }
+    const uint32_t ncells = (uint32_t)shard_bins_per_rank(B, world) * world;
+    if (ncells > (1u << 21)) { set_error("fpx_shard_probe_keys: too many bins"); return FPX_E_INVAL; }
+    FPX_HIP(hipSetDevice(snap->ctx->device));
+    Workspace* ws = ws_acquire(snap->ctx);
+    if (!ws) return FPX_E_NOMEM;
+    auto body = [&]() -> int {
+        int rc;
+        hipStream_t st = ws->stream;
+        const double t_start = now_ms();
+        __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);
+        const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
+        const size_t cell_words = (size_t)ncells * BIN_STRIDE, words = cell_words + LEAN_STAT_WORDS + 16;
+        if (words > ws->cap_cells) {
+            if (ws->d_cells) (void)hipFree(ws->d_cells);
+            if (ws->h_cells) (void)hipHostFree(ws->h_cells);
+            ws->d_cells = nullptr; ws->h_cells = nullptr; ws->cap_cells = 0;
+            FPX_HIP(hipMalloc(&ws->d_cells, words * sizeof(uint32_t)));
+            FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_cells), (LEAN_STAT_WORDS + 16) * sizeof(uint32_t)));
+            ws->cap_cells = words;
+        }
+        uint32_t* d_stats32 = ws->d_cells + cell_words;
+        if (ws->cap_hits == 0 && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)1 << 22))) return rc;
+        static const bool rec32_enabled = [] { const char* e = getenv("FPX_REC32"); return e ? atoi(e) != 0 : true; }();
+        uint64_t rec_cap = cell_cap;
+        for (int attempt = 0;; ++attempt) {
+            const uint32_t rec32 = rec32_enabled && !__atomic_load_n(&snap->rec32_refused, __ATOMIC_RELAXED) &&
+                                   snap->max_doc_declared < (0xFFFFFFFFu >> SHARD_BQ) ? 1u : 0u;
+            rec_cap = cell_cap << rec32;
+            FPX_HIP(hipMemsetAsync(ws->d_cells, 0, words * sizeof(uint32_t), st));
+            FPX_HIP(hipMemsetAsync(ws->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), st));
+            ProbeArgs a;
+            a.segs = snap->d_direct; a.P = key_cap; a.qb = qbits; a.ppw = 16u; a.bsp = 0u;
+            a.hits = ws->d_hits[1]; a.hit_cap = ws->cap_hits; a.counters = ws->d_counters;
+            a.def_list = nullptr; a.def_count = nullptr; a.def_cap = 0; a.ctr_off = 0; a.cancel = cancel;
+            a.lean_stats = reinterpret_cast<unsigned long long*>(d_stats32);
+            a.key_skip = KEY_SKIP_FLAGGED;
+            a.bins = d_send; a.bin_cap = rec_cap; a.bin_count = ws->d_cells; a.bin_shift = SHARD_BQ; a.rec32 = rec32;
+            const uint64_t wgs = (key_cap + FK_WG - 1) / FK_WG;
+            a.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs * world / 8192));
+            const uint64_t per_wg = (uint64_t)FK_WG * a.rounds;
+            FPX_HIP(hipEventRecord(ws->ev_probe0, st));
+            // ONE launch over the N slots (blockIdx.y = the source): every slot's fill level lives on the device
+            a.pairs = d_keys_recv; a.slot_stride = key_cap; a.P_dev = d_key_counts;
+            for (const GroupDesc& gd : snap->h_group) {
+                const GroupArgs gargs{gd, snap->d_direct};
+                const dim3 grid((uint32_t)((key_cap + per_wg - 1) / per_wg), world);
+                const Group* grp = snap->groups[&gd - snap->h_group.data()].get();
+                launch_probe_group(grp->packed, grp->ns == 8u, true, false, grid, st, a, gargs);
+            }
+            FPX_HIP(hipEventRecord(ws->ev_probe1, st));
+            BinArgs hb{};
+            hb.bins = d_send; hb.bin_cap = rec_cap; hb.bin_count = ws->d_cells; hb.shift = SHARD_BQ; hb.nbins = std::min<uint32_t>(ncells, MAX_SBINS);
+            hb.rec32 = rec32; hb.counters = ws->d_counters;
+            if (ncells <= MAX_SBINS)
+                hipLaunchKernelGGL(k_bin, dim3(64), dim3(256), 0, st, hb, (const uint64_t*)ws->d_hits[1], (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
+            else
+                hipLaunchKernelGGL(k_bin_each, dim3(64), dim3(256), 0, st, hb, (const uint64_t*)ws->d_hits[1], (const unsigned long long*)&ws->d_counters[CTR_HITS], (uint64_t)ws->cap_hits);
+            hipLaunchKernelGGL(k_cell_counts, dim3((ncells + 255) / 256), dim3(256), 0, st, (const unsigned int*)ws->d_cells, ncells, d_send_counts, ws->d_counters,
+                               rec32 << 31);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipMemcpyAsync(ws->h_counters, ws->d_counters, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipMemcpyAsync(ws->h_cells, d_stats32, (LEAN_STAT_WORDS + 16) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            FPX_SYNC(ws);
+            if (ws->h_counters[CTR_BINFAIL] == 3 && attempt < 3) { __atomic_store_n(&snap->rec32_refused, 1u, __ATOMIC_RELAXED); continue; }
+            if (ws->h_counters[CTR_HITS] > ws->cap_hits) {
+                if (attempt >= 3) { set_error("fpx_shard_probe_keys: misc buffer overflow persists"); return FPX_E_DEVICE; }
+                if ((rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)ws->h_counters[CTR_HITS] + 1024))) return rc;
+                continue;
+            }
+            break;
+        }
+        if (ws->h_counters[CTR_TOTAL] > rec_cap) {
+            const uint64_t per_cell = rec_cap / std::max<uint64_t>(cell_cap, 1);
+            if (needed_cell_cap) *needed_cell_cap = (ws->h_counters[CTR_TOTAL] * 17 / 16 + 128 + per_cell - 1) / std::max<uint64_t>(per_cell, 1);
+            set_error("fpx_shard_probe_keys: a bin holds %llu records, the send buffer has room for %llu per bin", (unsigned long long)ws->h_counters[CTR_TOTAL],
+                      (unsigned long long)rec_cap);
+            return FPX_E_AGAIN;
+        }
+        if (stats) {
+            const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
+            unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0;
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
+            stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS];
+            stats->algorithmic_bytes = blocks * 512ull; stats->probe_kernel_bytes = blocks * 512ull;
+            stats->probe_kernel_fetched_bytes = dreads * 64ull; stats->probe_kernel_ms = ms; stats->total_gpu_ms = ms; stats->probe_launches = 1;
+            stats->path_flags = 1u | 4u | 8u | 16u;
+        }
+        return FPX_OK;
+    };
+    const int rc = body();
+    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    ws_release(snap->ctx, ws);
+    return rc;
+}
+
 int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t rank, const uint64_t* d_recv, uint64_t cell_cap, const uint32_t* d_recv_counts,
                      uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, uint32_t* first_query, uint32_t* num_queries,
-                     uint64_t* needed_cell_cap)
+                     uint64_t* needed_cell_cap, uint32_t B_global)
 {
+    // B_global != 0: `qb` is this rank's SHARE of the batch of B_global queries -- exactly the queries it finishes (fpx_shard_keys)
     if (needed_cell_cap) *needed_cell_cap = 0;
     if (qb->ctx != ctx) { set_error("query batch belongs to a different context"); return FPX_E_INVAL; }
-    const uint32_t B = qb->B;
+    const uint32_t B = B_global ? B_global : qb->B;
     const uint32_t bpr = (uint32_t)shard_bins_per_rank(B, world);
     const uint32_t q_lo = std::min<uint64_t>(B, (uint64_t)rank * bpr << SHARD_BQ), q_hi = std::min<uint64_t>(B, (uint64_t)(rank + 1u) * bpr << SHARD_BQ);
     if (first_query) *first_query = q_lo;
     if (num_queries) *num_queries = q_hi - q_lo;
+    if (B_global && qb->B != q_hi - q_lo) { set_error("fpx_shard_score_share: the share holds %u queries, rank %u of %u finishes %u", qb->B, rank, world, q_hi - q_lo); return FPX_E_INVAL; }
     if (q_hi == q_lo) return FPX_OK;
+    // the options by BATCH query number (the kernels index them so): a share's array starts at the rank's first query
+    const uint32_t* d_opts_b = B_global ? qb->d_opts - (size_t)q_lo * 4 : qb->d_opts;
     const uint32_t nq = q_hi - q_lo;
     const unsigned qbits = bits_for(B);
     FPX_HIP(hipSetDevice(ctx->device));
@@ -1694,7 +1872,7 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ra
         const uint32_t sbf = 32u - qbits;
         // (k_finish walks the batch's queries from q_lo on: the view's first query is q_lo)
         auto finish = [&](const uint64_t* cands, uint64_t C) {
-            hipLaunchKernelGGL(k_finish, dim3((nq + 127) / 128), dim3(128), 0, st, cands, C, (const uint32_t*)qb->d_opts, nq, sbf, 0,
+            hipLaunchKernelGGL(k_finish, dim3((nq + 127) / 128), dim3(128), 0, st, cands, C, (const uint32_t*)d_opts_b, nq, sbf, 0,
                                ws->d_out, out_cap, ws->d_out_n, (const uint64_t*)(d_qcand + (size_t)q_lo * QCAND_SLOTS), (const uint32_t*)(d_qcand_n + q_lo),
                                (unsigned long long*)nullptr, q_lo);
         };
@@ -1705,7 +1883,7 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ra
         ScoreBinArgs sa{};
         sa.bins = d_recv; sa.bin_cap = cell_cap; sa.rec_mode = 2u; sa.bin_count = d_recv_counts; sa.nsrc = world; sa.src_stride = (uint64_t)bpr * cell_cap;
         sa.count_stride = bpr; sa.count_step = 1u; sa.bq = SHARD_BQ; sa.bin_base = rank * bpr; sa.B = B;
-        sa.opts = qb->d_opts; sa.sb = sbf; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
+        sa.opts = d_opts_b; sa.sb = sbf; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
         sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
         const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << SHARD_BQ) * 8u;
         const uint32_t my_bins = (nq + (1u << SHARD_BQ) - 1u) >> SHARD_BQ;

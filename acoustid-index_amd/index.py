@@ -583,6 +583,46 @@ def shard_score(ctx, qb, world, rank, d_recv_ptr, cell_cap, d_recv_counts_ptr, o
     return out, out_n, int(first.value), int(first.value) + int(num.value)
 
 
+def shard_keys(ctx, qb_share, world, rank, num_queries_global, d_keys_ptr, key_cap, d_key_counts_ptr):
+    """fpx_shard_keys: the keys of this rank's share of the batch, dealt to the ranks' windows.  Returns 0, or the key_cap it needs."""
+    from ._lib import FPX_E_AGAIN
+    need = C.c_uint64(0)
+    rc = lib().fpx_shard_keys(ctx.h, qb_share.h, world, rank, num_queries_global, C.c_void_p(d_keys_ptr), int(key_cap), C.c_void_p(d_key_counts_ptr), C.byref(need))
+    if rc == FPX_E_AGAIN:
+        return int(need.value)
+    check(rc)
+    return 0
+
+
+def shard_probe_keys(reader, d_keys_ptr, key_cap, d_key_counts_ptr, world, num_queries_global, d_send_ptr, cell_cap, d_send_counts_ptr, timeout_ms=0):
+    """fpx_shard_probe_keys: the received key slots -> the batch's bins.  Returns (stats, 0) or (None, needed_cell_cap)."""
+    from ._lib import FPX_E_AGAIN
+    st = Stats()
+    need = C.c_uint64(0)
+    rc = lib().fpx_shard_probe_keys(reader.snapshot.h, C.c_void_p(d_keys_ptr), int(key_cap), C.c_void_p(d_key_counts_ptr), world, num_queries_global, timeout_ms,
+                                    C.c_void_p(d_send_ptr), int(cell_cap), C.c_void_p(d_send_counts_ptr), C.byref(need), C.byref(st))
+    if rc == FPX_E_AGAIN:
+        return None, int(need.value)
+    check(rc)
+    return st, 0
+
+
+def shard_score_share(ctx, qb_share, world, rank, num_queries_global, d_recv_ptr, cell_cap, d_recv_counts_ptr, out=None, out_n=None, timeout_ms=0):
+    """fpx_shard_score_share: the final results of the share's queries -- out [share.B, cap, 2], out_n [share.B].
+    Returns (out, out_n, q_lo, q_hi) with q_lo .. q_hi the share's place in the global batch."""
+    from ._lib import FPX_E_AGAIN
+    if out is None:
+        out = np.zeros((max(1, qb_share.B), qb_share.cap, 2), np.uint32)
+        out_n = np.zeros(max(1, qb_share.B), np.uint32)
+    first, num, need = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    rc = lib().fpx_shard_score_share(ctx.h, qb_share.h, world, rank, num_queries_global, C.c_void_p(d_recv_ptr), int(cell_cap), C.c_void_p(d_recv_counts_ptr),
+                                     timeout_ms, _p(out), qb_share.cap, _p(out_n), C.byref(first), C.byref(num), C.byref(need))
+    if rc == FPX_E_AGAIN and need.value:
+        raise ShardCellsTooSmall(int(need.value))
+    check(rc)
+    return out, out_n, int(first.value), int(first.value) + int(num.value)
+
+
 def score_partial(ctx, qb, d_records_ptr, num_records, d_out_ptr, d_out_n_ptr, timeout_ms=0):
     """stage 2 of hash-range sharding (fpx_score_partial): received records -> per-query partial tables in HBM"""
     check(lib().fpx_score_partial(ctx.h, qb.h, d_records_ptr, int(num_records), timeout_ms, d_out_ptr, qb.cap, d_out_n_ptr))

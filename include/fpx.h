@@ -331,6 +331,33 @@ int fpx_shard_score(fpx_ctx *ctx, const fpx_query_batch *qb, uint32_t world, uin
                     const void *d_recv_counts, uint32_t timeout_ms, fpx_result *out, uint32_t out_cap, uint32_t *out_n,
                     uint32_t *first_query, uint32_t *num_queries, uint64_t *needed_cell_cap /* may be null */);
 
+/* The same protocol with the KEYS routed instead of the hashes replicated -- what scales: fpx_shard_probe wants the whole batch's
+ * hashes on every rank (at N ranks every query hash crosses a link N - 1 times and every rank reads all of them).  Here rank r
+ * uploads only ITS share of the batch -- `qb_share` holds exactly the queries it finishes, [r bpr 8, (r + 1) bpr 8) of the
+ * batch of num_queries_global --, and
+ *   fpx_shard_keys         makes their keys (dedupSorted where the keys are made; query numbers of the global batch) and deals them
+ *                          to the ranks by the hash's window: d_keys_send = [world][key_cap] 8-byte keys, in (hash bucket, query)
+ *                          order inside a slot, d_key_counts = [world] uint64 (both DEVICE memory).  FPX_E_AGAIN: a slot outgrew
+ *                          key_cap -- *needed_key_cap says what to allocate
+ *   (the caller's all-to-all #1: slot w and its count travel to rank w; ~1/8 of a query's hashes x 8 bytes per link)
+ *   fpx_shard_probe_keys   the N slots this rank received (slot s = the keys of its window from source s) -> the batch's bins, exactly
+ *                          as fpx_shard_probe leaves them (same d_send / d_send_counts, same FPX_E_AGAIN)
+ *   (all-to-all #2: the bins, as above)
+ *   fpx_shard_score_share  fpx_shard_score with the rank's share in place of the whole batch: the final results of ITS queries,
+ *                          out[i] for i = query - first_query.
+ * A query hash crosses one link once, as a key, whatever N; the results end on the rank the query came from.  world must be a
+ * power of two (the windows are the top bits of the hash).  Snapshots that are not groups of slices alone, queries of more than
+ * 2048 hashes and floors of 1 or 2: FPX_E_INVAL (the record protocol answers those). */
+int fpx_shard_keys(fpx_ctx *ctx, const fpx_query_batch *qb_share, uint32_t world, uint32_t rank, uint32_t num_queries_global,
+                   void *d_keys_send, uint64_t key_cap, void *d_key_counts, uint64_t *needed_key_cap);
+int fpx_shard_probe_keys(fpx_snapshot *snap, const void *d_keys_recv, uint64_t key_cap, const void *d_key_counts_recv, uint32_t world,
+                         uint32_t num_queries_global, uint32_t timeout_ms, void *d_send, uint64_t cell_cap, void *d_send_counts,
+                         uint64_t *needed_cell_cap, fpx_stats *stats);
+int fpx_shard_score_share(fpx_ctx *ctx, const fpx_query_batch *qb_share, uint32_t world, uint32_t rank, uint32_t num_queries_global,
+                          const void *d_recv, uint64_t cell_cap, const void *d_recv_counts, uint32_t timeout_ms,
+                          fpx_result *out, uint32_t out_cap, uint32_t *out_n, uint32_t *first_query, uint32_t *num_queries,
+                          uint64_t *needed_cell_cap /* may be null */);
+
 /* ---- device-side segment build and merge -------------------------------------------------------
  * fpx_segment_build: filefmt.writeBlocks + BlockEncoder (src/filefmt.zig:94-138, src/block.zig:438-567) run on the GPU
  * over caller-provided items (hash << 32 | id); the result is a resident FileSegment whose bytes equal what the

@@ -29,9 +29,8 @@ def _world_data(fpx, rng, S, per, H, seed):
     return data
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
-    import torch
+def _sharded_world(world, monkeypatch):
+    """the unsharded index (GPU + oracle) and one reader per 'rank': the rank's window of every segment, cut on the device"""
     from fpx_testlib import fpx, oracle, Pair
     monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
     monkeypatch.setenv("FPX_FUSE_MIN", "1")
@@ -58,6 +57,102 @@ def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
             whole.release()
         readers.append(fpx.IndexReader(fpx.Segments(ctx, segs)))
         assert all(g.grouped for g in segs), "the slices did not form a group with their window"
+    return fpx, ctx, full, readers, (seed, H, per, S, max_doc)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_routed_keys_protocol_matches_unsharded_and_oracle(world, monkeypatch):
+    """The protocol that scales (fpx_shard_keys / fpx_shard_probe_keys / fpx_shard_score_share): every 'rank' holds only ITS share of
+    the batch, makes the keys of those queries and deals them to the ranks' windows; a rank probes the key slots it received and
+    drops the records into the batch's bins; the bins travel back to the rank the queries came from.  Results, the counters' sums
+    and -- per query -- the oracle."""
+    import torch
+    fpx, ctx, full, readers, (seed, H, per, S, max_doc) = _sharded_world(world, monkeypatch)
+    B = 150
+    flat, off, _ = fpx.synth.make_queries(seed, 3, B, per * S, H, query_len=300, dist=1)
+    flat = flat.copy()
+    flat[5] = flat[4]                                                 # a duplicate hash inside a query
+    bpr = fpx.shard_bins_per_rank(B, world)
+    for opts in (fpx.http_options(), fpx.SearchOptions(500, 3, 10)):
+        # ---- every rank's share of the batch: the queries of the bins it finishes
+        shares = []
+        for r in range(world):
+            q_lo, q_hi = min(B, r * bpr * 8), min(B, (r + 1) * bpr * 8)
+            sub_off = (off[q_lo:q_hi + 1] - off[q_lo]).astype(np.uint64)
+            shares.append(fpx.QueryBatch(ctx, options=opts, flat=(np.ascontiguousarray(flat[int(off[q_lo]):int(off[q_hi])]), sub_off)))
+        # ---- keys, dealt to the windows (a slot too small on purpose first: the call says what it needs)
+        key_cap = 64
+        while True:
+            ks, need_max = [], 0
+            for r in range(world):
+                keys = torch.zeros((world, key_cap), dtype=torch.int64, device="cuda")
+                kcnt = torch.zeros((world,), dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                need_max = max(need_max, fpx.shard_keys(ctx, shares[r], world, r, B, keys.data_ptr(), key_cap, kcnt.data_ptr()))
+                ks.append((keys, kcnt))
+            if need_max == 0:
+                break
+            key_cap = need_max
+        assert key_cap > 64
+        # every key sits in its window's slot, carries a query of the sender's share, and the slots hold every unique query hash once
+        total_keys = 0
+        for r in range(world):
+            keys, kcnt = ks[r][0].cpu().numpy().view(np.uint64), ks[r][1].cpu().numpy()
+            qbits = max(1, int(np.ceil(np.log2(B)))) if B > 1 else 0
+            for w in range(world):
+                kk = keys[w, :int(kcnt[w])]
+                live = kk[(kk >> np.uint64(63)) == 0]
+                hh = ((live >> np.uint64(qbits)) & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+                qq = (live & np.uint64((1 << qbits) - 1)).astype(np.int64)
+                assert ((hh * world) >> np.uint64(32) == w).all()
+                assert ((qq >= min(B, r * bpr * 8)) & (qq < min(B, (r + 1) * bpr * 8))).all()
+                total_keys += len(live)
+        assert total_keys == sum(len(np.unique(flat[int(off[q]):int(off[q + 1])])) for q in range(B))
+        # ---- all-to-all #1, probes (the bins), all-to-all #2, finish
+        cell_cap = 16
+        for attempt in range(4):
+            sends, need_max = [], 0
+            tot = [0, 0, 0, 0]
+            for w in range(world):
+                rk = torch.stack([ks[r][0][w] for r in range(world)]).contiguous()
+                rc = torch.stack([ks[r][1][w] for r in range(world)]).contiguous()
+                send = torch.zeros((world, bpr, cell_cap), dtype=torch.int64, device="cuda")
+                counts = torch.zeros((world, bpr), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                st, need = fpx.shard_probe_keys(readers[w], rk.data_ptr(), key_cap, rc.data_ptr(), world, B, send.data_ptr(), cell_cap, counts.data_ptr())
+                if st is None:
+                    need_max = max(need_max, need)
+                    continue
+                sends.append((send, counts))
+                for i, v in enumerate((st.scanned_blocks, st.scanned_docs, st.probes, st.hits)):
+                    tot[i] += v
+            if need_max == 0:
+                break
+            cell_cap = need_max
+        assert need_max == 0
+        out = np.zeros((B, shares[0].cap, 2), np.uint32)
+        out_n = np.zeros(B, np.uint32)
+        for d in range(world):
+            recv = torch.stack([sends[r][0][d] for r in range(world)]).contiguous()
+            rc = torch.stack([sends[r][1][d] for r in range(world)]).contiguous()
+            torch.cuda.synchronize()
+            o, n, q_lo, q_hi = fpx.shard_score_share(ctx, shares[d], world, d, B, recv.data_ptr(), cell_cap, rc.data_ptr())
+            assert (q_lo, q_hi) == (min(B, d * bpr * 8), min(B, (d + 1) * bpr * 8))
+            out[q_lo:q_hi], out_n[q_lo:q_hi] = o[:q_hi - q_lo], n[:q_hi - q_lo]
+        got = fpx.results_to_lists(out, out_n)
+        whole = fpx.QueryBatch(ctx, options=opts, flat=(flat, off))
+        o2, n2, st_full = fpx.search_resident(full.reader, whole)
+        assert got == fpx.results_to_lists(o2, n2)
+        assert tuple(tot) == (st_full.scanned_blocks, st_full.scanned_docs, st_full.probes, st_full.hits)
+        for q in range(B):
+            want = full.osnap.search(flat[int(off[q]):int(off[q + 1])], opts.max_results, opts.min_score, opts.min_score_pct)
+            assert got[q] == want, (q, got[q][:4], want[:4])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_cells_of_hash_windows_match_unsharded_and_oracle(world, monkeypatch):
+    import torch
+    fpx, ctx, full, readers, (seed, H, per, S, max_doc) = _sharded_world(world, monkeypatch)
 
     flat, off, _ = fpx.synth.make_queries(seed, 3, 150, per * S, H, query_len=300, dist=1)
     flat = flat.copy()

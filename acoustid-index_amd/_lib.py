@@ -95,6 +95,8 @@ SIGNATURES = {
     "fpx_sharded_snapshot_retain": (None, [_vp]),
     "fpx_sharded_snapshot_release": (None, [_vp]),
     "fpx_sharded_snapshot_num_devices": (_u32, [_vp]),
+    "fpx_segment_create_file_windows": (C.c_int, [_vp, _u32, _vp, _sz, _u32, _vp, _u32, _u32, _u32, _u64, _vp, _vp, _u32, _vp]),
+    "fpx_sharded_snapshot_create_windows": (C.c_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp)]),
     "fpx_sharded_search": (C.c_int, [_vp, _vp, _u32, C.POINTER(Opts), _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(Stats)]),
     "fpx_sharded_search_batch": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_host_alloc": (C.c_int, [_sz, C.POINTER(_vp)]),

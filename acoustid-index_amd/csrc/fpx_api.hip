@@ -703,7 +703,8 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
                     const Group* g = sg->home.get();
                     GroupDesc gd{};
                     gd.lines = g->d_lines; gd.line0 = g->line0; gd.nseg = g->nseg; gd.win_lo = g->win_lo; gd.win_hi = g->win_hi;
-                    gd.ext_tab = g->d_ext_tab; gd.chunk0 = g->chunk0; gd.nchunks = g->nchunks;       // (the packed form's)
+                    gd.ext_tab = g->d_ext_tab; gd.chunk0 = g->chunk0; gd.nchunks = g->nchunks; gd.gmin = g->gmin;       // (the packed form's)
+                    gd.lo_all = 0u; gd.hi_all = 0xFFFFFFFFu;
                     for (uint32_t j = 0; j < FUSE_MAX; ++j) { gd.min_doc[j] = g->min_doc[j]; gd.first_hash[j] = g->first_hash[j]; gd.last_hash[j] = g->last_hash[j]; }
                     sn->groups.push_back(sg->home);
                     sn->h_group.push_back(gd);
@@ -713,6 +714,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
                 gd.active |= 1u << sg->col;
                 gd.seg_index[sg->col] = i; gd.has_dead[sg->col] = d.num_dead != 0u ? 1u : 0u;
                 gd.any_dead |= gd.has_dead[sg->col];
+                gd.lo_all = std::max(gd.lo_all, gd.first_hash[sg->col]); gd.hi_all = std::min(gd.hi_all, gd.last_hash[sg->col]);
             }
         }
         sn->n_group = (uint32_t)sn->h_group.size(); sn->n_solo = (uint32_t)h_solo.size();

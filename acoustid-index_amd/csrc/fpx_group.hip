@@ -43,6 +43,7 @@ struct BuildArgs {
     uint64_t line_begin;                   // first line of this chunk (= hash >> 5)
     uint32_t nlines;
     uint32_t inline_doubles;
+    uint32_t delta[FUSE_MAX];              // packed form: min_doc of column s - the group's one doc id base (added to every doc word)
 };
 
 struct DevMem {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_group_count(BuildArgs a, uint32_t* __re
     X[i] = (uint32_t)min(x, (uint64_t)0xFFFFFFFFull);
 }
 
-struct LongCopy { const uint32_t* src; uint32_t* dst; uint64_t n; };
+struct LongCopy { const uint32_t* src; uint32_t* dst; uint64_t n; uint32_t skip, delta; };     // words [skip, n) are docs: + delta (the packed form's one base)
 
 // per line again: the directory line, the words, the lists (long ones are queued for k_group_copy_long)
 template <int NS>
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void k_group_fill(BuildArgs a, const uint64_t*
             bool queued = false;
             if (n > LONG_LIST) {
                 const unsigned long long q = atomicAdd(&ctr[0], 1ull);
-                if (q < long_cap) { longq[q] = LongCopy{li, lists + x, n}; queued = true; }
+                if (q < long_cap) { longq[q] = LongCopy{li, lists + x, n, 0u, 0u}; queued = true; }
             }
             if (!queued) for (uint64_t t = 0; t < n; ++t) lists[x + t] = li[t];
             x += n;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void k_group_copy_long(const LongCopy* __restr
     const uint32_t lane = threadIdx.x & 63u;
     for (uint64_t i = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += (uint64_t)gridDim.x * 4u) {
         const LongCopy c = q[i];
-        for (uint64_t t = lane; t < c.n; t += 64u) c.dst[t] = c.src[t];
+        for (uint64_t t = lane; t < c.n; t += 64u) c.dst[t] = c.src[t] + (t >= c.skip ? c.delta : 0u);
     }
 }
 
@@ -319,11 +320,13 @@ __global__ __launch_bounds__(256) void k_pgroup_fill(BuildArgs a, const uint32_t
             cells |= 1ull << (j * NS + s);
             const uint32_t v = a.src[s].primary[rank[s]++];
             const uint32_t at = pos++;
-            if (v == GAP || (v >> 31) == 0u) { put(v); continue; }
+            const uint32_t dl = a.delta[s];                            // (the group's words count from ONE doc id base)
+            if (v == GAP) { put(v); continue; }
+            if ((v >> 31) == 0u) { put(v + dl); continue; }
             const uint32_t* li = a.src[s].extras + ((size_t)(v & 0x7FFFFFFFu) << a.src[s].xshift);
             const uint32_t hdr = li[0];
             if (a.inline_doubles != 0u && at < 32u && is_double(hdr)) {
-                put(li[1]); put(li[2]);
+                put(li[1] + dl); put(li[2] + dl);
                 dfl |= 1u << at; ndbl += 1u;
                 continue;
             }
@@ -333,9 +336,9 @@ __global__ __launch_bounds__(256) void k_pgroup_fill(BuildArgs a, const uint32_t
             bool queued = false;
             if (ln > LONG_LIST) {
                 const unsigned long long q = atomicAdd(&ctr[0], 1ull);
-                if (q < long_cap) { longq[q] = LongCopy{li, ext + x, ln}; queued = true; }
+                if (q < long_cap) { longq[q] = LongCopy{li, ext + x, ln, 1u + T, dl}; queued = true; }
             }
-            if (!queued) for (uint64_t u = 0; u < ln; ++u) ext[x + u] = li[u];
+            if (!queued) for (uint64_t u = 0; u < ln; ++u) ext[x + u] = li[u] + (u >= 1u + T ? dl : 0u);
             x += ln;
         }
     }
@@ -459,7 +462,12 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     const uint32_t hvl = ns == 16u ? 2u : 3u;                                     // log2 hash values per packed line
     const double win_frac = ((double)win_hi - (double)win_lo + 1.0) / 4294967296.0;
     const double per_line = (double)items_total / (4294967296.0 * (segs[0]->own_flags ? win_frac : 1.0)) * (double)(1u << hvl);
-    const bool packed = packed_forced >= 0 ? packed_forced != 0 : per_line >= 6.0;
+    // ... and its words count doc ids from ONE base for all columns (a lane adds a scalar, not its column's entry of a table): the
+    // group's doc ids must span less than 2^31 - 1
+    uint32_t gmin = 0xFFFFFFFFu, gmax = 0u;
+    for (uint32_t j = 0; j < k; ++j) { gmin = std::min(gmin, segs[j]->min_doc_id); gmax = std::max(gmax, segs[j]->max_doc_id); }
+    const bool span_ok = gmax >= gmin && (uint64_t)gmax - gmin < 0x7FFFFFF0ull;
+    const bool packed = span_ok && (packed_forced >= 0 ? packed_forced != 0 : per_line >= 6.0);
     constexpr uint32_t CHUNK_RECS = 1u << 18;                                     // a chunk: 2^26 hash values
     const uint32_t CHUNK_LINES = packed ? (1u << (GROUP_CHUNK_LOG2 - hvl)) : (1u << 21);
     const uint32_t line_words = packed ? GROUP_LINE_WORDS : 2u * ns;
@@ -483,8 +491,10 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     a.nseg = k; a.inline_doubles = inline_doubles ? 1u : 0u;
     for (uint32_t j = 0; j < k; ++j) {
         const Segment* s = segs[j];
-        g->min_doc[j] = s->min_doc_id; g->first_hash[j] = s->first_hash; g->last_hash[j] = s->last_hash;
+        g->min_doc[j] = packed ? gmin : s->min_doc_id; g->first_hash[j] = s->first_hash; g->last_hash[j] = s->last_hash;
+        a.delta[j] = packed ? s->min_doc_id - gmin : 0u;
     }
+    g->gmin = packed ? gmin : 0u;
     hipError_t e = hipMalloc(&g->d_lines, nlines * line_words * 4ull + 64);      // (+ 64: a lane's last 16-byte piece may start in the last line's last word)
     if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
     g->device_bytes = nlines * line_words * 4ull + 64;
@@ -621,8 +631,8 @@ int group_column_items(const Segment* s, uint64_t* items, hipStream_t st)
     const dim3 grid((uint32_t)((g->nlines + 255) / 256));
     auto launch = [&](const uint64_t* ib, uint32_t* co, uint64_t* it) {
         if (g->packed) {
-            if (g->ns == 8u) hipLaunchKernelGGL(k_pgroup_col_items<8>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, (const uint32_t* const*)g->d_ext_tab, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
-            else hipLaunchKernelGGL(k_pgroup_col_items<16>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, (const uint32_t* const*)g->d_ext_tab, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);
+            if (g->ns == 8u) hipLaunchKernelGGL(k_pgroup_col_items<8>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, (const uint32_t* const*)g->d_ext_tab, g->nlines, (uint64_t)g->line0, s->col, g->gmin, ib, co, it);
+            else hipLaunchKernelGGL(k_pgroup_col_items<16>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, (const uint32_t* const*)g->d_ext_tab, g->nlines, (uint64_t)g->line0, s->col, g->gmin, ib, co, it);
             return;
         }
         if (g->ns == 8u) hipLaunchKernelGGL(k_group_col_items<8>, grid, dim3(256), 0, st, (const uint32_t*)g->d_lines, g->nlines, (uint64_t)g->line0, s->col, s->min_doc_id, ib, co, it);

@@ -74,6 +74,8 @@ struct GroupDesc {
     const uint32_t* const* ext_tab;        // packed form: [nchunks] where each chunk's `ext` (overflowing words + lists) starts
     uint32_t line0;                        // first line held (a hash-window slice of the group; 0: the whole hash space)
     uint32_t chunk0, nchunks;              // packed form: first chunk held, chunks held
+    uint32_t gmin;                         // packed form: the words hold doc - gmin, ONE base for all columns (min_doc[s] == gmin)
+    uint32_t lo_all, hi_all;               // every ACTIVE column's [first_hash, last_hash] contains [lo_all, hi_all] (the usual hash: no per-column test)
     uint32_t nseg;                         // columns in use
     uint32_t active;                       // bit s: column s belongs to the snapshot being searched (a group outlives merged-away members)
     uint32_t any_dead;
@@ -165,6 +167,7 @@ struct Group {
     std::vector<uint32_t*> word_chunks, list_chunks;       // one pair per hash-space chunk (the lines hold their addresses)
     // the PACKED form (fpx_pgroup.hpp: a hash's words inside its line) of a dense group
     bool packed = false;
+    uint32_t gmin = 0;                     // packed form: the one doc id base of the group's words
     std::vector<uint32_t*> ext_chunks;     // one per hash-space chunk: overflowing words + lists
     uint32_t** d_ext_tab = nullptr;        // the same addresses in device memory (GroupDesc::ext_tab)
     uint32_t min_doc[FUSE_MAX] = {}, first_hash[FUSE_MAX] = {}, last_hash[FUSE_MAX] = {};

@@ -70,6 +70,8 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     const uint32_t qmask = a.qb >= 32u ? 0xFFFFFFFFu : ((1u << a.qb) - 1u);
     const uint32_t active = g->active, nactive = (uint32_t)__popc(active);
     const bool any_dead = g->any_dead != 0u;
+    // every column of the group belongs to the snapshot and none holds superseded docs: the straight-line walk (below)
+    const bool simple = !any_dead && active == (g->nseg >= 32u ? 0xFFFFFFFFu : ((1u << g->nseg) - 1u));
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_reads = 0;
     // (blockIdx.y: the key slot -- a rank of a hash-sharded index probes the keys every source sent it, a slot per source)
     const uint64_t* pairs = a.pairs + (size_t)blockIdx.y * a.slot_stride;
@@ -101,11 +103,14 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         const uint32_t sh = (h & ((1u << HVL) - 1u)) * (uint32_t)NS;                      // (<= 48 / 56)
         const uint32_t pm = (uint32_t)(bits >> sh) & ((1u << NS) - 1u);
         const uint32_t pos0 = (uint32_t)__popcll(bits & ((1ull << sh) - 1ull));
-        uint32_t inr = 0;
+        // (outside [first_hash, last_hash] the reference visits no block, src/FileSegment.zig:164,153; unused columns: empty range.
+        // Nearly every hash lies inside ALL active columns' ranges: one test instead of sixteen)
+        uint32_t inr = active;
+        if (h < g->lo_all || h > g->hi_all) {
+            inr = 0u;
 #pragma unroll
-        for (uint32_t s = 0; s < NS; ++s)
-            // (outside [first_hash, last_hash] the reference visits no block, src/FileSegment.zig:164,153; unused columns: empty range)
-            inr |= (h >= g->first_hash[s] && h <= g->last_hash[s]) ? (1u << s) : 0u;
+            for (uint32_t s = 0; s < NS; ++s) inr |= (h >= g->first_hash[s] && h <= g->last_hash[s]) ? (1u << s) : 0u;
+        }
         if (!valid) inr = 0u;
         my_blocks += (uint32_t)__popc(inr & active & ~pm);         // absent: the reference visits one block, finds nothing and stops
         const uint32_t k = (uint32_t)__popc(pm);
@@ -133,6 +138,43 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         // ---- walk them: single docs and doubles become records, the first list reference gets the lane's slot
         uint32_t docs[GK_WORDS];
         uint32_t keep = 0, n_esc = 0, esc_off = 0, esc_col = 0;
+        uint32_t mine_w = mine;                              // words the lane has walked itself (the wave does the rest)
+        if (simple) {
+            // THE USUAL SNAPSHOT -- every column of the group searched, no superseded docs: a word's column does not matter (the words
+            // count from ONE doc id base), so the walk is straight-line code: twelve words classified by their top bit, no branch.
+            // (Measured on the 100 M index: the branchy walk + its stores 0.235 ms of the kernel's 0.69, the wave's turns for the `more`
+            // lanes another 0.236 -- 5 % of the lanes, each a serial chain of loads for the whole wave.)
+            // Words behind the line's 28th live in `ext`: the few lanes that have some fetch them one by one (not a turn of the wave)
+            if (valid && nwords <= GK_WORDS && start + nwords > inl) {
+                const uint32_t ovf = gload_u32(lp + (GROUP_LINE_WORDS - 1u));
+#pragma unroll
+                for (uint32_t j = 0; j < GK_WORDS; ++j)
+                    if (j >= mine && j < nwords) gw[j] = gload_u32(ext + ovf + (start + j - inl));      // (j >= mine: start + j >= inl)
+                mine_w = nwords;
+            }
+            uint32_t lmask = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < GK_WORDS; ++j) {
+                const uint32_t word = gw[j];
+                const bool v = j < mine_w, neg = (int32_t)word < 0;
+                keep |= (v && !neg) ? (1u << j) : 0u;                               // a doc (a gap position and a list reference have bit 31)
+                lmask |= (v && neg && word != 0xFFFFFFFFu) ? (1u << j) : 0u;        // a list reference
+                docs[j] = g->gmin + word;
+            }
+            // second words of doubles among them: the t-th double, at position i, has its second word at i + t + 1
+            uint32_t second = 0;
+            for (uint32_t d = dm, t = 0; d != 0u; d &= d - 1u, ++t) second |= 1u << ((uint32_t)__builtin_ctz(d) + t + 1u);
+            my_docs += (uint32_t)__popc(keep);
+            my_blocks += (uint32_t)__popc(keep & ~second);
+            n_esc = (uint32_t)__popc(lmask);
+            if (lmask != 0u) {
+                const uint32_t j0 = (uint32_t)__builtin_ctz(lmask);
+                uint32_t e = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < GK_WORDS; ++j) e = j == j0 ? gw[j] : e;
+                esc_off = e & 0x7FFFFFFFu;
+            }
+        } else {
         uint64_t cols = 0;                                   // column of word j in bits 4j .. 4j+3
         {
             uint32_t rest = pm, i = 0;
@@ -141,7 +183,11 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             for (uint32_t j = 0; j < GK_WORDS; ++j) {
                 const uint32_t word = gw[j];
                 uint32_t doc = 0u;
+#ifdef FPX_DBG_NOWALK
+                if (false) {
+#else
                 if (j < mine) {
+#endif
                     const uint32_t s = (uint32_t)__builtin_ctz(rest);
                     cols |= (uint64_t)s << (4u * j);
                     if (word != 0xFFFFFFFFu && ((active >> s) & 1u) != 0u) {                 // (0xFFFFFFFF: a gap position -- nothing visited)
@@ -168,13 +214,17 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                 if (((keep >> j) & 1u) != 0u && s_has_dead[s] != 0u && is_dead_seg(ga.segs[s_seg_index[s]], docs[j])) keep &= ~(1u << j);
             }
         }
-        // the head of the first list: header + up to three docs in one load
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (n_esc != 0u) { x = gload_u4_a4(ext + esc_off); my_reads += 2u; }
+        }
+        // the head of the first list: header + up to three docs in one load -- and the next four, so that a list of up to seven docs
+        // (all but one in a million) is the lane's own business
+        uint4 x = make_uint4(0, 0, 0, 0), x2 = make_uint4(0, 0, 0, 0);
+        if (n_esc != 0u) { x = gload_u4_a4(ext + esc_off); x2 = gload_u4_a4(ext + esc_off + 4u); my_reads += 2u; }
         uint32_t xkeep = 0;
-        const uint32_t xT = (x.x >> 19) & 1u, xeff = x.x & 0xFFFFu, xin = n_esc ? min(xeff, xT ? 2u : 3u) : 0u;
+        const uint32_t xT = (x.x >> 19) & 1u, xeff = x.x & 0xFFFFu, xin = n_esc ? min(xeff, xT ? 6u : 7u) : 0u;
         const uint32_t xmd = s_min_doc[esc_col];
-        const uint32_t xd0 = xmd + (xT ? x.z : x.y), xd1 = xmd + (xT ? x.w : x.z), xd2 = xmd + x.w;
+        // docs 0 .. 6 of the list (T: the header is followed by the list's full length, the docs start a word later)
+        const uint32_t xd0 = xmd + (xT ? x.z : x.y), xd1 = xmd + (xT ? x.w : x.z), xd2 = xmd + (xT ? x2.x : x.w), xd3 = xmd + (xT ? x2.y : x2.x),
+                       xd4 = xmd + (xT ? x2.z : x2.y), xd5 = xmd + (xT ? x2.w : x2.z), xd6 = xmd + x2.w;
         if (n_esc != 0u) {
             my_blocks += (x.x >> 16) & 7u; my_docs += xeff;
             xkeep = (1u << xin) - 1u;
@@ -183,6 +233,10 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                 if ((xkeep & 1u) && is_dead_seg(f, xd0)) xkeep &= ~1u;
                 if ((xkeep & 2u) && is_dead_seg(f, xd1)) xkeep &= ~2u;
                 if ((xkeep & 4u) && is_dead_seg(f, xd2)) xkeep &= ~4u;
+                if ((xkeep & 8u) && is_dead_seg(f, xd3)) xkeep &= ~8u;
+                if ((xkeep & 16u) && is_dead_seg(f, xd4)) xkeep &= ~16u;
+                if ((xkeep & 32u) && is_dead_seg(f, xd5)) xkeep &= ~32u;
+                if ((xkeep & 64u) && is_dead_seg(f, xd6)) xkeep &= ~64u;
             }
         }
         // ---- one reservation per lane in the workgroup's stage -- and (BINNED) one in the lane's bin: the records' ranks there
@@ -218,19 +272,28 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         if (xkeep & 1u) put(xd0);
         if (xkeep & 2u) put(xd1);
         if (xkeep & 4u) put(xd2);
+        if (xkeep & 8u) put(xd3);
+        if (xkeep & 16u) put(xd4);
+        if (xkeep & 32u) put(xd5);
+        if (xkeep & 64u) put(xd6);
         if (QS && GQSTATS(a) && valid && (my_blocks != blocks_before || my_docs != docs_before))
             atomicAdd(&GQSTATS(a)[(uint32_t)(qpart >> 32)], (unsigned long long)(my_blocks - blocks_before) | ((unsigned long long)(my_docs - docs_before) << 32));
         // ---- the rare rest, by the whole wave: words beyond the lane's own (more than twelve, or behind the line's 28 in `ext`),
         //      further lists, lists longer than their head
         {
-            const bool more = nwords > mine || n_esc > 1u || (n_esc == 1u && xeff > xin);
+#ifdef FPX_DBG_NOMORE
+            const bool more = false;
+#else
+            const bool more = nwords > mine_w || n_esc > 1u || (n_esc == 1u && xeff > xin);
+#endif
             const bool hot = n_esc != 0u && xeff >= 64u;
             unsigned long long mo = __ballot((int)more);
             while (mo != 0ull) {
                 const int src = (int)__builtin_ctzll(mo);
                 mo &= mo - 1ull;
                 const uint32_t qlo = __shfl((uint32_t)(qpart >> 32), src);
-                const uint32_t pm_s = __shfl(pm, src), dm_s = __shfl(dm, src), nw_s = __shfl(nwords, src), mine_s = __shfl(mine, src);
+                const uint32_t pm_s = __shfl(pm, src), dm_s = __shfl(dm, src), nw_s = __shfl(nwords, src), mine_s = __shfl(mine_w, src);
+                const uint32_t xin_s = __shfl(xin, src);               // (docs of its first list the lane has emitted itself)
                 const uint32_t start_s = __shfl(start, src), inl_s = __shfl(inl, src);
                 const uint32_t* lp_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)lp, src));
                 const uint32_t* li_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)ext >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)ext, src));
@@ -274,7 +337,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                     const uint32_t hdr_l = is_list ? gload_u32(lp) : 0u;
                     const uint32_t eff_l = hdr_l & 0xFFFFu, T_l = (hdr_l >> 19) & 1u;
                     const bool slot_list = is_list && lane == (uint32_t)__builtin_ctzll(ml) && lane < mine_s;
-                    const uint32_t from_l = slot_list ? min(eff_l, T_l ? 2u : 3u) : 0u;
+                    const uint32_t from_l = slot_list ? min(eff_l, xin_s) : 0u;
                     if (is_list && !slot_list) {
                         my_blocks += (hdr_l >> 16) & 7u; my_docs += eff_l; my_reads += 2u;
                         if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
@@ -325,7 +388,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                         const uint32_t* list = li_s + off;
                         const uint32_t hdr = gload_u32(list), eff = hdr & 0xFFFFu, T = (hdr >> 19) & 1u;
                         uint32_t from = 0u;
-                        if (first && (uint32_t)el < mine_s) from = min(eff, T ? 2u : 3u);          // (the lane's slot took these)
+                        if (first && (uint32_t)el < mine_s) from = min(eff, xin_s);          // (the lane's slot took these)
                         else if (lane == 0) {
                             my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u;
                             if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr >> 16) & 7u) | ((unsigned long long)eff << 32));
@@ -367,7 +430,11 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                 }
             }
             __syncthreads();
+#ifdef FPX_DBG_NOFLUSH
+            for (uint32_t i = tid; i < 0u; i += FK_WG) {
+#else
             for (uint32_t i = tid; i < sc; i += FK_WG) {
+#endif
                 const uint64_t rec = stage[i];
                 const uint32_t b = gb_cell(a, rec); const uint32_t rk = s_rank[i];
                 if (rk < GB_NEED) {

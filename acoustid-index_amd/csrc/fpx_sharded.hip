@@ -43,6 +43,7 @@ struct Rccl {
     void* lib = nullptr;
     int (*CommInitAll)(ncclComm_t_*, int, const int*) = nullptr;
     int (*CommDestroy)(ncclComm_t_) = nullptr;
+    int (*CommAbort)(ncclComm_t_) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
@@ -66,6 +67,7 @@ static const Rccl& rccl()
         auto sym = [&](const char* n) { return dlsym(x.lib, n); };
         x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.CommAbort = reinterpret_cast<decltype(x.CommAbort)>(sym("ncclCommAbort"));
         x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
         x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
         x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
@@ -151,8 +153,138 @@ struct ShardedSnapshot {
     std::vector<ncclComm_t_> comms;
     std::vector<hipStream_t> xstreams;
     std::mutex rccl_mu;
-    bool use_rccl = false;
+    std::atomic<bool> use_rccl{false};
+    // HASH-WINDOW mode (fpx_sharded_snapshot_create_windows): context k = rank k holds window k of the hash space of ALL segments;
+    // a search routes the keys to their window's rank and the bins back to the rank the queries came from (routed-key protocol,
+    // fpx_search.hip: shard_keys_impl / shard_probe_keys_impl / shard_score_impl)
+    bool windows = false;
+    std::vector<struct WinBufs*> free_win;
+    std::atomic<uint64_t> key_cap{0}, cell_cap{0};       // slot sizes the last searches settled on
 };
+
+// per-call buffers of the hash-window mode, one set per rank (on its device)
+struct WinBufs {
+    uint32_t world = 0, bpr = 0;
+    uint64_t key_cap = 0, cell_cap = 0;
+    std::vector<uint64_t*> keys_send, keys_recv;             // [world][key_cap]
+    std::vector<unsigned long long*> kcnt_send, kcnt_recv;   // [world]
+    std::vector<uint64_t*> bins_send, bins_recv;             // [world][bpr][cell_cap]
+    std::vector<uint32_t*> bcnt_send, bcnt_recv;             // [world][bpr]
+    std::vector<hipStream_t> xs;                             // exchange streams (peer copies), one per rank
+};
+
+static void win_free_keys(ShardedSnapshot* ss, WinBufs* b)
+{
+    for (uint32_t k = 0; k < b->world; ++k) {
+        (void)hipSetDevice(ss->ctxs[k]->device);
+        if (k < b->keys_send.size() && b->keys_send[k]) (void)hipFree(b->keys_send[k]);
+        if (k < b->keys_recv.size() && b->keys_recv[k]) (void)hipFree(b->keys_recv[k]);
+    }
+    b->keys_send.assign(b->world, nullptr); b->keys_recv.assign(b->world, nullptr); b->key_cap = 0;
+}
+static void win_free_bins(ShardedSnapshot* ss, WinBufs* b)
+{
+    for (uint32_t k = 0; k < b->world; ++k) {
+        (void)hipSetDevice(ss->ctxs[k]->device);
+        if (k < b->bins_send.size() && b->bins_send[k]) (void)hipFree(b->bins_send[k]);
+        if (k < b->bins_recv.size() && b->bins_recv[k]) (void)hipFree(b->bins_recv[k]);
+        if (k < b->bcnt_send.size() && b->bcnt_send[k]) (void)hipFree(b->bcnt_send[k]);
+        if (k < b->bcnt_recv.size() && b->bcnt_recv[k]) (void)hipFree(b->bcnt_recv[k]);
+    }
+    b->bins_send.assign(b->world, nullptr); b->bins_recv.assign(b->world, nullptr);
+    b->bcnt_send.assign(b->world, nullptr); b->bcnt_recv.assign(b->world, nullptr);
+    b->cell_cap = 0; b->bpr = 0;
+}
+static void win_destroy(ShardedSnapshot* ss, WinBufs* b)
+{
+    if (!b) return;
+    win_free_keys(ss, b); win_free_bins(ss, b);
+    for (uint32_t k = 0; k < b->world; ++k) {
+        (void)hipSetDevice(ss->ctxs[k]->device);
+        if (k < b->kcnt_send.size() && b->kcnt_send[k]) (void)hipFree(b->kcnt_send[k]);
+        if (k < b->kcnt_recv.size() && b->kcnt_recv[k]) (void)hipFree(b->kcnt_recv[k]);
+        if (k < b->xs.size() && b->xs[k]) (void)hipStreamDestroy(b->xs[k]);
+    }
+    delete b;
+}
+static int win_reserve_keys(ShardedSnapshot* ss, WinBufs* b, uint64_t key_cap)
+{
+    if (b->key_cap >= key_cap && !b->keys_send.empty()) return FPX_OK;
+    win_free_keys(ss, b);
+    for (uint32_t k = 0; k < b->world; ++k) {
+        FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+        FPX_HIP(hipMalloc(&b->keys_send[k], (size_t)b->world * key_cap * sizeof(uint64_t)));
+        FPX_HIP(hipMalloc(&b->keys_recv[k], (size_t)b->world * key_cap * sizeof(uint64_t)));
+    }
+    b->key_cap = key_cap;
+    return FPX_OK;
+}
+static int win_reserve_bins(ShardedSnapshot* ss, WinBufs* b, uint32_t bpr, uint64_t cell_cap)
+{
+    if (b->cell_cap >= cell_cap && b->bpr == bpr && !b->bins_send.empty()) return FPX_OK;
+    cell_cap = std::max<uint64_t>(cell_cap, b->bpr == bpr ? b->cell_cap : 0ull);
+    win_free_bins(ss, b);
+    for (uint32_t k = 0; k < b->world; ++k) {
+        FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+        FPX_HIP(hipMalloc(&b->bins_send[k], (size_t)b->world * bpr * cell_cap * sizeof(uint64_t)));
+        FPX_HIP(hipMalloc(&b->bins_recv[k], (size_t)b->world * bpr * cell_cap * sizeof(uint64_t)));
+        FPX_HIP(hipMalloc(&b->bcnt_send[k], (size_t)b->world * bpr * sizeof(uint32_t)));
+        FPX_HIP(hipMalloc(&b->bcnt_recv[k], (size_t)b->world * bpr * sizeof(uint32_t)));
+    }
+    b->cell_cap = cell_cap; b->bpr = bpr;
+    return FPX_OK;
+}
+
+// One all-to-all among the ranks of a window-mode snapshot: chunk w of rank k's `send` (row_bytes each) becomes chunk k of rank w's
+// `recv`.  RCCL (grouped ncclSend / ncclRecv over xGMI) when every rank has a device of its own, peer copies otherwise.  Every
+// enqueue of a group is attempted and the group is always closed; after any RCCL error the communicators are aborted and the
+// snapshot falls back to peer copies (a half-built group must not be completed, and must not be left open either).
+template <typename T>
+static int win_all_to_all(ShardedSnapshot* ss, WinBufs* b, const std::vector<T*>& send, const std::vector<T*>& recv, size_t row_bytes)
+{
+    const uint32_t n = b->world;
+    if (ss->use_rccl.load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> g(ss->rccl_mu);
+        if (ss->use_rccl.load(std::memory_order_acquire)) {
+            const Rccl& r = rccl();
+            int nrc = r.GroupStart();
+            bool opened = nrc == 0;
+            for (uint32_t k = 0; k < n && nrc == 0; ++k) {
+                if (hipSetDevice(ss->ctxs[k]->device) != hipSuccess) { nrc = -1; break; }
+                for (uint32_t w = 0; w < n && nrc == 0; ++w) {
+                    nrc = r.Send(reinterpret_cast<const uint8_t*>(send[k]) + (size_t)w * row_bytes, row_bytes, NCCL_UINT8, (int)w, ss->comms[k], ss->xstreams[k]);
+                    if (nrc == 0) nrc = r.Recv(reinterpret_cast<uint8_t*>(recv[k]) + (size_t)w * row_bytes, row_bytes, NCCL_UINT8, (int)w, ss->comms[k], ss->xstreams[k]);
+                }
+            }
+            if (nrc != 0) {
+                // the group is abandoned: abort the communicators (GroupEnd on sends without their receives could hang), then balance
+                if (r.CommAbort) for (auto& c : ss->comms) if (c) { (void)r.CommAbort(c); c = nullptr; }
+                if (opened) (void)r.GroupEnd();
+                ss->use_rccl.store(false, std::memory_order_release);
+            } else if (r.GroupEnd() != 0) {
+                ss->use_rccl.store(false, std::memory_order_release);
+            } else {
+                for (uint32_t k = 0; k < n; ++k) {
+                    FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+                    FPX_HIP(hipStreamSynchronize(ss->xstreams[k]));
+                }
+                return FPX_OK;
+            }
+            (void)hipGetLastError();
+        }
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+        for (uint32_t w = 0; w < n; ++w)
+            FPX_HIP(hipMemcpyPeerAsync(reinterpret_cast<uint8_t*>(recv[w]) + (size_t)k * row_bytes, ss->ctxs[w]->device,
+                                       reinterpret_cast<const uint8_t*>(send[k]) + (size_t)w * row_bytes, ss->ctxs[k]->device, row_bytes, b->xs[k]));
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+        FPX_HIP(hipStreamSynchronize(b->xs[k]));
+    }
+    return FPX_OK;
+}
 
 static void bufs_destroy(ShardedSnapshot* ss, ShardBufs* b)
 {
@@ -208,6 +340,7 @@ static void sharded_free(ShardedSnapshot* ss)
     for (size_t k = 0; k < ss->xstreams.size(); ++k)
         if (ss->xstreams[k]) { (void)hipSetDevice(ss->ctxs[k]->device); (void)hipStreamDestroy(ss->xstreams[k]); }
     for (ShardBufs* b : ss->free_bufs) bufs_destroy(ss, b);
+    for (WinBufs* b : ss->free_win) win_destroy(ss, b);
     for (Snapshot* sn : ss->locals) fpx_snapshot_release(reinterpret_cast<fpx_snapshot*>(sn));
     delete ss;
 }
@@ -215,6 +348,9 @@ static void sharded_free(ShardedSnapshot* ss)
 }  // namespace fpx
 
 using namespace fpx;
+
+static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, const uint64_t* offsets, uint32_t B, const fpx_opts* opts, uint32_t timeout_ms,
+                                fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats);
 
 extern "C" {
 
@@ -276,7 +412,7 @@ int fpx_sharded_snapshot_create_on(fpx_ctx* root_ctx, fpx_segment* const* segs, 
                 bool ok = true;
                 for (size_t k = 0; k < ss->ctxs.size() && ok; ++k)
                     ok = hipSetDevice(devs[k]) == hipSuccess && hipStreamCreateWithFlags(&ss->xstreams[k], hipStreamNonBlocking) == hipSuccess;
-                ss->use_rccl = ok;
+                ss->use_rccl.store(ok);
             } else {
                 ss->comms.clear();
             }
@@ -326,6 +462,12 @@ int fpx_sharded_search_batch(fpx_sharded_snapshot* s, const uint32_t* hashes, co
     if (!ss || !offsets || !opts || !out_n || (!out && out_cap)) { set_error("null argument"); return FPX_E_INVAL; }
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (num_queries == 0) return FPX_OK;
+    if (ss->windows) {
+        for (uint32_t q = 0; q < num_queries; ++q)
+            if (offsets[q + 1] < offsets[q]) { set_error("offsets must be non-decreasing"); return FPX_E_INVAL; }
+        if (offsets[num_queries] && !hashes) { set_error("null argument"); return FPX_E_INVAL; }
+        return windows_search_batch(ss, hashes, offsets, num_queries, opts, timeout_ms, out, out_cap, out_n, stats);
+    }
     const DeviceGuard guard;                     // (this call moves the thread between the devices)
     const auto t_call = std::chrono::steady_clock::now();
     const size_t n = ss->ctxs.size();
@@ -371,23 +513,28 @@ int fpx_sharded_search_batch(fpx_sharded_snapshot* s, const uint32_t* hashes, co
         auto body = [&]() -> int {
             const int root = ss->ctxs[0]->device;
             bool gathered = false;
-            if (ss->use_rccl && n > 1) {
+            if (ss->use_rccl.load() && n > 1) {
                 // grouped send / recv: every shard's table and counts to rank 0 (ncclSend / ncclRecv pairs inside one group are
                 // RCCL's gather).  Bytes: B * cap * 8 + B * 4 per shard -- 0.33 MB at B = 1024, limit 40.
                 std::lock_guard<std::mutex> g(ss->rccl_mu);
                 const Rccl& r = rccl();
-                int nrc = r.GroupStart();
+                int nrc = ss->use_rccl.load() ? r.GroupStart() : -1;
+                const bool opened = nrc == 0;
+                // (no early return between GroupStart and GroupEnd: an error is collected, the group is closed -- after the
+                // communicators were aborted, so that sends without their receives cannot hang it -- and peer copies take over)
                 for (size_t k = 1; k < n && nrc == 0; ++k) {
-                    FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+                    if (hipSetDevice(ss->ctxs[k]->device) != hipSuccess) { nrc = -1; break; }
                     nrc = r.Send(b->d_part[k], (size_t)B * cap * sizeof(fpx_result), NCCL_UINT8, 0, ss->comms[k], ss->xstreams[k]);
                     if (nrc == 0) nrc = r.Send(b->d_cnt[k], (size_t)B * sizeof(uint32_t), NCCL_UINT8, 0, ss->comms[k], ss->xstreams[k]);
                 }
-                FPX_HIP(hipSetDevice(root));
+                if (nrc == 0 && hipSetDevice(root) != hipSuccess) nrc = -1;
                 for (size_t k = 1; k < n && nrc == 0; ++k) {
                     nrc = r.Recv(b->d_all + k * (size_t)B * cap, (size_t)B * cap * sizeof(fpx_result), NCCL_UINT8, (int)k, ss->comms[0], ss->xstreams[0]);
                     if (nrc == 0) nrc = r.Recv(b->d_all_cnt + k * (size_t)B, (size_t)B * sizeof(uint32_t), NCCL_UINT8, (int)k, ss->comms[0], ss->xstreams[0]);
                 }
-                const int erc = r.GroupEnd();
+                if (nrc != 0 && opened && r.CommAbort) for (auto& c : ss->comms) if (c) { (void)r.CommAbort(c); c = nullptr; }
+                const int erc = opened ? r.GroupEnd() : -1;
+                (void)hipGetLastError();
                 if (nrc == 0 && erc == 0) {
                     for (size_t k = 0; k < n; ++k) {
                         FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
@@ -395,7 +542,7 @@ int fpx_sharded_search_batch(fpx_sharded_snapshot* s, const uint32_t* hashes, co
                     }
                     gathered = true;
                 } else {
-                    ss->use_rccl = false;             // (peer copies from here on)
+                    ss->use_rccl.store(false);        // (peer copies from here on)
                 }
             }
             FPX_HIP(hipSetDevice(root));
@@ -433,6 +580,246 @@ int fpx_sharded_search_batch(fpx_sharded_snapshot* s, const uint32_t* hashes, co
         if (ss->free_bufs.size() < 8) { ss->free_bufs.push_back(b); b = nullptr; }
     }
     if (b) bufs_destroy(ss, b);
+    return rc;
+}
+
+// ---- hash-window mode -------------------------------------------------------------------------------------------------------
+int fpx_segment_create_file_windows(fpx_ctx* const* ctxs, uint32_t world, const uint8_t* blocks, size_t blocks_len, uint32_t block_size,
+                                    const uint32_t* block_index, uint32_t num_blocks, uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                    const uint32_t* doc_ids, const uint8_t* doc_alive, uint32_t num_docs, fpx_segment** out)
+{
+    if (!ctxs || !out || world == 0 || (world & (world - 1u)) != 0u || world > 64u) { set_error("fpx_segment_create_file_windows: 1, 2, 4 .. 64 contexts"); return FPX_E_INVAL; }
+    if ((!blocks && blocks_len) || (!block_index && num_blocks) || blocks_len < (size_t)num_blocks * block_size) { set_error("null / short argument"); return FPX_E_INVAL; }
+    const DeviceGuard guard;
+    for (uint32_t k = 0; k < world; ++k) out[k] = nullptr;
+    for (uint32_t k = 0; k < world; ++k) {
+        // window k: hashes in (lo_excl, hi_incl] = [k 2^32 / world, (k + 1) 2^32 / world); its blocks: from the first whose max hash
+        // reaches into the window through the first whose max hash >= hi_incl, + the three halo blocks a run may continue into
+        const bool has_lo = k != 0, has_hi = k + 1 != world;
+        const uint32_t lo_excl = has_lo ? (uint32_t)(((uint64_t)k << 32) / world - 1u) : 0u;
+        const uint32_t hi_incl = has_hi ? (uint32_t)(((uint64_t)(k + 1u) << 32) / world - 1u) : 0xFFFFFFFFu;
+        const uint32_t b0 = has_lo ? (uint32_t)(std::lower_bound(block_index, block_index + num_blocks, lo_excl + 1u) - block_index) : 0u;
+        uint32_t e = num_blocks;
+        if (has_hi) e = std::min<uint32_t>(num_blocks, (uint32_t)(std::lower_bound(block_index, block_index + num_blocks, hi_incl) - block_index) + 1u + 3u);
+        if (e < b0) e = b0;
+        const int rc = fpx_segment_create_file_slice(ctxs[k], blocks + (size_t)b0 * block_size, (size_t)(e - b0) * block_size, block_size, block_index + b0, e - b0,
+                                                     has_lo ? 1 : 0, lo_excl, has_hi ? 1 : 0, hi_incl, min_doc_id, max_doc_id, commit_id, doc_ids, doc_alive, num_docs, &out[k]);
+        if (rc != FPX_OK) {
+            for (uint32_t j = 0; j < k; ++j) { fpx_segment_release(out[j]); out[j] = nullptr; }
+            return rc;
+        }
+    }
+    return FPX_OK;
+}
+
+int fpx_sharded_snapshot_create_windows(fpx_ctx* const* ctxs, uint32_t world, fpx_segment* const* slices, uint32_t num_segs, fpx_sharded_snapshot** out)
+{
+    if (!out || !ctxs || world == 0 || (world & (world - 1u)) != 0u || world > 64u || (!slices && num_segs)) {
+        set_error("fpx_sharded_snapshot_create_windows: 1, 2, 4 .. 64 contexts, slices[world][num_segs]"); return FPX_E_INVAL;
+    }
+    *out = nullptr;
+    const DeviceGuard guard;
+    ShardedSnapshot* ss = new (std::nothrow) ShardedSnapshot();
+    if (!ss) return FPX_E_NOMEM;
+    ss->windows = true;
+    static const int workers = [] { const char* e = getenv("FPX_SHARDED_WORKERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    for (uint32_t k = 0; k < world; ++k) {
+        Ctx* c = reinterpret_cast<Ctx*>(ctxs[k]);
+        if (!c) { sharded_free(ss); set_error("null context"); return FPX_E_INVAL; }
+        ss->ctxs.push_back(c);
+        for (uint32_t j = 0; j < num_segs; ++j) {
+            const Segment* sg = reinterpret_cast<const Segment*>(slices[(size_t)k * num_segs + j]);
+            if (!sg || sg->ctx != c || sg->kind != 0) { sharded_free(ss); set_error("slices[%u][%u] is not a file segment of context %u", k, j, k); return FPX_E_INVAL; }
+        }
+        fpx_snapshot* sn = nullptr;
+        const int rc = fpx_snapshot_create(ctxs[k], slices + (size_t)k * num_segs, num_segs, &sn);
+        if (rc != FPX_OK) { sharded_free(ss); return rc; }
+        ss->locals.push_back(reinterpret_cast<Snapshot*>(sn));
+        try {
+            ss->pools.emplace_back(new DevicePool(c->device, workers));
+        } catch (...) {
+            sharded_free(ss);
+            set_error("could not start the worker threads of device %d", c->device);
+            return FPX_E_NOMEM;
+        }
+    }
+    // every rank's snapshot must be what the bin protocol takes: groups of slices with the rank's window (an index without segments is fine)
+    for (uint32_t k = 0; k < world && num_segs; ++k) {
+        const Snapshot* sn = ss->locals[k];
+        const uint32_t lo = (uint32_t)(((uint64_t)k << 32) / world), hi = (uint32_t)((((uint64_t)(k + 1u) << 32) / world) - 1u);
+        bool ok = sn->n_group != 0 && sn->n_solo == 0 && sn->n_file == 0 && sn->n_mem == 0;
+        for (const GroupDesc& gd : sn->h_group) ok = ok && gd.win_lo == lo && gd.win_hi == hi;
+        if (!ok) {
+            sharded_free(ss);
+            set_error("fpx_sharded_snapshot_create_windows: rank %u's slices did not form groups with the window [%u, %u] (dense 512-byte file segments cut by "
+                      "fpx_segment_create_file_windows / fpx_segment_slice; FPX_FUSE_MIN / FPX_DIRECT_MIN_ITEMS permitting)", k, lo, hi);
+            return FPX_E_INVAL;
+        }
+    }
+    {
+        std::vector<int> devs;
+        for (Ctx* c : ss->ctxs) devs.push_back(c->device);
+        std::vector<int> uniq = devs;
+        std::sort(uniq.begin(), uniq.end());
+        const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
+        if (world >= 2 && distinct && rccl().ok) {
+            ss->comms.assign(world, nullptr);
+            if (rccl().CommInitAll(ss->comms.data(), (int)world, devs.data()) == 0) {
+                ss->xstreams.assign(world, nullptr);
+                bool ok = true;
+                for (uint32_t k = 0; k < world && ok; ++k)
+                    ok = hipSetDevice(devs[k]) == hipSuccess && hipStreamCreateWithFlags(&ss->xstreams[k], hipStreamNonBlocking) == hipSuccess;
+                ss->use_rccl.store(ok);
+            } else {
+                ss->comms.clear();
+            }
+            (void)hipGetLastError();
+        }
+        for (uint32_t a = 0; a < world; ++a)               // peer access for the fallback copies
+            for (uint32_t b2 = 0; b2 < world; ++b2) {
+                if (devs[a] == devs[b2]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devs[a], devs[b2]) == hipSuccess && can) {
+                    (void)hipSetDevice(devs[a]);
+                    const hipError_t e = hipDeviceEnablePeerAccess(devs[b2], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+            }
+        (void)hipGetLastError();
+    }
+    *out = reinterpret_cast<fpx_sharded_snapshot*>(ss);
+    return FPX_OK;
+}
+
+// one batch through the routed-key protocol, every rank a context of this process
+static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, const uint64_t* offsets, uint32_t B, const fpx_opts* opts, uint32_t timeout_ms,
+                                fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats)
+{
+    const DeviceGuard guard;
+    const auto t_call = std::chrono::steady_clock::now();
+    const uint32_t n = (uint32_t)ss->ctxs.size();
+    const uint32_t bpr = fpx_shard_bins_per_rank(B, n);
+    std::vector<uint32_t> q_lo(n), q_hi(n);
+    uint64_t share_pairs = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        q_lo[k] = (uint32_t)std::min<uint64_t>(B, (uint64_t)k * bpr * 8u); q_hi[k] = (uint32_t)std::min<uint64_t>(B, (uint64_t)(k + 1u) * bpr * 8u);
+        share_pairs = std::max<uint64_t>(share_pairs, offsets[q_hi[k]] - offsets[q_lo[k]]);
+    }
+    WinBufs* b = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ss->mu);
+        if (!ss->free_win.empty()) { b = ss->free_win.back(); ss->free_win.pop_back(); }
+    }
+    if (!b) {
+        b = new (std::nothrow) WinBufs();
+        if (!b) return FPX_E_NOMEM;
+        b->world = n;
+        b->keys_send.assign(n, nullptr); b->keys_recv.assign(n, nullptr); b->kcnt_send.assign(n, nullptr); b->kcnt_recv.assign(n, nullptr);
+        b->bins_send.assign(n, nullptr); b->bins_recv.assign(n, nullptr); b->bcnt_send.assign(n, nullptr); b->bcnt_recv.assign(n, nullptr);
+        b->xs.assign(n, nullptr);
+        for (uint32_t k = 0; k < n; ++k) {
+            if (hipSetDevice(ss->ctxs[k]->device) != hipSuccess || hipMalloc(&b->kcnt_send[k], (size_t)n * 8) != hipSuccess || hipMalloc(&b->kcnt_recv[k], (size_t)n * 8) != hipSuccess ||
+                hipStreamCreateWithFlags(&b->xs[k], hipStreamNonBlocking) != hipSuccess) { win_destroy(ss, b); set_error("out of device memory"); return FPX_E_NOMEM; }
+        }
+    }
+    // what runs on every rank's pool at once
+    struct Done { std::mutex mu; std::condition_variable cv; uint32_t left; };
+    std::vector<int> rcs(n);
+    std::vector<std::string> errs(n);
+    auto run_all = [&](const std::function<int(uint32_t)>& fn) {
+        Done done; done.left = n;
+        for (uint32_t k = 0; k < n; ++k) {
+            ss->pools[k]->post([&, k] {
+                rcs[k] = fn(k);
+                if (rcs[k] != FPX_OK) errs[k] = fpx_last_error();
+                std::lock_guard<std::mutex> g(done.mu);
+                if (--done.left == 0) done.cv.notify_one();
+            });
+        }
+        std::unique_lock<std::mutex> lk(done.mu);
+        done.cv.wait(lk, [&] { return done.left == 0; });
+    };
+    auto first_error = [&]() -> int {                  // FPX_E_AGAIN only when nothing worse happened
+        int rc = FPX_OK;
+        for (uint32_t k = 0; k < n; ++k)
+            if (rcs[k] != FPX_OK && rcs[k] != FPX_E_AGAIN && rc == FPX_OK) { rc = rcs[k]; set_error("rank %u (device %d): %s", k, ss->ctxs[k]->device, errs[k].c_str()); }
+        if (rc == FPX_OK) for (uint32_t k = 0; k < n; ++k) if (rcs[k] == FPX_E_AGAIN) rc = FPX_E_AGAIN;
+        return rc;
+    };
+    std::vector<QueryBatch*> shares(n, nullptr);
+    std::vector<std::vector<uint64_t>> sub_off(n);
+    std::vector<uint64_t> needs(n, 0);
+    std::vector<fpx_stats> sts(n);
+    int rc = FPX_OK;
+    auto body = [&]() -> int {
+        int r;
+        // ---- the shares (1/N of the batch's hashes to each device) and their keys, dealt to the windows
+        uint64_t key_cap = std::max<uint64_t>(ss->key_cap.load(), share_pairs / n + share_pairs / (16ull * n) + 1024);
+        run_all([&](uint32_t k) -> int {
+            const uint32_t nq = q_hi[k] - q_lo[k];
+            sub_off[k].resize((size_t)nq + 1);
+            for (uint32_t q = 0; q <= nq; ++q) sub_off[k][q] = offsets[q_lo[k] + q] - offsets[q_lo[k]];
+            return query_batch_create_impl(ss->ctxs[k], hashes ? hashes + offsets[q_lo[k]] : nullptr, sub_off[k].data(), nq, opts + q_lo[k], &shares[k]);
+        });
+        if ((r = first_error())) return r;
+        for (int attempt = 0;; ++attempt) {
+            if ((r = win_reserve_keys(ss, b, key_cap))) return r;
+            run_all([&](uint32_t k) -> int {
+                return shard_keys_impl(ss->ctxs[k], shares[k], n, k, B, b->keys_send[k], b->key_cap, b->kcnt_send[k], &needs[k]);
+            });
+            r = first_error();
+            if (r == FPX_OK) break;
+            if (r != FPX_E_AGAIN || attempt >= 3) return r == FPX_E_AGAIN ? FPX_E_DEVICE : r;
+            for (uint32_t k = 0; k < n; ++k) key_cap = std::max(key_cap, needs[k]);
+        }
+        ss->key_cap.store(b->key_cap);
+        // ---- all-to-all #1: slot w of every rank's keys (and its count) to rank w
+        if ((r = win_all_to_all(ss, b, b->keys_send, b->keys_recv, (size_t)b->key_cap * sizeof(uint64_t)))) return r;
+        if ((r = win_all_to_all(ss, b, b->kcnt_send, b->kcnt_recv, sizeof(unsigned long long)))) return r;
+        // ---- probes: the received slots -> the batch's bins
+        uint64_t cell_cap = std::max<uint64_t>(ss->cell_cap.load(), 2048);
+        for (int attempt = 0;; ++attempt) {
+            if ((r = win_reserve_bins(ss, b, bpr, cell_cap))) return r;
+            run_all([&](uint32_t k) -> int {
+                return shard_probe_keys_impl(ss->locals[k], b->keys_recv[k], b->key_cap, b->kcnt_recv[k], n, B, timeout_ms, b->bins_send[k], b->cell_cap, b->bcnt_send[k],
+                                             &needs[k], &sts[k]);
+            });
+            r = first_error();
+            if (r == FPX_OK) break;
+            if (r != FPX_E_AGAIN || attempt >= 3) return r == FPX_E_AGAIN ? FPX_E_DEVICE : r;
+            for (uint32_t k = 0; k < n; ++k) cell_cap = std::max(cell_cap, needs[k]);      // (one size for all ranks: this process sees every need)
+        }
+        ss->cell_cap.store(b->cell_cap);
+        // ---- all-to-all #2: the bins (and their counts) to the rank that finishes their queries
+        if ((r = win_all_to_all(ss, b, b->bins_send, b->bins_recv, (size_t)bpr * b->cell_cap * sizeof(uint64_t)))) return r;
+        if ((r = win_all_to_all(ss, b, b->bcnt_send, b->bcnt_recv, (size_t)bpr * sizeof(uint32_t)))) return r;
+        if (timeout_ms && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count() > (double)timeout_ms) { set_error("search timeout"); return FPX_E_TIMEOUT; }
+        // ---- every rank finishes its queries: straight into the caller's rows
+        run_all([&](uint32_t k) -> int {
+            if (q_hi[k] == q_lo[k]) return FPX_OK;
+            return shard_score_impl(ss->ctxs[k], shares[k], n, k, b->bins_recv[k], b->cell_cap, b->bcnt_recv[k], timeout_ms,
+                                    out ? out + (size_t)q_lo[k] * out_cap : nullptr, out_cap, out_n + q_lo[k], nullptr, nullptr, nullptr, B);
+        });
+        return first_error();
+    };
+    rc = body();
+    for (uint32_t k = 0; k < n; ++k) if (shares[k]) query_batch_free(shares[k]);
+    if (rc == FPX_OK && stats) {
+        for (uint32_t k = 0; k < n; ++k) {
+            const fpx_stats& t = sts[k];
+            stats->probes += t.probes; stats->scanned_blocks += t.scanned_blocks; stats->scanned_docs += t.scanned_docs; stats->hits += t.hits;
+            stats->algorithmic_bytes += t.algorithmic_bytes; stats->probe_launches += t.probe_launches;
+            stats->probe_kernel_bytes += t.probe_kernel_bytes; stats->probe_kernel_fetched_bytes += t.probe_kernel_fetched_bytes;
+            stats->path_flags |= t.path_flags;
+            stats->probe_kernel_ms = std::max(stats->probe_kernel_ms, t.probe_kernel_ms);
+            stats->total_gpu_ms = std::max(stats->total_gpu_ms, t.total_gpu_ms);
+        }
+    }
+    {
+        std::lock_guard<std::mutex> g(ss->mu);
+        if (ss->free_win.size() < 8) { ss->free_win.push_back(b); b = nullptr; }
+    }
+    if (b) win_destroy(ss, b);
     return rc;
 }
 

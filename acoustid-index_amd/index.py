@@ -339,6 +339,33 @@ class ShardedSegments:
             pass
 
 
+def file_segment_windows(ctxs, blocks, block_size, block_index, min_doc_id, max_doc_id, commit_id, doc_ids, doc_alive=None):
+    """fpx_segment_create_file_windows: one segment file -> its len(ctxs) hash-window slices, slice k resident on ctxs[k]"""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    block_index = _u32(block_index)
+    ids, alive = _docs_args(doc_ids, doc_alive)
+    n = len(ids)
+    world = len(ctxs)
+    carr = (C.c_void_p * world)(*[c.h for c in ctxs])
+    outs = (C.c_void_p * world)()
+    check(lib().fpx_segment_create_file_windows(carr, world, _p(blocks), blocks.nbytes, block_size, _p(block_index), len(block_index),
+                                                min_doc_id, max_doc_id, commit_id, _p(ids), _p(alive), n, outs))
+    return [FileSegment._adopt(ctxs[k], C.c_void_p(outs[k])) for k in range(world)]
+
+
+class WindowShardedSegments(ShardedSegments):
+    """fpx_sharded_snapshot_create_windows: slices[k][j] = window k of segment j, resident on ctxs[k]"""
+
+    def __init__(self, ctxs, slices):
+        self.segments = [s for row in slices for s in row]
+        world, nseg = len(ctxs), (len(slices[0]) if slices else 0)
+        carr = (C.c_void_p * world)(*[c.h for c in ctxs])
+        arr = (C.c_void_p * max(1, world * nseg))(*[s.h for s in self.segments])
+        h = C.c_void_p()
+        check(lib().fpx_sharded_snapshot_create_windows(carr, world, arr, nseg, C.byref(h)))
+        self.h = h
+
+
 class SearchResults:
     """Collector handed to IndexReader.search (src/common.zig:73-176)."""
 

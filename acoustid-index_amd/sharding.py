@@ -257,3 +257,154 @@ class HashShardedReader:
             return self._search_records(qb, out, out_n)
         out, out_n = self.gather_merge(qb, out, out_n)
         return out, out_n, st
+
+
+class RoutedShardedReader:
+    """The protocol that scales (fpx_shard_keys / fpx_shard_probe_keys / fpx_shard_score_share): this rank holds its window of
+    the hash space of every segment AND only its share of the batch -- the queries it will finish.  Five stages per step:
+      keys(share)      any thread    the share's keys, dealt to the ranks' windows (slot w of the send buffer)
+      exchange_keys()  IN STEP ORDER all-to-all #1: slot w and its count to rank w
+      probe()          any thread    the received slots -> the batch's bins
+      exchange_bins()  IN STEP ORDER all-to-all #2: the bins to the rank whose queries they hold
+      score(out, n)    any thread    the final results of the share's queries
+    The two exchanges are collectives: every rank must issue them in the same order (bench.py does so from one thread).  Slot and
+    bin sizes are agreed without a collective of their own: keys -- an all-reduce(MAX) rides in exchange_keys only when a rank flagged
+    an overflow through its counts; bins -- the marked counts of fpx_shard_score (ShardCellsTooSmall)."""
+
+    def __init__(self, fpx, ctx, reader, dist, world, rank=None, group_world=None, host_staged=False):
+        import torch
+        self.fpx, self.ctx, self.reader, self.dist, self.world = fpx, ctx, reader, dist, world
+        self.group_world = world if group_world is None else group_world      # 1: ONE GPU plays `rank` of `world` (bench.py's emulation)
+        self.rank = (dist.get_rank() if self.group_world == world and world > 1 else 0) if rank is None else rank
+        self.host_staged = host_staged
+        self.device = torch.device("cuda", ctx.device)
+        self.key_cap = 0
+        self.cell_cap = 0
+        self._k = self._b = None
+        self.last_stats = None
+
+    def _key_bufs(self):
+        import torch
+        if self._k is None or self._k[0].shape[1] != self.key_cap:
+            self._k = (torch.zeros((self.world, self.key_cap), dtype=torch.int64, device=self.device),
+                       torch.zeros((self.world,), dtype=torch.int64, device=self.device))
+            torch.cuda.current_stream(self.device).synchronize()
+        return self._k
+
+    def _bin_bufs(self, bpr):
+        import torch
+        if self._b is None or self._b[0].shape[1:] != (bpr, self.cell_cap):
+            self._b = (torch.empty((self.world, bpr, self.cell_cap), dtype=torch.int64, device=self.device),
+                       torch.zeros((self.world, bpr), dtype=torch.int32, device=self.device))
+            torch.cuda.current_stream(self.device).synchronize()
+        return self._b
+
+    def keys(self, share, B_global):
+        fpx = self.fpx
+        self.share, self.B = share, B_global
+        self.bpr = fpx.shard_bins_per_rank(B_global, self.world)
+        if self.key_cap == 0:
+            per = int(share.offsets[-1]) // max(1, self.world)
+            self.key_cap = per + per // 16 + 1024
+        self.key_need = 0
+        keys, kcnt = self._key_bufs()
+        need = fpx.shard_keys(self.ctx, share, self.world, self.rank, B_global, keys.data_ptr(), self.key_cap, kcnt.data_ptr())
+        if need:
+            # a slot outgrew the buffer: the counts this rank sends say so (FPX_SHARD_NEED_MARK | need), every receiver sees the mark in
+            # exchange_keys, and all ranks redo the keys with the largest need
+            self.key_need = int(need)
+            kcnt.fill_(fpx.SHARD_NEED_MARK | int(need))
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _a2a(self, send):
+        import torch
+        if self.host_staged:
+            s = send.cpu()
+            r = torch.empty_like(s)
+            self.dist.all_to_all_single(r.view(-1), s.view(-1))
+            return r.to(self.device)
+        r = torch.empty_like(send)
+        self.dist.all_to_all_single(r.view(-1), send.view(-1))
+        return r
+
+    def exchange_keys(self):
+        import torch
+        fpx = self.fpx
+        for attempt in range(4):
+            keys, kcnt = self._key_bufs()
+            self.recv_keys, self.recv_kcnt = self._a2a(keys), self._a2a(kcnt)
+            torch.cuda.current_stream(self.device).synchronize()
+            marks = self.recv_kcnt.cpu().numpy()
+            flagged = marks[marks >= fpx.SHARD_NEED_MARK]
+            if len(flagged) == 0:
+                return
+            # every rank received a count from every sender: all of them see the same marks and take the same new size
+            self.key_cap = max(self.key_cap + 1, int((flagged & (fpx.SHARD_NEED_MARK - 1)).max()))
+            self.keys(self.share, self.B)
+        raise RuntimeError("the key slots' size did not settle in four exchanges")
+
+    def emulate_received_keys(self):
+        """ONE GPU playing a rank of `world` (group_world == 1): what came back from the 1-rank exchange are this rank's own slots --
+        slot w holds the keys of window w.  A real rank receives world slots of ITS window, one per source: the stand-in moves every
+        slot's keys into this rank's window (the hash's top bits) and into source w's query range, so that the probe kernel does a real
+        rank's work on them (the results are not a search's)."""
+        import torch
+        wb = int(self.world).bit_length() - 1
+        qbits = max(0, int(self.B - 1).bit_length())
+        if wb == 0:
+            return
+        hi_shift = qbits + 32 - wb
+        keep = ~(((1 << wb) - 1) << hi_shift) & 0x7FFFFFFFFFFFFFFF
+        share_n = self.share.B
+        k = self.recv_keys
+        sign = k < 0                                              # (bit 63: a flagged duplicate keeps its flag)
+        k = (k & keep) | (int(self.rank) << hi_shift)
+        k = k + (torch.arange(self.world, device=k.device, dtype=torch.int64) * share_n - self.rank * share_n)[:, None]
+        self.recv_keys = torch.where(sign, k | (-0x8000000000000000), k).contiguous()
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def probe(self):
+        fpx = self.fpx
+        if self.cell_cap == 0:
+            self.cell_cap = 2048
+        send, counts = self._bin_bufs(self.bpr)
+        st, need = fpx.shard_probe_keys(self.reader, self.recv_keys.data_ptr(), self.key_cap, self.recv_kcnt.data_ptr(), self.world, self.B,
+                                        send.data_ptr(), self.cell_cap, counts.data_ptr())
+        if st is None:
+            import torch
+            counts.fill_(fpx.SHARD_NEED_MARK | int(need))           # (see HashShardedReader.partial)
+            torch.cuda.current_stream(self.device).synchronize()
+            st = fpx.Stats()
+        self.last_stats = st
+        return st
+
+    def exchange_bins(self):
+        import torch
+        send, counts = self._bin_bufs(self.bpr)
+        self.recv_bins, self.recv_counts = self._a2a(send), self._a2a(counts)
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def score(self, out=None, out_n=None):
+        """the share's final results; on ShardCellsTooSmall every rank raises it for the same step: redo probe / exchange_bins / score"""
+        fpx = self.fpx
+        out, out_n, q_lo, q_hi = fpx.shard_score_share(self.ctx, self.share, self.world, self.rank, self.B, self.recv_bins.data_ptr(), self.cell_cap,
+                                                       self.recv_counts.data_ptr(), out, out_n)
+        self.last_range = (q_lo, q_hi)
+        return out, out_n
+
+    def search(self, share, B_global, out=None, out_n=None, emulate=False):
+        """one step, all five stages in turn (tests; bench.py pipelines them)"""
+        self.keys(share, B_global)
+        self.exchange_keys()
+        if emulate:
+            self.emulate_received_keys()
+        for attempt in range(4):
+            st = self.probe()
+            self.exchange_bins()
+            try:
+                out, out_n = self.score(out, out_n)
+                return out, out_n, st
+            except self.fpx.ShardCellsTooSmall as e:
+                self.cell_cap = max(int(e.need), self.cell_cap + 1)
+        raise RuntimeError("the bins' size did not settle in four exchanges")

@@ -45,10 +45,11 @@ def synth_items(seed, first_doc, num_docs, H, dist=0):
     return items
 
 
-def make_queries(seed, qseed, num_queries, total_docs, H, query_len=1000, dist=0, first_doc=1, flip_frac=0.10):
+def make_queries(seed, qseed, num_queries, total_docs, H, query_len=1000, dist=0, first_doc=1, flip_frac=0.10, first_query=0):
     """query q = all H hashes of a uniformly chosen target doc, one random bit flipped in
-    ~10 % of them, padded with uniform noise hashes up to `query_len`.  Returns (flat u32, offsets u64, targets)."""
-    qs = np.arange(num_queries, dtype=np.uint64)
+    ~10 % of them, padded with uniform noise hashes up to `query_len`.  Returns (flat u32, offsets u64, targets).
+    first_query: the queries [first_query, first_query + num_queries) of the batch (a rank's share of a sharded batch)."""
+    qs = np.arange(first_query, first_query + num_queries, dtype=np.uint64)
     r = mix64(np.uint64(qseed) ^ (qs * _D))
     targets = (np.uint64(first_doc) + r % np.uint64(total_docs)).astype(np.uint64)
     hs = synth_hashes(seed, targets, H, dist)                      # [Q, H]

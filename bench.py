@@ -184,8 +184,12 @@ def row_from(B, steps, dt, agg, segs, kernel_hint=None):
     return r
 
 
+PMC_COUNTERS = ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")
+
+
 def parse_pmc_dir(d):
-    """FETCH_SIZE (KB) per dispatch of the probe and calibration kernels out of a rocprofv3 counter_collection.csv"""
+    """the memory-side read REQUEST counters per dispatch of the probe and calibration kernels out of a rocprofv3 counter_collection.csv:
+    {kernel: [per dispatch {counter: value}]} in dispatch order"""
     import collections
     import csv
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -194,30 +198,42 @@ def parse_pmc_dir(d):
     per = collections.OrderedDict()
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") != "FETCH_SIZE":
+            if r.get("Counter_Name") not in PMC_COUNTERS:
                 continue
             n = r["Kernel_Name"]
-            short = n.split("(")[0].split("::")[-1].split("<")[0]
+            short = n.split("(")[0].split("::")[-1]
+            if not short.startswith("k_bw_pattern"):
+                short = short.split("<")[0]
             if short.startswith("k_probe") or short.startswith("k_bw_"):
                 key = (int(r["Dispatch_Id"]), short)
-                per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
+                per.setdefault(key, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
     by = collections.defaultdict(list)
     for (did, short), v in sorted(per.items()):
-        by[short].append(v)
+        by[short].append(dict(v))
     return by
 
 
+def ea_read_bytes(c):
+    """bytes the L2 asked the memory side for: every request by its size class.  (gfx950: all of them are 128-byte requests -- the
+    calibration kernels below say so in every run; rocprofv3's own FETCH_SIZE tallies them at 64 bytes, hence the x2 of rounds 1-3.)"""
+    n32, n64, n128 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_64B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+    other = max(0.0, c.get("TCC_EA0_RDREQ_sum", 0.0) - n32 - n64 - n128)
+    return 32.0 * n32 + 64.0 * (n64 + other) + 128.0 * n128
+
+
 def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
-    """HBM bytes of the dominant kernel, measured in THIS run: a child process of this script under
-    `rocprofv3 --pmc FETCH_SIZE` (counters in their own pass, no tracing besides --kernel-trace) repeats the headline
-    batch on an identically built index; the two bandwidth kernels of known byte counts calibrate the counter's unit in
-    the same pass (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of a wide coalesced read)."""
+    """HBM read requests and bytes of the dominant kernel, COUNTED in this run: a child process of this script under
+    `rocprofv3 --pmc TCC_EA0_RDREQ_sum / _32B / _64B / _128B` (counters in their own pass, no tracing besides --kernel-trace) repeats
+    the headline batch (distinct batches in rotation) on an identically built index.  In the same pass, kernels with KNOWN requests in
+    the probe kernel's own access mix (fpx_measure_access: a whole 128-byte line per lane as eight 16-byte loads; one unaligned 16-byte
+    piece per lane; half a line; a line and two pieces; and the two bandwidth kernels) are counted too: `calibration` reports
+    counted / known for each -- the counters' unit is verified on this kernel's access pattern, not assumed."""
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
     d = tempfile.mkdtemp(prefix="fpx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-           sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1",
+    cmd = [exe, "--kernel-trace", "--pmc", *PMC_COUNTERS, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "2",
            "--docs", str(docs), "--segments", str(args.segments), "--hashes", str(args.hashes), "--batch", str(args.batch),
            "--query-len", str(args.query_len), "--limit", str(args.limit), "--seed", str(args.seed)]
     if args.min_score is not None:
@@ -232,31 +248,40 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
         if p.returncode != 0:
             return None, f"rocprofv3 child exited {p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
         by = parse_pmc_dir(d)
-        main = next((k for k in ("k_probe_group", "k_probe_direct") if by and by.get(k)), "k_probe_lean8")
+        main = next((k for k in ("k_probe_pgroup", "k_probe_group", "k_probe_direct") if by and by.get(k)), "k_probe_lean8")
         if not by or not by.get(main):
-            return None, "no k_probe_group / k_probe_direct / k_probe_lean8 dispatch in the counter output"
+            return None, "no k_probe_pgroup / k_probe_group / k_probe_direct / k_probe_lean8 dispatch in the counter output"
         child = None
         for line in p.stdout.decode(errors="replace").splitlines():
             if line.startswith('{"pmc_child"'):
                 child = json.loads(line)
-        lean = by[main][-2:]
-        kb = sum(lean) / len(lean)
+        last = by[main][-2:]
+        req = sum(c.get("TCC_EA0_RDREQ_sum", 0.0) for c in last) / len(last)
+        nbytes = sum(ea_read_bytes(c) for c in last) / len(last)
         cal = {}
         if child:
-            for k, known in (("k_bw_stream", child["bw_stream_bytes"]), ("k_bw_random", child["bw_random_bytes"])):
-                if by.get(k):
-                    cal[k] = {"known_bytes": known, "FETCH_SIZE_KB": by[k][-1], "reported_over_known": by[k][-1] * 1024 / known}
-        ratios = [c["reported_over_known"] for c in cal.values()]
-        # the correction is whatever the calibration kernels say in this pass (x2 on gfx950 / ROCm 7.2)
-        corr = 1.0 / (sum(ratios) / len(ratios)) if ratios else 2.0
+            lanes = child.get("pattern_lanes", 0)
+            known = {"k_bw_stream": child["bw_stream_bytes"] / 128.0, "k_bw_random": child["bw_random_bytes"] / 128.0,
+                     "k_bw_pattern<0>": lanes, "k_bw_pattern<1>": lanes * 35.0 / 32.0, "k_bw_pattern<2>": lanes,
+                     "k_bw_pattern<3>": lanes * (1.0 + 2.0 * 35.0 / 32.0), "k_bw_pattern<4>": lanes, "k_bw_pattern<6>": lanes}
+            what = {"k_bw_stream": "streaming read, 16 B per lane", "k_bw_random": "random 512-byte blocks", "k_bw_pattern<0>": "a whole line per lane, eight 16-byte loads",
+                    "k_bw_pattern<1>": "one 16-byte piece per lane at a 4-byte-aligned address (3 of 32 straddle a line)", "k_bw_pattern<2>": "an aligned 64-byte half line per lane",
+                    "k_bw_pattern<3>": "a line and two pieces per lane", "k_bw_pattern<4>": "a line per eight lanes, read together", "k_bw_pattern<6>": "the first 16 bytes of a line per lane"}
+            for k, lines in known.items():
+                if by.get(k) and lines:
+                    c = by[k][-1]
+                    cal[k] = {"what": what[k], "known_128B_lines": lines, "requests_counted": c.get("TCC_EA0_RDREQ_sum", 0.0),
+                              "of_them_128B": c.get("TCC_EA0_RDREQ_128B_sum", 0.0), "bytes_counted": ea_read_bytes(c),
+                              "counted_over_known_bytes": ea_read_bytes(c) / (lines * 128.0)}
         out_dir = os.environ.get("FPX_BENCH_PMC_KEEP")
         if out_dir:
             out_dir = os.path.join(out_dir, keep_tag) if keep_tag else out_dir
             os.makedirs(out_dir, exist_ok=True)
-            for f in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
-                shutil.copy(f, out_dir)
-        return {"kernel": main, "hbm_read_bytes_per_launch": kb * 1024 * corr, "FETCH_SIZE_KB_per_launch": kb, "correction": corr,
-                "calibration": cal, "launches_averaged": len(lean),
+            with open(os.path.join(out_dir, "ea_read_requests.json"), "w") as fh:      # (the raw CSVs are tens of MB: the per-kernel sums are what is kept)
+                json.dump({k: v[-3:] for k, v in by.items()}, fh, indent=1)
+        return {"kernel": main, "hbm_read_bytes_per_launch": nbytes, "read_requests_per_launch": req,
+                "request_sizes": {k: sum(c.get(k, 0.0) for c in last) / len(last) for k in PMC_COUNTERS},
+                "calibration": cal, "launches_averaged": len(last),
                 "child_probe_kernel_ms_under_profiler": child.get("probe_kernel_ms") if child else None}, None
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -264,7 +289,7 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
 
 def stored_traffic(docs, S, H, B, qlen):
     """fallback: the committed PMC pass, only for the same configuration AND the same kernel sources"""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = tr["config"]
@@ -272,7 +297,7 @@ def stored_traffic(docs, S, H, B, qlen):
                 continue
             if tr.get("kernel_source_sha16") != kernel_source_hash():
                 continue
-            k = next((k for k in ("k_probe_group", "k_probe_direct") if k in tr), "k_probe_lean8")
+            k = next((k for k in ("k_probe_pgroup", "k_probe_group", "k_probe_direct") if k in tr), "k_probe_lean8")
             return tr[k]["hbm_read_bytes_per_launch_corrected"], f"profiles/{name}@{tr['kernel_source_sha16']}"
         except (OSError, KeyError, ValueError):
             continue
@@ -405,7 +430,7 @@ def pmc_child_main(args):
     ctx.measure_bandwidth(nbytes, bs)
     # ... and the pattern kernels (fpx_measure_access): known requests in k_probe_group's own access mix
     lanes = 8 << 20
-    pat_ms = {f"k_bw_pattern<{m}>": ctx.measure_access(nbytes, m, lanes) for m in (0, 1, 2, 3, 4, 5, 6)}
+    pat_ms = {f"k_bw_pattern<{m}>": ctx.measure_access(nbytes, m, lanes) for m in (0, 1, 2, 3, 4, 6)}
     # byte counts of the calibration kernels (csrc/fpx_search.hip: measure_bandwidth_impl, k_bw_pattern)
     print(json.dumps({"pmc_child": True, "bw_stream_bytes": nbytes // 4096 * 4096, "bw_random_bytes": 256 * 16 * (256 // 32) * 64 * bs,
                       "pattern_lanes": lanes, "pattern_ms": pat_ms,
@@ -496,7 +521,17 @@ def main():
     #      directory lines and pages in the caches / TLBs (a repeated batch is the TLB's best case)
     NQB = max(1, int(os.environ.get("FPX_BENCH_QUERY_BATCHES", "8")))
     opts = fpx.http_options(limit=args.limit, min_score=args.min_score)
-    batches = [fpx.synth.make_queries(args.seed, 4242 + 1000003 * i, B, docs, H, query_len=args.query_len) for i in range(NQB)]
+    # hash sharding, the ROUTED protocol (FPX_BENCH_ROUTED=0: round 3's, the whole batch's hashes on every rank): a rank holds only
+    # ITS share of the batch -- the queries it finishes -- and uploads nothing else
+    routed = shard_mode == "hash" and os.environ.get("FPX_BENCH_ROUTED", "1") != "0"
+    B_global = B
+    if routed:
+        bpr = fpx.shard_bins_per_rank(B_global, pw)
+        q_share = (min(B_global, rank * bpr * 8), min(B_global, (rank + 1) * bpr * 8))
+        B = q_share[1] - q_share[0]
+        batches = [fpx.synth.make_queries(args.seed, 4242 + 1000003 * i, B, docs, H, query_len=args.query_len, first_query=q_share[0]) for i in range(NQB)]
+    else:
+        batches = [fpx.synth.make_queries(args.seed, 4242 + 1000003 * i, B, docs, H, query_len=args.query_len) for i in range(NQB)]
     qbs = [fpx.QueryBatch(ctx, options=opts, flat=(f, o)) for f, o, _ in batches]
     flat, offsets, targets = batches[0]
     qb = qbs[0]
@@ -509,6 +544,10 @@ def main():
     outs = [(np.zeros((B, cap, 2), np.uint32), np.zeros(B, np.uint32)) for _ in range(nfl)]
     if not sharded:
         shardeds = None
+    elif routed:
+        # (four steps alive at once: keys of step t + 1, probe of t, score of t - 1, results of t - 2 being read)
+        shardeds = [fpx.sharding.RoutedShardedReader(fpx, ctx, reader, dist, pw, rank=rank, group_world=world, host_staged=(backend != "nccl")) for _ in range(4)]
+        outs = [(np.zeros((B, cap, 2), np.uint32), np.zeros(B, np.uint32)) for _ in range(4)]
     elif shard_mode == "hash":
         shardeds = [fpx.sharding.HashShardedReader(fpx, ctx, reader, dist, pw, host_staged=(backend != "nccl"), group_world=world) for _ in range(nfl)]
     else:
@@ -533,6 +572,61 @@ def main():
             else:
                 with cf.ThreadPoolExecutor(nfl) as ex:
                     list(ex.map(one, range(nsteps)))
+            return
+
+        if routed:
+            # Five stages per step (sharding.RoutedShardedReader); the two exchanges are collectives and are issued HERE, by this one
+            # thread, in a fixed schedule -- X1(t), X2(t - 1) at time t -- so that every rank enters them in the same order; the
+            # compute stages run on worker threads under them: keys(t + 1), probe(t), score(t - 1) overlap.
+            emulate = eworld > 1
+            with cf.ThreadPoolExecutor(3) as ex:
+                f_keys, f_probe, f_score = {}, {}, {}
+
+                def score_step(i):
+                    sh = shardeds[i % 4]
+                    o, n = outs[i % 4]
+                    for attempt in range(4):
+                        try:
+                            sh.score(o, n)
+                            return sh.last_stats
+                        except fpx.ShardCellsTooSmall as e:       # (every rank raises it for the same step; rare: the first steps)
+                            sh.cell_cap = max(int(e.need), sh.cell_cap + 1)
+                            raise
+                f_keys[0] = ex.submit(shardeds[0].keys, which(0), B_global)
+                for t in range(nsteps + 2):
+                    if t < nsteps:
+                        f_keys.pop(t).result()
+                        sh = shardeds[t % 4]
+                        sh.exchange_keys()
+                        if emulate:
+                            sh.emulate_received_keys()
+                        f_probe[t] = ex.submit(sh.probe)
+                    if t + 1 < nsteps:
+                        if t - 3 in f_score:
+                            f_score.pop(t - 3).result()
+                        f_keys[t + 1] = ex.submit(shardeds[(t + 1) % 4].keys, which(t + 1), B_global)
+                    if 0 <= t - 1 < nsteps:
+                        f_probe.pop(t - 1).result()
+                        sh = shardeds[(t - 1) % 4]
+                        sh.exchange_bins()
+                        f_score[t - 1] = ex.submit(score_step, t - 1)
+                    if 0 <= t - 2 < nsteps and (t - 2) in f_score:
+                        try:
+                            st = f_score.pop(t - 2).result()
+                        except fpx.ShardCellsTooSmall:
+                            # the step's bins were too small on some rank: every rank is here; redo the step's second half in lock step
+                            sh = shardeds[(t - 2) % 4]
+                            for attempt in range(4):
+                                sh.probe(); sh.exchange_bins()
+                                try:
+                                    sh.score(*outs[(t - 2) % 4]); break
+                                except fpx.ShardCellsTooSmall as e:
+                                    sh.cell_cap = max(int(e.need), sh.cell_cap + 1)
+                            st = sh.last_stats
+                        if record and st is not None:
+                            agg.add(st)
+                for i in sorted(f_score):
+                    f_score.pop(i).result()
             return
 
         def stage1(i):
@@ -590,7 +684,7 @@ def main():
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
-    out, out_n = outs[(args.steps - 1) % nfl]
+    out, out_n = outs[(args.steps - 1) % (4 if routed else nfl)]
     out, out_n = out.copy(), out_n.copy()
     flat, offsets, targets = batches[(args.steps - 1) % NQB]          # (the batch of the last timed step: what `out` answers)
     qb = qbs[(args.steps - 1) % NQB]
@@ -613,11 +707,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # roofline numerator / denominator of the slowest rank is this rank's own; report rank 0's kernel
-    qps = B * args.steps / dt
+    qps = B_global * args.steps / dt
 
     # ---- size-independent correctness property at full size: the target doc ranks first
     # (hash sharding: every rank finishes its own 1/N of the queries; rank 0 checks its share)
-    q_lo, q_hi = shardeds[(args.steps - 1) % nfl].last_range if (sharded and shard_mode == "hash") else (0, B)
+    if routed:
+        q_lo, q_hi = 0, B                              # (the rank's own share: `out` and `targets` are the share's)
+    else:
+        q_lo, q_hi = shardeds[(args.steps - 1) % nfl].last_range if (sharded and shard_mode == "hash") else (0, B)
     found = sum(1 for q in range(q_lo, q_hi) if out_n[q] > 0 and out[q, 0, 0] == targets[q])
     top_scores = [int(out[q, 0, 1]) for q in range(q_lo, q_hi) if out_n[q] > 0]
 
@@ -640,9 +737,11 @@ def main():
             "config": {"workload": f"{docs} fingerprints x {H} u32 hashes in {S} FileSegments (512-B blocks"
                                    f"{'; kept direct-addressed in HBM' if dominant_kernel(segs) != 'k_probe_lean8' else ''}), "
                                    + (f"the index sharded by hash range over {pw} GPUs (every rank 1/{pw} of the hash space of all segments)" if shard_mode == "hash"
-                                      else f"segments sharded over {world} GPU(s)") + f"; batch of {B} queries x {args.query_len} hashes, "
+                                      else f"segments sharded over {world} GPU(s)") + f"; batch of {B_global} queries x {args.query_len} hashes, "
                                    f"limit {args.limit}, min_score (n+19)/20, score_pct 10; {NQB} distinct batches resident in HBM, searched in rotation",
-                       "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B, "global_batch": B, "batch_per_gpu": B // pw if scaling == "weak" else B,
+                       "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B_global, "global_batch": B_global, "batch_per_gpu": B_global // pw,
+                       "protocol": ("routed keys: a rank uploads its share of the batch, keys travel to their window's rank, bins back (two all-to-alls)" if routed
+                                    else ("the whole batch's hashes resident on every rank, bins exchanged" if shard_mode == "hash" else None)),
                        "sharding": shard_mode, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "segment_layout": ("direct-addressed" + (", one group (hash-major, segment-minor)" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",
@@ -666,8 +765,8 @@ def main():
                                               "blocks_finished_by_generic_pass_per_step": agg.v["generic_iters"] / max(1, args.steps)}},
             "inflight": nfl,
             "query_batches_rotated": NQB,
-            **({"ms_per_step_long": dt_long / long_steps * 1e3, "value_long": B * long_steps / dt_long, "steps_long": long_steps,
-                "repeated_batch": {"steps": long_steps, "ms_per_step": dt_rep / long_steps * 1e3, "queries_per_s": B * long_steps / dt_rep,
+            **({"ms_per_step_long": dt_long / long_steps * 1e3, "value_long": B_global * long_steps / dt_long, "steps_long": long_steps,
+                "repeated_batch": {"steps": long_steps, "ms_per_step": dt_rep / long_steps * 1e3, "queries_per_s": B_global * long_steps / dt_rep,
                                    "note": "ONE resident batch searched again and again (what rounds 1-3 timed): its directory lines and pages "
                                            "are the previous step's; `value` and `value_long` rotate through distinct batches"}} if long_steps else {}),
             **({"emulated_rank_of_world": eworld, "note": "ONE rank's share of a sharded run emulated on one GPU: not a result"} if eworld > 1 else {}),
@@ -836,7 +935,7 @@ def main():
             t_p = time.perf_counter()
             pmc, err = run_pmc_child(args, docs)
             if pmc:
-                traffic, src = pmc["hbm_read_bytes_per_launch"], "in-run: rocprofv3 --pmc FETCH_SIZE child pass of this script"
+                traffic, src = pmc["hbm_read_bytes_per_launch"], "in-run: rocprofv3 --pmc TCC_EA0_RDREQ_{sum,32B,64B,128B} child pass of this script (requests counted by size; calibration kernels in the same pass)"
                 result["roofline"]["pmc"] = {**pmc, "seconds": round(time.perf_counter() - t_p, 1)}
             else:
                 result["roofline"]["pmc"] = {"error": err}
@@ -846,8 +945,13 @@ def main():
             rf = result["roofline"]
             gbs = traffic / (rf["avg_launch_ms"] * 1e-3) / 1e9
             rf.update({"traffic": traffic, "traffic_source": src, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
-                       "achieved_basis": "HBM read bytes by PMC (FETCH_SIZE, calibrated in the same pass) per launch / HIP-event time of the "
-                                         "unprofiled launches in this run"})
+                       "requests": pmc["read_requests_per_launch"] if pmc else None,
+                       "request_rate_G_per_s": (pmc["read_requests_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) if pmc else None,
+                       "request_rate_peak_measured_G_per_s": 47.0,
+                       "request_rate_note": "47 G requests/s: what this chip served random 128-byte reads at with many loads in flight (tools/random_read2.hip, "
+                                            "profiles/r02_random_read_rates.txt)",
+                       "achieved_basis": "HBM read bytes COUNTED by PMC (memory-side read requests by size class; all of them 128-byte on gfx950, verified by the "
+                                         "calibration kernels of the same pass) per launch / HIP-event time of the unprofiled launches in this run"})
 
     # ---- the same index in BLOCK form (FPX_DIRECT=0): the kernel north_star names -- coalesced loads of the segments' block
     #      pages, LDS-staged StreamVByte decode (src/streamvbyte.zig:341-412, src/block.zig:137-158) -- with its own roofline:
@@ -891,9 +995,10 @@ def main():
                 if pmc_b:
                     gbs = pmc_b["hbm_read_bytes_per_launch"] / (rfb["avg_launch_ms"] * 1e-3) / 1e9
                     rfb.update({"traffic": pmc_b["hbm_read_bytes_per_launch"], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "pmc": pmc_b,
-                                "achieved_basis": "HBM read bytes by PMC (FETCH_SIZE, calibrated in the same pass) per launch / HIP-event time of the "
+                                "requests": pmc_b["read_requests_per_launch"],
+                                "achieved_basis": "HBM read bytes COUNTED by PMC (memory-side read requests by size class) per launch / HIP-event time of the "
                                                   "unprofiled launches in this run",
-                                "traffic_source": "in-run: rocprofv3 --pmc FETCH_SIZE child pass of this script with FPX_DIRECT=0"})
+                                "traffic_source": "in-run: rocprofv3 --pmc TCC_EA0_RDREQ_* child pass of this script with FPX_DIRECT=0"})
                 else:
                     rfb["pmc"] = {"error": err_b}
             result["roofline_block_form"] = rfb

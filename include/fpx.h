@@ -247,6 +247,29 @@ int  fpx_sharded_search_batch(fpx_sharded_snapshot *snap, const uint32_t *hashes
                               uint32_t num_queries, const fpx_opts *opts, uint32_t timeout_ms,
                               fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats);
 
+/* The same one-call shape with the index sharded by HASH RANGE (the layout that scales): context k = rank k holds
+ * window k -- hashes [k 2^32 / world, (k + 1) 2^32 / world) -- of ALL segments.
+ *   fpx_segment_create_file_windows      one segment file -> its `world` window slices, slice k resident on ctxs[k] (the blocks that
+ *                                        hold the window's hashes + 3 halo blocks, src/FileSegment.zig:25,153-174; the whole docs
+ *                                        map with every slice).  Replaces the end of filefmt.readSegment (src/filefmt.zig:270-284).
+ *   fpx_sharded_snapshot_create_windows  slices[k * num_segs + j] = slice k of segment j (snapshot order, commit ids ascending);
+ *                                        rank k's slices become one group with its window.  world: 1, 2, 4 .. 64.
+ * fpx_sharded_search(_batch) on such a snapshot runs the routed-key protocol behind the one call: 1 / world of the batch's hashes
+ * goes to each device (H2D), the devices make the keys of their share and deal them to the windows' ranks (all-to-all #1: RCCL
+ * grouped send / recv over xGMI when every context has a device of its own, peer copies otherwise), every rank probes the keys of
+ * ITS window and drops the records into the batch's bins, the bins travel to the rank their queries came from (all-to-all #2)
+ * and that rank writes their final results straight into the caller's rows.  Same results as an unsharded snapshot of the whole
+ * segments.  Batches the bin protocol does not take (a score floor of 1 or 2, queries of more than 2048 hashes) fail with
+ * FPX_E_INVAL: a host that needs those keeps a segment-sharded snapshot next to this one. */
+int fpx_segment_create_file_windows(fpx_ctx *const *ctxs, uint32_t world,
+                                    const uint8_t *blocks, size_t blocks_len, uint32_t block_size,
+                                    const uint32_t *block_index, uint32_t num_blocks,
+                                    uint32_t min_doc_id, uint32_t max_doc_id, uint64_t commit_id,
+                                    const uint32_t *doc_ids, const uint8_t *doc_alive, uint32_t num_docs,
+                                    fpx_segment **out /* [world] */);
+int fpx_sharded_snapshot_create_windows(fpx_ctx *const *ctxs, uint32_t world, fpx_segment *const *slices, uint32_t num_segs,
+                                        fpx_sharded_snapshot **out);
+
 /* ---- pinned host memory --------------------------------------------------------------------------------------------
  * fpx_search_batch copies the caller's hashes to HBM and the results back.  From ordinary (pageable) memory the runtime
  * stages those copies and the calling thread waits for them; from page-locked memory they are asynchronous DMA.  A host

@@ -245,3 +245,34 @@ def test_hash_sharded_reader_over_one_rank_group(monkeypatch):
         assert (st.scanned_blocks, st.scanned_docs) == (st2.scanned_blocks, st2.scanned_docs)
     finally:
         dist.destroy_process_group()
+
+
+def test_routed_sharded_reader_over_one_rank_group(monkeypatch):
+    """sharding.RoutedShardedReader (what bench.py --gpus N runs) with a 1-rank process group: keys, all-to-all #1, probe, all-to-all #2,
+    score = the plain search; the slots and bins start too small on purpose (the marked-count agreement on their sizes)"""
+    import torch
+    import torch.distributed as dist
+    from fpx_testlib import fpx, Pair
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    monkeypatch.setenv("FPX_FUSE_MIN", "1")
+    ctx = fpx.Context(0)
+    rng = np.random.default_rng(6)
+    p = Pair(ctx)
+    for s, (items, lo, hi, ids, alive) in enumerate(_world_data(fpx, rng, 2, 4000, 48, 78)):
+        p.add_file(items, lo, hi, s + 1, ids, alive)
+    p.finish()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29643")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sh = fpx.sharding.RoutedShardedReader(fpx, ctx, p.reader, dist, 1)
+        sh.key_cap, sh.cell_cap = 32, 16
+        flat, off, _ = fpx.synth.make_queries(78, 3, 70, 8000, 48, query_len=200, dist=1)
+        qb = fpx.QueryBatch(ctx, options=fpx.http_options(), flat=(flat, off))
+        out, out_n, st = sh.search(qb, qb.B)
+        assert sh.key_cap > 32 and sh.cell_cap > 16 and sh.last_range == (0, qb.B)
+        o2, n2, st2 = fpx.search_resident(p.reader, qb)
+        assert fpx.results_to_lists(out, out_n) == fpx.results_to_lists(o2, n2)
+        assert (st.scanned_blocks, st.scanned_docs) == (st2.scanned_blocks, st2.scanned_docs)
+    finally:
+        dist.destroy_process_group()

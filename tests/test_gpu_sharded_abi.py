@@ -148,3 +148,74 @@ def test_an_index_without_segments_answers_with_no_results():
     empty = fpx.ShardedIndexReader(fpx.ShardedSegments([], root=ctx))
     r = fpx.SearchResults(fpx.http_options())
     assert empty.search(np.arange(100, dtype=np.uint32), r) == []
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_window_sharded_snapshot_routes_keys_behind_one_call(world, monkeypatch):
+    """fpx_segment_create_file_windows + fpx_sharded_snapshot_create_windows + fpx_sharded_search_batch: the index sharded by hash range
+    behind the one call (src/Index.zig:170-177 answers a search with one call) -- `world` contexts (distinct devices when the box has
+    them), the batch's hashes split over them, keys routed to their window's rank, bins back to the rank the queries came from.  Same
+    results and the same scanned blocks / docs as the unsharded snapshot and the oracle; many host threads at once."""
+    from fpx_testlib import fpx, oracle, Pair
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    monkeypatch.setenv("FPX_FUSE_MIN", "1")
+    ndev = _device_count()
+    ctxs = [fpx.Context(k % ndev) for k in range(world)]
+    seed, S, per, H = 60 + world, 4, 5000, 48
+    rng = np.random.default_rng(seed)
+    full = Pair(ctxs[0])
+    slices = [[] for _ in range(world)]
+    for s in range(S):
+        lo = s * per + 1
+        ids = np.arange(lo, lo + per, dtype=np.uint64)
+        extra = np.sort(rng.choice(np.arange(1, lo), 200, replace=False)).astype(np.uint64) if s else np.zeros(0, np.uint64)
+        tomb = np.sort(rng.choice(np.setdiff1d(np.arange(1, lo), extra), 50, replace=False)).astype(np.uint64) if s else np.zeros(0, np.uint64)
+        live_ids = np.concatenate([extra, ids])
+        h = fpx.synth.synth_hashes(seed + s, live_ids, H, 1).astype(np.uint64)       # hot pool: lists cut by the caps, runs across blocks
+        items = np.sort(((h << np.uint64(32)) | live_ids[:, None]).ravel())
+        doc_ids = np.concatenate([live_ids, tomb]).astype(np.uint32)
+        alive = np.concatenate([np.ones(len(live_ids), np.uint8), np.zeros(len(tomb), np.uint8)])
+        mn, mx = int(doc_ids.min()), int(doc_ids.max())
+        blocks, index = full.add_file(items, mn, mx, s + 1, doc_ids, alive)
+        for k, sl in enumerate(fpx.file_segment_windows(ctxs, blocks, 512, index, mn, mx, s + 1, doc_ids, alive)):
+            slices[k].append(sl)
+    full.finish()
+    sh = fpx.ShardedIndexReader(fpx.WindowShardedSegments(ctxs, slices))
+    assert sh.snapshot.num_devices == world
+    B = 200
+    flat, off, _ = fpx.synth.make_queries(seed, 3, B, S * per, H, query_len=160, dist=1)
+    flat = flat.copy()
+    flat[9] = flat[8]                                                 # a duplicate hash inside a query
+    queries = [flat[int(off[i]):int(off[i + 1])] for i in range(B)]
+    for opts in (fpx.http_options(), fpx.SearchOptions(500, 3, 10), fpx.SearchOptions(3, 4, 100)):
+        want, wst = full.check(queries, opts, with_stats=False)
+        for rep in range(2):                                          # (the slots' sizes settle on the first call)
+            got, st = sh.search_batch(queries, opts)
+            assert got == want
+            assert (st.scanned_blocks, st.scanned_docs, st.probes, st.hits) == (wst.scanned_blocks, wst.scanned_docs, wst.probes, wst.hits)
+        for q in (0, 57, B - 1):
+            assert got[q] == full.osnap.search(queries[q], opts.max_results, opts.min_score, opts.min_score_pct)
+    # a batch smaller than the number of ranks' bins, and one query alone
+    got, _ = sh.search_batch(queries[:5], fpx.http_options())
+    assert got == [full.osnap.search(q) for q in queries[:5]]
+    r = fpx.SearchResults(fpx.http_options())
+    assert sh.search(queries[3], r) == full.osnap.search(queries[3])
+    # what the bin protocol does not take is refused, not answered wrongly
+    with pytest.raises(fpx.FpxError):
+        sh.search_batch(queries[:16], fpx.SearchOptions(500, 1, 10))
+    # many host threads on the one snapshot
+    want = [full.osnap.search(q) for q in queries[:64]]
+    errs = []
+
+    def work(t):
+        try:
+            for rep in range(3):
+                lo = (t * 8 + rep * 16) % 48
+                g, _ = sh.search_batch(queries[lo:lo + 16], fpx.http_options())
+                assert g == want[lo:lo + 16]
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:1]

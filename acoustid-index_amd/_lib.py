@@ -61,6 +61,10 @@ SIGNATURES = {
     "fpx_segment_slice": (C.c_int, [_vp, C.c_int, _u32, C.c_int, _u32, C.POINTER(_vp)]),
     "fpx_shard_bins_per_rank": (_u32, [_u32, _u32]),
     "fpx_shard_probe": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, C.POINTER(_u64), C.POINTER(Stats)]),
+    "fpx_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "fpx_ctx_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
+    "fpx_segment_layout_reason": (C.c_char_p, [_vp]),
+    "fpx_snapshot_info": (C.c_int, [_vp, _vp, _u32]),
     "fpx_shard_keys": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u64, _vp, C.POINTER(_u64)]),
     "fpx_shard_probe_keys": (C.c_int, [_vp, _vp, _u64, _vp, _u32, _u32, _u32, _vp, _u64, _vp, C.POINTER(_u64), C.POINTER(Stats)]),
     "fpx_shard_score_share": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64)]),

@@ -198,11 +198,19 @@ int finish_file_segment(Segment* s)
     return decode_small_segment(s);
 }
 
+uint32_t ctx_fuse_min(const Ctx* c)
+{
+    const int64_t o = c ? c->opt_fuse_min.load(std::memory_order_relaxed) : -2;
+    if (o >= 0) return (uint32_t)o;
+    static const uint32_t env = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
+    return env;
+}
+
 // what the block kernels need of a candidate that stays in blocks after all (no room for another form)
 static int settle_in_blocks(Segment* s)
 {
     if (s->d_proberec || s->d_small_items || s->settled) return FPX_OK;
-    s->settled = true;
+    s->settled = true;                     // (s->why says what kept it from another form)
     int rc = build_presence(s);
     if (rc) return rc;
     return decode_small_segment(s);
@@ -214,7 +222,7 @@ static int settle_in_blocks(Segment* s)
 // What is left over becomes direct-addressed on its own, or (no room, a hash-window slice) settles in its blocks.
 int resolve_candidates(Ctx* c, const std::vector<Segment*>& segs)
 {
-    static const uint32_t fuse_min = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
+    const uint32_t fuse_min = ctx_fuse_min(c);
     std::vector<Segment*> lone;
     for (Segment* s : segs)
         // (a candidate that SETTLED in its blocks under an earlier snapshot stays there: that snapshot's descriptors point at its
@@ -309,6 +317,36 @@ int fpx_ctx_create(int device, fpx_ctx** out)
 }
 
 int fpx_ctx_device(const fpx_ctx* ctx) { return ctx ? reinterpret_cast<const Ctx*>(ctx)->device : -1; }
+
+static std::atomic<int64_t>* ctx_option(Ctx* c, const char* name)
+{
+    if (!c || !name) return nullptr;
+    if (!std::strcmp(name, "direct")) return &c->opt_direct;
+    if (!std::strcmp(name, "direct_min_items")) return &c->opt_direct_min_items;
+    if (!std::strcmp(name, "fuse_min")) return &c->opt_fuse_min;
+    if (!std::strcmp(name, "group_packed")) return &c->opt_group_packed;
+    return nullptr;
+}
+
+int fpx_ctx_set_option(fpx_ctx* ctx, const char* name, int64_t value)
+{
+    std::atomic<int64_t>* o = ctx_option(reinterpret_cast<Ctx*>(ctx), name);
+    if (!o) { set_error("fpx_ctx_set_option: unknown option (direct, direct_min_items, fuse_min, group_packed)"); return FPX_E_INVAL; }
+    o->store(value < -1 ? -2 : value);
+    return FPX_OK;
+}
+
+int fpx_ctx_get_option(const fpx_ctx* ctx, const char* name, int64_t* value)
+{
+    Ctx* c = const_cast<Ctx*>(reinterpret_cast<const Ctx*>(ctx));
+    if (!ctx_option(c, name) || !value) { set_error("fpx_ctx_get_option: unknown option"); return FPX_E_INVAL; }
+    // the value in force: the context's own, else the environment's, else the default
+    if (!std::strcmp(name, "direct")) *value = ctx_direct_enabled(c) ? 1 : 0;
+    else if (!std::strcmp(name, "direct_min_items")) *value = (int64_t)ctx_direct_min_items(c);
+    else if (!std::strcmp(name, "fuse_min")) *value = (int64_t)ctx_fuse_min(c);
+    else *value = ctx_group_packed(c);
+    return FPX_OK;
+}
 
 void fpx_ctx_destroy(fpx_ctx* ctx_)
 {
@@ -487,6 +525,15 @@ int fpx_segment_layout(const fpx_segment* seg)
     return !s || !s->direct ? 0 : s->home ? 2 : 1;
 }
 
+const char* fpx_segment_layout_reason(const fpx_segment* seg)
+{
+    const Segment* s = reinterpret_cast<const Segment*>(seg);
+    if (!s) return "";
+    if (s->kind == 1) return "memory segment: its sorted items as given";
+    if (s->kind == 2) return "remote: docs map only";
+    return s->why;
+}
+
 int fpx_segment_group_info(const fpx_segment* seg, uint64_t* info, uint32_t n)
 {
     const Segment* s = reinterpret_cast<const Segment*>(seg);
@@ -584,6 +631,8 @@ static void snapshot_free(Snapshot* sn)
     if (sn->d_solo) (void)hipFree(sn->d_solo);
     sn->groups.clear(); sn->solo_stores.clear();
     if (sn->d_mem) (void)hipFree(sn->d_mem);
+    if (sn->d_memtab) (void)hipFree(sn->d_memtab);
+    if (sn->d_membucket) (void)hipFree(sn->d_membucket);
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;
 }
@@ -761,11 +810,35 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         if (e == hipSuccess) e = hipMemcpy(sn->d_mem, sn->h_mem.data(), sn->n_mem * sizeof(MemDesc), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "snapshot upload"); }
+    if (sn->n_mem) {
+        const int mrc = build_memtab(sn);             // (FPX_E_NOMEM: the memory segments are probed one by one, as before)
+        if (mrc != FPX_OK && mrc != FPX_E_NOMEM) { snapshot_free(sn); return mrc; }
+    }
     *out = reinterpret_cast<fpx_snapshot*>(sn);
     return FPX_OK;
 }
 
 void fpx_snapshot_retain(fpx_snapshot* snap) { if (snap) reinterpret_cast<Snapshot*>(snap)->refs.fetch_add(1); }
+
+int fpx_snapshot_info(const fpx_snapshot* snap, uint64_t* info, uint32_t n)
+{
+    const Snapshot* sn = reinterpret_cast<const Snapshot*>(snap);
+    if (!sn || !info) { set_error("null argument"); return FPX_E_INVAL; }
+    uint64_t grouped = 0, packed = 0, settled = 0, bytes = 0;
+    for (const auto& g : sn->groups) packed += g->packed ? 1u : 0u;
+    for (const Segment* s : sn->segs) {
+        if (s->ctx != sn->ctx) continue;
+        if (s->kind == 0 && s->home) grouped += 1;
+        if (s->kind == 0 && s->settled) settled += 1;
+        bytes += fpx_segment_device_bytes(reinterpret_cast<const fpx_segment*>(s));
+    }
+    const uint64_t v[12] = {sn->n_lean, sn->n_gen, sn->n_small, sn->n_solo, grouped, sn->n_group, packed, sn->n_mem, settled, bytes,
+                            // a batch of this snapshot takes the one-launch path (records binned by the probe kernel, scored a bin per workgroup) when it
+                            // holds groups and nothing else
+                            (sn->n_group != 0 && sn->n_solo == 0 && sn->n_file == 0 && sn->n_mem == 0) ? 1ull : 0ull, sn->n_file};
+    for (uint32_t i = 0; i < n && i < 12u; ++i) info[i] = v[i];
+    return FPX_OK;
+}
 
 void fpx_snapshot_release(fpx_snapshot* snap)
 {

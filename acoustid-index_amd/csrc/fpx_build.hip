@@ -935,13 +935,17 @@ __global__ __launch_bounds__(256) void k_direct_rec_base(uint32_t* __restrict__ 
 
 __global__ void k_boff_tail(uint64_t* boff, uint32_t nb, const uint64_t* total) { boff[nb] = *total; }
 
-static bool direct_enabled()
+bool ctx_direct_enabled(const Ctx* c)
 {
+    const int64_t o = c ? c->opt_direct.load(std::memory_order_relaxed) : -2;
+    if (o >= 0) return o != 0;
     const char* e = getenv("FPX_DIRECT");                       // read per segment: the tests move it
     return e ? atoi(e) != 0 : true;
 }
-static uint64_t direct_min_items()
+uint64_t ctx_direct_min_items(const Ctx* c)
 {
+    const int64_t o = c ? c->opt_direct_min_items.load(std::memory_order_relaxed) : -2;
+    if (o >= 0) return (uint64_t)o;
     // from the size at which the block form would get probe records and the lean kernel: that kernel costs a batch ~0.3 ms per
     // segment whatever the segment's size (its probes' record lines), the direct form -- one more column of the snapshot's
     // fused directory -- next to nothing for the hashes a small segment does not have; it costs 1.07 GB of records + up to
@@ -985,10 +989,12 @@ __global__ __launch_bounds__(256) void k_direct_precheck(const uint8_t* __restri
 int direct_candidate(Segment* s, bool* ok)
 {
     *ok = false;
-    if (!direct_enabled() || s->kind != 0 || s->num_blocks == 0 || s->num_items == 0 ||
-        s->num_items < direct_min_items() || s->num_items > 0xFFFFFFFFull ||
-        (uint64_t)s->max_doc_id - (uint64_t)s->min_doc_id >= (1ull << 31) || s->max_doc_id < s->min_doc_id)
-        return FPX_OK;
+    if (!ctx_direct_enabled(s->ctx)) { s->why = "blocks: the direct-addressed forms are turned off (option direct = 0)"; return FPX_OK; }
+    if (s->kind != 0 || s->num_blocks == 0 || s->num_items == 0) { s->why = "blocks: an empty segment"; return FPX_OK; }
+    if (s->num_items < ctx_direct_min_items(s->ctx)) { s->why = "blocks: fewer items than option direct_min_items"; return FPX_OK; }
+    if (s->num_items > 0xFFFFFFFFull || (uint64_t)s->max_doc_id - (uint64_t)s->min_doc_id >= (1ull << 31) || s->max_doc_id < s->min_doc_id) {
+        s->why = "blocks: 2^32 items or more, or doc ids spanning 2^31 or more"; return FPX_OK;
+    }
     const uint32_t nb = s->num_blocks;
     hipStream_t st = 0;
     int rc;
@@ -1004,7 +1010,10 @@ int direct_candidate(Segment* s, bool* ok)
     FPX_HIP(hipStreamSynchronize(st));
     // a gap position costs a word: uniformly spread hashes have 2^32 / (items per block) of them whatever the segment's size
     // (39 M: 156 MB); a segment whose hashes cluster (more than 2^26 and more than a quarter of its items) keeps its blocks
-    if (h_out[1] != 0 || h_out[0] > std::max<uint64_t>(s->num_items / 4, 1ull << 26)) return FPX_OK;
+    if (h_out[1] != 0 || h_out[0] > std::max<uint64_t>(s->num_items / 4, 1ull << 26)) {
+        s->why = h_out[1] != 0 ? "blocks: not written by the reference's encoder (chunks of four items)" : "blocks: clustered hashes (too many gap positions)";
+        return FPX_OK;
+    }
     s->first_hash = h_ends[0]; s->last_hash = h_ends[1];
     if (!s->d_bstart) {
         FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
@@ -1017,6 +1026,7 @@ int direct_candidate(Segment* s, bool* ok)
         FPX_HIP(hipStreamSynchronize(st));
     }
     *ok = true;
+    s->why = "blocks: a candidate for a direct-addressed form, decided when a snapshot first holds it";
     return FPX_OK;
 }
 
@@ -1112,19 +1122,25 @@ void DirectPiece::release()
 // offsets) leaves it block-based, which is always correct.
 int build_direct(Segment* s)
 {
-    if (s->own_flags != 0u) return FPX_OK;                   // (a hash-window slice is direct-addressed only as part of a group)
+    if (s->own_flags != 0u) { s->why = "blocks: a hash-window slice on its own (it becomes direct-addressed as a column of a group)"; return FPX_OK; }
     const uint64_t n = s->num_items;
     const uint32_t nb = s->num_blocks;
     size_t free_b = 0, total_b = 0;
     // peak: the items (8 n) + records (1 GB) + primary and extras (<= ~10 n) on top of the blocks
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 18ull + ((size_t)10 << 30)) { (void)hipGetLastError(); return FPX_OK; }
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 18ull + ((size_t)10 << 30)) {
+        (void)hipGetLastError();
+        s->why = "blocks: not enough free HBM to convert it (the direct-addressed form is built next to the blocks)";
+        return FPX_OK;
+    }
     DirectPiece pc;
     const int rc = build_direct_piece(s, 0, nb, HashRange{0u, 0xFFFFFFFFu, 0u, 1u}, DIRECT_NREC, false, 0u, &pc);
     if (rc != FPX_OK) {
         pc.release();
         (void)hipGetLastError();
+        s->why = "blocks: the conversion to the direct-addressed form did not go through (memory, or lists too long for their offsets)";
         return rc == FPX_E_DEVICE ? rc : FPX_OK;             // an internal inconsistency is an error; anything else: stay block-based
     }
+    s->why = "direct-addressed on its own: no other dense segment of its hash window to form a group with";
     s->d_drec = pc.drec; s->d_primary = pc.primary; s->d_extras = pc.extras; s->extras_shift = pc.xshift;
     s->num_distinct = pc.distinct; s->num_positions = pc.positions; s->extras_words = pc.extras_words;
     s->direct = true;

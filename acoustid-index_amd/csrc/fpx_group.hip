@@ -18,6 +18,14 @@
 
 namespace fpx {
 
+int ctx_group_packed(const Ctx* c)
+{
+    const int64_t o = c ? c->opt_group_packed.load(std::memory_order_relaxed) : -2;
+    if (o >= -1) return (int)o;
+    const char* e = getenv("FPX_GROUP_PACKED");
+    return e ? atoi(e) : -1;
+}
+
 Group::~Group()
 {
     (void)hipSetDevice(device);
@@ -456,7 +464,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     // hash) pays when the lines are reasonably full: from ~6 positions per line on, i.e. from ~10 % of all (hash, column) cells
     // taken -- the 100 M index: 31 %, 20 positions + 3 second words of doubles per line of 29.  A sparser group keeps the
     // directory + words form (a line per 32 hash values): 4 - 16 x fewer lines.  FPX_GROUP_PACKED = 0 | 1 decides for every group.
-    static const int packed_forced = [] { const char* e = getenv("FPX_GROUP_PACKED"); return e ? atoi(e) : -1; }();
+    const int packed_forced = ctx_group_packed(ctx);
     uint64_t items_total = 0;
     for (uint32_t j = 0; j < k; ++j) items_total += segs[j]->num_items;
     const uint32_t hvl = ns == 16u ? 2u : 3u;                                     // log2 hash values per packed line
@@ -480,6 +488,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)3 << 30)) {
         (void)hipGetLastError();
+        for (uint32_t j = 0; j < k; ++j) if (!segs[j]->direct) segs[j]->why = "blocks: not enough free HBM to build the group next to the members' blocks";
         set_error("not enough free HBM to group %u segments (%.1f GB needed, %.1f free)", k, need / 1e9, free_b / 1e9);
         return FPX_E_NOMEM;
     }
@@ -612,6 +621,8 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     for (uint32_t j = 0; j < k; ++j) {
         Segment* s = segs[j];
         s->home = g; s->col = j;
+        s->why = packed ? "a column of a PACKED group (128-byte lines of 4 / 8 hash values with their words inside): one HBM line per query hash"
+                        : "a column of a group in its directory + words form (too sparse for the packed form, or doc ids spanning 2^31)";
         if (s->direct) { s->dstore.reset(); s->d_drec = s->d_primary = s->d_extras = nullptr; }
         else { free_block_form(s); s->direct = true; }
         s->device_bytes = ((size_t)s->num_blocks + 1) * 8;

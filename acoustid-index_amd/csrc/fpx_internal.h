@@ -194,6 +194,7 @@ struct Segment {
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
     // direct-addressed form (fpx_direct.hpp): replaces the blocks of a dense segment; d_bstart (item offset of every block) and
     // d_block_index stay, so that the blocks can be written out again byte for byte (materialize_blocks)
+    const char* why = "";          // why the segment is kept the way it is (fpx_segment_layout_reason): a static string
     bool candidate = false;        // direct_candidate() accepted it: a snapshot decides between a group, the direct form on its own, its blocks
     bool settled = false;          // ... and it settled in its blocks (no room for another form)
     bool direct = false;
@@ -233,6 +234,9 @@ struct Snapshot {
     SegDesc* d_solo = nullptr; uint32_t n_solo = 0;
     uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
+    // ... and ONE table of all memory segments' LIVE postings (superseded docs dropped), sorted by hash, behind a 2^20-entry bucket
+    // table: a query hash is looked up once for all memory segments, in any key order (fpx_probe_small.hpp: k_probe_memtab)
+    uint64_t* d_memtab = nullptr; uint32_t* d_membucket = nullptr; uint64_t n_memtab = 0;
     std::vector<std::shared_ptr<DeadSet>> dead_sets;   // shared with the segments' caches
     uint32_t max_block_size = 0;
     bool all_512 = true;                 // every file segment uses 512-B blocks (the only size the reference writes)
@@ -297,12 +301,20 @@ struct QueryBatch {
 
 struct Ctx {
     int device = 0;
+    // how this context keeps its file segments in HBM (fpx_ctx_set_option; below -1: the environment variable of the same name,
+    // then the built-in default) -- thresholds that decide a storage form belong to the index, not to the process's environment
+    std::atomic<int64_t> opt_direct{-2}, opt_direct_min_items{-2}, opt_fuse_min{-2}, opt_group_packed{-2};
     std::mutex mu;
     std::mutex group_mu;                  // serialises the grouping of segments (fpx_snapshot_create, fpx_segments_group)
     std::vector<Workspace*> free_ws;
     std::atomic<int> live_ws{0};
 };
 
+// the options of a context (fpx_ctx_set_option), falling back to the environment and the defaults
+bool ctx_direct_enabled(const Ctx* c);
+uint64_t ctx_direct_min_items(const Ctx* c);
+uint32_t ctx_fuse_min(const Ctx* c);
+int ctx_group_packed(const Ctx* c);       // -1: decided per group by its density
 void set_error(const char* fmt, ...);
 int  hip_fail(hipError_t e, const char* what);
 #define FPX_HIP(expr)                                              \
@@ -351,6 +363,7 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
 int merge_partials_impl(Ctx* ctx, const void* d_parts, const void* d_counts, uint32_t world,
                         uint32_t B, uint32_t part_cap, const fpx_opts* opts, const uint64_t* offsets,
                         fpx_result* out, uint32_t out_cap, uint32_t* out_n);
+int build_memtab(Snapshot* sn);            // fills Snapshot::d_memtab / d_membucket from d_mem (fpx_search.hip)
 int measure_bandwidth_impl(Ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs);
 int measure_access_impl(Ctx* ctx, size_t bytes, int mode, uint64_t lanes, double* ms_out);
 

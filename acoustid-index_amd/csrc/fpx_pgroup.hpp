@@ -33,8 +33,15 @@
 namespace fpx {
 
 // (waves per SIMD: the line's head and twelve words need far fewer registers than round 3's whole directory line)
+// (Twelve words and five waves per SIMD, measured on the 100 M index, batch of 8192 x 1000: 0.539 ms -- sixteen words: 0.577 at four
+// waves, 0.584 at five, the compiler spilling at six; twelve words at six waves: 0.597.  The wave's turns for hashes of 13+ words cost
+// less than four more words in every lane's walk.)
+#ifndef FPX_PK_WORDS
+#define FPX_PK_WORDS 12
+#endif
+constexpr uint32_t PK_WORDS = FPX_PK_WORDS; // words of a hash walked by its lane (16-byte pieces of its line); the rare rest by the wave
 #ifndef FPX_PK_WAVES
-#define FPX_PK_WAVES 6
+#define FPX_PK_WAVES 5
 #endif
 #define FPX_PK_OCC __attribute__((amdgpu_waves_per_eu(FPX_PK_WAVES, FPX_PK_WAVES)))
 template <int NS, bool BINNED, bool QS>
@@ -122,178 +129,190 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         const uint32_t n_line = (uint32_t)__popcll(bits) + (uint32_t)__popc(dfl);
         const uint32_t inl = n_line > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;    // words of the line that are in the line
         const uint32_t start = pos0 + dbl_before;
-        // ... of which the lane walks its first twelve, as far as they are in the line (the rest: the wave, below)
-        const uint32_t mine = min(min(nwords, GK_WORDS), start < inl ? inl - start : 0u);
-        // ---- its words: three loads from the same line, the second and third only where the hash has that many
-        uint32_t gw[GK_WORDS];
+        // ... of which the lane walks its first twelve (PK_WORDS), as far as they are in the line (the rest: the wave, below)
+        const uint32_t mine = min(min(nwords, PK_WORDS), start < inl ? inl - start : 0u);
+        // ---- its words: up to three loads from the same line (served by the caches: the line has just arrived)
+        uint32_t gw[PK_WORDS];
 #pragma unroll
-        for (uint32_t i = 0; i < GK_WORDS; ++i) gw[i] = 0u;
+        for (uint32_t i = 0; i < PK_WORDS; ++i) gw[i] = 0u;
 #pragma unroll
-        for (uint32_t i = 0; i < GK_WORDS / 4; ++i) {
+        for (uint32_t i = 0; i < PK_WORDS / 4; ++i) {
             if (mine > 4u * i) {
                 const uint4 v = gload_u4_a4(lp + 3u + start + 4u * i);
                 gw[4 * i] = v.x; gw[4 * i + 1] = v.y; gw[4 * i + 2] = v.z; gw[4 * i + 3] = v.w;
             }
         }
-        // ---- walk them: single docs and doubles become records, the first list reference gets the lane's slot
-        uint32_t docs[GK_WORDS];
-        uint32_t keep = 0, n_esc = 0, esc_off = 0, esc_col = 0;
+        // ---- walk them: single docs and doubles become records (gw[j] turns into the doc id), list references are noted
+        uint32_t keep = 0, lmask = 0, esc_col = 0, esc_col2 = 0;
         uint32_t mine_w = mine;                              // words the lane has walked itself (the wave does the rest)
+        uint32_t add_blocks = 0, add_docs = 0;               // the hash's contribution to the scan statistics
         if (simple) {
             // THE USUAL SNAPSHOT -- every column of the group searched, no superseded docs: a word's column does not matter (the words
-            // count from ONE doc id base), so the walk is straight-line code: twelve words classified by their top bit, no branch.
+            // count from ONE doc id base), so the walk is straight-line code: the words classified by their top bit, no branch.
             // (Measured on the 100 M index: the branchy walk + its stores 0.235 ms of the kernel's 0.69, the wave's turns for the `more`
-            // lanes another 0.236 -- 5 % of the lanes, each a serial chain of loads for the whole wave.)
+            // lanes another 0.236 -- 5 % of the lanes, each a serial chain of loads that its workgroup's other waves wait for.)
             // Words behind the line's 28th live in `ext`: the few lanes that have some fetch them one by one (not a turn of the wave)
-            if (valid && nwords <= GK_WORDS && start + nwords > inl) {
+            if (valid && nwords <= PK_WORDS && start + nwords > inl) {
                 const uint32_t ovf = gload_u32(lp + (GROUP_LINE_WORDS - 1u));
 #pragma unroll
-                for (uint32_t j = 0; j < GK_WORDS; ++j)
+                for (uint32_t j = 0; j < PK_WORDS; ++j)
                     if (j >= mine && j < nwords) gw[j] = gload_u32(ext + ovf + (start + j - inl));      // (j >= mine: start + j >= inl)
                 mine_w = nwords;
             }
-            uint32_t lmask = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < GK_WORDS; ++j) {
+            for (uint32_t j = 0; j < PK_WORDS; ++j) {
                 const uint32_t word = gw[j];
                 const bool v = j < mine_w, neg = (int32_t)word < 0;
                 keep |= (v && !neg) ? (1u << j) : 0u;                               // a doc (a gap position and a list reference have bit 31)
-                lmask |= (v && neg && word != 0xFFFFFFFFu) ? (1u << j) : 0u;        // a list reference
-                docs[j] = g->gmin + word;
+                lmask |= (v && neg && word != 0xFFFFFFFFu) ? (1u << j) : 0u;        // a list reference (its word stays as it is)
+                gw[j] = neg ? word : g->gmin + word;
             }
             // second words of doubles among them: the t-th double, at position i, has its second word at i + t + 1
             uint32_t second = 0;
             for (uint32_t d = dm, t = 0; d != 0u; d &= d - 1u, ++t) second |= 1u << ((uint32_t)__builtin_ctz(d) + t + 1u);
-            my_docs += (uint32_t)__popc(keep);
-            my_blocks += (uint32_t)__popc(keep & ~second);
-            n_esc = (uint32_t)__popc(lmask);
-            if (lmask != 0u) {
-                const uint32_t j0 = (uint32_t)__builtin_ctz(lmask);
-                uint32_t e = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < GK_WORDS; ++j) e = j == j0 ? gw[j] : e;
-                esc_off = e & 0x7FFFFFFFu;
-            }
+            add_docs = (uint32_t)__popc(keep);
+            add_blocks = (uint32_t)__popc(keep & ~second);
         } else {
-        uint64_t cols = 0;                                   // column of word j in bits 4j .. 4j+3
-        {
+            uint64_t cols = 0;                                   // column of word j in bits 4j .. 4j+3
             uint32_t rest = pm, i = 0;
             bool second = false;
 #pragma unroll
-            for (uint32_t j = 0; j < GK_WORDS; ++j) {
+            for (uint32_t j = 0; j < PK_WORDS; ++j) {
                 const uint32_t word = gw[j];
-                uint32_t doc = 0u;
-#ifdef FPX_DBG_NOWALK
-                if (false) {
-#else
                 if (j < mine) {
-#endif
                     const uint32_t s = (uint32_t)__builtin_ctz(rest);
                     cols |= (uint64_t)s << (4u * j);
                     if (word != 0xFFFFFFFFu && ((active >> s) & 1u) != 0u) {                 // (0xFFFFFFFF: a gap position -- nothing visited)
                         if (word >> 31) {
-                            if (n_esc == 0u) { esc_off = word & 0x7FFFFFFFu; esc_col = s; }
-                            n_esc += 1u;
+                            if (lmask == 0u) esc_col = s; else if ((lmask & (lmask - 1u)) == 0u) esc_col2 = s;
+                            lmask |= 1u << j;
                         } else {
-                            doc = s_min_doc[s] + word;
-                            my_blocks += second ? 0u : 1u; my_docs += 1u;
+                            gw[j] = s_min_doc[s] + word;
+                            add_blocks += second ? 0u : 1u; add_docs += 1u;
                             keep |= 1u << j;
                         }
                     }
                     if (((dm >> i) & 1u) != 0u && !second) second = true;
                     else { second = false; i += 1u; rest &= rest - 1u; }
                 }
-                docs[j] = doc;
             }
-        }
-        // superseded docs are dropped here: the stage mixes segments
-        if (any_dead) {
+            // superseded docs are dropped here: the stage mixes segments
+            if (any_dead) {
 #pragma unroll
-            for (uint32_t j = 0; j < GK_WORDS; ++j) {
-                const uint32_t s = (uint32_t)(cols >> (4u * j)) & 15u;
-                if (((keep >> j) & 1u) != 0u && s_has_dead[s] != 0u && is_dead_seg(ga.segs[s_seg_index[s]], docs[j])) keep &= ~(1u << j);
+                for (uint32_t j = 0; j < PK_WORDS; ++j) {
+                    const uint32_t s = (uint32_t)(cols >> (4u * j)) & 15u;
+                    if (((keep >> j) & 1u) != 0u && s_has_dead[s] != 0u && is_dead_seg(ga.segs[s_seg_index[s]], gw[j])) keep &= ~(1u << j);
+                }
             }
         }
-        }
-        // the head of the first list: header + up to three docs in one load -- and the next four, so that a list of up to seven docs
-        // (all but one in a million) is the lane's own business
-        uint4 x = make_uint4(0, 0, 0, 0), x2 = make_uint4(0, 0, 0, 0);
-        if (n_esc != 0u) { x = gload_u4_a4(ext + esc_off); x2 = gload_u4_a4(ext + esc_off + 4u); my_reads += 2u; }
-        uint32_t xkeep = 0;
-        const uint32_t xT = (x.x >> 19) & 1u, xeff = x.x & 0xFFFFu, xin = n_esc ? min(xeff, xT ? 6u : 7u) : 0u;
-        const uint32_t xmd = s_min_doc[esc_col];
-        // docs 0 .. 6 of the list (T: the header is followed by the list's full length, the docs start a word later)
-        const uint32_t xd0 = xmd + (xT ? x.z : x.y), xd1 = xmd + (xT ? x.w : x.z), xd2 = xmd + (xT ? x2.x : x.w), xd3 = xmd + (xT ? x2.y : x2.x),
-                       xd4 = xmd + (xT ? x2.z : x2.y), xd5 = xmd + (xT ? x2.w : x2.z), xd6 = xmd + x2.w;
-        if (n_esc != 0u) {
-            my_blocks += (x.x >> 16) & 7u; my_docs += xeff;
-            xkeep = (1u << xin) - 1u;
-            if (any_dead && s_has_dead[esc_col]) {
-                const SegDesc& f = ga.segs[s_seg_index[esc_col]];
-                if ((xkeep & 1u) && is_dead_seg(f, xd0)) xkeep &= ~1u;
-                if ((xkeep & 2u) && is_dead_seg(f, xd1)) xkeep &= ~2u;
-                if ((xkeep & 4u) && is_dead_seg(f, xd2)) xkeep &= ~4u;
-                if ((xkeep & 8u) && is_dead_seg(f, xd3)) xkeep &= ~8u;
-                if ((xkeep & 16u) && is_dead_seg(f, xd4)) xkeep &= ~16u;
-                if ((xkeep & 32u) && is_dead_seg(f, xd5)) xkeep &= ~32u;
-                if ((xkeep & 64u) && is_dead_seg(f, xd6)) xkeep &= ~64u;
-            }
-        }
-        // ---- one reservation per lane in the workgroup's stage -- and (BINNED) one in the lane's bin: the records' ranks there
-        const uint32_t cnt = (uint32_t)__popc(keep) + (uint32_t)__popc(xkeep);
-        const uint32_t par = round & 1u;
-        uint32_t pos = 0, brank = 0;
-        unsigned long long gpos = 0;
-        bool fits = true;
-        if (cnt != 0u) {
-            pos = atomicAdd(hs.count, cnt);
-            fits = pos + cnt <= FSTAGE_CAP;
-            if (!fits) {                             // the stage is full: this lane appends directly (BINNED: to the misc buffer, which k_bin bins)
-                atomicMin(hs.valid, pos);
-                gpos = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)cnt);
-            } else if constexpr (BINNED) {
-                const uint32_t b = gb_cell(a, qpart), bslot = gb_slot(a, qpart);
-                const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
-                brank = (old == GB_EMPTY || old == b) ? atomicAdd(&s_bcnt[par][bslot], cnt) : GB_EMPTY;       // (two bins on one slot: the misc buffer)
-            }
-        }
-        uint32_t o = 0;
-        auto put = [&](uint32_t doc) {
-            const uint64_t rec = qpart | doc;
-            if (fits) {
-                hs.buf[pos + o] = rec;
-                if constexpr (BINNED) s_rank[pos + o] = brank == GB_EMPTY ? GB_NEED : (uint16_t)(brank + o);
-            } else if (gpos + o < a.hit_cap) a.hits[gpos + o] = rec;
-            ++o;
+        uint32_t n_esc = (uint32_t)__popc(lmask);
+        // the word of the lane's t-th list reference (a select over its words: no register array is indexed by a lane's own number)
+        auto list_word = [&](uint32_t m) {
+            const uint32_t j0 = (uint32_t)__builtin_ctz(m);
+            uint32_t e = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < PK_WORDS; ++j) e = j == j0 ? gw[j] : e;
+            return e & 0x7FFFFFFFu;
         };
+        // a list's head: header + up to three docs in one load -- and the next four, so that a list of up to seven docs (all but one
+        // in a hundred million) is the lane's own business.  xd[0 .. 6]: docs 0 .. 6 of the list (T: the header is followed by the
+        // list's full length, the docs start a word later); returns the mask of the docs that count, after supersession
+        uint32_t xd[7];
+        uint32_t xeff = 0, xin = 0, xblk = 0;
+        auto list_head = [&](uint32_t off, uint32_t col) -> uint32_t {
+            const uint4 x = gload_u4_a4(ext + off), x2 = gload_u4_a4(ext + off + 4u);
+            my_reads += 2u;
+            const uint32_t xT = (x.x >> 19) & 1u, xmd = s_min_doc[col];
+            xeff = x.x & 0xFFFFu; xin = min(xeff, xT ? 6u : 7u);
+            xd[0] = xmd + (xT ? x.z : x.y); xd[1] = xmd + (xT ? x.w : x.z); xd[2] = xmd + (xT ? x2.x : x.w); xd[3] = xmd + (xT ? x2.y : x2.x);
+            xd[4] = xmd + (xT ? x2.z : x2.y); xd[5] = xmd + (xT ? x2.w : x2.z); xd[6] = xmd + x2.w;
+            xblk = (x.x >> 16) & 7u;                             // blocks the reference visits for it; xeff: docs it returns
+            uint32_t xk = (1u << xin) - 1u;
+            if (any_dead && s_has_dead[col]) {
+                const SegDesc& f = ga.segs[s_seg_index[col]];
 #pragma unroll
-        for (uint32_t j = 0; j < GK_WORDS; ++j)
-            if ((keep >> j) & 1u) put(docs[j]);
-        if (xkeep & 1u) put(xd0);
-        if (xkeep & 2u) put(xd1);
-        if (xkeep & 4u) put(xd2);
-        if (xkeep & 8u) put(xd3);
-        if (xkeep & 16u) put(xd4);
-        if (xkeep & 32u) put(xd5);
-        if (xkeep & 64u) put(xd6);
+                for (uint32_t t = 0; t < 7u; ++t) if (((xk >> t) & 1u) && is_dead_seg(f, xd[t])) xk &= ~(1u << t);
+            }
+            return xk;
+        };
+        // ---- the lane's records into the workgroup's stage: ONE reservation -- and (BINNED) one in the lane's bin: the records' ranks
+        //      there --, record j at pos + (records of the lane before it): the offset is a popcount, the store carries its own mask,
+        //      nothing else branches.  (As a lambda with a running offset and the full-stage fallback inside, the possible records cost
+        //      every wave ~480 issue slots per round; the fallback now sits behind one test.)
+        const uint32_t par = round & 1u;
+        const uint32_t qhi = (uint32_t)(qpart >> 32);
+        auto emit = [&](uint32_t km, uint32_t xk) {
+            const uint32_t nk = (uint32_t)__popc(km), cnt = nk + (uint32_t)__popc(xk);
+            if (cnt == 0u) return;
+            const uint32_t pos = atomicAdd(hs.count, cnt);
+            if (pos + cnt <= FSTAGE_CAP) {
+                uint32_t r0 = 0, rstep = 0;
+                if constexpr (BINNED) {
+                    const uint32_t b = gb_cell(a, qpart), bslot = gb_slot(a, qpart);
+                    const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
+                    const bool mine_bin = old == GB_EMPTY || old == b;                           // (two bins on one slot: the misc buffer)
+                    r0 = mine_bin ? atomicAdd(&s_bcnt[par][bslot], cnt) : (uint32_t)GB_NEED;
+                    rstep = mine_bin ? 1u : 0u;
+                }
+                uint64_t* dst = hs.buf + pos;
+                uint16_t* rk = s_rank + pos;
+#pragma unroll
+                for (uint32_t j = 0; j < PK_WORDS; ++j)
+                    if ((km >> j) & 1u) {
+                        const uint32_t o = (uint32_t)__popc(km & ((1u << j) - 1u));
+                        dst[o] = ((uint64_t)qhi << 32) | gw[j];
+                        if constexpr (BINNED) rk[o] = (uint16_t)(r0 + rstep * o);
+                    }
+#pragma unroll
+                for (uint32_t t = 0; t < 7u; ++t)
+                    if ((xk >> t) & 1u) {
+                        const uint32_t o = nk + (uint32_t)__popc(xk & ((1u << t) - 1u));
+                        dst[o] = ((uint64_t)qhi << 32) | xd[t];
+                        if constexpr (BINNED) rk[o] = (uint16_t)(r0 + rstep * o);
+                    }
+            } else {                                 // the stage is full: straight to the batch's record buffer (BINNED: k_bin bins it)
+                atomicMin(hs.valid, pos);
+                const unsigned long long gpos = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)cnt);
+#pragma unroll
+                for (uint32_t j = 0; j < PK_WORDS; ++j)
+                    if ((km >> j) & 1u) {
+                        const unsigned long long at = gpos + (uint32_t)__popc(km & ((1u << j) - 1u));
+                        if (at < a.hit_cap) a.hits[at] = ((uint64_t)qhi << 32) | gw[j];
+                    }
+#pragma unroll
+                for (uint32_t t = 0; t < 7u; ++t)
+                    if ((xk >> t) & 1u) {
+                        const unsigned long long at = gpos + nk + (uint32_t)__popc(xk & ((1u << t) - 1u));
+                        if (at < a.hit_cap) a.hits[at] = ((uint64_t)qhi << 32) | xd[t];
+                    }
+            }
+        };
+        uint32_t xkeep = 0;
+        if (n_esc != 0u) { xkeep = list_head(list_word(lmask), esc_col); add_blocks += xblk; add_docs += xeff; }
+        const uint32_t xeff1 = xeff, xin1 = xin;             // (of the FIRST list: what the wave's turn, if there is one, continues from)
+        emit(keep, xkeep);
+        // what is left for the whole wave: words beyond the lane's own, a third list, a list longer than its head
+        bool more = nwords > mine_w || n_esc > 2u || (n_esc != 0u && xeff1 > xin1);
+        // a SECOND list (one hash in two hundred): its head too, unless the wave has to come anyway
+        if (!more && n_esc == 2u) {
+            const uint32_t yk = list_head(list_word(lmask & (lmask - 1u)), esc_col2);
+            if (xeff > xin) more = true;                     // (longer than seven docs: the wave walks it from its start, and counts it)
+            else { add_blocks += xblk; add_docs += xeff; emit(0u, yk); }
+        }
+        my_blocks += add_blocks; my_docs += add_docs;
         if (QS && GQSTATS(a) && valid && (my_blocks != blocks_before || my_docs != docs_before))
             atomicAdd(&GQSTATS(a)[(uint32_t)(qpart >> 32)], (unsigned long long)(my_blocks - blocks_before) | ((unsigned long long)(my_docs - docs_before) << 32));
         // ---- the rare rest, by the whole wave: words beyond the lane's own (more than twelve, or behind the line's 28 in `ext`),
         //      further lists, lists longer than their head
         {
-#ifdef FPX_DBG_NOMORE
-            const bool more = false;
-#else
-            const bool more = nwords > mine_w || n_esc > 1u || (n_esc == 1u && xeff > xin);
-#endif
-            const bool hot = n_esc != 0u && xeff >= 64u;
+            const bool hot = n_esc != 0u && xeff1 >= 64u;
             unsigned long long mo = __ballot((int)more);
             while (mo != 0ull) {
                 const int src = (int)__builtin_ctzll(mo);
                 mo &= mo - 1ull;
                 const uint32_t qlo = __shfl((uint32_t)(qpart >> 32), src);
                 const uint32_t pm_s = __shfl(pm, src), dm_s = __shfl(dm, src), nw_s = __shfl(nwords, src), mine_s = __shfl(mine_w, src);
-                const uint32_t xin_s = __shfl(xin, src);               // (docs of its first list the lane has emitted itself)
+                const uint32_t xin_s = __shfl(xin1, src);              // (docs of its first list the lane has emitted itself)
                 const uint32_t start_s = __shfl(start, src), inl_s = __shfl(inl, src);
                 const uint32_t* lp_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)lp, src));
                 const uint32_t* li_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)ext >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)ext, src));
@@ -430,11 +449,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                 }
             }
             __syncthreads();
-#ifdef FPX_DBG_NOFLUSH
-            for (uint32_t i = tid; i < 0u; i += FK_WG) {
-#else
             for (uint32_t i = tid; i < sc; i += FK_WG) {
-#endif
                 const uint64_t rec = stage[i];
                 const uint32_t b = gb_cell(a, rec); const uint32_t rk = s_rank[i];
                 if (rk < GB_NEED) {

@@ -39,6 +39,61 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4a'. ALL memory segments at once: their live postings (a doc superseded within the snapshot is dropped when the table is built:
+//      hasNewerCommit, src/Index.zig:133-149, resolved per posting) merged into one array sorted by hash, duplicates kept
+//      (src/MemorySegment.zig:27-28,44-54: every matching item counts), behind a bucket table over the top 20 hash bits.  One
+//      thread per key, two loads to find the hash's run (usually empty): any key order, either dedup form -- which is what lets
+//      a snapshot with memory segments keep the (hash bucket, query) key order and the binned scoring of its groups.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t MEMTAB_BITS = 20;
+__global__ __launch_bounds__(WG) void k_memtab_gather(const MemDesc* mems, uint64_t* __restrict__ tab, unsigned long long* __restrict__ count)
+{
+    const MemDesc ms = mems[blockIdx.y];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * WG; i0 < ms.num_items; i0 += (uint64_t)gridDim.x * WG) {
+        const uint64_t i = i0 + threadIdx.x;
+        uint64_t it = 0;
+        bool live = false;
+        if (i < ms.num_items) { it = ms.items[i]; live = !is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, (uint32_t)it); }
+        const unsigned long long m = __ballot((int)live);
+        unsigned long long base = 0;
+        if (lane == 0 && m) base = atomicAdd(count, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0);
+        if (live) tab[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
+    }
+}
+__global__ void k_memtab_buckets(const uint64_t* __restrict__ tab, uint64_t n, uint32_t* __restrict__ bucket)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > (1u << MEMTAB_BITS)) return;
+    const uint64_t hv = (uint64_t)k << (32u - MEMTAB_BITS);           // first hash of bucket k (k == 2^20: past the last hash)
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if ((tab[m] >> 32) < hv) lo = m + 1; else hi = m; }
+    bucket[k] = (uint32_t)lo;
+}
+__global__ __launch_bounds__(WG) void k_probe_memtab(const uint64_t* __restrict__ tab, const uint32_t* __restrict__ bucket, const uint64_t* __restrict__ pairs,
+                                                      uint64_t P, uint32_t qb, uint32_t key_skip, uint64_t* hits, uint64_t hit_cap, unsigned long long* counters)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    if (p >= P) return;
+    const uint64_t key = gload_u64(pairs + p);
+    // dedupSorted (src/Index.zig:489-499): flagged where the keys were made, or found by looking back
+    if ((key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(pairs, p, key, qb, key_skip)) return;
+    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
+    const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
+    const uint32_t b = h >> (32u - MEMTAB_BITS);
+    const uint32_t lo = gload_u32(bucket + b), hi = gload_u32(bucket + b + 1u);
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint64_t it = gload_u64(tab + i);
+        const uint32_t ih = (uint32_t)(it >> 32);
+        if (ih > h) break;
+        if (ih != h) continue;
+        const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+        if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | (uint32_t)it;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 4b. small file segments (< 2^20 items; fresh checkpoints) in their decoded form (SegDesc::items / bstart).
 //     A batch holds thousands of pairs per BLOCK of such a segment, so the work is organised by block: one workgroup
 //     stages a block's items in LDS, finds the slice of the (bucket-sorted) pairs whose first block it is with two

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
         n += c >= SB_NEED_MARK ? 0ull : min((uint64_t)c, room);              // (a marked count: no records, the step is redone)
     }
     if (tid == 0) a.bin_n[bin] = a.nsrc == 1u ? raw_max : (uint32_t)min<uint64_t>(n, 0xFFFFFFFFull);
-    if (tid == 0 && a.nsrc > 1u && piece_over) {                                                // (a piece overflowed its cell)
+    if (tid == 0 && (a.nsrc > 1u || a.rec_mode == 2u) && piece_over) {                          // (a piece of a sharded batch overflowed its cell)
         atomicMax(&a.counters[CTR_BINFAIL], 2ull);
         atomicMax(&a.counters[CTR_TOTAL], (unsigned long long)raw_max);          // (a sender's "my bins need this many cells" mark travels as a count)
     }
@@ -180,7 +180,9 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                     const uint32_t doc = (uint32_t)rec, ql = (uint32_t)(rec >> 32) & qm;
                     if (!in_class(doc)) return;
                     const uint32_t hsh = mix32(doc ^ (ql * 0x9E3779B1u));
-                    if (cell_count(hsh & fmask) < s_floor[ql]) return;
+                    const uint32_t cc = cell_count(hsh & fmask);
+                    if (cc < floor_min) return;                        // (the bin's smallest floor, in a register: nearly every record leaves here)
+                    if (cc < s_floor[ql]) return;
                     if (passes > 1u && ((hsh >> 25) % passes) != pass) return;       // class bits apart from the slot bits (14..24)
                     // slot: doc << 32 | query-in-bin << 26 | count (26 bits)
                     const unsigned long long keyhi = ((unsigned long long)doc << 32) | ((unsigned long long)ql << SB_QL_SHIFT);

@@ -83,6 +83,36 @@ int build_bucket_table(Segment* seg, hipStream_t stream)
     return FPX_OK;
 }
 
+// the snapshot's ONE table of its memory segments' live postings (fpx_probe_small.hpp: k_probe_memtab)
+int build_memtab(Snapshot* sn)
+{
+    uint64_t total = 0, mmax = 0;
+    for (const MemDesc& m : sn->h_mem) { total += m.num_items; mmax = std::max<uint64_t>(mmax, m.num_items); }
+    if (total == 0 || total >= 0xFFFFFFF0ull) return FPX_OK;            // (nothing to look up / offsets would not fit: the per-segment kernels)
+    uint64_t* buf[2] = {nullptr, nullptr};
+    unsigned long long* d_count = nullptr;
+    void* d_temp = nullptr;
+    uint32_t* d_bucket = nullptr;
+    auto fail = [&](int rc) { for (auto* b : buf) if (b) (void)hipFree(b); if (d_count) (void)hipFree(d_count); if (d_temp) (void)hipFree(d_temp); if (d_bucket) (void)hipFree(d_bucket); (void)hipGetLastError(); return rc; };
+    const size_t tb = sort_u64_temp_bytes(total, 32, 64);
+    if (hipMalloc(&buf[0], (total + 1) * 8) != hipSuccess || hipMalloc(&buf[1], (total + 1) * 8) != hipSuccess || hipMalloc(&d_count, 8) != hipSuccess ||
+        hipMalloc(&d_temp, tb + 256) != hipSuccess || hipMalloc(&d_bucket, ((size_t)(1u << MEMTAB_BITS) + 2) * sizeof(uint32_t)) != hipSuccess)
+        return fail(FPX_E_NOMEM);
+    hipStream_t st = 0;
+    if (hipMemsetAsync(d_count, 0, 8, st) != hipSuccess) return fail(FPX_E_DEVICE);
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (mmax + WG - 1) / WG), 1024);
+    hipLaunchKernelGGL(k_memtab_gather, dim3(gx, sn->n_mem), dim3(WG), 0, st, (const MemDesc*)sn->d_mem, buf[0], d_count);
+    unsigned long long n = 0;
+    if (hipMemcpyAsync(&n, d_count, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(FPX_E_DEVICE);
+    int cur = 0;
+    if (n > 1 && sort_u64(d_temp, tb + 256, buf[0], buf[1], n, 32, 64, st, &cur) != hipSuccess) return fail(FPX_E_DEVICE);
+    hipLaunchKernelGGL(k_memtab_buckets, dim3(((1u << MEMTAB_BITS) + 256) / 256), dim3(256), 0, st, (const uint64_t*)buf[cur], (uint64_t)n, d_bucket);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(FPX_E_DEVICE);
+    sn->d_memtab = buf[cur]; sn->d_membucket = d_bucket; sn->n_memtab = n;
+    (void)hipFree(buf[1 - cur]); (void)hipFree(d_count); (void)hipFree(d_temp);
+    return FPX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
@@ -448,7 +478,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // kernels, which take it as a parameter, are the only ones that read the pairs)
     // Snapshots of direct-addressed segments only (their kernels are the only readers of the pairs): duplicates are flagged
     // when the keys are made (k_make_keys_dedup, queries of up to DEDUP_MAX hashes) and the sort takes one pass
-    bool flagged = snap->n_file == 0 && snap->n_mem == 0 && snap->n_direct != 0 && !score_only;
+    // (memory segments do not stand in the way once the snapshot has their ONE table: k_probe_memtab reads keys in any order)
+    bool flagged = snap->n_file == 0 && (snap->n_mem == 0 || snap->d_memtab != nullptr) && snap->n_direct != 0 && !score_only;
     for (uint32_t q = 0; q < B && flagged; ++q) flagged = offsets[q + 1] - offsets[q] <= DEDUP_MAX;
     const uint32_t key_skip = flagged ? KEY_SORT_SKIP_DIRECT : KEY_SORT_SKIP;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
@@ -545,7 +576,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     static const bool binned_enabled = [] { const char* e = getenv("FPX_BINNED"); return e ? atoi(e) != 0 : true; }();
     bool binned = false;
     uint32_t sbins = 0;
-    if (fast && binned_enabled && flagged && snap->n_group != 0 && snap->n_solo == 0 && bin_q_log2 >= 1u && bin_q_log2 <= 4u) {
+    // (segments direct-addressed on their own and memory segments append their records to the misc buffer, which k_bin bins: the
+    // snapshot a live index has between merges keeps the one-launch scoring of its groups)
+    if (fast && binned_enabled && flagged && snap->n_group != 0 && bin_q_log2 >= 1u && bin_q_log2 <= 4u) {
         uint32_t floor_lo = 0xFFFFFFFFu;
         for (uint32_t q = 0; q < B; ++q) {
             const uint64_t raw_len = offsets[q + 1] - offsets[q];
@@ -725,7 +758,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             FPX_HIP(hipGetLastError());
             probe_launches += 1;
         }
-        if (P && snap->n_mem) {
+        if (P && snap->n_mem && snap->d_memtab) {
+            hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((P + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
+                               d_pairs, P, qb, flagged ? KEY_SKIP_FLAGGED : key_skip, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
+            FPX_HIP(hipGetLastError());
+        } else if (P && snap->n_mem) {
             uint64_t mem_items = 0, mem_max = 0;
             for (const MemDesc& m : snap->h_mem) { mem_items += m.num_items; mem_max = std::max<uint64_t>(mem_max, m.num_items); }
             if (mem_items * 2 < P * snap->n_mem && !local_sort) {   // fewer items than (pair, segment) probes: search from the items' side (needs the batch-wide hash order)

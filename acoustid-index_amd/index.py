@@ -51,6 +51,15 @@ class Context:
         check(lib().fpx_measure_bandwidth(self.h, nbytes, block_size, C.byref(s), C.byref(r)))
         return s.value, r.value
 
+    def set_option(self, name, value):
+        """fpx_ctx_set_option: 'direct', 'direct_min_items', 'fuse_min', 'group_packed' (-1: back to the environment / default)"""
+        check(lib().fpx_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        check(lib().fpx_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def measure_access(self, nbytes, mode, lanes):
         """one launch of the counter-calibration kernel k_bw_pattern<mode> (fpx_measure_access); returns its HIP-event ms"""
         ms = C.c_double()
@@ -136,6 +145,10 @@ class _Segment:
         keys = ("columns", "line_columns", "bytes", "directory_bytes", "words_bytes", "lists_bytes", "doubles", "column", "window_lo", "window_hi",
                 "packed", "lines", "overflow_lines", "overflow_words")
         return {k: int(x) for k, x in zip(keys, v)}
+
+    @property
+    def layout_reason(self):
+        return (lib().fpx_segment_layout_reason(self.h) or b"").decode()
 
     @property
     def grouped(self):
@@ -285,6 +298,14 @@ class Segments:
         h = C.c_void_p()
         check(lib().fpx_snapshot_create(ctx.h, arr, len(self.segments), C.byref(h)))
         self.h = h
+
+    def info(self):
+        """fpx_snapshot_info as a dict"""
+        v = np.zeros(12, np.uint64)
+        check(lib().fpx_snapshot_info(self.h, _p(v), 12))
+        keys = ("lean", "generic", "small", "direct_solo", "group_columns", "groups", "packed_groups", "memory", "settled_in_blocks", "bytes",
+                "one_launch_path", "block_form_files")
+        return {k: int(x) for k, x in zip(keys, v)}
 
     def merge(self, sources, block_size=512):
         """Index.mergeToFileSegment on the GPU (fpx_segment_merge): SegmentMerger over `sources` (segments of this

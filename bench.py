@@ -844,6 +844,44 @@ def main():
                      "reference_visited_block_bytes": agg.v["probe_kernel_bytes"] / max(1, agg.v["probe_launches"]), "headline": True})
         result["by_batch"] = rows
 
+    # ---- a LIVE index's snapshot: the same 16 grouped segments + 16 memory segments of ~10^5 items each (fresh writes: new docs, 390
+    #      fingerprints per segment -- src/Index.zig:515-587 publishes a snapshot with a new memory segment per update; <= 16 before they
+    #      are checkpointed, :679-687).  Their ONE hash-sorted table is probed with the batch's keys as they are (k_probe_memtab) and
+    #      their records join the groups' bins (k_bin): the step must stay near the pure-group one.
+    if extras and os.environ.get("FPX_BENCH_MIXED", "1") != "0":
+        try:
+            mems, nm, per_mem = [], 16, 100_000 // H
+            for m in range(nm):
+                ids = np.arange(docs + 1 + m * per_mem, docs + 1 + (m + 1) * per_mem, dtype=np.uint64)
+                hh = fpx.synth.synth_hashes(args.seed + 77, ids, H, 0).astype(np.uint64)
+                items = np.sort(((hh << np.uint64(32)) | ids[:, None]).ravel())
+                mems.append(fpx.MemorySegment(ctx, items, int(ids[0]), int(ids[-1]), S + 1 + m, ids.astype(np.uint32)))
+            snap_m = fpx.Segments(ctx, list(segs) + mems)
+            reader_m = fpx.IndexReader(snap_m)
+            # queries: the batches as they are, every 16th query aimed at a doc of a memory segment instead (it must be found there)
+            fm, om, tm = batches[0][0].copy(), batches[0][1], batches[0][2].copy()
+            for q in range(0, B, 16):
+                d = docs + 1 + (q // 16) % (nm * per_mem)
+                fm[int(om[q]):int(om[q]) + H] = fpx.synth.synth_hashes(args.seed + 77, [d], H, 0)[0]
+                tm[q] = d
+            qm_ = fpx.QueryBatch(ctx, options=opts, flat=(fm, om))
+            dtm, aggm, outm, onm = timed_resident(fpx, reader_m, [qm_] + qbs[1:], 40, 6)
+            rowm = row_from(B, 40, dtm, aggm, segs)
+            om_, nm_, _ = fpx.search_resident(reader_m, qm_)
+            rowm["targets_found"] = int(sum(1 for q in range(B) if nm_[q] > 0 and om_[q, 0, 0] == tm[q]))
+            rowm["memory_segments"] = nm
+            rowm["memory_items"] = nm * per_mem * H
+            rowm["path_flags"] = aggm.path_flags
+            rowm["snapshot"] = snap_m.info()
+            rowm["note"] = "one batch in flight; compare with the by_batch row of the same batch size and in-flight count"
+            result["mixed"] = rowm
+            qm_.release(); snap_m.release()
+            for m_ in mems:
+                m_.release()
+            del reader_m, snap_m, mems
+        except Exception as e:
+            result["mixed"] = {"error": repr(e)}
+
     # ---- end to end: the batch handed over in HOST memory (H2D of the hashes + D2H of the results inside the call), from
     #      ordinary pageable arrays and from page-locked ones (fpx_host_alloc), one batch in flight and as many as the headline
     if extras:

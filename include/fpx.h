@@ -91,6 +91,17 @@ typedef struct {
 int  fpx_ctx_create(int device, fpx_ctx **out);
 void fpx_ctx_destroy(fpx_ctx *ctx);
 int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context lives on */
+/* How a context keeps its file segments in HBM.  Options (each falls back to the environment variable FPX_<NAME>, then to the
+ * default; value -1 = back to that fallback):
+ *   "direct"            1 | 0   dense segments trade their blocks for a direct-addressed form (default 1)
+ *   "direct_min_items"  items from which a segment counts as dense (default 2^20)
+ *   "fuse_min"          direct-addressed segments of one hash window that form a GROUP together: this many or more (default 2; 0: never)
+ *   "group_packed"      1 | 0 | -1   a group's form: PACKED lines (one HBM line per query hash; dense groups) | directory + words |
+ *                       by the group's density (default)
+ * They are read when a segment is created / a snapshot first holds it; fpx_segment_layout(), fpx_segment_layout_reason() and
+ * fpx_snapshot_info() say what came of it. */
+int  fpx_ctx_set_option(fpx_ctx *ctx, const char *name, int64_t value);
+int  fpx_ctx_get_option(const fpx_ctx *ctx, const char *name, int64_t *value);   /* the value in force */
 const char *fpx_strerror(int status);
 /* last error text of the calling thread (valid until its next fpx call) */
 const char *fpx_last_error(void);
@@ -138,6 +149,10 @@ uint64_t fpx_segment_device_bytes(const fpx_segment *seg);
  * presence bitmap with a rank directory and doc lists (csrc/fpx_direct.hpp).  Searches, counters, downloads and merges do
  * not depend on the form: a download re-encodes the file's blocks byte for byte. */
 int fpx_segment_layout(const fpx_segment *seg);
+/* ... and WHY, in words (a static string): e.g. "blocks: not enough free HBM to build the group next to the members' blocks" -- a
+ * host watches this after fpx_snapshot_create instead of finding out from its query rate (a segment that settled in its blocks is
+ * searched several times slower than a column of a group). */
+const char *fpx_segment_layout_reason(const fpx_segment *seg);
 /* What the group of a grouped segment (layout 2) looks like: info[0..13] = columns in use, columns of a directory line (8 / 16),
  * HBM bytes of the whole group, of its lines (directory), of its words, of its lists (packed form: lists + overflowing words),
  * positions stored as inline doubles, this segment's column, first and last hash of the group's hash window, 1 = the PACKED
@@ -155,6 +170,12 @@ int fpx_segment_download(const fpx_segment *seg, uint8_t *blocks, size_t blocks_
  * on another context's device takes part with its docs map only (like fpx_segment_create_remote). */
 int  fpx_snapshot_create(fpx_ctx *ctx, fpx_segment *const *segs, uint32_t num_segs, fpx_snapshot **out);
 /* acquireReader / IndexReader.deinit (src/Index.zig:430-434, :157-163) */
+/* What fpx_snapshot_create made of the segments on this context: info[0..11] = file segments searched in their blocks by the
+ * lean kernel, by the generic kernel, small ones searched in their decoded items, direct-addressed on their own, columns of
+ * groups, groups, PACKED groups, memory segments, candidates that SETTLED in their blocks (no HBM for another form: see
+ * fpx_segment_layout_reason), HBM bytes of the snapshot's segments, 1 = batches take the one-launch path (groups and nothing
+ * else), block-form file segments in all. */
+int  fpx_snapshot_info(const fpx_snapshot *snap, uint64_t *info, uint32_t n);
 void fpx_snapshot_retain(fpx_snapshot *snap);
 void fpx_snapshot_release(fpx_snapshot *snap);
 

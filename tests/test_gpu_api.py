@@ -159,3 +159,55 @@ def test_timeout_reports_search_timeout_and_no_results(env):
     # timeout 0 = unbounded (src/MultiIndex.zig:286,315)
     res, _ = p.reader.search_batch(qs[:4], fpx.http_options(), timeout_ms=0)
     assert res[0] == p.osnap.search(qs[0])
+
+
+def test_context_options_decide_the_storage_form_and_the_abi_says_what_came_of_it(monkeypatch):
+    """fpx_ctx_set_option / fpx_segment_layout_reason / fpx_snapshot_info: the thresholds that decide a segment's form are the
+    context's (the environment only supplies defaults), and a host can ask what became of every segment and why."""
+    import os
+    import numpy as np
+    from fpx_testlib import fpx, oracle
+    if os.environ.get("FPX_VARIANT_CHILD") == "1":
+        pytest.skip("the variant runs move the defaults through the environment")
+    for k in ("FPX_DIRECT", "FPX_DIRECT_MIN_ITEMS", "FPX_FUSE_MIN", "FPX_GROUP_PACKED"):
+        monkeypatch.delenv(k, raising=False)
+    ctx = fpx.Context(0)
+    assert ctx.get_option("direct") == 1 and ctx.get_option("direct_min_items") == 1 << 20 and ctx.get_option("fuse_min") == 2
+    assert ctx.get_option("group_packed") == -1
+    with pytest.raises(fpx.FpxError):
+        ctx.set_option("no_such_option", 1)
+
+    def seg(first, commit):
+        items = fpx.synth.synth_items(11, first, 3000, 48)
+        blocks, index = oracle.build_blocks(items, first, 512)
+        ids = np.arange(first, first + 3000, dtype=np.uint32)
+        return fpx.FileSegment(ctx, blocks, 512, index, first, first + 2999, commit, ids), oracle.file_segment(blocks, 512, index, first, first + 2999, commit, ids)
+    a, oa = seg(1, 1)                                   # default options: 144 000 items are below direct_min_items
+    assert "direct_min_items" in a.layout_reason
+    ctx.set_option("direct_min_items", 0)
+    b, ob = seg(3001, 2)
+    c, oc = seg(6001, 3)
+    assert "candidate" in b.layout_reason
+    snap = fpx.Segments(ctx, [a, b, c])
+    assert not a.direct and b.grouped and c.grouped and "directory + words" in b.layout_reason
+    info = snap.info()
+    assert (info["small"], info["group_columns"], info["groups"], info["packed_groups"], info["one_launch_path"]) == (1, 2, 1, 0, 0)
+    ctx.set_option("fuse_min", 0)                       # no groups: a dense segment becomes direct-addressed on its own
+    d, od = seg(9001, 4)
+    snap2 = fpx.Segments(ctx, [d])
+    assert d.direct and not d.grouped and "on its own" in d.layout_reason and snap2.info()["direct_solo"] == 1
+    ctx.set_option("fuse_min", 1)
+    ctx.set_option("group_packed", 1)                   # ... and a group's form is the context's choice too
+    e, oe = seg(12001, 5)
+    snap3 = fpx.Segments(ctx, [e])
+    assert e.grouped and "PACKED" in e.layout_reason and snap3.info()["packed_groups"] == 1 and snap3.info()["one_launch_path"] == 1
+    assert e.group_info()["packed"] == 1
+    # every form answers the same
+    q = fpx.synth.synth_hashes(11, [12345], 48)[0]
+    r = fpx.SearchResults(fpx.SearchOptions(10, 1, 0))
+    assert fpx.IndexReader(snap3).search(q, r) == oracle.Snapshot([oe], []).search(q, 10, 1, 0)
+    q = fpx.synth.synth_hashes(11, [3500], 48)[0]
+    assert fpx.IndexReader(snap).search(q, r) == oracle.Snapshot([oa, ob, oc], []).search(q, 10, 1, 0)
+    ctx.set_option("direct", 0)
+    f, _ = seg(15001, 6)
+    assert "turned off" in f.layout_reason

@@ -1,8 +1,6 @@
-"""tools/collect_profiles.py [src] -- copy what tools/profile_r03.sh produced (gpurun_out/prof_r03/) into profiles/r03_*:
-the files DESIGN.md and bench.py cite.  profiles/r03_traffic.json carries the kernels' source hash: bench.py falls back to
+"""tools/collect_profiles.py [src] -- copy what tools/profile_r04.sh produced (gpurun_out/prof_r04/) into profiles/r04_*:
+the files DESIGN.md and bench.py cite.  profiles/r04_traffic.json carries the kernels' source hash: bench.py falls back to
 it only when the hash still matches (its in-run PMC child pass is the primary source)."""
-import csv
-import glob
 import json
 import os
 import shutil
@@ -10,63 +8,53 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r03")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r04")
 dst = os.path.join(ROOT, "profiles")
+TAG = "r04"
 
 
 def last_json(path):
-    return json.loads(open(path).read().strip().splitlines()[-1])
+    lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def put_json(name, out):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        try:
+            json.dump(last_json(p), open(os.path.join(dst, out), "w"), indent=1)
+        except (ValueError, IndexError):
+            print("unreadable:", p)
 
 
 bench = last_json(os.path.join(src, "bench.json"))
-json.dump(bench, open(os.path.join(dst, "r03_bench.json"), "w"), indent=1)
-json.dump(last_json(os.path.join(src, "bench_under_rocprof.json")), open(os.path.join(dst, "r03_bench_under_rocprof.json"), "w"), indent=1)
-json.dump(last_json(os.path.join(src, "bench_block_under_rocprof.json")), open(os.path.join(dst, "r03_bench_block_under_rocprof.json"), "w"), indent=1)
-for name in ("emulated_rank_of_8_weak", "emulated_rank_of_8_strong", "emulated_rank_of_4_weak", "emulated_rank_of_2_weak"):
-    p = os.path.join(src, name + ".json")
-    if os.path.exists(p) and os.path.getsize(p):
-        json.dump(last_json(p), open(os.path.join(dst, "r03_" + name + ".json"), "w"), indent=1)
-
-
-def stats(sub, prefix, out):
-    f = glob.glob(os.path.join(src, sub, "**", prefix + "_kernel_stats.csv"), recursive=True)
-    if f:
-        shutil.copy(f[0], os.path.join(dst, out))
-
-
-stats("trace", "r03", "r03_kernel_stats.csv")
-stats("trace_block", "r03b", "r03_block_kernel_stats.csv")
-stats("trace1k", "r03b1k", "r03_kernel_stats_b1024.csv")
-stats("trace_emu", "r03emu", "r03_emulated_rank_of_8_kernel_stats.csv")
-
-
-def pmc_rows(sub, out):
-    """the PMC pass: only the rows of the probe and calibration kernels (the full file holds every build kernel too)"""
-    files = glob.glob(os.path.join(src, "pmc", sub, "*counter_collection.csv")) if sub else \
-        [f for f in glob.glob(os.path.join(src, "pmc", "*counter_collection.csv"))]
-    if not files:
-        return
-    rows = list(csv.DictReader(open(files[0])))
-    keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_probe", "k_bw_"))]
-    with open(os.path.join(dst, out), "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-        w.writeheader()
-        w.writerows(keep)
-
-
-pmc_rows("", "r03_pmc_fetch_size.csv")
-pmc_rows("block_form", "r03_block_pmc_fetch_size.csv")
+json.dump(bench, open(os.path.join(dst, f"{TAG}_bench.json"), "w"), indent=1)
+put_json("bench_under_rocprof.json", f"{TAG}_bench_under_rocprof.json")
+put_json("bench_block_under_rocprof.json", f"{TAG}_bench_block_under_rocprof.json")
+put_json("emulated_under_rocprof.json", f"{TAG}_emulated_rank_of_8_under_rocprof.json")
+for name in ("emulated_rank_of_8_weak", "emulated_rank_of_8_strong", "emulated_rank_of_4_weak", "emulated_rank_of_2_weak", "emulated_rank_of_8_weak_replicated_hashes"):
+    put_json(name + ".json", f"{TAG}_{name}.json")
+for tag, out in (("r04", "kernel_stats.csv"), ("r04b", "block_kernel_stats.csv"), ("r04b1k", "kernel_stats_b1024.csv"), ("r04emu", "emulated_rank_of_8_kernel_stats.csv")):
+    p = os.path.join(src, f"{tag}_kernel_stats.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{TAG}_{out}"))
+for sub, out in (("pmc", "ea_read_requests.json"), (os.path.join("pmc", "block_form"), "block_ea_read_requests.json")):
+    p = os.path.join(src, sub, "ea_read_requests.json")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{TAG}_{out}"))
 import bench as bench_mod  # noqa: E402
-tr = {"command": "bench.py's in-run children: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --pmc-child ... (the second with FPX_DIRECT=0)",
+tr = {"command": "bench.py's in-run children: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum "
+                 "-- python bench.py --pmc-child ... (the second with FPX_DIRECT=0)",
       "config": {k: bench["config"][k] for k in ("docs", "segments", "hashes_per_doc", "batch", "query_len")},
       "kernel_source_sha16": bench["kernel_source_sha16"]}
 for key in ("roofline", "roofline_block_form"):
     pmc = bench.get(key, {}).get("pmc", {})
     if "hbm_read_bytes_per_launch" in pmc:
-        tr.setdefault("calibration", pmc["calibration"]); tr.setdefault("correction", pmc["correction"])
-        tr[pmc.get("kernel", "k_probe_lean8")] = {"FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE_KB_per_launch"],
+        tr.setdefault("calibration", pmc["calibration"])
+        tr[pmc.get("kernel", "k_probe_lean8")] = {"read_requests_per_launch": pmc["read_requests_per_launch"], "request_sizes": pmc["request_sizes"],
                                                   "hbm_read_bytes_per_launch_corrected": pmc["hbm_read_bytes_per_launch"]}
-json.dump(tr, open(os.path.join(dst, "r03_traffic.json"), "w"), indent=1)
-assert bench["kernel_source_sha16"] == bench_mod.kernel_source_hash(), "the profile was taken on other kernel sources than the tree holds"
-os.system(f"{sys.executable} {os.path.join(ROOT, 'tools', 'kernel_resources.py')} {os.path.join(dst, 'r03_kernel_resources.txt')} > /dev/null")
+json.dump(tr, open(os.path.join(dst, f"{TAG}_traffic.json"), "w"), indent=1)
+if bench["kernel_source_sha16"] != bench_mod.kernel_source_hash():
+    print("WARNING: the profile was taken on other kernel sources than the tree holds (bench.py will not use r04_traffic.json as a fallback)")
+os.system(f"{sys.executable} {os.path.join(ROOT, 'tools', 'kernel_resources.py')} {os.path.join(dst, TAG + '_kernel_resources.txt')} > /dev/null")
 print("profiles/ updated from", src)

@@ -89,12 +89,14 @@ int build_memtab(Snapshot* sn)
     uint64_t total = 0, mmax = 0;
     for (const MemDesc& m : sn->h_mem) { total += m.num_items; mmax = std::max<uint64_t>(mmax, m.num_items); }
     if (total == 0 || total >= 0xFFFFFFF0ull) return FPX_OK;            // (nothing to look up / offsets would not fit: the per-segment kernels)
+    static const bool enabled = [] { const char* e = getenv("FPX_MEMTAB"); return e ? atoi(e) != 0 : true; }();
+    if (!enabled) return FPX_OK;
     uint64_t* buf[2] = {nullptr, nullptr};
     unsigned long long* d_count = nullptr;
     void* d_temp = nullptr;
     uint32_t* d_bucket = nullptr;
     auto fail = [&](int rc) { for (auto* b : buf) if (b) (void)hipFree(b); if (d_count) (void)hipFree(d_count); if (d_temp) (void)hipFree(d_temp); if (d_bucket) (void)hipFree(d_bucket); (void)hipGetLastError(); return rc; };
-    const size_t tb = sort_u64_temp_bytes(total, 32, 64);
+    const size_t tb = sort_u64_temp_bytes(total, 0, 64);
     if (hipMalloc(&buf[0], (total + 1) * 8) != hipSuccess || hipMalloc(&buf[1], (total + 1) * 8) != hipSuccess || hipMalloc(&d_count, 8) != hipSuccess ||
         hipMalloc(&d_temp, tb + 256) != hipSuccess || hipMalloc(&d_bucket, ((size_t)(1u << MEMTAB_BITS) + 2) * sizeof(uint32_t)) != hipSuccess)
         return fail(FPX_E_NOMEM);
@@ -105,7 +107,8 @@ int build_memtab(Snapshot* sn)
     unsigned long long n = 0;
     if (hipMemcpyAsync(&n, d_count, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(FPX_E_DEVICE);
     int cur = 0;
-    if (n > 1 && sort_u64(d_temp, tb + 256, buf[0], buf[1], n, 32, 64, st, &cur) != hipSuccess) return fail(FPX_E_DEVICE);
+    // (the whole key: Item order, src/segment.zig:90-94 -- hash, then doc)
+    if (n > 1 && sort_u64(d_temp, tb + 256, buf[0], buf[1], n, 0, 64, st, &cur) != hipSuccess) return fail(FPX_E_DEVICE);
     hipLaunchKernelGGL(k_memtab_buckets, dim3(((1u << MEMTAB_BITS) + 256) / 256), dim3(256), 0, st, (const uint64_t*)buf[cur], (uint64_t)n, d_bucket);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(FPX_E_DEVICE);
     sn->d_memtab = buf[cur]; sn->d_membucket = d_bucket; sn->n_memtab = n;

@@ -321,8 +321,13 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                     const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
                     unsigned long long me = __ballot((int)(rest_l != 0u));
                     unsigned long long gbase = 0;
+                    // BINNED: all these records belong to ONE query, i.e. one bin -- the reservation is taken THERE and the lists go straight
+                    // into the bin (round 3 left them in the misc buffer for k_bin: 575 M of the 625 M records of a hot-hash batch took
+                    // that detour)
+                    const uint32_t hot_bin = qlo >> a.bin_shift;
                     if (!filtered) {
-                        if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total);
+                        if constexpr (BINNED) { if (lane == 0) gbase = atomicAdd(&a.bin_count[(size_t)hot_bin * BIN_STRIDE], total); }
+                        else { if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total); }
                         gbase = __shfl(gbase, 0);
                     }
                     while (me != 0ull) {
@@ -334,7 +339,10 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                         if (!filtered) {
                             for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
                                 const unsigned long long at = gbase + (o2 - from) + lane;
-                                if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
+                                if constexpr (BINNED) {
+                                    if (o2 + lane < eff && at < a.bin_cap)
+                                        bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, hot_bin, at, ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane)), a.counters);
+                                } else if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
                             }
                             gbase += eff - from;
                         } else {                     // (superseded docs among them: through the stage, 64 at a time)

@@ -266,3 +266,122 @@ def test_hash_window_bin_protocol_world_size_2():
     mp.spawn(_bin_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     r = dict(ret)
     assert r[0][0] and r[1][0] and r[0][1] + r[1][1] == 19          # every query finished by exactly one rank
+
+
+# ---- the same index, ROUTED KEYS: a rank holds only its share of the batch; world_size 2 over gloo ------------------
+def _routed_worker(rank, world, port, ret):
+    """Rank r holds window r of every segment AND only the queries of the bins it finishes.  It makes the keys of its share
+    (dedupSorted where the keys are made; global query numbers), deals them to the ranks by the hash's window -- slot w of a fixed-shape
+    send buffer, its fill count next to it --, all-to-all #1; probes the slots it received (the oracle is the per-rank engine: a key =
+    one hash of one query), drops the postings into the batch's bins, all-to-all #2; finishes its queries.  The slots start too small
+    on purpose: the sender marks its counts (FPX_SHARD_NEED_MARK | need), every rank sees the mark in what it received and redoes the
+    keys with the same larger size -- no extra collective.  On a GPU box fpx_shard_keys / fpx_shard_probe_keys / fpx_shard_score_share run
+    the same protocol (tests/test_gpu_hashshard.py, tests/test_gpu_sharded_abi.py)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fpx_testlib import fpx, oracle
+        MARK = fpx.SHARD_NEED_MARK
+        seed, H, per = 61, 48, 3000
+        rng = np.random.default_rng(17)
+        lo_excl = None if rank == 0 else (rank << 32) // world - 1
+        hi_incl = None if rank == world - 1 else ((rank + 1) << 32) // world - 1
+        slices, full_segs = [], []
+        for s in range(3):
+            lo = s * per + 1
+            ids = np.arange(lo, lo + per, dtype=np.uint64)
+            extra = np.sort(rng.choice(np.arange(1, lo), 150, replace=False)).astype(np.uint64) if s else np.zeros(0, np.uint64)
+            all_ids = np.concatenate([extra, ids])
+            h = fpx.synth.synth_hashes(seed + s, all_ids, H, 1).astype(np.uint64)
+            items = np.sort(((h << np.uint64(32)) | all_ids[:, None]).ravel())
+            blocks, index = oracle.build_blocks(items, int(all_ids.min()), 512)
+            mk = lambda: oracle.file_segment(blocks, 512, index, int(all_ids.min()), int(all_ids.max()), s + 1, all_ids.astype(np.uint32))
+            full_segs.append(mk())
+            slices.append(mk().set_window(lo_excl, hi_incl))
+        local, full = oracle.Snapshot(slices, []), oracle.Snapshot(full_segs, [])
+        limit, pct = 10, 10
+        qdocs = [5, 77, 3001, 7000, 100, 200, 2999, 8999, 4242, 6001, 15, 3100, 8000, 1, 9000, 4500, 6100, 888, 3333]      # 19 queries: 3 bins
+        queries = [fpx.synth.synth_hashes(seed + min(2, (d - 1) // per), [d], H, 1)[0] for d in qdocs]
+        queries[3] = np.concatenate([queries[3], queries[3][:5]])          # duplicate hashes inside a query
+        B = len(queries)
+        nbins = (B + 7) // 8
+        bpr = (nbins + world - 1) // world
+        q_lo, q_hi = min(B, rank * bpr * 8), min(B, (rank + 1) * bpr * 8)
+        # ---- stage K: the keys of MY queries only, dealt to the windows; slots too small first
+        key_cap = 8
+        for attempt in range(3):
+            send = torch.zeros((world, key_cap, 2), dtype=torch.int64)              # a key: (hash, global query number)
+            cnt = torch.zeros((world,), dtype=torch.int64)
+            need = 0
+            for q in range(q_lo, q_hi):
+                for hsh in np.unique(queries[q]):                                    # dedupSorted, src/Index.zig:489-499
+                    w = (int(hsh) * world) >> 32
+                    k = int(cnt[w])
+                    if k < key_cap:
+                        send[w, k] = torch.tensor([int(hsh), q])
+                    cnt[w] = k + 1
+            need = int(cnt.max())
+            if need > key_cap:
+                cnt.fill_(MARK | need)                                               # "my slots need this many keys"
+            recv, rcnt = torch.empty_like(send), torch.empty_like(cnt)
+            dist.all_to_all_single(recv.view(-1), send.view(-1))                     # all-to-all #1
+            dist.all_to_all_single(rcnt, cnt)
+            marks = rcnt[rcnt >= MARK]
+            if len(marks) == 0:
+                break
+            key_cap = int((marks & (MARK - 1)).max())                                # every rank sees the same marks: the same new size
+        assert attempt >= 1 and key_cap > 8
+        # ---- stage P: the keys I received are hashes of MY window, from every source; their postings into the batch's bins
+        cap = 4096
+        bsend = torch.zeros((world, bpr, cap, 4), dtype=torch.int64)
+        bcnt = torch.zeros((world, bpr), dtype=torch.int32)
+        per_q = {}
+        for s in range(world):
+            for hsh, q in recv[s, :int(rcnt[s])].tolist():
+                assert ((hsh * world) >> 32) == rank
+                per_q.setdefault(q, []).append(hsh)
+        for q, hs in per_q.items():
+            b = q >> 3
+            for doc, (commit, score) in local.hits(np.array(hs, dtype=np.uint32)).items():
+                k = int(bcnt[b // bpr, b % bpr])
+                bsend[b // bpr, b % bpr, k] = torch.tensor([q, doc, commit, score])
+                bcnt[b // bpr, b % bpr] = k + 1
+        brecv, brc = fpx.sharding.exchange_bins(dist, bsend, bcnt)                  # all-to-all #2
+        # ---- stage S: my queries, finished
+        acc = {}
+        for s in range(world):
+            for b in range(bpr):
+                for q, doc, commit, score in brecv[s, b, :int(brc[s, b])].tolist():
+                    assert q_lo <= q < q_hi
+                    c, s_ = acc.get((q, doc), (0, 0))
+                    if commit > c:
+                        c, s_ = commit, 0
+                    if commit == c:
+                        s_ += score
+                    acc[(q, doc)] = (c, s_)
+        ok = True
+        for q in range(q_lo, q_hi):
+            floor = (len(queries[q]) + 19) // 20
+            ent = [(s_, doc) for (qq, doc), (c, s_) in acc.items() if qq == q and s_ >= floor and not full.has_newer_commit(doc, c)]
+            ent.sort(key=lambda e: (-e[0], e[1]))
+            res = []
+            for s_, doc in ent:
+                if len(res) == limit or s_ < floor:
+                    break
+                if not res:
+                    floor = max(floor, s_ * pct // 100)
+                res.append((doc, s_))
+            ok = ok and res == full.search(queries[q], max_results=limit, min_score=None, min_score_pct=pct)
+        ret[rank] = (bool(ok), q_hi - q_lo)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_routed_keys_protocol_world_size_2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_routed_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r = dict(ret)
+    assert r[0][0] and r[1][0] and r[0][1] + r[1][1] == 19

@@ -157,10 +157,10 @@ def test_window_sharded_snapshot_routes_keys_behind_one_call(world, monkeypatch)
     them), the batch's hashes split over them, keys routed to their window's rank, bins back to the rank the queries came from.  Same
     results and the same scanned blocks / docs as the unsharded snapshot and the oracle; many host threads at once."""
     from fpx_testlib import fpx, oracle, Pair
-    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
-    monkeypatch.setenv("FPX_FUSE_MIN", "1")
     ndev = _device_count()
     ctxs = [fpx.Context(k % ndev) for k in range(world)]
+    for c in ctxs:                                                    # (the contexts' own options: whatever the process's environment says)
+        c.set_option("direct", 1); c.set_option("direct_min_items", 0); c.set_option("fuse_min", 1)
     seed, S, per, H = 60 + world, 4, 5000, 48
     rng = np.random.default_rng(seed)
     full = Pair(ctxs[0])

@@ -9,7 +9,7 @@ from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegm
                     merge_partials, results_to_lists, build_memory_segment, probe_resident, score_partial,
                     shard_bins_per_rank, shard_probe, shard_score, merge_partials_raw,
                     ShardedSegments, ShardedIndexReader, host_array, SHARD_NEED_MARK, ShardCellsTooSmall,
-                    shard_keys, shard_probe_keys, shard_score_share, file_segment_windows, WindowShardedSegments)
+                    shard_keys, shard_probe_keys, shard_score_share, file_segment_windows, WindowShardedSegments, regroup)
 from . import synth  # noqa: F401
 from . import sharding  # noqa: F401
 from . import segfile  # noqa: F401

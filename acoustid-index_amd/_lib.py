@@ -82,6 +82,7 @@ SIGNATURES = {
     "fpx_segment_layout": (C.c_int, [_vp]),
     "fpx_segment_group_info": (C.c_int, [_vp, _vp, _u32]),
     "fpx_segment_download": (C.c_int, [_vp, _vp, _sz, _vp, _u32]),
+    "fpx_segments_regroup": (C.c_int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "fpx_snapshot_create": (C.c_int, [_vp, _vp, _u32, C.POINTER(_vp)]),
     "fpx_snapshot_retain": (None, [_vp]),
     "fpx_snapshot_release": (None, [_vp]),

@@ -255,6 +255,82 @@ int resolve_candidates(Ctx* c, const std::vector<Segment*>& segs)
     return FPX_OK;
 }
 
+// Rebuilding groups.  Groups are formed when segments first meet in a snapshot and never change afterwards: after a few
+// checkpoints and merges an index holds several groups (the old one with the merged-away members as dead columns, a new one
+// or a lone direct-addressed segment per merge result), and every group costs a probe launch and an HBM line per query hash.
+// regroup_segments gathers the whole-hash-space file segments of `segs` (up to 16, in order) into ONE new group: members that
+// sit in a group get their blocks encoded again from their column (byte for byte: materialize_blocks), the others join as they
+// are, and group_segments builds the new group chunk by chunk as for fresh segments.  The old groups stay with the snapshots
+// that hold them and go with the last of those.  Needs room for the grouped members' blocks and the new group next to the
+// old ones: FPX_E_NOMEM leaves everything as it was.  *regrouped = the members of the new group (0: nothing to gain).
+// Under Ctx::group_mu, like the grouping fpx_snapshot_create does.
+int regroup_segments(Ctx* c, const std::vector<Segment*>& segs, uint32_t* regrouped)
+{
+    *regrouped = 0;
+    if (ctx_fuse_min(c) == 0) return FPX_OK;
+    std::vector<Segment*> m;
+    for (Segment* s : segs) {
+        if (!s || s->kind != 0 || s->ctx != c || s->own_flags) continue;
+        if (std::find(m.begin(), m.end(), s) != m.end()) continue;
+        if (s->home || s->direct || (s->candidate && s->d_blocks && !s->settled)) m.push_back(s);
+        if (m.size() == FUSE_MAX) break;
+    }
+    if (m.size() < 2) return FPX_OK;
+    // anything to gain?  more than one unit (a group, a segment on its own), or a group with columns outside the list
+    std::vector<const Group*> homes;
+    uint32_t units = 0;
+    for (const Segment* s : m) {
+        if (!s->home) { units += 1; continue; }
+        if (std::find(homes.begin(), homes.end(), s->home.get()) == homes.end()) { homes.push_back(s->home.get()); units += 1; }
+    }
+    bool dead_columns = false;
+    for (const Group* g : homes) {
+        uint32_t live = 0;
+        for (const Segment* s : m) if (s->home.get() == g) live += 1;
+        if (live < g->nseg) dead_columns = true;
+    }
+    if (units <= 1 && !dead_columns) return FPX_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return hip_fail(hipGetLastError(), "hipSetDevice");
+    uint64_t need = (size_t)3 << 30, most_items = 0;
+    for (const Segment* s : m) if (s->home) { need += s->blocks_len + 16; most_items = std::max<uint64_t>(most_items, s->num_items); }
+    need += most_items * 8;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
+        (void)hipGetLastError();
+        set_error("not enough free HBM to rebuild the group of %zu segments (%.1f GB for their blocks, %.1f free)", m.size(), need / 1e9, free_b / 1e9);
+        return FPX_E_NOMEM;
+    }
+    struct Old { std::shared_ptr<Group> home; uint32_t col; const char* why; uint64_t device_bytes; };
+    std::vector<Old> old(m.size());
+    std::vector<uint8_t*> blocks(m.size(), nullptr);
+    int rc = FPX_OK;
+    for (size_t j = 0; j < m.size() && !rc; ++j)
+        if (m[j]->home) rc = materialize_blocks(m[j], &blocks[j]);
+    if (rc) {
+        for (uint8_t* b : blocks) if (b) (void)hipFree(b);
+        (void)hipGetLastError();
+        return rc == FPX_E_DEVICE || rc == FPX_E_INVAL ? rc : FPX_E_NOMEM;
+    }
+    for (size_t j = 0; j < m.size(); ++j) {
+        Segment* s = m[j];
+        old[j] = Old{s->home, s->col, s->why, s->device_bytes};
+        if (s->home) { s->home.reset(); s->direct = false; s->d_blocks = blocks[j]; }
+    }
+    std::shared_ptr<Group> g;
+    rc = group_segments(c, m.data(), (uint32_t)m.size(), &g);
+    if (rc) {                                  // nothing has changed in there: back to the old columns
+        for (size_t j = 0; j < m.size(); ++j) {
+            Segment* s = m[j];
+            if (!old[j].home) { s->why = old[j].why; continue; }
+            if (s->d_blocks) { (void)hipFree(s->d_blocks); s->d_blocks = nullptr; }
+            s->home = old[j].home; s->col = old[j].col; s->direct = true; s->why = old[j].why; s->device_bytes = old[j].device_bytes;
+        }
+        return rc;
+    }
+    *regrouped = (uint32_t)m.size();
+    return FPX_OK;
+}
+
 }  // namespace fpx
 
 using namespace fpx;
@@ -570,6 +646,19 @@ int fpx_segment_download(const fpx_segment* seg, uint8_t* blocks, size_t blocks_
         if (s->num_blocks) FPX_HIP(hipMemcpy(block_index, s->d_block_index, (size_t)s->num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return FPX_OK;
+}
+
+int fpx_segments_regroup(fpx_ctx* ctx, fpx_segment* const* segments, uint32_t n, uint32_t* regrouped)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    uint32_t dummy = 0;
+    if (!regrouped) regrouped = &dummy;
+    *regrouped = 0;
+    if (!c || (!segments && n)) { set_error("null argument"); return FPX_E_INVAL; }
+    std::vector<Segment*> segs;
+    for (uint32_t i = 0; i < n; ++i) segs.push_back(reinterpret_cast<Segment*>(segments[i]));
+    std::lock_guard<std::mutex> group_lock(c->group_mu);
+    return regroup_segments(c, segs, regrouped);
 }
 
 // ---------------------------------------------------------------- snapshot

@@ -17,6 +17,7 @@ import threading
 import numpy as np
 
 from . import index as _ix
+from ._lib import FPX_E_NOMEM, FpxError
 from . import segfile as _sf
 
 
@@ -95,15 +96,37 @@ class Index:
         with self._write:
             return self._checkpoint_locked()
 
-    def merge_files(self, lo, hi):
-        """Merge file segments [lo, hi) into one (the reference's merge policy picks the range; here the caller does)."""
+    def merge_files(self, lo, hi, regroup=True):
+        """Merge file segments [lo, hi) into one (the reference's merge policy picks the range; here the caller does).
+        regroup: gather the file segments into ONE group again before the result is published (fpx_segments_regroup: the merged
+        segment would otherwise wait on its own, next to a group whose merged-away columns are dead) -- when HBM has room for it."""
         with self._write:
             if not (0 <= lo < hi <= len(self.files)) or hi - lo < 2:
                 raise ValueError("need at least two adjacent file segments")
             merged = self._snapshot.merge(self.files[lo:hi], self.block_size)
             merged.merges = self._merged_info(self.files[lo:hi])
-            self._publish(self.files[:lo] + [merged] + self.files[hi:], self.memory)
+            files = self.files[:lo] + [merged] + self.files[hi:]
+            if regroup:
+                self._regroup(files)
+            self._publish(files, self.memory)
             return merged
+
+    def _regroup(self, files):
+        try:
+            return _ix.regroup(self.ctx, files)
+        except FpxError as e:
+            if e.status != FPX_E_NOMEM:
+                raise
+            return 0                                              # no room next to the old groups: they stay
+
+    def regroup(self):
+        """The index's groups of direct-addressed segments collapsed into one (fpx_segments_regroup) and published; readers keep
+        the snapshots they hold.  Returns the members of the new group (0: nothing to gain, or no room in HBM)."""
+        with self._write:
+            n = self._regroup(self.files)
+            if n:
+                self._publish(self.files, self.memory)
+            return n
 
     # ---- persistence in the reference's own formats (src/filefmt.zig, src/manifest.zig, src/snapshot.zig) -----------
     def persist(self, dirpath):

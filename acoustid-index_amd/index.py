@@ -288,6 +288,17 @@ class RemoteSegment(_Segment):
         super().__init__(ctx, h, commit_id, min_doc_id, max_doc_id, ids, alive)
 
 
+def regroup(ctx, segments):
+    """fpx_segments_regroup: the file segments of the next snapshot into ONE group again (after merges an index holds several
+    groups and dead columns).  Returns the number of members of the new group (0: nothing to gain); raises FpxError
+    (FPX_E_NOMEM) when HBM has no room for it -- nothing has changed then."""
+    segs = [s for s in segments if isinstance(s, FileSegment)]
+    arr = (C.c_void_p * max(1, len(segs)))(*[s.h for s in segs])
+    n = C.c_uint32(0)
+    check(lib().fpx_segments_regroup(ctx.h, arr, len(segs), C.byref(n)))
+    return int(n.value)
+
+
 class Segments:
     """Immutable snapshot: file[] then memory[], oldest -> newest (src/Index.zig:36-41)."""
 

@@ -159,6 +159,18 @@ const char *fpx_segment_layout_reason(const fpx_segment *seg);
  * form (a dense group: 128-byte lines of 4 / 8 hash values with their words inside, csrc/fpx_pgroup.hpp), lines, lines whose
  * words overflow into `ext`, words there.  (Introspection for benchmarks and capacity planning.) */
 int fpx_segment_group_info(const fpx_segment *seg, uint64_t *info, uint32_t n);
+/* Rebuild the groups of an index's file segments (no counterpart in the reference: the GPU form of what its merge policy does
+ * for the segment count, src/segment_merge_policy.zig -- here for the count of GROUPS).  Groups form when segments first meet in
+ * a snapshot and are never changed: after checkpoints and merges an index holds several (the old group with the merged-away
+ * members as dead columns, a new group or a lone direct-addressed segment per merge result), and every one costs a probe
+ * launch and an HBM line per query hash.  Of `segments` (the file segments of the next snapshot, in its order) the first 16
+ * that hold the whole hash space and are grouped, direct-addressed or waiting for their first snapshot become ONE new group:
+ * grouped members' blocks are encoded again from their columns (byte for byte), and the group is built chunk by chunk as for
+ * fresh segments.  Snapshots made before keep the old groups (which go with the last of them); the next fpx_snapshot_create
+ * sees the new one.  *regrouped = members of the new group; 0 = nothing to gain (one group without dead columns already).
+ * FPX_E_NOMEM: no room for the members' blocks + the new group next to the old ones -- nothing has changed.  Call it from the
+ * thread that publishes snapshots (it is serialised with fpx_snapshot_create), after a merge, off the query path. */
+int fpx_segments_regroup(fpx_ctx *ctx, fpx_segment *const *segments, uint32_t n, uint32_t *regrouped);
 /* copy a resident file segment's blocks (+terminator) and block index back to the host */
 int fpx_segment_download(const fpx_segment *seg, uint8_t *blocks, size_t blocks_cap,
                          uint32_t *block_index, uint32_t index_cap);

@@ -12,6 +12,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _world_data(fpx, rng, S, per, H, seed):
     data = []
     for s in range(S):
@@ -232,7 +239,7 @@ def test_hash_sharded_reader_over_one_rank_group(monkeypatch):
         p.add_file(items, lo, hi, s + 1, ids, alive)
     p.finish()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29641")
+    os.environ["MASTER_PORT"] = str(_free_port())              # (test_gpu_variants.py runs several of these processes at a time)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         sh = fpx.sharding.HashShardedReader(fpx, ctx, p.reader, dist, 1)
@@ -262,7 +269,7 @@ def test_routed_sharded_reader_over_one_rank_group(monkeypatch):
         p.add_file(items, lo, hi, s + 1, ids, alive)
     p.finish()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29643")
+    os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         sh = fpx.sharding.RoutedShardedReader(fpx, ctx, p.reader, dist, 1)

@@ -20,6 +20,7 @@
 namespace fpx {
 
 constexpr uint64_t KO_MAX_CELLS = 1ull << 22;        // buckets x queries the count table may have (16 MB)
+constexpr uint32_t KO_TILE = 4096;                   // keys k_scatter_keys orders in LDS at a time (32 KB)
 
 __device__ __forceinline__ uint32_t ko_wave_incl_scan(uint32_t v, uint32_t lane)
 {
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_
     __shared__ uint32_t s_pos[KO_MAX_BUCKETS];
     __shared__ uint32_t s_before[KO_MAX_BUCKETS + 1];
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_cnt[KO_MAX_BUCKETS], s_lstart[KO_MAX_BUCKETS], s_fill[KO_MAX_BUCKETS];
+    __shared__ uint64_t s_keys[KO_TILE];
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
     const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
     const uint32_t q0 = g * KO_GROUP, q1 = min(B, q0 + KO_GROUP);
@@ -119,16 +122,39 @@ __global__ __launch_bounds__(256) void k_scatter_keys(KeyOrder ko, const uint64_
         }
         return;
     }
+    // The group's keys in tiles of KO_TILE: a tile is brought into bucket order in LDS first, so that neighbouring threads write
+    // neighbouring keys of a bucket's run -- a wave's 64 keys leave in a handful of write requests.  (Written straight from the
+    // registers, every key was an 8-byte write request of its own: 8 M of them per batch of 8192 queries, 0.19 ms -- as many
+    // requests as the probe kernel's reads.)
     const uint64_t lo = offsets[q0] - base, hi = offsets[q1] - base;
-    for (uint64_t i0 = lo; i0 < hi; i0 += 1024u) {
-        uint64_t key[4];
+    for (uint64_t i0 = lo; i0 < hi; i0 += KO_TILE) {
+        const uint32_t n = (uint32_t)min<uint64_t>(KO_TILE, hi - i0);
+        uint64_t key[KO_TILE / 256u];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) { const uint64_t i = i0 + u * 256u + tid; key[u] = i < hi ? gload_u64(keys_in + i) : ~0ull; }
+        for (uint32_t u = 0; u < KO_TILE / 256u; ++u) { const uint32_t i = u * 256u + tid; key[u] = i < n ? gload_u64(keys_in + i0 + i) : ~0ull; }
+        s_cnt[tid] = 0u;
+        __syncthreads();
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            if (key[u] == ~0ull) continue;
-            place(key[u]);
+        for (uint32_t u = 0; u < KO_TILE / 256u; ++u)
+            if (key[u] != ~0ull) atomicAdd(&s_cnt[((uint32_t)(key[u] >> qb) >> ko.bshift) & bmask], 1u);
+        __syncthreads();
+        uint32_t tile_total;
+        const uint32_t lstart = ko_block_excl_scan(s_cnt[tid], tid, s_w, &tile_total);
+        s_lstart[tid] = lstart; s_fill[tid] = lstart;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < KO_TILE / 256u; ++u)
+            if (key[u] != ~0ull) s_keys[atomicAdd(&s_fill[((uint32_t)(key[u] >> qb) >> ko.bshift) & bmask], 1u)] = key[u];
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256u) {
+            const uint64_t k = s_keys[i];
+            const uint32_t b = ((uint32_t)(k >> qb) >> ko.bshift) & bmask;
+            const uint32_t at = s_pos[b] + (i - s_lstart[b]);
+            if (!slot_buckets) keys_out[at] = k;
+            else if (at < slot_cap) keys_out[(size_t)(b / slot_buckets) * slot_cap + at] = k;
         }
+        __syncthreads();
+        s_pos[tid] += s_cnt[tid];                                   // (buckets beyond ko.nb: never read)
     }
 }
 

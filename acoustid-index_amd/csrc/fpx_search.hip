@@ -246,7 +246,7 @@ static int sync_deadline(Workspace* ws, double t_start, uint32_t timeout_ms)
 
 // The count table of the batch's key order (fpx_keyorder.hpp): `bits` hash bits below the `win_bits` a hash window fixes, fewer
 // when the table would outgrow KO_MAX_CELLS.  Layout of ws->d_kocnt: [B x nb counts | nb totals | pad | the key count (u64)].
-static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigned bits, KeyOrder* ko, unsigned long long** P_dev, hipStream_t st)
+static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigned bits, KeyOrder* ko, unsigned long long** P_dev, hipStream_t st, bool per_group = false)
 {
     const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
     bits = std::min(bits, 8u);                       // KO_MAX_BUCKETS
@@ -268,9 +268,12 @@ static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigne
         *P_dev = reinterpret_cast<unsigned long long*>(ws->d_kocnt + (((size_t)G * nb + nb + 1) & ~(size_t)1));
         ko->qn = ws->d_kocnt + (size_t)G * nb + nb + 4;
     }
-    FPX_HIP(hipMemsetAsync(ko->cnt, 0, (size_t)G * nb * sizeof(uint32_t), st));
+    ko->per_group = per_group ? 1u : 0u;            // (k_make_keys_dedup stores every cell: nothing to zero)
+    if (!per_group) FPX_HIP(hipMemsetAsync(ko->cnt, 0, (size_t)G * nb * sizeof(uint32_t), st));
     return FPX_OK;
 }
+// from this many queries on a workgroup of k_make_keys_dedup makes the keys of a whole group of KO_GROUP queries (plain counts)
+constexpr uint32_t KO_PER_GROUP_MIN_B = 2048;
 
 // What the host looks at after a device-sized batch -- counters, the kernels' statistics, the bins' fill counts -- is written by
 // ONE small kernel into page-locked host memory that is mapped into the device, and k_finish writes a small batch's results there
@@ -503,9 +506,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // flight no longer fill each other's gaps (8192 queries: 1.16 against 0.97 ms per batch)
         static const uint64_t order_max = [] { const char* e = getenv("FPX_ORDER_MAX_PAIRS"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
         const bool own_order = flagged && !single_fast && P >= order_min && P <= order_max;
-        if (own_order && (rc = key_order_setup(ws, B, 0u, 32u - key_skip, &ko, nullptr, st))) return rc;
+        if (own_order && (rc = key_order_setup(ws, B, 0u, 32u - key_skip, &ko, nullptr, st, B >= KO_PER_GROUP_MIN_B))) return rc;
         if (flagged)
-            hipLaunchKernelGGL(k_make_keys_dedup, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
+            hipLaunchKernelGGL(k_make_keys_dedup, dim3(ko.per_group ? (B + KO_GROUP - 1u) / KO_GROUP : B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
                                single_fast ? ws->d_counters : nullptr, ws->d_def_count, (uint32_t)def_words, ko);
         else
             hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
@@ -1737,9 +1740,9 @@ int shard_keys_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ran
         const uint64_t P = offsets[B];
         if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
         KeyOrder ko{};
-        if ((rc = key_order_setup(ws, B, 0u, 8u, &ko, nullptr, st))) return rc;
+        if ((rc = key_order_setup(ws, B, 0u, 8u, &ko, nullptr, st, B >= KO_PER_GROUP_MIN_B))) return rc;
         if (ko.nb < world) { set_error("fpx_shard_keys: the batch is too large for %u ranks", world); return FPX_E_INVAL; }
-        hipLaunchKernelGGL(k_make_keys_dedup, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits, 0ull, ws->d_keys[0],
+        hipLaunchKernelGGL(k_make_keys_dedup, dim3(ko.per_group ? (B + KO_GROUP - 1u) / KO_GROUP : B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits, 0ull, ws->d_keys[0],
                            (unsigned long long*)nullptr, (unsigned int*)nullptr, 0u, ko, q_lo);
         hipLaunchKernelGGL(k_bucket_scan, dim3(ko.nb), dim3(256), 0, st, ko, (B + KO_GROUP - 1u) / KO_GROUP);
         hipLaunchKernelGGL(k_scatter_keys, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, (const uint64_t*)ws->d_keys[0], (const uint64_t*)qb->d_offsets, 0ull, 0u, B, qbits,

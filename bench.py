@@ -149,7 +149,10 @@ def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
 def dominant_kernel(segs, fused=False):
     files = [sg for sg in segs if sg.kind == "file"]
     if files and all(getattr(sg, "direct", False) for sg in files):
-        return "k_probe_group" if fused else "k_probe_direct"
+        if not fused:
+            return "k_probe_direct"
+        gi = next((sg.group_info() for sg in files if getattr(sg, "grouped", False)), None)
+        return "k_probe_pgroup" if gi and gi.get("packed") else "k_probe_group"
     return "k_probe_lean8"
 
 

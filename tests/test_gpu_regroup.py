@@ -144,3 +144,42 @@ def test_regroup_takes_in_a_segment_on_its_own(env):
     assert info["groups"] == 1 and info["direct_solo"] == 0 and info["group_columns"] == 3 and info["one_launch_path"] == 1, info
     after, _ = p.check(qs, fpx.http_options())
     assert after == before
+
+
+def test_regroup_at_segments_of_a_million_items(env):
+    """the same life cycle at the size where segments become direct-addressed by default (>= 2^20 items), hot-hash data: the oracle is
+    built from the files' own bytes (downloaded before the regroup) and must still agree afterwards, byte for byte downloads included"""
+    fpx, oracle, Pair, ctx = env
+    ctx.set_option("group_packed", -1)
+    ctx.set_option("direct_min_items", 1 << 20)
+    per, H = 24000, 48                                                        # 1.15 M items per segment
+    segs = [fpx.FileSegment.synth(ctx, 99, s * per + 1, per, H, 1, 512, s + 1) for s in range(4)]
+    snap = fpx.Segments(ctx, segs)
+    assert all(s.grouped for s in segs) and snap.info()["groups"] == 1
+    merged = snap.merge(segs[0:2], 512)
+    new = fpx.FileSegment.synth(ctx, 99, 4 * per + 1, per, H, 1, 512, 9)
+    files = [merged, segs[2], segs[3], new]
+    p = Pair(ctx)
+    p.gpu_segs = files
+    bytes_before = []
+    for f in files:
+        blocks, index = f.download()
+        ids, alive = f.docs()
+        bytes_before.append((blocks, index))
+        p.orc_file.append(oracle.file_segment(blocks, 512, index, f.min_doc_id, f.max_doc_id, f.commit_id, ids, alive))
+    p.finish()
+    info = p.reader.snapshot.info()
+    assert info["groups"] == 2 and info["group_columns"] == 4, info
+    flat, off, _ = fpx.synth.make_queries(99, 7, 48, 5 * per, H, query_len=300, dist=1)
+    qs = [flat[int(off[i]):int(off[i + 1])] for i in range(48)]
+    before, _ = p.check(qs, fpx.http_options())
+    assert fpx.regroup(ctx, files) == 4
+    p.finish()
+    info = p.reader.snapshot.info()
+    assert info["groups"] == 1 and info["group_columns"] == 4 and info["one_launch_path"] == 1, info
+    assert files[0].group_info()["columns"] == 4
+    after, _ = p.check(qs, fpx.http_options())
+    assert after == before
+    for f, (blocks, index) in zip(files, bytes_before):
+        b2, i2 = f.download()
+        assert np.array_equal(blocks, b2) and np.array_equal(index, i2)

@@ -676,7 +676,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
                     if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; }
                     static const uint32_t group_rounds = [] { const char* e = getenv("FPX_GROUP_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
-                    gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_group / 8192));
+                    gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
                     const uint64_t per_wg_gk = (uint64_t)FK_WG * gk.rounds;
                     for (const GroupDesc& gd : snap->h_group) {              // one launch per group: its descriptor is a kernel argument
                         const GroupArgs gargs{gd, snap->d_direct};

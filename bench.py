@@ -187,7 +187,9 @@ def row_from(B, steps, dt, agg, segs, kernel_hint=None):
     return r
 
 
-PMC_COUNTERS = ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")
+# memory-side requests of the L2, reads and writes, each with its dominant size class (four TCC counters fit one pass; round 4's first
+# passes also took RDREQ_32B / _64B: 0 and 0.1 % of the reads of every kernel here -- what is neither 128 B is tallied at 64 B)
+PMC_COUNTERS = ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")
 
 
 def parse_pmc_dir(d):
@@ -222,6 +224,12 @@ def ea_read_bytes(c):
     n32, n64, n128 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_64B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
     other = max(0.0, c.get("TCC_EA0_RDREQ_sum", 0.0) - n32 - n64 - n128)
     return 32.0 * n32 + 64.0 * (n64 + other) + 128.0 * n128
+
+
+def ea_write_bytes(c):
+    """bytes the L2 wrote to the memory side: 64-byte requests, and 32-byte ones (partly written sectors; atomics that bypass the cache)"""
+    w, w64 = c.get("TCC_EA0_WRREQ_sum", 0.0), c.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+    return 64.0 * w64 + 32.0 * max(0.0, w - w64)
 
 
 def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
@@ -261,6 +269,8 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
         last = by[main][-2:]
         req = sum(c.get("TCC_EA0_RDREQ_sum", 0.0) for c in last) / len(last)
         nbytes = sum(ea_read_bytes(c) for c in last) / len(last)
+        wreq = sum(c.get("TCC_EA0_WRREQ_sum", 0.0) for c in last) / len(last)
+        wbytes = sum(ea_write_bytes(c) for c in last) / len(last)
         cal = {}
         if child:
             lanes = child.get("pattern_lanes", 0)
@@ -283,6 +293,7 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
             with open(os.path.join(out_dir, "ea_read_requests.json"), "w") as fh:      # (the raw CSVs are tens of MB: the per-kernel sums are what is kept)
                 json.dump({k: v[-3:] for k, v in by.items()}, fh, indent=1)
         return {"kernel": main, "hbm_read_bytes_per_launch": nbytes, "read_requests_per_launch": req,
+                "hbm_write_bytes_per_launch": wbytes, "write_requests_per_launch": wreq, "hbm_bytes_per_launch": nbytes + wbytes,
                 "request_sizes": {k: sum(c.get(k, 0.0) for c in last) / len(last) for k in PMC_COUNTERS},
                 "calibration": cal, "launches_averaged": len(last),
                 "child_probe_kernel_ms_under_profiler": child.get("probe_kernel_ms") if child else None}, None
@@ -301,7 +312,7 @@ def stored_traffic(docs, S, H, B, qlen):
             if tr.get("kernel_source_sha16") != kernel_source_hash():
                 continue
             k = next((k for k in ("k_probe_pgroup", "k_probe_group", "k_probe_direct") if k in tr), "k_probe_lean8")
-            return tr[k]["hbm_read_bytes_per_launch_corrected"], f"profiles/{name}@{tr['kernel_source_sha16']}"
+            return tr[k].get("hbm_bytes_per_launch", tr[k]["hbm_read_bytes_per_launch_corrected"]), f"profiles/{name}@{tr['kernel_source_sha16']}"
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -976,7 +987,7 @@ def main():
             t_p = time.perf_counter()
             pmc, err = run_pmc_child(args, docs)
             if pmc:
-                traffic, src = pmc["hbm_read_bytes_per_launch"], "in-run: rocprofv3 --pmc TCC_EA0_RDREQ_{sum,32B,64B,128B} child pass of this script (requests counted by size; calibration kernels in the same pass)"
+                traffic, src = pmc["hbm_bytes_per_launch"], "in-run: rocprofv3 --pmc TCC_EA0_RDREQ_{sum,128B} TCC_EA0_WRREQ_{sum,64B} child pass of this script (memory-side requests counted, reads and writes; calibration kernels in the same pass)"
                 result["roofline"]["pmc"] = {**pmc, "seconds": round(time.perf_counter() - t_p, 1)}
             else:
                 result["roofline"]["pmc"] = {"error": err}
@@ -986,13 +997,16 @@ def main():
             rf = result["roofline"]
             gbs = traffic / (rf["avg_launch_ms"] * 1e-3) / 1e9
             rf.update({"traffic": traffic, "traffic_source": src, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
-                       "requests": pmc["read_requests_per_launch"] if pmc else None,
-                       "request_rate_G_per_s": (pmc["read_requests_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) if pmc else None,
+                       "traffic_read": pmc["hbm_read_bytes_per_launch"] if pmc else None, "traffic_written": pmc["hbm_write_bytes_per_launch"] if pmc else None,
+                       "requests": (pmc["read_requests_per_launch"] + pmc["write_requests_per_launch"]) if pmc else None,
+                       "read_requests": pmc["read_requests_per_launch"] if pmc else None, "write_requests": pmc["write_requests_per_launch"] if pmc else None,
+                       "request_rate_G_per_s": ((pmc["read_requests_per_launch"] + pmc["write_requests_per_launch"]) / (rf["avg_launch_ms"] * 1e-3) / 1e9) if pmc else None,
                        "request_rate_peak_measured_G_per_s": 47.0,
                        "request_rate_note": "47 G requests/s: what this chip served random 128-byte reads at with many loads in flight (tools/random_read2.hip, "
                                             "profiles/r02_random_read_rates.txt)",
-                       "achieved_basis": "HBM read bytes COUNTED by PMC (memory-side read requests by size class; all of them 128-byte on gfx950, verified by the "
-                                         "calibration kernels of the same pass) per launch / HIP-event time of the unprofiled launches in this run"})
+                       "achieved_basis": "HBM bytes COUNTED by PMC -- memory-side read requests (128-byte ones on gfx950: verified by the calibration kernels of "
+                                         "the same pass) + write requests (64-byte ones; the hit records leaving for their bins) -- per launch / HIP-event time of "
+                                         "the unprofiled launches in this run"})
 
     # ---- the same index in BLOCK form (FPX_DIRECT=0): the kernel north_star names -- coalesced loads of the segments' block
     #      pages, LDS-staged StreamVByte decode (src/streamvbyte.zig:341-412, src/block.zig:137-158) -- with its own roofline:
@@ -1034,12 +1048,13 @@ def main():
             if not args.no_pmc and os.environ.get("FPX_BENCH_PMC", "1") != "0":
                 pmc_b, err_b = run_pmc_child(args, docs, env_extra={"FPX_DIRECT": "0"}, keep_tag="block_form")
                 if pmc_b:
-                    gbs = pmc_b["hbm_read_bytes_per_launch"] / (rfb["avg_launch_ms"] * 1e-3) / 1e9
-                    rfb.update({"traffic": pmc_b["hbm_read_bytes_per_launch"], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "pmc": pmc_b,
-                                "requests": pmc_b["read_requests_per_launch"],
-                                "achieved_basis": "HBM read bytes COUNTED by PMC (memory-side read requests by size class) per launch / HIP-event time of the "
+                    gbs = pmc_b["hbm_bytes_per_launch"] / (rfb["avg_launch_ms"] * 1e-3) / 1e9
+                    rfb.update({"traffic": pmc_b["hbm_bytes_per_launch"], "traffic_read": pmc_b["hbm_read_bytes_per_launch"], "traffic_written": pmc_b["hbm_write_bytes_per_launch"],
+                                "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "pmc": pmc_b,
+                                "requests": pmc_b["read_requests_per_launch"] + pmc_b["write_requests_per_launch"],
+                                "achieved_basis": "HBM bytes COUNTED by PMC (memory-side read and write requests by size class) per launch / HIP-event time of the "
                                                   "unprofiled launches in this run",
-                                "traffic_source": "in-run: rocprofv3 --pmc TCC_EA0_RDREQ_* child pass of this script with FPX_DIRECT=0"})
+                                "traffic_source": "in-run: rocprofv3 --pmc TCC_EA0_RDREQ_* TCC_EA0_WRREQ_* child pass of this script with FPX_DIRECT=0"})
                 else:
                     rfb["pmc"] = {"error": err_b}
             result["roofline_block_form"] = rfb

@@ -43,7 +43,7 @@ for sub, out in (("pmc", "ea_read_requests.json"), (os.path.join("pmc", "block_f
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{TAG}_{out}"))
 import bench as bench_mod  # noqa: E402
-tr = {"command": "bench.py's in-run children: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum "
+tr = {"command": "bench.py's in-run children: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum "
                  "-- python bench.py --pmc-child ... (the second with FPX_DIRECT=0)",
       "config": {k: bench["config"][k] for k in ("docs", "segments", "hashes_per_doc", "batch", "query_len")},
       "kernel_source_sha16": bench["kernel_source_sha16"]}
@@ -51,8 +51,9 @@ for key in ("roofline", "roofline_block_form"):
     pmc = bench.get(key, {}).get("pmc", {})
     if "hbm_read_bytes_per_launch" in pmc:
         tr.setdefault("calibration", pmc["calibration"])
-        tr[pmc.get("kernel", "k_probe_lean8")] = {"read_requests_per_launch": pmc["read_requests_per_launch"], "request_sizes": pmc["request_sizes"],
-                                                  "hbm_read_bytes_per_launch_corrected": pmc["hbm_read_bytes_per_launch"]}
+        tr[pmc.get("kernel", "k_probe_lean8")] = {"read_requests_per_launch": pmc["read_requests_per_launch"], "write_requests_per_launch": pmc.get("write_requests_per_launch"),
+                                                  "request_sizes": pmc["request_sizes"], "hbm_read_bytes_per_launch_corrected": pmc["hbm_read_bytes_per_launch"],
+                                                  "hbm_write_bytes_per_launch": pmc.get("hbm_write_bytes_per_launch"), "hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch", pmc["hbm_read_bytes_per_launch"])}
 json.dump(tr, open(os.path.join(dst, f"{TAG}_traffic.json"), "w"), indent=1)
 if bench["kernel_source_sha16"] != bench_mod.kernel_source_hash():
     print("WARNING: the profile was taken on other kernel sources than the tree holds (bench.py will not use r04_traffic.json as a fallback)")

@@ -39,6 +39,8 @@ namespace fpx {
 #ifndef FPX_PK_WORDS
 #define FPX_PK_WORDS 12
 #endif
+constexpr uint32_t PK_RANKED = 0x80000000u;       // upper word of a staged record that carries its rank (see the kernel's stage)
+static_assert(GB_SLOTS <= 128u, "a staged record has seven bits for its bin's slot");
 constexpr uint32_t PK_WORDS = FPX_PK_WORDS; // words of a hash walked by its lane (16-byte pieces of its line); the rare rest by the wave
 #ifndef FPX_PK_WAVES
 #define FPX_PK_WAVES 5
@@ -53,7 +55,11 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     // budget by the occupancy it believes the static LDS allows, and it believes in 64 KB per CU (gfx950 has 160)
     extern __shared__ __align__(16) uint8_t gk_dyn[];
     uint64_t* stage = reinterpret_cast<uint64_t*>(gk_dyn);
-    uint16_t* s_rank = reinterpret_cast<uint16_t*>(gk_dyn + (size_t)FSTAGE_CAP * sizeof(uint64_t));      // (a rank inside a bin of one round: < 2048)
+    // (BINNED) a staged record that HAS its rank in its bin carries it, with the bin's slot and the query's number inside the bin, in
+    // its upper word -- PK_RANKED | slot << 24 | query-in-bin << 18 | rank --: one 8-byte LDS store per record and nothing else (round 3
+    // and the directory + words kernel keep the ranks in an array of their own: a second store, a second load, a reset per record).
+    // A record without one is the plain (q << 32 | doc), q < 2^24: the flush gives it a rank, or sends it to the misc buffer.
+    __shared__ uint32_t s_bsel[GB_SLOTS];                 // the bin of every slot of the round being flushed
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
@@ -66,7 +72,6 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     if (tid < FUSE_MAX) { s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
     if (tid < GROUP_CHUNKS) s_ext[tid] = tid < g->nchunks ? g->ext_tab[tid] : nullptr;
     if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid / GB_SLOTS][tid % GB_SLOTS] = 0u; s_bid[tid / GB_SLOTS][tid % GB_SLOTS] = GB_EMPTY; }
-    if constexpr (BINNED) for (uint32_t i = tid; i < FSTAGE_CAP; i += FK_WG) s_rank[i] = GB_NEED;
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
@@ -246,29 +251,27 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             if (cnt == 0u) return;
             const uint32_t pos = atomicAdd(hs.count, cnt);
             if (pos + cnt <= FSTAGE_CAP) {
-                uint32_t r0 = 0, rstep = 0;
+                uint32_t hi0 = qhi, hstep = 0;                // the records' upper words: hi0 + hstep * (records of the lane before it)
                 if constexpr (BINNED) {
                     const uint32_t b = gb_cell(a, qpart), bslot = gb_slot(a, qpart);
                     const uint32_t old = atomicCAS(&s_bid[par][bslot], GB_EMPTY, b);
-                    const bool mine_bin = old == GB_EMPTY || old == b;                           // (two bins on one slot: the misc buffer)
-                    r0 = mine_bin ? atomicAdd(&s_bcnt[par][bslot], cnt) : (uint32_t)GB_NEED;
-                    rstep = mine_bin ? 1u : 0u;
+                    if (old == GB_EMPTY || old == b) {                                            // (two bins on one slot: plain records, the misc buffer)
+                        hi0 = PK_RANKED | (bslot << 24) | ((qhi & ((1u << a.bin_shift) - 1u)) << 18) | atomicAdd(&s_bcnt[par][bslot], cnt);
+                        hstep = 1u;
+                    }
                 }
                 uint64_t* dst = hs.buf + pos;
-                uint16_t* rk = s_rank + pos;
 #pragma unroll
                 for (uint32_t j = 0; j < PK_WORDS; ++j)
                     if ((km >> j) & 1u) {
                         const uint32_t o = (uint32_t)__popc(km & ((1u << j) - 1u));
-                        dst[o] = ((uint64_t)qhi << 32) | gw[j];
-                        if constexpr (BINNED) rk[o] = (uint16_t)(r0 + rstep * o);
+                        dst[o] = ((uint64_t)(hi0 + hstep * o) << 32) | gw[j];
                     }
 #pragma unroll
                 for (uint32_t t = 0; t < 7u; ++t)
                     if ((xk >> t) & 1u) {
                         const uint32_t o = nk + (uint32_t)__popc(xk & ((1u << t) - 1u));
-                        dst[o] = ((uint64_t)qhi << 32) | xd[t];
-                        if constexpr (BINNED) rk[o] = (uint16_t)(r0 + rstep * o);
+                        dst[o] = ((uint64_t)(hi0 + hstep * o) << 32) | xd[t];
                     }
             } else {                                 // the stage is full: straight to the batch's record buffer (BINNED: k_bin bins it)
                 atomicMin(hs.valid, pos);
@@ -442,32 +445,39 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             __syncthreads();
             const uint32_t sc = min(stage_count, stage_valid);
             bool unplaced = false;
+            const uint32_t qlm = (1u << a.bin_shift) - 1u;
             for (uint32_t i = tid; i < sc; i += FK_WG) {
-                if (s_rank[i] != GB_NEED) continue;
-                const uint32_t b = gb_cell(a, stage[i]), sl = gb_slot(a, stage[i]);
+                const uint64_t rec = stage[i];
+                if ((uint32_t)(rec >> 32) & PK_RANKED) continue;
+                const uint32_t b = gb_cell(a, rec), sl = gb_slot(a, rec);
                 const uint32_t old = atomicCAS(&s_bid[par][sl], GB_EMPTY, b);
-                if (old == GB_EMPTY || old == b) s_rank[i] = (uint16_t)atomicAdd(&s_bcnt[par][sl], 1u); else unplaced = true;
+                if (old == GB_EMPTY || old == b)
+                    stage[i] = ((uint64_t)(PK_RANKED | (sl << 24) | (((uint32_t)(rec >> 32) & qlm) << 18) | atomicAdd(&s_bcnt[par][sl], 1u)) << 32) | (uint32_t)rec;
+                else unplaced = true;
             }
             __syncthreads();
             if (tid < GB_SLOTS) {
                 const uint32_t c = s_bcnt[par][tid];
                 if (c != 0u) {
-                    s_bbase[tid] = atomicAdd(&a.bin_count[(size_t)s_bid[par][tid] * BIN_STRIDE], c);
+                    const uint32_t b = s_bid[par][tid];
+                    s_bsel[tid] = b;
+                    s_bbase[tid] = atomicAdd(&a.bin_count[(size_t)b * BIN_STRIDE], c);
                     s_bcnt[par][tid] = 0u; s_bid[par][tid] = GB_EMPTY;          // (this parity's next use is two rounds away)
                 }
             }
             __syncthreads();
             for (uint32_t i = tid; i < sc; i += FK_WG) {
                 const uint64_t rec = stage[i];
-                const uint32_t b = gb_cell(a, rec); const uint32_t rk = s_rank[i];
-                if (rk < GB_NEED) {
-                    const uint64_t at = (uint64_t)s_bbase[gb_slot(a, rec)] + rk;
-                    if (at < a.bin_cap) bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, b, at, rec, a.counters);
+                const uint32_t hi = (uint32_t)(rec >> 32);
+                if (hi & PK_RANKED) {
+                    const uint32_t sl = (hi >> 24) & 127u, b = s_bsel[sl];
+                    const uint64_t at = (uint64_t)s_bbase[sl] + (hi & 0x3FFFFu);
+                    if (at < a.bin_cap)
+                        bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, b, at, ((uint64_t)((b << a.bin_shift) | ((hi >> 18) & 63u)) << 32) | (uint32_t)rec, a.counters);
                 } else {                            // (still no place: the misc buffer)
                     const unsigned long long gg = atomicAdd(&a.counters[CTR_HITS], 1ull);
                     if (gg < a.hit_cap) a.hits[gg] = rec;
                 }
-                s_rank[i] = GB_NEED;
             }
             (void)unplaced;
             __syncthreads();

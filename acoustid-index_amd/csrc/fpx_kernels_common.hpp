@@ -130,8 +130,8 @@ struct KeyOrder {
     uint32_t nb = 0;               // buckets, a power of two (0: no counting)
     uint32_t bshift = 0;           // bucket of hash h = (h >> bshift) & (nb - 1)
     uint32_t* qn = nullptr;        // [B] keys of each query (a hash window's keys: the query's slots hold that many), or null
-    uint32_t per_group = 0;        // k_make_keys_dedup: a workgroup makes the keys of a whole GROUP (KO_GROUP queries, one after the other)
-                                   // and stores its counts plainly -- `cnt` needs no zeroing and no atomics (large batches)
+    uint32_t* qrows = nullptr;     // [B][nb]: k_make_keys_dedup stores every query's bucket counts here, plainly (a row of 1 KB), and
+                                   // k_group_hist adds the rows of a group into `cnt` -- no zeroing and no atomics (large batches)
 };
 
 __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
@@ -142,46 +142,40 @@ __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restr
     __shared__ uint32_t tab[DEDUP_SLOTS];
     __shared__ uint32_t hist[KO_MAX_BUCKETS];
     __shared__ uint32_t seen_ones;                  // the hash 0xFFFFFFFF (the table's empty mark) is kept apart
-    const uint32_t tid = threadIdx.x;
-    // A query per workgroup -- or (ko.per_group: batches of thousands of queries) a group of KO_GROUP queries, one after the other:
-    // the group's bucket counts are then stored plainly.  With a query per workgroup the 256 counts of each of 8192 queries were
-    // 2 M atomics on 256 x 1024 cells: 80 of the kernel's 120 us.
-    const uint32_t qpw = (ko.nb && ko.per_group) ? KO_GROUP : 1u;
-    const uint32_t q_first = blockIdx.x * qpw;
-    if (q_first >= B) return;
-    if (zero_counters && blockIdx.x == 0 && tid < CTR_COUNT) zero_counters[tid] = 0ull;
-    if (zero_u32 && blockIdx.x == 0)
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= B) return;
+    if (zero_counters && q == 0 && tid < CTR_COUNT) zero_counters[tid] = 0ull;
+    if (zero_u32 && q == 0)
         for (uint32_t i = tid; i < zero_n; i += 256u) zero_u32[i] = 0u;
+    for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
     hist[tid] = 0u;
-    for (uint32_t q = q_first; q < min(B, q_first + qpw); ++q) {
-        if (q != q_first) __syncthreads();              // (the previous query's table is still being probed)
-        for (uint32_t i = tid; i < DEDUP_SLOTS; i += 256u) tab[i] = 0xFFFFFFFFu;
-        if (tid == 0) seen_ones = 0u;
-        __syncthreads();
-        const uint64_t lo = offsets[q], hi = offsets[q + 1];
-        for (uint64_t i = lo + tid; i < hi; i += 256u) {
-            const uint32_t h = hashes_base[i];
-            bool dup;
-            if (h == 0xFFFFFFFFu) {
-                dup = atomicExch(&seen_ones, 1u) != 0u;
-            } else {
-                uint32_t slot = (h * 0x9E3779B1u) >> 20;                 // 12 bits
-                for (;;) {
-                    const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, h);
-                    if (old == 0xFFFFFFFFu) { dup = false; break; }
-                    if (old == h) { dup = true; break; }
-                    slot = (slot + 1u) & (DEDUP_SLOTS - 1u);
-                }
+    if (tid == 0) seen_ones = 0u;
+    __syncthreads();
+    const uint64_t lo = offsets[q], hi = offsets[q + 1];
+    for (uint64_t i = lo + tid; i < hi; i += 256u) {
+        const uint32_t h = hashes_base[i];
+        bool dup;
+        if (h == 0xFFFFFFFFu) {
+            dup = atomicExch(&seen_ones, 1u) != 0u;
+        } else {
+            uint32_t slot = (h * 0x9E3779B1u) >> 20;                 // 12 bits
+            for (;;) {
+                const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, h);
+                if (old == 0xFFFFFFFFu) { dup = false; break; }
+                if (old == h) { dup = true; break; }
+                slot = (slot + 1u) & (DEDUP_SLOTS - 1u);
             }
-            keys[i - base] = (((uint64_t)h << qb) | (q + q_base)) | (dup ? KEY_DUP_FLAG : 0ull);
-            if (ko.nb) atomicAdd(&hist[(h >> ko.bshift) & (ko.nb - 1u)], 1u);       // (duplicates keep their place in the order)
         }
+        keys[i - base] = (((uint64_t)h << qb) | (q + q_base)) | (dup ? KEY_DUP_FLAG : 0ull);
+        if (ko.nb) atomicAdd(&hist[(h >> ko.bshift) & (ko.nb - 1u)], 1u);       // (duplicates keep their place in the order)
     }
     if (ko.nb) {
         __syncthreads();
         const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
-        if (qpw == KO_GROUP) { if (tid < ko.nb) ko.cnt[(size_t)tid * G + blockIdx.x] = hist[tid]; }
-        else if (tid < ko.nb && hist[tid] != 0u) atomicAdd(&ko.cnt[(size_t)tid * G + q_first / KO_GROUP], hist[tid]);
+        // large batches: the query's row of counts, stored plainly (k_group_hist adds a group's rows).  Straight into cnt[bucket][group]
+        // the 256 counts of each of 8192 queries were 2 M atomics on 256 x 1024 cells: 80 of the kernel's 120 us
+        if (ko.qrows) { if (tid < ko.nb) ko.qrows[(size_t)q * ko.nb + tid] = hist[tid]; }
+        else if (tid < ko.nb && hist[tid] != 0u) atomicAdd(&ko.cnt[(size_t)tid * G + q / KO_GROUP], hist[tid]);
     }
 }
 

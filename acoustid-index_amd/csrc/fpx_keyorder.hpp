@@ -47,6 +47,17 @@ __device__ __forceinline__ uint32_t ko_block_excl_scan(uint32_t v, uint32_t tid,
     return before + incl - v;
 }
 
+// large batches: cnt[b][g] = the sum of the rows of group g's queries (ko.qrows, written by k_make_keys_dedup).  One workgroup per group.
+__global__ __launch_bounds__(256) void k_group_hist(KeyOrder ko, uint32_t B)
+{
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
+    if (tid >= ko.nb) return;
+    uint32_t sum = 0;
+    for (uint32_t q = g * KO_GROUP; q < min(B, (g + 1u) * KO_GROUP); ++q) sum += gload_u32(ko.qrows + (size_t)q * ko.nb + tid);
+    ko.cnt[(size_t)tid * G + g] = sum;
+}
+
 // one workgroup per bucket: the bucket's row of `G` group counts is contiguous
 __global__ __launch_bounds__(256) void k_bucket_scan(KeyOrder ko, uint32_t G)
 {

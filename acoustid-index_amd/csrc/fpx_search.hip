@@ -246,13 +246,14 @@ static int sync_deadline(Workspace* ws, double t_start, uint32_t timeout_ms)
 
 // The count table of the batch's key order (fpx_keyorder.hpp): `bits` hash bits below the `win_bits` a hash window fixes, fewer
 // when the table would outgrow KO_MAX_CELLS.  Layout of ws->d_kocnt: [B x nb counts | nb totals | pad | the key count (u64)].
-static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigned bits, KeyOrder* ko, unsigned long long** P_dev, hipStream_t st, bool per_group = false)
+static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigned bits, KeyOrder* ko, unsigned long long** P_dev, hipStream_t st, bool rows = false)
 {
     const uint32_t G = (B + KO_GROUP - 1u) / KO_GROUP;
     bits = std::min(bits, 8u);                       // KO_MAX_BUCKETS
     while (bits > 0u && ((uint64_t)G << bits) > KO_MAX_CELLS) --bits;
     const uint32_t nb = 1u << bits;
-    const size_t words = (size_t)G * nb + nb + 4 + (P_dev ? (size_t)B : 0);
+    const size_t rows_at = ((size_t)G * nb + nb + 4 + (P_dev ? (size_t)B : 0) + 31) & ~(size_t)31;      // (the queries' rows of counts, a 128-byte boundary)
+    const size_t words = rows_at + (rows ? (size_t)B * nb : 0);
     if (words > ws->cap_kocnt) {
         if (ws->d_kocnt) (void)hipFree(ws->d_kocnt);
         ws->d_kocnt = nullptr; ws->cap_kocnt = 0;
@@ -268,12 +269,12 @@ static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigne
         *P_dev = reinterpret_cast<unsigned long long*>(ws->d_kocnt + (((size_t)G * nb + nb + 1) & ~(size_t)1));
         ko->qn = ws->d_kocnt + (size_t)G * nb + nb + 4;
     }
-    ko->per_group = per_group ? 1u : 0u;            // (k_make_keys_dedup stores every cell: nothing to zero)
-    if (!per_group) FPX_HIP(hipMemsetAsync(ko->cnt, 0, (size_t)G * nb * sizeof(uint32_t), st));
+    ko->qrows = rows ? ws->d_kocnt + rows_at : nullptr;      // (k_group_hist stores every cell of cnt: nothing to zero)
+    if (!rows) FPX_HIP(hipMemsetAsync(ko->cnt, 0, (size_t)G * nb * sizeof(uint32_t), st));
     return FPX_OK;
 }
-// from this many queries on a workgroup of k_make_keys_dedup makes the keys of a whole group of KO_GROUP queries (plain counts)
-constexpr uint32_t KO_PER_GROUP_MIN_B = 2048;
+// from this many queries on k_make_keys_dedup stores its query's counts as a row and k_group_hist adds the groups' rows (no atomics)
+constexpr uint32_t KO_ROWS_MIN_B = 2048;
 
 // What the host looks at after a device-sized batch -- counters, the kernels' statistics, the bins' fill counts -- is written by
 // ONE small kernel into page-locked host memory that is mapped into the device, and k_finish writes a small batch's results there
@@ -506,9 +507,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // flight no longer fill each other's gaps (8192 queries: 1.16 against 0.97 ms per batch)
         static const uint64_t order_max = [] { const char* e = getenv("FPX_ORDER_MAX_PAIRS"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
         const bool own_order = flagged && !single_fast && P >= order_min && P <= order_max;
-        if (own_order && (rc = key_order_setup(ws, B, 0u, 32u - key_skip, &ko, nullptr, st, B >= KO_PER_GROUP_MIN_B))) return rc;
+        if (own_order && (rc = key_order_setup(ws, B, 0u, 32u - key_skip, &ko, nullptr, st, B >= KO_ROWS_MIN_B))) return rc;
         if (flagged)
-            hipLaunchKernelGGL(k_make_keys_dedup, dim3(ko.per_group ? (B + KO_GROUP - 1u) / KO_GROUP : B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
+            hipLaunchKernelGGL(k_make_keys_dedup, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
                                single_fast ? ws->d_counters : nullptr, ws->d_def_count, (uint32_t)def_words, ko);
         else
             hipLaunchKernelGGL(k_make_keys, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, staged_single ? 0ull : base, ws->d_keys[0],
@@ -522,6 +523,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // one fused pair -- a rank's share of an index sharded over 8 GPUs: the pass costs 0.1 ms and buys k_probe_fused<2> 0.06;
         // k_probe_direct, whose neighbouring probes share record lines, keeps the order)
         if (own_order) {
+            if (ko.qrows) hipLaunchKernelGGL(k_group_hist, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, B);
             hipLaunchKernelGGL(k_bucket_scan, dim3(ko.nb), dim3(256), 0, st, ko, (B + KO_GROUP - 1u) / KO_GROUP);
             hipLaunchKernelGGL(k_scatter_keys, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, (const uint64_t*)ws->d_keys[0], d_offsets, staged_single ? 0ull : base, 0u, B, qb,
                                ws->d_keys[1], (unsigned long long*)nullptr);
@@ -677,6 +679,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; }
                     static const uint32_t group_rounds = [] { const char* e = getenv("FPX_GROUP_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
                     gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
+                    // (hot-hash data -- the previous batch brought 16+ records per key: a workgroup's rounds wait for the waves that copy the
+                    // long lists; three rounds: 3.5 ms per batch of 8192 on distribution Z where five take 4.4)
+                    if (!group_rounds && fast && est_H > 16ull * P) gk.rounds = std::min(gk.rounds, 3u);
                     const uint64_t per_wg_gk = (uint64_t)FK_WG * gk.rounds;
                     for (const GroupDesc& gd : snap->h_group) {              // one launch per group: its descriptor is a kernel argument
                         const GroupArgs gargs{gd, snap->d_direct};
@@ -1740,10 +1745,11 @@ int shard_keys_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ran
         const uint64_t P = offsets[B];
         if ((rc = grow_pair(ws->d_keys, &ws->cap_keys, (size_t)P + 1))) return rc;
         KeyOrder ko{};
-        if ((rc = key_order_setup(ws, B, 0u, 8u, &ko, nullptr, st, B >= KO_PER_GROUP_MIN_B))) return rc;
+        if ((rc = key_order_setup(ws, B, 0u, 8u, &ko, nullptr, st, B >= KO_ROWS_MIN_B))) return rc;
         if (ko.nb < world) { set_error("fpx_shard_keys: the batch is too large for %u ranks", world); return FPX_E_INVAL; }
-        hipLaunchKernelGGL(k_make_keys_dedup, dim3(ko.per_group ? (B + KO_GROUP - 1u) / KO_GROUP : B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits, 0ull, ws->d_keys[0],
+        hipLaunchKernelGGL(k_make_keys_dedup, dim3(B), dim3(256), 0, st, (const uint32_t*)qb->d_hashes, (const uint64_t*)qb->d_offsets, B, qbits, 0ull, ws->d_keys[0],
                            (unsigned long long*)nullptr, (unsigned int*)nullptr, 0u, ko, q_lo);
+        if (ko.qrows) hipLaunchKernelGGL(k_group_hist, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, B);
         hipLaunchKernelGGL(k_bucket_scan, dim3(ko.nb), dim3(256), 0, st, ko, (B + KO_GROUP - 1u) / KO_GROUP);
         hipLaunchKernelGGL(k_scatter_keys, dim3((B + KO_GROUP - 1u) / KO_GROUP), dim3(256), 0, st, ko, (const uint64_t*)ws->d_keys[0], (const uint64_t*)qb->d_offsets, 0ull, 0u, B, qbits,
                            d_keys_send, (unsigned long long*)nullptr, ko.nb / world, key_cap, d_key_counts);

@@ -32,6 +32,13 @@ json.dump(bench, open(os.path.join(dst, f"{TAG}_bench.json"), "w"), indent=1)
 put_json("bench_under_rocprof.json", f"{TAG}_bench_under_rocprof.json")
 put_json("bench_block_under_rocprof.json", f"{TAG}_bench_block_under_rocprof.json")
 put_json("emulated_under_rocprof.json", f"{TAG}_emulated_rank_of_8_under_rocprof.json")
+if os.path.exists(os.path.join(src, "merge_then_search.json")) and os.path.getsize(os.path.join(src, "merge_then_search.json")):
+    try:
+        m = last_json(os.path.join(src, "merge_then_search.json"))
+        m["command"] = "python tools/merge_then_search.py (one MI355X, one batch in flight)"
+        json.dump(m, open(os.path.join(dst, f"{TAG}_merge_then_search.json"), "w"), indent=1)
+    except (ValueError, IndexError):
+        print("unreadable: merge_then_search.json")
 for name in ("emulated_rank_of_8_weak", "emulated_rank_of_8_strong", "emulated_rank_of_4_weak", "emulated_rank_of_2_weak", "emulated_rank_of_8_weak_replicated_hashes"):
     put_json(name + ".json", f"{TAG}_{name}.json")
 for tag, out in (("r04", "kernel_stats.csv"), ("r04b", "block_kernel_stats.csv"), ("r04b1k", "kernel_stats_b1024.csv"), ("r04emu", "emulated_rank_of_8_kernel_stats.csv")):

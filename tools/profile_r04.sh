@@ -5,6 +5,7 @@
 #   2. rocprofv3 --kernel-trace --stats of bench.py (headline only, one batch in flight) -> r04_kernel_stats.csv + the line under the profiler
 #   3. the same with FPX_DIRECT=0 (the block form: k_probe_lean8) -> r04_block_kernel_stats.csv
 #   4. rocprofv3 --kernel-trace --stats of one B = 1024 run -> r04_kernel_stats_b1024.csv
+#   6. tools/merge_then_search.py (24 M index: fresh / after a merge / after fpx_segments_regroup) -> r04_merge_then_search.json
 #   5. FPX_BENCH_EMULATE_WORLD=8 / 4 / 2 (one GPU plays rank 0 of N, the routed-key protocol; weak, and strong at 8) -> r04_emulated_rank_of_*.json,
 #      and the kernel statistics of the rank-of-8 step -> r04_emulated_rank_of_8_kernel_stats.csv
 # Only summaries are kept (gpurun copies back at most 64 MiB).
@@ -32,5 +33,6 @@ FPX_BENCH_EMULATE_WORLD=8 FPX_BENCH_SCALING=strong python $R/bench.py --no-cpu-b
 FPX_BENCH_EMULATE_WORLD=8 FPX_BENCH_ROUTED=0 python $R/bench.py --no-cpu-baseline --no-extras > $O/emulated_rank_of_8_weak_replicated_hashes.json 2>> $O/emu.err
 FPX_BENCH_EMULATE_WORLD=8 FPX_BENCH_SETTLE_S=0 FPX_BENCH_LONG=0 trace r04emu $O/emulated_under_rocprof.json python $R/bench.py --no-cpu-baseline --no-extras --inflight 1
 tail -c 3000 $O/emu.err > $O/emu.tail; rm -f $O/emu.err
+python $R/tools/merge_then_search.py > $O/merge_then_search.json 2> $O/mts.err; tail -c 1000 $O/mts.err > $O/mts.tail; rm -f $O/mts.err
 python3 $R/tools/brief.py $O/bench.json $O/bench_under_rocprof.json $O/emulated_rank_of_8_weak.json $O/emulated_rank_of_4_weak.json $O/emulated_rank_of_2_weak.json $O/emulated_rank_of_8_strong.json $O/emulated_rank_of_8_weak_replicated_hashes.json
 du -sh $O; ls $O

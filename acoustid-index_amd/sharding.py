@@ -355,13 +355,12 @@ class RoutedShardedReader:
         if wb == 0:
             return
         hi_shift = qbits + 32 - wb
-        keep = ~(((1 << wb) - 1) << hi_shift) & 0x7FFFFFFFFFFFFFFF
+        keep = ~(((1 << wb) - 1) << hi_shift)                     # (as a signed 64-bit mask: bit 63 -- a flagged duplicate -- stays)
         share_n = self.share.B
-        k = self.recv_keys
-        sign = k < 0                                              # (bit 63: a flagged duplicate keeps its flag)
-        k = (k & keep) | (int(self.rank) << hi_shift)
-        k = k + (torch.arange(self.world, device=k.device, dtype=torch.int64) * share_n - self.rank * share_n)[:, None]
-        self.recv_keys = torch.where(sign, k | (-0x8000000000000000), k).contiguous()
+        # two in-place passes over the keys (the window's bits cleared, then rank bits + the source's query offset added: the cleared
+        # bits are zero, so the sum is the OR); the stand-in should cost the emulated step as little as it can -- a real rank has no such step
+        add = (torch.arange(self.world, device=self.recv_keys.device, dtype=torch.int64) * share_n - self.rank * share_n + (int(self.rank) << hi_shift))[:, None]
+        self.recv_keys.bitwise_and_(keep).add_(add)
         torch.cuda.current_stream(self.device).synchronize()
 
     def probe(self):

@@ -2073,35 +2073,43 @@ int measure_access_impl(Ctx* ctx, size_t bytes, int mode, uint64_t lanes, double
     while ((128ull << (nlines_log2 + 1)) <= bytes) ++nlines_log2;
     if (nlines_log2 < 16 || mode < 0 || mode > 6) { set_error("fpx_measure_access: buffer too small or unknown mode"); return FPX_E_INVAL; }
     if (lanes > (1ull << nlines_log2) / (mode == 3 ? 2 : 1)) { set_error("fpx_measure_access: more lanes than lines"); return FPX_E_INVAL; }
-    uint8_t* buf = nullptr; unsigned long long* sink = nullptr;
-    FPX_HIP(hipMalloc(&buf, (128ull << nlines_log2) + 64));
-    FPX_HIP(hipMalloc(&sink, 8));
-    FPX_HIP(hipMemset(buf, 0x5a, (128ull << nlines_log2) + 64));
-    FPX_HIP(hipMemset(sink, 0, 8));
-    hipEvent_t e0, e1;
-    FPX_HIP(hipEventCreate(&e0)); FPX_HIP(hipEventCreate(&e1));
-    const dim3 grid((uint32_t)((lanes + 255) / 256));
-    FPX_HIP(hipDeviceSynchronize());
-    float ms = 0.f;
-    for (int rep = 0; rep < 2; ++rep) {              // (the first launch also loads the kernel)
-    FPX_HIP(hipEventRecord(e0, 0));
-    switch (mode) {
-        case 0: hipLaunchKernelGGL(k_bw_pattern<0>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
-        case 1: hipLaunchKernelGGL(k_bw_pattern<1>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
-        case 2: hipLaunchKernelGGL(k_bw_pattern<2>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
-        case 3: hipLaunchKernelGGL(k_bw_pattern<3>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
-        case 4: hipLaunchKernelGGL(k_bw_pattern<4>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
-        case 5: hipLaunchKernelGGL(k_bw_pattern<5>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
-        default: hipLaunchKernelGGL(k_bw_pattern<6>, grid, dim3(256), 0, 0, (const uint8_t*)buf, nlines_log2, lanes, sink); break;
-    }
-    FPX_HIP(hipEventRecord(e1, 0));
-    FPX_HIP(hipEventSynchronize(e1));
-    FPX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    }
-    if (ms_out) *ms_out = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(buf); (void)hipFree(sink);
-    return FPX_OK;
+    uint8_t* buf = nullptr; unsigned long long* sk = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> int {
+        FPX_HIP(hipMalloc(&buf, (128ull << nlines_log2) + 64));
+        FPX_HIP(hipMalloc(&sk, 8));
+        FPX_HIP(hipMemset(buf, 0x5a, (128ull << nlines_log2) + 64));
+        FPX_HIP(hipMemset(sk, 0, 8));
+        FPX_HIP(hipEventCreate(&e0)); FPX_HIP(hipEventCreate(&e1));
+        const dim3 grid((uint32_t)((lanes + 255) / 256));
+        const uint8_t* b = buf;
+        FPX_HIP(hipDeviceSynchronize());
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {              // (the first launch also loads the kernel)
+            FPX_HIP(hipEventRecord(e0, 0));
+            switch (mode) {
+                case 0: hipLaunchKernelGGL(k_bw_pattern<0>, grid, dim3(256), 0, 0, b, nlines_log2, lanes, sk); break;
+                case 1: hipLaunchKernelGGL(k_bw_pattern<1>, grid, dim3(256), 0, 0, b, nlines_log2, lanes, sk); break;
+                case 2: hipLaunchKernelGGL(k_bw_pattern<2>, grid, dim3(256), 0, 0, b, nlines_log2, lanes, sk); break;
+                case 3: hipLaunchKernelGGL(k_bw_pattern<3>, grid, dim3(256), 0, 0, b, nlines_log2, lanes, sk); break;
+                case 4: hipLaunchKernelGGL(k_bw_pattern<4>, grid, dim3(256), 0, 0, b, nlines_log2, lanes, sk); break;
+                case 5: hipLaunchKernelGGL(k_bw_pattern<5>, grid, dim3(256), 0, 0, b, nlines_log2, lanes, sk); break;
+                default: hipLaunchKernelGGL(k_bw_pattern<6>, grid, dim3(256), 0, 0, b, nlines_log2, lanes, sk); break;
+            }
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipEventRecord(e1, 0));
+            FPX_HIP(hipEventSynchronize(e1));
+            FPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        if (ms_out) *ms_out = ms;
+        return FPX_OK;
+    };
+    const int rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (buf) (void)hipFree(buf);
+    if (sk) (void)hipFree(sk);
+    return rc;
 }
 
 int measure_bandwidth_impl(Ctx* ctx, size_t bytes, uint32_t block_size, double* stream_gbs, double* random_gbs)

@@ -449,9 +449,11 @@ int fpx_measure_bandwidth(fpx_ctx *ctx, size_t bytes, uint32_t block_size, doubl
 /* Calibration kernels for the memory-side performance counters (bench.py's rocprofv3 --pmc passes): `lanes` threads read, at
  * addresses that are a permutation of a `bytes`-sized buffer's lines / words (every line once, nothing served twice from a
  * cache), mode 0: one whole 128-byte line each (eight 16-byte loads: a directory line of k_probe_group); 1: one 16-byte piece
- * at a 4-byte-aligned address (a hash's words); 2: one aligned 64-byte half line; 3: a line and two pieces (the kernel's mix).
- * *ms = the launch's HIP-event time.  The requests the memory side must see are known exactly: lanes x 128 B (mode 0),
- * lanes x 19/16 sectors of 64 B (mode 1), lanes x 64 B (mode 2). */
+ * at a 4-byte-aligned address (a hash's words); 2: one aligned 64-byte half line; 3: a line and two pieces (round 3's mix);
+ * 4: a line per eight lanes, read together; 5: mode 0 with non-temporal loads; 6: the first 16 bytes of a line per lane (what
+ * k_probe_pgroup asks of its line).  *ms = the launch's HIP-event time.  The 128-byte lines the memory side must be asked
+ * for are known exactly: `lanes` (modes 0, 2, 4, 5, 6), lanes x 35/32 (mode 1: 3 pieces in 32 straddle a line), lanes x
+ * (1 + 2 x 35/32) (mode 3) -- on gfx950 every memory-side read is a 128-byte request, whatever the access width. */
 int fpx_measure_access(fpx_ctx *ctx, size_t bytes, int mode, uint64_t lanes, double *ms);
 
 #ifdef __cplusplus

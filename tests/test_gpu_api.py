@@ -211,3 +211,21 @@ def test_context_options_decide_the_storage_form_and_the_abi_says_what_came_of_i
     ctx.set_option("direct", 0)
     f, _ = seg(15001, 6)
     assert "turned off" in f.layout_reason
+
+
+def test_measure_access_runs_every_calibration_pattern_and_refuses_nonsense():
+    """fpx_measure_access: the kernels of known memory-side requests that bench.py's counter passes calibrate on"""
+    from fpx_testlib import fpx
+    ctx = fpx.Context(0)
+    nbytes, lanes = 64 << 20, 1 << 18                    # 2^19 lines
+    for mode in range(7):
+        ms = ctx.measure_access(nbytes, mode, lanes)
+        assert 0.0 < ms < 1000.0, (mode, ms)
+    with pytest.raises(fpx.FpxError):
+        ctx.measure_access(nbytes, 7, lanes)             # unknown pattern
+    with pytest.raises(fpx.FpxError):
+        ctx.measure_access(nbytes, 0, 1 << 20)           # more lanes than the buffer has lines
+    with pytest.raises(fpx.FpxError):
+        ctx.measure_access(1 << 20, 0, 16)               # buffer too small
+    stream, rnd = ctx.measure_bandwidth(256 << 20, 512) if hasattr(ctx, "measure_bandwidth") else (1.0, 1.0)
+    assert stream > 0 and rnd > 0

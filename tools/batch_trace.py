@@ -1,5 +1,6 @@
 """tools/batch_trace.py <batch> [steps] -- the default index (100 M x 256 in 16 segments), `steps` resident searches of one
-batch size: run under `rocprofv3 --kernel-trace --stats` to see where a step of that size spends its time."""
+batch size: run under `rocprofv3 --kernel-trace --stats` to see where a step of that size spends its time.
+BT_MEMORY_SEGMENTS=n: n memory segments of ~10^5 items next to the group (a live index's snapshot: bench.py's `mixed` row)."""
 import os
 import sys
 import time
@@ -17,7 +18,13 @@ S, H = 16, 256
 ctx = fpx.Context(0)
 per = docs // S
 segs = [fpx.FileSegment.synth(ctx, 20260928, s * per + 1, per, H, 0, 512, s + 1) for s in range(S)]
-reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+mems = []
+for m in range(int(os.environ.get("BT_MEMORY_SEGMENTS", "0"))):
+    ids = np.arange(docs + 1 + m * 390, docs + 1 + (m + 1) * 390, dtype=np.uint64)
+    hh = fpx.synth.synth_hashes(20260928 + 77, ids, H, 0).astype(np.uint64)
+    items = np.sort(((hh << np.uint64(32)) | ids[:, None]).ravel())
+    mems.append(fpx.MemorySegment(ctx, items, int(ids[0]), int(ids[-1]), S + 1 + m, ids.astype(np.uint32)))
+reader = fpx.IndexReader(fpx.Segments(ctx, segs + mems))
 flat, offsets, _ = fpx.synth.make_queries(20260928, 4242, B, per * S, H, query_len=1000)
 qb = fpx.QueryBatch(ctx, options=fpx.http_options(), flat=(flat, offsets))
 for _ in range(3):

@@ -274,10 +274,88 @@ struct DevBuf {
 
 // Encode `n` sorted items (device memory) into the blocks + block index of `s` (filefmt.writeBlocks,
 // src/filefmt.zig:94-138).  `s->block_size` is taken from the argument; on failure the caller frees `s`.
+// ... and the same over many workgroups for long arrays: parts of 2^14 counts -- their sums, the sums' prefix (the one-workgroup kernel
+// above, over 64-bit values), the parts again with their base.  (One workgroup over the 2^30 line counts of a packed group's column took
+// 2.5 s -- a thread walked a million counts 4 MB apart from its neighbour's --, twice per download or merge of a grouped segment: 5 of the
+// 5.6 s of fpx_segment_download on the 100 M index; over the 2^24 counts of a chunk 30 ms, twice per chunk of a group's build.)
+constexpr uint32_t SCAN_PART = 1u << 14;
+__global__ __launch_bounds__(256) void k_scan_part_sums(const uint32_t* __restrict__ count, uint64_t n, uint64_t* __restrict__ partsum)
+{
+    __shared__ uint64_t red[256];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * SCAN_PART, hi = std::min<uint64_t>(n, lo + SCAN_PART);
+    uint64_t s = 0;
+    for (uint64_t i = lo + tid; i < hi; i += 256u) s += count[i];
+    red[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 128u; d > 0u; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
+    if (tid == 0) partsum[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(1024) void k_scan_u64_inplace(uint64_t* __restrict__ v, uint64_t n, uint64_t* __restrict__ total)
+{
+    __shared__ uint64_t part[1024];
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t lo = threadIdx.x * per, hi = std::min<uint64_t>(lo + per, n);
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint64_t x = part[i]; part[i] = run; run += x; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint64_t i = lo; i < hi; ++i) { const uint64_t x = v[i]; v[i] = run; run += x; }
+}
+__global__ __launch_bounds__(256) void k_scan_part_write(const uint32_t* __restrict__ count, uint64_t n, const uint64_t* __restrict__ partbase,
+                                                         uint64_t* __restrict__ off)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * SCAN_PART, hi = std::min<uint64_t>(n, lo + SCAN_PART);
+    uint64_t run = partbase[blockIdx.x];
+    for (uint64_t t0 = lo; t0 < hi; t0 += 1024u) {                  // tiles of 1024 counts: four neighbours per thread
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const uint64_t i = t0 + tid * 4u + k; v[k] = i < hi ? count[i] : 0u; }
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        __syncthreads();                                            // (s_w is still being read by the previous tile)
+        if (lane == 63u) s_w[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const uint32_t t = s_w[k]; all += t; if (k < w) before += t; }
+        uint64_t at = run + before + (incl - mine);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const uint64_t i = t0 + tid * 4u + k; if (i < hi) off[i] = at; at += v[k]; }
+        run += all;
+    }
+}
+
 int scan_counts_u32(const uint32_t* counts, uint64_t n, uint64_t* offsets, uint64_t* total, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts, n, offsets, total);
-    FPX_HIP(hipGetLastError());
+    if (n <= (1u << 16)) {
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts, n, offsets, total);
+        FPX_HIP(hipGetLastError());
+        return FPX_OK;
+    }
+    const uint64_t nparts = (n + SCAN_PART - 1) / SCAN_PART;
+    if (nparts > 0x7FFFFFFFull) { set_error("scan of %llu counts", (unsigned long long)n); return FPX_E_INVAL; }
+    uint64_t* partsum = nullptr;
+    const bool pooled = hipMallocAsync(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t), st) == hipSuccess;
+    if (!pooled) { (void)hipGetLastError(); partsum = nullptr; FPX_HIP(hipMalloc(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t))); }
+    hipLaunchKernelGGL(k_scan_part_sums, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, partsum);
+    hipLaunchKernelGGL(k_scan_u64_inplace, dim3(1), dim3(1024), 0, st, partsum, nparts, total);
+    hipLaunchKernelGGL(k_scan_part_write, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, (const uint64_t*)partsum, offsets);
+    const hipError_t e = hipGetLastError();
+    if (pooled) (void)hipFreeAsync(partsum, st);
+    else { (void)hipStreamSynchronize(st); (void)hipFree(partsum); }
+    if (e != hipSuccess) return hip_fail(e, "scan_counts_u32");
     return FPX_OK;
 }
 
@@ -323,7 +401,7 @@ static int encode_sorted_items(const uint64_t* items, uint64_t n, uint32_t min_d
         }
         // counts are those of the last walk, which ran on the final entries only if nothing changed afterwards
         hipLaunchKernelGGL(k_walk, dim3(gch), dim3(256), 0, st, wa, 0);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, count.as<uint32_t>(), nchunks, boff.as<uint64_t>(), d_total);
+        if ((rc = scan_counts_u32(count.as<uint32_t>(), nchunks, boff.as<uint64_t>(), d_total, st))) return rc;
         FPX_HIP(hipGetLastError());
         uint64_t num_blocks64 = 0;
         FPX_HIP(hipMemcpyAsync(&num_blocks64, d_total, 8, hipMemcpyDeviceToHost, st));
@@ -608,8 +686,8 @@ int decode_small_segment(Segment* s)
     s->device_bytes += (s->num_items + 1) * sizeof(uint64_t);
     hipLaunchKernelGGL(k_block_item_counts, dim3((s->num_blocks + 255) / 256), dim3(256), 0, st,
                        s->d_blocks, s->block_size, s->num_blocks, counts.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)s->num_blocks,
-                       boff.as<uint64_t>(), tot.as<uint64_t>());
+    if ((rc = scan_counts_u32(counts.as<uint32_t>(), (uint64_t)s->num_blocks,
+                       boff.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
     hipLaunchKernelGGL(k_decode_items, dim3((s->num_blocks + 3) / 4), dim3(256), 0, st,
                        s->d_blocks, s->block_size, s->num_blocks, s->min_doc_id, boff.as<uint64_t>(),
                        (const uint32_t*)nullptr, 0u, s->d_small_items, live.as<uint8_t>());
@@ -1019,7 +1097,7 @@ int direct_candidate(Segment* s, bool* ok)
         FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
         s->device_bytes += ((size_t)nb + 1) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_block_item_counts, dim3((nb + 255) / 256), dim3(256), 0, st, s->d_blocks, s->block_size, nb, counts.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)nb, boff.as<uint64_t>(), tot.as<uint64_t>());
+        if ((rc = scan_counts_u32(counts.as<uint32_t>(), (uint64_t)nb, boff.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
         hipLaunchKernelGGL(k_boff_tail, dim3(1), dim3(1), 0, st, boff.as<uint64_t>(), nb, tot.as<uint64_t>());
         hipLaunchKernelGGL(k_bstart32, dim3((nb + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), nb, s->num_items, s->d_bstart);
         FPX_HIP(hipGetLastError());
@@ -1073,7 +1151,7 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     hipLaunchKernelGGL(k_direct_gap_bits, dim3(std::min<uint32_t>(nbl + 1u, 1u << 20)), dim3(256), 0, st, items.as<uint64_t>(), n,
                        boff.as<uint64_t>(), nbl, out->drec, hr, has_prev ? 1u : 0u, prev_last);
     hipLaunchKernelGGL(k_direct_rec_counts, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, rectot.as<uint32_t>(), nrec);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rectot.as<uint32_t>(), (uint64_t)nrec, recbase.as<uint64_t>(), d_tot + 3);
+    if ((rc = scan_counts_u32(rectot.as<uint32_t>(), (uint64_t)nrec, recbase.as<uint64_t>(), d_tot + 3, st))) return rc;
     hipLaunchKernelGGL(k_direct_rec_base, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, recbase.as<uint64_t>(), nrec);
     FPX_HIP(hipGetLastError());
     // distinct hashes and list words per block -> list bases
@@ -1085,8 +1163,8 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     for (;; pad = 1) {             // (list offsets of 31 bits: in words, or in pairs of words when the lists are longer than that)
         hipLaunchKernelGGL(k_direct_count, dim3((nbl + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nbl,
                            ns.as<uint32_t>(), nx.as<uint32_t>(), flags.as<int>(), pad, hr);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, ns.as<uint32_t>(), (uint64_t)nbl, sbase.as<uint64_t>(), d_tot + 1);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nx.as<uint32_t>(), (uint64_t)nbl, xbase.as<uint64_t>(), d_tot + 2);
+        if ((rc = scan_counts_u32(ns.as<uint32_t>(), (uint64_t)nbl, sbase.as<uint64_t>(), d_tot + 1, st))) return rc;
+        if ((rc = scan_counts_u32(nx.as<uint32_t>(), (uint64_t)nbl, xbase.as<uint64_t>(), d_tot + 2, st))) return rc;
         FPX_HIP(hipGetLastError());
         FPX_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
         FPX_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof h_flags, hipMemcpyDeviceToHost, st));
@@ -1208,7 +1286,7 @@ int materialize_items(const Segment* s, uint64_t* items, hipStream_t st)
     if ((rc = cnt.alloc((size_t)DIRECT_NREC * 4)) || (rc = base.alloc((size_t)DIRECT_NREC * 8)) || (rc = tot.alloc(8))) return rc;
     hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->extras_shift, s->min_doc_id,
                        (const uint64_t*)nullptr, cnt.as<uint32_t>(), (uint64_t*)nullptr);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, cnt.as<uint32_t>(), (uint64_t)DIRECT_NREC, base.as<uint64_t>(), tot.as<uint64_t>());
+    if ((rc = scan_counts_u32(cnt.as<uint32_t>(), (uint64_t)DIRECT_NREC, base.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
     hipLaunchKernelGGL(k_direct_rec_items, dim3(DIRECT_NREC / 256), dim3(256), 0, st, s->d_drec, s->d_primary, s->d_extras, s->extras_shift, s->min_doc_id,
                        base.as<uint64_t>(), (uint32_t*)nullptr, items);
     FPX_HIP(hipGetLastError());
@@ -1299,8 +1377,8 @@ int segment_merge_device(Ctx* ctx, const std::vector<MergeSource>& srcs, uint32_
             if ((rc = counts.alloc((size_t)g->num_blocks * 4)) || (rc = boff.alloc((size_t)g->num_blocks * 8)) || (rc = tot.alloc(8))) return rc;
             hipLaunchKernelGGL(k_block_item_counts, dim3((g->num_blocks + 255) / 256), dim3(256), 0, st,
                                g->d_blocks, g->block_size, g->num_blocks, counts.as<uint32_t>());
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, counts.as<uint32_t>(), (uint64_t)g->num_blocks,
-                               boff.as<uint64_t>(), tot.as<uint64_t>());
+            if ((rc = scan_counts_u32(counts.as<uint32_t>(), (uint64_t)g->num_blocks,
+                               boff.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
             hipLaunchKernelGGL(k_decode_items, dim3((g->num_blocks + 3) / 4), dim3(256), 0, st,
                                g->d_blocks, g->block_size, g->num_blocks, g->min_doc_id, boff.as<uint64_t>(),
                                dead.as<uint32_t>(), nd, all.as<uint64_t>() + off, live.as<uint8_t>() + off);

@@ -5,6 +5,7 @@ worker threads) -- on distinct devices when hipGetDeviceCount() >= 2, otherwise 
 degenerates to a device-to-device copy; everything else -- per-context local snapshots with foreign segments as docs-only
 members, concurrent partial searches, gather, merge -- is the multi-GPU code path).  Results, and the reference's
 scanned_blocks / scanned_docs totals, must equal the unsharded snapshot's and the oracle's bit for bit."""
+import os
 import threading
 
 import numpy as np
@@ -105,6 +106,9 @@ def test_sharded_search_is_reentrant():
 def test_foreign_segment_in_a_plain_snapshot_is_docs_only():
     """fpx_snapshot_create: a segment resident on another context contributes its docs map (supersession) and no hits"""
     from fpx_testlib import fpx, oracle, Pair
+    if os.environ.get("FPX_VARIANT_CHILD") == "1":
+        pytest.skip("the window mode sets its contexts' options itself: the variants' switches do not reach it (and its `world` groups "
+                    "next to two other children's are the suite's peak of HBM)")
     ndev = _device_count()
     a, b = fpx.Context(0), fpx.Context(1 % ndev)
     H = 32

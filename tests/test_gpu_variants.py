@@ -65,13 +65,13 @@ def _run_variant(env):
 
 @pytest.fixture(scope="module")
 def variant_runs():
-    """every variant's child process, FOUR at a time (each is a minute of small batches that leaves the GPU mostly idle: one
+    """every variant's child process, THREE at a time (each is a minute of small batches that leaves the GPU mostly idle: one
     after the other they were 11 of the suite's 14 minutes); a test waits for its own"""
     import concurrent.futures as cf
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         yield {}
         return
-    with cf.ThreadPoolExecutor(int(os.environ.get("FPX_VARIANT_JOBS", "4"))) as pool:
+    with cf.ThreadPoolExecutor(int(os.environ.get("FPX_VARIANT_JOBS", "3"))) as pool:
         yield {_name(env): pool.submit(_run_variant, env) for env in VARIANTS}
 
 

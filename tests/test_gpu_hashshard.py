@@ -12,11 +12,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+def _rendezvous_file():
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="fpx_pg_")
+    os.close(fd)
+    os.unlink(path)                                     # (the file store creates it)
+    return "file://" + path
 
 
 def _world_data(fpx, rng, S, per, H, seed):
@@ -238,9 +239,8 @@ def test_hash_sharded_reader_over_one_rank_group(monkeypatch):
     for s, (items, lo, hi, ids, alive) in enumerate(_world_data(fpx, rng, 2, 4000, 48, 77)):
         p.add_file(items, lo, hi, s + 1, ids, alive)
     p.finish()
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(_free_port())              # (test_gpu_variants.py runs several of these processes at a time)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    # (a rendezvous FILE, not a port: test_gpu_variants.py runs several of these processes at a time)
+    dist.init_process_group("nccl", init_method=_rendezvous_file(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         sh = fpx.sharding.HashShardedReader(fpx, ctx, p.reader, dist, 1)
         flat, off, _ = fpx.synth.make_queries(77, 3, 70, 8000, 48, query_len=200, dist=1)
@@ -268,9 +268,7 @@ def test_routed_sharded_reader_over_one_rank_group(monkeypatch):
     for s, (items, lo, hi, ids, alive) in enumerate(_world_data(fpx, rng, 2, 4000, 48, 78)):
         p.add_file(items, lo, hi, s + 1, ids, alive)
     p.finish()
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(_free_port())
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", init_method=_rendezvous_file(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         sh = fpx.sharding.RoutedShardedReader(fpx, ctx, p.reader, dist, 1)
         sh.key_cap, sh.cell_cap = 32, 16

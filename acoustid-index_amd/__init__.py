@@ -3,7 +3,7 @@
 Only the /_search hot path of acoustid/acoustid-index lives here:
 csrc/ holds the HIP kernels and the C ABI (include/fpx.h), this package is the host-side
 mirror of the reference's search interface."""
-from ._lib import FpxError, SearchTimeout, Stats, lib, LIB_PATH  # noqa: F401
+from ._lib import FpxError, ScanHistograms, SearchTimeout, Stats, lib, LIB_PATH  # noqa: F401
 from .index import (Context, FileSegment, IndexReader, MemorySegment, RemoteSegment, SearchOptions,  # noqa: F401
                     SearchResults, Segments, http_options, QueryBatch, search_resident, search_resident_partial,
                     merge_partials, results_to_lists, build_memory_segment, probe_resident, score_partial,

@@ -46,6 +46,34 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class ScanHistograms(C.Structure):
+    """fpx_scan_histograms: the reference's fpindex_scanned_docs_per_hash / fpindex_scanned_blocks_per_hash (src/metrics.zig:9-10),
+    buckets NOT cumulative, the last slot of each = above the last bound (+Inf)."""
+    _fields_ = [("docs_bucket", C.c_uint64 * 10), ("blocks_bucket", C.c_uint64 * 6),
+                ("docs_sum", C.c_uint64), ("blocks_sum", C.c_uint64), ("count", C.c_uint64)]
+    DOCS_BOUNDS = (1, 2, 3, 5, 10, 50, 100, 500, 1000)
+    BLOCKS_BOUNDS = (1, 2, 3, 5, 10)
+
+    def as_dict(self):
+        return {"docs_bucket": list(self.docs_bucket), "blocks_bucket": list(self.blocks_bucket),
+                "docs_sum": int(self.docs_sum), "blocks_sum": int(self.blocks_sum), "count": int(self.count)}
+
+    def prometheus(self):
+        """the two histograms in the text exposition format, as metrics.zig writes them (cumulative `le` buckets, _sum, _count)"""
+        lines = []
+        for name, bounds, buckets, total in (("fpindex_scanned_docs_per_hash", self.DOCS_BOUNDS, self.docs_bucket, self.docs_sum),
+                                             ("fpindex_scanned_blocks_per_hash", self.BLOCKS_BOUNDS, self.blocks_bucket, self.blocks_sum)):
+            lines.append(f"# TYPE {name} histogram")
+            run = 0
+            for b, n in zip(bounds, buckets):
+                run += int(n)
+                lines.append(f'{name}_bucket{{le="{b}"}} {run}')
+            lines.append(f'{name}_bucket{{le="+Inf"}} {int(self.count)}')
+            lines.append(f"{name}_sum {int(total)}")
+            lines.append(f"{name}_count {int(self.count)}")
+        return "\n".join(lines) + "\n"
+
+
 # every symbol include/fpx.h declares: name -> (restype, argtypes)
 _vp, _u32, _u64, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
 SIGNATURES = {
@@ -89,6 +117,7 @@ SIGNATURES = {
     "fpx_search": (C.c_int, [_vp, _vp, _u32, C.POINTER(Opts), _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(Stats)]),
     "fpx_search_batch": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_search_batch_stats": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats), _vp, _vp]),
+    "fpx_scan_histograms_observe": (C.c_int, [_vp, _vp, _vp, _u32, _u32, C.POINTER(ScanHistograms)]),
     "fpx_search_batch_partial": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_query_batch_create": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(_vp)]),
     "fpx_query_batch_release": (None, [_vp]),

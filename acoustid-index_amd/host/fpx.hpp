@@ -257,6 +257,21 @@ public:
             results[q].stats.scanned_docs = qd[q];
         }
     }
+
+    // metrics.observeScannedDocsPerHash / observeScannedBlocksPerHash (src/FileSegment.zig:177-178; buckets src/metrics.zig:9-10)
+    // for a SAMPLE of queries: every unique hash of every query replayed against every file segment of the snapshot on its own;
+    // the observations are added to `acc` (the process's running histograms)
+    void observeScanHistograms(const std::vector<std::vector<uint32_t>>& queries, fpx_scan_histograms& acc, uint32_t timeout_ms = 0) const
+    {
+        std::vector<uint64_t> offsets(queries.size() + 1, 0);
+        std::vector<uint32_t> flat;
+        for (size_t q = 0; q < queries.size(); ++q) {
+            flat.insert(flat.end(), queries[q].begin(), queries[q].end());
+            offsets[q + 1] = flat.size();
+        }
+        if (flat.empty()) flat.push_back(0);
+        check(fpx_scan_histograms_observe(snapshot_.handle(), flat.data(), offsets.data(), (uint32_t)queries.size(), timeout_ms, &acc));
+    }
 private:
     Segments snapshot_;
 };

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import Opts, Result, Stats, check, lib
+from ._lib import Opts, Result, ScanHistograms, Stats, check, lib
 
 
 @dataclass
@@ -485,6 +485,16 @@ class IndexReader:
                                            _p(out), cap, _p(out_n), C.byref(st), _p(qb), _p(qd)))
         res = [[(int(out[q, i, 0]), int(out[q, i, 1])) for i in range(out_n[q])] for q in range(B)]
         return res, st, qb[:B], qd[:B]
+
+    def observe_scan_histograms(self, queries, acc: ScanHistograms = None, timeout_ms=0):
+        """fpx_scan_histograms_observe: the reference's two per-(hash, segment) histograms (src/FileSegment.zig:177-178, buckets of
+        src/metrics.zig:9-10) for a SAMPLE of queries -- every unique hash of every query replayed against every file segment of
+        the snapshot on its own.  The observations are added to `acc` (a new ScanHistograms when None), which is returned."""
+        if acc is None:
+            acc = ScanHistograms()
+        flat_h, offsets = _flatten(queries)
+        check(lib().fpx_scan_histograms_observe(self.snapshot.h, _p(flat_h), _p(offsets), len(queries), timeout_ms, C.byref(acc)))
+        return acc
 
     def search_batch_raw(self, flat_h, offsets, copts, cap, timeout_ms=0, out=None, out_n=None):
         """Same call with pre-built numpy/ctypes buffers (used by bench.py's timed loop)."""

@@ -221,6 +221,31 @@ int fpx_search_batch_stats(fpx_snapshot *snap, const uint32_t *hashes, const uin
                            fpx_result *out, uint32_t out_cap, uint32_t *out_n, fpx_stats *stats,
                            uint64_t *scanned_blocks_q, uint64_t *scanned_docs_q);
 
+/* The reference's two per-(hash, segment) HISTOGRAMS, fed from a sample of the traffic.
+ * Replaces: metrics.observeScannedDocsPerHash(num_docs) / observeScannedBlocksPerHash(num_blocks) at the end of every hash's
+ * walk in FileSegment.search (src/FileSegment.zig:177-178), i.e. fpindex_scanned_docs_per_hash / fpindex_scanned_blocks_per_hash
+ * with the bucket bounds of src/metrics.zig:9-10.  fpx_search_batch_stats gives the SUMS of those observations per query (exact
+ * `_sum`); the buckets need every observation on its own, and the probe kernels answer a hash for sixteen segments at once.
+ * This call REPLAYS the queries it is given for the statistics alone: every query is sorted and de-duplicated as
+ * IndexReader.search does (src/Index.zig:170-172), and every unique hash is searched as a query of its own against each FILE
+ * segment of the snapshot that is resident on the snapshot's context, alone (a one-segment snapshot: a column of a group with
+ * the others masked out, a block-form segment in its blocks) -- so that the per-query statistics of fpx_search_batch_stats ARE
+ * the (num_blocks, num_docs) the reference observes for that (hash, segment).  A hash-window slice observes the hashes of its
+ * window only (the others are another rank's).  Memory segments observe nothing (src/MemorySegment.zig:44-54 has no metrics).
+ * Meant for a sample -- one request in a few hundred --: the replay costs about as much as searching the queries once per
+ * segment.  The observations are ADDED to *acc (zero it first, or keep it as the process's running histogram):
+ *   docs_bucket[i]   observations v with bound[i-1] < v <= bound[i], bounds 1 2 3 5 10 50 100 500 1000, [9] = above 1000 (+Inf)
+ *   blocks_bucket[i] bounds 1 2 3 5 10, [5] = above 10 (+Inf; the reference visits at most 4 blocks per hash)
+ *   docs_sum / blocks_sum / count   the histograms' `_sum` and `_count` (count: the same for both)
+ * Buckets are NOT cumulative; a Prometheus exporter adds them up. */
+typedef struct {
+    uint64_t docs_bucket[10];
+    uint64_t blocks_bucket[6];
+    uint64_t docs_sum, blocks_sum, count;
+} fpx_scan_histograms;
+int fpx_scan_histograms_observe(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets, uint32_t num_queries,
+                                uint32_t timeout_ms, fpx_scan_histograms *acc);
+
 /* Query batch already resident in HBM: what a host-side coalescer that keeps its staging buffers on the
  * device would hand over, and what bench.py times ("inputs resident in HBM when the timed region starts").
  * fpx_search_resident(snap, qb, ...) == fpx_search_batch(snap, <the arrays qb was created from>, ...). */

@@ -18,6 +18,14 @@ for so in acoustid-index_amd/build/exp/libfpx_*.so; do
   FPX_LIB=$R/$so timeout 600 python tools/probe_ab.py $STEPS > $O/$n.json 2> $O/$n.err
 done
 timeout 600 python tools/probe_ab.py $STEPS > $O/product_again.json 2> $O/product_again.err      # (the box's drift over the call)
+# ... and the block form (FPX_DIRECT=0: k_probe_lean8) for the libraries that change that kernel
+if ls acoustid-index_amd/build/exp/libfpx_*lean*.so > /dev/null 2>&1; then
+  FPX_DIRECT=0 timeout 600 python tools/probe_ab.py 10 > $O/blockform_product.json 2> $O/blockform_product.err
+  for so in acoustid-index_amd/build/exp/libfpx_*lean*.so; do
+    n=$(basename $so .so)
+    FPX_DIRECT=0 FPX_LIB=$R/$so timeout 600 python tools/probe_ab.py 10 > $O/blockform_$n.json 2> $O/blockform_$n.err
+  done
+fi
 python3 - <<PY
 import glob, json, os
 rows = []
@@ -28,9 +36,10 @@ for f in sorted(glob.glob("$O/*.json")):
     except Exception as e:
         rows.append((os.path.basename(f)[:-5], None, None, None, repr(e)))
 base = next((r[1] for r in rows if r[0] == "product"), None)
+base_b = next((r[1] for r in rows if r[0] == "blockform_product"), None)
 with open("$O/summary.txt", "w") as out:
     for r in rows:
-        line = f"{r[0]:90s} probe median {r[1]} min {r[2]} step {r[3]} found {r[4]}" + (f"  x{r[1] / base:.3f}" if base and r[1] else "")
+        line = f"{r[0]:90s} probe median {r[1]} min {r[2]} step {r[3]} found {r[4]}" + (f"  x{r[1] / (base_b if r[0].startswith('blockform_') else base):.3f}" if r[1] and (base_b if r[0].startswith('blockform_') else base) else "")
         print(line); out.write(line + "\n")
 PY
 for so in ${FPX_AB_PARITY:-}; do

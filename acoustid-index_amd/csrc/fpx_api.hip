@@ -294,10 +294,14 @@ int regroup_segments(Ctx* c, const std::vector<Segment*>& segs, uint32_t* regrou
     uint64_t need = (size_t)3 << 30, most_items = 0;
     for (const Segment* s : m) if (s->home) { need += s->blocks_len + 16; most_items = std::max<uint64_t>(most_items, s->num_items); }
     need += most_items * 8;
+    // ... and for the new group itself, next to the old ones (snapshots may be reading them): asked for BEFORE the members' blocks are
+    // encoded again -- the 100 M index (147 GB packed) cannot be rebuilt next to itself on one GPU, and finding that out used to cost
+    // seconds of encoding and ~50 GB of blocks on every merge
+    need += group_bytes_lower_bound(c, m.data(), (uint32_t)m.size());
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
         (void)hipGetLastError();
-        set_error("not enough free HBM to rebuild the group of %zu segments (%.1f GB for their blocks, %.1f free)", m.size(), need / 1e9, free_b / 1e9);
+        set_error("not enough free HBM to rebuild the group of %zu segments (%.1f GB for their blocks and the new group, %.1f free)", m.size(), need / 1e9, free_b / 1e9);
         return FPX_E_NOMEM;
     }
     struct Old { std::shared_ptr<Group> home; uint32_t col; const char* why; uint64_t device_bytes; };

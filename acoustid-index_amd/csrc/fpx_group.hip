@@ -435,6 +435,32 @@ __global__ void k_chunk_blocks(const uint32_t* __restrict__ block_index, uint32_
     out[4 * i + 3] = (b0 > 0 && b0 < nb) ? block_index[b0 - 1] : 0u;
 }
 
+// What a group of these segments takes at least: its lines + a share per item for lists / overflow words (the same figures
+// group_segments decides by).  regroup_segments adds it to the room it asks for BEFORE it encodes the members' blocks again.
+uint64_t group_bytes_lower_bound(const Ctx* ctx, Segment* const* segs, uint32_t k)
+{
+    if (k == 0) return 0;
+    const uint32_t ns = k <= 8u ? 8u : 16u, hvl = ns == 16u ? 2u : 3u;
+    uint32_t win_lo = 0u, win_hi = 0xFFFFFFFFu;
+    if (segs[0]->own_flags & 1u) win_lo = segs[0]->own_lo + 1u;
+    if (segs[0]->own_flags & 2u) win_hi = segs[0]->own_hi;
+    if (win_lo > win_hi) return 0;
+    uint64_t items_total = 0;
+    uint32_t gmin = 0xFFFFFFFFu, gmax = 0u;
+    for (uint32_t j = 0; j < k; ++j) { items_total += segs[j]->num_items; gmin = std::min(gmin, segs[j]->min_doc_id); gmax = std::max(gmax, segs[j]->max_doc_id); }
+    const double win_frac = ((double)win_hi - (double)win_lo + 1.0) / 4294967296.0;
+    const double per_line = (double)items_total / (4294967296.0 * (segs[0]->own_flags ? win_frac : 1.0)) * (double)(1u << hvl);
+    const int packed_forced = ctx_group_packed(ctx);
+    const bool span_ok = gmax >= gmin && (uint64_t)gmax - gmin < 0x7FFFFFF0ull;
+    const bool packed = span_ok && (packed_forced >= 0 ? packed_forced != 0 : per_line >= 6.0);
+    const uint64_t chunk_lines = packed ? (1ull << (GROUP_CHUNK_LOG2 - hvl)) : (1ull << 21);
+    const uint64_t line_words = packed ? GROUP_LINE_WORDS : 2u * ns;
+    const uint64_t nchunks = (uint64_t)(win_hi >> 26) - (win_lo >> 26) + 1u;
+    uint64_t need = nchunks * chunk_lines * line_words * 4ull;
+    for (uint32_t j = 0; j < k; ++j) need += (uint64_t)((double)segs[j]->num_items * (packed ? 0.4 : 4.0) * ((double)nchunks / 64.0));
+    return need;
+}
+
 // Moves k segments of one context into a new group: direct-addressed ones on their own (their arrays are read) and ones still
 // in blocks that direct_candidate() accepted (their pieces are built chunk by chunk of the hash space from the blocks, so a
 // 100-GB index never needs a second copy of itself in HBM).  On success every segment's postings live in the group
@@ -481,10 +507,9 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     const uint32_t line_words = packed ? GROUP_LINE_WORDS : 2u * ns;
     const uint32_t c_first = win_lo >> 26, c_last = win_hi >> 26, nchunks = c_last - c_first + 1u;
     const uint64_t nlines = (uint64_t)nchunks * CHUNK_LINES;
-    uint64_t need = nlines * line_words * 4ull;
     // (a lower bound of what the group will take; running out of HBM half way is noticed chunk by chunk and leaves the
     // segments as they are)
-    for (uint32_t j = 0; j < k; ++j) need += (uint64_t)((double)segs[j]->num_items * (packed ? 0.4 : 4.0) * ((double)nchunks / 64.0));
+    const uint64_t need = group_bytes_lower_bound(ctx, segs, k);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)3 << 30)) {
         (void)hipGetLastError();

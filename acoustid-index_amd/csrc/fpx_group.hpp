@@ -427,10 +427,22 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
             __syncthreads();
         }
     }
-    if (my_reads) atomicAdd(&wg_reads, (unsigned long long)my_reads);
-    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
-    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
-    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    // (x8: the lanes' statistics summed per wave on the DPP crossbar, added by one lane -- experiments/README.md: four atomicAdds of a
+    // lane's own value on one LDS address each are four serial 64-lane loops in the compiled kernel)
+    {
+        auto wave_total = [&](uint32_t v) -> unsigned long long {
+            const uint32_t incl = scan16(v);                                         // (the whole wave is here)
+            return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)incl, 15) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31) +
+                   (uint32_t)__builtin_amdgcn_readlane((int)incl, 47) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        };
+        const unsigned long long w_reads = wave_total(my_reads), w_blocks = wave_total(my_blocks), w_docs = wave_total(my_docs), w_probes = wave_total(my_probes);
+        if ((threadIdx.x & 63u) == 0u) {
+            if (w_reads) atomicAdd(&wg_reads, w_reads);
+            if (w_blocks) atomicAdd(&wg_blocks, w_blocks);
+            if (w_docs) atomicAdd(&wg_docs, w_docs);
+            if (w_probes) atomicAdd(&wg_probes, w_probes);
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         if (a.lean_stats) {

@@ -350,6 +350,7 @@ int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uin
                        uint64_t* d_records, uint64_t records_cap, uint64_t* counts, fpx_stats* stats);
 int score_records_impl(Ctx* ctx, const QueryBatch* qb, const uint64_t* d_records, uint64_t num_records, uint32_t timeout_ms,
                        fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n);
+uint64_t group_bytes_lower_bound(const Ctx* ctx, Segment* const* segs, uint32_t k);
 int shard_bins_per_rank(uint32_t B, uint32_t world);
 int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
                      uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats);

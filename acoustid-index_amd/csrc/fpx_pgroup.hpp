@@ -65,10 +65,12 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
     // per column, indexed by a lane's own column number; per chunk of the hash space: where its `ext` starts
     __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
+    __shared__ uint32_t s_first[FUSE_MAX], s_last[FUSE_MAX];      // (x1: the columns' hash ranges, read only where a hash lies outside [lo_all, hi_all])
     __shared__ const uint32_t* s_ext[GROUP_CHUNKS];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const GroupDesc* g = &ga.g;
+    if (tid < FUSE_MAX) { s_first[tid] = g->first_hash[tid]; s_last[tid] = g->last_hash[tid]; }
     if (tid < FUSE_MAX) { s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
     if (tid < GROUP_CHUNKS) s_ext[tid] = tid < g->nchunks ? g->ext_tab[tid] : nullptr;
     if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid / GB_SLOTS][tid % GB_SLOTS] = 0u; s_bid[tid / GB_SLOTS][tid % GB_SLOTS] = GB_EMPTY; }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         if (h < g->lo_all || h > g->hi_all) {
             inr = 0u;
 #pragma unroll
-            for (uint32_t s = 0; s < NS; ++s) inr |= (h >= g->first_hash[s] && h <= g->last_hash[s]) ? (1u << s) : 0u;
+            for (uint32_t s = 0; s < NS; ++s) inr |= (h >= s_first[s] && h <= s_last[s]) ? (1u << s) : 0u;
         }
         if (!valid) inr = 0u;
         my_blocks += (uint32_t)__popc(inr & active & ~pm);         // absent: the reference visits one block, finds nothing and stops
@@ -246,10 +248,31 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         //      every wave ~480 issue slots per round; the fallback now sits behind one test.)
         const uint32_t par = round & 1u;
         const uint32_t qhi = (uint32_t)(qpart >> 32);
-        auto emit = [&](uint32_t km, uint32_t xk) {
+        // (x5: the stage reservation.  atomicAdd(hs.count, cnt) with a lane's own cnt is rewritten by the compiler's atomic optimiser
+        // into ONE atomic per wave -- and, in its default strategy, a SERIAL loop over the wave's active lanes to find every lane's
+        // offset: s_ff1 / v_readlane / v_writelane / s_add / ... x 64 lanes = ~570 instructions per wave and round.  Where the
+        // whole wave is here (`whole`: the call at the loop's top level) the offsets come from a scan on the DPP crossbar instead:
+        // four row_shr adds, the four rows' totals read by lane number, one atomic by lane 0.)
+        auto emit = [&](uint32_t km, uint32_t xk, bool whole) {
             const uint32_t nk = (uint32_t)__popc(km), cnt = nk + (uint32_t)__popc(xk);
-            if (cnt == 0u) return;
-            const uint32_t pos = atomicAdd(hs.count, cnt);
+            uint32_t pos;
+            if (whole) {
+                const uint32_t incl = scan16(cnt);                                   // inclusive, inside each row of 16 lanes
+                const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31),
+                               r2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47), r3 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t total = r0 + r1 + r2 + r3;
+                if (total == 0u) return;                                             // (wave-uniform)
+                const uint32_t row = lane >> 4;
+                const uint32_t before = (row >= 1u ? r0 : 0u) + (row >= 2u ? r1 : 0u) + (row >= 3u ? r2 : 0u);
+                uint32_t wbase = 0;
+                if (lane == 0u) wbase = atomicAdd(hs.count, total);
+                wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                if (cnt == 0u) return;
+                pos = wbase + before + (incl - cnt);
+            } else {
+                if (cnt == 0u) return;
+                pos = atomicAdd(hs.count, cnt);
+            }
             if (pos + cnt <= FSTAGE_CAP) {
                 uint32_t hi0 = qhi, hstep = 0;                // the records' upper words: hi0 + hstep * (records of the lane before it)
                 if constexpr (BINNED) {
@@ -293,14 +316,14 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         uint32_t xkeep = 0;
         if (n_esc != 0u) { xkeep = list_head(list_word(lmask), esc_col); add_blocks += xblk; add_docs += xeff; }
         const uint32_t xeff1 = xeff, xin1 = xin;             // (of the FIRST list: what the wave's turn, if there is one, continues from)
-        emit(keep, xkeep);
+        emit(keep, xkeep, true);
         // what is left for the whole wave: words beyond the lane's own, a third list, a list longer than its head
         bool more = nwords > mine_w || n_esc > 2u || (n_esc != 0u && xeff1 > xin1);
         // a SECOND list (one hash in two hundred): its head too, unless the wave has to come anyway
         if (!more && n_esc == 2u) {
             const uint32_t yk = list_head(list_word(lmask & (lmask - 1u)), esc_col2);
             if (xeff > xin) more = true;                     // (longer than seven docs: the wave walks it from its start, and counts it)
-            else { add_blocks += xblk; add_docs += xeff; emit(0u, yk); }
+            else { add_blocks += xblk; add_docs += xeff; emit(0u, yk, false); }
         }
         my_blocks += add_blocks; my_docs += add_docs;
         if (QS && GQSTATS(a) && valid && (my_blocks != blocks_before || my_docs != docs_before))
@@ -444,9 +467,14 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             // hash's words beyond the lane's twelve; a clash of two bins on one slot) first, then one reservation per bin
             __syncthreads();
             const uint32_t sc = min(stage_count, stage_valid);
+            // (x4: the flush's stage index is opaque to the optimiser here, so that &stage[tid] is computed where it is used -- one add --
+            // instead of being kept across the whole round loop in a register the allocator then spills to scratch: two scratch loads
+            // per round, right behind the flush's barriers)
+            uint32_t ft = tid;
+            asm volatile("" : "+v"(ft));
             bool unplaced = false;
             const uint32_t qlm = (1u << a.bin_shift) - 1u;
-            for (uint32_t i = tid; i < sc; i += FK_WG) {
+            for (uint32_t i = ft; i < sc; i += FK_WG) {
                 const uint64_t rec = stage[i];
                 if ((uint32_t)(rec >> 32) & PK_RANKED) continue;
                 const uint32_t b = gb_cell(a, rec), sl = gb_slot(a, rec);
@@ -466,7 +494,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                 }
             }
             __syncthreads();
-            for (uint32_t i = tid; i < sc; i += FK_WG) {
+            for (uint32_t i = ft; i < sc; i += FK_WG) {
                 const uint64_t rec = stage[i];
                 const uint32_t hi = (uint32_t)(rec >> 32);
                 if (hi & PK_RANKED) {
@@ -485,10 +513,23 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             __syncthreads();
         }
     }
-    if (my_reads) atomicAdd(&wg_reads, (unsigned long long)my_reads);
-    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
-    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
-    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    // (x6: the lanes' statistics are summed per wave on the DPP crossbar and added by ONE lane.  Four atomicAdds of a lane's own value
+    // on one LDS address each became, in the compiler's atomic optimiser, four serial loops over the wave's 64 lanes -- s_ff1 /
+    // v_readlane x 2 / s_add / s_addc / ... : ~2 300 instructions per wave at the end of every workgroup.)
+    {
+        auto wave_total = [&](uint32_t v) -> unsigned long long {
+            const uint32_t incl = scan16(v);                                         // (the whole wave is here: the round loop's trip count is uniform)
+            return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)incl, 15) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31) +
+                   (uint32_t)__builtin_amdgcn_readlane((int)incl, 47) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        };
+        const unsigned long long w_reads = wave_total(my_reads), w_blocks = wave_total(my_blocks), w_docs = wave_total(my_docs), w_probes = wave_total(my_probes);
+        if (lane == 0u) {
+            if (w_reads) atomicAdd(&wg_reads, w_reads);
+            if (w_blocks) atomicAdd(&wg_blocks, w_blocks);
+            if (w_docs) atomicAdd(&wg_docs, w_docs);
+            if (w_probes) atomicAdd(&wg_probes, w_probes);
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         if (a.lean_stats) {

@@ -514,11 +514,24 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         }
     }
 
-    if (my_blocks >> 16) atomicAdd(&wg_reads, (unsigned long long)(my_blocks >> 16));      // late docid lines (one per run beyond byte 256)
-    my_blocks &= 0xFFFFu;
-    if (my_blocks) atomicAdd(&wg_blocks, (unsigned long long)my_blocks);
-    if (my_docs) atomicAdd(&wg_docs, (unsigned long long)my_docs);
-    if (my_probes) atomicAdd(&wg_probes, (unsigned long long)my_probes);
+    // (x7: the lanes' statistics summed per wave on the DPP crossbar, added by one lane -- see experiments/README.md: four atomicAdds of
+    // a lane's own value on one LDS address each are four serial 64-lane loops in the compiled kernel)
+    {
+        auto wave_total = [&](uint32_t v) -> unsigned long long {
+            const uint32_t incl = scan16(v);                                         // (the whole wave is here: the round loop's trip count is uniform)
+            return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)incl, 15) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31) +
+                   (uint32_t)__builtin_amdgcn_readlane((int)incl, 47) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        };
+        const unsigned long long w_late = wave_total(my_blocks >> 16);             // late docid lines (one per run beyond byte 256)
+        my_blocks &= 0xFFFFu;
+        const unsigned long long w_blocks = wave_total(my_blocks), w_docs = wave_total(my_docs), w_probes = wave_total(my_probes);
+        if ((tid & 63u) == 0u) {
+            if (w_late) atomicAdd(&wg_reads, w_late);
+            if (w_blocks) atomicAdd(&wg_blocks, w_blocks);
+            if (w_docs) atomicAdd(&wg_docs, w_docs);
+            if (w_probes) atomicAdd(&wg_probes, w_probes);
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         unsigned long long* st = a.lean_stats + (size_t)(blockIdx.x % LEAN_STAT_SETS) * 8u;     // see LEAN_STAT_SETS

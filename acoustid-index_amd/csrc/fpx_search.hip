@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <thread>
 #include <type_traits>
+#include <vector>
 
 #include "fpx_internal.h"
 
@@ -1895,7 +1896,25 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ra
     if (first_query) *first_query = q_lo;
     if (num_queries) *num_queries = q_hi - q_lo;
     if (B_global && qb->B != q_hi - q_lo) { set_error("fpx_shard_score_share: the share holds %u queries, rank %u of %u finishes %u", qb->B, rank, world, q_hi - q_lo); return FPX_E_INVAL; }
-    if (q_hi == q_lo) return FPX_OK;
+    if (q_hi == q_lo) {
+        // A rank that finishes no query of the batch (fewer bins than ranks: B = 1 or 72 at a world of 8) still takes part in the step's
+        // exchanges, and a sender whose bins outgrew the step's size marked EVERY count it sent: this rank must see the mark and return
+        // FPX_E_AGAIN with the others (they re-enter the collectives of the redo -- fpx.h, fpx_shard_score).
+        const size_t ncounts = (size_t)world * bpr;
+        if (d_recv_counts && ncounts) {
+            FPX_HIP(hipSetDevice(ctx->device));
+            std::vector<uint32_t> h(ncounts);
+            FPX_HIP(hipMemcpy(h.data(), d_recv_counts, ncounts * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint64_t need = 0;
+            for (uint32_t c : h) if (((uint64_t)c & 0x7FFFFFFFull) >= SHARD_NEED_MARK) need = std::max<uint64_t>(need, (uint64_t)c & (SHARD_NEED_MARK - 1u));
+            if (need) {
+                if (needed_cell_cap) *needed_cell_cap = need;
+                set_error("fpx_shard_score: a sender's bins need %llu cells, the exchange ran with %llu: redo the step", (unsigned long long)need, (unsigned long long)cell_cap);
+                return FPX_E_AGAIN;
+            }
+        }
+        return FPX_OK;
+    }
     // the options by BATCH query number (the kernels index them so): a share's array starts at the rank's first query
     const uint32_t* d_opts_b = B_global ? qb->d_opts - (size_t)q_lo * 4 : qb->d_opts;
     const uint32_t nq = q_hi - q_lo;

@@ -240,11 +240,18 @@ class HashShardedReader:
                 if not need:
                     raise
                 self._rec = torch.empty((need,), dtype=torch.int64, device=self.device)
-        got = exchange_records(self.dist, self._rec, counts, self.world)
+        if self.host_staged:
+            got = exchange_records(self.dist, self._rec[:int(sum(int(c) for c in counts))].cpu(), counts, self.world).to(self.device)
+        else:
+            got = exchange_records(self.dist, self._rec, counts, self.world)
         torch.cuda.current_stream(self.device).synchronize()
         d_part, d_cnt = self._tables(qb)
         fpx.score_partial(self.ctx, qb, got.data_ptr(), got.numel(), d_part.data_ptr(), d_cnt.data_ptr())
-        tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
+        if self.host_staged:
+            tables, cnts = gather_tables(self.dist, d_part.cpu(), d_cnt.cpu(), self.world)
+            tables, cnts = tables.to(self.device), cnts.to(self.device)
+        else:
+            tables, cnts = gather_tables(self.dist, d_part, d_cnt, self.world)
         torch.cuda.current_stream(self.device).synchronize()
         out, out_n = fpx.merge_partials(self.ctx, qb, tables.data_ptr(), cnts.data_ptr(), self.world, out, out_n)
         return out, out_n, st
@@ -279,6 +286,7 @@ class RoutedShardedReader:
         self.host_staged = host_staged
         self.device = torch.device("cuda", ctx.device)
         self.key_cap = 0
+        self._key_cap_agreed = False      # the ranks' first guesses differ (each only knows its own share): agreed once, in exchange_keys
         self.cell_cap = 0
         self._k = self._b = None
         self.last_stats = None
@@ -328,9 +336,24 @@ class RoutedShardedReader:
         self.dist.all_to_all_single(r.view(-1), send.view(-1))
         return r
 
+    def _agree_key_cap(self):
+        """The all-to-all of the key slots has ONE shape on every rank, and a rank's first guess comes from its own share (shares
+        differ: variable query lengths, a last rank with fewer queries).  One all-reduce(MAX) of (guess, need) the first time --
+        afterwards the size only changes through marked counts, which every rank sees alike."""
+        import torch
+        t = torch.tensor([int(self.key_cap), int(self.key_need)], dtype=torch.int64, device="cpu" if self.host_staged else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        cap = int(t.max().item())
+        if cap != self.key_cap or self.key_need:
+            self.key_cap = cap
+            self.keys(self.share, self.B)
+        self._key_cap_agreed = True
+
     def exchange_keys(self):
         import torch
         fpx = self.fpx
+        if not self._key_cap_agreed:
+            self._agree_key_cap()
         for attempt in range(4):
             keys, kcnt = self._key_bufs()
             self.recv_keys, self.recv_kcnt = self._a2a(keys), self._a2a(kcnt)

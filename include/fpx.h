@@ -92,7 +92,8 @@ int  fpx_ctx_create(int device, fpx_ctx **out);
 void fpx_ctx_destroy(fpx_ctx *ctx);
 int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context lives on */
 /* How a context keeps its file segments in HBM.  Options (each falls back to the environment variable FPX_<NAME>, then to the
- * default; value -1 = back to that fallback):
+ * default; a value below -1 = back to that fallback -- and so does -1 for every option but "group_packed", where -1 is the explicit
+ * setting "by density", environment or not):
  *   "direct"            1 | 0   dense segments trade their blocks for a direct-addressed form (default 1)
  *   "direct_min_items"  items from which a segment counts as dense (default 2^20)
  *   "fuse_min"          direct-addressed segments of one hash window that form a GROUP together: this many or more (default 2; 0: never)

@@ -54,3 +54,12 @@ def orc():
     oracle.build()
     oracle.lib()
     return oracle
+
+
+@pytest.fixture(autouse=True)
+def _collect_after_test():
+    """Segments, groups and snapshots are released by their Python owners' finalisers: a test's index caught in a reference cycle
+    would hold its HBM (a packed group: 69 - 137 GB) into the next test.  Collect after every test."""
+    yield
+    import gc
+    gc.collect()

@@ -121,72 +121,169 @@ def _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, nq,
     del osnap, osegs, keep
 
 
-def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192():
-    """configs[2] (one GPU) and configs[3] (segments sharded over 8 ranks, here 8 snapshots on one GPU)."""
-    import torch
-    from fpx_testlib import fpx, oracle
-    ctx = fpx.Context(0)
-    H, S, B, L, limit = 256, 16, 8192, 1000, 40
-    segs, per, docs = _build(fpx, ctx, 100_000_000, H, S)
-    import os
-    if os.environ.get("FPX_ALLOW_SHRINK") != "1":
-        assert docs == 100_000_000
-    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
-    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
-    opts = fpx.http_options(limit=limit)
-    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
-    out, out_n, st = fpx.search_resident(reader, qb)
-    out, out_n = out.copy(), out_n.copy()
-    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
-    assert st.probes == _unique_per_query(flat, offsets) * S
-    assert st.algorithmic_bytes == st.scanned_blocks * 512 and st.scanned_blocks >= st.probes * 0.97
-    assert st.hits >= int(out[:, 0, 1].astype(np.int64).sum())
-    # idempotence
-    out2, out_n2, st2 = fpx.search_resident(reader, qb)
-    assert (out_n2 == out_n).all() and (out2 == out).all()
-    assert (st2.scanned_blocks, st2.scanned_docs, st2.hits) == (st.scanned_blocks, st.scanned_docs, st.hits)
-    # in-kernel deadline (the reference cancels at zio.maybeYield, src/FileSegment.zig:144 -> error.SearchTimeout,
-    # src/MultiIndex.zig:314-322): a 1-ms deadline on a ~4-ms batch comes back as a timeout LONG before the batch would
-    # have finished, with no results, and the workspace is fine afterwards
-    # (the batch of 8192 itself is over in about a millisecond by now: the deadline test runs the batch four times over, ~4 ms)
-    import time
-    off4 = np.concatenate([offsets[:-1].astype(np.uint64) + np.uint64(k * len(flat)) for k in range(4)] + [np.array([4 * len(flat)], np.uint64)])
-    qb4 = fpx.QueryBatch(ctx, options=opts, flat=(np.tile(flat, 4), off4))
-    for _ in range(3):                                      # (a workspace's first batches of a new size take the general path and size the buffers)
-        fpx.search_resident(reader, qb4)
-    t0 = time.perf_counter()
-    o4, n4, _ = fpx.search_resident(reader, qb4)
-    t_full = time.perf_counter() - t0
-    assert (n4[:B] == out_n).all() and (o4[:B] == out).all() and (n4[3 * B:] == out_n).all()
-    t0 = time.perf_counter()
-    with pytest.raises(fpx.SearchTimeout):
-        fpx.search_resident(reader, qb4, timeout_ms=1)
-    t_cancel = time.perf_counter() - t0
-    assert t_cancel < max(0.003, 0.75 * t_full), (t_cancel, t_full)
-    qb4.release()
-    out3, out_n3, _ = fpx.search_resident(reader, qb, timeout_ms=10_000)       # a generous deadline changes nothing
-    assert (out_n3 == out_n).all() and (out3 == out).all()
-    # configs[3]: 8 ranks, two segments each + docs-only stand-ins for the others; tables merged as after an all-gather
-    world, cap = 8, qb.cap
-    remotes = [fpx.RemoteSegment(ctx, s * per + 1, (s + 1) * per, s + 1, np.arange(s * per + 1, (s + 1) * per + 1, dtype=np.uint32))
-               for s in range(S)]
-    parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
-    cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
-    blocks_sum = 0
-    for r in range(world):
-        rd = fpx.IndexReader(fpx.Segments(ctx, [segs[s] if s % world == r else remotes[s] for s in range(S)]))
-        pst = fpx.search_resident_partial(rd, qb, parts[r].data_ptr(), cnts[r].data_ptr())
-        blocks_sum += pst.scanned_blocks
-    torch.cuda.synchronize()
-    mo, mn = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
-    assert (mn == out_n).all() and (mo == out).all(), "8-way segment sharding must reproduce the unsharded result"
-    assert blocks_sum == st.scanned_blocks
-    # the oracle on a bounded sample: 24 queries x one segment
-    _oracle_sample(fpx, oracle, ctx, segs[3], 3 * per + 1, per, flat, offsets, opts, 24)
-    # ... and over the WHOLE index -- all 16 columns of the group, the headline kernel's own path -- on 48 queries of the batch
-    assert st.path_flags & 4 and st2.path_flags & 8, "the batch did not run k_probe_group<16, BINNED> + k_score_bin"
-    _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, 48, out, out_n)
+class TestHeadlineIndex:
+    """The two tests of the 100 M x 256 index in 16 segments share ONE build of it (round 4 built it once per test: 4 builds and two
+    107-GiB downloads took the suite to 935 s of the driver's 1200).  The hash-window test runs first: it cuts its slices from the
+    segments' BLOCKS (fpx_segment_slice), which the unsharded snapshot then trades for the packed group."""
+
+    @pytest.fixture(scope="class")
+    def index100m(self):
+        import os
+        from fpx_testlib import fpx
+        ctx = fpx.Context(0)
+        H, S = 256, 16
+        segs, per, docs = _build(fpx, ctx, 100_000_000, H, S, scratch=30 << 30)
+        if os.environ.get("FPX_ALLOW_SHRINK") != "1":
+            assert docs == 100_000_000
+        shared = {"ctx": ctx, "segs": segs, "per": per, "docs": docs, "H": H, "S": S}
+        yield shared
+        shared.clear()
+        for sg in segs:
+            sg.release()
+
+    def test_config3_hash_windows_of_8_ranks_at_full_size(self, index100m):
+        """configs[3] in the shape that scales: the 100 M index sharded by HASH RANGE over 8 ranks with the ROUTED-KEY
+        protocol, every rank played in turn by the one GPU.  Every rank holds its share of the batch -- the 1024 queries it will finish
+        -- makes their keys and deals them to the ranks' windows (fpx_shard_keys); rank w's slices are cut from the resident blocks
+        (fpx_segment_slice), grouped with their window, and probed with the eight key slots it received (fpx_shard_probe_keys: the
+        records dropped into the batch's bins); the bins travel as the second all-to-all would move them and every rank finishes its
+        share (fpx_shard_score_share).  Required: the eight shares, put together, equal the unsharded batch byte for byte, and the
+        ranks' scan counters add up to the unsharded ones.  src/Index.zig:170-177 (one search), src/FileSegment.zig:153-176 (a
+        hash's walk is independent of every other hash)."""
+        import torch
+        from fpx_testlib import fpx
+        ctx, segs, per, docs, H, S = (index100m[k] for k in ("ctx", "segs", "per", "docs", "H", "S"))
+        B, L, limit, world = 8192, 1000, 40, 8
+        flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
+        opts = fpx.http_options(limit=limit)
+        bpr = fpx.shard_bins_per_rank(B, world)
+        assert bpr * world * 8 == B
+        # ---- every rank's share of the batch and its keys, dealt to the windows (slot w of rank r: r's keys of window w)
+        shares = []
+        for r in range(world):
+            q_lo, q_hi = r * bpr * 8, (r + 1) * bpr * 8
+            sub_off = (offsets[q_lo:q_hi + 1] - offsets[q_lo]).astype(np.uint64)
+            shares.append(fpx.QueryBatch(ctx, options=opts, flat=(np.ascontiguousarray(flat[int(offsets[q_lo]):int(offsets[q_hi])]), sub_off)))
+        key_cap = (bpr * 8 * L // world) * 17 // 16 + 1024
+        ks = []
+        for r in range(world):
+            keys = torch.zeros((world, key_cap), dtype=torch.int64, device="cuda")
+            kcnt = torch.zeros((world,), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()                           # (torch fills on ITS stream; libfpx writes these on a stream of its own)
+            assert fpx.shard_keys(ctx, shares[r], world, r, B, keys.data_ptr(), key_cap, kcnt.data_ptr()) == 0, "raise the key slots' size"
+            ks.append((keys, kcnt))
+        # ---- all-to-all #1's effect + every rank's window in turn: cut, group, probe the received slots; its bins stay, the group goes
+        cell_cap = 4096                                        # (records of a bin from ONE rank: ~6250 x 8 / 8, two to a cell)
+        sends, tot = [], [0, 0, 0, 0]
+        for w in range(world):
+            lo_excl = None if w == 0 else (w << 32) // world - 1
+            hi_incl = None if w == world - 1 else ((w + 1) << 32) // world - 1
+            sl = [sg.window(lo_excl, hi_incl) for sg in segs]
+            snap = fpx.Segments(ctx, sl)
+            assert all(x.grouped for x in sl), ("the slices did not form a group with their window", [x.layout_reason for x in sl][:2])
+            rd = fpx.IndexReader(snap)
+            rk = torch.stack([ks[r][0][w] for r in range(world)]).contiguous()
+            rc = torch.stack([ks[r][1][w] for r in range(world)]).contiguous()
+            while True:
+                send = torch.zeros((world, bpr, cell_cap), dtype=torch.int64, device="cuda")
+                counts = torch.zeros((world, bpr), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                st, need = fpx.shard_probe_keys(rd, rk.data_ptr(), key_cap, rc.data_ptr(), world, B, send.data_ptr(), cell_cap, counts.data_ptr())
+                if st is not None:
+                    break
+                assert not sends, "every rank must use one bin size: raise the initial cell_cap"
+                cell_cap = int(need)
+            sends.append((send, counts))
+            for i, v in enumerate((st.scanned_blocks, st.scanned_docs, st.probes, st.hits)):
+                tot[i] += v
+            del rd, rk, rc
+            snap.release()
+            for x in sl:
+                x.release()
+        del ks
+        # ---- all-to-all #2's effect + every rank's finish of its share
+        cap = shares[0].cap
+        out = np.zeros((B, cap, 2), np.uint32)
+        out_n = np.zeros(B, np.uint32)
+        for d in range(world):
+            recv = torch.stack([sends[r][0][d] for r in range(world)]).contiguous()
+            rc = torch.stack([sends[r][1][d] for r in range(world)]).contiguous()
+            torch.cuda.synchronize()
+            o, n, q_lo, q_hi = fpx.shard_score_share(ctx, shares[d], world, d, B, recv.data_ptr(), cell_cap, rc.data_ptr())
+            assert (q_lo, q_hi) == (d * bpr * 8, (d + 1) * bpr * 8)
+            out[q_lo:q_hi], out_n[q_lo:q_hi] = o[:q_hi - q_lo], n[:q_hi - q_lo]
+        del sends, recv, rc, shares
+        torch.cuda.empty_cache()
+        # ---- the unsharded index (the blocks become the group now) and the same batch
+        qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+        reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+        o1, n1, st1 = fpx.search_resident(reader, qb)
+        assert (n1 == out_n).all() and (o1 == out).all(), "8 hash windows must reproduce the unsharded batch byte for byte"
+        assert tuple(tot) == (st1.scanned_blocks, st1.scanned_docs, st1.probes, st1.hits)
+        _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+
+    def test_config2_and_config3_100m_fingerprints_16_segments_batch_8192(self, index100m):
+        """configs[2] (one GPU) and configs[3] (segments sharded over 8 ranks, here 8 snapshots on one GPU)."""
+        import torch
+        from fpx_testlib import fpx, oracle
+        ctx, segs, per, docs, H, S = (index100m[k] for k in ("ctx", "segs", "per", "docs", "H", "S"))
+        B, L, limit = 8192, 1000, 40
+        reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+        flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
+        opts = fpx.http_options(limit=limit)
+        qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+        out, out_n, st = fpx.search_resident(reader, qb)
+        out, out_n = out.copy(), out_n.copy()
+        _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
+        assert st.probes == _unique_per_query(flat, offsets) * S
+        assert st.algorithmic_bytes == st.scanned_blocks * 512 and st.scanned_blocks >= st.probes * 0.97
+        assert st.hits >= int(out[:, 0, 1].astype(np.int64).sum())
+        # idempotence
+        out2, out_n2, st2 = fpx.search_resident(reader, qb)
+        assert (out_n2 == out_n).all() and (out2 == out).all()
+        assert (st2.scanned_blocks, st2.scanned_docs, st2.hits) == (st.scanned_blocks, st.scanned_docs, st.hits)
+        # in-kernel deadline (the reference cancels at zio.maybeYield, src/FileSegment.zig:144 -> error.SearchTimeout,
+        # src/MultiIndex.zig:314-322): a 1-ms deadline on a ~4-ms batch comes back as a timeout LONG before the batch would
+        # have finished, with no results, and the workspace is fine afterwards
+        # (the batch of 8192 itself is over in about a millisecond by now: the deadline test runs the batch four times over, ~4 ms)
+        import time
+        off4 = np.concatenate([offsets[:-1].astype(np.uint64) + np.uint64(k * len(flat)) for k in range(4)] + [np.array([4 * len(flat)], np.uint64)])
+        qb4 = fpx.QueryBatch(ctx, options=opts, flat=(np.tile(flat, 4), off4))
+        for _ in range(3):                                      # (a workspace's first batches of a new size take the general path and size the buffers)
+            fpx.search_resident(reader, qb4)
+        t0 = time.perf_counter()
+        o4, n4, _ = fpx.search_resident(reader, qb4)
+        t_full = time.perf_counter() - t0
+        assert (n4[:B] == out_n).all() and (o4[:B] == out).all() and (n4[3 * B:] == out_n).all()
+        t0 = time.perf_counter()
+        with pytest.raises(fpx.SearchTimeout):
+            fpx.search_resident(reader, qb4, timeout_ms=1)
+        t_cancel = time.perf_counter() - t0
+        assert t_cancel < max(0.003, 0.75 * t_full), (t_cancel, t_full)
+        qb4.release()
+        out3, out_n3, _ = fpx.search_resident(reader, qb, timeout_ms=10_000)       # a generous deadline changes nothing
+        assert (out_n3 == out_n).all() and (out3 == out).all()
+        # configs[3]: 8 ranks, two segments each + docs-only stand-ins for the others; tables merged as after an all-gather
+        world, cap = 8, qb.cap
+        remotes = [fpx.RemoteSegment(ctx, s * per + 1, (s + 1) * per, s + 1, np.arange(s * per + 1, (s + 1) * per + 1, dtype=np.uint32))
+                   for s in range(S)]
+        parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
+        cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
+        blocks_sum = 0
+        for r in range(world):
+            rd = fpx.IndexReader(fpx.Segments(ctx, [segs[s] if s % world == r else remotes[s] for s in range(S)]))
+            pst = fpx.search_resident_partial(rd, qb, parts[r].data_ptr(), cnts[r].data_ptr())
+            blocks_sum += pst.scanned_blocks
+        torch.cuda.synchronize()
+        mo, mn = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
+        assert (mn == out_n).all() and (mo == out).all(), "8-way segment sharding must reproduce the unsharded result"
+        assert blocks_sum == st.scanned_blocks
+        # the oracle on a bounded sample: 24 queries x one segment
+        _oracle_sample(fpx, oracle, ctx, segs[3], 3 * per + 1, per, flat, offsets, opts, 24)
+        # ... and over the WHOLE index -- all 16 columns of the group, the headline kernel's own path -- on 48 queries of the batch
+        assert st.path_flags & 4 and st2.path_flags & 8, "the batch did not run k_probe_group<16, BINNED> + k_score_bin"
+        _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, 48, out, out_n)
 
 
 def test_config1_10m_fingerprints_one_segment_batch_1024():
@@ -302,72 +399,3 @@ def test_direct_addressed_form_equals_block_form_at_full_size(dist, monkeypatch)
     assert (n0 == n1).all() and (o0 == o1).all()
     assert np.array_equal(i0, i1) and np.array_equal(b0, b1)
     assert int(n0.min()) >= 1
-
-
-def test_config3_hash_windows_of_8_ranks_at_full_size():
-    """configs[3] in the shape that scales: the 100 M index sharded by HASH RANGE over 8 ranks, every rank played in
-    turn by the one GPU.  Rank r's slices are cut from the resident blocks (fpx_segment_slice), grouped with their window, probed
-    with the whole batch of 8192 (fpx_shard_probe: only the window's hashes, the records dropped into the batch's bins); then the
-    pieces travel as the all-to-all would move them and EVERY rank finishes its 1024 queries (fpx_shard_score).  Required: the
-    eight shares, put together, equal the unsharded batch byte for byte, and the ranks' scan counters add up to the unsharded
-    ones.  src/Index.zig:170-177 (one search), src/FileSegment.zig:153-176 (a hash's walk is independent of every other hash)."""
-    import os
-    import torch
-    from fpx_testlib import fpx
-    ctx = fpx.Context(0)
-    H, S, B, L, limit, world = 256, 16, 8192, 1000, 40, 8
-    segs, per, docs = _build(fpx, ctx, 100_000_000, H, S, scratch=30 << 30)
-    if os.environ.get("FPX_ALLOW_SHRINK") != "1":
-        assert docs == 100_000_000
-    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
-    opts = fpx.http_options(limit=limit)
-    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
-    bpr = fpx.shard_bins_per_rank(B, world)
-    assert bpr * world * 8 == B
-    # ---- every rank's window in turn: cut, group, probe; its send buffer (8 x bpr bins) stays, the group goes
-    cell_cap = 4096                                            # (records of a bin from ONE rank: ~6250 x 8 / 8, two to a cell)
-    sends, tot = [], [0, 0, 0, 0]
-    for r in range(world):
-        lo_excl = None if r == 0 else (r << 32) // world - 1
-        hi_incl = None if r == world - 1 else ((r + 1) << 32) // world - 1
-        sl = [sg.window(lo_excl, hi_incl) for sg in segs]
-        snap = fpx.Segments(ctx, sl)
-        assert all(x.grouped for x in sl), "the slices did not form a group with their window"
-        rd = fpx.IndexReader(snap)
-        while True:
-            send = torch.zeros((world, bpr, cell_cap), dtype=torch.int64, device="cuda")
-            counts = torch.zeros((world, bpr), dtype=torch.int32, device="cuda")
-            torch.cuda.synchronize()                           # (torch fills on ITS stream; libfpx writes these on a stream of its own)
-            st, need = fpx.shard_probe(rd, qb, world, send.data_ptr(), cell_cap, counts.data_ptr())
-            if st is not None:
-                break
-            assert not sends, "every rank must use one bin size: raise the initial cell_cap"
-            cell_cap = int(need)
-        sends.append((send, counts))
-        for i, v in enumerate((st.scanned_blocks, st.scanned_docs, st.probes, st.hits)):
-            tot[i] += v
-        del rd
-        snap.release()
-        for x in sl:
-            x.release()
-    # ---- the all-to-all's effect + every rank's finish
-    cap = qb.cap
-    out = np.zeros((B, cap, 2), np.uint32)
-    out_n = np.zeros(B, np.uint32)
-    covered = 0
-    for d in range(world):
-        recv = torch.stack([sends[r][0][d] for r in range(world)]).contiguous()
-        rc = torch.stack([sends[r][1][d] for r in range(world)]).contiguous()
-        torch.cuda.synchronize()
-        out, out_n, q_lo, q_hi = fpx.shard_score(ctx, qb, world, d, recv.data_ptr(), cell_cap, rc.data_ptr(), out, out_n)
-        assert (q_lo, q_hi) == (d * bpr * 8, (d + 1) * bpr * 8)
-        covered += q_hi - q_lo
-    assert covered == B
-    del sends, recv, rc
-    torch.cuda.empty_cache()
-    # ---- the unsharded index (the blocks become the group now) and the same batch
-    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
-    o1, n1, st1 = fpx.search_resident(reader, qb)
-    assert (n1 == out_n).all() and (o1 == out).all(), "8 hash windows must reproduce the unsharded batch byte for byte"
-    assert tuple(tot) == (st1.scanned_blocks, st1.scanned_docs, st1.probes, st1.hits)
-    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)

@@ -54,25 +54,74 @@ def _name(env):
     return ",".join(f"{k}={v}" for k, v in env.items())
 
 
-def _run_variant(env):
-    e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
+def _suites(env):
     suites = FUSED_SUITES if env.get("FPX_FUSE_MIN") == "1" else DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
     if env.get("FPX_FUSE_MIN") == "1" and len(env) > 2:          # the sub-variants of the grouped form: the suites that reach the switched code
         suites = FUSED_SHORT
-    return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
-                          cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+    return suites
+
+
+def _need_gb(env):
+    """HBM a variant's child may hold at its peak.  A packed group's lines cost memory by the HASH SPACE, not by the items: 69 GB for
+    up to eight columns, 137 GB for sixteen -- and tests/test_gpu_hashshard.py holds the unsharded group AND the ranks' windows of it
+    (another 69 GB between them).  The directory + words form: 8.6 / 17 GB per group.  Everything else: small indexes in blocks."""
+    if env.get("FPX_GROUP_PACKED") == "1":
+        return 170
+    if env.get("FPX_FUSE_MIN") == "1":
+        return 45
+    return 15
+
+
+def _free_gb():
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    return free_b / 2**30
+
+
+class _HbmScheduler:
+    """Starts a variant's child when the device has room for what it may take (round 4 ran three children at a time whatever they
+    needed: next to two neighbours the packed variant's groups did not fit once, its segments stayed in their blocks, and the test
+    that asserts the grouped layout failed -- HBM exhaustion, not a race: alone, and with the room reserved, it passes)."""
+
+    def __init__(self, jobs):
+        import threading
+        self.cv = threading.Condition()
+        self.budget = _free_gb() - 10.0      # what the device has free now, before any child runs
+        self.reserved = 0.0                  # GB promised to the running children (they take it gradually: the free HBM of the moment would over-admit)
+        self.running = 0
+        self.jobs = jobs
+
+    def run(self, env):
+        need = _need_gb(env)
+        with self.cv:
+            while self.running and (self.running >= self.jobs or self.reserved + need > self.budget):
+                self.cv.wait()
+            self.running += 1
+            self.reserved += need
+        try:
+            e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
+            return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + _suites(env),
+                                  cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+        finally:
+            with self.cv:
+                self.running -= 1
+                self.reserved -= need
+                self.cv.notify_all()
 
 
 @pytest.fixture(scope="module")
 def variant_runs():
-    """every variant's child process, THREE at a time (each is a minute of small batches that leaves the GPU mostly idle: one
-    after the other they were 11 of the suite's 14 minutes); a test waits for its own"""
+    """every variant's child process, as many at a time as the device's free HBM allows (each is a minute of small batches that leaves
+    the GPU mostly idle: one after the other they were 11 of the suite's 14 minutes); a test waits for its own"""
     import concurrent.futures as cf
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         yield {}
         return
-    with cf.ThreadPoolExecutor(int(os.environ.get("FPX_VARIANT_JOBS", "3"))) as pool:
-        yield {_name(env): pool.submit(_run_variant, env) for env in VARIANTS}
+    sched = _HbmScheduler(int(os.environ.get("FPX_VARIANT_JOBS", "4")))
+    # the largest first: the packed variant starts on an empty device, the small ones fill in around it
+    order = sorted(VARIANTS, key=_need_gb, reverse=True)
+    with cf.ThreadPoolExecutor(len(VARIANTS)) as pool:
+        yield {_name(env): pool.submit(sched.run, env) for env in order}
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=_name)
@@ -80,13 +129,4 @@ def test_parity_suites_on_the_alternative_paths(env, variant_runs):
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         pytest.skip("already inside a variant run")
     r = variant_runs[_name(env)].result()
-    if r.returncode != 0:
-        # Three children share the one GPU (up to 137 GB of group lines each in the packed variant, process groups, dozens of contexts): a
-        # child that fails next to the others is run once more ON ITS OWN -- after all the others have finished -- and that run decides.
-        # Seen once in round 4: the packed variant failed in the full suite and passed 76 / 76 alone and next to two neighbours.
-        first = r.stdout[-1500:] + r.stderr[-500:]
-        for f in variant_runs.values():
-            f.result()
-        r = _run_variant(env)
-        sys.stderr.write(f"\nvariant {_name(env)} failed next to the other children and was run again alone (rc {r.returncode}); first failure:\n{first}\n")
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-1000:]

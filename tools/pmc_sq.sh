@@ -15,7 +15,7 @@ for pass_ in "ab":
     if not f: print("no output for pass", pass_); continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); last = {}
     for r in csv.DictReader(open(f[0])):
-        if any(k in r["Kernel_Name"] for k in ("k_probe_lean8", "k_probe_direct", "k_probe_group")):
+        if any(k in r["Kernel_Name"] for k in ("k_probe_lean8", "k_probe_direct", "k_probe_group", "k_probe_pgroup")):
             agg[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
     if agg:
         d = max(agg)

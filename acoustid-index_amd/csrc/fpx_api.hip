@@ -237,6 +237,7 @@ int resolve_candidates(Ctx* c, const std::vector<Segment*>& segs)
             if (done[j]) continue;
             const Segment* a = lone[i]; const Segment* b = lone[j];
             if (a->own_flags != b->own_flags || ((a->own_flags & 1u) && a->own_lo != b->own_lo) || ((a->own_flags & 2u) && a->own_hi != b->own_hi)) continue;
+            if (a->block_size != b->block_size) continue;          // (a group's visited blocks are counted in bytes of ONE block size)
             batch.push_back(lone[j]); idx.push_back(j);
         }
         for (size_t j : idx) done[j] = true;
@@ -272,6 +273,7 @@ int regroup_segments(Ctx* c, const std::vector<Segment*>& segs, uint32_t* regrou
     for (Segment* s : segs) {
         if (!s || s->kind != 0 || s->ctx != c || s->own_flags) continue;
         if (std::find(m.begin(), m.end(), s) != m.end()) continue;
+        if (!m.empty() && s->block_size != m[0]->block_size) continue;      // (one block size per group)
         if (s->home || s->direct || (s->candidate && s->d_blocks && !s->settled)) m.push_back(s);
         if (m.size() == FUSE_MAX) break;
     }
@@ -825,6 +827,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     }
     sn->n_file = (uint32_t)sn->h_file.size();
     sn->n_mem = (uint32_t)sn->h_mem.size();
+    for (const MemDesc& m : sn->h_mem) sn->mem_items += m.num_items;
     sn->n_direct = (uint32_t)sn->h_direct.size();
     if (sn->max_block_size == 0) sn->max_block_size = 512;
     hipError_t e = hipSuccess;
@@ -846,6 +849,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
                     GroupDesc gd{};
                     gd.lines = g->d_lines; gd.line0 = g->line0; gd.nseg = g->nseg; gd.win_lo = g->win_lo; gd.win_hi = g->win_hi;
                     gd.ext_tab = g->d_ext_tab; gd.chunk0 = g->chunk0; gd.nchunks = g->nchunks; gd.gmin = g->gmin;       // (the packed form's)
+                    gd.block_size = g->block_size;
                     gd.lo_all = 0u; gd.hi_all = 0xFFFFFFFFu;
                     for (uint32_t j = 0; j < FUSE_MAX; ++j) { gd.min_doc[j] = g->min_doc[j]; gd.first_hash[j] = g->first_hash[j]; gd.last_hash[j] = g->last_hash[j]; }
                     sn->groups.push_back(sg->home);

@@ -484,6 +484,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         if (s->own_flags != segs[0]->own_flags || ((s->own_flags & 1u) && s->own_lo != segs[0]->own_lo) || ((s->own_flags & 2u) && s->own_hi != segs[0]->own_hi)) {
             set_error("the members of a group must share one hash window"); return FPX_E_INVAL;
         }
+        if (s->block_size != segs[0]->block_size) { set_error("the members of a group must share one block size"); return FPX_E_INVAL; }
     }
     if (win_lo > win_hi) { set_error("empty hash window"); return FPX_E_INVAL; }
     // The PACKED form (fpx_pgroup.hpp: 128-byte lines of 64 / ns hash values with their words inside -- one HBM line per query
@@ -519,7 +520,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     }
     auto g = std::make_shared<Group>();
     g->device = ctx->device; g->ns = ns; g->nseg = k; g->line0 = c_first * CHUNK_LINES; g->nlines = nlines; g->win_lo = win_lo; g->win_hi = win_hi;
-    g->packed = packed; g->chunk0 = c_first; g->nchunks = nchunks;
+    g->packed = packed; g->chunk0 = c_first; g->nchunks = nchunks; g->block_size = segs[0]->block_size;
     for (uint32_t j = 0; j < FUSE_MAX; ++j) { g->first_hash[j] = 1u; g->last_hash[j] = 0u; }      // unused columns: empty hash range
     BuildArgs a{};
     a.nseg = k; a.inline_doubles = inline_doubles ? 1u : 0u;

@@ -449,10 +449,12 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
             unsigned long long* st = a.lean_stats + (size_t)(blockIdx.x % LEAN_STAT_SETS) * 8u;
             if (wg_reads) atomicAdd(&st[4], wg_reads);
             if (wg_blocks) atomicAdd(&st[1], wg_blocks);
+            // (the host prices the sets' blocks at 512 bytes; blocks of another size add the difference -- mod 2^64 -- to slot 5)
+            if (wg_blocks && g->block_size != 512u) atomicAdd(&st[5], wg_blocks * (unsigned long long)g->block_size - wg_blocks * 512ull);
             if (wg_docs) atomicAdd(&st[2], wg_docs);
             if (wg_probes) atomicAdd(&st[3], wg_probes);
         } else {
-            if (wg_blocks) { atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks); atomicAdd(&a.counters[CTR_BYTES], wg_blocks * 512ull); }
+            if (wg_blocks) { atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks); atomicAdd(&a.counters[CTR_BYTES], wg_blocks * (unsigned long long)g->block_size); }
             if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
             if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
             if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);       // (64-byte units here)

@@ -80,6 +80,7 @@ struct GroupDesc {
     uint32_t active;                       // bit s: column s belongs to the snapshot being searched (a group outlives merged-away members)
     uint32_t any_dead;
     uint32_t win_lo, win_hi;               // hashes outside are not probed here (0, 0xFFFFFFFF: no window)
+    uint32_t block_size;                   // of the members' blocks (one size per group): a visited block's algorithmic bytes (src/filefmt.zig:29-31,71)
     uint32_t min_doc[FUSE_MAX], first_hash[FUSE_MAX], last_hash[FUSE_MAX];
     uint32_t seg_index[FUSE_MAX];          // the column's descriptor in Snapshot::d_direct (supersession filter)
     uint32_t has_dead[FUSE_MAX];
@@ -163,6 +164,7 @@ struct Group {
     uint32_t line0 = 0; uint64_t nlines = 0;
     uint32_t chunk0 = 0, nchunks = 0;
     uint32_t win_lo = 0, win_hi = 0xFFFFFFFFu;
+    uint32_t block_size = 512;             // the members' (one block size per group: the statistics' byte counts)
     uint32_t* d_lines = nullptr;
     std::vector<uint32_t*> word_chunks, list_chunks;       // one pair per hash-space chunk (the lines hold their addresses)
     // the PACKED form (fpx_pgroup.hpp: a hash's words inside its line) of a dense group
@@ -237,6 +239,7 @@ struct Snapshot {
     // ... and ONE table of all memory segments' LIVE postings (superseded docs dropped), sorted by hash, behind a 2^20-entry bucket
     // table: a query hash is looked up once for all memory segments, in any key order (fpx_probe_small.hpp: k_probe_memtab)
     uint64_t* d_memtab = nullptr; uint32_t* d_membucket = nullptr; uint64_t n_memtab = 0;
+    uint64_t mem_items = 0;                // items of all memory segments together (0: nothing to look up, table or not)
     std::vector<std::shared_ptr<DeadSet>> dead_sets;   // shared with the segments' caches
     uint32_t max_block_size = 0;
     bool all_512 = true;                 // every file segment uses 512-B blocks (the only size the reference writes)
@@ -351,6 +354,7 @@ int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uin
 int score_records_impl(Ctx* ctx, const QueryBatch* qb, const uint64_t* d_records, uint64_t num_records, uint32_t timeout_ms,
                        fpx_result* d_out, uint32_t out_cap, uint32_t* d_out_n);
 uint64_t group_bytes_lower_bound(const Ctx* ctx, Segment* const* segs, uint32_t k);
+constexpr uint32_t SHARD_DEDUP_MAX = 2048;      // = DEDUP_MAX (fpx_kernels_common.hpp): the routed keys' queries hold at most this many hashes
 int shard_bins_per_rank(uint32_t B, uint32_t world);
 int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,
                      uint64_t* d_send, uint64_t cell_cap, uint32_t* d_send_counts, uint64_t* needed_cell_cap, fpx_stats* stats);

@@ -71,10 +71,15 @@ __global__ void k_memtab_buckets(const uint64_t* __restrict__ tab, uint64_t n, u
     while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if ((tab[m] >> 32) < hv) lo = m + 1; else hi = m; }
     bucket[k] = (uint32_t)lo;
 }
+// (blockIdx.y: the key slot -- a rank of a hash-sharded index looks up the keys every source sent it, `slot_stride` keys apart, slot
+// s filled to P_dev[s]; one slot of P keys otherwise)
 __global__ __launch_bounds__(WG) void k_probe_memtab(const uint64_t* __restrict__ tab, const uint32_t* __restrict__ bucket, const uint64_t* __restrict__ pairs,
-                                                      uint64_t P, uint32_t qb, uint32_t key_skip, uint64_t* hits, uint64_t hit_cap, unsigned long long* counters)
+                                                      uint64_t P, uint32_t qb, uint32_t key_skip, uint64_t* hits, uint64_t hit_cap, unsigned long long* counters,
+                                                      const unsigned long long* __restrict__ P_dev = nullptr, uint64_t slot_stride = 0)
 {
     const uint64_t p = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    pairs += (size_t)blockIdx.y * slot_stride;
+    if (P_dev) P = min((uint64_t)P_dev[blockIdx.y], P);
     if (p >= P) return;
     const uint64_t key = gload_u64(pairs + p);
     // dedupSorted (src/Index.zig:489-499): flagged where the keys were made, or found by looking back

@@ -794,12 +794,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             // the lean / direct kernels' statistics: LEAN_STAT_SETS copies on separate cache lines (a workgroup adds to set
             // blockIdx.x % LEAN_STAT_SETS), summed here into the slots the code below reads
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
-            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0, dreads = 0;
+            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0, dreads = 0, bytes_off = 0;
             for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
                 reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4];
+                bytes_off += ls[i * 8 + 5];          // (block sizes other than 512 in the direct-addressed forms: the difference, mod 2^64)
             }
             ws->h_counters[CTR_LEAN_READS] = reads + (dreads + 1) / 2;           // (k_probe_direct counts 64-byte requests)
-            ws->h_counters[8 + CTR_BLOCKS] = blocks; ws->h_counters[8 + CTR_BYTES] = blocks * 512ull;
+            ws->h_counters[8 + CTR_BLOCKS] = blocks; ws->h_counters[8 + CTR_BYTES] = blocks * 512ull + bytes_off;
             ws->h_counters[8 + CTR_DOCS] = docs; ws->h_counters[8 + CTR_PROBES] = probes;
         }
         if (P && (snap->n_file || snap->n_direct)) {
@@ -957,12 +958,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         if (!partial && (rc = deliver_results(ws, B, out_cap, staged, out, out_n, st))) return rc;
         if (stats) {
-            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0;
+            unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0, bytes_off = 0;
             if (spread) {
                 const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
                 unsigned long long dreads = 0;
                 for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
                     reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4];
+                    bytes_off += ls[i * 8 + 5];      // (direct-addressed segments of a block size other than 512: the difference, mod 2^64)
                 }
                 reads += (dreads + 1) / 2;
             }
@@ -977,13 +979,13 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->scanned_blocks += ws->h_counters[CTR_BLOCKS] + blocks;
             stats->scanned_docs += ws->h_counters[CTR_DOCS] + docs;
             stats->hits += H;
-            stats->algorithmic_bytes += ws->h_counters[CTR_BYTES] + blocks * 512ull;
+            stats->algorithmic_bytes += ws->h_counters[CTR_BYTES] + blocks * 512ull + bytes_off;
             stats->candidates += Cf + ws->h_counters[CTR_SLOTCANDS];
             stats->probe_kernel_ms += ms;
             stats->total_gpu_ms += total_ms;
             stats->probe_launches += probe_launches;
             stats->generic_iters += (uint32_t)ws->h_counters[CTR_GENERIC];
-            stats->probe_kernel_bytes += ln ? blocks * 512ull : ws->h_counters[CTR_BYTES];
+            stats->probe_kernel_bytes += ln ? blocks * 512ull + bytes_off : ws->h_counters[CTR_BYTES];
             stats->probe_kernel_fetched_bytes += ln ? reads * 128ull : snap->n_direct ? ws->h_counters[CTR_LEAN_READS] * 64ull + (snap->n_file ? ws->h_counters[CTR_BYTES] : 0ull)
                                                                      : ws->h_counters[CTR_BYTES];
             stats->probe_aux_ms += aux;
@@ -1540,6 +1542,7 @@ static unsigned log2_exact(uint32_t v) { unsigned b = 0; while ((1u << b) < v) +
 // hash bits the keys of a window are ordered by: with the window's own constant bits, the top 8 (as on one GPU)
 static unsigned shard_sort_bits(unsigned win_bits) { return win_bits >= 8u ? 0u : 8u - win_bits; }
 
+static_assert(SHARD_DEDUP_MAX == DEDUP_MAX, "fpx_sharded.hip routes longer queries to the record protocol");
 // bins per rank: the batch's bins of 2^SHARD_BQ queries, dealt to the ranks in contiguous runs
 int shard_bins_per_rank(uint32_t B, uint32_t world)
 {
@@ -1557,8 +1560,10 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
     if (B == 0) return FPX_OK;
     // the bin protocol serves snapshots that are groups of direct-addressed segments with one hash window and nothing else;
     // anything else goes through fpx_probe_resident / fpx_score_partial (same results)
-    if (snap->n_group == 0 || snap->n_solo != 0 || snap->n_file != 0 || snap->n_mem != 0) {
-        set_error("fpx_shard_probe: the snapshot is not made of groups of direct-addressed segments alone (use fpx_probe_resident)"); return FPX_E_INVAL;
+    // ... and memory segments behind the snapshot's ONE table (k_probe_memtab reads keys in any order; its records are binned with the
+    // ones the group kernels could not place): a live index -- every Index.update publishes a memory segment, src/Index.zig:515-587
+    if (snap->n_group == 0 || snap->n_solo != 0 || snap->n_file != 0 || (snap->n_mem != 0 && !snap->d_memtab && snap->mem_items != 0)) {
+        set_error("fpx_shard_probe: the snapshot is not made of groups of direct-addressed segments (and memory segments behind their table) alone (use fpx_probe_resident)"); return FPX_E_INVAL;
     }
     uint32_t win_lo = snap->h_group[0].win_lo, win_hi = snap->h_group[0].win_hi;
     for (const GroupDesc& gd : snap->h_group)
@@ -1655,6 +1660,10 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
                 const Group* grp = snap->groups[&gd - snap->h_group.data()].get();
                 launch_probe_group(grp->packed, grp->ns == 8u, true, false, grid, st, a, gargs);
             }
+            // the memory segments' table: the window's keys looked up there too, the records into the misc buffer (k_bin bins them)
+            if (snap->n_mem && snap->d_memtab)
+                hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((P + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
+                                   (const uint64_t*)ws->d_keys[kcur], P, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, (const unsigned long long*)d_P, 0ull);
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             // what the kernel could not place itself (a clash of two bins on one slot of a round, a full stage): k_bin
             BinArgs hb{};
@@ -1692,11 +1701,12 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
         if (stats) {
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
             unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0;
-            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; }
+            unsigned long long bytes_off = 0;
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; bytes_off += ls[i * 8 + 5]; }
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
             stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS];
-            stats->algorithmic_bytes = blocks * 512ull; stats->probe_kernel_bytes = blocks * 512ull;
+            stats->algorithmic_bytes = blocks * 512ull + bytes_off; stats->probe_kernel_bytes = blocks * 512ull + bytes_off;
             stats->probe_kernel_fetched_bytes = dreads * 64ull; stats->probe_kernel_ms = ms; stats->total_gpu_ms = ms; stats->probe_launches = 1;
             stats->path_flags = 1u | 4u | 8u | 16u;
         }
@@ -1781,8 +1791,8 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
     if (needed_cell_cap) *needed_cell_cap = 0;
     const uint32_t B = B_global;
     if (B == 0) return FPX_OK;
-    if (snap->n_group == 0 || snap->n_solo != 0 || snap->n_file != 0 || snap->n_mem != 0) {
-        set_error("fpx_shard_probe_keys: the snapshot is not made of groups of direct-addressed segments alone (use fpx_probe_resident)"); return FPX_E_INVAL;
+    if (snap->n_group == 0 || snap->n_solo != 0 || snap->n_file != 0 || (snap->n_mem != 0 && !snap->d_memtab && snap->mem_items != 0)) {
+        set_error("fpx_shard_probe_keys: the snapshot is not made of groups of direct-addressed segments (and memory segments behind their table) alone (use fpx_probe_resident)"); return FPX_E_INVAL;
     }
     const unsigned qbits = bits_for(B);
     if (qbits > 24u) { set_error("fpx_shard_probe_keys: at most 2^24 queries"); return FPX_E_INVAL; }
@@ -1835,6 +1845,10 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
                 const Group* grp = snap->groups[&gd - snap->h_group.data()].get();
                 launch_probe_group(grp->packed, grp->ns == 8u, true, false, grid, st, a, gargs);
             }
+            // the memory segments' table (replicated on every rank: a rank only receives the keys of its window)
+            if (snap->n_mem && snap->d_memtab)
+                hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((key_cap + WG - 1) / WG), world), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
+                                   d_keys_recv, key_cap, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, d_key_counts, key_cap);
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             BinArgs hb{};
             hb.bins = d_send; hb.bin_cap = rec_cap; hb.bin_count = ws->d_cells; hb.shift = SHARD_BQ; hb.nbins = std::min<uint32_t>(ncells, MAX_SBINS);
@@ -1867,11 +1881,12 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
         if (stats) {
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
             unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0;
-            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; }
+            unsigned long long bytes_off = 0;
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; bytes_off += ls[i * 8 + 5]; }
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
             stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS];
-            stats->algorithmic_bytes = blocks * 512ull; stats->probe_kernel_bytes = blocks * 512ull;
+            stats->algorithmic_bytes = blocks * 512ull + bytes_off; stats->probe_kernel_bytes = blocks * 512ull + bytes_off;
             stats->probe_kernel_fetched_bytes = dreads * 64ull; stats->probe_kernel_ms = ms; stats->total_gpu_ms = ms; stats->probe_launches = 1;
             stats->path_flags = 1u | 4u | 8u | 16u;
         }

@@ -171,6 +171,9 @@ struct WinBufs {
     std::vector<uint64_t*> bins_send, bins_recv;             // [world][bpr][cell_cap]
     std::vector<uint32_t*> bcnt_send, bcnt_recv;             // [world][bpr]
     std::vector<hipStream_t> xs;                             // exchange streams (peer copies), one per rank
+    // record protocol (batches with a score floor of 1 or 2): hit records by destination rank, what every rank received
+    std::vector<uint64_t*> rec_send, rec_recv;
+    std::vector<uint64_t> rec_send_cap, rec_recv_cap;        // in records, per rank
 };
 
 static void win_free_keys(ShardedSnapshot* ss, WinBufs* b)
@@ -201,6 +204,8 @@ static void win_destroy(ShardedSnapshot* ss, WinBufs* b)
     win_free_keys(ss, b); win_free_bins(ss, b);
     for (uint32_t k = 0; k < b->world; ++k) {
         (void)hipSetDevice(ss->ctxs[k]->device);
+        if (k < b->rec_send.size() && b->rec_send[k]) (void)hipFree(b->rec_send[k]);
+        if (k < b->rec_recv.size() && b->rec_recv[k]) (void)hipFree(b->rec_recv[k]);
         if (k < b->kcnt_send.size() && b->kcnt_send[k]) (void)hipFree(b->kcnt_send[k]);
         if (k < b->kcnt_recv.size() && b->kcnt_recv[k]) (void)hipFree(b->kcnt_recv[k]);
         if (k < b->xs.size() && b->xs[k]) (void)hipStreamDestroy(b->xs[k]);
@@ -629,7 +634,10 @@ int fpx_sharded_snapshot_create_windows(fpx_ctx* const* ctxs, uint32_t world, fp
         ss->ctxs.push_back(c);
         for (uint32_t j = 0; j < num_segs; ++j) {
             const Segment* sg = reinterpret_cast<const Segment*>(slices[(size_t)k * num_segs + j]);
-            if (!sg || sg->ctx != c || sg->kind != 0) { sharded_free(ss); set_error("slices[%u][%u] is not a file segment of context %u", k, j, k); return FPX_E_INVAL; }
+            // (file slices of the rank's window, and MEMORY segments: a live index publishes one with every update, src/Index.zig:515-587,
+            // and IndexReader.search walks them after the file segments, :173-175 -- each rank holds a copy of the (small) segment and looks
+            // up the keys of its window in it)
+            if (!sg || sg->ctx != c || (sg->kind != 0 && sg->kind != 1)) { sharded_free(ss); set_error("slices[%u][%u] is not a file or memory segment of context %u", k, j, k); return FPX_E_INVAL; }
         }
         fpx_snapshot* sn = nullptr;
         const int rc = fpx_snapshot_create(ctxs[k], slices + (size_t)k * num_segs, num_segs, &sn);
@@ -647,12 +655,12 @@ int fpx_sharded_snapshot_create_windows(fpx_ctx* const* ctxs, uint32_t world, fp
     for (uint32_t k = 0; k < world && num_segs; ++k) {
         const Snapshot* sn = ss->locals[k];
         const uint32_t lo = (uint32_t)(((uint64_t)k << 32) / world), hi = (uint32_t)((((uint64_t)(k + 1u) << 32) / world) - 1u);
-        bool ok = sn->n_group != 0 && sn->n_solo == 0 && sn->n_file == 0 && sn->n_mem == 0;
+        bool ok = sn->n_group != 0 && sn->n_solo == 0 && sn->n_file == 0 && (sn->n_mem == 0 || sn->d_memtab != nullptr || sn->mem_items == 0);
         for (const GroupDesc& gd : sn->h_group) ok = ok && gd.win_lo == lo && gd.win_hi == hi;
         if (!ok) {
             sharded_free(ss);
-            set_error("fpx_sharded_snapshot_create_windows: rank %u's slices did not form groups with the window [%u, %u] (dense 512-byte file segments cut by "
-                      "fpx_segment_create_file_windows / fpx_segment_slice; FPX_FUSE_MIN / FPX_DIRECT_MIN_ITEMS permitting)", k, lo, hi);
+            set_error("fpx_sharded_snapshot_create_windows: rank %u's segments did not form groups with the window [%u, %u] + memory segments behind one table (dense "
+                      "file segments cut by fpx_segment_create_file_windows / fpx_segment_slice; FPX_FUSE_MIN / FPX_DIRECT_MIN_ITEMS permitting)", k, lo, hi);
             return FPX_E_INVAL;
         }
     }
@@ -717,6 +725,7 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
         b->keys_send.assign(n, nullptr); b->keys_recv.assign(n, nullptr); b->kcnt_send.assign(n, nullptr); b->kcnt_recv.assign(n, nullptr);
         b->bins_send.assign(n, nullptr); b->bins_recv.assign(n, nullptr); b->bcnt_send.assign(n, nullptr); b->bcnt_recv.assign(n, nullptr);
         b->xs.assign(n, nullptr);
+        b->rec_send.assign(n, nullptr); b->rec_recv.assign(n, nullptr); b->rec_send_cap.assign(n, 0); b->rec_recv_cap.assign(n, 0);
         for (uint32_t k = 0; k < n; ++k) {
             if (hipSetDevice(ss->ctxs[k]->device) != hipSuccess || hipMalloc(&b->kcnt_send[k], (size_t)n * 8) != hipSuccess || hipMalloc(&b->kcnt_recv[k], (size_t)n * 8) != hipSuccess ||
                 hipStreamCreateWithFlags(&b->xs[k], hipStreamNonBlocking) != hipSuccess) { win_destroy(ss, b); set_error("out of device memory"); return FPX_E_NOMEM; }
@@ -802,7 +811,111 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
         });
         return first_error();
     };
-    rc = body();
+    // ---- the RECORD protocol, for what the bins do not take: a batch with a score floor of 1 or 2 (the legacy front end searches
+    //      with limit = max_results, min_score = 1: src/legacy.zig:185-196 -- nearly every counted doc is a candidate) or with queries of
+    //      more than DEDUP_MAX hashes.  Every rank probes ITS window with the whole batch (fpx_probe_resident: the records grouped by the
+    //      rank that counts their doc, doc & (N - 1)), the pieces travel, every rank scores the docs it was dealt into per-query tables
+    //      (fpx_score_partial), and the tables meet on rank 0 for the merge (fpx_merge_partials) -- the protocol of
+    //      sharding.HashShardedReader._search_records, behind the one call.
+    auto body_records = [&]() -> int {
+        int r;
+        uint32_t cap = 1;
+        for (uint32_t q = 0; q < B; ++q) cap = std::max(cap, std::min(opts[q].max_results, out_cap ? out_cap : 1u));
+        run_all([&](uint32_t k) -> int { return query_batch_create_impl(ss->ctxs[k], hashes, offsets, B, opts, &shares[k]); });
+        if ((r = first_error())) return r;
+        std::vector<std::vector<uint64_t>> counts(n, std::vector<uint64_t>(n, 0));
+        for (int attempt = 0;; ++attempt) {
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint64_t want = std::max<uint64_t>(b->rec_send_cap[k], (uint64_t)1 << 20);
+                if (b->rec_send[k] && b->rec_send_cap[k] >= want) continue;
+                FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+                if (b->rec_send[k]) { (void)hipFree(b->rec_send[k]); b->rec_send[k] = nullptr; b->rec_send_cap[k] = 0; }
+                FPX_HIP(hipMalloc(&b->rec_send[k], want * sizeof(uint64_t)));
+                b->rec_send_cap[k] = want;
+            }
+            run_all([&](uint32_t k) -> int {
+                return probe_records_impl(ss->locals[k], shares[k], n, timeout_ms, b->rec_send[k], b->rec_send_cap[k], counts[k].data(), &sts[k]);
+            });
+            bool grown = false;
+            for (uint32_t k = 0; k < n; ++k) {
+                uint64_t total = 0;
+                for (uint64_t c : counts[k]) total += c;
+                if (rcs[k] == FPX_E_INVAL && total > b->rec_send_cap[k] && attempt < 3) {     // (the buffer was too small: the counts say by how much)
+                    b->rec_send_cap[k] = total + total / 16 + 1024; rcs[k] = FPX_OK; grown = true;
+                    FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+                    (void)hipFree(b->rec_send[k]); b->rec_send[k] = nullptr;
+                    FPX_HIP(hipMalloc(&b->rec_send[k], b->rec_send_cap[k] * sizeof(uint64_t)));
+                }
+            }
+            if ((r = first_error())) return r;
+            if (!grown) break;
+        }
+        // ---- the exchange: piece w of rank k's records to rank w, behind the pieces of the ranks before k
+        std::vector<uint64_t> got(n, 0);
+        for (uint32_t w = 0; w < n; ++w) {
+            for (uint32_t k = 0; k < n; ++k) got[w] += counts[k][w];
+            if (b->rec_recv_cap[w] < got[w] + 1) {
+                FPX_HIP(hipSetDevice(ss->ctxs[w]->device));
+                if (b->rec_recv[w]) { (void)hipFree(b->rec_recv[w]); b->rec_recv[w] = nullptr; b->rec_recv_cap[w] = 0; }
+                const uint64_t want = got[w] + got[w] / 8 + 1024;
+                FPX_HIP(hipMalloc(&b->rec_recv[w], want * sizeof(uint64_t)));
+                b->rec_recv_cap[w] = want;
+            }
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+            uint64_t src = 0;
+            for (uint32_t w = 0; w < n; ++w) {
+                uint64_t dst = 0;
+                for (uint32_t k2 = 0; k2 < k; ++k2) dst += counts[k2][w];
+                if (counts[k][w])
+                    FPX_HIP(hipMemcpyPeerAsync(b->rec_recv[w] + dst, ss->ctxs[w]->device, b->rec_send[k] + src, ss->ctxs[k]->device, counts[k][w] * sizeof(uint64_t), b->xs[k]));
+                src += counts[k][w];
+            }
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
+            FPX_HIP(hipStreamSynchronize(b->xs[k]));
+        }
+        // ---- every rank's tables of the docs it was dealt, then the merge on rank 0 (the tables: the segment-sharded mode's buffers)
+        ShardBufs* tb = nullptr;
+        {
+            std::lock_guard<std::mutex> g(ss->mu);
+            if (!ss->free_bufs.empty()) { tb = ss->free_bufs.back(); ss->free_bufs.pop_back(); }
+        }
+        if (!tb) tb = new (std::nothrow) ShardBufs();
+        if (!tb) return FPX_E_NOMEM;
+        auto tables = [&]() -> int {
+            int r2 = bufs_reserve(ss, tb, B, cap);
+            if (r2) return r2;
+            run_all([&](uint32_t k) -> int {
+                return score_records_impl(ss->ctxs[k], shares[k], b->rec_recv[k], got[k], timeout_ms, tb->d_part[k], cap, tb->d_cnt[k]);
+            });
+            if ((r2 = first_error())) return r2;
+            const int root = ss->ctxs[0]->device;
+            FPX_HIP(hipSetDevice(root));
+            for (uint32_t k = 1; k < n; ++k) {
+                FPX_HIP(hipMemcpyPeerAsync(tb->d_all + k * (size_t)B * cap, root, tb->d_part[k], ss->ctxs[k]->device, (size_t)B * cap * sizeof(fpx_result), tb->copy_stream));
+                FPX_HIP(hipMemcpyPeerAsync(tb->d_all_cnt + k * (size_t)B, root, tb->d_cnt[k], ss->ctxs[k]->device, (size_t)B * sizeof(uint32_t), tb->copy_stream));
+            }
+            if (n > 1) FPX_HIP(hipStreamSynchronize(tb->copy_stream));
+            if (timeout_ms && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count() > (double)timeout_ms) { set_error("search timeout"); return FPX_E_TIMEOUT; }
+            return merge_partials_impl(ss->ctxs[0], tb->d_all, tb->d_all_cnt, n, B, cap, opts, offsets, out, out_cap, out_n);
+        };
+        r = tables();
+        {
+            std::lock_guard<std::mutex> g(ss->mu);
+            if (ss->free_bufs.size() < 8) { ss->free_bufs.push_back(tb); tb = nullptr; }
+        }
+        if (tb) bufs_destroy(ss, tb);
+        return r;
+    };
+    bool records = false;
+    for (uint32_t q = 0; q < B && !records; ++q) {
+        const uint64_t len = offsets[q + 1] - offsets[q];
+        records = len > SHARD_DEDUP_MAX || (opts[q].has_min_score ? opts[q].min_score : (uint32_t)((len + 19) / 20)) <= 2u;
+    }
+    rc = records ? body_records() : body();
     for (uint32_t k = 0; k < n; ++k) if (shares[k]) query_batch_free(shares[k]);
     if (rc == FPX_OK && stats) {
         for (uint32_t k = 0; k < n; ++k) {

@@ -312,14 +312,18 @@ int  fpx_sharded_search_batch(fpx_sharded_snapshot *snap, const uint32_t *hashes
  *                                        hold the window's hashes + 3 halo blocks, src/FileSegment.zig:25,153-174; the whole docs
  *                                        map with every slice).  Replaces the end of filefmt.readSegment (src/filefmt.zig:270-284).
  *   fpx_sharded_snapshot_create_windows  slices[k * num_segs + j] = slice k of segment j (snapshot order, commit ids ascending);
- *                                        rank k's slices become one group with its window.  world: 1, 2, 4 .. 64.
+ *                                        rank k's slices become one group with its window.  world: 1, 2, 4 .. 64.  MEMORY segments
+ *                                        (fpx_segment_create_memory on ctxs[k], one copy per rank: a live index publishes one with every
+ *                                        update, src/Index.zig:515-587) take their place in the list like on one GPU; a rank looks up
+ *                                        the keys of its window in them.
  * fpx_sharded_search(_batch) on such a snapshot runs the routed-key protocol behind the one call: 1 / world of the batch's hashes
  * goes to each device (H2D), the devices make the keys of their share and deal them to the windows' ranks (all-to-all #1: RCCL
  * grouped send / recv over xGMI when every context has a device of its own, peer copies otherwise), every rank probes the keys of
  * ITS window and drops the records into the batch's bins, the bins travel to the rank their queries came from (all-to-all #2)
  * and that rank writes their final results straight into the caller's rows.  Same results as an unsharded snapshot of the whole
- * segments.  Batches the bin protocol does not take (a score floor of 1 or 2, queries of more than 2048 hashes) fail with
- * FPX_E_INVAL: a host that needs those keeps a segment-sharded snapshot next to this one. */
+ * segments.  Batches the bin protocol does not take (a score floor of 1 or 2 -- the legacy front end's options, src/legacy.zig:185-196 --,
+ * queries of more than 2048 hashes) run the RECORD protocol behind the same call: every rank probes its window with the whole batch,
+ * the hit records travel to the rank that counts their doc (doc & (world - 1)), the ranks' per-query tables are merged on rank 0. */
 int fpx_segment_create_file_windows(fpx_ctx *const *ctxs, uint32_t world,
                                     const uint8_t *blocks, size_t blocks_len, uint32_t block_size,
                                     const uint32_t *block_index, uint32_t num_blocks,

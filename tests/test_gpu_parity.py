@@ -88,7 +88,22 @@ def test_block_sizes(env, block_size):
     p.add_file(fpx.synth.synth_items(seed, 1, ndocs, H, dist=1), 1, ndocs, 1, np.arange(1, ndocs + 1), block_size=block_size)
     p.finish()
     qs, _ = _queries(fpx, seed, 32, ndocs, H, 120, dist=1)
-    p.check(qs, fpx.http_options())
+    got, st = p.check(qs, fpx.http_options())
+    # SURVEY 8(d)'s numerator: visited blocks x the SEGMENT's block size (src/filefmt.zig:29-31,71) -- in every storage form (the
+    # variants of tests/test_gpu_variants.py run this with the segment direct-addressed, alone and as a group's column)
+    assert st.scanned_blocks > 0 and st.algorithmic_bytes == st.scanned_blocks * block_size, (st.algorithmic_bytes, st.scanned_blocks, block_size)
+    # ... also with a second segment of ANOTHER block size in the snapshot (the two never share a group)
+    p2 = Pair(ctx)
+    p2.add_file(fpx.synth.synth_items(seed, 1, ndocs, H, dist=1), 1, ndocs, 1, np.arange(1, ndocs + 1), block_size=block_size)
+    p2.add_file(fpx.synth.synth_items(seed + 1, ndocs + 1, ndocs, H, dist=1), ndocs + 1, 2 * ndocs, 2, np.arange(ndocs + 1, 2 * ndocs + 1), block_size=512)
+    p2.finish()
+    singles = [oracle.Snapshot([sg], []) for sg in p2.orc_file]
+    want_bytes = 0
+    for q in qs[:12]:
+        for one, bs in zip(singles, (block_size, 512)):
+            want_bytes += one.search(q, with_stats=True)[1].scanned_blocks * bs
+    got2, st2 = p2.check(qs[:12], fpx.http_options())
+    assert st2.algorithmic_bytes == want_bytes, (st2.algorithmic_bytes, want_bytes)
     p.check(qs[:8], fpx.SearchOptions(500, 1, 10))
 
 

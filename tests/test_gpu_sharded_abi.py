@@ -183,15 +183,28 @@ def test_window_sharded_snapshot_routes_keys_behind_one_call(world, monkeypatch)
         blocks, index = full.add_file(items, mn, mx, s + 1, doc_ids, alive)
         for k, sl in enumerate(fpx.file_segment_windows(ctxs, blocks, 512, index, mn, mx, s + 1, doc_ids, alive)):
             slices[k].append(sl)
-    full.finish()
-    sh = fpx.ShardedIndexReader(fpx.WindowShardedSegments(ctxs, slices))
-    assert sh.snapshot.num_devices == world
     B = 200
     flat, off, _ = fpx.synth.make_queries(seed, 3, B, S * per, H, query_len=160, dist=1)
     flat = flat.copy()
     flat[9] = flat[8]                                                 # a duplicate hash inside a query
     queries = [flat[int(off[i]):int(off[i + 1])] for i in range(B)]
-    for opts in (fpx.http_options(), fpx.SearchOptions(500, 3, 10), fpx.SearchOptions(3, 4, 100)):
+    # a LIVE index: two memory segments on top (every Index.update publishes one, src/Index.zig:515-587; IndexReader.search walks them
+    # after the file segments, :173-175) -- new docs that match queries, an old doc re-inserted with other hashes (its file postings are
+    # superseded), a delete.  Every rank holds a copy of each memory segment and looks up the keys of its window in it.
+    q0, q1 = [int(h) for h in queries[0][:60]], [int(h) for h in queries[57][:90]]
+    for changes in ([("insert", 900001, q0), ("insert", 7, q1[:40]), ("delete", 11)],
+                    [("insert", 900002, q1), ("insert", 900001, q0[:30] + q1[:20]), ("delete", per + 3)]):
+        commit = len(full.gpu_segs) + 1
+        full.add_memory_changes(changes, commit)
+        m = full.orc_mem[-1]
+        ids, alive = m.docs()
+        for k in range(world):
+            slices[k].append(fpx.MemorySegment(ctxs[k], m.items(), m.min_doc_id, m.max_doc_id, commit, ids, alive))
+    full.finish()
+    sh = fpx.ShardedIndexReader(fpx.WindowShardedSegments(ctxs, slices))
+    assert sh.snapshot.num_devices == world
+    # (legacy options -- limit = max_results, min_score = 1, src/legacy.zig:185-196: the record protocol behind the same call)
+    for opts in (fpx.http_options(), fpx.SearchOptions(500, 3, 10), fpx.SearchOptions(3, 4, 100), fpx.SearchOptions(500, 1, 0)):
         want, wst = full.check(queries, opts, with_stats=False)
         for rep in range(2):                                          # (the slots' sizes settle on the first call)
             got, st = sh.search_batch(queries, opts)
@@ -204,9 +217,11 @@ def test_window_sharded_snapshot_routes_keys_behind_one_call(world, monkeypatch)
     assert got == [full.osnap.search(q) for q in queries[:5]]
     r = fpx.SearchResults(fpx.http_options())
     assert sh.search(queries[3], r) == full.osnap.search(queries[3])
-    # what the bin protocol does not take is refused, not answered wrongly
-    with pytest.raises(fpx.FpxError):
-        sh.search_batch(queries[:16], fpx.SearchOptions(500, 1, 10))
+    # one legacy-floor query in a batch sends the whole batch through the record protocol; the memory segments' docs are found
+    mixed = [fpx.http_options()] * 15 + [fpx.SearchOptions(500, 2, 10)]
+    got, _ = sh.search_batch(queries[:16], mixed)
+    assert got == [full.osnap.search(q, o.max_results, o.min_score, o.min_score_pct) for q, o in zip(queries[:16], mixed)]
+    assert 900001 in [d for d, _ in got[0]], got[0][:5]
     # many host threads on the one snapshot
     want = [full.osnap.search(q) for q in queries[:64]]
     errs = []

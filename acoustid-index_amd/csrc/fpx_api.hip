@@ -198,13 +198,56 @@ int finish_file_segment(Segment* s)
     return decode_small_segment(s);
 }
 
-uint32_t ctx_fuse_min(const Ctx* c)
+// ---- the option table: name (fpx_ctx_set_option), environment variable, default, smallest value a context may set
+struct OptInfo { const char* name; const char* env; int64_t dflt; int64_t min_set; bool env_once; };
+static const OptInfo OPT_TABLE[OPT_COUNT] = {
+    /* OPT_DIRECT */             {"direct", "FPX_DIRECT", 1, 0, false},                         // (the two the tests move between segments: read every time)
+    /* OPT_DIRECT_MIN_ITEMS */   {"direct_min_items", "FPX_DIRECT_MIN_ITEMS", 1ll << 20, 0, false},
+    /* OPT_FUSE_MIN */           {"fuse_min", "FPX_FUSE_MIN", 2, 0, true},
+    /* OPT_GROUP_PACKED */       {"group_packed", "FPX_GROUP_PACKED", -1, -1, false},
+    /* OPT_PRESENCE_MIN_ITEMS */ {"presence_min_items", "FPX_PRESENCE_MIN_ITEMS", 1ll << 20, 0, false},
+    /* OPT_LEAN_HEAD */          {"lean_head", "FPX_LEAN_HEAD", 0, 0, true},
+    /* OPT_INLINE_DOUBLES */     {"inline_doubles", "FPX_INLINE_DOUBLES", 1, 0, true},
+    /* OPT_MEMTAB */             {"memtab", "FPX_MEMTAB", 1, 0, true},
+    /* OPT_FAST */               {"fast", "FPX_FAST", 1, 0, true},
+    /* OPT_BINNED */             {"binned", "FPX_BINNED", 1, 0, true},
+    /* OPT_BIN_Q_LOG2 */         {"bin_q_log2", "FPX_BIN_Q_LOG2", -1, -1, true},
+    /* OPT_REC32 */              {"rec32", "FPX_REC32", 1, 0, true},
+    /* OPT_LOCAL_SORT_MAX */     {"local_sort_max", "FPX_LOCAL_SORT_MAX", 1ll << 20, 0, true},
+    /* OPT_ORDER_MIN_PAIRS */    {"order_min_pairs", "FPX_ORDER_MIN_PAIRS", 1ll << 17, 0, true},
+    /* OPT_ORDER_MAX_PAIRS */    {"order_max_pairs", "FPX_ORDER_MAX_PAIRS", 1ll << 20, 0, true},
+    /* OPT_LEAN_MIN */           {"lean_min", "FPX_LEAN_MIN", 1ll << 16, 0, true},
+    /* OPT_STAGED_OUT_MAX */     {"staged_out_max", "FPX_STAGED_OUT_MAX", -1, 0, true},        // (-1: the built-in STAGED_OUT_MAX of fpx_search.hip)
+    /* OPT_GROUP_ROUNDS */       {"group_rounds", "FPX_GROUP_ROUNDS", 0, 0, true},
+    /* OPT_DIRECT_ROUNDS */      {"direct_rounds", "FPX_DIRECT_ROUNDS", 0, 0, true},
+    /* OPT_LEAN_ROUNDS */        {"lean_rounds", "FPX_LEAN_ROUNDS", 0, 0, true},
+    /* OPT_SHARDED_WORKERS */    {"sharded_workers", "FPX_SHARDED_WORKERS", 3, 1, true},
+};
+
+int64_t ctx_opt(const Ctx* c, CtxOpt o)
 {
-    const int64_t o = c ? c->opt_fuse_min.load(std::memory_order_relaxed) : -2;
-    if (o >= 0) return (uint32_t)o;
-    static const uint32_t env = [] { const char* v = getenv("FPX_FUSE_MIN"); return v ? (uint32_t)atoi(v) : 2u; }();
-    return env;
+    const OptInfo& t = OPT_TABLE[o];
+    if (c) {
+        const int64_t v = c->opts[o].load(std::memory_order_relaxed);
+        if (v != OPT_UNSET) return v;
+    }
+    // the environment: once per process where a batch asks (a getenv per batch and option is not free), every time for the few
+    // options the tests move between two segments of one process
+    if (t.env_once) {
+        static std::atomic<int64_t> cache[OPT_COUNT];
+        static std::atomic<uint32_t> have{0};
+        if (!(have.load(std::memory_order_acquire) & (1u << o))) {
+            const char* e = getenv(t.env);
+            cache[o].store(e ? (int64_t)strtoll(e, nullptr, 0) : t.dflt, std::memory_order_relaxed);
+            have.fetch_or(1u << o, std::memory_order_release);
+        }
+        return cache[o].load(std::memory_order_relaxed);
+    }
+    const char* e = getenv(t.env);
+    return e ? (int64_t)strtoll(e, nullptr, 0) : t.dflt;
 }
+
+uint32_t ctx_fuse_min(const Ctx* c) { return (uint32_t)std::max<int64_t>(0, ctx_opt(c, OPT_FUSE_MIN)); }
 
 // what the block kernels need of a candidate that stays in blocks after all (no room for another form)
 static int settle_in_blocks(Segment* s)
@@ -400,33 +443,34 @@ int fpx_ctx_create(int device, fpx_ctx** out)
 
 int fpx_ctx_device(const fpx_ctx* ctx) { return ctx ? reinterpret_cast<const Ctx*>(ctx)->device : -1; }
 
-static std::atomic<int64_t>* ctx_option(Ctx* c, const char* name)
+static int opt_by_name(const char* name)
 {
-    if (!c || !name) return nullptr;
-    if (!std::strcmp(name, "direct")) return &c->opt_direct;
-    if (!std::strcmp(name, "direct_min_items")) return &c->opt_direct_min_items;
-    if (!std::strcmp(name, "fuse_min")) return &c->opt_fuse_min;
-    if (!std::strcmp(name, "group_packed")) return &c->opt_group_packed;
-    return nullptr;
+    if (!name) return -1;
+    for (int o = 0; o < OPT_COUNT; ++o) if (!std::strcmp(name, OPT_TABLE[o].name)) return o;
+    return -1;
 }
 
 int fpx_ctx_set_option(fpx_ctx* ctx, const char* name, int64_t value)
 {
-    std::atomic<int64_t>* o = ctx_option(reinterpret_cast<Ctx*>(ctx), name);
-    if (!o) { set_error("fpx_ctx_set_option: unknown option (direct, direct_min_items, fuse_min, group_packed)"); return FPX_E_INVAL; }
-    o->store(value < -1 ? -2 : value);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    const int o = opt_by_name(name);
+    if (!c || o < 0) {
+        std::string all;
+        for (int i = 0; i < OPT_COUNT; ++i) { if (i) all += ", "; all += OPT_TABLE[i].name; }
+        set_error("fpx_ctx_set_option: unknown option (%s)", all.c_str());
+        return FPX_E_INVAL;
+    }
+    // below the option's smallest value: back to the fallback (environment variable, then default)
+    c->opts[o].store(value < OPT_TABLE[o].min_set ? OPT_UNSET : value, std::memory_order_relaxed);
     return FPX_OK;
 }
 
 int fpx_ctx_get_option(const fpx_ctx* ctx, const char* name, int64_t* value)
 {
-    Ctx* c = const_cast<Ctx*>(reinterpret_cast<const Ctx*>(ctx));
-    if (!ctx_option(c, name) || !value) { set_error("fpx_ctx_get_option: unknown option"); return FPX_E_INVAL; }
-    // the value in force: the context's own, else the environment's, else the default
-    if (!std::strcmp(name, "direct")) *value = ctx_direct_enabled(c) ? 1 : 0;
-    else if (!std::strcmp(name, "direct_min_items")) *value = (int64_t)ctx_direct_min_items(c);
-    else if (!std::strcmp(name, "fuse_min")) *value = (int64_t)ctx_fuse_min(c);
-    else *value = ctx_group_packed(c);
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    const int o = opt_by_name(name);
+    if (!c || o < 0 || !value) { set_error("fpx_ctx_get_option: unknown option"); return FPX_E_INVAL; }
+    *value = ctx_opt(c, (CtxOpt)o);         // the value in force: the context's own, else the environment's, else the default
     return FPX_OK;
 }
 

@@ -747,11 +747,7 @@ __global__ __launch_bounds__(256) void k_presence_bits(const uint8_t* __restrict
 }
 
 // the segments the lean kernel takes (smaller ones are kept decoded and probed block-wise, where a bitmap buys nothing)
-static uint64_t presence_min_items()
-{
-    const char* e = getenv("FPX_PRESENCE_MIN_ITEMS");          // read per segment: the tests move it
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 20);
-}
+static uint64_t presence_min_items(const Ctx* c) { return (uint64_t)std::max<int64_t>(0, ctx_opt(c, OPT_PRESENCE_MIN_ITEMS)); }
 
 // {block_index[b], header min_hash} per block, three all-ones sentinels behind; head_max = the largest end (in bytes) of
 // header + hash control + hash data + docid control bytes over all blocks (src/block.zig:46-50: docids_offset at byte 6)
@@ -813,7 +809,7 @@ int build_presence(Segment* s)
     if (he != hipSuccess) return hip_fail(he, "block records");
     FPX_HIP(hipGetLastError());
     // (the docid control bytes are read as one dword per lane: 4 bytes of slack)
-    static const int forced_head = [] { const char* e = getenv("FPX_LEAN_HEAD"); return e ? atoi(e) : 0; }();
+    const int forced_head = (int)ctx_opt(s->ctx, OPT_LEAN_HEAD);
     s->head_lines = (head_max + 4u <= 256u && forced_head != 4) ? 2u : 4u;
     // one presence bit per 2^shift hash values, the largest shift that leaves >= 5.7 bits per item (<= 16 % of them set,
     // 16 % on top of the blocks' bytes); a segment of more than 2^32 / 5.7 items gets shift 0 (1.6 G items: 31 % set).
@@ -829,7 +825,7 @@ int build_presence(Segment* s)
     if (hipMalloc(&s->d_proberec, bytes) != hipSuccess) { s->d_proberec = nullptr; (void)hipGetLastError(); return FPX_OK; }
     FPX_HIP(hipMemsetAsync(s->d_proberec, 0, bytes, 0));
     // FPX_PRESENCE_MIN_ITEMS above the segment's size: every bit set, i.e. every probe reads its block (tests, A/B runs)
-    const bool with_bits = s->num_items >= presence_min_items();
+    const bool with_bits = s->num_items >= presence_min_items(s->ctx);
     if (with_bits)
         hipLaunchKernelGGL(k_presence_bits, dim3((s->num_blocks + 3) / 4), dim3(256), 0, 0,
                            s->d_blocks, s->block_size, s->num_blocks, s->d_proberec, shift);
@@ -926,10 +922,25 @@ __device__ __forceinline__ uint64_t direct_rank(const uint32_t* __restrict__ dre
 //   the offset counts words, or -- pad = 1, for a segment with more than 2^31 words of lists (beyond ~2.2 G items) -- PAIRS of
 //   words, its lists starting at even words (Segment::extras_shift)
 // (the words of GAP positions keep the 0xFFFFFFFF they were initialised with)
+// (a hot hash's list -- thousands to millions of docs -- is not copied by the one thread that owns its first block: it is queued for
+// k_direct_copy_long, a workgroup per list.  Distribution Z at 100 M docs: the lists of the hot pool took the conversion from 24 to 54 s.)
+struct DirectLong { uint64_t src, dst, cnt; };
+constexpr uint64_t DIRECT_LONG = 256;          // docs from which a list is copied by a workgroup
+__global__ __launch_bounds__(256) void k_direct_copy_long(const uint64_t* __restrict__ items, uint32_t min_doc, uint32_t* __restrict__ extras,
+                                                          const DirectLong* __restrict__ longq, const unsigned int* __restrict__ long_n, uint32_t long_cap)
+{
+    const uint32_t nq = min(*long_n, long_cap);
+    for (uint32_t e = blockIdx.x; e < nq; e += gridDim.x) {
+        const DirectLong q = longq[e];
+        for (uint64_t t = threadIdx.x; t < q.cnt; t += 256u) extras[q.dst + t] = (uint32_t)items[q.src + t] - min_doc;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict__ items, uint64_t n, const uint64_t* __restrict__ boff,
                                                      uint32_t nb, uint32_t min_doc, const uint32_t* __restrict__ drec,
                                                      const uint64_t* __restrict__ xbase, uint32_t* __restrict__ primary,
-                                                     uint32_t* __restrict__ extras, uint32_t pad, HashRange hr)
+                                                     uint32_t* __restrict__ extras, uint32_t pad, HashRange hr,
+                                                     DirectLong* __restrict__ longq, unsigned int* __restrict__ long_n, uint32_t long_cap)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
@@ -949,7 +960,10 @@ __global__ __launch_bounds__(256) void k_direct_fill(const uint64_t* __restrict_
                 primary[r] = 0x80000000u | (uint32_t)(x >> pad);
                 extras[x++] = ri.eff | (ri.vis << 16) | (T << 19);
                 if (T) extras[x++] = (uint32_t)cnt;
-                for (uint64_t t = 0; t < cnt; ++t) extras[x++] = (uint32_t)items[i + t] - min_doc;
+                unsigned int slot = 0xFFFFFFFFu;
+                if (cnt >= DIRECT_LONG && longq) slot = atomicAdd(long_n, 1u);
+                if (slot < long_cap) { longq[slot] = DirectLong{i, x, cnt}; x += cnt; }
+                else for (uint64_t t = 0; t < cnt; ++t) extras[x++] = (uint32_t)items[i + t] - min_doc;
                 if (pad && (x & 1ull)) extras[x++] = 0u;
             } else {
                 primary[r] = (uint32_t)it - min_doc;
@@ -1013,24 +1027,12 @@ __global__ __launch_bounds__(256) void k_direct_rec_base(uint32_t* __restrict__ 
 
 __global__ void k_boff_tail(uint64_t* boff, uint32_t nb, const uint64_t* total) { boff[nb] = *total; }
 
-bool ctx_direct_enabled(const Ctx* c)
-{
-    const int64_t o = c ? c->opt_direct.load(std::memory_order_relaxed) : -2;
-    if (o >= 0) return o != 0;
-    const char* e = getenv("FPX_DIRECT");                       // read per segment: the tests move it
-    return e ? atoi(e) != 0 : true;
-}
-uint64_t ctx_direct_min_items(const Ctx* c)
-{
-    const int64_t o = c ? c->opt_direct_min_items.load(std::memory_order_relaxed) : -2;
-    if (o >= 0) return (uint64_t)o;
-    // from the size at which the block form would get probe records and the lean kernel: that kernel costs a batch ~0.3 ms per
-    // segment whatever the segment's size (its probes' record lines), the direct form -- one more column of the snapshot's
-    // fused directory -- next to nothing for the hashes a small segment does not have; it costs 1.07 GB of records + up to
-    // 0.27 GB of gap positions per segment
-    const char* e = getenv("FPX_DIRECT_MIN_ITEMS");
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 20);
-}
+bool ctx_direct_enabled(const Ctx* c) { return ctx_opt(c, OPT_DIRECT) != 0; }
+// (default 2^20: from the size at which the block form would get probe records and the lean kernel: that kernel costs a batch ~0.3 ms
+// per segment whatever the segment's size (its probes' record lines), the direct form -- one more column of the snapshot's fused
+// directory -- next to nothing for the hashes a small segment does not have; it costs 1.07 GB of records + up to 0.27 GB of gap
+// positions per segment)
+uint64_t ctx_direct_min_items(const Ctx* c) { return (uint64_t)std::max<int64_t>(0, ctx_opt(c, OPT_DIRECT_MIN_ITEMS)); }
 
 // item offsets of the blocks [b0, b0 + nbl] relative to block b0, 64-bit (what the conversion kernels index `items` with)
 __global__ void k_local_boff(const uint32_t* __restrict__ bstart, uint32_t nbl, uint64_t* __restrict__ boff)
@@ -1179,8 +1181,19 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     FPX_HIP(hipMalloc(&out->extras, (X + 8) * sizeof(uint32_t)));
     FPX_HIP(hipMemsetAsync(out->primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
     FPX_HIP(hipMemsetAsync(out->extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
+    // (at most n / DIRECT_LONG lists are that long; a queue that cannot be had -- memory -- leaves the copies to k_direct_fill's threads)
+    const uint32_t long_cap = (uint32_t)std::min<uint64_t>(n / DIRECT_LONG + 16, 1u << 22);
+    DevBuf longq;
+    DirectLong* d_longq = longq.alloc((size_t)long_cap * sizeof(DirectLong) + 16) == FPX_OK ? longq.as<DirectLong>() : nullptr;
+    unsigned int* d_long_n = d_longq ? reinterpret_cast<unsigned int*>(d_longq + long_cap) : nullptr;
+    (void)hipGetLastError();
+    if (d_long_n) FPX_HIP(hipMemsetAsync(d_long_n, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k_direct_fill, dim3((nbl + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nbl,
-                       s->min_doc_id, (const uint32_t*)out->drec, xbase.as<uint64_t>(), out->primary, out->extras, pad, hr);
+                       s->min_doc_id, (const uint32_t*)out->drec, xbase.as<uint64_t>(), out->primary, out->extras, pad, hr,
+                       d_longq, d_long_n, d_longq ? long_cap : 0u);
+    if (d_longq)
+        hipLaunchKernelGGL(k_direct_copy_long, dim3(std::min<uint32_t>(long_cap, 4096u)), dim3(256), 0, st, items.as<uint64_t>(), s->min_doc_id, out->extras,
+                           (const DirectLong*)d_longq, (const unsigned int*)d_long_n, long_cap);
     FPX_HIP(hipGetLastError());
     FPX_HIP(hipStreamSynchronize(st));
     out->distinct = D; out->positions = Dp; out->extras_words = X;

@@ -18,13 +18,7 @@
 
 namespace fpx {
 
-int ctx_group_packed(const Ctx* c)
-{
-    const int64_t o = c ? c->opt_group_packed.load(std::memory_order_relaxed) : -2;
-    if (o >= -1) return (int)o;
-    const char* e = getenv("FPX_GROUP_PACKED");
-    return e ? atoi(e) : -1;
-}
+int ctx_group_packed(const Ctx* c) { return (int)ctx_opt(c, OPT_GROUP_PACKED); }      // -1: by the group's density
 
 Group::~Group()
 {
@@ -472,7 +466,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     out->reset();
     if (k == 0 || k > FUSE_MAX) { set_error("a group holds 1..16 segments"); return FPX_E_INVAL; }
     FPX_HIP(hipSetDevice(ctx->device));
-    static const bool inline_doubles = [] { const char* e = getenv("FPX_INLINE_DOUBLES"); return e ? atoi(e) != 0 : true; }();
+    const bool inline_doubles = ctx_opt(ctx, OPT_INLINE_DOUBLES) != 0;
     const uint32_t ns = k <= 8u ? 8u : 16u;
     // the window: hashes in (own_lo, own_hi] (a slice of an index sharded by hash range), the same for every member
     uint32_t win_lo = 0u, win_hi = 0xFFFFFFFFu;

@@ -302,11 +302,24 @@ struct QueryBatch {
     std::vector<fpx_opts> opts;
 };
 
+// Everything that steers the library's behaviour is an OPTION OF A CONTEXT (fpx_ctx_set_option / fpx_ctx_get_option): the value the
+// context was given, else the environment variable FPX_<NAME> (the tests' and the A/B tools' way in), else the built-in default.
+// Thresholds that decide a storage form or a kernel path belong to the index, not to the process's environment.
+enum CtxOpt : int {
+    OPT_DIRECT, OPT_DIRECT_MIN_ITEMS, OPT_FUSE_MIN, OPT_GROUP_PACKED,            // storage forms (read when a segment is created / first held)
+    OPT_PRESENCE_MIN_ITEMS, OPT_LEAN_HEAD, OPT_INLINE_DOUBLES, OPT_MEMTAB,
+    OPT_FAST, OPT_BINNED, OPT_BIN_Q_LOG2, OPT_REC32,                             // search paths (read per batch)
+    OPT_LOCAL_SORT_MAX, OPT_ORDER_MIN_PAIRS, OPT_ORDER_MAX_PAIRS, OPT_LEAN_MIN, OPT_STAGED_OUT_MAX,
+    OPT_GROUP_ROUNDS, OPT_DIRECT_ROUNDS, OPT_LEAN_ROUNDS,
+    OPT_SHARDED_WORKERS,
+    OPT_COUNT
+};
+constexpr int64_t OPT_UNSET = -2;
+
 struct Ctx {
     int device = 0;
-    // how this context keeps its file segments in HBM (fpx_ctx_set_option; below -1: the environment variable of the same name,
-    // then the built-in default) -- thresholds that decide a storage form belong to the index, not to the process's environment
-    std::atomic<int64_t> opt_direct{-2}, opt_direct_min_items{-2}, opt_fuse_min{-2}, opt_group_packed{-2};
+    std::atomic<int64_t> opts[OPT_COUNT];
+    Ctx() { for (auto& o : opts) o.store(OPT_UNSET, std::memory_order_relaxed); }
     std::mutex mu;
     std::mutex group_mu;                  // serialises the grouping of segments (fpx_snapshot_create, fpx_segments_group)
     std::vector<Workspace*> free_ws;
@@ -314,6 +327,7 @@ struct Ctx {
 };
 
 // the options of a context (fpx_ctx_set_option), falling back to the environment and the defaults
+int64_t ctx_opt(const Ctx* c, CtxOpt o);   // the value in force (c may be null: environment, then default)
 bool ctx_direct_enabled(const Ctx* c);
 uint64_t ctx_direct_min_items(const Ctx* c);
 uint32_t ctx_fuse_min(const Ctx* c);

@@ -45,6 +45,16 @@ constexpr uint32_t PK_WORDS = FPX_PK_WORDS; // words of a hash walked by its lan
 #ifndef FPX_PK_WAVES
 #define FPX_PK_WAVES 5
 #endif
+// The next round's line heads are fetched while this round's records are flushed.  A wave of this kernel spends 72 % of its life
+// parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r05_sq_counters.txt: its VALU is busy a fifth of the time): a round is a CHAIN of
+// latencies -- key, line head (HBM), words, list head (HBM), stage, bin reservations (memory-side atomics), stores -- and only five
+// waves per SIMD to overlap them.  0: off.  1: the head waits in registers (three more per lane).  2: the head goes straight into
+// LDS (global_load_lds_dwordx4: a gather of 16 bytes per lane into the wave's 1 KB of LDS, no register held while it is under way).
+#ifndef FPX_PK_PREFETCH
+#define FPX_PK_PREFETCH 2
+#endif
+// (dynamic LDS behind the stage -- launch_probe_group --: a line head of 16 bytes and a key of 2 x 4 bytes per lane)
+constexpr uint32_t PK_HEAD_LDS = FPX_PK_PREFETCH == 2 ? FK_WG * 16u + FK_WG * 8u : 0u;
 #define FPX_PK_OCC __attribute__((amdgpu_waves_per_eu(FPX_PK_WAVES, FPX_PK_WAVES)))
 template <int NS, bool BINNED, bool QS>
 __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, GroupArgs ga)
@@ -92,25 +102,115 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     const uint64_t P = a.P_dev ? min((uint64_t)a.P_dev[blockIdx.y], a.P) : a.P;
 
     const uint64_t wg_base = (uint64_t)blockIdx.x * (uint64_t)FK_WG * a.rounds;
+    // a round's key: is it a probe at all (dedupSorted, src/Index.zig:489-499: flagged by k_make_keys_dedup, or found by looking back;
+    // a hash-window slice of the group -- the index sharded by hash range -- leaves the other hashes to another rank), and its line
+    // (a lane's key by its 32-bit number inside the workgroup's run of keys: no 64-bit value per lane is carried across a round)
+    const uint64_t* const wg_pairs = pairs + wg_base;
+    const uint32_t wg_n = (uint32_t)min<uint64_t>(P > wg_base ? P - wg_base : 0ull, (uint64_t)FK_WG * a.rounds);
+    auto key_valid = [&](uint32_t i, uint64_t key) -> bool {
+        if (i >= wg_n) return false;
+        if ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(pairs, wg_base + i, key, a.qb, a.key_skip)) return false;
+        const uint32_t h = (uint32_t)(key >> a.qb);
+        return h >= g->win_lo && h <= g->win_hi;
+    };
+    auto line_of = [&](uint64_t key) -> const uint32_t* { return g->lines + (size_t)(((uint32_t)(key >> a.qb) >> HVL) - g->line0) * GROUP_LINE_WORDS; };
+#if FPX_PK_PREFETCH == 1
+    uint64_t key_n = 0;                                    // the next round's key, and whether it is a probe
+    bool valid_n = false;
+    uint32_t hd_nx = 0, hd_ny = 0, hd_nz = 0;
+    auto fetch_head = [&](bool v, const uint32_t* line) {
+        hd_nx = 0; hd_ny = 0; hd_nz = 0;
+        if (v) { const uint4 t = gload_u4(reinterpret_cast<const uint8_t*>(line)); hd_nx = t.x; hd_ny = t.y; hd_nz = t.z; }
+    };
+    {
+        key_n = tid < wg_n ? gload_u64(wg_pairs + tid) : 0ull;
+        valid_n = key_valid(tid, key_n);
+        fetch_head(valid_n, line_of(key_n));
+    }
+#elif FPX_PK_PREFETCH == 2
+    // Behind the stage: this wave's 64 line heads of 16 bytes, and (for the whole workgroup) the keys' low and high words.  A gather
+    // into LDS writes lane l's piece at M0 + l x its size; nothing of the next round is held in a register while this round is worked on.
+    uint8_t* const head_lds = gk_dyn + (size_t)FSTAGE_CAP * sizeof(uint64_t);
+    uint32_t* const key_lds = reinterpret_cast<uint32_t*>(head_lds + FK_WG * 16u);           // [2][FK_WG]
+    const uint32_t wave0 = tid & ~63u;
+    const uint32_t head_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(head_lds + wave0 * 16u));
+    const uint32_t klo_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(key_lds + wave0));
+    const uint32_t khi_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(key_lds + FK_WG + wave0));
+    auto fetch_head = [&](bool v, const uint32_t* line) {
+        if (v) {
+            uint32_t m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "s"(head_m0), "v"((const FPX_GLOBAL uint8_t*)line) : "memory");
+        }
+    };
+    auto fetch_key = [&](uint32_t i) {                    // (lanes past the batch's end fetch nothing: key_valid looks at the number first)
+        if (i < wg_n) {
+            uint32_t m0_saved;
+            // (no instruction offset: it would move the LDS address with the memory address)
+            const FPX_GLOBAL uint32_t* kw = (const FPX_GLOBAL uint32_t*)(wg_pairs + i);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\t"
+                         "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %4, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "s"(klo_m0), "s"(khi_m0), "v"(kw), "v"(kw + 1) : "memory");
+        }
+    };
+    auto take_key = [&]() -> uint64_t {                   // (after the gathers have landed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return ((uint64_t)key_lds[FK_WG + tid] << 32) | key_lds[tid];
+    };
+    bool valid_n = false;
+    {
+        fetch_key(tid);
+        const uint64_t k0 = take_key();
+        valid_n = key_valid(tid, k0);
+        fetch_head(valid_n, line_of(k0));
+    }
+#endif
     for (uint32_t round = 0; round < a.rounds; ++round) {
-        const uint64_t p = wg_base + (uint64_t)round * FK_WG + tid;
-        bool valid = p < P;
-        const uint64_t key = valid ? gload_u64(pairs + p) : 0ull;
-        // dedupSorted, src/Index.zig:489-499: flagged by k_make_keys_dedup, or found by looking back
-        if (valid && ((a.key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(pairs, p, key, a.qb, a.key_skip))) valid = false;
+        const uint32_t ki = round * FK_WG + tid;
+#if FPX_PK_PREFETCH == 1
+        const uint64_t key = key_n;
+        bool valid = valid_n;
+#elif FPX_PK_PREFETCH == 2
+        // (the key and the line head of this round were sent for during the last one; the key is read again here -- two LDS words --
+        // rather than kept: the kernel has no register to spare at five waves per SIMD)
+        const uint64_t key_l = take_key();
+        const uint64_t key = ki < wg_n ? key_l : 0ull;
+        bool valid = valid_n;
+#else
+        const uint64_t key = ki < wg_n ? gload_u64(wg_pairs + ki) : 0ull;
+        bool valid = key_valid(ki, key);
+#endif
         const uint32_t h = (uint32_t)(key >> a.qb);
         const uint32_t blocks_before = QS ? my_blocks : 0u, docs_before = QS ? my_docs : 0u;
-        // a hash-window slice of the group (the index sharded by hash range): the other hashes are another rank's probes
-        if (h < g->win_lo || h > g->win_hi) valid = false;
         const uint64_t qpart = (uint64_t)((uint32_t)key & qmask) << 32;
         // ---- the head of the line: position bits, double flags (and the line's first word)
-        const uint32_t* lp = g->lines + (size_t)((h >> HVL) - g->line0) * GROUP_LINE_WORDS;
+        const uint32_t* lp = line_of(key);
         uint4 hd = make_uint4(0, 0, 0, 0);
+#if FPX_PK_PREFETCH == 1
+        hd.x = hd_nx; hd.y = hd_ny; hd.z = hd_nz;
+#elif FPX_PK_PREFETCH == 2
+        {
+            uint32_t ht = tid;                      // (opaque: the slot's address is formed here, not hoisted out of the round loop and spilled)
+            asm volatile("" : "+v"(ht));
+            const uint4 t = *reinterpret_cast<const uint4*>(head_lds + ht * 16u);         // (take_key has waited for the gathers)
+            if (valid) hd = t;
+        }
+#else
+        if (valid) hd = gload_u4(reinterpret_cast<const uint8_t*>(lp));
+#endif
         if (valid) {
-            hd = gload_u4(reinterpret_cast<const uint8_t*>(lp));
             my_probes += nactive;
             my_reads += 2u;                        // (64-byte units: a line)
         }
+#if FPX_PK_PREFETCH
+        // the next round's key: under way while this round's words are walked
+        const bool more_rounds = round + 1u < a.rounds;
+#if FPX_PK_PREFETCH == 1
+        if (more_rounds) key_n = ki + FK_WG < wg_n ? gload_u64(wg_pairs + ki + FK_WG) : 0ull;
+#else
+        if (more_rounds) fetch_key(ki + FK_WG);        // (this round's key and head have been read: their slots are free)
+#endif
+#endif
         const uint32_t* ext = s_ext[valid ? (h >> GROUP_CHUNK_LOG2) - g->chunk0 : 0u];
         // ---- the hash's columns: which have it, where its words start
         const uint64_t bits = ((uint64_t)hd.y << 32) | hd.x;
@@ -161,9 +261,10 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             // Words behind the line's 28th live in `ext`: the few lanes that have some fetch them one by one (not a turn of the wave)
             if (valid && nwords <= PK_WORDS && start + nwords > inl) {
                 const uint32_t ovf = gload_u32(lp + (GROUP_LINE_WORDS - 1u));
+                const uint32_t* ob = ext + ovf + start - inl;        // (x2: ONE 64-bit base, word j at an immediate offset of its load)
 #pragma unroll
                 for (uint32_t j = 0; j < PK_WORDS; ++j)
-                    if (j >= mine && j < nwords) gw[j] = gload_u32(ext + ovf + (start + j - inl));      // (j >= mine: start + j >= inl)
+                    if (j >= mine && j < nwords) gw[j] = gload_u32(ob + j);      // (j >= mine: start + j >= inl)
                 mine_w = nwords;
             }
 #pragma unroll
@@ -460,6 +561,18 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                 }
             }
         }
+#if FPX_PK_PREFETCH == 1
+        // ---- the next round's line head sets out now: it travels while this round's records are ranked, reserved and stored
+        valid_n = more_rounds && key_valid((round + 1u) * FK_WG + tid, key_n);
+        if (more_rounds) fetch_head(valid_n, line_of(key_n));
+#elif FPX_PK_PREFETCH == 2
+        valid_n = false;
+        if (more_rounds) {
+            const uint64_t kn = take_key();
+            valid_n = key_valid((round + 1u) * FK_WG + tid, kn);
+            fetch_head(valid_n, line_of(kn));
+        }
+#endif
         if constexpr (!BINNED) {
             fused_flush(hs, a, round + 1u == a.rounds, tid);
         } else {

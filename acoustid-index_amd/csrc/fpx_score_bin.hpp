@@ -22,6 +22,25 @@ constexpr uint32_t SB_QL_SHIFT = 26;               // table slot: doc << 32 | qu
 constexpr uint32_t SB_NEED_MARK = 0x40000000u;     // FPX_SHARD_NEED_MARK: a travelling count that says "my bins need this many cells" instead of a size
 constexpr uint32_t SB_CAND = 32;                   // candidates of a query gathered in LDS before they move to the shared list
 
+// The (query-in-bin, doc) hash of the counting filter and the exact table.  k_score_bin is bound by its own instruction stream (two
+// passes over a bin's ~40 000 records, a hash per record and pass): mix32 over (doc ^ ql * c) is three 32-bit multiplies -- quarter
+// rate on this chip --, the class test of an over-full bin three more, computed for every record whether the bin is classed or not.
+// 1: ONE multiply (Fibonacci hashing; the fold brings the product's high bits down to the cell / slot / pass fields), and the class
+// test only in the instantiation of the record loops that a classed bin takes.  The filter and the table stay exact by construction
+// (a cell can only over-count; the table compares whole keys), so the hash decides speed alone.
+#ifndef FPX_SB_HASH
+#define FPX_SB_HASH 1
+#endif
+__device__ __forceinline__ uint32_t sb_hash(uint32_t doc, uint32_t ql)
+{
+#if FPX_SB_HASH == 0
+    return mix32(doc ^ (ql * 0x9E3779B1u));
+#else
+    uint32_t x = (doc ^ (ql << 26) ^ (ql << 13)) * 0x9E3779B1u;          // (ql < 64)
+    return x ^ (x >> 15);
+#endif
+}
+
 struct ScoreBinArgs {
     const uint64_t* bins; uint64_t bin_cap; const unsigned int* bin_count;      // as BinArgs; bin_cap in 8-byte CELLS (two 4-byte records each)
     uint32_t rec_mode;                             // 0: 8-byte records; 1: 4-byte records (bin_record32); 2: per piece -- bit 31 of the piece's count says
@@ -155,15 +174,18 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
             K = (uint32_t)max<uint64_t>(1ull, min<uint64_t>((n + F - 1ull) / F, 1024ull));
         }
         auto cell_count = [&](uint32_t c) -> uint32_t { return wide ? filter[c] : ((filter[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu); };
+        // (the body once per instantiation: CL = the bin is counted in K > 1 classes of docs)
+        auto classes = [&](auto cl_tag) {
+        constexpr bool CL = decltype(cl_tag)::value || FPX_SB_HASH == 0;
         for (uint32_t kc = 0; kc < K; ++kc) {
-            auto in_class = [&](uint32_t doc) -> bool { return K == 1u || __umulhi(mix32(doc ^ 0x85EBCA6Bu), K) == kc; };
+            auto in_class = [&](uint32_t doc) -> bool { if constexpr (CL) return K == 1u || __umulhi(mix32(doc ^ 0x85EBCA6Bu), K) == kc; else return true; };
             for (uint32_t i = tid; i < (1u << (SB_FILTER_LOG2 - 1u)); i += SB_WG) filter[i] = 0u;
             __syncthreads();
             // ---- stage A: every record of the class into its (query, doc) cell
             for_each_record([&](uint64_t rec) {
                 const uint32_t doc = (uint32_t)rec, ql = (uint32_t)(rec >> 32) & qm;
                 if (!in_class(doc)) return;
-                const uint32_t c = mix32(doc ^ (ql * 0x9E3779B1u)) & fmask;
+                const uint32_t c = sb_hash(doc, ql) & fmask;
                 if (wide) atomicAdd(&filter[c], 1u); else atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
             });
             __syncthreads();
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                 for_each_record([&](uint64_t rec) {
                     const uint32_t doc = (uint32_t)rec, ql = (uint32_t)(rec >> 32) & qm;
                     if (!in_class(doc)) return;
-                    const uint32_t hsh = mix32(doc ^ (ql * 0x9E3779B1u));
+                    const uint32_t hsh = sb_hash(doc, ql);
                     const uint32_t cc = cell_count(hsh & fmask);
                     if (cc < floor_min) return;                        // (the bin's smallest floor, in a register: nearly every record leaves here)
                     if (cc < s_floor[ql]) return;
@@ -228,6 +250,8 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                 __syncthreads();
             }
         }
+        };
+        if (K == 1u) classes(std::false_type{}); else classes(std::true_type{});
     }
     // ---- hand-over: up to QCAND_SLOTS candidates stay in the query's own slots, more move to the shared list entirely
     __syncthreads();

@@ -90,8 +90,7 @@ int build_memtab(Snapshot* sn)
     uint64_t total = 0, mmax = 0;
     for (const MemDesc& m : sn->h_mem) { total += m.num_items; mmax = std::max<uint64_t>(mmax, m.num_items); }
     if (total == 0 || total >= 0xFFFFFFF0ull) return FPX_OK;            // (nothing to look up / offsets would not fit: the per-segment kernels)
-    static const bool enabled = [] { const char* e = getenv("FPX_MEMTAB"); return e ? atoi(e) != 0 : true; }();
-    if (!enabled) return FPX_OK;
+    if (ctx_opt(sn->ctx, OPT_MEMTAB) == 0) return FPX_OK;
     uint64_t* buf[2] = {nullptr, nullptr};
     unsigned long long* d_count = nullptr;
     void* d_temp = nullptr;
@@ -149,8 +148,8 @@ static int grow_pair(uint64_t* p[2], size_t* cap, size_t need)
 static void launch_probe_group(bool packed, bool ns8, bool binned, bool qs, dim3 grid, hipStream_t st, const ProbeArgs& a, const GroupArgs& g)
 {
     const size_t dyn = (size_t)FSTAGE_CAP * sizeof(uint64_t) + (binned ? (size_t)FSTAGE_CAP * sizeof(uint16_t) : 0u);       // stage (+ ranks)
-    if (packed) {                                 // a dense group: its words live in its lines (fpx_pgroup.hpp)
-#define FPX_LPP(NS, BN, QSV) hipLaunchKernelGGL((k_probe_pgroup<NS, BN, QSV>), grid, dim3(FK_WG), dyn, st, a, g)
+    if (packed) {                                 // a dense group: its words live in its lines (fpx_pgroup.hpp; + the prefetched line heads)
+#define FPX_LPP(NS, BN, QSV) hipLaunchKernelGGL((k_probe_pgroup<NS, BN, QSV>), grid, dim3(FK_WG), (size_t)FSTAGE_CAP * sizeof(uint64_t) + PK_HEAD_LDS, st, a, g)
         if (ns8) {
             if (binned) { if (qs) FPX_LPP(8, true, true); else FPX_LPP(8, true, false); }
             else { if (qs) FPX_LPP(8, false, true); else FPX_LPP(8, false, false); }
@@ -320,10 +319,11 @@ static int stage_results(Workspace* ws, uint32_t B, uint32_t out_cap, hipStream_
     return FPX_OK;
 }
 // the same staging, filled by k_finish itself: where it writes a batch's counts and results (mapped addresses of h_out)
-static int staged_targets(Workspace* ws, uint32_t B, uint32_t out_cap, bool* staged, uint32_t** d_n, fpx_result** d_res)
+static int staged_targets(Workspace* ws, const Ctx* ctx, uint32_t B, uint32_t out_cap, bool* staged, uint32_t** d_n, fpx_result** d_res)
 {
     const size_t bytes = (size_t)B * sizeof(uint32_t) + (size_t)B * out_cap * sizeof(fpx_result);
-    static const size_t staged_max = [] { const char* e = getenv("FPX_STAGED_OUT_MAX"); return e ? (size_t)strtoull(e, nullptr, 0) : STAGED_OUT_MAX; }();
+    const int64_t staged_opt = ctx_opt(ctx, OPT_STAGED_OUT_MAX);
+    const size_t staged_max = staged_opt < 0 ? STAGED_OUT_MAX : (size_t)staged_opt;
     *staged = bytes <= staged_max;
     if (!*staged) return FPX_OK;
     if (bytes > ws->cap_h_out) {
@@ -357,11 +357,7 @@ static int deliver_results(Workspace* ws, uint32_t B, uint32_t out_cap, bool sta
 // ------------------------------------------------------------------------------------------------
 // `offsets` are absolute positions into the batch the view [q0, q0+B) belongs to; `hashes` (host) points at
 // absolute position 0 and is only read when the batch is not resident.
-static uint64_t lean_min_probes()
-{
-    static const uint64_t v = [] { const char* e = getenv("FPX_LEAN_MIN"); return e ? strtoull(e, nullptr, 0) : (1ull << 16); }();
-    return v;
-}
+static uint64_t lean_min_probes(const Ctx* c) { return (uint64_t)std::max<int64_t>(0, ctx_opt(c, OPT_LEAN_MIN)); }
 
 // Hash-range sharding of one segment (second mode) cuts the pipeline at the hit records: a doc's
 // postings may come from several GPUs, so the records travel (grouped by doc & (world - 1)) before they are counted.
@@ -419,7 +415,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // device-mapped pinned memory (no copy, memset or event calls), synchronises once, and is checked at the end;
     // anything that does not fit falls back to the general path.
     bool single_fast = B == 1 && !partial && !ex && !no_fast && P != 0 && out_cap <= SINGLE_OUT_MAX &&
-                       (snap->n_lean == 0 || P * snap->n_file < lean_min_probes());
+                       (snap->n_lean == 0 || P * snap->n_file < lean_min_probes(snap->ctx));
     if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_begin, st));
     if (resident) {
         d_hashes_base = resident->d_hashes;
@@ -491,7 +487,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     for (uint32_t q = 0; q < B && flagged; ++q) flagged = offsets[q + 1] - offsets[q] <= DEDUP_MAX;
     const uint32_t key_skip = flagged ? KEY_SORT_SKIP_DIRECT : KEY_SORT_SKIP;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
-    static const uint64_t local_sort_max = [] { const char* e = getenv("FPX_LOCAL_SORT_MAX"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
+    const uint64_t local_sort_max = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_LOCAL_SORT_MAX));
     bool local_sort = P && !score_only && !single_fast && !flagged && B >= 2u && P <= local_sort_max && snap->n_small == 0;
     if (local_sort)
         for (uint32_t q = 0; q < B && local_sort; ++q) local_sort = offsets[q + 1] - offsets[q] <= QSORT_MAX;
@@ -502,11 +498,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     } else if (P && !score_only) {
         // flagged keys are brought into (hash bucket, query) order by our own counting sort, whose counts k_make_keys_dedup takes
         // on its way (fpx_keyorder.hpp); tiny batches stay in query order (the three launches cost what the order buys)
-        static const uint64_t order_min = [] { const char* e = getenv("FPX_ORDER_MIN_PAIRS"); return e ? strtoull(e, nullptr, 0) : (1ull << 17); }();
+        const uint64_t order_min = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_ORDER_MIN_PAIRS));
         KeyOrder ko{};
         // ... and large ones keep the library's pass: there our three launches cost 0.03 ms more than its five, and two batches in
         // flight no longer fill each other's gaps (8192 queries: 1.16 against 0.97 ms per batch)
-        static const uint64_t order_max = [] { const char* e = getenv("FPX_ORDER_MAX_PAIRS"); return e ? strtoull(e, nullptr, 0) : (1ull << 20); }();
+        const uint64_t order_max = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_ORDER_MAX_PAIRS));
         const bool own_order = flagged && !single_fast && P >= order_min && P <= order_max;
         if (own_order && (rc = key_order_setup(ws, B, 0u, 32u - key_skip, &ko, nullptr, st, B >= KO_ROWS_MIN_B))) return rc;
         if (flagged)
@@ -564,7 +560,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     //      candidate slots) instead of three.  It needs an estimate of the record count to size its bins: the first batch of a
     //      workspace takes the general path.  Anything it cannot handle (a full bin, a full deferred list, scores too wide
     //      for the candidate key) is noticed after the synchronisation and the batch is redone on the general path.
-    static const bool fast_enabled = [] { const char* e = getenv("FPX_FAST"); return e ? atoi(e) != 0 : true; }();
+    const bool fast_enabled = ctx_opt(snap->ctx, OPT_FAST) != 0;
     const uint32_t nb_bits = qb > BIN_QUERIES_LOG2 ? qb - BIN_QUERIES_LOG2 : 0u;
     bool fast = fast_enabled && !ex && !no_fast && !single_fast && B >= 2u && P != 0 && qb <= 24u && (1u << nb_bits) <= MAX_BINS &&
                 ws->hint_H != 0 && ws->hint_P != 0;
@@ -578,11 +574,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // into bins of 2^BQ queries itself and k_score_bin scores a bin per workgroup (fpx_score_bin.hpp) -- no partition kernels
     // Queries per bin: eight, fewer for batches that would not give k_score_bin ~2048 workgroups otherwise (a workgroup's time is
     // a chain of tile-load latencies: 8192 queries in bins of 4: 170 -> 154 us, 1024 queries in bins of 2: 66 -> 29 us)
-    static const int bin_q_forced = [] { const char* e = getenv("FPX_BIN_Q_LOG2"); return e ? atoi(e) : -1; }();
+    const int bin_q_forced = (int)ctx_opt(snap->ctx, OPT_BIN_Q_LOG2);
     uint32_t bin_q_log2 = 3u;
     if (bin_q_forced >= 0) bin_q_log2 = (uint32_t)bin_q_forced;
     else while (bin_q_log2 > 1u && (B >> bin_q_log2) < 2048u) --bin_q_log2;
-    static const bool binned_enabled = [] { const char* e = getenv("FPX_BINNED"); return e ? atoi(e) != 0 : true; }();
+    const bool binned_enabled = ctx_opt(snap->ctx, OPT_BINNED) != 0;
     bool binned = false;
     uint32_t sbins = 0;
     // (segments direct-addressed on their own and memory segments append their records to the misc buffer, which k_bin bins: the
@@ -620,7 +616,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         h_bin.bin_count = d_bin_count;
         if (binned) {
             // 4-byte records where the doc ids leave room for the query's bits inside its bin (fpx_partition.hpp)
-            static const bool rec32_enabled = [] { const char* e = getenv("FPX_REC32"); return e ? atoi(e) != 0 : true; }();
+            const bool rec32_enabled = ctx_opt(snap->ctx, OPT_REC32) != 0;
             h_bin.rec32 = rec32_enabled && !__atomic_load_n(&snap->rec32_refused, __ATOMIC_RELAXED) &&
                           snap->max_doc_declared < (0xFFFFFFFFu >> bin_q_log2) ? 1u : 0u;
             h_bin.counters = ws->d_counters;
@@ -660,7 +656,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             const size_t lds = STAGE_CAP * sizeof(uint64_t) + sizeof(DecodeLut) + (size_t)PWAVES * 4 * a.bsp;
             // big batches: every kind of file segment has its own kernel
             const bool lean = (snap->n_lean != 0 || snap->n_small != 0) && !force_generic && P < 0x80000000ull && qb <= 24u &&   // pair indices + a tag bit in the deferred lists; 8 spare bits in q
-                              total >= lean_min_probes();
+                              total >= lean_min_probes(snap->ctx);
             if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_probe0, st));
             if (attempt > 0 && (snap->n_lean || snap->n_direct))
                 FPX_HIP(hipMemsetAsync(ws->d_def_count, 0, def_words * sizeof(unsigned int), st));   // (first attempt: k_make_keys)
@@ -678,7 +674,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     ProbeArgs gk = a;
                     gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
                     if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; }
-                    static const uint32_t group_rounds = [] { const char* e = getenv("FPX_GROUP_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
+                    const uint32_t group_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_GROUP_ROUNDS));
                     gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
                     // (hot-hash data -- the previous batch brought 16+ records per key: a workgroup's rounds wait for the waves that copy the
                     // long lists; three rounds: 3.5 ms per batch of 8192 on distribution Z where five take 4.4)
@@ -695,7 +691,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 if (n_solo) {
                     ProbeArgs dk = a;
                     dk.segs = d_solo; dk.lean_stats = stat_sets;
-                    static const uint32_t direct_rounds = [] { const char* e = getenv("FPX_DIRECT_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
+                    const uint32_t direct_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_DIRECT_ROUNDS));
                     dk.rounds = direct_rounds ? direct_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_solo / 8192));
                     const uint64_t per_wg_dk = (uint64_t)DK_WG * DK_KPL * dk.rounds;
                     hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), n_solo), dim3(DK_WG), 0, st, dk);
@@ -709,7 +705,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     // rounds of 1024 pairs per workgroup: more rounds amortise the workgroup's set-up (decode tables, barriers) --
                     // measured at 8.2 M pairs x 16 segments: 5.48 ms with 1, 5.11 with 2, 5.01 with 6, 5.14 with 16 -- as long
                     // as the grid still fills the chip several times over (>= 4096 workgroups)
-                    static const uint32_t lean_rounds = [] { const char* e = getenv("FPX_LEAN_ROUNDS"); return e ? (uint32_t)atoi(e) : 0u; }();
+                    const uint32_t lean_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_LEAN_ROUNDS));
                     const uint64_t wgs_at_1 = (P + 1023) / 1024 * snap->n_lean;
                     l.segs = snap->d_lean; l.ctr_off = 8u;
                     l.rounds = lean_rounds ? lean_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_at_1 / 4096));
@@ -896,7 +892,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         // (the results travel through pinned staging: a copy to the caller's pageable memory would block the host until the
         // stream reaches it, and a blocked host cannot watch the deadline.  Small batches: k_finish writes into the staging itself)
         bool staged = false;
-        if (!partial && (rc = staged_targets(ws, B, out_cap, &staged, &d_res_n, &d_res))) return rc;
+        if (!partial && (rc = staged_targets(ws, snap->ctx, B, out_cap, &staged, &d_res_n, &d_res))) return rc;
         // optimistic finish: every query's candidates fit its own slots (C == 0); redone below after a sort otherwise
         hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
                            (const uint64_t*)ws->d_cands[0], (uint64_t)0, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
@@ -1612,7 +1608,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
         if (ws->cap_hits == 0 && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)1 << 22))) return rc;
         // a query's share of its hashes + slack; a query that needs more has the whole query's length on the second attempt
         uint32_t stride = (uint32_t)std::min<uint64_t>(max_len, (uint64_t)((double)max_len * share * 1.25) + 48);
-        static const bool rec32_enabled = [] { const char* e = getenv("FPX_REC32"); return e ? atoi(e) != 0 : true; }();
+        const bool rec32_enabled = ctx_opt(snap->ctx, OPT_REC32) != 0;
         uint64_t rec_cap = cell_cap;                           // records a bin's cells hold
         for (int attempt = 0;; ++attempt) {
             // 4-byte records (two per 8-byte cell) where the doc ids leave room for the query's three bits inside its bin
@@ -1818,7 +1814,7 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
         }
         uint32_t* d_stats32 = ws->d_cells + cell_words;
         if (ws->cap_hits == 0 && (rc = grow_pair(ws->d_hits, &ws->cap_hits, (size_t)1 << 22))) return rc;
-        static const bool rec32_enabled = [] { const char* e = getenv("FPX_REC32"); return e ? atoi(e) != 0 : true; }();
+        const bool rec32_enabled = ctx_opt(snap->ctx, OPT_REC32) != 0;
         uint64_t rec_cap = cell_cap;
         for (int attempt = 0;; ++attempt) {
             const uint32_t rec32 = rec32_enabled && !__atomic_load_n(&snap->rec32_refused, __ATOMIC_RELAXED) &&

@@ -385,7 +385,7 @@ int fpx_sharded_snapshot_create_on(fpx_ctx* root_ctx, fpx_segment* const* segs, 
         for (uint32_t i = 0; i < num_segs && ss->ctxs.empty(); ++i) ss->ctxs.push_back(reinterpret_cast<const Segment*>(segs[i])->ctx);
         if (ss->ctxs.empty()) { delete ss; set_error("an empty sharded snapshot needs a context to live on: fpx_sharded_snapshot_create_on"); return FPX_E_INVAL; }
     }
-    static const int workers = [] { const char* e = getenv("FPX_SHARDED_WORKERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    auto workers_of = [](const Ctx* c) { const int64_t v = ctx_opt(c, OPT_SHARDED_WORKERS); return (int)(v < 1 ? 1 : (v > 16 ? 16 : v)); };
     for (Ctx* c : ss->ctxs) {
         // the same segment list on every device: fpx_snapshot_create keeps the postings of the segments that live on
         // `c` and only the docs maps of the others (supersession, Segments.hasNewerCommit, src/Index.zig:133-149)
@@ -394,7 +394,7 @@ int fpx_sharded_snapshot_create_on(fpx_ctx* root_ctx, fpx_segment* const* segs, 
         if (rc != FPX_OK) { sharded_free(ss); return rc; }
         ss->locals.push_back(reinterpret_cast<Snapshot*>(sn));
         try {
-            ss->pools.emplace_back(new DevicePool(c->device, workers));
+            ss->pools.emplace_back(new DevicePool(c->device, workers_of(c)));
         } catch (...) {                           // (std::system_error / bad_alloc must not cross the C boundary)
             sharded_free(ss);
             set_error("could not start the worker threads of device %d", c->device);
@@ -627,7 +627,7 @@ int fpx_sharded_snapshot_create_windows(fpx_ctx* const* ctxs, uint32_t world, fp
     ShardedSnapshot* ss = new (std::nothrow) ShardedSnapshot();
     if (!ss) return FPX_E_NOMEM;
     ss->windows = true;
-    static const int workers = [] { const char* e = getenv("FPX_SHARDED_WORKERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    auto workers_of = [](const Ctx* c) { const int64_t v = ctx_opt(c, OPT_SHARDED_WORKERS); return (int)(v < 1 ? 1 : (v > 16 ? 16 : v)); };
     for (uint32_t k = 0; k < world; ++k) {
         Ctx* c = reinterpret_cast<Ctx*>(ctxs[k]);
         if (!c) { sharded_free(ss); set_error("null context"); return FPX_E_INVAL; }
@@ -644,7 +644,7 @@ int fpx_sharded_snapshot_create_windows(fpx_ctx* const* ctxs, uint32_t world, fp
         if (rc != FPX_OK) { sharded_free(ss); return rc; }
         ss->locals.push_back(reinterpret_cast<Snapshot*>(sn));
         try {
-            ss->pools.emplace_back(new DevicePool(c->device, workers));
+            ss->pools.emplace_back(new DevicePool(c->device, workers_of(c)));
         } catch (...) {
             sharded_free(ss);
             set_error("could not start the worker threads of device %d", c->device);

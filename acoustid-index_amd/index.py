@@ -52,7 +52,8 @@ class Context:
         return s.value, r.value
 
     def set_option(self, name, value):
-        """fpx_ctx_set_option: 'direct', 'direct_min_items', 'fuse_min', 'group_packed' (-1: back to the environment / default)"""
+        """fpx_ctx_set_option: any option of include/fpx.h ('direct', 'fuse_min', 'binned', 'fast', 'rec32', ...); a value below the
+        option's smallest (-1, or -2 for 'group_packed' / 'bin_q_log2') puts it back to the environment / default"""
         check(lib().fpx_ctx_set_option(self.h, name.encode(), int(value)))
 
     def get_option(self, name):

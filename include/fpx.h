@@ -91,16 +91,31 @@ typedef struct {
 int  fpx_ctx_create(int device, fpx_ctx **out);
 void fpx_ctx_destroy(fpx_ctx *ctx);
 int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context lives on */
-/* How a context keeps its file segments in HBM.  Options (each falls back to the environment variable FPX_<NAME>, then to the
- * default; a value below -1 = back to that fallback -- and so does -1 for every option but "group_packed", where -1 is the explicit
- * setting "by density", environment or not):
- *   "direct"            1 | 0   dense segments trade their blocks for a direct-addressed form (default 1)
- *   "direct_min_items"  items from which a segment counts as dense (default 2^20)
- *   "fuse_min"          direct-addressed segments of one hash window that form a GROUP together: this many or more (default 2; 0: never)
- *   "group_packed"      1 | 0 | -1   a group's form: PACKED lines (one HBM line per query hash; dense groups) | directory + words |
- *                       by the group's density (default)
- * They are read when a segment is created / a snapshot first holds it; fpx_segment_layout(), fpx_segment_layout_reason() and
- * fpx_snapshot_info() say what came of it. */
+/* The options of a context: everything that steers the library's behaviour.  Each falls back to the environment variable
+ * FPX_<NAME> (the tests' and the A/B tools' way in), then to the default; a value below the option's smallest one (-1 for most,
+ * -2 for "group_packed" and "bin_q_log2", where -1 is the explicit setting "decide by the data") = back to that fallback.
+ * Storage forms -- read when a segment is created / a snapshot first holds it; fpx_segment_layout(), fpx_segment_layout_reason()
+ * and fpx_snapshot_info() say what came of it:
+ *   "direct"             1 | 0   dense segments trade their blocks for a direct-addressed form (default 1)
+ *   "direct_min_items"   items from which a segment counts as dense (default 2^20)
+ *   "fuse_min"           direct-addressed segments of one hash window that form a GROUP together: this many or more (default 2; 0: never)
+ *   "group_packed"       1 | 0 | -1   a group's form: PACKED lines (one HBM line per query hash; dense groups) | directory + words |
+ *                        by the group's density (default)
+ *   "presence_min_items" items from which a segment in blocks gets presence bits and probe records (the lean kernel; default 2^20)
+ *   "lean_head"          4: the lean kernel always fetches whole blocks (default 0: two lines where a block's head fits them)
+ *   "inline_doubles"     1 | 0   a hash with two docs keeps both in the group's words (default 1)
+ *   "memtab"             1 | 0   a snapshot's memory segments behind ONE hash-sorted table (default 1)
+ * Search paths -- read per batch:
+ *   "fast"               1 | 0   the device-sized path (one host round trip per batch; default 1)
+ *   "binned"             1 | 0   groups drop their records into bins of a few queries, scored a bin per workgroup (default 1)
+ *   "bin_q_log2"         log2 of the queries per bin (-1: by the batch's size, default)
+ *   "rec32"              1 | 0   4-byte records in the bins where the doc ids leave room (default 1)
+ *   "local_sort_max", "order_min_pairs", "order_max_pairs"   pair counts that choose how a batch's keys are ordered
+ *   "lean_min"           probes from which block-form segments take the lean kernel (default 2^16)
+ *   "staged_out_max"     bytes of results a batch stages in pinned memory (-1: built-in)
+ *   "group_rounds", "direct_rounds", "lean_rounds"   rounds per workgroup of the probe kernels (0: by the batch's size)
+ *   "sharded_workers"    worker threads per device of a sharded snapshot (1..16, default 3)
+ * (FPX_SHARDED_RCCL alone stays with the process: whether librccl is loaded at all.) */
 int  fpx_ctx_set_option(fpx_ctx *ctx, const char *name, int64_t value);
 int  fpx_ctx_get_option(const fpx_ctx *ctx, const char *name, int64_t *value);   /* the value in force */
 const char *fpx_strerror(int status);

@@ -213,6 +213,53 @@ def test_context_options_decide_the_storage_form_and_the_abi_says_what_came_of_i
     assert "turned off" in f.layout_reason
 
 
+def test_search_path_options_belong_to_the_context_too(monkeypatch):
+    """The switches of the search paths (binned scoring, the device-sized path, record width, key order, rounds per workgroup) are
+    options of a CONTEXT, with the environment as their fallback: two contexts of one process take different paths to the same
+    results, and an unset option (a value below its smallest) falls back again."""
+    import os
+    import numpy as np
+    from fpx_testlib import fpx, oracle, Pair
+    if os.environ.get("FPX_VARIANT_CHILD") == "1":
+        pytest.skip("the variant runs move the defaults through the environment")
+    for k in ("FPX_BINNED", "FPX_FAST", "FPX_REC32", "FPX_BIN_Q_LOG2", "FPX_GROUP_ROUNDS", "FPX_MEMTAB"):
+        monkeypatch.delenv(k, raising=False)
+
+    def world(ctx):
+        p = Pair(ctx)
+        for s in range(3):
+            lo = s * 4000 + 1
+            p.add_file(fpx.synth.synth_items(5 + s, lo, 4000, 64, dist=1), lo, lo + 3999, s + 1, np.arange(lo, lo + 4000, dtype=np.uint32))
+        return p.finish()
+    flat, off, _ = fpx.synth.make_queries(5, 3, 96, 12000, 64, query_len=200, dist=1)
+    qs = [flat[int(off[i]):int(off[i + 1])] for i in range(96)]
+    a, b = fpx.Context(0), fpx.Context(0)
+    for c in (a, b):
+        c.set_option("direct_min_items", 0); c.set_option("fuse_min", 1)
+    assert a.get_option("binned") == 1 and a.get_option("fast") == 1 and a.get_option("rec32") == 1 and a.get_option("bin_q_log2") == -1
+    assert a.get_option("group_rounds") == 0 and a.get_option("sharded_workers") == 3 and a.get_option("lean_min") == 1 << 16
+    b.set_option("binned", 0); b.set_option("rec32", 0); b.set_option("group_rounds", 2); b.set_option("order_min_pairs", 0)
+    pa, pb = world(a), world(b)
+    ga, sta = pa.check(qs, fpx.http_options())                   # (check: the general path, then the device-sized one, both == the oracle)
+    gb, stb = pb.check(qs, fpx.http_options())
+    assert ga == gb
+    _, st2a = pa.reader.search_batch(qs, fpx.http_options())
+    _, st2b = pb.reader.search_batch(qs, fpx.http_options())
+    assert st2a.path_flags & 8 and not (st2b.path_flags & 8), (st2a.path_flags, st2b.path_flags)      # bit 3: scored a bin per workgroup
+    b.set_option("fast", 0)
+    _, st3b = pb.reader.search_batch(qs, fpx.http_options())
+    assert not (st3b.path_flags & 1)                             # bit 0: the device-sized path
+    b.set_option("fast", -1); b.set_option("binned", -1)         # back to the fallback (environment, then default)
+    assert b.get_option("fast") == 1 and b.get_option("binned") == 1
+    pb.reader.search_batch(qs, fpx.http_options())
+    _, st4b = pb.reader.search_batch(qs, fpx.http_options())
+    assert st4b.path_flags & 1 and st4b.path_flags & 8
+    monkeypatch.setenv("FPX_PRESENCE_MIN_ITEMS", "12345")         # (one of the few the environment is asked for every time)
+    assert a.get_option("presence_min_items") == 12345
+    a.set_option("presence_min_items", 7)
+    assert a.get_option("presence_min_items") == 7 and b.get_option("presence_min_items") == 12345
+
+
 def test_measure_access_runs_every_calibration_pattern_and_refuses_nonsense():
     """fpx_measure_access: the kernels of known memory-side requests that bench.py's counter passes calibrate on"""
     from fpx_testlib import fpx

@@ -40,7 +40,10 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
 FUSED_SHORT = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py", "tests/test_gpu_hashshard.py"]
 
 
-VARIANTS = [{"FPX_DIRECT": "0"}, {"FPX_LOCAL_SORT_MAX": "0"}, {"FPX_FAST": "0"}, {"FPX_LEAN_HEAD": "4"},
+# (the three switches of the block form's paths run TOGETHER -- batch-wide sort, general path, whole-block lean kernel --: each on its
+# own was another child of four suites, a fifth of the GPU suite's time between them; the batch-wide sort with the device-sized path
+# and the partial-fetch lean kernel is what tests/test_gpu_fullsize.py's block-form runs take)
+VARIANTS = [{"FPX_DIRECT": "0"},
             {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"},
@@ -90,6 +93,8 @@ class _HbmScheduler:
         self.reserved = 0.0                  # GB promised to the running children (they take it gradually: the free HBM of the moment would over-admit)
         self.running = 0
         self.jobs = jobs
+        import time
+        self.t_start = time.time()
 
     def run(self, env):
         need = _need_gb(env)
@@ -98,11 +103,17 @@ class _HbmScheduler:
                 self.cv.wait()
             self.running += 1
             self.reserved += need
+        import time
+        t0 = time.time()
         try:
             e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
             return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + _suites(env),
                                   cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
         finally:
+            out = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(out):               # (a GPU box run by tools/*.sh: how long every child took, for the suite's time budget)
+                with open(os.path.join(out, "variant_times.txt"), "a") as f:
+                    f.write(f"{_name(env)}: started {t0 - self.t_start:.0f} s into the module, took {time.time() - t0:.0f} s\n")
             with self.cv:
                 self.running -= 1
                 self.reserved -= need

@@ -802,6 +802,23 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         sn->segs.push_back(s);
         sn->max_doc_declared = std::max(sn->max_doc_declared, s->max_doc_id);
     }
+    // the snapshot's hash window: when every file segment that carries postings here is a slice of ONE window (a rank of an index
+    // sharded by hash range), the memory segments -- which every rank holds whole -- answer for that window's hashes only, so that the
+    // ranks' answers add up (the record protocol probes every rank with the whole batch)
+    uint32_t mem_win_lo = 0u, mem_win_hi = 0xFFFFFFFFu;
+    {
+        bool any = false, same = true;
+        uint32_t fl = 0, lo = 0, hi = 0;
+        for (const Segment* s : sn->segs) {
+            if (s->kind != 0 || s->ctx != c) continue;
+            if (!any) { any = true; fl = s->own_flags; lo = s->own_lo; hi = s->own_hi; }
+            else if (s->own_flags != fl || ((fl & 1u) && s->own_lo != lo) || ((fl & 2u) && s->own_hi != hi)) same = false;
+        }
+        if (any && same && fl != 0u) {
+            if (fl & 1u) mem_win_lo = lo == 0xFFFFFFFFu ? 0xFFFFFFFFu : lo + 1u;
+            if (fl & 2u) mem_win_hi = hi;
+        }
+    }
     std::vector<uint32_t> dead;
     std::vector<Segment*> direct_segs;               // parallel to sn->h_direct
     std::lock_guard<std::mutex> group_lock(c->group_mu);      // (the segments' forms must not change under the descriptors built below)
@@ -864,6 +881,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             if (s->block_size != 512) sn->all_512 = false;
         } else {
             MemDesc d{};
+            d.win_lo = mem_win_lo; d.win_hi = mem_win_hi;
             d.items = s->d_items; d.dead = d_dead; d.num_items = s->num_items;
             d.num_dead = (uint32_t)dead.size(); d.shadow_lo = slo; d.shadow_hi = shi;
             sn->h_mem.push_back(d);

@@ -93,6 +93,8 @@ struct MemDesc {
     uint64_t num_items;
     uint32_t num_dead;
     uint32_t shadow_lo, shadow_hi;
+    uint32_t win_lo, win_hi;       // the snapshot's hash window (its file segments are slices of one window: a rank of an index sharded by hash
+                                   // range): the memory segments -- held whole by every rank -- answer for the window's hashes only
     uint32_t pad;
 };
 

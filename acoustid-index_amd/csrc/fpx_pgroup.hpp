@@ -51,7 +51,7 @@ constexpr uint32_t PK_WORDS = FPX_PK_WORDS; // words of a hash walked by its lan
 // waves per SIMD to overlap them.  0: off.  1: the head waits in registers (three more per lane).  2: the head goes straight into
 // LDS (global_load_lds_dwordx4: a gather of 16 bytes per lane into the wave's 1 KB of LDS, no register held while it is under way).
 #ifndef FPX_PK_PREFETCH
-#define FPX_PK_PREFETCH 2
+#define FPX_PK_PREFETCH 0
 #endif
 // (dynamic LDS behind the stage -- launch_probe_group --: a line head of 16 bytes and a key of 2 x 4 bytes per lane)
 constexpr uint32_t PK_HEAD_LDS = FPX_PK_PREFETCH == 2 ? FK_WG * 16u + FK_WG * 8u : 0u;

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uin
     const uint64_t key = pairs[p];
     if (is_duplicate_pair(pairs, p, key, qb)) return;
     const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
+    if (h < ms.win_lo || h > ms.win_hi) return;                  // (a hash-window snapshot: another rank's hash)
     uint64_t lo = 0, hi = ms.num_items;
     while (lo < hi) {
         uint64_t m = (lo + hi) >> 1;
@@ -54,7 +55,11 @@ __global__ __launch_bounds__(WG) void k_memtab_gather(const MemDesc* mems, uint6
         const uint64_t i = i0 + threadIdx.x;
         uint64_t it = 0;
         bool live = false;
-        if (i < ms.num_items) { it = ms.items[i]; live = !is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, (uint32_t)it); }
+        if (i < ms.num_items) {
+            it = ms.items[i];
+            const uint32_t ih = (uint32_t)(it >> 32);                // (a hash-window snapshot keeps its window's postings alone)
+            live = ih >= ms.win_lo && ih <= ms.win_hi && !is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, (uint32_t)it);
+        }
         const unsigned long long m = __ballot((int)live);
         unsigned long long base = 0;
         if (lane == 0 && m) base = atomicAdd(count, (unsigned long long)__popcll(m));
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(WG) void k_probe_mem_items(const MemDesc* mems, con
     for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < ms.num_items; i += (uint64_t)gridDim.x * WG) {
         const uint64_t it = ms.items[i];
         const uint32_t h = (uint32_t)(it >> 32), d = (uint32_t)it;
+        if (h < ms.win_lo || h > ms.win_hi) continue;                // (a hash-window snapshot: another rank's hash)
         const uint32_t bucket = h >> KEY_SORT_SKIP;
         uint64_t lo = 0, hi = P;
         while (lo < hi) {                                        // first pair of the item's bucket

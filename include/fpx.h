@@ -330,7 +330,9 @@ int  fpx_sharded_search_batch(fpx_sharded_snapshot *snap, const uint32_t *hashes
  *                                        rank k's slices become one group with its window.  world: 1, 2, 4 .. 64.  MEMORY segments
  *                                        (fpx_segment_create_memory on ctxs[k], one copy per rank: a live index publishes one with every
  *                                        update, src/Index.zig:515-587) take their place in the list like on one GPU; a rank looks up
- *                                        the keys of its window in them.
+ *                                        the keys of its window in them.  (A snapshot whose file segments are slices of ONE hash
+ *                                        window answers for that window's hashes in its memory segments too, whichever entry point
+ *                                        searches it: the ranks' answers add up.)
  * fpx_sharded_search(_batch) on such a snapshot runs the routed-key protocol behind the one call: 1 / world of the batch's hashes
  * goes to each device (H2D), the devices make the keys of their share and deal them to the windows' ranks (all-to-all #1: RCCL
  * grouped send / recv over xGMI when every context has a device of its own, peer copies otherwise), every rank probes the keys of

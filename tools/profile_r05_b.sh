@@ -11,12 +11,12 @@ for so in acoustid-index_amd/build/exp/libfpx_*.so; do
   n=$(basename $so .so)
   FPX_LIB=$R/$so timeout 600 python tools/probe_ab.py 40 > $O/$n.json 2> $O/$n.err
 done
-for r in 3 4 8 10; do FPX_GROUP_ROUNDS=$r timeout 600 python tools/probe_ab.py 40 > $O/product_rounds$r.json 2> $O/product_rounds$r.err; done
+for r in 4 8; do FPX_GROUP_ROUNDS=$r timeout 600 python tools/probe_ab.py 40 > $O/product_rounds$r.json 2> $O/product_rounds$r.err; done
 cat $O/*.json > $O/summary.txt
 FPX_VARIANT_CHILD=1 FPX_DIRECT_MIN_ITEMS=0 FPX_FUSE_MIN=1 FPX_GROUP_PACKED=1 timeout 1500 \
   python -m pytest -x -q -m gpu -p no:cacheprovider tests/test_gpu_golden.py tests/test_gpu_parity.py tests/test_gpu_direct.py tests/test_gpu_hashshard.py tests/test_gpu_fuzz.py > $O/parity_packed.log 2>&1
 echo "parity packed rc $?" >> $O/summary.txt
-timeout 1500 python -m pytest -x -q -m gpu -p no:cacheprovider tests/test_gpu_fullsize.py::TestHeadlineIndex tests/test_gpu_sharded_abi.py tests/test_gpu_two_ranks.py tests/test_gpu_parity.py > $O/parity_new.log 2>&1
+timeout 1500 python -m pytest -x -q -m gpu -p no:cacheprovider tests/test_gpu_fullsize.py::TestHeadlineIndex tests/test_gpu_sharded_abi.py tests/test_gpu_two_ranks.py tests/test_gpu_parity.py tests/test_gpu_api.py tests/test_gpu_direct.py > $O/parity_new.log 2>&1
 echo "parity new rc $?" >> $O/summary.txt
 FPX_VARIANT_CHILD=1 FPX_DIRECT_MIN_ITEMS=0 FPX_FUSE_MIN=1 timeout 900 python -m pytest -x -q -m gpu -p no:cacheprovider tests/test_gpu_parity.py tests/test_gpu_sharded_abi.py > $O/parity_fused.log 2>&1
 echo "parity fused rc $?" >> $O/summary.txt

@@ -121,6 +121,7 @@ enum Counter : int {
                          // workgroup leaves at its next cancel point, the results are discarded (error.SearchTimeout)
     CTR_TOTAL = 11,      // device-sized path: hit records of the batch (sum of the queries' counts, written by k_l2_scan)
     CTR_BINFAIL = 12,    // k_score_bin: a bin met more distinct (query, doc) pairs than its table takes: the batch is redone on the general path
+    CTR_PADS = 15,       // "no record" entries that pad the bins' reservations to whole sectors (BIN_ALIGN): the bins' fill counts include them
     CTR_SLOTCANDS = 14,  // candidates handed from k_score to k_finish through the queries' own slots (statistics)
     CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
 };

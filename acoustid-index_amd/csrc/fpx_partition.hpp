@@ -23,6 +23,14 @@
 
 namespace fpx {
 
+// A workgroup's records for a bin are reserved in multiples of BIN_ALIGN records and the tail is filled with "no record": every 64-byte
+// sector of a bin is then written by ONE workgroup.  The bins are shared by all workgroups, i.e. by all eight dies, each with an L2 of
+// its own: a sector that two dies each wrote a part of left the chip as two masked writes (244 MB written for 160 MB of records, 4.2 M
+// write requests where 2.5 M sectors were filled -- profiles/r04_traffic.json); the kernel sits at 78 % of the chip's request rate.
+#ifndef FPX_BIN_ALIGN
+#define FPX_BIN_ALIGN 16
+#endif
+constexpr uint32_t BIN_ALIGN = FPX_BIN_ALIGN;      // records (16 x 4 bytes = a sector; 8-byte records: two sectors); 1: off
 constexpr uint32_t BIN_STRIDE = 32;         // 32-bit words between the bins' fill counters: a 128-B line each
 constexpr uint32_t MAX_BINS = 128;          // bins of the two-level partition (128 queries each)
 constexpr uint32_t MAX_SBINS = 4096;        // bins of 2^BQ queries that k_score_bin takes whole (fpx_score_bin.hpp)
@@ -48,6 +56,12 @@ __device__ __forceinline__ uint32_t bin_record32(uint64_t rec, uint32_t shift)
 }
 // (The host chooses the narrow form by the segments' declared doc id ranges; a file whose postings exceed its header's range is
 // caught here: CTR_BINFAIL = 3, the batch is redone with wide records and the snapshot remembers.  All ones is no record.)
+// "no record": what pads a reservation to whole 64-byte sectors (BIN_ALIGN) -- k_score_bin and k_bin's readers skip it
+__device__ __forceinline__ void bin_store_null(uint64_t* bins, uint64_t bin_cap, uint32_t rec32, uint32_t bn, uint64_t pos)
+{
+    if (rec32) reinterpret_cast<uint32_t*>(bins)[(size_t)bn * bin_cap + pos] = 0xFFFFFFFFu;
+    else bins[(size_t)bn * bin_cap + pos] = ~0ull;
+}
 __device__ __forceinline__ void bin_store(uint64_t* bins, uint64_t bin_cap, uint32_t rec32, uint32_t shift, uint32_t bn, uint64_t pos, uint64_t rec,
                                           unsigned long long* counters)
 {

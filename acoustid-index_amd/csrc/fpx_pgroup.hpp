@@ -72,6 +72,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     __shared__ uint32_t s_bsel[GB_SLOTS];                 // the bin of every slot of the round being flushed
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
+    __shared__ uint32_t wg_pads;
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
     // per column, indexed by a lane's own column number; per chunk of the hash space: where its `ext` starts
     __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid / GB_SLOTS][tid % GB_SLOTS] = 0u; s_bid[tid / GB_SLOTS][tid % GB_SLOTS] = GB_EMPTY; }
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;
-        wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
+        wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0; wg_pads = 0;
         s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;        // cancel point (src/FileSegment.zig:144), once per workgroup
     }
     __syncthreads();
@@ -501,7 +502,13 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                     // that detour)
                     const uint32_t hot_bin = qlo >> a.bin_shift;
                     if (!filtered) {
-                        if constexpr (BINNED) { if (lane == 0) gbase = atomicAdd(&a.bin_count[(size_t)hot_bin * BIN_STRIDE], total); }
+                        if constexpr (BINNED) {
+                            // (whole sectors here too, or the bin's later reservations would start inside one)
+                            const uint32_t tr = (total + (BIN_ALIGN - 1u)) & ~(BIN_ALIGN - 1u);
+                            if (lane == 0) { gbase = atomicAdd(&a.bin_count[(size_t)hot_bin * BIN_STRIDE], tr); if (tr != total) atomicAdd(&wg_pads, tr - total); }
+                            gbase = __shfl(gbase, 0);
+                            if (lane < tr - total && gbase + total + lane < a.bin_cap) bin_store_null(a.bins, a.bin_cap, a.rec32, hot_bin, gbase + total + lane);
+                        }
                         else { if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total); }
                         gbase = __shfl(gbase, 0);
                     }
@@ -602,7 +609,14 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                 if (c != 0u) {
                     const uint32_t b = s_bid[par][tid];
                     s_bsel[tid] = b;
-                    s_bbase[tid] = atomicAdd(&a.bin_count[(size_t)b * BIN_STRIDE], c);
+                    // whole sectors: the reservation rounded up to BIN_ALIGN records, its tail filled with "no record" (fpx_partition.hpp)
+                    const uint32_t cr = (c + (BIN_ALIGN - 1u)) & ~(BIN_ALIGN - 1u);
+                    const uint32_t base = atomicAdd(&a.bin_count[(size_t)b * BIN_STRIDE], cr);
+                    s_bbase[tid] = base;
+                    if (cr != c) {
+                        atomicAdd(&wg_pads, cr - c);
+                        for (uint32_t t = c; t < cr; ++t) if ((uint64_t)base + t < a.bin_cap) bin_store_null(a.bins, a.bin_cap, a.rec32, b, (uint64_t)base + t);
+                    }
                     s_bcnt[par][tid] = 0u; s_bid[par][tid] = GB_EMPTY;          // (this parity's next use is two rounds away)
                 }
             }
@@ -653,7 +667,9 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             if (wg_blocks && g->block_size != 512u) atomicAdd(&st[5], wg_blocks * (unsigned long long)g->block_size - wg_blocks * 512ull);
             if (wg_docs) atomicAdd(&st[2], wg_docs);
             if (wg_probes) atomicAdd(&st[3], wg_probes);
+            if (wg_pads) atomicAdd(&st[6], (unsigned long long)wg_pads);
         } else {
+            if (wg_pads) atomicAdd(&a.counters[CTR_PADS], (unsigned long long)wg_pads);
             if (wg_blocks) { atomicAdd(&a.counters[CTR_BLOCKS], wg_blocks); atomicAdd(&a.counters[CTR_BYTES], wg_blocks * (unsigned long long)g->block_size); }
             if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
             if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);

@@ -147,8 +147,9 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                     if (cur[u] == ~0ull) continue;                       // (beyond the piece: a real cell never reads all ones -- its docs are < 2^(32 - bq))
                     const uint64_t i = t0 + (uint64_t)u * SB_WG + tid;
                     const uint32_t lo = (uint32_t)cur[u], hi = (uint32_t)(cur[u] >> 32);
-                    fn(((uint64_t)(lo & qm) << 32) | (lo >> a.bq));
-                    if (2u * i + 1u < nrec) fn(((uint64_t)(hi & qm) << 32) | (hi >> a.bq));
+                    // (all ones: "no record" -- the tail of a reservation padded to whole sectors, fpx_partition.hpp)
+                    if (lo != 0xFFFFFFFFu) fn(((uint64_t)(lo & qm) << 32) | (lo >> a.bq));
+                    if (2u * i + 1u < nrec && hi != 0xFFFFFFFFu) fn(((uint64_t)(hi & qm) << 32) | (hi >> a.bq));
                 }
             } else {
 #pragma unroll

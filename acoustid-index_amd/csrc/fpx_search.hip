@@ -623,7 +623,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             h_bin.nbins = sbins; h_bin.shift = bin_q_log2;
             // twice the expected share + room for the spread of a small bin; a bin that overflows is seen after the batch's
             // synchronisation and the batch is redone on the general path
-            h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / sbins, std::max<uint64_t>(2 * est_H / sbins + 8192, 16384)) & ~(uint64_t)1;
+            h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / sbins, std::max<uint64_t>(2 * est_H / sbins + 8192, 16384)) & ~(uint64_t)31;      // (whole lines per bin: reservations padded to BIN_ALIGN records start on a sector)
             FPX_HIP(hipMemsetAsync(d_bin_count, 0, (size_t)sbins * BIN_STRIDE * sizeof(uint32_t), st));
         } else {
             h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
@@ -955,12 +955,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (!partial && (rc = deliver_results(ws, B, out_cap, staged, out, out_n, st))) return rc;
         if (stats) {
             unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0, bytes_off = 0;
+            unsigned long long pads = ws->h_counters[CTR_PADS];          // ("no record" entries in the bins' counts: fpx_partition.hpp, BIN_ALIGN)
             if (spread) {
                 const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
                 unsigned long long dreads = 0;
                 for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
                     reads += ls[i * 8 + 0]; blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4];
                     bytes_off += ls[i * 8 + 5];      // (direct-addressed segments of a block size other than 512: the difference, mod 2^64)
+                    pads += ls[i * 8 + 6];
                 }
                 reads += (dreads + 1) / 2;
             }
@@ -974,7 +976,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probes += ws->h_counters[CTR_PROBES] + probes;
             stats->scanned_blocks += ws->h_counters[CTR_BLOCKS] + blocks;
             stats->scanned_docs += ws->h_counters[CTR_DOCS] + docs;
-            stats->hits += H;
+            stats->hits += H - (binned ? std::min<unsigned long long>(pads, H) : 0ull);
             stats->algorithmic_bytes += ws->h_counters[CTR_BYTES] + blocks * 512ull + bytes_off;
             stats->candidates += Cf + ws->h_counters[CTR_SLOTCANDS];
             stats->probe_kernel_ms += ms;
@@ -1698,10 +1700,11 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
             unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0;
             unsigned long long bytes_off = 0;
-            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; bytes_off += ls[i * 8 + 5]; }
+            unsigned long long pads = ws->h_counters[CTR_PADS];
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; bytes_off += ls[i * 8 + 5]; pads += ls[i * 8 + 6]; }
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
-            stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS];
+            stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS] - std::min<unsigned long long>(pads, ws->h_counters[CTR_SLOTCANDS]);
             stats->algorithmic_bytes = blocks * 512ull + bytes_off; stats->probe_kernel_bytes = blocks * 512ull + bytes_off;
             stats->probe_kernel_fetched_bytes = dreads * 64ull; stats->probe_kernel_ms = ms; stats->total_gpu_ms = ms; stats->probe_launches = 1;
             stats->path_flags = 1u | 4u | 8u | 16u;
@@ -1878,10 +1881,11 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
             unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0;
             unsigned long long bytes_off = 0;
-            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; bytes_off += ls[i * 8 + 5]; }
+            unsigned long long pads = ws->h_counters[CTR_PADS];
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) { blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4]; bytes_off += ls[i * 8 + 5]; pads += ls[i * 8 + 6]; }
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
-            stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS];
+            stats->probes = probes; stats->scanned_blocks = blocks; stats->scanned_docs = docs; stats->hits = ws->h_counters[CTR_SLOTCANDS] - std::min<unsigned long long>(pads, ws->h_counters[CTR_SLOTCANDS]);
             stats->algorithmic_bytes = blocks * 512ull + bytes_off; stats->probe_kernel_bytes = blocks * 512ull + bytes_off;
             stats->probe_kernel_fetched_bytes = dreads * 64ull; stats->probe_kernel_ms = ms; stats->total_gpu_ms = ms; stats->probe_launches = 1;
             stats->path_flags = 1u | 4u | 8u | 16u;

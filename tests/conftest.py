@@ -38,6 +38,11 @@ def pytest_collection_modifyitems(config, items):
     gpu_items = [it for it in items if it.get_closest_marker("gpu")]
     if not gpu_items:
         return
+    # The variant children (tests/test_gpu_variants.py) are admitted by the HBM that is free when their module starts: it goes FIRST,
+    # before this process has built (and cached workspaces for) the full-size indexes
+    first = [it for it in items if "test_gpu_variants" in it.nodeid]
+    if first:
+        items[:] = first + [it for it in items if "test_gpu_variants" not in it.nodeid]
     ok, why = _gpu_present()
     if ok:
         return

@@ -37,7 +37,6 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
                 "tests/test_gpu_hashshard.py", "tests/test_gpu_fuzz.py::test_fuzz_lean_sized_worlds"]
 
 
-FUSED_SHORT = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py", "tests/test_gpu_hashshard.py"]
 
 
 # (the three switches of the block form's paths run TOGETHER -- batch-wide sort, general path, whole-block lean kernel --: each on its
@@ -58,10 +57,16 @@ def _name(env):
 
 
 def _suites(env):
-    suites = FUSED_SUITES if env.get("FPX_FUSE_MIN") == "1" else DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
-    if env.get("FPX_FUSE_MIN") == "1" and len(env) > 2:          # the sub-variants of the grouped form: the suites that reach the switched code
-        suites = FUSED_SHORT
-    return suites
+    if env.get("FPX_FUSE_MIN") == "1":
+        # the sub-variants of the grouped form: the suites that reach the switched code
+        if "FPX_BINNED" in env or "FPX_FAST" in env:
+            return ["tests/test_gpu_parity.py", "tests/test_gpu_direct.py"]
+        if "FPX_INLINE_DOUBLES" in env:
+            return ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py"]
+        if "FPX_REC32" in env:
+            return ["tests/test_gpu_parity.py", "tests/test_gpu_hashshard.py"]
+        return FUSED_SUITES
+    return DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
 
 
 def _need_gb(env):
@@ -69,9 +74,9 @@ def _need_gb(env):
     up to eight columns, 137 GB for sixteen -- and tests/test_gpu_hashshard.py holds the unsharded group AND the ranks' windows of it
     (another 69 GB between them).  The directory + words form: 8.6 / 17 GB per group.  Everything else: small indexes in blocks."""
     if env.get("FPX_GROUP_PACKED") == "1":
-        return 170
+        return 150
     if env.get("FPX_FUSE_MIN") == "1":
-        return 45
+        return 45 if len(env) == 2 or "FPX_REC32" in env else 30       # (the window slices of tests/test_gpu_hashshard.py next to the whole group)
     return 15
 
 
@@ -128,7 +133,7 @@ def variant_runs():
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         yield {}
         return
-    sched = _HbmScheduler(int(os.environ.get("FPX_VARIANT_JOBS", "4")))
+    sched = _HbmScheduler(int(os.environ.get("FPX_VARIANT_JOBS", "6")))
     # the largest first: the packed variant starts on an empty device, the small ones fill in around it
     order = sorted(VARIANTS, key=_need_gb, reverse=True)
     with cf.ThreadPoolExecutor(len(VARIANTS)) as pool:

@@ -23,14 +23,16 @@
 
 namespace fpx {
 
-// A workgroup's records for a bin are reserved in multiples of BIN_ALIGN records and the tail is filled with "no record": every 64-byte
-// sector of a bin is then written by ONE workgroup.  The bins are shared by all workgroups, i.e. by all eight dies, each with an L2 of
-// its own: a sector that two dies each wrote a part of left the chip as two masked writes (244 MB written for 160 MB of records, 4.2 M
-// write requests where 2.5 M sectors were filled -- profiles/r04_traffic.json); the kernel sits at 78 % of the chip's request rate.
+// BIN_ALIGN > 1: a workgroup's records for a bin are reserved in multiples of BIN_ALIGN records and the tail is filled with "no record",
+// so that every 64-byte sector of a bin is written by ONE workgroup.  Why it was tried (round 5): the bins are shared by all workgroups,
+// i.e. by all eight dies, each with an L2 of its own, and the probe kernel's 160 MB of records leave the chip in 4.2 M write requests
+// where 2.5 M sectors are filled (profiles/r04_traffic.json).  Measured on the 100 M index (profiles/r05_ab_bin_align.txt): 16 records
+// (a sector) 0.4345 ms, 32 (a line) 0.4585, OFF 0.4087 -- the pads' stores sit in the flush between two barriers and cost more than
+// the whole sectors save.  Off (1) by default; the readers skip "no record" either way.
 #ifndef FPX_BIN_ALIGN
-#define FPX_BIN_ALIGN 16
+#define FPX_BIN_ALIGN 1
 #endif
-constexpr uint32_t BIN_ALIGN = FPX_BIN_ALIGN;      // records (16 x 4 bytes = a sector; 8-byte records: two sectors); 1: off
+constexpr uint32_t BIN_ALIGN = FPX_BIN_ALIGN;      // records (16 x 4 bytes = a sector); 1: off
 constexpr uint32_t BIN_STRIDE = 32;         // 32-bit words between the bins' fill counters: a 128-B line each
 constexpr uint32_t MAX_BINS = 128;          // bins of the two-level partition (128 queries each)
 constexpr uint32_t MAX_SBINS = 4096;        // bins of 2^BQ queries that k_score_bin takes whole (fpx_score_bin.hpp)

@@ -22,14 +22,14 @@ constexpr uint32_t SB_QL_SHIFT = 26;               // table slot: doc << 32 | qu
 constexpr uint32_t SB_NEED_MARK = 0x40000000u;     // FPX_SHARD_NEED_MARK: a travelling count that says "my bins need this many cells" instead of a size
 constexpr uint32_t SB_CAND = 32;                   // candidates of a query gathered in LDS before they move to the shared list
 
-// The (query-in-bin, doc) hash of the counting filter and the exact table.  k_score_bin is bound by its own instruction stream (two
-// passes over a bin's ~40 000 records, a hash per record and pass): mix32 over (doc ^ ql * c) is three 32-bit multiplies -- quarter
-// rate on this chip --, the class test of an over-full bin three more, computed for every record whether the bin is classed or not.
-// 1: ONE multiply (Fibonacci hashing; the fold brings the product's high bits down to the cell / slot / pass fields), and the class
-// test only in the instantiation of the record loops that a classed bin takes.  The filter and the table stay exact by construction
-// (a cell can only over-count; the table compares whole keys), so the hash decides speed alone.
+// The (query-in-bin, doc) hash of the counting filter and the exact table.  0: mix32 over (doc ^ ql * c) -- three 32-bit multiplies,
+// quarter rate on this chip, plus three more for the class test of over-full bins.  1: ONE multiply (Fibonacci hashing, folded) and
+// the class test only in the instantiation a classed bin takes.  The filter and the table are exact by construction (a cell can only
+// over-count; the table compares whole keys), so the hash decides speed alone -- and measured, it decides nothing: the step of the
+// headline batch is the same to 0.1 % either way (round 5, profiles/r05_ab_bin_align.txt): the kernel waits for its tile loads and
+// its LDS atomics, not for its VALU.  0 stays the default.
 #ifndef FPX_SB_HASH
-#define FPX_SB_HASH 1
+#define FPX_SB_HASH 0
 #endif
 __device__ __forceinline__ uint32_t sb_hash(uint32_t doc, uint32_t ql)
 {

@@ -303,7 +303,7 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
 
 def stored_traffic(docs, S, H, B, qlen):
     """fallback: the committed PMC pass, only for the same configuration AND the same kernel sources"""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = tr["config"]

@@ -1,5 +1,5 @@
-"""tools/collect_profiles.py [src] -- copy what tools/profile_r04.sh produced (gpurun_out/prof_r04/) into profiles/r04_*:
-the files DESIGN.md and bench.py cite.  profiles/r04_traffic.json carries the kernels' source hash: bench.py falls back to
+"""tools/collect_profiles.py [src] [tag] -- copy what tools/profile_r05.sh produced (gpurun_out/prof_r05/) into profiles/r05_*:
+the files DESIGN.md and bench.py cite.  profiles/<tag>_traffic.json carries the kernels' source hash: bench.py falls back to
 it only when the hash still matches (its in-run PMC child pass is the primary source)."""
 import json
 import os
@@ -8,9 +8,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r04")
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r05"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 dst = os.path.join(ROOT, "profiles")
-TAG = "r04"
 
 
 def last_json(path):
@@ -41,7 +41,8 @@ if os.path.exists(os.path.join(src, "merge_then_search.json")) and os.path.getsi
         print("unreadable: merge_then_search.json")
 for name in ("emulated_rank_of_8_weak", "emulated_rank_of_8_strong", "emulated_rank_of_4_weak", "emulated_rank_of_2_weak", "emulated_rank_of_8_weak_replicated_hashes"):
     put_json(name + ".json", f"{TAG}_{name}.json")
-for tag, out in (("r04", "kernel_stats.csv"), ("r04b", "block_kernel_stats.csv"), ("r04b1k", "kernel_stats_b1024.csv"), ("r04emu", "emulated_rank_of_8_kernel_stats.csv")):
+for tag, out in ((TAG, "kernel_stats.csv"), (TAG + "b", "block_kernel_stats.csv"), (TAG + "b1k", "kernel_stats_b1024.csv"), (TAG + "emu", "emulated_rank_of_8_kernel_stats.csv"),
+                 (TAG + "sbh", "kernel_stats_score_hash1.csv")):
     p = os.path.join(src, f"{tag}_kernel_stats.csv")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{TAG}_{out}"))
@@ -63,6 +64,6 @@ for key in ("roofline", "roofline_block_form"):
                                                   "hbm_write_bytes_per_launch": pmc.get("hbm_write_bytes_per_launch"), "hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch", pmc["hbm_read_bytes_per_launch"])}
 json.dump(tr, open(os.path.join(dst, f"{TAG}_traffic.json"), "w"), indent=1)
 if bench["kernel_source_sha16"] != bench_mod.kernel_source_hash():
-    print("WARNING: the profile was taken on other kernel sources than the tree holds (bench.py will not use r04_traffic.json as a fallback)")
+    print("WARNING: the profile was taken on other kernel sources than the tree holds (bench.py will not use this traffic file as a fallback)")
 os.system(f"{sys.executable} {os.path.join(ROOT, 'tools', 'kernel_resources.py')} {os.path.join(dst, TAG + '_kernel_resources.txt')} > /dev/null")
 print("profiles/ updated from", src)

@@ -22,25 +22,6 @@ constexpr uint32_t SB_QL_SHIFT = 26;               // table slot: doc << 32 | qu
 constexpr uint32_t SB_NEED_MARK = 0x40000000u;     // FPX_SHARD_NEED_MARK: a travelling count that says "my bins need this many cells" instead of a size
 constexpr uint32_t SB_CAND = 32;                   // candidates of a query gathered in LDS before they move to the shared list
 
-// The (query-in-bin, doc) hash of the counting filter and the exact table.  0: mix32 over (doc ^ ql * c) -- three 32-bit multiplies,
-// quarter rate on this chip, plus three more for the class test of over-full bins.  1: ONE multiply (Fibonacci hashing, folded) and
-// the class test only in the instantiation a classed bin takes.  The filter and the table are exact by construction (a cell can only
-// over-count; the table compares whole keys), so the hash decides speed alone -- and measured, it decides nothing: the step of the
-// headline batch is the same to 0.1 % either way (round 5, profiles/r05_ab_bin_align.txt): the kernel waits for its tile loads and
-// its LDS atomics, not for its VALU.  0 stays the default.
-#ifndef FPX_SB_HASH
-#define FPX_SB_HASH 0
-#endif
-__device__ __forceinline__ uint32_t sb_hash(uint32_t doc, uint32_t ql)
-{
-#if FPX_SB_HASH == 0
-    return mix32(doc ^ (ql * 0x9E3779B1u));
-#else
-    uint32_t x = (doc ^ (ql << 26) ^ (ql << 13)) * 0x9E3779B1u;          // (ql < 64)
-    return x ^ (x >> 15);
-#endif
-}
-
 struct ScoreBinArgs {
     const uint64_t* bins; uint64_t bin_cap; const unsigned int* bin_count;      // as BinArgs; bin_cap in 8-byte CELLS (two 4-byte records each)
     uint32_t rec_mode;                             // 0: 8-byte records; 1: 4-byte records (bin_record32); 2: per piece -- bit 31 of the piece's count says
@@ -57,14 +38,17 @@ struct ScoreBinArgs {
     uint64_t* qcand; uint32_t* qcand_n;            // the queries' own candidate slots
     uint32_t* bin_n;                               // [nbins] the bin's record count as found (the host adds them up; > bin_cap: redo)
     const uint32_t* cancel;
+    uint32_t flog2;                                // log2 of the filter's 16-bit cells (0: SB_FILTER_LOG2): the host gives bins of hundreds of thousands
+                                                   // of records (hot-hash data) a filter that counts them in ONE class -- two passes instead of 2 K
 };
 
 __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
 {
     extern __shared__ __align__(16) uint8_t sb_smem[];
     unsigned long long* table = reinterpret_cast<unsigned long long*>(sb_smem);                          // 2^SB_TABLE_LOG2 slots
-    unsigned int* filter = reinterpret_cast<unsigned int*>(sb_smem + ((size_t)8u << SB_TABLE_LOG2));    // 2^(SB_FILTER_LOG2 - 1) words
-    uint64_t* cbuf = reinterpret_cast<uint64_t*>(sb_smem + ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2));   // [2^bq][SB_CAND]
+    const uint32_t flog2 = a.flog2 ? a.flog2 : SB_FILTER_LOG2;
+    unsigned int* filter = reinterpret_cast<unsigned int*>(sb_smem + ((size_t)8u << SB_TABLE_LOG2));    // 2^(flog2 - 1) words
+    uint64_t* cbuf = reinterpret_cast<uint64_t*>(sb_smem + ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << flog2));   // [2^bq][SB_CAND]
     __shared__ uint32_t s_floor[SB_QMAX], s_ccnt[SB_QMAX], s_cbase[SB_QMAX], s_over[SB_QMAX];
     __shared__ uint32_t s_claimed, s_full, s_cancel;
     const uint32_t tid = threadIdx.x, bin = blockIdx.x;
@@ -147,9 +131,15 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                     if (cur[u] == ~0ull) continue;                       // (beyond the piece: a real cell never reads all ones -- its docs are < 2^(32 - bq))
                     const uint64_t i = t0 + (uint64_t)u * SB_WG + tid;
                     const uint32_t lo = (uint32_t)cur[u], hi = (uint32_t)(cur[u] >> 32);
-                    // (all ones: "no record" -- the tail of a reservation padded to whole sectors, fpx_partition.hpp)
-                    if (lo != 0xFFFFFFFFu) fn(((uint64_t)(lo & qm) << 32) | (lo >> a.bq));
-                    if (2u * i + 1u < nrec && hi != 0xFFFFFFFFu) fn(((uint64_t)(hi & qm) << 32) | (hi >> a.bq));
+                    // (BIN_ALIGN > 1 only: all ones in a half is "no record", the tail of a padded reservation -- fpx_partition.hpp.  The two
+                    // tests cost the kernel 18 % when compiled in: 146 -> 173 us, profiles/r05_kernel_stats_first.csv)
+                    if constexpr (BIN_ALIGN > 1u) {
+                        if (lo != 0xFFFFFFFFu) fn(((uint64_t)(lo & qm) << 32) | (lo >> a.bq));
+                        if (2u * i + 1u < nrec && hi != 0xFFFFFFFFu) fn(((uint64_t)(hi & qm) << 32) | (hi >> a.bq));
+                    } else {
+                        fn(((uint64_t)(lo & qm) << 32) | (lo >> a.bq));
+                        if (2u * i + 1u < nrec) fn(((uint64_t)(hi & qm) << 32) | (hi >> a.bq));
+                    }
                 }
             } else {
 #pragma unroll
@@ -163,7 +153,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
     if (n != 0u && n >= (uint64_t)floor_min) {
         // 16-bit cells while no cell can overflow (fewer than 2^16 records in all), 32-bit ones beyond
         const bool wide = n >= 65536ull;
-        const uint32_t F = wide ? (1u << (SB_FILTER_LOG2 - 1u)) : (1u << SB_FILTER_LOG2), fmask = F - 1u;
+        const uint32_t F = wide ? (1u << (flog2 - 1u)) : (1u << flog2), fmask = F - 1u;
         const uint32_t T = 1u << SB_TABLE_LOG2, tmask = T - 1u, fill = T * 3u / 4u;
         // a bin far above the filter's size is counted in K rounds over disjoint doc classes (as k_score's CLASSED form)
         uint32_t K = 1u;
@@ -175,18 +165,15 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
             K = (uint32_t)max<uint64_t>(1ull, min<uint64_t>((n + F - 1ull) / F, 1024ull));
         }
         auto cell_count = [&](uint32_t c) -> uint32_t { return wide ? filter[c] : ((filter[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu); };
-        // (the body once per instantiation: CL = the bin is counted in K > 1 classes of docs)
-        auto classes = [&](auto cl_tag) {
-        constexpr bool CL = decltype(cl_tag)::value || FPX_SB_HASH == 0;
         for (uint32_t kc = 0; kc < K; ++kc) {
-            auto in_class = [&](uint32_t doc) -> bool { if constexpr (CL) return K == 1u || __umulhi(mix32(doc ^ 0x85EBCA6Bu), K) == kc; else return true; };
-            for (uint32_t i = tid; i < (1u << (SB_FILTER_LOG2 - 1u)); i += SB_WG) filter[i] = 0u;
+            auto in_class = [&](uint32_t doc) -> bool { return K == 1u || __umulhi(mix32(doc ^ 0x85EBCA6Bu), K) == kc; };
+            for (uint32_t i = tid; i < (1u << (flog2 - 1u)); i += SB_WG) filter[i] = 0u;
             __syncthreads();
             // ---- stage A: every record of the class into its (query, doc) cell
             for_each_record([&](uint64_t rec) {
                 const uint32_t doc = (uint32_t)rec, ql = (uint32_t)(rec >> 32) & qm;
                 if (!in_class(doc)) return;
-                const uint32_t c = sb_hash(doc, ql) & fmask;
+                const uint32_t c = mix32(doc ^ (ql * 0x9E3779B1u)) & fmask;
                 if (wide) atomicAdd(&filter[c], 1u); else atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
             });
             __syncthreads();
@@ -202,7 +189,7 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                 for_each_record([&](uint64_t rec) {
                     const uint32_t doc = (uint32_t)rec, ql = (uint32_t)(rec >> 32) & qm;
                     if (!in_class(doc)) return;
-                    const uint32_t hsh = sb_hash(doc, ql);
+                    const uint32_t hsh = mix32(doc ^ (ql * 0x9E3779B1u));
                     const uint32_t cc = cell_count(hsh & fmask);
                     if (cc < floor_min) return;                        // (the bin's smallest floor, in a register: nearly every record leaves here)
                     if (cc < s_floor[ql]) return;
@@ -251,8 +238,6 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
                 __syncthreads();
             }
         }
-        };
-        if (K == 1u) classes(std::false_type{}); else classes(std::true_type{});
     }
     // ---- hand-over: up to QCAND_SLOTS candidates stay in the query's own slots, more move to the shared list entirely
     __syncthreads();

@@ -844,7 +844,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             sa.nsrc = 1u; sa.src_stride = 0; sa.count_stride = 0; sa.count_step = BIN_STRIDE;
             sa.opts = d_opts; sa.sb = 32u - qb; sa.cands = ws->d_cands[0]; sa.cand_cap = ws->cap_cands; sa.counters = ws->d_counters;
             sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
-            const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << h_bin.shift) * 8u;
+            // bins of hundreds of thousands of records (hot-hash data: 12 x the records of a uniform batch) get a filter of 2^15 32-bit cells
+            // -- 128 KB, one workgroup per CU -- that counts them in ONE class: two passes over the bin where the 32-KB filter needs 2 K
+            sa.flog2 = est_H / sbins > 60000ull ? 16u : 0u;
+            const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << (sa.flog2 ? sa.flog2 : SB_FILTER_LOG2)) + ((size_t)SB_CAND << h_bin.shift) * 8u;
+            static const hipError_t lds_attr_sb_big = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)lds_attr_sb_big;
             hipLaunchKernelGGL(k_score_bin, dim3(sbins), dim3(SB_WG), sb_lds, st, sa);
         } else {
         hipLaunchKernelGGL(k_l2_count, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, d_qcount, B);
@@ -865,8 +870,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (floor_min <= 2u && est_H / B > (1u << SCORE_TABLE_LOG2)) { log2t = 13; log2f = 11; }
         const size_t cand_guess = std::max<size_t>(1u << 16, (size_t)B * 64);
         if (ws->cap_cands < cand_guess && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess))) return rc;
-        static const hipError_t lds_attr_sb = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)lds_attr_sb;
         static const hipError_t lds_attrs_f[3] = {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),

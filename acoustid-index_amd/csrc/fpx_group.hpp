@@ -337,12 +337,22 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                         const uint32_t eff = __shfl(eff_l, el), T = __shfl(T_l, el), from = __shfl(from_l, el), c2 = __shfl(col, el);
                         const uint32_t md = s_min_doc[c2];
                         if (!filtered) {
-                            for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
-                                const unsigned long long at = gbase + (o2 - from) + lane;
-                                if constexpr (BINNED) {
-                                    if (o2 + lane < eff && at < a.bin_cap)
-                                        bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, hot_bin, at, ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane)), a.counters);
-                                } else if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
+                            for (uint32_t o2 = from; o2 < eff; o2 += 256u) {          // (four loads under way before the first store: fpx_pgroup.hpp)
+                                uint32_t dv[4];
+#pragma unroll
+                                for (uint32_t u = 0; u < 4u; ++u) {
+                                    const uint32_t ix = o2 + u * 64u + lane;
+                                    dv[u] = ix < eff ? gload_u32(list + 1u + T + ix) : 0u;
+                                }
+#pragma unroll
+                                for (uint32_t u = 0; u < 4u; ++u) {
+                                    const uint32_t ix = o2 + u * 64u + lane;
+                                    const unsigned long long at = gbase + (ix - from);
+                                    if constexpr (BINNED) {
+                                        if (ix < eff && at < a.bin_cap)
+                                            bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, hot_bin, at, ((uint64_t)qlo << 32) | (uint64_t)(md + dv[u]), a.counters);
+                                    } else if (ix < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + dv[u]);
+                                }
                             }
                             gbase += eff - from;
                         } else {                     // (superseded docs among them: through the stage, 64 at a time)

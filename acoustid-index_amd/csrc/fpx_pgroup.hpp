@@ -519,12 +519,24 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                         const uint32_t eff = __shfl(eff_l, el), T = __shfl(T_l, el), from = __shfl(from_l, el), c2 = __shfl(col, el);
                         const uint32_t md = s_min_doc[c2];
                         if (!filtered) {
-                            for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
-                                const unsigned long long at = gbase + (o2 - from) + lane;
-                                if constexpr (BINNED) {
-                                    if (o2 + lane < eff && at < a.bin_cap)
-                                        bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, hot_bin, at, ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane)), a.counters);
-                                } else if (o2 + lane < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + gload_u32(list + 1u + T + o2 + lane));
+                            // (FOUR loads under way before the first store: one load and its store at a time, a list of 1000 docs was a chain
+                            // of sixteen memory latencies that the workgroup's other waves waited for at the flush's barrier)
+                            for (uint32_t o2 = from; o2 < eff; o2 += 256u) {
+                                uint32_t dv[4];
+#pragma unroll
+                                for (uint32_t u = 0; u < 4u; ++u) {
+                                    const uint32_t ix = o2 + u * 64u + lane;
+                                    dv[u] = ix < eff ? gload_u32(list + 1u + T + ix) : 0u;
+                                }
+#pragma unroll
+                                for (uint32_t u = 0; u < 4u; ++u) {
+                                    const uint32_t ix = o2 + u * 64u + lane;
+                                    const unsigned long long at = gbase + (ix - from);
+                                    if constexpr (BINNED) {
+                                        if (ix < eff && at < a.bin_cap)
+                                            bin_store(a.bins, a.bin_cap, a.rec32, a.bin_shift, hot_bin, at, ((uint64_t)qlo << 32) | (uint64_t)(md + dv[u]), a.counters);
+                                    } else if (ix < eff && at < a.hit_cap) a.hits[at] = ((uint64_t)qlo << 32) | (uint64_t)(md + dv[u]);
+                                }
                             }
                             gbase += eff - from;
                         } else {                     // (superseded docs among them: through the stage, 64 at a time)

@@ -73,10 +73,12 @@ def _need_gb(env):
     """HBM a variant's child may hold at its peak.  A packed group's lines cost memory by the HASH SPACE, not by the items: 69 GB for
     up to eight columns, 137 GB for sixteen -- and tests/test_gpu_hashshard.py holds the unsharded group AND the ranks' windows of it
     (another 69 GB between them).  The directory + words form: 8.6 / 17 GB per group.  Everything else: small indexes in blocks."""
+    # (measured the hard way: with 150 / 30 the packed child ran out of HBM next to four neighbours -- a download out of a packed group
+    # takes 6 GB of line counts and bases on top of two groups)
     if env.get("FPX_GROUP_PACKED") == "1":
-        return 150
+        return 170
     if env.get("FPX_FUSE_MIN") == "1":
-        return 45 if len(env) == 2 or "FPX_REC32" in env else 30       # (the window slices of tests/test_gpu_hashshard.py next to the whole group)
+        return 45
     return 15
 
 
@@ -94,7 +96,7 @@ class _HbmScheduler:
     def __init__(self, jobs):
         import threading
         self.cv = threading.Condition()
-        self.budget = _free_gb() - 10.0      # what the device has free now, before any child runs
+        self.budget = _free_gb() - 15.0      # what the device has free now, before any child runs
         self.reserved = 0.0                  # GB promised to the running children (they take it gradually: the free HBM of the moment would over-admit)
         self.running = 0
         self.jobs = jobs

@@ -771,6 +771,7 @@ static void snapshot_free(Snapshot* sn)
     sn->groups.clear(); sn->solo_stores.clear();
     if (sn->d_mem) (void)hipFree(sn->d_mem);
     if (sn->d_memtab) (void)hipFree(sn->d_memtab);
+    if (sn->d_membits) (void)hipFree(sn->d_membits);
     if (sn->d_membucket) (void)hipFree(sn->d_membucket);
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;

@@ -242,6 +242,7 @@ struct Snapshot {
     // ... and ONE table of all memory segments' LIVE postings (superseded docs dropped), sorted by hash, behind a 2^20-entry bucket
     // table: a query hash is looked up once for all memory segments, in any key order (fpx_probe_small.hpp: k_probe_memtab)
     uint64_t* d_memtab = nullptr; uint32_t* d_membucket = nullptr; uint64_t n_memtab = 0;
+    uint32_t* d_membits = nullptr;         // one bit per 256 hash values: the table holds a posting there (k_probe_memtab's first load)
     uint64_t mem_items = 0;                // items of all memory segments together (0: nothing to look up, table or not)
     std::vector<std::shared_ptr<DeadSet>> dead_sets;   // shared with the segments' caches
     uint32_t max_block_size = 0;

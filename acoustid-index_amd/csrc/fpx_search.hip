@@ -110,8 +110,16 @@ int build_memtab(Snapshot* sn)
     // (the whole key: Item order, src/segment.zig:90-94 -- hash, then doc)
     if (n > 1 && sort_u64(d_temp, tb + 256, buf[0], buf[1], n, 0, 64, st, &cur) != hipSuccess) return fail(FPX_E_DEVICE);
     hipLaunchKernelGGL(k_memtab_buckets, dim3(((1u << MEMTAB_BITS) + 256) / 256), dim3(256), 0, st, (const uint64_t*)buf[cur], (uint64_t)n, d_bucket);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(FPX_E_DEVICE);
-    sn->d_memtab = buf[cur]; sn->d_membucket = d_bucket; sn->n_memtab = n;
+    // (the presence bits: optional -- without them the kernel starts at the bucket table)
+    uint32_t* d_bits = nullptr;
+    const size_t bits_bytes = ((size_t)1 << (32u - MEMTAB_FILTER_SHIFT)) / 8u;
+    if (n != 0 && hipMalloc(&d_bits, bits_bytes) == hipSuccess) {
+        if (hipMemsetAsync(d_bits, 0, bits_bytes, st) != hipSuccess) { (void)hipFree(d_bits); d_bits = nullptr; }
+        else hipLaunchKernelGGL(k_memtab_bits, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, (const uint64_t*)buf[cur], (uint64_t)n, d_bits);
+    }
+    (void)hipGetLastError();
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { if (d_bits) (void)hipFree(d_bits); return fail(FPX_E_DEVICE); }
+    sn->d_memtab = buf[cur]; sn->d_membucket = d_bucket; sn->n_memtab = n; sn->d_membits = d_bits;
     (void)hipFree(buf[1 - cur]); (void)hipFree(d_count); (void)hipFree(d_temp);
     return FPX_OK;
 }
@@ -768,7 +776,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         if (P && snap->n_mem && snap->d_memtab) {
             hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((P + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
-                               d_pairs, P, qb, flagged ? KEY_SKIP_FLAGGED : key_skip, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
+                               d_pairs, P, qb, flagged ? KEY_SKIP_FLAGGED : key_skip, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters,
+                               (const unsigned long long*)nullptr, 0ull, (const uint32_t*)snap->d_membits);
             FPX_HIP(hipGetLastError());
         } else if (P && snap->n_mem) {
             uint64_t mem_items = 0, mem_max = 0;
@@ -1664,7 +1673,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             // the memory segments' table: the window's keys looked up there too, the records into the misc buffer (k_bin bins them)
             if (snap->n_mem && snap->d_memtab)
                 hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((P + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
-                                   (const uint64_t*)ws->d_keys[kcur], P, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, (const unsigned long long*)d_P, 0ull);
+                                   (const uint64_t*)ws->d_keys[kcur], P, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, (const unsigned long long*)d_P, 0ull, (const uint32_t*)snap->d_membits);
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             // what the kernel could not place itself (a clash of two bins on one slot of a round, a full stage): k_bin
             BinArgs hb{};
@@ -1850,7 +1859,7 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
             // the memory segments' table (replicated on every rank: a rank only receives the keys of its window)
             if (snap->n_mem && snap->d_memtab)
                 hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((key_cap + WG - 1) / WG), world), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
-                                   d_keys_recv, key_cap, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, d_key_counts, key_cap);
+                                   d_keys_recv, key_cap, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, d_key_counts, key_cap, (const uint32_t*)snap->d_membits);
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             BinArgs hb{};
             hb.bins = d_send; hb.bin_cap = rec_cap; hb.bin_count = ws->d_cells; hb.shift = SHARD_BQ; hb.nbins = std::min<uint32_t>(ncells, MAX_SBINS);

@@ -41,6 +41,7 @@ namespace fpx {
 #endif
 constexpr uint32_t PK_RANKED = 0x80000000u;       // upper word of a staged record that carries its rank (see the kernel's stage)
 static_assert(GB_SLOTS <= 128u, "a staged record has seven bits for its bin's slot");
+static_assert(FPX_PK_WORDS % 4 == 0, "the words are fetched in 16-byte pieces");
 constexpr uint32_t PK_WORDS = FPX_PK_WORDS; // words of a hash walked by its lane (16-byte pieces of its line); the rare rest by the wave
 #ifndef FPX_PK_WAVES
 #define FPX_PK_WAVES 5

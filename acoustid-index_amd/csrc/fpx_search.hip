@@ -857,8 +857,15 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             // -- 128 KB, one workgroup per CU -- that counts them in ONE class: two passes over the bin where the 32-KB filter needs 2 K
             sa.flog2 = est_H / sbins > 60000ull ? 16u : 0u;
             const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << (sa.flog2 ? sa.flog2 : SB_FILTER_LOG2)) + ((size_t)SB_CAND << h_bin.shift) * 8u;
-            static const hipError_t lds_attr_sb_big = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-            (void)lds_attr_sb_big;
+            {   // (a function's attribute belongs to the device it is set on: once per device, not once per process)
+                static std::atomic<uint64_t> attr_done{0};
+                const uint64_t bit = 1ull << ((unsigned)snap->ctx->device & 63u);
+                if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+                    (void)hipGetLastError();
+                    attr_done.fetch_or(bit, std::memory_order_release);
+                }
+            }
             hipLaunchKernelGGL(k_score_bin, dim3(sbins), dim3(SB_WG), sb_lds, st, sa);
         } else {
         hipLaunchKernelGGL(k_l2_count, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, d_qcount, B);

@@ -244,8 +244,17 @@ static int win_reserve_bins(ShardedSnapshot* ss, WinBufs* b, uint32_t bpr, uint6
 // `recv`.  RCCL (grouped ncclSend / ncclRecv over xGMI) when every rank has a device of its own, peer copies otherwise.  Every
 // enqueue of a group is attempted and the group is always closed; after any RCCL error the communicators are aborted and the
 // snapshot falls back to peer copies (a half-built group must not be completed, and must not be left open either).
+struct A2APart { std::vector<const uint8_t*> send; std::vector<uint8_t*> recv; size_t row_bytes; };
 template <typename T>
-static int win_all_to_all(ShardedSnapshot* ss, WinBufs* b, const std::vector<T*>& send, const std::vector<T*>& recv, size_t row_bytes)
+static A2APart a2a_part(const std::vector<T*>& send, const std::vector<T*>& recv, size_t row_bytes)
+{
+    A2APart p; p.row_bytes = row_bytes;
+    for (T* x : send) p.send.push_back(reinterpret_cast<const uint8_t*>(x));
+    for (T* x : recv) p.recv.push_back(reinterpret_cast<uint8_t*>(x));
+    return p;
+}
+// (`parts`: what travels together -- the slots and their counts -- in ONE group / one round of copies, waited for once)
+static int win_all_to_all(ShardedSnapshot* ss, WinBufs* b, const A2APart* parts, int nparts)
 {
     const uint32_t n = b->world;
     if (ss->use_rccl.load(std::memory_order_acquire)) {
@@ -256,9 +265,12 @@ static int win_all_to_all(ShardedSnapshot* ss, WinBufs* b, const std::vector<T*>
             bool opened = nrc == 0;
             for (uint32_t k = 0; k < n && nrc == 0; ++k) {
                 if (hipSetDevice(ss->ctxs[k]->device) != hipSuccess) { nrc = -1; break; }
-                for (uint32_t w = 0; w < n && nrc == 0; ++w) {
-                    nrc = r.Send(reinterpret_cast<const uint8_t*>(send[k]) + (size_t)w * row_bytes, row_bytes, NCCL_UINT8, (int)w, ss->comms[k], ss->xstreams[k]);
-                    if (nrc == 0) nrc = r.Recv(reinterpret_cast<uint8_t*>(recv[k]) + (size_t)w * row_bytes, row_bytes, NCCL_UINT8, (int)w, ss->comms[k], ss->xstreams[k]);
+                for (int pi = 0; pi < nparts && nrc == 0; ++pi) {
+                    const A2APart& p = parts[pi];
+                    for (uint32_t w = 0; w < n && nrc == 0; ++w) {
+                        nrc = r.Send(p.send[k] + (size_t)w * p.row_bytes, p.row_bytes, NCCL_UINT8, (int)w, ss->comms[k], ss->xstreams[k]);
+                        if (nrc == 0) nrc = r.Recv(p.recv[k] + (size_t)w * p.row_bytes, p.row_bytes, NCCL_UINT8, (int)w, ss->comms[k], ss->xstreams[k]);
+                    }
                 }
             }
             if (nrc != 0) {
@@ -280,9 +292,11 @@ static int win_all_to_all(ShardedSnapshot* ss, WinBufs* b, const std::vector<T*>
     }
     for (uint32_t k = 0; k < n; ++k) {
         FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
-        for (uint32_t w = 0; w < n; ++w)
-            FPX_HIP(hipMemcpyPeerAsync(reinterpret_cast<uint8_t*>(recv[w]) + (size_t)k * row_bytes, ss->ctxs[w]->device,
-                                       reinterpret_cast<const uint8_t*>(send[k]) + (size_t)w * row_bytes, ss->ctxs[k]->device, row_bytes, b->xs[k]));
+        for (int pi = 0; pi < nparts; ++pi) {
+            const A2APart& p = parts[pi];
+            for (uint32_t w = 0; w < n; ++w)
+                FPX_HIP(hipMemcpyPeerAsync(p.recv[w] + (size_t)k * p.row_bytes, ss->ctxs[w]->device, p.send[k] + (size_t)w * p.row_bytes, ss->ctxs[k]->device, p.row_bytes, b->xs[k]));
+        }
     }
     for (uint32_t k = 0; k < n; ++k) {
         FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
@@ -764,16 +778,17 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
         int r;
         // ---- the shares (1/N of the batch's hashes to each device) and their keys, dealt to the windows
         uint64_t key_cap = std::max<uint64_t>(ss->key_cap.load(), share_pairs / n + share_pairs / (16ull * n) + 1024);
-        run_all([&](uint32_t k) -> int {
-            const uint32_t nq = q_hi[k] - q_lo[k];
-            sub_off[k].resize((size_t)nq + 1);
-            for (uint32_t q = 0; q <= nq; ++q) sub_off[k][q] = offsets[q_lo[k] + q] - offsets[q_lo[k]];
-            return query_batch_create_impl(ss->ctxs[k], hashes ? hashes + offsets[q_lo[k]] : nullptr, sub_off[k].data(), nq, opts + q_lo[k], &shares[k]);
-        });
-        if ((r = first_error())) return r;
+        // (ONE fan-out for the share's upload and its keys: a batch's stages are host-sequenced, every fan-out is a round of wake-ups)
         for (int attempt = 0;; ++attempt) {
             if ((r = win_reserve_keys(ss, b, key_cap))) return r;
             run_all([&](uint32_t k) -> int {
+                if (!shares[k]) {
+                    const uint32_t nq = q_hi[k] - q_lo[k];
+                    sub_off[k].resize((size_t)nq + 1);
+                    for (uint32_t q = 0; q <= nq; ++q) sub_off[k][q] = offsets[q_lo[k] + q] - offsets[q_lo[k]];
+                    const int crc = query_batch_create_impl(ss->ctxs[k], hashes ? hashes + offsets[q_lo[k]] : nullptr, sub_off[k].data(), nq, opts + q_lo[k], &shares[k]);
+                    if (crc != FPX_OK) return crc;
+                }
                 return shard_keys_impl(ss->ctxs[k], shares[k], n, k, B, b->keys_send[k], b->key_cap, b->kcnt_send[k], &needs[k]);
             });
             r = first_error();
@@ -783,8 +798,10 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
         }
         ss->key_cap.store(b->key_cap);
         // ---- all-to-all #1: slot w of every rank's keys (and its count) to rank w
-        if ((r = win_all_to_all(ss, b, b->keys_send, b->keys_recv, (size_t)b->key_cap * sizeof(uint64_t)))) return r;
-        if ((r = win_all_to_all(ss, b, b->kcnt_send, b->kcnt_recv, sizeof(unsigned long long)))) return r;
+        {
+            const A2APart parts[2] = {a2a_part(b->keys_send, b->keys_recv, (size_t)b->key_cap * sizeof(uint64_t)), a2a_part(b->kcnt_send, b->kcnt_recv, sizeof(unsigned long long))};
+            if ((r = win_all_to_all(ss, b, parts, 2))) return r;
+        }
         // ---- probes: the received slots -> the batch's bins
         uint64_t cell_cap = std::max<uint64_t>(ss->cell_cap.load(), 2048);
         for (int attempt = 0;; ++attempt) {
@@ -800,8 +817,10 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
         }
         ss->cell_cap.store(b->cell_cap);
         // ---- all-to-all #2: the bins (and their counts) to the rank that finishes their queries
-        if ((r = win_all_to_all(ss, b, b->bins_send, b->bins_recv, (size_t)bpr * b->cell_cap * sizeof(uint64_t)))) return r;
-        if ((r = win_all_to_all(ss, b, b->bcnt_send, b->bcnt_recv, (size_t)bpr * sizeof(uint32_t)))) return r;
+        {
+            const A2APart parts[2] = {a2a_part(b->bins_send, b->bins_recv, (size_t)bpr * b->cell_cap * sizeof(uint64_t)), a2a_part(b->bcnt_send, b->bcnt_recv, (size_t)bpr * sizeof(uint32_t))};
+            if ((r = win_all_to_all(ss, b, parts, 2))) return r;
+        }
         if (timeout_ms && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count() > (double)timeout_ms) { set_error("search timeout"); return FPX_E_TIMEOUT; }
         // ---- every rank finishes its queries: straight into the caller's rows
         run_all([&](uint32_t k) -> int {

@@ -222,6 +222,7 @@ static const OptInfo OPT_TABLE[OPT_COUNT] = {
     /* OPT_DIRECT_ROUNDS */      {"direct_rounds", "FPX_DIRECT_ROUNDS", 0, 0, true},
     /* OPT_LEAN_ROUNDS */        {"lean_rounds", "FPX_LEAN_ROUNDS", 0, 0, true},
     /* OPT_SHARDED_WORKERS */    {"sharded_workers", "FPX_SHARDED_WORKERS", 3, 1, true},
+    /* OPT_KEY_ORDER_BITS */     {"key_order_bits", "FPX_KEY_ORDER_BITS", 8, 0, true},          // top hash bits the flagged keys of a large batch are ordered by
 };
 
 int64_t ctx_opt(const Ctx* c, CtxOpt o)
@@ -471,6 +472,24 @@ int fpx_ctx_get_option(const fpx_ctx* ctx, const char* name, int64_t* value)
     const int o = opt_by_name(name);
     if (!c || o < 0 || !value) { set_error("fpx_ctx_get_option: unknown option"); return FPX_E_INVAL; }
     *value = ctx_opt(c, (CtxOpt)o);         // the value in force: the context's own, else the environment's, else the default
+    return FPX_OK;
+}
+
+int fpx_ctx_scan_histograms(const fpx_ctx* ctx, fpx_scan_histograms* out, uint64_t* unbucketed)
+{
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    if (!c || !out) { set_error("null argument"); return FPX_E_INVAL; }
+    uint64_t h[HIST_SLOTS + 1];
+    for (uint32_t i = 0; i <= HIST_SLOTS; ++i) h[i] = c->scan_hist[i].load(std::memory_order_relaxed);
+    std::memset(out, 0, sizeof *out);
+    // the slots hold what falls OUTSIDE the histograms' first buckets, and the totals (fpx_internal.h): the first buckets are the rest
+    uint64_t docs_rest = 0, blocks_rest = 0;
+    for (uint32_t i = 0; i < 9; ++i) { out->docs_bucket[i + 1] = h[i]; docs_rest += h[i]; }
+    for (uint32_t i = 0; i < 3; ++i) { out->blocks_bucket[i + 1] = h[9 + i]; blocks_rest += h[9 + i]; }
+    out->count = h[HIST_COUNT]; out->docs_sum = h[HIST_DOCS]; out->blocks_sum = h[HIST_BLOCKS];
+    out->docs_bucket[0] = out->count - std::min(out->count, docs_rest);
+    out->blocks_bucket[0] = out->count - std::min(out->count, blocks_rest);
+    if (unbucketed) *unbucketed = h[HIST_SLOTS];
     return FPX_OK;
 }
 

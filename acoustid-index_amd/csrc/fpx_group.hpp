@@ -78,6 +78,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
     uint16_t* s_rank = reinterpret_cast<uint16_t*>(gk_dyn + (size_t)FSTAGE_CAP * sizeof(uint64_t));      // (a rank inside a bin of one round: < 2048)
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
+    __shared__ uint32_t wg_h[HIST_SLOTS];                 // the scan histograms' slots of this workgroup (fpx_direct.hpp: hist_observe)
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
     // per column, indexed by a lane's own column number
     __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
     if (tid < FUSE_MAX) { s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
     if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid / GB_SLOTS][tid % GB_SLOTS] = 0u; s_bid[tid / GB_SLOTS][tid % GB_SLOTS] = GB_EMPTY; }
     if constexpr (BINNED) for (uint32_t i = tid; i < FSTAGE_CAP; i += FK_WG) s_rank[i] = GB_NEED;
+    if (tid < HIST_SLOTS) wg_h[tid] = 0u;
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                         } else {
                             doc = s_min_doc[s] + word;
                             my_blocks += second ? 0u : 1u; my_docs += 1u;
+                            if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += second ? (1u << 16) : 0u;     // (a double: ONE observation of two docs, counted at its second word)
                             keep |= 1u << j;
                         }
                     }
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
         const uint32_t xd0 = xmd + (xT ? x.z : x.y), xd1 = xmd + (xT ? x.w : x.z), xd2 = xmd + x.w;
         if (n_esc != 0u) {
             my_blocks += (x.x >> 16) & 7u; my_docs += xeff;
+            hist_observe(wg_h, xeff, (x.x >> 16) & 7u);
             xkeep = (1u << xin) - 1u;
             if (any_dead && s_has_dead[esc_col]) {
                 const SegDesc& f = ga.segs[s_seg_index[esc_col]];
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                     const uint32_t doc = s_min_doc[col] + wv;
                     if (plain) {
                         my_blocks += second ? 0u : 1u; my_docs += 1u;
+                        if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += second ? (1u << 16) : 0u;
                         if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (second ? 0ull : 1ull) | (1ull << 32));
                     }
                     const bool kp = plain && !(any_dead && s_has_dead[col] && is_dead_seg(ga.segs[s_seg_index[col]], doc));
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                     const uint32_t from_l = slot_list ? min(eff_l, T_l ? 2u : 3u) : 0u;
                     if (is_list && !slot_list) {
                         my_blocks += (hdr_l >> 16) & 7u; my_docs += eff_l; my_reads += 2u;
+                        hist_observe(wg_h, eff_l, (hdr_l >> 16) & 7u);
                         if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
                     }
                     const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                         if (first && (uint32_t)el < GK_WORDS) from = min(eff, T ? 2u : 3u);          // (the lane's slot took these)
                         else if (lane == 0) {
                             my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u;
+                            hist_observe(wg_h, eff, (hdr >> 16) & 7u);
                             if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr >> 16) & 7u) | ((unsigned long long)eff << 32));
                         }
                         first = false;
@@ -445,8 +452,11 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
             return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)incl, 15) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31) +
                    (uint32_t)__builtin_amdgcn_readlane((int)incl, 47) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         };
-        const unsigned long long w_reads = wave_total(my_reads), w_blocks = wave_total(my_blocks), w_docs = wave_total(my_docs), w_probes = wave_total(my_probes);
+        // (my_probes: the probes in its lower half, the doubles among them in its upper one -- 16 per key and round at most, rounds <= 1024)
+        const unsigned long long w_reads = wave_total(my_reads), w_blocks = wave_total(my_blocks), w_docs = wave_total(my_docs), w_probes = wave_total(my_probes & 0xFFFFu);
+        const uint32_t w_doubles = (uint32_t)wave_total(my_probes >> 16);
         if ((threadIdx.x & 63u) == 0u) {
+            if (w_doubles) atomicAdd(&wg_h[0], w_doubles);                       // (two docs: the second bucket of the docs histogram)
             if (w_reads) atomicAdd(&wg_reads, w_reads);
             if (w_blocks) atomicAdd(&wg_blocks, w_blocks);
             if (w_docs) atomicAdd(&wg_docs, w_docs);
@@ -470,6 +480,7 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
             if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);       // (64-byte units here)
         }
     }
+    hist_publish(a, wg_h, wg_probes, wg_docs, wg_blocks, tid);
 }
 
 }  // namespace fpx

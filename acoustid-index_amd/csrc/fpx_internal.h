@@ -103,7 +103,16 @@ struct MemDesc {
 // LEAN_STAT_SETS copies of the slots on separate lines (workgroup i -> set i % LEAN_STAT_SETS), summed on the host.
 constexpr uint32_t LEAN_STAT_SETS = 64;
 constexpr uint32_t DEF_COUNT_STRIDE = 32;      // 32-bit words between the segments' deferred-list counts: a line each, for the same reason
-constexpr size_t LEAN_STAT_WORDS = (size_t)LEAN_STAT_SETS * 8 * 2;      // in 32-bit words (8 x u64 = one 64-B line per set)
+// The scan histograms of the direct-addressed kernels (src/FileSegment.zig:177-178, buckets of src/metrics.zig:9-10): every (hash, segment)
+// walk is ONE observation of (num_docs, num_blocks).  Nearly all observe (0 | 1 doc, 0 | 1 block) -- the first bucket of both histograms --,
+// so the kernels count the OTHERS and the totals; the first buckets are what is left.  HIST_SLOTS 64-bit slots per set (a line), behind the
+// LEAN_STAT_SETS x 8 statistics slots:
+//   0..8   observations in docs bucket 1..9 (2 | 3 | 4-5 | 6-10 | 11-50 | 51-100 | 101-500 | 501-1000 | more)
+//   9..11  observations in blocks bucket 1..3 (2 | 3 | 4-5 blocks; the reference stops after four)
+//   12     observations in all, 13 their docs, 14 their blocks (the histograms' _count and _sum)
+constexpr uint32_t HIST_SLOTS = 16;
+constexpr uint32_t HIST_COUNT = 12, HIST_DOCS = 13, HIST_BLOCKS = 14;
+constexpr size_t LEAN_STAT_WORDS = (size_t)LEAN_STAT_SETS * (8 + HIST_SLOTS) * 2;      // in 32-bit words ([SETS][8] u64 statistics, then [SETS][HIST_SLOTS] u64)
 
 // per-batch counters living in device memory (one 64-bit word each)
 enum Counter : int {
@@ -123,7 +132,8 @@ enum Counter : int {
     CTR_BINFAIL = 12,    // k_score_bin: a bin met more distinct (query, doc) pairs than its table takes: the batch is redone on the general path
     CTR_PADS = 15,       // "no record" entries that pad the bins' reservations to whole sectors (BIN_ALIGN): the bins' fill counts include them
     CTR_SLOTCANDS = 14,  // candidates handed from k_score to k_finish through the queries' own slots (statistics)
-    CTR_COUNT = 16       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
+    CTR_HIST = 16,       // [16..31]: the HIST_SLOTS histogram slots of a launch too small for the spread sets (LEAN_STAT_SETS)
+    CTR_COUNT = 32       // [8..15]: the same statistics slots, written by k_probe_lean8 (ctr_off = 8)
 };
 
 // ---------------------------------------------------------------- host objects
@@ -285,6 +295,7 @@ struct Workspace {
     uint64_t hint_misc = 0;               // records the last binned batch left in the misc buffer (sizes k_bin's grid)
     uint64_t hint_P = 0, hint_H = 0;      // pairs and hit records of the last batch this workspace ran (sizes the next one)
     uint32_t fast_penalty = 0;            // batches left before the device-sized path is tried again after it had to be redone
+    uint64_t batch_hist[HIST_SLOTS + 1] = {};  // the scan histogram slots of the batch run_batch just finished, [HIST_SLOTS]: walks answered from blocks (search_split adds them to the context's)
     // pinned host staging
     unsigned long long* h_counters = nullptr;
     // one small query travels in ONE pinned copy: [offsets 2 x u64 | opts 4 x u32 | hashes]
@@ -316,6 +327,7 @@ enum CtxOpt : int {
     OPT_LOCAL_SORT_MAX, OPT_ORDER_MIN_PAIRS, OPT_ORDER_MAX_PAIRS, OPT_LEAN_MIN, OPT_STAGED_OUT_MAX,
     OPT_GROUP_ROUNDS, OPT_DIRECT_ROUNDS, OPT_LEAN_ROUNDS,
     OPT_SHARDED_WORKERS,
+    OPT_KEY_ORDER_BITS,
     OPT_COUNT
 };
 constexpr int64_t OPT_UNSET = -2;
@@ -323,12 +335,16 @@ constexpr int64_t OPT_UNSET = -2;
 struct Ctx {
     int device = 0;
     std::atomic<int64_t> opts[OPT_COUNT];
-    Ctx() { for (auto& o : opts) o.store(OPT_UNSET, std::memory_order_relaxed); }
+    Ctx() { for (auto& o : opts) o.store(OPT_UNSET, std::memory_order_relaxed); for (auto& h : scan_hist) h.store(0, std::memory_order_relaxed); }
     std::mutex mu;
     std::mutex group_mu;                  // serialises the grouping of segments (fpx_snapshot_create, fpx_segments_group)
     std::vector<Workspace*> free_ws;
     std::atomic<int> live_ws{0};
+    // the running scan histograms of the probes the direct-addressed kernels answered (fpx_ctx_scan_histograms), in HIST_SLOTS slots;
+    // [HIST_SLOTS]: (hash, segment) walks the block-form kernels answered meanwhile -- counted, not bucketed
+    std::atomic<uint64_t> scan_hist[HIST_SLOTS + 1];
 };
+void ctx_hist_add(Ctx* c, const uint64_t* slots, uint64_t unbucketed);     // (a batch's slots, after it has succeeded)
 
 // the options of a context (fpx_ctx_set_option), falling back to the environment and the defaults
 int64_t ctx_opt(const Ctx* c, CtxOpt o);   // the value in force (c may be null: environment, then default)

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi, s_cancel;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
     __shared__ uint32_t wg_pads;
+    __shared__ uint32_t wg_h[HIST_SLOTS];                 // the scan histograms' slots of this workgroup (fpx_direct.hpp: hist_observe)
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
     // per column, indexed by a lane's own column number; per chunk of the hash space: where its `ext` starts
     __shared__ uint32_t s_min_doc[FUSE_MAX], s_has_dead[FUSE_MAX], s_seg_index[FUSE_MAX];
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
     if (tid < FUSE_MAX) { s_first[tid] = g->first_hash[tid]; s_last[tid] = g->last_hash[tid]; }
     if (tid < FUSE_MAX) { s_min_doc[tid] = g->min_doc[tid]; s_has_dead[tid] = g->has_dead[tid]; s_seg_index[tid] = g->seg_index[tid]; }
     if (tid < GROUP_CHUNKS) s_ext[tid] = tid < g->nchunks ? g->ext_tab[tid] : nullptr;
+    if (tid < HIST_SLOTS) wg_h[tid] = 0u;
     if (BINNED && tid < 2u * GB_SLOTS) { s_bcnt[tid / GB_SLOTS][tid % GB_SLOTS] = 0u; s_bid[tid / GB_SLOTS][tid % GB_SLOTS] = GB_EMPTY; }
     if (tid == 0) {
         stage_count = 0; stage_valid = FSTAGE_CAP;
@@ -282,6 +284,8 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             for (uint32_t d = dm, t = 0; d != 0u; d &= d - 1u, ++t) second |= 1u << ((uint32_t)__builtin_ctz(d) + t + 1u);
             add_docs = (uint32_t)__popc(keep);
             add_blocks = (uint32_t)__popc(keep & ~second);
+            // (the scan histograms: a double is ONE observation of two docs, counted where its second word is -- the upper half of my_probes)
+            if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += (uint32_t)__popc(keep & second) << 16;
         } else {
             uint64_t cols = 0;                                   // column of word j in bits 4j .. 4j+3
             uint32_t rest = pm, i = 0;
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                         } else {
                             gw[j] = s_min_doc[s] + word;
                             add_blocks += second ? 0u : 1u; add_docs += 1u;
+                            if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += second ? (1u << 16) : 0u;
                             keep |= 1u << j;
                         }
                     }
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             }
         };
         uint32_t xkeep = 0;
-        if (n_esc != 0u) { xkeep = list_head(list_word(lmask), esc_col); add_blocks += xblk; add_docs += xeff; }
+        if (n_esc != 0u) { xkeep = list_head(list_word(lmask), esc_col); add_blocks += xblk; add_docs += xeff; hist_observe(wg_h, xeff, xblk); }
         const uint32_t xeff1 = xeff, xin1 = xin;             // (of the FIRST list: what the wave's turn, if there is one, continues from)
         emit(keep, xkeep, true);
         // what is left for the whole wave: words beyond the lane's own, a third list, a list longer than its head
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
         if (!more && n_esc == 2u) {
             const uint32_t yk = list_head(list_word(lmask & (lmask - 1u)), esc_col2);
             if (xeff > xin) more = true;                     // (longer than seven docs: the wave walks it from its start, and counts it)
-            else { add_blocks += xblk; add_docs += xeff; emit(0u, yk, false); }
+            else { add_blocks += xblk; add_docs += xeff; hist_observe(wg_h, xeff, xblk); emit(0u, yk, false); }
         }
         my_blocks += add_blocks; my_docs += add_docs;
         if (QS && GQSTATS(a) && valid && (my_blocks != blocks_before || my_docs != docs_before))
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                     const uint32_t doc = s_min_doc[col] + wv;
                     if (plain) {
                         my_blocks += second ? 0u : 1u; my_docs += 1u;
+                        if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += second ? (1u << 16) : 0u;
                         if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (second ? 0ull : 1ull) | (1ull << 32));
                     }
                     const bool kp = plain && !(any_dead && s_has_dead[col] && is_dead_seg(ga.segs[s_seg_index[col]], doc));
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                     const uint32_t from_l = slot_list ? min(eff_l, xin_s) : 0u;
                     if (is_list && !slot_list) {
                         my_blocks += (hdr_l >> 16) & 7u; my_docs += eff_l; my_reads += 2u;
+                        hist_observe(wg_h, eff_l, (hdr_l >> 16) & 7u);
                         if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
                     }
                     const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
@@ -565,6 +572,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                         if (first && (uint32_t)el < mine_s) from = min(eff, xin_s);          // (the lane's slot took these)
                         else if (lane == 0) {
                             my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u;
+                            hist_observe(wg_h, eff, (hdr >> 16) & 7u);
                             if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr >> 16) & 7u) | ((unsigned long long)eff << 32));
                         }
                         first = false;
@@ -662,8 +670,11 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)incl, 15) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31) +
                    (uint32_t)__builtin_amdgcn_readlane((int)incl, 47) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         };
-        const unsigned long long w_reads = wave_total(my_reads), w_blocks = wave_total(my_blocks), w_docs = wave_total(my_docs), w_probes = wave_total(my_probes);
+        // (my_probes: the probes in its lower half, the doubles among them in its upper one -- 16 per key and round at most, rounds <= 1024)
+        const unsigned long long w_reads = wave_total(my_reads), w_blocks = wave_total(my_blocks), w_docs = wave_total(my_docs), w_probes = wave_total(my_probes & 0xFFFFu);
+        const uint32_t w_doubles = (uint32_t)wave_total(my_probes >> 16);
         if (lane == 0u) {
+            if (w_doubles) atomicAdd(&wg_h[0], w_doubles);                       // (two docs: the second bucket of the docs histogram)
             if (w_reads) atomicAdd(&wg_reads, w_reads);
             if (w_blocks) atomicAdd(&wg_blocks, w_blocks);
             if (w_docs) atomicAdd(&wg_docs, w_docs);
@@ -689,6 +700,7 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
             if (wg_reads) atomicAdd(&a.counters[CTR_LEAN_READS], wg_reads);       // (64-byte units here)
         }
     }
+    hist_publish(a, wg_h, wg_probes, wg_docs, wg_blocks, tid);
 }
 
 }  // namespace fpx

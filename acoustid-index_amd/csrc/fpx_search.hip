@@ -390,6 +390,25 @@ __global__ void k_dest_bounds(const uint64_t* __restrict__ recs, uint64_t n, uin
     bounds[d] = lo;
 }
 
+// The scan histogram slots of a batch that has reached the host (fpx_internal.h, HIST_SLOTS): what small launches added to the batch's
+// counters + the spread sets behind the statistics sets (`sets`: the [LEAN_STAT_SETS][8] statistics, or null); `probes`: every (hash,
+// file segment) walk of the batch -- those the direct-addressed kernels did not answer were answered from blocks, unbucketed.
+static void gather_hist(uint64_t* dst, const unsigned long long* h_counters, const unsigned long long* sets, uint64_t probes)
+{
+    for (uint32_t i = 0; i < HIST_SLOTS; ++i) dst[i] = h_counters[CTR_HIST + i];
+    if (sets) {
+        const unsigned long long* hs = sets + (size_t)LEAN_STAT_SETS * 8;
+        for (uint32_t k = 0; k < LEAN_STAT_SETS; ++k)
+            for (uint32_t i = 0; i < HIST_SLOTS; ++i) dst[i] += hs[(size_t)k * HIST_SLOTS + i];
+    }
+    dst[HIST_SLOTS] = probes > dst[HIST_COUNT] ? probes - dst[HIST_COUNT] : 0ull;
+}
+void ctx_hist_add(Ctx* c, const uint64_t* slots, uint64_t unbucketed)
+{
+    for (uint32_t i = 0; i < HIST_SLOTS; ++i) if (slots[i]) c->scan_hist[i].fetch_add(slots[i], std::memory_order_relaxed);
+    if (unbucketed) c->scan_hist[HIST_SLOTS].fetch_add(unbucketed, std::memory_order_relaxed);
+}
+
 static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, uint32_t q0,
                      const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
@@ -401,6 +420,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // batch re-enters here (a redo on the general path, the two halves of a split)
     const double t_start = t_call != 0.0 ? t_call : now_ms();
     hipStream_t st = ws->stream;
+    std::memset(ws->batch_hist, 0, sizeof ws->batch_hist);
     __atomic_store_n(ws->h_cancel, 0u, __ATOMIC_RELEASE);           // (the stream is idle: the previous call synchronised it)
     const uint32_t* cancel = timeout_ms ? ws->d_cancel : nullptr;
     const uint64_t base = offsets[0];
@@ -493,7 +513,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // (memory segments do not stand in the way once the snapshot has their ONE table: k_probe_memtab reads keys in any order)
     bool flagged = snap->n_file == 0 && (snap->n_mem == 0 || snap->d_memtab != nullptr) && snap->n_direct != 0 && !score_only;
     for (uint32_t q = 0; q < B && flagged; ++q) flagged = offsets[q + 1] - offsets[q] <= DEDUP_MAX;
-    const uint32_t key_skip = flagged ? KEY_SORT_SKIP_DIRECT : KEY_SORT_SKIP;
+    // (flagged keys are ordered for locality alone: by how many of the top hash bits is the context's choice -- fewer bits, fewer
+    // queries per round of a workgroup, larger reservations in their bins)
+    const uint32_t key_skip = flagged ? 32u - (uint32_t)std::min<int64_t>(8, std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_KEY_ORDER_BITS))) : KEY_SORT_SKIP;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
     const uint64_t local_sort_max = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_LOCAL_SORT_MAX));
     bool local_sort = P && !score_only && !single_fast && !flagged && B >= 2u && P <= local_sort_max && snap->n_small == 0;
@@ -683,7 +705,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
                     if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; }
                     const uint32_t group_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_GROUP_ROUNDS));
-                    gk.rounds = group_rounds ? group_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
+                    gk.rounds = group_rounds ? std::min(group_rounds, 1024u) : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
                     // (hot-hash data -- the previous batch brought 16+ records per key: a workgroup's rounds wait for the waves that copy the
                     // long lists; three rounds: 3.5 ms per batch of 8192 on distribution Z where five take 4.4)
                     if (!group_rounds && fast && est_H > 16ull * P) gk.rounds = std::min(gk.rounds, 3u);
@@ -920,7 +942,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         {
             PublishArgs pa{};
             pa.counters = ws->d_counters; pa.h_counters = mapped_address(ws->h_counters);
-            pa.a_src = ws->d_def_count; pa.a_dst = spread ? mapped_address(ws->h_def_count) : nullptr; pa.a_n = spread ? (uint32_t)def_words : 0u;
+            pa.a_src = ws->d_def_count; pa.a_dst = spread ? mapped_address(ws->h_def_count) : nullptr; pa.a_n = spread ? (uint32_t)def_words : 0u;      // (not spread: the histogram slots ride in the counters)
             uint32_t* d_hbins = mapped_address(ws->h_bins);
             pa.b_src = binned ? d_bin_n : d_bin_count; pa.b_dst = d_hbins + BINQ_HEAD;
             pa.b_n = binned ? sbins : h_bin.nbins; pa.b_stride = binned ? 1u : BIN_STRIDE;
@@ -972,6 +994,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             FPX_SYNC(ws);
         }
         if (!partial && (rc = deliver_results(ws, B, out_cap, staged, out, out_n, st))) return rc;
+        {
+            const unsigned long long* ls = spread ? reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off) : nullptr;
+            unsigned long long probes = ws->h_counters[CTR_PROBES];
+            if (ls) for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) probes += ls[i * 8 + 3];
+            gather_hist(ws->batch_hist, ws->h_counters, ls, probes);
+        }
         if (stats) {
             unsigned long long reads = 0, blocks = 0, docs = 0, probes = 0, bytes_off = 0;
             unsigned long long pads = ws->h_counters[CTR_PADS];          // ("no record" entries in the bins' counts: fpx_partition.hpp, BIN_ALIGN)
@@ -1038,6 +1066,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         *out_n = (uint32_t)ws->h_counters[CTR_COUNT];
         std::memcpy(out, ws->h_counters + CTR_COUNT + 1, (size_t)*out_n * sizeof(fpx_result));
+        gather_hist(ws->batch_hist, ws->h_counters, nullptr, ws->h_counters[CTR_PROBES]);
         if (stats) {                             // counters only: the fast path takes no device timestamps
             const float total_ms = 0.f, ms = 0.f;
             stats->probes += ws->h_counters[CTR_PROBES];
@@ -1073,6 +1102,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                                                : snap->n_direct ? ws->h_counters[CTR_LEAN_READS] * 64ull + (snap->n_file ? ws->h_counters[CTR_BYTES] : 0ull)   // (k_probe_direct / _fused without the spread statistics: 64-byte units)
                                                : ws->h_counters[CTR_BYTES];
 
+    if (!score_only)
+        gather_hist(ws->batch_hist, ws->h_counters, spread ? reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off) : nullptr, c_probes);
     uint64_t C = 0, C_slots = 0;                   // candidates in the shared list / in the queries' own slots
     uint64_t* d_qcand = nullptr;
     uint32_t* d_qcand_n = nullptr;
@@ -1268,6 +1299,7 @@ static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
         if (q_docs) q_docs[0] = local.scanned_docs;
     }
     if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    if (rc == FPX_OK) ctx_hist_add(snap->ctx, ws->batch_hist, ws->batch_hist[HIST_SLOTS]);       // (the context's running scan histograms: fpx_ctx_scan_histograms)
     ws_release(snap->ctx, ws);
     if (rc == FPX_OK) { if (stats) add_stats(stats, local); return FPX_OK; }
     if (rc != FPX_SPLIT) return rc;
@@ -1715,6 +1747,14 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
                       (unsigned long long)rec_cap);
             return FPX_E_AGAIN;
         }
+        {   // the window's probes join the context's running scan histograms (a step the ranks redo for larger buffers is observed again)
+            const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
+            unsigned long long probes = 0;
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) probes += ls[i * 8 + 3];
+            uint64_t hist[HIST_SLOTS + 1];
+            gather_hist(hist, ws->h_counters, ls, probes);
+            ctx_hist_add(snap->ctx, hist, hist[HIST_SLOTS]);
+        }
         if (stats) {
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
             unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0;
@@ -1895,6 +1935,14 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
             set_error("fpx_shard_probe_keys: a bin holds %llu records, the send buffer has room for %llu per bin", (unsigned long long)ws->h_counters[CTR_TOTAL],
                       (unsigned long long)rec_cap);
             return FPX_E_AGAIN;
+        }
+        {   // the window's probes join the context's running scan histograms (a step the ranks redo for larger buffers is observed again)
+            const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);
+            unsigned long long probes = 0;
+            for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) probes += ls[i * 8 + 3];
+            uint64_t hist[HIST_SLOTS + 1];
+            gather_hist(hist, ws->h_counters, ls, probes);
+            ctx_hist_add(snap->ctx, hist, hist[HIST_SLOTS]);
         }
         if (stats) {
             const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_cells);

@@ -60,6 +60,14 @@ public:
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     fpx_ctx* handle() const { return h_; }
+    // the running scan histograms of everything the context's direct-addressed segments answered (metrics.scanned_docs_per_hash /
+    // scanned_blocks_per_hash, src/metrics.zig:9-10); `unbucketed`: walks answered from blocks meanwhile
+    fpx_scan_histograms scanHistograms(uint64_t* unbucketed = nullptr) const
+    {
+        fpx_scan_histograms h;
+        check(fpx_ctx_scan_histograms(h_, &h, unbucketed));
+        return h;
+    }
 private:
     fpx_ctx* h_ = nullptr;
 };

@@ -56,6 +56,15 @@ class Context:
         option's smallest (-1, or -2 for 'group_packed' / 'bin_q_log2') puts it back to the environment / default"""
         check(lib().fpx_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def scan_histograms(self):
+        """fpx_ctx_scan_histograms: the context's RUNNING scan histograms (src/FileSegment.zig:177-178, buckets of src/metrics.zig:9-10) --
+        every (hash, segment) walk the direct-addressed kernels answered since the context was created, bucketed as it was answered.
+        Returns (ScanHistograms, walks answered from blocks meanwhile: counted, not bucketed)."""
+        from ._lib import ScanHistograms
+        acc, unb = ScanHistograms(), C.c_uint64(0)
+        check(lib().fpx_ctx_scan_histograms(self.h, C.byref(acc), C.byref(unb)))
+        return acc, int(unb.value)
+
     def get_option(self, name):
         v = C.c_int64()
         check(lib().fpx_ctx_get_option(self.h, name.encode(), C.byref(v)))

@@ -111,6 +111,7 @@ int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context live
  *   "bin_q_log2"         log2 of the queries per bin (-1: by the batch's size, default)
  *   "rec32"              1 | 0   4-byte records in the bins where the doc ids leave room (default 1)
  *   "local_sort_max", "order_min_pairs", "order_max_pairs"   pair counts that choose how a batch's keys are ordered
+ *   "key_order_bits"     top hash bits the keys of a batch on direct-addressed segments are ordered by (0..8, default 8)
  *   "lean_min"           probes from which block-form segments take the lean kernel (default 2^16)
  *   "staged_out_max"     bytes of results a batch stages in pinned memory (-1: built-in)
  *   "group_rounds", "direct_rounds", "lean_rounds"   rounds per workgroup of the probe kernels (0: by the batch's size)
@@ -261,6 +262,15 @@ typedef struct {
 } fpx_scan_histograms;
 int fpx_scan_histograms_observe(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets, uint32_t num_queries,
                                 uint32_t timeout_ms, fpx_scan_histograms *acc);
+/* The same two histograms for ALL the traffic of a context, exact and free, where the segments are direct-addressed (every
+ * dense segment: the forms that answer the 100 M index).  Their kernels hold every (hash, segment) walk's (num_docs, num_blocks)
+ * explicitly -- absent | one doc | two docs inline | a list's header -- and bucket the walks as they answer them; a context keeps
+ * the RUNNING totals of every search that succeeded on it (any entry point, any thread; a batch that was redone on another path
+ * counts once; a step of the fpx_shard_* protocols that the ranks redo for larger buffers is observed again).  *out receives the
+ * totals since the context was created -- the process-wide histograms src/metrics.zig keeps --, in fpx_scan_histograms' layout.
+ * Walks that were answered from BLOCKS meanwhile (segments below "direct_min_items" between merges, "direct" = 0) are not
+ * bucketed by their kernels: *unbucketed (may be NULL) counts them; sample those with fpx_scan_histograms_observe, or scale. */
+int fpx_ctx_scan_histograms(const fpx_ctx *ctx, fpx_scan_histograms *out, uint64_t *unbucketed);
 
 /* Query batch already resident in HBM: what a host-side coalescer that keeps its staging buffers on the
  * device would hand over, and what bench.py times ("inputs resident in HBM when the timed region starts").

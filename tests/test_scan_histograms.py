@@ -150,7 +150,55 @@ def _child():
         # the searches themselves are untouched by the replay
         p.check(queries[:4], fpx.http_options())
         print(f"{label}: {want['count']} observations, docs buckets {want['docs_bucket']}, blocks buckets {want['blocks_bucket']}", flush=True)
+    _running_histograms(fpx, oracle, Pair, items, queries)
     print("scan histograms ok", flush=True)
+
+
+def _running_histograms(fpx, oracle, Pair, items, queries):
+    """fpx_ctx_scan_histograms: the direct-addressed kernels bucket every walk as they answer it -- the context's running totals grow
+    by exactly the oracle's observations with every search, whatever the entry point and the path (a workspace's first batch takes the
+    general path, its second the device-sized one, a single query its own); walks answered from blocks are counted, not bucketed"""
+    def delta(a, b):
+        return {k: ([y - x for x, y in zip(a[k], b[k])] if isinstance(a[k], list) else b[k] - a[k]) for k in a}
+
+    forms = (("blocks", {}, False), ("a group, directory + words", {"direct_min_items": 0, "group_packed": 0}, True),
+             ("a packed group", {"direct_min_items": 0, "group_packed": 1}, True), ("each on its own", {"direct_min_items": 0, "fuse_min": 0}, True))
+    for label, options, bucketed in forms:
+        ctx = fpx.Context(0)
+        for k, v in options.items():
+            ctx.set_option(k, v)
+        p = Pair(ctx)
+        for it, lo, hi, cid in items:
+            p.add_file(it, lo, hi, cid, np.arange(lo, hi + 1, dtype=np.uint32))
+        p.add_memory_changes([("insert", 900001, [int(h) for h in queries[0][:20]])], len(items) + 1)
+        p.finish()
+        want, per_query = expected_histograms(oracle, p.orc_file, queries)
+        zero = {k: ([0] * len(v) if isinstance(v, list) else 0) for k, v in want.items()}
+        h0, u0 = ctx.scan_histograms()
+        assert h0.as_dict() == zero and u0 == 0, (label, h0.as_dict(), u0)
+        flags = []
+        for rep in range(3):                                   # the batch entry point: general path, then the device-sized one
+            before, ub = ctx.scan_histograms()
+            got, st = p.reader.search_batch(queries, fpx.http_options())
+            after, ua = ctx.scan_histograms()
+            flags.append(st.path_flags)
+            d = delta(before.as_dict(), after.as_dict())
+            assert d == (want if bucketed else zero), (label, rep, d, want)
+            assert ua - ub == (0 if bucketed else want["count"]), (label, rep, ua - ub)
+        before, ub = ctx.scan_histograms()
+        for q in queries:                                      # the single-query entry point, query by query
+            res = fpx.SearchResults(fpx.http_options())
+            p.reader.search(q, res)
+        after, ua = ctx.scan_histograms()
+        d = delta(before.as_dict(), after.as_dict())
+        assert d == (want if bucketed else zero), (label, "single", d, want)
+        assert ua - ub == (0 if bucketed else want["count"]), (label, "single", ua - ub)
+        # legacy options (a floor of 1: the general path's count-only rounds) observe the same walks
+        before, _ = ctx.scan_histograms()
+        p.reader.search_batch(queries, fpx.SearchOptions(500, 1, 0))          # (src/legacy.zig:185-196)
+        after, _ = ctx.scan_histograms()
+        assert delta(before.as_dict(), after.as_dict()) == (want if bucketed else zero), (label, "legacy")
+        print(f"running histograms, {label}: ok (path flags of the three batches {flags})", flush=True)
 
 
 @pytest.mark.gpu

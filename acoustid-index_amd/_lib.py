@@ -119,6 +119,7 @@ SIGNATURES = {
     "fpx_search_batch_stats": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats), _vp, _vp]),
     "fpx_scan_histograms_observe": (C.c_int, [_vp, _vp, _vp, _u32, _u32, C.POINTER(ScanHistograms)]),
     "fpx_ctx_scan_histograms": (C.c_int, [_vp, C.POINTER(ScanHistograms), C.POINTER(C.c_uint64)]),
+    "fpx_ctx_trim": (C.c_uint64, [_vp]),
     "fpx_search_batch_partial": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, C.POINTER(Stats)]),
     "fpx_query_batch_create": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(_vp)]),
     "fpx_query_batch_release": (None, [_vp]),

@@ -28,6 +28,83 @@ int hip_fail(hipError_t e, const char* what)
     return e == hipErrorOutOfMemory ? FPX_E_NOMEM : FPX_E_DEVICE;
 }
 
+// ---------------------------------------------------------------- device memory (fpx_internal.h: line_pool_*, dmalloc)
+namespace {
+constexpr int POOL_DEVICES = 64;
+constexpr size_t POOL_MIN_BYTES = (size_t)1 << 30;       // smaller buffers map and unmap in milliseconds
+struct LinePool { std::mutex mu; void* p = nullptr; size_t bytes = 0; };
+LinePool g_line_pool[POOL_DEVICES];
+}  // namespace
+
+void* line_pool_take(int device, size_t bytes)
+{
+    if (device < 0 || device >= POOL_DEVICES) return nullptr;
+    LinePool& lp = g_line_pool[device];
+    void* old = nullptr;
+    void* hit = nullptr;
+    {
+        std::lock_guard<std::mutex> g(lp.mu);
+        if (lp.p && lp.bytes == bytes) hit = lp.p; else old = lp.p;
+        lp.p = nullptr; lp.bytes = 0;
+    }
+    if (old) (void)hipFree(old);
+    return hit;
+}
+
+void line_pool_put(int device, void* p, size_t bytes)
+{
+    if (!p) return;
+    void* old = p;
+    if (device >= 0 && device < POOL_DEVICES && bytes >= POOL_MIN_BYTES) {
+        LinePool& lp = g_line_pool[device];
+        std::lock_guard<std::mutex> g(lp.mu);
+        old = lp.p;
+        lp.p = p; lp.bytes = bytes;
+    }
+    if (old) (void)hipFree(old);
+}
+
+size_t line_pool_flush(int device)
+{
+    size_t freed = 0;
+    for (int d = device < 0 ? 0 : device; d < (device < 0 ? POOL_DEVICES : std::min(device + 1, POOL_DEVICES)); ++d) {
+        LinePool& lp = g_line_pool[d];
+        void* old = nullptr;
+        {
+            std::lock_guard<std::mutex> g(lp.mu);
+            old = lp.p; freed += lp.bytes;
+            lp.p = nullptr; lp.bytes = 0;
+        }
+        if (old) (void)hipFree(old);
+    }
+    return freed;
+}
+
+size_t line_pool_bytes(int device)
+{
+    if (device < 0 || device >= POOL_DEVICES) return 0;
+    std::lock_guard<std::mutex> g(g_line_pool[device].mu);
+    return g_line_pool[device].bytes;
+}
+
+hipError_t dmalloc_raw(void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || line_pool_flush(device) == 0) return e;
+    (void)hipGetLastError();
+    return hipMalloc(p, bytes);
+}
+
+hipError_t mem_info(size_t* free_b, size_t* total_b)
+{
+    const hipError_t e = hipMemGetInfo(free_b, total_b);
+    int device = 0;
+    if (e == hipSuccess && hipGetDevice(&device) == hipSuccess) *free_b += line_pool_bytes(device);
+    return e;
+}
+
 // ---------------------------------------------------------------- workspace pool
 Workspace* ws_acquire(Ctx* ctx)
 {
@@ -45,7 +122,7 @@ Workspace* ws_acquire(Ctx* ctx)
               hipEventCreate(&w->ev_begin) == hipSuccess && hipEventCreate(&w->ev_probe0) == hipSuccess &&
               hipEventCreate(&w->ev_probe1) == hipSuccess && hipEventCreate(&w->ev_probe2) == hipSuccess &&
               hipEventCreate(&w->ev_end) == hipSuccess &&
-              hipMalloc(&w->d_counters, COUNTERS_BYTES) == hipSuccess &&
+              dmalloc(&w->d_counters, COUNTERS_BYTES) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&w->h_counters), COUNTERS_BYTES, hipHostMallocMapped) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&w->h_cancel), 64, hipHostMallocMapped) == hipSuccess &&
               hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<uint32_t**>(&w->d_cancel)), w->h_cancel, 0) == hipSuccess;
@@ -170,7 +247,7 @@ int finish_file_segment(Segment* s)
     if (rc) return rc;
     {
         const size_t words = ((size_t)s->num_blocks + 63) / 64 * 2 + 2;
-        FPX_HIP(hipMalloc(&s->d_cont, words * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&s->d_cont, words * sizeof(uint32_t)));
         FPX_HIP(hipMemset(s->d_cont, 0, words * sizeof(uint32_t)));
         s->device_bytes += words * sizeof(uint32_t);
         if (s->num_blocks)
@@ -178,7 +255,7 @@ int finish_file_segment(Segment* s)
                                s->d_blocks, s->block_size, s->num_blocks, s->d_block_index, s->d_cont);
     }
     unsigned long long* d_total = nullptr;
-    FPX_HIP(hipMalloc(&d_total, 8));
+    FPX_HIP(dmalloc(&d_total, 8));
     FPX_HIP(hipMemset(d_total, 0, 8));
     if (s->num_blocks)
         hipLaunchKernelGGL(k_count_items, dim3((s->num_blocks + 255) / 256), dim3(256), 0, 0,
@@ -345,7 +422,7 @@ int regroup_segments(Ctx* c, const std::vector<Segment*>& segs, uint32_t* regrou
     // seconds of encoding and ~50 GB of blocks on every merge
     need += group_bytes_lower_bound(c, m.data(), (uint32_t)m.size());
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
+    if (mem_info(&free_b, &total_b) != hipSuccess || free_b < need) {
         (void)hipGetLastError();
         set_error("not enough free HBM to rebuild the group of %zu segments (%.1f GB for their blocks and the new group, %.1f free)", m.size(), need / 1e9, free_b / 1e9);
         return FPX_E_NOMEM;
@@ -475,6 +552,14 @@ int fpx_ctx_get_option(const fpx_ctx* ctx, const char* name, int64_t* value)
     return FPX_OK;
 }
 
+uint64_t fpx_ctx_trim(fpx_ctx* ctx)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    return line_pool_flush(c->device);
+}
+
 int fpx_ctx_scan_histograms(const fpx_ctx* ctx, fpx_scan_histograms* out, uint64_t* unbucketed)
 {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
@@ -527,8 +612,8 @@ static int create_file_impl(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_
     // src/streamvbyte.zig:5 / src/FileSegment.zig:87 made explicit)
     s->blocks_len = ((size_t)num_blocks + 1) * block_size;
     const size_t alloc = s->blocks_len + 16;
-    hipError_t e = hipMalloc(&s->d_blocks, alloc);
-    if (e == hipSuccess) e = hipMalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t));
+    hipError_t e = dmalloc(&s->d_blocks, alloc);
+    if (e == hipSuccess) e = dmalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t));
     if (e != hipSuccess) { segment_free(s); return hip_fail(e, "hipMalloc(segment)"); }
     s->device_bytes = alloc + ((size_t)num_blocks + 1) * sizeof(uint32_t);
     const size_t copy = (size_t)num_blocks * block_size;
@@ -594,8 +679,8 @@ int fpx_segment_slice(fpx_segment* seg, int has_lo, uint32_t lo_excl, int has_hi
     s->doc_ids = g->doc_ids; s->doc_alive = g->doc_alive;
     s->blocks_len = ((size_t)s->num_blocks + 1) * s->block_size;
     const size_t alloc = s->blocks_len + 16, copy = (size_t)s->num_blocks * s->block_size;
-    hipError_t er = hipMalloc(&s->d_blocks, alloc);
-    if (er == hipSuccess) er = hipMalloc(&s->d_block_index, ((size_t)s->num_blocks + 1) * sizeof(uint32_t));
+    hipError_t er = dmalloc(&s->d_blocks, alloc);
+    if (er == hipSuccess) er = dmalloc(&s->d_block_index, ((size_t)s->num_blocks + 1) * sizeof(uint32_t));
     if (er != hipSuccess) { segment_free(s); return hip_fail(er, "hipMalloc(segment slice)"); }
     s->device_bytes = alloc + ((size_t)s->num_blocks + 1) * sizeof(uint32_t);
     if ((er = hipMemset(s->d_blocks + copy, 0, alloc - copy)) != hipSuccess ||
@@ -625,7 +710,7 @@ int fpx_segment_create_memory(fpx_ctx* ctx_, const uint64_t* items, size_t num_i
     s->ctx = c; s->kind = 1; s->commit_id = commit_id; s->min_doc_id = min_doc_id; s->max_doc_id = max_doc_id;
     s->num_items = num_items;
     set_docs(s, doc_ids, doc_alive, num_docs);
-    hipError_t e = hipMalloc(&s->d_items, (num_items + 1) * sizeof(uint64_t));
+    hipError_t e = dmalloc(&s->d_items, (num_items + 1) * sizeof(uint64_t));
     if (e == hipSuccess && num_items) e = hipMemcpy(s->d_items, items, num_items * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) { segment_free(s); return hip_fail(e, "memory segment upload"); }
     s->device_bytes = (num_items + 1) * sizeof(uint64_t);
@@ -866,7 +951,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
                 ds = std::make_shared<DeadSet>();
                 ds->device = c->device;
                 ds->ids = dead;
-                hipError_t e = hipMalloc(&ds->d_list, dead.size() * sizeof(uint32_t));
+                hipError_t e = dmalloc(&ds->d_list, dead.size() * sizeof(uint32_t));
                 if (e == hipSuccess) e = hipMemcpy(ds->d_list, dead.data(), dead.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
                 // One bit per doc id of [slo, shi]: the per-posting supersession test becomes one load (the sorted list
                 // costs a 17-step binary search per hit).  Ids are assigned densely in practice; a range wider than 2^29
@@ -874,7 +959,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
                 if (e == hipSuccess && s->kind == 0 && (uint64_t)shi - slo < (1ull << 29)) {
                     std::vector<uint32_t> bits(((size_t)(shi - slo) >> 5) + 1, 0u);
                     for (uint32_t id : dead) bits[(id - slo) >> 5] |= 1u << ((id - slo) & 31u);
-                    e = hipMalloc(&ds->d_bits, bits.size() * sizeof(uint32_t));
+                    e = dmalloc(&ds->d_bits, bits.size() * sizeof(uint32_t));
                     if (e == hipSuccess) e = hipMemcpy(ds->d_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
                 }
                 if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "dead set upload"); }
@@ -914,7 +999,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     if (sn->max_block_size == 0) sn->max_block_size = 512;
     hipError_t e = hipSuccess;
     if (sn->n_direct) {
-        e = hipMalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
+        e = dmalloc(&sn->d_direct, sn->n_direct * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_direct, sn->h_direct.data(), sn->n_direct * sizeof(SegDesc), hipMemcpyHostToDevice);
         // Direct-addressed segments are searched in GROUPS of up to 16 (fpx_group.hpp: one directory line and one run of words
         // answer a hash for the whole group; resolve_candidates, above, formed them).  A group whose other columns are not part
@@ -947,12 +1032,12 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         }
         sn->n_group = (uint32_t)sn->h_group.size(); sn->n_solo = (uint32_t)h_solo.size();
         if (e == hipSuccess && sn->n_solo) {
-            e = hipMalloc(&sn->d_solo, h_solo.size() * sizeof(SegDesc));
+            e = dmalloc(&sn->d_solo, h_solo.size() * sizeof(SegDesc));
             if (e == hipSuccess) e = hipMemcpy(sn->d_solo, h_solo.data(), h_solo.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
         }
     }
     if (e == hipSuccess && sn->n_file) {
-        e = hipMalloc(&sn->d_file, sn->n_file * sizeof(SegDesc));
+        e = dmalloc(&sn->d_file, sn->n_file * sizeof(SegDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_file, sn->h_file.data(), sn->n_file * sizeof(SegDesc), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && sn->n_file) {
@@ -972,20 +1057,20 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         lean.insert(lean.end(), lean4.begin(), lean4.end());
         sn->n_lean = (uint32_t)lean.size(); sn->n_gen = (uint32_t)gen.size(); sn->n_small = (uint32_t)small.size();
         if (sn->n_small) {
-            e = hipMalloc(&sn->d_small, small.size() * sizeof(SegDesc));
+            e = dmalloc(&sn->d_small, small.size() * sizeof(SegDesc));
             if (e == hipSuccess) e = hipMemcpy(sn->d_small, small.data(), small.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
         }
         if (e == hipSuccess && sn->n_lean) {
-            e = hipMalloc(&sn->d_lean, lean.size() * sizeof(SegDesc));
+            e = dmalloc(&sn->d_lean, lean.size() * sizeof(SegDesc));
             if (e == hipSuccess) e = hipMemcpy(sn->d_lean, lean.data(), lean.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
         }
         if (e == hipSuccess && sn->n_gen) {
-            e = hipMalloc(&sn->d_gen, gen.size() * sizeof(SegDesc));
+            e = dmalloc(&sn->d_gen, gen.size() * sizeof(SegDesc));
             if (e == hipSuccess) e = hipMemcpy(sn->d_gen, gen.data(), gen.size() * sizeof(SegDesc), hipMemcpyHostToDevice);
         }
     }
     if (e == hipSuccess && sn->n_mem) {
-        e = hipMalloc(&sn->d_mem, sn->n_mem * sizeof(MemDesc));
+        e = dmalloc(&sn->d_mem, sn->n_mem * sizeof(MemDesc));
         if (e == hipSuccess) e = hipMemcpy(sn->d_mem, sn->h_mem.data(), sn->n_mem * sizeof(MemDesc), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "snapshot upload"); }

@@ -266,7 +266,7 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
     int alloc(size_t bytes)
     {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        hipError_t e = dmalloc(&p, bytes ? bytes : 16);
         if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return FPX_E_NOMEM; }
         return FPX_OK;
     }
@@ -348,7 +348,7 @@ int scan_counts_u32(const uint32_t* counts, uint64_t n, uint64_t* offsets, uint6
     if (nparts > 0x7FFFFFFFull) { set_error("scan of %llu counts", (unsigned long long)n); return FPX_E_INVAL; }
     uint64_t* partsum = nullptr;
     const bool pooled = hipMallocAsync(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t), st) == hipSuccess;
-    if (!pooled) { (void)hipGetLastError(); partsum = nullptr; FPX_HIP(hipMalloc(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t))); }
+    if (!pooled) { (void)hipGetLastError(); partsum = nullptr; FPX_HIP(dmalloc(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t))); }
     hipLaunchKernelGGL(k_scan_part_sums, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, partsum);
     hipLaunchKernelGGL(k_scan_u64_inplace, dim3(1), dim3(1024), 0, st, partsum, nparts, total);
     hipLaunchKernelGGL(k_scan_part_write, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, (const uint64_t*)partsum, offsets);
@@ -417,8 +417,8 @@ static int encode_sorted_items(const uint64_t* items, uint64_t n, uint32_t min_d
     // encode
     s->num_blocks = num_blocks;
     s->blocks_len = ((size_t)num_blocks + 1) * block_size;
-    FPX_HIP(hipMalloc(&s->d_blocks, s->blocks_len + 16));
-    FPX_HIP(hipMalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t)));
+    FPX_HIP(dmalloc(&s->d_blocks, s->blocks_len + 16));
+    FPX_HIP(dmalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t)));
     s->device_bytes = s->blocks_len + 16 + ((size_t)num_blocks + 1) * sizeof(uint32_t);
     FPX_HIP(hipMemsetAsync(s->d_blocks + (size_t)num_blocks * block_size, 0, block_size + 16, st));   // terminator + slack
     if (num_blocks) {
@@ -678,9 +678,9 @@ int decode_small_segment(Segment* s)
     if ((rc = counts.alloc((size_t)s->num_blocks * 4)) || (rc = boff.alloc((size_t)s->num_blocks * 8)) || (rc = tot.alloc(8)) ||
         (rc = live.alloc(s->num_items + 16)))
         return rc;
-    FPX_HIP(hipMalloc(&s->d_small_items, (s->num_items + 1) * sizeof(uint64_t)));
+    FPX_HIP(dmalloc(&s->d_small_items, (s->num_items + 1) * sizeof(uint64_t)));
     if (!s->d_bstart) {
-        FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)s->num_blocks + 1) * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&s->d_bstart, ((size_t)s->num_blocks + 1) * sizeof(uint32_t)));
         s->device_bytes += ((size_t)s->num_blocks + 1) * sizeof(uint32_t);
     }
     s->device_bytes += (s->num_items + 1) * sizeof(uint64_t);
@@ -796,10 +796,10 @@ __global__ void k_fill_proberec(const uint32_t* __restrict__ block_index, const 
 int build_presence(Segment* s)
 {
     if (s->block_size != 512 || s->num_blocks == 0 || s->num_items < (1ull << 20)) return FPX_OK;      // not a lean segment
-    FPX_HIP(hipMalloc(&s->d_blockrec, ((size_t)s->num_blocks + 3) * sizeof(uint2)));
+    FPX_HIP(dmalloc(&s->d_blockrec, ((size_t)s->num_blocks + 3) * sizeof(uint2)));
     s->device_bytes += ((size_t)s->num_blocks + 3) * sizeof(uint2);
     unsigned int* d_head_max = nullptr;
-    FPX_HIP(hipMalloc(&d_head_max, sizeof(unsigned int)));
+    FPX_HIP(dmalloc(&d_head_max, sizeof(unsigned int)));
     FPX_HIP(hipMemsetAsync(d_head_max, 0, sizeof(unsigned int), 0));
     hipLaunchKernelGGL(k_block_records, dim3((s->num_blocks + 3 + 255) / 256), dim3(256), 0, 0,
                        s->d_blocks, s->d_block_index, s->num_blocks, s->d_blockrec, d_head_max);
@@ -821,8 +821,8 @@ int build_presence(Segment* s)
     const size_t bytes = (size_t)nrec * 64u;
     size_t free_b = 0, total_b = 0;
     // (without the records the segment is searched by the generic kernel: correct, slower)
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) return FPX_OK;
-    if (hipMalloc(&s->d_proberec, bytes) != hipSuccess) { s->d_proberec = nullptr; (void)hipGetLastError(); return FPX_OK; }
+    if (mem_info(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) return FPX_OK;
+    if (dmalloc(&s->d_proberec, bytes) != hipSuccess) { s->d_proberec = nullptr; (void)hipGetLastError(); return FPX_OK; }
     FPX_HIP(hipMemsetAsync(s->d_proberec, 0, bytes, 0));
     // FPX_PRESENCE_MIN_ITEMS above the segment's size: every bit set, i.e. every probe reads its block (tests, A/B runs)
     const bool with_bits = s->num_items >= presence_min_items(s->ctx);
@@ -1096,7 +1096,7 @@ int direct_candidate(Segment* s, bool* ok)
     }
     s->first_hash = h_ends[0]; s->last_hash = h_ends[1];
     if (!s->d_bstart) {
-        FPX_HIP(hipMalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&s->d_bstart, ((size_t)nb + 1) * sizeof(uint32_t)));
         s->device_bytes += ((size_t)nb + 1) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_block_item_counts, dim3((nb + 255) / 256), dim3(256), 0, st, s->d_blocks, s->block_size, nb, counts.as<uint32_t>());
         if ((rc = scan_counts_u32(counts.as<uint32_t>(), (uint64_t)nb, boff.as<uint64_t>(), tot.as<uint64_t>(), st))) return rc;
@@ -1122,7 +1122,7 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     int rc;
     *out = DirectPiece{};
     out->nrec = nrec;
-    FPX_HIP(hipMalloc(&out->drec, (size_t)nrec * 64u));
+    FPX_HIP(dmalloc(&out->drec, (size_t)nrec * 64u));
     FPX_HIP(hipMemsetAsync(out->drec, 0, (size_t)nrec * 64u, st));
     DevBuf rectot, recbase, tot;
     if ((rc = rectot.alloc((size_t)nrec * 4)) || (rc = recbase.alloc((size_t)nrec * 8)) || (rc = tot.alloc(64))) return rc;
@@ -1130,8 +1130,8 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     FPX_HIP(hipMemsetAsync(tot.p, 0, 64, st));
     if (nbl == 0) {                      // no block of the segment reaches into the range: every position clear
         hipLaunchKernelGGL(k_direct_rec_counts, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, rectot.as<uint32_t>(), nrec);
-        FPX_HIP(hipMalloc(&out->primary, 16 * sizeof(uint32_t)));
-        FPX_HIP(hipMalloc(&out->extras, 16 * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&out->primary, 16 * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&out->extras, 16 * sizeof(uint32_t)));
         FPX_HIP(hipMemsetAsync(out->primary, 0xFF, 16 * sizeof(uint32_t), st));
         FPX_HIP(hipMemsetAsync(out->extras, 0, 16 * sizeof(uint32_t), st));
         FPX_HIP(hipStreamSynchronize(st));
@@ -1177,8 +1177,8 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
     if (Dp < D) { set_error("internal: %llu set bits for %llu distinct hashes", (unsigned long long)Dp, (unsigned long long)D); return FPX_E_DEVICE; }
     if (h_flags[0] || h_flags[1] || (X >> pad) >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull) return FPX_E_INVAL;      // does not qualify
-    FPX_HIP(hipMalloc(&out->primary, (Dp + 4) * sizeof(uint32_t)));
-    FPX_HIP(hipMalloc(&out->extras, (X + 8) * sizeof(uint32_t)));
+    FPX_HIP(dmalloc(&out->primary, (Dp + 4) * sizeof(uint32_t)));
+    FPX_HIP(dmalloc(&out->extras, (X + 8) * sizeof(uint32_t)));
     FPX_HIP(hipMemsetAsync(out->primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
     FPX_HIP(hipMemsetAsync(out->extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
     // (at most n / DIRECT_LONG lists are that long; a queue that cannot be had -- memory -- leaves the copies to k_direct_fill's threads)
@@ -1218,7 +1218,7 @@ int build_direct(Segment* s)
     const uint32_t nb = s->num_blocks;
     size_t free_b = 0, total_b = 0;
     // peak: the items (8 n) + records (1 GB) + primary and extras (<= ~10 n) on top of the blocks
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 18ull + ((size_t)10 << 30)) {
+    if (mem_info(&free_b, &total_b) != hipSuccess || free_b < n * 18ull + ((size_t)10 << 30)) {
         (void)hipGetLastError();
         s->why = "blocks: not enough free HBM to convert it (the direct-addressed form is built next to the blocks)";
         return FPX_OK;
@@ -1328,7 +1328,7 @@ int materialize_blocks(const Segment* s, uint8_t** d_blocks_out)
     if ((rc = materialize_items(s, items.as<uint64_t>(), st))) return rc;
     hipLaunchKernelGGL(k_bstart_quads, dim3((nb + 256) / 256), dim3(256), 0, st, s->d_bstart, nb, quads.as<uint64_t>());
     uint8_t* blocks = nullptr;
-    FPX_HIP(hipMalloc(&blocks, s->blocks_len + 16));
+    FPX_HIP(dmalloc(&blocks, s->blocks_len + 16));
     hipError_t e = hipMemsetAsync(blocks + (size_t)nb * s->block_size, 0, s->block_size + 16, st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_encode_blocks, dim3((nb + 3) / 4), dim3(256), 4 * s->block_size, st, items.as<uint64_t>(), n, s->min_doc_id,

@@ -53,7 +53,7 @@ struct DevMem {
     ~DevMem() { if (p) (void)hipFree(p); }
     int alloc(size_t bytes)
     {
-        const hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        const hipError_t e = dmalloc(&p, bytes ? bytes : 8);
         if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc(group build)"); }
         return FPX_OK;
     }
@@ -506,7 +506,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     // segments as they are)
     const uint64_t need = group_bytes_lower_bound(ctx, segs, k);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)3 << 30)) {
+    if (mem_info(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)3 << 30)) {
         (void)hipGetLastError();
         for (uint32_t j = 0; j < k; ++j) if (!segs[j]->direct) segs[j]->why = "blocks: not enough free HBM to build the group next to the members' blocks";
         set_error("not enough free HBM to group %u segments (%.1f GB needed, %.1f free)", k, need / 1e9, free_b / 1e9);
@@ -524,7 +524,12 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         a.delta[j] = packed ? s->min_doc_id - gmin : 0u;
     }
     g->gmin = packed ? gmin : 0u;
-    hipError_t e = hipMalloc(&g->d_lines, nlines * line_words * 4ull + 64);      // (+ 64: a lane's last 16-byte piece may start in the last line's last word)
+    // (+ 64: a lane's last 16-byte piece may start in the last line's last word.)  The buffer the device's last group of this size left
+    // behind is taken over -- mapping 137 GB anew costs seconds; every line is written below
+    g->lines_alloc_bytes = nlines * line_words * 4ull + 64;
+    hipError_t e = hipSuccess;
+    g->d_lines = static_cast<uint32_t*>(line_pool_take(ctx->device, g->lines_alloc_bytes));
+    if (!g->d_lines) e = dmalloc(&g->d_lines, g->lines_alloc_bytes);
     if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
     g->device_bytes = nlines * line_words * 4ull + 64;
     FPX_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(g->d_lines) + nlines * line_words * 4ull, 0, 64, 0));
@@ -582,7 +587,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
             FPX_HIP(hipStreamSynchronize(st));
             if (h_x >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_NOMEM; }
             uint32_t* ext = nullptr;
-            e = hipMalloc(&ext, (h_x + 8) * 4ull);
+            e = dmalloc(&ext, (h_x + 8) * 4ull);
             if (e != hipSuccess) { (void)hipGetLastError(); set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
             g->ext_chunks.push_back(ext);
             FPX_HIP(hipMemsetAsync(ext + h_x, 0, 8 * 4, st));                        // (a list's head is read four words at a time)
@@ -609,8 +614,8 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         FPX_HIP(hipStreamSynchronize(st));
         if (h_tot[1] >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_NOMEM; }
         uint32_t* words = nullptr; uint32_t* lists = nullptr;
-        e = hipMalloc(&words, (h_tot[0] + 16) * 4ull);
-        if (e == hipSuccess) { g->word_chunks.push_back(words); e = hipMalloc(&lists, (h_tot[1] + 8) * 4ull); }
+        e = dmalloc(&words, (h_tot[0] + 16) * 4ull);
+        if (e == hipSuccess) { g->word_chunks.push_back(words); e = dmalloc(&lists, (h_tot[1] + 8) * 4ull); }
         if (e != hipSuccess) { (void)hipGetLastError(); set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
         g->list_chunks.push_back(lists);
         FPX_HIP(hipMemsetAsync(words + h_tot[0], 0, 16 * 4, st));                 // (a hash's words are read four at a time)
@@ -632,7 +637,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     FPX_HIP(hipStreamSynchronize(st));
     g->doubles = h_ctr[1]; g->overflow_lines = h_ctr[2]; g->overflow_words = h_ctr[3];
     if (packed) {
-        FPX_HIP(hipMalloc(&g->d_ext_tab, (size_t)nchunks * sizeof(uint32_t*)));
+        FPX_HIP(dmalloc(&g->d_ext_tab, (size_t)nchunks * sizeof(uint32_t*)));
         FPX_HIP(hipMemcpy(g->d_ext_tab, g->ext_chunks.data(), (size_t)nchunks * sizeof(uint32_t*), hipMemcpyHostToDevice));
         g->total_words = h_ctr[4];                       // (one per position + one per double; `overflow_words` of them live in `ext`)
     }

@@ -178,7 +178,7 @@ struct Group {
     uint32_t chunk0 = 0, nchunks = 0;
     uint32_t win_lo = 0, win_hi = 0xFFFFFFFFu;
     uint32_t block_size = 512;             // the members' (one block size per group: the statistics' byte counts)
-    uint32_t* d_lines = nullptr;
+    uint32_t* d_lines = nullptr; size_t lines_alloc_bytes = 0;
     std::vector<uint32_t*> word_chunks, list_chunks;       // one pair per hash-space chunk (the lines hold their addresses)
     // the PACKED form (fpx_pgroup.hpp: a hash's words inside its line) of a dense group
     bool packed = false;
@@ -354,6 +354,18 @@ uint32_t ctx_fuse_min(const Ctx* c);
 int ctx_group_packed(const Ctx* c);       // -1: decided per group by its density
 void set_error(const char* fmt, ...);
 int  hip_fail(hipError_t e, const char* what);
+// ---- device memory.  A group's LINES cost memory by the hash space (8.6 .. 137 GB), and the runtime takes SECONDS to map and to unmap an
+// allocation of that size (measured on an MI355X: hipMalloc of 137 GB 5.3 s, hipFree of 64 GB 1.9 s -- an index that regroups after every
+// merge pays that each time, a test suite of small indexes a thousand times).  The line buffer a group leaves behind stays with its DEVICE
+// -- one buffer at most -- and the next group of exactly that size takes it over; a group of any other size frees it first, and so does
+// every allocation of the library that runs out of memory (dmalloc), so the process never holds more than it held at its peak.
+void*  line_pool_take(int device, size_t bytes);             // the cached buffer if it has exactly this size (any other is freed), else null
+void   line_pool_put(int device, void* p, size_t bytes);     // p becomes the cached buffer (what it replaces is freed); small ones are freed at once
+size_t line_pool_flush(int device);                          // frees the cached buffer; the bytes that went (device < 0: of every device)
+size_t line_pool_bytes(int device);
+hipError_t dmalloc_raw(void** p, size_t bytes);              // hipMalloc on the current device; out of memory: line_pool_flush + once more
+template <class T> inline hipError_t dmalloc(T** p, size_t bytes) { return dmalloc_raw(reinterpret_cast<void**>(p), bytes); }
+hipError_t mem_info(size_t* free_b, size_t* total_b);        // hipMemGetInfo, the current device's cached buffer counted as free
 #define FPX_HIP(expr)                                              \
     do {                                                           \
         hipError_t _e = (expr);                                    \

@@ -75,7 +75,7 @@ int build_bucket_table(Segment* seg, hipStream_t stream)
     while (bits < 25u && (1ull << bits) < (uint64_t)seg->num_blocks) ++bits;
     seg->num_buckets = 1u << bits;
     seg->bucket_shift = 32u - bits;
-    FPX_HIP(hipMalloc(&seg->d_bucket, ((size_t)seg->num_buckets + 1) * sizeof(uint32_t)));
+    FPX_HIP(dmalloc(&seg->d_bucket, ((size_t)seg->num_buckets + 1) * sizeof(uint32_t)));
     seg->device_bytes += ((size_t)seg->num_buckets + 1) * sizeof(uint32_t);
     const uint32_t n = seg->num_buckets + 1;
     hipLaunchKernelGGL(k_build_buckets, dim3((n + 255) / 256), dim3(256), 0, stream,
@@ -97,8 +97,8 @@ int build_memtab(Snapshot* sn)
     uint32_t* d_bucket = nullptr;
     auto fail = [&](int rc) { for (auto* b : buf) if (b) (void)hipFree(b); if (d_count) (void)hipFree(d_count); if (d_temp) (void)hipFree(d_temp); if (d_bucket) (void)hipFree(d_bucket); (void)hipGetLastError(); return rc; };
     const size_t tb = sort_u64_temp_bytes(total, 0, 64);
-    if (hipMalloc(&buf[0], (total + 1) * 8) != hipSuccess || hipMalloc(&buf[1], (total + 1) * 8) != hipSuccess || hipMalloc(&d_count, 8) != hipSuccess ||
-        hipMalloc(&d_temp, tb + 256) != hipSuccess || hipMalloc(&d_bucket, ((size_t)(1u << MEMTAB_BITS) + 2) * sizeof(uint32_t)) != hipSuccess)
+    if (dmalloc(&buf[0], (total + 1) * 8) != hipSuccess || dmalloc(&buf[1], (total + 1) * 8) != hipSuccess || dmalloc(&d_count, 8) != hipSuccess ||
+        dmalloc(&d_temp, tb + 256) != hipSuccess || dmalloc(&d_bucket, ((size_t)(1u << MEMTAB_BITS) + 2) * sizeof(uint32_t)) != hipSuccess)
         return fail(FPX_E_NOMEM);
     hipStream_t st = 0;
     if (hipMemsetAsync(d_count, 0, 8, st) != hipSuccess) return fail(FPX_E_DEVICE);
@@ -113,7 +113,7 @@ int build_memtab(Snapshot* sn)
     // (the presence bits: optional -- without them the kernel starts at the bucket table)
     uint32_t* d_bits = nullptr;
     const size_t bits_bytes = ((size_t)1 << (32u - MEMTAB_FILTER_SHIFT)) / 8u;
-    if (n != 0 && hipMalloc(&d_bits, bits_bytes) == hipSuccess) {
+    if (n != 0 && dmalloc(&d_bits, bits_bytes) == hipSuccess) {
         if (hipMemsetAsync(d_bits, 0, bits_bytes, st) != hipSuccess) { (void)hipFree(d_bits); d_bits = nullptr; }
         else hipLaunchKernelGGL(k_memtab_bits, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, (const uint64_t*)buf[cur], (uint64_t)n, d_bits);
     }
@@ -134,7 +134,7 @@ static int grow(T** p, size_t* cap, size_t need, size_t slack_num = 5, size_t sl
     size_t ncap = need * slack_num / slack_den + 64;
     if (*p) (void)hipFree(*p);
     *p = nullptr; *cap = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), ncap * sizeof(T));
+    hipError_t e = dmalloc(reinterpret_cast<void**>(p), ncap * sizeof(T));
     if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", ncap * sizeof(T), hipGetErrorString(e)); return FPX_E_NOMEM; }
     *cap = ncap;
     return FPX_OK;
@@ -198,9 +198,9 @@ static int ensure_queries(Workspace* ws, size_t B)
     if (ws->d_opts) (void)hipFree(ws->d_opts);
     if (ws->d_out_n) (void)hipFree(ws->d_out_n);
     ws->d_offsets = nullptr; ws->d_opts = nullptr; ws->d_out_n = nullptr; ws->cap_queries = 0;
-    if (hipMalloc(&ws->d_offsets, cap * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc(&ws->d_opts, cap * 4 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&ws->d_out_n, cap * sizeof(uint32_t)) != hipSuccess) {
+    if (dmalloc(&ws->d_offsets, cap * sizeof(uint64_t)) != hipSuccess ||
+        dmalloc(&ws->d_opts, cap * 4 * sizeof(uint32_t)) != hipSuccess ||
+        dmalloc(&ws->d_out_n, cap * sizeof(uint32_t)) != hipSuccess) {
         set_error("hipMalloc(query arrays) failed");
         return FPX_E_NOMEM;
     }
@@ -265,7 +265,7 @@ static int key_order_setup(Workspace* ws, uint32_t B, unsigned win_bits, unsigne
     if (words > ws->cap_kocnt) {
         if (ws->d_kocnt) (void)hipFree(ws->d_kocnt);
         ws->d_kocnt = nullptr; ws->cap_kocnt = 0;
-        hipError_t e = hipMalloc(&ws->d_kocnt, words * sizeof(uint32_t));
+        hipError_t e = dmalloc(&ws->d_kocnt, words * sizeof(uint32_t));
         if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", words * sizeof(uint32_t), hipGetErrorString(e)); return FPX_E_NOMEM; }
         ws->cap_kocnt = words;
     }
@@ -494,7 +494,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             // [n_lean deferred-list counts, one per 128-B line | LEAN_STAT_SETS x 8 u64 statistics slots of the lean kernel]
             const size_t nseg = std::max(1u, snap->n_lean);
             const size_t words = nseg * DEF_COUNT_STRIDE + LEAN_STAT_WORDS;
-            FPX_HIP(hipMalloc(&ws->d_def_count, words * sizeof(unsigned int)));
+            FPX_HIP(dmalloc(&ws->d_def_count, words * sizeof(unsigned int)));
             FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_def_count), words * sizeof(unsigned int), hipHostMallocMapped));
             ws->cap_def_segs = nseg;
         }
@@ -635,8 +635,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (ws->d_qcursor) (void)hipFree(ws->d_qcursor);
             ws->d_binq = nullptr; ws->d_qcursor = nullptr; ws->cap_binq = 0;
             const size_t ncap = words * 5 / 4;
-            FPX_HIP(hipMalloc(&ws->d_binq, ncap * sizeof(uint32_t)));
-            FPX_HIP(hipMalloc(&ws->d_qcursor, ncap * sizeof(unsigned long long)));
+            FPX_HIP(dmalloc(&ws->d_binq, ncap * sizeof(uint32_t)));
+            FPX_HIP(dmalloc(&ws->d_qcursor, ncap * sizeof(unsigned long long)));
             ws->cap_binq = ncap;
         }
         if (!ws->h_bins) FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_bins), (BINQ_HEAD + (size_t)MAX_BINS * BIN_STRIDE + MAX_SBINS) * sizeof(uint32_t), hipHostMallocMapped));
@@ -1397,9 +1397,9 @@ int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* of
     std::vector<uint32_t> h_opts;
     fill_opts(h_opts, opts, offsets, B);
     const uint64_t P = offsets[B];
-    hipError_t e = hipMalloc(&qb->d_hashes, (P + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&qb->d_offsets, ((size_t)B + 1) * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&qb->d_opts, ((size_t)B * 4 + 4) * sizeof(uint32_t));
+    hipError_t e = dmalloc(&qb->d_hashes, (P + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = dmalloc(&qb->d_offsets, ((size_t)B + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = dmalloc(&qb->d_opts, ((size_t)B * 4 + 4) * sizeof(uint32_t));
     if (e == hipSuccess && P) e = hipMemcpy(qb->d_hashes, hashes, P * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(qb->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && B) e = hipMemcpy(qb->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -1652,7 +1652,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             if (ws->d_cells) (void)hipFree(ws->d_cells);
             if (ws->h_cells) (void)hipHostFree(ws->h_cells);
             ws->d_cells = nullptr; ws->h_cells = nullptr; ws->cap_cells = 0;
-            FPX_HIP(hipMalloc(&ws->d_cells, words * sizeof(uint32_t)));
+            FPX_HIP(dmalloc(&ws->d_cells, words * sizeof(uint32_t)));
             FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_cells), (LEAN_STAT_WORDS + 16) * sizeof(uint32_t)));
             ws->cap_cells = words;
         }
@@ -1870,7 +1870,7 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
             if (ws->d_cells) (void)hipFree(ws->d_cells);
             if (ws->h_cells) (void)hipHostFree(ws->h_cells);
             ws->d_cells = nullptr; ws->h_cells = nullptr; ws->cap_cells = 0;
-            FPX_HIP(hipMalloc(&ws->d_cells, words * sizeof(uint32_t)));
+            FPX_HIP(dmalloc(&ws->d_cells, words * sizeof(uint32_t)));
             FPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_cells), (LEAN_STAT_WORDS + 16) * sizeof(uint32_t)));
             ws->cap_cells = words;
         }
@@ -2177,8 +2177,8 @@ int measure_access_impl(Ctx* ctx, size_t bytes, int mode, uint64_t lanes, double
     uint8_t* buf = nullptr; unsigned long long* sk = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto body = [&]() -> int {
-        FPX_HIP(hipMalloc(&buf, (128ull << nlines_log2) + 64));
-        FPX_HIP(hipMalloc(&sk, 8));
+        FPX_HIP(dmalloc(&buf, (128ull << nlines_log2) + 64));
+        FPX_HIP(dmalloc(&sk, 8));
         FPX_HIP(hipMemset(buf, 0x5a, (128ull << nlines_log2) + 64));
         FPX_HIP(hipMemset(sk, 0, 8));
         FPX_HIP(hipEventCreate(&e0)); FPX_HIP(hipEventCreate(&e1));
@@ -2220,8 +2220,8 @@ int measure_bandwidth_impl(Ctx* ctx, size_t bytes, uint32_t block_size, double* 
     bytes = bytes / 4096 * 4096;
     if (bytes < (1u << 20)) { set_error("buffer too small"); return FPX_E_INVAL; }
     uint8_t* buf = nullptr; unsigned long long* sink = nullptr;
-    FPX_HIP(hipMalloc(&buf, bytes));
-    FPX_HIP(hipMalloc(&sink, 8));
+    FPX_HIP(dmalloc(&buf, bytes));
+    FPX_HIP(dmalloc(&sink, 8));
     FPX_HIP(hipMemset(buf, 0x5a, bytes));
     FPX_HIP(hipMemset(sink, 0, 8));
     hipEvent_t e0, e1;

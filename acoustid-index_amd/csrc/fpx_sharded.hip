@@ -218,8 +218,8 @@ static int win_reserve_keys(ShardedSnapshot* ss, WinBufs* b, uint64_t key_cap)
     win_free_keys(ss, b);
     for (uint32_t k = 0; k < b->world; ++k) {
         FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
-        FPX_HIP(hipMalloc(&b->keys_send[k], (size_t)b->world * key_cap * sizeof(uint64_t)));
-        FPX_HIP(hipMalloc(&b->keys_recv[k], (size_t)b->world * key_cap * sizeof(uint64_t)));
+        FPX_HIP(dmalloc(&b->keys_send[k], (size_t)b->world * key_cap * sizeof(uint64_t)));
+        FPX_HIP(dmalloc(&b->keys_recv[k], (size_t)b->world * key_cap * sizeof(uint64_t)));
     }
     b->key_cap = key_cap;
     return FPX_OK;
@@ -231,10 +231,10 @@ static int win_reserve_bins(ShardedSnapshot* ss, WinBufs* b, uint32_t bpr, uint6
     win_free_bins(ss, b);
     for (uint32_t k = 0; k < b->world; ++k) {
         FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
-        FPX_HIP(hipMalloc(&b->bins_send[k], (size_t)b->world * bpr * cell_cap * sizeof(uint64_t)));
-        FPX_HIP(hipMalloc(&b->bins_recv[k], (size_t)b->world * bpr * cell_cap * sizeof(uint64_t)));
-        FPX_HIP(hipMalloc(&b->bcnt_send[k], (size_t)b->world * bpr * sizeof(uint32_t)));
-        FPX_HIP(hipMalloc(&b->bcnt_recv[k], (size_t)b->world * bpr * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&b->bins_send[k], (size_t)b->world * bpr * cell_cap * sizeof(uint64_t)));
+        FPX_HIP(dmalloc(&b->bins_recv[k], (size_t)b->world * bpr * cell_cap * sizeof(uint64_t)));
+        FPX_HIP(dmalloc(&b->bcnt_send[k], (size_t)b->world * bpr * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&b->bcnt_recv[k], (size_t)b->world * bpr * sizeof(uint32_t)));
     }
     b->cell_cap = cell_cap; b->bpr = bpr;
     return FPX_OK;
@@ -340,13 +340,13 @@ static int bufs_reserve(ShardedSnapshot* ss, ShardBufs* b, size_t B, size_t cap)
     b->cap_tab = std::max(need_tab, b->cap_tab); b->cap_q = std::max(need_q, b->cap_q);
     FPX_HIP(hipSetDevice(ss->ctxs[0]->device));
     if (!b->copy_stream) FPX_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
-    FPX_HIP(hipMalloc(&b->d_all, n * b->cap_tab * sizeof(fpx_result)));
-    FPX_HIP(hipMalloc(&b->d_all_cnt, n * b->cap_q * sizeof(uint32_t)));
+    FPX_HIP(dmalloc(&b->d_all, n * b->cap_tab * sizeof(fpx_result)));
+    FPX_HIP(dmalloc(&b->d_all_cnt, n * b->cap_q * sizeof(uint32_t)));
     b->d_part[0] = b->d_all; b->d_cnt[0] = b->d_all_cnt;
     for (size_t k = 1; k < n; ++k) {
         FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
-        FPX_HIP(hipMalloc(&b->d_part[k], b->cap_tab * sizeof(fpx_result)));
-        FPX_HIP(hipMalloc(&b->d_cnt[k], b->cap_q * sizeof(uint32_t)));
+        FPX_HIP(dmalloc(&b->d_part[k], b->cap_tab * sizeof(fpx_result)));
+        FPX_HIP(dmalloc(&b->d_cnt[k], b->cap_q * sizeof(uint32_t)));
     }
     return FPX_OK;
 }
@@ -741,7 +741,7 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
         b->xs.assign(n, nullptr);
         b->rec_send.assign(n, nullptr); b->rec_recv.assign(n, nullptr); b->rec_send_cap.assign(n, 0); b->rec_recv_cap.assign(n, 0);
         for (uint32_t k = 0; k < n; ++k) {
-            if (hipSetDevice(ss->ctxs[k]->device) != hipSuccess || hipMalloc(&b->kcnt_send[k], (size_t)n * 8) != hipSuccess || hipMalloc(&b->kcnt_recv[k], (size_t)n * 8) != hipSuccess ||
+            if (hipSetDevice(ss->ctxs[k]->device) != hipSuccess || dmalloc(&b->kcnt_send[k], (size_t)n * 8) != hipSuccess || dmalloc(&b->kcnt_recv[k], (size_t)n * 8) != hipSuccess ||
                 hipStreamCreateWithFlags(&b->xs[k], hipStreamNonBlocking) != hipSuccess) { win_destroy(ss, b); set_error("out of device memory"); return FPX_E_NOMEM; }
         }
     }
@@ -849,7 +849,7 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
                 if (b->rec_send[k] && b->rec_send_cap[k] >= want) continue;
                 FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
                 if (b->rec_send[k]) { (void)hipFree(b->rec_send[k]); b->rec_send[k] = nullptr; b->rec_send_cap[k] = 0; }
-                FPX_HIP(hipMalloc(&b->rec_send[k], want * sizeof(uint64_t)));
+                FPX_HIP(dmalloc(&b->rec_send[k], want * sizeof(uint64_t)));
                 b->rec_send_cap[k] = want;
             }
             run_all([&](uint32_t k) -> int {
@@ -863,7 +863,7 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
                     b->rec_send_cap[k] = total + total / 16 + 1024; rcs[k] = FPX_OK; grown = true;
                     FPX_HIP(hipSetDevice(ss->ctxs[k]->device));
                     (void)hipFree(b->rec_send[k]); b->rec_send[k] = nullptr;
-                    FPX_HIP(hipMalloc(&b->rec_send[k], b->rec_send_cap[k] * sizeof(uint64_t)));
+                    FPX_HIP(dmalloc(&b->rec_send[k], b->rec_send_cap[k] * sizeof(uint64_t)));
                 }
             }
             if ((r = first_error())) return r;
@@ -877,7 +877,7 @@ static int windows_search_batch(ShardedSnapshot* ss, const uint32_t* hashes, con
                 FPX_HIP(hipSetDevice(ss->ctxs[w]->device));
                 if (b->rec_recv[w]) { (void)hipFree(b->rec_recv[w]); b->rec_recv[w] = nullptr; b->rec_recv_cap[w] = 0; }
                 const uint64_t want = got[w] + got[w] / 8 + 1024;
-                FPX_HIP(hipMalloc(&b->rec_recv[w], want * sizeof(uint64_t)));
+                FPX_HIP(dmalloc(&b->rec_recv[w], want * sizeof(uint64_t)));
                 b->rec_recv_cap[w] = want;
             }
         }

@@ -62,6 +62,7 @@ public:
     fpx_ctx* handle() const { return h_; }
     // the running scan histograms of everything the context's direct-addressed segments answered (metrics.scanned_docs_per_hash /
     // scanned_blocks_per_hash, src/metrics.zig:9-10); `unbucketed`: walks answered from blocks meanwhile
+    uint64_t trim() { return fpx_ctx_trim(h_); }          // frees the line buffer kept for the next group
     fpx_scan_histograms scanHistograms(uint64_t* unbucketed = nullptr) const
     {
         fpx_scan_histograms h;

@@ -56,6 +56,10 @@ class Context:
         option's smallest (-1, or -2 for 'group_packed' / 'bin_q_log2') puts it back to the environment / default"""
         check(lib().fpx_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def trim(self):
+        """fpx_ctx_trim: frees the line buffer the library keeps on this GPU for the next group; the bytes that went"""
+        return int(lib().fpx_ctx_trim(self.h))
+
     def scan_histograms(self):
         """fpx_ctx_scan_histograms: the context's RUNNING scan histograms (src/FileSegment.zig:177-178, buckets of src/metrics.zig:9-10) --
         every (hash, segment) walk the direct-addressed kernels answered since the context was created, bucketed as it was answered.

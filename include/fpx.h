@@ -119,6 +119,12 @@ int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context live
  * (FPX_SHARDED_RCCL alone stays with the process: whether librccl is loaded at all.) */
 int  fpx_ctx_set_option(fpx_ctx *ctx, const char *name, int64_t value);
 int  fpx_ctx_get_option(const fpx_ctx *ctx, const char *name, int64_t *value);   /* the value in force */
+/* Device memory the library keeps for reuse on the context's GPU: the LINE buffer of the last group that was released (a group's
+ * lines cost memory by the hash space -- 8.6 .. 137 GB -- and the runtime takes seconds to map and unmap that much; the next group
+ * of the same size, e.g. the one fpx_segments_regroup builds after the next merge, takes the buffer over).  One buffer per device
+ * at most; the library frees it by itself before any of its own allocations fails for lack of memory.  fpx_ctx_trim frees it
+ * now (another process, or another library in this one, is to have the memory) and returns the bytes that went. */
+uint64_t fpx_ctx_trim(fpx_ctx *ctx);
 const char *fpx_strerror(int status);
 /* last error text of the calling thread (valid until its next fpx call) */
 const char *fpx_last_error(void);

@@ -135,6 +135,10 @@ def variant_runs():
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         yield {}
         return
+    from fpx_testlib import fpx
+    c = fpx.Context(0)
+    c.trim()                                 # (a line buffer this process may keep for its next group is not the children's to wait for)
+    c.close()
     sched = _HbmScheduler(int(os.environ.get("FPX_VARIANT_JOBS", "6")))
     # the largest first: the packed variant starts on an empty device, the small ones fill in around it
     order = sorted(VARIANTS, key=_need_gb, reverse=True)

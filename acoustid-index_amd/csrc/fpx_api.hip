@@ -97,6 +97,11 @@ hipError_t dmalloc_raw(void** p, size_t bytes)
     return hipMalloc(p, bytes);
 }
 
+thread_local DevArena* tl_arena = nullptr;
+thread_local DevArena* tl_scratch = nullptr;
+void* arena_take(size_t bytes) { return tl_arena ? tl_arena->take(bytes) : nullptr; }
+void* scratch_take(size_t bytes) { return tl_scratch ? tl_scratch->take(bytes) : nullptr; }
+
 hipError_t mem_info(size_t* free_b, size_t* total_b)
 {
     const hipError_t e = hipMemGetInfo(free_b, total_b);

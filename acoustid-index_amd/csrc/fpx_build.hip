@@ -262,10 +262,13 @@ __global__ __launch_bounds__(256) void k_encode_blocks(const uint64_t* __restric
 // ---- driver ----------------------------------------------------------------------------------------------
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool own = true;                         // false: carved from the arena of the group being built (fpx_internal.h: DevArena)
+    ~DevBuf() { if (p && own) (void)hipFree(p); }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
     int alloc(size_t bytes)
     {
+        if ((p = scratch_take(bytes ? bytes : 16)) != nullptr) { own = false; return FPX_OK; }
+        own = true;
         hipError_t e = dmalloc(&p, bytes ? bytes : 16);
         if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return FPX_E_NOMEM; }
         return FPX_OK;
@@ -1122,7 +1125,14 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     int rc;
     *out = DirectPiece{};
     out->nrec = nrec;
-    FPX_HIP(dmalloc(&out->drec, (size_t)nrec * 64u));
+    if (tl_scratch) tl_scratch->rewind();          // (the last piece ended with its stream waited for)
+    // (the piece's arrays come out of the group builder's arena where there is one: rewound after the chunk, nothing to free)
+    auto piece_alloc = [](uint32_t** p, bool* own, size_t bytes) -> hipError_t {
+        if ((*p = static_cast<uint32_t*>(arena_take(bytes))) != nullptr) { *own = false; return hipSuccess; }
+        *own = true;
+        return dmalloc(p, bytes);
+    };
+    FPX_HIP(piece_alloc(&out->drec, &out->own_drec, (size_t)nrec * 64u));
     FPX_HIP(hipMemsetAsync(out->drec, 0, (size_t)nrec * 64u, st));
     DevBuf rectot, recbase, tot;
     if ((rc = rectot.alloc((size_t)nrec * 4)) || (rc = recbase.alloc((size_t)nrec * 8)) || (rc = tot.alloc(64))) return rc;
@@ -1130,8 +1140,8 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     FPX_HIP(hipMemsetAsync(tot.p, 0, 64, st));
     if (nbl == 0) {                      // no block of the segment reaches into the range: every position clear
         hipLaunchKernelGGL(k_direct_rec_counts, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, rectot.as<uint32_t>(), nrec);
-        FPX_HIP(dmalloc(&out->primary, 16 * sizeof(uint32_t)));
-        FPX_HIP(dmalloc(&out->extras, 16 * sizeof(uint32_t)));
+        FPX_HIP(piece_alloc(&out->primary, &out->own_primary, 16 * sizeof(uint32_t)));
+        FPX_HIP(piece_alloc(&out->extras, &out->own_extras, 16 * sizeof(uint32_t)));
         FPX_HIP(hipMemsetAsync(out->primary, 0xFF, 16 * sizeof(uint32_t), st));
         FPX_HIP(hipMemsetAsync(out->extras, 0, 16 * sizeof(uint32_t), st));
         FPX_HIP(hipStreamSynchronize(st));
@@ -1177,8 +1187,8 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
     if (Dp < D) { set_error("internal: %llu set bits for %llu distinct hashes", (unsigned long long)Dp, (unsigned long long)D); return FPX_E_DEVICE; }
     if (h_flags[0] || h_flags[1] || (X >> pad) >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull) return FPX_E_INVAL;      // does not qualify
-    FPX_HIP(dmalloc(&out->primary, (Dp + 4) * sizeof(uint32_t)));
-    FPX_HIP(dmalloc(&out->extras, (X + 8) * sizeof(uint32_t)));
+    FPX_HIP(piece_alloc(&out->primary, &out->own_primary, (Dp + 4) * sizeof(uint32_t)));
+    FPX_HIP(piece_alloc(&out->extras, &out->own_extras, (X + 8) * sizeof(uint32_t)));
     FPX_HIP(hipMemsetAsync(out->primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
     FPX_HIP(hipMemsetAsync(out->extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
     // (at most n / DIRECT_LONG lists are that long; a queue that cannot be had -- memory -- leaves the copies to k_direct_fill's threads)
@@ -1202,9 +1212,9 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
 
 void DirectPiece::release()
 {
-    if (drec) (void)hipFree(drec);
-    if (primary) (void)hipFree(primary);
-    if (extras) (void)hipFree(extras);
+    if (drec && own_drec) (void)hipFree(drec);
+    if (primary && own_primary) (void)hipFree(primary);
+    if (extras && own_extras) (void)hipFree(extras);
     drec = primary = extras = nullptr;
 }
 

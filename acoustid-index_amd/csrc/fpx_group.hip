@@ -24,10 +24,28 @@ Group::~Group()
 {
     (void)hipSetDevice(device);
     if (d_lines) (void)hipFree(d_lines);
-    for (uint32_t* p : word_chunks) if (p) (void)hipFree(p);
-    for (uint32_t* p : list_chunks) if (p) (void)hipFree(p);
     if (d_ext_tab) (void)hipFree(d_ext_tab);
-    for (uint32_t* p : ext_chunks) if (p) (void)hipFree(p);
+    for (void* p : chunk_allocs) if (p) (void)hipFree(p);       // (word_chunks / list_chunks / ext_chunks point into these)
+}
+
+uint32_t* Group::chunk_alloc(size_t bytes)
+{
+    constexpr size_t SLAB = (size_t)64 << 20, OWN_FROM = (size_t)16 << 20;
+    const size_t need = (bytes + 255u) & ~(size_t)255u;
+    void* p = nullptr;
+    if (need >= OWN_FROM) {                                      // a dense group's chunk: an allocation of its own, nothing wasted
+        if (dmalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        chunk_allocs.push_back(p);
+        return static_cast<uint32_t*>(p);
+    }
+    if (need > slab_left) {
+        if (dmalloc(&p, SLAB) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        chunk_allocs.push_back(p);
+        slab_cur = static_cast<uint8_t*>(p); slab_left = SLAB;
+    }
+    p = slab_cur;
+    slab_cur += need; slab_left -= need;
+    return static_cast<uint32_t*>(p);
 }
 
 namespace {
@@ -561,8 +579,16 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         DirectPiece pc[FUSE_MAX];
         ~Pieces() { for (DirectPiece& p : pc) p.release(); }
     };
+    // the members' pieces of a chunk -- and everything it takes to build them -- out of ONE allocation, rewound chunk by chunk
+    DevArena arena, scratch;
+    struct ArenaScope {
+        DevArena* prev; DevArena* prev_s;
+        ArenaScope(DevArena* a, DevArena* s) : prev(tl_arena), prev_s(tl_scratch) { tl_arena = a; tl_scratch = s; }
+        ~ArenaScope() { tl_arena = prev; tl_scratch = prev_s; }
+    } arena_scope(&arena, &scratch);
     for (uint32_t ci = 0; ci < nchunks; ++ci) {
         const uint32_t c = c_first + ci;
+        arena.rewind();                                // (the last chunk's kernels have been waited for)
         Pieces pieces;
         for (uint32_t j = 0; j < k; ++j) {
             const Segment* s = segs[j];
@@ -586,9 +612,8 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
             FPX_HIP(hipMemcpyAsync(&h_x, tot.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, st));
             FPX_HIP(hipStreamSynchronize(st));
             if (h_x >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_NOMEM; }
-            uint32_t* ext = nullptr;
-            e = dmalloc(&ext, (h_x + 8) * 4ull);
-            if (e != hipSuccess) { (void)hipGetLastError(); set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
+            uint32_t* ext = g->chunk_alloc((h_x + 8) * 4ull);
+            if (!ext) { set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
             g->ext_chunks.push_back(ext);
             FPX_HIP(hipMemsetAsync(ext + h_x, 0, 8 * 4, st));                        // (a list's head is read four words at a time)
             FPX_HIP(hipMemsetAsync(ctr.p, 0, 8, st));
@@ -613,10 +638,10 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         FPX_HIP(hipMemcpyAsync(h_tot, tot.p, 16, hipMemcpyDeviceToHost, st));
         FPX_HIP(hipStreamSynchronize(st));
         if (h_tot[1] >= 0x7FFFFFF0ull) { set_error("a chunk of the group holds more than 2^31 words of lists"); return FPX_E_NOMEM; }
-        uint32_t* words = nullptr; uint32_t* lists = nullptr;
-        e = dmalloc(&words, (h_tot[0] + 16) * 4ull);
-        if (e == hipSuccess) { g->word_chunks.push_back(words); e = dmalloc(&lists, (h_tot[1] + 8) * 4ull); }
-        if (e != hipSuccess) { (void)hipGetLastError(); set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
+        uint32_t* words = g->chunk_alloc((h_tot[0] + 16) * 4ull);
+        uint32_t* lists = words ? g->chunk_alloc((h_tot[1] + 8) * 4ull) : nullptr;
+        if (!words || !lists) { set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
+        g->word_chunks.push_back(words);
         g->list_chunks.push_back(lists);
         FPX_HIP(hipMemsetAsync(words + h_tot[0], 0, 16 * 4, st));                 // (a hash's words are read four at a time)
         FPX_HIP(hipMemsetAsync(lists + h_tot[1], 0, 8 * 4, st));

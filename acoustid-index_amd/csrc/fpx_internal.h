@@ -184,6 +184,11 @@ struct Group {
     bool packed = false;
     uint32_t gmin = 0;                     // packed form: the one doc id base of the group's words
     std::vector<uint32_t*> ext_chunks;     // one per hash-space chunk: overflowing words + lists
+    // what the chunks' arrays were allocated as: big ones on their own, small ones (a sparse group: a test's, a fresh index's) carved from
+    // slabs of 64 MB -- 64 chunks x 2 arrays of a few KB each were 128 allocations per group, and freeing an allocation costs milliseconds
+    std::vector<void*> chunk_allocs;
+    uint8_t* slab_cur = nullptr; size_t slab_left = 0;
+    uint32_t* chunk_alloc(size_t bytes);   // null: out of memory
     uint32_t** d_ext_tab = nullptr;        // the same addresses in device memory (GroupDesc::ext_tab)
     uint32_t min_doc[FUSE_MAX] = {}, first_hash[FUSE_MAX] = {}, last_hash[FUSE_MAX] = {};
     uint64_t device_bytes = 0, total_words = 0, total_list_words = 0, doubles = 0, overflow_lines = 0, overflow_words = 0;
@@ -366,6 +371,39 @@ size_t line_pool_bytes(int device);
 hipError_t dmalloc_raw(void** p, size_t bytes);              // hipMalloc on the current device; out of memory: line_pool_flush + once more
 template <class T> inline hipError_t dmalloc(T** p, size_t bytes) { return dmalloc_raw(reinterpret_cast<void**>(p), bytes); }
 hipError_t mem_info(size_t* free_b, size_t* total_b);        // hipMemGetInfo, the current device's cached buffer counted as free
+// A group is built from 64 chunks x up to 16 members' pieces, and every piece used to take fourteen allocations of its own (and give
+// them back: the runtime unmaps -- and the driver wipes -- what is freed): 14 000 hipMalloc / hipFree pairs for the 100 M index, 8 000 for
+// a test's group of nine tiny segments.  DevArena: ONE allocation the pieces of a chunk carve their arrays from, rewound after every
+// chunk.  What does not fit is allocated the old way and the arena grows at its next rewind (the first chunk sizes it).
+struct DevArena {
+    uint8_t* base = nullptr;
+    size_t cap = 0, used = 0, missed = 0;          // missed: bytes asked for since the last rewind that did not fit
+    ~DevArena() { if (base) (void)hipFree(base); }
+    void* take(size_t bytes)                       // null: does not fit (the caller allocates on its own)
+    {
+        const size_t need = (bytes + 255u) & ~(size_t)255u;
+        if (used + need > cap) { missed += need; return nullptr; }
+        void* p = base + used;
+        used += need;
+        return p;
+    }
+    void rewind()                                  // (nothing that uses the arena's memory is under way: the caller has waited)
+    {
+        if (missed) {
+            const size_t want = (used + missed) * 5 / 4 + ((size_t)1 << 20);
+            if (base) (void)hipFree(base);
+            base = nullptr; cap = 0;
+            if (dmalloc(&base, want) == hipSuccess) cap = want; else { (void)hipGetLastError(); base = nullptr; }
+        }
+        used = 0; missed = 0;
+    }
+};
+// Two of them while a group is built: a chunk's OUTPUTS (the members' pieces: alive until the chunk's lines are filled) and a piece's
+// SCRATCH (decoded items, counts, bases: rewound piece by piece, so that sixteen members' scratch never adds up)
+extern thread_local DevArena* tl_arena;                      // outputs of the chunk being built on this thread (null: none)
+extern thread_local DevArena* tl_scratch;                    // scratch of the piece being built
+void* arena_take(size_t bytes);                              // from tl_arena, or null
+void* scratch_take(size_t bytes);                            // from tl_scratch, or null
 #define FPX_HIP(expr)                                              \
     do {                                                           \
         hipError_t _e = (expr);                                    \
@@ -435,6 +473,7 @@ struct HashRange { uint32_t lo, hi, rec0, whole; };      // hashes [lo, hi] into
 // the direct-addressed arrays of a hash range of a segment (fpx_direct.hpp: records of 256 hash values, primary, extras)
 struct DirectPiece {
     uint32_t* drec = nullptr; uint32_t* primary = nullptr; uint32_t* extras = nullptr;
+    bool own_drec = true, own_primary = true, own_extras = true;      // false: carved from the builder's arena (DevArena)
     uint32_t nrec = 0, xshift = 0;
     uint64_t distinct = 0, positions = 0, extras_words = 0;
     void release();

@@ -129,7 +129,7 @@ def _child():
     from fpx_testlib import Pair, fpx, oracle
     oracle.build()
     items, queries = _world(fpx, oracle)
-    for label, options in (("block form", {}), ("direct-addressed, grouped", {"direct_min_items": 0}),
+    for label, options in (("block form", {"direct": 0}), ("the default forms (segments of 1.15 M items: direct-addressed)", {}), ("direct-addressed, grouped", {"direct_min_items": 0}),
                            ("direct-addressed, each on its own", {"direct_min_items": 0, "fuse_min": 0})):
         ctx = fpx.Context(0)
         for k, v in options.items():
@@ -161,7 +161,7 @@ def _running_histograms(fpx, oracle, Pair, items, queries):
     def delta(a, b):
         return {k: ([y - x for x, y in zip(a[k], b[k])] if isinstance(a[k], list) else b[k] - a[k]) for k in a}
 
-    forms = (("blocks", {}, False), ("a group, directory + words", {"direct_min_items": 0, "group_packed": 0}, True),
+    forms = (("blocks", {"direct": 0}, False), ("a group, directory + words", {"direct_min_items": 0, "group_packed": 0}, True),
              ("a packed group", {"direct_min_items": 0, "group_packed": 1}, True), ("each on its own", {"direct_min_items": 0, "fuse_min": 0}, True))
     for label, options, bucketed in forms:
         ctx = fpx.Context(0)

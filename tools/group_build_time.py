@@ -18,18 +18,6 @@ from __graft_entry__ import load_package  # noqa: E402
 fpx = load_package()
 ctx = fpx.Context(0)
 res = {}
-for gb in (8, 64, 137):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    x = torch.empty(gb << 30, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    del x
-    torch.cuda.empty_cache()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    res[f"hipMalloc_{gb}GB_s"] = round(t1 - t0, 3)
-    res[f"hipFree_{gb}GB_s"] = round(t2 - t1, 3)
 for nseg in (1, 3, 9):
     for rep in range(2):
         t0 = time.perf_counter()
@@ -47,4 +35,16 @@ for nseg in (1, 3, 9):
         torch.cuda.synchronize()
         t4 = time.perf_counter()
         res[f"group_of_{nseg}_rep{rep}"] = {"synth_s": round(t1 - t0, 3), "snapshot_s": round(t2 - t1, 3), "search_s": round(t3 - t2, 3), "free_s": round(t4 - t3, 3)}
+for gb in (8, 64, 137):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = torch.empty(gb << 30, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    del x
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    res[f"hipMalloc_{gb}GB_s"] = round(t1 - t0, 3)
+    res[f"hipFree_{gb}GB_s"] = round(t2 - t1, 3)
 print(json.dumps(res))

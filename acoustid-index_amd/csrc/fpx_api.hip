@@ -36,7 +36,7 @@ struct LinePool { std::mutex mu; void* p = nullptr; size_t bytes = 0; };
 LinePool g_line_pool[POOL_DEVICES];
 }  // namespace
 
-void* line_pool_take(int device, size_t bytes)
+void* line_pool_take(int device, size_t bytes, size_t max_bytes, size_t* got)
 {
     if (device < 0 || device >= POOL_DEVICES) return nullptr;
     LinePool& lp = g_line_pool[device];
@@ -44,7 +44,7 @@ void* line_pool_take(int device, size_t bytes)
     void* hit = nullptr;
     {
         std::lock_guard<std::mutex> g(lp.mu);
-        if (lp.p && lp.bytes == bytes) hit = lp.p; else old = lp.p;
+        if (lp.p && lp.bytes >= bytes && lp.bytes <= std::max(bytes, max_bytes)) { hit = lp.p; *got = lp.bytes; } else old = lp.p;
         lp.p = nullptr; lp.bytes = 0;
     }
     if (old) (void)hipFree(old);
@@ -305,6 +305,7 @@ static const OptInfo OPT_TABLE[OPT_COUNT] = {
     /* OPT_LEAN_ROUNDS */        {"lean_rounds", "FPX_LEAN_ROUNDS", 0, 0, true},
     /* OPT_SHARDED_WORKERS */    {"sharded_workers", "FPX_SHARDED_WORKERS", 3, 1, true},
     /* OPT_KEY_ORDER_BITS */     {"key_order_bits", "FPX_KEY_ORDER_BITS", 8, 0, true},          // top hash bits the flagged keys of a large batch are ordered by
+    /* OPT_LINE_POOL_SLACK */    {"line_pool_slack", "FPX_LINE_POOL_SLACK", 0, 0, false},       // per cent a kept line buffer may be larger than the group that takes it
 };
 
 int64_t ctx_opt(const Ctx* c, CtxOpt o)

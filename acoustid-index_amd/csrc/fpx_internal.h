@@ -333,6 +333,7 @@ enum CtxOpt : int {
     OPT_GROUP_ROUNDS, OPT_DIRECT_ROUNDS, OPT_LEAN_ROUNDS,
     OPT_SHARDED_WORKERS,
     OPT_KEY_ORDER_BITS,
+    OPT_LINE_POOL_SLACK,
     OPT_COUNT
 };
 constexpr int64_t OPT_UNSET = -2;
@@ -364,7 +365,8 @@ int  hip_fail(hipError_t e, const char* what);
 // merge pays that each time, a test suite of small indexes a thousand times).  The line buffer a group leaves behind stays with its DEVICE
 // -- one buffer at most -- and the next group of exactly that size takes it over; a group of any other size frees it first, and so does
 // every allocation of the library that runs out of memory (dmalloc), so the process never holds more than it held at its peak.
-void*  line_pool_take(int device, size_t bytes);             // the cached buffer if it has exactly this size (any other is freed), else null
+// the cached buffer if it holds `bytes` and no more than `max_bytes` (its size in *got; any other is freed), else null
+void*  line_pool_take(int device, size_t bytes, size_t max_bytes, size_t* got);
 void   line_pool_put(int device, void* p, size_t bytes);     // p becomes the cached buffer (what it replaces is freed); small ones are freed at once
 size_t line_pool_flush(int device);                          // frees the cached buffer; the bytes that went (device < 0: of every device)
 size_t line_pool_bytes(int device);

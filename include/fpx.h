@@ -112,6 +112,8 @@ int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context live
  *   "rec32"              1 | 0   4-byte records in the bins where the doc ids leave room (default 1)
  *   "local_sort_max", "order_min_pairs", "order_max_pairs"   pair counts that choose how a batch's keys are ordered
  *   "key_order_bits"     top hash bits the keys of a batch on direct-addressed segments are ordered by (0..8, default 8)
+ *   "line_pool_slack"    per cent by which the line buffer kept on the GPU (fpx_ctx_trim) may exceed the lines of the group that takes
+ *                        it over (default 0: an exact fit; a host that builds groups of several sizes in turn may allow more)
  *   "lean_min"           probes from which block-form segments take the lean kernel (default 2^16)
  *   "staged_out_max"     bytes of results a batch stages in pinned memory (-1: built-in)
  *   "group_rounds", "direct_rounds", "lean_rounds"   rounds per workgroup of the probe kernels (0: by the batch's size)

@@ -114,13 +114,17 @@ class _HbmScheduler:
         t0 = time.time()
         try:
             e = dict(os.environ, FPX_VARIANT_CHILD="1", **env)
-            return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + _suites(env),
-                                  cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+            r = None
+            r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--durations=25"] + _suites(env),
+                               cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+            return r
         finally:
             out = os.path.join(ROOT, "gpurun_out")
-            if os.path.isdir(out):               # (a GPU box run by tools/*.sh: how long every child took, for the suite's time budget)
+            if os.path.isdir(out):               # (a GPU box run by tools/*.sh: how long every child took, and its slowest tests, for the suite's time budget)
                 with open(os.path.join(out, "variant_times.txt"), "a") as f:
                     f.write(f"{_name(env)}: started {t0 - self.t_start:.0f} s into the module, took {time.time() - t0:.0f} s\n")
+                    if r is not None:
+                        f.write("".join("    " + ln + "\n" for ln in r.stdout.splitlines() if " call " in ln or " setup " in ln))
             with self.cv:
                 self.running -= 1
                 self.reserved -= need

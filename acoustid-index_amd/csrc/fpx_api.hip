@@ -157,6 +157,7 @@ void ws_destroy(Workspace* w)
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->d_qstats) (void)hipFree(w->d_qstats);
     if (w->d_kocnt) (void)hipFree(w->d_kocnt);
+    if (w->d_refs) (void)hipFree(w->d_refs);
     if (w->d_cells) (void)hipFree(w->d_cells);
     if (w->h_cells) (void)hipHostFree(w->h_cells);
     void* bufs[] = {w->d_hashes, w->d_offsets, w->d_opts, w->d_keys[0], w->d_keys[1], w->d_hits[0], w->d_hits[1],
@@ -306,6 +307,7 @@ static const OptInfo OPT_TABLE[OPT_COUNT] = {
     /* OPT_SHARDED_WORKERS */    {"sharded_workers", "FPX_SHARDED_WORKERS", 3, 1, true},
     /* OPT_KEY_ORDER_BITS */     {"key_order_bits", "FPX_KEY_ORDER_BITS", 8, 0, true},          // top hash bits the flagged keys of a large batch are ordered by
     /* OPT_LINE_POOL_SLACK */    {"line_pool_slack", "FPX_LINE_POOL_SLACK", 0, 0, false},       // per cent a kept line buffer may be larger than the group that takes it
+    /* OPT_HOT_REFS */           {"hot_refs", "FPX_HOT_REFS", -1, -1, true},                     // 1 | 0 | -1: hot lists reach the score kernel by reference | are copied | by the last batch's records
 };
 
 int64_t ctx_opt(const Ctx* c, CtxOpt o)

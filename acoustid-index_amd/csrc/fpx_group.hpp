@@ -55,6 +55,19 @@ constexpr uint32_t GB_EMPTY = 0xFFFFFFFFu;
 constexpr uint16_t GB_NEED = 0xFFF0u;       // s_rank: the staged record has no rank in its bin yet (every entry between rounds)
 
 // the bin of a record, and the bin's slot in a round's table (a round's keys belong to neighbouring queries: neighbouring bins)
+// A hot list offered to its query's bin by reference (ProbeArgs::refs).  False: the bin's entries are taken (or there are none) -- the
+// caller copies the list as before.  The counter: entries in the low word (it keeps counting past the capacity: the reader clamps), the
+// docs behind the entries that were TAKEN in the high one (the score kernel sizes its filter by the bin's records, copied or not).
+__device__ __forceinline__ bool hot_ref_offer(const ProbeArgs& a, uint32_t bin, const uint32_t* docs, uint32_t cnt, uint32_t base, uint32_t q)
+{
+    unsigned long long* rc = reinterpret_cast<unsigned long long*>(a.bin_count + (size_t)bin * BIN_STRIDE + 2u);
+    const unsigned long long old = atomicAdd(rc, 1ull | ((unsigned long long)cnt << 32));
+    const uint32_t r = (uint32_t)old;
+    if (r >= a.ref_cap) { atomicAdd(rc, 0ull - ((unsigned long long)cnt << 32)); return false; }
+    const uint64_t p = (uint64_t)docs;
+    a.refs[(size_t)bin * a.ref_cap + r] = make_uint4((uint32_t)p, (uint32_t)(p >> 32) | (cnt << 16), base, q);       // (cnt < 2^16: a list header's field)
+    return true;
+}
 __device__ __forceinline__ uint32_t gb_cell(const ProbeArgs& a, uint64_t rec) { return (uint32_t)(rec >> 32) >> a.bin_shift; }
 __device__ __forceinline__ uint32_t gb_slot(const ProbeArgs& a, uint64_t rec) { return ((uint32_t)(rec >> 32) >> a.bin_shift) & (GB_SLOTS - 1u); }
 
@@ -319,19 +332,25 @@ __global__ __launch_bounds__(FK_WG) FPX_GK_OCC void k_probe_group(ProbeArgs a, G
                         hist_observe(wg_h, eff_l, (hdr_l >> 16) & 7u);
                         if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
                     }
-                    const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
+                    uint32_t rest_l = is_list ? eff_l - from_l : 0u;
                     if (rest_l) my_reads += ((rest_l + 31u) >> 5) * 2u;
+                    const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
+                    const uint32_t hot_bin = qlo >> a.bin_shift;
+                    // ... or, where the batch has room for references, NOT AT ALL: the list's address goes to the query's bin and k_score_bin
+                    // reads the docs where they are (a hot hash's lists are the same for every query that holds it: copied, they were 575 M of
+                    // a hot-hash batch's 625 M records, written once and read twice)
+                    if constexpr (BINNED) {
+                        if (a.ref_cap != 0u && !filtered && rest_l != 0u && hot_ref_offer(a, hot_bin, lp + 1u + T_l + from_l, rest_l, s_min_doc[col], qlo)) rest_l = 0u;
+                    }
                     uint32_t total = rest_l;
 #pragma unroll
                     for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
-                    const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
                     unsigned long long me = __ballot((int)(rest_l != 0u));
                     unsigned long long gbase = 0;
                     // BINNED: all these records belong to ONE query, i.e. one bin -- the reservation is taken THERE and the lists go straight
                     // into the bin (round 3 left them in the misc buffer for k_bin: 575 M of the 625 M records of a hot-hash batch took
                     // that detour)
-                    const uint32_t hot_bin = qlo >> a.bin_shift;
-                    if (!filtered) {
+                    if (!filtered && total != 0u) {
                         if constexpr (BINNED) { if (lane == 0) gbase = atomicAdd(&a.bin_count[(size_t)hot_bin * BIN_STRIDE], total); }
                         else { if (lane == 0) gbase = atomicAdd(&a.counters[CTR_HITS], (unsigned long long)total); }
                         gbase = __shfl(gbase, 0);

@@ -293,6 +293,7 @@ struct Workspace {
     // straight from the device blocks the host until the stream gets there and costs ~100 us of driver time per call; a
     // copy into pinned memory is asynchronous, and the host moves the bytes on after the batch's synchronisation
     uint8_t* h_out = nullptr; size_t cap_h_out = 0;
+    uint4* d_refs = nullptr; size_t cap_refs = 0;                     // hot lists by reference: [bins][ref_cap] entries (ProbeArgs::refs)
     uint32_t* d_kocnt = nullptr; size_t cap_kocnt = 0;                // the key order's count table [B][buckets] + totals + the key count (fpx_keyorder.hpp)
     unsigned long long* d_qstats = nullptr; size_t cap_qstats = 0;    // per-query scan statistics (blocks | docs << 32), when asked for
     uint32_t* d_cells = nullptr; uint32_t* h_cells = nullptr; size_t cap_cells = 0;   // fpx_shard_probe: the cells' fill counters + statistics slots
@@ -334,6 +335,7 @@ enum CtxOpt : int {
     OPT_SHARDED_WORKERS,
     OPT_KEY_ORDER_BITS,
     OPT_LINE_POOL_SLACK,
+    OPT_HOT_REFS,
     OPT_COUNT
 };
 constexpr int64_t OPT_UNSET = -2;

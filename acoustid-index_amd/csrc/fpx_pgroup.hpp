@@ -497,19 +497,24 @@ __global__ __launch_bounds__(FK_WG) FPX_PK_OCC void k_probe_pgroup(ProbeArgs a, 
                         hist_observe(wg_h, eff_l, (hdr_l >> 16) & 7u);
                         if (GQSTATS(a)) atomicAdd(&GQSTATS(a)[qlo], (unsigned long long)((hdr_l >> 16) & 7u) | ((unsigned long long)eff_l << 32));
                     }
-                    const uint32_t rest_l = is_list ? eff_l - from_l : 0u;
+                    uint32_t rest_l = is_list ? eff_l - from_l : 0u;
                     if (rest_l) my_reads += ((rest_l + 31u) >> 5) * 2u;
+                    const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
+                    const uint32_t hot_bin = qlo >> a.bin_shift;
+                    // ... or, where the batch has room for references, NOT AT ALL (fpx_group.hpp: hot_ref_offer): the list's address goes to the
+                    // query's bin and k_score_bin reads the docs where they are
+                    if constexpr (BINNED) {
+                        if (a.ref_cap != 0u && !filtered && rest_l != 0u && hot_ref_offer(a, hot_bin, lp + 1u + T_l + from_l, rest_l, s_min_doc[col], qlo)) rest_l = 0u;
+                    }
                     uint32_t total = rest_l;
 #pragma unroll
                     for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
-                    const bool filtered = any_dead && __ballot((int)(is_list && s_has_dead[col] != 0u)) != 0ull;
                     unsigned long long me = __ballot((int)(rest_l != 0u));
                     unsigned long long gbase = 0;
                     // BINNED: all these records belong to ONE query, i.e. one bin -- the reservation is taken THERE and the lists go straight
                     // into the bin (round 3 left them in the misc buffer for k_bin: 575 M of the 625 M records of a hot-hash batch took
                     // that detour)
-                    const uint32_t hot_bin = qlo >> a.bin_shift;
-                    if (!filtered) {
+                    if (!filtered && total != 0u) {
                         if constexpr (BINNED) {
                             // (whole sectors here too, or the bin's later reservations would start inside one)
                             const uint32_t tr = (total + (BIN_ALIGN - 1u)) & ~(BIN_ALIGN - 1u);

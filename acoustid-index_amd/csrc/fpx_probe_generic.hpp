@@ -39,6 +39,10 @@ struct ProbeArgs {
     unsigned long long* qstats = nullptr;
     const unsigned long long* P_dev = nullptr;  // the number of pairs lives on the device (a rank's compacted share of the keys; [slots] of them): P is their capacity
     uint64_t slot_stride = 0;                   // k_probe_group / _pgroup with gridDim.y slots of keys: slot y = pairs + y * slot_stride, P_dev[y] keys
+    // BINNED: a HOT hash's lists (64+ docs each) may travel BY REFERENCE -- [nbins][ref_cap] entries of (address of the docs, how many,
+    // their doc id base, the query) that k_score_bin reads the docs through, instead of a copy of every list into every query's bin;
+    // the bins' reference counts sit in their fill counters' lines (word 2: count | docs << 32).  ref_cap 0: lists are copied
+    uint4* refs = nullptr; uint32_t ref_cap = 0;
     uint32_t rec32 = 0;                         // BINNED: the bins hold 4-byte records (bin_record32, fpx_partition.hpp)   // the number of pairs lives on the device (a rank's compacted share of the keys): P is their capacity
 };
 

@@ -38,10 +38,14 @@ struct ScoreBinArgs {
     uint64_t* qcand; uint32_t* qcand_n;            // the queries' own candidate slots
     uint32_t* bin_n;                               // [nbins] the bin's record count as found (the host adds them up; > bin_cap: redo)
     const uint32_t* cancel;
+    const uint4* refs; uint32_t ref_cap;           // hot lists by reference (ProbeArgs::refs; nsrc == 1 only): [nbins][ref_cap] of (address of the docs | how many << 48,
+                                                   // their doc id base, the query); the bin's count of them | their docs << 32 at word 2 of its fill counter's line
     uint32_t flog2;                                // log2 of the filter's 16-bit cells (0: SB_FILTER_LOG2): the host gives bins of hundreds of thousands
                                                    // of records (hot-hash data) a filter that counts them in ONE class -- two passes instead of 2 K
 };
 
+// (REFS: hot lists may have come by reference -- an instantiation of its own: their loop costs the usual one five registers, a workgroup per CU)
+template <bool REFS>
 __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
 {
     extern __shared__ __align__(16) uint8_t sb_smem[];
@@ -69,6 +73,14 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
         raw_max = max(raw_max, c);
         piece_over = piece_over || (uint64_t)c > room;
         n += c >= SB_NEED_MARK ? 0ull : min((uint64_t)c, room);              // (a marked count: no records, the step is redone)
+    }
+    // the lists that came by reference: their docs are records of the bin like the copied ones (the filter's size, the classes)
+    uint32_t nref = 0;
+    if constexpr (REFS) {
+        const unsigned long long rc = *reinterpret_cast<const unsigned long long*>(a.bin_count + (size_t)bin * a.count_step + 2u);
+        nref = min((uint32_t)rc, a.ref_cap);
+        n += rc >> 32;
+        if (tid == 0 && (rc >> 32) != 0ull) atomicAdd(&a.counters[CTR_TOTAL], rc >> 32);       // (the host adds them to the bins' counts: the batch's hit records)
     }
     if (tid == 0) a.bin_n[bin] = a.nsrc == 1u ? raw_max : (uint32_t)min<uint64_t>(n, 0xFFFFFFFFull);
     if (tid == 0 && (a.nsrc > 1u || a.rec_mode == 2u) && piece_over) {                          // (a piece of a sharded batch overflowed its cell)
@@ -147,6 +159,21 @@ __global__ __launch_bounds__(SB_WG) void k_score_bin(ScoreBinArgs a)
             }
 #pragma unroll
             for (uint32_t u = 0; u < SB_RPT; ++u) cur[u] = nxt[u];
+        }
+        // ... and the docs of the lists that came by reference, a list per wave, four loads under way per lane (the lists of a hot hash are
+        // shared by every query that holds it: they stay in the caches)
+        if constexpr (REFS) for (uint32_t r = tid >> 6; r < nref; r += SB_WG / 64u) {
+            const uint4 rf = a.refs[(size_t)bin * a.ref_cap + r];
+            const uint32_t* docs = reinterpret_cast<const uint32_t*>(((uint64_t)(rf.y & 0xFFFFu) << 32) | rf.x);
+            const uint32_t cnt = rf.y >> 16;
+            const uint64_t qpart = (uint64_t)(rf.w & qm) << 32;
+            for (uint32_t i0 = tid & 63u; i0 < cnt; i0 += 256u) {
+                uint32_t dv[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) dv[u] = i0 + 64u * u < cnt ? gload_u32(docs + i0 + 64u * u) : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) if (i0 + 64u * u < cnt) fn(qpart | (uint64_t)(rf.z + dv[u]));
+            }
         }
     };
 

@@ -596,6 +596,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 ws->hint_H != 0 && ws->hint_P != 0;
     if (fast && ws->fast_penalty != 0) { ws->fast_penalty -= 1; fast = false; }
     BinArgs h_bin{};
+    constexpr uint32_t HOT_REF_CAP = 4096;                                       // references to hot lists a bin takes (16 bytes each)
+    uint32_t ref_cap = 0;                                                        // 0: hot lists are copied into the bins
     uint32_t* d_bin_count = nullptr;
     uint32_t* d_qcount = nullptr;
     uint64_t est_H = 0;
@@ -655,6 +657,19 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             // synchronisation and the batch is redone on the general path
             h_bin.bin_cap = std::min<uint64_t>(ws->cap_hits / sbins, std::max<uint64_t>(2 * est_H / sbins + 8192, 16384)) & ~(uint64_t)31;      // (whole lines per bin: reservations padded to BIN_ALIGN records start on a sector)
             FPX_HIP(hipMemsetAsync(d_bin_count, 0, (size_t)sbins * BIN_STRIDE * sizeof(uint32_t), st));
+            // Hot-hash data (the last batch brought 16+ records per key): the lists of a hot hash -- thousands of docs, the same for every
+            // query that holds the hash -- reach the score kernel BY REFERENCE (ProbeArgs::refs): HOT_REF_CAP entries per bin, their
+            // counts in the bins' counter lines (zeroed above); a bin with more lists has the rest copied as before
+            const int64_t hot_refs = ctx_opt(snap->ctx, OPT_HOT_REFS);
+            if (hot_refs > 0 || (hot_refs < 0 && est_H > 16ull * P)) {
+                ref_cap = HOT_REF_CAP;
+                if ((size_t)sbins * ref_cap > ws->cap_refs) {
+                    if (ws->d_refs) (void)hipFree(ws->d_refs);
+                    ws->d_refs = nullptr; ws->cap_refs = 0;
+                    if (dmalloc(&ws->d_refs, (size_t)sbins * ref_cap * sizeof(uint4)) == hipSuccess) ws->cap_refs = (size_t)sbins * ref_cap;
+                    else { (void)hipGetLastError(); ref_cap = 0; }              // (no room: the lists are copied)
+                }
+            }
         } else {
             h_bin.nbins = 1u << nb_bits; h_bin.shift = qb - nb_bits;
             // a bin holds at most 4x its expected share (never more than its slice of the buffer): the level-2 grids are sized by
@@ -703,7 +718,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 if (snap->n_group) {
                     ProbeArgs gk = a;
                     gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
-                    if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; }
+                    if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; gk.refs = ref_cap ? ws->d_refs : nullptr; gk.ref_cap = ref_cap; }
                     const uint32_t group_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_GROUP_ROUNDS));
                     gk.rounds = group_rounds ? std::min(group_rounds, 1024u) : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
                     // (hot-hash data -- the previous batch brought 16+ records per key: a workgroup's rounds wait for the waves that copy the
@@ -877,18 +892,21 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
             // bins of hundreds of thousands of records (hot-hash data: 12 x the records of a uniform batch) get a filter of 2^15 32-bit cells
             // -- 128 KB, one workgroup per CU -- that counts them in ONE class: two passes over the bin where the 32-KB filter needs 2 K
+            sa.refs = ref_cap ? ws->d_refs : nullptr; sa.ref_cap = ref_cap;
             sa.flog2 = est_H / sbins > 60000ull ? 16u : 0u;
             const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << (sa.flog2 ? sa.flog2 : SB_FILTER_LOG2)) + ((size_t)SB_CAND << h_bin.shift) * 8u;
             {   // (a function's attribute belongs to the device it is set on: once per device, not once per process)
                 static std::atomic<uint64_t> attr_done{0};
                 const uint64_t bit = 1ull << ((unsigned)snap->ctx->device & 63u);
                 if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_bin<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
                     (void)hipGetLastError();
                     attr_done.fetch_or(bit, std::memory_order_release);
                 }
             }
-            hipLaunchKernelGGL(k_score_bin, dim3(sbins), dim3(SB_WG), sb_lds, st, sa);
+            if (ref_cap) hipLaunchKernelGGL(k_score_bin<true>, dim3(sbins), dim3(SB_WG), sb_lds, st, sa);
+            else hipLaunchKernelGGL(k_score_bin<false>, dim3(sbins), dim3(SB_WG), sb_lds, st, sa);
         } else {
         hipLaunchKernelGGL(k_l2_count, dim3(tiles, h_bin.nbins), dim3(256), 0, st, h_bin, d_qcount, B);
         hipLaunchKernelGGL(k_l2_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)d_qcount, B, ws->d_qrange, ws->d_qcursor, d_qcand_n,
@@ -961,8 +979,9 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             bin_total += c;
         }
         const uint64_t misc = ws->h_counters[CTR_HITS];
-        H = binned ? bin_total : ws->h_counters[CTR_TOTAL];
-        if (worst_bin > h_bin.bin_cap || misc > ws->cap_hits || H > ws->cap_hits) { redo = true; hits_short = true; }
+        const uint64_t ref_docs = (binned && ref_cap) ? ws->h_counters[CTR_TOTAL] : 0;         // (docs of the lists that travelled by reference: records of the batch, in no buffer)
+        H = binned ? bin_total + ref_docs : ws->h_counters[CTR_TOTAL];
+        if (worst_bin > h_bin.bin_cap || misc > ws->cap_hits || H - ref_docs > ws->cap_hits) { redo = true; hits_short = true; }
         if (used_lean)
             for (uint32_t i = 0; i < snap->n_lean; ++i) redo = redo || ws->h_def_count[(size_t)i * DEF_COUNT_STRIDE] > def_cap;
         if (ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands || ws->h_counters[CTR_BINFAIL] != 0) redo = true;
@@ -1034,7 +1053,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             stats->probe_kernel_fetched_bytes += ln ? reads * 128ull : snap->n_direct ? ws->h_counters[CTR_LEAN_READS] * 64ull + (snap->n_file ? ws->h_counters[CTR_BYTES] : 0ull)
                                                                      : ws->h_counters[CTR_BYTES];
             stats->probe_aux_ms += aux;
-            stats->path_flags |= 1u | (Cf ? 2u : 0u) | (used_fused ? 4u : 0u) | (binned ? 8u : 0u);
+            stats->path_flags |= 1u | (Cf ? 2u : 0u) | (used_fused ? 4u : 0u) | (binned ? 8u : 0u) | (ref_docs ? 32u : 0u);
         }
         if ((rc = deliver_qstats())) return rc;
         ws->hint_P = P; ws->hint_H = std::max<uint64_t>(H, 1);
@@ -2037,7 +2056,7 @@ int shard_score_impl(Ctx* ctx, const QueryBatch* qb, uint32_t world, uint32_t ra
         sa.qcand = d_qcand; sa.qcand_n = d_qcand_n; sa.bin_n = d_bin_n; sa.cancel = cancel;
         const size_t sb_lds = ((size_t)8u << SB_TABLE_LOG2) + ((size_t)2u << SB_FILTER_LOG2) + ((size_t)SB_CAND << SHARD_BQ) * 8u;
         const uint32_t my_bins = (nq + (1u << SHARD_BQ) - 1u) >> SHARD_BQ;
-        hipLaunchKernelGGL(k_score_bin, dim3(my_bins), dim3(SB_WG), sb_lds, st, sa);
+        hipLaunchKernelGGL(k_score_bin<false>, dim3(my_bins), dim3(SB_WG), sb_lds, st, sa);
         finish(ws->d_cands[0], 0);
         FPX_HIP(hipGetLastError());
         if ((rc = stage_results(ws, nq, out_cap, st, &staged))) return rc;

@@ -78,7 +78,8 @@ typedef struct {
                                    more candidates than slots.  Neither: the general path (first batch of a workspace,
                                    exchanges, anything the device-sized path handed back).  bit 2: direct-addressed segments
                                    were probed as a GROUP (k_probe_group), bit 3: ... whose records went straight into bins of a
-                                   few queries, scored a bin per workgroup (k_score_bin) */
+                                   few queries, scored a bin per workgroup (k_score_bin), bit 4: the batch ran a step of a sharded protocol,
+                                   bit 5: ... and hot hashes' lists reached the score kernel by reference ("hot_refs") */
     uint64_t probe_kernel_fetched_bytes; /* block bytes the main probe kernel really fetched, in 128-byte lines: a probe
                                    whose hash the segment's presence bits know to be absent counts as a visited block (as in
                                    the reference) without the block being read, and a block that is read costs two lines up
@@ -112,6 +113,8 @@ int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context live
  *   "rec32"              1 | 0   4-byte records in the bins where the doc ids leave room (default 1)
  *   "local_sort_max", "order_min_pairs", "order_max_pairs"   pair counts that choose how a batch's keys are ordered
  *   "key_order_bits"     top hash bits the keys of a batch on direct-addressed segments are ordered by (0..8, default 8)
+ *   "hot_refs"           1 | 0 | -1   the lists of HOT hashes (64+ docs) reach the score kernel by reference instead of a copy per query |
+ *                        are copied into the bins | by the records the workspace's last batch brought (default)
  *   "line_pool_slack"    per cent by which the line buffer kept on the GPU (fpx_ctx_trim) may exceed the lines of the group that takes
  *                        it over (default 0: an exact fit; a host that builds groups of several sizes in turn may allow more)
  *   "lean_min"           probes from which block-form segments take the lean kernel (default 2^16)

@@ -115,6 +115,32 @@ def test_hot_list_is_cut_where_the_reference_stops(env, monkeypatch):
     assert got[0] == want
 
 
+@pytest.mark.parametrize("nseg", [6, 2])
+def test_hot_lists_reach_the_score_kernel_by_reference(env, nseg, monkeypatch):
+    """"hot_refs": the list of a hot hash (the hash with 3000 docs: > 1000 returned, four blocks) is not copied into every query's bin --
+    its address is, and k_score_bin reads the docs where they are.  Same results, same counters, as with copies and as the oracle's."""
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, nseg, monkeypatch)
+    big = _queries(rng, allitems, 40)
+    try:
+        ctx.set_option("hot_refs", 0)
+        got0, st0 = p.check(big, fpx.http_options())
+        assert st0.path_flags & 8 and not st0.path_flags & 32
+        ctx.set_option("hot_refs", 1)
+        got1, st1 = p.check(big, fpx.http_options())
+        _, st2 = p.reader.search_batch(big, fpx.http_options())          # (the device-sized path: the one that bins)
+        assert st2.path_flags & 8 and st2.path_flags & 32, st2.path_flags
+        assert got1 == got0 and (st1.hits, st1.scanned_docs, st1.scanned_blocks) == (st0.hits, st0.scanned_docs, st0.scanned_blocks)
+        assert (st2.hits, st2.scanned_docs) == (st0.hits, st0.scanned_docs)
+        # a query of the hot hash alone in a batch of its copies: every bin full of references to ONE list
+        many = [np.array([HOT, SHARED], dtype=np.uint32)] * 64
+        # (a floor of 3 keeps the batch on the binned path -- floors of 1 / 2 take the general one --: no doc holds three of a query's two hashes)
+        gotm, stm = p.check(many, fpx.SearchOptions(max_results=100, min_score=3, min_score_pct=0))
+        assert all(g == [] for g in gotm) and stm.hits > 64 * 1000
+    finally:
+        ctx.set_option("hot_refs", -2)
+
+
 def test_download_and_merge_of_direct_addressed_segments_give_the_files_bytes(env, monkeypatch):
     fpx, oracle, Pair, ctx = env
     monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")

@@ -99,6 +99,9 @@ def test_argument_checks_need_no_gpu():
     rc = fpx.lib().fpx_scan_histograms_observe(None, None, off.ctypes.data_as(C.c_void_p), 1, 0, C.byref(acc))
     assert rc == -4 and b"null" in fpx.lib().fpx_last_error()
     assert acc.count == 0
+    # the running histograms of a context, and the memory it keeps: no context, nothing
+    assert fpx.lib().fpx_ctx_scan_histograms(None, C.byref(acc), None) == -4 and b"null" in fpx.lib().fpx_last_error()
+    assert fpx.lib().fpx_ctx_trim(None) == 0
 
 
 def test_replay_premise_on_the_oracle(orc):

@@ -29,7 +29,7 @@ build = time.perf_counter() - t0
 opts = fpx.http_options()
 qbs = []
 for i in range(3):
-    f, o, t = fpx.synth.make_queries(20260928, 4242 + 1000003 * i, B, per * S, H, query_len=1000)
+    f, o, t = fpx.synth.make_queries(20260928, 4242 + 1000003 * i, B, per * S, H, query_len=1000, dist=int(os.environ.get("AB_DIST", 0)))
     qbs.append(fpx.QueryBatch(ctx, options=opts, flat=(f, o)))
 want = None
 for combo in itertools.product(*[v for _, v in axes]):
@@ -50,5 +50,5 @@ for combo in itertools.product(*[v for _, v in axes]):
         want = got
     same = bool(np.array_equal(want[1], got[1]) and all(np.array_equal(want[0][q, :want[1][q]], got[0][q, :got[1][q]]) for q in range(0, B, 7)))
     print(json.dumps({"options": dict(zip([n for n, _ in axes], combo)), "probe_ms_median": round(float(np.median(pm)), 4), "probe_ms_min": round(float(np.min(pm)), 4),
-                      "gpu_ms_median": round(float(np.median(gm)), 4), "step_ms": round(dt / steps * 1e3, 4), "flags": flags, "same_results": same,
+                      "gpu_ms_median": round(float(np.median(gm)), 4), "step_ms": round(dt / steps * 1e3, 4), "flags": flags, "hits": int(st.hits), "same_results": same,
                       "build_s": round(build, 1)}), flush=True)

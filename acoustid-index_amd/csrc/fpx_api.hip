@@ -87,14 +87,24 @@ size_t line_pool_bytes(int device)
     return g_line_pool[device].bytes;
 }
 
+// FPX_POISON=1 (a debugging aid of the tests): every fresh allocation is filled with 0xCD before it is handed out -- nothing in the
+// library may depend on what fresh device memory happens to hold (usually zeros; under several processes' churn, another process's data)
+static bool poison_enabled()
+{
+    static const bool on = [] { const char* e = getenv("FPX_POISON"); return e && e[0] == '1'; }();
+    return on;
+}
 hipError_t dmalloc_raw(void** p, size_t bytes)
 {
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipErrorOutOfMemory) return e;
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || line_pool_flush(device) == 0) return e;
-    (void)hipGetLastError();
-    return hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess || line_pool_flush(device) == 0) return e;
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && poison_enabled()) (void)hipMemset(*p, 0xCD, bytes);
+    return e;
 }
 
 thread_local DevArena* tl_arena = nullptr;

@@ -1185,7 +1185,11 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     }
     out->xshift = pad;
     const uint64_t D = h_tot[1], X = h_tot[2], Dp = h_tot[3];               // distinct hashes, list words, set bits (hashes + gap positions)
-    if (Dp < D) { set_error("internal: %llu set bits for %llu distinct hashes", (unsigned long long)Dp, (unsigned long long)D); return FPX_E_DEVICE; }
+    if (Dp < D) {
+        set_error("internal: %llu set bits for %llu distinct hashes (piece of %u records, blocks %u + %u, %llu items, %llu list words)", (unsigned long long)Dp,
+                  (unsigned long long)D, nrec, b0, nbl, (unsigned long long)n, (unsigned long long)X);
+        return FPX_E_DEVICE;
+    }
     if (h_flags[0] || h_flags[1] || (X >> pad) >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull) return FPX_E_INVAL;      // does not qualify
     FPX_HIP(piece_alloc(&out->primary, &out->own_primary, (Dp + 4) * sizeof(uint32_t)));
     FPX_HIP(piece_alloc(&out->extras, &out->own_extras, (X + 8) * sizeof(uint32_t)));

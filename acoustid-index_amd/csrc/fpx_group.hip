@@ -584,9 +584,10 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     };
     // the members' pieces of a chunk -- and everything it takes to build them -- out of ONE allocation, rewound chunk by chunk
     DevArena arena, scratch;
+    static const bool arenas_on = [] { const char* e = getenv("FPX_BUILD_ARENAS"); return !(e && e[0] == '0'); }();      // (0: the A/B of the arenas)
     struct ArenaScope {
         DevArena* prev; DevArena* prev_s;
-        ArenaScope(DevArena* a, DevArena* s) : prev(tl_arena), prev_s(tl_scratch) { tl_arena = a; tl_scratch = s; }
+        ArenaScope(DevArena* a, DevArena* s) : prev(tl_arena), prev_s(tl_scratch) { if (arenas_on) { tl_arena = a; tl_scratch = s; } }
         ~ArenaScope() { tl_arena = prev; tl_scratch = prev_s; }
     } arena_scope(&arena, &scratch);
     for (uint32_t ci = 0; ci < nchunks; ++ci) {

@@ -65,6 +65,10 @@ def _suites(env):
             return ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py"]
         if "FPX_REC32" in env:
             return ["tests/test_gpu_parity.py", "tests/test_gpu_hashshard.py"]
+        if "FPX_GROUP_PACKED" in env:
+            # (every group of this child costs 64 / 137 GB of lines and seconds of mapping them, however small its segments: the suites
+            # that reach the packed form's own code -- its probe kernel, its builder, its downloads, its window slices)
+            return [s for s in FUSED_SUITES if "test_gpu_api" not in s and "test_gpu_fuzz" not in s]
         return FUSED_SUITES
     return DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
 

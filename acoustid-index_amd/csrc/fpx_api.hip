@@ -103,7 +103,12 @@ hipError_t dmalloc_raw(void** p, size_t bytes)
         (void)hipGetLastError();
         e = hipMalloc(p, bytes);
     }
-    if (e == hipSuccess && poison_enabled()) (void)hipMemset(*p, 0xCD, bytes);
+    if (e == hipSuccess && poison_enabled()) {
+        // (FPX_POISON_MIN / _MAX: only allocations of that many bytes -- which buffer was it?)
+        static const size_t lo = [] { const char* v = getenv("FPX_POISON_MIN"); return v ? (size_t)strtoull(v, nullptr, 0) : (size_t)0; }();
+        static const size_t hi = [] { const char* v = getenv("FPX_POISON_MAX"); return v ? (size_t)strtoull(v, nullptr, 0) : ~(size_t)0; }();
+        if (bytes >= lo && bytes <= hi) (void)hipMemset(*p, 0xCD, bytes);
+    }
     return e;
 }
 

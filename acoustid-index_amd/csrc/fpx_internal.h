@@ -374,6 +374,10 @@ size_t line_pool_flush(int device);                          // frees the cached
 size_t line_pool_bytes(int device);
 hipError_t dmalloc_raw(void** p, size_t bytes);              // hipMalloc on the current device; out of memory: line_pool_flush + once more
 template <class T> inline hipError_t dmalloc(T** p, size_t bytes) { return dmalloc_raw(reinterpret_cast<void**>(p), bytes); }
+// a memset of the group builder: hipMemsetAsync -- or (FPX_BUILD_FILLK=1, the A/B of a suspicion) a kernel of our own on the same stream
+hipError_t dfill(void* p, int value, size_t bytes, hipStream_t st);
+// FPX_BUILD_SYNC=1: the arenas' rewinds wait for the whole device (what the fourteen hipFree calls per piece did before the arenas)
+void arena_sync_point();
 hipError_t mem_info(size_t* free_b, size_t* total_b);        // hipMemGetInfo, the current device's cached buffer counted as free
 // A group is built from 64 chunks x up to 16 members' pieces, and every piece used to take fourteen allocations of its own (and give
 // them back: the runtime unmaps -- and the driver wipes -- what is freed): 14 000 hipMalloc / hipFree pairs for the 100 M index, 8 000 for
@@ -382,17 +386,27 @@ hipError_t mem_info(size_t* free_b, size_t* total_b);        // hipMemGetInfo, t
 struct DevArena {
     uint8_t* base = nullptr;
     size_t cap = 0, used = 0, missed = 0;          // missed: bytes asked for since the last rewind that did not fit
-    ~DevArena() { if (base) (void)hipFree(base); }
+    const char* name = "arena";
+    // FPX_ARENA_GUARD=<bytes> (a debugging aid): that many bytes of 0xA5 behind every allocation, checked at the rewind -- a kernel that
+    // writes past the end of its buffer used to hit an allocation's padding, here it would hit its neighbour
+    std::vector<std::pair<size_t, size_t>> guards; // (offset of the guard, bytes of the allocation before it)
+    static size_t guard_bytes();
+    void check_guards();
+    ~DevArena() { check_guards(); if (base) (void)hipFree(base); }
     void* take(size_t bytes)                       // null: does not fit (the caller allocates on its own)
     {
-        const size_t need = (bytes + 255u) & ~(size_t)255u;
+        const size_t g = guard_bytes();
+        const size_t body = (bytes + 255u) & ~(size_t)255u, need = body + g;
         if (used + need > cap) { missed += need; return nullptr; }
         void* p = base + used;
+        if (g) { (void)hipMemset(base + used + body, 0xA5, g); guards.emplace_back(used + body, bytes); }
         used += need;
         return p;
     }
     void rewind()                                  // (nothing that uses the arena's memory is under way: the caller has waited)
     {
+        arena_sync_point();
+        check_guards();
         if (missed) {
             const size_t want = (used + missed) * 5 / 4 + ((size_t)1 << 20);
             if (base) (void)hipFree(base);

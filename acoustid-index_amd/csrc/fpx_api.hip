@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstring>
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <execinfo.h>
+#include <atomic>
 
 #include <algorithm>
 #include <new>
@@ -104,10 +107,27 @@ hipError_t dmalloc_raw(void** p, size_t bytes)
         e = hipMalloc(p, bytes);
     }
     if (e == hipSuccess && poison_enabled()) {
-        // (FPX_POISON_MIN / _MAX: only allocations of that many bytes -- which buffer was it?)
+        // (FPX_POISON_MIN / _MAX: only allocations of that many bytes; FPX_POISON_ORD_LO / _HI: only the process's n-th allocations --
+        // tools/poison_bisect.py narrows "which buffer was it" down to one; FPX_ALLOC_LOG: ordinal, bytes and the caller's return
+        // addresses of every allocation.  The fill is waited for: the library's streams do not wait for the null stream's work.)
         static const size_t lo = [] { const char* v = getenv("FPX_POISON_MIN"); return v ? (size_t)strtoull(v, nullptr, 0) : (size_t)0; }();
         static const size_t hi = [] { const char* v = getenv("FPX_POISON_MAX"); return v ? (size_t)strtoull(v, nullptr, 0) : ~(size_t)0; }();
-        if (bytes >= lo && bytes <= hi) (void)hipMemset(*p, 0xCD, bytes);
+        static const uint64_t olo = [] { const char* v = getenv("FPX_POISON_ORD_LO"); return v ? (uint64_t)strtoull(v, nullptr, 0) : (uint64_t)0; }();
+        static const uint64_t ohi = [] { const char* v = getenv("FPX_POISON_ORD_HI"); return v ? (uint64_t)strtoull(v, nullptr, 0) : ~(uint64_t)0; }();
+        static FILE* const log = [] { const char* v = getenv("FPX_ALLOC_LOG"); return v ? std::fopen(v, "w") : (FILE*)nullptr; }();
+        static std::atomic<uint64_t> ordinal{0};
+        const uint64_t ord = ordinal.fetch_add(1);
+        if (log) {
+            void* bt[6];
+            const int nb = backtrace(bt, 6);
+            Dl_info di{};
+            std::fprintf(log, "%llu %zu", (unsigned long long)ord, bytes);
+            for (int i = 1; i < nb; ++i)
+                if (dladdr(bt[i], &di) && di.dli_fbase) std::fprintf(log, " %s+0x%zx", di.dli_fname ? std::strrchr(di.dli_fname, '/') ? std::strrchr(di.dli_fname, '/') + 1 : di.dli_fname : "?", (size_t)((char*)bt[i] - (char*)di.dli_fbase));
+            std::fprintf(log, "\n");
+            std::fflush(log);
+        }
+        if (bytes >= lo && bytes <= hi && ord >= olo && ord <= ohi) { (void)hipMemset(*p, 0xCD, bytes); (void)hipDeviceSynchronize(); }
     }
     return e;
 }

@@ -311,6 +311,13 @@ void DevArena::check_guards()
     }
     guards.clear();
 }
+void arena_fill_point(void* base, size_t bytes)
+{
+    static const int v = [] { const char* e = getenv("FPX_ARENA_FILL"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
+    if (v < 0 || !base || !bytes) return;
+    (void)hipMemset(base, v, bytes);
+    (void)hipDeviceSynchronize();
+}
 void arena_sync_point()
 {
     static const bool on = [] { const char* e = getenv("FPX_BUILD_SYNC"); return e && e[0] == '1'; }();
@@ -391,15 +398,27 @@ int scan_counts_u32(const uint32_t* counts, uint64_t n, uint64_t* offsets, uint6
     }
     const uint64_t nparts = (n + SCAN_PART - 1) / SCAN_PART;
     if (nparts > 0x7FFFFFFFull) { set_error("scan of %llu counts", (unsigned long long)n); return FPX_E_INVAL; }
+    // The parts' sums: out of the group builder's scratch arena where there is one, else an allocation of its own.  NOT out of the
+    // runtime's stream-ordered pool (hipMallocAsync / hipFreeAsync, round 4): with the builder's arenas -- no hipFree between two scans
+    // any more -- one group build in twenty came out with part sums that read as ZERO between k_scan_part_sums and k_scan_u64_inplace
+    // when four processes shared the GPU ("0 set bits for 398477 distinct hashes", or wrong ranks and wrong search results); the pool
+    // gives a block back to the system at the stream's next wait and hands out its successor at once (FPX_SCAN_POOLED=1: the A/B).
+    static const bool use_pool = [] { const char* v = getenv("FPX_SCAN_POOLED"); return v && v[0] == '1'; }();
     uint64_t* partsum = nullptr;
-    const bool pooled = hipMallocAsync(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t), st) == hipSuccess;
-    if (!pooled) { (void)hipGetLastError(); partsum = nullptr; FPX_HIP(dmalloc(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t))); }
+    DevBuf own;
+    const bool pooled = use_pool && hipMallocAsync(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t), st) == hipSuccess;
+    if (!pooled) {
+        (void)hipGetLastError();
+        const int rc = own.alloc(nparts * sizeof(uint64_t));
+        if (rc) return rc;
+        partsum = own.as<uint64_t>();
+    }
     hipLaunchKernelGGL(k_scan_part_sums, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, partsum);
     hipLaunchKernelGGL(k_scan_u64_inplace, dim3(1), dim3(1024), 0, st, partsum, nparts, total);
     hipLaunchKernelGGL(k_scan_part_write, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, (const uint64_t*)partsum, offsets);
     const hipError_t e = hipGetLastError();
     if (pooled) (void)hipFreeAsync(partsum, st);
-    else { (void)hipStreamSynchronize(st); (void)hipFree(partsum); }
+    else if (own.own) (void)hipStreamSynchronize(st);             // (its destructor frees it; an arena's piece goes with the rewind)
     if (e != hipSuccess) return hip_fail(e, "scan_counts_u32");
     return FPX_OK;
 }

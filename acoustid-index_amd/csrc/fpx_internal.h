@@ -378,6 +378,8 @@ template <class T> inline hipError_t dmalloc(T** p, size_t bytes) { return dmall
 hipError_t dfill(void* p, int value, size_t bytes, hipStream_t st);
 // FPX_BUILD_SYNC=1: the arenas' rewinds wait for the whole device (what the fourteen hipFree calls per piece did before the arenas)
 void arena_sync_point();
+// FPX_ARENA_FILL=<byte>: a rewound arena is filled with that byte (0: what fresh allocations held; 0xCD: what they must not depend on)
+void arena_fill_point(void* base, size_t bytes);
 hipError_t mem_info(size_t* free_b, size_t* total_b);        // hipMemGetInfo, the current device's cached buffer counted as free
 // A group is built from 64 chunks x up to 16 members' pieces, and every piece used to take fourteen allocations of its own (and give
 // them back: the runtime unmaps -- and the driver wipes -- what is freed): 14 000 hipMalloc / hipFree pairs for the 100 M index, 8 000 for
@@ -414,6 +416,7 @@ struct DevArena {
             if (dmalloc(&base, want) == hipSuccess) cap = want; else { (void)hipGetLastError(); base = nullptr; }
         }
         used = 0; missed = 0;
+        arena_fill_point(base, cap);
     }
 };
 // Two of them while a group is built: a chunk's OUTPUTS (the members' pieces: alive until the chunk's lines are filled) and a piece's

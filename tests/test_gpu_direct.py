@@ -122,16 +122,18 @@ def test_hot_lists_reach_the_score_kernel_by_reference(env, nseg, monkeypatch):
     fpx, oracle, Pair, ctx = env
     p, allitems, rng = _world(fpx, Pair, ctx, nseg, monkeypatch)
     big = _queries(rng, allitems, 40)
+    # (the variants of tests/test_gpu_variants.py that switch the bins off run this too: no bins, no references -- the same results)
+    binned = os.environ.get("FPX_BINNED", "1") != "0" and os.environ.get("FPX_FAST", "1") != "0"
     try:
         ctx.set_option("hot_refs", 0)
         got0, st0 = p.check(big, fpx.http_options())
-        assert st0.path_flags & 8 and not st0.path_flags & 32
+        assert bool(st0.path_flags & 8) == binned and not st0.path_flags & 32, st0.path_flags
         ctx.set_option("hot_refs", 1)
         got1, st1 = p.check(big, fpx.http_options())
         _, st2 = p.reader.search_batch(big, fpx.http_options())          # (the device-sized path: the one that bins)
         # (six segments: the hot hash's segment has docs that a later segment re-inserts -- its lists pass the supersession filter on
         # their way, copied; two segments: nothing newer than the hot hash's segment, its list travels by reference)
-        assert st2.path_flags & 8 and bool(st2.path_flags & 32) == (nseg == 2), st2.path_flags
+        assert bool(st2.path_flags & 8) == binned and bool(st2.path_flags & 32) == (binned and nseg == 2), st2.path_flags
         assert got1 == got0 and (st1.hits, st1.scanned_docs, st1.scanned_blocks) == (st0.hits, st0.scanned_docs, st0.scanned_blocks)
         assert (st2.hits, st2.scanned_docs) == (st0.hits, st0.scanned_docs)
         # a query of the hot hash alone in a batch of its copies: every bin full of references to ONE list

@@ -896,6 +896,9 @@ int build_presence(Segment* s)
     hipLaunchKernelGGL(k_fill_proberec, dim3((nrec + 255) / 256), dim3(256), 0, 0,
                        s->d_block_index, s->d_blockrec, s->num_blocks, shift + 8u, nrec, s->d_proberec, with_bits ? 0u : 1u);
     FPX_HIP(hipGetLastError());
+    // (the records are read by the searches' streams, which do not wait for the null stream's work: it is waited for here, not by
+    // whatever synchronous call happens to follow)
+    FPX_HIP(hipStreamSynchronize(0));
     s->device_bytes += bytes;
     return FPX_OK;
 }

@@ -275,19 +275,6 @@ struct DevBuf {
     }
 };
 
-__global__ void k_fill_words(uint32_t* __restrict__ p, uint32_t v, uint64_t n)
-{
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
-}
-hipError_t dfill(void* p, int value, size_t bytes, hipStream_t st)
-{
-    static const bool own = [] { const char* e = getenv("FPX_BUILD_FILLK"); return e && e[0] == '1'; }();
-    if (!own || (bytes & 3u) || ((uintptr_t)p & 3u) || bytes == 0) return hipMemsetAsync(p, value, bytes, st);
-    const uint32_t b = (uint32_t)value & 0xFFu, v = b | (b << 8) | (b << 16) | (b << 24);
-    const uint64_t n = bytes / 4;
-    hipLaunchKernelGGL(k_fill_words, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536)), dim3(256), 0, st, static_cast<uint32_t*>(p), v, n);
-    return hipGetLastError();
-}
 size_t DevArena::guard_bytes()
 {
     static const size_t g = [] { const char* e = getenv("FPX_ARENA_GUARD"); return e ? ((size_t)strtoull(e, nullptr, 0) + 255u) & ~(size_t)255u : (size_t)0; }();
@@ -311,19 +298,6 @@ void DevArena::check_guards()
     }
     guards.clear();
 }
-void arena_fill_point(void* base, size_t bytes)
-{
-    static const int v = [] { const char* e = getenv("FPX_ARENA_FILL"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
-    if (v < 0 || !base || !bytes) return;
-    (void)hipMemset(base, v, bytes);
-    (void)hipDeviceSynchronize();
-}
-void arena_sync_point()
-{
-    static const bool on = [] { const char* e = getenv("FPX_BUILD_SYNC"); return e && e[0] == '1'; }();
-    if (on) (void)hipDeviceSynchronize();
-}
-
 // Encode `n` sorted items (device memory) into the blocks + block index of `s` (filefmt.writeBlocks,
 // src/filefmt.zig:94-138).  `s->block_size` is taken from the argument; on failure the caller frees `s`.
 // ... and the same over many workgroups for long arrays: parts of 2^14 counts -- their sums, the sums' prefix (the one-workgroup kernel
@@ -401,24 +375,19 @@ int scan_counts_u32(const uint32_t* counts, uint64_t n, uint64_t* offsets, uint6
     // The parts' sums: out of the group builder's scratch arena where there is one, else an allocation of its own.  NOT out of the
     // runtime's stream-ordered pool (hipMallocAsync / hipFreeAsync, round 4): with the builder's arenas -- no hipFree between two scans
     // any more -- one group build in twenty came out with part sums that read as ZERO between k_scan_part_sums and k_scan_u64_inplace
-    // when four processes shared the GPU ("0 set bits for 398477 distinct hashes", or wrong ranks and wrong search results); the pool
-    // gives a block back to the system at the stream's next wait and hands out its successor at once (FPX_SCAN_POOLED=1: the A/B).
-    static const bool use_pool = [] { const char* v = getenv("FPX_SCAN_POOLED"); return v && v[0] == '1'; }();
-    uint64_t* partsum = nullptr;
+    // when four processes shared the GPU ("0 set bits for 398477 distinct hashes", or wrong ranks and wrong search results): 8 of 160
+    // runs with the pool, 0 of 240 without (profiles/r05_arena_flake_ab.txt).  What the runtime does there was not established.
     DevBuf own;
-    const bool pooled = use_pool && hipMallocAsync(reinterpret_cast<void**>(&partsum), nparts * sizeof(uint64_t), st) == hipSuccess;
-    if (!pooled) {
-        (void)hipGetLastError();
+    {
         const int rc = own.alloc(nparts * sizeof(uint64_t));
         if (rc) return rc;
-        partsum = own.as<uint64_t>();
     }
+    uint64_t* partsum = own.as<uint64_t>();
     hipLaunchKernelGGL(k_scan_part_sums, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, partsum);
     hipLaunchKernelGGL(k_scan_u64_inplace, dim3(1), dim3(1024), 0, st, partsum, nparts, total);
     hipLaunchKernelGGL(k_scan_part_write, dim3((uint32_t)nparts), dim3(256), 0, st, counts, n, (const uint64_t*)partsum, offsets);
     const hipError_t e = hipGetLastError();
-    if (pooled) (void)hipFreeAsync(partsum, st);
-    else if (own.own) (void)hipStreamSynchronize(st);             // (its destructor frees it; an arena's piece goes with the rewind)
+    if (own.own) (void)hipStreamSynchronize(st);             // (its destructor frees it; an arena's piece goes with the rewind)
     if (e != hipSuccess) return hip_fail(e, "scan_counts_u32");
     return FPX_OK;
 }
@@ -1197,17 +1166,17 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
         return dmalloc(p, bytes);
     };
     FPX_HIP(piece_alloc(&out->drec, &out->own_drec, (size_t)nrec * 64u));
-    FPX_HIP(dfill(out->drec, 0, (size_t)nrec * 64u, st));
+    FPX_HIP(hipMemsetAsync(out->drec, 0, (size_t)nrec * 64u, st));
     DevBuf rectot, recbase, tot;
     if ((rc = rectot.alloc((size_t)nrec * 4)) || (rc = recbase.alloc((size_t)nrec * 8)) || (rc = tot.alloc(64))) return rc;
     uint64_t* d_tot = tot.as<uint64_t>();
-    FPX_HIP(dfill(tot.p, 0, 64, st));
+    FPX_HIP(hipMemsetAsync(tot.p, 0, 64, st));
     if (nbl == 0) {                      // no block of the segment reaches into the range: every position clear
         hipLaunchKernelGGL(k_direct_rec_counts, dim3((nrec + 255) / 256), dim3(256), 0, st, out->drec, rectot.as<uint32_t>(), nrec);
         FPX_HIP(piece_alloc(&out->primary, &out->own_primary, 16 * sizeof(uint32_t)));
         FPX_HIP(piece_alloc(&out->extras, &out->own_extras, 16 * sizeof(uint32_t)));
-        FPX_HIP(dfill(out->primary, 0xFF, 16 * sizeof(uint32_t), st));
-        FPX_HIP(dfill(out->extras, 0, 16 * sizeof(uint32_t), st));
+        FPX_HIP(hipMemsetAsync(out->primary, 0xFF, 16 * sizeof(uint32_t), st));
+        FPX_HIP(hipMemsetAsync(out->extras, 0, 16 * sizeof(uint32_t), st));
         FPX_HIP(hipStreamSynchronize(st));
         return FPX_OK;
     }
@@ -1218,7 +1187,7 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     const uint64_t n = (uint64_t)h_b[1] - h_b[0];
     DevBuf boff, items, ns, nx, xbase, sbase, flags;
     if ((rc = boff.alloc(((size_t)nbl + 1) * 8)) || (rc = items.alloc(n * 8 + 8)) || (rc = flags.alloc(64))) return rc;
-    FPX_HIP(dfill(flags.p, 0, 64, st));
+    FPX_HIP(hipMemsetAsync(flags.p, 0, 64, st));
     hipLaunchKernelGGL(k_local_boff, dim3((nbl + 256) / 256), dim3(256), 0, st, (const uint32_t*)(s->d_bstart + b0), nbl, boff.as<uint64_t>());
     hipLaunchKernelGGL(k_decode_items, dim3((nbl + 3) / 4), dim3(256), 0, st, blocks, s->block_size, nbl, s->min_doc_id,
                        boff.as<uint64_t>(), (const uint32_t*)nullptr, 0u, items.as<uint64_t>(), (uint8_t*)nullptr);
@@ -1257,15 +1226,15 @@ int build_direct_piece(const Segment* s, uint32_t b0, uint32_t nbl, HashRange hr
     if (h_flags[0] || h_flags[1] || (X >> pad) >= 0x7FFFFFF0ull || Dp >= 0xFFFFFFF0ull) return FPX_E_INVAL;      // does not qualify
     FPX_HIP(piece_alloc(&out->primary, &out->own_primary, (Dp + 4) * sizeof(uint32_t)));
     FPX_HIP(piece_alloc(&out->extras, &out->own_extras, (X + 8) * sizeof(uint32_t)));
-    FPX_HIP(dfill(out->primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
-    FPX_HIP(dfill(out->extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
+    FPX_HIP(hipMemsetAsync(out->primary, 0xFF, (Dp + 4) * sizeof(uint32_t), st));        // every word a gap until k_direct_fill says otherwise
+    FPX_HIP(hipMemsetAsync(out->extras + X, 0, 8 * sizeof(uint32_t), st));               // (list heads are read four words at a time)
     // (at most n / DIRECT_LONG lists are that long; a queue that cannot be had -- memory -- leaves the copies to k_direct_fill's threads)
     const uint32_t long_cap = (uint32_t)std::min<uint64_t>(n / DIRECT_LONG + 16, 1u << 22);
     DevBuf longq;
     DirectLong* d_longq = longq.alloc((size_t)long_cap * sizeof(DirectLong) + 16) == FPX_OK ? longq.as<DirectLong>() : nullptr;
     unsigned int* d_long_n = d_longq ? reinterpret_cast<unsigned int*>(d_longq + long_cap) : nullptr;
     (void)hipGetLastError();
-    if (d_long_n) FPX_HIP(dfill(d_long_n, 0, sizeof(unsigned int), st));
+    if (d_long_n) FPX_HIP(hipMemsetAsync(d_long_n, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k_direct_fill, dim3((nbl + 255) / 256), dim3(256), 0, st, items.as<uint64_t>(), n, boff.as<uint64_t>(), nbl,
                        s->min_doc_id, (const uint32_t*)out->drec, xbase.as<uint64_t>(), out->primary, out->extras, pad, hr,
                        d_longq, d_long_n, d_longq ? long_cap : 0u);

@@ -553,7 +553,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     if (!g->d_lines) e = dmalloc(&g->d_lines, g->lines_alloc_bytes);
     if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
     g->device_bytes = nlines * line_words * 4ull + 64;
-    FPX_HIP(dfill(reinterpret_cast<uint8_t*>(g->d_lines) + nlines * line_words * 4ull, 0, 64, 0));
+    FPX_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(g->d_lines) + nlines * line_words * 4ull, 0, 64, 0));
     // which blocks of the members still in blocks hold each chunk's hashes
     std::vector<std::vector<uint32_t>> ranges(k);
     {
@@ -577,7 +577,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         (rc = offX.alloc((size_t)CHUNK_LINES * 8)) || (rc = tot.alloc(16)) || (rc = longq.alloc((size_t)LONG_CAP * sizeof(LongCopy))) || (rc = ctr.alloc(64)))
         return rc;
     hipStream_t st = 0;
-    FPX_HIP(dfill(ctr.p, 0, 64, st));
+    FPX_HIP(hipMemsetAsync(ctr.p, 0, 64, st));
     struct Pieces {                                 // this chunk's pieces of the members still in blocks
         DirectPiece pc[FUSE_MAX];
         ~Pieces() { for (DirectPiece& p : pc) p.release(); }
@@ -620,8 +620,8 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
             uint32_t* ext = g->chunk_alloc((h_x + 8) * 4ull);
             if (!ext) { set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
             g->ext_chunks.push_back(ext);
-            FPX_HIP(dfill(ext + h_x, 0, 8 * 4, st));                        // (a list's head is read four words at a time)
-            FPX_HIP(dfill(ctr.p, 0, 8, st));
+            FPX_HIP(hipMemsetAsync(ext + h_x, 0, 8 * 4, st));                        // (a list's head is read four words at a time)
+            FPX_HIP(hipMemsetAsync(ctr.p, 0, 8, st));
             uint32_t* lines = g->d_lines + (size_t)ci * CHUNK_LINES * GROUP_LINE_WORDS;
             if (ns == 8u) hipLaunchKernelGGL(k_pgroup_fill<8>, grid, dim3(256), 0, st, a, (const uint32_t*)W.as<uint32_t>(), (const uint64_t*)offX.as<uint64_t>(), lines, ext,
                                              longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());
@@ -648,9 +648,9 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         if (!words || !lists) { set_error("out of HBM while building a group"); return FPX_E_NOMEM; }
         g->word_chunks.push_back(words);
         g->list_chunks.push_back(lists);
-        FPX_HIP(dfill(words + h_tot[0], 0, 16 * 4, st));                 // (a hash's words are read four at a time)
-        FPX_HIP(dfill(lists + h_tot[1], 0, 8 * 4, st));
-        FPX_HIP(dfill(ctr.p, 0, 8, st));
+        FPX_HIP(hipMemsetAsync(words + h_tot[0], 0, 16 * 4, st));                 // (a hash's words are read four at a time)
+        FPX_HIP(hipMemsetAsync(lists + h_tot[1], 0, 8 * 4, st));
+        FPX_HIP(hipMemsetAsync(ctr.p, 0, 8, st));
         uint32_t* lines = g->d_lines + (size_t)ci * CHUNK_LINES * (2u * ns);
         if (ns == 8u) hipLaunchKernelGGL(k_group_fill<8>, grid, dim3(256), 0, st, a, offW.as<uint64_t>(), offX.as<uint64_t>(), lines, words, lists,
                                          longq.as<LongCopy>(), LONG_CAP, ctr.as<unsigned long long>());

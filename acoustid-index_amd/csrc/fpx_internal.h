@@ -374,12 +374,6 @@ size_t line_pool_flush(int device);                          // frees the cached
 size_t line_pool_bytes(int device);
 hipError_t dmalloc_raw(void** p, size_t bytes);              // hipMalloc on the current device; out of memory: line_pool_flush + once more
 template <class T> inline hipError_t dmalloc(T** p, size_t bytes) { return dmalloc_raw(reinterpret_cast<void**>(p), bytes); }
-// a memset of the group builder: hipMemsetAsync -- or (FPX_BUILD_FILLK=1, the A/B of a suspicion) a kernel of our own on the same stream
-hipError_t dfill(void* p, int value, size_t bytes, hipStream_t st);
-// FPX_BUILD_SYNC=1: the arenas' rewinds wait for the whole device (what the fourteen hipFree calls per piece did before the arenas)
-void arena_sync_point();
-// FPX_ARENA_FILL=<byte>: a rewound arena is filled with that byte (0: what fresh allocations held; 0xCD: what they must not depend on)
-void arena_fill_point(void* base, size_t bytes);
 hipError_t mem_info(size_t* free_b, size_t* total_b);        // hipMemGetInfo, the current device's cached buffer counted as free
 // A group is built from 64 chunks x up to 16 members' pieces, and every piece used to take fourteen allocations of its own (and give
 // them back: the runtime unmaps -- and the driver wipes -- what is freed): 14 000 hipMalloc / hipFree pairs for the 100 M index, 8 000 for
@@ -407,7 +401,6 @@ struct DevArena {
     }
     void rewind()                                  // (nothing that uses the arena's memory is under way: the caller has waited)
     {
-        arena_sync_point();
         check_guards();
         if (missed) {
             const size_t want = (used + missed) * 5 / 4 + ((size_t)1 << 20);
@@ -416,7 +409,6 @@ struct DevArena {
             if (dmalloc(&base, want) == hipSuccess) cap = want; else { (void)hipGetLastError(); base = nullptr; }
         }
         used = 0; missed = 0;
-        arena_fill_point(base, cap);
     }
 };
 // Two of them while a group is built: a chunk's OUTPUTS (the members' pieces: alive until the chunk's lines are filled) and a piece's

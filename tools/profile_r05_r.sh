@@ -1,6 +1,7 @@
 #!/bin/bash
 # (i) which allocation's fresh contents matter: tools/poison_bisect.py over the zipf parity test;
 # (ii) the arenas' flake under four processes at a time: a rewound arena filled with 0xCD / with zeros, 4 KB guards behind every allocation
+# (FPX_ARENA_FILL existed for this run only -- commit 31de873)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05r
 rm -rf $O; mkdir -p $O

@@ -1,6 +1,7 @@
 #!/bin/bash
 # the arenas' flake, the suspect named by tools/profile_r05_r.sh's runs (part sums of the long prefix scans out of the runtime's
 # stream-ordered pool): four processes at a time, 160 runs with the pool (FPX_SCAN_POOLED=1: the library as it was), 240 without (as it is)
+# (FPX_SCAN_POOLED existed for this run only -- commit 31de873; the library no longer has the pooled path)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05s
 rm -rf $O; mkdir -p $O

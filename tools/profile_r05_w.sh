@@ -1,6 +1,7 @@
 #!/bin/bash
 # k_score_bin: the filter's size (score_filter_log2: LDS per workgroup) x the compiler's register budget (FPX_SB_WAVES=8: four workgroups
 # per CU) x records per thread and tile (FPX_SB_RPT) -- tools/options_ab.py on the headline index, one library after the other
+# (the option score_filter_log2 and the FPX_SB_* macros existed for this run only: nothing won -- profiles/r05_ab_score_bin_occupancy.txt)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05w
 rm -rf $O; mkdir -p $O

@@ -16,6 +16,9 @@ variant runs in a process of its own):
 * FPX_INLINE_DOUBLES=0   ... with every hash of several docs behind a list reference (no inline doubles)
 * FPX_REC32=0            ... with 8-byte records in the bins (by default 4-byte ones where the doc ids leave room), bins of eight
                          queries whatever the batch, the keys of every batch ordered by our counting sort (FPX_ORDER_MIN_PAIRS=0)
+* FPX_POISON=1           ... with every fresh device allocation of the library filled with 0xCD before it is handed out (csrc/fpx_api.hip:
+                         dmalloc_raw): nothing may depend on what fresh device memory happens to hold -- usually zeros, which is how such a
+                         dependence hides (tools/poison_bisect.py narrows a failure down to one allocation)
 * FPX_DIRECT=0           no segment direct-addressed: segments of >= 2^20 items (direct-addressed by default) are searched in
                          their blocks by the lean kernel (tests/test_gpu_fullsize.py compares the two forms at full size)
 """
@@ -49,7 +52,8 @@ VARIANTS = [{"FPX_DIRECT": "0"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_GROUP_PACKED": "1"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_BINNED": "0"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"},
-            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_BIN_Q_LOG2": "3", "FPX_ORDER_MIN_PAIRS": "0"}]
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_BIN_Q_LOG2": "3", "FPX_ORDER_MIN_PAIRS": "0"},
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_POISON": "1"}]
 
 
 def _name(env):
@@ -61,6 +65,8 @@ def _suites(env):
         # the sub-variants of the grouped form: the suites that reach the switched code
         if "FPX_BINNED" in env or "FPX_FAST" in env:
             return ["tests/test_gpu_parity.py", "tests/test_gpu_direct.py"]
+        if "FPX_POISON" in env:         # (the builders, the group's arenas, the searches' workspaces, merges and downloads)
+            return ["tests/test_gpu_parity.py", "tests/test_gpu_direct.py", "tests/test_gpu_merge.py"]
         if "FPX_INLINE_DOUBLES" in env:
             return ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py"]
         if "FPX_REC32" in env:

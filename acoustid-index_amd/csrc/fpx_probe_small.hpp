@@ -88,30 +88,85 @@ __global__ void k_memtab_buckets(const uint64_t* __restrict__ tab, uint64_t n, u
 }
 // (blockIdx.y: the key slot -- a rank of a hash-sharded index looks up the keys every source sent it, `slot_stride` keys apart, slot
 // s filled to P_dev[s]; one slot of P keys otherwise)
+// (MEMTAB_KPT keys per thread, a workgroup's keys WG apart: the keys' loads, then the bit words' loads, go out together -- one key per
+// thread was a chain of two load latencies per wave, 62 us for the 8 M keys of a headline batch)
+constexpr uint32_t MEMTAB_KPT = 4;
+inline uint32_t memtab_grid(uint64_t P) { return (uint32_t)((P + (uint64_t)WG * MEMTAB_KPT - 1) / ((uint64_t)WG * MEMTAB_KPT)); }
 __global__ __launch_bounds__(WG) void k_probe_memtab(const uint64_t* __restrict__ tab, const uint32_t* __restrict__ bucket, const uint64_t* __restrict__ pairs,
                                                       uint64_t P, uint32_t qb, uint32_t key_skip, uint64_t* hits, uint64_t hit_cap, unsigned long long* counters,
                                                       const unsigned long long* __restrict__ P_dev = nullptr, uint64_t slot_stride = 0,
                                                       const uint32_t* __restrict__ bits = nullptr)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    const uint64_t p0 = (uint64_t)blockIdx.x * WG * MEMTAB_KPT + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     pairs += (size_t)blockIdx.y * slot_stride;
     if (P_dev) P = min((uint64_t)P_dev[blockIdx.y], P);
-    if (p >= P) return;
-    const uint64_t key = gload_u64(pairs + p);
-    // dedupSorted (src/Index.zig:489-499): flagged where the keys were made, or found by looking back
-    if ((key_skip & KEY_SKIP_FLAGGED) ? (key >> 63) != 0ull : is_duplicate_pair(pairs, p, key, qb, key_skip)) return;
     const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
-    const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
-    if (bits) { const uint32_t c = h >> MEMTAB_FILTER_SHIFT; if (((gload_u32(bits + (c >> 5)) >> (c & 31u)) & 1u) == 0u) return; }
-    const uint32_t b = h >> (32u - MEMTAB_BITS);
-    const uint32_t lo = gload_u32(bucket + b), hi = gload_u32(bucket + b + 1u);
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint64_t it = gload_u64(tab + i);
-        const uint32_t ih = (uint32_t)(it >> 32);
-        if (ih > h) break;
-        if (ih != h) continue;
-        const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
-        if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | (uint32_t)it;
+    uint64_t key[MEMTAB_KPT];
+    bool act[MEMTAB_KPT];
+#pragma unroll
+    for (uint32_t k = 0; k < MEMTAB_KPT; ++k) {
+        const uint64_t p = p0 + (uint64_t)k * WG;
+        act[k] = p < P;
+        key[k] = act[k] ? gload_u64(pairs + p) : 0ull;
+    }
+    // dedupSorted (src/Index.zig:489-499): flagged where the keys were made, or found by looking back
+#pragma unroll
+    for (uint32_t k = 0; k < MEMTAB_KPT; ++k)
+        if (act[k] && ((key_skip & KEY_SKIP_FLAGGED) ? (key[k] >> 63) != 0ull : is_duplicate_pair(pairs, p0 + (uint64_t)k * WG, key[k], qb, key_skip))) act[k] = false;
+    if (bits) {
+        uint32_t bw[MEMTAB_KPT];
+#pragma unroll
+        for (uint32_t k = 0; k < MEMTAB_KPT; ++k) bw[k] = act[k] ? gload_u32(bits + (((uint32_t)(key[k] >> qb) >> MEMTAB_FILTER_SHIFT) >> 5)) : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < MEMTAB_KPT; ++k) act[k] = act[k] && ((bw[k] >> (((uint32_t)(key[k] >> qb) >> MEMTAB_FILTER_SHIFT) & 31u)) & 1u) != 0u;
+    }
+    // the run of each key's hash in the table: the keys' bucket bounds go out together, then the buckets' first two entries (a bucket
+    // holds 1.5 postings of a live index's 1.6 M on average) -- four keys one after the other were four chains of dependent loads per wave
+    uint32_t start[MEMTAB_KPT], cnt[MEMTAB_KPT], blo[MEMTAB_KPT], bhi[MEMTAB_KPT], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < MEMTAB_KPT; ++k) {
+        const uint32_t b = (uint32_t)(key[k] >> qb) >> (32u - MEMTAB_BITS);
+        blo[k] = act[k] ? gload_u32(bucket + b) : 0u;
+        bhi[k] = act[k] ? gload_u32(bucket + b + 1u) : 0u;
+    }
+    uint64_t e0[MEMTAB_KPT], e1[MEMTAB_KPT];
+#pragma unroll
+    for (uint32_t k = 0; k < MEMTAB_KPT; ++k) {
+        e0[k] = blo[k] < bhi[k] ? gload_u64(tab + blo[k]) : ~0ull;
+        e1[k] = blo[k] + 1u < bhi[k] ? gload_u64(tab + blo[k] + 1u) : ~0ull;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < MEMTAB_KPT; ++k) {
+        start[k] = 0u; cnt[k] = 0u;
+        if (blo[k] >= bhi[k]) continue;
+        const uint32_t h = (uint32_t)(key[k] >> qb);
+        uint32_t i = blo[k];
+        const uint32_t hi = bhi[k];
+        // (entries 0 and 1 from registers, the rest of a longer bucket from memory)
+        auto hash_at = [&](uint32_t j) -> uint32_t { return j == blo[k] ? (uint32_t)(e0[k] >> 32) : j == blo[k] + 1u ? (uint32_t)(e1[k] >> 32) : (uint32_t)(gload_u64(tab + j) >> 32); };
+        while (i < hi && hash_at(i) < h) ++i;
+        start[k] = i;
+        while (i < hi && hash_at(i) == h) ++i;
+        cnt[k] = i - start[k];
+        mine += cnt[k];
+    }
+    // ... and ONE reservation per wave for all its hits: the batch's hit counter is one address, which the memory system serves an add
+    // per clock -- the 134 000 hits of a live-index batch, each with an add of its own, were the kernel's 60 us
+    if (__ballot((int)(mine != 0u)) == 0ull) return;
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    const uint32_t total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 0u) base = atomicAdd(&counters[CTR_HITS], (unsigned long long)total);
+    base = __shfl(base, 0, 64);
+    unsigned long long g = base + (incl - mine);
+#pragma unroll
+    for (uint32_t k = 0; k < MEMTAB_KPT; ++k) {
+        const uint32_t q = (uint32_t)key[k] & qmask;
+        for (uint32_t t = 0; t < cnt[k]; ++t, ++g)
+            if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | (uint32_t)gload_u64(tab + start[k] + t);
     }
 }
 

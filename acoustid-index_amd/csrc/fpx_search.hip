@@ -812,7 +812,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             probe_launches += 1;
         }
         if (P && snap->n_mem && snap->d_memtab) {
-            hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((P + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
+            hipLaunchKernelGGL(k_probe_memtab, dim3(memtab_grid(P)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
                                d_pairs, P, qb, flagged ? KEY_SKIP_FLAGGED : key_skip, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters,
                                (const unsigned long long*)nullptr, 0ull, (const uint32_t*)snap->d_membits);
             FPX_HIP(hipGetLastError());
@@ -1730,7 +1730,7 @@ int shard_probe_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint3
             }
             // the memory segments' table: the window's keys looked up there too, the records into the misc buffer (k_bin bins them)
             if (snap->n_mem && snap->d_memtab)
-                hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((P + WG - 1) / WG)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
+                hipLaunchKernelGGL(k_probe_memtab, dim3(memtab_grid(P)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
                                    (const uint64_t*)ws->d_keys[kcur], P, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, (const unsigned long long*)d_P, 0ull, (const uint32_t*)snap->d_membits);
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             // what the kernel could not place itself (a clash of two bins on one slot of a round, a full stage): k_bin
@@ -1924,7 +1924,7 @@ int shard_probe_keys_impl(Snapshot* snap, const uint64_t* d_keys_recv, uint64_t 
             }
             // the memory segments' table (replicated on every rank: a rank only receives the keys of its window)
             if (snap->n_mem && snap->d_memtab)
-                hipLaunchKernelGGL(k_probe_memtab, dim3((uint32_t)((key_cap + WG - 1) / WG), world), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
+                hipLaunchKernelGGL(k_probe_memtab, dim3(memtab_grid(key_cap), world), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
                                    d_keys_recv, key_cap, qbits, KEY_SKIP_FLAGGED, ws->d_hits[1], (uint64_t)ws->cap_hits, ws->d_counters, d_key_counts, key_cap, (const uint32_t*)snap->d_membits);
             FPX_HIP(hipEventRecord(ws->ev_probe1, st));
             BinArgs hb{};

@@ -451,6 +451,38 @@ def pmc_child_main(args):
                       "probe_kernel_ms": agg.v["probe_kernel_ms"] / max(1, agg.v["probe_launches"])}), flush=True)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <a free one> bench.py <the same arguments>` -- one rank per GPU, rank 0
+    prints the JSON line.  (A driver that starts the ranks itself sets WORLD_SIZE and never comes here.)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher (WORLD_SIZE unset): " + " ".join(cmd), file=sys.stderr, flush=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def launch_check(rank, world):
+    """FPX_BENCH_LAUNCH_CHECK=1: the ranks meet (gloo, no GPU needed), all-reduce their numbers, rank 0 prints one line -- what the
+    CPU test of the self-launch looks at (tests/test_dist_gloo.py)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "sum_of_ranks_plus_one": t.item(),
+                          "launcher": os.environ.get("TORCHELASTIC_RUN_ID") is not None}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.pmc_child:
@@ -458,9 +490,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)                 # `python bench.py --gpus N` on its own: the ranks are started here
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} under a launcher of WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("FPX_BENCH_LAUNCH_CHECK") == "1":
+        return launch_check(rank, world)
 
     import torch                                   # first: one HIP runtime for torch and libfpx
     import torch.distributed as dist

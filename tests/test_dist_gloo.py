@@ -14,6 +14,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket()
@@ -385,3 +387,29 @@ def test_routed_keys_protocol_world_size_2():
     mp.spawn(_routed_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     r = dict(ret)
     assert r[0][0] and r[1][0] and r[0][1] + r[1][1] == 19
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` -- no torchrun on the command line, no WORLD_SIZE in the environment (how a driver that runs
+    `--gpus 8` the way it runs `--gpus 1` calls it): bench.py re-executes itself under torch.distributed.run, the two ranks
+    meet, rank 0 prints ONE JSON line with n_gpus = 2 as the last line of stdout, exit status 0.  FPX_BENCH_LAUNCH_CHECK=1 stops
+    the ranks after the rendezvous (gloo): the search itself needs a GPU (tests/test_gpu_two_ranks.py runs it for real)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FPX_BENCH_LAUNCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    assert "no launcher" in r.stderr and "torch.distributed.run" in r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "sum_of_ranks_plus_one": 3.0, "launcher": True}
+
+
+def test_bench_refuses_a_launcher_of_another_size():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr

@@ -343,6 +343,7 @@ static const OptInfo OPT_TABLE[OPT_COUNT] = {
     /* OPT_KEY_ORDER_BITS */     {"key_order_bits", "FPX_KEY_ORDER_BITS", 8, 0, true},          // top hash bits the flagged keys of a large batch are ordered by
     /* OPT_LINE_POOL_SLACK */    {"line_pool_slack", "FPX_LINE_POOL_SLACK", 0, 0, false},       // per cent a kept line buffer may be larger than the group that takes it
     /* OPT_HOT_REFS */           {"hot_refs", "FPX_HOT_REFS", -1, -1, true},                     // 1 | 0 | -1: hot lists reach the score kernel by reference | are copied | by the last batch's records
+    /* OPT_QUERY_WG */           {"query_wg", "FPX_QUERY_WG", 1, 0, false},                      // 1 | 0: a snapshot that is ONE packed group is searched a query per workgroup (fpx_qsearch.hpp) | by the keys - probe - bins - score pipeline
 };
 
 int64_t ctx_opt(const Ctx* c, CtxOpt o)

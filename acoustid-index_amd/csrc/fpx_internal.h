@@ -250,6 +250,7 @@ struct Snapshot {
     std::vector<GroupDesc> h_group; uint32_t n_group = 0;
     uint32_t max_doc_declared = 0;       // the largest doc id the segments' headers declare (sizes the bins' records, fpx_partition.hpp)
     uint32_t rec32_refused = 0;          // a posting exceeded it: this snapshot's bins hold wide records from then on
+    uint32_t qs_skip = 0;                // batches that stay off the one-workgroup-per-query path (fpx_qsearch.hpp) after a query's records outgrew its LDS array
     std::vector<std::shared_ptr<DirectStore>> solo_stores;       // the arrays d_solo points into
     SegDesc* d_solo = nullptr; uint32_t n_solo = 0;
     uint32_t max_small_blocks = 0;
@@ -336,6 +337,7 @@ enum CtxOpt : int {
     OPT_KEY_ORDER_BITS,
     OPT_LINE_POOL_SLACK,
     OPT_HOT_REFS,
+    OPT_QUERY_WG,
     OPT_COUNT
 };
 constexpr int64_t OPT_UNSET = -2;

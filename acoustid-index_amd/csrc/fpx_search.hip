@@ -46,6 +46,7 @@
 #include "fpx_probe_small.hpp"
 #include "fpx_score.hpp"
 #include "fpx_score_bin.hpp"
+#include "fpx_qsearch.hpp"
 
 namespace fpx {
 
@@ -180,6 +181,7 @@ static void launch_probe_group(bool packed, bool ns8, bool binned, bool qs, dim3
 }
 
 constexpr int FPX_SPLIT = 1;   // internal: candidate key does not fit 64 bits, split the batch
+constexpr int FPX_REDO_QS = 3; // internal: the one-workgroup-per-query path gave up (a query's records outgrew its LDS array, scores too wide): the pipeline
 constexpr int FPX_REDO = 2;    // internal: the device-sized path met something only the general path handles (a full bin, ...)
 
 static unsigned bits_for(uint64_t n)   // number of bits needed to represent values in [0, n)
@@ -413,7 +415,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                      const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                      const fpx_opts* opts, uint32_t timeout_ms, bool partial,
                      fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, const Exchange* ex = nullptr,
-                     bool no_fast = false, double t_call = 0.0, uint64_t* q_blocks = nullptr, uint64_t* q_docs = nullptr)
+                     bool no_fast = false, double t_call = 0.0, uint64_t* q_blocks = nullptr, uint64_t* q_docs = nullptr, bool no_qs = false)
 {
     const bool probe_only = ex && ex->mode == 1, score_only = ex && ex->mode == 2;
     // the deadline counts from the API call's entry (one deadline per search, src/MultiIndex.zig:314-322), however often the
@@ -504,6 +506,26 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     const size_t def_words = def_stat_off + LEAN_STAT_WORDS;
     // (every memset is a 5-us launch of its own: the batch's zeroing rides in kernels that run anyway where it can)
 
+    // ---- ONE WORKGROUP PER QUERY (fpx_qsearch.hpp): the snapshot is one packed group and nothing else, every column of it searched, no
+    //      superseded docs -- the resident index between merges --, the queries short enough for their hash set and their floor above the
+    //      legacy protocol's: dedup, probe, count and floor happen in ONE kernel, no keys are made or ordered, no record reaches HBM.
+    //      Anything else, and a batch that kernel hands back (hot hashes: a query's records outgrow its LDS array), runs the pipeline below.
+    bool qs_path = false;
+    if (!ex && !no_fast && !no_qs && !single_fast && B >= 2u && P != 0 && qb <= 24u && snap->n_file == 0 && snap->n_solo == 0 && snap->n_group == 1 &&
+        snap->n_direct != 0 && (snap->n_mem == 0 || snap->mem_items == 0) && snap->groups[0]->packed && ctx_opt(snap->ctx, OPT_QUERY_WG) != 0) {
+        const GroupDesc& gd = snap->h_group[0];
+        qs_path = gd.any_dead == 0u && gd.active == (gd.nseg >= 32u ? 0xFFFFFFFFu : ((1u << gd.nseg) - 1u));
+        for (uint32_t q = 0; q < B && qs_path; ++q) {
+            const uint64_t raw_len = offsets[q + 1] - offsets[q];
+            qs_path = raw_len <= QS_MAX_HASHES && (opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20)) > 2u;
+        }
+        if (qs_path) {
+            // (after a batch that was handed back: the next ones do not try again at once -- hot-hash traffic comes in runs)
+            uint32_t skip = __atomic_load_n(&snap->qs_skip, __ATOMIC_RELAXED);
+            if (skip != 0u) { __atomic_store_n(&snap->qs_skip, skip - 1u, __ATOMIC_RELAXED); qs_path = false; }
+        }
+    }
+
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
     // (every kernel of the batch must look back over the same bucket width: the coarser order only where the direct-addressed
@@ -518,14 +540,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     const uint32_t key_skip = flagged ? 32u - (uint32_t)std::min<int64_t>(8, std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_KEY_ORDER_BITS))) : KEY_SORT_SKIP;
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
     const uint64_t local_sort_max = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_LOCAL_SORT_MAX));
-    bool local_sort = P && !score_only && !single_fast && !flagged && B >= 2u && P <= local_sort_max && snap->n_small == 0;
+    bool local_sort = P && !score_only && !single_fast && !flagged && !qs_path && B >= 2u && P <= local_sort_max && snap->n_small == 0;
     if (local_sort)
         for (uint32_t q = 0; q < B && local_sort; ++q) local_sort = offsets[q + 1] - offsets[q] <= QSORT_MAX;
     if (local_sort) {
         hipLaunchKernelGGL(k_make_keys_sorted, dim3(B), dim3(256), 0, st, d_hashes_base, d_offsets, B, qb, base, ws->d_keys[0],
                            (snap->n_lean || snap->n_direct) ? ws->d_def_count : nullptr, (uint32_t)def_words);
         FPX_HIP(hipGetLastError());
-    } else if (P && !score_only) {
+    } else if (P && !score_only && !qs_path) {
         // flagged keys are brought into (hash bucket, query) order by our own counting sort, whose counts k_make_keys_dedup takes
         // on its way (fpx_keyorder.hpp); tiny batches stay in query order (the three launches cost what the order buys)
         const uint64_t order_min = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_ORDER_MIN_PAIRS));
@@ -577,6 +599,95 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         return FPX_OK;
     };
+    if (qs_path) {
+        const GroupDesc& gd = snap->h_group[0];
+        const Group* grp = snap->groups[0].get();
+        if ((rc = grow(&ws->d_qcand, &ws->cap_qcand, (size_t)B * QCAND_SLOTS + 2 * ((size_t)B / 2 + 1)))) return rc;
+        uint64_t* d_qcand = ws->d_qcand;
+        uint32_t* d_qcand_n = reinterpret_cast<uint32_t*>(ws->d_qcand + (size_t)B * QCAND_SLOTS);
+        const size_t cand_guess0 = std::max<size_t>(1u << 16, (size_t)B * 64);
+        if (ws->cap_cands < cand_guess0 && (rc = grow_pair(ws->d_cands, &ws->cap_cands, cand_guess0))) return rc;
+        const uint32_t sbf = 32u - qb;
+        hipLaunchKernelGGL(k_qs_zero, dim3(8), dim3(256), 0, st, ws->d_counters, ws->d_def_count, (uint32_t)def_words);
+        FPX_HIP(hipEventRecord(ws->ev_probe0, st));
+        QSearchArgs qa{};
+        qa.hashes_base = d_hashes_base; qa.offsets = d_offsets; qa.opts = d_opts; qa.B = B; qa.sb = sbf;
+        qa.cands = ws->d_cands[0]; qa.cand_cap = ws->cap_cands; qa.qcand = d_qcand; qa.qcand_n = d_qcand_n;
+        qa.counters = ws->d_counters; qa.stat_sets = reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off);
+        qa.qstats = want_q ? ws->d_qstats : nullptr; qa.cancel = cancel;
+        const GroupArgs gargs{gd, snap->d_direct};
+        if (grp->ns == 8u) {
+            if (want_q) hipLaunchKernelGGL((k_search_query<8, true>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            else hipLaunchKernelGGL((k_search_query<8, false>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+        } else {
+            if (want_q) hipLaunchKernelGGL((k_search_query<16, true>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            else hipLaunchKernelGGL((k_search_query<16, false>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+        }
+        FPX_HIP(hipGetLastError());
+        FPX_HIP(hipEventRecord(ws->ev_probe1, st));
+        fpx_result* d_res = partial ? out : ws->d_out;
+        uint32_t* d_res_n = partial ? out_n : ws->d_out_n;
+        bool staged = false;
+        if (!partial && (rc = staged_targets(ws, snap->ctx, B, out_cap, &staged, &d_res_n, &d_res))) return rc;
+        hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
+                           (const uint64_t*)ws->d_cands[0], (uint64_t)0, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
+                           (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
+        {
+            PublishArgs pa{};
+            pa.counters = ws->d_counters; pa.h_counters = mapped_address(ws->h_counters);
+            pa.a_src = ws->d_def_count; pa.a_dst = mapped_address(ws->h_def_count); pa.a_n = (uint32_t)def_words;
+            if (!pa.h_counters || !pa.a_dst) { set_error("page-locked host memory is not mapped into the device"); return FPX_E_DEVICE; }
+            hipLaunchKernelGGL(k_publish, dim3(4), dim3(256), 0, st, pa);
+            FPX_HIP(hipGetLastError());
+        }
+        FPX_HIP(hipEventRecord(ws->ev_end, st));
+        FPX_SYNC(ws);
+        if (ws->h_counters[CTR_BINFAIL] != 0 || ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands) {
+            if (ws->h_counters[CTR_BINFAIL] != 0) __atomic_store_n(&snap->qs_skip, 32u, __ATOMIC_RELAXED);
+            return FPX_REDO_QS;
+        }
+        uint64_t Cf = 0;
+        int ccur2 = 0;
+        if (ws->h_counters[CTR_CANDS] != 0) {
+            // some queries have more candidates than slots: sort the shared list and finish again (second round trip)
+            Cf = ws->h_counters[CTR_CANDS];
+            const size_t tb2 = sort_u64_temp_bytes(Cf, 0, 64);
+            if ((rc = grow(reinterpret_cast<uint8_t**>(&ws->d_temp), &ws->cap_temp, tb2 + 256))) return rc;
+            FPX_HIP(sort_u64(ws->d_temp, ws->cap_temp, ws->d_cands[0], ws->d_cands[1], Cf, 0, 64, st, &ccur2));
+            if (stats) FPX_HIP(hipMemsetAsync(&ws->d_counters[CTR_SLOTCANDS], 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_finish, dim3((B + 127) / 128), dim3(128), 0, st,
+                               (const uint64_t*)ws->d_cands[ccur2], Cf, d_opts, B, sbf, partial ? 1 : 0, d_res, out_cap, d_res_n,
+                               (const uint64_t*)d_qcand, (const uint32_t*)d_qcand_n, stats ? ws->d_counters : nullptr);
+            FPX_HIP(hipGetLastError());
+            FPX_HIP(hipMemcpyAsync(&ws->h_counters[CTR_SLOTCANDS], &ws->d_counters[CTR_SLOTCANDS], sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            FPX_HIP(hipEventRecord(ws->ev_end, st));
+            FPX_SYNC(ws);
+        }
+        if (!partial && (rc = deliver_results(ws, B, out_cap, staged, out, out_n, st))) return rc;
+        const unsigned long long* ls = reinterpret_cast<const unsigned long long*>(ws->h_def_count + def_stat_off);
+        unsigned long long blocks = 0, docs = 0, probes = 0, dreads = 0, bytes_off = 0, records = 0;
+        for (uint32_t i = 0; i < LEAN_STAT_SETS; ++i) {
+            blocks += ls[i * 8 + 1]; docs += ls[i * 8 + 2]; probes += ls[i * 8 + 3]; dreads += ls[i * 8 + 4];
+            bytes_off += ls[i * 8 + 5]; records += ls[i * 8 + 7];
+        }
+        gather_hist(ws->batch_hist, ws->h_counters, ls, probes);
+        if (stats) {
+            float ms = 0.f, total_ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ws->ev_probe0, ws->ev_probe1);
+            (void)hipEventElapsedTime(&total_ms, ws->ev_begin, ws->ev_end);
+            stats->probes += probes; stats->scanned_blocks += blocks; stats->scanned_docs += docs; stats->hits += records;
+            stats->algorithmic_bytes += blocks * 512ull + bytes_off;
+            stats->candidates += Cf + ws->h_counters[CTR_SLOTCANDS];
+            stats->probe_kernel_ms += ms; stats->total_gpu_ms += total_ms; stats->probe_launches += 1;
+            stats->probe_kernel_bytes += blocks * 512ull + bytes_off;
+            stats->probe_kernel_fetched_bytes += (dreads + 1) / 2 * 128ull;
+            stats->path_flags |= 1u | (Cf ? 2u : 0u) | 4u | 64u;
+        }
+        if ((rc = deliver_qstats())) return rc;
+        ws->hint_P = P; ws->hint_H = std::max<uint64_t>(records, 1);          // (sizes the pipeline's bins should a later batch take it)
+        ws->hint_misc = 0; ws->hint_def = 0;
+        return FPX_OK;
+    }
     // ---- 3+4: probes (rerun with a larger hit buffer on overflow)
     uint64_t H = 0;
     float probe_ms = 0.f, aux_ms = 0.f;
@@ -1309,6 +1420,10 @@ static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
     if (!ws) return FPX_E_NOMEM;
     fpx_stats local{};
     int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, false, t_call, q_blocks, q_docs);
+    if (rc == FPX_REDO_QS) {                    // the one-workgroup-per-query path handed the batch back: the pipeline
+        local = fpx_stats{};
+        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, false, t_call, q_blocks, q_docs, true);
+    }
     if (rc == FPX_REDO) {                       // the device-sized path gave up (after its synchronisation): the general path
         local = fpx_stats{};
         rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, true, t_call, q_blocks, q_docs);

@@ -121,6 +121,10 @@ class StatAgg:
     def fused(self):
         return bool(self.path_flags & 4)
 
+    @property
+    def query_wg(self):
+        return bool(self.path_flags & 64)
+
 
 def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
     """What the dominant kernel has to pull from HBM per launch, modelled from counts the kernel reports.
@@ -146,9 +150,13 @@ def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
     return {"blocks": fetched_per_launch, "probe_records": pr, "pairs": pairs, "total": fetched_per_launch + pr + pairs}
 
 
-def dominant_kernel(segs, fused=False):
+def dominant_kernel(segs, fused=False, query_wg=False):
+    """query_wg: the batches ran a query per workgroup (fpx_stats.path_flags bit 6: k_search_query -- dedup, probe, count and floor in
+    one kernel; the posting-decode + histogram kernel of a resident index)"""
     files = [sg for sg in segs if sg.kind == "file"]
     if files and all(getattr(sg, "direct", False) for sg in files):
+        if query_wg:
+            return "k_search_query"
         if not fused:
             return "k_probe_direct"
         gi = next((sg.group_info() for sg in files if getattr(sg, "grouped", False)), None)
@@ -209,7 +217,7 @@ def parse_pmc_dir(d):
             short = n.split("(")[0].split("::")[-1]
             if not short.startswith("k_bw_pattern"):
                 short = short.split("<")[0]
-            if short.startswith("k_probe") or short.startswith("k_bw_"):
+            if short.startswith("k_probe") or short.startswith("k_search") or short.startswith("k_bw_"):
                 key = (int(r["Dispatch_Id"]), short)
                 per.setdefault(key, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
     by = collections.defaultdict(list)
@@ -259,9 +267,9 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
         if p.returncode != 0:
             return None, f"rocprofv3 child exited {p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
         by = parse_pmc_dir(d)
-        main = next((k for k in ("k_probe_pgroup", "k_probe_group", "k_probe_direct") if by and by.get(k)), "k_probe_lean8")
+        main = next((k for k in ("k_search_query", "k_probe_pgroup", "k_probe_group", "k_probe_direct") if by and by.get(k)), "k_probe_lean8")
         if not by or not by.get(main):
-            return None, "no k_probe_pgroup / k_probe_group / k_probe_direct / k_probe_lean8 dispatch in the counter output"
+            return None, "no k_search_query / k_probe_pgroup / k_probe_group / k_probe_direct / k_probe_lean8 dispatch in the counter output"
         child = None
         for line in p.stdout.decode(errors="replace").splitlines():
             if line.startswith('{"pmc_child"'):
@@ -303,7 +311,7 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
 
 def stored_traffic(docs, S, H, B, qlen):
     """fallback: the committed PMC pass, only for the same configuration AND the same kernel sources"""
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = tr["config"]
@@ -311,7 +319,7 @@ def stored_traffic(docs, S, H, B, qlen):
                 continue
             if tr.get("kernel_source_sha16") != kernel_source_hash():
                 continue
-            k = next((k for k in ("k_probe_pgroup", "k_probe_group", "k_probe_direct") if k in tr), "k_probe_lean8")
+            k = next((k for k in ("k_search_query", "k_probe_pgroup", "k_probe_group", "k_probe_direct") if k in tr), "k_probe_lean8")
             return tr[k].get("hbm_bytes_per_launch", tr[k]["hbm_read_bytes_per_launch_corrected"]), f"profiles/{name}@{tr['kernel_source_sha16']}"
         except (OSError, KeyError, ValueError):
             continue
@@ -799,7 +807,7 @@ def main():
                        "index_build_seconds": round(build_s, 2), "shrunk_to_fit": shrunk},
             # achieved / frac: PHYSICAL bytes of the dominant kernel per launch / its HIP-event time / peak.  Filled with the
             # model here and replaced by the in-run PMC figure below when the rocprofv3 child pass succeeds.
-            "roofline": {"bound": "hbm", "kernel": "fpx::" + dominant_kernel(segs, agg.fused), "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fpx::" + dominant_kernel(segs, agg.fused, agg.query_wg), "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": moved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "achieved_basis": "model",
                          "avg_launch_ms": avg_ms, "launches_timed": launches,
@@ -1118,7 +1126,7 @@ def main():
             # on the general path with buffers regrown for 12 x the records (seconds of hipMalloc), the next four stay on the general
             # path, the sixth sizes the device-sized path's buffers: the steady state starts at the seventh)
             dtz, aggz, outz, onz = timed_resident(fpx, reader_z, qb_z, 5, 8)
-            rowz = row_from(B, 5, dtz, aggz, segs_z, "fpx::" + dominant_kernel(segs_z, aggz.fused))
+            rowz = row_from(B, 5, dtz, aggz, segs_z, "fpx::" + dominant_kernel(segs_z, aggz.fused, aggz.query_wg))
             rowz["records_per_batch"] = aggz.v["hits"] / max(1, aggz.steps)
             rowz["index_build_seconds"] = round(build_z, 2)
             rowz["targets_found"] = int(sum(1 for q in range(B) if onz[q] > 0 and outz[q, 0, 0] == tz[q]))

@@ -79,7 +79,8 @@ typedef struct {
                                    exchanges, anything the device-sized path handed back).  bit 2: direct-addressed segments
                                    were probed as a GROUP (k_probe_group), bit 3: ... whose records went straight into bins of a
                                    few queries, scored a bin per workgroup (k_score_bin), bit 4: the batch ran a step of a sharded protocol,
-                                   bit 5: ... and hot hashes' lists reached the score kernel by reference ("hot_refs") */
+                                   bit 5: ... and hot hashes' lists reached the score kernel by reference ("hot_refs"),
+                                   bit 6: the batch was searched a query per workgroup (k_search_query: no keys, no bins) */
     uint64_t probe_kernel_fetched_bytes; /* block bytes the main probe kernel really fetched, in 128-byte lines: a probe
                                    whose hash the segment's presence bits know to be absent counts as a visited block (as in
                                    the reference) without the block being read, and a block that is read costs two lines up
@@ -107,6 +108,9 @@ int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context live
  *   "inline_doubles"     1 | 0   a hash with two docs keeps both in the group's words (default 1)
  *   "memtab"             1 | 0   a snapshot's memory segments behind ONE hash-sorted table (default 1)
  * Search paths -- read per batch:
+ *   "query_wg"           1 | 0   a snapshot that is ONE packed group and nothing else (the resident index between merges) is searched a
+ *                        QUERY PER WORKGROUP -- dedup, probe, count and floor in one kernel, the hit records never leaving the CU
+ *                        (csrc/fpx_qsearch.hpp; default 1) | by the pipeline below like every other snapshot
  *   "fast"               1 | 0   the device-sized path (one host round trip per batch; default 1)
  *   "binned"             1 | 0   groups drop their records into bins of a few queries, scored a bin per workgroup (default 1)
  *   "bin_q_log2"         log2 of the queries per bin (-1: by the batch's size, default)

@@ -1,0 +1,188 @@
+"""k_search_query (csrc/fpx_qsearch.hpp): a snapshot that is ONE packed group is searched a QUERY PER WORKGROUP -- dedupSorted,
+FileSegment.search for every column, SearchResults.incr and the floor of finish in one kernel, the records held in LDS
+(src/Index.zig:170-177,489-499, src/FileSegment.zig:135-180, src/common.zig:121-171).  Through the C ABI, against the oracle:
+results, the reference's scanned blocks / docs per query and in all, the scan histograms (tests/test_scan_histograms.py runs on
+grouped forms too).  The data reaches the kernel's rare paths:
+
+* lists of 2, 3, 4, 5 and 70 docs (heads inline, the rest read by the wave), a hash of 3000 docs in one segment (the reference stops
+  after four blocks / beyond 1000 docs), hashes 0 and 0xFFFFFFFF (the hash set's empty mark), duplicates inside a query,
+  hashes outside the segments' hash ranges and in the gaps before a block's first hash;
+* queries of 1 .. 4096 hashes in one batch; one of 4097 hands the batch to the pipeline, and so does a floor of 1 or 2;
+* many docs above the floor: more candidates than a query's slots (the shared list, the second finish) and more distinct docs in
+  floor-reaching cells than the exact table takes (classes);
+* a query whose records outgrow the LDS array: the batch is redone by the pipeline, bit-exact, and later batches come back;
+* groups of 2, 8 (lines of 8 hash values) and 9, 16 columns (lines of 4)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HOT, SHARED, CROWD = 0x12345678, 0x0BADF00D, 0x51515151
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fpx_testlib import fpx, oracle, Pair
+    ctx = fpx.Context(0)
+    yield fpx, oracle, Pair, ctx
+
+
+def _items(rng, s, per, first_doc, crowd):
+    docs = np.arange(first_doc, first_doc + per, dtype=np.uint64)
+    h = rng.integers(0, 1 << 32, (per, 48), dtype=np.uint64)
+    items = [((h << np.uint64(32)) | docs[:, None]).ravel()]
+
+    def post(hash_, ids):
+        items.append((np.uint64(hash_) << np.uint64(32)) | np.asarray(ids, dtype=np.uint64))
+
+    post(SHARED, docs[: [2, 3, 4, 70, 5, 2][s % 6]])
+    if s == 0:
+        post(0, docs[:2]); post(0xFFFFFFFF, docs[5:8])
+        for k in range(30):                                      # `crowd` docs that share thirty hashes: all of them reach a floor of 25
+            post(CROWD + k * 7919, docs[100:100 + crowd])
+    if s == 1:
+        post(HOT, docs[:3000])
+        post(1, docs[:1]); post(0xFFFFFFFE, docs[:1])
+    return np.unique(np.concatenate(items))
+
+
+def _world(fpx, Pair, ctx, nseg, monkeypatch, per=3200, crowd=250):
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    ctx.set_option("group_packed", 1)
+    try:
+        rng = np.random.default_rng(606 + nseg)
+        p = Pair(ctx)
+        allitems = []
+        for s in range(nseg):
+            first = s * per + 1
+            items = _items(rng, s, per, first, crowd)
+            p.add_file(items, first, first + per - 1, s + 1, np.arange(first, first + per, dtype=np.uint32))
+            allitems.append(items)
+        p.finish()
+    finally:
+        ctx.set_option("group_packed", -2)
+    assert all(g.direct and g.grouped for g in p.gpu_segs), [g.layout_reason() for g in p.gpu_segs]
+    return p, allitems, rng
+
+
+def _query(rng, allitems, i, qlen, special=True):
+    src = allitems[i % len(allitems)]
+    doc = src[rng.integers(0, len(src))] & np.uint64(0xFFFFFFFF)
+    own = (src[(src & np.uint64(0xFFFFFFFF)) == doc] >> np.uint64(32)).astype(np.uint32)[:max(1, qlen // 2)]
+    parts = [own]
+    if special and qlen >= 64:
+        parts.append(np.array([SHARED, 0, 1, 0xFFFFFFFE, 0xFFFFFFFF, SHARED, 0], dtype=np.uint32))              # (with duplicates)
+        parts.append((own[:8].astype(np.int64) + rng.integers(-3, 4, min(8, len(own)))).clip(0, 0xFFFFFFFF).astype(np.uint32))
+    have = sum(len(x) for x in parts)
+    if qlen > have:
+        parts.append(rng.integers(0, 1 << 32, qlen - have, dtype=np.uint64).astype(np.uint32))
+    q = np.concatenate(parts)[:qlen]
+    rng.shuffle(q)
+    return q
+
+
+@pytest.mark.parametrize("nseg", [16, 9, 8, 2])
+def test_one_workgroup_per_query_equals_the_oracle(env, nseg, monkeypatch):
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, nseg, monkeypatch)
+    queries = [_query(rng, allitems, i, 1000) for i in range(48)]
+    queries[3] = np.concatenate([queries[3][:990], np.array([HOT], dtype=np.uint32)])       # the 3000-doc hash: a list of > 1000 docs walked by the wave
+    queries[7] = np.concatenate([queries[7], queries[7][:100]])                              # a tenth of the query twice
+    for opts in (fpx.http_options(), fpx.http_options(limit=3), fpx.SearchOptions(max_results=500, min_score=3, min_score_pct=0),
+                 fpx.SearchOptions(max_results=40, min_score=10, min_score_pct=100)):
+        got, st = p.check(queries, opts)
+        assert st.path_flags & 64, f"the batch did not run k_search_query ({st.path_flags})"
+        assert st.path_flags & 4 and not st.path_flags & 8
+    # (the same through the pipeline: keys, probe, bins, score)
+    ctx.set_option("query_wg", 0)
+    try:
+        got_p, st_p = p.check(queries, fpx.http_options())
+        assert not st_p.path_flags & 64
+    finally:
+        ctx.set_option("query_wg", -1)
+    got_q, st_q = p.reader.search_batch(queries, fpx.http_options())
+    assert got_q == got_p and (st_q.scanned_blocks, st_q.scanned_docs, st_q.probes, st_q.hits) == (st_p.scanned_blocks, st_p.scanned_docs, st_p.probes, st_p.hits)
+
+
+def test_query_lengths_and_who_takes_the_batch(env, monkeypatch):
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, 4, monkeypatch)
+    lens = [1, 2, 7, 63, 64, 255, 256, 257, 300, 1000, 1023, 1024, 1025, 2500, 4095, 4096, 0, 5]
+    queries = [_query(rng, allitems, i, n) if n else np.zeros(0, dtype=np.uint32) for i, n in enumerate(lens)]
+    opts = fpx.SearchOptions(max_results=100, min_score=3, min_score_pct=10)
+    got, st = p.check(queries, opts)
+    assert st.path_flags & 64
+    # default floor (n + 19) / 20: the short queries' floors are 1 and 2 -- the legacy protocol's: the pipeline's count-only round
+    got, st = p.check(queries, fpx.http_options())
+    assert not st.path_flags & 64
+    longer = queries + [_query(rng, allitems, 99, 4097)]
+    got, st = p.check(longer, opts)
+    assert not st.path_flags & 64, "a query of 4097 hashes does not fit the kernel's hash set"
+    # an explicit floor of 2
+    got, st = p.check(queries, fpx.SearchOptions(max_results=100, min_score=2, min_score_pct=10))
+    assert not st.path_flags & 64
+
+
+def test_many_candidates_and_more_docs_than_the_table_takes(env, monkeypatch):
+    """250 docs share thirty hashes: a query of those hashes has 250 docs at score 30 -- more than its four slots (the shared list), more
+    than the 32 of its LDS buffer, more than the exact table's 192 (two classes)."""
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, 3, monkeypatch)
+    crowd = np.array([CROWD + k * 7919 for k in range(30)], dtype=np.uint32)
+    queries = []
+    for i in range(24):
+        noise = rng.integers(0, 1 << 32, 900, dtype=np.uint64).astype(np.uint32)
+        q = np.concatenate([crowd[: 30 if i % 3 == 0 else 26 + i % 4], noise])
+        rng.shuffle(q)
+        queries.append(q)
+    for opts in (fpx.SearchOptions(max_results=500, min_score=25, min_score_pct=0), fpx.SearchOptions(max_results=100, min_score=20, min_score_pct=10),
+                 fpx.SearchOptions(max_results=10, min_score=28, min_score_pct=95)):
+        got, st = p.check(queries, opts)
+        assert st.path_flags & 64
+        assert st.path_flags & 2, "no query overflowed its candidate slots"
+    assert len(got[0]) == 10
+
+
+def test_records_beyond_the_lds_array_go_back_to_the_pipeline(env, monkeypatch):
+    """a query holding twelve hashes of 1000+ docs each: more records than the 8192 its workgroup keeps -- the whole batch is redone by the
+    pipeline (same results, same counters), the next batches stay there, and the path comes back"""
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    ctx.set_option("group_packed", 1)
+    try:
+        rng = np.random.default_rng(99)
+        p = Pair(ctx)
+        per, allitems = 4000, []
+        hots = [0x40000000 + 977 * k for k in range(12)]
+        for s in range(3):
+            first = s * per + 1
+            docs = np.arange(first, first + per, dtype=np.uint64)
+            h = rng.integers(0, 1 << 32, (per, 48), dtype=np.uint64)
+            items = [((h << np.uint64(32)) | docs[:, None]).ravel()]
+            for k in hots[s::3]:
+                items.append((np.uint64(k) << np.uint64(32)) | docs[:1500])
+            items = np.unique(np.concatenate(items))
+            p.add_file(items, first, first + per - 1, s + 1, np.arange(first, first + per, dtype=np.uint32))
+            allitems.append(items)
+        p.finish()
+    finally:
+        ctx.set_option("group_packed", -2)
+    plain = [_query(rng, allitems, i, 1000, special=False) for i in range(16)]
+    got, st = p.check(plain, fpx.http_options())
+    assert st.path_flags & 64
+    heavy = list(plain)
+    heavy[5] = np.concatenate([plain[5][:900], np.array(hots, dtype=np.uint32)])
+    got_h, st_h = p.reader.search_batch(heavy, fpx.http_options())
+    assert not st_h.path_flags & 64, "12 x 1000+ records fit 8192?"
+    for q, g in zip(heavy, got_h):
+        assert g == p.osnap.search(q, 40, None, 10)
+    ctx.set_option("query_wg", 0)
+    try:
+        got_p, st_p = p.reader.search_batch(heavy, fpx.http_options())
+    finally:
+        ctx.set_option("query_wg", -1)
+    assert got_p == got_h and (st_p.scanned_blocks, st_p.scanned_docs, st_p.hits) == (st_h.scanned_blocks, st_h.scanned_docs, st_h.hits)
+    flags = [p.reader.search_batch(plain, fpx.http_options())[1].path_flags & 64 for _ in range(40)]
+    assert flags[0] == 0 and flags[-1] == 64, flags           # (32 batches stay with the pipeline, then the path is tried again)
+    got2, _ = p.check(plain, fpx.http_options())
+    assert got2 == got

@@ -41,9 +41,25 @@ constexpr uint32_t QS_FLOG2 = FPX_QS_FLOG2;        // the filter: 2^11 16-bit ce
 constexpr uint32_t QS_TLOG2 = 8;                   // the exact table: 2^8 slots of doc << 32 | count
 constexpr uint32_t QS_MAX_HASHES = QS_REC_CAP >= 8192u ? 4096u : 2048u;   // longest query taken (its hash set: up to QS_REC_CAP slots, before the records move in)
 constexpr uint32_t QS_MAX_ROUNDS = 32;             // (a lane remembers which of its rounds' hashes are probes in one word)
+#ifndef FPX_QS_WORDS
+#define FPX_QS_WORDS 12
+#endif
+#ifndef FPX_QS_CH
+#define FPX_QS_CH 4
+#endif
+constexpr uint32_t QS_WORDS = FPX_QS_WORDS;                  // words of a hash walked by its lane (four 16-byte pieces of its line); the rare rest by the wave
+constexpr uint32_t QS_CH = FPX_QS_CH;                      // rounds whose line heads are under way together
+constexpr uint32_t QS_TASKS = (((size_t)2u << QS_FLOG2) + ((size_t)8u << QS_TLOG2)) / 8u;      // deferred lists / words of a query (8 bytes each: they live where the filter and the exact table will)
+constexpr uint32_t QS_TASK_WORDS = 8;              // words a deferred "words" task carries at most (a list's task: its header + seven docs)
 static_assert(QS_MAX_HASHES * 2u <= QS_REC_CAP, "the dedup set lives where the records will");
 static_assert((QS_MAX_HASHES + QS_WG - 1u) / QS_WG <= QS_MAX_ROUNDS, "rounds per query");
-constexpr size_t QS_LDS_BYTES = (size_t)QS_REC_CAP * 4u + ((size_t)2u << QS_FLOG2) + ((size_t)8u << QS_TLOG2) + (size_t)SB_CAND * 8u;
+static_assert(QS_WORDS % 4 == 0 && QS_WORDS <= 16, "the words are fetched in 16-byte pieces; a lane's masks of them are 16 bits");
+#ifndef FPX_QS_WGS_PER_CU
+#define FPX_QS_WGS_PER_CU 4
+#endif
+constexpr uint32_t QS_WGS_PER_CU = FPX_QS_WGS_PER_CU;       // workgroups a CU holds (its 160 KB of LDS, 128 registers per lane): the kernel's grid is that many per CU
+// [records + a sink word | filter | exact table (before: the task queue) | candidate buffer]
+constexpr size_t QS_LDS_BYTES = ((size_t)QS_REC_CAP + 4u) * 4u + ((size_t)2u << QS_FLOG2) + ((size_t)8u << QS_TLOG2) + (size_t)SB_CAND * 8u;
 
 struct QSearchArgs {
     const uint32_t* hashes_base; const uint64_t* offsets;      // hashes_base[i]: the hash at ABSOLUTE position i of the batch; offsets[q] absolute
@@ -58,73 +74,164 @@ struct QSearchArgs {
 };
 
 #define FPX_QS_OCC __attribute__((amdgpu_waves_per_eu(FPX_QS_WAVES)))
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ uint3 gload_u3(const uint32_t* p)            // the first three words of a line (16-byte aligned)
+{
+    const u32x3_t v = *(const FPX_GLOBAL u32x3_t*)p;
+    return make_uint3(v.x, v.y, v.z);
+}
+__device__ __forceinline__ uint32_t qs_cell(uint32_t doc) { return (doc ^ (doc >> QS_FLOG2)) & ((1u << QS_FLOG2) - 1u); }
+// a deferred task: the address of a list, or of up to eight words of a hash that its lane did not walk (beyond its own, or overflowed from
+// the line into `ext`) -- bits 0..45: address >> 2, 46..48: words - 1, 49..56: which of them are second words of doubles, 57..62: the
+// hash's chunk (a list reference among the words counts from the chunk's `ext`), 63: a list
+__device__ __forceinline__ unsigned long long qs_task_list(const uint32_t* p, uint32_t chunk)
+{
+    return ((unsigned long long)p >> 2) | ((unsigned long long)chunk << 57) | (1ull << 63);
+}
+__device__ __forceinline__ unsigned long long qs_task_words(const uint32_t* p, uint32_t cnt, uint32_t second, uint32_t chunk)
+{
+    return ((unsigned long long)p >> 2) | ((unsigned long long)(cnt - 1u) << 46) | ((unsigned long long)(second & 0xFFu) << 49) | ((unsigned long long)chunk << 57);
+}
+__device__ __forceinline__ const uint32_t* qs_task_ptr(unsigned long long e) { return reinterpret_cast<const uint32_t*>((e & ((1ull << 46) - 1ull)) << 2); }
+
+// (FPX_QS_PROF: an experiment build -- wave 0 of every workgroup adds the clocks it spent between the kernel's phases to the batch's
+// counters [16 ..], which the host prints; tools/build_variant.sh qs_prof -DFPX_QS_PROF=1)
+#ifdef FPX_QS_PROF
+#define QS_MARK(i) do { if (tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(&a.counters[CTR_HIST + (i)], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define QS_MARK(i) do { } while (0)
+#endif
 template <int NS, bool QS>
 __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a, GroupArgs ga)
 {
+#ifdef FPX_QS_PROF
+    unsigned long long t_prev = clock64();
+#endif
     constexpr uint32_t HVL = NS == 16 ? 2u : 3u;        // log2 of the hash values per line
     constexpr uint32_t T = 1u << QS_TLOG2, TMASK = T - 1u;
     extern __shared__ __align__(16) uint8_t qs_dyn[];
-    uint32_t* const recs = reinterpret_cast<uint32_t*>(qs_dyn);                                         // [QS_REC_CAP] docs; before: the query's hash set
-    uint32_t* const filter = recs + QS_REC_CAP;                                                         // 2^(QS_FLOG2 - 1) words of two cells
+    uint32_t* const recs = reinterpret_cast<uint32_t*>(qs_dyn);                                         // [QS_REC_CAP] docs (+ a sink); before: the query's hash set
+    uint32_t* const filter = recs + QS_REC_CAP + 4u;                                                    // 2^(QS_FLOG2 - 1) words of two cells
     unsigned long long* const table = reinterpret_cast<unsigned long long*>(filter + (1u << (QS_FLOG2 - 1u)));
+    unsigned long long* const tasks = reinterpret_cast<unsigned long long*>(filter);                   // (until the records are complete)
     uint64_t* const cbuf = reinterpret_cast<uint64_t*>(table + T);                                      // [SB_CAND]
-    __shared__ uint32_t s_count, s_over_recs, s_seen_ones, s_cancel, s_claimed, s_full, s_ccnt, s_cshared, s_cbase_lo, s_cbase_hi;
+    __shared__ uint32_t s_count, s_ntask, s_over_recs, s_seen_ones, s_cancel, s_claimed, s_full, s_ccnt, s_cshared, s_cbase_lo, s_cbase_hi;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
     __shared__ uint32_t wg_h[HIST_SLOTS];
     __shared__ uint32_t s_first[FUSE_MAX], s_last[FUSE_MAX];
     __shared__ const uint32_t* s_ext[GROUP_CHUNKS];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, q = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const GroupDesc* g = &ga.g;
-    const uint64_t q_lo = a.offsets[q];
-    const uint32_t n = (uint32_t)(a.offsets[q + 1] - q_lo);
-    const uint32_t rounds = (n + QS_WG - 1u) / QS_WG;
+    // The workgroup STAYS: it takes query blockIdx.x, then every gridDim.x-th one (the host launches as many workgroups as the chip holds
+    // at once).  What a query's start waits for -- its offsets, its hashes, the heads of its first lines: three latencies in a row -- is
+    // asked for while the query before it is still being counted.
+    uint32_t q = blockIdx.x;
+    uint64_t q_lo = a.offsets[q];
+    uint32_t n = (uint32_t)(a.offsets[q + 1] - q_lo);
+    const uint32_t* qh = a.hashes_base + q_lo;
+    if (tid < FUSE_MAX) { s_first[tid] = g->first_hash[tid]; s_last[tid] = g->last_hash[tid]; }
+    if (tid < GROUP_CHUNKS) s_ext[tid] = tid < g->nchunks ? g->ext_tab[tid] : nullptr;
+    // ---- the first QS_CH rounds' hashes and the heads of their lines (position bits, double flags) set out at once: a round is a chain
+    //      of latencies -- hash, line head (HBM), words, ... -- and a CU holds sixteen waves to overlap them; what does not depend on the
+    //      round before it is asked for up front.  (A duplicate's line is fetched for nothing: dedup runs while the heads travel.)
+    uint32_t hh[QS_CH];
+    uint3 hd[QS_CH];
+    auto line_of = [&](uint32_t h) -> const uint32_t* { return g->lines + (size_t)((h >> HVL) - g->line0) * GROUP_LINE_WORDS; };
+    auto load_hashes = [&](uint32_t c) {
+#pragma unroll
+        for (uint32_t u = 0; u < QS_CH; ++u) {
+            const uint32_t i = (c * QS_CH + u) * QS_WG + tid;
+            hh[u] = i < n ? gload_u32(qh + i) : 0u;
+        }
+    };
+    auto issue_heads = [&](uint32_t c) {
+#pragma unroll
+        for (uint32_t u = 0; u < QS_CH; ++u) {
+            const uint32_t i = (c * QS_CH + u) * QS_WG + tid;
+            hd[u] = make_uint3(0u, 0u, 0u);
+            if (i < n && hh[u] >= g->win_lo && hh[u] <= g->win_hi) hd[u] = gload_u3(line_of(hh[u]));
+        }
+    };
+    load_hashes(0u);
+    issue_heads(0u);
+  for (;;) {
+    const uint32_t rounds = (n + QS_WG - 1u) / QS_WG, nchunks = (rounds + QS_CH - 1u) / QS_CH;
     // the query's hash set: 2^sbits >= 2 n slots
     uint32_t sbits = 8u;
     while ((1u << sbits) < 2u * n) ++sbits;
-    if (tid < FUSE_MAX) { s_first[tid] = g->first_hash[tid]; s_last[tid] = g->last_hash[tid]; }
-    if (tid < GROUP_CHUNKS) s_ext[tid] = tid < g->nchunks ? g->ext_tab[tid] : nullptr;
     if (tid < HIST_SLOTS) wg_h[tid] = 0u;
     for (uint32_t i = tid; i < (1u << sbits); i += QS_WG) recs[i] = 0xFFFFFFFFu;
     if (tid == 0) {
-        s_count = 0u; s_over_recs = 0u; s_seen_ones = 0u; s_ccnt = 0u; s_cshared = 0u;
+        s_count = 0u; s_ntask = 0u; s_over_recs = 0u; s_seen_ones = 0u; s_ccnt = 0u; s_cshared = 0u;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
         s_cancel = cancel_requested(a.cancel, a.counters) ? 1u : 0u;        // cancel point (src/FileSegment.zig:144), once per query
     }
     __syncthreads();
     if (s_cancel) return;
+    QS_MARK(0);
     // ---- dedupSorted (src/Index.zig:171-172,489-499): the first occurrence of a hash is the probe, later ones are dropped.  A lane notes
     //      which of its rounds' hashes are probes (a hash-window slice of the group leaves the other hashes to another rank)
     uint32_t vmask = 0u;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * QS_WG + tid;
-        if (i >= n) break;
-        const uint32_t h = gload_u32(a.hashes_base + q_lo + i);
-        bool dup;
-        if (h == 0xFFFFFFFFu) dup = atomicExch(&s_seen_ones, 1u) != 0u;     // (the set's empty mark is kept apart)
-        else {
-            uint32_t slot = (h * 0x9E3779B1u) >> (32u - sbits);
-            for (;;) {
-                const uint32_t old = atomicCAS(&recs[slot], 0xFFFFFFFFu, h);
-                if (old == 0xFFFFFFFFu) { dup = false; break; }
-                if (old == h) { dup = true; break; }
-                slot = (slot + 1u) & ((1u << sbits) - 1u);
-            }
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        uint32_t hc[QS_CH];
+#pragma unroll
+        for (uint32_t u = 0; u < QS_CH; ++u) {
+            const uint32_t i = (c * QS_CH + u) * QS_WG + tid;
+            hc[u] = c == 0u ? hh[u] : (i < n ? gload_u32(qh + i) : 0u);
         }
-        if (!dup && h >= g->win_lo && h <= g->win_hi) vmask |= 1u << r;
+#pragma unroll
+        for (uint32_t u = 0; u < QS_CH; ++u) {
+            const uint32_t i = (c * QS_CH + u) * QS_WG + tid;
+            if (i >= n) continue;
+            const uint32_t h = hc[u];
+            bool dup;
+            if (h == 0xFFFFFFFFu) dup = atomicExch(&s_seen_ones, 1u) != 0u;     // (the set's empty mark is kept apart)
+            else {
+                uint32_t slot = (h * 0x9E3779B1u) >> (32u - sbits);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&recs[slot], 0xFFFFFFFFu, h);
+                    if (old == 0xFFFFFFFFu) { dup = false; break; }
+                    if (old == h) { dup = true; break; }
+                    slot = (slot + 1u) & ((1u << sbits) - 1u);
+                }
+            }
+            if (!dup && h >= g->win_lo && h <= g->win_hi) vmask |= 1u << (c * QS_CH + u);
+        }
     }
-    for (uint32_t i = tid; i < (1u << (QS_FLOG2 - 1u)); i += QS_WG) filter[i] = 0u;
     __syncthreads();                                    // (the set is done with: its slots are the record array now)
+    QS_MARK(1);
 
     const uint32_t active = g->active, nactive = (uint32_t)__popc(active);
     uint32_t my_blocks = 0, my_docs = 0, my_probes = 0, my_reads = 0;
-    // a doc joins the query's records: its place in the array is the caller's, its filter cell is counted here
-    auto put = [&](uint32_t at, uint32_t doc) {
-        recs[at] = doc;
-        const uint32_t c = (doc * 0x9E3779B1u) >> (32u - QS_FLOG2);
-        atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
+    // ---- records.  `n` docs of the lane (mask km over d[]) join the query's array: one reservation per wave -- a scan on the DPP
+    //      crossbar: the whole wave is here (fpx_pgroup.hpp x5) --, doc j at pos + (docs of the lane before it); a slot without a doc
+    //      writes the sink word behind the array (no branch per slot).  The filter is counted later, over the array (every lane busy).
+    auto reserve = [&](uint32_t cnt) -> uint32_t {
+        const uint32_t incl = scan16(cnt);
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31),
+                       r2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47), r3 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t total = r0 + r1 + r2 + r3;
+        uint32_t wbase = 0;
+        if (total != 0u) {                                                       // (wave-uniform)
+            if (lane == 0u) wbase = atomicAdd(&s_count, total);
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        }
+        const uint32_t row = lane >> 4;
+        return wbase + (row >= 1u ? r0 : 0u) + (row >= 2u ? r1 : 0u) + (row >= 3u ? r2 : 0u) + (incl - cnt);
     };
-    // (one record of some lanes of the wave -- the wave's turns below: lists, words beyond a lane's own)
+    auto emit = [&](uint32_t km, const auto& d) {
+        constexpr uint32_t N = sizeof(d) / sizeof(uint32_t);
+        const uint32_t cnt = (uint32_t)__popc(km);
+        const uint32_t pos = reserve(cnt);
+        if (cnt != 0u && pos + cnt > QS_REC_CAP) s_over_recs = 1u;               // (more records than the array takes: the batch goes the long way)
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const uint32_t at = pos + (uint32_t)__popc(km & ((1u << j) - 1u));
+            recs[(((km >> j) & 1u) != 0u && at < QS_REC_CAP) ? at : QS_REC_CAP] = d[j];
+        }
+    };
+    // (one record of some lanes of the wave: the wave's turns, long lists)
     auto emit1 = [&](bool kp, uint32_t doc) {
         const unsigned long long m = __ballot((int)kp);
         if (m == 0ull) return;
@@ -133,20 +240,20 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         base = __shfl(base, (int)__builtin_ctzll(m));
         if (kp) {
             const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (at < QS_REC_CAP) put(at, doc); else s_over_recs = 1u;
+            if (at < QS_REC_CAP) recs[at] = doc; else s_over_recs = 1u;
         }
     };
+    // a task joins the queue (a full queue: the batch goes the long way)
+    auto push_task = [&](unsigned long long e) {
+        const uint32_t at = atomicAdd(&s_ntask, 1u);
+        if (at < QS_TASKS) tasks[at] = e; else s_over_recs = 1u;
+    };
 
-    for (uint32_t round = 0; round < rounds; ++round) {
-        const bool valid = ((vmask >> round) & 1u) != 0u;
-        const uint32_t h = valid ? gload_u32(a.hashes_base + q_lo + round * QS_WG + tid) : 0u;
-        // ---- the head of the hash's line: position bits, double flags (fpx_pgroup.hpp: the layout)
-        const uint32_t* lp = g->lines + (size_t)((h >> HVL) - g->line0) * GROUP_LINE_WORDS;
-        uint4 hd = make_uint4(0, 0, 0, 0);
-        if (valid) hd = gload_u4(reinterpret_cast<const uint8_t*>(lp));
+    // ---- FileSegment.search for every column, a hash per lane and round (fpx_pgroup.hpp: the line's layout)
+    auto probe = [&](uint32_t h, uint3 head, bool valid) {
         if (valid) { my_probes += nactive; my_reads += 2u; }
-        const uint32_t* ext = s_ext[valid ? (h >> GROUP_CHUNK_LOG2) - g->chunk0 : 0u];
-        const uint64_t bits = ((uint64_t)hd.y << 32) | hd.x;
+        const uint64_t bits = valid ? (((uint64_t)head.y << 32) | head.x) : 0ull;
+        const uint32_t dfl = valid ? head.z : 0u;
         const uint32_t sh = (h & ((1u << HVL) - 1u)) * (uint32_t)NS;
         const uint32_t pm = (uint32_t)(bits >> sh) & ((1u << NS) - 1u);
         const uint32_t pos0 = (uint32_t)__popcll(bits & ((1ull << sh) - 1ull));
@@ -160,174 +267,186 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         if (!valid) inr = 0u;
         my_blocks += (uint32_t)__popc(inr & active & ~pm);         // absent: the reference visits one block, finds nothing and stops
         const uint32_t k = (uint32_t)__popc(pm);
-        const uint32_t dfl = hd.z;
         const uint32_t dbl_before = pos0 >= 32u ? (uint32_t)__popc(dfl) : (uint32_t)__popc(dfl & ((1u << pos0) - 1u));
         const uint32_t dm = pos0 >= 32u ? 0u : ((dfl >> pos0) & ((1u << k) - 1u));
         const uint32_t nwords = k + (uint32_t)__popc(dm);
         const uint32_t n_line = (uint32_t)__popcll(bits) + (uint32_t)__popc(dfl);
         const uint32_t inl = n_line > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;
         const uint32_t start = pos0 + dbl_before;
-        const uint32_t mine = min(min(nwords, PK_WORDS), start < inl ? inl - start : 0u);
-        uint32_t gw[PK_WORDS];
+        const uint32_t mine = min(min(nwords, QS_WORDS), start < inl ? inl - start : 0u);
+        uint32_t gw[QS_WORDS];
 #pragma unroll
-        for (uint32_t i = 0; i < PK_WORDS; ++i) gw[i] = 0u;
+        for (uint32_t i = 0; i < QS_WORDS; ++i) gw[i] = 0xFFFFFFFFu;
+        {
+            const uint32_t* lp = line_of(h) + 3u + start;
 #pragma unroll
-        for (uint32_t i = 0; i < PK_WORDS / 4; ++i) {
-            if (mine > 4u * i) {
-                const uint4 v = gload_u4_a4(lp + 3u + start + 4u * i);
-                gw[4 * i] = v.x; gw[4 * i + 1] = v.y; gw[4 * i + 2] = v.z; gw[4 * i + 3] = v.w;
+            for (uint32_t i = 0; i < QS_WORDS / 4; ++i) {
+                if (mine > 4u * i) {
+                    const uint4 v = gload_u4_a4(lp + 4u * i);
+                    gw[4 * i] = v.x; gw[4 * i + 1] = v.y; gw[4 * i + 2] = v.z; gw[4 * i + 3] = v.w;
+                }
             }
         }
-        uint32_t keep = 0, lmask = 0, mine_w = mine, add_blocks = 0, add_docs = 0;
-        // words behind the line's 28th live in `ext`: the few lanes that have some fetch them one by one
-        if (valid && nwords <= PK_WORDS && start + nwords > inl) {
-            const uint32_t ovf = gload_u32(lp + (GROUP_LINE_WORDS - 1u));
-            const uint32_t* ob = ext + ovf + start - inl;
+        // second words of doubles: the t-th double, at position i, has its second word at i + t + 1
+        uint32_t second = 0;
+        for (uint32_t d = dm, t = 0; d != 0u; d &= d - 1u, ++t) second |= 1u << ((uint32_t)__builtin_ctz(d) + t + 1u);
+        uint32_t keep = 0, lmask = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < PK_WORDS; ++j)
-                if (j >= mine && j < nwords) gw[j] = gload_u32(ob + j);
-            mine_w = nwords;
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < PK_WORDS; ++j) {
+        for (uint32_t j = 0; j < QS_WORDS; ++j) {
             const uint32_t word = gw[j];
-            const bool v = j < mine_w, neg = (int32_t)word < 0;
+            const bool v = j < mine, neg = (int32_t)word < 0;
             keep |= (v && !neg) ? (1u << j) : 0u;                               // a doc (a gap position and a list reference have bit 31)
             lmask |= (v && neg && word != 0xFFFFFFFFu) ? (1u << j) : 0u;        // a list reference
             gw[j] = neg ? word : g->gmin + word;
         }
-        {
-            // second words of doubles: the t-th double, at position i, has its second word at i + t + 1
-            uint32_t second = 0;
-            for (uint32_t d = dm, t = 0; d != 0u; d &= d - 1u, ++t) second |= 1u << ((uint32_t)__builtin_ctz(d) + t + 1u);
-            add_docs = (uint32_t)__popc(keep);
-            add_blocks = (uint32_t)__popc(keep & ~second);
-            if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += (uint32_t)__popc(keep & second) << 16;
-        }
-        const uint32_t n_esc = (uint32_t)__popc(lmask);
-        auto list_word = [&](uint32_t m) {
-            const uint32_t j0 = (uint32_t)__builtin_ctz(m);
-            uint32_t e = 0;
+        my_docs += (uint32_t)__popc(keep);
+        my_blocks += (uint32_t)__popc(keep & ~second);
+        // (the scan histograms: a double is ONE observation of two docs, counted where its second word is -- the upper half of my_probes)
+        if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += (uint32_t)__popc(keep & second) << 16;
+        emit(keep, gw);
+        // ---- what the round does not wait for joins the query's task queue -- the hash's lists (their heads are other lines: HBM), its
+        //      words beyond the lane's own and those that overflowed the line into `ext` --; the workgroup takes the tasks up together
+        //      once its rounds are done
+        if (lmask != 0u || nwords != mine) {
+            const uint32_t chunk = (h >> GROUP_CHUNK_LOG2) - g->chunk0;
+            const uint32_t* ext = s_ext[chunk];
+            uint32_t lm = lmask;
+            while (lm != 0u) {
+                const uint32_t j0 = (uint32_t)__builtin_ctz(lm);
+                lm &= lm - 1u;
+                uint32_t e = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < PK_WORDS; ++j) e = j == j0 ? gw[j] : e;
-            return e & 0x7FFFFFFFu;
-        };
-        // a list's head: header + up to seven docs in two loads (fpx_pgroup.hpp: list_head)
-        uint32_t xd[7];
-        uint32_t xeff = 0, xin = 0, xblk = 0;
-        auto list_head = [&](uint32_t off) -> uint32_t {
-            const uint4 x = gload_u4_a4(ext + off), x2 = gload_u4_a4(ext + off + 4u);
-            my_reads += 2u;
-            const uint32_t xT = (x.x >> 19) & 1u, xmd = g->gmin;
-            xeff = x.x & 0xFFFFu; xin = min(xeff, xT ? 6u : 7u);
-            xd[0] = xmd + (xT ? x.z : x.y); xd[1] = xmd + (xT ? x.w : x.z); xd[2] = xmd + (xT ? x2.x : x.w); xd[3] = xmd + (xT ? x2.y : x2.x);
-            xd[4] = xmd + (xT ? x2.z : x2.y); xd[5] = xmd + (xT ? x2.w : x2.z); xd[6] = xmd + x2.w;
-            xblk = (x.x >> 16) & 7u;
-            return (1u << xin) - 1u;
-        };
-        // ---- the lane's records into the query's array: one reservation per wave (a scan on the DPP crossbar where the whole wave is
-        //      here, fpx_pgroup.hpp x5), record j at pos + (records of the lane before it)
-        auto emit = [&](uint32_t km, uint32_t xk, bool whole) {
-            const uint32_t nk = (uint32_t)__popc(km), cnt = nk + (uint32_t)__popc(xk);
-            uint32_t pos;
-            if (whole) {
-                const uint32_t incl = scan16(cnt);
-                const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31),
-                               r2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47), r3 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const uint32_t total = r0 + r1 + r2 + r3;
-                if (total == 0u) return;                                             // (wave-uniform)
-                const uint32_t row = lane >> 4;
-                const uint32_t before = (row >= 1u ? r0 : 0u) + (row >= 2u ? r1 : 0u) + (row >= 3u ? r2 : 0u);
-                uint32_t wbase = 0;
-                if (lane == 0u) wbase = atomicAdd(&s_count, total);
-                wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-                if (cnt == 0u) return;
-                pos = wbase + before + (incl - cnt);
-            } else {
-                if (cnt == 0u) return;
-                pos = atomicAdd(&s_count, cnt);
+                for (uint32_t j = 0; j < QS_WORDS; ++j) e = j == j0 ? gw[j] : e;
+                push_task(qs_task_list(ext + (e & 0x7FFFFFFFu), chunk));
             }
-            if (pos + cnt <= QS_REC_CAP) {
-#pragma unroll
-                for (uint32_t j = 0; j < PK_WORDS; ++j)
-                    if ((km >> j) & 1u) put(pos + (uint32_t)__popc(km & ((1u << j) - 1u)), gw[j]);
-#pragma unroll
-                for (uint32_t t = 0; t < 7u; ++t)
-                    if ((xk >> t) & 1u) put(pos + nk + (uint32_t)__popc(xk & ((1u << t) - 1u)), xd[t]);
-            } else s_over_recs = 1u;                   // (more records than the array takes: the batch goes the long way)
-        };
-        uint32_t xkeep = 0;
-        if (n_esc != 0u) { xkeep = list_head(list_word(lmask)); add_blocks += xblk; add_docs += xeff; hist_observe(wg_h, xeff, xblk); }
-        const uint32_t xeff1 = xeff, xin1 = xin;             // (of the FIRST list: what the wave's turn, if there is one, continues from)
-        emit(keep, xkeep, true);
-        // what is left for the whole wave: words beyond the lane's own, a third list, a list longer than its head
-        bool more = nwords > mine_w || n_esc > 2u || (n_esc != 0u && xeff1 > xin1);
-        if (!more && n_esc == 2u) {                          // a SECOND list (one hash in two hundred): its head too
-            const uint32_t yk = list_head(list_word(lmask & (lmask - 1u)));
-            if (xeff > xin) more = true;                     // (longer than seven docs: the wave walks it from its start, and counts it)
-            else { add_blocks += xblk; add_docs += xeff; hist_observe(wg_h, xeff, xblk); emit(0u, yk, false); }
-        }
-        my_blocks += add_blocks; my_docs += add_docs;
-        // ---- the rare rest, by the whole wave (fpx_pgroup.hpp: the same turns, their records into the query's array)
-        {
-            unsigned long long mo = __ballot((int)more);
-            while (mo != 0ull) {
-                const int src = (int)__builtin_ctzll(mo);
-                mo &= mo - 1ull;
-                const uint32_t pm_s = __shfl(pm, src), dm_s = __shfl(dm, src), nw_s = __shfl(nwords, src), mine_s = __shfl(mine_w, src);
-                const uint32_t xin_s = __shfl(xin1, src);
-                const uint32_t start_s = __shfl(start, src), inl_s = __shfl(inl, src);
-                const uint32_t* lp_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)lp >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)lp, src));
-                const uint32_t* li_s = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)ext >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)ext, src));
-                const uint32_t ovf_s = start_s + nw_s > inl_s ? gload_u32(lp_s + (GROUP_LINE_WORDS - 1u)) : 0u;
-                // lane l looks at word l of the hash (nwords <= 32): its column, and whether it is a double's second word
-                uint32_t col = 0, wv = 0xFFFFFFFFu;
-                bool second = false;
-                if (lane < nw_s) {
-                    uint32_t rest = pm_s, i = 0, j = 0;
-                    for (;;) {
-                        col = (uint32_t)__builtin_ctz(rest);
-                        const uint32_t span = 1u + ((dm_s >> i) & 1u);
-                        if (lane < j + span) { second = lane == j + 1u; break; }
-                        j += span; i += 1u; rest &= rest - 1u;
-                    }
-                    const uint32_t idx = start_s + lane;
-                    wv = idx < inl_s ? gload_u32(lp_s + 3u + idx) : gload_u32(li_s + ovf_s + (idx - inl_s));
-                }
-                const bool act = lane < nw_s && ((active >> col) & 1u) != 0u && wv != 0xFFFFFFFFu;
-                {
-                    const bool plain = act && (wv >> 31) == 0u && lane >= mine_s;
-                    if (plain) {
-                        my_blocks += second ? 0u : 1u; my_docs += 1u;
-                        if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += second ? (1u << 16) : 0u;
-                    }
-                    emit1(plain, g->gmin + wv);
-                }
-                unsigned long long me = __ballot((int)(act && (wv >> 31) != 0u));
-                bool first = true;
-                while (me != 0ull) {
-                    const int el = (int)__builtin_ctzll(me);
-                    me &= me - 1ull;
-                    const uint32_t off = __shfl(wv, el) & 0x7FFFFFFFu;
-                    const uint32_t* list = li_s + off;
-                    const uint32_t hdr = gload_u32(list), eff = hdr & 0xFFFFu, Tl = (hdr >> 19) & 1u;
-                    uint32_t from = 0u;
-                    if (first && (uint32_t)el < mine_s) from = min(eff, xin_s);          // (the lane's own emit took these)
-                    else if (lane == 0) {
-                        my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u;
-                        hist_observe(wg_h, eff, (hdr >> 16) & 7u);
-                    }
-                    first = false;
-                    for (uint32_t o2 = from; o2 < eff; o2 += 64u) {
-                        const bool kp = o2 + lane < eff;
-                        const uint32_t dv = g->gmin + (kp ? gload_u32(list + 1u + Tl + o2 + lane) : 0u);
-                        emit1(kp, dv);
-                    }
-                    if (lane == 0 && eff > from) my_reads += ((eff - from + 31u) >> 5) * 2u;
-                }
+            uint32_t j = mine;
+            // ... words still in the line (the hash has more than the lane walks)
+            while (j < nwords && start + j < inl) {
+                const uint32_t c = min(min(nwords - j, inl - (start + j)), QS_TASK_WORDS);
+                push_task(qs_task_words(line_of(h) + 3u + start + j, c, second >> j, chunk));
+                j += c;
             }
+            // ... and behind its end, in `ext` at the offset the line's last word holds
+            if (j < nwords) {
+                const uint32_t* ob = ext + gload_u32(line_of(h) + (GROUP_LINE_WORDS - 1u));
+                while (j < nwords) {                     // (start + j >= inl here)
+                    const uint32_t c = min(nwords - j, QS_TASK_WORDS);
+                    push_task(qs_task_words(ob + (start + j - inl), c, second >> j, chunk));
+                    j += c;
+                }
+                my_reads += 2u;
+            }
+        }
+    };
+
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        if (c != 0u) { load_hashes(c); issue_heads(c); }
+        // (ONE copy of the round's code: the chunk's hashes and heads move up a register each round -- unrolled four times the kernel is
+        // 50 KB of instructions)
+#pragma nounroll
+        for (uint32_t u = 0; u < QS_CH; ++u) {
+            const uint32_t round = c * QS_CH + u;
+            if (round >= rounds) break;                                                    // (uniform)
+            probe(hh[0], hd[0], ((vmask >> round) & 1u) != 0u);
+#pragma unroll
+            for (uint32_t v = 0; v + 1 < QS_CH; ++v) { hh[v] = hh[v + 1]; hd[v] = hd[v + 1]; }
         }
     }
+    __syncthreads();
+    QS_MARK(2);
+    // ---- the NEXT query's offsets and hashes set out now (the chunk registers are free): they travel under this query's tasks and counting
+    const uint32_t qn = q + gridDim.x;
+    const bool has_next = qn < a.B;                      // (uniform)
+    uint64_t nq_lo = 0; uint32_t nn = 0;
+    if (has_next) {
+        nq_lo = a.offsets[qn]; nn = (uint32_t)(a.offsets[qn + 1] - nq_lo);
+        const uint32_t n_keep = n; const uint32_t* qh_keep = qh;
+        n = nn; qh = a.hashes_base + nq_lo;
+        load_hashes(0u);
+        n = n_keep; qh = qh_keep;
+    }
+    // ---- the deferred tasks, a task per lane: every list head and overflow piece of the query is asked for at once.  (A list inside
+    //      overflowing words is a task of the next pass.)
+    {
+        uint32_t t_lo = 0;
+        for (;;) {
+            const uint32_t t_hi = min(s_ntask, QS_TASKS);                        // (uniform: read behind a barrier ...
+            __syncthreads();                                                      // ... and nobody pushes before everybody has read it)
+            if (t_lo >= t_hi) break;
+            for (uint32_t t0 = t_lo; t0 < t_hi; t0 += QS_WG) {
+                const bool has = t0 + tid < t_hi;
+                const unsigned long long e = has ? tasks[t0 + tid] : 0ull;
+                const bool is_list = has && (e >> 63) != 0ull;
+                const uint32_t* p = qs_task_ptr(e);
+                uint32_t d[QS_TASK_WORDS];
+#pragma unroll
+                for (uint32_t j = 0; j < QS_TASK_WORDS; ++j) d[j] = 0xFFFFFFFFu;
+                const uint32_t cnt = !has ? 0u : is_list ? 8u : ((uint32_t)(e >> 46) & 7u) + 1u;          // words to fetch: a list's header + seven, or the task's
+#pragma unroll
+                for (uint32_t i = 0; i < QS_TASK_WORDS / 4; ++i) {
+                    if (cnt > 4u * i) {
+                        const uint4 v = gload_u4_a4(p + 4u * i);
+                        d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+                    }
+                }
+                uint32_t km = 0, lm = 0;
+                bool long_list = false;
+                uint32_t eff = 0, Tl = 0, xin = 0;
+                if (is_list) {
+                    // header: docs the reference RETURNS | blocks it VISITS << 16 | T << 19 [T: the list's full length follows]; then the docs
+                    const uint32_t hdr = d[0];
+                    eff = hdr & 0xFFFFu; Tl = (hdr >> 19) & 1u;
+                    xin = min(eff, Tl ? 6u : 7u);
+                    km = ((1u << xin) - 1u) << (1u + Tl);
+                    my_blocks += (hdr >> 16) & 7u; my_docs += eff; my_reads += 2u;
+                    hist_observe(wg_h, eff, (hdr >> 16) & 7u);
+                    long_list = eff > xin;
+                    if (long_list) my_reads += ((eff - xin + 31u) >> 5) * 2u;
+                } else if (has) {
+                    const uint32_t second = (uint32_t)(e >> 49) & 0xFFu;
+#pragma unroll
+                    for (uint32_t j = 0; j < QS_TASK_WORDS; ++j) {
+                        const bool v = j < cnt, neg = (int32_t)d[j] < 0;
+                        km |= (v && !neg) ? (1u << j) : 0u;
+                        lm |= (v && neg && d[j] != 0xFFFFFFFFu) ? (1u << j) : 0u;
+                    }
+                    my_docs += (uint32_t)__popc(km); my_blocks += (uint32_t)__popc(km & ~second);
+                    if constexpr (SCAN_HIST && (FPX_SH_BITS & 2)) my_probes += (uint32_t)__popc(km & second) << 16;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < QS_TASK_WORDS; ++j) d[j] = ((int32_t)d[j] < 0 && !is_list) ? d[j] : g->gmin + d[j];
+                emit(km, d);
+                while (lm != 0u) {                      // (a list inside the words: the next pass's)
+                    const uint32_t j0 = (uint32_t)__builtin_ctz(lm);
+                    lm &= lm - 1u;
+                    uint32_t w = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < QS_TASK_WORDS; ++j) w = j == j0 ? d[j] : w;
+                    const uint32_t chunk = (uint32_t)(e >> 57) & 63u;
+                    push_task(qs_task_list(s_ext[chunk] + (w & 0x7FFFFFFFu), chunk));
+                }
+                // lists longer than their head: the wave reads them on, 64 docs at a time
+                unsigned long long ml = __ballot((int)long_list);
+                while (ml != 0ull) {
+                    const int src = (int)__builtin_ctzll(ml);
+                    ml &= ml - 1ull;
+                    const uint32_t* list = reinterpret_cast<const uint32_t*>(((uint64_t)__shfl((uint32_t)((uint64_t)p >> 32), src) << 32) | __shfl((uint32_t)(uint64_t)p, src));
+                    const uint32_t eff_s = __shfl(eff, src), T_s = __shfl(Tl, src), from = __shfl(xin, src);
+                    for (uint32_t o2 = from; o2 < eff_s; o2 += 64u) {
+                        const bool kp = o2 + lane < eff_s;
+                        const uint32_t dv = g->gmin + (kp ? gload_u32(list + 1u + T_s + o2 + lane) : 0u);
+                        emit1(kp, dv);
+                    }
+                }
+            }
+            t_lo = t_hi;
+            __syncthreads();
+        }
+    }
+
+    // (every task has been read: the queue's slots become the filter and the exact table)
+    for (uint32_t i = tid; i < (1u << (QS_FLOG2 - 1u)); i += QS_WG) filter[i] = 0u;
+    for (uint32_t s = tid; s < T; s += QS_WG) table[s] = 0ull;
     // ---- the query's statistics (what FileSegment.search observes per hash, summed: src/FileSegment.zig:177-178)
     {
         auto wave_total = [&](uint32_t v) -> unsigned long long {
@@ -345,9 +464,20 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
             if (w_probes) atomicAdd(&wg_probes, w_probes);
         }
     }
-    for (uint32_t s = tid; s < T; s += QS_WG) table[s] = 0ull;
-    __syncthreads();
+    __syncthreads();                                    // (the records are complete, the filter and the table are clear)
+    QS_MARK(3);
     const uint32_t nrec = min(s_count, QS_REC_CAP);
+    // ---- SearchResults.incr (src/common.zig:121-129), first the filter: every record into its doc's cell
+    for (uint32_t i = tid; i < nrec; i += QS_WG) {
+        const uint32_t c = qs_cell(recs[i]);
+        atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
+    }
+    if (has_next) {                                      // ... and the heads of its first lines (its hashes have arrived by now)
+        const uint32_t n_keep = n;
+        n = nn;
+        issue_heads(0u);
+        n = n_keep;
+    }
     if (tid == 0) {
         unsigned long long* st = a.stat_sets + (size_t)(q % LEAN_STAT_SETS) * 8u;
         if (wg_reads) atomicAdd(&st[4], wg_reads);
@@ -363,8 +493,8 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         const unsigned long long v = tid == HIST_COUNT ? wg_probes : tid == HIST_DOCS ? wg_docs : tid == HIST_BLOCKS ? wg_blocks : (unsigned long long)wg_h[tid];
         if (v != 0ull) atomicAdd(&a.stat_sets[(size_t)LEAN_STAT_SETS * 8u + (size_t)(q % LEAN_STAT_SETS) * HIST_SLOTS + tid], v);
     }
-    // ---- SearchResults.incr + the floor of finish (src/common.zig:121-145): a doc can only reach the floor if its cell did; those
-    //      records are counted exactly, in `passes` loads over classes of them when they are more than the table takes
+    // ---- ... then the floor of finish (src/common.zig:131-145): a doc can only reach the floor if its cell did; those records are
+    //      counted exactly, in `passes` loads over classes of them when they are more than the table takes
     const uint32_t floor_q = a.opts[q * 4u + 1u];
     const uint64_t smax = a.sb >= 32u ? 0xFFFFFFFFull : ((1ull << a.sb) - 1ull);
     if (s_over_recs == 0u && nrec != 0u && nrec >= floor_q) {
@@ -375,10 +505,10 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
                 for (uint32_t s = tid; s < T; s += QS_WG) table[s] = 0ull;
             }
             if (tid == 0) { s_claimed = 0u; s_full = 0u; }
-            __syncthreads();
+            __syncthreads();                            // (the first pass: the filter's counts are complete behind this barrier)
             for (uint32_t i = tid; i < nrec; i += QS_WG) {
                 const uint32_t doc = recs[i];
-                const uint32_t hsh = doc * 0x9E3779B1u, c = hsh >> (32u - QS_FLOG2);
+                const uint32_t c = qs_cell(doc);
                 const uint32_t cc = (filter[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu;
                 if (cc < floor_q) continue;
                 const uint32_t h2 = mix32(doc);
@@ -428,6 +558,7 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     }
     // ---- hand-over: up to QCAND_SLOTS candidates stay in the query's own slots, more move to the shared list entirely
     __syncthreads();
+    QS_MARK(4);
     const uint32_t cn = min(s_ccnt, SB_CAND);
     const bool shared = s_cshared != 0u || cn > QCAND_SLOTS;
     if (tid == 0) {
@@ -446,6 +577,11 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
             if (gi < a.cand_cap) a.cands[gi] = key;
         }
     }
+    QS_MARK(5);
+    if (!has_next) break;
+    q = qn; q_lo = nq_lo; n = nn; qh = a.hashes_base + nq_lo;
+    __syncthreads();                                    // (the candidate buffer and the flags have been read: the next query may reset them)
+  }
 }
 
 // zeroes what a batch of k_search_query adds to: the batch's counters and the statistics sets (one launch instead of two memsets)

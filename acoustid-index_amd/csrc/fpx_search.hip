@@ -23,6 +23,7 @@
 // The kernels live in headers of this translation unit: fpx_kernels_common.hpp, fpx_probe_generic.hpp (k_probe),
 // fpx_probe_lean.hpp (k_probe_lean8, the dominant kernel), fpx_probe_small.hpp (memory / small segments), fpx_score.hpp
 // (k_bounds, k_score, k_finish, k_merge).  This file holds the host side: run_batch and the C-ABI implementations.
+#include <cstdio>
 #include <cstring>
 #include <hip/hip_runtime.h>
 
@@ -616,12 +617,20 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         qa.counters = ws->d_counters; qa.stat_sets = reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off);
         qa.qstats = want_q ? ws->d_qstats : nullptr; qa.cancel = cancel;
         const GroupArgs gargs{gd, snap->d_direct};
+        // as many workgroups as the chip holds at once (LDS: QS_WGS_PER_CU per CU); each takes every gridDim.x-th query
+        static std::atomic<int> cus_of[64];
+        int cus = cus_of[(unsigned)snap->ctx->device & 63u].load(std::memory_order_relaxed);
+        if (cus == 0) {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, snap->ctx->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+            cus_of[(unsigned)snap->ctx->device & 63u].store(cus, std::memory_order_relaxed);
+        }
+        const dim3 qgrid(std::min<uint32_t>(B, (uint32_t)cus * QS_WGS_PER_CU));
         if (grp->ns == 8u) {
-            if (want_q) hipLaunchKernelGGL((k_search_query<8, true>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
-            else hipLaunchKernelGGL((k_search_query<8, false>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            if (want_q) hipLaunchKernelGGL((k_search_query<8, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            else hipLaunchKernelGGL((k_search_query<8, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
         } else {
-            if (want_q) hipLaunchKernelGGL((k_search_query<16, true>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
-            else hipLaunchKernelGGL((k_search_query<16, false>), dim3(B), dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            if (want_q) hipLaunchKernelGGL((k_search_query<16, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            else hipLaunchKernelGGL((k_search_query<16, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
         }
         FPX_HIP(hipGetLastError());
         FPX_HIP(hipEventRecord(ws->ev_probe1, st));
@@ -642,6 +651,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         }
         FPX_HIP(hipEventRecord(ws->ev_end, st));
         FPX_SYNC(ws);
+#ifdef FPX_QS_PROF
+        fprintf(stderr, "qs_prof clocks/query: setup %.0f dedup %.0f rounds %.0f tasks %.0f count+exact %.0f handover %.0f\n", ws->h_counters[CTR_HIST] / (double)B, ws->h_counters[CTR_HIST + 1] / (double)B,
+                ws->h_counters[CTR_HIST + 2] / (double)B, ws->h_counters[CTR_HIST + 3] / (double)B, ws->h_counters[CTR_HIST + 4] / (double)B, ws->h_counters[CTR_HIST + 5] / (double)B);
+#endif
         if (ws->h_counters[CTR_BINFAIL] != 0 || ws->h_counters[CTR_MAXSCORE] != 0 || ws->h_counters[CTR_CANDS] > ws->cap_cands) {
             if (ws->h_counters[CTR_BINFAIL] != 0) __atomic_store_n(&snap->qs_skip, 32u, __ATOMIC_RELAXED);
             return FPX_REDO_QS;

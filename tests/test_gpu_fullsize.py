@@ -301,24 +301,78 @@ def test_config1_10m_fingerprints_one_segment_batch_1024():
     _oracle_sample(fpx, oracle, ctx, segs[0], 1, per, flat, offsets, opts, 64)
 
 
-def test_config4_share_of_one_rank_125m_fingerprints_120_hashes_limit_100():
-    """configs[4] is 1 B fingerprints x 120 hashes over 8 GPUs: one rank holds 125 M of them in 16 segments."""
+def test_config4_all_eight_ranks_of_1b_fingerprints_120_hashes_batch_8192_limit_100():
+    """configs[4] -- 1 B fingerprints x 120 hashes in 128 segments over 8 GPUs, batch 8192, limit 100 -- with EVERY rank played in
+    turn by the one GPU: rank r holds segments 16 r .. 16 r + 15 (125 M fingerprints, ids (16 r + s) x 7 812 500 + 1 ...), searches
+    the whole batch against them (fpx_search_resident_partial: its table per query, only the absolute floor applied -- DESIGN 6b,
+    north_star's "RCCL reduce of partial score tables"), and after the eighth rank the eight tables are merged as the all-gather
+    would have left them (fpx_merge_partials: k-way merge, the relative cut-off over the merged list).  Required: the merged
+    result holds every query's target first (the targets are drawn over all 1 B fingerprints: 1/8 of them live on each rank),
+    SearchResults.finish's contract (src/common.zig:131-171), probes = unique hashes x 128 segments; per rank: the oracle on one of
+    its segments, downloaded, for a few queries -- results and the reference's scanned blocks / docs (src/FileSegment.zig:135-180).
+    No docs-only stand-ins for the other ranks' segments here (the configs[3] test has them): the id ranges are disjoint, no segment
+    mentions a doc of another, nothing is superseded.
+    The routed-key protocol (hash windows) is NOT replayed at this size: a rank's window holds 1/8 of the hash space of
+    all 128 segments, i.e. every window needs the whole 1 B x 120 = 120 G items generated, cut and dropped again -- eight times;
+    its eight-rank replay at full size is the configs[3] test above (100 M x 256), its exchange logic tests/test_gpu_hashshard.py."""
+    import torch
+    from fpx_testlib import fpx, oracle
+    ctx = fpx.Context(0)
+    world, S, H, B, L, limit = 8, 16, 120, 8192, 1000, 100
+    per = 1_000_000_000 // (world * S)
+    docs_all = per * world * S
+    _fit(125_000_000, lambda d: int(d * H * 5.0 + (d // S) * H * 8 * 2.3) + (30 << 30), "a rank's 125 M x 120 share")
+    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs_all, H, query_len=L)
+    opts = fpx.http_options(limit=limit)
+    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
+    cap = qb.cap
+    parts = torch.zeros((world, B, cap, 2), dtype=torch.int32, device="cuda")
+    cnts = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()            # (torch fills on ITS stream; libfpx writes these on a stream of its own)
+    probes = 0
+    own_first = np.zeros(B, bool)
+    for r in range(world):
+        segs = [fpx.FileSegment.synth(ctx, SEED, (r * S + s) * per + 1, per, H, 0, 512, r * S + s + 1) for s in range(S)]
+        reader = fpx.IndexReader(fpx.Segments(ctx, segs))
+        pst = fpx.search_resident_partial(reader, qb, parts[r].data_ptr(), cnts[r].data_ptr())
+        probes += pst.probes
+        # the rank's own queries (their target lives here): its table alone already has the target first
+        mine = (targets.astype(np.int64) - 1) // (per * S) == r
+        torch.cuda.synchronize()
+        pr, pn = parts[r].cpu().numpy().view(np.uint32), cnts[r].cpu().numpy().view(np.uint32)
+        assert (pn[mine] >= 1).all() and (pr[mine, 0, 0] == targets[mine]).all(), f"rank {r}: a target of its own is not first in its table"
+        own_first |= mine
+        # the oracle on one of the rank's segments (a different column for every rank), 6 queries
+        k = (5 * r + 3) % S
+        _oracle_sample(fpx, oracle, ctx, segs[k], (r * S + k) * per + 1, per, flat, offsets, opts, 6)
+        del reader
+        for sg in segs:
+            sg.release()
+        del segs
+    assert own_first.all()
+    mo, mn = fpx.merge_partials(ctx, qb, parts.data_ptr(), cnts.data_ptr(), world)
+    _check_finish_contract(mo, mn, targets, H, limit, (L + 19) // 20, 10)
+    assert probes == _unique_per_query(flat, offsets) * S * world
+    # every entry of the merged list comes from exactly one rank's table, with that rank's score
+    pr_all, pn_all = parts.cpu().numpy().view(np.uint32), cnts.cpu().numpy().view(np.uint32)
+    for q in range(0, B, 257):
+        have = {}
+        for r in range(world):
+            for i in range(int(pn_all[r, q])):
+                assert int(pr_all[r, q, i, 0]) not in have
+                have[int(pr_all[r, q, i, 0])] = int(pr_all[r, q, i, 1])
+        for i in range(int(mn[q])):
+            assert have[int(mo[q, i, 0])] == int(mo[q, i, 1])
+    qb.release()
+
+
+def test_config4_share_of_one_rank_with_hot_hashes():
+    """one rank's share of configs[4] (125 M x 120 in 16 segments) with SURVEY 8(d)'s distribution Z (hot-hash pool: the 4-block /
+    1000-doc caps at work), oracle sample"""
     from fpx_testlib import fpx, oracle
     ctx = fpx.Context(0)
     H, S, B, L, limit = 120, 16, 8192, 1000, 100
-    segs, per, docs = _build(fpx, ctx, 125_000_000, H, S, est_bytes_per_item=5.0)
-    reader = fpx.IndexReader(fpx.Segments(ctx, segs))
-    flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L)
     opts = fpx.http_options(limit=limit)
-    qb = fpx.QueryBatch(ctx, options=opts, flat=(flat, offsets))
-    out, out_n, st = fpx.search_resident(reader, qb)
-    _check_finish_contract(out, out_n, targets, H, limit, (L + 19) // 20, 10)
-    assert st.probes == _unique_per_query(flat, offsets) * S
-    _oracle_sample(fpx, oracle, ctx, segs[15], 15 * per + 1, per, flat, offsets, opts, 16)
-    # the same share with SURVEY 8(d)'s distribution Z (hot-hash pool: the 4-block / 1000-doc caps at work), oracle sample
-    del reader, qb
-    for sg in segs:
-        sg.release()
     segs, per, docs = _build(fpx, ctx, 125_000_000, H, S, est_bytes_per_item=5.0, dist=1, scratch=30 << 30)
     reader = fpx.IndexReader(fpx.Segments(ctx, segs))
     flat, offsets, targets = fpx.synth.make_queries(SEED, 4242, B, docs, H, query_len=L, dist=1)

@@ -210,6 +210,8 @@ void ws_destroy(Workspace* w)
     if (w->ev_probe1) (void)hipEventDestroy(w->ev_probe1);
     if (w->ev_probe2) (void)hipEventDestroy(w->ev_probe2);
     if (w->ev_end) (void)hipEventDestroy(w->ev_end);
+    if (w->copy_stream) { (void)hipStreamSynchronize(w->copy_stream); (void)hipStreamDestroy(w->copy_stream); }
+    for (hipEvent_t& e : w->ev_chunk) if (e) (void)hipEventDestroy(e);
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }

@@ -298,6 +298,11 @@ struct Workspace {
     uint32_t* d_kocnt = nullptr; size_t cap_kocnt = 0;                // the key order's count table [B][buckets] + totals + the key count (fpx_keyorder.hpp)
     unsigned long long* d_qstats = nullptr; size_t cap_qstats = 0;    // per-query scan statistics (blocks | docs << 32), when asked for
     uint32_t* d_cells = nullptr; uint32_t* h_cells = nullptr; size_t cap_cells = 0;   // fpx_shard_probe: the cells' fill counters + statistics slots
+    // a large batch handed over in host memory and searched a query per workgroup (fpx_qsearch.hpp) is uploaded in UP_CHUNKS pieces on a stream of
+    // its own; the kernel of piece c waits for ev_chunk[c] only: the upload of piece c + 1 travels under it
+    static constexpr uint32_t UP_CHUNKS = 4;
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_chunk[UP_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint32_t> h_opts;         // the batch's options as the kernels read them (kept here: their copy is not waited for)
     uint32_t hint_def = 0;                // longest deferred list of the last batch (sizes the deferred pass's grid)
     uint64_t hint_misc = 0;               // records the last binned batch left in the misc buffer (sizes k_bin's grid)
     uint64_t hint_P = 0, hint_H = 0;      // pairs and hit records of the last batch this workspace ran (sizes the next one)

@@ -64,7 +64,7 @@ constexpr size_t QS_LDS_BYTES = ((size_t)QS_REC_CAP + 4u) * 4u + ((size_t)2u << 
 struct QSearchArgs {
     const uint32_t* hashes_base; const uint64_t* offsets;      // hashes_base[i]: the hash at ABSOLUTE position i of the batch; offsets[q] absolute
     const uint32_t* opts;                                      // [B][4]: max_results, floor, pct, raw length
-    uint32_t B, sb;                                            // sb: bits of the score field in a candidate key
+    uint32_t q_begin, q_end, sb;                               // the launch's queries [q_begin, q_end) of the batch; sb: bits of the score field in a candidate key
     uint64_t* cands; uint64_t cand_cap;                        // the shared candidate list (queries with more candidates than slots)
     uint64_t* qcand; uint32_t* qcand_n;                        // the queries' own candidate slots
     unsigned long long* counters;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     // The workgroup STAYS: it takes query blockIdx.x, then every gridDim.x-th one (the host launches as many workgroups as the chip holds
     // at once).  What a query's start waits for -- its offsets, its hashes, the heads of its first lines: three latencies in a row -- is
     // asked for while the query before it is still being counted.
-    uint32_t q = blockIdx.x;
+    uint32_t q = a.q_begin + blockIdx.x;
     uint64_t q_lo = a.offsets[q];
     uint32_t n = (uint32_t)(a.offsets[q + 1] - q_lo);
     const uint32_t* qh = a.hashes_base + q_lo;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     QS_MARK(2);
     // ---- the NEXT query's offsets and hashes set out now (the chunk registers are free): they travel under this query's tasks and counting
     const uint32_t qn = q + gridDim.x;
-    const bool has_next = qn < a.B;                      // (uniform)
+    const bool has_next = qn < a.q_end;                      // (uniform)
     uint64_t nq_lo = 0; uint32_t nn = 0;
     if (has_next) {
         nq_lo = a.offsets[qn]; nn = (uint32_t)(a.offsets[qn + 1] - nq_lo);

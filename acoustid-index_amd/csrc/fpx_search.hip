@@ -447,6 +447,27 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // anything that does not fit falls back to the general path.
     bool single_fast = B == 1 && !partial && !ex && !no_fast && P != 0 && out_cap <= SINGLE_OUT_MAX &&
                        (snap->n_lean == 0 || P * snap->n_file < lean_min_probes(snap->ctx));
+    // ---- ONE WORKGROUP PER QUERY (fpx_qsearch.hpp): the snapshot is one packed group and nothing else, every column of it searched, no
+    //      superseded docs -- the resident index between merges --, the queries short enough for their hash set and their floor above the
+    //      legacy protocol's: dedup, probe, count and floor happen in ONE kernel, no keys are made or ordered, no record reaches HBM.
+    //      Anything else, and a batch that kernel hands back (hot hashes: a query's records outgrow its LDS array), runs the pipeline below.
+    bool qs_path = false;
+    if (!ex && !no_fast && !no_qs && !single_fast && B >= 2u && P != 0 && qb <= 24u && snap->n_file == 0 && snap->n_solo == 0 && snap->n_group == 1 &&
+        snap->n_direct != 0 && (snap->n_mem == 0 || snap->mem_items == 0) && snap->groups[0]->packed && ctx_opt(snap->ctx, OPT_QUERY_WG) != 0) {
+        const GroupDesc& gd = snap->h_group[0];
+        qs_path = gd.any_dead == 0u && gd.active == (gd.nseg >= 32u ? 0xFFFFFFFFu : ((1u << gd.nseg) - 1u));
+        for (uint32_t q = 0; q < B && qs_path; ++q) {
+            const uint64_t raw_len = offsets[q + 1] - offsets[q];
+            qs_path = raw_len <= QS_MAX_HASHES && (opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20)) > 2u;
+        }
+        if (qs_path) {
+            // (after a batch that was handed back: the next ones do not try again at once -- hot-hash traffic comes in runs)
+            uint32_t skip = __atomic_load_n(&snap->qs_skip, __ATOMIC_RELAXED);
+            if (skip != 0u) { __atomic_store_n(&snap->qs_skip, skip - 1u, __ATOMIC_RELAXED); qs_path = false; }
+        }
+    }
+
+    uint32_t up_chunks = 0, up_q[Workspace::UP_CHUNKS + 1] = {0};      // (a chunked upload: the pieces' query ranges)
     if (!single_fast) FPX_HIP(hipEventRecord(ws->ev_begin, st));
     if (resident) {
         d_hashes_base = resident->d_hashes;
@@ -471,8 +492,30 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         staged_single = true;
     } else {
         if ((rc = grow(&ws->d_hashes, &ws->cap_hashes, (size_t)P + 1))) return rc;
-        std::vector<uint32_t> h_opts;
+        std::vector<uint32_t>& h_opts = ws->h_opts;
         fill_opts(h_opts, opts, offsets, B);
+        if (qs_path && B >= 1024u && P >= (1u << 20)) {
+            // A large batch for k_search_query: every query is a workgroup's own business, so the batch is uploaded in pieces on a stream of
+            // its own and the kernel over piece c waits for THAT piece only -- piece c + 1 crosses PCIe under it (33 MB per batch of
+            // 8192 x 1000 hashes: 0.6 ms of link time next to 0.45 ms of kernel).  Nothing here waits: the options live in the workspace.
+            if (!ws->copy_stream) {
+                FPX_HIP(hipStreamCreateWithFlags(&ws->copy_stream, hipStreamNonBlocking));
+                for (hipEvent_t& e : ws->ev_chunk) FPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            hipStream_t cs = ws->copy_stream;
+            FPX_HIP(hipMemcpyAsync(ws->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
+            FPX_HIP(hipMemcpyAsync(ws->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+            up_chunks = Workspace::UP_CHUNKS;
+            for (uint32_t c = 0; c <= up_chunks; ++c) up_q[c] = (uint32_t)((uint64_t)B * c / up_chunks);
+            for (uint32_t c = 0; c < up_chunks; ++c) {
+                const uint64_t h0 = offsets[up_q[c]] - base, h1 = offsets[up_q[c + 1]] - base;
+                if (h1 > h0) FPX_HIP(hipMemcpyAsync(ws->d_hashes + h0, hashes + base + h0, (h1 - h0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+                FPX_HIP(hipEventRecord(ws->ev_chunk[c], cs));
+            }
+            d_hashes_base = ws->d_hashes - base;
+            d_offsets = ws->d_offsets;
+            d_opts = ws->d_opts;
+        } else {
         // (pageable sources go through the runtime's own staging.  A private page-locked ring per workspace was tried in round 3:
         // 3.8 / 5.2 M queries/s with one / two callers against 4.6 / 6.5 M this way -- the host's extra copy costs more than the
         // runtime's lock; what round 2 measured as "two pageable callers serialise" was the second caller's workspace being
@@ -480,10 +523,11 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         if (P) FPX_HIP(hipMemcpyAsync(ws->d_hashes, hashes + base, P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         FPX_HIP(hipMemcpyAsync(ws->d_offsets, offsets, ((size_t)B + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         FPX_HIP(hipMemcpyAsync(ws->d_opts, h_opts.data(), h_opts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        FPX_HIP(hipStreamSynchronize(st));             // h_opts is a local
+        FPX_HIP(hipStreamSynchronize(st));             // (the caller's arrays may go once the call returns an error further down)
         d_hashes_base = ws->d_hashes - base;
         d_offsets = ws->d_offsets;
         d_opts = ws->d_opts;
+        }
     }
     // deferred-probe lists of the lean kernel: room for 1/8 of the pairs per segment (typically < 2 % are deferred)
     const size_t def_cap = std::max<size_t>(4096, (size_t)(P / 8));
@@ -506,26 +550,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     const size_t def_stat_off = (size_t)ws->cap_def_segs * DEF_COUNT_STRIDE;
     const size_t def_words = def_stat_off + LEAN_STAT_WORDS;
     // (every memset is a 5-us launch of its own: the batch's zeroing rides in kernels that run anyway where it can)
-
-    // ---- ONE WORKGROUP PER QUERY (fpx_qsearch.hpp): the snapshot is one packed group and nothing else, every column of it searched, no
-    //      superseded docs -- the resident index between merges --, the queries short enough for their hash set and their floor above the
-    //      legacy protocol's: dedup, probe, count and floor happen in ONE kernel, no keys are made or ordered, no record reaches HBM.
-    //      Anything else, and a batch that kernel hands back (hot hashes: a query's records outgrow its LDS array), runs the pipeline below.
-    bool qs_path = false;
-    if (!ex && !no_fast && !no_qs && !single_fast && B >= 2u && P != 0 && qb <= 24u && snap->n_file == 0 && snap->n_solo == 0 && snap->n_group == 1 &&
-        snap->n_direct != 0 && (snap->n_mem == 0 || snap->mem_items == 0) && snap->groups[0]->packed && ctx_opt(snap->ctx, OPT_QUERY_WG) != 0) {
-        const GroupDesc& gd = snap->h_group[0];
-        qs_path = gd.any_dead == 0u && gd.active == (gd.nseg >= 32u ? 0xFFFFFFFFu : ((1u << gd.nseg) - 1u));
-        for (uint32_t q = 0; q < B && qs_path; ++q) {
-            const uint64_t raw_len = offsets[q + 1] - offsets[q];
-            qs_path = raw_len <= QS_MAX_HASHES && (opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20)) > 2u;
-        }
-        if (qs_path) {
-            // (after a batch that was handed back: the next ones do not try again at once -- hot-hash traffic comes in runs)
-            uint32_t skip = __atomic_load_n(&snap->qs_skip, __ATOMIC_RELAXED);
-            if (skip != 0u) { __atomic_store_n(&snap->qs_skip, skip - 1u, __ATOMIC_RELAXED); qs_path = false; }
-        }
-    }
 
     // ---- 1+2: keys, sort by (hash, q)
     int kcur = 0;
@@ -612,7 +636,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         hipLaunchKernelGGL(k_qs_zero, dim3(8), dim3(256), 0, st, ws->d_counters, ws->d_def_count, (uint32_t)def_words);
         FPX_HIP(hipEventRecord(ws->ev_probe0, st));
         QSearchArgs qa{};
-        qa.hashes_base = d_hashes_base; qa.offsets = d_offsets; qa.opts = d_opts; qa.B = B; qa.sb = sbf;
+        qa.hashes_base = d_hashes_base; qa.offsets = d_offsets; qa.opts = d_opts; qa.q_begin = 0u; qa.q_end = B; qa.sb = sbf;
         qa.cands = ws->d_cands[0]; qa.cand_cap = ws->cap_cands; qa.qcand = d_qcand; qa.qcand_n = d_qcand_n;
         qa.counters = ws->d_counters; qa.stat_sets = reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off);
         qa.qstats = want_q ? ws->d_qstats : nullptr; qa.cancel = cancel;
@@ -624,13 +648,18 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, snap->ctx->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
             cus_of[(unsigned)snap->ctx->device & 63u].store(cus, std::memory_order_relaxed);
         }
-        const dim3 qgrid(std::min<uint32_t>(B, (uint32_t)cus * QS_WGS_PER_CU));
-        if (grp->ns == 8u) {
-            if (want_q) hipLaunchKernelGGL((k_search_query<8, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
-            else hipLaunchKernelGGL((k_search_query<8, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
-        } else {
-            if (want_q) hipLaunchKernelGGL((k_search_query<16, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
-            else hipLaunchKernelGGL((k_search_query<16, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+        for (uint32_t c = 0; c < std::max(1u, up_chunks); ++c) {
+            qa.q_begin = up_chunks ? up_q[c] : 0u; qa.q_end = up_chunks ? up_q[c + 1] : B;
+            if (qa.q_end == qa.q_begin) continue;
+            if (up_chunks) FPX_HIP(hipStreamWaitEvent(st, ws->ev_chunk[c], 0));           // (the piece's hashes have arrived; the next piece is on its way)
+            const dim3 qgrid(std::min<uint32_t>(qa.q_end - qa.q_begin, (uint32_t)cus * QS_WGS_PER_CU));
+            if (grp->ns == 8u) {
+                if (want_q) hipLaunchKernelGGL((k_search_query<8, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+                else hipLaunchKernelGGL((k_search_query<8, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            } else {
+                if (want_q) hipLaunchKernelGGL((k_search_query<16, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+                else hipLaunchKernelGGL((k_search_query<16, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+            }
         }
         FPX_HIP(hipGetLastError());
         FPX_HIP(hipEventRecord(ws->ev_probe1, st));
@@ -1445,7 +1474,7 @@ static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
         if (q_blocks) q_blocks[0] = local.scanned_blocks;
         if (q_docs) q_docs[0] = local.scanned_docs;
     }
-    if (rc != FPX_OK) (void)hipStreamSynchronize(ws->stream);
+    if (rc != FPX_OK) { (void)hipStreamSynchronize(ws->stream); if (ws->copy_stream) (void)hipStreamSynchronize(ws->copy_stream); }
     if (rc == FPX_OK) ctx_hist_add(snap->ctx, ws->batch_hist, ws->batch_hist[HIST_SLOTS]);       // (the context's running scan histograms: fpx_ctx_scan_histograms)
     ws_release(snap->ctx, ws);
     if (rc == FPX_OK) { if (stats) add_stats(stats, local); return FPX_OK; }

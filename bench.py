@@ -126,7 +126,7 @@ class StatAgg:
         return bool(self.path_flags & 64)
 
 
-def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
+def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False, query_wg=False):
     """What the dominant kernel has to pull from HBM per launch, modelled from counts the kernel reports.
     Block-form segments (k_probe_lean8): the blocks it fetched (counted) + the 128-B lines of the probe records (presence
     bits + block range + block records, 64 B per 256 hash buckets) its probes touch (expected value for uniform hashes) +
@@ -146,7 +146,7 @@ def model_moved_bytes(segs, fetched_per_launch, probes_per_launch, fused=False):
                 pr += touched_bytes(float((1 << 24) * 64), per_seg)
         elif sg.getSize() >= (1 << 20):
             pr += touched_bytes(float(probe_record_bytes(sg.getSize())), per_seg)
-    pairs = 8.0 * (per_seg if fused else probes_per_launch)
+    pairs = (4.0 if query_wg else 8.0) * (per_seg if fused else probes_per_launch)      # (k_search_query reads the query's hashes, not pairs)
     return {"blocks": fetched_per_launch, "probe_records": pr, "pairs": pairs, "total": fetched_per_launch + pr + pairs}
 
 
@@ -183,7 +183,7 @@ def row_from(B, steps, dt, agg, segs, kernel_hint=None):
     avg_ms = agg.v["probe_kernel_ms"] / launches
     fetched = agg.v["probe_kernel_fetched_bytes"] / launches
     probes = agg.v["probes"] / max(1, agg.steps)
-    moved = model_moved_bytes(segs, fetched, probes, agg.fused)
+    moved = model_moved_bytes(segs, fetched, probes, agg.fused, agg.query_wg)
     r = {"batch": B, "steps": steps, "ms_per_step": dt / steps * 1e3, "queries_per_s": B * steps / dt,
          "probe_kernel_ms": avg_ms if avg_ms > 0 else None,
          "probe_kernel_fetched_block_bytes": fetched,
@@ -307,6 +307,33 @@ def run_pmc_child(args, docs, timeout_s=420, env_extra=None, keep_tag=None):
                 "child_probe_kernel_ms_under_profiler": child.get("probe_kernel_ms") if child else None}, None
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def measure_random_lines(footprint_gb):
+    """tools/random_lines.bin (built by __graft_entry__.build from tools/random_lines.hip): G random 128-byte lines/s this chip serves when every
+    lane of 4 / 8 waves per SIMD waits for a line of its own, spread over `footprint_gb` -- the ceiling of a kernel whose every request is a
+    random line of the index (k_search_query).  The figure committed under profiles/ when the binary is missing or fails."""
+    exe = os.path.join(ROOT, "tools", "random_lines.bin")
+    best, src = None, None
+    if os.path.exists(exe):
+        try:
+            p = subprocess.run([exe, str(int(footprint_gb))], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            for line in p.stdout.decode(errors="replace").splitlines():
+                if line.startswith("{"):
+                    r = json.loads(line)
+                    if best is None or r["G_lines_per_s"] > best:
+                        best = r["G_lines_per_s"]
+            src = f"in-run: tools/random_lines.bin over {int(footprint_gb)} GB"
+        except (subprocess.TimeoutExpired, OSError, ValueError):
+            best = None
+    if best is None:
+        try:
+            rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r06_random_lines_by_footprint.txt")) if l.startswith("{")]
+            rows = [r for r in rows if r["footprint_GB"] >= 100]
+            best, src = max(r["G_lines_per_s"] for r in rows), "profiles/r06_random_lines_by_footprint.txt (146 GB)"
+        except (OSError, ValueError):
+            return None, None
+    return best, src
 
 
 def stored_traffic(docs, S, H, B, qlen):
@@ -784,7 +811,7 @@ def main():
         ref_bytes = agg.v["probe_kernel_bytes"] / launches        # 512 B per block the REFERENCE visits
         fetched = agg.v["probe_kernel_fetched_bytes"] / launches  # blocks the kernel really read
         probes = agg.v["probes"] / max(1, agg.steps)
-        moved = model_moved_bytes(segs, fetched, probes, agg.fused)
+        moved = model_moved_bytes(segs, fetched, probes, agg.fused, agg.query_wg)
         moved_gbs = moved["total"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ref_gbs = ref_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         result = {
@@ -796,7 +823,8 @@ def main():
                                    f"{'; kept direct-addressed in HBM' if dominant_kernel(segs) != 'k_probe_lean8' else ''}), "
                                    + (f"the index sharded by hash range over {pw} GPUs (every rank 1/{pw} of the hash space of all segments)" if shard_mode == "hash"
                                       else f"segments sharded over {world} GPU(s)") + f"; batch of {B_global} queries x {args.query_len} hashes, "
-                                   f"limit {args.limit}, min_score (n+19)/20, score_pct 10; {NQB} distinct batches resident in HBM, searched in rotation",
+                                   f"limit {args.limit}, min_score (n+19)/20, score_pct 10; {NQB} distinct batches resident in HBM, searched in rotation"
+                                   + ("; a query per workgroup (k_search_query: dedup, probe, count and floor in one kernel)" if agg.query_wg else ""),
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B_global, "global_batch": B_global, "batch_per_gpu": B_global // pw,
                        "protocol": ("routed keys: a rank uploads its share of the batch, keys travel to their window's rank, bins back (two all-to-alls)" if routed
                                     else ("the whole batch's hashes resident on every rank, bins exchanged" if shard_mode == "hash" else None)),
@@ -808,13 +836,13 @@ def main():
             # achieved / frac: PHYSICAL bytes of the dominant kernel per launch / its HIP-event time / peak.  Filled with the
             # model here and replaced by the in-run PMC figure below when the rocprofv3 child pass succeeds.
             "roofline": {"bound": "hbm", "kernel": "fpx::" + dominant_kernel(segs, agg.fused, agg.query_wg), "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": moved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "frac": moved_gbs / HBM_PEAK_GBS, "frac_sec8d": ref_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "achieved_basis": "model",
                          "avg_launch_ms": avg_ms, "launches_timed": launches,
                          "moved_model": {**moved, "GBs": moved_gbs, "frac": moved_gbs / HBM_PEAK_GBS,
                                          "note": model_moved_bytes.__doc__.split("\n", 1)[1].strip().replace("\n    ", " ")},
                          "reference_equivalent": {"bytes_per_launch": ref_bytes, "GBs": ref_gbs, "over_peak": ref_gbs / HBM_PEAK_GBS,
-                                                  "note": "SURVEY 8(d)'s algorithmic figure: 512 B for every block the REFERENCE visits.  NOT a roofline "
+                                                  "note": "SURVEY 8(d)'s algorithmic figure (= roofline.frac_sec8d x peak): 512 B for every block the REFERENCE visits.  NOT a roofline "
                                                           "fraction: the presence bitmaps answer the probes of absent hashes without reading their block, "
                                                           "so it may exceed the peak"},
                          "all_probe_passes": {"algorithmic_bytes_per_step": agg.v["algorithmic_bytes"] / max(1, args.steps),
@@ -895,6 +923,7 @@ def main():
             rf["achieved"], rf["frac"] = rf["moved_model"]["GBs"], rf["moved_model"]["frac"]
             rf["reference_equivalent"]["GBs"] = rf["reference_equivalent"]["bytes_per_launch"] / k
             rf["reference_equivalent"]["over_peak"] = rf["reference_equivalent"]["GBs"] / HBM_PEAK_GBS
+            rf["frac_sec8d"] = rf["reference_equivalent"]["over_peak"]
         rows.append({"batch": B, "inflight": nfl, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "queries_per_s": qps,
                      "probe_kernel_ms": result["roofline"]["avg_launch_ms"],
                      "probe_kernel_fetched_block_bytes": agg.v["probe_kernel_fetched_bytes"] / max(1, agg.v["probe_launches"]),
@@ -1009,6 +1038,7 @@ def main():
             s.release()
         del reader, snapshot, segs
         torch.cuda.synchronize()
+        rl_rate, rl_src = measure_random_lines(index_bytes / 2**30) if os.environ.get("FPX_BENCH_RANDOM_LINES", "1") != "0" else (None, None)
         try:
             d1, b1 = 10_000_000, 1024
             s1, _ = synth_index(fpx, ctx, args.seed, d1, 1, H, {0})
@@ -1047,9 +1077,13 @@ def main():
                        "requests": (pmc["read_requests_per_launch"] + pmc["write_requests_per_launch"]) if pmc else None,
                        "read_requests": pmc["read_requests_per_launch"] if pmc else None, "write_requests": pmc["write_requests_per_launch"] if pmc else None,
                        "request_rate_G_per_s": ((pmc["read_requests_per_launch"] + pmc["write_requests_per_launch"]) / (rf["avg_launch_ms"] * 1e-3) / 1e9) if pmc else None,
-                       "request_rate_peak_measured_G_per_s": 47.0,
-                       "request_rate_note": "47 G requests/s: what this chip served random 128-byte reads at with many loads in flight (tools/random_read2.hip, "
-                                            "profiles/r02_random_read_rates.txt)",
+                       "request_rate_peak_measured_G_per_s": 47.0 if rl_rate is None else rl_rate,
+                       "request_rate_note": ("47 G requests/s: what this chip served random 128-byte reads at over 8 GB with many loads in flight "
+                                             "(profiles/r02_random_read_rates.txt)" if rl_rate is None else
+                                             f"G random 128-byte lines/s, a line per lane, every lane of the chip waiting for one, over the index's footprint ({rl_src}); "
+                                             "over 8 GB: 41, over 1 GB: 57 (profiles/r06_random_lines_by_footprint.txt)"),
+                       "frac_of_measured_random_line_rate": (((pmc["read_requests_per_launch"] + pmc["write_requests_per_launch"]) / (rf["avg_launch_ms"] * 1e-3) / 1e9) / rl_rate)
+                                                            if (pmc and rl_rate) else None,
                        "achieved_basis": "HBM bytes COUNTED by PMC -- memory-side read requests (128-byte ones on gfx950: verified by the calibration kernels of "
                                          "the same pass) + write requests (64-byte ones; the hit records leaving for their bins) -- per launch / HIP-event time of "
                                          "the unprofiled launches in this run"})

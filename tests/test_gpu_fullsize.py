@@ -282,7 +282,20 @@ class TestHeadlineIndex:
         # the oracle on a bounded sample: 24 queries x one segment
         _oracle_sample(fpx, oracle, ctx, segs[3], 3 * per + 1, per, flat, offsets, opts, 24)
         # ... and over the WHOLE index -- all 16 columns of the group, the headline kernel's own path -- on 48 queries of the batch
-        assert st.path_flags & 4 and st2.path_flags & 8, "the batch did not run k_probe_group<16, BINNED> + k_score_bin"
+        assert st.path_flags & 4 and st.path_flags & 64 and st2.path_flags & 64, "the batch did not run k_search_query (a query per workgroup)"
+        # the same batch through the pipeline the other snapshots take (keys ordered by hash bucket, k_probe_pgroup<16, BINNED>, k_score_bin):
+        # byte for byte the same results, the same scan counters
+        ctx.set_option("query_wg", 0)
+        try:
+            for _ in range(8):                                 # (a workspace's first pipeline batches measure and size its bins; the next ones bin)
+                op, onp, stp = fpx.search_resident(reader, qb)
+                if stp.path_flags & 8:
+                    break
+            assert stp.path_flags & 8 and not stp.path_flags & 64, "the batch did not run k_probe_group<16, BINNED> + k_score_bin"
+            assert (onp == out_n).all() and (op == out).all()
+            assert (stp.scanned_blocks, stp.scanned_docs, stp.probes, stp.hits) == (st.scanned_blocks, st.scanned_docs, st.probes, st.hits)
+        finally:
+            ctx.set_option("query_wg", -1)
         _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, 48, out, out_n)
 
 

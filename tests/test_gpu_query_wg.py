@@ -186,3 +186,25 @@ def test_records_beyond_the_lds_array_go_back_to_the_pipeline(env, monkeypatch):
     assert flags[0] == 0 and flags[-1] == 64, flags           # (32 batches stay with the pipeline, then the path is tried again)
     got2, _ = p.check(plain, fpx.http_options())
     assert got2 == got
+
+
+def test_a_large_batch_from_host_memory_is_uploaded_in_pieces(env, monkeypatch):
+    """fpx_search_batch with 1200 queries x ~1000 hashes in HOST memory on the query-per-workgroup path: the batch crosses PCIe in four pieces
+    on a stream of its own and the kernel over a piece waits for that piece only (csrc/fpx_search.hip: up_chunks).  Same results as the
+    batch resident in HBM (one launch over all queries), as the oracle on a sample, and the same scan counters."""
+    fpx, oracle, Pair, ctx = env
+    p, allitems, rng = _world(fpx, Pair, ctx, 5, monkeypatch)
+    lens = [1000, 937, 1024, 400, 1100, 1000, 2047, 64]
+    queries = [_query(rng, allitems, i, lens[i % len(lens)]) for i in range(1200)]
+    opts = fpx.SearchOptions(max_results=40, min_score=5, min_score_pct=10)
+    got, st = p.reader.search_batch(queries, opts)
+    assert st.path_flags & 64
+    qb = fpx.QueryBatch(ctx, queries=queries, options=opts)
+    o, n, st_r = fpx.search_resident(p.reader, qb)
+    assert fpx.results_to_lists(o, n) == got
+    assert (st_r.scanned_blocks, st_r.scanned_docs, st_r.probes, st_r.hits) == (st.scanned_blocks, st.scanned_docs, st.probes, st.hits)
+    for i in list(range(0, 1200, 61)) + [299, 300, 599, 600, 899, 900, 1199]:        # (the pieces' edges among them)
+        assert got[i] == p.osnap.search(queries[i], 40, 5, 10), i
+    got2, _ = p.reader.search_batch(queries, opts)                                    # (the workspace's second batch: its buffers are there)
+    assert got2 == got
+    qb.release()

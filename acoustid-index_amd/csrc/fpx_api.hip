@@ -335,15 +335,9 @@ static const OptInfo OPT_TABLE[OPT_COUNT] = {
     /* OPT_REC32 */              {"rec32", "FPX_REC32", 1, 0, true},
     /* OPT_LOCAL_SORT_MAX */     {"local_sort_max", "FPX_LOCAL_SORT_MAX", 1ll << 20, 0, true},
     /* OPT_ORDER_MIN_PAIRS */    {"order_min_pairs", "FPX_ORDER_MIN_PAIRS", 1ll << 17, 0, true},
-    /* OPT_ORDER_MAX_PAIRS */    {"order_max_pairs", "FPX_ORDER_MAX_PAIRS", 1ll << 20, 0, true},
     /* OPT_LEAN_MIN */           {"lean_min", "FPX_LEAN_MIN", 1ll << 16, 0, true},
-    /* OPT_STAGED_OUT_MAX */     {"staged_out_max", "FPX_STAGED_OUT_MAX", -1, 0, true},        // (-1: the built-in STAGED_OUT_MAX of fpx_search.hip)
     /* OPT_GROUP_ROUNDS */       {"group_rounds", "FPX_GROUP_ROUNDS", 0, 0, true},
-    /* OPT_DIRECT_ROUNDS */      {"direct_rounds", "FPX_DIRECT_ROUNDS", 0, 0, true},
-    /* OPT_LEAN_ROUNDS */        {"lean_rounds", "FPX_LEAN_ROUNDS", 0, 0, true},
     /* OPT_SHARDED_WORKERS */    {"sharded_workers", "FPX_SHARDED_WORKERS", 3, 1, true},
-    /* OPT_KEY_ORDER_BITS */     {"key_order_bits", "FPX_KEY_ORDER_BITS", 8, 0, true},          // top hash bits the flagged keys of a large batch are ordered by
-    /* OPT_LINE_POOL_SLACK */    {"line_pool_slack", "FPX_LINE_POOL_SLACK", 0, 0, false},       // per cent a kept line buffer may be larger than the group that takes it
     /* OPT_HOT_REFS */           {"hot_refs", "FPX_HOT_REFS", -1, -1, true},                     // 1 | 0 | -1: hot lists reach the score kernel by reference | are copied | by the last batch's records
     /* OPT_QUERY_WG */           {"query_wg", "FPX_QUERY_WG", 1, 0, false},                      // 1 | 0: a snapshot that is ONE packed group is searched a query per workgroup (fpx_qsearch.hpp) | by the keys - probe - bins - score pipeline
 };

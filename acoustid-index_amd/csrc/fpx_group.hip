@@ -547,7 +547,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     // ("line_pool_slack": how much larger than the group's lines the kept buffer may be -- 0, an exact fit, unless a host that builds
     // groups of several sizes in turn, e.g. a test suite, says otherwise)
     g->lines_alloc_bytes = nlines * line_words * 4ull + 64;
-    const size_t slack_pct = (size_t)std::max<int64_t>(0, ctx_opt(ctx, OPT_LINE_POOL_SLACK));
+    const size_t slack_pct = 0;                      // (the kept line buffer is taken over by a group of exactly its size: round 6 folded the option)
     hipError_t e = hipSuccess;
     g->d_lines = static_cast<uint32_t*>(line_pool_take(ctx->device, g->lines_alloc_bytes, g->lines_alloc_bytes + g->lines_alloc_bytes / 100 * slack_pct, &g->lines_alloc_bytes));
     if (!g->d_lines) e = dmalloc(&g->d_lines, g->lines_alloc_bytes);

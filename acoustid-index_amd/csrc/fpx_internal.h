@@ -336,11 +336,9 @@ enum CtxOpt : int {
     OPT_DIRECT, OPT_DIRECT_MIN_ITEMS, OPT_FUSE_MIN, OPT_GROUP_PACKED,            // storage forms (read when a segment is created / first held)
     OPT_PRESENCE_MIN_ITEMS, OPT_LEAN_HEAD, OPT_INLINE_DOUBLES, OPT_MEMTAB,
     OPT_FAST, OPT_BINNED, OPT_BIN_Q_LOG2, OPT_REC32,                             // search paths (read per batch)
-    OPT_LOCAL_SORT_MAX, OPT_ORDER_MIN_PAIRS, OPT_ORDER_MAX_PAIRS, OPT_LEAN_MIN, OPT_STAGED_OUT_MAX,
-    OPT_GROUP_ROUNDS, OPT_DIRECT_ROUNDS, OPT_LEAN_ROUNDS,
+    OPT_LOCAL_SORT_MAX, OPT_ORDER_MIN_PAIRS, OPT_LEAN_MIN,
+    OPT_GROUP_ROUNDS,
     OPT_SHARDED_WORKERS,
-    OPT_KEY_ORDER_BITS,
-    OPT_LINE_POOL_SLACK,
     OPT_HOT_REFS,
     OPT_QUERY_WG,
     OPT_COUNT

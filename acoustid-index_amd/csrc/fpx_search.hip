@@ -333,7 +333,7 @@ static int stage_results(Workspace* ws, uint32_t B, uint32_t out_cap, hipStream_
 static int staged_targets(Workspace* ws, const Ctx* ctx, uint32_t B, uint32_t out_cap, bool* staged, uint32_t** d_n, fpx_result** d_res)
 {
     const size_t bytes = (size_t)B * sizeof(uint32_t) + (size_t)B * out_cap * sizeof(fpx_result);
-    const int64_t staged_opt = ctx_opt(ctx, OPT_STAGED_OUT_MAX);
+    const int64_t staged_opt = -1;                   // (the built-in STAGED_OUT_MAX)
     const size_t staged_max = staged_opt < 0 ? STAGED_OUT_MAX : (size_t)staged_opt;
     *staged = bytes <= staged_max;
     if (!*staged) return FPX_OK;
@@ -562,7 +562,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     for (uint32_t q = 0; q < B && flagged; ++q) flagged = offsets[q + 1] - offsets[q] <= DEDUP_MAX;
     // (flagged keys are ordered for locality alone: by how many of the top hash bits is the context's choice -- fewer bits, fewer
     // queries per round of a workgroup, larger reservations in their bins)
-    const uint32_t key_skip = flagged ? 32u - (uint32_t)std::min<int64_t>(8, std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_KEY_ORDER_BITS))) : KEY_SORT_SKIP;
+    const uint32_t key_skip = flagged ? KEY_SORT_SKIP_DIRECT : KEY_SORT_SKIP;      // (flagged keys: the top 8 hash bits -- 8 / 7 / 6 bits measured alike, 5 / 4 slower: round 5)
     // small batches sort their keys per query in ONE kernel (k_make_keys_sorted) instead of batch-wide in eleven launches
     const uint64_t local_sort_max = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_LOCAL_SORT_MAX));
     bool local_sort = P && !score_only && !single_fast && !flagged && !qs_path && B >= 2u && P <= local_sort_max && snap->n_small == 0;
@@ -579,7 +579,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         KeyOrder ko{};
         // ... and large ones keep the library's pass: there our three launches cost 0.03 ms more than its five, and two batches in
         // flight no longer fill each other's gaps (8192 queries: 1.16 against 0.97 ms per batch)
-        const uint64_t order_max = (uint64_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_ORDER_MAX_PAIRS));
+        const uint64_t order_max = 1ull << 20;
         const bool own_order = flagged && !single_fast && P >= order_min && P <= order_max;
         if (own_order && (rc = key_order_setup(ws, B, 0u, 32u - key_skip, &ko, nullptr, st, B >= KO_ROWS_MIN_B))) return rc;
         if (flagged)
@@ -889,7 +889,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                 if (n_solo) {
                     ProbeArgs dk = a;
                     dk.segs = d_solo; dk.lean_stats = stat_sets;
-                    const uint32_t direct_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_DIRECT_ROUNDS));
+                    const uint32_t direct_rounds = 0u;
                     dk.rounds = direct_rounds ? direct_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, wgs_solo / 8192));
                     const uint64_t per_wg_dk = (uint64_t)DK_WG * DK_KPL * dk.rounds;
                     hipLaunchKernelGGL(k_probe_direct, dim3((uint32_t)((P + per_wg_dk - 1) / per_wg_dk), n_solo), dim3(DK_WG), 0, st, dk);
@@ -903,7 +903,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     // rounds of 1024 pairs per workgroup: more rounds amortise the workgroup's set-up (decode tables, barriers) --
                     // measured at 8.2 M pairs x 16 segments: 5.48 ms with 1, 5.11 with 2, 5.01 with 6, 5.14 with 16 -- as long
                     // as the grid still fills the chip several times over (>= 4096 workgroups)
-                    const uint32_t lean_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_LEAN_ROUNDS));
+                    const uint32_t lean_rounds = 0u;
                     const uint64_t wgs_at_1 = (P + 1023) / 1024 * snap->n_lean;
                     l.segs = snap->d_lean; l.ctr_off = 8u;
                     l.rounds = lean_rounds ? lean_rounds : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_at_1 / 4096));

@@ -1014,6 +1014,29 @@ def main():
         e["queries_per_s"] = e["pageable"]["queries_per_s_1_in_flight"]
         e["over_resident_1_in_flight"] = e["queries_per_s"] / (B * args.steps / dt) if nfl == 1 else None
         e["pinned_over_resident"] = e["pinned"][f"queries_per_s_{nfl}_in_flight"] / qps
+        # what the LINK allows: the batch's hashes have to cross PCIe once -- page-locked host memory to HBM, timed here with plain copies of a
+        # batch's size (torch, its own stream), nothing else running
+        try:
+            src_pin = torch.empty(int(flat.nbytes) // 4, dtype=torch.int32).pin_memory()
+            dst_dev = torch.empty_like(src_pin, device="cuda")
+            for _ in range(3):
+                dst_dev.copy_(src_pin, non_blocking=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                dst_dev.copy_(src_pin, non_blocking=True)
+            torch.cuda.synchronize()
+            gbs = 20 * flat.nbytes / (time.perf_counter() - t1) / 1e9
+            e["pcie_h2d_GBs_measured"] = gbs
+            e["link_bound_queries_per_s"] = gbs * 1e9 / (e["h2d_bytes_per_step"] / B)
+            e["pinned_over_link_bound"] = e["pinned"][f"queries_per_s_{nfl}_in_flight"] / e["link_bound_queries_per_s"]
+            e["note"] = ("a batch's hashes (4 KB per query of 1000) cross PCIe once: the link, not the kernel, bounds a search handed over in host memory -- "
+                         "`link_bound_queries_per_s` = the measured copy rate / the bytes per query; a large batch is uploaded in four pieces, the kernel over a "
+                         "piece waiting for that piece only (csrc/fpx_search.hip: up_chunks)")
+            del src_pin, dst_dev
+        except Exception as ex:                      # (the rates above stand without it)
+            e["pcie_h2d_GBs_measured"] = None
+            e["note"] = repr(ex)
         result["end_to_end"] = e
         # the headline names both rates: queries resident in HBM (`value`) and handed over in page-locked host memory
         result["config"]["workload"] += (f" (`value`: {qps / 1e6:.2f} M queries/s; the same batches from page-locked host memory, H2D inside the call, "
@@ -1055,6 +1078,27 @@ def main():
             snap1.release()
             s1[0].release()
             del r1, snap1, s1
+            # ... and the same index as a packed group of ONE column ("fuse_min" 1, "group_packed" 1: lines of eight hash values, 69 GB of them whatever
+            # the item count): a query per workgroup (k_search_query<8>) instead of a lane per (hash, segment) on the segment's own records
+            try:
+                ctx.set_option("fuse_min", 1); ctx.set_option("group_packed", 1)
+                s1p, _ = synth_index(fpx, ctx, args.seed, d1, 1, H, {0})
+                snap1p = fpx.Segments(ctx, s1p)
+                r1p = fpx.IndexReader(snap1p)
+                q1p = fpx.QueryBatch(ctx, options=opts, flat=(f1, o1))
+                dtp, aggp, ocp, onp_ = timed_resident(fpx, r1p, q1p, 40, 5)
+                rowp = row_from(b1, 40, dtp, aggp, s1p, "fpx::" + dominant_kernel(s1p, aggp.fused, aggp.query_wg))
+                rowp["targets_found"] = int(sum(1 for q in range(b1) if onp_[q] > 0 and ocp[q, 0, 0] == t1[q]))
+                rowp["same_results_as_config1"] = bool(np.array_equal(onp_, onc) and np.array_equal(ocp, oc))
+                rowp["index_bytes"] = int(sum(s_.device_bytes for s_ in s1p))
+                rowp["group"] = s1p[0].group_info() if s1p[0].grouped else None
+                result["config1_packed"] = rowp
+                q1p.release(); snap1p.release(); s1p[0].release()
+                del r1p, snap1p, s1p
+            except Exception as e:
+                result["config1_packed"] = {"error": str(e)}
+            finally:
+                ctx.set_option("fuse_min", -1); ctx.set_option("group_packed", -2)
         except Exception as e:                     # the headline stands without it
             result["config1"] = {"error": str(e)}
         torch.cuda.synchronize()

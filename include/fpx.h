@@ -115,15 +115,11 @@ int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context live
  *   "binned"             1 | 0   groups drop their records into bins of a few queries, scored a bin per workgroup (default 1)
  *   "bin_q_log2"         log2 of the queries per bin (-1: by the batch's size, default)
  *   "rec32"              1 | 0   4-byte records in the bins where the doc ids leave room (default 1)
- *   "local_sort_max", "order_min_pairs", "order_max_pairs"   pair counts that choose how a batch's keys are ordered
- *   "key_order_bits"     top hash bits the keys of a batch on direct-addressed segments are ordered by (0..8, default 8)
+ *   "local_sort_max", "order_min_pairs"   pair counts that choose how a batch's keys are ordered
  *   "hot_refs"           1 | 0 | -1   the lists of HOT hashes (64+ docs) reach the score kernel by reference instead of a copy per query |
  *                        are copied into the bins | by the records the workspace's last batch brought (default)
- *   "line_pool_slack"    per cent by which the line buffer kept on the GPU (fpx_ctx_trim) may exceed the lines of the group that takes
- *                        it over (default 0: an exact fit; a host that builds groups of several sizes in turn may allow more)
  *   "lean_min"           probes from which block-form segments take the lean kernel (default 2^16)
- *   "staged_out_max"     bytes of results a batch stages in pinned memory (-1: built-in)
- *   "group_rounds", "direct_rounds", "lean_rounds"   rounds per workgroup of the probe kernels (0: by the batch's size)
+ *   "group_rounds"       rounds per workgroup of the groups' probe kernels (0: by the batch's size)
  *   "sharded_workers"    worker threads per device of a sharded snapshot (1..16, default 3)
  * (FPX_SHARDED_RCCL alone stays with the process: whether librccl is loaded at all.) */
 int  fpx_ctx_set_option(fpx_ctx *ctx, const char *name, int64_t value);

@@ -1210,6 +1210,83 @@ uint32_t orc_synth_hash(uint64_t seed, uint32_t doc, uint32_t j, int dist)
     return (uint32_t)(r >> 32);
 }
 
+/* ---- a whole synthetic segment's items, SORTED, on `nthreads` host threads (tests/test_gpu_fullsize.py builds one 1.6 G-item segment of the
+ *      100 M index here, on the host, so that full-size parity does not only see blocks the GPU encoded itself).  Items are generated doc by
+ *      doc (orc_synth_hash), dealt into 2^11 buckets by their top hash bits -- every thread a contiguous range of docs, so a bucket holds
+ *      its items in ascending doc order --, and each bucket is sorted by the remaining 21 hash bits with a stable LSD radix: (hash, doc)
+ *      order, what filefmt.writeBlocks is fed (src/filefmt.zig:94-138).  `out` and `tmp`: num_docs * H items each. */
+typedef struct {
+    uint64_t seed; uint32_t first_doc, num_docs, H; int dist;
+    uint64_t *out, *tmp; uint32_t nthreads, tid;
+    size_t *counts;            /* [nthreads][2048] */
+    size_t *bucket_start;      /* [2049] */
+    pthread_barrier_t *bar;
+} synth_mt_job;
+
+static void *synth_mt_worker(void *arg)
+{
+    synth_mt_job *j = (synth_mt_job *)arg;
+    const uint32_t d0 = (uint32_t)((uint64_t)j->num_docs * j->tid / j->nthreads), d1 = (uint32_t)((uint64_t)j->num_docs * (j->tid + 1) / j->nthreads);
+    size_t *cnt = j->counts + (size_t)j->tid * 2048;
+    memset(cnt, 0, 2048 * sizeof(size_t));
+    for (uint32_t d = d0; d < d1; d++)
+        for (uint32_t k = 0; k < j->H; k++) cnt[orc_synth_hash(j->seed, j->first_doc + d, k, j->dist) >> 21]++;
+    pthread_barrier_wait(j->bar);
+    if (j->tid == 0) {                                   /* bucket b: thread 0's items, then thread 1's, ... */
+        size_t sum = 0;
+        for (uint32_t b = 0; b < 2048; b++) {
+            j->bucket_start[b] = sum;
+            for (uint32_t t = 0; t < j->nthreads; t++) { size_t c = j->counts[(size_t)t * 2048 + b]; j->counts[(size_t)t * 2048 + b] = sum; sum += c; }
+        }
+        j->bucket_start[2048] = sum;
+    }
+    pthread_barrier_wait(j->bar);
+    for (uint32_t d = d0; d < d1; d++)
+        for (uint32_t k = 0; k < j->H; k++) {
+            const uint32_t h = orc_synth_hash(j->seed, j->first_doc + d, k, j->dist);
+            j->tmp[cnt[h >> 21]++] = ((uint64_t)h << 32) | (uint64_t)(j->first_doc + d);
+        }
+    pthread_barrier_wait(j->bar);
+    /* every 'nthreads'-th bucket: three stable passes over hash bits 0..6, 7..13, 14..20 (tmp -> out -> tmp -> out) */
+    for (uint32_t b = j->tid; b < 2048; b += j->nthreads) {
+        const size_t lo = j->bucket_start[b], n = j->bucket_start[b + 1] - lo;
+        uint64_t *src = j->tmp + lo, *dst = j->out + lo;
+        for (int pass = 0; pass < 3; pass++) {
+            size_t c[128] = {0};
+            const int shift = 32 + 7 * pass;
+            for (size_t i = 0; i < n; i++) c[(src[i] >> shift) & 127]++;
+            size_t sum = 0;
+            for (int v = 0; v < 128; v++) { size_t t = c[v]; c[v] = sum; sum += t; }
+            for (size_t i = 0; i < n; i++) dst[c[(src[i] >> shift) & 127]++] = src[i];
+            uint64_t *t = src; src = dst; dst = t;
+        }
+        /* (three passes: the sorted bucket ends in `out`) */
+    }
+    return NULL;
+}
+
+int orc_synth_items_sorted_mt(uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist, uint64_t *out, uint64_t *tmp, uint32_t nthreads)
+{
+    if (!out || !tmp || nthreads == 0 || nthreads > 256) return -1;
+    synth_mt_job *jobs = (synth_mt_job *)calloc(nthreads, sizeof *jobs);
+    pthread_t *th = (pthread_t *)malloc(nthreads * sizeof *th);
+    size_t *counts = (size_t *)malloc((size_t)nthreads * 2048 * sizeof(size_t)), *bstart = (size_t *)malloc(2049 * sizeof(size_t));
+    pthread_barrier_t bar;
+    if (!jobs || !th || !counts || !bstart || pthread_barrier_init(&bar, NULL, nthreads)) { free(jobs); free(th); free(counts); free(bstart); return -1; }
+    uint32_t started = 0;
+    for (; started < nthreads; started++) {
+        synth_mt_job *j = &jobs[started];
+        j->seed = seed; j->first_doc = first_doc; j->num_docs = num_docs; j->H = H; j->dist = dist; j->out = out; j->tmp = tmp;
+        j->nthreads = nthreads; j->tid = started; j->counts = counts; j->bucket_start = bstart; j->bar = &bar;
+        if (pthread_create(&th[started], NULL, synth_mt_worker, j)) break;
+    }
+    int rc = started == nthreads ? 0 : -1;               /* (a thread that could not start leaves the others at the barrier: fatal, not handled) */
+    for (uint32_t t = 0; t < started; t++) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&bar);
+    free(jobs); free(th); free(counts); free(bstart);
+    return rc;
+}
+
 void orc_sort_u64(uint64_t *v, size_t n)     /* LSD radix sort, 8 x 8 bits */
 {
     if (n < 2) return;

@@ -174,6 +174,8 @@ uint64_t orc_mix64(uint64_t x);
 /* hash j of document `doc` under `seed`; dist 0 = uniform u32, 1 = 2 % hot pool */
 uint32_t orc_synth_hash(uint64_t seed, uint32_t doc, uint32_t j, int dist);
 /* fill items[(doc-first_doc)*H + j] = hash<<32|doc for docs [first_doc, first_doc+num_docs), then sort */
+/* the same items SORTED by (hash, doc), on `nthreads` host threads; out, tmp: num_docs * H items each */
+int orc_synth_items_sorted_mt(uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist, uint64_t *out, uint64_t *tmp, uint32_t nthreads);
 void orc_synth_items(uint64_t seed, uint32_t first_doc, uint32_t num_docs, uint32_t H, int dist,
                      uint64_t *items);
 void orc_sort_u64(uint64_t *v, size_t n);

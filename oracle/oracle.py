@@ -95,6 +95,7 @@ def lib():
         "orc_mix64": (C.c_uint64, [C.c_uint64]),
         "orc_synth_hash": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
         "orc_synth_items": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]),
+        "orc_synth_items_sorted_mt": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint32]),
         "orc_sort_u64": (None, [vp, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
@@ -395,6 +396,15 @@ def synth_hash(seed, doc, j, dist=0):
 def synth_items(seed, first_doc, num_docs, H, dist=0):
     items = np.zeros(num_docs * H, np.uint64)
     lib().orc_synth_items(seed, first_doc, num_docs, H, dist, _ptr(items))
+    return items
+
+
+def synth_items_sorted(seed, first_doc, num_docs, H, dist=0, nthreads=8):
+    """a synthetic segment's items in (hash, doc) order, generated and sorted on `nthreads` host threads (orc_synth_items_sorted_mt)"""
+    items = np.empty(num_docs * H, np.uint64)
+    tmp = np.empty(num_docs * H, np.uint64)
+    if lib().orc_synth_items_sorted_mt(seed, first_doc, num_docs, H, dist, _ptr(items), _ptr(tmp), nthreads) != 0:
+        raise MemoryError("orc_synth_items_sorted_mt")
     return items
 
 

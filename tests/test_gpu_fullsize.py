@@ -94,7 +94,7 @@ def _oracle_sample(fpx, oracle, ctx, seg, first_doc, ndocs, flat, offsets, opts,
     assert (st.scanned_blocks, st.scanned_docs) == (blocks_seen, docs_seen)
 
 
-def _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, nq, out, out_n):
+def _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, nq, out, out_n, host_column=None):
     """The oracle over ALL segments (downloaded from HBM into host RAM: 107 GiB for the 100 M index, re-encoded from the group on
     the way) on the batch's first `nq` queries, against (a) what the FULL batch returned for them -- the headline path: one
     radix pass, k_probe_group<16, BINNED>, k_score_bin -- and (b) the per-query scanned blocks / docs of the full batch through
@@ -102,6 +102,10 @@ def _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, nq,
     osegs, keep = [], []
     for s, sg in enumerate(segs):
         blocks, index = sg.download()
+        if host_column is not None and host_column[0] == s:
+            # (the column that was written on the host: what the packed group gives back is those bytes)
+            assert np.array_equal(index, host_column[2]) and np.array_equal(np.frombuffer(blocks, np.uint8), np.frombuffer(host_column[1], np.uint8)), \
+                "fpx_segment_download of the host-built column differs from the bytes that were uploaded"
         keep.append((blocks, index))
         lo = s * per + 1
         ids = np.arange(lo, lo + per, dtype=np.uint32)
@@ -135,7 +139,28 @@ class TestHeadlineIndex:
         segs, per, docs = _build(fpx, ctx, 100_000_000, H, S, scratch=30 << 30)
         if os.environ.get("FPX_ALLOW_SHRINK") != "1":
             assert docs == 100_000_000
-        shared = {"ctx": ctx, "segs": segs, "per": per, "docs": docs, "H": H, "S": S}
+        # ---- column 3 of the sixteen is built ON THE HOST: its 1.6 G items generated and sorted by the oracle's threads, its blocks written by
+        #      the oracle's restatement of filefmt.writeBlocks (orc_build_blocks, src/filefmt.zig:94-138, src/block.zig:438-567) and uploaded
+        #      through fpx_segment_create_file -- so the full-size index holds blocks the GPU's encoder never saw.  The segment the GPU
+        #      synthesised for that column must hold the same bytes (its builder against the reference writer at FULL size), and what
+        #      fpx_segment_download re-encodes from the packed group later must be these bytes again (the oracle leg of the next test).
+        import time
+        from oracle import oracle
+        k = 3
+        t0 = time.perf_counter()
+        items = oracle.synth_items_sorted(SEED, k * per + 1, per, H, 0, nthreads=min(16, os.cpu_count() or 8))
+        t_items = time.perf_counter() - t0
+        hb, hi = oracle.build_blocks(items, k * per + 1, 512)
+        del items
+        t_host = time.perf_counter() - t0
+        gb, gi = segs[k].download()
+        assert np.array_equal(gi, hi), "block index: GPU builder vs the oracle's writer at full size"
+        assert len(gb) == len(hb) and np.array_equal(np.frombuffer(gb, np.uint8), np.frombuffer(hb, np.uint8)), "blocks: GPU builder vs the oracle's writer at full size"
+        del gb, gi
+        segs[k].release()
+        segs[k] = fpx.FileSegment(ctx, hb, 512, hi, k * per + 1, (k + 1) * per, k + 1, np.arange(k * per + 1, (k + 1) * per + 1, dtype=np.uint32))
+        print(f"column {k} built on the host: {per * H} items sorted in {t_items:.1f} s, blocks written by {t_host:.1f} s, uploaded by {time.perf_counter() - t0:.1f} s")
+        shared = {"ctx": ctx, "segs": segs, "per": per, "docs": docs, "H": H, "S": S, "host_column": (k, hb, hi)}
         yield shared
         shared.clear()
         for sg in segs:
@@ -296,7 +321,7 @@ class TestHeadlineIndex:
             assert (stp.scanned_blocks, stp.scanned_docs, stp.probes, stp.hits) == (st.scanned_blocks, st.scanned_docs, st.probes, st.hits)
         finally:
             ctx.set_option("query_wg", -1)
-        _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, 48, out, out_n)
+        _oracle_whole_index(fpx, oracle, reader, segs, per, flat, offsets, opts, 48, out, out_n, host_column=index100m.get("host_column"))
 
 
 def test_config1_10m_fingerprints_one_segment_batch_1024():

@@ -45,7 +45,7 @@ constexpr uint32_t QS_MAX_ROUNDS = 32;             // (a lane remembers which of
 #define FPX_QS_WORDS 12
 #endif
 #ifndef FPX_QS_CH
-#define FPX_QS_CH 4
+#define FPX_QS_CH 2
 #endif
 constexpr uint32_t QS_WORDS = FPX_QS_WORDS;                  // words of a hash walked by its lane (four 16-byte pieces of its line); the rare rest by the wave
 constexpr uint32_t QS_CH = FPX_QS_CH;                      // rounds whose line heads are under way together
@@ -154,7 +154,6 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         }
     };
     load_hashes(0u);
-    issue_heads(0u);
   for (;;) {
     const uint32_t rounds = (n + QS_WG - 1u) / QS_WG, nchunks = (rounds + QS_CH - 1u) / QS_CH;
     // the query's hash set: 2^sbits >= 2 n slots
@@ -250,7 +249,35 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     };
 
     // ---- FileSegment.search for every column, a hash per lane and round (fpx_pgroup.hpp: the line's layout)
-    auto probe = [&](uint32_t h, uint3 head, bool valid) {
+    // (the words of a hash the lane walks itself -- up to QS_WORDS, as far as they are in the line -- asked for as soon as the line's head is
+    // there: the line is still in the L2 then.  Asked for a few rounds later -- round 6's first form fetched all heads up front -- the line
+    // had been evicted and was fetched from memory AGAIN: 2.27 requests per query hash, profiles/r06_bench.json)
+    auto words_of = [&](uint32_t h, uint3 head, bool valid, uint32_t (&gw)[QS_WORDS]) {
+        const uint64_t bits = valid ? (((uint64_t)head.y << 32) | head.x) : 0ull;
+        const uint32_t dfl = valid ? head.z : 0u;
+        const uint32_t sh = (h & ((1u << HVL) - 1u)) * (uint32_t)NS;
+        const uint32_t pm = (uint32_t)(bits >> sh) & ((1u << NS) - 1u);
+        const uint32_t pos0 = (uint32_t)__popcll(bits & ((1ull << sh) - 1ull));
+        const uint32_t k = (uint32_t)__popc(pm);
+        const uint32_t dbl_before = pos0 >= 32u ? (uint32_t)__popc(dfl) : (uint32_t)__popc(dfl & ((1u << pos0) - 1u));
+        const uint32_t dm = pos0 >= 32u ? 0u : ((dfl >> pos0) & ((1u << k) - 1u));
+        const uint32_t nwords = k + (uint32_t)__popc(dm);
+        const uint32_t n_line = (uint32_t)__popcll(bits) + (uint32_t)__popc(dfl);
+        const uint32_t inl = n_line > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;
+        const uint32_t start = pos0 + dbl_before;
+        const uint32_t mine = min(min(nwords, QS_WORDS), start < inl ? inl - start : 0u);
+#pragma unroll
+        for (uint32_t i = 0; i < QS_WORDS; ++i) gw[i] = 0xFFFFFFFFu;
+        const uint32_t* lp = line_of(h) + 3u + start;
+#pragma unroll
+        for (uint32_t i = 0; i < QS_WORDS / 4; ++i) {
+            if (mine > 4u * i) {
+                const uint4 v = gload_u4_a4(lp + 4u * i);
+                gw[4 * i] = v.x; gw[4 * i + 1] = v.y; gw[4 * i + 2] = v.z; gw[4 * i + 3] = v.w;
+            }
+        }
+    };
+    auto probe = [&](uint32_t h, uint3 head, bool valid, uint32_t (&gw)[QS_WORDS]) {
         if (valid) { my_probes += nactive; my_reads += 2u; }
         const uint64_t bits = valid ? (((uint64_t)head.y << 32) | head.x) : 0ull;
         const uint32_t dfl = valid ? head.z : 0u;
@@ -274,19 +301,6 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         const uint32_t inl = n_line > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;
         const uint32_t start = pos0 + dbl_before;
         const uint32_t mine = min(min(nwords, QS_WORDS), start < inl ? inl - start : 0u);
-        uint32_t gw[QS_WORDS];
-#pragma unroll
-        for (uint32_t i = 0; i < QS_WORDS; ++i) gw[i] = 0xFFFFFFFFu;
-        {
-            const uint32_t* lp = line_of(h) + 3u + start;
-#pragma unroll
-            for (uint32_t i = 0; i < QS_WORDS / 4; ++i) {
-                if (mine > 4u * i) {
-                    const uint4 v = gload_u4_a4(lp + 4u * i);
-                    gw[4 * i] = v.x; gw[4 * i + 1] = v.y; gw[4 * i + 2] = v.z; gw[4 * i + 3] = v.w;
-                }
-            }
-        }
         // second words of doubles: the t-th double, at position i, has its second word at i + t + 1
         uint32_t second = 0;
         for (uint32_t d = dm, t = 0; d != 0u; d &= d - 1u, ++t) second |= 1u << ((uint32_t)__builtin_ctz(d) + t + 1u);
@@ -339,18 +353,17 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         }
     };
 
+    static_assert(QS_CH == 2, "the rounds run in pairs");
     for (uint32_t c = 0; c < nchunks; ++c) {
-        if (c != 0u) { load_hashes(c); issue_heads(c); }
-        // (ONE copy of the round's code: the chunk's hashes and heads move up a register each round -- unrolled four times the kernel is
-        // 50 KB of instructions)
-#pragma nounroll
-        for (uint32_t u = 0; u < QS_CH; ++u) {
-            const uint32_t round = c * QS_CH + u;
-            if (round >= rounds) break;                                                    // (uniform)
-            probe(hh[0], hd[0], ((vmask >> round) & 1u) != 0u);
-#pragma unroll
-            for (uint32_t v = 0; v + 1 < QS_CH; ++v) { hh[v] = hh[v + 1]; hd[v] = hd[v + 1]; }
-        }
+        // two rounds at a time: their line heads, then -- as the heads arrive -- the words of both, then both rounds out of registers
+        if (c != 0u) load_hashes(c);
+        issue_heads(c);
+        const bool v0 = ((vmask >> (c * QS_CH)) & 1u) != 0u, v1 = ((vmask >> (c * QS_CH + 1u)) & 1u) != 0u;
+        uint32_t gw0[QS_WORDS], gw1[QS_WORDS];
+        words_of(hh[0], hd[0], v0, gw0);
+        words_of(hh[1], hd[1], v1, gw1);
+        probe(hh[0], hd[0], v0, gw0);
+        if (c * QS_CH + 1u < rounds) probe(hh[1], hd[1], v1, gw1);                        // (uniform)
     }
     __syncthreads();
     QS_MARK(2);
@@ -468,15 +481,15 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     QS_MARK(3);
     const uint32_t nrec = min(s_count, QS_REC_CAP);
     // ---- SearchResults.incr (src/common.zig:121-129), first the filter: every record into its doc's cell
-    for (uint32_t i = tid; i < nrec; i += QS_WG) {
-        const uint32_t c = qs_cell(recs[i]);
-        atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
-    }
-    if (has_next) {                                      // ... and the heads of its first lines (its hashes have arrived by now)
-        const uint32_t n_keep = n;
-        n = nn;
-        issue_heads(0u);
-        n = n_keep;
+    // (four records per lane and turn, read as one 16-byte piece: the loop is a chain of LDS latencies -- a record, then its cell)
+    for (uint32_t i = tid * 4u; i < nrec; i += QS_WG * 4u) {
+        const uint4 r4 = *reinterpret_cast<const uint4*>(recs + i);             // (the array ends with four spare words)
+        const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t c = qs_cell(r[u]);
+            if (i + u < nrec) atomicAdd(&filter[c >> 1], 1u << (16u * (c & 1u)));
+        }
     }
     if (tid == 0) {
         unsigned long long* st = a.stat_sets + (size_t)(q % LEAN_STAT_SETS) * 8u;
@@ -506,11 +519,16 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
             }
             if (tid == 0) { s_claimed = 0u; s_full = 0u; }
             __syncthreads();                            // (the first pass: the filter's counts are complete behind this barrier)
-            for (uint32_t i = tid; i < nrec; i += QS_WG) {
-                const uint32_t doc = recs[i];
-                const uint32_t c = qs_cell(doc);
-                const uint32_t cc = (filter[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu;
-                if (cc < floor_q) continue;
+            for (uint32_t i4 = tid * 4u; i4 < nrec; i4 += QS_WG * 4u) {
+              const uint4 r4 = *reinterpret_cast<const uint4*>(recs + i4);
+              const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+              uint32_t cnt4[4];
+#pragma unroll
+              for (uint32_t u = 0; u < 4u; ++u) { const uint32_t c = qs_cell(r[u]); cnt4[u] = (filter[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu; }
+#pragma unroll
+              for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t doc = r[u];
+                if (i4 + u >= nrec || cnt4[u] < floor_q) continue;
                 const uint32_t h2 = mix32(doc);
                 if (passes > 1u && (h2 >> 16) % passes != pass) continue;
                 const unsigned long long keyhi = (unsigned long long)doc << 32;
@@ -526,6 +544,7 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
                     if ((cur >> 32) == (keyhi >> 32)) { atomicAdd(&table[s], 1ull); break; }
                     s = (s + 1u) & TMASK;
                 }
+              }
             }
             __syncthreads();
             if (pass == 0u && (s_claimed > T * 3u / 4u || s_full != 0u) && passes < 64u) {

@@ -31,3 +31,5 @@ for pass_ in "abc":
         if ds:
             print(pass_, k, {c: round(v) for c, v in agg[(k, max(ds))].items()})
 PY
+# (the raw counter CSVs are tens of MB each: gpurun copies back at most 64 MiB)
+rm -rf $R/gpurun_out/$tag/a $R/gpurun_out/$tag/b $R/gpurun_out/$tag/c

@@ -24,3 +24,21 @@ except Exception as e:
 PY
   done
 done
+if [ "${PMC:-0}" = 1 ]; then
+  # memory-side requests of k_search_query per launch (the same counters and child as bench.py's in-run pass)
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/qs_pmc
+  rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d /tmp/qs_pmc -o pmc -- \
+    python $R/bench.py --pmc-child --steps 2 --warmup 2 > /tmp/qs_pmc.log 2>&1
+  python - <<PY
+import sys
+sys.path.insert(0, "$R")
+import bench
+by = bench.parse_pmc_dir("/tmp/qs_pmc")
+for k in ("k_search_query", "k_probe_pgroup"):
+    if by and by.get(k):
+        c = by[k][-1]
+        print(k, "read requests %.3f M" % (c.get("TCC_EA0_RDREQ_sum", 0) / 1e6), "write requests %.3f M" % (c.get("TCC_EA0_WRREQ_sum", 0) / 1e6), "read GB %.3f" % (bench.ea_read_bytes(c) / 1e9))
+PY
+  rm -rf /tmp/qs_pmc
+fi

@@ -206,19 +206,20 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     // ---- records.  `n` docs of the lane (mask km over d[]) join the query's array: one reservation per wave -- a scan on the DPP
     //      crossbar: the whole wave is here (fpx_pgroup.hpp x5) --, doc j at pos + (docs of the lane before it); a slot without a doc
     //      writes the sink word behind the array (no branch per slot).  The filter is counted later, over the array (every lane busy).
-    auto reserve = [&](uint32_t cnt) -> uint32_t {
+    auto reserve_in = [&](uint32_t* counter, uint32_t cnt) -> uint32_t {
         const uint32_t incl = scan16(cnt);
         const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31),
                        r2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47), r3 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t total = r0 + r1 + r2 + r3;
         uint32_t wbase = 0;
         if (total != 0u) {                                                       // (wave-uniform)
-            if (lane == 0u) wbase = atomicAdd(&s_count, total);
+            if (lane == 0u) wbase = atomicAdd(counter, total);
             wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
         }
         const uint32_t row = lane >> 4;
         return wbase + (row >= 1u ? r0 : 0u) + (row >= 2u ? r1 : 0u) + (row >= 3u ? r2 : 0u) + (incl - cnt);
     };
+    auto reserve = [&](uint32_t cnt) -> uint32_t { return reserve_in(&s_count, cnt); };
     auto emit = [&](uint32_t km, const auto& d) {
         constexpr uint32_t N = sizeof(d) / sizeof(uint32_t);
         const uint32_t cnt = (uint32_t)__popc(km);
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     // (the words of a hash the lane walks itself -- up to QS_WORDS, as far as they are in the line -- asked for as soon as the line's head is
     // there: the line is still in the L2 then.  Asked for a few rounds later -- round 6's first form fetched all heads up front -- the line
     // had been evicted and was fetched from memory AGAIN: 2.27 requests per query hash, profiles/r06_bench.json)
-    auto words_of = [&](uint32_t h, uint3 head, bool valid, uint32_t (&gw)[QS_WORDS]) {
+    // (... and what the walk needs of the head's arithmetic, packed: start | mine << 7 | nwords << 11 | inl << 17, and pm | dm << 16)
+    auto words_of = [&](uint32_t h, uint3 head, bool valid, uint32_t (&gw)[QS_WORDS], uint32_t& hx, uint32_t& hy) {
         const uint64_t bits = valid ? (((uint64_t)head.y << 32) | head.x) : 0ull;
         const uint32_t dfl = valid ? head.z : 0u;
         const uint32_t sh = (h & ((1u << HVL) - 1u)) * (uint32_t)NS;
@@ -276,14 +278,13 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
                 gw[4 * i] = v.x; gw[4 * i + 1] = v.y; gw[4 * i + 2] = v.z; gw[4 * i + 3] = v.w;
             }
         }
+        hx = start | (mine << 7) | (nwords << 11) | (inl << 17);          // (start <= 96, mine <= 12, nwords <= 32, inl <= 29)
+        hy = pm | (dm << 16);
     };
-    auto probe = [&](uint32_t h, uint3 head, bool valid, uint32_t (&gw)[QS_WORDS]) {
+    auto probe = [&](uint32_t h, uint32_t hx, uint32_t hy, bool valid, uint32_t (&gw)[QS_WORDS]) {
         if (valid) { my_probes += nactive; my_reads += 2u; }
-        const uint64_t bits = valid ? (((uint64_t)head.y << 32) | head.x) : 0ull;
-        const uint32_t dfl = valid ? head.z : 0u;
-        const uint32_t sh = (h & ((1u << HVL) - 1u)) * (uint32_t)NS;
-        const uint32_t pm = (uint32_t)(bits >> sh) & ((1u << NS) - 1u);
-        const uint32_t pos0 = (uint32_t)__popcll(bits & ((1ull << sh) - 1ull));
+        const uint32_t pm = hy & 0xFFFFu, dm = hy >> 16;
+        const uint32_t start = hx & 127u, mine = (hx >> 7) & 15u, nwords = (hx >> 11) & 63u, inl = (hx >> 17) & 31u;
         // (outside [first_hash, last_hash] the reference visits no block, src/FileSegment.zig:164,153)
         uint32_t inr = active;
         if (h < g->lo_all || h > g->hi_all) {
@@ -293,14 +294,6 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         }
         if (!valid) inr = 0u;
         my_blocks += (uint32_t)__popc(inr & active & ~pm);         // absent: the reference visits one block, finds nothing and stops
-        const uint32_t k = (uint32_t)__popc(pm);
-        const uint32_t dbl_before = pos0 >= 32u ? (uint32_t)__popc(dfl) : (uint32_t)__popc(dfl & ((1u << pos0) - 1u));
-        const uint32_t dm = pos0 >= 32u ? 0u : ((dfl >> pos0) & ((1u << k) - 1u));
-        const uint32_t nwords = k + (uint32_t)__popc(dm);
-        const uint32_t n_line = (uint32_t)__popcll(bits) + (uint32_t)__popc(dfl);
-        const uint32_t inl = n_line > GROUP_INLINE ? GROUP_INLINE - 1u : GROUP_INLINE;
-        const uint32_t start = pos0 + dbl_before;
-        const uint32_t mine = min(min(nwords, QS_WORDS), start < inl ? inl - start : 0u);
         // second words of doubles: the t-th double, at position i, has its second word at i + t + 1
         uint32_t second = 0;
         for (uint32_t d = dm, t = 0; d != 0u; d &= d - 1u, ++t) second |= 1u << ((uint32_t)__builtin_ctz(d) + t + 1u);
@@ -321,7 +314,15 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         // ---- what the round does not wait for joins the query's task queue -- the hash's lists (their heads are other lines: HBM), its
         //      words beyond the lane's own and those that overflowed the line into `ext` --; the workgroup takes the tasks up together
         //      once its rounds are done
-        if (lmask != 0u || nwords != mine) {
+        // (their places in the queue: one reservation per wave, a scan on the DPP crossbar -- a lane's own atomic on the one counter is compiled
+        // into a serial loop over the wave's lanes)
+        const uint32_t in_line = (nwords != mine && start + mine < inl) ? min(nwords - mine, inl - (start + mine)) : 0u;
+        const uint32_t in_ext = nwords - mine - in_line;
+        const uint32_t nt = (uint32_t)__popc(lmask) + (in_line + QS_TASK_WORDS - 1u) / QS_TASK_WORDS + (in_ext + QS_TASK_WORDS - 1u) / QS_TASK_WORDS;
+        uint32_t tat = reserve_in(&s_ntask, nt);
+        if (nt != 0u) {
+            if (tat + nt > QS_TASKS) { s_over_recs = 1u; tat = QS_TASKS; }        // (a full queue: the batch goes the long way)
+            auto put_task = [&](unsigned long long e) { if (tat < QS_TASKS) tasks[tat] = e; ++tat; };
             const uint32_t chunk = (h >> GROUP_CHUNK_LOG2) - g->chunk0;
             const uint32_t* ext = s_ext[chunk];
             uint32_t lm = lmask;
@@ -331,13 +332,13 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
                 uint32_t e = 0;
 #pragma unroll
                 for (uint32_t j = 0; j < QS_WORDS; ++j) e = j == j0 ? gw[j] : e;
-                push_task(qs_task_list(ext + (e & 0x7FFFFFFFu), chunk));
+                put_task(qs_task_list(ext + (e & 0x7FFFFFFFu), chunk));
             }
             uint32_t j = mine;
             // ... words still in the line (the hash has more than the lane walks)
-            while (j < nwords && start + j < inl) {
-                const uint32_t c = min(min(nwords - j, inl - (start + j)), QS_TASK_WORDS);
-                push_task(qs_task_words(line_of(h) + 3u + start + j, c, second >> j, chunk));
+            while (j < mine + in_line) {
+                const uint32_t c = min(mine + in_line - j, QS_TASK_WORDS);
+                put_task(qs_task_words(line_of(h) + 3u + start + j, c, second >> j, chunk));
                 j += c;
             }
             // ... and behind its end, in `ext` at the offset the line's last word holds
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
                 const uint32_t* ob = ext + gload_u32(line_of(h) + (GROUP_LINE_WORDS - 1u));
                 while (j < nwords) {                     // (start + j >= inl here)
                     const uint32_t c = min(nwords - j, QS_TASK_WORDS);
-                    push_task(qs_task_words(ob + (start + j - inl), c, second >> j, chunk));
+                    put_task(qs_task_words(ob + (start + j - inl), c, second >> j, chunk));
                     j += c;
                 }
                 my_reads += 2u;
@@ -359,11 +360,11 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         if (c != 0u) load_hashes(c);
         issue_heads(c);
         const bool v0 = ((vmask >> (c * QS_CH)) & 1u) != 0u, v1 = ((vmask >> (c * QS_CH + 1u)) & 1u) != 0u;
-        uint32_t gw0[QS_WORDS], gw1[QS_WORDS];
-        words_of(hh[0], hd[0], v0, gw0);
-        words_of(hh[1], hd[1], v1, gw1);
-        probe(hh[0], hd[0], v0, gw0);
-        if (c * QS_CH + 1u < rounds) probe(hh[1], hd[1], v1, gw1);                        // (uniform)
+        uint32_t gw0[QS_WORDS], gw1[QS_WORDS], hx0, hy0, hx1, hy1;
+        words_of(hh[0], hd[0], v0, gw0, hx0, hy0);
+        words_of(hh[1], hd[1], v1, gw1, hx1, hy1);
+        probe(hh[0], hx0, hy0, v0, gw0);
+        if (c * QS_CH + 1u < rounds) probe(hh[1], hx1, hy1, v1, gw1);                    // (uniform)
     }
     __syncthreads();
     QS_MARK(2);

@@ -1,26 +1,28 @@
 #!/bin/bash
-# round 6: parity tests of k_search_query, then the headline batch (one and three in flight) with the product's library [and variants]
+# tools/qs_ab.sh -- A/B of k_search_query builds on ONE box: TESTS=1 its parity tests first; VARIANTS="base <name> ..." (base = the product, the others
+# acoustid-index_amd/build/exp/libfpx_<name>.so from tools/build_variant.sh) x NFL="1 3" batches in flight on the headline batch; PMC=1 the memory-side
+# requests per launch afterwards.  Replaces the round-5 / round-6 one-off recipes (profile_r05_b .. y, r06_qs_*).
 cd "$(dirname "$0")/.."
 R=$(pwd)
-mkdir -p gpurun_out/r06_qsr
+mkdir -p gpurun_out/qs_ab
 if [ "${TESTS:-1}" = 1 ]; then
-  timeout 900 python -m pytest tests/test_gpu_query_wg.py -x -q 2>&1 | tail -30 > gpurun_out/r06_qsr/tests.txt
-  tail -12 gpurun_out/r06_qsr/tests.txt
+  timeout 900 python -m pytest tests/test_gpu_query_wg.py -x -q 2>&1 | tail -30 > gpurun_out/qs_ab/tests.txt
+  tail -12 gpurun_out/qs_ab/tests.txt
 fi
 for v in ${VARIANTS:-base}; do
   lib=$R/acoustid-index_amd/build/exp/libfpx_$v.so
   [ $v = base ] && lib=$R/acoustid-index_amd/libfpx.so
   for nfl in ${NFL:-1 3}; do
     FPX_LIB=$lib FPX_BENCH_LONG=0 timeout ${BENCH_TIMEOUT:-150} python bench.py --no-cpu-baseline --no-extras --no-measure-bw --steps 60 --inflight $nfl \
-      > gpurun_out/r06_qsr/${v}_nfl${nfl}.json 2> gpurun_out/r06_qsr/${v}_nfl${nfl}.err
+      > gpurun_out/qs_ab/${v}_nfl${nfl}.json 2> gpurun_out/qs_ab/${v}_nfl${nfl}.err
     python - <<PY
 import json
 try:
-    r = json.loads(open("gpurun_out/r06_qsr/${v}_nfl${nfl}.json").read().strip().splitlines()[-1])
+    r = json.loads(open("gpurun_out/qs_ab/${v}_nfl${nfl}.json").read().strip().splitlines()[-1])
     print("$v", "inflight", $nfl, "ms_per_step %.4f" % r["ms_per_step"], "kernel_ms %.4f" % r["roofline"]["avg_launch_ms"], "gpu_ms %.4f" % r["gpu_ms_per_step"], "found", r["targets_found"], r["roofline"]["kernel"], "hits", r["hits_per_step"])
 except Exception as e:
     print("$v", "inflight", $nfl, "failed", e)
-    print(open("gpurun_out/r06_qsr/${v}_nfl${nfl}.err").read()[-800:])
+    print(open("gpurun_out/qs_ab/${v}_nfl${nfl}.err").read()[-800:])
 PY
   done
 done

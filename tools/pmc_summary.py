@@ -8,7 +8,7 @@ import os
 import sys
 
 d = sys.argv[1]
-want = ("k_probe", "k_bw_", "k_score_bin", "k_make_keys", "Onesweep")
+want = ("k_search", "k_probe", "k_bw_", "k_score_bin", "k_make_keys", "Onesweep")
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):

@@ -71,6 +71,8 @@ struct QSearchArgs {
     unsigned long long* stat_sets;                             // [LEAN_STAT_SETS][8] statistics + [LEAN_STAT_SETS][HIST_SLOTS] histogram slots
     unsigned long long* qstats;                                // [B] blocks | docs << 32, or null
     const uint32_t* cancel;
+    // a live index's memory segments: their ONE hash-sorted table of live postings (fpx_probe_small.hpp: k_probe_memtab), or null
+    const uint64_t* mem_tab; const uint32_t* mem_bucket; const uint32_t* mem_bits;
 };
 
 #define FPX_QS_OCC __attribute__((amdgpu_waves_per_eu(FPX_QS_WAVES)))
@@ -101,7 +103,8 @@ __device__ __forceinline__ const uint32_t* qs_task_ptr(unsigned long long e) { r
 #else
 #define QS_MARK(i) do { } while (0)
 #endif
-template <int NS, bool QS>
+// (MEM: the snapshot has memory segments -- an instantiation of its own: their look-up costs the usual one registers)
+template <int NS, bool QS, bool MEM>
 __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a, GroupArgs ga)
 {
 #ifdef FPX_QS_PROF
@@ -172,12 +175,21 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     // ---- dedupSorted (src/Index.zig:171-172,489-499): the first occurrence of a hash is the probe, later ones are dropped.  A lane notes
     //      which of its rounds' hashes are probes (a hash-window slice of the group leaves the other hashes to another rank)
     uint32_t vmask = 0u;
+    uint32_t mmask = 0u;                                // (MEM) ... and which of them the memory segments' table may hold: a bit per 256 hash values
     for (uint32_t c = 0; c < nchunks; ++c) {
         uint32_t hc[QS_CH];
+        uint32_t mb[QS_CH];
 #pragma unroll
         for (uint32_t u = 0; u < QS_CH; ++u) {
             const uint32_t i = (c * QS_CH + u) * QS_WG + tid;
             hc[u] = c == 0u ? hh[u] : (i < n ? gload_u32(qh + i) : 0u);
+        }
+        if constexpr (MEM) {                            // (their bit words travel under the set's compare-and-swaps)
+#pragma unroll
+            for (uint32_t u = 0; u < QS_CH; ++u) {
+                const uint32_t i = (c * QS_CH + u) * QS_WG + tid;
+                mb[u] = (i < n && a.mem_bits != nullptr) ? gload_u32(a.mem_bits + ((hc[u] >> MEMTAB_FILTER_SHIFT) >> 5)) : 0xFFFFFFFFu;
+            }
         }
 #pragma unroll
         for (uint32_t u = 0; u < QS_CH; ++u) {
@@ -195,9 +207,13 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
                     slot = (slot + 1u) & ((1u << sbits) - 1u);
                 }
             }
-            if (!dup && h >= g->win_lo && h <= g->win_hi) vmask |= 1u << (c * QS_CH + u);
+            if (!dup && h >= g->win_lo && h <= g->win_hi) {
+                vmask |= 1u << (c * QS_CH + u);
+                if constexpr (MEM) mmask |= ((mb[u] >> ((h >> MEMTAB_FILTER_SHIFT) & 31u)) & 1u) << (c * QS_CH + u);
+            }
         }
     }
+    (void)mmask;
     __syncthreads();                                    // (the set is done with: its slots are the record array now)
     QS_MARK(1);
 
@@ -365,6 +381,33 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         words_of(hh[1], hd[1], v1, gw1, hx1, hy1);
         probe(hh[0], hx0, hy0, v0, gw0);
         if (c * QS_CH + 1u < rounds) probe(hh[1], hx1, hy1, v1, gw1);                    // (uniform)
+    }
+    // ---- MemorySegment.search (src/MemorySegment.zig:44-54) for all memory segments at once: the query's probes looked up in the snapshot's
+    //      table of their live postings -- a bit per 256 hash values says "nothing there" for nine probes in ten --, four rounds' loads out
+    //      together; every matching item is a record (a doc a newer segment supersedes was dropped when the table was built)
+    if constexpr (MEM) {
+        for (uint32_t c0 = 0; c0 < rounds; c0 += 4u) {
+            if (__ballot((int)(((mmask >> c0) & 15u) != 0u)) == 0ull) continue;          // (wave-uniform: nine probes in ten have nothing there)
+            uint32_t mh[4], blo[4], bhi[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const bool act = ((mmask >> (c0 + u)) & 1u) != 0u;
+                mh[u] = act ? gload_u32(qh + (c0 + u) * QS_WG + tid) : 0u;
+                const uint32_t b = mh[u] >> (32u - MEMTAB_BITS);
+                blo[u] = act ? gload_u32(a.mem_bucket + b) : 0u;
+                bhi[u] = act ? gload_u32(a.mem_bucket + b + 1u) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u)
+                for (uint32_t i = blo[u]; i < bhi[u]; ++i) {                       // (a bucket holds a posting or two)
+                    const uint64_t it = gload_u64(a.mem_tab + i);
+                    if ((uint32_t)(it >> 32) > mh[u]) break;
+                    if ((uint32_t)(it >> 32) == mh[u]) {
+                        const uint32_t at = atomicAdd(&s_count, 1u);
+                        if (at < QS_REC_CAP) recs[at] = (uint32_t)it; else s_over_recs = 1u;
+                    }
+                }
+        }
     }
     __syncthreads();
     QS_MARK(2);

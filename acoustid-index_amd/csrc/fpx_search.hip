@@ -453,7 +453,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     //      Anything else, and a batch that kernel hands back (hot hashes: a query's records outgrow its LDS array), runs the pipeline below.
     bool qs_path = false;
     if (!ex && !no_fast && !no_qs && !single_fast && B >= 2u && P != 0 && qb <= 24u && snap->n_file == 0 && snap->n_solo == 0 && snap->n_group == 1 &&
-        snap->n_direct != 0 && (snap->n_mem == 0 || snap->mem_items == 0) && snap->groups[0]->packed && ctx_opt(snap->ctx, OPT_QUERY_WG) != 0) {
+        snap->n_direct != 0 && (snap->n_mem == 0 || snap->mem_items == 0 || snap->d_memtab != nullptr) && snap->groups[0]->packed && ctx_opt(snap->ctx, OPT_QUERY_WG) != 0) {
         const GroupDesc& gd = snap->h_group[0];
         qs_path = gd.any_dead == 0u && gd.active == (gd.nseg >= 32u ? 0xFFFFFFFFu : ((1u << gd.nseg) - 1u));
         for (uint32_t q = 0; q < B && qs_path; ++q) {
@@ -640,6 +640,7 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         qa.cands = ws->d_cands[0]; qa.cand_cap = ws->cap_cands; qa.qcand = d_qcand; qa.qcand_n = d_qcand_n;
         qa.counters = ws->d_counters; qa.stat_sets = reinterpret_cast<unsigned long long*>(ws->d_def_count + def_stat_off);
         qa.qstats = want_q ? ws->d_qstats : nullptr; qa.cancel = cancel;
+        if (snap->n_mem != 0 && snap->mem_items != 0) { qa.mem_tab = snap->d_memtab; qa.mem_bucket = snap->d_membucket; qa.mem_bits = snap->d_membits; }
         const GroupArgs gargs{gd, snap->d_direct};
         // as many workgroups as the chip holds at once (LDS: QS_WGS_PER_CU per CU); each takes every gridDim.x-th query
         static std::atomic<int> cus_of[64];
@@ -653,12 +654,14 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             if (qa.q_end == qa.q_begin) continue;
             if (up_chunks) FPX_HIP(hipStreamWaitEvent(st, ws->ev_chunk[c], 0));           // (the piece's hashes have arrived; the next piece is on its way)
             const dim3 qgrid(std::min<uint32_t>(qa.q_end - qa.q_begin, (uint32_t)cus * QS_WGS_PER_CU));
+            const bool mem = qa.mem_tab != nullptr;
+            auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs); };
             if (grp->ns == 8u) {
-                if (want_q) hipLaunchKernelGGL((k_search_query<8, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
-                else hipLaunchKernelGGL((k_search_query<8, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+                if (mem) { if (want_q) launch(k_search_query<8, true, true>); else launch(k_search_query<8, false, true>); }
+                else { if (want_q) launch(k_search_query<8, true, false>); else launch(k_search_query<8, false, false>); }
             } else {
-                if (want_q) hipLaunchKernelGGL((k_search_query<16, true>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
-                else hipLaunchKernelGGL((k_search_query<16, false>), qgrid, dim3(QS_WG), QS_LDS_BYTES, st, qa, gargs);
+                if (mem) { if (want_q) launch(k_search_query<16, true, true>); else launch(k_search_query<16, false, true>); }
+                else { if (want_q) launch(k_search_query<16, true, false>); else launch(k_search_query<16, false, false>); }
             }
         }
         FPX_HIP(hipGetLastError());

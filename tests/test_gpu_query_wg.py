@@ -208,3 +208,50 @@ def test_a_large_batch_from_host_memory_is_uploaded_in_pieces(env, monkeypatch):
     got2, _ = p.reader.search_batch(queries, opts)                                    # (the workspace's second batch: its buffers are there)
     assert got2 == got
     qb.release()
+
+
+def test_a_live_index_memory_segments_next_to_the_group(env, monkeypatch):
+    """Index.update publishes a snapshot with a new MemorySegment per commit (src/Index.zig:515-587): their ONE hash-sorted table of live postings is
+    looked up by the query's workgroup too (MemorySegment.search, src/MemorySegment.zig:44-54) -- the snapshot stays on the query-per-workgroup path
+    as long as no doc of the group is superseded; a memory segment that re-inserts a doc of a file segment sends it to the pipeline.  Both == the oracle."""
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    ctx.set_option("group_packed", 1)
+
+    def world(reinsert):
+        rng = np.random.default_rng(4242)
+        p = Pair(ctx)
+        per, allitems = 3000, []
+        for s in range(4):
+            first = s * per + 1
+            items = _items(rng, s, per, first, 40)
+            p.add_file(items, first, first + per - 1, s + 1, np.arange(first, first + per, dtype=np.uint32))
+            allitems.append(items)
+        for m in range(5):                                        # five commits of 60 new docs each; a hash shared with the file segments among them
+            first = 4 * per + 1 + m * 60
+            docs = np.arange(first, first + 60, dtype=np.uint64)
+            ids = list(range(first, first + 60))
+            h = rng.integers(0, 1 << 32, (60, 48), dtype=np.uint64)
+            items = [((h << np.uint64(32)) | docs[:, None]).ravel(), (np.uint64(SHARED) << np.uint64(32)) | docs[:3]]
+            if reinsert and m == 2:
+                ids.append(17)                                     # doc 17 of the first file segment, written again
+                items.append((rng.integers(0, 1 << 32, 48, dtype=np.uint64) << np.uint64(32)) | np.uint64(17))
+            items = np.unique(np.concatenate(items))
+            p.add_memory(items, min(ids), max(ids), 5 + m, np.array(sorted(ids), dtype=np.uint32))
+            allitems.append(items)
+        p.finish()
+        return p, allitems, rng
+    try:
+        p, allitems, rng = world(False)
+        queries = [_query(rng, allitems, i, 1000) for i in range(40)]      # (every ninth query aims at a doc of a memory segment)
+        for opts in (fpx.http_options(), fpx.SearchOptions(max_results=100, min_score=3, min_score_pct=0)):
+            got, st = p.check(queries, opts)
+            assert st.path_flags & 64, st.path_flags
+        mem_hits = sum(1 for i, g in enumerate(got) if g and g[0][0] > 12000)
+        assert mem_hits >= 10, "no query found its doc in a memory segment"
+        p2, allitems2, rng2 = world(True)
+        queries2 = [_query(rng2, allitems2, i, 1000) for i in range(40)]
+        got2, st2 = p2.check(queries2, fpx.http_options())
+        assert not st2.path_flags & 64, "a superseded doc in the group: the pipeline filters per posting"
+    finally:
+        ctx.set_option("group_packed", -2)

@@ -975,7 +975,7 @@ def main():
     #      ordinary pageable arrays and from page-locked ones (fpx_host_alloc), one batch in flight and as many as the headline
     if extras:
         copts = qb.copts
-        k3 = max(6, args.steps // 2)
+        k3 = max(48, args.steps)               # (ten calls were mostly the pipeline filling: 8.8 M where sixty give 11.4 M)
 
         def e2e(src_flats, bufs, inflight):
             def one(i):

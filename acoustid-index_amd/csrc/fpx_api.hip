@@ -232,11 +232,95 @@ static void set_docs(Segment* s, const uint32_t* ids, const uint8_t* alive, uint
     }
 }
 
+// ---- VmBuf (fpx_internal.h)
+bool VmBuf::supported(int device)
+{
+    static std::atomic<int> known[64];                          // 0: not asked yet, 1: no, 2: yes
+    std::atomic<int>& k = known[(unsigned)device & 63u];
+    int v = k.load(std::memory_order_relaxed);
+    if (v == 0) {
+        const char* e = getenv("FPX_VM");
+        int attr = 0;
+        v = (e && e[0] == '0') ? 1 : (hipDeviceGetAttribute(&attr, hipDeviceAttributeVirtualMemoryManagementSupported, device) == hipSuccess && attr) ? 2 : 1;
+        (void)hipGetLastError();
+        k.store(v, std::memory_order_relaxed);
+    }
+    return v == 2;
+}
+int VmBuf::reserve(int dev, size_t bytes, size_t piece_bytes)
+{
+    device = dev; piece = piece_bytes;
+    const size_t n = (bytes + piece - 1) / piece;
+    void* p = nullptr;
+    if (hipMemAddressReserve(&p, n * piece, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return FPX_E_NOMEM; }
+    va = static_cast<uint8_t*>(p); reserved = n * piece;
+    handles.assign(n, hipMemGenericAllocationHandle_t{}); mapped.assign(n, 0);
+    return FPX_OK;
+}
+int VmBuf::map_range(size_t lo, size_t hi)
+{
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t i = lo / piece; i < handles.size() && i * piece < hi; ++i) {
+        if (mapped[i]) continue;
+        hipError_t e = hipMemCreate(&handles[i], piece, &prop, 0);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); if (line_pool_flush(device) != 0) e = hipMemCreate(&handles[i], piece, &prop, 0); }
+        if (e != hipSuccess) { (void)hipGetLastError(); return FPX_E_NOMEM; }
+        if (hipMemMap(va + i * piece, piece, 0, handles[i], 0) != hipSuccess || hipMemSetAccess(va + i * piece, piece, &acc, 1) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipMemRelease(handles[i]); return FPX_E_DEVICE;
+        }
+        mapped[i] = 1;
+    }
+    return FPX_OK;
+}
+void VmBuf::release_below(size_t upto)
+{
+    for (size_t i = 0; i < handles.size() && (i + 1) * piece <= upto; ++i) {
+        if (!mapped[i]) continue;
+        (void)hipMemUnmap(va + i * piece, piece);
+        (void)hipMemRelease(handles[i]);
+        mapped[i] = 0;
+    }
+}
+size_t VmBuf::mapped_bytes() const { size_t n = 0; for (uint8_t m : mapped) n += m ? piece : 0; return n; }
+VmBuf::~VmBuf()
+{
+    if (!va) return;
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();                                // (nothing may still be reading the range)
+    release_below(reserved);
+    (void)hipMemAddressFree(va, reserved);
+}
+
+constexpr size_t BLOCKS_VM_MIN = (size_t)256 << 20, BLOCKS_VM_PIECE = (size_t)64 << 20;
+hipError_t blocks_alloc(Segment* s, size_t bytes)
+{
+    s->vm_blocks.reset(); s->d_blocks = nullptr;
+    if (bytes >= BLOCKS_VM_MIN && VmBuf::supported(s->ctx->device)) {
+        std::unique_ptr<VmBuf> vm(new (std::nothrow) VmBuf());
+        if (vm && vm->reserve(s->ctx->device, bytes, BLOCKS_VM_PIECE) == FPX_OK) {
+            const int rc = vm->map_range(0, bytes);
+            if (rc == FPX_OK) { s->d_blocks = vm->va; s->vm_blocks = std::move(vm); return hipSuccess; }
+            if (rc == FPX_E_NOMEM) return hipErrorOutOfMemory;
+        }
+        (void)hipGetLastError();                                 // (the address range could not be had: one allocation, as before)
+    }
+    return dmalloc(&s->d_blocks, bytes);
+}
+void blocks_free(Segment* s)
+{
+    if (s->vm_blocks) s->vm_blocks.reset();
+    else if (s->d_blocks) (void)hipFree(s->d_blocks);
+    s->d_blocks = nullptr;
+}
+
 static void segment_free(Segment* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
-    if (s->d_blocks) (void)hipFree(s->d_blocks);
+    blocks_free(s);
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
@@ -385,6 +469,8 @@ int resolve_candidates(Ctx* c, const std::vector<Segment*>& segs)
 {
     const uint32_t fuse_min = ctx_fuse_min(c);
     std::vector<Segment*> lone;
+    for (const Segment* s : segs)
+        if (s->blocks_lost) { set_error("a segment lost its blocks in a group build that failed: it must be created again"); return FPX_E_INVAL; }
     for (Segment* s : segs)
         // (a candidate that SETTLED in its blocks under an earlier snapshot stays there: that snapshot's descriptors point at its
         // block-form buffers, which a later conversion would free under it)
@@ -406,6 +492,8 @@ int resolve_candidates(Ctx* c, const std::vector<Segment*>& segs)
         std::shared_ptr<Group> g;
         const int grc = group_segments(c, batch.data(), (uint32_t)batch.size(), &g);
         if (grc == FPX_E_DEVICE || grc == FPX_E_INVAL) return grc;
+        if (grc != FPX_OK)
+            for (const Segment* b : batch) if (b->blocks_lost) { set_error("a group build failed after its members' blocks had begun to go back: the segments must be created again"); return FPX_E_DEVICE; }
         // (FPX_E_NOMEM: they stay as they are)
     }
     for (Segment* s : lone) {
@@ -489,7 +577,7 @@ int regroup_segments(Ctx* c, const std::vector<Segment*>& segs, uint32_t* regrou
         for (size_t j = 0; j < m.size(); ++j) {
             Segment* s = m[j];
             if (!old[j].home) { s->why = old[j].why; continue; }
-            if (s->d_blocks) { (void)hipFree(s->d_blocks); s->d_blocks = nullptr; }
+            blocks_free(s);
             s->home = old[j].home; s->col = old[j].col; s->direct = true; s->why = old[j].why; s->device_bytes = old[j].device_bytes;
         }
         return rc;
@@ -652,7 +740,7 @@ static int create_file_impl(fpx_ctx* ctx_, const uint8_t* blocks, size_t blocks_
     // src/streamvbyte.zig:5 / src/FileSegment.zig:87 made explicit)
     s->blocks_len = ((size_t)num_blocks + 1) * block_size;
     const size_t alloc = s->blocks_len + 16;
-    hipError_t e = dmalloc(&s->d_blocks, alloc);
+    hipError_t e = blocks_alloc(s, alloc);
     if (e == hipSuccess) e = dmalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t));
     if (e != hipSuccess) { segment_free(s); return hip_fail(e, "hipMalloc(segment)"); }
     s->device_bytes = alloc + ((size_t)num_blocks + 1) * sizeof(uint32_t);
@@ -719,7 +807,7 @@ int fpx_segment_slice(fpx_segment* seg, int has_lo, uint32_t lo_excl, int has_hi
     s->doc_ids = g->doc_ids; s->doc_alive = g->doc_alive;
     s->blocks_len = ((size_t)s->num_blocks + 1) * s->block_size;
     const size_t alloc = s->blocks_len + 16, copy = (size_t)s->num_blocks * s->block_size;
-    hipError_t er = dmalloc(&s->d_blocks, alloc);
+    hipError_t er = blocks_alloc(s, alloc);
     if (er == hipSuccess) er = dmalloc(&s->d_block_index, ((size_t)s->num_blocks + 1) * sizeof(uint32_t));
     if (er != hipSuccess) { segment_free(s); return hip_fail(er, "hipMalloc(segment slice)"); }
     s->device_bytes = alloc + ((size_t)s->num_blocks + 1) * sizeof(uint32_t);

@@ -450,7 +450,7 @@ static int encode_sorted_items(const uint64_t* items, uint64_t n, uint32_t min_d
     // encode
     s->num_blocks = num_blocks;
     s->blocks_len = ((size_t)num_blocks + 1) * block_size;
-    FPX_HIP(dmalloc(&s->d_blocks, s->blocks_len + 16));
+    FPX_HIP(blocks_alloc(s, s->blocks_len + 16));
     FPX_HIP(dmalloc(&s->d_block_index, ((size_t)num_blocks + 1) * sizeof(uint32_t)));
     s->device_bytes = s->blocks_len + 16 + ((size_t)num_blocks + 1) * sizeof(uint32_t);
     FPX_HIP(hipMemsetAsync(s->d_blocks + (size_t)num_blocks * block_size, 0, block_size + 16, st));   // terminator + slack
@@ -474,7 +474,7 @@ static int encode_sorted_items(const uint64_t* items, uint64_t n, uint32_t min_d
 static void free_partial_segment(Segment* s)
 {
     if (!s) return;
-    if (s->d_blocks) (void)hipFree(s->d_blocks);
+    blocks_free(s);
     if (s->d_block_index) (void)hipFree(s->d_block_index);
     if (s->d_bucket) (void)hipFree(s->d_bucket);
     if (s->d_cont) (void)hipFree(s->d_cont);
@@ -1293,7 +1293,7 @@ int build_direct(Segment* s)
 void free_block_form(Segment* s)
 {
     (void)hipSetDevice(s->ctx->device);
-    if (s->d_blocks) { (void)hipFree(s->d_blocks); s->d_blocks = nullptr; }
+    blocks_free(s);
     if (s->d_bucket) { (void)hipFree(s->d_bucket); s->d_bucket = nullptr; }
     if (s->d_cont) { (void)hipFree(s->d_cont); s->d_cont = nullptr; }
     if (s->d_proberec) { (void)hipFree(s->d_proberec); s->d_proberec = nullptr; }

@@ -23,7 +23,9 @@ int ctx_group_packed(const Ctx* c) { return (int)ctx_opt(c, OPT_GROUP_PACKED); }
 Group::~Group()
 {
     (void)hipSetDevice(device);
-    if (d_lines) (void)hipFree(d_lines);
+    if (vm_lines) vm_lines.reset();
+    else if (d_lines) (void)hipFree(d_lines);
+    vm_ext.reset();
     if (d_ext_tab) (void)hipFree(d_ext_tab);
     for (void* p : chunk_allocs) if (p) (void)hipFree(p);       // (word_chunks / list_chunks / ext_chunks point into these)
 }
@@ -33,6 +35,12 @@ uint32_t* Group::chunk_alloc(size_t bytes)
     constexpr size_t SLAB = (size_t)64 << 20, OWN_FROM = (size_t)16 << 20;
     const size_t need = (bytes + 255u) & ~(size_t)255u;
     void* p = nullptr;
+    if (vm_ext) {                                                // (a group built in place: everything out of piece-backed ranges)
+        if (vm_ext_used + need > vm_ext->reserved || vm_ext->map_range(vm_ext_used, vm_ext_used + need) != FPX_OK) return nullptr;
+        p = vm_ext->va + vm_ext_used;
+        vm_ext_used += need;
+        return static_cast<uint32_t*>(p);
+    }
     if (need >= OWN_FROM) {                                      // a dense group's chunk: an allocation of its own, nothing wasted
         if (dmalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         chunk_allocs.push_back(p);
@@ -523,8 +531,18 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     // (a lower bound of what the group will take; running out of HBM half way is noticed chunk by chunk and leaves the
     // segments as they are)
     const uint64_t need = group_bytes_lower_bound(ctx, segs, k);
+    // IN PLACE: where the members' blocks and the group's lines are backed piece by piece (VmBuf), a chunk's lines are mapped as they are
+    // filled and the members' blocks of the chunk go back right after -- the build needs room for the DIFFERENCE, not for both
+    const uint64_t lines_bytes = nlines * (uint64_t)line_words * 4ull + 64;
+    bool in_place = VmBuf::supported(ctx->device) && lines_bytes >= ((uint64_t)1 << 30);
+    uint64_t vm_blocks_total = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        if (segs[j]->direct) continue;
+        if (!segs[j]->vm_blocks) in_place = false; else vm_blocks_total += segs[j]->blocks_len;
+    }
+    const uint64_t room_needed = in_place ? (need > vm_blocks_total ? need - vm_blocks_total : 0ull) + ((uint64_t)10 << 30) : need + ((uint64_t)3 << 30);
     size_t free_b = 0, total_b = 0;
-    if (mem_info(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)3 << 30)) {
+    if (mem_info(&free_b, &total_b) != hipSuccess || free_b < room_needed) {
         (void)hipGetLastError();
         for (uint32_t j = 0; j < k; ++j) if (!segs[j]->direct) segs[j]->why = "blocks: not enough free HBM to build the group next to the members' blocks";
         set_error("not enough free HBM to group %u segments (%.1f GB needed, %.1f free)", k, need / 1e9, free_b / 1e9);
@@ -549,11 +567,30 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     g->lines_alloc_bytes = nlines * line_words * 4ull + 64;
     const size_t slack_pct = 0;                      // (the kept line buffer is taken over by a group of exactly its size: round 6 folded the option)
     hipError_t e = hipSuccess;
-    g->d_lines = static_cast<uint32_t*>(line_pool_take(ctx->device, g->lines_alloc_bytes, g->lines_alloc_bytes + g->lines_alloc_bytes / 100 * slack_pct, &g->lines_alloc_bytes));
-    if (!g->d_lines) e = dmalloc(&g->d_lines, g->lines_alloc_bytes);
-    if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
+    const size_t chunk_line_bytes = (size_t)CHUNK_LINES * line_words * 4u;
+    if (in_place) {
+        g->vm_lines.reset(new (std::nothrow) VmBuf());
+        if (!g->vm_lines || g->vm_lines->reserve(ctx->device, g->lines_alloc_bytes, std::min<size_t>(chunk_line_bytes, (size_t)256 << 20)) != FPX_OK) { g->vm_lines.reset(); in_place = false; }
+        else g->d_lines = reinterpret_cast<uint32_t*>(g->vm_lines->va);
+        if (in_place) {                                          // (the chunks' arrays: address space for as many bytes as the lines take, backed as they are carved)
+            g->vm_ext.reset(new (std::nothrow) VmBuf());
+            if (!g->vm_ext || g->vm_ext->reserve(ctx->device, std::max<size_t>(g->lines_alloc_bytes, (size_t)8 << 30), (size_t)64 << 20) != FPX_OK) {
+                g->vm_ext.reset(); g->vm_lines.reset(); g->d_lines = nullptr; in_place = false;
+            }
+        }
+    }
+    if (!in_place) {
+        g->d_lines = static_cast<uint32_t*>(line_pool_take(ctx->device, g->lines_alloc_bytes, g->lines_alloc_bytes + g->lines_alloc_bytes / 100 * slack_pct, &g->lines_alloc_bytes));
+        if (!g->d_lines) e = dmalloc(&g->d_lines, g->lines_alloc_bytes);
+        if (e != hipSuccess) { g->d_lines = nullptr; (void)hipGetLastError(); set_error("hipMalloc(group directory) failed"); return FPX_E_NOMEM; }
+        FPX_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(g->d_lines) + nlines * line_words * 4ull, 0, 64, 0));
+    }
     g->device_bytes = nlines * line_words * 4ull + 64;
-    FPX_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(g->d_lines) + nlines * line_words * 4ull, 0, 64, 0));
+    // (in place: a failure after the first blocks have gone back leaves the members without their blocks -- said so, and refused by every later use)
+    struct LostGuard {
+        Segment* const* segs; uint32_t k; bool armed = false, done = false;
+        ~LostGuard() { if (armed && !done) for (uint32_t j = 0; j < k; ++j) if (segs[j]->vm_blocks && !segs[j]->direct) { segs[j]->blocks_lost = true; segs[j]->why = "LOST: a group build gave part of its blocks back and failed"; } }
+    } lost{segs, k};
     // which blocks of the members still in blocks hold each chunk's hashes
     std::vector<std::vector<uint32_t>> ranges(k);
     {
@@ -591,9 +628,26 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         ArenaScope(DevArena* a, DevArena* s) : prev(tl_arena), prev_s(tl_scratch) { if (arenas_on) { tl_arena = a; tl_scratch = s; } }
         ~ArenaScope() { tl_arena = prev; tl_scratch = prev_s; }
     } arena_scope(&arena, &scratch);
+    auto chunk_done = [&](uint32_t ci) {               // (the chunk's kernels have been waited for)
+        if (!in_place) return;
+        for (uint32_t j = 0; j < k; ++j) {
+            Segment* s = segs[j];
+            if (s->direct || !s->vm_blocks) continue;
+            const size_t upto = ci + 1u < nchunks ? (size_t)ranges[j][(size_t)(ci + 1u) * 4] * s->block_size : (size_t)s->vm_blocks->reserved;
+            if (upto >= s->vm_blocks->piece) lost.armed = true;
+            s->vm_blocks->release_below(upto);
+        }
+    };
     for (uint32_t ci = 0; ci < nchunks; ++ci) {
         const uint32_t c = c_first + ci;
         arena.rewind();                                // (the last chunk's kernels have been waited for)
+        if (in_place) {
+            const bool last = ci + 1u == nchunks;
+            if ((rc = g->vm_lines->map_range((size_t)ci * chunk_line_bytes, (size_t)(ci + 1u) * chunk_line_bytes + (last ? 64u : 0u)))) {
+                set_error("out of HBM while building a group in place (chunk %u of %u)", ci, nchunks); return rc;
+            }
+            if (last) FPX_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(g->d_lines) + nlines * line_words * 4ull, 0, 64, 0));
+        }
         Pieces pieces;
         for (uint32_t j = 0; j < k; ++j) {
             const Segment* s = segs[j];
@@ -632,6 +686,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
             FPX_HIP(hipStreamSynchronize(st));            // (the pieces go with this scope)
             g->total_list_words += h_x;
             g->device_bytes += (h_x + 8) * 4ull;
+            chunk_done(ci);
             continue;
         }
         if (ns == 8u) hipLaunchKernelGGL(k_group_count<8>, grid, dim3(256), 0, st, a, W.as<uint32_t>(), X.as<uint32_t>());
@@ -661,6 +716,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         FPX_HIP(hipStreamSynchronize(st));            // (the pieces go with this scope)
         g->total_words += h_tot[0]; g->total_list_words += h_tot[1];
         g->device_bytes += (h_tot[0] + 16 + h_tot[1] + 8) * 4ull;
+        chunk_done(ci);
     }
     unsigned long long h_ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     FPX_HIP(hipMemcpyAsync(h_ctr, ctr.p, 64, hipMemcpyDeviceToHost, st));
@@ -682,6 +738,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
         else { free_block_form(s); s->direct = true; }
         s->device_bytes = ((size_t)s->num_blocks + 1) * 8;
     }
+    lost.done = true;
     *out = g;
     return FPX_OK;
 }

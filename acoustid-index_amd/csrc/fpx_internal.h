@@ -168,6 +168,24 @@ struct DirectStore {
     }
 };
 
+// A device buffer backed PIECE BY PIECE (hipMemAddressReserve + hipMemCreate / hipMemMap): one contiguous range for the kernels, whose pieces can
+// be taken and given back one at a time.  A dense segment's blocks live in one (their head goes back as the group that replaces them grows,
+// chunk of the hash space by chunk: release_below), and so do a group's lines (mapped chunk by chunk as they are filled: map_range) -- the
+// conversion of an index no longer needs its blocks AND its group side by side (268 of 288 GB for the 100 M index until round 5).
+struct VmBuf {
+    int device = 0;
+    uint8_t* va = nullptr;
+    size_t reserved = 0, piece = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;      // per piece
+    std::vector<uint8_t> mapped;                               // per piece
+    ~VmBuf();
+    static bool supported(int device);                         // (FPX_VM=0 switches the whole mechanism off)
+    int reserve(int device, size_t bytes, size_t piece_bytes); // the address range alone
+    int map_range(size_t lo, size_t hi);                       // backs the pieces that cover [lo, hi) (those not backed yet); FPX_E_NOMEM: out of memory
+    void release_below(size_t upto);                           // gives back the whole pieces below `upto`
+    size_t mapped_bytes() const;
+};
+
 // Host side of a group (GroupDesc is its device view).  Member segments and the snapshots that search it share it; the HBM
 // goes when the last of them does.  A member that was merged away stays as a dead column until the group is rebuilt.
 struct Group {
@@ -179,6 +197,10 @@ struct Group {
     uint32_t win_lo = 0, win_hi = 0xFFFFFFFFu;
     uint32_t block_size = 512;             // the members' (one block size per group: the statistics' byte counts)
     uint32_t* d_lines = nullptr; size_t lines_alloc_bytes = 0;
+    std::unique_ptr<VmBuf> vm_lines;       // the lines' backing when they were mapped chunk by chunk (d_lines = its range; else one hipMalloc)
+    // ... and then the chunks' arrays are carved from ONE piece-backed range too: this runtime credits memory that hipMemRelease gives back only when
+    // the whole address range goes (tools/vmm_check2.hip), so while the members' blocks are going back hipMalloc believes in less memory than there is
+    std::unique_ptr<VmBuf> vm_ext; size_t vm_ext_used = 0;
     std::vector<uint32_t*> word_chunks, list_chunks;       // one pair per hash-space chunk (the lines hold their addresses)
     // the PACKED form (fpx_pgroup.hpp: a hash's words inside its line) of a dense group
     bool packed = false;
@@ -205,6 +227,8 @@ struct Segment {
     std::vector<uint8_t> doc_alive; // parallel to doc_ids; carried for merges (src/segment_merger.zig:112-118)
     // file
     uint8_t* d_blocks = nullptr; size_t blocks_len = 0; uint32_t block_size = 0;
+    std::unique_ptr<VmBuf> vm_blocks;      // the blocks' backing when they are large (d_blocks = its range): their head can go back piece by piece
+    bool blocks_lost = false;              // a group build gave part of the blocks back and then failed: the segment cannot be searched any more
     uint32_t* d_block_index = nullptr; uint32_t num_blocks = 0;
     uint32_t* d_bucket = nullptr; uint32_t bucket_shift = 32; uint32_t num_buckets = 1;
     uint32_t* d_cont = nullptr;    // continuation bitmap, (num_blocks + 31) / 32 + 1 words
@@ -443,6 +467,9 @@ hipError_t select_u64(void* temp, size_t temp_bytes, const uint64_t* in, const u
 
 // fpx_search.hip
 int build_bucket_table(Segment* seg, hipStream_t stream);
+// fpx_api.hip: a file segment's block buffer -- piece-backed from BLOCKS_VM_MIN bytes on where the runtime can, one allocation otherwise
+hipError_t blocks_alloc(Segment* s, size_t bytes);
+void blocks_free(Segment* s);
 int query_batch_create_impl(Ctx* ctx, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                             const fpx_opts* opts, QueryBatch** out);
 void query_batch_free(QueryBatch* qb);

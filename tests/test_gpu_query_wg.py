@@ -61,7 +61,7 @@ def _world(fpx, Pair, ctx, nseg, monkeypatch, per=3200, crowd=250):
         p.finish()
     finally:
         ctx.set_option("group_packed", -2)
-    assert all(g.direct and g.grouped for g in p.gpu_segs), [g.layout_reason() for g in p.gpu_segs]
+    assert all(g.direct and g.grouped for g in p.gpu_segs), [g.layout_reason for g in p.gpu_segs]
     return p, allitems, rng
 
 

@@ -39,41 +39,7 @@ __device__ __forceinline__ uint4 gload_u4_a4(const uint32_t* p)          // four
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// ---- the scan histograms of the direct-addressed kernels (slots: fpx_internal.h, HIST_SLOTS).  An observation is one (hash, segment)
-// walk's (num_docs, num_blocks), src/FileSegment.zig:177-178; its buckets are those of src/metrics.zig:9-10.  Only what falls OUTSIDE the
-// first bucket of a histogram is counted as it happens (a hash with several docs: one in twelve probes of the 100 M index has one) --
-// into sixteen LDS words of the workgroup, which leave with its statistics.
-#ifndef FPX_SCAN_HIST
-#define FPX_SCAN_HIST 1            // (0: compiled out -- the A/B of what the histograms cost the probe kernels)
-#endif
-constexpr bool SCAN_HIST = FPX_SCAN_HIST != 0;
-#ifndef FPX_SH_BITS
-#define FPX_SH_BITS 7
-#endif
-__device__ __forceinline__ uint32_t hist_docs_bucket(uint32_t v)            // index of the first bound of {1, 2, 3, 5, 10, 50, 100, 500, 1000} >= v; 9: none
-{
-    return v <= 1u ? 0u : v <= 3u ? v - 1u : v <= 5u ? 3u : v <= 10u ? 4u : v <= 50u ? 5u : v <= 100u ? 6u : v <= 500u ? 7u : v <= 1000u ? 8u : 9u;
-}
-__device__ __forceinline__ void hist_observe(uint32_t* wg_h, uint32_t docs, uint32_t blocks)
-{
-    // (branch-free: an observation inside a histogram's first bucket goes to slot 15, which nobody reads -- a conditional atomic costs the
-    // probe kernels a saved exec mask each, and their scalar registers are spilled as it is)
-    if constexpr (!SCAN_HIST || !(FPX_SH_BITS & 1)) return;
-    const uint32_t db = hist_docs_bucket(docs), bb = min(blocks, 4u);
-    atomicAdd(&wg_h[db != 0u ? db - 1u : 15u], 1u);
-    atomicAdd(&wg_h[bb >= 2u ? 7u + bb : 15u], 1u);                              // (2 | 3 | 4-5 blocks -> slots 9 | 10 | 11; MAX_BLOCKS_PER_HASH = 4)
-}
-// the workgroup's slots join the launch's: its set of the spread statistics, or (a small launch) the batch's counters
-__device__ __forceinline__ void hist_publish(const ProbeArgs& a, const uint32_t* wg_h, unsigned long long probes, unsigned long long docs,
-                                             unsigned long long blocks, uint32_t tid)
-{
-    if constexpr (!SCAN_HIST || !(FPX_SH_BITS & 4)) return;
-    if (tid >= HIST_SLOTS - 1u) return;                      // (slot 15: hist_observe's sink)
-    const unsigned long long v = tid == HIST_COUNT ? probes : tid == HIST_DOCS ? docs : tid == HIST_BLOCKS ? blocks : (unsigned long long)wg_h[tid];
-    if (v == 0ull) return;
-    unsigned long long* dst = a.lean_stats ? a.lean_stats + (size_t)LEAN_STAT_SETS * 8u + (size_t)(blockIdx.x % LEAN_STAT_SETS) * HIST_SLOTS : a.counters + CTR_HIST;
-    atomicAdd(&dst[tid], v);
-}
+// (the scan histograms' helpers -- hist_observe, hist_publish: fpx_probe_generic.hpp, behind ProbeArgs)
 
 __global__ __launch_bounds__(DK_WG) void k_probe_direct(ProbeArgs a)
 {

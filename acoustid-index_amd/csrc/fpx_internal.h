@@ -377,8 +377,8 @@ struct Ctx {
     std::mutex group_mu;                  // serialises the grouping of segments (fpx_snapshot_create, fpx_segments_group)
     std::vector<Workspace*> free_ws;
     std::atomic<int> live_ws{0};
-    // the running scan histograms of the probes the direct-addressed kernels answered (fpx_ctx_scan_histograms), in HIST_SLOTS slots;
-    // [HIST_SLOTS]: (hash, segment) walks the block-form kernels answered meanwhile -- counted, not bucketed
+    // the running scan histograms of the walks the probe kernels answered (fpx_ctx_scan_histograms), in HIST_SLOTS slots;
+    // [HIST_SLOTS]: (hash, segment) walks that were counted but not bucketed (none: every probe kernel buckets its walks)
     std::atomic<uint64_t> scan_hist[HIST_SLOTS + 1];
 };
 void ctx_hist_add(Ctx* c, const uint64_t* slots, uint64_t unbucketed);     // (a batch's slots, after it has succeeded)

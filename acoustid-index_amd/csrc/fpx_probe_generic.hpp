@@ -46,6 +46,42 @@ struct ProbeArgs {
     uint32_t rec32 = 0;                         // BINNED: the bins hold 4-byte records (bin_record32, fpx_partition.hpp)   // the number of pairs lives on the device (a rank's compacted share of the keys): P is their capacity
 };
 
+// ---- the scan histograms of the probe kernels, block form and direct-addressed (slots: fpx_internal.h, HIST_SLOTS).  An observation is one (hash, segment)
+// walk's (num_docs, num_blocks), src/FileSegment.zig:177-178; its buckets are those of src/metrics.zig:9-10.  Only what falls OUTSIDE the
+// first bucket of a histogram is counted as it happens (a hash with several docs: one in twelve probes of the 100 M index has one) --
+// into sixteen LDS words of the workgroup, which leave with its statistics.
+#ifndef FPX_SCAN_HIST
+#define FPX_SCAN_HIST 1            // (0: compiled out -- the A/B of what the histograms cost the probe kernels)
+#endif
+constexpr bool SCAN_HIST = FPX_SCAN_HIST != 0;
+#ifndef FPX_SH_BITS
+#define FPX_SH_BITS 7
+#endif
+__device__ __forceinline__ uint32_t hist_docs_bucket(uint32_t v)            // index of the first bound of {1, 2, 3, 5, 10, 50, 100, 500, 1000} >= v; 9: none
+{
+    return v <= 1u ? 0u : v <= 3u ? v - 1u : v <= 5u ? 3u : v <= 10u ? 4u : v <= 50u ? 5u : v <= 100u ? 6u : v <= 500u ? 7u : v <= 1000u ? 8u : 9u;
+}
+__device__ __forceinline__ void hist_observe(uint32_t* wg_h, uint32_t docs, uint32_t blocks)
+{
+    // (branch-free: an observation inside a histogram's first bucket goes to slot 15, which nobody reads -- a conditional atomic costs the
+    // probe kernels a saved exec mask each, and their scalar registers are spilled as it is)
+    if constexpr (!SCAN_HIST || !(FPX_SH_BITS & 1)) return;
+    const uint32_t db = hist_docs_bucket(docs), bb = min(blocks, 4u);
+    atomicAdd(&wg_h[db != 0u ? db - 1u : 15u], 1u);
+    atomicAdd(&wg_h[bb >= 2u ? 7u + bb : 15u], 1u);                              // (2 | 3 | 4-5 blocks -> slots 9 | 10 | 11; MAX_BLOCKS_PER_HASH = 4)
+}
+// the workgroup's slots join the launch's: its set of the spread statistics, or (a small launch) the batch's counters
+__device__ __forceinline__ void hist_publish(const ProbeArgs& a, const uint32_t* wg_h, unsigned long long probes, unsigned long long docs,
+                                             unsigned long long blocks, uint32_t tid)
+{
+    if constexpr (!SCAN_HIST || !(FPX_SH_BITS & 4)) return;
+    if (tid >= HIST_SLOTS - 1u) return;                      // (slot 15: hist_observe's sink)
+    const unsigned long long v = tid == HIST_COUNT ? probes : tid == HIST_DOCS ? docs : tid == HIST_BLOCKS ? blocks : (unsigned long long)wg_h[tid];
+    if (v == 0ull) return;
+    unsigned long long* dst = a.lean_stats ? a.lean_stats + (size_t)LEAN_STAT_SETS * 8u + (size_t)(blockIdx.x % LEAN_STAT_SETS) * HIST_SLOTS : a.counters + CTR_HIST;
+    atomicAdd(&dst[tid], v);
+}
+
 // Cancel point -- the GPU form of zio.maybeYield() in the reference's hot loop (src/FileSegment.zig:144,
 // src/MemorySegment.zig:47), whose error.Canceled becomes error.SearchTimeout (src/MultiIndex.zig:319-322).  The host
 // thread that waits for the stream sets a word in pinned memory when the deadline passes; one workgroup in 64 reads it
@@ -383,6 +419,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
     __shared__ uint32_t stage_count, stage_valid, flush_base_lo, flush_base_hi;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
     __shared__ uint32_t wave_run[PWAVES];                                  // write pass of a long-run wave: slots handed out
+    __shared__ uint32_t wg_h[HIST_SLOTS];                                  // the scan histograms' slots of this workgroup (hist_observe)
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 4, gl = lane & 15u;
@@ -399,6 +436,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
 
     __shared__ uint32_t s_cancel;
     if (tid < 256u) init_lut(lut, tid);
+    if (tid < HIST_SLOTS) wg_h[tid] = 0u;
     if (tid == 0) {
         stage_count = 0; stage_valid = STAGE_CAP;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0;
@@ -695,6 +733,9 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
                     } else stage_emit(hs, a, (kf & 1u) != 0u, ((uint64_t)pq << 32) | dd[0], lane);
                 }
             }
+            // the row's walk is over: one observation of (num_docs, num_blocks), src/FileSegment.zig:177-178 (0 | 1 of both: the first buckets,
+            // which are what the totals leave)
+            if (gl == 0u && !count_only && (ndv > 1u || nbv > 1u)) hist_observe(wg_h, ndv, nbv);
         }
         if (count_only) {
             // the wave's total -> one reservation; the write pass hands out its slots through an LDS word of the wave
@@ -732,6 +773,7 @@ __global__ __launch_bounds__(PWG) void k_probe(ProbeArgs a)
         if (wg_docs) atomicAdd(&a.counters[CTR_DOCS], wg_docs);
         if (wg_probes) atomicAdd(&a.counters[CTR_PROBES], wg_probes);
     }
+    hist_publish(a, wg_h, wg_probes, wg_docs, wg_blocks, tid);            // (the deferred pass: the walks k_probe_lean8 counted and left to it)
 }
 
 }  // namespace fpx

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     __shared__ uint32_t def_stage[DEF_STAGE_CAP];
     __shared__ uint32_t def_n, def_base;
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_reads;
+    __shared__ uint32_t wg_h[HIST_SLOTS];                                  // the scan histograms' slots of this workgroup (hist_observe)
     const HitStage hs{stage, &stage_count, &stage_valid, &flush_base_lo, &flush_base_hi};
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = lane >> 3, l = lane & 7u;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 
     __shared__ uint32_t s_cancel;
     if (tid < 256u) init_lean_lut(lut, tid);
+    if (tid < HIST_SLOTS) wg_h[tid] = 0u;
     if (tid == 0) {
         stage_count = 0; stage_valid = STAGE_CAP; def_n = 0;
         wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_reads = 0;
@@ -472,6 +474,7 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 } else {
                     my_blocks += 1; my_docs += cnt;
                     if (a.qstats) atomicAdd(&a.qstats[pq], 1ull | ((unsigned long long)cnt << 32));
+                    if (cnt > 1u) hist_observe(wg_h, cnt, 1u);             // (a walk that ends in this block; the deferred ones are observed by k_probe)
                 }
             }
             // -- emission (wave-uniform control flow): doc = min_doc_id + the prefix sum of the run's deltas over the group's
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(L8_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (wg_docs) atomicAdd(&st[2], wg_docs);
         if (wg_probes) atomicAdd(&st[3], wg_probes);
     }
+    hist_publish(a, wg_h, wg_probes, wg_docs, wg_blocks, tid);
 }
 
 }  // namespace fpx

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const u
     __shared__ uint64_t blk_items[SMALL_LDS_ITEMS];
     __shared__ uint64_t prange[2];
     __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    __shared__ uint32_t wg_h[HIST_SLOTS];                                  // the scan histograms' slots of this workgroup (hist_observe)
     const SegDesc seg = segs[blockIdx.y];
     const uint32_t tid = threadIdx.x;
     const uint32_t bfirst = blockIdx.x * SMALL_BPW;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const u
     const uint32_t bend = min(bfirst + SMALL_BPW, seg.num_blocks);
     const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
     if (tid == 0) { wg_blocks = 0; wg_docs = 0; wg_probes = 0; }
+    if (tid < HIST_SLOTS) wg_h[tid] = 0u;
     unsigned long long my_blocks = 0, my_docs = 0, my_probes = 0;
     for (uint32_t b = bfirst; b < bend; ++b) {
         const uint32_t s0 = seg.bstart[b], n = seg.bstart[b + 1] - s0;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const u
                 }
             }
             my_blocks += nb; my_docs += nd;
+            if (nd > 1u || nb > 1u) hist_observe(wg_h, nd, nb);
             if (qstats) atomicAdd(&qstats[q], (unsigned long long)nb | ((unsigned long long)nd << 32));
         }
     }
@@ -277,6 +280,10 @@ __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const u
         if (wg_probes) atomicAdd(&counters[CTR_PROBES], wg_probes);
         if (wg_blocks) { atomicAdd(&counters[CTR_BLOCKS], wg_blocks); atomicAdd(&counters[CTR_BYTES], wg_blocks * seg.block_size); }
         if (wg_docs) atomicAdd(&counters[CTR_DOCS], wg_docs);
+    }
+    if (SCAN_HIST && tid < HIST_SLOTS - 1u) {                              // (hist_publish, for a kernel without ProbeArgs)
+        const unsigned long long v = tid == HIST_COUNT ? wg_probes : tid == HIST_DOCS ? wg_docs : tid == HIST_BLOCKS ? wg_blocks : (unsigned long long)wg_h[tid];
+        if (v != 0ull) atomicAdd(&counters[CTR_HIST + tid], v);
     }
 }
 

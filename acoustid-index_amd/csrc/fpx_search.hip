@@ -395,7 +395,7 @@ __global__ void k_dest_bounds(const uint64_t* __restrict__ recs, uint64_t n, uin
 
 // The scan histogram slots of a batch that has reached the host (fpx_internal.h, HIST_SLOTS): what small launches added to the batch's
 // counters + the spread sets behind the statistics sets (`sets`: the [LEAN_STAT_SETS][8] statistics, or null); `probes`: every (hash,
-// file segment) walk of the batch -- those the direct-addressed kernels did not answer were answered from blocks, unbucketed.
+// file segment) walk of the batch -- every probe kernel observes its own, so none is left over (dst[HIST_SLOTS]: counted, not bucketed).
 static void gather_hist(uint64_t* dst, const unsigned long long* h_counters, const unsigned long long* sets, uint64_t probes)
 {
     for (uint32_t i = 0; i < HIST_SLOTS; ++i) dst[i] = h_counters[CTR_HIST + i];

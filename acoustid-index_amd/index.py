@@ -62,8 +62,8 @@ class Context:
 
     def scan_histograms(self):
         """fpx_ctx_scan_histograms: the context's RUNNING scan histograms (src/FileSegment.zig:177-178, buckets of src/metrics.zig:9-10) --
-        every (hash, segment) walk the direct-addressed kernels answered since the context was created, bucketed as it was answered.
-        Returns (ScanHistograms, walks answered from blocks meanwhile: counted, not bucketed)."""
+        every (hash, file segment) walk answered since the context was created, bucketed by the kernel that answered it.
+        Returns (ScanHistograms, walks counted but not bucketed: 0 -- the block forms' kernels bucket theirs too)."""
         from ._lib import ScanHistograms
         acc, unb = ScanHistograms(), C.c_uint64(0)
         check(lib().fpx_ctx_scan_histograms(self.h, C.byref(acc), C.byref(unb)))

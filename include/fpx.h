@@ -273,14 +273,14 @@ typedef struct {
 } fpx_scan_histograms;
 int fpx_scan_histograms_observe(fpx_snapshot *snap, const uint32_t *hashes, const uint64_t *offsets, uint32_t num_queries,
                                 uint32_t timeout_ms, fpx_scan_histograms *acc);
-/* The same two histograms for ALL the traffic of a context, exact and free, where the segments are direct-addressed (every
- * dense segment: the forms that answer the 100 M index).  Their kernels hold every (hash, segment) walk's (num_docs, num_blocks)
- * explicitly -- absent | one doc | two docs inline | a list's header -- and bucket the walks as they answer them; a context keeps
+/* The same two histograms for ALL the traffic of a context, exact and free.  The direct-addressed forms' kernels hold every (hash,
+ * segment) walk's (num_docs, num_blocks) explicitly -- absent | one doc | two docs inline | a list's header --, the block forms' kernels
+ * have them when a walk ends (src/FileSegment.zig:171-178); all of them bucket the walks as they answer them; a context keeps
  * the RUNNING totals of every search that succeeded on it (any entry point, any thread; a batch that was redone on another path
  * counts once; a step of the fpx_shard_* protocols that the ranks redo for larger buffers is observed again).  *out receives the
  * totals since the context was created -- the process-wide histograms src/metrics.zig keeps --, in fpx_scan_histograms' layout.
- * Walks that were answered from BLOCKS meanwhile (segments below "direct_min_items" between merges, "direct" = 0) are not
- * bucketed by their kernels: *unbucketed (may be NULL) counts them; sample those with fpx_scan_histograms_observe, or scale. */
+ * *unbucketed (may be NULL): walks that were counted but not bucketed -- 0 now that the block forms' kernels bucket theirs too (it
+ * counted the walks answered from BLOCKS: segments below "direct_min_items" between merges, "direct" = 0); kept for its callers. */
 int fpx_ctx_scan_histograms(const fpx_ctx *ctx, fpx_scan_histograms *out, uint64_t *unbucketed);
 
 /* Query batch already resident in HBM: what a host-side coalescer that keeps its staging buffers on the

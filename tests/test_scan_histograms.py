@@ -154,17 +154,22 @@ def _child():
         p.check(queries[:4], fpx.http_options())
         print(f"{label}: {want['count']} observations, docs buckets {want['docs_bucket']}, blocks buckets {want['blocks_bucket']}", flush=True)
     _running_histograms(fpx, oracle, Pair, items, queries)
+    # segments of 0.4 M items stay decoded next to their blocks (k_probe_small) when a batch is large enough for the kernels of its own
+    items_s, queries_s = _world(fpx, oracle, seed=6, per=4000)
+    _running_histograms(fpx, oracle, Pair, items_s, queries_s, forms=(("blocks of small segments, decoded", {"direct": 0, "lean_min": 0}, True),
+                                                                      ("blocks of small segments, the general kernel", {"direct": 0}, True)))
     print("scan histograms ok", flush=True)
 
 
-def _running_histograms(fpx, oracle, Pair, items, queries):
-    """fpx_ctx_scan_histograms: the direct-addressed kernels bucket every walk as they answer it -- the context's running totals grow
-    by exactly the oracle's observations with every search, whatever the entry point and the path (a workspace's first batch takes the
-    general path, its second the device-sized one, a single query its own); walks answered from blocks are counted, not bucketed"""
+def _running_histograms(fpx, oracle, Pair, items, queries, forms=None):
+    """fpx_ctx_scan_histograms: the probe kernels -- block form (k_probe, k_probe_lean8 + its deferred pass) and direct-addressed -- bucket
+    every walk as they answer it: the context's running totals grow by exactly the oracle's observations with every search, whatever the
+    entry point and the path (a workspace's first batch takes the general path, its second the device-sized one, a single query its own)"""
     def delta(a, b):
         return {k: ([y - x for x, y in zip(a[k], b[k])] if isinstance(a[k], list) else b[k] - a[k]) for k in a}
 
-    forms = (("blocks", {"direct": 0}, False), ("a group, directory + words", {"direct_min_items": 0, "group_packed": 0}, True),
+    forms = forms or (("blocks", {"direct": 0}, True), ("blocks, the big batches' kernels (k_probe_lean8, its deferred pass)", {"direct": 0, "lean_min": 0}, True),
+             ("a group, directory + words", {"direct_min_items": 0, "group_packed": 0}, True),
              ("a packed group", {"direct_min_items": 0, "group_packed": 1}, True), ("each on its own", {"direct_min_items": 0, "fuse_min": 0}, True))
     for label, options, bucketed in forms:
         ctx = fpx.Context(0)

@@ -411,16 +411,12 @@ static const OptInfo OPT_TABLE[OPT_COUNT] = {
     /* OPT_GROUP_PACKED */       {"group_packed", "FPX_GROUP_PACKED", -1, -1, false},
     /* OPT_PRESENCE_MIN_ITEMS */ {"presence_min_items", "FPX_PRESENCE_MIN_ITEMS", 1ll << 20, 0, false},
     /* OPT_LEAN_HEAD */          {"lean_head", "FPX_LEAN_HEAD", 0, 0, true},
-    /* OPT_INLINE_DOUBLES */     {"inline_doubles", "FPX_INLINE_DOUBLES", 1, 0, true},
-    /* OPT_MEMTAB */             {"memtab", "FPX_MEMTAB", 1, 0, true},
     /* OPT_FAST */               {"fast", "FPX_FAST", 1, 0, true},
     /* OPT_BINNED */             {"binned", "FPX_BINNED", 1, 0, true},
-    /* OPT_BIN_Q_LOG2 */         {"bin_q_log2", "FPX_BIN_Q_LOG2", -1, -1, true},
     /* OPT_REC32 */              {"rec32", "FPX_REC32", 1, 0, true},
     /* OPT_LOCAL_SORT_MAX */     {"local_sort_max", "FPX_LOCAL_SORT_MAX", 1ll << 20, 0, true},
     /* OPT_ORDER_MIN_PAIRS */    {"order_min_pairs", "FPX_ORDER_MIN_PAIRS", 1ll << 17, 0, true},
     /* OPT_LEAN_MIN */           {"lean_min", "FPX_LEAN_MIN", 1ll << 16, 0, true},
-    /* OPT_GROUP_ROUNDS */       {"group_rounds", "FPX_GROUP_ROUNDS", 0, 0, true},
     /* OPT_SHARDED_WORKERS */    {"sharded_workers", "FPX_SHARDED_WORKERS", 3, 1, true},
     /* OPT_HOT_REFS */           {"hot_refs", "FPX_HOT_REFS", -1, -1, true},                     // 1 | 0 | -1: hot lists reach the score kernel by reference | are copied | by the last batch's records
     /* OPT_QUERY_WG */           {"query_wg", "FPX_QUERY_WG", 1, 0, false},                      // 1 | 0: a snapshot that is ONE packed group is searched a query per workgroup (fpx_qsearch.hpp) | by the keys - probe - bins - score pipeline
@@ -1203,8 +1199,8 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     }
     if (e != hipSuccess) { snapshot_free(sn); return hip_fail(e, "snapshot upload"); }
     if (sn->n_mem) {
-        const int mrc = build_memtab(sn);             // (FPX_E_NOMEM: the memory segments are probed one by one, as before)
-        if (mrc != FPX_OK && mrc != FPX_E_NOMEM) { snapshot_free(sn); return mrc; }
+        const int mrc = build_memtab(sn);             // (FPX_E_NOMEM: no room for two copies of the memory segments' items)
+        if (mrc != FPX_OK) { snapshot_free(sn); return mrc; }
     }
     *out = reinterpret_cast<fpx_snapshot*>(sn);
     return FPX_OK;

@@ -70,7 +70,6 @@ struct BuildArgs {
     uint32_t nseg;
     uint64_t line_begin;                   // first line of this chunk (= hash >> 5)
     uint32_t nlines;
-    uint32_t inline_doubles;
     uint32_t delta[FUSE_MAX];              // packed form: min_doc of column s - the group's one doc id base (added to every doc word)
 };
 
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(256) void k_group_count(BuildArgs a, uint32_t* __re
         if (s < a.nseg) src_line(a.src[s], L, &bits[s], &rank[s]);
         P += (uint32_t)__popc(bits[s]);
     }
-    const bool inl = a.inline_doubles != 0u && P <= CAP;
+    const bool inl = P <= CAP;
     uint32_t w = P;
     uint64_t x = 0;
     for (uint32_t j = 0; j < 32u; ++j) {
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(256) void k_group_fill(BuildArgs a, const uint64_t*
         if (s < a.nseg) src_line(a.src[s], L, &bits[s], &rank[s]);
         P += (uint32_t)__popc(bits[s]);
     }
-    const bool inl = a.inline_doubles != 0u && P <= CAP;
+    const bool inl = P <= CAP;
     uint32_t* out = words + offW[i];
     uint64_t x = offX[i];
     uint32_t dbl[NM];
@@ -299,7 +298,7 @@ __global__ __launch_bounds__(256) void k_pgroup_count(BuildArgs a, uint32_t* __r
             if (v == GAP || (v >> 31) == 0u) continue;
             const uint32_t* li = a.src[s].extras + ((size_t)(v & 0x7FFFFFFFu) << a.src[s].xshift);
             const uint32_t hdr = li[0];
-            if (a.inline_doubles != 0u && at < 32u && is_double(hdr)) { w += 1u; continue; }
+            if (at < 32u && is_double(hdr)) { w += 1u; continue; }
             const uint32_t T = (hdr >> 19) & 1u, cnt = T ? li[1] : (hdr & 0xFFFFu);
             x += 1ull + T + cnt;
         }
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(256) void k_pgroup_fill(BuildArgs a, const uint32_t
             if ((v >> 31) == 0u) { put(v + dl); continue; }
             const uint32_t* li = a.src[s].extras + ((size_t)(v & 0x7FFFFFFFu) << a.src[s].xshift);
             const uint32_t hdr = li[0];
-            if (a.inline_doubles != 0u && at < 32u && is_double(hdr)) {
+            if (at < 32u && is_double(hdr)) {
                 put(li[1] + dl); put(li[2] + dl);
                 dfl |= 1u << at; ndbl += 1u;
                 continue;
@@ -492,7 +491,6 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     out->reset();
     if (k == 0 || k > FUSE_MAX) { set_error("a group holds 1..16 segments"); return FPX_E_INVAL; }
     FPX_HIP(hipSetDevice(ctx->device));
-    const bool inline_doubles = ctx_opt(ctx, OPT_INLINE_DOUBLES) != 0;
     const uint32_t ns = k <= 8u ? 8u : 16u;
     // the window: hashes in (own_lo, own_hi] (a slice of an index sharded by hash range), the same for every member
     uint32_t win_lo = 0u, win_hi = 0xFFFFFFFFu;
@@ -553,7 +551,7 @@ int group_segments(Ctx* ctx, Segment* const* segs, uint32_t k, std::shared_ptr<G
     g->packed = packed; g->chunk0 = c_first; g->nchunks = nchunks; g->block_size = segs[0]->block_size;
     for (uint32_t j = 0; j < FUSE_MAX; ++j) { g->first_hash[j] = 1u; g->last_hash[j] = 0u; }      // unused columns: empty hash range
     BuildArgs a{};
-    a.nseg = k; a.inline_doubles = inline_doubles ? 1u : 0u;
+    a.nseg = k;
     for (uint32_t j = 0; j < k; ++j) {
         const Segment* s = segs[j];
         g->min_doc[j] = packed ? gmin : s->min_doc_id; g->first_hash[j] = s->first_hash; g->last_hash[j] = s->last_hash;

@@ -358,10 +358,9 @@ struct QueryBatch {
 // Thresholds that decide a storage form or a kernel path belong to the index, not to the process's environment.
 enum CtxOpt : int {
     OPT_DIRECT, OPT_DIRECT_MIN_ITEMS, OPT_FUSE_MIN, OPT_GROUP_PACKED,            // storage forms (read when a segment is created / first held)
-    OPT_PRESENCE_MIN_ITEMS, OPT_LEAN_HEAD, OPT_INLINE_DOUBLES, OPT_MEMTAB,
-    OPT_FAST, OPT_BINNED, OPT_BIN_Q_LOG2, OPT_REC32,                             // search paths (read per batch)
+    OPT_PRESENCE_MIN_ITEMS, OPT_LEAN_HEAD,
+    OPT_FAST, OPT_BINNED, OPT_REC32,                                             // search paths (read per batch)
     OPT_LOCAL_SORT_MAX, OPT_ORDER_MIN_PAIRS, OPT_LEAN_MIN,
-    OPT_GROUP_ROUNDS,
     OPT_SHARDED_WORKERS,
     OPT_HOT_REFS,
     OPT_QUERY_WG,

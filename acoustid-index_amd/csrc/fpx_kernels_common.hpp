@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_make_keys_dedup(const uint32_t* __restr
 // are a third of a 64-query batch's time.  dedupSorted (src/Index.zig:171-172,489-499) is exactly this per-query sort +
 // adjacent test; what the batch-wide hash order adds -- neighbouring probes walking the probe records as a stream -- does not
 // exist at these sizes (every probe touches lines of its own).  Kernels that search the pairs by hash across the batch
-// (k_probe_small, k_probe_mem_items) are not used with this order.
+// (k_probe_small) are not used with this order.
 constexpr uint32_t QSORT_MAX = 2048;        // longest query the LDS sort takes
 __global__ __launch_bounds__(256) void k_make_keys_sorted(const uint32_t* __restrict__ hashes_base, const uint64_t* __restrict__ offsets,
                                                           uint32_t B, uint32_t qb, uint64_t base, uint64_t* __restrict__ keys,

@@ -1,4 +1,4 @@
-// fpx_probe_small.hpp -- memory segments (k_probe_mem, k_probe_mem_items) and small decoded file segments (k_probe_small).
+// fpx_probe_small.hpp -- memory segments (k_probe_memtab) and small decoded file segments (k_probe_small).
 // Part of the fpx_search.hip translation unit (included there, in this order: common, generic, lean, small, score).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -10,37 +10,7 @@
 namespace fpx {
 
 // ------------------------------------------------------------------------------------------------
-// 4. memory segments (src/MemorySegment.zig:44-54): equal_range on hash over sorted u64 items, no caps
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_probe_mem(const MemDesc* mems, const uint64_t* __restrict__ pairs, uint64_t P,
-                                                   uint32_t qb, uint64_t* hits, uint64_t hit_cap,
-                                                   unsigned long long* counters)
-{
-    const MemDesc ms = mems[blockIdx.y];
-    const uint64_t p = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
-    if (p >= P) return;
-    const uint64_t key = pairs[p];
-    if (is_duplicate_pair(pairs, p, key, qb)) return;
-    const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
-    if (h < ms.win_lo || h > ms.win_hi) return;                  // (a hash-window snapshot: another rank's hash)
-    uint64_t lo = 0, hi = ms.num_items;
-    while (lo < hi) {
-        uint64_t m = (lo + hi) >> 1;
-        if ((uint32_t)(ms.items[m] >> 32) < h) lo = m + 1; else hi = m;
-    }
-    for (uint64_t i = lo; i < ms.num_items; ++i) {
-        const uint64_t it = ms.items[i];
-        if ((uint32_t)(it >> 32) != h) break;
-        const uint32_t d = (uint32_t)it;
-        if (is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, d)) continue;
-        unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
-        if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 4a'. ALL memory segments at once: their live postings (a doc superseded within the snapshot is dropped when the table is built:
+// 4. memory segments (src/MemorySegment.zig:44-54: equal range on hash over sorted items, no caps), ALL of a snapshot at once: their live postings (a doc superseded within the snapshot is dropped when the table is built:
 //      hasNewerCommit, src/Index.zig:133-149, resolved per posting) merged into one array sorted by hash, duplicates kept
 //      (src/MemorySegment.zig:27-28,44-54: every matching item counts), behind a bucket table over the top 20 hash bits.  One
 //      thread per key, two loads to find the hash's run (usually empty): any key order, either dedup form -- which is what lets
@@ -284,39 +254,6 @@ __global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const u
     if (SCAN_HIST && tid < HIST_SLOTS - 1u) {                              // (hist_publish, for a kernel without ProbeArgs)
         const unsigned long long v = tid == HIST_COUNT ? wg_probes : tid == HIST_DOCS ? wg_docs : tid == HIST_BLOCKS ? wg_blocks : (unsigned long long)wg_h[tid];
         if (v != 0ull) atomicAdd(&counters[CTR_HIST + tid], v);
-    }
-}
-
-// The same probes from the other side, for big batches: a memory segment holds at most ~10^5 items, a batch millions
-// of pairs, so one thread per ITEM looks its hash up in the (bucket-sorted) pairs -- 60x fewer searches than one thread
-// per (pair, segment).  The pairs of a bucket (top 32 - KEY_SORT_SKIP hash bits) are contiguous but unordered inside it.
-__global__ __launch_bounds__(WG) void k_probe_mem_items(const MemDesc* mems, const uint64_t* __restrict__ pairs, uint64_t P,
-                                                         uint32_t qb, uint64_t* hits, uint64_t hit_cap,
-                                                         unsigned long long* counters)
-{
-    const MemDesc ms = mems[blockIdx.y];
-    const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
-    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < ms.num_items; i += (uint64_t)gridDim.x * WG) {
-        const uint64_t it = ms.items[i];
-        const uint32_t h = (uint32_t)(it >> 32), d = (uint32_t)it;
-        if (h < ms.win_lo || h > ms.win_hi) continue;                // (a hash-window snapshot: another rank's hash)
-        const uint32_t bucket = h >> KEY_SORT_SKIP;
-        uint64_t lo = 0, hi = P;
-        while (lo < hi) {                                        // first pair of the item's bucket
-            const uint64_t m = (lo + hi) >> 1;
-            if (((uint32_t)(pairs[m] >> qb) >> KEY_SORT_SKIP) < bucket) lo = m + 1; else hi = m;
-        }
-        bool dead_known = false, dead = false;
-        for (uint64_t p = lo; p < P; ++p) {
-            const uint64_t key = pairs[p];
-            const uint32_t ph = (uint32_t)(key >> qb);
-            if ((ph >> KEY_SORT_SKIP) != bucket) break;
-            if (ph != h || is_duplicate_pair(pairs, p, key, qb)) continue;
-            if (!dead_known) { dead = is_dead(ms.dead, ms.num_dead, ms.shadow_lo, ms.shadow_hi, d); dead_known = true; }
-            if (dead) break;
-            const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
-            if (g < hit_cap) hits[g] = ((uint64_t)((uint32_t)key & qmask) << 32) | d;
-        }
     }
 }
 

@@ -7,22 +7,18 @@
 //   MemorySegment.search    src/MemorySegment.zig:44-54
 //   SearchResults.incr/finish src/common.zig:121-171  + Segments.hasNewerCommit src/Index.zig:133-149
 //
-// GPU formulation (batch of B queries at once):
-//   1. k_make_keys      (hash, q) pair per query hash, packed hash << QB | q
-//   2. radix sort       all pairs of the batch by (hash, q): duplicates become adjacent (dedup) and
-//                       consecutive probes walk block_index / bucket tables sequentially
-//   3. k_probe          per (pair, file segment): bucket-table + block_index lower_bound, 512-B block ->
-//                       LDS, lane-per-quad StreamVByte decode with half-wave prefix sums, equal-range match,
-//                       ranged docid decode, supersession filter, hits (q, doc) staged in LDS and appended
-//   4. k_probe_mem      per (pair, memory segment): equal_range over sorted items
-//   5. radix partition  hit records by q; k_bounds; k_score counts each query's records in LDS (counting filter + exact
-//                       table) and keeps score >= min_score
-//   6. k_finish         (score desc, doc asc), relative cut-off, top-k; k_merge for per-rank partial tables
-// Integer gather/scan work: HBM-bound, no MFMA.
-//
-// The kernels live in headers of this translation unit: fpx_kernels_common.hpp, fpx_probe_generic.hpp (k_probe),
-// fpx_probe_lean.hpp (k_probe_lean8, the dominant kernel), fpx_probe_small.hpp (memory / small segments), fpx_score.hpp
-// (k_bounds, k_score, k_finish, k_merge).  This file holds the host side: run_batch and the C-ABI implementations.
+// GPU formulation (a batch of B queries at once) -- two of them, chosen per batch by run_batch:
+//   A. a snapshot that is ONE packed group (the resident index between merges): k_search_query (fpx_qsearch.hpp), a QUERY PER WORKGROUP --
+//      dedup, the group's lines, counting and the floor in one kernel, the hit records never leaving the CU -- then k_finish, k_publish.
+//   B. everything else, the pipeline over all the batch's hashes:
+//      1. k_make_keys*     (hash, q) keys, packed hash << QB | q; ordered by hash bucket (fpx_keyorder.hpp / fpx_sort.hip) or per query in LDS:
+//                          duplicates become adjacent (dedupSorted) and neighbouring probes walk neighbouring lines
+//      2. probe kernels    by storage form -- blocks: k_probe (fpx_probe_generic.hpp), k_probe_lean8 (fpx_probe_lean.hpp), k_probe_small;
+//                          direct-addressed: k_probe_direct, k_probe_group, k_probe_pgroup; memory segments: k_probe_memtab
+//      3. scoring          records binned by the probe kernel and scored a bin per workgroup (k_score_bin), or partitioned by query
+//                          (fpx_partition.hpp) and counted by k_score: a counting filter + an exact table in LDS, score >= min_score
+//      4. k_finish         (score desc, doc asc), relative cut-off, top-k; k_merge for per-rank partial tables
+// Integer gather/scan work: HBM-request-bound, no MFMA.  This file holds the host side: run_batch and the C-ABI implementations.
 #include <cstdio>
 #include <cstring>
 #include <hip/hip_runtime.h>
@@ -91,8 +87,8 @@ int build_memtab(Snapshot* sn)
 {
     uint64_t total = 0, mmax = 0;
     for (const MemDesc& m : sn->h_mem) { total += m.num_items; mmax = std::max<uint64_t>(mmax, m.num_items); }
-    if (total == 0 || total >= 0xFFFFFFF0ull) return FPX_OK;            // (nothing to look up / offsets would not fit: the per-segment kernels)
-    if (ctx_opt(sn->ctx, OPT_MEMTAB) == 0) return FPX_OK;
+    if (total == 0) return FPX_OK;                                      // (nothing to look up)
+    if (total >= 0xFFFFFFF0ull) { set_error("a snapshot's memory segments hold %llu items: their table's offsets are 32 bits", (unsigned long long)total); return FPX_E_INVAL; }
     uint64_t* buf[2] = {nullptr, nullptr};
     unsigned long long* d_count = nullptr;
     void* d_temp = nullptr;
@@ -762,10 +758,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
     // into bins of 2^BQ queries itself and k_score_bin scores a bin per workgroup (fpx_score_bin.hpp) -- no partition kernels
     // Queries per bin: eight, fewer for batches that would not give k_score_bin ~2048 workgroups otherwise (a workgroup's time is
     // a chain of tile-load latencies: 8192 queries in bins of 4: 170 -> 154 us, 1024 queries in bins of 2: 66 -> 29 us)
-    const int bin_q_forced = (int)ctx_opt(snap->ctx, OPT_BIN_Q_LOG2);
     uint32_t bin_q_log2 = 3u;
-    if (bin_q_forced >= 0) bin_q_log2 = (uint32_t)bin_q_forced;
-    else while (bin_q_log2 > 1u && (B >> bin_q_log2) < 2048u) --bin_q_log2;
+    while (bin_q_log2 > 1u && (B >> bin_q_log2) < 2048u) --bin_q_log2;
     const bool binned_enabled = ctx_opt(snap->ctx, OPT_BINNED) != 0;
     bool binned = false;
     uint32_t sbins = 0;
@@ -875,11 +869,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     ProbeArgs gk = a;
                     gk.segs = snap->d_direct; gk.lean_stats = stat_sets;
                     if (binned) { gk.bins = h_bin.bins; gk.bin_cap = h_bin.bin_cap; gk.bin_count = h_bin.bin_count; gk.bin_shift = h_bin.shift; gk.rec32 = h_bin.rec32; gk.refs = ref_cap ? ws->d_refs : nullptr; gk.ref_cap = ref_cap; }
-                    const uint32_t group_rounds = (uint32_t)std::max<int64_t>(0, ctx_opt(snap->ctx, OPT_GROUP_ROUNDS));
-                    gk.rounds = group_rounds ? std::min(group_rounds, 1024u) : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
+                    gk.rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(6, wgs_group / 6000));   // (8192 x 1000: 0.626 / 0.580 / 0.566 / 0.564 ms at 2 / 3 / 4 / 6)
                     // (hot-hash data -- the previous batch brought 16+ records per key: a workgroup's rounds wait for the waves that copy the
                     // long lists; three rounds: 3.5 ms per batch of 8192 on distribution Z where five take 4.4)
-                    if (!group_rounds && fast && est_H > 16ull * P) gk.rounds = std::min(gk.rounds, 3u);
+                    if (fast && est_H > 16ull * P) gk.rounds = std::min(gk.rounds, 3u);
                     const uint64_t per_wg_gk = (uint64_t)FK_WG * gk.rounds;
                     for (const GroupDesc& gd : snap->h_group) {              // one launch per group: its descriptor is a kernel argument
                         const GroupArgs gargs{gd, snap->d_direct};
@@ -971,18 +964,6 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
             hipLaunchKernelGGL(k_probe_memtab, dim3(memtab_grid(P)), dim3(WG), 0, st, (const uint64_t*)snap->d_memtab, (const uint32_t*)snap->d_membucket,
                                d_pairs, P, qb, flagged ? KEY_SKIP_FLAGGED : key_skip, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters,
                                (const unsigned long long*)nullptr, 0ull, (const uint32_t*)snap->d_membits);
-            FPX_HIP(hipGetLastError());
-        } else if (P && snap->n_mem) {
-            uint64_t mem_items = 0, mem_max = 0;
-            for (const MemDesc& m : snap->h_mem) { mem_items += m.num_items; mem_max = std::max<uint64_t>(mem_max, m.num_items); }
-            if (mem_items * 2 < P * snap->n_mem && !local_sort) {   // fewer items than (pair, segment) probes: search from the items' side (needs the batch-wide hash order)
-                const uint32_t gxm = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (mem_max + WG - 1) / WG), 4096);
-                hipLaunchKernelGGL(k_probe_mem_items, dim3(gxm, snap->n_mem), dim3(WG), 0, st,
-                                   snap->d_mem, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
-            } else {
-                hipLaunchKernelGGL(k_probe_mem, dim3((uint32_t)((P + WG - 1) / WG), snap->n_mem), dim3(WG), 0, st,
-                                   snap->d_mem, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters);
-            }
             FPX_HIP(hipGetLastError());
         }
         if (single_fast || fast) break;             // nothing below needs the counts on the host yet

@@ -95,7 +95,7 @@ void fpx_ctx_destroy(fpx_ctx *ctx);
 int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context lives on */
 /* The options of a context: everything that steers the library's behaviour.  Each falls back to the environment variable
  * FPX_<NAME> (the tests' and the A/B tools' way in), then to the default; a value below the option's smallest one (-1 for most,
- * -2 for "group_packed" and "bin_q_log2", where -1 is the explicit setting "decide by the data") = back to that fallback.
+ * -2 for "group_packed", where -1 is the explicit setting "decide by the data") = back to that fallback.
  * Storage forms -- read when a segment is created / a snapshot first holds it; fpx_segment_layout(), fpx_segment_layout_reason()
  * and fpx_snapshot_info() say what came of it:
  *   "direct"             1 | 0   dense segments trade their blocks for a direct-addressed form (default 1)
@@ -105,21 +105,17 @@ int  fpx_ctx_device(const fpx_ctx *ctx);     /* the HIP ordinal the context live
  *                        by the group's density (default)
  *   "presence_min_items" items from which a segment in blocks gets presence bits and probe records (the lean kernel; default 2^20)
  *   "lean_head"          4: the lean kernel always fetches whole blocks (default 0: two lines where a block's head fits them)
- *   "inline_doubles"     1 | 0   a hash with two docs keeps both in the group's words (default 1)
- *   "memtab"             1 | 0   a snapshot's memory segments behind ONE hash-sorted table (default 1)
  * Search paths -- read per batch:
  *   "query_wg"           1 | 0   a snapshot that is ONE packed group and nothing else (the resident index between merges) is searched a
  *                        QUERY PER WORKGROUP -- dedup, probe, count and floor in one kernel, the hit records never leaving the CU
  *                        (csrc/fpx_qsearch.hpp; default 1) | by the pipeline below like every other snapshot
  *   "fast"               1 | 0   the device-sized path (one host round trip per batch; default 1)
  *   "binned"             1 | 0   groups drop their records into bins of a few queries, scored a bin per workgroup (default 1)
- *   "bin_q_log2"         log2 of the queries per bin (-1: by the batch's size, default)
  *   "rec32"              1 | 0   4-byte records in the bins where the doc ids leave room (default 1)
  *   "local_sort_max", "order_min_pairs"   pair counts that choose how a batch's keys are ordered
  *   "hot_refs"           1 | 0 | -1   the lists of HOT hashes (64+ docs) reach the score kernel by reference instead of a copy per query |
  *                        are copied into the bins | by the records the workspace's last batch brought (default)
  *   "lean_min"           probes from which block-form segments take the lean kernel (default 2^16)
- *   "group_rounds"       rounds per workgroup of the groups' probe kernels (0: by the batch's size)
  *   "sharded_workers"    worker threads per device of a sharded snapshot (1..16, default 3)
  * (FPX_SHARDED_RCCL alone stays with the process: whether librccl is loaded at all.) */
 int  fpx_ctx_set_option(fpx_ctx *ctx, const char *name, int64_t value);

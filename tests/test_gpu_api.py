@@ -222,7 +222,7 @@ def test_search_path_options_belong_to_the_context_too(monkeypatch):
     from fpx_testlib import fpx, oracle, Pair
     if os.environ.get("FPX_VARIANT_CHILD") == "1":
         pytest.skip("the variant runs move the defaults through the environment")
-    for k in ("FPX_BINNED", "FPX_FAST", "FPX_REC32", "FPX_BIN_Q_LOG2", "FPX_GROUP_ROUNDS", "FPX_MEMTAB"):
+    for k in ("FPX_BINNED", "FPX_FAST", "FPX_REC32"):
         monkeypatch.delenv(k, raising=False)
 
     def world(ctx):
@@ -236,9 +236,9 @@ def test_search_path_options_belong_to_the_context_too(monkeypatch):
     a, b = fpx.Context(0), fpx.Context(0)
     for c in (a, b):
         c.set_option("direct_min_items", 0); c.set_option("fuse_min", 1)
-    assert a.get_option("binned") == 1 and a.get_option("fast") == 1 and a.get_option("rec32") == 1 and a.get_option("bin_q_log2") == -1
-    assert a.get_option("group_rounds") == 0 and a.get_option("sharded_workers") == 3 and a.get_option("lean_min") == 1 << 16
-    b.set_option("binned", 0); b.set_option("rec32", 0); b.set_option("group_rounds", 2); b.set_option("order_min_pairs", 0)
+    assert a.get_option("binned") == 1 and a.get_option("fast") == 1 and a.get_option("rec32") == 1
+    assert a.get_option("sharded_workers") == 3 and a.get_option("lean_min") == 1 << 16
+    b.set_option("binned", 0); b.set_option("rec32", 0); b.set_option("order_min_pairs", 0)
     pa, pb = world(a), world(b)
     ga, sta = pa.check(qs, fpx.http_options())                   # (check: the general path, then the device-sized one, both == the oracle)
     gb, stb = pb.check(qs, fpx.http_options())

@@ -13,10 +13,9 @@ variant runs in a process of its own):
 * FPX_GROUP_PACKED=1     ... every group in the PACKED form (k_probe_pgroup: 128-byte lines of 4 / 8 hash values with their words inside;
                          by default only groups dense enough for it -- the full-size indexes of tests/test_gpu_fullsize.py)
 * FPX_BINNED=0           ... with the two-level partition + k_score instead (the path of mixed snapshots)
-* FPX_INLINE_DOUBLES=0   ... with every hash of several docs behind a list reference (no inline doubles)
-* FPX_REC32=0            ... with 8-byte records in the bins (by default 4-byte ones where the doc ids leave room), bins of eight
-                         queries whatever the batch, the keys of every batch ordered by our counting sort (FPX_ORDER_MIN_PAIRS=0)
-* FPX_POISON=1           ... with every fresh device allocation of the library filled with 0xCD before it is handed out (csrc/fpx_api.hip:
+* FPX_REC32=0            ... with 8-byte records in the bins (by default 4-byte ones where the doc ids leave room), the keys of every
+                         batch ordered by our counting sort (FPX_ORDER_MIN_PAIRS=0), and in the same child
+  FPX_POISON=1           every fresh device allocation of the library filled with 0xCD before it is handed out (csrc/fpx_api.hip:
                          dmalloc_raw): nothing may depend on what fresh device memory happens to hold -- usually zeros, which is how such a
                          dependence hides (tools/poison_bisect.py narrows a failure down to one allocation)
 * FPX_DIRECT=0           no segment direct-addressed: segments of >= 2^20 items (direct-addressed by default) are searched in
@@ -45,15 +44,15 @@ FUSED_SUITES = ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/t
 # (the three switches of the block form's paths run TOGETHER -- batch-wide sort, general path, whole-block lean kernel --: each on its
 # own was another child of four suites, a fifth of the GPU suite's time between them; the batch-wide sort with the device-sized path
 # and the partial-fetch lean kernel is what tests/test_gpu_fullsize.py's block-form runs take)
+# (seven children.  Round 5 ran ten: the grouped form on the general path alone -- every workspace's first batch takes it in the other
+# children --, the builder without inline doubles and forced bin sizes -- options folded into constants since --, and the poisoned
+# allocations in a child of their own)
 VARIANTS = [{"FPX_DIRECT": "0"},
             {"FPX_LOCAL_SORT_MAX": "0", "FPX_FAST": "0", "FPX_LEAN_HEAD": "4"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "0"}, {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1"},
-            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_FAST": "0", "FPX_LOCAL_SORT_MAX": "0"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_GROUP_PACKED": "1"},
             {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_BINNED": "0"},
-            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_INLINE_DOUBLES": "0", "FPX_BIN_Q_LOG2": "2"},
-            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_BIN_Q_LOG2": "3", "FPX_ORDER_MIN_PAIRS": "0"},
-            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_POISON": "1"}]
+            {"FPX_DIRECT_MIN_ITEMS": "0", "FPX_FUSE_MIN": "1", "FPX_REC32": "0", "FPX_ORDER_MIN_PAIRS": "0", "FPX_POISON": "1"}]
 
 
 def _name(env):
@@ -63,18 +62,16 @@ def _name(env):
 def _suites(env):
     if env.get("FPX_FUSE_MIN") == "1":
         # the sub-variants of the grouped form: the suites that reach the switched code
-        if "FPX_BINNED" in env or "FPX_FAST" in env:
+        if "FPX_BINNED" in env:
             return ["tests/test_gpu_parity.py", "tests/test_gpu_direct.py"]
-        if "FPX_POISON" in env:         # (the builders, the group's arenas, the searches' workspaces, merges and downloads)
-            return ["tests/test_gpu_parity.py", "tests/test_gpu_direct.py", "tests/test_gpu_merge.py"]
-        if "FPX_INLINE_DOUBLES" in env:
-            return ["tests/test_gpu_golden.py", "tests/test_gpu_parity.py", "tests/test_gpu_direct.py"]
-        if "FPX_REC32" in env:
-            return ["tests/test_gpu_parity.py", "tests/test_gpu_hashshard.py"]
+        if "FPX_POISON" in env:         # (the builders, the group's arenas, the searches' workspaces, merges and downloads; the bins' records, the windows' cells)
+            return ["tests/test_gpu_parity.py", "tests/test_gpu_direct.py", "tests/test_gpu_merge.py", "tests/test_gpu_hashshard.py"]
         if "FPX_GROUP_PACKED" in env:
             # (every group of this child costs 64 / 137 GB of lines and seconds of mapping them, however small its segments: the suites
-            # that reach the packed form's own code -- its probe kernel, its builder, its downloads, its window slices)
-            return [s for s in FUSED_SUITES if "test_gpu_api" not in s and "test_gpu_fuzz" not in s]
+            # that reach the packed form's own code -- its probe kernel, its builder, its downloads, its window slices.  The golden
+            # scenarios -- a snapshot, so a group, per step: 53 s of this child's 324 -- run on groups in the child above; what the packed form
+            # adds is its lines, which the suites here, tests/test_gpu_query_wg.py and the full-size tests search)
+            return [s for s in FUSED_SUITES if "test_gpu_api" not in s and "test_gpu_fuzz" not in s and "test_gpu_golden" not in s]
         return FUSED_SUITES
     return DIRECT_SUITES if "FPX_DIRECT_MIN_ITEMS" in env else SUITES
 

@@ -3,12 +3,19 @@
 
 One step = one pass of the hot path over one batch of synthetic queries (default: 8192 queries x 1000 hashes)
 against a seeded synthetic index resident in HBM (default: BASELINE.json configs[2], 100 M fingerprints x 256
-hashes in 16 FileSegments).  With --gpus N > 1 the SAME index is sharded by HASH RANGE over the ranks: rank r holds the
-window [r 2^32 / N, (r + 1) 2^32 / N) of the hash space of all 16 segments, makes / sorts / probes only the query hashes
-of its window and drops the hit records into the batch's bins of eight queries; the bins travel to the rank that FINISHES
-their queries (one RCCL all-to-all of fixed shape; no table exchange, no merge).  The global batch grows with N (8192 x N
-queries per step: weak scaling -- a rank's probe and score work per step stays what one GPU's is; FPX_BENCH_SCALING=strong
-keeps 8192).  FPX_BENCH_SHARD=segment: the older protocol (whole segments per rank, tables only).
+hashes in 16 FileSegments).  With --gpus N > 1 (the script launches its own N ranks under torch.distributed.run when no launcher did):
+  replica (default when the whole index fits one GPU's HBM, as the 100 M index does: 147 of 288 GB)  every rank holds the WHOLE index and
+          searches its own batches of 8192 queries -- the path's units are queries, they are independent, nothing is exchanged (barrier +
+          max-over-ranks time only); the reference scales reads the same way (replicas that each hold the full index, README.md:105).
+          `value` = N x 8192 x K / time; "scaling": "weak".
+  hash    (FPX_BENCH_SHARD=hash; default when the index does not fit)  the index sharded by HASH RANGE: rank r holds the window
+          [r 2^32 / N, (r + 1) 2^32 / N) of the hash space of all 16 segments, probes only the query hashes of its window and drops the hit
+          records into the batch's bins; the bins travel to the rank that FINISHES their queries (RCCL all-to-alls of fixed shape).  The
+          global batch grows with N (8192 x N per step: weak; FPX_BENCH_SCALING=strong keeps 8192).
+  segment (FPX_BENCH_SHARD=segment: north_star's wording, BASELINE.json configs[3])  whole segments per rank, every rank searches every
+          query against its segments, the partial tables are gathered and merged (fpx_merge_partials).
+DESIGN.md 6 says why the default is what it is: in the packed form a query hash costs one HBM line whatever the number of columns behind it,
+so sharding the SEGMENTS does not divide a rank's work, and sharding the HASH SPACE leaves every rank the bookkeeping of all the queries.
 
 Prints ONE JSON line (rank 0).  At N = 1 the line also carries, measured in the same run:
   roofline      physical bytes of the dominant kernel / its HIP-event time / 8 TB/s (<= 1); `traffic` = HBM bytes by PMC
@@ -566,21 +573,37 @@ def main():
     docs = args.docs
     free_b, total_b = torch.cuda.mem_get_info()
     pw = max(world, eworld)                            # ranks of the protocol (eworld: one GPU plays rank 0 of that many)
-    sharded = pw > 1
-    shard_mode = os.environ.get("FPX_BENCH_SHARD", "hash") if sharded else None
+    # N > 1: how the N GPUs share the work.  "replica" (the default when the whole index fits one GPU's HBM -- the 100 M index: 147 of
+    # 288 GB): every rank holds the WHOLE index and searches its own batches -- the units of this path are queries, they are independent,
+    # and no data-path collective is needed (the reference scales reads the same way: replicas that each hold the full index, README.md:105).
+    # "hash" (the default when it does not fit): hash windows + routed keys; "segment": north_star's wording -- whole segments per rank,
+    # the ranks' partial tables reduced.  In the packed form a query hash costs ONE line whatever the number of columns behind it, so
+    # sharding the segments does not divide a rank's work and sharding the hash space leaves every rank all the queries' bookkeeping:
+    # DESIGN.md 6 has the three side by side.
+    def fits_one_gpu(d):
+        return (d * H * 5.4 + (d // S) * H * 8 * 2.3) * 1.30 + (8 << 30) <= free_b      # (blocks + a segment's build scratch; the conversion in place needs ~1.25 x the blocks at its peak)
+    shard_mode = os.environ.get("FPX_BENCH_SHARD") if pw > 1 else None
+    if pw > 1 and not shard_mode:
+        shard_mode = "replica" if (world > 1 and fits_one_gpu(docs)) else "hash"
+    if shard_mode == "replica" and world <= 1:
+        raise SystemExit("bench.py: FPX_BENCH_SHARD=replica with one rank is the N = 1 run")
+    replica = shard_mode == "replica"
+    sharded = pw > 1 and not replica
     if shard_mode == "hash" and (pw & (pw - 1)):
         shard_mode = "segment"                         # hash windows need a power-of-two number of ranks
-    scaling = os.environ.get("FPX_BENCH_SCALING", "weak" if shard_mode == "hash" else "strong") if sharded else "strong"
-    if scaling == "weak":
+    scaling = os.environ.get("FPX_BENCH_SCALING", "weak" if shard_mode in ("hash", "replica") else "strong") if pw > 1 else "strong"
+    if replica:
+        scaling = "weak"                               # (a rank's batch is the N = 1 batch; the job's is N of them)
+    elif scaling == "weak":
         B *= pw                                        # the global batch: every rank still probes ~8192 queries' worth of hashes
-    local_segs = list(range(S)) if shard_mode == "hash" else [s for s in range(S) if s % pw == rank]
+    local_segs = list(range(S)) if shard_mode in ("hash", "replica") else [s for s in range(S) if s % pw == rank]
     window = None
     if shard_mode == "hash":
         window = (None if rank == 0 else (rank << 32) // pw - 1, None if rank == pw - 1 else ((rank + 1) << 32) // pw - 1)
 
     def need_bytes(d):
         est_seg = (d // S) * H * 5.4                       # ~4.5-5.3 B/item in blocks + derived tables
-        share = len(local_segs) / pw if shard_mode == "hash" else len(local_segs)
+        share = len(local_segs) / pw if shard_mode == "hash" else len(local_segs)       # (replica: all of them, whole)
         return est_seg * share + (d // S) * H * 8 * 2.3 + (4 << 30)   # + build scratch of one segment
     shrunk = False
     if need_bytes(docs) > free_b * 0.92:
@@ -615,6 +638,10 @@ def main():
         q_share = (min(B_global, rank * bpr * 8), min(B_global, (rank + 1) * bpr * 8))
         B = q_share[1] - q_share[0]
         batches = [fpx.synth.make_queries(args.seed, 4242 + 1000003 * i, B, docs, H, query_len=args.query_len, first_query=q_share[0]) for i in range(NQB)]
+    elif replica:
+        # (every rank its own queries: other targets, other noise)
+        B_global = B * world
+        batches = [fpx.synth.make_queries(args.seed, 4242 + 1000003 * i + 7919 * rank, B, docs, H, query_len=args.query_len) for i in range(NQB)]
     else:
         batches = [fpx.synth.make_queries(args.seed, 4242 + 1000003 * i, B, docs, H, query_len=args.query_len) for i in range(NQB)]
     qbs = [fpx.QueryBatch(ctx, options=opts, flat=(f, o)) for f, o, _ in batches]
@@ -822,12 +849,15 @@ def main():
             "config": {"workload": f"{docs} fingerprints x {H} u32 hashes in {S} FileSegments (512-B blocks"
                                    f"{'; kept direct-addressed in HBM' if dominant_kernel(segs) != 'k_probe_lean8' else ''}), "
                                    + (f"the index sharded by hash range over {pw} GPUs (every rank 1/{pw} of the hash space of all segments)" if shard_mode == "hash"
+                                      else f"the WHOLE index on each of {world} GPUs (replicas: it fits one GPU's HBM), every rank searching its own batches of {B} queries -- "
+                                           f"no data-path collective; FPX_BENCH_SHARD=segment | hash run the sharded protocols" if replica
                                       else f"segments sharded over {world} GPU(s)") + f"; batch of {B_global} queries x {args.query_len} hashes, "
                                    f"limit {args.limit}, min_score (n+19)/20, score_pct 10; {NQB} distinct batches resident in HBM, searched in rotation"
                                    + ("; a query per workgroup (k_search_query: dedup, probe, count and floor in one kernel)" if agg.query_wg else ""),
                        "docs": docs, "segments": S, "hashes_per_doc": H, "batch": B_global, "global_batch": B_global, "batch_per_gpu": B_global // pw,
                        "protocol": ("routed keys: a rank uploads its share of the batch, keys travel to their window's rank, bins back (two all-to-alls)" if routed
-                                    else ("the whole batch's hashes resident on every rank, bins exchanged" if shard_mode == "hash" else None)),
+                                    else ("the whole batch's hashes resident on every rank, bins exchanged" if shard_mode == "hash"
+                                          else ("replicas: queries sharded over the ranks, nothing exchanged (barrier + max-over-ranks time only)" if replica else None))),
                        "sharding": shard_mode, "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "segment_layout": ("direct-addressed" + (", one group (hash-major, segment-minor)" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",

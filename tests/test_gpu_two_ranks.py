@@ -165,3 +165,28 @@ def test_two_processes_drive_the_sharded_readers_end_to_end(tmp_path):
 if __name__ == "__main__" and sys.argv[1:2] == ["child"]:
     sys.path.insert(0, ROOT)
     _child(int(sys.argv[2]), sys.argv[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [None, "segment", "hash"])
+def test_bench_with_two_ranks_launches_itself_and_prints_one_line(mode):
+    """`python bench.py --gpus 2` as the driver runs it -- no launcher on the command line -- on ONE GPU (FPX_BENCH_DEVICE=0, gloo): the
+    default (replicas: the index fits, every rank searches its own batches, nothing exchanged) and the two sharded protocols.  One JSON
+    line from rank 0 that names the mode, counts the whole job's queries, and whose last step found every query's target."""
+    import json
+    env = dict(os.environ, FPX_BENCH_BACKEND="gloo", FPX_BENCH_DEVICE="0", FPX_BENCH_LONG="0", FPX_BENCH_SETTLE_S="0", MASTER_PORT="29631")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("FPX_BENCH_SHARD", None)
+    if mode:
+        env["FPX_BENCH_SHARD"] = mode
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--docs", "2000000", "--segments", "4",
+                        "--batch", "512", "--no-measure-bw"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["sharding"] == (mode or "replica")
+    assert d["targets_found"] == d["targets_total"] > 0
+    if mode is None:
+        assert d["scaling"] == "weak" and d["config"]["global_batch"] == 1024 and d["config"]["batch_per_gpu"] == 512
+        assert abs(d["value"] - 1024 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+        assert "replicas" in d["config"]["workload"]

@@ -559,12 +559,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", device))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
     ctx = fpx.Context(device)
 
     # ---- index: S contiguous id ranges, commit_id = s + 1.  The configuration is NOT shrunk to fit:
@@ -589,6 +583,16 @@ def main():
         raise SystemExit("bench.py: FPX_BENCH_SHARD=replica with one rank is the N = 1 run")
     replica = shard_mode == "replica"
     sharded = pw > 1 and not replica
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (replicas exchange nothing on the data path: their barriers and the max-over-ranks of the time go through gloo -- the ranks' GPUs
+        # see no collective at all -- unless FPX_BENCH_BACKEND asks for RCCL; the sharded protocols' exchanges are RCCL's)
+        if replica and "FPX_BENCH_BACKEND" not in os.environ:
+            backend = "gloo"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if shard_mode == "hash" and (pw & (pw - 1)):
         shard_mode = "segment"                         # hash windows need a power-of-two number of ranks
     scaling = os.environ.get("FPX_BENCH_SCALING", "weak" if shard_mode in ("hash", "replica") else "strong") if pw > 1 else "strong"
@@ -858,7 +862,7 @@ def main():
                        "protocol": ("routed keys: a rank uploads its share of the batch, keys travel to their window's rank, bins back (two all-to-alls)" if routed
                                     else ("the whole batch's hashes resident on every rank, bins exchanged" if shard_mode == "hash"
                                           else ("replicas: queries sharded over the ranks, nothing exchanged (barrier + max-over-ranks time only)" if replica else None))),
-                       "sharding": shard_mode, "query_len": args.query_len,
+                       "sharding": shard_mode, "process_group_backend": (backend if world > 1 else None), "query_len": args.query_len,
                        "index_bytes_rank0": index_bytes, "index_blocks_rank0": index_blocks,
                        "segment_layout": ("direct-addressed" + (", one group (hash-major, segment-minor)" if agg.fused else "")) if dominant_kernel(segs) != "k_probe_lean8" else "blocks",
                        "group": next((sg.group_info() for sg in segs if sg.kind == "file" and sg.grouped), None),

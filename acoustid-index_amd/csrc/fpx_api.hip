@@ -197,7 +197,7 @@ void ws_destroy(Workspace* w)
     if (w->h_cells) (void)hipHostFree(w->h_cells);
     void* bufs[] = {w->d_hashes, w->d_offsets, w->d_opts, w->d_keys[0], w->d_keys[1], w->d_hits[0], w->d_hits[1],
                     w->d_cands[0], w->d_cands[1], w->d_temp, w->d_counters, w->d_out, w->d_out_n, w->d_def_list, w->d_def_count, w->d_qrange, w->d_qcand,
-                    w->d_binq, w->d_qcursor};
+                    w->d_binq, w->d_qcursor, w->d_parts, w->d_parts_n};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (w->h_counters) (void)hipHostFree(w->h_counters);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -327,6 +327,7 @@ static void segment_free(Segment* s)
     if (s->d_proberec) (void)hipFree(s->d_proberec);
     if (s->d_blockrec) (void)hipFree(s->d_blockrec);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
+    if (s->d_small_aux) (void)hipFree(s->d_small_aux);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
     if (s->d_items) (void)hipFree(s->d_items);
     if (!s->dstore) {                      // (a direct-addressed segment's arrays belong to its DirectStore, a grouped one's to the group)
@@ -1001,15 +1002,64 @@ static void snapshot_free(Snapshot* sn)
     if (sn->d_memtab) (void)hipFree(sn->d_memtab);
     if (sn->d_membits) (void)hipFree(sn->d_membits);
     if (sn->d_membucket) (void)hipFree(sn->d_membucket);
+    for (Snapshot*& p : sn->part) { if (p) snapshot_free(p); p = nullptr; }
     for (Segment* s : sn->segs) fpx_segment_release(reinterpret_cast<fpx_segment*>(s));
     delete sn;
 }
+
+// `mask` (or null: all): which of the context's segments carry their POSTINGS into the snapshot; the others are docs-only members, like
+// the segments of another context (supersession only).  `resolve`: the segments' storage forms are decided first (resolve_candidates).
+static int snapshot_build(Ctx* c, fpx_segment* const* segs, uint32_t num_segs, const std::vector<uint8_t>* mask, bool resolve, Snapshot** out);
 
 int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_segs, fpx_snapshot** out)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx_);
     if (!c || !out || (!segs && num_segs)) { set_error("null argument"); return FPX_E_INVAL; }
     *out = nullptr;
+    Snapshot* sn = nullptr;
+    int rc = snapshot_build(c, segs, num_segs, nullptr, true, &sn);
+    if (rc != FPX_OK) return rc;
+    // TWO PARTS.  k_search_query (fpx_qsearch.hpp) takes a snapshot that is one packed group and nothing else -- but a LIVE index is never
+    // that for long: checkpoints leave small file segments next to the group (src/Index.zig:679-687), merges a larger one, and with any of
+    // them the whole batch used to fall back to the pipeline's general scoring (tools/live_index.py: 0.57 -> 2.06 ms per batch of 8192 with
+    // three segments of 0.5 M items next to the 100 M index).  A doc lives in ONE segment, so the snapshot's answer is the merge of the
+    // answers of any partition of its segments (what the segment-sharded mode does across devices): part 0 = the group (+ the memory
+    // segments, behind their table), searched a query per workgroup; part 1 = the other file segments, by the pipeline, whose records are
+    // few; k_merge (fpx_score.hpp) puts the two tables together under the queries' relative cut-off.  search_batch_impl decides per batch.
+    if (sn->n_group == 1 && sn->groups[0]->packed && (sn->n_file != 0 || sn->n_solo != 0) && ctx_opt(c, OPT_QUERY_WG) != 0) {
+        const GroupDesc& gd = sn->h_group[0];
+        bool ok = gd.any_dead == 0u && gd.active == (gd.nseg >= 32u ? 0xFFFFFFFFu : ((1u << gd.nseg) - 1u));
+        std::vector<uint8_t> m0(num_segs, 0), m1(num_segs, 0);
+        for (uint32_t i = 0; i < num_segs && ok; ++i) {
+            const Segment* s = reinterpret_cast<const Segment*>(segs[i]);
+            if (s->kind == 2 || s->ctx != c) continue;
+            if (s->kind == 0 && s->own_flags != 0u) ok = false;                    // (a rank's hash window: the sharded protocols' business)
+            else if (s->kind == 1 || s->home == sn->groups[0]) m0[i] = 1; else m1[i] = 1;
+        }
+        if (ok) {
+            Snapshot *p0 = nullptr, *p1 = nullptr;
+            if (snapshot_build(c, segs, num_segs, &m0, false, &p0) == FPX_OK && snapshot_build(c, segs, num_segs, &m1, false, &p1) == FPX_OK &&
+                p0->n_group == 1 && p0->n_file == 0 && p0->n_solo == 0 && p0->groups[0] == sn->groups[0] && p1->n_group == 0 && p1->n_mem == 0 &&
+                (p0->n_mem == 0 || p0->mem_items == 0 || p0->d_memtab != nullptr)) {
+                sn->part[0] = p0; sn->part[1] = p1;
+            } else {                                                               // (no room, or the forms moved under us: the snapshot works without)
+                if (p0) snapshot_free(p0);
+                if (p1) snapshot_free(p1);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    *out = reinterpret_cast<fpx_snapshot*>(sn);
+    return FPX_OK;
+}
+
+static int snapshot_build(Ctx* c, fpx_segment* const* segs, uint32_t num_segs, const std::vector<uint8_t>* mask, bool resolve, Snapshot** out)
+{
+    *out = nullptr;
+    auto here = [&](size_t i) {                      // does segment i carry postings in this snapshot?
+        const Segment* s = reinterpret_cast<const Segment*>(segs[i]);
+        return s->kind != 2 && s->ctx == c && (!mask || (*mask)[i] != 0);
+    };
     bool seen_memory = false;
     for (uint32_t i = 0; i < num_segs; ++i) {
         const Segment* s = reinterpret_cast<const Segment*>(segs[i]);
@@ -1038,8 +1088,9 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     {
         bool any = false, same = true;
         uint32_t fl = 0, lo = 0, hi = 0;
-        for (const Segment* s : sn->segs) {
-            if (s->kind != 0 || s->ctx != c) continue;
+        for (size_t i = 0; i < sn->segs.size(); ++i) {
+            const Segment* s = sn->segs[i];
+            if (s->kind != 0 || !here(i)) continue;
             if (!any) { any = true; fl = s->own_flags; lo = s->own_lo; hi = s->own_hi; }
             else if (s->own_flags != fl || ((fl & 1u) && s->own_lo != lo) || ((fl & 2u) && s->own_hi != hi)) same = false;
         }
@@ -1051,7 +1102,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     std::vector<uint32_t> dead;
     std::vector<Segment*> direct_segs;               // parallel to sn->h_direct
     std::lock_guard<std::mutex> group_lock(c->group_mu);      // (the segments' forms must not change under the descriptors built below)
-    {
+    if (resolve) {
         const int rrc = resolve_candidates(c, sn->segs);
         if (rrc != FPX_OK) { snapshot_free(sn); return rrc; }
     }
@@ -1059,8 +1110,8 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         Segment* s = sn->segs[i];
         // docs-only members: explicit stand-ins (kind 2) and segments resident on ANOTHER context's device -- in a sharded
         // snapshot every device sees the whole segment list, keeps the postings of its own segments and uses the others'
-        // docs maps for supersession only (fpx_sharded_snapshot_create)
-        if (s->kind == 2 || s->ctx != c) continue;
+        // docs maps for supersession only (fpx_sharded_snapshot_create); the same for a PART of a snapshot and the segments of the other part
+        if (!here(i)) continue;
         compute_dead(sn->segs, i, dead);
         uint32_t* d_dead = nullptr;
         uint32_t* d_bits = nullptr;
@@ -1098,6 +1149,11 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
             SegDesc d{};
             d.dead_bits = d_bits;
             d.items = s->d_small_items; d.bstart = s->d_bstart;
+            if (s->d_small_items && s->d_small_aux) {
+                d.sbucket = s->d_small_aux; d.sfirst = s->d_small_aux + ((size_t)1 << (32u - s->small_shift)) + 1u;
+                d.scode = d.sfirst + ((size_t)s->num_items + 63u) / 32u;
+                d.sshift = s->small_shift; d.cshift = s->small_cshift; d.num_items = (uint32_t)s->num_items;
+            }
             d.blocks = s->d_blocks; d.block_index = s->d_block_index; d.bucket = s->d_bucket; d.dead = d_dead; d.cont = s->d_cont;
             d.proberec = s->d_proberec; d.blockrec = s->d_blockrec; d.present_shift = s->present_shift;
             d.own_flags = s->own_flags; d.own_lo = s->own_lo; d.own_hi = s->own_hi;
@@ -1168,8 +1224,9 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         // k_probe_lean8 pays off on 512-B segments dense enough that hash deltas fit two bytes (>= 2^20 items)
         std::vector<SegDesc> lean, lean4, gen, small;
         size_t fi = 0;
-        for (Segment* sg : sn->segs) {
-            if (sg->kind != 0 || sg->ctx != c || sg->direct) continue;
+        for (size_t si = 0; si < sn->segs.size(); ++si) {
+            Segment* sg = sn->segs[si];
+            if (sg->kind != 0 || !here(si) || sg->direct) continue;
             const SegDesc& d = sn->h_file[fi++];
             if (d.block_size == 512 && sg->num_items >= (1ull << 20) && d.num_blocks < (1u << 30) && d.blockrec && d.proberec) {
                 if (sg->head_lines == 2) lean.push_back(d); else lean4.push_back(d);
@@ -1202,7 +1259,7 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
         const int mrc = build_memtab(sn);             // (FPX_E_NOMEM: no room for two copies of the memory segments' items)
         if (mrc != FPX_OK) { snapshot_free(sn); return mrc; }
     }
-    *out = reinterpret_cast<fpx_snapshot*>(sn);
+    *out = sn;
     return FPX_OK;
 }
 

@@ -481,6 +481,7 @@ static void free_partial_segment(Segment* s)
     if (s->d_proberec) (void)hipFree(s->d_proberec);
     if (s->d_blockrec) (void)hipFree(s->d_blockrec);
     if (s->d_small_items) (void)hipFree(s->d_small_items);
+    if (s->d_small_aux) (void)hipFree(s->d_small_aux);
     if (s->d_bstart) (void)hipFree(s->d_bstart);
     if (s->d_drec) (void)hipFree(s->d_drec);
     if (s->d_primary) (void)hipFree(s->d_primary);
@@ -699,9 +700,45 @@ __global__ void k_bstart32(const uint64_t* __restrict__ boff, uint32_t num_block
     if (b == num_blocks) bstart[b] = (uint32_t)total;
 }
 
+// the decoded items' bucket table and block-first bits (SegDesc::sbucket, sfirst)
+__global__ void k_small_buckets(const uint64_t* __restrict__ items, uint32_t n, uint32_t shift, uint32_t nbuckets, uint32_t* __restrict__ bucket)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nbuckets) return;
+    const uint64_t hv = (uint64_t)k << shift;                       // first hash of bucket k (k == nbuckets: past the last hash)
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((items[m] >> 32) < hv) lo = m + 1; else hi = m; }
+    bucket[k] = lo;
+}
+__global__ void k_small_first_bits(const uint32_t* __restrict__ bstart, uint32_t num_blocks, uint32_t* __restrict__ bits)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= num_blocks) return;
+    const uint32_t i = bstart[b];
+    if (b == 0u || i != bstart[b - 1u]) atomicOr(&bits[i >> 5], 1u << (i & 31u));      // (an empty block has no first item)
+}
+
+// (SegDesc::scode) one thread per word of sixteen cells
+__global__ void k_small_codes(const uint64_t* __restrict__ items, uint32_t n, const uint32_t* __restrict__ first_bits, uint32_t cshift, uint32_t nwords,
+                              uint32_t* __restrict__ codes)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    auto lower = [&](uint64_t hv) { uint32_t lo = 0, hi = n; while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((items[m] >> 32) < hv) lo = m + 1; else hi = m; } return lo; };
+    uint32_t word = 0, at = lower(((uint64_t)w * 16u) << cshift);
+    for (uint32_t c = 0; c < 16u; ++c) {
+        const uint32_t nxt = lower(((uint64_t)w * 16u + c + 1u) << cshift);
+        // no item in the cell: every hash of it is absent, and the walk would visit the block of item `at` unless that item opens its block
+        if (nxt == at) word |= ((at < n && ((first_bits[at >> 5] >> (at & 31u)) & 1u) == 0u) ? 1u : 2u) << (2u * c);
+        at = nxt;
+    }
+    codes[w] = word;
+}
+
 // A small file segment (a fresh checkpoint: 10^5 .. 10^6 items) holds wide hash deltas, which the lean probe kernel
 // does not decode, and probing it block by block with the generic kernel costs more than a 1.6 G-item segment does.
-// It is decoded ONCE, when it becomes resident; searches then binary-search its items (k_probe_small).
+// It is decoded ONCE, when it becomes resident; a search's keys then find their hash among its items through a bucket table
+// (k_probe_small: a couple of dependent loads per key).
 int decode_small_segment(Segment* s)
 {
     if (s->kind != 0 || s->num_blocks == 0 || s->num_items == 0 || s->num_items >= (1ull << 20)) return FPX_OK;
@@ -726,6 +763,24 @@ int decode_small_segment(Segment* s)
                        (const uint32_t*)nullptr, 0u, s->d_small_items, live.as<uint8_t>());
     hipLaunchKernelGGL(k_bstart32, dim3((s->num_blocks + 256) / 256), dim3(256), 0, st, boff.as<uint64_t>(), s->num_blocks,
                        s->num_items, s->d_bstart);
+    {
+        uint32_t lg = 8;
+        while (lg < 20u && (1ull << lg) < s->num_items) ++lg;
+        const uint32_t nbits = lg - 1u, nbuckets = 1u << nbits;                       // ~2 items per bucket
+        const uint32_t cbits = std::min(lg + 3u, 24u), cwords = (1u << cbits) / 16u;  // eight cells per item
+        const size_t fwords = ((size_t)s->num_items + 63u) / 32u;
+        const size_t words = (size_t)nbuckets + 1u + fwords + cwords;
+        FPX_HIP(dmalloc(&s->d_small_aux, words * sizeof(uint32_t)));
+        s->small_shift = 32u - nbits; s->small_cshift = 32u - cbits;
+        s->device_bytes += words * sizeof(uint32_t);
+        FPX_HIP(hipMemsetAsync(s->d_small_aux + nbuckets + 1u, 0, fwords * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_small_buckets, dim3((nbuckets + 256) / 256), dim3(256), 0, st, (const uint64_t*)s->d_small_items, (uint32_t)s->num_items,
+                           s->small_shift, nbuckets, s->d_small_aux);
+        hipLaunchKernelGGL(k_small_first_bits, dim3((s->num_blocks + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->d_bstart, s->num_blocks,
+                           s->d_small_aux + nbuckets + 1u);
+        hipLaunchKernelGGL(k_small_codes, dim3((cwords + 255) / 256), dim3(256), 0, st, (const uint64_t*)s->d_small_items, (uint32_t)s->num_items,
+                           (const uint32_t*)(s->d_small_aux + nbuckets + 1u), s->small_cshift, cwords, s->d_small_aux + nbuckets + 1u + fwords);
+    }
     FPX_HIP(hipGetLastError());
     FPX_HIP(hipStreamSynchronize(st));
     return FPX_OK;
@@ -1299,6 +1354,7 @@ void free_block_form(Segment* s)
     if (s->d_proberec) { (void)hipFree(s->d_proberec); s->d_proberec = nullptr; }
     if (s->d_blockrec) { (void)hipFree(s->d_blockrec); s->d_blockrec = nullptr; }
     if (s->d_small_items) { (void)hipFree(s->d_small_items); s->d_small_items = nullptr; }
+    if (s->d_small_aux) { (void)hipFree(s->d_small_aux); s->d_small_aux = nullptr; }
 }
 
 // ---- back to items and blocks (downloads, merges) ---------------------------------------------------------------------

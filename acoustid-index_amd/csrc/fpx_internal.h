@@ -41,6 +41,15 @@ struct SegDesc {
     // small segments (< 2^20 items) are also kept DECODED: sorted items + where each block starts among them
     const uint64_t* items;         // hash << 32 | doc, or null
     const uint32_t* bstart;        // [num_blocks + 1] item offset of each block
+    // ... with what a KEY needs to find its hash among them in a couple of dependent loads (k_probe_small): sbucket[k] = the first item
+    // whose hash is >= k << sshift ([2^(32 - sshift) + 1] entries: ~2 items per bucket), sfirst: bit i = item i is the first of its block
+    // scode: two bits per 2^cshift hash values (eight such cells per item: seven keys in eight are answered by this ONE load) -- 0: the
+    // cell holds items (look them up), 1: none, and it lies inside a block's hash range (an absent hash there costs the reference one
+    // visited block), 2: none, in the gap between two blocks / outside them (no visit, src/FileSegment.zig:153,164)
+    const uint32_t* sbucket;
+    const uint32_t* sfirst;
+    const uint32_t* scode;
+    uint32_t sshift, cshift, num_items;
     uint32_t num_blocks;
     uint32_t block_size;
     uint32_t bucket_shift;         // bucket of hash h = h >> bucket_shift (32 -> one bucket)
@@ -236,6 +245,7 @@ struct Segment {
     uint32_t head_lines = 4;       // 2: in EVERY block the header, the hashes and the docid control bytes end before byte 252, so
                                    // k_probe_lean8<2> may fetch two 128-B lines first and the matching docid bytes afterwards
     uint64_t* d_small_items = nullptr; uint32_t* d_bstart = nullptr;   // decoded copy of a small segment (see SegDesc)
+    uint32_t* d_small_aux = nullptr; uint32_t small_shift = 0, small_cshift = 0;   // ... its bucket table [2^(32 - small_shift) + 1], the block-first bits of its items, the cells' codes (SegDesc)
     // direct-addressed form (fpx_direct.hpp): replaces the blocks of a dense segment; d_bstart (item offset of every block) and
     // d_block_index stay, so that the blocks can be written out again byte for byte (materialize_blocks)
     const char* why = "";          // why the segment is kept the way it is (fpx_segment_layout_reason): a static string
@@ -277,6 +287,7 @@ struct Snapshot {
     uint32_t qs_skip = 0;                // batches that stay off the one-workgroup-per-query path (fpx_qsearch.hpp) after a query's records outgrew its LDS array
     std::vector<std::shared_ptr<DirectStore>> solo_stores;       // the arrays d_solo points into
     SegDesc* d_solo = nullptr; uint32_t n_solo = 0;
+    Snapshot* part[2] = {nullptr, nullptr};   // [0]: its ONE packed group + the memory segments, [1]: its other file segments -- searched apart, tables merged (fpx_snapshot_create); or none
     uint32_t max_small_blocks = 0;
     MemDesc* d_mem = nullptr; uint32_t n_mem = 0;
     // ... and ONE table of all memory segments' LIVE postings (superseded docs dropped), sorted by hash, behind a 2^20-entry bucket
@@ -331,6 +342,8 @@ struct Workspace {
     uint64_t hint_misc = 0;               // records the last binned batch left in the misc buffer (sizes k_bin's grid)
     uint64_t hint_P = 0, hint_H = 0;      // pairs and hit records of the last batch this workspace ran (sizes the next one)
     uint32_t fast_penalty = 0;            // batches left before the device-sized path is tried again after it had to be redone
+    fpx_result* d_parts = nullptr; size_t cap_parts = 0;       // a snapshot in two parts: their tables [2][B][cap] and counts [2][B] (search_parts)
+    uint32_t* d_parts_n = nullptr; size_t cap_parts_n = 0;
     uint64_t batch_hist[HIST_SLOTS + 1] = {};  // the scan histogram slots of the batch run_batch just finished, [HIST_SLOTS]: walks answered from blocks (search_split adds them to the context's)
     // pinned host staging
     unsigned long long* h_counters = nullptr;

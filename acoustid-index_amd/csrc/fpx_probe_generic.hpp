@@ -70,12 +70,14 @@ __device__ __forceinline__ void hist_observe(uint32_t* wg_h, uint32_t docs, uint
     atomicAdd(&wg_h[db != 0u ? db - 1u : 15u], 1u);
     atomicAdd(&wg_h[bb >= 2u ? 7u + bb : 15u], 1u);                              // (2 | 3 | 4-5 blocks -> slots 9 | 10 | 11; MAX_BLOCKS_PER_HASH = 4)
 }
-// the workgroup's slots join the launch's: its set of the spread statistics, or (a small launch) the batch's counters
+// the workgroup's slots join the launch's: its set of the spread statistics, or (a small launch) the batch's counters -- where the
+// histograms' totals (observations, their docs, their blocks) are the counters' own CTR_PROBES / _DOCS / _BLOCKS: the host adds those
+// (gather_hist), the kernel does not pay three more atomics on the counters' line for them
 __device__ __forceinline__ void hist_publish(const ProbeArgs& a, const uint32_t* wg_h, unsigned long long probes, unsigned long long docs,
                                              unsigned long long blocks, uint32_t tid)
 {
     if constexpr (!SCAN_HIST || !(FPX_SH_BITS & 4)) return;
-    if (tid >= HIST_SLOTS - 1u) return;                      // (slot 15: hist_observe's sink)
+    if (tid >= (a.lean_stats ? HIST_SLOTS - 1u : HIST_COUNT)) return;      // (slot 15: hist_observe's sink)
     const unsigned long long v = tid == HIST_COUNT ? probes : tid == HIST_DOCS ? docs : tid == HIST_BLOCKS ? blocks : (unsigned long long)wg_h[tid];
     if (v == 0ull) return;
     unsigned long long* dst = a.lean_stats ? a.lean_stats + (size_t)LEAN_STAT_SETS * 8u + (size_t)(blockIdx.x % LEAN_STAT_SETS) * HIST_SLOTS : a.counters + CTR_HIST;

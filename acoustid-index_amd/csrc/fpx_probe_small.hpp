@@ -141,120 +141,161 @@ __global__ __launch_bounds__(WG) void k_probe_memtab(const uint64_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// 4b. small file segments (< 2^20 items; fresh checkpoints) in their decoded form (SegDesc::items / bstart).
-//     A batch holds thousands of pairs per BLOCK of such a segment, so the work is organised by block: one workgroup
-//     stages a block's items in LDS, finds the slice of the (bucket-sorted) pairs whose first block it is with two
-//     binary searches, and streams that slice -- FileSegment.search restated per block, with the same walk over <= 4
-//     blocks, the > 1000 docs stop and the same counters (src/FileSegment.zig:145-175), nothing decoded per probe.
+// 5. small file segments (< 2^20 items: fresh checkpoints, src/Index.zig:679-687), kept DECODED next to their blocks: sorted items, a
+//    bucket table over the top hash bits (~2 items per bucket) and one bit per item "first of its block".  One thread per (key, segment),
+//    the keys in ANY order: two loads for the bucket, a step or two to the first item >= h, and FileSegment.search's walk
+//    (src/FileSegment.zig:143-179) read off the items -- the hash is absent: the block that would be visited is the one holding that
+//    item unless the item is its first (h falls in the gap before it, :164); present: every doc of the run, a block more each time the
+//    run crosses a block-first item, until four blocks or past 1000 docs (:171-174).
+//    (Rounds 1-5 walked the segment's blocks with the batch's keys looked up by hash range: 0.46 ms per batch of 8192 x 1000 keys for
+//    three segments of 0.5 M items -- as long as the 100 M index next to them takes.)
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t SMALL_LDS_ITEMS = 2048;     // MAX_ITEMS_PER_BLOCK
-constexpr uint32_t SMALL_BPW = 8;              // consecutive blocks per workgroup: their pair slices are consecutive too
-__global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, const uint64_t* __restrict__ pairs, uint64_t P,
+constexpr uint32_t SMALL_KPT = 4;
+constexpr uint32_t SMALL_STAGE = 2048;         // hit records a workgroup holds back (16 KB of LDS)
+constexpr uint32_t SMALL_GRID = 768;            // workgroups at most (three per CU; measured with 8 M keys x 3 segments: 0.206 ms -- 0.305 with 4096: every workgroup ends with four atomics on the counters' one line)
+__global__ __launch_bounds__(WG) void k_probe_small(const SegDesc* segs, uint32_t nsegs, const uint64_t* __restrict__ pairs, uint64_t P,
                                                      uint32_t qb, uint64_t* hits, uint64_t hit_cap,
                                                      unsigned long long* counters, unsigned long long* qstats = nullptr)
 {
-    __shared__ uint64_t blk_items[SMALL_LDS_ITEMS];
-    __shared__ uint64_t prange[2];
-    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes;
+    __shared__ unsigned long long wg_blocks, wg_docs, wg_probes, wg_bytes;
     __shared__ uint32_t wg_h[HIST_SLOTS];                                  // the scan histograms' slots of this workgroup (hist_observe)
-    const SegDesc seg = segs[blockIdx.y];
+    // the workgroup's hit records wait here for ONE reservation in the batch's buffer (a query aimed at a fresh doc brings a record per
+    // hash: 131 k records per batch in tools/live_index.py -- an atomic on the batch's one counter for each was most of this kernel's time)
+    __shared__ uint64_t stage[SMALL_STAGE];
+    __shared__ uint32_t stage_n;
+    __shared__ unsigned long long stage_base;
     const uint32_t tid = threadIdx.x;
-    const uint32_t bfirst = blockIdx.x * SMALL_BPW;
-    if (bfirst >= seg.num_blocks) return;
-    const uint32_t bend = min(bfirst + SMALL_BPW, seg.num_blocks);
     const uint32_t qmask = qb >= 32u ? 0xFFFFFFFFu : ((1u << qb) - 1u);
-    if (tid == 0) { wg_blocks = 0; wg_docs = 0; wg_probes = 0; }
+    if (tid == 0) { wg_blocks = 0; wg_docs = 0; wg_probes = 0; wg_bytes = 0; stage_n = 0; }
     if (tid < HIST_SLOTS) wg_h[tid] = 0u;
-    unsigned long long my_blocks = 0, my_docs = 0, my_probes = 0;
-    for (uint32_t b = bfirst; b < bend; ++b) {
-        const uint32_t s0 = seg.bstart[b], n = seg.bstart[b + 1] - s0;
-        const uint32_t hmin = (uint32_t)(seg.items[s0] >> 32), hmax = seg.block_index[b];
-        const bool has_prev = b != 0u;
-        const uint32_t hprev = has_prev ? seg.block_index[b - 1] : 0u;           // hashes <= hprev start in an earlier block
-        const bool last_block = b + 1u == seg.num_blocks;
-        __syncthreads();                                                         // the previous block's items are done with
-        for (uint32_t i = tid; i < n; i += WG) blk_items[i] = seg.items[s0 + i];
-        if (tid < 2u) {
-            // pairs are sorted by bucket = hash >> KEY_SORT_SKIP: [first pair of the bucket of hprev, first pair after the
-            // bucket of hmax); the last block also takes the pairs above every block (they probe nothing but are counted).
-            // After the workgroup's first block the searches start from the previous slice (a few steps instead of 23).
-            const uint32_t want = tid == 0u ? (has_prev ? (hprev >> KEY_SORT_SKIP) : 0u) : (hmax >> KEY_SORT_SKIP);
-            uint64_t lo = 0, hi = P;
-            if (b != bfirst) {
-                // the previous block's slice ended at E = first pair after the bucket of hprev: this block's slice starts
-                // inside that bucket, a little before E, and ends somewhere after E
-                const uint64_t E = prange[1];
-                auto bucket_at = [&](uint64_t i) { return (uint32_t)(pairs[i] >> qb) >> KEY_SORT_SKIP; };
-                if (tid == 0u) {
-                    hi = E;
-                    lo = E > 4096 ? E - 4096 : 0;
-                    if (lo != 0 && bucket_at(lo - 1) >= want) lo = 0;              // (a bucket with > 4096 pairs)
-                } else {
-                    lo = E;
-                    if (E + 65536 < P && bucket_at(E + 65536) > want) hi = E + 65536;
-                }
-            }
-            if (tid == 1u && last_block) lo = hi = P;
-            while (lo < hi) {
-                const uint64_t m = (lo + hi) >> 1;
-                const uint32_t bk = (uint32_t)(pairs[m] >> qb) >> KEY_SORT_SKIP;
-                if (tid == 0u ? bk < want : bk <= want) lo = m + 1; else hi = m;
-            }
-            prange[tid] = lo;
-        }
+    __syncthreads();
+    unsigned long long my_blocks = 0, my_docs = 0, my_probes = 0, my_bytes = 0;
+    // (SMALL_KPT keys per thread, a workgroup's keys WG apart, against every small segment in turn: the keys' loads, the bucket bounds', each
+    // step of the searches and the items' go out together -- one key at a time is a chain of five load latencies per wave)
+    auto flush = [&](bool last) {                                          // (the whole workgroup; between rounds)
         __syncthreads();
-        for (uint64_t p = prange[0] + tid; p < prange[1]; p += WG) {
-            const uint64_t key = pairs[p];
-            const uint32_t h = (uint32_t)(key >> qb), q = (uint32_t)key & qmask;
-            if ((has_prev && h <= hprev) || (!last_block && h > hmax)) continue;   // edges of the boundary buckets
-            if (seg.own_flags != 0u && !owned_hash(seg, h)) continue;
-            if (is_duplicate_pair(pairs, p, key, qb)) continue;
-            my_probes += 1;
-            if (h > hmax || h < hmin) continue;                                    // above every block / in the gap before this one
-            // equal range of h among the staged items
-            uint32_t lo = 0, hi = n;
-            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint32_t)(blk_items[m] >> 32) < h) lo = m + 1; else hi = m; }
-            uint32_t nb = 1, nd = 0;
-            for (uint32_t i = lo; i < n && (uint32_t)(blk_items[i] >> 32) == h; ++i) {
-                ++nd;
-                const uint32_t d = (uint32_t)blk_items[i];
-                if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
-                const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull); // hits in a small segment are rare
-                if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
-            }
-            // the walk goes on while the next block starts with h (:164), up to 4 blocks / past 1000 docs (:172-173)
-            for (uint32_t nbk = b + 1u; nb < (uint32_t)MAX_BLOCKS_PER_HASH && nd <= (uint32_t)MAX_DOCS_PER_HASH && nbk < seg.num_blocks; ++nbk) {
-                const uint32_t s1 = seg.bstart[nbk], e1 = seg.bstart[nbk + 1];
-                if ((uint32_t)(seg.items[s1] >> 32) != h) break;
-                ++nb;
-                for (uint32_t i = s1; i < e1; ++i) {
-                    const uint64_t it = seg.items[i];
-                    if ((uint32_t)(it >> 32) != h) break;
-                    ++nd;
-                    const uint32_t d = (uint32_t)it;
-                    if (seg.num_dead != 0u && is_dead_seg(seg, d)) continue;
-                    const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
-                    if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
-                }
-            }
-            my_blocks += nb; my_docs += nd;
-            if (nd > 1u || nb > 1u) hist_observe(wg_h, nd, nb);
-            if (qstats) atomicAdd(&qstats[q], (unsigned long long)nb | ((unsigned long long)nd << 32));
+        const uint32_t cnt = min(stage_n, SMALL_STAGE);
+        if (cnt >= SMALL_STAGE / 2u || (last && cnt != 0u)) {
+            if (tid == 0) stage_base = atomicAdd(&counters[CTR_HITS], (unsigned long long)cnt);
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += WG) { const unsigned long long g = stage_base + i; if (g < hit_cap) hits[g] = stage[i]; }
+            __syncthreads();
+            if (tid == 0) stage_n = 0;
         }
+    };
+    for (uint64_t base = (uint64_t)blockIdx.x * WG * SMALL_KPT; base < P; base += (uint64_t)gridDim.x * WG * SMALL_KPT) {
+        const uint64_t p0 = base + tid;
+        uint64_t key[SMALL_KPT];
+        uint32_t h[SMALL_KPT];
+        bool live[SMALL_KPT];
+#pragma unroll
+        for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+            const uint64_t p = p0 + (uint64_t)k * WG;
+            live[k] = p < P;
+            key[k] = live[k] ? gload_u64(pairs + p) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+            h[k] = (uint32_t)(key[k] >> qb);
+            if (live[k] && is_duplicate_pair(pairs, p0 + (uint64_t)k * WG, key[k], qb)) live[k] = false;     // dedupSorted, src/Index.zig:489-499
+        }
+        for (uint32_t s = 0; s < nsegs; ++s) {
+            const SegDesc& seg = segs[s];
+            const uint64_t* __restrict__ items = seg.items;
+            const uint32_t* __restrict__ sbucket = seg.sbucket;
+            const uint32_t* __restrict__ sfirst = seg.sfirst;
+            const uint32_t* __restrict__ scode = seg.scode;
+            const uint32_t n = seg.num_items, sshift = seg.sshift, cshift = seg.cshift, own_flags = seg.own_flags, num_dead = seg.num_dead, block_size = seg.block_size;
+            uint32_t lo[SMALL_KPT], hi[SMALL_KPT], cw[SMALL_KPT];
+            bool act[SMALL_KPT];
+            // seven keys in eight fall into a cell without items: its code says what the reference's walk would have cost
+#pragma unroll
+            for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+                act[k] = live[k] && (own_flags == 0u || owned_hash(seg, h[k]));
+                cw[k] = act[k] ? gload_u32(scode + ((h[k] >> cshift) >> 4)) : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+                if (!act[k]) continue;
+                my_probes += 1;
+                const uint32_t code = (cw[k] >> (((h[k] >> cshift) & 15u) * 2u)) & 3u;
+                if (code == 0u) continue;
+                act[k] = false;
+                if (code == 1u) { my_blocks += 1; my_bytes += block_size; if (qstats) atomicAdd(&qstats[(uint32_t)key[k] & qmask], 1ull); }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+                // the first item whose hash is >= h: its bucket's bounds, then a binary search inside (a bucket holds ~2 items)
+                const uint32_t bk = h[k] >> sshift;
+                lo[k] = act[k] ? gload_u32(sbucket + bk) : 0u;
+                hi[k] = act[k] ? gload_u32(sbucket + bk + 1u) : 0u;
+            }
+            for (;;) {
+                bool more = false;
+                uint32_t v[SMALL_KPT];
+#pragma unroll
+                for (uint32_t k = 0; k < SMALL_KPT; ++k) v[k] = lo[k] < hi[k] ? (uint32_t)(gload_u64(items + ((lo[k] + hi[k]) >> 1)) >> 32) : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+                    if (lo[k] < hi[k]) { const uint32_t m = (lo[k] + hi[k]) >> 1; if (v[k] < h[k]) lo[k] = m + 1u; else hi[k] = m; }
+                    more = more || lo[k] < hi[k];
+                }
+                if (!more) break;
+            }
+            uint64_t it[SMALL_KPT];
+            uint32_t fw[SMALL_KPT];
+#pragma unroll
+            for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+                act[k] = act[k] && lo[k] < n;                                      // (above every block: nothing is visited, :153)
+                it[k] = act[k] ? gload_u64(items + lo[k]) : 0ull;
+                fw[k] = act[k] ? gload_u32(sfirst + (lo[k] >> 5)) : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < SMALL_KPT; ++k) {
+                if (!act[k]) continue;
+                const uint32_t i = lo[k], q = (uint32_t)key[k] & qmask;
+                if ((uint32_t)(it[k] >> 32) != h[k]) {
+                    // absent: the walk visits the block of item i, finds nothing and stops -- unless i opens its block (the gap before it, :164)
+                    if (((fw[k] >> (i & 31u)) & 1u) == 0u) { my_blocks += 1; my_bytes += block_size; if (qstats) atomicAdd(&qstats[q], 1ull); }
+                    continue;
+                }
+                uint32_t nb = 1, nd = 0;
+                for (uint32_t j = i; j < n; ++j) {
+                    const uint64_t itj = gload_u64(items + j);
+                    if ((uint32_t)(itj >> 32) != h[k]) break;
+                    if (j != i && ((gload_u32(sfirst + (j >> 5)) >> (j & 31u)) & 1u) != 0u) {     // the run goes on in the next block (:171-174)
+                        if (nb >= (uint32_t)MAX_BLOCKS_PER_HASH || nd > (uint32_t)MAX_DOCS_PER_HASH) break;
+                        ++nb;
+                    }
+                    ++nd;
+                    const uint32_t d = (uint32_t)itj;
+                    if (num_dead != 0u && is_dead_seg(seg, d)) continue;
+                    const uint32_t slot = atomicAdd(&stage_n, 1u);
+                    if (slot < SMALL_STAGE) stage[slot] = ((uint64_t)q << 32) | d;
+                    else {                                                         // (a hot hash: more records in a round than the stage holds)
+                        const unsigned long long g = atomicAdd(&counters[CTR_HITS], 1ull);
+                        if (g < hit_cap) hits[g] = ((uint64_t)q << 32) | d;
+                    }
+                }
+                my_blocks += nb; my_docs += nd; my_bytes += (unsigned long long)nb * block_size;
+                if (nd > 1u || nb > 1u) hist_observe(wg_h, nd, nb);
+                if (qstats) atomicAdd(&qstats[q], (unsigned long long)nb | ((unsigned long long)nd << 32));
+            }
+        }
+        flush(false);
     }
+    flush(true);
     if (my_probes) atomicAdd(&wg_probes, my_probes);
-    if (my_blocks) atomicAdd(&wg_blocks, my_blocks);
+    if (my_blocks) { atomicAdd(&wg_blocks, my_blocks); atomicAdd(&wg_bytes, my_bytes); }
     if (my_docs) atomicAdd(&wg_docs, my_docs);
     __syncthreads();
     if (tid == 0) {
         if (wg_probes) atomicAdd(&counters[CTR_PROBES], wg_probes);
-        if (wg_blocks) { atomicAdd(&counters[CTR_BLOCKS], wg_blocks); atomicAdd(&counters[CTR_BYTES], wg_blocks * seg.block_size); }
+        if (wg_blocks) { atomicAdd(&counters[CTR_BLOCKS], wg_blocks); atomicAdd(&counters[CTR_BYTES], wg_bytes); }
         if (wg_docs) atomicAdd(&counters[CTR_DOCS], wg_docs);
     }
-    if (SCAN_HIST && tid < HIST_SLOTS - 1u) {                              // (hist_publish, for a kernel without ProbeArgs)
-        const unsigned long long v = tid == HIST_COUNT ? wg_probes : tid == HIST_DOCS ? wg_docs : tid == HIST_BLOCKS ? wg_blocks : (unsigned long long)wg_h[tid];
-        if (v != 0ull) atomicAdd(&counters[CTR_HIST + tid], v);
-    }
+    // (the histograms' totals are the counters above: gather_hist)
+    if (SCAN_HIST && tid < HIST_COUNT && wg_h[tid] != 0u) atomicAdd(&counters[CTR_HIST + tid], (unsigned long long)wg_h[tid]);
 }
 
 }  // namespace fpx

@@ -395,6 +395,8 @@ __global__ void k_dest_bounds(const uint64_t* __restrict__ recs, uint64_t n, uin
 static void gather_hist(uint64_t* dst, const unsigned long long* h_counters, const unsigned long long* sets, uint64_t probes)
 {
     for (uint32_t i = 0; i < HIST_SLOTS; ++i) dst[i] = h_counters[CTR_HIST + i];
+    // (kernels that keep their statistics in the batch's counters leave the histograms' totals to them: hist_publish)
+    dst[HIST_COUNT] += h_counters[CTR_PROBES]; dst[HIST_DOCS] += h_counters[CTR_DOCS]; dst[HIST_BLOCKS] += h_counters[CTR_BLOCKS];
     if (sets) {
         const unsigned long long* hs = sets + (size_t)LEAN_STAT_SETS * 8;
         for (uint32_t k = 0; k < LEAN_STAT_SETS; ++k)
@@ -935,8 +937,8 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
                     hipLaunchKernelGGL((k_probe<true, true>), dim3(gxd, snap->n_lean), dim3(PWG), lds, st, d);
                 }
                 if (snap->n_small) {
-                    hipLaunchKernelGGL(k_probe_small, dim3((snap->max_small_blocks + SMALL_BPW - 1) / SMALL_BPW, snap->n_small), dim3(WG), 0, st,
-                                       snap->d_small, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters,
+                    hipLaunchKernelGGL(k_probe_small, dim3((uint32_t)std::min<uint64_t>((P + (uint64_t)WG * SMALL_KPT - 1) / ((uint64_t)WG * SMALL_KPT), SMALL_GRID)), dim3(WG), 0, st,
+                                       snap->d_small, snap->n_small, d_pairs, P, qb, ws->d_hits[fast ? 1 : 0], (uint64_t)ws->cap_hits, ws->d_counters,
                                        want_q ? ws->d_qstats : (unsigned long long*)nullptr);
                 }
                 if (snap->n_gen) {
@@ -1436,6 +1438,89 @@ static void add_stats(fpx_stats* dst, const fpx_stats& s)
 }
 
 // one pass, or -- when (query index, score) do not fit the 64-bit candidate key -- two half batches
+// would part 0 of the snapshot run this batch a query per workgroup?  (run_batch's own test for it, on the host arrays; a batch it would
+// not take gains nothing from two parts)
+static bool parts_take(const Snapshot* snap, const uint64_t* offsets, const fpx_opts* opts, uint32_t B)
+{
+    if (ctx_opt(snap->ctx, OPT_QUERY_WG) == 0) return false;
+    if (bits_for(B) > 24u || offsets[B] == offsets[0]) return false;
+    for (uint32_t q = 0; q < B; ++q) {
+        const uint64_t raw_len = offsets[q + 1] - offsets[q];
+        if (raw_len > QS_MAX_HASHES || (opts[q].has_min_score ? opts[q].min_score : (uint32_t)((raw_len + 19) / 20)) <= 2u) return false;
+    }
+    return true;
+}
+
+// one batch on one workspace, redone where a path hands it back; FPX_OK, FPX_SPLIT (the caller halves the batch) or an error
+static int run_with_redos(Snapshot* snap, Workspace* ws, const QueryBatch* resident, uint32_t q0, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                          const fpx_opts* opts, uint32_t timeout_ms, bool partial, fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* local,
+                          double t_call, uint64_t* q_blocks, uint64_t* q_docs)
+{
+    int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, local, nullptr, false, t_call, q_blocks, q_docs);
+    if (rc == FPX_REDO_QS) {                    // the one-workgroup-per-query path handed the batch back: the pipeline
+        *local = fpx_stats{};
+        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, local, nullptr, false, t_call, q_blocks, q_docs, true);
+    }
+    if (rc == FPX_REDO) {                       // the device-sized path gave up (after its synchronisation): the general path
+        *local = fpx_stats{};
+        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, local, nullptr, true, t_call, q_blocks, q_docs);
+    }
+    return rc;
+}
+
+// A snapshot in TWO PARTS (fpx_snapshot_create): part 0 -- its one packed group, the memory segments behind their table -- a query per
+// workgroup, part 1 -- the file segments next to the group -- by the pipeline, each into a table of its own ([B][cap] rows, no relative
+// cut-off yet: `partial`); k_merge puts the tables together as it does the ranks' of a segment-sharded index.  The batch is uploaded ONCE:
+// part 1 reads part 0's copy.  FPX_SPLIT: nothing has been delivered, the caller takes the whole snapshot's path (which halves the batch).
+static int search_parts(Snapshot* snap, const QueryBatch* resident, const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
+                        const fpx_opts* opts, uint32_t timeout_ms, fpx_result* out, uint32_t out_cap, uint32_t* out_n, fpx_stats* stats, double t_call,
+                        uint64_t* q_blocks, uint64_t* q_docs)
+{
+    Ctx* ctx = snap->ctx;
+    uint32_t cap = 1;
+    for (uint32_t q = 0; q < B; ++q) cap = std::max(cap, std::min(opts[q].max_results, out_cap ? out_cap : 1u));
+    Workspace* w0 = ws_acquire(ctx);
+    Workspace* w1 = w0 ? ws_acquire(ctx) : nullptr;
+    if (!w1) { if (w0) ws_release(ctx, w0); return FPX_E_NOMEM; }
+    fpx_stats l0{}, l1{};
+    std::vector<uint64_t> qb1, qd1;
+    if (q_blocks) qb1.assign(B, 0);
+    if (q_docs) qd1.assign(B, 0);
+    auto body = [&]() -> int {
+        int rc;
+        if ((rc = grow(&w0->d_parts, &w0->cap_parts, (size_t)2 * B * cap + 1))) return rc;
+        if ((rc = grow(&w0->d_parts_n, &w0->cap_parts_n, (size_t)2 * B + 1))) return rc;
+        rc = run_with_redos(snap->part[0], w0, resident, 0, hashes, offsets, B, opts, timeout_ms, true, w0->d_parts, cap, w0->d_parts_n, &l0, t_call, q_blocks, q_docs);
+        if (rc != FPX_OK) return rc;
+        // (part 1 reads the batch where part 0's run left it: the caller's resident batch, or this call's upload in w0)
+        QueryBatch view;
+        const QueryBatch* rb = resident;
+        if (!rb) {
+            view.ctx = ctx; view.B = B; view.d_hashes = w0->d_hashes - offsets[0]; view.d_offsets = w0->d_offsets; view.d_opts = w0->d_opts;
+            view.offsets.assign(offsets, offsets + B + 1); view.opts.assign(opts, opts + B);
+            rb = &view;
+        }
+        rc = run_with_redos(snap->part[1], w1, rb, 0, nullptr, rb->offsets.data(), B, rb->opts.data(), timeout_ms, true, w0->d_parts + (size_t)B * cap, cap, w0->d_parts_n + B, &l1,
+                            t_call, q_blocks ? qb1.data() : nullptr, q_docs ? qd1.data() : nullptr);
+        if (rc != FPX_OK) return rc;
+        if (timeout_ms && now_ms() - t_call > (double)timeout_ms) { set_error("search timeout"); return FPX_E_TIMEOUT; }
+        return merge_partials_impl(ctx, w0->d_parts, w0->d_parts_n, 2, B, cap, opts, offsets, out, out_cap, out_n);
+    };
+    const int rc = body();
+    if (rc != FPX_OK) {
+        (void)hipStreamSynchronize(w0->stream); (void)hipStreamSynchronize(w1->stream);
+        if (w0->copy_stream) (void)hipStreamSynchronize(w0->copy_stream);
+    } else {
+        ctx_hist_add(ctx, w0->batch_hist, w0->batch_hist[HIST_SLOTS]);
+        ctx_hist_add(ctx, w1->batch_hist, w1->batch_hist[HIST_SLOTS]);
+        for (uint32_t q = 0; q < B; ++q) { if (q_blocks) q_blocks[q] += qb1[q]; if (q_docs) q_docs[q] += qd1[q]; }
+        if (stats) { add_stats(stats, l0); add_stats(stats, l1); stats->path_flags |= 128u; }
+    }
+    ws_release(ctx, w1);
+    ws_release(ctx, w0);
+    return rc;
+}
+
 static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
                         const uint32_t* hashes, const uint64_t* offsets, uint32_t B,
                         const fpx_opts* opts, uint32_t timeout_ms, bool partial,
@@ -1445,15 +1530,7 @@ static int search_split(Snapshot* snap, const QueryBatch* resident, uint32_t q0,
     Workspace* ws = ws_acquire(snap->ctx);
     if (!ws) return FPX_E_NOMEM;
     fpx_stats local{};
-    int rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, false, t_call, q_blocks, q_docs);
-    if (rc == FPX_REDO_QS) {                    // the one-workgroup-per-query path handed the batch back: the pipeline
-        local = fpx_stats{};
-        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, false, t_call, q_blocks, q_docs, true);
-    }
-    if (rc == FPX_REDO) {                       // the device-sized path gave up (after its synchronisation): the general path
-        local = fpx_stats{};
-        rc = run_batch(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, nullptr, true, t_call, q_blocks, q_docs);
-    }
+    int rc = run_with_redos(snap, ws, resident, q0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, &local, t_call, q_blocks, q_docs);
     if (rc == FPX_OK && B == 1) {               // (one query: its statistics are the call's)
         if (q_blocks) q_blocks[0] = local.scanned_blocks;
         if (q_docs) q_docs[0] = local.scanned_docs;
@@ -1488,7 +1565,13 @@ int search_batch_impl(Snapshot* snap, const QueryBatch* resident, const uint32_t
         if (offsets[q + 1] - offsets[q] >= (1ull << 32)) { set_error("query longer than 2^32-1 hashes"); return FPX_E_INVAL; }
     }
     FPX_HIP(hipSetDevice(snap->ctx->device));
-    return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, now_ms(), q_blocks, q_docs);
+    const double t_call = now_ms();
+    if (!partial && snap->part[0] && B >= 2u && parts_take(snap, offsets, opts, B)) {
+        const int rc = search_parts(snap, resident, hashes, offsets, B, opts, timeout_ms, out, out_cap, out_n, stats, t_call, q_blocks, q_docs);
+        if (rc != FPX_SPLIT) return rc;
+        if (stats) std::memset(stats, 0, sizeof *stats);
+    }
+    return search_split(snap, resident, 0, hashes, offsets, B, opts, timeout_ms, partial, out, out_cap, out_n, stats, t_call, q_blocks, q_docs);
 }
 
 int probe_records_impl(Snapshot* snap, const QueryBatch* qb, uint32_t world, uint32_t timeout_ms,

@@ -80,7 +80,10 @@ typedef struct {
                                    were probed as a GROUP (k_probe_group), bit 3: ... whose records went straight into bins of a
                                    few queries, scored a bin per workgroup (k_score_bin), bit 4: the batch ran a step of a sharded protocol,
                                    bit 5: ... and hot hashes' lists reached the score kernel by reference ("hot_refs"),
-                                   bit 6: the batch was searched a query per workgroup (k_search_query: no keys, no bins) */
+                                   bit 6: the batch was searched a query per workgroup (k_search_query: no keys, no bins),
+                                   bit 7: the snapshot was searched in TWO PARTS -- its one packed group (+ the memory segments) a query
+                                   per workgroup, the file segments next to it by the pipeline, the two tables merged (a live index
+                                   between merges: fpx_snapshot_create) */
     uint64_t probe_kernel_fetched_bytes; /* block bytes the main probe kernel really fetched, in 128-byte lines: a probe
                                    whose hash the segment's presence bits know to be absent counts as a visited block (as in
                                    the reference) without the block being read, and a block that is read costs two lines up

@@ -255,3 +255,96 @@ def test_a_live_index_memory_segments_next_to_the_group(env, monkeypatch):
         assert not st2.path_flags & 64, "a superseded doc in the group: the pipeline filters per posting"
     finally:
         ctx.set_option("group_packed", -2)
+
+
+def test_a_live_index_file_segments_next_to_the_group_are_searched_apart(env, monkeypatch):
+    """Checkpoints leave small file segments next to the group (src/Index.zig:679-687), merges a larger one: the snapshot is searched in TWO
+    PARTS (csrc/fpx_api.hip: fpx_snapshot_create) -- the group + the memory segments a query per workgroup, the other file segments (in
+    blocks: decoded small ones; direct-addressed on its own: the merged one) by the pipeline, the two tables merged under the queries' relative
+    cut-off (k_merge) -- a doc lives in one segment.  Results, every query's scanned blocks / docs and the context's scan histograms == the
+    oracle's; from host memory and resident; a doc of the group written again in a later file segment sends the snapshot back to one part."""
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    ctx.set_option("group_packed", 1)
+
+    def world(reinsert):
+        rng = np.random.default_rng(777)
+        p = Pair(ctx)
+        per, allitems = 3000, []
+        for s in range(4):
+            first = s * per + 1
+            items = _items(rng, s, per, first, 40)
+            p.add_file(items, first, first + per - 1, s + 1, np.arange(first, first + per, dtype=np.uint32))
+            allitems.append(items)
+        p.finish()                                                # (the four meet in a snapshot: a packed group)
+        assert all(g.grouped for g in p.gpu_segs)
+        nxt, commit = 4 * per + 1, 5
+        ctx.set_option("direct_min_items", 1 << 20)               # checkpoints: 3 x 48 000 items, in blocks
+        for s in range(3):
+            docs = np.arange(nxt, nxt + 1000, dtype=np.uint64)
+            ids = list(range(nxt, nxt + 1000))
+            h = rng.integers(0, 1 << 32, (1000, 48), dtype=np.uint64)
+            items = [((h << np.uint64(32)) | docs[:, None]).ravel(), (np.uint64(SHARED) << np.uint64(32)) | docs[:7], (np.uint64(HOT) << np.uint64(32)) | docs[:600]]
+            if reinsert and s == 1:
+                ids.append(17)                                    # doc 17 of the group's first column, written again
+                items.append((rng.integers(0, 1 << 32, 48, dtype=np.uint64) << np.uint64(32)) | np.uint64(17))
+            items = np.unique(np.concatenate(items))
+            p.add_file(items, min(ids), max(ids), commit, np.array(sorted(ids), dtype=np.uint32))
+            allitems.append(items)
+            nxt += 1000; commit += 1
+        ctx.set_option("direct_min_items", 0)                     # a merged one: direct-addressed, alone (one candidate is no group)
+        docs = np.arange(nxt, nxt + 2500, dtype=np.uint64)
+        h = rng.integers(0, 1 << 32, (2500, 48), dtype=np.uint64)
+        items = np.unique(np.concatenate([((h << np.uint64(32)) | docs[:, None]).ravel(), (np.uint64(SHARED) << np.uint64(32)) | docs[:70]]))
+        p.add_file(items, nxt, nxt + 2499, commit, np.arange(nxt, nxt + 2500, dtype=np.uint32))
+        allitems.append(items)
+        nxt += 2500; commit += 1
+        ctx.set_option("direct_min_items", -1)
+        for m in range(3):                                        # fresh writes
+            docs = np.arange(nxt, nxt + 60, dtype=np.uint64)
+            h = rng.integers(0, 1 << 32, (60, 48), dtype=np.uint64)
+            items = np.unique(np.concatenate([((h << np.uint64(32)) | docs[:, None]).ravel(), (np.uint64(SHARED) << np.uint64(32)) | docs[:3]]))
+            p.add_memory(items, nxt, nxt + 59, commit, np.arange(nxt, nxt + 60, dtype=np.uint32))
+            allitems.append(items)
+            nxt += 60; commit += 1
+        p.finish()
+        return p, allitems, rng
+    try:
+        p, allitems, rng = world(False)
+        info = p.reader.snapshot.info() if hasattr(p.reader, "snapshot") else None
+        layouts = [g.layout_reason for g in p.gpu_segs]
+        assert sum(1 for g in p.gpu_segs[:4] if g.grouped) == 4 and not any(g.grouped for g in p.gpu_segs[4:]), layouts
+        queries = [_query(rng, allitems, i, 1000) for i in range(66)]          # (a query in eleven aims at each addition)
+        queries[3] = np.concatenate([queries[3][:990], np.array([HOT], dtype=np.uint32)])
+        h0, _ = ctx.scan_histograms()
+        for opts in (fpx.http_options(), fpx.SearchOptions(max_results=100, min_score=3, min_score_pct=0), fpx.SearchOptions(max_results=7, min_score=4, min_score_pct=60)):
+            got, st = p.check(queries, opts)
+            assert st.path_flags & 128 and st.path_flags & 64, f"not searched in two parts ({st.path_flags}; layouts {layouts}, {info})"
+        h1, unb = ctx.scan_histograms()
+        walks = sum(len(np.unique(q)) for q in queries) * 8                    # (a walk per unique hash and file segment; p.check searches a batch three times)
+        assert h1.count - h0.count == 3 * 3 * walks and unb == 0, (h1.count - h0.count, 9 * walks, unb)
+        found_in = [sum(1 for g in got if g and lo <= g[0][0] <= hi) for lo, hi in ((1, 12000), (12001, 15000), (15001, 17500), (17501, 17680))]
+        assert all(n >= 3 for n in found_in), found_in                        # the group, the checkpoints, the merged one, the memory segments
+        # resident in HBM: the same two parts, the same answers
+        qb = fpx.QueryBatch(ctx, queries=queries, options=fpx.http_options())
+        o, n, st_r = fpx.search_resident(p.reader, qb)
+        assert st_r.path_flags & 128
+        want, _ = p.reader.search_batch(queries, fpx.http_options())
+        assert fpx.results_to_lists(o, n) == want
+        qb.release()
+        # one part again: the pipeline over the whole snapshot -- the same answers
+        ctx.set_option("query_wg", 0)
+        try:
+            got_p, st_p = p.reader.search_batch(queries, fpx.http_options())
+            assert not st_p.path_flags & (128 | 64) and got_p == want
+        finally:
+            ctx.set_option("query_wg", -1)
+        # a batch k_search_query does not take (a floor of 2) is not split either
+        got_l, st_l = p.check(queries[:8], fpx.SearchOptions(max_results=40, min_score=2, min_score_pct=10))
+        assert not st_l.path_flags & 128
+        p2, allitems2, rng2 = world(True)
+        queries2 = [_query(rng2, allitems2, i, 1000) for i in range(33)]
+        got2, st2 = p2.check(queries2, fpx.http_options())
+        assert not st2.path_flags & 128, "a superseded doc in the group: per-posting filtering, one part"
+    finally:
+        ctx.set_option("group_packed", -2); ctx.set_option("direct_min_items", -1)

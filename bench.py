@@ -23,6 +23,7 @@ Prints ONE JSON line (rank 0).  At N = 1 the line also carries, measured in the 
                 kernels' source hash attached); the reference-equivalent figure of SURVEY 8(d) is kept separately
   by_batch      the same index at B = 1, 64, 256, 1024 (BASELINE.md's batch for this row) and the headline batch, one batch in
                 flight each, next to the headline (three in flight)
+  mixed / live  a LIVE index's snapshots: the group + 16 memory segments; ... + file segments next to the group (checkpoints, a merged one): two parts
   end_to_end    fpx_search_batch from host memory, pageable and page-locked (H2D of the queries, D2H of the results inside)
   config1       BASELINE.json configs[1]: 10 M fingerprints in ONE segment, batch 1024
   roofline_block_form / block_form   the same index built again in block form (FPX_DIRECT=0): k_probe_lean8 -- the kernel the
@@ -976,7 +977,7 @@ def main():
                 ids = np.arange(docs + 1 + m * per_mem, docs + 1 + (m + 1) * per_mem, dtype=np.uint64)
                 hh = fpx.synth.synth_hashes(args.seed + 77, ids, H, 0).astype(np.uint64)
                 items = np.sort(((hh << np.uint64(32)) | ids[:, None]).ravel())
-                mems.append(fpx.MemorySegment(ctx, items, int(ids[0]), int(ids[-1]), S + 1 + m, ids.astype(np.uint32)))
+                mems.append(fpx.MemorySegment(ctx, items, int(ids[0]), int(ids[-1]), S + 9 + m, ids.astype(np.uint32)))
             snap_m = fpx.Segments(ctx, list(segs) + mems)
             reader_m = fpx.IndexReader(snap_m)
             # queries: the batches as they are, every 16th query aimed at a doc of a memory segment instead (it must be found there)
@@ -999,9 +1000,54 @@ def main():
             rowm["note"] = "one batch in flight; compare with the by_batch row of the same batch size and in-flight count"
             result["mixed"] = rowm
             qm_.release(); snap_m.release()
+            del reader_m, snap_m
+            # ... and what a live index holds besides: FILE segments next to the group -- three checkpoints of 0.5 M items (src/Index.zig:679-687;
+            # in blocks, decoded) and a merged one of 2.5 M (direct-addressed on its own).  The snapshot is searched in TWO PARTS
+            # (fpx_snapshot_create): the group + the memory segments a query per workgroup, the file segments by the pipeline, tables merged.
+            try:
+                nd0 = docs + 1 + nm * per_mem
+                files, first = [], nd0
+                for j, per_f in enumerate((2000, 2000, 2000, 10000)):
+                    files.append(fpx.FileSegment.synth(ctx, args.seed + 5, first, per_f, H, 0, 512, S + 1 + j))
+                    first += per_f
+                snap_l = fpx.Segments(ctx, list(segs) + files + mems)
+                reader_l = fpx.IndexReader(snap_l)
+                fl, ol, tl = batches[0][0].copy(), batches[0][1], batches[0][2].copy()
+                fdocs = np.arange(nd0, first, 97)
+                for q in range(0, B, 16):                           # every 16th query aims at a doc of a file segment next to the group, or of a memory segment
+                    if (q // 16) % 2:
+                        d, sd = docs + 1 + (q // 16) % (nm * per_mem), args.seed + 77
+                    else:
+                        d, sd = int(fdocs[(q // 16) % len(fdocs)]), args.seed + 5
+                    fl[int(ol[q]):int(ol[q]) + H] = fpx.synth.synth_hashes(sd, [d], H, 0)[0]
+                    tl[q] = d
+                ql_ = fpx.QueryBatch(ctx, options=opts, flat=(fl, ol))
+                dtl, aggl, _, _ = timed_resident(fpx, reader_l, [ql_] + qbs[1:], 40, 16)
+                rowl = {"batch": B, "steps": 40, "ms_per_step": dtl / 40 * 1e3, "queries_per_s": B * 40 / dtl, "gpu_ms_per_step": aggl.v["total_gpu_ms"] / 40}
+                o_l, n_l, st_l = fpx.search_resident(reader_l, ql_)
+                rowl["targets_found"] = int(sum(1 for q in range(B) if n_l[q] > 0 and o_l[q, 0, 0] == tl[q]))
+                rowl["path_flags"] = aggl.path_flags
+                rowl["two_parts"] = bool(aggl.path_flags & 128)
+                rowl["snapshot"] = snap_l.info()
+                rowl["file_segments_next_to_the_group"] = [{"items": int(f_.num_docs) * H, "layout": f_.layout_reason} for f_ in files]
+                # the same snapshot through the pipeline alone (what rounds 1-5 did with it)
+                ctx.set_option("query_wg", 0)
+                try:
+                    dtp_, aggp_, _, _ = timed_resident(fpx, reader_l, [ql_] + qbs[1:], 20, 16)
+                    rowl["one_part_pipeline_ms_per_step"] = dtp_ / 20 * 1e3
+                finally:
+                    ctx.set_option("query_wg", -1)
+                rowl["note"] = "one batch in flight, resident; compare with `mixed` (no file segments next to the group) and the by_batch row of this batch size"
+                result["live"] = rowl
+                ql_.release(); snap_l.release()
+                for f_ in files:
+                    f_.release()
+                del reader_l, snap_l, files
+            except Exception as e:
+                result["live"] = {"error": repr(e)}
             for m_ in mems:
                 m_.release()
-            del reader_m, snap_m, mems
+            del mems
         except Exception as e:
             result["mixed"] = {"error": repr(e)}
 

@@ -76,7 +76,14 @@ def main():
     for si, (label, extra, extra_docs) in enumerate(shapes):
         if only is not None and str(si) not in only.split(","):
             continue
+        t_s = time.perf_counter()
         snap = fpx.Segments(ctx, list(segs) + extra)
+        snap_ms = (time.perf_counter() - t_s) * 1e3
+        snap2 = fpx.Segments(ctx, list(segs) + extra)                # (a second snapshot of the same segments: what every later update pays)
+        t_s = time.perf_counter()
+        snap3 = fpx.Segments(ctx, list(segs) + extra)
+        snap_again_ms = (time.perf_counter() - t_s) * 1e3
+        snap2.release(); snap3.release()
         reader = fpx.IndexReader(snap)
         qs = [aimed(b, extra_docs, seed_of) for b in batches]
         qbs = [fpx.QueryBatch(ctx, options=opts, flat=(f, o)) for f, o, _ in qs]
@@ -84,7 +91,7 @@ def main():
         last = qs[(16 + steps - 1) % len(qs)]
         found = int(sum(1 for q in range(B) if out_n[q] > 0 and out[q, 0, 0] == last[2][q]))
         print(json.dumps({"snapshot": label, "ms_per_step": round(dt / steps * 1e3, 4), "queries_per_s": round(B * steps / dt),
-                          "gpu_ms_per_step": round(agg.v["total_gpu_ms"] / steps, 4), "path_flags": agg.path_flags, "targets_found": found, "of": B,
+                          "gpu_ms_per_step": round(agg.v["total_gpu_ms"] / steps, 4), "snapshot_create_ms": round(snap_ms, 2), "snapshot_create_again_ms": round(snap_again_ms, 2), "path_flags": agg.path_flags, "targets_found": found, "of": B,
                           "info": {k: v for k, v in snap.info().items() if k in ("lean", "generic", "small", "direct_solo", "groups", "packed_groups", "memory")}}), flush=True)
         for q_ in qbs:
             q_.release()

@@ -50,6 +50,15 @@ for sub, out in (("pmc", "ea_read_requests.json"), (os.path.join("pmc", "block_f
     p = os.path.join(src, sub, "ea_read_requests.json")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{TAG}_{out}"))
+for name, out in (("live_index.txt", "live_index.txt"), ("live_kernel_stats.csv", "live_kernel_stats.csv")):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f"{TAG}_{out}"))
+put_json("bench_two_replicas_one_gpu.json", f"{TAG}_bench_two_replicas_one_gpu.json")
+put_json("bench_pipeline_under_rocprof.json", f"{TAG}_bench_pipeline_under_rocprof.json")
+p = os.path.join(src, f"{TAG}pipe_kernel_stats.csv")
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(dst, f"{TAG}_pipeline_kernel_stats.csv"))
 import bench as bench_mod  # noqa: E402
 tr = {"command": "bench.py's in-run children: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum "
                  "-- python bench.py --pmc-child ... (the second with FPX_DIRECT=0)",

@@ -7,6 +7,7 @@
 #   4. rocprofv3 --kernel-trace --stats of one B = 1024 run -> r06_kernel_stats_b1024.csv
 
 
+#   6. tools/live_index.py (a live index's snapshot shapes), its kernels under rocprofv3, bench.py --gpus 2 as two replicas on this GPU
 #   5. FPX_BENCH_EMULATE_WORLD=8 (one GPU plays rank 0 of 8, the routed-key protocol, weak) and the pipeline on the headline index (query_wg 0)
 # Only summaries are kept (gpurun copies back at most 64 MiB).
 R=$GRAFT_REPO_ROOT
@@ -31,5 +32,11 @@ FPX_BENCH_EMULATE_WORLD=8 python $R/bench.py --no-cpu-baseline --no-extras > $O/
 FPX_QUERY_WG=0 FPX_BENCH_LONG=0 trace r06pipe $O/bench_pipeline_under_rocprof.json python $R/bench.py --no-cpu-baseline --no-extras --inflight 1
 tail -c 3000 $O/emu.err > $O/emu.tail; rm -f $O/emu.err
 
+# a live index's snapshot shapes (tools/live_index.py) and the kernels of the fullest one; two replicas sharing this one GPU (the N > 1 default, flow only)
+cd $R && python tools/live_index.py > $O/live_index.txt 2>> $O/live.err
+SHAPES=4 STEPS=40 bash tools/live_trace.sh > /dev/null 2>&1 && cp $R/gpurun_out/live_trace/live_kernel_stats_shape4.csv $O/live_kernel_stats.csv
+FPX_BENCH_DEVICE=0 python bench.py --gpus 2 --steps 10 --warmup 2 --docs 20000000 --segments 8 > $O/bench_two_replicas_one_gpu.json 2>> $O/live.err
+tail -c 2000 $O/live.err > $O/live.tail; rm -f $O/live.err
+cd /tmp
 python3 $R/tools/brief.py $O/bench.json $O/bench_under_rocprof.json $O/bench_pipeline_under_rocprof.json $O/emulated_rank_of_8_weak.json
 du -sh $O; ls $O

@@ -206,7 +206,10 @@ int fpx_segment_download(const fpx_segment *seg, uint8_t *blocks, size_t blocks_
 /* Replaces: Index.createSnapshot + swapSnapshot (src/Index.zig:450-485).  `segs` is the
  * Segments snapshot order: file[] then memory[], oldest -> newest, commit_id strictly
  * ascending (src/Index.zig:36-41).  Builds the supersession tables.  Retains the segments.  A segment that is resident
- * on another context's device takes part with its docs map only (like fpx_segment_create_remote). */
+ * on another context's device takes part with its docs map only (like fpx_segment_create_remote).
+ * A snapshot of [one packed group without superseded docs] + [other file segments] -- a live index between merges -- is also laid out
+ * in TWO PARTS that batches are searched through apart and merged (a doc lives in one segment; fpx_stats.path_flags bit 7): nothing
+ * for the caller to do, a few hundred microseconds of snapshot creation. */
 int  fpx_snapshot_create(fpx_ctx *ctx, fpx_segment *const *segs, uint32_t num_segs, fpx_snapshot **out);
 /* acquireReader / IndexReader.deinit (src/Index.zig:430-434, :157-163) */
 /* What fpx_snapshot_create made of the segments on this context: info[0..11] = file segments searched in their blocks by the

@@ -348,3 +348,66 @@ def test_a_live_index_file_segments_next_to_the_group_are_searched_apart(env, mo
         assert not st2.path_flags & 128, "a superseded doc in the group: per-posting filtering, one part"
     finally:
         ctx.set_option("group_packed", -2); ctx.set_option("direct_min_items", -1)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_live_worlds_in_two_parts(env, monkeypatch, seed):
+    """seeded worlds of a packed group of 2 - 6 columns, 1 - 4 file segments of random sizes next to it (in blocks, or direct-addressed alone),
+    0 - 3 memory segments, doc ids interleaved between the group and the others in commit order, deletions (tombstones in a later segment's
+    docs map: the snapshot goes back to one part) in one world of four; queries of 60 - 1500 hashes, a third of them aimed at a doc.
+    Whatever path a batch takes: results, per-query scan statistics == the oracle (Pair.check)."""
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    ctx.set_option("group_packed", 1)
+    rng = np.random.default_rng(9000 + seed)
+    try:
+        p = Pair(ctx)
+        allitems, nxt, commit = [], 1, 1
+        ncol = int(rng.integers(2, 7))
+        for s in range(ncol):
+            per = int(rng.integers(800, 3000))
+            items = _items(rng, s, per, nxt, 40)
+            p.add_file(items, nxt, nxt + per - 1, commit, np.arange(nxt, nxt + per, dtype=np.uint32))
+            allitems.append(items)
+            nxt += per + int(rng.integers(0, 50)); commit += 1
+        p.finish()
+        assert all(g.grouped for g in p.gpu_segs)
+        group_docs = nxt
+        for s in range(int(rng.integers(1, 5))):
+            alone = bool(rng.integers(0, 3) == 0)
+            ctx.set_option("direct_min_items", 0 if alone else 1 << 20)
+            per = int(rng.integers(50, 2500))
+            docs = np.arange(nxt, nxt + per, dtype=np.uint64)
+            ids, alive = list(range(nxt, nxt + per)), [1] * per
+            h = rng.integers(0, 1 << 32, (per, int(rng.integers(8, 64))), dtype=np.uint64)
+            parts = [((h << np.uint64(32)) | docs[:, None]).ravel(), (np.uint64(SHARED) << np.uint64(32)) | docs[: min(per, 9)]]
+            if rng.integers(0, 2):
+                parts.append((np.uint64(HOT) << np.uint64(32)) | docs[: min(per, int(rng.integers(100, 1500)))])
+            if seed == 3 and s == 0:
+                ids.insert(0, 5); alive.insert(0, 0)               # doc 5 of the group deleted here: a tombstone
+            items = np.unique(np.concatenate(parts))
+            p.add_file(items, min(ids), max(ids), commit, np.array(ids, dtype=np.uint32), np.array(alive, dtype=np.uint8))
+            allitems.append(items)
+            nxt += per + int(rng.integers(0, 30)); commit += 1
+        ctx.set_option("direct_min_items", -1)
+        for m in range(int(rng.integers(0, 4))):
+            per = int(rng.integers(5, 80))
+            docs = np.arange(nxt, nxt + per, dtype=np.uint64)
+            h = rng.integers(0, 1 << 32, (per, 32), dtype=np.uint64)
+            items = np.unique(((h << np.uint64(32)) | docs[:, None]).ravel())
+            p.add_memory(items, nxt, nxt + per - 1, commit, np.arange(nxt, nxt + per, dtype=np.uint32))
+            allitems.append(items)
+            nxt += per; commit += 1
+        p.finish()
+        lens = rng.integers(60, 1500, 40)
+        queries = [_query(rng, allitems, i, int(lens[i]), special=bool(i % 3 == 0)) for i in range(40)]
+        queries[1] = np.concatenate([queries[1], np.array([HOT, SHARED], dtype=np.uint32)])
+        for opts in (fpx.http_options(), fpx.SearchOptions(max_results=int(rng.integers(1, 60)), min_score=int(rng.integers(3, 9)), min_score_pct=int(rng.integers(0, 100)))):
+            got, st = p.check(queries, opts)
+            if seed == 3:
+                assert not st.path_flags & 128, "a deleted doc of the group: one part"
+            else:
+                assert st.path_flags & 128, f"not in two parts: {st.path_flags}, {[g.layout_reason for g in p.gpu_segs]}"
+        assert any(g and g[0][0] >= group_docs for g in got) and any(g and g[0][0] < group_docs for g in got)
+    finally:
+        ctx.set_option("group_packed", -2); ctx.set_option("direct_min_items", -1)

@@ -1026,21 +1026,34 @@ int fpx_snapshot_create(fpx_ctx* ctx_, fpx_segment* const* segs, uint32_t num_se
     // answers of any partition of its segments (what the segment-sharded mode does across devices): part 0 = the group (+ the memory
     // segments, behind their table), searched a query per workgroup; part 1 = the other file segments, by the pipeline, whose records are
     // few; k_merge (fpx_score.hpp) puts the two tables together under the queries' relative cut-off.  search_batch_impl decides per batch.
-    if (sn->n_group == 1 && sn->groups[0]->packed && (sn->n_file != 0 || sn->n_solo != 0) && ctx_opt(c, OPT_QUERY_WG) != 0) {
-        const GroupDesc& gd = sn->h_group[0];
-        bool ok = gd.any_dead == 0u && gd.active == (gd.nseg >= 32u ? 0xFFFFFFFFu : ((1u << gd.nseg) - 1u));
+    // (several groups -- a merge's results met in a snapshot and formed one of their own: part 0 is the LARGEST packed group that is whole
+    // here, every column searched and no doc of it superseded; the other groups go with part 1)
+    int g0 = -1;
+    uint64_t g0_items = 0;
+    if (ctx_opt(c, OPT_QUERY_WG) != 0 && (sn->n_file != 0 || sn->n_solo != 0 || sn->n_group > 1)) {
+        for (uint32_t gi = 0; gi < sn->n_group; ++gi) {
+            const GroupDesc& gd = sn->h_group[gi];
+            const Group* g = sn->groups[gi].get();
+            if (!g->packed || gd.any_dead != 0u || gd.active != (gd.nseg >= 32u ? 0xFFFFFFFFu : ((1u << gd.nseg) - 1u))) continue;
+            uint64_t items = 0;
+            for (const Segment* s : sn->segs) if (s->kind == 0 && s->ctx == c && s->home == sn->groups[gi]) items += s->num_items;
+            if (g0 < 0 || items > g0_items) { g0 = (int)gi; g0_items = items; }
+        }
+    }
+    if (g0 >= 0) {
+        bool ok = true;
         std::vector<uint8_t> m0(num_segs, 0), m1(num_segs, 0);
         for (uint32_t i = 0; i < num_segs && ok; ++i) {
             const Segment* s = reinterpret_cast<const Segment*>(segs[i]);
             if (s->kind == 2 || s->ctx != c) continue;
             if (s->kind == 0 && s->own_flags != 0u) ok = false;                    // (a rank's hash window: the sharded protocols' business)
-            else if (s->kind == 1 || s->home == sn->groups[0]) m0[i] = 1; else m1[i] = 1;
+            else if (s->kind == 1 || s->home == sn->groups[g0]) m0[i] = 1; else m1[i] = 1;
         }
         if (ok) {
             Snapshot *p0 = nullptr, *p1 = nullptr;
             if (snapshot_build(c, segs, num_segs, &m0, false, &p0) == FPX_OK && snapshot_build(c, segs, num_segs, &m1, false, &p1) == FPX_OK &&
-                p0->n_group == 1 && p0->n_file == 0 && p0->n_solo == 0 && p0->groups[0] == sn->groups[0] && p1->n_group == 0 && p1->n_mem == 0 &&
-                (p0->n_mem == 0 || p0->mem_items == 0 || p0->d_memtab != nullptr)) {
+                p0->n_group == 1 && p0->n_file == 0 && p0->n_solo == 0 && p0->groups[0] == sn->groups[g0] && p1->n_mem == 0 &&
+                (p1->n_file != 0 || p1->n_direct != 0) && (p0->n_mem == 0 || p0->mem_items == 0 || p0->d_memtab != nullptr)) {
                 sn->part[0] = p0; sn->part[1] = p1;
             } else {                                                               // (no room, or the forms moved under us: the snapshot works without)
                 if (p0) snapshot_free(p0);

@@ -411,3 +411,50 @@ def test_random_live_worlds_in_two_parts(env, monkeypatch, seed):
         assert any(g and g[0][0] >= group_docs for g in got) and any(g and g[0][0] < group_docs for g in got)
     finally:
         ctx.set_option("group_packed", -2); ctx.set_option("direct_min_items", -1)
+
+
+def test_a_second_group_next_to_the_large_one(env, monkeypatch):
+    """Merges' results that meet in a snapshot form a group of their own (fpx_snapshot_create groups two or more candidates): the snapshot holds TWO
+    groups.  Part 0 is the larger packed group -- a query per workgroup --, the smaller group, a checkpoint in blocks and the memory segments'
+    neighbours go with part 1 (k_probe_pgroup + bins, k_probe_small); tables merged.  == the oracle, per-query statistics included."""
+    fpx, oracle, Pair, ctx = env
+    monkeypatch.setenv("FPX_DIRECT_MIN_ITEMS", "0")
+    ctx.set_option("group_packed", 1)
+    try:
+        rng = np.random.default_rng(5151)
+        p = Pair(ctx)
+        per, allitems, nxt, commit = 3000, [], 1, 1
+        for s in range(5):
+            items = _items(rng, s, per, nxt, 40)
+            p.add_file(items, nxt, nxt + per - 1, commit, np.arange(nxt, nxt + per, dtype=np.uint32))
+            allitems.append(items); nxt += per; commit += 1
+        p.finish()
+        big = p.gpu_segs[0].group_info()
+        for s in range(2):                                        # two merged segments, candidates both: a second group
+            docs = np.arange(nxt, nxt + 900, dtype=np.uint64)
+            h = rng.integers(0, 1 << 32, (900, 40), dtype=np.uint64)
+            items = np.unique(np.concatenate([((h << np.uint64(32)) | docs[:, None]).ravel(), (np.uint64(SHARED) << np.uint64(32)) | docs[:11]]))
+            p.add_file(items, nxt, nxt + 899, commit, np.arange(nxt, nxt + 900, dtype=np.uint32))
+            allitems.append(items); nxt += 900; commit += 1
+        ctx.set_option("direct_min_items", 1 << 20)               # a checkpoint, in blocks
+        docs = np.arange(nxt, nxt + 500, dtype=np.uint64)
+        h = rng.integers(0, 1 << 32, (500, 40), dtype=np.uint64)
+        items = np.unique(((h << np.uint64(32)) | docs[:, None]).ravel())
+        p.add_file(items, nxt, nxt + 499, commit, np.arange(nxt, nxt + 500, dtype=np.uint32))
+        allitems.append(items); nxt += 500; commit += 1
+        ctx.set_option("direct_min_items", -1)
+        docs = np.arange(nxt, nxt + 40, dtype=np.uint64)
+        h = rng.integers(0, 1 << 32, (40, 40), dtype=np.uint64)
+        items = np.unique(((h << np.uint64(32)) | docs[:, None]).ravel())
+        p.add_memory(items, nxt, nxt + 39, commit, np.arange(nxt, nxt + 40, dtype=np.uint32))
+        allitems.append(items)
+        p.finish()
+        infos = [g.group_info() for g in p.gpu_segs[:7]]
+        assert all(i is not None for i in infos) and infos[5]["columns"] == 2 and infos[0]["columns"] == 5 == big["columns"], infos
+        queries = [_query(rng, allitems, i, 1000) for i in range(45)]
+        for opts in (fpx.http_options(), fpx.SearchOptions(max_results=80, min_score=4, min_score_pct=30)):
+            got, st = p.check(queries, opts)
+            assert st.path_flags & 128 and st.path_flags & 64, st.path_flags
+        assert sum(1 for g in got if g and 15000 < g[0][0] <= 16800) >= 3, "no query found its doc in the second group"
+    finally:
+        ctx.set_option("group_packed", -2); ctx.set_option("direct_min_items", -1)

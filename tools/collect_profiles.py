@@ -35,7 +35,7 @@ put_json("emulated_under_rocprof.json", f"{TAG}_emulated_rank_of_8_under_rocprof
 if os.path.exists(os.path.join(src, "merge_then_search.json")) and os.path.getsize(os.path.join(src, "merge_then_search.json")):
     try:
         m = last_json(os.path.join(src, "merge_then_search.json"))
-        m["command"] = "python tools/merge_then_search.py (one MI355X, one batch in flight)"
+        m["command"] = "MTS_SEGMENTS=8 MTS_DOCS=25000000 FPX_GROUP_PACKED=1 python tools/merge_then_search.py (one MI355X, one batch in flight)" if TAG >= "r06" else "python tools/merge_then_search.py (one MI355X, one batch in flight)"
         json.dump(m, open(os.path.join(dst, f"{TAG}_merge_then_search.json"), "w"), indent=1)
     except (ValueError, IndexError):
         print("unreadable: merge_then_search.json")

@@ -6,7 +6,10 @@ groups -- the 100 M index's packed group is 147 GB, fpx_segments_regroup has no 
   drifted   segments 0 and 1 merged on the GPU (fpx_segment_merge): the merge's output direct-addressed on its own next to the
             old group, whose two merged-away columns are dead
   regrouped after fpx_segments_regroup: one group of fifteen
-The three must return the same results (no doc is superseded).  Prints one JSON line (profiles/r04_merge_then_search.json)."""
+The three must return the same results (no doc is superseded).  Prints one JSON line (profiles/r04_merge_then_search.json).
+Round 6 (profiles/r06_merge_then_search.json): MTS_SEGMENTS=8 MTS_DOCS=25000000 FPX_GROUP_PACKED=1 -- PACKED groups of eight columns
+(69 GB of lines each: two fit): fresh and regrouped run a query per workgroup, drifted (a group with two columns gone + the merge's output
+on its own) the pipeline."""
 import json
 import os
 import sys
@@ -18,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package  # noqa: E402
 
 fpx = load_package()
-DOCS, S, H, B, SEED = int(os.environ.get("MTS_DOCS", 24_000_000)), 16, 256, 8192, 20260929
+DOCS, S, H, B, SEED = int(os.environ.get("MTS_DOCS", 24_000_000)), int(os.environ.get("MTS_SEGMENTS", 16)), 256, 8192, 20260929
 ctx = fpx.Context(0)
 per = DOCS // S
 t0 = time.perf_counter()

@@ -36,6 +36,8 @@ tail -c 3000 $O/emu.err > $O/emu.tail; rm -f $O/emu.err
 cd $R && python tools/live_index.py > $O/live_index.txt 2>> $O/live.err
 SHAPES=4 STEPS=40 bash tools/live_trace.sh > /dev/null 2>&1 && cp $R/gpurun_out/live_trace/live_kernel_stats_shape4.csv $O/live_kernel_stats.csv
 FPX_BENCH_DEVICE=0 python bench.py --gpus 2 --steps 10 --warmup 2 --docs 20000000 --segments 8 > $O/bench_two_replicas_one_gpu.json 2>> $O/live.err
+# a merge and what fpx_segments_regroup gives back, at a size where two packed groups fit (8 columns: 69 GB of lines each)
+MTS_SEGMENTS=8 MTS_DOCS=25000000 FPX_GROUP_PACKED=1 python tools/merge_then_search.py > $O/merge_then_search.json 2>> $O/live.err
 tail -c 2000 $O/live.err > $O/live.tail; rm -f $O/live.err
 cd /tmp
 python3 $R/tools/brief.py $O/bench.json $O/bench_under_rocprof.json $O/bench_pipeline_under_rocprof.json $O/emulated_rank_of_8_weak.json

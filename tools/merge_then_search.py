@@ -43,13 +43,15 @@ def measure(files, steps=40):
         out, out_n, st = fpx.search_resident(reader, qb)
         outs.append((np.array(out[:, :4, :], copy=True), np.array(out_n, copy=True)))
     t = time.perf_counter()
-    probe = 0.0
+    probe, gpu, flags = 0.0, 0.0, 0
     for i in range(steps):
-        out, out_n, st = fpx.search_resident(reader, batches[i % len(batches)][0])
+        out, out_n, st = fpx.search_resident(reader, batches[i % len(batches)][0], 0, out, out_n)     # (the result arrays are reused)
         probe += st.probe_kernel_ms + st.probe_aux_ms
+        gpu += st.total_gpu_ms
+        flags |= st.path_flags
     dt = (time.perf_counter() - t) / steps
     found = int((outs[0][0][:, 0, 0] == batches[0][1]).sum())
-    return {"ms_per_step": dt * 1e3, "queries_per_s": B / dt, "probe_kernels_ms": probe / steps, "targets_found": found,
+    return {"ms_per_step": dt * 1e3, "queries_per_s": B / dt, "probe_kernels_ms": probe / steps, "gpu_ms_per_step": gpu / steps, "path_flags": flags, "targets_found": found,
             "snapshot": snap.info()}, outs, snap
 
 

@@ -88,10 +88,22 @@ def main():
         qs = [aimed(b, extra_docs, seed_of) for b in batches]
         qbs = [fpx.QueryBatch(ctx, options=opts, flat=(f, o)) for f, o, _ in qs]
         dt, agg, out, out_n = bench.timed_resident(fpx, reader, qbs, steps, 16)
+        nfl = int(os.environ.get("INFLIGHT", 3))                     # ... and with several callers (a coalescer's worker threads)
+        import concurrent.futures as cf
+        bufs = [(np.zeros_like(out), np.zeros_like(out_n)) for _ in range(nfl)]
+
+        def one(i):
+            o, n_ = bufs[i % nfl]
+            fpx.search_resident(reader, qbs[i % len(qbs)], 0, o, n_)
+        with cf.ThreadPoolExecutor(nfl) as ex:
+            list(ex.map(one, range(4 * nfl)))
+            t_m = time.perf_counter()
+            list(ex.map(one, range(steps * nfl)))
+            dt_m = time.perf_counter() - t_m
         last = qs[(16 + steps - 1) % len(qs)]
         found = int(sum(1 for q in range(B) if out_n[q] > 0 and out[q, 0, 0] == last[2][q]))
         print(json.dumps({"snapshot": label, "ms_per_step": round(dt / steps * 1e3, 4), "queries_per_s": round(B * steps / dt),
-                          "gpu_ms_per_step": round(agg.v["total_gpu_ms"] / steps, 4), "snapshot_create_ms": round(snap_ms, 2), "snapshot_create_again_ms": round(snap_again_ms, 2), "path_flags": agg.path_flags, "targets_found": found, "of": B,
+                          "gpu_ms_per_step": round(agg.v["total_gpu_ms"] / steps, 4), "callers": nfl, "ms_per_step_with_callers": round(dt_m / (steps * nfl) * 1e3, 4), "queries_per_s_with_callers": round(B * steps * nfl / dt_m), "snapshot_create_ms": round(snap_ms, 2), "snapshot_create_again_ms": round(snap_again_ms, 2), "path_flags": agg.path_flags, "targets_found": found, "of": B,
                           "info": {k: v for k, v in snap.info().items() if k in ("lean", "generic", "small", "direct_solo", "groups", "packed_groups", "memory")}}), flush=True)
         for q_ in qbs:
             q_.release()

@@ -389,6 +389,7 @@ struct Ctx {
     std::mutex group_mu;                  // serialises the grouping of segments (fpx_snapshot_create, fpx_segments_group)
     std::vector<Workspace*> free_ws;
     std::atomic<int> live_ws{0};
+    std::atomic<int> qs_running{0};       // batches between the launch of their k_search_query and its end (run_batch: a batch that is alone is run differently)
     // the running scan histograms of the walks the probe kernels answered (fpx_ctx_scan_histograms), in HIST_SLOTS slots;
     // [HIST_SLOTS]: (hash, segment) walks that were counted but not bucketed (none: every probe kernel buckets its walks)
     std::atomic<uint64_t> scan_hist[HIST_SLOTS + 1];

@@ -54,6 +54,13 @@ constexpr uint32_t QS_TASK_WORDS = 8;              // words a deferred "words" t
 static_assert(QS_MAX_HASHES * 2u <= QS_REC_CAP, "the dedup set lives where the records will");
 static_assert((QS_MAX_HASHES + QS_WG - 1u) / QS_WG <= QS_MAX_ROUNDS, "rounds per query");
 static_assert(QS_WORDS % 4 == 0 && QS_WORDS <= 16, "the words are fetched in 16-byte pieces; a lane's masks of them are 16 bits");
+#ifndef FPX_QS_DYN
+#define FPX_QS_DYN 1               // 1: a launch's workgroups take their queries from a counter (after their first two); 0: every gridDim.x-th
+#endif
+#ifndef FPX_QS_STAGGER
+#define FPX_QS_STAGGER 1           // delays of 3.4 us between the start of a CU's workgroups (0: none)
+#endif
+constexpr uint32_t QS_STAGGER = FPX_QS_STAGGER;
 #ifndef FPX_QS_WGS_PER_CU
 #define FPX_QS_WGS_PER_CU 4
 #endif
@@ -73,6 +80,10 @@ struct QSearchArgs {
     const uint32_t* cancel;
     // a live index's memory segments: their ONE hash-sorted table of live postings (fpx_probe_small.hpp: k_probe_memtab), or null
     const uint64_t* mem_tab; const uint32_t* mem_bucket; const uint32_t* mem_bits;
+    // the launch's queue of queries: a workgroup's first two are blockIdx.x and blockIdx.x + gridDim.x, the others q_begin + 2 gridDim.x + (what
+    // this counter hands out) -- or null: every gridDim.x-th
+    unsigned int* next_q;
+    uint32_t stagger;                                          // delays of 3.4 us between the start of a CU's workgroups (0: none)
 };
 
 #define FPX_QS_OCC __attribute__((amdgpu_waves_per_eu(FPX_QS_WAVES)))
@@ -123,13 +134,15 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     __shared__ uint32_t wg_h[HIST_SLOTS];
     __shared__ uint32_t s_first[FUSE_MAX], s_last[FUSE_MAX];
     __shared__ const uint32_t* s_ext[GROUP_CHUNKS];
+    __shared__ uint32_t s_q2;                           // the query after the next one (handed out by the launch's counter)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const GroupDesc* g = &ga.g;
-    // The workgroup STAYS: it takes query blockIdx.x, then every gridDim.x-th one (the host launches as many workgroups as the chip holds
-    // at once).  What a query's start waits for -- its offsets, its hashes, the heads of its first lines: three latencies in a row -- is
+    // The workgroup STAYS: it takes query blockIdx.x, then blockIdx.x + gridDim.x, then what the launch's counter hands out (the host launches as
+    // many workgroups as the chip holds at once; a workgroup that starts late -- behind another batch's kernel -- or draws long queries takes fewer).  What a query's start waits for -- its offsets, its hashes, the heads of its first lines: three latencies in a row -- is
     // asked for while the query before it is still being counted.
     uint32_t q = a.q_begin + blockIdx.x;
+    uint32_t qn1 = q + gridDim.x;                       // the query after this one
     uint64_t q_lo = a.offsets[q];
     uint32_t n = (uint32_t)(a.offsets[q + 1] - q_lo);
     const uint32_t* qh = a.hashes_base + q_lo;
@@ -157,6 +170,16 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
         }
     };
     load_hashes(0u);
+  // Queries of one length keep a CU's four workgroups in LOCKSTEP -- all four in their rounds (the memory system's turn), then all four counting
+  // (the LDS's and the VALU's) --: the workgroups of the chip's second, third and fourth wave of residents start a few microseconds apart
+  // (s_sleep 127 = 3.4 us, `slot` times).  Measured, one batch of 8192 x 1000 in flight: 0.445 -> 0.430 ms (0.426 with twice the delay, 0.431 with four
+  // times: the last workgroups' late start is the batch's tail).  Three batches in flight desynchronise one another -- a kernel's workgroups
+  // start as the one before lets go of the CUs, one by one, PROVIDED its workgroups end one by one: with the queries handed out by a counter
+  // they end together and the next kernel starts in lockstep again (0.412 -> 0.43 ms per batch, and jittery).  So the host asks for both -- the
+  // counter and the delays -- only for a batch that finds the device to itself (run_batch: Ctx::qs_running).
+  // Only where a workgroup has four or more queries ahead of it: a small batch is one query's latency.
+  if (a.stagger != 0u && a.q_end - a.q_begin >= 4u * gridDim.x)
+      for (uint32_t i = 0; i < ((blockIdx.x >> 8) & 3u) * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   for (;;) {
     const uint32_t rounds = (n + QS_WG - 1u) / QS_WG, nchunks = (rounds + QS_CH - 1u) / QS_CH;
     // the query's hash set: 2^sbits >= 2 n slots
@@ -412,7 +435,10 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     __syncthreads();
     QS_MARK(2);
     // ---- the NEXT query's offsets and hashes set out now (the chunk registers are free): they travel under this query's tasks and counting
-    const uint32_t qn = q + gridDim.x;
+    // (... and the query after THAT is asked of the launch's counter: the answer has the tasks and the counting to arrive in)
+    uint32_t r2 = 0u;
+    if (tid == 0u && a.next_q != nullptr) r2 = atomicAdd(a.next_q, 1u);
+    const uint32_t qn = qn1;
     const bool has_next = qn < a.q_end;                      // (uniform)
     uint64_t nq_lo = 0; uint32_t nn = 0;
     if (has_next) {
@@ -642,8 +668,10 @@ __global__ __launch_bounds__(QS_WG) FPX_QS_OCC void k_search_query(QSearchArgs a
     }
     QS_MARK(5);
     if (!has_next) break;
+    if (tid == 0u) s_q2 = a.next_q != nullptr ? a.q_begin + 2u * gridDim.x + r2 : qn + gridDim.x;
     q = qn; q_lo = nq_lo; n = nn; qh = a.hashes_base + nq_lo;
     __syncthreads();                                    // (the candidate buffer and the flags have been read: the next query may reset them)
+    qn1 = s_q2;
   }
 }
 

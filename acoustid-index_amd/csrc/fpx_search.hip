@@ -633,6 +633,12 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         const uint32_t sbf = 32u - qb;
         hipLaunchKernelGGL(k_qs_zero, dim3(8), dim3(256), 0, st, ws->d_counters, ws->d_def_count, (uint32_t)def_words);
         FPX_HIP(hipEventRecord(ws->ev_probe0, st));
+        struct Running {                                 // batches of this context inside their k_search_query launches, this one included
+            std::atomic<int>* c; int before;
+            explicit Running(std::atomic<int>* c_) : c(c_), before(c_->fetch_add(1)) {}
+            ~Running() { c->fetch_sub(1); }
+        } running(&snap->ctx->qs_running);
+        const bool alone = running.before == 0;
         QSearchArgs qa{};
         qa.hashes_base = d_hashes_base; qa.offsets = d_offsets; qa.opts = d_opts; qa.q_begin = 0u; qa.q_end = B; qa.sb = sbf;
         qa.cands = ws->d_cands[0]; qa.cand_cap = ws->cap_cands; qa.qcand = d_qcand; qa.qcand_n = d_qcand_n;
@@ -650,6 +656,10 @@ static int run_batch(Snapshot* snap, Workspace* ws, const QueryBatch* resident, 
         for (uint32_t c = 0; c < std::max(1u, up_chunks); ++c) {
             qa.q_begin = up_chunks ? up_q[c] : 0u; qa.q_end = up_chunks ? up_q[c + 1] : B;
             if (qa.q_end == qa.q_begin) continue;
+            // (alone on the device: the launch's queue of queries -- a word of the deferred lists' counts, zeroed by k_qs_zero, unused on this
+            // path -- and a staggered start; next to other batches' kernels neither: fpx_qsearch.hpp says why)
+            qa.next_q = (FPX_QS_DYN && alone) ? ws->d_def_count + c : nullptr;
+            qa.stagger = alone ? QS_STAGGER : 0u;
             if (up_chunks) FPX_HIP(hipStreamWaitEvent(st, ws->ev_chunk[c], 0));           // (the piece's hashes have arrived; the next piece is on its way)
             const dim3 qgrid(std::min<uint32_t>(qa.q_end - qa.q_begin, (uint32_t)cus * QS_WGS_PER_CU));
             const bool mem = qa.mem_tab != nullptr;

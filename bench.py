@@ -1102,11 +1102,13 @@ def main():
             for _ in range(3):
                 dst_dev.copy_(src_pin, non_blocking=True)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                dst_dev.copy_(src_pin, non_blocking=True)
-            torch.cuda.synchronize()
-            gbs = 20 * flat.nbytes / (time.perf_counter() - t1) / 1e9
+            gbs = 0.0
+            for _rep in range(3):                    # (the best of three rounds: a round has been seen at a fifth of the others' rate)
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    dst_dev.copy_(src_pin, non_blocking=True)
+                torch.cuda.synchronize()
+                gbs = max(gbs, 20 * flat.nbytes / (time.perf_counter() - t1) / 1e9)
             e["pcie_h2d_GBs_measured"] = gbs
             e["link_bound_queries_per_s"] = gbs * 1e9 / (e["h2d_bytes_per_step"] / B)
             e["pinned_over_link_bound"] = e["pinned"][f"queries_per_s_{nfl}_in_flight"] / e["link_bound_queries_per_s"]
